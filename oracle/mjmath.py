@@ -1,0 +1,494 @@
+"""ORACLE (test infrastructure, not product code) — MuJoCo arithmetic restated in numpy.
+
+Parity status: **unpinned against MuJoCo itself**.  The `mujoco` wheel (reference
+pin: mujoco >= 3.1.6, /root/reference/pyproject.toml:27-28) is a third-party
+dependency that is not vendored under /root/reference and is not installed in the
+build image, so these functions restate MuJoCo's published algorithms
+(engine_core_smooth.c mj_kinematics/mj_comPos, engine_support.c mj_jac*/
+mj_differentiatePos/mj_integratePos, engine_util_spatial.c quaternion helpers,
+engine_collision_primitive.c capsule/sphere routines) from SURVEY.md Appendix A.
+They are pinned indirectly by the reference's own property tests re-run on top of
+them (finite-difference Jacobians tests/test_jacobians.py:41-68, site pose
+tests/test_configuration.py:36-53) — see tests/test_oracle_*.py.
+
+Each function cites the reference call site it serves.  Single-problem, loop-based,
+float64; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this package.
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+mjMINVAL = 1e-15
+mjMAXVAL = 1e10
+mjPI = math.pi
+
+JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
+GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX = 0, 2, 3, 5, 6
+
+
+# ------------------------------------------------------------- mju_* helpers
+def mju_normalize3(v: np.ndarray) -> float:
+    """In place; returns the norm (mink/limits/collision_avoidance_limit.py:49)."""
+    n = math.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+    if n < mjMINVAL:
+        v[0], v[1], v[2] = 1.0, 0.0, 0.0
+    else:
+        inv = 1.0 / n
+        v[0] *= inv; v[1] *= inv; v[2] *= inv
+    return n
+
+
+def mju_normalize4(q: np.ndarray) -> float:
+    n = math.sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3])
+    if n < mjMINVAL:
+        q[0], q[1], q[2], q[3] = 1.0, 0.0, 0.0, 0.0
+    elif abs(n - 1.0) > mjMINVAL:
+        inv = 1.0 / n
+        q *= inv
+    return n
+
+
+def mju_mulQuat(res: np.ndarray, a: np.ndarray, b: np.ndarray) -> None:
+    """Hamilton product (mink/lie/so3.py:150)."""
+    r0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3]
+    r1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2]
+    r2 = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1]
+    r3 = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]
+    res[0], res[1], res[2], res[3] = r0, r1, r2, r3
+
+
+def mju_negQuat(res: np.ndarray, q: np.ndarray) -> None:
+    res[0], res[1], res[2], res[3] = q[0], -q[1], -q[2], -q[3]
+
+
+def mju_quat2Mat(res: np.ndarray, q: np.ndarray) -> None:
+    """Row-major 3x3 (mink/lie/so3.py:113)."""
+    q00, q01, q02, q03 = q[0] * q[0], q[0] * q[1], q[0] * q[2], q[0] * q[3]
+    q11, q12, q13 = q[1] * q[1], q[1] * q[2], q[1] * q[3]
+    q22, q23, q33 = q[2] * q[2], q[2] * q[3], q[3] * q[3]
+    res[0] = q00 + q11 - q22 - q33
+    res[4] = q00 - q11 + q22 - q33
+    res[8] = q00 - q11 - q22 + q33
+    res[1] = 2 * (q12 - q03)
+    res[2] = 2 * (q13 + q02)
+    res[3] = 2 * (q12 + q03)
+    res[5] = 2 * (q23 - q01)
+    res[6] = 2 * (q13 - q02)
+    res[7] = 2 * (q23 + q01)
+
+
+def mju_mat2Quat(quat: np.ndarray, mat: np.ndarray) -> None:
+    """Row-major 3x3 → unit quaternion (mink/lie/so3.py:83, mink/utils.py:35)."""
+    m = mat
+    if m[0] + m[4] + m[8] > 0:
+        quat[0] = 0.5 * math.sqrt(1 + m[0] + m[4] + m[8])
+        quat[1] = 0.25 * (m[7] - m[5]) / quat[0]
+        quat[2] = 0.25 * (m[2] - m[6]) / quat[0]
+        quat[3] = 0.25 * (m[3] - m[1]) / quat[0]
+    elif m[0] > m[4] and m[0] > m[8]:
+        quat[1] = 0.5 * math.sqrt(1 + m[0] - m[4] - m[8])
+        quat[0] = 0.25 * (m[7] - m[5]) / quat[1]
+        quat[2] = 0.25 * (m[1] + m[3]) / quat[1]
+        quat[3] = 0.25 * (m[2] + m[6]) / quat[1]
+    elif m[4] > m[8]:
+        quat[2] = 0.5 * math.sqrt(1 - m[0] + m[4] - m[8])
+        quat[0] = 0.25 * (m[2] - m[6]) / quat[2]
+        quat[1] = 0.25 * (m[1] + m[3]) / quat[2]
+        quat[3] = 0.25 * (m[5] + m[7]) / quat[2]
+    else:
+        quat[3] = 0.5 * math.sqrt(1 - m[0] - m[4] + m[8])
+        quat[0] = 0.25 * (m[3] - m[1]) / quat[3]
+        quat[1] = 0.25 * (m[2] + m[6]) / quat[3]
+        quat[2] = 0.25 * (m[5] + m[7]) / quat[3]
+    mju_normalize4(quat)
+
+
+def mju_axisAngle2Quat(res: np.ndarray, axis: np.ndarray, angle: float) -> None:
+    if angle == 0:
+        res[0], res[1], res[2], res[3] = 1.0, 0.0, 0.0, 0.0
+    else:
+        s = math.sin(angle * 0.5)
+        res[0] = math.cos(angle * 0.5)
+        res[1], res[2], res[3] = axis[0] * s, axis[1] * s, axis[2] * s
+
+
+def _mulMatVec3(mat9: np.ndarray, v: np.ndarray) -> np.ndarray:
+    return np.array([
+        mat9[0] * v[0] + mat9[1] * v[1] + mat9[2] * v[2],
+        mat9[3] * v[0] + mat9[4] * v[1] + mat9[5] * v[2],
+        mat9[6] * v[0] + mat9[7] * v[1] + mat9[8] * v[2],
+    ])
+
+
+def mju_rotVecQuat(vec: np.ndarray, quat: np.ndarray) -> np.ndarray:
+    if vec[0] == 0 and vec[1] == 0 and vec[2] == 0:
+        return np.zeros(3)
+    if quat[0] == 1 and quat[1] == 0 and quat[2] == 0 and quat[3] == 0:
+        return np.array(vec, dtype=np.float64)
+    mat = np.empty(9)
+    mju_quat2Mat(mat, quat)
+    return _mulMatVec3(mat, vec)
+
+
+def mju_quat2Vel(quat: np.ndarray, dt: float) -> np.ndarray:
+    axis = np.array([quat[1], quat[2], quat[3]])
+    sin_a_2 = mju_normalize3(axis)
+    speed = 2 * math.atan2(sin_a_2, quat[0])
+    if speed > mjPI:
+        speed -= 2 * mjPI
+    speed /= dt
+    return axis * speed
+
+
+def mju_quatIntegrate(quat: np.ndarray, vel: np.ndarray, scale: float) -> None:
+    tmp = np.array(vel, dtype=np.float64)
+    angle = scale * mju_normalize3(tmp)
+    qrot = np.empty(4)
+    mju_axisAngle2Quat(qrot, tmp, angle)
+    mju_normalize4(quat)
+    mju_mulQuat(quat, quat.copy(), qrot)
+
+
+# ------------------------------------------------------------------- MjData
+class Data:
+    """The subset of ``mjData`` mink reads (mink/configuration.py:50-64)."""
+
+    def __init__(self, m):
+        self.qpos = np.array(m.qpos0, dtype=np.float64)
+        self.mocap_pos = np.array(m.mocap_pos, dtype=np.float64).reshape(-1, 3)
+        self.mocap_quat = np.array(m.mocap_quat, dtype=np.float64).reshape(-1, 4)
+        self.xpos = np.zeros((m.nbody, 3))
+        self.xquat = np.zeros((m.nbody, 4)); self.xquat[:, 0] = 1
+        self.xmat = np.zeros((m.nbody, 9))
+        self.xipos = np.zeros((m.nbody, 3))
+        self.xanchor = np.zeros((m.njnt, 3))
+        self.xaxis = np.zeros((m.njnt, 3))
+        self.geom_xpos = np.zeros((m.ngeom, 3))
+        self.geom_xmat = np.zeros((m.ngeom, 9))
+        self.site_xpos = np.zeros((m.nsite, 3))
+        self.site_xmat = np.zeros((m.nsite, 9))
+        self.subtree_com = np.zeros((m.nbody, 3))
+        self.cdof = np.zeros((m.nv, 6))
+
+
+def _local2global(d: Data, pos, quat, body):
+    xpos = _mulMatVec3(d.xmat[body], pos) + d.xpos[body]
+    tmp = np.empty(4)
+    mju_mulQuat(tmp, d.xquat[body], quat)
+    xmat = np.empty(9)
+    mju_quat2Mat(xmat, tmp)
+    return xpos, xmat
+
+
+def mj_kinematics(m, d: Data) -> None:
+    """Tree forward kinematics (mink/configuration.py:63); SURVEY Appendix A.1."""
+    d.xpos[0] = 0
+    d.xquat[0] = (1, 0, 0, 0)
+    d.xmat[0] = (1, 0, 0, 0, 1, 0, 0, 0, 1)
+    qpos = d.qpos
+    for i in range(1, m.nbody):
+        jntadr, jntnum = int(m.body_jntadr[i]), int(m.body_jntnum[i])
+        if jntnum == 1 and m.jnt_type[jntadr] == JNT_FREE:
+            qadr = int(m.jnt_qposadr[jntadr])
+            xpos = np.array(qpos[qadr:qadr + 3])
+            xquat = np.array(qpos[qadr + 3:qadr + 7])
+            mju_normalize4(xquat)
+            d.xanchor[jntadr] = xpos
+            d.xaxis[jntadr] = m.jnt_axis[jntadr]
+        else:
+            pid = int(m.body_parentid[i])
+            mid = int(m.body_mocapid[i])
+            if mid >= 0:
+                bodypos = d.mocap_pos[mid]
+                bodyquat = np.array(d.mocap_quat[mid])
+                mju_normalize4(bodyquat)
+            else:
+                bodypos, bodyquat = m.body_pos[i], m.body_quat[i]
+            if pid:
+                xpos = _mulMatVec3(d.xmat[pid], bodypos) + d.xpos[pid]
+                xquat = np.empty(4)
+                mju_mulQuat(xquat, d.xquat[pid], bodyquat)
+            else:
+                xpos = np.array(bodypos, dtype=np.float64)
+                xquat = np.array(bodyquat, dtype=np.float64)
+            for jid in range(jntadr, jntadr + jntnum):
+                qadr, jtype = int(m.jnt_qposadr[jid]), int(m.jnt_type[jid])
+                xaxis = mju_rotVecQuat(m.jnt_axis[jid], xquat)
+                xanchor = mju_rotVecQuat(m.jnt_pos[jid], xquat) + xpos
+                d.xaxis[jid] = xaxis
+                d.xanchor[jid] = xanchor
+                if jtype == JNT_SLIDE:
+                    xpos = xpos + xaxis * (qpos[qadr] - m.qpos0[qadr])
+                elif jtype in (JNT_BALL, JNT_HINGE):
+                    qloc = np.empty(4)
+                    if jtype == JNT_BALL:
+                        qloc[:] = qpos[qadr:qadr + 4]
+                        mju_normalize4(qloc)
+                    else:
+                        mju_axisAngle2Quat(qloc, m.jnt_axis[jid], qpos[qadr] - m.qpos0[qadr])
+                    mju_mulQuat(xquat, xquat.copy(), qloc)
+                    vec = mju_rotVecQuat(m.jnt_pos[jid], xquat)
+                    xpos = xanchor - vec
+                else:
+                    raise ValueError("free joint must be the only joint of its body")
+        mju_normalize4(xquat)
+        d.xquat[i] = xquat
+        d.xpos[i] = xpos
+        mju_quat2Mat(d.xmat[i], xquat)
+    for i in range(m.nbody):
+        d.xipos[i] = _mulMatVec3(d.xmat[i], m.body_ipos[i]) + d.xpos[i]
+    for g in range(m.ngeom):
+        d.geom_xpos[g], d.geom_xmat[g] = _local2global(d, m.geom_pos[g], m.geom_quat[g], int(m.geom_bodyid[g]))
+    for s in range(m.nsite):
+        d.site_xpos[s], d.site_xmat[s] = _local2global(d, m.site_pos[s], m.site_quat[s], int(m.site_bodyid[s]))
+
+
+def _dofCom(axis, offset):
+    res = np.zeros(6)
+    if offset is not None:
+        res[:3] = axis
+        res[3:] = np.cross(axis, offset)
+    else:
+        res[3:] = axis
+    return res
+
+
+def mj_comPos(m, d: Data) -> None:
+    """subtree_com and cdof (mink/configuration.py:64); SURVEY Appendix A.2."""
+    d.subtree_com[:] = 0
+    for i in range(m.nbody - 1, -1, -1):
+        d.subtree_com[i] += d.xipos[i] * m.body_mass[i]
+        if i:
+            d.subtree_com[int(m.body_parentid[i])] += d.subtree_com[i]
+        if m.body_subtreemass[i] < mjMINVAL:
+            d.subtree_com[i] = d.xipos[i]
+        else:
+            d.subtree_com[i] = d.subtree_com[i] * (1.0 / max(mjMINVAL, m.body_subtreemass[i]))
+    for j in range(m.njnt):
+        da, bi = int(m.jnt_dofadr[j]), int(m.jnt_bodyid[j])
+        offset = d.subtree_com[int(m.body_rootid[bi])] - d.xanchor[j]
+        jt = int(m.jnt_type[j])
+        skip = 0
+        if jt == JNT_FREE:
+            d.cdof[da:da + 3] = 0
+            for i in range(3):
+                d.cdof[da + i, 3 + i] = 1
+            skip = 3
+        if jt in (JNT_FREE, JNT_BALL):
+            for i in range(3):
+                axis = np.array([d.xmat[bi, i], d.xmat[bi, i + 3], d.xmat[bi, i + 6]])
+                d.cdof[da + skip + i] = _dofCom(axis, offset)
+        elif jt == JNT_SLIDE:
+            d.cdof[da] = _dofCom(d.xaxis[j], None)
+        elif jt == JNT_HINGE:
+            d.cdof[da] = _dofCom(d.xaxis[j], offset)
+
+
+def mj_jac(m, d: Data, jacp, jacr, point, body: int) -> None:
+    """World-aligned point Jacobian (collision_avoidance_limit.py:69,71); A.3."""
+    if jacp is not None:
+        jacp[:] = 0
+    if jacr is not None:
+        jacr[:] = 0
+    offset = np.asarray(point) - d.subtree_com[int(m.body_rootid[body])]
+    while body and not m.body_dofnum[body]:
+        body = int(m.body_parentid[body])
+    if not body:
+        return
+    i = int(m.body_dofadr[body] + m.body_dofnum[body] - 1)
+    while i >= 0:
+        cdof = d.cdof[i]
+        if jacr is not None:
+            jacr[:, i] = cdof[:3]
+        if jacp is not None:
+            jacp[:, i] = cdof[3:] + np.cross(cdof[:3], offset)
+        i = int(m.dof_parentid[i])
+
+
+def mj_jacBody(m, d, jacp, jacr, body):
+    mj_jac(m, d, jacp, jacr, d.xpos[body], body)
+
+
+def mj_jacBodyCom(m, d, jacp, jacr, body):
+    mj_jac(m, d, jacp, jacr, d.xipos[body], body)
+
+
+def mj_jacGeom(m, d, jacp, jacr, geom):
+    mj_jac(m, d, jacp, jacr, d.geom_xpos[geom], int(m.geom_bodyid[geom]))
+
+
+def mj_jacSite(m, d, jacp, jacr, site):
+    """mink/constants.py:11-13 → mink/configuration.py:144-145."""
+    mj_jac(m, d, jacp, jacr, d.site_xpos[site], int(m.site_bodyid[site]))
+
+
+def mj_jacSubtreeCom(m, d: Data, jacp, body: int) -> None:
+    """mink/tasks/com_task.py:96; SURVEY Appendix A.4."""
+    jacp[:] = 0
+    jacp_b = np.zeros((3, m.nv))
+    for b in range(body, m.nbody):
+        if b > body and m.body_parentid[b] < body:
+            break
+        mj_jacBodyCom(m, d, jacp_b, None, b)
+        jacp += jacp_b * m.body_mass[b]
+    jacp *= 1.0 / m.body_subtreemass[body]
+
+
+def mj_differentiatePos(m, qvel, dt, qpos1, qpos2) -> None:
+    """qvel = (qpos2 ⊖ qpos1)/dt (posture_task.py:107, configuration_limit.py:100,110)."""
+    for j in range(m.njnt):
+        padr, vadr, jt = int(m.jnt_qposadr[j]), int(m.jnt_dofadr[j]), int(m.jnt_type[j])
+        if jt == JNT_FREE:
+            for i in range(3):
+                qvel[vadr + i] = (qpos2[padr + i] - qpos1[padr + i]) / dt
+            vadr += 3; padr += 3
+        if jt in (JNT_FREE, JNT_BALL):
+            neg = np.empty(4); dif = np.empty(4)
+            mju_negQuat(neg, qpos1[padr:padr + 4])
+            mju_mulQuat(dif, neg, qpos2[padr:padr + 4])
+            qvel[vadr:vadr + 3] = mju_quat2Vel(dif, dt)
+        else:
+            qvel[vadr] = (qpos2[padr] - qpos1[padr]) / dt
+
+
+def mj_integratePos(m, qpos, qvel, dt) -> None:
+    """In place q ← q ⊕ v·dt (mink/configuration.py:225,235); A.6."""
+    for j in range(m.njnt):
+        padr, vadr, jt = int(m.jnt_qposadr[j]), int(m.jnt_dofadr[j]), int(m.jnt_type[j])
+        if jt == JNT_FREE:
+            for i in range(3):
+                qpos[padr + i] += dt * qvel[vadr + i]
+            padr += 3; vadr += 3
+        if jt in (JNT_FREE, JNT_BALL):
+            quat = np.array(qpos[padr:padr + 4])
+            mju_quatIntegrate(quat, qvel[vadr:vadr + 3], dt)
+            qpos[padr:padr + 4] = quat
+        else:
+            qpos[padr] += dt * qvel[vadr]
+
+
+# --------------------------------------------------------------- collisions
+def _sphere_sphere(p1, r1, p2, r2, margin):
+    """mjraw_SphereSphere: returns list of (dist, pos, normal)."""
+    dif = p2 - p1
+    cdist = math.sqrt(float(dif @ dif))
+    dist = cdist - r1 - r2
+    if dist > margin:
+        return []
+    n = dif.copy()
+    if cdist < mjMINVAL:
+        n = np.array([1.0, 0.0, 0.0])
+    else:
+        n = n / cdist
+    pos = p1 + n * (r1 + 0.5 * dist)
+    return [(dist, pos, n)]
+
+
+def _capsule_capsule(pos1, mat1, size1, pos2, mat2, size2, margin):
+    """mjc_CapsuleCapsule restated: segment–segment closest
+    points then sphere–sphere; the parallel case yields up to two contacts."""
+    axis1 = np.array([mat1[2], mat1[5], mat1[8]])
+    axis2 = np.array([mat2[2], mat2[5], mat2[8]])
+    dif = pos1 - pos2
+    ma = float(axis1 @ axis1); mb = -float(axis1 @ axis2); mc = float(axis2 @ axis2)
+    u = -float(axis1 @ dif); v = float(axis2 @ dif)
+    det = ma * mc - mb * mb
+    out = []
+    if abs(det) >= mjMINVAL:
+        x1 = (mc * u - mb * v) / det
+        x2 = (ma * v - mb * u) / det
+        if x1 > size1[1]:
+            x1 = size1[1]; x2 = (v - mb * size1[1]) / mc
+        elif x1 < -size1[1]:
+            x1 = -size1[1]; x2 = (v + mb * size1[1]) / mc
+        if x2 > size2[1]:
+            x2 = size2[1]; x1 = (u - mb * size2[1]) / ma
+        elif x2 < -size2[1]:
+            x2 = -size2[1]; x1 = (u + mb * size2[1]) / ma
+        x1 = min(max(x1, -size1[1]), size1[1])
+        x2 = min(max(x2, -size2[1]), size2[1])
+        out += _sphere_sphere(pos1 + axis1 * x1, size1[0], pos2 + axis2 * x2, size2[0], margin)
+    else:
+        # parallel axes: test both ends of each capsule against the other segment
+        cands = []
+        for s in (+1.0, -1.0):
+            x1 = s * size1[1]
+            x2 = (v - mb * x1) / mc
+            if -size2[1] <= x2 <= size2[1]:
+                cands.append((x1, x2))
+        for s in (+1.0, -1.0):
+            x2 = s * size2[1]
+            x1 = (u - mb * x2) / ma
+            if -size1[1] <= x1 <= size1[1]:
+                cands.append((x1, x2))
+        # (no end projects inside the other segment ⇒ no contact is generated)
+        for x1, x2 in cands[:2]:
+            out += _sphere_sphere(pos1 + axis1 * x1, size1[0], pos2 + axis2 * x2, size2[0], margin)
+    return out
+
+
+def _sphere_capsule(pos1, size1, pos2, mat2, size2, margin):
+    axis = np.array([mat2[2], mat2[5], mat2[8]])
+    x = float(axis @ (pos1 - pos2))
+    x = min(max(x, -size2[1]), size2[1])
+    return _sphere_sphere(pos1, size1[0], pos2 + axis * x, size2[0], margin)
+
+
+def _plane_sphere(pos1, mat1, pos2, size2, margin):
+    n = np.array([mat1[2], mat1[5], mat1[8]])
+    cdist = float(n @ (pos2 - pos1))
+    dist = cdist - size2[0]
+    if dist > margin:
+        return []
+    pos = pos2 - n * (size2[0] + 0.5 * dist)
+    return [(dist, pos, n)]
+
+
+def _plane_capsule(pos1, mat1, pos2, mat2, size2, margin):
+    axis = np.array([mat2[2], mat2[5], mat2[8]])
+    out = []
+    for s in (+1.0, -1.0):
+        out += _plane_sphere(pos1, mat1, pos2 + axis * s * size2[1], size2, margin)
+    return out
+
+
+def mj_geomDistance(m, d: Data, geom1: int, geom2: int, distmax: float, fromto) -> float:
+    """Smallest signed distance between two geoms and the connecting segment
+    (mink/limits/collision_avoidance_limit.py:219); SURVEY Appendix A.8.
+    Only the analytic pairs used by the benchmark configs are restated."""
+    g1, g2 = int(geom1), int(geom2)
+    t1, t2 = int(m.geom_type[g1]), int(m.geom_type[g2])
+    flip = t1 > t2
+    if flip:
+        g1, g2, t1, t2 = g2, g1, t2, t1
+    p1, p2 = d.geom_xpos[g1], d.geom_xpos[g2]
+    R1, R2 = d.geom_xmat[g1], d.geom_xmat[g2]
+    s1, s2 = m.geom_size[g1], m.geom_size[g2]
+    if not (m.geom_valid[g1] and m.geom_valid[g2]):
+        raise NotImplementedError("geom needs mesh data")
+    if (t1, t2) == (GEOM_CAPSULE, GEOM_CAPSULE):
+        cons = _capsule_capsule(p1, R1, s1, p2, R2, s2, distmax)
+    elif (t1, t2) == (GEOM_SPHERE, GEOM_SPHERE):
+        cons = _sphere_sphere(p1, s1[0], p2, s2[0], distmax)
+    elif (t1, t2) == (GEOM_SPHERE, GEOM_CAPSULE):
+        cons = _sphere_capsule(p1, s1, p2, R2, s2, distmax)
+    elif (t1, t2) == (GEOM_PLANE, GEOM_SPHERE):
+        cons = _plane_sphere(p1, R1, p2, s2, distmax)
+    elif (t1, t2) == (GEOM_PLANE, GEOM_CAPSULE):
+        cons = _plane_capsule(p1, R1, p2, R2, s2, distmax)
+    else:
+        raise NotImplementedError(f"geom pair types ({t1},{t2}) not restated")
+    if fromto is not None:
+        fromto[:] = 0
+    if not cons:
+        return distmax
+    dist, pos, n = min(cons, key=lambda c: c[0])
+    if fromto is not None:
+        s = -1.0 if flip else 1.0
+        fromto[0:3] = pos - n * (0.5 * s * dist)
+        fromto[3:6] = pos + n * (0.5 * s * dist)
+    return dist
