@@ -1,0 +1,74 @@
+"""oracle/ik.py replayed against fixtures recorded from the real mink
+(tests/golden/ik_*.npz).  CPU only."""
+
+import os
+
+import numpy as np
+import pytest
+
+import oracle_configs as oc
+from oracle import ik, qp_gi
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, f"ik_{name}.npz"))
+
+
+def _check(cfgfn, d, extra=None, vtol=1e-9):
+    n = len(d["q"])
+    for i in range(n):
+        args = [d["frame_targets"][i], d["posture_target"]]
+        if extra is not None:
+            args.append(d[extra][i])
+        m, tasks, limits, dt, damping = cfgfn(*args)
+        assert dt == float(d["dt"]) and damping == float(d["damping"])
+        cfg = ik.Configuration(m, d["q"][i])
+        P, c, G, h = ik.build_ik(cfg, tasks, dt, damping, limits)
+        scale = max(1.0, np.abs(d["H"][i]).max())
+        np.testing.assert_allclose(P, d["H"][i], rtol=0, atol=1e-12 * scale)
+        np.testing.assert_allclose(c, d["c"][i], rtol=0, atol=1e-12 * max(1.0, np.abs(d["c"][i]).max()))
+        np.testing.assert_allclose(h, d["h"][i], rtol=0, atol=1e-13)
+        if i < len(d["G"]):
+            np.testing.assert_allclose(G, d["G"][i], rtol=0, atol=1e-13)
+            J = np.vstack([ik.task_error_jacobian(cfg, t)[1] for t in tasks])
+            np.testing.assert_allclose(J, d["task_J"][i], rtol=0, atol=1e-11)
+        e = np.concatenate([ik.task_error_jacobian(cfg, t)[0] for t in tasks])
+        np.testing.assert_allclose(e, d["task_e"][i], rtol=0, atol=1e-13)
+        v = ik.solve_ik(m, cfg, tasks, dt, damping, limits)
+        np.testing.assert_allclose(v, d["v"][i], rtol=0, atol=vtol * max(1.0, np.abs(d["v"][i]).max()))
+        assert qp_gi.kkt_residual(P, c, G, h, v * dt) < 1e-7 * max(1.0, np.abs(c).max())
+
+
+def test_ur5e_c2(golden_dir):
+    _check(oc.ur5e_c2, _load(golden_dir, "ur5e_c2"))
+
+
+def test_g1_c3(golden_dir):
+    _check(oc.g1_c3, _load(golden_dir, "g1_c3"))
+
+
+def test_g1_full(golden_dir):
+    _check(oc.g1_full, _load(golden_dir, "g1_full"), extra="com_target")
+
+
+def test_shadow_c4(golden_dir):
+    _check(oc.shadow_c4, _load(golden_dir, "shadow_c4"))
+
+
+def test_ur5e_c1_trajectory(golden_dir):
+    """Config 1: the reference's own convergence behaviour (tests/test_solve_ik.py:95-148)
+    replayed: same v at every step of the recorded solve+integrate trajectory."""
+    d = _load(golden_dir, "ur5e_c1")
+    m, tasks, limits, dt, damping = oc.ur5e_c1([d["frame_target"]], d["posture_target"])
+    cfg = ik.Configuration(m, d["q"][0])
+    errs = []
+    for k in range(len(d["q"])):
+        np.testing.assert_allclose(cfg.q, d["q"][k], rtol=0, atol=1e-12)
+        v = ik.solve_ik(m, cfg, tasks, dt, damping, limits)
+        np.testing.assert_allclose(v, d["v"][k], rtol=0, atol=1e-9 * max(1.0, np.abs(v).max()))
+        errs.append(np.linalg.norm(ik.task_error_jacobian(cfg, tasks[0])[0]))
+        cfg.update(cfg.integrate(v, dt))
+    # error contracts until it balances the posture regulariser (≈1.3e-4)
+    assert all(b < a for a, b in zip(errs[:4], errs[1:5]))
+    assert errs[-1] < 2e-4
+    np.testing.assert_allclose(cfg.q, d["q_final"], rtol=0, atol=1e-12)
