@@ -1,0 +1,214 @@
+/*
+ * minkhip.h — C ABI of libminkhip.so: batched differential IK on MI355X (gfx950).
+ *
+ * Drop-in boundary for the ONE hot path of kevinzakka/mink: `solve_ik` over a batch
+ * of independent (q, target) instances.  The reference has no FFI of its own on
+ * this path — it is a pure-Python plugin API that crosses into native code through
+ * the third-party wheels `mujoco` (pybind11) and `quadprog` (Cython).  Every entry
+ * point below therefore cites the reference *Python* interface it replaces
+ * (file:line in /root/reference) and is what a ctypes binding of that interface
+ * binds (see INTEGRATION.md for the binding a mink maintainer would add).
+ *
+ * Conventions
+ *   - extern "C", plain pointers + sizes, no torch/numpy types.
+ *   - every function returns MKH_OK (0) or a negative MKH_E_* code and never
+ *     throws; mkh_last_error() gives a thread-local message.
+ *   - arrays are float64 / int32, row-major, batch-major: q is (B, nq), v is (B, nv).
+ *   - data pointers of the per-call functions are DEVICE pointers when
+ *     MKH_FLAG_DEVICE_PTRS is set (e.g. torch.Tensor.data_ptr() on ROCm; the call
+ *     is then asynchronous on `stream`), otherwise HOST pointers (the library
+ *     stages through its own pinned/device buffers and returns after completion).
+ *   - the library owns everything it allocates; the caller owns every buffer it
+ *     passes.  One in-flight call per MkhProblem; distinct problems are independent.
+ *   - per-instance `status` (int32): bit flags MKH_ST_*.
+ */
+#ifndef MINKHIP_H_
+#define MINKHIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MKH_VERSION 100
+
+/* return codes */
+#define MKH_OK 0
+#define MKH_E_INVALID (-1)   /* bad argument / unsupported model feature   */
+#define MKH_E_HIP (-2)       /* HIP runtime error (message has the detail)  */
+#define MKH_E_NOGPU (-3)     /* no gfx950 device visible                    */
+#define MKH_E_LIMIT (-4)     /* model exceeds a compiled-in size limit      */
+
+/* per-instance status bits written to status_out */
+#define MKH_ST_OK 0
+#define MKH_ST_OUTSIDE_LIMITS 1  /* q violates a joint range by > 1e-6 (mink/configuration.py:77-110); still solved */
+#define MKH_ST_INFEASIBLE 2      /* constraints inconsistent (quadprog "no solution" → mink/solve_ik.py:103 assert) */
+#define MKH_ST_NOT_PD 4          /* H not positive definite (quadprog "matrix G is not positive definite") */
+#define MKH_ST_ITER_LIMIT 8      /* active-set iteration cap hit */
+#define MKH_ST_ROW_OVERFLOW 16   /* more simultaneously detected contacts than tableau rows */
+
+/* flags */
+#define MKH_FLAG_DEVICE_PTRS 1   /* data pointers are device pointers; async on stream */
+#define MKH_FLAG_POSTURE_BATCHED 2  /* posture_target is (B, nq) instead of (nq,)       */
+#define MKH_FLAG_COM_BATCHED 4      /* com_target is (B, 3) instead of (3,)             */
+
+/* frame types (mink/constants.py:3 SUPPORTED_FRAMES) */
+#define MKH_FRAME_BODY 0
+#define MKH_FRAME_GEOM 1
+#define MKH_FRAME_SITE 2
+
+typedef struct MkhModel MkhModel;
+typedef struct MkhProblem MkhProblem;
+
+/*
+ * One-time flattened copy of the mjModel kinematic tree: the mjModel fields the
+ * reference hot path reads (mink/configuration.py:53-155, limits/*.py constructors,
+ * tasks/posture_task.py:44).  Field names/semantics are MuJoCo's.  Host pointers;
+ * copied at mkh_model_create.
+ */
+typedef struct MkhFlatModel {
+  int32_t nq, nv, nbody, njnt, ngeom, nsite;
+  const int32_t *body_parentid, *body_rootid, *body_jntnum, *body_jntadr, *body_dofnum, *body_dofadr;
+  const double *body_pos /*nbody*3*/, *body_quat /*nbody*4*/, *body_ipos /*nbody*3*/;
+  const double *body_mass, *body_subtreemass;
+  const int32_t *jnt_type, *jnt_qposadr, *jnt_dofadr, *jnt_bodyid, *jnt_limited;
+  const double *jnt_pos /*njnt*3*/, *jnt_axis /*njnt*3*/, *jnt_range /*njnt*2*/, *qpos0 /*nq*/;
+  const int32_t *dof_bodyid, *dof_jntid, *dof_parentid;
+  const int32_t *site_bodyid;
+  const double *site_pos /*nsite*3*/, *site_quat /*nsite*4*/;
+  const int32_t *geom_bodyid, *geom_type;
+  const double *geom_size /*ngeom*3*/, *geom_pos /*ngeom*3*/, *geom_quat /*ngeom*4*/;
+} MkhFlatModel;
+
+/* mink.FrameTask(frame_name, frame_type, position_cost, orientation_cost, gain, lm_damping)
+ * — mink/tasks/frame_task.py:29-46; cost = [position x3, orientation x3] (:60,:75). */
+typedef struct MkhFrameTaskDesc {
+  int32_t frame_type, frame_id;
+  double cost[6];
+  double gain, lm_damping;
+} MkhFrameTaskDesc;
+
+/* mink.PostureTask(model, cost, gain, lm_damping) — mink/tasks/posture_task.py:29-52.
+ * mink.DampingTask is the gain=0 special case (mink/tasks/damping_task.py:11-20). */
+typedef struct MkhPostureTaskDesc {
+  const double *cost /*nv*/;
+  double gain, lm_damping;
+} MkhPostureTaskDesc;
+
+/* mink.ComTask(cost, gain, lm_damping) — mink/tasks/com_task.py:25-35 (subtree of body 1). */
+typedef struct MkhComTaskDesc {
+  double cost[3];
+  double gain, lm_damping;
+} MkhComTaskDesc;
+
+/* mink.ConfigurationLimit(model, gain, min_distance_from_limits) —
+ * mink/limits/configuration_limit.py:18-67.  lower/upper are the constructor's
+ * per-qpos arrays (±mjMAXVAL where unlimited); indices are its dof `indices`. */
+typedef struct MkhConfigurationLimitDesc {
+  double gain;
+  const double *lower /*nq*/, *upper /*nq*/;
+  int32_t n_indices;
+  const int32_t *indices;
+} MkhConfigurationLimitDesc;
+
+/* mink.VelocityLimit(model, velocities) — mink/limits/velocity_limit.py:33-69:
+ * `indices` (dof ids) and `limit` (max |v|). */
+typedef struct MkhVelocityLimitDesc {
+  int32_t n_indices;
+  const int32_t *indices;
+  const double *limit;
+} MkhVelocityLimitDesc;
+
+/* mink.CollisionAvoidanceLimit(model, geom_pairs, gain, minimum_distance_from_collisions,
+ * collision_detection_distance, bound_relaxation) — mink/limits/collision_avoidance_limit.py:145-185;
+ * geom_id_pairs is the constructor's filtered (min,max) id list (:253-278). */
+typedef struct MkhCollisionLimitDesc {
+  int32_t n_pairs;
+  const int32_t *geom_id_pairs /*n_pairs*2*/;
+  double gain, minimum_distance_from_collisions, collision_detection_distance, bound_relaxation;
+} MkhCollisionLimitDesc;
+
+/* The task/limit lists solve_ik receives (mink/solve_ik.py:68-77).  The QP objective is a
+ * sum, so list order only affects rounding; limits=[] disables limits, the Python layer
+ * materialises mink's limits=None default (a fresh ConfigurationLimit, solve_ik.py:28-29). */
+typedef struct MkhProblemDesc {
+  int32_t n_frame_tasks;
+  const MkhFrameTaskDesc *frame_tasks;
+  int32_t n_posture_tasks;
+  const MkhPostureTaskDesc *posture_tasks; /* each has its own target slot */
+  int32_t n_com_tasks;
+  const MkhComTaskDesc *com_tasks;
+  int32_t n_configuration_limits;
+  const MkhConfigurationLimitDesc *configuration_limits;
+  int32_t n_velocity_limits;
+  const MkhVelocityLimitDesc *velocity_limits;
+  int32_t n_collision_limits;
+  const MkhCollisionLimitDesc *collision_limits;
+} MkhProblemDesc;
+
+/* Optional debug/parity taps: any non-NULL pointer receives that intermediate for the
+ * whole batch (same host/device convention as the other data pointers). */
+typedef struct MkhTaps {
+  double *xpos;      /* (B, nbody, 3)  data.xpos          (mink/configuration.py:63)  */
+  double *xquat;     /* (B, nbody, 4)  data.xquat                                     */
+  double *frame_pose;/* (B, n_frame_tasks, 7) wxyz_xyz, get_transform_frame_to_world (:157-185) */
+  double *subtree_com;/*(B, 3)        data.subtree_com[1] (mink/tasks/com_task.py:82) */
+  double *task_e;    /* (B, n_rows)   compute_error of frame tasks (6 each), posture (nv each), com (3 each) */
+  double *task_J;    /* (B, n_rows, nv) compute_jacobian, same row order             */
+  double *H;         /* (B, nv, nv)   build_ik(...).P   (mink/solve_ik.py:63)         */
+  double *c;         /* (B, nv)       build_ik(...).q                                 */
+  double *box_lo;    /* (B, nv)  merged box  lo <= dq <= hi  from Configuration/VelocityLimit rows */
+  double *box_hi;    /* (B, nv)                                                        */
+  double *coll_G;    /* (B, n_pairs, nv) CollisionAvoidanceLimit G rows (0 when inactive) */
+  double *coll_h;    /* (B, n_pairs)     and h (+inf when inactive)                   */
+  int32_t *qp_iters; /* (B,)  active-set pivots after the unconstrained solve         */
+} MkhTaps;
+
+int32_t mkh_version(void);
+const char *mkh_last_error(void);
+int32_t mkh_device_count(void);
+
+/* Upload the flattened kinematic tree once (replaces per-call mj_kinematics/mj_jac* reads of mjModel). */
+int32_t mkh_model_create(const MkhFlatModel *host_model, int32_t device, MkhModel **out);
+void mkh_model_destroy(MkhModel *model);
+
+/* Snapshot the Task/Limit plugin objects of one solve_ik call site into a device descriptor. */
+int32_t mkh_problem_create(MkhModel *model, const MkhProblemDesc *desc, int32_t max_batch, MkhProblem **out);
+void mkh_problem_destroy(MkhProblem *problem);
+int32_t mkh_problem_num_task_rows(const MkhProblem *problem);
+int32_t mkh_problem_num_collision_pairs(const MkhProblem *problem);
+
+/*
+ * Batched mink.solve_ik (mink/solve_ik.py:68-105):
+ *   v[b] = solve_ik(Configuration(model, q[b]), tasks(targets[b]), dt, "quadprog", damping, limits=limits)
+ *   q              (B, nq)
+ *   frame_targets  (B, n_frame_tasks, 7)  transform_target_to_world as wxyz_xyz (frame_task.py:77-83)
+ *   posture_target (n_posture_tasks, nq) or (B, n_posture_tasks, nq) with MKH_FLAG_POSTURE_BATCHED
+ *   com_target     (n_com_tasks, 3) or (B, n_com_tasks, 3) with MKH_FLAG_COM_BATCHED
+ *   v_out          (B, nv)   velocity dq/dt
+ *   status_out     (B,)      MKH_ST_* bits (may be NULL)
+ */
+int32_t mkh_solve(MkhProblem *problem, int32_t B, const double *q, const double *frame_targets,
+                  const double *posture_target, const double *com_target, double dt, double damping,
+                  double *v_out, int32_t *status_out, int32_t flags, void *hip_stream);
+
+/* Same inputs; additionally writes the requested intermediates (build_ik / compute_error /
+ * compute_jacobian / get_transform_frame_to_world parity taps).  v_out/status_out may be NULL
+ * to skip the QP. */
+int32_t mkh_eval(MkhProblem *problem, int32_t B, const double *q, const double *frame_targets,
+                 const double *posture_target, const double *com_target, double dt, double damping,
+                 double *v_out, int32_t *status_out, const MkhTaps *taps, int32_t flags, void *hip_stream);
+
+/* Configuration.integrate (mink/configuration.py:214-226): q_out[b] = q[b] (+) v[b]*dt. */
+int32_t mkh_integrate(MkhModel *model, int32_t B, const double *q, const double *v, double dt,
+                      double *q_out, int32_t flags, void *hip_stream);
+
+/* Launch geometry actually used for a batch of B (for benchmarks / occupancy reports). */
+int32_t mkh_problem_launch_info(const MkhProblem *problem, int32_t B, int32_t *grid, int32_t *block,
+                                int32_t *lds_bytes, int32_t *tableau_rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINKHIP_H_ */

@@ -1,0 +1,376 @@
+"""ctypes binding of libminkhip.so (include/minkhip.h).
+
+This is the whole Python↔device boundary: plain pointers and sizes, no torch types.
+numpy arrays are passed as host pointers (the library stages them); torch CUDA
+tensors are passed as device pointers with MKH_FLAG_DEVICE_PTRS (asynchronous on the
+current torch stream).  There is no CPU fallback: if the library or a GPU is missing
+every call raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from .flatmodel import FlatModel
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libminkhip.so")
+
+MKH_OK = 0
+FLAG_DEVICE_PTRS, FLAG_POSTURE_BATCHED, FLAG_COM_BATCHED = 1, 2, 4
+ST_OUTSIDE_LIMITS, ST_INFEASIBLE, ST_NOT_PD, ST_ITER_LIMIT, ST_ROW_OVERFLOW = 1, 2, 4, 8, 16
+FRAME_TYPE_ID = {"body": 0, "geom": 1, "site": 2}
+
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int32)
+
+
+class MkhFlatModel(C.Structure):
+    _fields_ = (
+        [(n, C.c_int32) for n in ("nq", "nv", "nbody", "njnt", "ngeom", "nsite")]
+        + [(n, _pi) for n in ("body_parentid", "body_rootid", "body_jntnum", "body_jntadr",
+                              "body_dofnum", "body_dofadr")]
+        + [(n, _pd) for n in ("body_pos", "body_quat", "body_ipos", "body_mass", "body_subtreemass")]
+        + [(n, _pi) for n in ("jnt_type", "jnt_qposadr", "jnt_dofadr", "jnt_bodyid", "jnt_limited")]
+        + [(n, _pd) for n in ("jnt_pos", "jnt_axis", "jnt_range", "qpos0")]
+        + [(n, _pi) for n in ("dof_bodyid", "dof_jntid", "dof_parentid", "site_bodyid")]
+        + [(n, _pd) for n in ("site_pos", "site_quat")]
+        + [(n, _pi) for n in ("geom_bodyid", "geom_type")]
+        + [(n, _pd) for n in ("geom_size", "geom_pos", "geom_quat")]
+    )
+
+
+class MkhFrameTaskDesc(C.Structure):
+    _fields_ = [("frame_type", C.c_int32), ("frame_id", C.c_int32), ("cost", C.c_double * 6),
+                ("gain", C.c_double), ("lm_damping", C.c_double)]
+
+
+class MkhPostureTaskDesc(C.Structure):
+    _fields_ = [("cost", _pd), ("gain", C.c_double), ("lm_damping", C.c_double)]
+
+
+class MkhComTaskDesc(C.Structure):
+    _fields_ = [("cost", C.c_double * 3), ("gain", C.c_double), ("lm_damping", C.c_double)]
+
+
+class MkhConfigurationLimitDesc(C.Structure):
+    _fields_ = [("gain", C.c_double), ("lower", _pd), ("upper", _pd), ("n_indices", C.c_int32),
+                ("indices", _pi)]
+
+
+class MkhVelocityLimitDesc(C.Structure):
+    _fields_ = [("n_indices", C.c_int32), ("indices", _pi), ("limit", _pd)]
+
+
+class MkhCollisionLimitDesc(C.Structure):
+    _fields_ = [("n_pairs", C.c_int32), ("geom_id_pairs", _pi), ("gain", C.c_double),
+                ("minimum_distance_from_collisions", C.c_double),
+                ("collision_detection_distance", C.c_double), ("bound_relaxation", C.c_double)]
+
+
+class MkhProblemDesc(C.Structure):
+    _fields_ = [
+        ("n_frame_tasks", C.c_int32), ("frame_tasks", C.POINTER(MkhFrameTaskDesc)),
+        ("n_posture_tasks", C.c_int32), ("posture_tasks", C.POINTER(MkhPostureTaskDesc)),
+        ("n_com_tasks", C.c_int32), ("com_tasks", C.POINTER(MkhComTaskDesc)),
+        ("n_configuration_limits", C.c_int32), ("configuration_limits", C.POINTER(MkhConfigurationLimitDesc)),
+        ("n_velocity_limits", C.c_int32), ("velocity_limits", C.POINTER(MkhVelocityLimitDesc)),
+        ("n_collision_limits", C.c_int32), ("collision_limits", C.POINTER(MkhCollisionLimitDesc)),
+    ]
+
+
+TAP_NAMES = ("xpos", "xquat", "frame_pose", "subtree_com", "task_e", "task_J", "H", "c", "box_lo",
+             "box_hi", "coll_G", "coll_h", "qp_iters")
+
+
+class MkhTaps(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in TAP_NAMES]
+
+
+class MinkHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libminkhip.so (built by mink_amd/csrc/build.py).  Fails loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise MinkHipError(
+            f"{_LIB_PATH} not found: build it with `python -m mink_amd.csrc.build` "
+            "(there is no CPU fallback for the solve path)")
+    L = C.CDLL(_LIB_PATH)
+    L.mkh_version.restype = C.c_int32
+    L.mkh_last_error.restype = C.c_char_p
+    L.mkh_device_count.restype = C.c_int32
+    L.mkh_model_create.argtypes = [C.POINTER(MkhFlatModel), C.c_int32, C.POINTER(C.c_void_p)]
+    L.mkh_model_destroy.argtypes = [C.c_void_p]
+    L.mkh_model_destroy.restype = None
+    L.mkh_problem_create.argtypes = [C.c_void_p, C.POINTER(MkhProblemDesc), C.c_int32, C.POINTER(C.c_void_p)]
+    L.mkh_problem_destroy.argtypes = [C.c_void_p]
+    L.mkh_problem_destroy.restype = None
+    L.mkh_problem_num_task_rows.argtypes = [C.c_void_p]
+    L.mkh_problem_num_collision_pairs.argtypes = [C.c_void_p]
+    common = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+              C.c_void_p, C.c_void_p]
+    L.mkh_solve.argtypes = common + [C.c_int32, C.c_void_p]
+    L.mkh_eval.argtypes = common + [C.POINTER(MkhTaps), C.c_int32, C.c_void_p]
+    L.mkh_integrate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                C.c_int32, C.c_void_p]
+    L.mkh_problem_launch_info.argtypes = [C.c_void_p, C.c_int32] + [C.POINTER(C.c_int32)] * 4
+    for f in ("mkh_model_create", "mkh_problem_create", "mkh_problem_num_task_rows",
+              "mkh_problem_num_collision_pairs", "mkh_solve", "mkh_eval", "mkh_integrate",
+              "mkh_problem_launch_info"):
+        getattr(L, f).restype = C.c_int32
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = (
+    "mkh_version", "mkh_last_error", "mkh_device_count", "mkh_model_create", "mkh_model_destroy",
+    "mkh_problem_create", "mkh_problem_destroy", "mkh_problem_num_task_rows",
+    "mkh_problem_num_collision_pairs", "mkh_solve", "mkh_eval", "mkh_integrate", "mkh_problem_launch_info",
+)
+
+
+def _check(rc: int) -> None:
+    if rc != MKH_OK:
+        raise MinkHipError(f"libminkhip error {rc}: {lib().mkh_last_error().decode()}")
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+class NativeModel:
+    """Device copy of a FlatModel (mkh_model_create)."""
+
+    def __init__(self, model: FlatModel, device: int = 0):
+        self.model = model
+        self.device = int(device)
+        m = model
+        self._keep = {}
+        fm = MkhFlatModel()
+        for n in ("nq", "nv", "nbody", "njnt", "ngeom", "nsite"):
+            setattr(fm, n, int(getattr(m, n)))
+        for n, ctype in MkhFlatModel._fields_[6:]:
+            arr = getattr(m, n)
+            arr = _i32(arr) if ctype is _pi else _f64(arr)
+            if arr.size == 0:
+                arr = np.zeros(1, dtype=arr.dtype)
+            self._keep[n] = arr
+            setattr(fm, n, arr.ctypes.data_as(ctype))
+        h = C.c_void_p()
+        _check(lib().mkh_model_create(C.byref(fm), self.device, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().mkh_model_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def integrate(self, q, v, dt: float, out=None):
+        """Configuration.integrate for a batch (mkh_integrate)."""
+        if _is_torch(q):
+            import torch
+            q = q.contiguous(); v = v.contiguous()
+            out = torch.empty_like(q) if out is None else out
+            stream = torch.cuda.current_stream(q.device).cuda_stream
+            _check(lib().mkh_integrate(self.handle, q.shape[0], q.data_ptr(), v.data_ptr(), float(dt),
+                                       out.data_ptr(), FLAG_DEVICE_PTRS, stream))
+            return out
+        q = _f64(q); v = _f64(v)
+        out = np.empty_like(q)
+        _check(lib().mkh_integrate(self.handle, q.shape[0], q.ctypes.data, v.ctypes.data, float(dt),
+                                   out.ctypes.data, 0, None))
+        return out
+
+
+class NativeProblem:
+    """Device descriptor of one solve_ik call site (mkh_problem_create)."""
+
+    def __init__(self, nmodel: NativeModel, frame_tasks: Sequence[dict] = (), posture_tasks: Sequence[dict] = (),
+                 com_tasks: Sequence[dict] = (), configuration_limits: Sequence[dict] = (),
+                 velocity_limits: Sequence[dict] = (), collision_limits: Sequence[dict] = (),
+                 max_batch: int = 1):
+        self.nmodel = nmodel
+        m = nmodel.model
+        keep = []
+        d = MkhProblemDesc()
+
+        def arr(ctype_struct, items):
+            a = (ctype_struct * max(1, len(items)))()
+            keep.append(a)
+            return a
+
+        ft = arr(MkhFrameTaskDesc, frame_tasks)
+        for i, t in enumerate(frame_tasks):
+            ft[i].frame_type = FRAME_TYPE_ID[t["frame_type"]]
+            ft[i].frame_id = int(t["frame_id"])
+            ft[i].cost = (C.c_double * 6)(*[float(x) for x in t["cost"]])
+            ft[i].gain = float(t.get("gain", 1.0)); ft[i].lm_damping = float(t.get("lm_damping", 0.0))
+        pt = arr(MkhPostureTaskDesc, posture_tasks)
+        for i, t in enumerate(posture_tasks):
+            c = _f64(np.broadcast_to(t["cost"], (m.nv,))); keep.append(c)
+            pt[i].cost = c.ctypes.data_as(_pd)
+            pt[i].gain = float(t.get("gain", 1.0)); pt[i].lm_damping = float(t.get("lm_damping", 0.0))
+        ct = arr(MkhComTaskDesc, com_tasks)
+        for i, t in enumerate(com_tasks):
+            ct[i].cost = (C.c_double * 3)(*[float(x) for x in np.broadcast_to(t["cost"], (3,))])
+            ct[i].gain = float(t.get("gain", 1.0)); ct[i].lm_damping = float(t.get("lm_damping", 0.0))
+        cl = arr(MkhConfigurationLimitDesc, configuration_limits)
+        for i, t in enumerate(configuration_limits):
+            lo, up, idx = _f64(t["lower"]), _f64(t["upper"]), _i32(t["indices"])
+            keep += [lo, up, idx]
+            cl[i].gain = float(t["gain"]); cl[i].lower = lo.ctypes.data_as(_pd); cl[i].upper = up.ctypes.data_as(_pd)
+            cl[i].n_indices = len(idx); cl[i].indices = idx.ctypes.data_as(_pi)
+        vl = arr(MkhVelocityLimitDesc, velocity_limits)
+        for i, t in enumerate(velocity_limits):
+            idx, lim = _i32(t["indices"]), _f64(t["limit"])
+            keep += [idx, lim]
+            vl[i].n_indices = len(idx); vl[i].indices = idx.ctypes.data_as(_pi); vl[i].limit = lim.ctypes.data_as(_pd)
+        co = arr(MkhCollisionLimitDesc, collision_limits)
+        for i, t in enumerate(collision_limits):
+            pairs = _i32(np.asarray(t["geom_id_pairs"]).reshape(-1, 2)); keep.append(pairs)
+            co[i].n_pairs = len(pairs); co[i].geom_id_pairs = pairs.ctypes.data_as(_pi)
+            co[i].gain = float(t["gain"])
+            co[i].minimum_distance_from_collisions = float(t["minimum_distance_from_collisions"])
+            co[i].collision_detection_distance = float(t["collision_detection_distance"])
+            co[i].bound_relaxation = float(t["bound_relaxation"])
+        d.n_frame_tasks, d.frame_tasks = len(frame_tasks), ft
+        d.n_posture_tasks, d.posture_tasks = len(posture_tasks), pt
+        d.n_com_tasks, d.com_tasks = len(com_tasks), ct
+        d.n_configuration_limits, d.configuration_limits = len(configuration_limits), cl
+        d.n_velocity_limits, d.velocity_limits = len(velocity_limits), vl
+        d.n_collision_limits, d.collision_limits = len(collision_limits), co
+        h = C.c_void_p()
+        _check(lib().mkh_problem_create(nmodel.handle, C.byref(d), int(max_batch), C.byref(h)))
+        self.handle = h
+        self.max_batch = int(max_batch)
+        self.n_frame, self.n_posture, self.n_com = len(frame_tasks), len(posture_tasks), len(com_tasks)
+        self.n_rows = lib().mkh_problem_num_task_rows(h)
+        self.n_pairs = lib().mkh_problem_num_collision_pairs(h)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().mkh_problem_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def launch_info(self, B: int) -> Dict[str, int]:
+        g, b, l, t = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _check(lib().mkh_problem_launch_info(self.handle, int(B), C.byref(g), C.byref(b), C.byref(l), C.byref(t)))
+        return {"grid": g.value, "block": b.value, "lds_bytes": l.value, "tableau_rows": t.value}
+
+    # ------------------------------------------------------------------ solve
+    def _tap_shapes(self, B: int) -> Dict[str, tuple]:
+        m = self.nmodel.model
+        return {
+            "xpos": (B, m.nbody, 3), "xquat": (B, m.nbody, 4), "frame_pose": (B, self.n_frame, 7),
+            "subtree_com": (B, 3), "task_e": (B, self.n_rows), "task_J": (B, self.n_rows, m.nv),
+            "H": (B, m.nv, m.nv), "c": (B, m.nv), "box_lo": (B, m.nv), "box_hi": (B, m.nv),
+            "coll_G": (B, self.n_pairs, m.nv), "coll_h": (B, self.n_pairs), "qp_iters": (B,),
+        }
+
+    def solve(self, q, frame_targets=None, posture_target=None, com_target=None, dt: float = 1e-2,
+              damping: float = 1e-12, taps: Sequence[str] = (), solve_qp: bool = True,
+              out=None, status_out=None):
+        """Returns (v, status[, taps dict]).  numpy in → numpy out (synchronous);
+        torch CUDA tensors in → torch tensors out (asynchronous on the current stream)."""
+        m = self.nmodel.model
+        use_torch = _is_torch(q)
+        B = int(q.shape[0])
+        flags = 0
+
+        def tgt(x, per, name):
+            nonlocal flags
+            if x is None:
+                return None
+            return x
+
+        if use_torch:
+            import torch
+            dev = q.device
+
+            def prep(x):
+                return None if x is None else x.to(device=dev, dtype=torch.float64).contiguous()
+
+            q = prep(q); frame_targets = prep(frame_targets); posture_target = prep(posture_target)
+            com_target = prep(com_target)
+            ptr = lambda x: 0 if x is None else x.data_ptr()
+            flags |= FLAG_DEVICE_PTRS
+            v = (torch.empty((B, m.nv), dtype=torch.float64, device=dev) if out is None else out) if solve_qp else None
+            st = (torch.empty((B,), dtype=torch.int32, device=dev) if status_out is None else status_out) if solve_qp else None
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            tapbufs = {}
+            shapes = self._tap_shapes(B)
+            for n in taps:
+                dt_ = torch.int32 if n == "qp_iters" else torch.float64
+                tapbufs[n] = torch.empty(shapes[n], dtype=dt_, device=dev)
+                if n in ("task_e", "task_J", "subtree_com"):
+                    tapbufs[n].zero_()
+        else:
+            q = _f64(q)
+            frame_targets = None if frame_targets is None else _f64(frame_targets)
+            posture_target = None if posture_target is None else _f64(posture_target)
+            com_target = None if com_target is None else _f64(com_target)
+            ptr = lambda x: None if x is None else x.ctypes.data
+            v = (np.empty((B, m.nv)) if out is None else out) if solve_qp else None
+            st = (np.zeros((B,), dtype=np.int32) if status_out is None else status_out) if solve_qp else None
+            stream = None
+            shapes = self._tap_shapes(B)
+            tapbufs = {n: np.zeros(shapes[n], dtype=np.int32 if n == "qp_iters" else np.float64) for n in taps}
+        if q.shape != (B, m.nq):
+            raise ValueError(f"q must have shape (B, {m.nq}), got {tuple(q.shape)}")
+        if self.n_frame and (frame_targets is None or tuple(frame_targets.shape) != (B, self.n_frame, 7)):
+            raise ValueError(f"frame_targets must have shape ({B}, {self.n_frame}, 7)")
+        if self.n_posture:
+            if posture_target is None:
+                raise ValueError("posture_target is required")
+            if tuple(posture_target.shape) == (B, self.n_posture, m.nq):
+                flags |= FLAG_POSTURE_BATCHED
+            elif tuple(posture_target.shape) != (self.n_posture, m.nq):
+                raise ValueError(f"posture_target must have shape ({self.n_posture}, {m.nq}) or (B, ...)")
+        if self.n_com:
+            if com_target is None:
+                raise ValueError("com_target is required")
+            if tuple(com_target.shape) == (B, self.n_com, 3):
+                flags |= FLAG_COM_BATCHED
+            elif tuple(com_target.shape) != (self.n_com, 3):
+                raise ValueError(f"com_target must have shape ({self.n_com}, 3) or (B, ...)")
+        args = [self.handle, B, ptr(q), ptr(frame_targets), ptr(posture_target), ptr(com_target), float(dt),
+                float(damping), ptr(v), ptr(st)]
+        if taps or not solve_qp:
+            tp = MkhTaps()
+            for n in taps:
+                setattr(tp, n, tapbufs[n].data_ptr() if use_torch else tapbufs[n].ctypes.data)
+            _check(lib().mkh_eval(*args, C.byref(tp), flags, stream))
+            return v, st, tapbufs
+        _check(lib().mkh_solve(*args, flags, stream))
+        return v, st

@@ -1,0 +1,845 @@
+// One-wavefront-per-problem differential-IK kernel for gfx950 (MI355X, wave64).
+//
+// One launch = one batched mink.solve_ik (mink/solve_ik.py:68-105).  A workgroup is
+// exactly one wavefront; it loops over problems b = blockIdx.x, += gridDim.x.
+// Lanes change role by phase:
+//   body lane   (l < nbody)   forward kinematics by pointer jumping over the tree
+//                             (replaces mj_kinematics, mink/configuration.py:63)
+//   task lane   (l < n_frame) frame pose, e = log(T_bt), jlog blocks
+//                             (mink/tasks/frame_task.py:95-146, mink/lie/se3.py)
+//   dof lane    (l < nv)      world Jacobian column of dof l (replaces mj_jacSite /
+//                             mj_jac / mj_jacSubtreeCom), task Jacobian column, box limits,
+//                             column l of H = Σ JᵀW²J + (λ+Σμ)I (mink/tasks/task.py:125-138)
+//   pair lane   (l < n_pairs) capsule/sphere/plane signed distance + half-space row
+//                             (mink/limits/collision_avoidance_limit.py:187-229)
+//   tableau lane(l < ntab)    one column of the symmetric sweep tableau of
+//                             K = [[H, Aᵀ],[A, 0]] held in VGPRs; the dual active-set QP
+//                             (replaces qpsolvers→quadprog, mink/solve_ik.py:101) is a
+//                             sequence of rank-1 sweeps: v_readlane broadcast + v_fma_f64.
+// Per-problem J rows, task blocks, poses and half-space rows are staged in LDS.
+#pragma once
+#include "collide_dev.h"
+#include "lie_dev.h"
+#include "mkh_types.h"
+#include "wave_ops.h"
+
+namespace mkh {
+
+// ------------------------------------------------------------------ LDS layout
+struct LdsLayout {
+  int q, X, jnt, tgt, task, J, dof, com, col, A, total;  // offsets in doubles
+};
+__host__ __device__ inline int lds_even(int x) { return (x + 1) & ~1; }
+__host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int njnt, int n_frame,
+                                                int n_posture, int n_com, int max_rows) {
+  LdsLayout L;
+  int o = 0;
+  L.q = o;    o += lds_even(nq);
+  L.X = o;    o += nbody * 8;
+  L.jnt = o;  o += lds_even(njnt * 6);
+  L.tgt = o;  o += lds_even(n_frame * 7 + n_com * 3);
+  L.task = o; o += n_frame * 48;
+  L.J = o;    o += (n_frame + n_com) * lds_even(nv * 6);
+  L.dof = o;  o += kWave * 10;
+  L.com = o;  o += (n_com > 0 ? nbody * 4 : 0);
+  L.col = o;  o += max_rows * 16;
+  L.A = o;    o += max_rows * kWave;
+  L.total = o;
+  return L;
+}
+
+// ------------------------------------------------------------- tableau access
+// A lane's tableau column is a plain register array `double T[NT]`; every index into it
+// is a compile-time constant after unrolling, so it lives in VGPRs.  hipcc sends any
+// runtime-indexed private array (even a wave-uniform index into an ext_vector) to scratch,
+// so the two places that need row k for a runtime k (wave-uniform) go through a scalar
+// switch: one s_cbranch tree to a leaf that touches a statically named register.
+#define MKH_C1(i)                                  \
+  case (i):                                        \
+    if constexpr ((i) < NT) { MKH_CASE_BODY(i) }   \
+    asm volatile("");                              \
+    break;
+#define MKH_C4(i) MKH_C1(i) MKH_C1((i) + 1) MKH_C1((i) + 2) MKH_C1((i) + 3)
+#define MKH_C16(i) MKH_C4(i) MKH_C4((i) + 4) MKH_C4((i) + 8) MKH_C4((i) + 12)
+#define MKH_C64 MKH_C16(0) MKH_C16(16) MKH_C16(32) MKH_C16(48)
+
+template <int NT>
+__device__ __forceinline__ double tab_get(const double (&T)[NT], int k /*uniform*/) {
+  double r = 0.0;
+#define MKH_CASE_BODY(i) r = T[(i)];
+  switch (k) { MKH_C64 default: break; }
+#undef MKH_CASE_BODY
+  return r;
+}
+template <int NT>
+__device__ __forceinline__ void tab_set(double (&T)[NT], int k /*uniform*/, double v) {
+#define MKH_CASE_BODY(i) T[(i)] = v;
+  switch (k) { MKH_C64 default: break; }
+#undef MKH_CASE_BODY
+}
+
+// Per-lane QP bookkeeping.  Column `lane` of the tableau is stored unscaled in R with
+// a lazy column scale: true T[i][lane] = sc * R[i].
+struct QpLane {
+  double z, w, lo, hi, sc, isc;
+  int kind;    // 0 dof, 1 half-space row, 2 padding
+  int basic;   // swept into the basis
+  int at_hi;   // nonbasic dof sitting at its upper bound (else lower)
+};
+
+// Symmetric sweep (reverse = un-sweep) of the tableau on index k (wave-uniform).
+// rk = R[k][lane] must be passed in (the caller usually has it from the ratio test).
+template <int NT>
+__device__ __forceinline__ void pivot(double (&T)[NT], QpLane& s, int k, bool reverse, double rk, int lane,
+                                      int ntab) {
+  const double pk = s.sc * rk;                 // true T[k][lane]
+  const double d = readlane_f64(pk, k);        // true T[k][k]
+  const double inv = 1.0 / d;
+  const double sck = readlane_f64(s.sc, k);
+  const double g = (lane == k) ? 0.0 : rk * (sck * inv);
+#pragma unroll
+  for (int b = 0; b < NT / 16; ++b) {
+    if (b * 16 < ntab) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const double raw = readlane_f64(T[b * 16 + i], k);
+        T[b * 16 + i] = fma(-raw, g, T[b * 16 + i]);
+      }
+    }
+  }
+  // row k of every other column: T[k][j] = ±T[k][j]/d   (R units: ±rk·inv)
+  const double sgn = reverse ? -1.0 : 1.0;
+  double newk = sgn * rk * inv;
+  if (lane == k) {
+    // column k: T[i][k] = ±T[i][k]/d via the lazy scale; T[k][k] = −1/d
+    newk = -sgn * s.isc;                       // (−1/d) / (±sc/d)
+    s.sc = sgn * s.sc * inv;
+    s.isc = sgn * s.isc * d;
+  }
+  tab_set<NT>(T, k, newk);
+}
+
+// ----------------------------------------------------------------- the kernel
+template <int NB>
+__global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, const SolveArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int lane = lane_id();
+  const int nq = P.nq, nv = P.nv, nbody = P.nbody;
+  const LdsLayout L = lds_layout(nq, nv, nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows);
+  double* const sq = smem + L.q;
+  double* const sX = smem + L.X;
+  double* const sJnt = smem + L.jnt;
+  double* const sTgt = smem + L.tgt;
+  double* const sTask = smem + L.task;
+  double* const sJ = smem + L.J;
+  double* const sDof = smem + L.dof;
+  double* const sCom = smem + L.com;
+  double* const sCol = smem + L.col;
+  double* const sA = smem + L.A;
+  constexpr int NT = NB * 16;
+  const double kInf = __builtin_huge_val();
+
+  const bool is_body = lane < nbody;
+  const bool is_dof = lane < nv;
+  const int ntab = nv + P.max_rows;                   // tableau indices in use (upper bound)
+
+  for (int pb = blockIdx.x; pb < A.B; pb += gridDim.x) {
+    int status = 0;
+    // Opaque per-iteration zero: table loads below are indexed with it so that LICM cannot hoist
+    // them out of the problem loop and keep ~60 VGPRs of lane constants live through the QP.
+    int oz;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
+    const int ol = lane + oz;
+    wave_sync();  // previous problem's LDS readers are done
+    // ------------------------------------------------------------ load inputs
+    for (int i = lane; i < nq; i += 64) sq[i] = A.q[(size_t)pb * nq + i];
+    {
+      const int nt = P.n_frame * 7;
+      for (int i = lane; i < nt; i += 64) sTgt[i] = A.frame_targets[(size_t)pb * nt + i];
+      const int nc = P.n_com * 3;
+      if (lane < nc) sTgt[nt + lane] = A.com_target[(A.com_batched ? (size_t)pb * nc : 0) + lane];
+    }
+    wave_sync();
+
+    // ------------------------------------------------- FK: local transforms
+    // X = pose of body `lane` relative to its parent, joints applied
+    // (mj_kinematics).
+    V3 xp{0, 0, 0};
+    Q4 xq{1, 0, 0, 0};
+    int b_jadr = 0, b_jnum = 0;
+    if (is_body) {
+      const double* bf = P.body_f + ol;
+      xp = {bf[(BF_POS + 0) * 64], bf[(BF_POS + 1) * 64], bf[(BF_POS + 2) * 64]};
+      xq = {bf[(BF_QUAT + 0) * 64], bf[(BF_QUAT + 1) * 64], bf[(BF_QUAT + 2) * 64], bf[(BF_QUAT + 3) * 64]};
+      b_jadr = P.body_i[BI_JNTADR * 64 + ol];
+      b_jnum = P.body_i[BI_JNTNUM * 64 + ol];
+      for (int jn = 0; jn < b_jnum; ++jn) {
+        const int j = b_jadr + jn;
+        const int jt = P.jnt_i[j * JI_COUNT + JI_TYPE];
+        const int qa = P.jnt_i[j * JI_COUNT + JI_QADR];
+        const double* jf = P.jnt_f + j * JF_COUNT;
+        if (jt == JNT_FREE) {
+          xp = {sq[qa], sq[qa + 1], sq[qa + 2]};
+          xq = qnormalize(Q4{sq[qa + 3], sq[qa + 4], sq[qa + 5], sq[qa + 6]});
+        } else if (jt == JNT_SLIDE) {
+          V3 ax{jf[JF_AXIS], jf[JF_AXIS + 1], jf[JF_AXIS + 2]};
+          xp = xp + (sq[qa] - jf[JF_QPOS0]) * qrot(xq, ax);
+        } else {
+          V3 jp{jf[JF_POS], jf[JF_POS + 1], jf[JF_POS + 2]};
+          Q4 qloc;
+          if (jt == JNT_HINGE) {
+            V3 ax{jf[JF_AXIS], jf[JF_AXIS + 1], jf[JF_AXIS + 2]};
+            qloc = axis_angle(ax, sq[qa] - jf[JF_QPOS0]);
+          } else {
+            qloc = qnormalize(Q4{sq[qa], sq[qa + 1], sq[qa + 2], sq[qa + 3]});
+          }
+          V3 anchor = xp + qrot(xq, jp);
+          xq = qmul(xq, qloc);
+          xp = anchor - qrot(xq, jp);
+        }
+      }
+    }
+    // ---------------------------------------- FK: pointer jumping to the root
+    for (int r = 0; r < P.nrounds; ++r) {
+      wave_sync();
+      if (is_body) {
+        double* o = sX + lane * 8;
+        o[0] = xp.x; o[1] = xp.y; o[2] = xp.z; o[3] = xq.w; o[4] = xq.x; o[5] = xq.y; o[6] = xq.z;
+      }
+      wave_sync();
+      if (is_body) {
+        const double* a = sX + P.body_i[(BI_ANC0 + r) * 64 + ol] * 8;
+        V3 ap{a[0], a[1], a[2]};
+        Q4 aq{a[3], a[4], a[5], a[6]};
+        xp = ap + qrot(aq, xp);
+        xq = qmul(aq, xq);
+      }
+    }
+    xq = qnormalize(xq);
+    wave_sync();
+    if (is_body) {
+      double* o = sX + lane * 8;
+      o[0] = xp.x; o[1] = xp.y; o[2] = xp.z; o[3] = xq.w; o[4] = xq.x; o[5] = xq.y; o[6] = xq.z;
+      if (A.t_xpos) {
+        double* t = A.t_xpos + ((size_t)pb * nbody + lane) * 3;
+        t[0] = xp.x; t[1] = xp.y; t[2] = xp.z;
+      }
+      if (A.t_xquat) {
+        double* t = A.t_xquat + ((size_t)pb * nbody + lane) * 4;
+        t[0] = xq.w; t[1] = xq.x; t[2] = xq.y; t[3] = xq.z;
+      }
+    }
+    wave_sync();
+    // --------------------- joint anchors / axes in the world (xanchor, xaxis)
+    if (is_body && b_jnum > 0) {
+      if (b_jnum == 1) {
+        // single joint: rotation about its own axis/anchor leaves both invariant, so the
+        // final body frame gives them directly.
+        const int j = b_jadr;
+        const double* jf = P.jnt_f + j * JF_COUNT;
+        V3 ax = qrot(xq, V3{jf[JF_AXIS], jf[JF_AXIS + 1], jf[JF_AXIS + 2]});
+        V3 an = xp + qrot(xq, V3{jf[JF_POS], jf[JF_POS + 1], jf[JF_POS + 2]});
+        double* o = sJnt + j * 6;
+        o[0] = ax.x; o[1] = ax.y; o[2] = ax.z; o[3] = an.x; o[4] = an.y; o[5] = an.z;
+      } else {
+        // several joints in one body: replay them from the parent's world pose.
+        const double* a = sX + P.body_i[BI_PARENT * 64 + ol] * 8;
+        const double* bf = P.body_f + ol;
+        V3 fp = V3{a[0], a[1], a[2]} + qrot(Q4{a[3], a[4], a[5], a[6]},
+                                            V3{bf[(BF_POS + 0) * 64], bf[(BF_POS + 1) * 64], bf[(BF_POS + 2) * 64]});
+        Q4 fq = qmul(Q4{a[3], a[4], a[5], a[6]}, Q4{bf[(BF_QUAT + 0) * 64], bf[(BF_QUAT + 1) * 64],
+                                                    bf[(BF_QUAT + 2) * 64], bf[(BF_QUAT + 3) * 64]});
+        for (int jn = 0; jn < b_jnum; ++jn) {
+          const int j = b_jadr + jn;
+          const int jt = P.jnt_i[j * JI_COUNT + JI_TYPE];
+          const int qa = P.jnt_i[j * JI_COUNT + JI_QADR];
+          const double* jf = P.jnt_f + j * JF_COUNT;
+          V3 axl{jf[JF_AXIS], jf[JF_AXIS + 1], jf[JF_AXIS + 2]};
+          V3 jp{jf[JF_POS], jf[JF_POS + 1], jf[JF_POS + 2]};
+          V3 ax = qrot(fq, axl);
+          V3 an = fp + qrot(fq, jp);
+          double* o = sJnt + j * 6;
+          o[0] = ax.x; o[1] = ax.y; o[2] = ax.z; o[3] = an.x; o[4] = an.y; o[5] = an.z;
+          if (jt == JNT_SLIDE) {
+            fp = fp + (sq[qa] - jf[JF_QPOS0]) * ax;
+          } else if (jt == JNT_HINGE || jt == JNT_BALL) {
+            Q4 qloc = (jt == JNT_HINGE) ? axis_angle(axl, sq[qa] - jf[JF_QPOS0])
+                                        : qnormalize(Q4{sq[qa], sq[qa + 1], sq[qa + 2], sq[qa + 3]});
+            fq = qmul(fq, qloc);
+            fp = an - qrot(fq, jp);
+          }
+        }
+      }
+    }
+    wave_sync();
+    // --------------------------- dof lane: motion axis of dof `lane` (cdof)
+    // jacp(p) = lin + ang × (p − anchor), jacr = ang  (mj_jac)
+    int d_kind = DOF_HINGE, d_k = 0, d_body = 0, d_qadr = -1;
+    {
+    V3 d_ang{0, 0, 0}, d_lin{0, 0, 0}, d_anchor{0, 0, 0};
+    double q_dof = 0.0;  // joint coordinate for hinge/slide dofs
+    if (is_dof) {
+      const int32_t* di = P.dof_i + ol;
+      const int d_jnt = di[DI_JNT * 64];
+      d_kind = di[DI_KIND * 64];
+      d_k = di[DI_K * 64];
+      d_body = di[DI_BODY * 64];
+      d_qadr = di[DI_QADR * 64];
+      if (d_kind == DOF_HINGE) {
+        const double* o = sJnt + d_jnt * 6;
+        d_ang = {o[0], o[1], o[2]};
+        d_anchor = {o[3], o[4], o[5]};
+        q_dof = sq[d_qadr];
+      } else if (d_kind == DOF_SLIDE) {
+        const double* o = sJnt + d_jnt * 6;
+        d_lin = {o[0], o[1], o[2]};
+        q_dof = sq[d_qadr];
+      } else if (d_kind == DOF_FREE_LIN) {
+        d_lin = {d_k == 0 ? 1.0 : 0.0, d_k == 1 ? 1.0 : 0.0, d_k == 2 ? 1.0 : 0.0};
+      } else {  // ball / free rotational dof: body-frame axis k, about the joint anchor
+        const double* xb = sX + d_body * 8;
+        M3 R = qmat(Q4{xb[3], xb[4], xb[5], xb[6]});
+        d_ang = (d_k == 0) ? V3{R.m[0], R.m[3], R.m[6]}
+                           : ((d_k == 1) ? V3{R.m[1], R.m[4], R.m[7]} : V3{R.m[2], R.m[5], R.m[8]});
+        if (d_kind == DOF_FREE_ANG) {
+          d_anchor = {xb[0], xb[1], xb[2]};
+        } else {
+          const double* o = sJnt + d_jnt * 6;
+          d_anchor = {o[3], o[4], o[5]};
+        }
+      }
+    }
+    // Configuration.check_limits (mink/configuration.py:77-110), tol = 1e-6
+    {
+      bool viol = false;
+      if (is_dof && (d_kind == DOF_HINGE || d_kind == DOF_SLIDE))
+        viol = q_dof < P.dof_f[DF_RANGE_LO * 64 + ol] - 1e-6 || q_dof > P.dof_f[DF_RANGE_HI * 64 + ol] + 1e-6;
+      if (__ballot(viol)) status |= 1;
+    }
+    // stash the dof's motion axis in LDS; phases below reload it instead of keeping 20 VGPRs live
+    {
+      double* o = sDof + lane * 10;
+      o[0] = d_ang.x; o[1] = d_ang.y; o[2] = d_ang.z; o[3] = d_lin.x; o[4] = d_lin.y; o[5] = d_lin.z;
+      o[6] = d_anchor.x; o[7] = d_anchor.y; o[8] = d_anchor.z; o[9] = q_dof;
+    }
+    }
+    const double* const my_dof = sDof + lane * 10;   // {ang, lin, anchor, q} of dof `lane`
+#define MKH_LOAD_DOF_AXES()                                                        \
+  const V3 d_ang{my_dof[0], my_dof[1], my_dof[2]}, d_lin{my_dof[3], my_dof[4], my_dof[5]}, \
+      d_anchor{my_dof[6], my_dof[7], my_dof[8]}
+
+    // -------------------------------------- subtree CoM (mj_comPos) for ComTask
+    V3 com_root{0, 0, 0};
+    if (P.n_com > 0) {
+      V3 b_ipos{0, 0, 0};
+      double b_mass = 0.0, b_stmass = 0.0;
+      int b_last = 0, b_inrobot = 0;
+      if (is_body) {
+        const double* bf = P.body_f + ol;
+        b_ipos = {bf[(BF_IPOS + 0) * 64], bf[(BF_IPOS + 1) * 64], bf[(BF_IPOS + 2) * 64]};
+        b_mass = bf[BF_MASS * 64];
+        b_stmass = bf[BF_SUBTREEMASS * 64];
+        b_last = P.body_i[BI_SUBTREE_LAST * 64 + ol];
+        b_inrobot = P.body_i[BI_IN_ROBOT * 64 + ol];
+      }
+      V3 xi = xp + qrot(xq, b_ipos);
+      const double m = (is_body && b_inrobot) ? b_mass : 0.0;
+      double sx = m * xi.x, sy = m * xi.y, sz = m * xi.z;
+      // inclusive scan over body ids (a subtree is a contiguous id range in MuJoCo's DFS order)
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        double tx = __shfl_up(sx, o), ty = __shfl_up(sy, o), tz = __shfl_up(sz, o);
+        if (lane >= o) { sx += tx; sy += ty; sz += tz; }
+      }
+      const int hi_l = is_body ? b_last : 0, lo_l = lane - 1;
+      double ex = __shfl(sx, hi_l), ey = __shfl(sy, hi_l), ez = __shfl(sz, hi_l);
+      double bx = __shfl(sx, lo_l < 0 ? 0 : lo_l), by = __shfl(sy, lo_l < 0 ? 0 : lo_l),
+             bz = __shfl(sz, lo_l < 0 ? 0 : lo_l);
+      if (lane == 0) { bx = 0; by = 0; bz = 0; }
+      V3 cs = xi;
+      if (b_stmass >= 1e-15) {
+        const double im = 1.0 / b_stmass;
+        cs = {(ex - bx) * im, (ey - by) * im, (ez - bz) * im};
+      }
+      if (is_body) {
+        double* o = sCom + lane * 4;
+        o[0] = cs.x; o[1] = cs.y; o[2] = cs.z; o[3] = b_stmass;
+      }
+      wave_sync();
+      const double* cr = sCom + P.robot_root * 4;
+      com_root = {cr[0], cr[1], cr[2]};
+      if (A.t_subtree_com && lane < 3) A.t_subtree_com[(size_t)pb * 3 + lane] = cr[lane];
+    }
+
+    // ------------------------------------------- task lanes: pose, error, jlog
+    double mu_lane = 0.0;  // Levenberg–Marquardt term of the task owned by this lane
+    if (lane < P.n_frame) {
+      const FrameTaskDev& ft = P.frame[lane];
+      const double* xb = sX + ft.body * 8;
+      SE3 F;
+      Q4 bq{xb[3], xb[4], xb[5], xb[6]};
+      F.p = V3{xb[0], xb[1], xb[2]} + qrot(bq, V3{ft.lpos[0], ft.lpos[1], ft.lpos[2]});
+      F.q = qmul(bq, Q4{ft.lquat[0], ft.lquat[1], ft.lquat[2], ft.lquat[3]});
+      const double* tg = sTgt + lane * 7;
+      SE3 Tt{Q4{tg[0], tg[1], tg[2], tg[3]}, V3{tg[4], tg[5], tg[6]}};
+      // e = target.minus(frame) = log(T_frame⁻¹ · T_target)          (frame_task.py:119-122)
+      V3 ev, ew;
+      se3_log(se3_mul(se3_inv(F), Tt), ev, ew);
+      // jlog(T_tb) = ljacinv(−log(T_tb)) = ljacinv(e)   since T_tb = T_bt⁻¹   (frame_task.py:144-146)
+      double Jm[9], Qm[9];
+      bool ident;
+      se3_ljacinv(ev, ew, Jm, Qm, ident);
+      M3 Rf = qmat(F.q);
+      double* o = sTask + lane * 48;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { o[i] = Jm[i]; o[9 + i] = Qm[i]; o[18 + i] = Rf.m[i]; }
+      o[27] = F.p.x; o[28] = F.p.y; o[29] = F.p.z;
+      const double e6[6] = {ev.x, ev.y, ev.z, ew.x, ew.y, ew.z};
+      double ss = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double we = ft.cost[r] * (-ft.gain * e6[r]);  // weighted_error (task.py:129-130)
+        o[30 + r] = we;
+        ss += we * we;
+        if (A.t_task_e) A.t_task_e[(size_t)pb * P.n_rows_tap + ft.row0 + r] = e6[r];
+      }
+      mu_lane = ft.lm_damping * ss;                          // task.py:131
+      if (A.t_frame_pose) {
+        double* t = A.t_frame_pose + ((size_t)pb * P.n_frame + lane) * 7;
+        t[0] = F.q.w; t[1] = F.q.x; t[2] = F.q.y; t[3] = F.q.z; t[4] = F.p.x; t[5] = F.p.y; t[6] = F.p.z;
+      }
+    }
+    double mu_total = A.damping + wave_sum(mu_lane);         // solve_ik.py:16 + Σ μ_t
+
+    // ------------------------------------------- posture tasks (diagonal)
+    double c_lane = 0.0;   // c[lane]
+    double hdiag = 0.0;    // H[lane][lane]
+    for (int t = 0; t < P.n_posture; ++t) {
+      const double* tq = A.posture_target + (A.posture_batched ? ((size_t)pb * P.n_posture + t) * nq : (size_t)t * nq);
+      double e = 0.0, jd = 0.0;
+      const double cost = is_dof ? P.posture_cost[t * 64 + lane] : 0.0;
+      if (is_dof) {
+        if (d_kind == DOF_HINGE || d_kind == DOF_SLIDE) {
+          e = tq[d_qadr] - my_dof[9];                        // mj_differentiatePos, dt = 1
+          jd = -1.0;
+        } else if (d_kind == DOF_BALL) {
+          // ball joint: qvel = quat2Vel(conj(q1) ⊗ q2)      (posture_task.py:107)
+          const int qa = d_qadr;
+          Q4 q1{sq[qa], sq[qa + 1], sq[qa + 2], sq[qa + 3]}, q2{tq[qa], tq[qa + 1], tq[qa + 2], tq[qa + 3]};
+          Q4 df = qmul(qconj(q1), q2);
+          double ax[3] = {df.x, df.y, df.z};
+          double sn = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+          if (sn < 1e-15) { ax[0] = 1; ax[1] = 0; ax[2] = 0; } else { ax[0] /= sn; ax[1] /= sn; ax[2] /= sn; }
+          double sp = 2.0 * atan2(sn, df.w);
+          if (sp > M_PI) sp -= 2.0 * M_PI;
+          e = ((d_k == 0) ? ax[0] : ((d_k == 1) ? ax[1] : ax[2])) * sp;
+          jd = -1.0;
+        }  // free-joint dofs: error and Jacobian column zeroed (posture_task.py:115-116,139-141)
+      }
+      const double we = cost * (-P.posture_gain[t] * e);
+      const double wj = cost * jd;
+      hdiag += wj * wj;
+      c_lane -= we * wj;
+      if (P.posture_lm[t] != 0.0) mu_total += P.posture_lm[t] * wave_sum(we * we);
+      if (A.t_task_e && is_dof) A.t_task_e[(size_t)pb * P.n_rows_tap + P.posture_row0[t] + lane] = e;
+      if (A.t_task_J && is_dof) {
+        for (int r = 0; r < nv; ++r)
+          A.t_task_J[((size_t)pb * P.n_rows_tap + P.posture_row0[t] + r) * nv + lane] = (r == lane) ? jd : 0.0;
+      }
+    }
+    // ComTask error & LM term (com_task.py:71-82)
+    for (int t = 0; t < P.n_com; ++t) {
+      const double* tg = sTgt + P.n_frame * 7 + t * 3;
+      const double e3[3] = {com_root.x - tg[0], com_root.y - tg[1], com_root.z - tg[2]};
+      double ss = 0.0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double we = P.com_cost[t][r] * (-P.com_gain[t] * e3[r]);
+        ss += we * we;
+        if (A.t_task_e && lane == 0) A.t_task_e[(size_t)pb * P.n_rows_tap + P.com_row0[t] + r] = e3[r];
+      }
+      mu_total += P.com_lm[t] * ss;
+    }
+
+    hdiag += mu_total;
+    const double hdiag_base = hdiag;   // damping + Σμ + posture diagonal: the explicit diagonal of H
+
+    // ------------------------------ frame + CoM tasks: Jacobian columns, H, c
+    const int n_jt = P.n_frame + P.n_com;
+    const int jstride = lds_even(nv * 6);
+    for (int t = 0; t < n_jt; ++t) {
+      double Jt[6] = {0, 0, 0, 0, 0, 0}, cw[6] = {0, 0, 0, 0, 0, 0}, we6[6] = {0, 0, 0, 0, 0, 0};
+      uint64_t mask;
+      int nrow, row0;
+      bool second_half;
+      if (t < P.n_frame) {
+        const FrameTaskDev& ft = P.frame[t];
+        mask = ft.dof_mask;
+        nrow = 6;
+        row0 = ft.row0;
+        second_half = ft.any_ori != 0;
+        const double* o = sTask + t * 48;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { cw[r] = ft.cost[r]; we6[r] = o[30 + r]; }
+        if (is_dof && ((mask >> lane) & 1)) {
+          V3 pf{o[27], o[28], o[29]};
+          MKH_LOAD_DOF_AXES();
+          V3 jp = d_lin + cross(d_ang, pf - d_anchor);
+          M3 Rf;
+#pragma unroll
+          for (int i = 0; i < 9; ++i) Rf.m[i] = o[18 + i];
+          V3 a = mulT(Rf, jp), w = mulT(Rf, d_ang);          // body-frame Jacobian (configuration.py:148-153)
+          // J_task = −jlog·ᴮJ with jlog = [[J, −J·Q·J],[0, J]]:  y = J·w;  rows 0-2 = −J·(a − Q·y), rows 3-5 = −y
+          const double wv[3] = {w.x, w.y, w.z};
+          double y[3], z3[3];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) y[r] = o[3 * r] * wv[0] + o[3 * r + 1] * wv[1] + o[3 * r + 2] * wv[2];
+          const double av[3] = {a.x, a.y, a.z};
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            z3[r] = av[r] - (o[9 + 3 * r] * y[0] + o[9 + 3 * r + 1] * y[1] + o[9 + 3 * r + 2] * y[2]);
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            Jt[r] = -(o[3 * r] * z3[0] + o[3 * r + 1] * z3[1] + o[3 * r + 2] * z3[2]);
+            Jt[3 + r] = -y[r];
+          }
+        }
+      } else {
+        // CoM Jacobian column (mj_jacSubtreeCom closed form)
+        const int tc = t - P.n_frame;
+        mask = ~0ull;
+        nrow = 3;
+        row0 = P.com_row0[tc];
+        second_half = false;
+        {
+          const double* tg = sTgt + P.n_frame * 7 + tc * 3;
+          const double e3[3] = {com_root.x - tg[0], com_root.y - tg[1], com_root.z - tg[2]};
+#pragma unroll
+          for (int r = 0; r < 3; ++r) { cw[r] = P.com_cost[tc][r]; we6[r] = cw[r] * (-P.com_gain[tc] * e3[r]); }
+        }
+        if (is_dof) {
+          const double* cd = sCom + d_body * 4;
+          const int inrobot = P.body_i[BI_IN_ROBOT * 64 + d_body];
+          if (inrobot) {
+            const double fac = cd[3] / sCom[P.robot_root * 4 + 3];
+            MKH_LOAD_DOF_AXES();
+            V3 jc = fac * (d_lin + cross(d_ang, V3{cd[0], cd[1], cd[2]} - d_anchor));
+            Jt[0] = jc.x; Jt[1] = jc.y; Jt[2] = jc.z;
+          }
+        }
+      }
+      if (A.t_task_J && is_dof) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+          if (r < nrow) A.t_task_J[((size_t)pb * P.n_rows_tap + row0 + r) * nv + lane] = Jt[r];
+      }
+      double Jw[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        Jw[r] = cw[r] * Jt[r];                               // weighted_jacobian (task.py:129)
+        c_lane -= we6[r] * Jw[r];                            // c = −weighted_errorᵀ·weighted_jacobian
+        hdiag += Jw[r] * Jw[r];
+      }
+      if (is_dof) {
+        double* o = sJ + t * jstride + lane * 6;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) o[r] = Jw[r];
+      }
+    }
+    if (A.t_c && is_dof) A.t_c[(size_t)pb * nv + lane] = c_lane;
+    // ------------------------------------------------------------ box limits
+    // lo ≤ Δq ≤ hi from ConfigurationLimit rows (configuration_limit.py:94-124) and
+    // VelocityLimit rows (velocity_limit.py:96-101); never materialise the dense G.
+    double lo = -kInf, hi = kInf;
+    if (is_dof) {
+      const double q_dof = my_dof[9];
+      for (int t = 0; t < P.n_cfg; ++t) {
+        const double lw = P.cfg_lower[t * 64 + lane], up = P.cfg_upper[t * 64 + lane];
+        if (up < kInf) hi = fmin(hi, P.cfg_gain[t] * (up - q_dof));
+        if (lw > -kInf) lo = fmax(lo, -(P.cfg_gain[t] * (q_dof - lw)));
+      }
+      for (int t = 0; t < P.n_vel; ++t) {
+        const double vm = P.vel_limit[t * 64 + lane];
+        if (vm < kInf) { hi = fmin(hi, A.dt * vm); lo = fmax(lo, -(A.dt * vm)); }
+      }
+      if (A.t_box_lo) A.t_box_lo[(size_t)pb * nv + lane] = lo;
+      if (A.t_box_hi) A.t_box_hi[(size_t)pb * nv + lane] = hi;
+    }
+
+    // ------------------------------------------- collision half-space rows
+    int nrows = 0;
+    if (P.n_pairs > 0) {
+      for (int base = 0; base < P.n_pairs; base += 64) {
+        const int pi = base + lane;
+        bool active = false;
+        double hk = kInf;
+        V3 nrm{1, 0, 0}, from{0, 0, 0}, to{0, 0, 0};
+        uint64_t m1 = 0, m2 = 0;
+        if (pi < P.n_pairs) {
+          const CollisionPairDev& cp = P.pairs[pi];
+          const double* x1 = sX + cp.body1 * 8;
+          const double* x2 = sX + cp.body2 * 8;
+          Q4 bq1{x1[3], x1[4], x1[5], x1[6]}, bq2{x2[3], x2[4], x2[5], x2[6]};
+          V3 gp1 = V3{x1[0], x1[1], x1[2]} + qrot(bq1, V3{cp.lpos1[0], cp.lpos1[1], cp.lpos1[2]});
+          V3 gp2 = V3{x2[0], x2[1], x2[2]} + qrot(bq2, V3{cp.lpos2[0], cp.lpos2[1], cp.lpos2[2]});
+          Q4 gq1 = qmul(bq1, Q4{cp.lquat1[0], cp.lquat1[1], cp.lquat1[2], cp.lquat1[3]});
+          Q4 gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
+          double dist;
+          geom_distance(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
+                        V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to);
+          active = dist != cp.ddetect;                         // Contact.inactive (:52-56)
+          if (active) {
+            hk = (dist > cp.dmin) ? (cp.gain * (dist - cp.dmin) / A.dt) + cp.relax : cp.relax;  // :200-205
+            nrm = to - from;                                   // Contact.normal (:46-50)
+            const double nn = sqrt(dot(nrm, nrm));
+            nrm = (nn < 1e-15) ? V3{1.0, 0.0, 0.0} : (1.0 / nn) * nrm;
+            m1 = cp.mask1;
+            m2 = cp.mask2;
+          }
+          if (A.t_coll_h) A.t_coll_h[(size_t)pb * P.n_pairs + pi] = hk;
+        }
+        const unsigned long long am = __ballot(active);
+        const int slot = nrows + __popcll(am & ((1ull << lane) - 1ull));
+        if (active && slot < P.max_rows) {
+          double* o = sCol + slot * 16;
+          o[0] = nrm.x; o[1] = nrm.y; o[2] = nrm.z; o[3] = from.x; o[4] = from.y; o[5] = from.z;
+          o[6] = to.x; o[7] = to.y; o[8] = to.z; o[9] = hk;
+          o[10] = __longlong_as_double((long long)m1);
+          o[11] = __longlong_as_double((long long)m2);
+          o[12] = (double)pi;
+        }
+        nrows += __popcll(am);
+      }
+      if (nrows > P.max_rows) { status |= 16; nrows = P.max_rows; }
+      wave_sync();
+      // G[s][lane] = −nᵀ(jacp₂(to) − jacp₁(from))   (compute_contact_normal_jacobian :59-72)
+      for (int s = 0; s < nrows; ++s) {
+        const double* o = sCol + s * 16;
+        double a = 0.0;
+        if (is_dof) {
+          const uint64_t m1 = (uint64_t)__double_as_longlong(o[10]), m2 = (uint64_t)__double_as_longlong(o[11]);
+          V3 n{o[0], o[1], o[2]};
+          V3 dj{0, 0, 0};
+          MKH_LOAD_DOF_AXES();
+          if ((m2 >> lane) & 1) dj = dj + d_lin + cross(d_ang, V3{o[6], o[7], o[8]} - d_anchor);
+          if ((m1 >> lane) & 1) dj = dj - (d_lin + cross(d_ang, V3{o[3], o[4], o[5]} - d_anchor));
+          a = -dot(n, dj);
+          if (A.t_coll_G) A.t_coll_G[((size_t)pb * P.n_pairs + (int)o[12]) * nv + lane] = a;
+        }
+        sA[s * 64 + lane] = a;
+      }
+    }
+    wave_sync();
+
+    if (!A.do_qp) continue;
+
+    // ------------------------------------------------- build the tableau column
+    // lane j holds column j of K = [[H, Aᵀ],[A, 0]].  Built only now so that the 2·NT tableau
+    // VGPRs are not live during FK / task / collision phases.
+    double T[NT];
+    {
+      const double dg = is_dof ? hdiag_base : ((lane >= ntab) ? 1.0 : 0.0);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) T[i] = (lane == i) ? dg : 0.0;
+    }
+    for (int t = 0; t < n_jt; ++t) {
+      uint64_t mask = ~0ull;
+      bool second_half = false;
+      if (t < P.n_frame) { mask = P.frame[t].dof_mask; second_half = P.frame[t].any_ori != 0; }
+      const double* base = sJ + t * jstride;
+      double Jw[6] = {0, 0, 0, 0, 0, 0};
+      if (is_dof) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) Jw[r] = base[lane * 6 + r];
+      }
+      // H[i][lane] += Σ_r Jw[r][i]·Jw[r][lane], rows i restricted to the task's chain
+#pragma unroll
+      for (int row = 0; row < NT; ++row) {
+        if (row < nv && ((mask >> row) & 1)) {
+          const double* o = base + row * 6;
+          double acc = T[row];
+          acc = fma(o[0], Jw[0], acc);
+          acc = fma(o[1], Jw[1], acc);
+          acc = fma(o[2], Jw[2], acc);
+          if (second_half) {
+            acc = fma(o[3], Jw[3], acc);
+            acc = fma(o[4], Jw[4], acc);
+            acc = fma(o[5], Jw[5], acc);
+          }
+          T[row] = acc;
+        }
+      }
+    }
+    if (A.t_H && is_dof) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        if (i < nv) A.t_H[((size_t)pb * nv + i) * nv + lane] = T[i];
+    }
+    if (nrows > 0) {
+      // rows nv+s of the dof columns, and column nv+s (owned by lane nv+s) = A[s][:]
+      for (int s = 0; s < nrows; ++s) tab_set<NT>(T, nv + s, is_dof ? sA[s * 64 + lane] : 0.0);
+      if (lane >= nv && lane < nv + nrows) {
+        const double* o = sA + (lane - nv) * 64;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+          if (i < nv) T[i] = o[i];
+      }
+    }
+
+
+    // ====================================================================== QP
+    // Dual active set (Goldfarb–Idnani) on the sweep tableau; see tools/proto_tableau_qp.py
+    // for the numpy statement of the same algorithm.
+    QpLane s;
+    s.sc = 1.0; s.isc = 1.0; s.basic = 0; s.at_hi = 0;
+    s.z = 0.0;
+    double rown = 1.0;
+    if (is_dof) {
+      s.kind = 0; s.w = c_lane; s.lo = lo; s.hi = hi;
+    } else if (lane < nv + nrows) {
+      s.kind = 1; s.lo = 0.0; s.hi = kInf;
+      s.w = -sCol[(lane - nv) * 16 + 9];                      // A·0 − h
+      const double* o = sA + (lane - nv) * 64;
+      double nn = 0.0;
+      for (int i = 0; i < nv; ++i) nn += o[i] * o[i];
+      rown = sqrt(nn);
+    } else {
+      s.kind = 2; s.w = 0.0; s.lo = -kInf; s.hi = kInf;
+    }
+    // inconsistent box ⇒ quadprog "constraints are inconsistent"
+    if (__ballot(is_dof && lo > hi + 1e-12)) status |= 2;
+    const double hmax = wave_max(is_dof ? hdiag : 0.0);
+    const double thr_dof = 1e-13 / (hmax * (double)nv);
+
+    // One loop drives both phases so that the sweep is instantiated once:
+    //   phase 0 (k0 < nv): bring dof k0 into the basis, x0 = −H⁻¹c (Gauss–Jordan, no ratio test)
+    //   phase 1: GI — pick the most violated primal condition p, then step/pivot until p is resolved.
+    int iters = 0;
+    const int max_iters = 8 * (ntab + 8);
+    int k0 = 0;          // next dof to bring in (phase 0)
+    int p = -1;          // GI: index being driven (−1 ⇒ select a new one)
+    bool p_basic = false, upper = false;
+    double beta = 0.0, sgn = 1.0, thr = 0.0;
+    while (!(status & 14)) {
+      int piv;
+      bool rev;
+      double rk;
+      if (k0 < nv) {
+        piv = k0++;
+        rev = false;
+        rk = tab_get<NT>(T, piv);
+        const double tau = s.sc * rk;
+        const double d = readlane_f64(tau, piv);
+        if (!(d > 0.0)) { status |= 4; break; }
+        const double alpha = -readlane_f64(s.w, piv) / d;
+        if (s.basic) s.z -= alpha * tau; else s.w += alpha * tau;
+        if (lane == piv) { s.z += alpha; s.w = 0.0; s.basic = 1; }
+      } else {
+        if (p < 0) {
+          // ---- most violated primal condition (GI step 1)
+          double viol = 0.0;
+          if (s.kind == 0 && s.basic) viol = fmax(s.z - s.hi, s.lo - s.z);
+          else if (s.kind == 1 && !s.basic && rown > 0.0) viol = s.w / rown;
+          const double vmax = wave_max(viol);
+          if (!(vmax > 1e-12)) break;
+          p = first_lane(viol == vmax);
+          p_basic = readlane_i32(s.basic, p) != 0;              // (A) basic dof  /  (B) inactive row
+          upper = false;
+          beta = 0.0;
+          if (p_basic) {
+            const double zp = readlane_f64(s.z, p), hp = readlane_f64(s.hi, p), lp = readlane_f64(s.lo, p);
+            upper = (zp - hp) > (lp - zp);
+            beta = upper ? hp : lp;
+          }
+          sgn = (p_basic && upper) ? -1.0 : 1.0;
+          const double rn = readlane_f64(rown, p);
+          thr = p_basic ? thr_dof : thr_dof * rn * rn;
+        }
+        if (++iters > max_iters) { status |= 8; break; }
+        rk = tab_get<NT>(T, p);
+        const double tau = s.sc * rk;                            // column p of the tableau
+        const double tpp = readlane_f64(tau, p);
+        // full step length t2 (GI step 2b)
+        double t2 = kInf;
+        if (p_basic) {
+          if (fabs(tpp) > thr) t2 = fabs((readlane_f64(s.z, p) - beta) / tpp);
+        } else {
+          if (-tpp > thr) t2 = fabs(readlane_f64(s.w, p) / tpp);
+        }
+        // partial step length t1: keep the multipliers of the active set dual feasible
+        const double r = sgn * tau;
+        double t = kInf;
+        if (lane != p) {
+          if (s.kind == 1 && s.basic) { if (r > 0.0) t = fmax(s.z, 0.0) / r; }
+          else if (s.kind == 0 && !s.basic) {
+            if (s.at_hi) { if (r > 0.0) t = fmax(-s.w, 0.0) / r; }
+            else { if (r < 0.0) t = fmax(s.w, 0.0) / (-r); }
+          }
+        }
+        const double t1 = wave_min(t);
+        if (!(fmin(t1, t2) < kInf)) { status |= 2; break; }     // no step possible: infeasible
+        const bool full = t2 <= t1;
+        const double alpha = sgn * (full ? t2 : t1);
+        if (s.basic) s.z -= alpha * tau; else s.w += alpha * tau;
+        if (lane == p) { if (p_basic) s.w += alpha; else s.z += alpha; }
+        if (full) {
+          if (lane == p) {
+            if (p_basic) { s.z = beta; s.basic = 0; s.at_hi = upper ? 1 : 0; }
+            else { s.w = 0.0; s.basic = 1; }
+          }
+          piv = p;
+          rev = p_basic;
+          p = -1;
+        } else {
+          piv = first_lane(t == t1);
+          rev = readlane_i32(s.basic, piv) != 0;
+          if (lane == piv) {
+            if (rev) { s.z = 0.0; s.basic = 0; }                // row leaves the active set
+            else { s.w = 0.0; s.basic = 1; }                    // dof leaves its bound
+          }
+          rk = tab_get<NT>(T, piv);
+        }
+      }
+      pivot<NT>(T, s, piv, rev, rk, lane, ntab);
+    }
+    if (A.t_qp_iters && lane == 0) A.t_qp_iters[pb] = iters;
+    if (A.v_out && is_dof) {
+      const double bad = __builtin_nan("");
+      A.v_out[(size_t)pb * nv + lane] = (status & 14) ? bad : s.z / A.dt;   // v = dq / dt (solve_ik.py:104)
+    }
+    if (A.status_out && lane == 0) A.status_out[pb] = status;
+  }
+}
+
+// q_out = q ⊕ v·dt (mj_integratePos; Configuration.integrate, mink/configuration.py:214-226).
+// One thread per (problem, joint).
+__global__ __launch_bounds__(256) void integrate_kernel(const DeviceProblem P, int B, const double* __restrict__ q,
+                                                        const double* __restrict__ v, double dt,
+                                                        double* __restrict__ q_out) {
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)B * P.njnt;
+  if (tid >= total) return;
+  const int b = (int)(tid / P.njnt), j = (int)(tid % P.njnt);
+  const int jt = P.jnt_i[j * JI_COUNT + JI_TYPE];
+  int qa = P.jnt_i[j * JI_COUNT + JI_QADR];
+  int va = P.jnt_i[j * JI_COUNT + JI_DADR];
+  const double* qi = q + (size_t)b * P.nq;
+  const double* vi = v + (size_t)b * P.nv;
+  double* qo = q_out + (size_t)b * P.nq;
+  if (jt == JNT_HINGE || jt == JNT_SLIDE) { qo[qa] = qi[qa] + dt * vi[va]; return; }
+  if (jt == JNT_FREE) {
+    for (int i = 0; i < 3; ++i) qo[qa + i] = qi[qa + i] + dt * vi[va + i];
+    qa += 3; va += 3;
+  }
+  // mju_quatIntegrate: q ← normalize(q) ⊗ axisangle(v̂, dt·|v|)
+  V3 w{vi[va], vi[va + 1], vi[va + 2]};
+  const double n = sqrt(dot(w, w));
+  V3 ax = (n < 1e-15) ? V3{1.0, 0.0, 0.0} : (1.0 / n) * w;
+  const double ang = dt * n;
+  Q4 qr = (ang == 0.0) ? Q4{1, 0, 0, 0} : axis_angle(ax, ang);
+  Q4 q0 = qnormalize(Q4{qi[qa], qi[qa + 1], qi[qa + 2], qi[qa + 3]});
+  Q4 r = qmul(q0, qr);
+  qo[qa] = r.w; qo[qa + 1] = r.x; qo[qa + 2] = r.y; qo[qa + 3] = r.z;
+}
+
+}  // namespace mkh

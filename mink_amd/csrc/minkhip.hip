@@ -1,0 +1,581 @@
+// libminkhip.so — host side of the C ABI declared in include/minkhip.h.
+//
+// mkh_model_create / mkh_problem_create flatten the mjModel fields and the Task/Limit
+// plugin objects of one mink.solve_ik call site into lane tables on the device
+// (mkh_types.h); mkh_solve launches the one-wavefront-per-problem kernel (ik_kernel.h).
+#include "../../include/minkhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "ik_kernel.h"
+
+using namespace mkh;
+
+static thread_local std::string g_err;
+static int32_t fail(int32_t code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIP_OK(expr)                                                                             \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) return fail(MKH_E_HIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                      __FILE__, __LINE__);                                       \
+  } while (0)
+
+template <class T>
+static hipError_t upload(const std::vector<T>& h, T** d) {
+  *d = nullptr;
+  const size_t n = h.empty() ? 1 : h.size();
+  hipError_t e = hipMalloc((void**)d, n * sizeof(T));
+  if (e != hipSuccess) return e;
+  if (!h.empty()) e = hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+  return e;
+}
+
+struct MkhModel {
+  int device = 0;
+  int nq = 0, nv = 0, nbody = 0, njnt = 0, ngeom = 0, nsite = 0, nrounds = 0;
+  // host copies needed when problems are created
+  std::vector<int32_t> body_parentid, body_rootid, body_jntnum, body_jntadr, body_dofnum, body_dofadr;
+  std::vector<int32_t> jnt_type, jnt_qposadr, jnt_dofadr, jnt_bodyid, jnt_limited;
+  std::vector<int32_t> dof_bodyid, dof_jntid, dof_parentid, site_bodyid, geom_bodyid, geom_type;
+  std::vector<double> body_pos, body_quat, site_pos, site_quat, geom_size, geom_pos, geom_quat, jnt_range;
+  // device tables
+  double* d_body_f = nullptr;
+  int32_t* d_body_i = nullptr;
+  double* d_jnt_f = nullptr;
+  int32_t* d_jnt_i = nullptr;
+  int32_t* d_dof_i = nullptr;
+  double* d_dof_f = nullptr;
+  int num_cus = 0;
+};
+
+struct MkhProblem {
+  MkhModel* model = nullptr;
+  DeviceProblem dev{};
+  int nb = 1;  // tableau blocks of 16
+  int max_batch = 0;
+  int lds_bytes = 0;
+  int blocks_per_cu = 1;
+  // device descriptor storage
+  FrameTaskDev* d_frame = nullptr;
+  double* d_posture_cost = nullptr;
+  double *d_cfg_lower = nullptr, *d_cfg_upper = nullptr, *d_vel = nullptr;
+  CollisionPairDev* d_pairs = nullptr;
+  // staging buffers for host-pointer calls
+  double *s_q = nullptr, *s_ft = nullptr, *s_pt = nullptr, *s_ct = nullptr, *s_v = nullptr;
+  int32_t* s_status = nullptr;
+  size_t s_pt_cap = 0, s_ct_cap = 0;
+};
+
+template <class T>
+static hipError_t ensure(T** buf, size_t n) {
+  if (*buf) return hipSuccess;
+  return hipMalloc((void**)buf, (n ? n : 1) * sizeof(T));
+}
+
+extern "C" {
+
+int32_t mkh_version(void) { return MKH_VERSION; }
+const char* mkh_last_error(void) { return g_err.c_str(); }
+
+int32_t mkh_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static uint64_t dof_chain_mask(const MkhModel* m, int body) {
+  uint64_t mask = 0;
+  while (body > 0 && m->body_dofnum[body] == 0) body = m->body_parentid[body];
+  if (body == 0) return 0;
+  int i = m->body_dofadr[body] + m->body_dofnum[body] - 1;
+  while (i >= 0) {
+    mask |= 1ull << i;
+    i = m->dof_parentid[i];
+  }
+  return mask;
+}
+
+int32_t mkh_model_create(const MkhFlatModel* h, int32_t device, MkhModel** out) {
+  if (!h || !out) return fail(MKH_E_INVALID, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MKH_E_NOGPU, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(MKH_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+  if (h->nbody > kWave) return fail(MKH_E_LIMIT, "nbody=%d exceeds the one-wavefront limit of %d bodies", h->nbody, kWave);
+  if (h->nv > kWave) return fail(MKH_E_LIMIT, "nv=%d exceeds the one-wavefront limit of %d dofs", h->nv, kWave);
+  if (h->nv < 1 || h->nbody < 2) return fail(MKH_E_INVALID, "model has no degrees of freedom");
+  HIP_OK(hipSetDevice(device));
+  MkhModel* m = new MkhModel();
+  m->device = device;
+  m->nq = h->nq; m->nv = h->nv; m->nbody = h->nbody; m->njnt = h->njnt; m->ngeom = h->ngeom; m->nsite = h->nsite;
+  auto cpi = [](const int32_t* p, int n) { return std::vector<int32_t>(p, p + n); };
+  auto cpd = [](const double* p, int n) { return std::vector<double>(p, p + n); };
+  m->body_parentid = cpi(h->body_parentid, h->nbody); m->body_rootid = cpi(h->body_rootid, h->nbody);
+  m->body_jntnum = cpi(h->body_jntnum, h->nbody); m->body_jntadr = cpi(h->body_jntadr, h->nbody);
+  m->body_dofnum = cpi(h->body_dofnum, h->nbody); m->body_dofadr = cpi(h->body_dofadr, h->nbody);
+  m->jnt_type = cpi(h->jnt_type, h->njnt); m->jnt_qposadr = cpi(h->jnt_qposadr, h->njnt);
+  m->jnt_dofadr = cpi(h->jnt_dofadr, h->njnt); m->jnt_bodyid = cpi(h->jnt_bodyid, h->njnt);
+  m->jnt_limited = cpi(h->jnt_limited, h->njnt); m->jnt_range = cpd(h->jnt_range, h->njnt * 2);
+  m->dof_bodyid = cpi(h->dof_bodyid, h->nv); m->dof_jntid = cpi(h->dof_jntid, h->nv);
+  m->dof_parentid = cpi(h->dof_parentid, h->nv);
+  m->site_bodyid = cpi(h->site_bodyid, h->nsite); m->geom_bodyid = cpi(h->geom_bodyid, h->ngeom);
+  m->geom_type = cpi(h->geom_type, h->ngeom);
+  m->body_pos = cpd(h->body_pos, h->nbody * 3); m->body_quat = cpd(h->body_quat, h->nbody * 4);
+  m->site_pos = cpd(h->site_pos, h->nsite * 3); m->site_quat = cpd(h->site_quat, h->nsite * 4);
+  m->geom_size = cpd(h->geom_size, h->ngeom * 3); m->geom_pos = cpd(h->geom_pos, h->ngeom * 3);
+  m->geom_quat = cpd(h->geom_quat, h->ngeom * 4);
+
+  const double inf = std::numeric_limits<double>::infinity();
+  // ---- body tables
+  std::vector<int> depth(h->nbody, 0);
+  int maxdepth = 0;
+  for (int b = 1; b < h->nbody; ++b) {
+    if (h->body_parentid[b] >= b) { delete m; return fail(MKH_E_INVALID, "body %d has parent id >= its own id", b); }
+    depth[b] = depth[h->body_parentid[b]] + 1;
+    if (depth[b] > maxdepth) maxdepth = depth[b];
+  }
+  int nrounds = 0;
+  while ((1 << nrounds) < maxdepth) ++nrounds;
+  if (nrounds > kMaxRounds) { delete m; return fail(MKH_E_LIMIT, "kinematic tree too deep"); }
+  m->nrounds = nrounds;
+  std::vector<double> body_f(BF_COUNT * 64, 0.0);
+  std::vector<int32_t> body_i(BI_COUNT * 64, 0);
+  std::vector<int> subtree_last(h->nbody);
+  for (int b = h->nbody - 1; b >= 0; --b) {
+    subtree_last[b] = b;
+    for (int c = b + 1; c < h->nbody; ++c)
+      if (h->body_parentid[c] == b && subtree_last[c] > subtree_last[b]) subtree_last[b] = subtree_last[c];
+  }
+  for (int b = 0; b < h->nbody; ++b) {
+    for (int k = 0; k < 3; ++k) body_f[(BF_POS + k) * 64 + b] = h->body_pos[3 * b + k];
+    for (int k = 0; k < 4; ++k) body_f[(BF_QUAT + k) * 64 + b] = h->body_quat[4 * b + k];
+    for (int k = 0; k < 3; ++k) body_f[(BF_IPOS + k) * 64 + b] = h->body_ipos[3 * b + k];
+    body_f[BF_MASS * 64 + b] = h->body_mass[b];
+    body_f[BF_SUBTREEMASS * 64 + b] = h->body_subtreemass[b];
+    body_i[BI_PARENT * 64 + b] = h->body_parentid[b];
+    body_i[BI_JNTADR * 64 + b] = h->body_jntadr[b] < 0 ? 0 : h->body_jntadr[b];
+    body_i[BI_JNTNUM * 64 + b] = h->body_jntnum[b];
+    body_i[BI_SUBTREE_LAST * 64 + b] = subtree_last[b];
+    body_i[BI_IN_ROBOT * 64 + b] = (b >= 1 && h->body_rootid[b] == 1) ? 1 : 0;  // subtree of body 1 (ComTask)
+    // pointer-jumping ancestors: anc_0 = parent, anc_{r+1} = anc_r(anc_r)
+    int a = h->body_parentid[b];
+    for (int r = 0; r < kMaxRounds; ++r) {
+      body_i[(BI_ANC0 + r) * 64 + b] = a;
+      // advance 2^r more steps
+      int steps = 1 << r, x = a;
+      for (int k = 0; k < steps && x > 0; ++k) x = h->body_parentid[x];
+      a = x;
+    }
+  }
+  // the anc recurrence above must satisfy anc_{r+1}(b) = anc_r(anc_r(b)); verify
+  for (int b = 0; b < h->nbody; ++b)
+    for (int r = 0; r + 1 < kMaxRounds; ++r) {
+      int a = body_i[(BI_ANC0 + r) * 64 + b];
+      int aa = body_i[(BI_ANC0 + r) * 64 + a];
+      if (body_i[(BI_ANC0 + r + 1) * 64 + b] != aa) { delete m; return fail(MKH_E_INVALID, "internal: ancestor table"); }
+    }
+  // ---- joint arrays
+  std::vector<double> jnt_f(h->njnt * JF_COUNT, 0.0);
+  std::vector<int32_t> jnt_i(h->njnt * JI_COUNT, 0);
+  for (int j = 0; j < h->njnt; ++j) {
+    for (int k = 0; k < 3; ++k) jnt_f[j * JF_COUNT + JF_AXIS + k] = h->jnt_axis[3 * j + k];
+    for (int k = 0; k < 3; ++k) jnt_f[j * JF_COUNT + JF_POS + k] = h->jnt_pos[3 * j + k];
+    jnt_f[j * JF_COUNT + JF_QPOS0] = h->qpos0[h->jnt_qposadr[j]];
+    jnt_i[j * JI_COUNT + JI_TYPE] = h->jnt_type[j];
+    jnt_i[j * JI_COUNT + JI_QADR] = h->jnt_qposadr[j];
+    jnt_i[j * JI_COUNT + JI_DADR] = h->jnt_dofadr[j];
+    if (h->jnt_type[j] == JNT_FREE && (h->body_jntnum[h->jnt_bodyid[j]] != 1)) {
+      delete m; return fail(MKH_E_INVALID, "free joint must be the only joint of its body");
+    }
+  }
+  // ---- dof tables
+  std::vector<int32_t> dof_i(DI_COUNT * 64, 0);
+  std::vector<double> dof_f(DF_COUNT * 64, 0.0);
+  for (int d = 0; d < 64; ++d) { dof_f[DF_RANGE_LO * 64 + d] = -inf; dof_f[DF_RANGE_HI * 64 + d] = inf; dof_i[DI_QADR * 64 + d] = -1; }
+  for (int d = 0; d < h->nv; ++d) {
+    const int j = h->dof_jntid[d];
+    const int jt = h->jnt_type[j];
+    const int k = d - h->jnt_dofadr[j];
+    int kind, kk = 0, qadr = -1;
+    if (jt == JNT_HINGE) { kind = DOF_HINGE; qadr = h->jnt_qposadr[j]; }
+    else if (jt == JNT_SLIDE) { kind = DOF_SLIDE; qadr = h->jnt_qposadr[j]; }
+    else if (jt == JNT_BALL) { kind = DOF_BALL; kk = k; qadr = h->jnt_qposadr[j]; }
+    else { if (k < 3) { kind = DOF_FREE_LIN; kk = k; } else { kind = DOF_FREE_ANG; kk = k - 3; } }
+    dof_i[DI_JNT * 64 + d] = j;
+    dof_i[DI_KIND * 64 + d] = kind;
+    dof_i[DI_K * 64 + d] = kk;
+    dof_i[DI_BODY * 64 + d] = h->dof_bodyid[d];
+    dof_i[DI_QADR * 64 + d] = qadr;
+    dof_i[DI_JIDX * 64 + d] = j - h->body_jntadr[h->jnt_bodyid[j]];
+    if ((jt == JNT_HINGE || jt == JNT_SLIDE) && h->jnt_limited[j]) {
+      dof_f[DF_RANGE_LO * 64 + d] = h->jnt_range[2 * j];
+      dof_f[DF_RANGE_HI * 64 + d] = h->jnt_range[2 * j + 1];
+    }
+  }
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = upload(body_f, &m->d_body_f);
+  if (e == hipSuccess) e = upload(body_i, &m->d_body_i);
+  if (e == hipSuccess) e = upload(jnt_f, &m->d_jnt_f);
+  if (e == hipSuccess) e = upload(jnt_i, &m->d_jnt_i);
+  if (e == hipSuccess) e = upload(dof_i, &m->d_dof_i);
+  if (e == hipSuccess) e = upload(dof_f, &m->d_dof_f);
+  hipDeviceProp_t prop;
+  if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) { mkh_model_destroy(m); return fail(MKH_E_HIP, "model upload: %s", hipGetErrorString(e)); }
+  m->num_cus = prop.multiProcessorCount;
+  *out = m;
+  return MKH_OK;
+}
+
+void mkh_model_destroy(MkhModel* m) {
+  if (!m) return;
+  hipSetDevice(m->device);
+  hipFree(m->d_body_f); hipFree(m->d_body_i); hipFree(m->d_jnt_f); hipFree(m->d_jnt_i);
+  hipFree(m->d_dof_i); hipFree(m->d_dof_f);
+  delete m;
+}
+
+static void fill_base(const MkhModel* m, DeviceProblem& P) {
+  P.nq = m->nq; P.nv = m->nv; P.nbody = m->nbody; P.njnt = m->njnt; P.nrounds = m->nrounds;
+  P.robot_root = 1;
+  P.body_f = m->d_body_f; P.body_i = m->d_body_i; P.jnt_f = m->d_jnt_f; P.jnt_i = m->d_jnt_i;
+  P.dof_i = m->d_dof_i; P.dof_f = m->d_dof_f;
+}
+
+int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_batch, MkhProblem** out) {
+  if (!m || !d || !out) return fail(MKH_E_INVALID, "null argument");
+  *out = nullptr;
+  if (max_batch < 1) return fail(MKH_E_INVALID, "max_batch must be >= 1");
+  if (d->n_frame_tasks > kMaxFrameTasks) return fail(MKH_E_LIMIT, "at most %d frame tasks", kMaxFrameTasks);
+  if (d->n_posture_tasks > kMaxPostureTasks) return fail(MKH_E_LIMIT, "at most %d posture tasks", kMaxPostureTasks);
+  if (d->n_com_tasks > kMaxComTasks) return fail(MKH_E_LIMIT, "at most %d CoM tasks", kMaxComTasks);
+  if (d->n_configuration_limits > kMaxBoxTerms || d->n_velocity_limits > kMaxBoxTerms)
+    return fail(MKH_E_LIMIT, "at most %d configuration and %d velocity limits", kMaxBoxTerms, kMaxBoxTerms);
+  HIP_OK(hipSetDevice(m->device));
+  const double inf = std::numeric_limits<double>::infinity();
+  MkhProblem* p = new MkhProblem();
+  p->model = m;
+  p->max_batch = max_batch;
+  DeviceProblem& P = p->dev;
+  fill_base(m, P);
+  P.n_frame = d->n_frame_tasks; P.n_posture = d->n_posture_tasks; P.n_com = d->n_com_tasks;
+  P.n_cfg = d->n_configuration_limits; P.n_vel = d->n_velocity_limits;
+  auto bail = [&](int32_t code) { mkh_problem_destroy(p); return code; };
+
+  // ---- frame tasks: resolve the frame to (body, local pose); rows of the tap layout
+  int row = 0;
+  std::vector<FrameTaskDev> ft(d->n_frame_tasks);
+  for (int t = 0; t < d->n_frame_tasks; ++t) {
+    const MkhFrameTaskDesc& s = d->frame_tasks[t];
+    FrameTaskDev& f = ft[t];
+    memset(&f, 0, sizeof f);
+    const double *lp = nullptr, *lq = nullptr;
+    static const double zero3[3] = {0, 0, 0}, ident4[4] = {1, 0, 0, 0};
+    if (s.frame_type == MKH_FRAME_BODY) {
+      if (s.frame_id < 0 || s.frame_id >= m->nbody) return bail(fail(MKH_E_INVALID, "frame task %d: body id %d out of range", t, s.frame_id));
+      f.body = s.frame_id; lp = zero3; lq = ident4;
+    } else if (s.frame_type == MKH_FRAME_SITE) {
+      if (s.frame_id < 0 || s.frame_id >= m->nsite) return bail(fail(MKH_E_INVALID, "frame task %d: site id %d out of range", t, s.frame_id));
+      f.body = m->site_bodyid[s.frame_id]; lp = &m->site_pos[3 * s.frame_id]; lq = &m->site_quat[4 * s.frame_id];
+    } else if (s.frame_type == MKH_FRAME_GEOM) {
+      if (s.frame_id < 0 || s.frame_id >= m->ngeom) return bail(fail(MKH_E_INVALID, "frame task %d: geom id %d out of range", t, s.frame_id));
+      f.body = m->geom_bodyid[s.frame_id]; lp = &m->geom_pos[3 * s.frame_id]; lq = &m->geom_quat[4 * s.frame_id];
+    } else {
+      return bail(fail(MKH_E_INVALID, "frame task %d: unsupported frame type %d", t, s.frame_type));
+    }
+    for (int k = 0; k < 3; ++k) f.lpos[k] = lp[k];
+    for (int k = 0; k < 4; ++k) f.lquat[k] = lq[k];
+    for (int k = 0; k < 6; ++k) {
+      if (!(s.cost[k] >= 0.0)) return bail(fail(MKH_E_INVALID, "frame task %d: cost must be >= 0", t));
+      f.cost[k] = s.cost[k];
+    }
+    f.gain = s.gain; f.lm_damping = s.lm_damping;
+    f.dof_mask = dof_chain_mask(m, f.body);
+    f.row0 = row; row += 6;
+    f.any_ori = (s.cost[3] != 0.0 || s.cost[4] != 0.0 || s.cost[5] != 0.0) ? 1 : 0;
+  }
+  std::vector<double> pcost((size_t)(d->n_posture_tasks ? d->n_posture_tasks : 1) * 64, 0.0);
+  for (int t = 0; t < d->n_posture_tasks; ++t) {
+    for (int i = 0; i < m->nv; ++i) pcost[t * 64 + i] = d->posture_tasks[t].cost[i];
+    P.posture_gain[t] = d->posture_tasks[t].gain; P.posture_lm[t] = d->posture_tasks[t].lm_damping;
+    P.posture_row0[t] = row; row += m->nv;
+  }
+  for (int t = 0; t < d->n_com_tasks; ++t) {
+    for (int k = 0; k < 3; ++k) P.com_cost[t][k] = d->com_tasks[t].cost[k];
+    P.com_gain[t] = d->com_tasks[t].gain; P.com_lm[t] = d->com_tasks[t].lm_damping;
+    P.com_row0[t] = row; row += 3;
+  }
+  P.n_rows_tap = row;
+
+  // ---- box limits: per-dof lower/upper in joint coordinates (±inf = absent)
+  std::vector<double> clo((size_t)(P.n_cfg ? P.n_cfg : 1) * 64, -inf), chi((size_t)(P.n_cfg ? P.n_cfg : 1) * 64, inf);
+  for (int t = 0; t < P.n_cfg; ++t) {
+    const MkhConfigurationLimitDesc& c = d->configuration_limits[t];
+    if (!(c.gain > 0.0 && c.gain <= 1.0)) return bail(fail(MKH_E_INVALID, "configuration limit gain must be in (0, 1]"));
+    P.cfg_gain[t] = c.gain;
+    for (int k = 0; k < c.n_indices; ++k) {
+      const int dof = c.indices[k];
+      if (dof < 0 || dof >= m->nv) return bail(fail(MKH_E_INVALID, "configuration limit: dof %d out of range", dof));
+      const int jt = m->jnt_type[m->dof_jntid[dof]];
+      if (jt != JNT_HINGE && jt != JNT_SLIDE) return bail(fail(MKH_E_INVALID, "configuration limit on ball/free dof %d is not supported", dof));
+      const int qa = m->jnt_qposadr[m->dof_jntid[dof]];
+      clo[t * 64 + dof] = c.lower[qa];
+      chi[t * 64 + dof] = c.upper[qa];
+    }
+  }
+  std::vector<double> vlim((size_t)(P.n_vel ? P.n_vel : 1) * 64, inf);
+  for (int t = 0; t < P.n_vel; ++t) {
+    const MkhVelocityLimitDesc& v = d->velocity_limits[t];
+    for (int k = 0; k < v.n_indices; ++k) {
+      const int dof = v.indices[k];
+      if (dof < 0 || dof >= m->nv) return bail(fail(MKH_E_INVALID, "velocity limit: dof %d out of range", dof));
+      vlim[t * 64 + dof] = std::fmin(vlim[t * 64 + dof], v.limit[k]);
+    }
+  }
+  // ---- collision pairs
+  std::vector<CollisionPairDev> pairs;
+  for (int t = 0; t < d->n_collision_limits; ++t) {
+    const MkhCollisionLimitDesc& c = d->collision_limits[t];
+    for (int k = 0; k < c.n_pairs; ++k) {
+      const int g1 = c.geom_id_pairs[2 * k], g2 = c.geom_id_pairs[2 * k + 1];
+      if (g1 < 0 || g2 < 0 || g1 >= m->ngeom || g2 >= m->ngeom) return bail(fail(MKH_E_INVALID, "collision pair (%d,%d): geom id out of range", g1, g2));
+      CollisionPairDev cp;
+      memset(&cp, 0, sizeof cp);
+      int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+      auto supported = [](int a, int b) {
+        if (a > b) { int x = a; a = b; b = x; }
+        return (a == GEOM_CAPSULE && b == GEOM_CAPSULE) || (a == GEOM_SPHERE && b == GEOM_SPHERE) ||
+               (a == GEOM_SPHERE && b == GEOM_CAPSULE) || (a == GEOM_PLANE && (b == GEOM_SPHERE || b == GEOM_CAPSULE));
+      };
+      if (!supported(t1, t2)) return bail(fail(MKH_E_INVALID, "collision pair (%d,%d): geom types (%d,%d) have no analytic distance routine yet", g1, g2, t1, t2));
+      cp.type1 = t1; cp.type2 = t2; cp.body1 = m->geom_bodyid[g1]; cp.body2 = m->geom_bodyid[g2];
+      for (int i = 0; i < 3; ++i) { cp.size1[i] = m->geom_size[3 * g1 + i]; cp.size2[i] = m->geom_size[3 * g2 + i];
+                                    cp.lpos1[i] = m->geom_pos[3 * g1 + i]; cp.lpos2[i] = m->geom_pos[3 * g2 + i]; }
+      for (int i = 0; i < 4; ++i) { cp.lquat1[i] = m->geom_quat[4 * g1 + i]; cp.lquat2[i] = m->geom_quat[4 * g2 + i]; }
+      cp.mask1 = dof_chain_mask(m, cp.body1); cp.mask2 = dof_chain_mask(m, cp.body2);
+      cp.gain = c.gain; cp.dmin = c.minimum_distance_from_collisions; cp.ddetect = c.collision_detection_distance;
+      cp.relax = c.bound_relaxation;
+      pairs.push_back(cp);
+    }
+  }
+  P.n_pairs = (int)pairs.size();
+  P.max_rows = P.n_pairs < (kWave - m->nv) ? P.n_pairs : (kWave - m->nv);
+  const int ntab = m->nv + P.max_rows;
+  p->nb = (ntab + 15) / 16;
+  if (p->nb < 1) p->nb = 1;
+
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = upload(ft, &p->d_frame);
+  if (e == hipSuccess) e = upload(pcost, &p->d_posture_cost);
+  if (e == hipSuccess) e = upload(clo, &p->d_cfg_lower);
+  if (e == hipSuccess) e = upload(chi, &p->d_cfg_upper);
+  if (e == hipSuccess) e = upload(vlim, &p->d_vel);
+  if (e == hipSuccess) e = upload(pairs, &p->d_pairs);
+  if (e != hipSuccess) return bail(fail(MKH_E_HIP, "problem upload: %s", hipGetErrorString(e)));
+  P.frame = p->d_frame; P.posture_cost = p->d_posture_cost; P.cfg_lower = p->d_cfg_lower; P.cfg_upper = p->d_cfg_upper;
+  P.vel_limit = p->d_vel; P.pairs = p->d_pairs;
+
+  const LdsLayout L = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows);
+  p->lds_bytes = L.total * (int)sizeof(double);
+  if (p->lds_bytes > 64 * 1024) return bail(fail(MKH_E_LIMIT, "problem needs %d bytes of LDS per wavefront (> 64 KiB)", p->lds_bytes));
+  // resident waves per CU: bounded by LDS (160 KiB/CU) and by VGPRs (launch_bounds: 2 waves/SIMD)
+  int by_lds = (160 * 1024) / (p->lds_bytes > 0 ? p->lds_bytes : 1);
+  p->blocks_per_cu = by_lds < 8 ? by_lds : 8;
+  if (p->blocks_per_cu < 1) p->blocks_per_cu = 1;
+  *out = p;
+  return MKH_OK;
+}
+
+void mkh_problem_destroy(MkhProblem* p) {
+  if (!p) return;
+  hipSetDevice(p->model->device);
+  hipFree(p->d_frame); hipFree(p->d_posture_cost); hipFree(p->d_cfg_lower); hipFree(p->d_cfg_upper);
+  hipFree(p->d_vel); hipFree(p->d_pairs);
+  hipFree(p->s_q); hipFree(p->s_ft); hipFree(p->s_pt); hipFree(p->s_ct); hipFree(p->s_v); hipFree(p->s_status);
+  delete p;
+}
+
+int32_t mkh_problem_num_task_rows(const MkhProblem* p) { return p ? p->dev.n_rows_tap : 0; }
+int32_t mkh_problem_num_collision_pairs(const MkhProblem* p) { return p ? p->dev.n_pairs : 0; }
+
+static int grid_for(const MkhProblem* p, int B) {
+  int g = p->model->num_cus * p->blocks_per_cu;
+  return B < g ? B : g;
+}
+
+int32_t mkh_problem_launch_info(const MkhProblem* p, int32_t B, int32_t* grid, int32_t* block, int32_t* lds_bytes,
+                                int32_t* tableau_rows) {
+  if (!p) return fail(MKH_E_INVALID, "null problem");
+  if (grid) *grid = grid_for(p, B);
+  if (block) *block = kWave;
+  if (lds_bytes) *lds_bytes = p->lds_bytes;
+  if (tableau_rows) *tableau_rows = p->nb * 16;
+  return MKH_OK;
+}
+
+static int32_t launch(MkhProblem* p, const SolveArgs& a, hipStream_t stream) {
+  const int grid = grid_for(p, a.B);
+  switch (p->nb) {
+    case 1: hipLaunchKernelGGL(ik_solve_kernel<1>, dim3(grid), dim3(kWave), p->lds_bytes, stream, p->dev, a); break;
+    case 2: hipLaunchKernelGGL(ik_solve_kernel<2>, dim3(grid), dim3(kWave), p->lds_bytes, stream, p->dev, a); break;
+    case 3: hipLaunchKernelGGL(ik_solve_kernel<3>, dim3(grid), dim3(kWave), p->lds_bytes, stream, p->dev, a); break;
+    default: hipLaunchKernelGGL(ik_solve_kernel<4>, dim3(grid), dim3(kWave), p->lds_bytes, stream, p->dev, a); break;
+  }
+  HIP_OK(hipGetLastError());
+  return MKH_OK;
+}
+
+struct TapBuf {
+  void* host; void* dev; size_t bytes;
+};
+
+int32_t mkh_eval(MkhProblem* p, int32_t B, const double* q, const double* frame_targets, const double* posture_target,
+                 const double* com_target, double dt, double damping, double* v_out, int32_t* status_out,
+                 const MkhTaps* taps, int32_t flags, void* hip_stream) {
+  if (!p) return fail(MKH_E_INVALID, "null problem");
+  if (B < 1) return fail(MKH_E_INVALID, "B must be >= 1");
+  const DeviceProblem& P = p->dev;
+  if (!q) return fail(MKH_E_INVALID, "q is null");
+  if (P.n_frame > 0 && !frame_targets) return fail(MKH_E_INVALID, "frame_targets is null (TargetNotSet)");
+  if (P.n_posture > 0 && !posture_target) return fail(MKH_E_INVALID, "posture_target is null (TargetNotSet)");
+  if (P.n_com > 0 && !com_target) return fail(MKH_E_INVALID, "com_target is null (TargetNotSet)");
+  if (!(dt > 0.0)) return fail(MKH_E_INVALID, "dt must be > 0");
+  HIP_OK(hipSetDevice(p->model->device));
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const bool devp = (flags & MKH_FLAG_DEVICE_PTRS) != 0;
+  const bool pbat = (flags & MKH_FLAG_POSTURE_BATCHED) != 0, cbat = (flags & MKH_FLAG_COM_BATCHED) != 0;
+  SolveArgs a;
+  memset(&a, 0, sizeof a);
+  a.B = B; a.posture_batched = pbat; a.com_batched = cbat; a.do_qp = (v_out != nullptr);
+  a.dt = dt; a.damping = damping;
+  const size_t nq = P.nq, nv = P.nv;
+  const size_t n_pt = (size_t)P.n_posture * nq * (pbat ? B : 1), n_ct = (size_t)P.n_com * 3 * (cbat ? B : 1);
+  std::vector<TapBuf> tb;
+  if (devp) {
+    a.q = q; a.frame_targets = frame_targets; a.posture_target = posture_target; a.com_target = com_target;
+    a.v_out = v_out; a.status_out = status_out;
+    if (taps) {
+      a.t_xpos = taps->xpos; a.t_xquat = taps->xquat; a.t_frame_pose = taps->frame_pose;
+      a.t_subtree_com = taps->subtree_com; a.t_task_e = taps->task_e; a.t_task_J = taps->task_J; a.t_H = taps->H;
+      a.t_c = taps->c; a.t_box_lo = taps->box_lo; a.t_box_hi = taps->box_hi; a.t_coll_G = taps->coll_G;
+      a.t_coll_h = taps->coll_h; a.t_qp_iters = taps->qp_iters;
+      if (a.t_coll_G) HIP_OK(hipMemsetAsync(a.t_coll_G, 0, (size_t)B * P.n_pairs * nv * sizeof(double), stream));
+    }
+    return launch(p, a, stream);
+  }
+  // ---- host pointers: stage through library-owned device buffers
+  if (B > p->max_batch) return fail(MKH_E_INVALID, "B=%d exceeds max_batch=%d of this problem", B, p->max_batch);
+  const size_t mb = p->max_batch;
+  HIP_OK(ensure(&p->s_q, mb * nq));
+  HIP_OK(ensure(&p->s_ft, mb * P.n_frame * 7));
+  HIP_OK(ensure(&p->s_v, mb * nv));
+  HIP_OK(ensure(&p->s_status, mb));
+  if (n_pt > p->s_pt_cap) { hipFree(p->s_pt); p->s_pt = nullptr; HIP_OK(hipMalloc((void**)&p->s_pt, n_pt * sizeof(double))); p->s_pt_cap = n_pt; }
+  if (n_ct > p->s_ct_cap) { hipFree(p->s_ct); p->s_ct = nullptr; HIP_OK(hipMalloc((void**)&p->s_ct, n_ct * sizeof(double))); p->s_ct_cap = n_ct; }
+  HIP_OK(hipMemcpyAsync(p->s_q, q, (size_t)B * nq * sizeof(double), hipMemcpyHostToDevice, stream));
+  if (P.n_frame) HIP_OK(hipMemcpyAsync(p->s_ft, frame_targets, (size_t)B * P.n_frame * 7 * sizeof(double), hipMemcpyHostToDevice, stream));
+  if (n_pt) HIP_OK(hipMemcpyAsync(p->s_pt, posture_target, n_pt * sizeof(double), hipMemcpyHostToDevice, stream));
+  if (n_ct) HIP_OK(hipMemcpyAsync(p->s_ct, com_target, n_ct * sizeof(double), hipMemcpyHostToDevice, stream));
+  a.q = p->s_q; a.frame_targets = p->s_ft; a.posture_target = p->s_pt; a.com_target = p->s_ct;
+  a.v_out = v_out ? p->s_v : nullptr;
+  a.status_out = p->s_status;
+  int32_t rc = MKH_OK;
+  auto tap = [&](void* host, size_t bytes, bool zero) -> void* {
+    if (!host || rc != MKH_OK) return nullptr;
+    void* dptr = nullptr;
+    if (hipMalloc(&dptr, bytes ? bytes : 1) != hipSuccess) { rc = fail(MKH_E_HIP, "tap buffer allocation failed"); return nullptr; }
+    if (zero) hipMemsetAsync(dptr, 0, bytes, stream);
+    tb.push_back({host, dptr, bytes});
+    return dptr;
+  };
+  if (taps) {
+    const size_t Bz = B;
+    a.t_xpos = (double*)tap(taps->xpos, Bz * P.nbody * 3 * 8, false);
+    a.t_xquat = (double*)tap(taps->xquat, Bz * P.nbody * 4 * 8, false);
+    a.t_frame_pose = (double*)tap(taps->frame_pose, Bz * P.n_frame * 7 * 8, false);
+    a.t_subtree_com = (double*)tap(taps->subtree_com, Bz * 3 * 8, true);
+    a.t_task_e = (double*)tap(taps->task_e, Bz * P.n_rows_tap * 8, true);
+    a.t_task_J = (double*)tap(taps->task_J, Bz * P.n_rows_tap * nv * 8, true);
+    a.t_H = (double*)tap(taps->H, Bz * nv * nv * 8, false);
+    a.t_c = (double*)tap(taps->c, Bz * nv * 8, false);
+    a.t_box_lo = (double*)tap(taps->box_lo, Bz * nv * 8, false);
+    a.t_box_hi = (double*)tap(taps->box_hi, Bz * nv * 8, false);
+    a.t_coll_G = (double*)tap(taps->coll_G, Bz * P.n_pairs * nv * 8, true);
+    a.t_coll_h = (double*)tap(taps->coll_h, Bz * P.n_pairs * 8, false);
+    a.t_qp_iters = (int32_t*)tap(taps->qp_iters, Bz * 4, true);
+  }
+  if (rc == MKH_OK) rc = launch(p, a, stream);
+  if (rc == MKH_OK) {
+    hipError_t e = hipSuccess;
+    if (v_out) e = hipMemcpyAsync(v_out, p->s_v, (size_t)B * nv * sizeof(double), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && status_out && v_out)
+      e = hipMemcpyAsync(status_out, p->s_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+    for (auto& t : tb)
+      if (e == hipSuccess) e = hipMemcpyAsync(t.host, t.dev, t.bytes, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) rc = fail(MKH_E_HIP, "solve: %s", hipGetErrorString(e));
+  }
+  for (auto& t : tb) hipFree(t.dev);
+  return rc;
+}
+
+int32_t mkh_solve(MkhProblem* p, int32_t B, const double* q, const double* frame_targets, const double* posture_target,
+                  const double* com_target, double dt, double damping, double* v_out, int32_t* status_out,
+                  int32_t flags, void* hip_stream) {
+  if (!v_out) return fail(MKH_E_INVALID, "v_out is null");
+  return mkh_eval(p, B, q, frame_targets, posture_target, com_target, dt, damping, v_out, status_out, nullptr, flags,
+                  hip_stream);
+}
+
+int32_t mkh_integrate(MkhModel* m, int32_t B, const double* q, const double* v, double dt, double* q_out,
+                      int32_t flags, void* hip_stream) {
+  if (!m || !q || !v || !q_out) return fail(MKH_E_INVALID, "null argument");
+  if (B < 1) return fail(MKH_E_INVALID, "B must be >= 1");
+  HIP_OK(hipSetDevice(m->device));
+  hipStream_t stream = (hipStream_t)hip_stream;
+  DeviceProblem P;
+  memset(&P, 0, sizeof P);
+  fill_base(m, P);
+  const long long total = (long long)B * m->njnt;
+  const int block = 256;
+  const int grid = (int)((total + block - 1) / block);
+  if (flags & MKH_FLAG_DEVICE_PTRS) {
+    hipLaunchKernelGGL(integrate_kernel, dim3(grid), dim3(block), 0, stream, P, B, q, v, dt, q_out);
+    HIP_OK(hipGetLastError());
+    return MKH_OK;
+  }
+  double *dq = nullptr, *dv = nullptr, *dout = nullptr;
+  const size_t bq = (size_t)B * m->nq * 8, bv = (size_t)B * m->nv * 8;
+  HIP_OK(hipMalloc((void**)&dq, bq));
+  hipError_t e = hipMalloc((void**)&dv, bv);
+  if (e == hipSuccess) e = hipMalloc((void**)&dout, bq);
+  if (e == hipSuccess) e = hipMemcpyAsync(dq, q, bq, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(dv, v, bv, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(integrate_kernel, dim3(grid), dim3(block), 0, stream, P, B, dq, dv, dt, dout);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(q_out, dout, bq, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  hipFree(dq); hipFree(dv); hipFree(dout);
+  if (e != hipSuccess) return fail(MKH_E_HIP, "integrate: %s", hipGetErrorString(e));
+  return MKH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// Device-side problem descriptor: the flattened model + task/limit snapshot laid
+// out as lane tables (structure-of-arrays with stride 64 so that lane l reads
+// table[field*64 + l] coalesced).  Built once on the host in minkhip.hip.
+#pragma once
+#include <stdint.h>
+
+namespace mkh {
+
+constexpr int kWave = 64;
+constexpr int kMaxRounds = 6;      // pointer-jumping rounds: tree depth <= 64
+constexpr int kMaxFrameTasks = 16;
+constexpr int kMaxPostureTasks = 4;
+constexpr int kMaxComTasks = 2;
+constexpr int kMaxBoxTerms = 4;    // ConfigurationLimit / VelocityLimit instances each
+
+// dof kinds
+enum { DOF_FREE_LIN = 0, DOF_BALL = 1, DOF_SLIDE = 2, DOF_HINGE = 3, DOF_FREE_ANG = 4 };
+// joint types (MuJoCo mjtJoint)
+enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
+
+// body lane table fields (double)
+enum { BF_POS = 0, BF_QUAT = 3, BF_IPOS = 7, BF_MASS = 10, BF_SUBTREEMASS = 11, BF_COUNT = 12 };
+// body lane table fields (int)
+enum { BI_PARENT = 0, BI_JNTADR = 1, BI_JNTNUM = 2, BI_SUBTREE_LAST = 3, BI_IN_ROBOT = 4, BI_ANC0 = 5,
+       BI_COUNT = BI_ANC0 + kMaxRounds };
+// joint arrays (indexed by joint id, double)
+enum { JF_AXIS = 0, JF_POS = 3, JF_QPOS0 = 6, JF_COUNT = 7 };
+enum { JI_TYPE = 0, JI_QADR = 1, JI_DADR = 2, JI_COUNT = 3 };
+// dof lane table (int)
+enum { DI_JNT = 0, DI_KIND = 1, DI_K = 2, DI_BODY = 3, DI_QADR = 4, DI_JIDX = 5, DI_COUNT = 6 };
+// dof lane table (double)
+enum { DF_RANGE_LO = 0, DF_RANGE_HI = 1, DF_COUNT = 2 };
+
+struct FrameTaskDev {
+  int32_t body;          // body the frame is attached to
+  int32_t pad;
+  double lpos[3];        // frame pose in the body frame
+  double lquat[4];
+  double cost[6];
+  double gain, lm_damping;
+  uint64_t dof_mask;     // dofs on the chain world -> body (mj_jac's ancestor walk)
+  int32_t row0;          // first row in the (e, J) tap layout
+  int32_t any_ori;       // any orientation cost > 0
+};
+
+struct CollisionPairDev {
+  int32_t type1, type2, body1, body2;
+  double size1[3], size2[3];
+  double lpos1[3], lpos2[3];
+  double lquat1[4], lquat2[4];
+  uint64_t mask1, mask2;
+  double gain, dmin, ddetect, relax;
+};
+
+struct DeviceProblem {
+  // sizes
+  int32_t nq, nv, nbody, njnt, nrounds;
+  int32_t n_frame, n_posture, n_com, n_cfg, n_vel, n_pairs, n_rows_tap;
+  int32_t max_rows;      // tableau rows reserved for half-spaces (ntab = nv + max_rows)
+  int32_t robot_root;    // body 1 (ComTask subtree root)
+  // model lane tables
+  const double* body_f;  // [BF_COUNT][64]
+  const int32_t* body_i; // [BI_COUNT][64]
+  const double* jnt_f;   // [njnt][JF_COUNT]
+  const int32_t* jnt_i;  // [njnt][JI_COUNT]
+  const int32_t* dof_i;  // [DI_COUNT][64]
+  const double* dof_f;   // [DF_COUNT][64]
+  // tasks
+  const FrameTaskDev* frame;       // [n_frame]
+  const double* posture_cost;      // [n_posture][64]
+  double posture_gain[kMaxPostureTasks], posture_lm[kMaxPostureTasks];
+  int32_t posture_row0[kMaxPostureTasks];
+  double com_cost[kMaxComTasks][3], com_gain[kMaxComTasks], com_lm[kMaxComTasks];
+  int32_t com_row0[kMaxComTasks];
+  // limits
+  const double* cfg_lower;         // [n_cfg][64] per dof (value at the dof's qpos address), ±inf when absent
+  const double* cfg_upper;         // [n_cfg][64]
+  double cfg_gain[kMaxBoxTerms];
+  const double* vel_limit;         // [n_vel][64], +inf when absent
+  const CollisionPairDev* pairs;   // [n_pairs]
+};
+
+struct SolveArgs {
+  int32_t B;
+  int32_t posture_batched, com_batched, do_qp;
+  const double* q;                 // (B, nq)
+  const double* frame_targets;     // (B, n_frame, 7)
+  const double* posture_target;    // (n_posture, nq) or (B, n_posture, nq)
+  const double* com_target;        // (n_com, 3) or (B, n_com, 3)
+  double dt, damping;
+  double* v_out;                   // (B, nv)
+  int32_t* status_out;             // (B,)
+  // taps (nullable)
+  double *t_xpos, *t_xquat, *t_frame_pose, *t_subtree_com, *t_task_e, *t_task_J, *t_H, *t_c, *t_box_lo,
+      *t_box_hi, *t_coll_G, *t_coll_h;
+  int32_t* t_qp_iters;
+};
+
+}  // namespace mkh

@@ -1,0 +1,62 @@
+// Cross-lane primitives for one-wavefront-per-problem kernels on gfx950 (wave64).
+//
+// Everything here stays in the VALU/SGPR path: v_readlane for broadcasts (an SGPR
+// pair feeds v_fma_f64 directly), DPP row permutes for reductions.  `__shfl` is
+// deliberately avoided: with a wave-uniform source lane hipcc still lowers it to
+// ds_bpermute_b32 (LDS pipe, ~50+ cycles) instead of v_readlane_b32.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mkh {
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// Broadcast lane `src` (wave-uniform) of x to all lanes through SGPRs.
+__device__ __forceinline__ double readlane_f64(double x, int src) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int readlane_i32(int x, int src) { return __builtin_amdgcn_readlane(x, src); }
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
+// DPP controls (gfx9): quad_perm[1,0,3,2]=0xB1, quad_perm[2,3,0,1]=0x4E,
+// row_half_mirror=0x141 (i -> 7-i in each 8), row_mirror=0x140 (i -> 15-i in each 16).
+// After the four steps every 16-lane row holds its own reduction; rows are then
+// combined through v_readlane, which also makes the result wave-uniform.
+#define MKH_WAVE_REDUCE(NAME, OP)                                     \
+  __device__ __forceinline__ double NAME(double x) {                  \
+    x = OP(x, dpp_f64<0xB1>(x));                                      \
+    x = OP(x, dpp_f64<0x4E>(x));                                      \
+    x = OP(x, dpp_f64<0x141>(x));                                     \
+    x = OP(x, dpp_f64<0x140>(x));                                     \
+    double a = readlane_f64(x, 0), b = readlane_f64(x, 16);           \
+    double c = readlane_f64(x, 32), d = readlane_f64(x, 48);          \
+    return OP(OP(a, b), OP(c, d));                                    \
+  }
+__device__ __forceinline__ double op_max(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ double op_min(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ double op_add(double a, double b) { return a + b; }
+MKH_WAVE_REDUCE(wave_max, op_max)
+MKH_WAVE_REDUCE(wave_min, op_min)
+MKH_WAVE_REDUCE(wave_sum, op_add)
+#undef MKH_WAVE_REDUCE
+
+// Index of the first lane where pred holds (wave-uniform), or -1.
+__device__ __forceinline__ int first_lane(bool pred) {
+  unsigned long long m = __ballot(pred);
+  return m ? (int)__builtin_ctzll(m) : -1;
+}
+
+// Make LDS writes of this wave visible to its other lanes.  The block is exactly
+// one wavefront (launch_bounds 64), DS ops of a wave execute in order, so this is
+// a compiler-level fence plus an lgkmcnt wait; the s_barrier is elided by LLVM.
+__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+
+}  // namespace mkh
