@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""Headline benchmark: batched differential-IK solves/sec on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric, configs[2]): Unitree G1 (nq=44, nv=43), 4 FrameTasks
+(feet + palms) + PostureTask + ConfigurationLimit + VelocityLimit box limits, batch
+65 536 per GPU, float64.  A "step" is one batched solve_ik over the resident batch
+(inputs already in HBM).  For N > 1 the driver launches one rank per GPU via
+torch.distributed.run; the batch shards by rank (weak scaling, configs[4] = 8 x 65 536)
+and each step ends with an RCCL gather of v to rank 0.
+
+Prints ONE JSON line (rank 0) with the whole-job solves/sec, the HBM roofline of the
+kernel (algorithmic bytes / launch duration from HIP events) and a CPU baseline.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+BYTES_PER_SOLVE_G1 = 44 * 8 + 4 * 7 * 8 + 43 * 8 + 4   # q + 4 frame targets + v + status = 924 B
+HBM_PEAK_GBS = 8000.0                                   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(model, q, targets, posture_target, budget_s=15.0):
+    """Restated reference (oracle/: numpy port of mink + MuJoCo arithmetic + GI QP) timed on
+    one host core over a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from oracle import ik
+    import oracle_configs as oc
+
+    n_done = 0
+    t0 = time.perf_counter()
+    while n_done < len(q):
+        m, tasks, limits, dt, damping = oc.g1_c3(targets[n_done], posture_target)
+        ik.solve_ik(model, q[n_done], tasks, dt, damping, limits)
+        n_done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    return {"value": n_done / el, "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": f"{n_done} G1 config-3 problems from the benchmark batch, oracle/ik.py (numpy), 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="problems per GPU")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of v (N>1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    B = args.batch
+    model = workloads.load_robot("g1")
+    nm = nat.NativeModel(model, device=local_rank)
+    prob, dt, damping = workloads.g1_config(model, nm, B)
+    rng = np.random.default_rng(1000 + rank)
+    stand = model.key_qpos[model.name2id("key", "stand")]
+    q_h, tg_h = workloads.make_batch(model, nm, prob, rng, B, base_q=stand)
+    q = torch.from_numpy(q_h).to(dev)
+    tg = torch.from_numpy(tg_h).to(dev)
+    pt = torch.from_numpy(stand[None, :].copy()).to(dev)
+    v = torch.empty((B, model.nv), dtype=torch.float64, device=dev)
+    st = torch.empty((B,), dtype=torch.int32, device=dev)
+    gather_list = None
+    do_gather = world > 1 and not args.no_gather
+    if do_gather and rank == 0:
+        gather_list = [torch.empty_like(v) for _ in range(world)]
+
+    def step():
+        prob.solve(q, tg, pt, None, dt, damping, out=v, status_out=st)
+        if do_gather:
+            dist.gather(v, gather_list, dst=0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps      # HIP events on the launch stream
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    status = st.cpu().numpy()
+    n_bad = int(((status & ~1) != 0).sum())
+    if rank == 0:
+        total = world * B * args.steps
+        value = total / elapsed
+        ach = BYTES_PER_SOLVE_G1 * B / (kern_ms * 1e-3) / 1e9
+        info = prob.launch_info(B)
+        out = {
+            "metric": "IK solves/sec (whole node), Unitree G1 4 FrameTasks + box limits, batch 65536",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Unitree G1 (nq=44,nv=43): 4 FrameTasks(feet+palms)+PostureTask+"
+                                   "ConfigurationLimit+VelocityLimit, dt=5e-3, damping=1e-1 (BASELINE configs[2])",
+                       "batch_per_gpu": B, "global_batch": world * B,
+                       "parallelism": f"batch-sharded x{world}" + (", RCCL gather of v" if do_gather else ""),
+                       "launch": info, "failed_instances": n_bad},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ik_solve_kernel<3>", "kernel_ms": kern_ms,
+                         "algorithmic_bytes_per_solve": BYTES_PER_SOLVE_G1,
+                         "note": "fp64 VALU/latency-bound by design (≈0.15 Mflop per solve, nv=43); "
+                                 "HBM fraction reported as the contract requires"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, q_h, tg_h, stand)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds/loads and exports every
+symbol include/minkhip.h declares; argument validation fails loudly without a GPU."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from mink_amd.csrc import build
+    build.build(verbose=False)
+    from mink_amd import _native
+    return _native.lib()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(REPO, "include", "minkhip.h")).read()
+    declared = set(re.findall(r"\b(mkh_[a-z_]+)\s*\(", hdr))
+    assert len(declared) >= 12
+    from mink_amd import _native
+    assert declared == set(_native.EXPORTED_SYMBOLS)
+    for s in declared:
+        assert getattr(lib, s) is not None
+
+
+def test_version_and_struct_layout(lib):
+    from mink_amd import _native as nat
+    assert lib.mkh_version() == 100
+    # ctypes mirrors must match the C layout the library was compiled with
+    assert ctypes.sizeof(nat.MkhFrameTaskDesc) == 8 + 6 * 8 + 16
+    assert ctypes.sizeof(nat.MkhComTaskDesc) == 3 * 8 + 16
+    assert ctypes.sizeof(nat.MkhTaps) == 13 * ctypes.sizeof(ctypes.c_void_p)
+
+
+def test_no_gpu_fails_loudly(lib):
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+    if lib.mkh_device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(nat.MinkHipError, match="no HIP device"):
+        nat.NativeModel(workloads.load_robot("ur5e"))
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle (or any CPU fallback)."""
+    for root, _, files in os.walk(os.path.join(REPO, "mink_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f

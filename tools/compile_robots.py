@@ -1,0 +1,27 @@
+"""Compile the benchmark robots' MJCF (from the reference's examples/, the only source of
+robot models in the build image) into FlatModel JSON shipped with the package.
+
+    python tools/compile_robots.py      # needs /root/reference
+
+Generated data, not reference source: plain arrays of the mjModel fields listed in
+mink_amd/flatmodel.py."""
+
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from mink_amd.mjcf import load_mjcf  # noqa: E402
+
+EX = "/root/reference/examples/"
+ROBOTS = {
+    "ur5e": EX + "universal_robots_ur5e/scene.xml",
+    "g1": EX + "unitree_g1/scene.xml",
+    "shadow_left": EX + "shadow_hand/scene_left.xml",
+}
+out = os.path.join(REPO, "mink_amd", "robots")
+os.makedirs(out, exist_ok=True)
+for name, path in ROBOTS.items():
+    m = load_mjcf(path)
+    m.save(os.path.join(out, f"{name}.json"))
+    print(name, "nq", m.nq, "nv", m.nv, "nbody", m.nbody)
