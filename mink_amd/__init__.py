@@ -1,0 +1,26 @@
+"""mink_amd — MI355X-native batched differential IK behind mink's `solve_ik` / Task / Limit API.
+
+The public names mirror kevinzakka/mink (mink/__init__.py:47-86) for the accelerated path.
+"""
+
+from .configuration import Configuration
+from .constants import SUPPORTED_FRAMES
+from .exceptions import (InvalidDamping, InvalidFrame, InvalidGain, InvalidKeyframe, InvalidMocapBody,
+                         InvalidTarget, LimitDefinitionError, MinkError, NotWithinConfigurationLimits,
+                         SolverError, TargetNotSet, TaskDefinitionError, UnsupportedFrame)
+from .flatmodel import FlatModel
+from .lie import SE3, SO3
+from .limits import CollisionAvoidanceLimit, ConfigurationLimit, Constraint, Limit, VelocityLimit
+from .mjcf import load_mjcf, loads_mjcf
+from .solve_ik import Problem, build_ik, solve_ik
+from .tasks import ComTask, DampingTask, FrameTask, Objective, PostureTask, RelativeFrameTask, Task
+from .workloads import load_robot
+
+__all__ = (
+    "ComTask", "Configuration", "build_ik", "solve_ik", "DampingTask", "FrameTask", "RelativeFrameTask",
+    "PostureTask", "Task", "Objective", "ConfigurationLimit", "VelocityLimit", "CollisionAvoidanceLimit",
+    "Constraint", "Limit", "SO3", "SE3", "MinkError", "UnsupportedFrame", "InvalidFrame", "InvalidKeyframe",
+    "NotWithinConfigurationLimits", "TargetNotSet", "InvalidMocapBody", "SUPPORTED_FRAMES", "FlatModel",
+    "load_mjcf", "loads_mjcf", "load_robot", "Problem", "SolverError", "TaskDefinitionError", "InvalidTarget",
+    "InvalidGain", "InvalidDamping", "LimitDefinitionError",
+)

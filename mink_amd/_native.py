@@ -106,6 +106,13 @@ def lib() -> C.CDLL:
         raise MinkHipError(
             f"{_LIB_PATH} not found: build it with `python -m mink_amd.csrc.build` "
             "(there is no CPU fallback for the solve path)")
+    try:
+        # PyTorch-ROCm ships its own libamdhip64; load it first so that the process has ONE HIP
+        # runtime (loading /opt/rocm's copy first makes a later torch.cuda init fail with
+        # "No HIP GPUs are available").  torch is only plumbing here: memory, streams, RCCL.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_LIB_PATH)
     L.mkh_version.restype = C.c_int32
     L.mkh_last_error.restype = C.c_char_p

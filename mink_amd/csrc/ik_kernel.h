@@ -631,7 +631,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
     }
     wave_sync();
 
-    if (!A.do_qp) continue;
+    if (!A.do_qp && !A.t_H) continue;
 
     // ------------------------------------------------- build the tableau column
     // lane j holds column j of K = [[H, Aᵀ],[A, 0]].  Built only now so that the 2·NT tableau
@@ -675,6 +675,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
       for (int i = 0; i < NT; ++i)
         if (i < nv) A.t_H[((size_t)pb * nv + i) * nv + lane] = T[i];
     }
+    if (!A.do_qp) continue;
     if (nrows > 0) {
       // rows nv+s of the dof columns, and column nv+s (owned by lane nv+s) = A[s][:]
       for (int s = 0; s < nrows; ++s) tab_set<NT>(T, nv + s, is_dof ? sA[s * 64 + lane] : 0.0);

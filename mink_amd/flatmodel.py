@@ -64,7 +64,7 @@ class _Named(SimpleNamespace):
     """Tiny stand-in for mujoco's named accessors (``model.joint(name).id``)."""
 
 
-@dataclass
+@dataclass(eq=False)   # identity hash: models are cache keys (device handles, compiled problems)
 class FlatModel:
     nq: int = 0
     nv: int = 0

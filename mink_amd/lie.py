@@ -1,0 +1,267 @@
+"""SO3 / SE3 value classes of the mink API (mink/lie/so3.py, se3.py, base.py), batched.
+
+Host-side utilities for *constructing targets* (`FrameTask.set_target(SE3)`); the per-solve Lie
+algebra of the hot path (log, jlog, adjoint action on Jacobians) runs on the device
+(csrc/lie_dev.h).  Parameters may carry any leading batch shape: SO3.wxyz (..., 4),
+SE3.wxyz_xyz (..., 7).  Tangents are (v, ω) for SE3 as in the reference (se3.py:20-21).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+_EPS = 1e-10  # get_epsilon(float64), mink/lie/utils.py:4-8
+
+
+def _qmul(a, b):
+    aw, ax, ay, az = np.moveaxis(a, -1, 0)
+    bw, bx, by, bz = np.moveaxis(b, -1, 0)
+    return np.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], axis=-1)
+
+
+def skew(x):
+    x = np.asarray(x, dtype=np.float64)
+    z = np.zeros_like(x[..., 0])
+    return np.stack([np.stack([z, -x[..., 2], x[..., 1]], -1), np.stack([x[..., 2], z, -x[..., 0]], -1),
+                     np.stack([-x[..., 1], x[..., 0], z], -1)], -2)
+
+
+@dataclass(frozen=True)
+class SO3:
+    wxyz: np.ndarray
+
+    def __post_init__(self):
+        w = np.asarray(self.wxyz, dtype=np.float64)
+        if w.shape[-1] != 4:
+            raise ValueError(f"Expeced wxyz to be a length 4 vector but got {w.shape[-1]}.")
+        object.__setattr__(self, "wxyz", w)
+
+    def __repr__(self):
+        return f"SO3(wxyz={np.round(self.wxyz, 5)})"
+
+    def parameters(self):
+        return self.wxyz
+
+    def copy(self):
+        return SO3(self.wxyz.copy())
+
+    @classmethod
+    def identity(cls):
+        return SO3(np.array([1.0, 0.0, 0.0, 0.0]))
+
+    @classmethod
+    def from_matrix(cls, R):
+        R = np.asarray(R, dtype=np.float64)
+        m00, m11, m22 = R[..., 0, 0], R[..., 1, 1], R[..., 2, 2]
+        q = np.empty(R.shape[:-2] + (4,))
+        tr = m00 + m11 + m22
+        c0 = tr > 0
+        c1 = ~c0 & (m00 > m11) & (m00 > m22)
+        c2 = ~c0 & ~c1 & (m11 > m22)
+        c3 = ~c0 & ~c1 & ~c2
+        for cond, vals in (
+            (c0, (1 + tr, R[..., 2, 1] - R[..., 1, 2], R[..., 0, 2] - R[..., 2, 0], R[..., 1, 0] - R[..., 0, 1])),
+            (c1, (R[..., 2, 1] - R[..., 1, 2], 1 + m00 - m11 - m22, R[..., 0, 1] + R[..., 1, 0], R[..., 0, 2] + R[..., 2, 0])),
+            (c2, (R[..., 0, 2] - R[..., 2, 0], R[..., 0, 1] + R[..., 1, 0], 1 - m00 + m11 - m22, R[..., 1, 2] + R[..., 2, 1])),
+            (c3, (R[..., 1, 0] - R[..., 0, 1], R[..., 0, 2] + R[..., 2, 0], R[..., 1, 2] + R[..., 2, 1], 1 - m00 - m11 + m22)),
+        ):
+            v = np.stack(np.broadcast_arrays(*vals), -1)
+            q = np.where(cond[..., None], v, q)
+        return SO3(q / np.linalg.norm(q, axis=-1, keepdims=True))
+
+    @classmethod
+    def from_rpy_radians(cls, roll, pitch, yaw):
+        x = cls.exp(np.array([roll, 0.0, 0.0])); y = cls.exp(np.array([0.0, pitch, 0.0]))
+        z = cls.exp(np.array([0.0, 0.0, yaw]))
+        return z @ y @ x
+
+    @classmethod
+    def from_x_radians(cls, t): return cls.exp(np.array([t, 0.0, 0.0]))
+    @classmethod
+    def from_y_radians(cls, t): return cls.exp(np.array([0.0, t, 0.0]))
+    @classmethod
+    def from_z_radians(cls, t): return cls.exp(np.array([0.0, 0.0, t]))
+
+    @classmethod
+    def sample_uniform(cls, rng=None):
+        u1, u2, u3 = (np.random if rng is None else rng).uniform(0, [1.0, 2 * np.pi, 2 * np.pi])
+        a, b = np.sqrt(1 - u1), np.sqrt(u1)
+        return SO3(np.array([a * np.sin(u2), a * np.cos(u2), b * np.sin(u3), b * np.cos(u3)]))
+
+    def as_matrix(self):
+        w, x, y, z = np.moveaxis(self.wxyz, -1, 0)
+        return np.stack([
+            np.stack([w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
+            np.stack([2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)], -1),
+            np.stack([2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z], -1)], -2)
+
+    def inverse(self):
+        return SO3(self.wxyz * np.array([1.0, -1.0, -1.0, -1.0]))
+
+    def normalize(self):
+        return SO3(self.wxyz / np.linalg.norm(self.wxyz, axis=-1, keepdims=True))
+
+    def apply(self, target):
+        target = np.asarray(target, dtype=np.float64)
+        p = np.concatenate([np.zeros(target.shape[:-1] + (1,)), target], -1)
+        return _qmul(_qmul(self.wxyz, p), self.inverse().wxyz)[..., 1:]
+
+    def multiply(self, other):
+        return SO3(_qmul(self.wxyz, other.wxyz))
+
+    def __matmul__(self, other):
+        if isinstance(other, np.ndarray):
+            return self.apply(other)
+        return self.multiply(other)
+
+    @classmethod
+    def exp(cls, tangent):
+        t = np.asarray(tangent, dtype=np.float64)
+        th2 = (t * t).sum(-1, keepdims=True)
+        small = th2 < _EPS
+        th = np.sqrt(np.where(small, 1.0, th2))
+        real = np.where(small, 1 - th2 / 8 + th2 * th2 / 384, np.cos(0.5 * th))
+        imag = np.where(small, 0.5 - th2 / 48 + th2 * th2 / 3840, np.sin(0.5 * th) / th)
+        return SO3(np.concatenate([real, imag * t], -1))
+
+    def log(self):
+        w = self.wxyz[..., :1]
+        v = self.wxyz[..., 1:]
+        n2 = (v * v).sum(-1, keepdims=True)
+        small = n2 < _EPS
+        n = np.sqrt(np.where(small, 1.0, n2))
+        ws = np.where(small, w, 1.0)
+        at = np.arctan2(np.where(w < 0, -n, n), np.abs(w))
+        f_t = 2.0 / ws - 2.0 / 3.0 * n2 / ws ** 3
+        f_pi = np.where(w > 0, 1.0, -1.0) * np.pi / n
+        f = np.where(small, f_t, np.where(np.abs(w) < _EPS, f_pi, 2.0 * at / n))
+        return f * v
+
+    def adjoint(self):
+        return self.as_matrix()
+
+    def rminus(self, other): return (other.inverse() @ self).log()
+    def minus(self, other): return self.rminus(other)
+    def rplus(self, t): return self @ SO3.exp(t)
+    def plus(self, t): return self.rplus(t)
+    def lplus(self, t): return SO3.exp(t) @ self
+    def lminus(self, other): return (self @ other.inverse()).log()
+
+
+@dataclass(frozen=True)
+class SE3:
+    wxyz_xyz: np.ndarray
+
+    def __post_init__(self):
+        w = np.asarray(self.wxyz_xyz, dtype=np.float64)
+        if w.shape[-1] != 7:
+            raise ValueError(f"Expected wxyz_xyz to be a length 7 vector but got {w.shape[-1]}.")
+        object.__setattr__(self, "wxyz_xyz", w)
+
+    def __repr__(self):
+        return f"SE3(wxyz={np.round(self.wxyz_xyz[..., :4], 5)}, xyz={np.round(self.wxyz_xyz[..., 4:], 5)})"
+
+    def copy(self): return SE3(np.array(self.wxyz_xyz))
+    def parameters(self): return self.wxyz_xyz
+
+    @classmethod
+    def identity(cls): return SE3(np.array([1.0, 0, 0, 0, 0, 0, 0]))
+
+    @classmethod
+    def from_rotation_and_translation(cls, rotation: SO3, translation):
+        t = np.asarray(translation, dtype=np.float64)
+        q, t = np.broadcast_arrays(rotation.wxyz, t[..., :1] * 0 + 1)[0], t
+        shape = np.broadcast_shapes(rotation.wxyz.shape[:-1], t.shape[:-1])
+        return SE3(np.concatenate([np.broadcast_to(rotation.wxyz, shape + (4,)),
+                                   np.broadcast_to(t, shape + (3,))], -1))
+
+    @classmethod
+    def from_rotation(cls, rotation: SO3):
+        return cls.from_rotation_and_translation(rotation, np.zeros(3))
+
+    @classmethod
+    def from_translation(cls, translation):
+        return cls.from_rotation_and_translation(SO3.identity(), translation)
+
+    @classmethod
+    def from_matrix(cls, M):
+        M = np.asarray(M, dtype=np.float64)
+        return cls.from_rotation_and_translation(SO3.from_matrix(M[..., :3, :3]), M[..., :3, 3])
+
+    @classmethod
+    def sample_uniform(cls, rng=None):
+        g = np.random if rng is None else rng
+        return cls.from_rotation_and_translation(SO3.sample_uniform(rng), g.uniform(-1.0, 1.0, size=3))
+
+    def rotation(self): return SO3(self.wxyz_xyz[..., :4])
+    def translation(self): return self.wxyz_xyz[..., 4:]
+
+    def as_matrix(self):
+        R = self.rotation().as_matrix()
+        M = np.zeros(R.shape[:-2] + (4, 4))
+        M[..., :3, :3] = R
+        M[..., :3, 3] = self.translation()
+        M[..., 3, 3] = 1.0
+        return M
+
+    def inverse(self):
+        Ri = self.rotation().inverse()
+        return SE3.from_rotation_and_translation(Ri, -Ri.apply(self.translation()))
+
+    def normalize(self):
+        return SE3.from_rotation_and_translation(self.rotation().normalize(), self.translation())
+
+    def apply(self, target):
+        return self.rotation().apply(target) + self.translation()
+
+    def multiply(self, other):
+        return SE3.from_rotation_and_translation(self.rotation() @ other.rotation(),
+                                                 self.rotation().apply(other.translation()) + self.translation())
+
+    def __matmul__(self, other):
+        if isinstance(other, np.ndarray):
+            return self.apply(other)
+        return self.multiply(other)
+
+    @classmethod
+    def exp(cls, tangent):
+        t = np.asarray(tangent, dtype=np.float64)
+        w = t[..., 3:]
+        rot = SO3.exp(w)
+        th2 = (w * w).sum(-1)[..., None, None]
+        small = th2 < _EPS
+        th2s = np.where(small, 1.0, th2)
+        th = np.sqrt(th2s)
+        S = skew(w)
+        V = np.where(small, rot.as_matrix(),
+                     np.eye(3) + (1 - np.cos(th)) / th2s * S + (th - np.sin(th)) / (th2s * th) * (S @ S))
+        return cls.from_rotation_and_translation(rot, (V @ t[..., :3, None])[..., 0])
+
+    def log(self):
+        w = self.rotation().log()
+        th2 = (w * w).sum(-1)[..., None, None]
+        small = th2 < _EPS
+        th2s = np.where(small, 1.0, th2)
+        th = np.sqrt(th2s)
+        S = skew(w)
+        k = np.where(small, 1.0 / 12.0, (1.0 - th * np.cos(0.5 * th) / (2.0 * np.sin(0.5 * th))) / th2s)
+        Vinv = np.eye(3) - 0.5 * S + k * (S @ S)
+        return np.concatenate([(Vinv @ self.translation()[..., None])[..., 0], w], -1)
+
+    def adjoint(self):
+        R = self.rotation().as_matrix()
+        A = np.zeros(R.shape[:-2] + (6, 6))
+        A[..., :3, :3] = R
+        A[..., :3, 3:] = skew(self.translation()) @ R
+        A[..., 3:, 3:] = R
+        return A
+
+    def rminus(self, other): return (other.inverse() @ self).log()
+    def minus(self, other): return self.rminus(other)
+    def rplus(self, t): return self @ SE3.exp(t)
+    def plus(self, t): return self.rplus(t)
+    def lplus(self, t): return SE3.exp(t) @ self
+    def lminus(self, other): return (self @ other.inverse()).log()

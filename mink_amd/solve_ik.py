@@ -1,0 +1,140 @@
+"""Batched `solve_ik` / `build_ik` with mink's signature (mink/solve_ik.py:43-105).
+
+The Task/Limit objects are snapshotted into one device descriptor per call site
+(cached on the Configuration by their constructor state); targets travel per call.
+"""
+
+from __future__ import annotations
+
+import logging
+from typing import NamedTuple, Optional, Sequence
+
+import numpy as np
+
+from . import _native as nat
+from . import exceptions
+from .configuration import Configuration
+from .flatmodel import JNT_FREE
+
+DEVICE_SOLVERS = ("mi355x", "hip", "quadprog")
+
+
+class Problem(NamedTuple):
+    """The (P, q, G, h) of qpsolvers.Problem, possibly with a leading batch dimension."""
+    P: np.ndarray
+    q: np.ndarray
+    G: Optional[np.ndarray]
+    h: Optional[np.ndarray]
+
+
+def _key(x):
+    if isinstance(x, dict):
+        return tuple((k, _key(v)) for k, v in sorted(x.items()))
+    if isinstance(x, np.ndarray):
+        return (x.shape, x.tobytes())
+    if isinstance(x, (list, tuple)):
+        return tuple(_key(v) for v in x)
+    return x
+
+
+def _compile(configuration: Configuration, tasks: Sequence, limits: Optional[Sequence], batch: int):
+    from .limits import ConfigurationLimit
+
+    if limits is None:
+        limits = [ConfigurationLimit(configuration.model)]          # mink/solve_ik.py:28-29
+    groups = {"frame": [], "posture": [], "com": [], "cfg": [], "vel": [], "col": []}
+    layout = {"frame": [], "posture": [], "com": []}
+    for t in tasks:
+        kind, desc = t._native_desc(configuration)
+        groups[kind].append(desc)
+        layout[kind].append(t)
+    for lim in limits:
+        kind, desc = lim._native_desc()
+        if kind in ("cfg", "vel") and len(desc["indices"]) == 0:
+            continue                                                # inactive Constraint() (solve_ik.py:34)
+        groups[kind].append(desc)
+    key = (_key(groups), batch)
+    cache = configuration._problems
+    if key not in cache:
+        cache[key] = nat.NativeProblem(
+            configuration.native, frame_tasks=groups["frame"], posture_tasks=groups["posture"],
+            com_tasks=groups["com"], configuration_limits=groups["cfg"], velocity_limits=groups["vel"],
+            collision_limits=groups["col"], max_batch=batch)
+    return cache[key], layout
+
+
+def _gather_targets(configuration: Configuration, layout):
+    B = configuration.batch_size
+    ft = pt = ct = None
+    if layout["frame"]:
+        ft = np.stack([t._native_target(configuration) for t in layout["frame"]], axis=1)
+    if layout["posture"]:
+        rows = [t._native_target(configuration) for t in layout["posture"]]
+        if any(r.ndim == 2 for r in rows):
+            pt = np.stack([np.broadcast_to(r, (B, r.shape[-1])) for r in rows], axis=1)
+        else:
+            pt = np.stack(rows, axis=0)
+    if layout["com"]:
+        rows = [t._native_target(configuration) for t in layout["com"]]
+        if any(r.ndim == 2 for r in rows):
+            ct = np.stack([np.broadcast_to(r, (B, 3)) for r in rows], axis=1)
+        else:
+            ct = np.stack(rows, axis=0)
+    return ft, pt, ct
+
+
+def build_ik(configuration: Configuration, tasks: Sequence, dt: float, damping: float = 1e-12,
+             limits: Optional[Sequence] = None) -> Problem:
+    """mink/solve_ik.py:43-65: the dense QP (P, q, G, h) — evaluated on the device, returned for
+    inspection.  G/h stack the limits in list order exactly like the reference."""
+    from .limits import ConfigurationLimit
+
+    prob, layout = _compile(configuration, tasks, limits, configuration.batch_size)
+    ft, pt, ct = _gather_targets(configuration, layout)
+    _, _, out = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping, taps=["H", "c"], solve_qp=False)
+    lims = [ConfigurationLimit(configuration.model)] if limits is None else limits
+    G_list, h_list = [], []
+    for lim in lims:
+        c = lim.compute_qp_inequalities(configuration, dt)
+        if not c.inactive:
+            G_list.append(np.asarray(c.G)); h_list.append(np.asarray(c.h))
+    un = configuration._unbatch
+    if not G_list:
+        return Problem(un(out["H"]), un(out["c"]), None, None)
+    B = configuration.batch_size
+
+    def bcast(a, nd):
+        return a if (not configuration.batched or a.ndim == nd + 1) else np.broadcast_to(a, (B,) + a.shape)
+
+    G = np.concatenate([bcast(g, 2) for g in G_list], axis=-2)
+    h = np.concatenate([bcast(x, 1) for x in h_list], axis=-1)
+    return Problem(un(out["H"]), un(out["c"]), G, h)
+
+
+def solve_ik(configuration: Configuration, tasks: Sequence, dt: float, solver: str = "mi355x",
+             damping: float = 1e-12, safety_break: bool = False, limits: Optional[Sequence] = None,
+             return_status: bool = False, **kwargs) -> np.ndarray:
+    """Velocity tangent to the batch of configurations (mink/solve_ik.py:68-105).
+
+    `solver` is kept for signature compatibility; every value selects the device active-set
+    solver (the reference forwards the string to qpsolvers).  Returns v of shape (nv,) or (B, nv).
+    """
+    del kwargs
+    prob, layout = _compile(configuration, tasks, limits, configuration.batch_size)
+    ft, pt, ct = _gather_targets(configuration, layout)
+    v, status = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping)
+    if (status & nat.ST_OUTSIDE_LIMITS).any():
+        configuration.check_limits(safety_break=safety_break)      # raises / warns like the reference
+    bad = np.nonzero(status & ~nat.ST_OUTSIDE_LIMITS)[0]
+    if len(bad):
+        s = int(status[bad[0]])
+        why = ("constraints are inconsistent, no solution" if s & nat.ST_INFEASIBLE else
+               "matrix P is not positive definite" if s & nat.ST_NOT_PD else
+               "active-set iteration limit reached" if s & nat.ST_ITER_LIMIT else
+               "more simultaneous contacts than tableau rows")
+        raise exceptions.SolverError(f"QP failed for {len(bad)} of {len(status)} instances "
+                                     f"(first: index {int(bad[0])}, status {s}): {why}")
+    v = configuration._unbatch(v)
+    if return_status:
+        return v, configuration._unbatch(status)
+    return v

@@ -1,0 +1,233 @@
+"""Task plugin classes of the mink API: same constructors, validation and error strings as
+mink/tasks/{task,frame_task,posture_task,com_task,damping_task}.py; targets may be batched.
+`compute_error` / `compute_jacobian` / `compute_qp_objective` evaluate on the device."""
+
+from __future__ import annotations
+
+import abc
+from typing import NamedTuple, Optional
+
+import numpy as np
+
+from . import _native as nat
+from .configuration import Configuration, as_flat_model
+from .exceptions import (InvalidDamping, InvalidGain, InvalidTarget, TargetNotSet, TaskDefinitionError)
+from .lie import SE3
+
+
+class Objective(NamedTuple):
+    """mink/tasks/task.py:12-22."""
+    H: np.ndarray
+    c: np.ndarray
+
+    def value(self, x: np.ndarray) -> float:
+        return x.T @ self.H @ x + self.c @ x
+
+
+class Task(abc.ABC):
+    """mink/tasks/task.py:25-138."""
+
+    def __init__(self, cost: np.ndarray, gain: float = 1.0, lm_damping: float = 0.0):
+        if not 0.0 <= gain <= 1.0:
+            raise InvalidGain("`gain` must be in the range [0, 1]")
+        if lm_damping < 0.0:
+            raise InvalidDamping("`lm_damping` must be >= 0")
+        self.cost = cost
+        self.gain = gain
+        self.lm_damping = lm_damping
+
+    # -- device plumbing -------------------------------------------------
+    @abc.abstractmethod
+    def _native_desc(self, configuration: Configuration):
+        """(kind, descriptor dict) for mkh_problem_create."""
+
+    @abc.abstractmethod
+    def _native_target(self, configuration: Configuration) -> np.ndarray:
+        """Target rows for mkh_solve."""
+
+    def _eval(self, configuration: Configuration, taps):
+        from .solve_ik import _compile, _gather_targets
+        prob, layout = _compile(configuration, [self], limits=[], batch=configuration.batch_size)
+        ft, pt, ct = _gather_targets(configuration, layout)
+        _, _, out = prob.solve(configuration.q_batch, ft, pt, ct, 1.0, 0.0, taps=taps, solve_qp=False)
+        return out
+
+    def compute_error(self, configuration: Configuration) -> np.ndarray:
+        return configuration._unbatch(self._eval(configuration, ["task_e"])["task_e"])
+
+    def compute_jacobian(self, configuration: Configuration) -> np.ndarray:
+        return configuration._unbatch(self._eval(configuration, ["task_J"])["task_J"])
+
+    def compute_qp_objective(self, configuration: Configuration) -> Objective:
+        out = self._eval(configuration, ["H", "c"])   # damping = 0 ⇒ exactly this task's (H, c)
+        return Objective(configuration._unbatch(out["H"]), configuration._unbatch(out["c"]))
+
+
+class FrameTask(Task):
+    """mink/tasks/frame_task.py:16-146."""
+
+    k: int = 6
+
+    def __init__(self, frame_name: str, frame_type: str, position_cost, orientation_cost, gain: float = 1.0,
+                 lm_damping: float = 0.0):
+        super().__init__(cost=np.zeros((self.k,)), gain=gain, lm_damping=lm_damping)
+        self.frame_name = frame_name
+        self.frame_type = frame_type
+        self.position_cost = position_cost
+        self.orientation_cost = orientation_cost
+        self.transform_target_to_world: Optional[SE3] = None
+        self.set_position_cost(position_cost)
+        self.set_orientation_cost(orientation_cost)
+
+    def set_position_cost(self, position_cost) -> None:
+        position_cost = np.atleast_1d(position_cost)
+        if position_cost.ndim != 1 or position_cost.shape[0] not in (1, 3):
+            raise TaskDefinitionError(
+                f"{self.__class__.__name__} position cost should be a vector of shape "
+                "1 (aka identical cost for all coordinates) or (3,) but got "
+                f"{position_cost.shape}")
+        if not np.all(position_cost >= 0.0):
+            raise TaskDefinitionError(f"{self.__class__.__name__} position cost should be >= 0")
+        self.cost[:3] = position_cost
+
+    def set_orientation_cost(self, orientation_cost) -> None:
+        orientation_cost = np.atleast_1d(orientation_cost)
+        if orientation_cost.ndim != 1 or orientation_cost.shape[0] not in (1, 3):
+            raise TaskDefinitionError(
+                f"{self.__class__.__name__} orientation cost should be a vector of "
+                "shape 1 (aka identical cost for all coordinates) or (3,) but got "
+                f"{orientation_cost.shape}")
+        if not np.all(orientation_cost >= 0.0):
+            raise TaskDefinitionError(f"{self.__class__.__name__} position cost should be >= 0")
+        self.cost[3:] = orientation_cost
+
+    def set_target(self, transform_target_to_world: SE3) -> None:
+        """Single pose or a batch (B, 7); copied (mink/tasks/frame_task.py:77-83)."""
+        self.transform_target_to_world = transform_target_to_world.copy()
+
+    def set_target_from_configuration(self, configuration: Configuration) -> None:
+        self.set_target(configuration.get_transform_frame_to_world(self.frame_name, self.frame_type))
+
+    def _native_desc(self, configuration):
+        fid = configuration._frame_id(self.frame_name, self.frame_type)
+        return "frame", {"frame_type": self.frame_type, "frame_id": fid, "cost": self.cost.tolist(),
+                         "gain": self.gain, "lm_damping": self.lm_damping}
+
+    def _native_target(self, configuration):
+        if self.transform_target_to_world is None:
+            raise TargetNotSet(self.__class__.__name__)
+        t = self.transform_target_to_world.wxyz_xyz
+        B = configuration.batch_size
+        if t.ndim == 1:
+            return np.broadcast_to(t, (B, 7))
+        if t.shape != (B, 7):
+            raise InvalidTarget(f"Expected target pose batch to have shape ({B}, 7) but got {t.shape}")
+        return t
+
+
+class PostureTask(Task):
+    """mink/tasks/posture_task.py:17-142."""
+
+    def __init__(self, model, cost, gain: float = 1.0, lm_damping: float = 0.0):
+        m = as_flat_model(model)
+        super().__init__(cost=np.zeros((m.nv,)), gain=gain, lm_damping=lm_damping)
+        self.target_q: Optional[np.ndarray] = None
+        _, v_ids = m.freejoint_dims()
+        self._v_ids = np.asarray(v_ids) if v_ids else None
+        self.k = m.nv
+        self.nq = m.nq
+        self.set_cost(cost)
+
+    def set_cost(self, cost) -> None:
+        cost = np.atleast_1d(cost)
+        if cost.ndim != 1 or cost.shape[0] not in (1, self.k):
+            raise TaskDefinitionError(
+                f"{self.__class__.__name__} cost must be a vector of shape (1,) "
+                f"(aka identical cost for all dofs) or ({self.k},). Got {cost.shape}")
+        if not np.all(cost >= 0.0):
+            raise TaskDefinitionError(f"{self.__class__.__name__} cost should be >= 0")
+        self.cost[: self.k] = cost
+
+    def set_target(self, target_q) -> None:
+        target_q = np.atleast_1d(target_q)
+        if target_q.ndim == 2 and target_q.shape[1] == self.nq:
+            self.target_q = np.array(target_q, dtype=np.float64)      # batched posture target
+            return
+        if target_q.ndim != 1 or target_q.shape[0] != (self.nq):
+            raise InvalidTarget(f"Expected target posture to have shape ({self.nq},) but got {target_q.shape}")
+        self.target_q = np.array(target_q, dtype=np.float64)
+
+    def set_target_from_configuration(self, configuration: Configuration) -> None:
+        self.set_target(configuration.q)
+
+    def _native_desc(self, configuration):
+        return "posture", {"cost": self.cost.copy(), "gain": self.gain, "lm_damping": self.lm_damping}
+
+    def _native_target(self, configuration):
+        if self.target_q is None:
+            raise TargetNotSet(self.__class__.__name__)
+        return self.target_q
+
+
+class DampingTask(PostureTask):
+    """mink/tasks/damping_task.py:11-20."""
+
+    def __init__(self, model, cost):
+        m = as_flat_model(model)
+        super().__init__(model=m, cost=cost, gain=0.0, lm_damping=0.0)
+        self.target_q = np.array(m.qpos0)
+
+
+class ComTask(Task):
+    """mink/tasks/com_task.py:16-97."""
+
+    k: int = 3
+
+    def __init__(self, cost, gain: float = 1.0, lm_damping: float = 0.0):
+        super().__init__(cost=np.zeros((self.k,)), gain=gain, lm_damping=lm_damping)
+        self.target_com: Optional[np.ndarray] = None
+        self.set_cost(cost)
+
+    def set_cost(self, cost) -> None:
+        cost = np.atleast_1d(cost)
+        if cost.ndim != 1 or cost.shape[0] not in (1, self.k):
+            raise TaskDefinitionError(
+                f"{self.__class__.__name__} cost must be a vector of shape (1,) "
+                f"(aka identical cost for all coordinates) or ({self.k},). "
+                f"Got {cost.shape}")
+        if not np.all(cost >= 0.0):
+            raise TaskDefinitionError(f"{self.__class__.__name__} cost must be >= 0")
+        self.cost[:] = cost
+
+    def set_target(self, target_com) -> None:
+        target_com = np.atleast_1d(target_com)
+        if target_com.ndim == 2 and target_com.shape[1] == self.k:
+            self.target_com = np.array(target_com, dtype=np.float64)
+            return
+        if target_com.ndim != 1 or target_com.shape[0] != (self.k):
+            raise InvalidTarget(f"Expected target CoM to have shape ({self.k},) but got {target_com.shape}")
+        self.target_com = np.array(target_com, dtype=np.float64)
+
+    def set_target_from_configuration(self, configuration: Configuration) -> None:
+        self.set_target(configuration.subtree_com())
+
+    def _native_desc(self, configuration):
+        return "com", {"cost": self.cost.tolist(), "gain": self.gain, "lm_damping": self.lm_damping}
+
+    def _native_target(self, configuration):
+        if self.target_com is None:
+            raise TargetNotSet(self.__class__.__name__)
+        return self.target_com
+
+
+class RelativeFrameTask(Task):
+    """mink/tasks/relative_frame_task.py — not on the accelerated path yet."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("RelativeFrameTask is not implemented on the device path yet")
+
+    def _native_desc(self, configuration):  # pragma: no cover
+        raise NotImplementedError
+
+    def _native_target(self, configuration):  # pragma: no cover
+        raise NotImplementedError

@@ -1,0 +1,264 @@
+"""The reference's own behavioural tests, re-pointed at the device path through the mink-shaped
+API (reference tests/test_solve_ik.py:33-148, test_frame_task.py:124-173, test_posture_task.py:87-108,
+test_com_task.py:67-92, test_damping_task.py:21-26, test_jacobians.py:41-108,
+test_configuration.py:36-118, test_configuration_limit.py:123-156), and checked against the
+CPU oracle where the reference compares with MuJoCo."""
+
+import numpy as np
+import pytest
+
+import mink_amd as mink
+import oracle_configs as oc
+from oracle import ik as oik
+from oracle import lie as olie
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ur5e():
+    return mink.load_robot("ur5e")
+
+
+@pytest.fixture(scope="module")
+def g1():
+    return mink.load_robot("g1")
+
+
+def _ur5e_limits(m):
+    return [mink.ConfigurationLimit(m), mink.VelocityLimit(m, {n: np.pi for n in m.jnt_names})]
+
+
+# ------------------------------------------------------------------ solve_ik
+def test_checks_and_ignores_configuration_limits(ur5e):
+    cfg = mink.Configuration(ur5e)
+    q = ur5e.key_qpos[0].copy()
+    q[0] = 7.0                                  # range is ±6.28319
+    cfg.update(q)
+    with pytest.raises(mink.NotWithinConfigurationLimits):
+        mink.solve_ik(cfg, [], limits=[mink.ConfigurationLimit(ur5e)], dt=1.0, safety_break=True, solver="quadprog")
+    v = mink.solve_ik(cfg, [], limits=[mink.ConfigurationLimit(ur5e)], dt=1.0, solver="quadprog", safety_break=False)
+    # the limit pushes the joint back inside: Δq ≤ gain·(q_max − q) < 0
+    assert v[0] <= 0.95 * (6.28319 - 7.0) + 1e-12
+
+
+def test_no_limits_and_default_limits(ur5e):
+    cfg = mink.Configuration(ur5e)
+    p = mink.build_ik(cfg, [], limits=[], dt=1.0)
+    assert p.G is None and p.h is None
+    p = mink.build_ik(cfg, [], dt=1.0)
+    assert p.G.shape == (12, 6) and p.h.shape == (12,)
+    np.testing.assert_allclose(p.P, np.eye(6) * 1e-12, atol=0)
+
+
+def test_trivial_solution(ur5e):
+    cfg = mink.Configuration(ur5e)
+    v = mink.solve_ik(cfg, [], limits=[], dt=1e-3, solver="quadprog")
+    np.testing.assert_allclose(v, np.zeros(6))
+
+
+def test_single_task_fulfilled(ur5e):
+    cfg = mink.Configuration(ur5e)
+    task = mink.FrameTask("attachment_site", "site", position_cost=1.0, orientation_cost=1.0)
+    task.set_target(cfg.get_transform_frame_to_world("attachment_site", "site"))
+    v = mink.solve_ik(cfg, [task], limits=_ur5e_limits(ur5e), dt=1e-3, solver="quadprog")
+    np.testing.assert_allclose(v, np.zeros(6), atol=1e-10)
+
+
+def test_single_task_convergence(ur5e):
+    cfg = mink.Configuration(ur5e)
+    cfg.update_from_keyframe("home")
+    task = mink.FrameTask("attachment_site", "site", position_cost=1.0, orientation_cost=1.0)
+    T0 = cfg.get_transform_frame_to_world("attachment_site", "site")
+    target = T0 @ mink.SE3.from_translation(np.array([0, 0, 0.1]))
+    task.set_target(target)
+    dt = 5e-3
+    lims = _ur5e_limits(ur5e)
+    velocity = mink.solve_ik(cfg, [task], limits=lims, dt=dt, solver="quadprog")
+    assert not np.allclose(velocity, 0.0)
+    assert abs(np.linalg.norm(task.compute_error(cfg)) - 0.1) < 1e-7
+    last_error = 1e6
+    for nb_steps in range(50):
+        error = np.linalg.norm(task.compute_error(cfg))
+        if error < 1e-6 and np.allclose(velocity, 0.0):
+            break
+        assert error < last_error
+        last_error = error
+        cfg.integrate_inplace(velocity, dt)
+        velocity = mink.solve_ik(cfg, [task], limits=lims, dt=dt, solver="quadprog")
+    assert np.allclose(velocity, 0.0)
+    assert np.linalg.norm(task.compute_error(cfg)) < 1e-7
+    np.testing.assert_allclose(cfg.get_transform_frame_to_world("attachment_site", "site").as_matrix(),
+                               target.as_matrix(), atol=1e-7)
+    assert nb_steps < 20
+
+
+def test_infeasible_instance_raises(ur5e):
+    cfg = mink.Configuration(ur5e)
+    q = ur5e.key_qpos[0].copy()
+    q[0] = 7.0
+    cfg.update(q)
+    lims = [mink.ConfigurationLimit(ur5e), mink.VelocityLimit(ur5e, {"shoulder_pan": 1e-3})]
+    with pytest.raises(mink.SolverError, match="inconsistent"):
+        mink.solve_ik(cfg, [], limits=lims, dt=1e-3)          # must retreat 0.68 rad but may move 1e-6
+
+
+def test_batched_equals_single(g1):
+    rng = np.random.default_rng(0)
+    from mink_amd import workloads
+    B = 16
+    q = workloads.sample_q(g1, rng, B, base_q=g1.key_qpos[0])
+    cfgB = mink.Configuration(g1, q)
+    tasks = [mink.FrameTask(s, "site", 200.0, 10.0, lm_damping=1.0) for s in ("left_foot", "right_foot")]
+    cfgT = mink.Configuration(g1, cfgB.integrate(rng.normal(scale=0.1, size=(B, g1.nv)), 1.0))
+    for t in tasks:
+        t.set_target(cfgT.get_transform_frame_to_world(t.frame_name, "site"))
+    post = mink.PostureTask(g1, 1.0); post.set_target(g1.key_qpos[0])
+    lims = [mink.ConfigurationLimit(g1)]
+    vB = mink.solve_ik(cfgB, tasks + [post], 5e-3, "mi355x", 1e-1, limits=lims)
+    assert vB.shape == (B, g1.nv)
+    for i in (0, 5, 15):
+        cfg1 = mink.Configuration(g1, q[i])
+        t1 = [mink.FrameTask(t.frame_name, "site", 200.0, 10.0, lm_damping=1.0) for t in tasks]
+        for a, b in zip(t1, tasks):
+            a.set_target(mink.SE3(b.transform_target_to_world.wxyz_xyz[i]))
+        v1 = mink.solve_ik(cfg1, t1 + [post], 5e-3, "mi355x", 1e-1, limits=lims)
+        assert v1.shape == (g1.nv,)
+        np.testing.assert_array_equal(v1, vB[i])          # same kernel, same arithmetic: bitwise
+
+
+# -------------------------------------------------------------------- tasks
+def test_frame_task_objective(g1):
+    """unit cost ⇒ H = JᵀJ, c = eᵀJ; zero error at target (reference tests/test_frame_task.py:124-173)."""
+    cfg = mink.Configuration(g1)
+    cfg.update_from_keyframe("stand")
+    task = mink.FrameTask("pelvis", "body", position_cost=1.0, orientation_cost=1.0)
+    T = cfg.get_transform_frame_to_world("pelvis", "body")
+    task.set_target(T)
+    np.testing.assert_allclose(task.compute_error(cfg), np.zeros(6), atol=1e-14)
+    task.set_target(T @ mink.SE3.from_translation(np.array([0.0, 0.01, 0.0])))
+    J = task.compute_jacobian(cfg)
+    e = task.compute_error(cfg)
+    H, c = task.compute_qp_objective(cfg)
+    np.testing.assert_allclose(H, J.T @ J, atol=1e-13)
+    np.testing.assert_allclose(c, e.T @ J, atol=1e-15)
+    with pytest.raises(mink.TargetNotSet):
+        mink.FrameTask("pelvis", "body", 1.0, 1.0).compute_error(cfg)
+    with pytest.raises(mink.InvalidFrame):
+        bad = mink.FrameTask("nope", "body", 1.0, 1.0)
+        bad.set_target(T)
+        bad.compute_error(cfg)
+    with pytest.raises(mink.UnsupportedFrame):
+        cfg.get_transform_frame_to_world("pelvis", "joint")
+
+
+def test_posture_com_damping_objectives(g1):
+    cfg = mink.Configuration(g1)
+    cfg.update_from_keyframe("stand")
+    post = mink.PostureTask(g1, cost=1.0)
+    post.set_target_from_configuration(cfg)
+    np.testing.assert_allclose(post.compute_error(cfg), 0.0, atol=0)
+    rng = np.random.default_rng(1)
+    tgt = cfg.q
+    tgt[7:] += rng.normal(scale=0.1, size=g1.nq - 7)
+    post.set_target(tgt)
+    J, e = post.compute_jacobian(cfg), post.compute_error(cfg)
+    H, c = post.compute_qp_objective(cfg)
+    np.testing.assert_allclose(H, J.T @ J, atol=1e-14)
+    np.testing.assert_allclose(c, e.T @ J, atol=1e-14)
+    assert np.all(e[:6] == 0) and np.all(J[:, :6] == 0)            # floating base untouched
+    H0, c0 = mink.PostureTask(g1, cost=0.0).__class__(g1, cost=0.0), None
+    dmp = mink.DampingTask(g1, cost=1.0)
+    Hd, cd = dmp.compute_qp_objective(cfg)
+    ref = np.eye(g1.nv); ref[:6, :6] = 0
+    np.testing.assert_allclose(Hd, ref, atol=0)
+    np.testing.assert_allclose(cd, 0.0, atol=0)
+    com = mink.ComTask(cost=1.0)
+    com.set_target_from_configuration(cfg)
+    np.testing.assert_allclose(com.compute_error(cfg), 0.0, atol=1e-15)
+    ocfg = oik.Configuration(oc.model("g1"), cfg.q)
+    np.testing.assert_allclose(cfg.subtree_com(), ocfg.data.subtree_com[1], atol=1e-14)
+
+
+def _fd_jacobian(cfg, task, h=1e-6):
+    J = task.compute_jacobian(cfg)
+    e0 = task.compute_error(cfg)
+    nv = cfg.nv
+    qs = np.stack([cfg.integrate(np.eye(nv)[i] * h, 1.0) for i in range(nv)])
+    eh = task.compute_error(mink.Configuration(cfg.model, qs))     # one batched launch
+    return J, ((eh - e0) / h).T
+
+
+def test_task_jacobians_finite_difference(g1):
+    """reference tests/test_jacobians.py:41-108 (G1, h=1e-6, ∞-norm 1e-5 / 1e-6)."""
+    rng = np.random.default_rng(42)
+    from mink_amd import workloads
+    q = workloads.sample_q(g1, rng, 1, base_q=g1.key_qpos[0])[0]
+    q[3:7] = olie.so3_exp(rng.normal(size=3))
+    cfg = mink.Configuration(g1, q)
+    for name, ftype in (("left_palm", "site"), ("torso_link", "body"), ("right_foot", "site")):
+        task = mink.FrameTask(name, ftype, 1.0, 1.0)
+        task.set_target(mink.SE3(olie.se3_exp(rng.normal(size=6))))
+        J, Jfd = _fd_jacobian(cfg, task)
+        assert np.abs(J - Jfd).max() < 1e-5
+    post = mink.PostureTask(g1, 1.0)
+    post.set_target(g1.key_qpos[0])
+    J, Jfd = _fd_jacobian(cfg, post)
+    assert np.abs(J - Jfd)[6:, 6:].max() < 1e-6
+    com = mink.ComTask(1.0)
+    com.set_target(np.zeros(3))
+    J, Jfd = _fd_jacobian(cfg, com)
+    assert np.abs(J - Jfd).max() < 1e-6
+
+
+# ------------------------------------------------------------ configuration
+def test_configuration_kinematics_vs_oracle(g1):
+    rng = np.random.default_rng(3)
+    from mink_amd import workloads
+    B = 8
+    q = workloads.sample_q(g1, rng, B, base_q=g1.key_qpos[0])
+    cfg = mink.Configuration(g1, q)
+    m = oc.model("g1")
+    for name, ftype in (("head", "site"), ("left_knee_link", "body"), ("right_palm", "site")):
+        T = cfg.get_transform_frame_to_world(name, ftype)
+        Jb = cfg.get_frame_jacobian(name, ftype)
+        fid = m.name2id(ftype, name)
+        for i in range(B):
+            o = oik.Configuration(m, q[i])
+            Tr = o.get_transform_frame_to_world(fid, ftype)
+            if np.dot(Tr[:4], T.wxyz_xyz[i, :4]) < 0:
+                Tr[:4] = -Tr[:4]                                    # quaternion double cover
+            np.testing.assert_allclose(T.wxyz_xyz[i], Tr, atol=1e-14)
+            np.testing.assert_allclose(Jb[i], o.get_frame_jacobian(fid, ftype), atol=1e-13)
+    v = rng.normal(size=(B, g1.nv))
+    qn = cfg.integrate(v, 0.05)
+    for i in range(B):
+        np.testing.assert_allclose(qn[i], oik.Configuration(m, q[i]).integrate(v[i], 0.05), atol=1e-15)
+
+
+def test_limit_inequalities_vs_oracle():
+    m = mink.load_robot("shadow_left")
+    om = oc.model("shadow_left")
+    d = np.load(oc.GOLDEN + "/ik_shadow_c4.npz")
+    q = d["q"][:6]
+    cfg = mink.Configuration(m, q)
+    f = list(oc.SHADOW_FINGERS)
+    groups = [[f"{x}_1", f"{x}_2"] for x in f]
+    col = mink.CollisionAvoidanceLimit(m, [(groups[i], groups[j]) for i in range(5) for j in range(i + 1, 5)],
+                                       collision_detection_distance=0.03)
+    cl = mink.ConfigurationLimit(m, gain=0.5, min_distance_from_limits=0.01)
+    dt = 2e-3
+    Gc, hc = col.compute_qp_inequalities(cfg, dt)
+    Gl, hl = cl.compute_qp_inequalities(cfg, dt)
+    assert Gc.shape == (6, 40, 24) and Gl.shape == (48, 24)
+    assert (hc[np.isfinite(hc)] >= 0).all()                         # h ≥ bound_relaxation (reference :47-63)
+    for i in range(6):
+        o = oik.Configuration(om, q[i])
+        G, h = oik.limit_inequalities(o, oik.CollisionAvoidanceLimitSpec(col.geom_id_pairs, collision_detection_distance=0.03), dt)
+        fin = np.isfinite(h)
+        assert (np.isfinite(hc[i]) == fin).all()
+        np.testing.assert_allclose(hc[i][fin], h[fin], atol=1e-9)
+        np.testing.assert_allclose(Gc[i], G, atol=1e-11)
+        G, h = oik.limit_inequalities(o, oik.ConfigurationLimitSpec(0.5, 0.01), dt)
+        np.testing.assert_allclose(hl[i], h, atol=1e-15)
+        np.testing.assert_array_equal(Gl, G)

@@ -1,0 +1,113 @@
+"""Full-size checks (BASELINE sizes) through size-independent properties: feasibility of every
+instance, KKT stationarity on a sample via the H/c taps, determinism, batch-permutation
+equivariance, oracle agreement on a random subsample, device-pointer (torch) path = host path."""
+
+import numpy as np
+import pytest
+
+import native_configs as nc
+import oracle_configs as oc
+from oracle import ik as oik
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g1_setup():
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+    model = workloads.load_robot("g1")
+    nm = nat.NativeModel(model)
+    B = 65536
+    prob, dt, damping = nc.build("g1_c3", nm, B)
+    rng = np.random.default_rng(2024)
+    stand = model.key_qpos[0]
+    q, tg = workloads.make_batch(model, nm, prob, rng, B, base_q=stand)
+    return model, nm, prob, dt, damping, q, tg, stand
+
+
+def test_g1_full_batch_properties(g1_setup):
+    model, nm, prob, dt, damping, q, tg, stand = g1_setup
+    B = len(q)
+    v, st, taps = prob.solve(q, tg, stand[None, :], None, dt, damping, taps=["box_lo", "box_hi", "qp_iters"])
+    assert (st == 0).all()
+    dq = v * dt
+    lo, hi = taps["box_lo"], taps["box_hi"]
+    tol = 1e-12 * 4
+    assert (dq <= hi + tol).all() and (dq >= lo - tol).all()       # primal feasibility of all 65 536
+    it = taps["qp_iters"]
+    print("G1 B=65536: active-set pivots after x0: mean %.1f max %d" % (it.mean(), it.max()))
+    # determinism + permutation equivariance (bitwise)
+    v2, _ = prob.solve(q, tg, stand[None, :], None, dt, damping)
+    np.testing.assert_array_equal(v, v2)
+    perm = np.random.default_rng(0).permutation(B)
+    v3, _ = prob.solve(q[perm], tg[perm], stand[None, :], None, dt, damping)
+    np.testing.assert_array_equal(v3, v[perm])
+    # KKT on a sample: H dq + c = −μ with μ only on active bounds and correctly signed
+    idx = np.arange(0, B, 257)[:256]
+    _, _, t = prob.solve(q[idx], tg[idx], stand[None, :], None, dt, damping, taps=["H", "c"])
+    g = np.einsum("bij,bj->bi", t["H"], dq[idx]) + t["c"]
+    scale = np.abs(t["c"]).max(axis=1, keepdims=True)
+    at_hi = np.abs(dq[idx] - hi[idx]) < 1e-13
+    at_lo = np.abs(dq[idx] - lo[idx]) < 1e-13
+    free = ~(at_hi | at_lo)
+    assert (np.abs(g)[free] / np.broadcast_to(scale, g.shape)[free]).max() < 1e-9
+    assert (g[at_hi & ~at_lo] <= 1e-9 * np.broadcast_to(scale, g.shape)[at_hi & ~at_lo]).all()
+    assert (g[at_lo & ~at_hi] >= -1e-9 * np.broadcast_to(scale, g.shape)[at_lo & ~at_hi]).all()
+    # oracle on a random subsample
+    m = oc.model("g1")
+    worst = 0.0
+    for i in np.random.default_rng(1).choice(B, size=24, replace=False):
+        mm, tasks, limits, dt_o, damp_o = oc.g1_c3(tg[i], stand)
+        v_ref = oik.solve_ik(m, q[i], tasks, dt_o, damp_o, limits)
+        worst = max(worst, np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max()))
+    print("oracle subsample max rel err", worst)
+    assert worst < 1e-8
+
+
+def test_device_pointer_path_matches_host_path(g1_setup):
+    torch = pytest.importorskip("torch")
+    model, nm, prob, dt, damping, q, tg, stand = g1_setup
+    n = 4096
+    v_h, st_h = prob.solve(q[:n], tg[:n], stand[None, :], None, dt, damping)
+    dev = torch.device("cuda", 0)
+    v_d, st_d = prob.solve(torch.from_numpy(q[:n]).to(dev), torch.from_numpy(tg[:n]).to(dev),
+                           torch.from_numpy(stand[None, :].copy()).to(dev), None, dt, damping)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(v_d.cpu().numpy(), v_h)
+    np.testing.assert_array_equal(st_d.cpu().numpy(), st_h)
+
+
+@pytest.mark.parametrize("name,B", [("ur5e_c2", 4096), ("shadow_c4", 16384)])
+def test_other_configs_full_batch(name, B):
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+    robot = nc.ROBOT_OF[name]
+    model = workloads.load_robot(robot)
+    nm = nat.NativeModel(model)
+    prob, dt, damping = nc.build(name, nm, B)
+    rng = np.random.default_rng(5)
+    base = model.key_qpos[model.name2id("key", "home" if robot == "ur5e" else "grasp hard")]
+    q, tg = workloads.make_batch(model, nm, prob, rng, B, base_q=base)
+    if robot == "shadow_left":
+        q[::2] = 0.5 * (q[::2] + base)            # bring fingers close: active collision rows
+    taps = ["box_lo", "box_hi", "qp_iters"] + (["coll_G", "coll_h"] if prob.n_pairs else [])
+    v, st, t = prob.solve(q, tg, base[None, :], None, dt, damping, taps=taps)
+    assert ((st & ~1) == 0).all(), np.unique(st)
+    dq = v * dt
+    assert (dq <= t["box_hi"] + 1e-11).all() and (dq >= t["box_lo"] - 1e-11).all()
+    if prob.n_pairs:
+        Gx = np.einsum("bpj,bj->bp", t["coll_G"], dq)
+        fin = np.isfinite(t["coll_h"])
+        nrm = np.linalg.norm(t["coll_G"], axis=2)
+        assert (Gx[fin] <= t["coll_h"][fin] + 1e-10 * np.maximum(1.0, nrm[fin])).all()   # half-spaces respected
+        print(name, "active contact rows per instance: mean %.1f max %d" % (fin.sum(1).mean(), fin.sum(1).max()))
+    m = oc.model(robot)
+    cfgfn = getattr(oc, name)
+    worst = 0.0
+    for i in np.random.default_rng(1).choice(B, size=16, replace=False):
+        mm, tasks, limits, dt_o, damp_o = cfgfn(tg[i], base)
+        v_ref = oik.solve_ik(m, q[i], tasks, dt_o, damp_o, limits)
+        worst = max(worst, np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max()))
+    print(name, "oracle subsample max rel err", worst, "pivots mean", t["qp_iters"].mean())
+    assert worst < 1e-7
