@@ -90,15 +90,13 @@ def main():
     pt = torch.from_numpy(stand[None, :].copy()).to(dev)
     v = torch.empty((B, model.nv), dtype=torch.float64, device=dev)
     st = torch.empty((B,), dtype=torch.int32, device=dev)
-    gather_list = None
     do_gather = world > 1 and not args.no_gather
-    if do_gather and rank == 0:
-        gather_list = [torch.empty_like(v) for _ in range(world)]
+    from mink_amd.distributed import gather_rows
 
     def step():
         prob.solve(q, tg, pt, None, dt, damping, out=v, status_out=st)
         if do_gather:
-            dist.gather(v, gather_list, dst=0)
+            gather_rows(v, world * B, dst=0)           # RCCL gather of v to rank 0 (tests/test_distributed_cpu.py)
 
     for _ in range(args.warmup):
         step()
