@@ -163,6 +163,7 @@ typedef struct MkhTaps {
   double *coll_G;    /* (B, n_pairs, nv) CollisionAvoidanceLimit G rows (0 when inactive) */
   double *coll_h;    /* (B, n_pairs)     and h (+inf when inactive)                   */
   int32_t *qp_iters; /* (B,)  active-set pivots after the unconstrained solve         */
+  int64_t *cycles;   /* (B, 8) shader-clock stamps at the kernel's phase boundaries (profiling) */
 } MkhTaps;
 
 int32_t mkh_version(void);

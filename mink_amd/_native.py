@@ -83,7 +83,7 @@ class MkhProblemDesc(C.Structure):
 
 
 TAP_NAMES = ("xpos", "xquat", "frame_pose", "subtree_com", "task_e", "task_J", "H", "c", "box_lo",
-             "box_hi", "coll_G", "coll_h", "qp_iters")
+             "box_hi", "coll_G", "coll_h", "qp_iters", "cycles")
 
 
 class MkhTaps(C.Structure):
@@ -303,6 +303,7 @@ class NativeProblem:
             "subtree_com": (B, 3), "task_e": (B, self.n_rows), "task_J": (B, self.n_rows, m.nv),
             "H": (B, m.nv, m.nv), "c": (B, m.nv), "box_lo": (B, m.nv), "box_hi": (B, m.nv),
             "coll_G": (B, self.n_pairs, m.nv), "coll_h": (B, self.n_pairs), "qp_iters": (B,),
+            "cycles": (B, 8),
         }
 
     def solve(self, q, frame_targets=None, posture_target=None, com_target=None, dt: float = 1e-2,
@@ -338,7 +339,7 @@ class NativeProblem:
             tapbufs = {}
             shapes = self._tap_shapes(B)
             for n in taps:
-                dt_ = torch.int32 if n == "qp_iters" else torch.float64
+                dt_ = torch.int32 if n == "qp_iters" else (torch.int64 if n == "cycles" else torch.float64)
                 tapbufs[n] = torch.empty(shapes[n], dtype=dt_, device=dev)
                 if n in ("task_e", "task_J", "subtree_com"):
                     tapbufs[n].zero_()
@@ -352,7 +353,7 @@ class NativeProblem:
             st = (np.zeros((B,), dtype=np.int32) if status_out is None else status_out) if solve_qp else None
             stream = None
             shapes = self._tap_shapes(B)
-            tapbufs = {n: np.zeros(shapes[n], dtype=np.int32 if n == "qp_iters" else np.float64) for n in taps}
+            tapbufs = {n: np.zeros(shapes[n], dtype=np.int32 if n == "qp_iters" else (np.int64 if n == "cycles" else np.float64)) for n in taps}
         if q.shape != (B, m.nq):
             raise ValueError(f"q must have shape (B, {m.nq}), got {tuple(q.shape)}")
         if self.n_frame and (frame_targets is None or tuple(frame_targets.shape) != (B, self.n_frame, 7)):

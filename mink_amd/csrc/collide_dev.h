@@ -26,9 +26,15 @@ __device__ __forceinline__ Contact sphere_sphere(V3 p1, double r1, V3 p2, double
 }
 
 __device__ __forceinline__ Contact better(Contact a, Contact b) {
-  if (!b.hit) return a;
-  if (!a.hit) return b;
-  return (b.dist < a.dist) ? b : a;
+  // field-wise selects: returning one of two structs by value makes hipcc select between two
+  // stack addresses, i.e. a real scratch array
+  const bool tb = b.hit && (!a.hit || b.dist < a.dist);
+  Contact r;
+  r.hit = a.hit || b.hit;
+  r.dist = tb ? b.dist : a.dist;
+  r.pos = {tb ? b.pos.x : a.pos.x, tb ? b.pos.y : a.pos.y, tb ? b.pos.z : a.pos.z};
+  r.n = {tb ? b.n.x : a.n.x, tb ? b.n.y : a.n.y, tb ? b.n.z : a.n.z};
+  return r;
 }
 
 __device__ __forceinline__ Contact capsule_capsule(V3 pos1, V3 axis1, double r1, double l1,

@@ -1,0 +1,116 @@
+"""Generate tab_asm.inc: the QP tableau column of a lane as PINNED VGPRs driven by inline asm.
+
+Why: hipcc cannot keep a 48-double per-lane array in registers through a loop with control flow —
+it copies the array between register sets at block boundaries and spills loop-invariant values
+into the pivot's critical path (scratch reloads of an LDS address cost ~500 cycles each).  So the
+tableau lives in a fixed physical register range the compiler never allocates
+(`amdgpu_num_vgpr` caps the compiler below it; asm clobbers make the range count towards the
+kernel's VGPR total), and the four operations that touch it are emitted here with literal
+register numbers:
+
+    zero()                    T[i] = 0
+    rank1(lds_addr, g)        T[i] += lds[i]·g      software-pipelined ds_read_b128 + v_fma_f64
+    publish(lds_addr)         lds[i] = T[i]         (caller masks exec to the owning lane)
+    get<I>() / set<I>(x)      single element, compile-time index (tableau build, taps)
+
+Register map for NT rows (wave64, 2 waves/SIMD ⇒ 256 VGPRs per lane):
+    v[256-2·NT, 256)              tableau column (NT doubles)
+    v[256-2·NT-32, 256-2·NT)      LDS staging for rank1 (8 × 128 bit in flight)
+    v[0, 256-2·NT-32)             everything the compiler allocates
+"""
+
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NTS = (8, 16, 24, 32, 40, 48, 56, 64)
+TOTAL = 256
+NTMP = 32  # 8 x b128
+
+
+def gen(nt: int) -> str:
+    t0 = TOTAL - 2 * nt
+    tmp0 = t0 - NTMP
+    budget = tmp0
+    treg = lambda i: f"v[{t0 + 2 * i}:{t0 + 2 * i + 1}]"
+    clob_t = ",".join(f'"v{r}"' for r in range(t0, TOTAL))
+    clob_tmp = ",".join(f'"v{r}"' for r in range(tmp0, t0))
+    out = []
+    out.append(f"template <> struct Tab<{nt}> {{")
+    out.append(f"  static constexpr int kRows = {nt};")
+    out.append(f"  static constexpr int kCompilerVgprs = {budget};")
+    # zero
+    body = "\\n\\t".join(f"v_mov_b32 v{r}, 0" for r in range(t0, TOTAL))
+    out.append("  __device__ static __forceinline__ void zero() {")
+    out.append(f'    asm volatile("{body}" ::: {clob_t});')
+    out.append("  }")
+    # rank1
+    nload = nt // 2
+    depth = NTMP // 4
+    lines = ["s_waitcnt lgkmcnt(0)"]
+    def load(k):
+        slot = k % depth
+        r = tmp0 + 4 * slot
+        return f"ds_read_b128 v[{r}:{r + 3}], %0 offset:{16 * k}"
+    for k in range(min(depth, nload)):
+        lines.append(load(k))
+    for k in range(nload):
+        issued = min(nload, k + depth)
+        lines.append(f"s_waitcnt lgkmcnt({issued - k - 1})")
+        slot = k % depth
+        r = tmp0 + 4 * slot
+        lines.append(f"v_fma_f64 {treg(2 * k)}, v[{r}:{r + 1}], %1, {treg(2 * k)}")
+        lines.append(f"v_fma_f64 {treg(2 * k + 1)}, v[{r + 2}:{r + 3}], %1, {treg(2 * k + 1)}")
+        if k + depth < nload:
+            lines.append(load(k + depth))
+    body = "\\n\\t".join(lines)
+    out.append("  // T[i] += lds[i]*g ; lds_addr = LDS byte address of a 16-byte aligned vector of >= kRows doubles")
+    out.append("  __device__ static __forceinline__ void rank1(unsigned lds_addr, double g) {")
+    out.append(f'    asm volatile("{body}"')
+    out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
+    out.append("  }")
+    # publish
+    lines = [f"ds_write_b64 %0, {treg(i)} offset:{8 * i}" for i in range(nt)]
+    lines.append("s_waitcnt lgkmcnt(0)")
+    body = "\\n\\t".join(lines)
+    out.append("  __device__ static __forceinline__ void publish(unsigned lds_addr) {")
+    out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : "memory");')
+    out.append("  }")
+    # dynamic row read through the VGPR index mode (uniform runtime index, pinned base register)
+    out.append("  // T[k] for a wave-uniform runtime k: s_set_gpr_idx_on + v_mov_b32 relative to the pinned base.")
+    out.append("  __device__ static __forceinline__ double get_dyn(int k) {")
+    out.append("    int lo, hi;")
+    out.append("    const int idx = __builtin_amdgcn_readfirstlane(2 * k);")
+    out.append(f'    asm volatile("s_set_gpr_idx_on %2, gpr_idx(SRC0)\\n\\tv_mov_b32 %0, v{t0}\\n\\tv_mov_b32 %1, v{t0 + 1}\\n\\ts_set_gpr_idx_off"')
+    out.append('                 : "=&v"(lo), "=&v"(hi) : "s"(idx) : "m0");')
+    out.append("    return __hiloint2double(hi, lo);")
+    out.append("  }")
+    # get / set with compile-time index
+    out.append("  template <int I> __device__ static __forceinline__ double get() {")
+    out.append("    int lo, hi;")
+    for i in range(nt):
+        kw = "if" if i == 0 else "else if"
+        out.append(f'    {kw} constexpr (I == {i}) asm volatile("v_mov_b32 %0, v{t0 + 2 * i}\\n\\tv_mov_b32 %1, v{t0 + 2 * i + 1}" : "=v"(lo), "=v"(hi));')
+    out.append("    else { lo = 0; hi = 0; }")
+    out.append("    return __hiloint2double(hi, lo);")
+    out.append("  }")
+    out.append("  template <int I> __device__ static __forceinline__ void set(double x) {")
+    out.append("    const int lo = __double2loint(x), hi = __double2hiint(x);")
+    for i in range(nt):
+        kw = "if" if i == 0 else "else if"
+        out.append(f'    {kw} constexpr (I == {i}) asm volatile("v_mov_b32 v{t0 + 2 * i}, %0\\n\\tv_mov_b32 v{t0 + 2 * i + 1}, %1" :: "v"(lo), "v"(hi) : "v{t0 + 2 * i}", "v{t0 + 2 * i + 1}");')
+    out.append("  }")
+    out.append("};")
+    return "\n".join(out)
+
+
+def main():
+    parts = ["// GENERATED by gen_tab_asm.py — do not edit.  Pinned-VGPR tableau primitives (see the generator's docstring).",
+             "#pragma once", "#include <hip/hip_runtime.h>", "namespace mkh {", "template <int NT> struct Tab;"]
+    parts += [gen(nt) for nt in NTS]
+    parts.append("}  // namespace mkh")
+    with open(os.path.join(HERE, "tab_asm.inc"), "w") as fh:
+        fh.write("\n".join(parts) + "\n")
+
+
+if __name__ == "__main__":
+    main()

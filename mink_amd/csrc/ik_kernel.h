@@ -22,12 +22,14 @@
 #include "lie_dev.h"
 #include "mkh_types.h"
 #include "wave_ops.h"
+#include "tab_asm.inc"
+#include <utility>
 
 namespace mkh {
 
 // ------------------------------------------------------------------ LDS layout
 struct LdsLayout {
-  int q, X, jnt, tgt, task, J, dof, com, col, A, total;  // offsets in doubles
+  int q, X, jnt, tgt, task, J, dof, com, col, A, piv, total;  // offsets in doubles
 };
 __host__ __device__ inline int lds_even(int x) { return (x + 1) & ~1; }
 __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int njnt, int n_frame,
@@ -39,93 +41,88 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
   L.jnt = o;  o += lds_even(njnt * 6);
   L.tgt = o;  o += lds_even(n_frame * 7 + n_com * 3);
   L.task = o; o += n_frame * 48;
-  L.J = o;    o += (n_frame + n_com) * lds_even(nv * 6);
+  L.J = o;    o += (n_frame + n_com) * 6 * kWave;   // weighted Jacobian rows [task][r][64]
   L.dof = o;  o += kWave * 10;
   L.com = o;  o += (n_com > 0 ? nbody * 4 : 0);
   L.col = o;  o += max_rows * 16;
   L.A = o;    o += max_rows * kWave;
+  L.piv = o;  o += kWave;          // pivot column broadcast buffer (16-byte aligned: all offsets are even)
   L.total = o;
   return L;
 }
 
-// ------------------------------------------------------------- tableau access
-// A lane's tableau column is a plain register array `double T[NT]`; every index into it
-// is a compile-time constant after unrolling, so it lives in VGPRs.  hipcc sends any
-// runtime-indexed private array (even a wave-uniform index into an ext_vector) to scratch,
-// so the two places that need row k for a runtime k (wave-uniform) go through a scalar
-// switch: one s_cbranch tree to a leaf that touches a statically named register.
-#define MKH_C1(i)                                  \
-  case (i):                                        \
-    if constexpr ((i) < NT) { MKH_CASE_BODY(i) }   \
-    asm volatile("");                              \
-    break;
-#define MKH_C4(i) MKH_C1(i) MKH_C1((i) + 1) MKH_C1((i) + 2) MKH_C1((i) + 3)
-#define MKH_C16(i) MKH_C4(i) MKH_C4((i) + 4) MKH_C4((i) + 8) MKH_C4((i) + 12)
-#define MKH_C64 MKH_C16(0) MKH_C16(16) MKH_C16(32) MKH_C16(48)
-
-template <int NT>
-__device__ __forceinline__ double tab_get(const double (&T)[NT], int k /*uniform*/) {
-  double r = 0.0;
-#define MKH_CASE_BODY(i) r = T[(i)];
-  switch (k) { MKH_C64 default: break; }
-#undef MKH_CASE_BODY
-  return r;
+// Compile-time loop: f(std::integral_constant<int, I>{}) for I in [0, N).
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
 }
-template <int NT>
-__device__ __forceinline__ void tab_set(double (&T)[NT], int k /*uniform*/, double v) {
-#define MKH_CASE_BODY(i) T[(i)] = v;
-  switch (k) { MKH_C64 default: break; }
-#undef MKH_CASE_BODY
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// Per-lane QP bookkeeping.  Column `lane` of the tableau is stored unscaled in R with
-// a lazy column scale: true T[i][lane] = sc * R[i].
+// LDS byte address of a pointer into the dynamic shared segment (low half of the flat address).
+__device__ __forceinline__ unsigned lds_addr(const double* p) { return (unsigned)(size_t)p; }
+
+// Per-lane QP bookkeeping.  Lane j owns column j of the symmetric tableau, stored unscaled in
+// R[i] with a lazy SYMMETRIC scale:  true T[i][j] = σ_i·σ_j·R[i][j]  (i ≠ j),  true T[j][j] = D.
+// A sweep multiplies row k and column k by ±1/d — that is one scalar update of σ_k, so no register
+// whose index depends on the runtime pivot is ever written (hipcc would send it to scratch, and a
+// scalar switch over statically named registers costs ~500 cycles of branches per access).
 struct QpLane {
-  double z, w, lo, hi, sc, isc;
+  double z, w, lo, hi, sg, D;
   int kind;    // 0 dof, 1 half-space row, 2 padding
   int basic;   // swept into the basis
   int at_hi;   // nonbasic dof sitting at its upper bound (else lower)
 };
 
-// Symmetric sweep (reverse = un-sweep) of the tableau on index k (wave-uniform).
-// rk = R[k][lane] must be passed in (the caller usually has it from the ratio test).
+// Lane `col` publishes its raw tableau column R[0..NT) in LDS (the only cross-lane transport of
+// the QP): every lane then reads its own entry (ratio test / multiplier) and streams the whole
+// vector back with broadcast reads for the rank-1 update.  Entry `col` is published as 0 so that
+// row `col` of every column is left alone by the update (its change is carried by σ_col).
 template <int NT>
-__device__ __forceinline__ void pivot(double (&T)[NT], QpLane& s, int k, bool reverse, double rk, int lane,
-                                      int ntab) {
-  const double pk = s.sc * rk;                 // true T[k][lane]
-  const double d = readlane_f64(pk, k);        // true T[k][k]
+__device__ __forceinline__ void publish_column(int col, int lane, double* sPiv) {
+  // Column `col` equals row `col` (R is symmetric): lane i holds R[col][i] in tableau register
+  // `col`.  One indexed register read (VGPR index mode on the pinned base) + ONE ds_write_b64 for
+  // the whole wave.  Having lane `col` dump its 48 registers itself costs 48 single-lane LDS
+  // writes = 750-1850 cycles (measured, tools/ubench) — half of the whole pivot.
+  const double rowv = Tab<NT>::get_dyn(col);
+  wave_sync();                                   // earlier readers of sPiv are done
+  sPiv[lane] = (lane == col) ? 0.0 : rowv;
+  wave_sync();
+}
+
+// Symmetric sweep (reverse = un-sweep) on index k (wave-uniform); sPiv holds column k.
+template <int NT>
+__device__ __forceinline__ void pivot(QpLane& s, int k, bool reverse, int lane, const double* sPiv) {
+  const double sk = readlane_f64(s.sg, k);
+  const double d = readlane_f64(s.D, k);         // true T[k][k]
   const double inv = 1.0 / d;
-  const double sck = readlane_f64(s.sc, k);
-  const double g = (lane == k) ? 0.0 : rk * (sck * inv);
-#pragma unroll
-  for (int b = 0; b < NT / 16; ++b) {
-    if (b * 16 < ntab) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const double raw = readlane_f64(T[b * 16 + i], k);
-        T[b * 16 + i] = fma(-raw, g, T[b * 16 + i]);
-      }
-    }
-  }
-  // row k of every other column: T[k][j] = ±T[k][j]/d   (R units: ±rk·inv)
-  const double sgn = reverse ? -1.0 : 1.0;
-  double newk = sgn * rk * inv;
+  const double own = sPiv[lane];                 // raw R[lane][k]  (0 for lane k)
+  const double ck = s.sg * sk * own;             // true T[lane][k]
+  const double g = (sk * sk) * own * inv;        // R-units multiplier of this lane's column
+  Tab<NT>::rank1(lds_addr(sPiv), -g);            // R[i][lane] −= R[i][k]·g   (row k: published 0)
   if (lane == k) {
-    // column k: T[i][k] = ±T[i][k]/d via the lazy scale; T[k][k] = −1/d
-    newk = -sgn * s.isc;                       // (−1/d) / (±sc/d)
-    s.sc = sgn * s.sc * inv;
-    s.isc = sgn * s.isc * d;
+    s.D = -inv;                                  // T[k][k] = −1/d
+    s.sg = (reverse ? -sk : sk) * inv;           // row/column k scaled by ±1/d
+  } else {
+    s.D = fma(-ck * inv, ck, s.D);               // T[j][j] −= T[j][k]²/d
   }
-  tab_set<NT>(T, k, newk);
 }
 
 // ----------------------------------------------------------------- the kernel
-template <int NB>
-__global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, const SolveArgs A) {
+template <int NT>
+// P lives in device memory (not in the kernarg segment): hipcc materialises every by-value kernel
+// argument field in SGPRs at kernel entry and keeps it there, which starved the QP loop of SGPRs
+// (580 SGPR spills, v_readlane results serialised through one SGPR pair).
+#define MKH_TAP(f) (tp ? tp->f : nullptr)
+__global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __restrict__ Pg, const SolveArgs A,
+                                                         const TapArgs* __restrict__ tp) {
+  const DeviceProblem& P0 = *Pg;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = lane_id();
-  const int nq = P.nq, nv = P.nv, nbody = P.nbody;
-  const LdsLayout L = lds_layout(nq, nv, nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows);
+  const int nq = P0.nq, nv = P0.nv, nbody = P0.nbody;
+  const LdsLayout L = lds_layout(nq, nv, nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows);
   double* const sq = smem + L.q;
   double* const sX = smem + L.X;
   double* const sJnt = smem + L.jnt;
@@ -136,20 +133,27 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
   double* const sCom = smem + L.com;
   double* const sCol = smem + L.col;
   double* const sA = smem + L.A;
-  constexpr int NT = NB * 16;
+  double* const sPiv = smem + L.piv;
   const double kInf = __builtin_huge_val();
 
   const bool is_body = lane < nbody;
   const bool is_dof = lane < nv;
-  const int ntab = nv + P.max_rows;                   // tableau indices in use (upper bound)
+  const int ntab = nv + P0.max_rows;                   // tableau indices in use (upper bound)
 
   for (int pb = blockIdx.x; pb < A.B; pb += gridDim.x) {
     int status = 0;
+    long long tc[8];
+    int tci = 0;
+#define MKH_TICK() do { if (MKH_TAP(t_cycles)) tc[tci] = __builtin_readcyclecounter(); ++tci; } while (0)
+    MKH_TICK();   // 0: start
     // Opaque per-iteration zero: table loads below are indexed with it so that LICM cannot hoist
     // them out of the problem loop and keep ~60 VGPRs of lane constants live through the QP.
     int oz;
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
     const int ol = lane + oz;
+    const DeviceProblem* Pq = Pg;
+    asm volatile("" : "+s"(Pq));          // opaque: descriptor fields are (re)loaded where they are used
+    const DeviceProblem& P = *Pq;
     wave_sync();  // previous problem's LDS readers are done
     // ------------------------------------------------------------ load inputs
     for (int i = lane; i < nq; i += 64) sq[i] = A.q[(size_t)pb * nq + i];
@@ -220,16 +224,17 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
     if (is_body) {
       double* o = sX + lane * 8;
       o[0] = xp.x; o[1] = xp.y; o[2] = xp.z; o[3] = xq.w; o[4] = xq.x; o[5] = xq.y; o[6] = xq.z;
-      if (A.t_xpos) {
-        double* t = A.t_xpos + ((size_t)pb * nbody + lane) * 3;
+      if (MKH_TAP(t_xpos)) {
+        double* t = MKH_TAP(t_xpos) + ((size_t)pb * nbody + lane) * 3;
         t[0] = xp.x; t[1] = xp.y; t[2] = xp.z;
       }
-      if (A.t_xquat) {
-        double* t = A.t_xquat + ((size_t)pb * nbody + lane) * 4;
+      if (MKH_TAP(t_xquat)) {
+        double* t = MKH_TAP(t_xquat) + ((size_t)pb * nbody + lane) * 4;
         t[0] = xq.w; t[1] = xq.x; t[2] = xq.y; t[3] = xq.z;
       }
     }
     wave_sync();
+    MKH_TICK();   // 1: FK done
     // --------------------- joint anchors / axes in the world (xanchor, xaxis)
     if (is_body && b_jnum > 0) {
       if (b_jnum == 1) {
@@ -368,9 +373,10 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
       wave_sync();
       const double* cr = sCom + P.robot_root * 4;
       com_root = {cr[0], cr[1], cr[2]};
-      if (A.t_subtree_com && lane < 3) A.t_subtree_com[(size_t)pb * 3 + lane] = cr[lane];
+      if (MKH_TAP(t_subtree_com) && lane < 3) MKH_TAP(t_subtree_com)[(size_t)pb * 3 + lane] = cr[lane];
     }
 
+    MKH_TICK();   // 2: joint axes / dof lanes / com done
     // ------------------------------------------- task lanes: pose, error, jlog
     double mu_lane = 0.0;  // Levenberg–Marquardt term of the task owned by this lane
     if (lane < P.n_frame) {
@@ -401,16 +407,17 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
         const double we = ft.cost[r] * (-ft.gain * e6[r]);  // weighted_error (task.py:129-130)
         o[30 + r] = we;
         ss += we * we;
-        if (A.t_task_e) A.t_task_e[(size_t)pb * P.n_rows_tap + ft.row0 + r] = e6[r];
+        if (MKH_TAP(t_task_e)) MKH_TAP(t_task_e)[(size_t)pb * P.n_rows_tap + ft.row0 + r] = e6[r];
       }
       mu_lane = ft.lm_damping * ss;                          // task.py:131
-      if (A.t_frame_pose) {
-        double* t = A.t_frame_pose + ((size_t)pb * P.n_frame + lane) * 7;
+      if (MKH_TAP(t_frame_pose)) {
+        double* t = MKH_TAP(t_frame_pose) + ((size_t)pb * P.n_frame + lane) * 7;
         t[0] = F.q.w; t[1] = F.q.x; t[2] = F.q.y; t[3] = F.q.z; t[4] = F.p.x; t[5] = F.p.y; t[6] = F.p.z;
       }
     }
     double mu_total = A.damping + wave_sum(mu_lane);         // solve_ik.py:16 + Σ μ_t
 
+    MKH_TICK();   // 3: task lanes done
     // ------------------------------------------- posture tasks (diagonal)
     double c_lane = 0.0;   // c[lane]
     double hdiag = 0.0;    // H[lane][lane]
@@ -441,10 +448,10 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
       hdiag += wj * wj;
       c_lane -= we * wj;
       if (P.posture_lm[t] != 0.0) mu_total += P.posture_lm[t] * wave_sum(we * we);
-      if (A.t_task_e && is_dof) A.t_task_e[(size_t)pb * P.n_rows_tap + P.posture_row0[t] + lane] = e;
-      if (A.t_task_J && is_dof) {
+      if (MKH_TAP(t_task_e) && is_dof) MKH_TAP(t_task_e)[(size_t)pb * P.n_rows_tap + P.posture_row0[t] + lane] = e;
+      if (MKH_TAP(t_task_J) && is_dof) {
         for (int r = 0; r < nv; ++r)
-          A.t_task_J[((size_t)pb * P.n_rows_tap + P.posture_row0[t] + r) * nv + lane] = (r == lane) ? jd : 0.0;
+          MKH_TAP(t_task_J)[((size_t)pb * P.n_rows_tap + P.posture_row0[t] + r) * nv + lane] = (r == lane) ? jd : 0.0;
       }
     }
     // ComTask error & LM term (com_task.py:71-82)
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
       for (int r = 0; r < 3; ++r) {
         const double we = P.com_cost[t][r] * (-P.com_gain[t] * e3[r]);
         ss += we * we;
-        if (A.t_task_e && lane == 0) A.t_task_e[(size_t)pb * P.n_rows_tap + P.com_row0[t] + r] = e3[r];
+        if (MKH_TAP(t_task_e) && lane == 0) MKH_TAP(t_task_e)[(size_t)pb * P.n_rows_tap + P.com_row0[t] + r] = e3[r];
       }
       mu_total += P.com_lm[t] * ss;
     }
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
 
     // ------------------------------ frame + CoM tasks: Jacobian columns, H, c
     const int n_jt = P.n_frame + P.n_com;
-    const int jstride = lds_even(nv * 6);
+    const int jstride = 6 * kWave;
     for (int t = 0; t < n_jt; ++t) {
       double Jt[6] = {0, 0, 0, 0, 0, 0}, cw[6] = {0, 0, 0, 0, 0, 0}, we6[6] = {0, 0, 0, 0, 0, 0};
       uint64_t mask;
@@ -528,10 +535,10 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
           }
         }
       }
-      if (A.t_task_J && is_dof) {
+      if (MKH_TAP(t_task_J) && is_dof) {
 #pragma unroll
         for (int r = 0; r < 6; ++r)
-          if (r < nrow) A.t_task_J[((size_t)pb * P.n_rows_tap + row0 + r) * nv + lane] = Jt[r];
+          if (r < nrow) MKH_TAP(t_task_J)[((size_t)pb * P.n_rows_tap + row0 + r) * nv + lane] = Jt[r];
       }
       double Jw[6];
 #pragma unroll
@@ -540,13 +547,14 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
         c_lane -= we6[r] * Jw[r];                            // c = −weighted_errorᵀ·weighted_jacobian
         hdiag += Jw[r] * Jw[r];
       }
-      if (is_dof) {
-        double* o = sJ + t * jstride + lane * 6;
+      {
+        double* o = sJ + t * jstride + lane;                   // row r of task t: sJ[t][r][0..63]
 #pragma unroll
-        for (int r = 0; r < 6; ++r) o[r] = Jw[r];
+        for (int r = 0; r < 6; ++r) o[r * kWave] = is_dof ? Jw[r] : 0.0;
       }
     }
-    if (A.t_c && is_dof) A.t_c[(size_t)pb * nv + lane] = c_lane;
+    if (MKH_TAP(t_c) && is_dof) MKH_TAP(t_c)[(size_t)pb * nv + lane] = c_lane;
+    MKH_TICK();   // 4: posture + task Jacobian columns done
     // ------------------------------------------------------------ box limits
     // lo ≤ Δq ≤ hi from ConfigurationLimit rows (configuration_limit.py:94-124) and
     // VelocityLimit rows (velocity_limit.py:96-101); never materialise the dense G.
@@ -562,8 +570,8 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
         const double vm = P.vel_limit[t * 64 + lane];
         if (vm < kInf) { hi = fmin(hi, A.dt * vm); lo = fmax(lo, -(A.dt * vm)); }
       }
-      if (A.t_box_lo) A.t_box_lo[(size_t)pb * nv + lane] = lo;
-      if (A.t_box_hi) A.t_box_hi[(size_t)pb * nv + lane] = hi;
+      if (MKH_TAP(t_box_lo)) MKH_TAP(t_box_lo)[(size_t)pb * nv + lane] = lo;
+      if (MKH_TAP(t_box_hi)) MKH_TAP(t_box_hi)[(size_t)pb * nv + lane] = hi;
     }
 
     // ------------------------------------------- collision half-space rows
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
             m1 = cp.mask1;
             m2 = cp.mask2;
           }
-          if (A.t_coll_h) A.t_coll_h[(size_t)pb * P.n_pairs + pi] = hk;
+          if (MKH_TAP(t_coll_h)) MKH_TAP(t_coll_h)[(size_t)pb * P.n_pairs + pi] = hk;
         }
         const unsigned long long am = __ballot(active);
         const int slot = nrows + __popcll(am & ((1ull << lane) - 1ull));
@@ -624,75 +632,60 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
           if ((m2 >> lane) & 1) dj = dj + d_lin + cross(d_ang, V3{o[6], o[7], o[8]} - d_anchor);
           if ((m1 >> lane) & 1) dj = dj - (d_lin + cross(d_ang, V3{o[3], o[4], o[5]} - d_anchor));
           a = -dot(n, dj);
-          if (A.t_coll_G) A.t_coll_G[((size_t)pb * P.n_pairs + (int)o[12]) * nv + lane] = a;
+          if (MKH_TAP(t_coll_G)) MKH_TAP(t_coll_G)[((size_t)pb * P.n_pairs + (int)o[12]) * nv + lane] = a;
         }
         sA[s * 64 + lane] = a;
       }
     }
     wave_sync();
 
-    if (!A.do_qp && !A.t_H) continue;
+    MKH_TICK();   // 5: limits + collision rows done
+    if (!A.do_qp && !MKH_TAP(t_H)) continue;
 
     // ------------------------------------------------- build the tableau column
     // lane j holds column j of K = [[H, Aᵀ],[A, 0]].  Built only now so that the 2·NT tableau
     // VGPRs are not live during FK / task / collision phases.
-    double T[NT];
-    {
-      const double dg = is_dof ? hdiag_base : ((lane >= ntab) ? 1.0 : 0.0);
-#pragma unroll
-      for (int i = 0; i < NT; ++i) T[i] = (lane == i) ? dg : 0.0;
-    }
+    // The column lives in pinned VGPRs (tab_asm.inc); the diagonal of K is carried separately (s.D),
+    // the diagonal register of the column is never read as a value.
+    Tab<NT>::zero();
     for (int t = 0; t < n_jt; ++t) {
-      uint64_t mask = ~0ull;
       bool second_half = false;
-      if (t < P.n_frame) { mask = P.frame[t].dof_mask; second_half = P.frame[t].any_ori != 0; }
+      if (t < P.n_frame) second_half = P.frame[t].any_ori != 0;
       const double* base = sJ + t * jstride;
-      double Jw[6] = {0, 0, 0, 0, 0, 0};
-      if (is_dof) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) Jw[r] = base[lane * 6 + r];
-      }
-      // H[i][lane] += Σ_r Jw[r][i]·Jw[r][lane], rows i restricted to the task's chain
-#pragma unroll
-      for (int row = 0; row < NT; ++row) {
-        if (row < nv && ((mask >> row) & 1)) {
-          const double* o = base + row * 6;
-          double acc = T[row];
-          acc = fma(o[0], Jw[0], acc);
-          acc = fma(o[1], Jw[1], acc);
-          acc = fma(o[2], Jw[2], acc);
-          if (second_half) {
-            acc = fma(o[3], Jw[3], acc);
-            acc = fma(o[4], Jw[4], acc);
-            acc = fma(o[5], Jw[5], acc);
-          }
-          T[row] = acc;
-        }
-      }
+      const int nrow = second_half ? 6 : 3;
+      // H[:, lane] += Σ_r Jw_r · Jw_r[lane]: one rank-1 update per weighted Jacobian row
+      for (int r = 0; r < nrow; ++r) Tab<NT>::rank1(lds_addr(base + r * kWave), base[r * kWave + lane]);
     }
-    if (A.t_H && is_dof) {
-#pragma unroll
-      for (int i = 0; i < NT; ++i)
-        if (i < nv) A.t_H[((size_t)pb * nv + i) * nv + lane] = T[i];
+    if (MKH_TAP(t_H) && is_dof) {
+      double* hrow = MKH_TAP(t_H) + (size_t)pb * nv * nv + lane;
+      static_for<NT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (i < nv) hrow[(size_t)i * nv] = (i == lane) ? hdiag : Tab<NT>::template get<i>();
+      });
     }
     if (!A.do_qp) continue;
     if (nrows > 0) {
-      // rows nv+s of the dof columns, and column nv+s (owned by lane nv+s) = A[s][:]
-      for (int s = 0; s < nrows; ++s) tab_set<NT>(T, nv + s, is_dof ? sA[s * 64 + lane] : 0.0);
+      // rows nv+s of the dof columns (static register index, runtime LDS address) ...
+      static_for<NT>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if (i >= nv && i < nv + nrows) Tab<NT>::template set<i>(is_dof ? sA[(i - nv) * 64 + lane] : 0.0);
+      });
+      // ... and column nv+s (owned by lane nv+s) = A[s][:]
       if (lane >= nv && lane < nv + nrows) {
         const double* o = sA + (lane - nv) * 64;
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-          if (i < nv) T[i] = o[i];
+        static_for<NT>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          if (i < nv) Tab<NT>::template set<i>(o[i]);
+        });
       }
     }
-
 
     // ====================================================================== QP
     // Dual active set (Goldfarb–Idnani) on the sweep tableau; see tools/proto_tableau_qp.py
     // for the numpy statement of the same algorithm.
     QpLane s;
-    s.sc = 1.0; s.isc = 1.0; s.basic = 0; s.at_hi = 0;
+    s.sg = 1.0; s.basic = 0; s.at_hi = 0;
+    s.D = is_dof ? hdiag : ((lane >= ntab) ? 1.0 : 0.0);   // true diagonal of K
     s.z = 0.0;
     double rown = 1.0;
     if (is_dof) {
@@ -712,6 +705,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
     const double hmax = wave_max(is_dof ? hdiag : 0.0);
     const double thr_dof = 1e-13 / (hmax * (double)nv);
 
+    MKH_TICK();   // 6: tableau built
     // One loop drives both phases so that the sweep is instantiated once:
     //   phase 0 (k0 < nv): bring dof k0 into the basis, x0 = −H⁻¹c (Gauss–Jordan, no ratio test)
     //   phase 1: GI — pick the most violated primal condition p, then step/pivot until p is resolved.
@@ -721,21 +715,17 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
     int p = -1;          // GI: index being driven (−1 ⇒ select a new one)
     bool p_basic = false, upper = false;
     double beta = 0.0, sgn = 1.0, thr = 0.0;
+    // Each iteration = publish ONE column `col`, (ratio-)test on it, then optionally sweep on the
+    // same column.  A blocking constraint l found by the ratio test becomes the column of the next
+    // iteration (`pend`), so the loop has a single publish site and a single sweep site.
+    int pend = -1;       // pending sweep of a blocking index (reverse flag in pend_rev)
+    bool pend_rev = false;
     while (!(status & 14)) {
-      int piv;
-      bool rev;
-      double rk;
-      if (k0 < nv) {
-        piv = k0++;
-        rev = false;
-        rk = tab_get<NT>(T, piv);
-        const double tau = s.sc * rk;
-        const double d = readlane_f64(tau, piv);
-        if (!(d > 0.0)) { status |= 4; break; }
-        const double alpha = -readlane_f64(s.w, piv) / d;
-        if (s.basic) s.z -= alpha * tau; else s.w += alpha * tau;
-        if (lane == piv) { s.z += alpha; s.w = 0.0; s.basic = 1; }
-      } else {
+      const bool ph0 = k0 < nv;
+      int col;
+      if (ph0) col = k0;
+      else if (pend >= 0) col = pend;
+      else {
         if (p < 0) {
           // ---- most violated primal condition (GI step 1)
           double viol = 0.0;
@@ -757,9 +747,24 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
           thr = p_basic ? thr_dof : thr_dof * rn * rn;
         }
         if (++iters > max_iters) { status |= 8; break; }
-        rk = tab_get<NT>(T, p);
-        const double tau = s.sc * rk;                            // column p of the tableau
-        const double tpp = readlane_f64(tau, p);
+        col = p;
+      }
+      publish_column<NT>(col, lane, sPiv);
+      bool do_sweep = true, rev = false;
+      if (ph0) {
+        ++k0;
+        const double d = readlane_f64(s.D, col);
+        if (!(d > 0.0)) { status |= 4; break; }
+        const double tau = (lane == col) ? d : s.sg * readlane_f64(s.sg, col) * sPiv[lane];
+        const double alpha = -readlane_f64(s.w, col) / d;
+        if (s.basic) s.z -= alpha * tau; else s.w += alpha * tau;
+        if (lane == col) { s.z += alpha; s.w = 0.0; s.basic = 1; }
+      } else if (pend >= 0) {
+        rev = pend_rev;
+        pend = -1;
+      } else {
+        const double tpp = readlane_f64(s.D, p);
+        const double tau = (lane == p) ? tpp : s.sg * readlane_f64(s.sg, p) * sPiv[lane];
         // full step length t2 (GI step 2b)
         double t2 = kInf;
         if (p_basic) {
@@ -788,22 +793,23 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem P, 
             if (p_basic) { s.z = beta; s.basic = 0; s.at_hi = upper ? 1 : 0; }
             else { s.w = 0.0; s.basic = 1; }
           }
-          piv = p;
           rev = p_basic;
           p = -1;
         } else {
-          piv = first_lane(t == t1);
-          rev = readlane_i32(s.basic, piv) != 0;
-          if (lane == piv) {
-            if (rev) { s.z = 0.0; s.basic = 0; }                // row leaves the active set
+          pend = first_lane(t == t1);                           // blocking index: sweep it next iteration
+          pend_rev = readlane_i32(s.basic, pend) != 0;
+          if (lane == pend) {
+            if (pend_rev) { s.z = 0.0; s.basic = 0; }           // row leaves the active set
             else { s.w = 0.0; s.basic = 1; }                    // dof leaves its bound
           }
-          rk = tab_get<NT>(T, piv);
+          do_sweep = false;
         }
       }
-      pivot<NT>(T, s, piv, rev, rk, lane, ntab);
+      if (do_sweep) pivot<NT>(s, col, rev, lane, sPiv);
     }
-    if (A.t_qp_iters && lane == 0) A.t_qp_iters[pb] = iters;
+    MKH_TICK();   // 7: QP done
+    if (MKH_TAP(t_cycles) && lane < 8) MKH_TAP(t_cycles)[(size_t)pb * 8 + lane] = (lane == 0) ? tc[0] : (lane == 1) ? tc[1] : (lane == 2) ? tc[2] : (lane == 3) ? tc[3] : (lane == 4) ? tc[4] : (lane == 5) ? tc[5] : (lane == 6) ? tc[6] : tc[7];
+    if (MKH_TAP(t_qp_iters) && lane == 0) MKH_TAP(t_qp_iters)[pb] = iters;
     if (A.v_out && is_dof) {
       const double bad = __builtin_nan("");
       A.v_out[(size_t)pb * nv + lane] = (status & 14) ? bad : s.z / A.dt;   // v = dq / dt (solve_ik.py:104)

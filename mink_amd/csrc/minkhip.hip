@@ -67,7 +67,7 @@ struct MkhModel {
 struct MkhProblem {
   MkhModel* model = nullptr;
   DeviceProblem dev{};
-  int nb = 1;  // tableau blocks of 16
+  int nt = 8;  // tableau rows per lane (compiled variants: multiples of 8)
   int max_batch = 0;
   int lds_bytes = 0;
   int blocks_per_cu = 1;
@@ -76,6 +76,8 @@ struct MkhProblem {
   double* d_posture_cost = nullptr;
   double *d_cfg_lower = nullptr, *d_cfg_upper = nullptr, *d_vel = nullptr;
   CollisionPairDev* d_pairs = nullptr;
+  DeviceProblem* d_dev = nullptr;   // device copy of `dev` (the kernel reads the descriptor from memory)
+  TapArgs* d_taps = nullptr;
   // staging buffers for host-pointer calls
   double *s_q = nullptr, *s_ft = nullptr, *s_pt = nullptr, *s_ct = nullptr, *s_v = nullptr;
   int32_t* s_status = nullptr;
@@ -377,8 +379,8 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   P.n_pairs = (int)pairs.size();
   P.max_rows = P.n_pairs < (kWave - m->nv) ? P.n_pairs : (kWave - m->nv);
   const int ntab = m->nv + P.max_rows;
-  p->nb = (ntab + 15) / 16;
-  if (p->nb < 1) p->nb = 1;
+  p->nt = ((ntab + 7) / 8) * 8;
+  if (p->nt < 8) p->nt = 8;
 
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = upload(ft, &p->d_frame);
@@ -398,6 +400,10 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   int by_lds = (160 * 1024) / (p->lds_bytes > 0 ? p->lds_bytes : 1);
   p->blocks_per_cu = by_lds < 8 ? by_lds : 8;
   if (p->blocks_per_cu < 1) p->blocks_per_cu = 1;
+  if (hipMalloc((void**)&p->d_dev, sizeof(DeviceProblem)) != hipSuccess ||
+      hipMemcpy(p->d_dev, &p->dev, sizeof(DeviceProblem), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc((void**)&p->d_taps, sizeof(TapArgs)) != hipSuccess)
+    return bail(fail(MKH_E_HIP, "descriptor upload failed"));
   *out = p;
   return MKH_OK;
 }
@@ -406,7 +412,7 @@ void mkh_problem_destroy(MkhProblem* p) {
   if (!p) return;
   hipSetDevice(p->model->device);
   hipFree(p->d_frame); hipFree(p->d_posture_cost); hipFree(p->d_cfg_lower); hipFree(p->d_cfg_upper);
-  hipFree(p->d_vel); hipFree(p->d_pairs);
+  hipFree(p->d_vel); hipFree(p->d_pairs); hipFree(p->d_dev); hipFree(p->d_taps);
   hipFree(p->s_q); hipFree(p->s_ft); hipFree(p->s_pt); hipFree(p->s_ct); hipFree(p->s_v); hipFree(p->s_status);
   delete p;
 }
@@ -425,18 +431,25 @@ int32_t mkh_problem_launch_info(const MkhProblem* p, int32_t B, int32_t* grid, i
   if (grid) *grid = grid_for(p, B);
   if (block) *block = kWave;
   if (lds_bytes) *lds_bytes = p->lds_bytes;
-  if (tableau_rows) *tableau_rows = p->nb * 16;
+  if (tableau_rows) *tableau_rows = p->nt;
   return MKH_OK;
 }
 
-static int32_t launch(MkhProblem* p, const SolveArgs& a, hipStream_t stream) {
-  const int grid = grid_for(p, a.B);
-  switch (p->nb) {
-    case 1: hipLaunchKernelGGL(ik_solve_kernel<1>, dim3(grid), dim3(kWave), p->lds_bytes, stream, p->dev, a); break;
-    case 2: hipLaunchKernelGGL(ik_solve_kernel<2>, dim3(grid), dim3(kWave), p->lds_bytes, stream, p->dev, a); break;
-    case 3: hipLaunchKernelGGL(ik_solve_kernel<3>, dim3(grid), dim3(kWave), p->lds_bytes, stream, p->dev, a); break;
-    default: hipLaunchKernelGGL(ik_solve_kernel<4>, dim3(grid), dim3(kWave), p->lds_bytes, stream, p->dev, a); break;
+static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hipStream_t stream) {
+  const TapArgs* dtaps = nullptr;
+  if (taps) {
+    HIP_OK(hipMemcpyAsync(p->d_taps, taps, sizeof(TapArgs), hipMemcpyHostToDevice, stream));
+    HIP_OK(hipStreamSynchronize(stream));   // taps are a debug path: keep the host struct's lifetime simple
+    dtaps = p->d_taps;
   }
+  const int grid = grid_for(p, a.B);
+#define MKH_LAUNCH(N) \
+  case N: hipLaunchKernelGGL(ik_solve_kernel<N>, dim3(grid), dim3(kWave), p->lds_bytes, stream, p->d_dev, a, dtaps); break;
+  switch (p->nt) {
+    MKH_LAUNCH(8) MKH_LAUNCH(16) MKH_LAUNCH(24) MKH_LAUNCH(32) MKH_LAUNCH(40) MKH_LAUNCH(48) MKH_LAUNCH(56)
+    default: hipLaunchKernelGGL(ik_solve_kernel<64>, dim3(grid), dim3(kWave), p->lds_bytes, stream, p->d_dev, a, dtaps); break;
+  }
+#undef MKH_LAUNCH
   HIP_OK(hipGetLastError());
   return MKH_OK;
 }
@@ -462,6 +475,9 @@ int32_t mkh_eval(MkhProblem* p, int32_t B, const double* q, const double* frame_
   const bool pbat = (flags & MKH_FLAG_POSTURE_BATCHED) != 0, cbat = (flags & MKH_FLAG_COM_BATCHED) != 0;
   SolveArgs a;
   memset(&a, 0, sizeof a);
+  TapArgs t;
+  memset(&t, 0, sizeof t);
+  bool any_tap = false;
   a.B = B; a.posture_batched = pbat; a.com_batched = cbat; a.do_qp = (v_out != nullptr);
   a.dt = dt; a.damping = damping;
   const size_t nq = P.nq, nv = P.nv;
@@ -471,13 +487,13 @@ int32_t mkh_eval(MkhProblem* p, int32_t B, const double* q, const double* frame_
     a.q = q; a.frame_targets = frame_targets; a.posture_target = posture_target; a.com_target = com_target;
     a.v_out = v_out; a.status_out = status_out;
     if (taps) {
-      a.t_xpos = taps->xpos; a.t_xquat = taps->xquat; a.t_frame_pose = taps->frame_pose;
-      a.t_subtree_com = taps->subtree_com; a.t_task_e = taps->task_e; a.t_task_J = taps->task_J; a.t_H = taps->H;
-      a.t_c = taps->c; a.t_box_lo = taps->box_lo; a.t_box_hi = taps->box_hi; a.t_coll_G = taps->coll_G;
-      a.t_coll_h = taps->coll_h; a.t_qp_iters = taps->qp_iters;
-      if (a.t_coll_G) HIP_OK(hipMemsetAsync(a.t_coll_G, 0, (size_t)B * P.n_pairs * nv * sizeof(double), stream));
+      t.t_xpos = taps->xpos; t.t_xquat = taps->xquat; t.t_frame_pose = taps->frame_pose;
+      t.t_subtree_com = taps->subtree_com; t.t_task_e = taps->task_e; t.t_task_J = taps->task_J; t.t_H = taps->H;
+      t.t_c = taps->c; t.t_box_lo = taps->box_lo; t.t_box_hi = taps->box_hi; t.t_coll_G = taps->coll_G;
+      t.t_coll_h = taps->coll_h; t.t_qp_iters = taps->qp_iters; t.t_cycles = (long long*)taps->cycles;
+      if (t.t_coll_G) HIP_OK(hipMemsetAsync(t.t_coll_G, 0, (size_t)B * P.n_pairs * nv * sizeof(double), stream));
     }
-    return launch(p, a, stream);
+    return launch(p, a, taps ? &t : nullptr, stream);
   }
   // ---- host pointers: stage through library-owned device buffers
   if (B > p->max_batch) return fail(MKH_E_INVALID, "B=%d exceeds max_batch=%d of this problem", B, p->max_batch);
@@ -506,21 +522,22 @@ int32_t mkh_eval(MkhProblem* p, int32_t B, const double* q, const double* frame_
   };
   if (taps) {
     const size_t Bz = B;
-    a.t_xpos = (double*)tap(taps->xpos, Bz * P.nbody * 3 * 8, false);
-    a.t_xquat = (double*)tap(taps->xquat, Bz * P.nbody * 4 * 8, false);
-    a.t_frame_pose = (double*)tap(taps->frame_pose, Bz * P.n_frame * 7 * 8, false);
-    a.t_subtree_com = (double*)tap(taps->subtree_com, Bz * 3 * 8, true);
-    a.t_task_e = (double*)tap(taps->task_e, Bz * P.n_rows_tap * 8, true);
-    a.t_task_J = (double*)tap(taps->task_J, Bz * P.n_rows_tap * nv * 8, true);
-    a.t_H = (double*)tap(taps->H, Bz * nv * nv * 8, false);
-    a.t_c = (double*)tap(taps->c, Bz * nv * 8, false);
-    a.t_box_lo = (double*)tap(taps->box_lo, Bz * nv * 8, false);
-    a.t_box_hi = (double*)tap(taps->box_hi, Bz * nv * 8, false);
-    a.t_coll_G = (double*)tap(taps->coll_G, Bz * P.n_pairs * nv * 8, true);
-    a.t_coll_h = (double*)tap(taps->coll_h, Bz * P.n_pairs * 8, false);
-    a.t_qp_iters = (int32_t*)tap(taps->qp_iters, Bz * 4, true);
+    t.t_xpos = (double*)tap(taps->xpos, Bz * P.nbody * 3 * 8, false);
+    t.t_xquat = (double*)tap(taps->xquat, Bz * P.nbody * 4 * 8, false);
+    t.t_frame_pose = (double*)tap(taps->frame_pose, Bz * P.n_frame * 7 * 8, false);
+    t.t_subtree_com = (double*)tap(taps->subtree_com, Bz * 3 * 8, true);
+    t.t_task_e = (double*)tap(taps->task_e, Bz * P.n_rows_tap * 8, true);
+    t.t_task_J = (double*)tap(taps->task_J, Bz * P.n_rows_tap * nv * 8, true);
+    t.t_H = (double*)tap(taps->H, Bz * nv * nv * 8, false);
+    t.t_c = (double*)tap(taps->c, Bz * nv * 8, false);
+    t.t_box_lo = (double*)tap(taps->box_lo, Bz * nv * 8, false);
+    t.t_box_hi = (double*)tap(taps->box_hi, Bz * nv * 8, false);
+    t.t_coll_G = (double*)tap(taps->coll_G, Bz * P.n_pairs * nv * 8, true);
+    t.t_coll_h = (double*)tap(taps->coll_h, Bz * P.n_pairs * 8, false);
+    t.t_qp_iters = (int32_t*)tap(taps->qp_iters, Bz * 4, true);
+    t.t_cycles = (long long*)tap(taps->cycles, Bz * 8 * 8, true);
   }
-  if (rc == MKH_OK) rc = launch(p, a, stream);
+  if (rc == MKH_OK) rc = launch(p, a, taps ? &t : nullptr, stream);
   if (rc == MKH_OK) {
     hipError_t e = hipSuccess;
     if (v_out) e = hipMemcpyAsync(v_out, p->s_v, (size_t)B * nv * sizeof(double), hipMemcpyDeviceToHost, stream);

@@ -90,10 +90,15 @@ struct SolveArgs {
   double dt, damping;
   double* v_out;                   // (B, nv)
   int32_t* status_out;             // (B,)
-  // taps (nullable)
+};
+
+// Debug/parity taps (nullable pointers).  Lives in device memory and is passed by pointer so
+// that a production launch (taps == nullptr) does not pin 28 SGPRs of null pointers.
+struct TapArgs {
   double *t_xpos, *t_xquat, *t_frame_pose, *t_subtree_com, *t_task_e, *t_task_J, *t_H, *t_c, *t_box_lo,
       *t_box_hi, *t_coll_G, *t_coll_h;
   int32_t* t_qp_iters;
+  long long* t_cycles;             // (B, 8) shader-clock stamps at phase boundaries (profiling)
 };
 
 }  // namespace mkh

@@ -34,7 +34,7 @@ def test_version_and_struct_layout(lib):
     # ctypes mirrors must match the C layout the library was compiled with
     assert ctypes.sizeof(nat.MkhFrameTaskDesc) == 8 + 6 * 8 + 16
     assert ctypes.sizeof(nat.MkhComTaskDesc) == 3 * 8 + 16
-    assert ctypes.sizeof(nat.MkhTaps) == 13 * ctypes.sizeof(ctypes.c_void_p)
+    assert ctypes.sizeof(nat.MkhTaps) == 14 * ctypes.sizeof(ctypes.c_void_p)
 
 
 def test_no_gpu_fails_loudly(lib):

@@ -1,0 +1,25 @@
+"""Per-phase shader-clock breakdown of ik_solve_kernel (cycles tap).  GPU only.
+    python tools/phase_profile.py [B]"""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mink_amd import _native as nat, workloads
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+model = workloads.load_robot("g1")
+nm = nat.NativeModel(model)
+prob, dt, damping = workloads.g1_config(model, nm, B)
+stand = model.key_qpos[0]
+q, tg = workloads.make_batch(model, nm, prob, np.random.default_rng(0), B, base_q=stand)
+for _ in range(2):
+    v, st, t = prob.solve(q, tg, stand[None, :], None, dt, damping, taps=["cycles", "qp_iters"])
+c = t["cycles"].astype(np.int64)
+d = np.diff(c, axis=1)
+names = ["load+FK", "axes/dof/com", "task lanes", "posture+J cols", "limits+coll", "build T", "QP"]
+tot = (c[:, 7] - c[:, 0])
+print("launch", prob.launch_info(B))
+print("per-problem wave cycles: mean %.0f  p50 %.0f  p99 %.0f  max %d" % (tot.mean(), np.median(tot), np.percentile(tot, 99), tot.max()))
+for k, n in enumerate(names):
+    print("  %-16s mean %8.0f  (%4.1f%%)" % (n, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean()))
+it = t["qp_iters"]
+print("pivots after x0: mean %.1f; QP cycles per pivot (incl. phase 0's %d): %.0f" % (it.mean(), model.nv, d[:, 6].mean() / (it.mean() + model.nv)))
