@@ -43,16 +43,21 @@ def gen(nt: int) -> str:
     out.append("  __device__ static __forceinline__ void zero() {")
     out.append(f'    asm volatile("{body}" ::: {clob_t});')
     out.append("  }")
-    # rank1
+    # rank1 = prefetch (first `depth` loads) + body; the split lets the caller put the reciprocal /
+    # multiplier arithmetic between them so that the LDS latency of the first loads is hidden.
     nload = nt // 2
     depth = NTMP // 4
-    lines = ["s_waitcnt lgkmcnt(0)"]
     def load(k):
         slot = k % depth
         r = tmp0 + 4 * slot
         return f"ds_read_b128 v[{r}:{r + 3}], %0 offset:{16 * k}"
-    for k in range(min(depth, nload)):
-        lines.append(load(k))
+    lines = ["s_waitcnt lgkmcnt(0)"] + [load(k) for k in range(min(depth, nload))]
+    body = "\\n\\t".join(lines)
+    out.append("  // issue the first loads of lds[0..kRows) (must be followed by rank1_body with the same address)")
+    out.append("  __device__ static __forceinline__ void rank1_prefetch(unsigned lds_addr) {")
+    out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_tmp}, "memory");')
+    out.append("  }")
+    lines = []
     for k in range(nload):
         issued = min(nload, k + depth)
         lines.append(f"s_waitcnt lgkmcnt({issued - k - 1})")
@@ -63,10 +68,15 @@ def gen(nt: int) -> str:
         if k + depth < nload:
             lines.append(load(k + depth))
     body = "\\n\\t".join(lines)
-    out.append("  // T[i] += lds[i]*g ; lds_addr = LDS byte address of a 16-byte aligned vector of >= kRows doubles")
-    out.append("  __device__ static __forceinline__ void rank1(unsigned lds_addr, double g) {")
+    out.append("  // T[i] += lds[i]*g.  No LDS/scalar-memory instruction may be issued between prefetch and body")
+    out.append("  // (the body's s_waitcnt counts assume only its own loads are outstanding).")
+    out.append("  __device__ static __forceinline__ void rank1_body(unsigned lds_addr, double g) {")
     out.append(f'    asm volatile("{body}"')
     out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
+    out.append("  }")
+    out.append("  __device__ static __forceinline__ void rank1(unsigned lds_addr, double g) {")
+    out.append("    rank1_prefetch(lds_addr);")
+    out.append("    rank1_body(lds_addr, g);")
     out.append("  }")
     # publish
     lines = [f"ds_write_b64 %0, {treg(i)} offset:{8 * i}" for i in range(nt)]

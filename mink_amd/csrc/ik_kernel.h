@@ -46,7 +46,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
   L.com = o;  o += (n_com > 0 ? nbody * 4 : 0);
   L.col = o;  o += max_rows * 16;
   L.A = o;    o += max_rows * kWave;
-  L.piv = o;  o += kWave;          // pivot column broadcast buffer (16-byte aligned: all offsets are even)
+  L.piv = o;  o += kWave + 8;      // pivot column broadcast buffer + 8 scalar slots of the pivot lane
   L.total = o;
   return L;
 }
@@ -80,28 +80,49 @@ struct QpLane {
 // the QP): every lane then reads its own entry (ratio test / multiplier) and streams the whole
 // vector back with broadcast reads for the rank-1 update.  Entry `col` is published as 0 so that
 // row `col` of every column is left alone by the update (its change is carried by σ_col).
+struct PivotScalars { double d, sg, w, z; };   // D, σ, w, z of the pivot lane, broadcast through LDS
+
+// 1/d without the IEEE division sequence (v_div_scale/fmas/fixup ≈ 145 cycles in the pivot's
+// dependent chain): hardware reciprocal + two Newton steps (≤ 1 ulp for normal d).
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
 template <int NT>
-__device__ __forceinline__ void publish_column(int col, int lane, double* sPiv) {
+__device__ __forceinline__ double publish_column(const QpLane& s, int col, int lane, double* sPiv,
+                                                 PivotScalars& ps) {
   // Column `col` equals row `col` (R is symmetric): lane i holds R[col][i] in tableau register
   // `col`.  One indexed register read (VGPR index mode on the pinned base) + ONE ds_write_b64 for
   // the whole wave.  Having lane `col` dump its 48 registers itself costs 48 single-lane LDS
-  // writes = 750-1850 cycles (measured, tools/ubench) — half of the whole pivot.
+  // writes = 750-1850 cycles (measured, tools/ubench) — half of the whole pivot.  The pivot lane's
+  // scalars ride along in the same LDS round trip (a v_readlane chain costs ~90 cycles each).
   const double rowv = Tab<NT>::get_dyn(col);
+  const double own = (lane == col) ? 0.0 : rowv;
   wave_sync();                                   // earlier readers of sPiv are done
-  sPiv[lane] = (lane == col) ? 0.0 : rowv;
+  sPiv[lane] = own;
+  if (lane == col) {
+    double2* o = reinterpret_cast<double2*>(sPiv + kWave);
+    o[0] = double2{s.D, s.sg};
+    o[1] = double2{s.w, s.z};
+  }
   wave_sync();
+  const double2* o = reinterpret_cast<const double2*>(sPiv + kWave);
+  const double2 a = o[0], b = o[1];
+  ps.d = a.x; ps.sg = a.y; ps.w = b.x; ps.z = b.y;
+  return own;                                    // raw R[lane][col] (0 for lane col)
 }
 
 // Symmetric sweep (reverse = un-sweep) on index k (wave-uniform); sPiv holds column k.
 template <int NT>
-__device__ __forceinline__ void pivot(QpLane& s, int k, bool reverse, int lane, const double* sPiv) {
-  const double sk = readlane_f64(s.sg, k);
-  const double d = readlane_f64(s.D, k);         // true T[k][k]
-  const double inv = 1.0 / d;
-  const double own = sPiv[lane];                 // raw R[lane][k]  (0 for lane k)
+__device__ __forceinline__ void pivot(QpLane& s, int k, bool reverse, int lane, const double* sPiv,
+                                      double own, const PivotScalars& ps, double inv) {
+  const double sk = ps.sg;
   const double ck = s.sg * sk * own;             // true T[lane][k]
   const double g = (sk * sk) * own * inv;        // R-units multiplier of this lane's column
-  Tab<NT>::rank1(lds_addr(sPiv), -g);            // R[i][lane] −= R[i][k]·g   (row k: published 0)
+  Tab<NT>::rank1_body(lds_addr(sPiv), -g);       // R[i][lane] −= R[i][k]·g   (row k: published 0)
   if (lane == k) {
     s.D = -inv;                                  // T[k][k] = −1/d
     s.sg = (reverse ? -sk : sk) * inv;           // row/column k scaled by ±1/d
@@ -706,25 +727,33 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
     const double thr_dof = 1e-13 / (hmax * (double)nv);
 
     MKH_TICK();   // 6: tableau built
-    // One loop drives both phases so that the sweep is instantiated once:
-    //   phase 0 (k0 < nv): bring dof k0 into the basis, x0 = −H⁻¹c (Gauss–Jordan, no ratio test)
-    //   phase 1: GI — pick the most violated primal condition p, then step/pivot until p is resolved.
     int iters = 0;
     const int max_iters = 8 * (ntab + 8);
-    int k0 = 0;          // next dof to bring in (phase 0)
-    int p = -1;          // GI: index being driven (−1 ⇒ select a new one)
+    // ---- phase 0: bring every dof into the basis, x0 = −H⁻¹c (Gauss–Jordan, no ratio tests).
+    // Tight loop: publish row k → (LDS loads of the rank-1 update already in flight) → 1/d,
+    // multipliers, z/w update → rank-1 update.
+    for (int k = 0; k < nv; ++k) {
+      PivotScalars ps;
+      const double own = publish_column<NT>(s, k, lane, sPiv, ps);
+      Tab<NT>::rank1_prefetch(lds_addr(sPiv));
+      if (!(ps.d > 0.0)) { status |= 4; break; }
+      const double inv = fast_rcp(ps.d);
+      const double tau = (lane == k) ? ps.d : s.sg * ps.sg * own;     // column k of the tableau
+      const double alpha = -ps.w * inv;
+      if (s.basic) s.z -= alpha * tau; else s.w += alpha * tau;
+      if (lane == k) { s.z += alpha; s.w = 0.0; s.basic = 1; }
+      pivot<NT>(s, k, false, lane, sPiv, own, ps, inv);
+    }
+    // ---- phase 1: Goldfarb–Idnani.  Each iteration publishes ONE column `col`; a blocking
+    // constraint found by the ratio test becomes the column of the next iteration (`pend`).
+    int p = -1;          // index being driven (−1 ⇒ select a new one)
     bool p_basic = false, upper = false;
     double beta = 0.0, sgn = 1.0, thr = 0.0;
-    // Each iteration = publish ONE column `col`, (ratio-)test on it, then optionally sweep on the
-    // same column.  A blocking constraint l found by the ratio test becomes the column of the next
-    // iteration (`pend`), so the loop has a single publish site and a single sweep site.
     int pend = -1;       // pending sweep of a blocking index (reverse flag in pend_rev)
     bool pend_rev = false;
     while (!(status & 14)) {
-      const bool ph0 = k0 < nv;
       int col;
-      if (ph0) col = k0;
-      else if (pend >= 0) col = pend;
+      if (pend >= 0) col = pend;
       else {
         if (p < 0) {
           // ---- most violated primal condition (GI step 1)
@@ -749,28 +778,23 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
         if (++iters > max_iters) { status |= 8; break; }
         col = p;
       }
-      publish_column<NT>(col, lane, sPiv);
-      bool do_sweep = true, rev = false;
-      if (ph0) {
-        ++k0;
-        const double d = readlane_f64(s.D, col);
-        if (!(d > 0.0)) { status |= 4; break; }
-        const double tau = (lane == col) ? d : s.sg * readlane_f64(s.sg, col) * sPiv[lane];
-        const double alpha = -readlane_f64(s.w, col) / d;
-        if (s.basic) s.z -= alpha * tau; else s.w += alpha * tau;
-        if (lane == col) { s.z += alpha; s.w = 0.0; s.basic = 1; }
-      } else if (pend >= 0) {
+      PivotScalars ps;
+      const double own = publish_column<NT>(s, col, lane, sPiv, ps);
+      Tab<NT>::rank1_prefetch(lds_addr(sPiv));
+      const double inv = fast_rcp(ps.d);                         // 1 / T[col][col]
+      bool rev = false;
+      if (pend >= 0) {
         rev = pend_rev;
         pend = -1;
       } else {
-        const double tpp = readlane_f64(s.D, p);
-        const double tau = (lane == p) ? tpp : s.sg * readlane_f64(s.sg, p) * sPiv[lane];
+        const double tau = (lane == col) ? ps.d : s.sg * ps.sg * own;   // column `col` of the tableau
+        const double tpp = ps.d;
         // full step length t2 (GI step 2b)
         double t2 = kInf;
         if (p_basic) {
-          if (fabs(tpp) > thr) t2 = fabs((readlane_f64(s.z, p) - beta) / tpp);
+          if (fabs(tpp) > thr) t2 = fabs((ps.z - beta) * inv);
         } else {
-          if (-tpp > thr) t2 = fabs(readlane_f64(s.w, p) / tpp);
+          if (-tpp > thr) t2 = fabs(ps.w * inv);
         }
         // partial step length t1: keep the multipliers of the active set dual feasible
         const double r = sgn * tau;
@@ -802,10 +826,12 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
             if (pend_rev) { s.z = 0.0; s.basic = 0; }           // row leaves the active set
             else { s.w = 0.0; s.basic = 1; }                    // dof leaves its bound
           }
-          do_sweep = false;
+          // the prefetched loads are simply abandoned: drain them before LDS is reused
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          continue;
         }
       }
-      if (do_sweep) pivot<NT>(s, col, rev, lane, sPiv);
+      pivot<NT>(s, col, rev, lane, sPiv, own, ps, inv);
     }
     MKH_TICK();   // 7: QP done
     if (MKH_TAP(t_cycles) && lane < 8) MKH_TAP(t_cycles)[(size_t)pb * 8 + lane] = (lane == 0) ? tc[0] : (lane == 1) ? tc[1] : (lane == 2) ? tc[2] : (lane == 3) ? tc[3] : (lane == 4) ? tc[4] : (lane == 5) ? tc[5] : (lane == 6) ? tc[6] : tc[7];

@@ -1,11 +1,9 @@
 // Micro-benchmarks of the QP building blocks (cycles per call, one wave / block).
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../../mink_amd/csrc/wave_ops.h"
-#include "../../mink_amd/csrc/tab_asm.inc"
+#include "../../mink_amd/csrc/ik_kernel.h"
 using namespace mkh;
 constexpr int NT = 48;
-__device__ __forceinline__ unsigned lds_addr(const double* p) { return (unsigned)(size_t)p; }
 
 template <int WHICH>
 __global__ __launch_bounds__(64, 2) __attribute__((amdgpu_num_vgpr(Tab<NT>::kCompilerVgprs)))
@@ -27,6 +25,11 @@ void k(double* out, long long* cyc, int iters) {
     if (WHICH == 5) { __syncthreads(); sm[64 + lane] = acc; __syncthreads(); acc += sm[64 + ((lane + 1) & 63)]; }
     if (WHICH == 6) { acc += (double)first_lane(acc * x > 3.0 + it); }
     if (WHICH == 7) { acc = acc / (x + it); }
+    if (WHICH == 8) { QpLane q; q.D = acc; q.sg = x; q.w = acc; q.z = x; PivotScalars ps; double own = publish_column<NT>(q, col, lane, sm, ps); acc += own + ps.d * 1e-9; col = (col + 7) % 43; }
+    if (WHICH == 9) { QpLane q; q.D = acc; q.sg = 1.0; q.w = acc; q.z = x; PivotScalars ps; double own = publish_column<NT>(q, col, lane, sm, ps); double inv = fast_rcp(ps.d + 2.0); pivot<NT>(q, col, false, lane, sm, own * 1e-3, ps, inv); acc = q.D * 1e-3 + 1.0; col = (col + 7) % 43; }
+    if (WHICH == 10) { acc = fast_rcp(acc + 1.5); }
+    if (WHICH == 11) { asm volatile("v_fma_f64 v[160:161], %0, %0, v[160:161]\n v_fma_f64 v[162:163], %0, %0, v[162:163]\n v_fma_f64 v[164:165], %0, %0, v[164:165]\n v_fma_f64 v[166:167], %0, %0, v[166:167]\n v_fma_f64 v[168:169], %0, %0, v[168:169]\n v_fma_f64 v[170:171], %0, %0, v[170:171]\n v_fma_f64 v[172:173], %0, %0, v[172:173]\n v_fma_f64 v[174:175], %0, %0, v[174:175]" :: "v"(acc) : "v160","v161","v162","v163","v164","v165","v166","v167","v168","v169","v170","v171","v172","v173","v174","v175"); }
+    if (WHICH == 12) { acc += Tab<NT>::get_dyn(col); col = (col + 7) % 43; }
   }
   long long t1 = __builtin_readcyclecounter();
   out[blockIdx.x * 64 + lane] = acc + Tab<NT>::get<5>();
@@ -47,7 +50,7 @@ template <int W> void run(const char* name, int grid) {
   hipFree(out); hipFree(cyc); delete[] h;
 }
 int main() {
-  for (int grid : {256, 2048}) {   // 1 wave/CU and 8 waves/CU (2 per SIMD)
+  for (int grid : {256, 1536}) {   // 1 wave/CU and 8 waves/CU (2 per SIMD)
     run<0>("rank1 (24 b128 + 48 fma)", grid);
     run<1>("publish (48 ds_write_b64)", grid);
     run<2>("fp64 reciprocal", grid);
@@ -56,6 +59,11 @@ int main() {
     run<5>("sync+lds write+sync+read", grid);
     run<6>("ballot first_lane", grid);
     run<7>("fp64 divide", grid);
+    run<8>("publish_column (new)", grid);
+    run<9>("publish+rcp+pivot", grid);
+    run<10>("fast_rcp", grid);
+    run<11>("8 independent v_fma_f64", grid);
+    run<12>("get_dyn", grid);
   }
   return 0;
 }
