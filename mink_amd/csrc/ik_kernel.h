@@ -33,7 +33,7 @@ struct LdsLayout {
 };
 __host__ __device__ inline int lds_even(int x) { return (x + 1) & ~1; }
 __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int njnt, int n_frame,
-                                                int n_posture, int n_com, int max_rows) {
+                                                int n_posture, int n_com, int max_rows, int n_jrows, int nt) {
   LdsLayout L;
   int o = 0;
   L.q = o;    o += lds_even(nq);
@@ -41,8 +41,8 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
   L.jnt = o;  o += lds_even(njnt * 6);
   L.tgt = o;  o += lds_even(n_frame * 7 + n_com * 3);
   L.task = o; o += n_frame * 48;
-  L.J = o;    o += (n_frame + n_com) * 6 * kWave;   // weighted Jacobian rows [task][r][64]
-  L.dof = o;  o += kWave * 10;
+  L.J = o;    o += n_jrows * nt;                    // weighted Jacobian rows with nonzero cost, [row][nt]
+  L.dof = o;  o += lds_even(nv * 10);
   L.com = o;  o += (n_com > 0 ? nbody * 4 : 0);
   L.col = o;  o += max_rows * 16;
   L.A = o;    o += max_rows * kWave;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = lane_id();
   const int nq = P0.nq, nv = P0.nv, nbody = P0.nbody;
-  const LdsLayout L = lds_layout(nq, nv, nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows);
+  const LdsLayout L = lds_layout(nq, nv, nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows, P0.n_jrows, NT);
   double* const sq = smem + L.q;
   double* const sX = smem + L.X;
   double* const sJnt = smem + L.jnt;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
       if (__ballot(viol)) status |= 1;
     }
     // stash the dof's motion axis in LDS; phases below reload it instead of keeping 20 VGPRs live
-    {
+    if (is_dof) {
       double* o = sDof + lane * 10;
       o[0] = d_ang.x; o[1] = d_ang.y; o[2] = d_ang.z; o[3] = d_lin.x; o[4] = d_lin.y; o[5] = d_lin.z;
       o[6] = d_anchor.x; o[7] = d_anchor.y; o[8] = d_anchor.z; o[9] = q_dof;
@@ -494,11 +494,10 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
 
     // ------------------------------ frame + CoM tasks: Jacobian columns, H, c
     const int n_jt = P.n_frame + P.n_com;
-    const int jstride = 6 * kWave;
     for (int t = 0; t < n_jt; ++t) {
       double Jt[6] = {0, 0, 0, 0, 0, 0}, cw[6] = {0, 0, 0, 0, 0, 0}, we6[6] = {0, 0, 0, 0, 0, 0};
       uint64_t mask;
-      int nrow, row0;
+      int nrow, row0, rowmask, jrow0;
       bool second_half;
       if (t < P.n_frame) {
         const FrameTaskDev& ft = P.frame[t];
@@ -506,6 +505,8 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
         nrow = 6;
         row0 = ft.row0;
         second_half = ft.any_ori != 0;
+        rowmask = ft.rowmask;
+        jrow0 = ft.jrow0;
         const double* o = sTask + t * 48;
 #pragma unroll
         for (int r = 0; r < 6; ++r) { cw[r] = ft.cost[r]; we6[r] = o[30 + r]; }
@@ -539,6 +540,8 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
         nrow = 3;
         row0 = P.com_row0[tc];
         second_half = false;
+        rowmask = P.com_rowmask[tc];
+        jrow0 = P.com_jrow0[tc];
         {
           const double* tg = sTgt + P.n_frame * 7 + tc * 3;
           const double e3[3] = {com_root.x - tg[0], com_root.y - tg[1], com_root.z - tg[2]};
@@ -568,10 +571,12 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
         c_lane -= we6[r] * Jw[r];                            // c = −weighted_errorᵀ·weighted_jacobian
         hdiag += Jw[r] * Jw[r];
       }
-      {
-        double* o = sJ + t * jstride + lane;                   // row r of task t: sJ[t][r][0..63]
+      if (lane < NT) {
+        double* o = sJ + jrow0 * NT + lane;                    // compact rows of task t: sJ[jrow0 + c][0..NT)
+        int c = 0;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) o[r * kWave] = is_dof ? Jw[r] : 0.0;
+        for (int r = 0; r < 6; ++r)
+          if ((rowmask >> r) & 1) { o[c * NT] = is_dof ? Jw[r] : 0.0; ++c; }
       }
     }
     if (MKH_TAP(t_c) && is_dof) MKH_TAP(t_c)[(size_t)pb * nv + lane] = c_lane;
@@ -669,13 +674,10 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
     // The column lives in pinned VGPRs (tab_asm.inc); the diagonal of K is carried separately (s.D),
     // the diagonal register of the column is never read as a value.
     Tab<NT>::zero();
-    for (int t = 0; t < n_jt; ++t) {
-      bool second_half = false;
-      if (t < P.n_frame) second_half = P.frame[t].any_ori != 0;
-      const double* base = sJ + t * jstride;
-      const int nrow = second_half ? 6 : 3;
-      // H[:, lane] += Σ_r Jw_r · Jw_r[lane]: one rank-1 update per weighted Jacobian row
-      for (int r = 0; r < nrow; ++r) Tab<NT>::rank1(lds_addr(base + r * kWave), base[r * kWave + lane]);
+    // H[:, lane] += Σ_rows Jw_row · Jw_row[lane]: one rank-1 update per staged (nonzero-cost) row
+    for (int r = 0; r < P.n_jrows; ++r) {
+      const double* row = sJ + r * NT;
+      Tab<NT>::rank1(lds_addr(row), (lane < NT) ? row[lane] : 0.0);
     }
     if (MKH_TAP(t_H) && is_dof) {
       double* hrow = MKH_TAP(t_H) + (size_t)pb * nv * nv + lane;

@@ -281,7 +281,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   auto bail = [&](int32_t code) { mkh_problem_destroy(p); return code; };
 
   // ---- frame tasks: resolve the frame to (body, local pose); rows of the tap layout
-  int row = 0;
+  int row = 0, jrows = 0;
   std::vector<FrameTaskDev> ft(d->n_frame_tasks);
   for (int t = 0; t < d->n_frame_tasks; ++t) {
     const MkhFrameTaskDesc& s = d->frame_tasks[t];
@@ -311,6 +311,10 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     f.dof_mask = dof_chain_mask(m, f.body);
     f.row0 = row; row += 6;
     f.any_ori = (s.cost[3] != 0.0 || s.cost[4] != 0.0 || s.cost[5] != 0.0) ? 1 : 0;
+    f.rowmask = 0;
+    for (int k = 0; k < 6; ++k) if (s.cost[k] != 0.0) f.rowmask |= 1 << k;
+    f.jrow0 = jrows;
+    jrows += __builtin_popcount(f.rowmask);
   }
   std::vector<double> pcost((size_t)(d->n_posture_tasks ? d->n_posture_tasks : 1) * 64, 0.0);
   for (int t = 0; t < d->n_posture_tasks; ++t) {
@@ -322,8 +326,13 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     for (int k = 0; k < 3; ++k) P.com_cost[t][k] = d->com_tasks[t].cost[k];
     P.com_gain[t] = d->com_tasks[t].gain; P.com_lm[t] = d->com_tasks[t].lm_damping;
     P.com_row0[t] = row; row += 3;
+    P.com_rowmask[t] = 0;
+    for (int k = 0; k < 3; ++k) if (d->com_tasks[t].cost[k] != 0.0) P.com_rowmask[t] |= 1 << k;
+    P.com_jrow0[t] = jrows;
+    jrows += __builtin_popcount(P.com_rowmask[t]);
   }
   P.n_rows_tap = row;
+  P.n_jrows = jrows;
 
   // ---- box limits: per-dof lower/upper in joint coordinates (±inf = absent)
   std::vector<double> clo((size_t)(P.n_cfg ? P.n_cfg : 1) * 64, -inf), chi((size_t)(P.n_cfg ? P.n_cfg : 1) * 64, inf);
@@ -393,7 +402,8 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   P.frame = p->d_frame; P.posture_cost = p->d_posture_cost; P.cfg_lower = p->d_cfg_lower; P.cfg_upper = p->d_cfg_upper;
   P.vel_limit = p->d_vel; P.pairs = p->d_pairs;
 
-  const LdsLayout L = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows);
+  P.nt = p->nt;
+  const LdsLayout L = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, P.n_jrows, p->nt);
   p->lds_bytes = L.total * (int)sizeof(double);
   if (p->lds_bytes > 64 * 1024) return bail(fail(MKH_E_LIMIT, "problem needs %d bytes of LDS per wavefront (> 64 KiB)", p->lds_bytes));
   // resident waves per CU: bounded by LDS (160 KiB/CU) and by VGPRs (launch_bounds: 2 waves/SIMD)

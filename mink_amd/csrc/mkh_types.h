@@ -41,6 +41,8 @@ struct FrameTaskDev {
   uint64_t dof_mask;     // dofs on the chain world -> body (mj_jac's ancestor walk)
   int32_t row0;          // first row in the (e, J) tap layout
   int32_t any_ori;       // any orientation cost > 0
+  int32_t rowmask;       // bit r set iff cost[r] > 0: only those rows are staged in LDS / enter H
+  int32_t jrow0;         // first compact LDS row of this task
 };
 
 struct CollisionPairDev {
@@ -57,6 +59,8 @@ struct DeviceProblem {
   int32_t nq, nv, nbody, njnt, nrounds;
   int32_t n_frame, n_posture, n_com, n_cfg, n_vel, n_pairs, n_rows_tap;
   int32_t max_rows;      // tableau rows reserved for half-spaces (ntab = nv + max_rows)
+  int32_t n_jrows;       // weighted Jacobian rows staged in LDS (Σ nonzero-cost rows of frame + CoM tasks)
+  int32_t nt;            // tableau rows per lane of the compiled kernel variant (row stride of the J rows)
   int32_t robot_root;    // body 1 (ComTask subtree root)
   // model lane tables
   const double* body_f;  // [BF_COUNT][64]
@@ -72,6 +76,7 @@ struct DeviceProblem {
   int32_t posture_row0[kMaxPostureTasks];
   double com_cost[kMaxComTasks][3], com_gain[kMaxComTasks], com_lm[kMaxComTasks];
   int32_t com_row0[kMaxComTasks];
+  int32_t com_rowmask[kMaxComTasks], com_jrow0[kMaxComTasks];
   // limits
   const double* cfg_lower;         // [n_cfg][64] per dof (value at the dof's qpos address), ±inf when absent
   const double* cfg_upper;         // [n_cfg][64]
