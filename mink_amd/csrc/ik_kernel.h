@@ -41,7 +41,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
   L.jnt = o;  o += lds_even(njnt * 6);
   L.tgt = o;  o += lds_even(n_frame * 7 + n_com * 3);
   L.task = o; o += n_frame * 48;
-  L.J = o;    o += n_jrows * nt;                    // weighted Jacobian rows with nonzero cost, [row][nt]
+  L.J = o;    o += 6 * nt;                          // weighted Jacobian rows of ONE task, [r][nt]
   L.dof = o;  o += lds_even(nv * 10);
   L.com = o;  o += (n_com > 0 ? nbody * 4 : 0);
   L.col = o;  o += max_rows * 16;
@@ -494,6 +494,9 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
 
     // ------------------------------ frame + CoM tasks: Jacobian columns, H, c
     const int n_jt = P.n_frame + P.n_com;
+    // The tableau column lives in pinned VGPRs (tab_asm.inc), outside the compiler's budget, so H is
+    // accumulated right here, task by task, while the lane still holds its own weighted column.
+    Tab<NT>::zero();
     for (int t = 0; t < n_jt; ++t) {
       double Jt[6] = {0, 0, 0, 0, 0, 0}, cw[6] = {0, 0, 0, 0, 0, 0}, we6[6] = {0, 0, 0, 0, 0, 0};
       uint64_t mask;
@@ -571,12 +574,21 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
         c_lane -= we6[r] * Jw[r];                            // c = −weighted_errorᵀ·weighted_jacobian
         hdiag += Jw[r] * Jw[r];
       }
+      wave_sync();                                             // previous task's rows are consumed
       if (lane < NT) {
-        double* o = sJ + jrow0 * NT + lane;                    // compact rows of task t: sJ[jrow0 + c][0..NT)
+        double* o = sJ + lane;                                 // compact rows of this task: sJ[c][0..NT)
         int c = 0;
 #pragma unroll
         for (int r = 0; r < 6; ++r)
           if ((rowmask >> r) & 1) { o[c * NT] = is_dof ? Jw[r] : 0.0; ++c; }
+      }
+      wave_sync();
+      // H[:, lane] += Σ_r Jw_r · Jw_r[lane]: one rank-1 update per staged (nonzero-cost) row
+      {
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+          if ((rowmask >> r) & 1) { Tab<NT>::rank1(lds_addr(sJ + c * NT), is_dof ? Jw[r] : 0.0); ++c; }
       }
     }
     if (MKH_TAP(t_c) && is_dof) MKH_TAP(t_c)[(size_t)pb * nv + lane] = c_lane;
@@ -671,14 +683,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
     // ------------------------------------------------- build the tableau column
     // lane j holds column j of K = [[H, Aᵀ],[A, 0]].  Built only now so that the 2·NT tableau
     // VGPRs are not live during FK / task / collision phases.
-    // The column lives in pinned VGPRs (tab_asm.inc); the diagonal of K is carried separately (s.D),
-    // the diagonal register of the column is never read as a value.
-    Tab<NT>::zero();
-    // H[:, lane] += Σ_rows Jw_row · Jw_row[lane]: one rank-1 update per staged (nonzero-cost) row
-    for (int r = 0; r < P.n_jrows; ++r) {
-      const double* row = sJ + r * NT;
-      Tab<NT>::rank1(lds_addr(row), (lane < NT) ? row[lane] : 0.0);
-    }
+    // (the diagonal of K is carried separately in s.D; the diagonal register of the column is never read)
     if (MKH_TAP(t_H) && is_dof) {
       double* hrow = MKH_TAP(t_H) + (size_t)pb * nv * nv + lane;
       static_for<NT>([&](auto ic) {
