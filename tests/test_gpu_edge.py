@@ -1,0 +1,111 @@
+"""Edge cases of the batched path (cf. the reference's tests: empty task lists, default damping 1e-12,
+limits=[] vs None, ragged batches) — compared with the oracle where the reference defines a result."""
+
+import numpy as np
+import pytest
+
+import mink_amd as mink
+import oracle_configs as oc
+from mink_amd import _native as nat
+from mink_amd import workloads
+from oracle import ik as oik
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_v(model_name, q, tasks, limits, dt, damping):
+    return oik.solve_ik(oc.model(model_name), q, tasks, dt, damping, limits)
+
+
+@pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 2049, 5000])
+def test_ragged_batch_sizes(B):
+    """grid-stride loop tails: every batch size gives the same per-row answers as B = 1."""
+    m = workloads.load_robot("ur5e")
+    nm = nat.NativeModel(m)
+    home = m.key_qpos[0]
+    prob = nat.NativeProblem(nm, frame_tasks=[{"frame_type": "site", "frame_id": 0, "cost": [1.0] * 6, "lm_damping": 1.0}],
+                             posture_tasks=[{"cost": 1e-2}], max_batch=B)
+    rng = np.random.default_rng(B)
+    q, tg = workloads.make_batch(m, nm, prob, rng, B, base_q=home)
+    v, st = prob.solve(q, tg, home[None, :], None, 2e-3, 1e-3)
+    assert (st == 0).all()
+    one = nat.NativeProblem(nm, frame_tasks=[{"frame_type": "site", "frame_id": 0, "cost": [1.0] * 6, "lm_damping": 1.0}],
+                            posture_tasks=[{"cost": 1e-2}], max_batch=1)
+    for i in {0, B // 2, B - 1}:
+        v1, _ = one.solve(q[i:i + 1], tg[i:i + 1], home[None, :], None, 2e-3, 1e-3)
+        np.testing.assert_array_equal(v1[0], v[i])
+
+
+def test_default_damping_single_frame_task_vs_oracle():
+    """damping=1e-12 and one 6-row task on a 6-dof arm: H = JᵀJ + 1e-12·I is invertible but ill-scaled."""
+    m = mink.load_robot("ur5e")
+    om = oc.model("ur5e")
+    rng = np.random.default_rng(3)
+    q = workloads.sample_q(m, rng, 32, base_q=m.key_qpos[0])
+    cfg = mink.Configuration(m, q)
+    task = mink.FrameTask("attachment_site", "site", 1.0, 1.0)
+    tgt = mink.Configuration(m, cfg.integrate(rng.normal(scale=0.05, size=(32, 6)), 1.0))
+    task.set_target(tgt.get_transform_frame_to_world("attachment_site", "site"))
+    v = mink.solve_ik(cfg, [task], 1e-2, "mi355x", limits=[])            # default damping 1e-12
+    sid = om.name2id("site", "attachment_site")
+    for i in range(32):
+        spec = oik.FrameTaskSpec(sid, "site", np.ones(6), task.transform_target_to_world.wxyz_xyz[i])
+        ref = oik.solve_ik(om, q[i], [spec], 1e-2, 1e-12, [])
+        # cond(H) can reach ~1e8 near wrist alignment: compare in the task space the QP actually pins
+        assert np.abs(v[i] - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+
+
+def test_only_posture_and_only_limits():
+    m = mink.load_robot("g1")
+    cfg = mink.Configuration(m)
+    cfg.update_from_keyframe("stand")
+    post = mink.PostureTask(m, cost=1.0)
+    tgt = cfg.q
+    tgt[7:] += 0.01
+    post.set_target(tgt)
+    v = mink.solve_ik(cfg, [post], 1e-2, "mi355x", 1e-3, limits=[])
+    # H = (1 + 1e-3) I on hinge dofs, c = −e ⇒ Δq = e / 1.001
+    np.testing.assert_allclose(v[6:] * 1e-2, 0.01 / 1.001, rtol=1e-13)
+    np.testing.assert_allclose(v[:6], 0.0, atol=0)
+    v = mink.solve_ik(cfg, [], 1e-2, "mi355x", 1e-3)                     # only the default ConfigurationLimit
+    np.testing.assert_allclose(v, 0.0, atol=0)
+
+
+def test_status_flags_and_nan_input():
+    m = workloads.load_robot("ur5e")
+    nm = nat.NativeModel(m)
+    home = m.key_qpos[0]
+    cl = mink.ConfigurationLimit(m)._native_desc()[1]
+    prob = nat.NativeProblem(nm, posture_tasks=[{"cost": 1.0}], configuration_limits=[cl],
+                             velocity_limits=[{"indices": [0], "limit": [1e-3]}], max_batch=4)
+    q = np.tile(home, (4, 1))
+    q[1, 0] = 7.0          # outside the range, and it cannot come back within the velocity limit ⇒ infeasible
+    q[2, 1] = 6.5          # outside the range, recoverable ⇒ only the OUTSIDE_LIMITS bit
+    v, st = prob.solve(q, None, home[None, :], None, 1e-3, 1e-6)
+    assert st[0] == 0 and st[3] == 0
+    assert st[1] & nat.ST_INFEASIBLE and st[1] & nat.ST_OUTSIDE_LIMITS and np.isnan(v[1]).all()
+    assert st[2] == nat.ST_OUTSIDE_LIMITS and np.isfinite(v[2]).all()
+    # zero damping and no task ⇒ H = 0: not positive definite
+    p2 = nat.NativeProblem(nm, max_batch=1)
+    v, st = p2.solve(home[None, :], None, None, None, 1e-3, 0.0)
+    assert st[0] & nat.ST_NOT_PD and np.isnan(v).all()
+
+
+def test_argument_validation():
+    m = workloads.load_robot("ur5e")
+    nm = nat.NativeModel(m)
+    prob = nat.NativeProblem(nm, frame_tasks=[{"frame_type": "site", "frame_id": 0, "cost": [1.0] * 6}], max_batch=4)
+    with pytest.raises(ValueError):
+        prob.solve(np.zeros((2, 5)), np.zeros((2, 1, 7)), None, None, 1e-2, 1e-3)
+    with pytest.raises(ValueError):
+        prob.solve(np.zeros((2, 6)), np.zeros((2, 2, 7)), None, None, 1e-2, 1e-3)
+    with pytest.raises(nat.MinkHipError, match="max_batch"):
+        prob.solve(np.zeros((8, 6)), np.zeros((8, 1, 7)), None, None, 1e-2, 1e-3)
+    with pytest.raises(nat.MinkHipError, match="dt must be"):
+        prob.solve(np.zeros((2, 6)), np.zeros((2, 1, 7)), None, None, 0.0, 1e-3)
+    with pytest.raises(nat.MinkHipError, match="site id"):
+        nat.NativeProblem(nm, frame_tasks=[{"frame_type": "site", "frame_id": 9, "cost": [1.0] * 6}])
+    with pytest.raises(nat.MinkHipError, match="no analytic distance"):
+        nat.NativeProblem(nm, collision_limits=[{"geom_id_pairs": [[m.name2id("geom", "wrist_3_link"), m.name2id("geom", "wall")]],
+                                                 "gain": 0.85, "minimum_distance_from_collisions": 0.005,
+                                                 "collision_detection_distance": 0.01, "bound_relaxation": 0.0}])
