@@ -194,6 +194,19 @@ int32_t mkh_solve(MkhProblem *problem, int32_t B, const double *q, const double 
                   const double *posture_target, const double *com_target, double dt, double damping,
                   double *v_out, int32_t *status_out, int32_t flags, void *hip_stream);
 
+/*
+ * Fused outer IK loop on the device — what mink's callers write around solve_ik
+ * (examples/arm_ur5e_actuators.py:88-97, examples/arm_aloha.py:146-169):
+ *   for _ in range(n_steps): v = solve_ik(cfg, ...); cfg.integrate_inplace(v, dt)
+ * q stays on chip between steps.  q_out (B, nq) receives the final configuration (may alias q),
+ * v_out the last velocity, status_out the OR of the per-step status bits; an instance stops at the
+ * first step whose QP fails.
+ */
+int32_t mkh_solve_steps(MkhProblem *problem, int32_t B, const double *q, const double *frame_targets,
+                        const double *posture_target, const double *com_target, double dt, double damping,
+                        int32_t n_steps, double *q_out, double *v_out, int32_t *status_out, int32_t flags,
+                        void *hip_stream);
+
 /* Same inputs; additionally writes the requested intermediates (build_ik / compute_error /
  * compute_jacobian / get_transform_frame_to_world parity taps).  v_out/status_out may be NULL
  * to skip the QP. */

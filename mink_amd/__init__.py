@@ -12,12 +12,12 @@ from .flatmodel import FlatModel
 from .lie import SE3, SO3
 from .limits import CollisionAvoidanceLimit, ConfigurationLimit, Constraint, Limit, VelocityLimit
 from .mjcf import load_mjcf, loads_mjcf
-from .solve_ik import Problem, build_ik, solve_ik
+from .solve_ik import Problem, build_ik, solve_ik, solve_ik_steps
 from .tasks import ComTask, DampingTask, FrameTask, Objective, PostureTask, RelativeFrameTask, Task
 from .workloads import load_robot
 
 __all__ = (
-    "ComTask", "Configuration", "build_ik", "solve_ik", "DampingTask", "FrameTask", "RelativeFrameTask",
+    "ComTask", "Configuration", "build_ik", "solve_ik", "solve_ik_steps", "DampingTask", "FrameTask", "RelativeFrameTask",
     "PostureTask", "Task", "Objective", "ConfigurationLimit", "VelocityLimit", "CollisionAvoidanceLimit",
     "Constraint", "Limit", "SO3", "SE3", "MinkError", "UnsupportedFrame", "InvalidFrame", "InvalidKeyframe",
     "NotWithinConfigurationLimits", "TargetNotSet", "InvalidMocapBody", "SUPPORTED_FRAMES", "FlatModel",

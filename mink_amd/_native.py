@@ -129,12 +129,13 @@ def lib() -> C.CDLL:
               C.c_void_p, C.c_void_p]
     L.mkh_solve.argtypes = common + [C.c_int32, C.c_void_p]
     L.mkh_eval.argtypes = common + [C.POINTER(MkhTaps), C.c_int32, C.c_void_p]
+    L.mkh_solve_steps.argtypes = common[:8] + [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.mkh_integrate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                 C.c_int32, C.c_void_p]
     L.mkh_problem_launch_info.argtypes = [C.c_void_p, C.c_int32] + [C.POINTER(C.c_int32)] * 4
     for f in ("mkh_model_create", "mkh_problem_create", "mkh_problem_num_task_rows",
               "mkh_problem_num_collision_pairs", "mkh_solve", "mkh_eval", "mkh_integrate",
-              "mkh_problem_launch_info"):
+              "mkh_problem_launch_info", "mkh_solve_steps"):
         getattr(L, f).restype = C.c_int32
     _lib = L
     return L
@@ -144,6 +145,7 @@ EXPORTED_SYMBOLS = (
     "mkh_version", "mkh_last_error", "mkh_device_count", "mkh_model_create", "mkh_model_destroy",
     "mkh_problem_create", "mkh_problem_destroy", "mkh_problem_num_task_rows",
     "mkh_problem_num_collision_pairs", "mkh_solve", "mkh_eval", "mkh_integrate", "mkh_problem_launch_info",
+    "mkh_solve_steps",
 )
 
 
@@ -308,7 +310,7 @@ class NativeProblem:
 
     def solve(self, q, frame_targets=None, posture_target=None, com_target=None, dt: float = 1e-2,
               damping: float = 1e-12, taps: Sequence[str] = (), solve_qp: bool = True,
-              out=None, status_out=None):
+              out=None, status_out=None, n_steps: Optional[int] = None, q_out=None):
         """Returns (v, status[, taps dict]).  numpy in → numpy out (synchronous);
         torch CUDA tensors in → torch tensors out (asynchronous on the current stream)."""
         m = self.nmodel.model
@@ -374,6 +376,15 @@ class NativeProblem:
                 raise ValueError(f"com_target must have shape ({self.n_com}, 3) or (B, ...)")
         args = [self.handle, B, ptr(q), ptr(frame_targets), ptr(posture_target), ptr(com_target), float(dt),
                 float(damping), ptr(v), ptr(st)]
+        if n_steps is not None:
+            # fused (solve, integrate) x n_steps on the device: returns (q_final, v_last, status)
+            if use_torch:
+                import torch
+                qo = torch.empty_like(q) if q_out is None else q_out
+            else:
+                qo = np.empty_like(q) if q_out is None else q_out
+            _check(lib().mkh_solve_steps(*args[:8], int(n_steps), ptr(qo), ptr(v), ptr(st), flags, stream))
+            return qo, v, st
         if taps or not solve_qp:
             tp = MkhTaps()
             for n in taps:

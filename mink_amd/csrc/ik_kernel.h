@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
   const int ntab = nv + P0.max_rows;                   // tableau indices in use (upper bound)
 
   for (int pb = blockIdx.x; pb < A.B; pb += gridDim.x) {
-    int status = 0;
+    int status_all = 0;
     long long tc[8];
     int tci = 0;
 #define MKH_TICK() do { if (MKH_TAP(t_cycles)) tc[tci] = __builtin_readcyclecounter(); ++tci; } while (0)
@@ -185,6 +185,11 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
       if (lane < nc) sTgt[nt + lane] = A.com_target[(A.com_batched ? (size_t)pb * nc : 0) + lane];
     }
     wave_sync();
+    // Fused outer loop (mink's callers iterate solve_ik + integrate_inplace, e.g.
+    // examples/arm_ur5e_actuators.py:88-97): q stays in LDS between steps.
+    for (int step = 0; step < A.n_steps; ++step) {
+    int status = 0;
+    tci = 1;                                                 // phase stamps 1..7 belong to the current step
 
     // ------------------------------------------------- FK: local transforms
     // X = pose of body `lane` relative to its parent, joints applied
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
     wave_sync();
 
     MKH_TICK();   // 5: limits + collision rows done
-    if (!A.do_qp && !MKH_TAP(t_H)) continue;
+    if (!A.do_qp && !MKH_TAP(t_H)) break;
 
     // ------------------------------------------------- build the tableau column
     // lane j holds column j of K = [[H, Aᵀ],[A, 0]].  Built only now so that the 2·NT tableau
@@ -691,7 +696,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
         if (i < nv) hrow[(size_t)i * nv] = (i == lane) ? hdiag : Tab<NT>::template get<i>();
       });
     }
-    if (!A.do_qp) continue;
+    if (!A.do_qp) break;
     if (nrows > 0) {
       // rows nv+s of the dof columns (static register index, runtime LDS address) ...
       static_for<NT>([&](auto ic) {
@@ -843,11 +848,46 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
     MKH_TICK();   // 7: QP done
     if (MKH_TAP(t_cycles) && lane < 8) MKH_TAP(t_cycles)[(size_t)pb * 8 + lane] = (lane == 0) ? tc[0] : (lane == 1) ? tc[1] : (lane == 2) ? tc[2] : (lane == 3) ? tc[3] : (lane == 4) ? tc[4] : (lane == 5) ? tc[5] : (lane == 6) ? tc[6] : tc[7];
     if (MKH_TAP(t_qp_iters) && lane == 0) MKH_TAP(t_qp_iters)[pb] = iters;
-    if (A.v_out && is_dof) {
-      const double bad = __builtin_nan("");
-      A.v_out[(size_t)pb * nv + lane] = (status & 14) ? bad : s.z / A.dt;   // v = dq / dt (solve_ik.py:104)
+    status_all |= status;
+    const bool last = (step + 1 == A.n_steps) || (status & 14);
+    if (last) {
+      if (A.v_out && is_dof) {
+        const double bad = __builtin_nan("");
+        A.v_out[(size_t)pb * nv + lane] = (status & 14) ? bad : s.z / A.dt;   // v = dq / dt (solve_ik.py:104)
+      }
+      if (status & 14) break;
     }
-    if (A.status_out && lane == 0) A.status_out[pb] = status;
+    if (A.n_steps > 1 || A.q_out) {
+      // q ← q ⊕ Δq (mj_integratePos, Configuration.integrate_inplace, mink/configuration.py:228-236)
+      wave_sync();
+      if (is_dof) sDof[lane * 10 + 9] = s.z;                   // Δq of dof `lane` (slot 9 = q is dead now)
+      wave_sync();
+      if (lane < P.njnt) {
+        const int jt = P.jnt_i[lane * JI_COUNT + JI_TYPE];
+        int qa = P.jnt_i[lane * JI_COUNT + JI_QADR];
+        int va = P.jnt_i[lane * JI_COUNT + JI_DADR];
+        if (jt == JNT_HINGE || jt == JNT_SLIDE) {
+          sq[qa] += sDof[va * 10 + 9];
+        } else {
+          if (jt == JNT_FREE) {
+            for (int i = 0; i < 3; ++i) sq[qa + i] += sDof[(va + i) * 10 + 9];
+            qa += 3; va += 3;
+          }
+          V3 w{sDof[va * 10 + 9], sDof[(va + 1) * 10 + 9], sDof[(va + 2) * 10 + 9]};
+          const double n = sqrt(dot(w, w));
+          V3 ax = (n < 1e-15) ? V3{1.0, 0.0, 0.0} : (1.0 / n) * w;
+          Q4 qr = (n == 0.0) ? Q4{1, 0, 0, 0} : axis_angle(ax, n);
+          Q4 r = qmul(qnormalize(Q4{sq[qa], sq[qa + 1], sq[qa + 2], sq[qa + 3]}), qr);
+          sq[qa] = r.w; sq[qa + 1] = r.x; sq[qa + 2] = r.y; sq[qa + 3] = r.z;
+        }
+      }
+      wave_sync();
+    }
+    }  // step loop
+    if (A.q_out) {
+      for (int i = lane; i < nq; i += 64) A.q_out[(size_t)pb * nq + i] = sq[i];
+    }
+    if (A.status_out && lane == 0) A.status_out[pb] = status_all;
   }
 }
 

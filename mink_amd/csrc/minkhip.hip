@@ -468,9 +468,9 @@ struct TapBuf {
   void* host; void* dev; size_t bytes;
 };
 
-int32_t mkh_eval(MkhProblem* p, int32_t B, const double* q, const double* frame_targets, const double* posture_target,
-                 const double* com_target, double dt, double damping, double* v_out, int32_t* status_out,
-                 const MkhTaps* taps, int32_t flags, void* hip_stream) {
+static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* frame_targets, const double* posture_target,
+                   const double* com_target, double dt, double damping, double* v_out, int32_t* status_out,
+                   const MkhTaps* taps, int32_t flags, void* hip_stream, int32_t n_steps, double* q_out) {
   if (!p) return fail(MKH_E_INVALID, "null problem");
   if (B < 1) return fail(MKH_E_INVALID, "B must be >= 1");
   const DeviceProblem& P = p->dev;
@@ -479,6 +479,7 @@ int32_t mkh_eval(MkhProblem* p, int32_t B, const double* q, const double* frame_
   if (P.n_posture > 0 && !posture_target) return fail(MKH_E_INVALID, "posture_target is null (TargetNotSet)");
   if (P.n_com > 0 && !com_target) return fail(MKH_E_INVALID, "com_target is null (TargetNotSet)");
   if (!(dt > 0.0)) return fail(MKH_E_INVALID, "dt must be > 0");
+  if (n_steps < 1) return fail(MKH_E_INVALID, "n_steps must be >= 1");
   HIP_OK(hipSetDevice(p->model->device));
   hipStream_t stream = (hipStream_t)hip_stream;
   const bool devp = (flags & MKH_FLAG_DEVICE_PTRS) != 0;
@@ -489,13 +490,13 @@ int32_t mkh_eval(MkhProblem* p, int32_t B, const double* q, const double* frame_
   memset(&t, 0, sizeof t);
   bool any_tap = false;
   a.B = B; a.posture_batched = pbat; a.com_batched = cbat; a.do_qp = (v_out != nullptr);
-  a.dt = dt; a.damping = damping;
+  a.dt = dt; a.damping = damping; a.n_steps = n_steps;
   const size_t nq = P.nq, nv = P.nv;
   const size_t n_pt = (size_t)P.n_posture * nq * (pbat ? B : 1), n_ct = (size_t)P.n_com * 3 * (cbat ? B : 1);
   std::vector<TapBuf> tb;
   if (devp) {
     a.q = q; a.frame_targets = frame_targets; a.posture_target = posture_target; a.com_target = com_target;
-    a.v_out = v_out; a.status_out = status_out;
+    a.v_out = v_out; a.status_out = status_out; a.q_out = q_out;
     if (taps) {
       t.t_xpos = taps->xpos; t.t_xquat = taps->xquat; t.t_frame_pose = taps->frame_pose;
       t.t_subtree_com = taps->subtree_com; t.t_task_e = taps->task_e; t.t_task_J = taps->task_J; t.t_H = taps->H;
@@ -521,6 +522,7 @@ int32_t mkh_eval(MkhProblem* p, int32_t B, const double* q, const double* frame_
   a.q = p->s_q; a.frame_targets = p->s_ft; a.posture_target = p->s_pt; a.com_target = p->s_ct;
   a.v_out = v_out ? p->s_v : nullptr;
   a.status_out = p->s_status;
+  a.q_out = q_out ? p->s_q : nullptr;               // in place in the staging buffer
   int32_t rc = MKH_OK;
   auto tap = [&](void* host, size_t bytes, bool zero) -> void* {
     if (!host || rc != MKH_OK) return nullptr;
@@ -551,6 +553,7 @@ int32_t mkh_eval(MkhProblem* p, int32_t B, const double* q, const double* frame_
   if (rc == MKH_OK) {
     hipError_t e = hipSuccess;
     if (v_out) e = hipMemcpyAsync(v_out, p->s_v, (size_t)B * nv * sizeof(double), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && q_out) e = hipMemcpyAsync(q_out, p->s_q, (size_t)B * nq * sizeof(double), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess && status_out && v_out)
       e = hipMemcpyAsync(status_out, p->s_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
     for (auto& t : tb)
@@ -562,12 +565,28 @@ int32_t mkh_eval(MkhProblem* p, int32_t B, const double* q, const double* frame_
   return rc;
 }
 
+int32_t mkh_eval(MkhProblem* p, int32_t B, const double* q, const double* frame_targets, const double* posture_target,
+                 const double* com_target, double dt, double damping, double* v_out, int32_t* status_out,
+                 const MkhTaps* taps, int32_t flags, void* hip_stream) {
+  return run(p, B, q, frame_targets, posture_target, com_target, dt, damping, v_out, status_out, taps, flags, hip_stream,
+             1, nullptr);
+}
+
 int32_t mkh_solve(MkhProblem* p, int32_t B, const double* q, const double* frame_targets, const double* posture_target,
                   const double* com_target, double dt, double damping, double* v_out, int32_t* status_out,
                   int32_t flags, void* hip_stream) {
   if (!v_out) return fail(MKH_E_INVALID, "v_out is null");
-  return mkh_eval(p, B, q, frame_targets, posture_target, com_target, dt, damping, v_out, status_out, nullptr, flags,
-                  hip_stream);
+  return run(p, B, q, frame_targets, posture_target, com_target, dt, damping, v_out, status_out, nullptr, flags,
+             hip_stream, 1, nullptr);
+}
+
+int32_t mkh_solve_steps(MkhProblem* p, int32_t B, const double* q, const double* frame_targets,
+                        const double* posture_target, const double* com_target, double dt, double damping,
+                        int32_t n_steps, double* q_out, double* v_out, int32_t* status_out, int32_t flags,
+                        void* hip_stream) {
+  if (!v_out || !q_out) return fail(MKH_E_INVALID, "v_out / q_out is null");
+  return run(p, B, q, frame_targets, posture_target, com_target, dt, damping, v_out, status_out, nullptr, flags,
+             hip_stream, n_steps, q_out);
 }
 
 int32_t mkh_integrate(MkhModel* m, int32_t B, const double* q, const double* v, double dt, double* q_out,

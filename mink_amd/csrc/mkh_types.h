@@ -95,6 +95,8 @@ struct SolveArgs {
   double dt, damping;
   double* v_out;                   // (B, nv)
   int32_t* status_out;             // (B,)
+  int32_t n_steps;                 // fused outer loop: (solve, q ← q ⊕ v·dt) repeated n_steps times
+  double* q_out;                   // (B, nq) configuration after the last step (nullable)
 };
 
 // Debug/parity taps (nullable pointers).  Lives in device memory and is passed by pointer so

@@ -138,3 +138,24 @@ def solve_ik(configuration: Configuration, tasks: Sequence, dt: float, solver: s
     if return_status:
         return v, configuration._unbatch(status)
     return v
+
+
+def solve_ik_steps(configuration: Configuration, tasks: Sequence, dt: float, n_steps: int,
+                   solver: str = "mi355x", damping: float = 1e-12, safety_break: bool = False,
+                   limits: Optional[Sequence] = None, update: bool = True):
+    """`n_steps` iterations of  v = solve_ik(...); configuration.integrate_inplace(v, dt)  fused in one
+    kernel launch (the loop mink's callers write themselves, e.g. examples/arm_ur5e_actuators.py:88-97).
+
+    Returns (q_final, v_last); with `update` the configuration is advanced in place."""
+    prob, layout = _compile(configuration, tasks, limits, configuration.batch_size)
+    ft, pt, ct = _gather_targets(configuration, layout)
+    q, v, status = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping, n_steps=int(n_steps))
+    if (status & nat.ST_OUTSIDE_LIMITS).any() and safety_break:
+        configuration.check_limits(safety_break=True)
+    bad = np.nonzero(status & ~nat.ST_OUTSIDE_LIMITS)[0]
+    if len(bad):
+        raise exceptions.SolverError(f"QP failed for {len(bad)} of {len(status)} instances "
+                                     f"(first: index {int(bad[0])}, status {int(status[bad[0]])})")
+    if update:
+        configuration.update(q if configuration.batched else q[0])
+    return configuration._unbatch(q), configuration._unbatch(v)
