@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MKH_VERSION 100
+#define MKH_VERSION 101
 
 /* return codes */
 #define MKH_OK 0
@@ -87,6 +87,10 @@ typedef struct MkhFrameTaskDesc {
   int32_t frame_type, frame_id;
   double cost[6];
   double gain, lm_damping;
+  /* mink.RelativeFrameTask(frame, root, ...) — mink/tasks/relative_frame_task.py:28-48: pose of the
+   * frame expressed in `root`; root_type < 0 selects the plain FrameTask (pose in the world).  The
+   * task's target slot then holds transform_target_to_root. */
+  int32_t root_type, root_id;
 } MkhFrameTaskDesc;
 
 /* mink.PostureTask(model, cost, gain, lm_damping) — mink/tasks/posture_task.py:29-52.

@@ -45,7 +45,7 @@ class MkhFlatModel(C.Structure):
 
 class MkhFrameTaskDesc(C.Structure):
     _fields_ = [("frame_type", C.c_int32), ("frame_id", C.c_int32), ("cost", C.c_double * 6),
-                ("gain", C.c_double), ("lm_damping", C.c_double)]
+                ("gain", C.c_double), ("lm_damping", C.c_double), ("root_type", C.c_int32), ("root_id", C.c_int32)]
 
 
 class MkhPostureTaskDesc(C.Structure):
@@ -239,6 +239,8 @@ class NativeProblem:
             ft[i].frame_id = int(t["frame_id"])
             ft[i].cost = (C.c_double * 6)(*[float(x) for x in t["cost"]])
             ft[i].gain = float(t.get("gain", 1.0)); ft[i].lm_damping = float(t.get("lm_damping", 0.0))
+            ft[i].root_type = FRAME_TYPE_ID[t["root_type"]] if t.get("root_type") is not None else -1
+            ft[i].root_id = int(t.get("root_id", 0))
         pt = arr(MkhPostureTaskDesc, posture_tasks)
         for i, t in enumerate(posture_tasks):
             c = _f64(np.broadcast_to(t["cost"], (m.nv,))); keep.append(c)

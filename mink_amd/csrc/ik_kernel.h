@@ -40,7 +40,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
   L.X = o;    o += nbody * 8;
   L.jnt = o;  o += lds_even(njnt * 6);
   L.tgt = o;  o += lds_even(n_frame * 7 + n_com * 3);
-  L.task = o; o += n_frame * 48;
+  L.task = o; o += n_frame * 64;
   L.J = o;    o += 6 * nt;                          // weighted Jacobian rows of ONE task, [r][nt]
   L.dof = o;  o += lds_even(nv * 10);
   L.com = o;  o += (n_com > 0 ? nbody * 4 : 0);
@@ -132,13 +132,28 @@ __device__ __forceinline__ void pivot(QpLane& s, int k, bool reverse, int lane, 
 }
 
 // ----------------------------------------------------------------- the kernel
-template <int NT>
+// Compile-time feature set of a kernel variant.  The hot production variant (FEAT = 0) carries no
+// tap code, no RelativeFrameTask / CoM / collision branches and no fused step loop: fewer live values
+// for the compiler's 128-VGPR budget and a smaller instruction footprint.
+enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL = 31 };
+
 // P lives in device memory (not in the kernarg segment): hipcc materialises every by-value kernel
 // argument field in SGPRs at kernel entry and keeps it there, which starved the QP loop of SGPRs
 // (580 SGPR spills, v_readlane results serialised through one SGPR pair).
-#define MKH_TAP(f) (tp ? tp->f : nullptr)
-__global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __restrict__ Pg, const SolveArgs A,
-                                                         const TapArgs* __restrict__ tp) {
+// One kernel per translation unit: the variant TU defines MKH_NT (tableau rows per lane) and
+// MKH_FEAT before including this header.  Not a template because `amdgpu_num_vgpr` — the cap that
+// keeps the compiler out of the pinned tableau registers — only accepts an integer literal.
+#ifdef MKH_NT
+#define MKH_TAP(f) ((kTaps && tp) ? tp->f : nullptr)
+#define MKH_CAT2(a, b, c) a##b##_##c
+#define MKH_CAT(a, b, c) MKH_CAT2(a, b, c)
+#define MKH_KERNEL_NAME MKH_CAT(ik_solve_kernel_, MKH_NT, MKH_FEAT)
+static_assert(Tab<MKH_NT>::kCompilerVgprs == 256 - 2 * MKH_NT - 32, "register map of tab_asm.inc changed");
+__global__ __launch_bounds__(64, 2) __attribute__((amdgpu_num_vgpr(256 - 2 * MKH_NT - 32)))
+void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, const TapArgs* __restrict__ tp) {
+  constexpr int NT = MKH_NT, FEAT = MKH_FEAT;
+  constexpr bool kTaps = (FEAT & F_TAPS) != 0, kRel = (FEAT & F_REL) != 0, kCom = (FEAT & F_COM) != 0;
+  constexpr bool kColl = (FEAT & F_COLL) != 0, kSteps = (FEAT & F_STEPS) != 0;
   const DeviceProblem& P0 = *Pg;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = lane_id();
@@ -187,7 +202,8 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
     wave_sync();
     // Fused outer loop (mink's callers iterate solve_ik + integrate_inplace, e.g.
     // examples/arm_ur5e_actuators.py:88-97): q stays in LDS between steps.
-    for (int step = 0; step < A.n_steps; ++step) {
+    const int n_steps = kSteps ? A.n_steps : 1;
+    for (int step = 0; step < n_steps; ++step) {
     int status = 0;
     tci = 1;                                                 // phase stamps 1..7 belong to the current step
 
@@ -361,7 +377,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
 
     // -------------------------------------- subtree CoM (mj_comPos) for ComTask
     V3 com_root{0, 0, 0};
-    if (P.n_com > 0) {
+    if (kCom && P.n_com > 0) {
       V3 b_ipos{0, 0, 0};
       double b_mass = 0.0, b_stmass = 0.0;
       int b_last = 0, b_inrobot = 0;
@@ -414,15 +430,38 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
       F.q = qmul(bq, Q4{ft.lquat[0], ft.lquat[1], ft.lquat[2], ft.lquat[3]});
       const double* tg = sTgt + lane * 7;
       SE3 Tt{Q4{tg[0], tg[1], tg[2], tg[3]}, V3{tg[4], tg[5], tg[6]}};
-      // e = target.minus(frame) = log(T_frame⁻¹ · T_target)          (frame_task.py:119-122)
+      double* o = sTask + lane * 64;
       V3 ev, ew;
-      se3_log(se3_mul(se3_inv(F), Tt), ev, ew);
-      // jlog(T_tb) = ljacinv(−log(T_tb)) = ljacinv(e)   since T_tb = T_bt⁻¹   (frame_task.py:144-146)
       double Jm[9], Qm[9];
       bool ident;
-      se3_ljacinv(ev, ew, Jm, Qm, ident);
+      if (!(kRel && ft.relative)) {
+        // e = target.minus(frame) = log(T_frame⁻¹ · T_target)          (frame_task.py:119-122)
+        se3_log(se3_mul(se3_inv(F), Tt), ev, ew);
+        // jlog(T_tb) = ljacinv(−log(T_tb)) = ljacinv(e)   since T_tb = T_bt⁻¹   (frame_task.py:144-146)
+        se3_ljacinv(ev, ew, Jm, Qm, ident);
+      } else {
+        // RelativeFrameTask (relative_frame_task.py:106-142): T_fr = T_root⁻¹·T_frame,
+        // e = T_fr.rminus(target) = log(target⁻¹·T_fr),  J = jlog(T_tf)·(ᶠJ − Ad(T_fr⁻¹)·ʳJ)
+        const double* xr = sX + ft.root_body * 8;
+        Q4 rq0{xr[3], xr[4], xr[5], xr[6]};
+        SE3 Rt;
+        Rt.p = V3{xr[0], xr[1], xr[2]} + qrot(rq0, V3{ft.root_lpos[0], ft.root_lpos[1], ft.root_lpos[2]});
+        Rt.q = qmul(rq0, Q4{ft.root_lquat[0], ft.root_lquat[1], ft.root_lquat[2], ft.root_lquat[3]});
+        const SE3 Tfr = se3_mul(se3_inv(Rt), F);
+        se3_log(se3_mul(se3_inv(Tt), Tfr), ev, ew);
+        se3_ljacinv(-1.0 * ev, -1.0 * ew, Jm, Qm, ident);       // jlog(T) = ljacinv(−log T)
+        const SE3 Trf = se3_inv(Tfr);
+        const M3 Rr = qmat(Rt.q), Rrf = qmat(Trf.q);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { o[36 + i] = Rr.m[i]; o[48 + i] = Rrf.m[i]; }
+        o[45] = Rt.p.x; o[46] = Rt.p.y; o[47] = Rt.p.z;
+        o[57] = Trf.p.x; o[58] = Trf.p.y; o[59] = Trf.p.z;
+        if (MKH_TAP(t_frame_pose)) {                            // tap: pose of the frame in the root
+          double* t = MKH_TAP(t_frame_pose) + ((size_t)pb * P.n_frame + lane) * 7;
+          t[0] = Tfr.q.w; t[1] = Tfr.q.x; t[2] = Tfr.q.y; t[3] = Tfr.q.z; t[4] = Tfr.p.x; t[5] = Tfr.p.y; t[6] = Tfr.p.z;
+        }
+      }
       M3 Rf = qmat(F.q);
-      double* o = sTask + lane * 48;
 #pragma unroll
       for (int i = 0; i < 9; ++i) { o[i] = Jm[i]; o[9 + i] = Qm[i]; o[18 + i] = Rf.m[i]; }
       o[27] = F.p.x; o[28] = F.p.y; o[29] = F.p.z;
@@ -436,7 +475,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
         if (MKH_TAP(t_task_e)) MKH_TAP(t_task_e)[(size_t)pb * P.n_rows_tap + ft.row0 + r] = e6[r];
       }
       mu_lane = ft.lm_damping * ss;                          // task.py:131
-      if (MKH_TAP(t_frame_pose)) {
+      if (MKH_TAP(t_frame_pose) && !(kRel && ft.relative)) {
         double* t = MKH_TAP(t_frame_pose) + ((size_t)pb * P.n_frame + lane) * 7;
         t[0] = F.q.w; t[1] = F.q.x; t[2] = F.q.y; t[3] = F.q.z; t[4] = F.p.x; t[5] = F.p.y; t[6] = F.p.z;
       }
@@ -481,7 +520,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
       }
     }
     // ComTask error & LM term (com_task.py:71-82)
-    for (int t = 0; t < P.n_com; ++t) {
+    for (int t = 0; t < (kCom ? P.n_com : 0); ++t) {
       const double* tg = sTgt + P.n_frame * 7 + t * 3;
       const double e3[3] = {com_root.x - tg[0], com_root.y - tg[1], com_root.z - tg[2]};
       double ss = 0.0;
@@ -498,7 +537,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
     const double hdiag_base = hdiag;   // damping + Σμ + posture diagonal: the explicit diagonal of H
 
     // ------------------------------ frame + CoM tasks: Jacobian columns, H, c
-    const int n_jt = P.n_frame + P.n_com;
+    const int n_jt = P.n_frame + (kCom ? P.n_com : 0);
     // The tableau column lives in pinned VGPRs (tab_asm.inc), outside the compiler's budget, so H is
     // accumulated right here, task by task, while the lane still holds its own weighted column.
     Tab<NT>::zero();
@@ -515,18 +554,38 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
         second_half = ft.any_ori != 0;
         rowmask = ft.rowmask;
         jrow0 = ft.jrow0;
-        const double* o = sTask + t * 48;
+        const double* o = sTask + t * 64;
 #pragma unroll
         for (int r = 0; r < 6; ++r) { cw[r] = ft.cost[r]; we6[r] = o[30 + r]; }
-        if (is_dof && ((mask >> lane) & 1)) {
-          V3 pf{o[27], o[28], o[29]};
+        const bool rel = kRel && ft.relative != 0;
+        const uint64_t rmask = rel ? ft.root_mask : 0ull;
+        if (is_dof && (((mask | rmask) >> lane) & 1)) {
           MKH_LOAD_DOF_AXES();
-          V3 jp = d_lin + cross(d_ang, pf - d_anchor);
-          M3 Rf;
+          V3 a{0, 0, 0}, w{0, 0, 0};
+          if ((mask >> lane) & 1) {
+            V3 pf{o[27], o[28], o[29]};
+            V3 jp = d_lin + cross(d_ang, pf - d_anchor);
+            M3 Rf;
 #pragma unroll
-          for (int i = 0; i < 9; ++i) Rf.m[i] = o[18 + i];
-          V3 a = mulT(Rf, jp), w = mulT(Rf, d_ang);          // body-frame Jacobian (configuration.py:148-153)
-          // J_task = −jlog·ᴮJ with jlog = [[J, −J·Q·J],[0, J]]:  y = J·w;  rows 0-2 = −J·(a − Q·y), rows 3-5 = −y
+            for (int i = 0; i < 9; ++i) Rf.m[i] = o[18 + i];
+            a = mulT(Rf, jp); w = mulT(Rf, d_ang);             // body-frame Jacobian (configuration.py:148-153)
+          }
+          double sign = -1.0;                                   // FrameTask: J = −jlog(T_tb)·ᴮJ
+          if (rel) {
+            sign = 1.0;                                         // RelativeFrameTask: J = +jlog(T_tf)·(ᶠJ − Ad·ʳJ)
+            if ((rmask >> lane) & 1) {
+              V3 pr{o[45], o[46], o[47]};
+              V3 jp = d_lin + cross(d_ang, pr - d_anchor);
+              M3 Rr, Rrf;
+#pragma unroll
+              for (int i = 0; i < 9; ++i) { Rr.m[i] = o[36 + i]; Rrf.m[i] = o[48 + i]; }
+              V3 ar = mulT(Rr, jp), wr = mulT(Rr, d_ang);       // root's body-frame column
+              V3 Rw = mul(Rrf, wr);                             // Ad(T_fr⁻¹) = [[R, [t]×R],[0, R]]
+              a = a - (mul(Rrf, ar) + cross(V3{o[57], o[58], o[59]}, Rw));
+              w = w - Rw;
+            }
+          }
+          // jlog = [[J, −J·Q·J],[0, J]]:  y = J·w;  rows 0-2 = ±J·(a − Q·y), rows 3-5 = ±y
           const double wv[3] = {w.x, w.y, w.z};
           double y[3], z3[3];
 #pragma unroll
@@ -537,8 +596,8 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
             z3[r] = av[r] - (o[9 + 3 * r] * y[0] + o[9 + 3 * r + 1] * y[1] + o[9 + 3 * r + 2] * y[2]);
 #pragma unroll
           for (int r = 0; r < 3; ++r) {
-            Jt[r] = -(o[3 * r] * z3[0] + o[3 * r + 1] * z3[1] + o[3 * r + 2] * z3[2]);
-            Jt[3 + r] = -y[r];
+            Jt[r] = sign * (o[3 * r] * z3[0] + o[3 * r + 1] * z3[1] + o[3 * r + 2] * z3[2]);
+            Jt[3 + r] = sign * y[r];
           }
         }
       } else {
@@ -619,7 +678,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
 
     // ------------------------------------------- collision half-space rows
     int nrows = 0;
-    if (P.n_pairs > 0) {
+    if (kColl && P.n_pairs > 0) {
       for (int base = 0; base < P.n_pairs; base += 64) {
         const int pi = base + lane;
         bool active = false;
@@ -697,7 +756,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
       });
     }
     if (!A.do_qp) break;
-    if (nrows > 0) {
+    if (kColl && nrows > 0) {
       // rows nv+s of the dof columns (static register index, runtime LDS address) ...
       static_for<NT>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -849,7 +908,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
     if (MKH_TAP(t_cycles) && lane < 8) MKH_TAP(t_cycles)[(size_t)pb * 8 + lane] = (lane == 0) ? tc[0] : (lane == 1) ? tc[1] : (lane == 2) ? tc[2] : (lane == 3) ? tc[3] : (lane == 4) ? tc[4] : (lane == 5) ? tc[5] : (lane == 6) ? tc[6] : tc[7];
     if (MKH_TAP(t_qp_iters) && lane == 0) MKH_TAP(t_qp_iters)[pb] = iters;
     status_all |= status;
-    const bool last = (step + 1 == A.n_steps) || (status & 14);
+    const bool last = (step + 1 == n_steps) || (status & 14);
     if (last) {
       if (A.v_out && is_dof) {
         const double bad = __builtin_nan("");
@@ -857,7 +916,7 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
       }
       if (status & 14) break;
     }
-    if (A.n_steps > 1 || A.q_out) {
+    if (kSteps && (n_steps > 1 || A.q_out)) {
       // q ← q ⊕ Δq (mj_integratePos, Configuration.integrate_inplace, mink/configuration.py:228-236)
       wave_sync();
       if (is_dof) sDof[lane * 10 + 9] = s.z;                   // Δq of dof `lane` (slot 9 = q is dead now)
@@ -884,13 +943,16 @@ __global__ __launch_bounds__(64, 2) void ik_solve_kernel(const DeviceProblem* __
       wave_sync();
     }
     }  // step loop
-    if (A.q_out) {
+    if (kSteps && A.q_out) {
       for (int i = lane; i < nq; i += 64) A.q_out[(size_t)pb * nq + i] = sq[i];
     }
     if (A.status_out && lane == 0) A.status_out[pb] = status_all;
   }
 }
 
+#endif  // MKH_NT
+
+#ifndef MKH_NT   // the host translation unit (minkhip.hip) owns the small streaming kernel
 // q_out = q ⊕ v·dt (mj_integratePos; Configuration.integrate, mink/configuration.py:214-226).
 // One thread per (problem, joint).
 __global__ __launch_bounds__(256) void integrate_kernel(const DeviceProblem P, int B, const double* __restrict__ q,
@@ -921,5 +983,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(const DeviceProblem P, i
   Q4 r = qmul(q0, qr);
   qo[qa] = r.w; qo[qa + 1] = r.x; qo[qa + 2] = r.y; qo[qa + 3] = r.z;
 }
+
+#endif  // !MKH_NT
 
 }  // namespace mkh

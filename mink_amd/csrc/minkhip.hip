@@ -71,6 +71,7 @@ struct MkhProblem {
   int max_batch = 0;
   int lds_bytes = 0;
   int blocks_per_cu = 1;
+  bool has_relative = false;
   // device descriptor storage
   FrameTaskDev* d_frame = nullptr;
   double* d_posture_cost = nullptr;
@@ -83,6 +84,14 @@ struct MkhProblem {
   int32_t* s_status = nullptr;
   size_t s_pt_cap = 0, s_ct_cap = 0;
 };
+
+// Kernel variants live in their own translation units (mink_amd/csrc/build.py generates one
+// variant_<NT>_<FEAT>.hip per compiled combination so that they build in parallel); this is the
+// generated dispatcher.
+namespace mkh {
+int launch_variant(int nt, int feat, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
+                   const SolveArgs& a, const TapArgs* taps);
+}
 
 template <class T>
 static hipError_t ensure(T** buf, size_t n) {
@@ -287,22 +296,34 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     const MkhFrameTaskDesc& s = d->frame_tasks[t];
     FrameTaskDev& f = ft[t];
     memset(&f, 0, sizeof f);
-    const double *lp = nullptr, *lq = nullptr;
     static const double zero3[3] = {0, 0, 0}, ident4[4] = {1, 0, 0, 0};
-    if (s.frame_type == MKH_FRAME_BODY) {
-      if (s.frame_id < 0 || s.frame_id >= m->nbody) return bail(fail(MKH_E_INVALID, "frame task %d: body id %d out of range", t, s.frame_id));
-      f.body = s.frame_id; lp = zero3; lq = ident4;
-    } else if (s.frame_type == MKH_FRAME_SITE) {
-      if (s.frame_id < 0 || s.frame_id >= m->nsite) return bail(fail(MKH_E_INVALID, "frame task %d: site id %d out of range", t, s.frame_id));
-      f.body = m->site_bodyid[s.frame_id]; lp = &m->site_pos[3 * s.frame_id]; lq = &m->site_quat[4 * s.frame_id];
-    } else if (s.frame_type == MKH_FRAME_GEOM) {
-      if (s.frame_id < 0 || s.frame_id >= m->ngeom) return bail(fail(MKH_E_INVALID, "frame task %d: geom id %d out of range", t, s.frame_id));
-      f.body = m->geom_bodyid[s.frame_id]; lp = &m->geom_pos[3 * s.frame_id]; lq = &m->geom_quat[4 * s.frame_id];
-    } else {
-      return bail(fail(MKH_E_INVALID, "frame task %d: unsupported frame type %d", t, s.frame_type));
-    }
+    auto resolve = [&](int ftype, int fid, int32_t& body, const double*& lp, const double*& lq) -> int32_t {
+      if (ftype == MKH_FRAME_BODY) {
+        if (fid < 0 || fid >= m->nbody) return fail(MKH_E_INVALID, "frame task %d: body id %d out of range", t, fid);
+        body = fid; lp = zero3; lq = ident4;
+      } else if (ftype == MKH_FRAME_SITE) {
+        if (fid < 0 || fid >= m->nsite) return fail(MKH_E_INVALID, "frame task %d: site id %d out of range", t, fid);
+        body = m->site_bodyid[fid]; lp = &m->site_pos[3 * fid]; lq = &m->site_quat[4 * fid];
+      } else if (ftype == MKH_FRAME_GEOM) {
+        if (fid < 0 || fid >= m->ngeom) return fail(MKH_E_INVALID, "frame task %d: geom id %d out of range", t, fid);
+        body = m->geom_bodyid[fid]; lp = &m->geom_pos[3 * fid]; lq = &m->geom_quat[4 * fid];
+      } else {
+        return fail(MKH_E_INVALID, "frame task %d: unsupported frame type %d", t, ftype);
+      }
+      return MKH_OK;
+    };
+    const double *lp = nullptr, *lq = nullptr;
+    if (resolve(s.frame_type, s.frame_id, f.body, lp, lq) != MKH_OK) return bail(MKH_E_INVALID);
     for (int k = 0; k < 3; ++k) f.lpos[k] = lp[k];
     for (int k = 0; k < 4; ++k) f.lquat[k] = lq[k];
+    if (s.root_type >= 0) {
+      f.relative = 1;
+      p->has_relative = true;
+      if (resolve(s.root_type, s.root_id, f.root_body, lp, lq) != MKH_OK) return bail(MKH_E_INVALID);
+      for (int k = 0; k < 3; ++k) f.root_lpos[k] = lp[k];
+      for (int k = 0; k < 4; ++k) f.root_lquat[k] = lq[k];
+      f.root_mask = dof_chain_mask(m, f.root_body);
+    }
     for (int k = 0; k < 6; ++k) {
       if (!(s.cost[k] >= 0.0)) return bail(fail(MKH_E_INVALID, "frame task %d: cost must be >= 0", t));
       f.cost[k] = s.cost[k];
@@ -388,8 +409,11 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   P.n_pairs = (int)pairs.size();
   P.max_rows = P.n_pairs < (kWave - m->nv) ? P.n_pairs : (kWave - m->nv);
   const int ntab = m->nv + P.max_rows;
-  p->nt = ((ntab + 7) / 8) * 8;
-  if (p->nt < 8) p->nt = 8;
+  {
+    static const int kVariants[] = {8, 16, 24, 32, 48, 64};
+    p->nt = 64;
+    for (int v : kVariants) if (ntab <= v) { p->nt = v; break; }
+  }
 
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = upload(ft, &p->d_frame);
@@ -453,13 +477,16 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
     dtaps = p->d_taps;
   }
   const int grid = grid_for(p, a.B);
-#define MKH_LAUNCH(N) \
-  case N: hipLaunchKernelGGL(ik_solve_kernel<N>, dim3(grid), dim3(kWave), p->lds_bytes, stream, p->d_dev, a, dtaps); break;
-  switch (p->nt) {
-    MKH_LAUNCH(8) MKH_LAUNCH(16) MKH_LAUNCH(24) MKH_LAUNCH(32) MKH_LAUNCH(40) MKH_LAUNCH(48) MKH_LAUNCH(56)
-    default: hipLaunchKernelGGL(ik_solve_kernel<64>, dim3(grid), dim3(kWave), p->lds_bytes, stream, p->d_dev, a, dtaps); break;
-  }
-#undef MKH_LAUNCH
+  // lean production variant unless the call needs a feature it leaves out
+  int need = 0;
+  if (taps) need |= F_TAPS;
+  if (p->has_relative) need |= F_REL;
+  if (p->dev.n_com > 0) need |= F_COM;
+  if (p->dev.n_pairs > 0) need |= F_COLL;
+  if (a.n_steps > 1 || a.q_out) need |= F_STEPS;
+  const int feat = (need == 0) ? 0 : ((need == F_STEPS) ? F_STEPS : F_ALL);
+  if (mkh::launch_variant(p->nt, feat, grid, p->lds_bytes, stream, p->d_dev, a, dtaps) != 0)
+    return fail(MKH_E_INVALID, "no kernel variant for %d tableau rows", p->nt);
   HIP_OK(hipGetLastError());
   return MKH_OK;
 }

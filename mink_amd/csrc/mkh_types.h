@@ -43,6 +43,11 @@ struct FrameTaskDev {
   int32_t any_ori;       // any orientation cost > 0
   int32_t rowmask;       // bit r set iff cost[r] > 0: only those rows are staged in LDS / enter H
   int32_t jrow0;         // first compact LDS row of this task
+  int32_t relative;      // RelativeFrameTask: pose of the frame in the root frame
+  int32_t root_body;
+  double root_lpos[3];
+  double root_lquat[4];
+  uint64_t root_mask;
 };
 
 struct CollisionPairDev {

@@ -220,14 +220,24 @@ class ComTask(Task):
         return self.target_com
 
 
-class RelativeFrameTask(Task):
-    """mink/tasks/relative_frame_task.py — not on the accelerated path yet."""
+class RelativeFrameTask(FrameTask):
+    """mink/tasks/relative_frame_task.py:16-142: pose of a frame relative to another moving frame."""
 
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("RelativeFrameTask is not implemented on the device path yet")
+    def __init__(self, frame_name: str, frame_type: str, root_name: str, root_type: str, position_cost,
+                 orientation_cost, gain: float = 1.0, lm_damping: float = 0.0):
+        super().__init__(frame_name, frame_type, position_cost, orientation_cost, gain=gain, lm_damping=lm_damping)
+        self.root_name = root_name
+        self.root_type = root_type
 
-    def _native_desc(self, configuration):  # pragma: no cover
-        raise NotImplementedError
+    @property
+    def transform_target_to_root(self) -> Optional[SE3]:
+        return self.transform_target_to_world
 
-    def _native_target(self, configuration):  # pragma: no cover
-        raise NotImplementedError
+    def set_target_from_configuration(self, configuration: Configuration) -> None:
+        self.set_target(configuration.get_transform(self.frame_name, self.frame_type, self.root_name, self.root_type))
+
+    def _native_desc(self, configuration):
+        kind, d = super()._native_desc(configuration)
+        d["root_type"] = self.root_type
+        d["root_id"] = configuration._frame_id(self.root_name, self.root_type)
+        return kind, d

@@ -262,3 +262,42 @@ def test_limit_inequalities_vs_oracle():
         G, h = oik.limit_inequalities(o, oik.ConfigurationLimitSpec(0.5, 0.01), dt)
         np.testing.assert_allclose(hl[i], h, atol=1e-15)
         np.testing.assert_array_equal(Gl, G)
+
+
+def test_relative_frame_task(g1):
+    """reference tests/test_relative_frame_task.py:128-154 (root = world ⇒ −FrameTask) + oracle parity + FD."""
+    rng = np.random.default_rng(9)
+    from mink_amd import workloads
+    q = workloads.sample_q(g1, rng, 1, base_q=g1.key_qpos[0])[0]
+    cfg = mink.Configuration(g1, q)
+    target = mink.SE3(olie.se3_exp(rng.normal(size=6) * 0.3))
+    rel = mink.RelativeFrameTask("left_palm", "site", "world", "body", position_cost=1.0, orientation_cost=1.0)
+    rel.set_target(target)
+    absolute = mink.FrameTask("left_palm", "site", position_cost=1.0, orientation_cost=1.0)
+    absolute.set_target(target)
+    np.testing.assert_allclose(rel.compute_error(cfg), -absolute.compute_error(cfg), atol=1e-13)
+    np.testing.assert_allclose(rel.compute_jacobian(cfg), -absolute.compute_jacobian(cfg), atol=1e-11)
+    # moving root: palm relative to torso
+    rel = mink.RelativeFrameTask("left_palm", "site", "torso_link", "body", position_cost=[1.0, 2.0, 3.0],
+                                 orientation_cost=0.5, gain=0.8, lm_damping=0.3)
+    rel.set_target(target)
+    m = oc.model("g1")
+    spec = oik.RelativeFrameTaskSpec(m.name2id("site", "left_palm"), "site", m.name2id("body", "torso_link"), "body",
+                                     rel.cost, target.wxyz_xyz, 0.8, 0.3)
+    o = oik.Configuration(m, q)
+    e_ref, J_ref = oik.task_error_jacobian(o, spec)
+    np.testing.assert_allclose(rel.compute_error(cfg), e_ref, atol=1e-13)
+    np.testing.assert_allclose(rel.compute_jacobian(cfg), J_ref, atol=1e-11)
+    J, Jfd = _fd_jacobian(cfg, rel)
+    assert np.abs(J - Jfd).max() < 1e-5
+    H_ref, c_ref = oik.task_qp_objective(o, spec)
+    H, c = rel.compute_qp_objective(cfg)
+    np.testing.assert_allclose(H, H_ref, atol=1e-11 * np.abs(H_ref).max())
+    np.testing.assert_allclose(c, c_ref, atol=1e-12 * max(1.0, np.abs(c_ref).max()))
+    post = mink.PostureTask(g1, 1.0); post.set_target(g1.key_qpos[0])
+    v = mink.solve_ik(cfg, [rel, post], 1e-2, "mi355x", 1e-3, limits=[mink.ConfigurationLimit(g1)])
+    v_ref = oik.solve_ik(m, o, [spec, oik.PostureTaskSpec(np.ones(g1.nv), g1.key_qpos[0])], 1e-2, 1e-3,
+                         [oik.ConfigurationLimitSpec()])
+    np.testing.assert_allclose(v, v_ref, atol=1e-9 * max(1.0, np.abs(v_ref).max()))
+    rel.set_target_from_configuration(cfg)
+    np.testing.assert_allclose(rel.compute_error(cfg), 0.0, atol=1e-14)
