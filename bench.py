@@ -26,7 +26,36 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 BYTES_PER_SOLVE_G1 = 44 * 8 + 4 * 7 * 8 + 43 * 8 + 4   # q + 4 frame targets + v + status = 924 B
+FLOP_PER_SOLVE_G1 = (55 + 18) * 48 * 64 * 2             # issued fp64 FMA flops of the tableau per solve (≈0.45 Mflop)
 HBM_PEAK_GBS = 8000.0                                   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6                          # MI355X fp64 vector peak (same guide, chip table)
+
+
+def measured_traffic():
+    """HBM bytes per launch of the IK kernel from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate
+    rocprofv3 --pmc runs, calibrated on a known-size copy: tools/profile.sh, tools/rocprof_summary.py).
+    Counters cannot be read from inside a timed run, so this comes from the newest committed
+    profiles/*_pmc.json of the same workload; None when no calibrated summary exists."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "*_g1_b65536_pmc.json"))):
+        try:
+            with open(path) as fh:
+                hbm = json.load(fh).get("hbm", {})
+            if "traffic_bytes_per_launch" in hbm:
+                best = (hbm["traffic_bytes_per_launch"], os.path.relpath(path, REPO))
+        except (OSError, ValueError):
+            pass
+    return best
+
+
+def pcie_inclusive(prob, q_h, tg_h, stand, dt, damping, reps=3):
+    """Host-pointer call (the C ABI stages through pinned buffers: H2D q + targets, D2H v + status)."""
+    prob.solve(q_h, tg_h, stand[None, :], None, dt, damping)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        prob.solve(q_h, tg_h, stand[None, :], None, dt, damping)
+    return len(q_h) * reps / (time.perf_counter() - t0)
 
 
 def cpu_baseline(model, q, targets, posture_target, budget_s=15.0):
@@ -133,6 +162,7 @@ def main():
         value = total / elapsed
         ach = BYTES_PER_SOLVE_G1 * B / (kern_ms * 1e-3) / 1e9
         info = prob.launch_info(B)
+        traffic = measured_traffic() if B == 65536 else None
         out = {
             "metric": "IK solves/sec (whole node), Unitree G1 4 FrameTasks + box limits, batch 65536",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -144,12 +174,22 @@ def main():
                        "parallelism": f"batch-sharded x{world}" + (", RCCL gather of v" if do_gather else ""),
                        "launch": info, "failed_instances": n_bad},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": f"ik_solve_kernel<{info['tableau_rows']}>", "kernel_ms": kern_ms,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None,
+                         "kernel": f"ik_solve_kernel_{info['tableau_rows']}_0", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_solve": BYTES_PER_SOLVE_G1,
-                         "note": "fp64 VALU/latency-bound by design (≈0.15 Mflop per solve, nv=43); "
-                                 "HBM fraction reported as the contract requires"},
+                         "algorithmic_bytes_per_launch": BYTES_PER_SOLVE_G1 * B,
+                         "note": "fp64 VALU/latency-bound by design (nv=43 serial pivots in one wave); "
+                                 "HBM fraction reported as the contract requires, fp64 view alongside",
+                         # secondary compute view: issued fp64 tableau work only (55 pivots x NT rows x
+                         # 64 lanes x 2 flop + 18 H rank-1 updates), DESIGN.md §3.1
+                         "fp64_view": {"flop_per_solve": FLOP_PER_SOLVE_G1,
+                                       "achieved_tflops": FLOP_PER_SOLVE_G1 * B / (kern_ms * 1e-3) / 1e12,
+                                       "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                                       "frac": FLOP_PER_SOLVE_G1 * B / (kern_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS}},
         }
+        if world == 1:
+            out["pcie_inclusive_value"] = pcie_inclusive(prob, q_h, tg_h, stand, dt, damping)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, q_h, tg_h, stand)
         print(json.dumps(out))

@@ -16,21 +16,28 @@ register numbers:
 Register map for NT rows (wave64, 2 waves/SIMD ⇒ 256 VGPRs per lane):
     v[256-2·NT, 256)              tableau column (NT doubles)
     v[256-2·NT-32, 256-2·NT)      LDS staging for rank1 (8 × 128 bit in flight)
-    v[0, 256-2·NT-32)             everything the compiler allocates
+    v[0, 256-2·NT-16)             everything the compiler allocates
+
+The compiler's range overlaps the UPPER half of the staging registers: those are only ever live inside
+one asm statement (rank1_body, which lists them as clobbers), so the compiler may use them for values
+that do not live across a rank-1 update (FK, task algebra).  The LOWER half carries the loads that
+rank1_prefetch leaves in flight across compiler-generated code (reciprocal, multipliers) until
+rank1_body consumes them, so it stays out of the compiler's reach.
 """
 
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-NTS = (8, 16, 24, 32, 40, 48, 56, 64)
+NTS = (8, 16, 24, 32, 40, 44, 48, 56, 64)
 TOTAL = 256
 NTMP = 32  # 8 x b128
+NPRE = 4   # loads issued by rank1_prefetch (their 16 registers are off limits to the compiler)
 
 
 def gen(nt: int) -> str:
     t0 = TOTAL - 2 * nt
     tmp0 = t0 - NTMP
-    budget = tmp0
+    budget = tmp0 + 4 * NPRE
     treg = lambda i: f"v[{t0 + 2 * i}:{t0 + 2 * i + 1}]"
     clob_t = ",".join(f'"v{r}"' for r in range(t0, TOTAL))
     clob_tmp = ",".join(f'"v{r}"' for r in range(tmp0, t0))
@@ -51,13 +58,14 @@ def gen(nt: int) -> str:
         slot = k % depth
         r = tmp0 + 4 * slot
         return f"ds_read_b128 v[{r}:{r + 3}], %0 offset:{16 * k}"
-    lines = ["s_waitcnt lgkmcnt(0)"] + [load(k) for k in range(min(depth, nload))]
+    lines = ["s_waitcnt lgkmcnt(0)"] + [load(k) for k in range(min(NPRE, nload))]
     body = "\\n\\t".join(lines)
+    clob_pre = ",".join(f'"v{r}"' for r in range(tmp0, tmp0 + 4 * NPRE))
     out.append("  // issue the first loads of lds[0..kRows) (must be followed by rank1_body with the same address)")
     out.append("  __device__ static __forceinline__ void rank1_prefetch(unsigned lds_addr) {")
-    out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_tmp}, "memory");')
+    out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_pre}, "memory");')
     out.append("  }")
-    lines = []
+    lines = [load(k) for k in range(min(NPRE, nload), min(depth, nload))]
     for k in range(nload):
         issued = min(nload, k + depth)
         lines.append(f"s_waitcnt lgkmcnt({issued - k - 1})")

@@ -1,7 +1,9 @@
 // One-wavefront-per-problem differential-IK kernel for gfx950 (MI355X, wave64).
 //
 // One launch = one batched mink.solve_ik (mink/solve_ik.py:68-105).  A workgroup is
-// exactly one wavefront; it loops over problems b = blockIdx.x, += gridDim.x.
+// exactly one wavefront; it loops over the problems of its XCD's contiguous slice of the batch
+// (workgroups are dealt round-robin to the 8 XCDs, each with its own L2: keeping neighbouring rows of
+// q / targets / v in ONE L2 lets partial cache lines at row boundaries merge before they reach HBM).
 // Lanes change role by phase:
 //   body lane   (l < nbody)   forward kinematics by pointer jumping over the tree
 //                             (replaces mj_kinematics, mink/configuration.py:63)
@@ -26,6 +28,8 @@
 #include <utility>
 
 namespace mkh {
+
+constexpr int kNumXcd = 8;   // MI355X: 8 XCDs × 32 CUs, one L2 each
 
 // ------------------------------------------------------------------ LDS layout
 struct LdsLayout {
@@ -148,8 +152,8 @@ enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL =
 #define MKH_CAT2(a, b, c) a##b##_##c
 #define MKH_CAT(a, b, c) MKH_CAT2(a, b, c)
 #define MKH_KERNEL_NAME MKH_CAT(ik_solve_kernel_, MKH_NT, MKH_FEAT)
-static_assert(Tab<MKH_NT>::kCompilerVgprs == 256 - 2 * MKH_NT - 32, "register map of tab_asm.inc changed");
-__global__ __launch_bounds__(64, 2) __attribute__((amdgpu_num_vgpr(256 - 2 * MKH_NT - 32)))
+static_assert(Tab<MKH_NT>::kCompilerVgprs == 256 - 2 * MKH_NT - 16, "register map of tab_asm.inc changed");
+__global__ __launch_bounds__(64, 2) __attribute__((amdgpu_num_vgpr(256 - 2 * MKH_NT - 16)))
 void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, const TapArgs* __restrict__ tp) {
   constexpr int NT = MKH_NT, FEAT = MKH_FEAT;
   constexpr bool kTaps = (FEAT & F_TAPS) != 0, kRel = (FEAT & F_REL) != 0, kCom = (FEAT & F_COM) != 0;
@@ -176,7 +180,16 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   const bool is_dof = lane < nv;
   const int ntab = nv + P0.max_rows;                   // tableau indices in use (upper bound)
 
-  for (int pb = blockIdx.x; pb < A.B; pb += gridDim.x) {
+  // XCD-aware problem mapping: workgroup g runs on XCD g % 8; XCD x owns rows [x·per, (x+1)·per).
+  int pb_begin = blockIdx.x, pb_end = A.B, pb_stride = gridDim.x;
+  if ((gridDim.x & (kNumXcd - 1)) == 0) {
+    const int per = (A.B + kNumXcd - 1) / kNumXcd;
+    const int xcd = blockIdx.x & (kNumXcd - 1);
+    pb_stride = gridDim.x / kNumXcd;
+    pb_begin = xcd * per + blockIdx.x / kNumXcd;
+    pb_end = min(A.B, (xcd + 1) * per);
+  }
+  for (int pb = pb_begin; pb < pb_end; pb += pb_stride) {
     int status_all = 0;
     long long tc[8];
     int tci = 0;

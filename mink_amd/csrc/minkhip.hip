@@ -410,7 +410,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   P.max_rows = P.n_pairs < (kWave - m->nv) ? P.n_pairs : (kWave - m->nv);
   const int ntab = m->nv + P.max_rows;
   {
-    static const int kVariants[] = {8, 16, 24, 32, 48, 64};
+    static const int kVariants[] = {8, 16, 24, 32, 44, 48, 64};
     p->nt = 64;
     for (int v : kVariants) if (ntab <= v) { p->nt = v; break; }
   }

@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Condense rocprofv3 output directories into the small files kept under profiles/.
+
+  python tools/rocprof_summary.py pmc  <out.json> <dir> [<dir> ...]   # --pmc passes (one dir each)
+  python tools/rocprof_summary.py stats <out.csv> <dir>               # --kernel-trace --stats pass
+
+The pmc summary lists, per counter, the value of every dispatch of the IK kernel (summed over the
+counter's instances/XCDs) and of the calibration copy kernel (tools/pmc_workload.py), and derives
+HBM bytes per IK launch from FETCH_SIZE / WRITE_SIZE calibrated on that copy.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+COPY_BYTES = 64 * 1024 * 1024 * 8          # tools/pmc_workload.py: 512 MiB read and 512 MiB written
+
+
+def read_counters(d):
+    out = defaultdict(lambda: defaultdict(dict))  # kernel -> counter -> dispatch id -> value
+    res = {}
+    for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                k = row["Kernel_Name"]
+                c = row["Counter_Name"]
+                did = int(row["Dispatch_Id"])
+                out[k][c][did] = out[k][c].get(did, 0.0) + float(row["Counter_Value"])
+                if k not in res:
+                    res[k] = {f: row.get(f) for f in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size",
+                                                      "LDS_Block_Size", "Workgroup_Size", "Grid_Size")}
+    return out, res
+
+
+def pmc(out_path, dirs):
+    ik, copy, resources = defaultdict(list), defaultdict(list), {}
+    for d in dirs:
+        counters, res = read_counters(d)
+        for k, cs in counters.items():
+            if k.startswith("ik_solve_kernel") or "ik_solve_kernel" in k:
+                tgt = ik
+                resources[k] = res[k]
+            elif "copy" in k.lower() or "elementwise" in k.lower():
+                tgt = copy
+            else:
+                continue
+            for c, per in cs.items():
+                vals = [per[i] for i in sorted(per)]
+                # the copy kernel list may include small torch copies (H2D staging): keep the largest
+                if tgt is copy:
+                    tgt[c] = [max(vals + tgt.get(c, []))]
+                else:
+                    tgt[c] = tgt.get(c, []) + vals
+    summary = {"ik_solve_kernel": {c: {"per_dispatch": v} for c, v in sorted(ik.items())},
+               "calibration_copy_512MiB": {c: v[0] for c, v in sorted(copy.items())},
+               "kernel_resources": resources}
+    # HBM bytes per IK launch.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; the calibration
+    # factor is (known bytes) / (reported bytes) of the copy kernel in the same pass.
+    hbm = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        if c in ik and c in copy and copy[c][0] > 0:
+            cal = COPY_BYTES / (copy[c][0] * 1024.0)
+            solves = ik[c][1:] if len(ik[c]) > 1 else ik[c]      # dispatch 0 = FK-only target launch
+            raw = sum(solves) / len(solves) * 1024.0
+            hbm[c] = {"raw_bytes_per_launch": raw, "calibration_factor": cal, "bytes_per_launch": raw * cal}
+    if len(hbm) == 2:
+        hbm["traffic_bytes_per_launch"] = hbm["FETCH_SIZE"]["bytes_per_launch"] + hbm["WRITE_SIZE"]["bytes_per_launch"]
+    summary["hbm"] = hbm
+    with open(out_path, "w") as fh:
+        json.dump(summary, fh, indent=1)
+    print(json.dumps(hbm, indent=1))
+
+
+def stats(out_path, d):
+    paths = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    if not paths:
+        raise SystemExit(f"no kernel_stats.csv under {d}")
+    with open(paths[0]) as fh, open(out_path, "w") as out:
+        out.write(fh.read())
+    print(open(out_path).read())
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "pmc":
+        pmc(sys.argv[2], sys.argv[3:])
+    else:
+        stats(sys.argv[2], sys.argv[3])
