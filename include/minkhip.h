@@ -52,6 +52,7 @@ extern "C" {
 #define MKH_FLAG_DEVICE_PTRS 1   /* data pointers are device pointers; async on stream */
 #define MKH_FLAG_POSTURE_BATCHED 2  /* posture_target is (B, nq) instead of (nq,)       */
 #define MKH_FLAG_COM_BATCHED 4      /* com_target is (B, 3) instead of (3,)             */
+#define MKH_FLAG_DIRECT_QP 8        /* never use the low-rank start of the QP (parity/diagnostic switch) */
 
 /* frame types (mink/constants.py:3 SUPPORTED_FRAMES) */
 #define MKH_FRAME_BODY 0
@@ -183,6 +184,9 @@ int32_t mkh_problem_create(MkhModel *model, const MkhProblemDesc *desc, int32_t 
 void mkh_problem_destroy(MkhProblem *problem);
 int32_t mkh_problem_num_task_rows(const MkhProblem *problem);
 int32_t mkh_problem_num_collision_pairs(const MkhProblem *problem);
+/* Name of the kernel variant the last solve/eval on this handle launched ("" before the first call):
+ * "ik_solve_kernel_<rows>_<features>[_r<dof rows>]".  Diagnostic (benchmarks, profiles). */
+const char *mkh_problem_last_kernel(const MkhProblem *problem);
 
 /*
  * Batched mink.solve_ik (mink/solve_ik.py:68-105):

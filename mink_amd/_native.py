@@ -20,7 +20,7 @@ from .flatmodel import FlatModel
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libminkhip.so")
 
 MKH_OK = 0
-FLAG_DEVICE_PTRS, FLAG_POSTURE_BATCHED, FLAG_COM_BATCHED = 1, 2, 4
+FLAG_DEVICE_PTRS, FLAG_POSTURE_BATCHED, FLAG_COM_BATCHED, FLAG_DIRECT_QP = 1, 2, 4, 8
 ST_OUTSIDE_LIMITS, ST_INFEASIBLE, ST_NOT_PD, ST_ITER_LIMIT, ST_ROW_OVERFLOW = 1, 2, 4, 8, 16
 FRAME_TYPE_ID = {"body": 0, "geom": 1, "site": 2}
 
@@ -125,6 +125,8 @@ def lib() -> C.CDLL:
     L.mkh_problem_destroy.restype = None
     L.mkh_problem_num_task_rows.argtypes = [C.c_void_p]
     L.mkh_problem_num_collision_pairs.argtypes = [C.c_void_p]
+    L.mkh_problem_last_kernel.argtypes = [C.c_void_p]
+    L.mkh_problem_last_kernel.restype = C.c_char_p
     common = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
               C.c_void_p, C.c_void_p]
     L.mkh_solve.argtypes = common + [C.c_int32, C.c_void_p]
@@ -145,7 +147,7 @@ EXPORTED_SYMBOLS = (
     "mkh_version", "mkh_last_error", "mkh_device_count", "mkh_model_create", "mkh_model_destroy",
     "mkh_problem_create", "mkh_problem_destroy", "mkh_problem_num_task_rows",
     "mkh_problem_num_collision_pairs", "mkh_solve", "mkh_eval", "mkh_integrate", "mkh_problem_launch_info",
-    "mkh_solve_steps",
+    "mkh_solve_steps", "mkh_problem_last_kernel",
 )
 
 
@@ -294,6 +296,10 @@ class NativeProblem:
         except Exception:
             pass
 
+    def last_kernel(self) -> str:
+        """Kernel variant launched by the last solve on this handle (diagnostic)."""
+        return lib().mkh_problem_last_kernel(self.handle).decode()
+
     def launch_info(self, B: int) -> Dict[str, int]:
         g, b, l, t = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         _check(lib().mkh_problem_launch_info(self.handle, int(B), C.byref(g), C.byref(b), C.byref(l), C.byref(t)))
@@ -312,13 +318,13 @@ class NativeProblem:
 
     def solve(self, q, frame_targets=None, posture_target=None, com_target=None, dt: float = 1e-2,
               damping: float = 1e-12, taps: Sequence[str] = (), solve_qp: bool = True,
-              out=None, status_out=None, n_steps: Optional[int] = None, q_out=None):
+              out=None, status_out=None, n_steps: Optional[int] = None, q_out=None, direct_qp: bool = False):
         """Returns (v, status[, taps dict]).  numpy in → numpy out (synchronous);
         torch CUDA tensors in → torch tensors out (asynchronous on the current stream)."""
         m = self.nmodel.model
         use_torch = _is_torch(q)
         B = int(q.shape[0])
-        flags = 0
+        flags = FLAG_DIRECT_QP if direct_qp else 0
 
         def tgt(x, per, name):
             nonlocal flags

@@ -30,6 +30,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 NTS = (8, 16, 24, 32, 40, 44, 48, 56, 64)
 TOTAL = 256
+NRS = (16, 24, 32, 44, 48)   # dof-row counts of the low-rank start (kernel variants MKH_NR)
 NTMP = 32  # 8 x b128
 NPRE = 4   # loads issued by rank1_prefetch (their 16 registers are off limits to the compiler)
 
@@ -54,10 +55,10 @@ def gen(nt: int) -> str:
     # multiplier arithmetic between them so that the LDS latency of the first loads is hidden.
     nload = nt // 2
     depth = NTMP // 4
-    def load(k):
+    def load(k, addr="%0"):
         slot = k % depth
         r = tmp0 + 4 * slot
-        return f"ds_read_b128 v[{r}:{r + 3}], %0 offset:{16 * k}"
+        return f"ds_read_b128 v[{r}:{r + 3}], {addr} offset:{16 * k}"
     lines = ["s_waitcnt lgkmcnt(0)"] + [load(k) for k in range(min(NPRE, nload))]
     body = "\\n\\t".join(lines)
     clob_pre = ",".join(f'"v{r}"' for r in range(tmp0, tmp0 + 4 * NPRE))
@@ -102,6 +103,59 @@ def gen(nt: int) -> str:
     out.append('                 : "=&v"(lo), "=&v"(hi) : "s"(idx) : "m0");')
     out.append("    return __hiloint2double(hi, lo);")
     out.append("  }")
+    # runtime row write (VGPR index mode on the destination)
+    out.append("  // T[k] = x for a wave-uniform runtime k (lanes masked off by exec keep their value).")
+    out.append("  __device__ static __forceinline__ void set_dyn(int k, double x) {")
+    out.append("    const int lo = __double2loint(x), hi = __double2hiint(x);")
+    out.append("    const int idx = __builtin_amdgcn_readfirstlane(2 * k);")
+    out.append(f'    asm volatile("s_set_gpr_idx_on %2, gpr_idx(DST)\\n\\tv_mov_b32 v{t0}, %0\\n\\tv_mov_b32 v{t0 + 1}, %1\\n\\ts_set_gpr_idx_off"')
+    out.append(f'                 :: "v"(lo), "v"(hi), "s"(idx) : "m0", {clob_t});')
+    out.append("  }")
+    # partial-row primitives for the low-rank start (rows [0, NR) = the dof rows)
+    for nr in [r for r in NRS if r <= nt]:
+        nl = nr // 2
+        # rank1 over the first nr rows (prefetch is shared: it only issues the first NPRE loads)
+        lines = [load(k) for k in range(min(NPRE, nl), min(depth, nl))]
+        for k in range(nl):
+            issued = min(nl, k + depth)
+            lines.append(f"s_waitcnt lgkmcnt({issued - k - 1})")
+            r = tmp0 + 4 * (k % depth)
+            lines.append(f"v_fma_f64 {treg(2 * k)}, v[{r}:{r + 1}], %1, {treg(2 * k)}")
+            lines.append(f"v_fma_f64 {treg(2 * k + 1)}, v[{r + 2}:{r + 3}], %1, {treg(2 * k + 1)}")
+            if k + depth < nl:
+                lines.append(load(k + depth))
+        body = "\\n\\t".join(lines)
+        out.append(f"  // rank1_body restricted to rows [0, {nr})")
+        out.append(f"  __device__ static __forceinline__ void rank1_body_{nr}(unsigned lds_addr, double g) {{")
+        out.append(f'    asm volatile("{body}"')
+        out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
+        out.append("  }")
+        # dot: Σ_{i<nr} lds[i]·T[i]  (two accumulators break the FMA dependency chain)
+        lines = ["s_waitcnt lgkmcnt(0)"] + [load(k, "%2") for k in range(min(depth, nl))]
+        for k in range(nl):
+            issued = min(nl, k + depth)
+            lines.append(f"s_waitcnt lgkmcnt({issued - k - 1})")
+            r = tmp0 + 4 * (k % depth)
+            lines.append(f"v_fma_f64 %0, v[{r}:{r + 1}], {treg(2 * k)}, %0")
+            lines.append(f"v_fma_f64 %1, v[{r + 2}:{r + 3}], {treg(2 * k + 1)}, %1")
+            if k + depth < nl:
+                lines.append(load(k + depth, "%2"))
+        body = "\\n\\t".join(lines)
+        out.append(f"  // Σ_{{i<{nr}}} lds[i]·T[i]")
+        out.append(f"  __device__ static __forceinline__ double dot_{nr}(unsigned lds_addr) {{")
+        out.append("    double a0 = 0.0, a1 = 0.0;")
+        out.append(f'    asm volatile("{body}"')
+        out.append(f'                 : "+v"(a0), "+v"(a1) : "v"(lds_addr) : {clob_tmp}, "memory");')
+        out.append("    return a0 + a1;")
+        out.append("  }")
+        # column load: T[i] = lds[i] for i < nr (per-lane address, not a broadcast)
+        lines = [f"ds_read_b128 v[{t0 + 4 * k}:{t0 + 4 * k + 3}], %0 offset:{16 * k}" for k in range(nl)]
+        lines.append("s_waitcnt lgkmcnt(0)")
+        body = "\\n\\t".join(lines)
+        out.append(f"  // T[i] = lds[i], i < {nr}")
+        out.append(f"  __device__ static __forceinline__ void load_col_{nr}(unsigned lds_addr) {{")
+        out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_t}, "memory");')
+        out.append("  }")
     # get / set with compile-time index
     out.append("  template <int I> __device__ static __forceinline__ double get() {")
     out.append("    int lo, hi;")

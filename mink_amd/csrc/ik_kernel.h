@@ -37,7 +37,7 @@ struct LdsLayout {
 };
 __host__ __device__ inline int lds_even(int x) { return (x + 1) & ~1; }
 __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int njnt, int n_frame,
-                                                int n_posture, int n_com, int max_rows, int n_jrows, int nt) {
+                                                int n_posture, int n_com, int max_rows, int j_rows, int j_stride) {
   LdsLayout L;
   int o = 0;
   L.q = o;    o += lds_even(nq);
@@ -45,7 +45,9 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
   L.jnt = o;  o += lds_even(njnt * 6);
   L.tgt = o;  o += lds_even(n_frame * 7 + n_com * 3);
   L.task = o; o += n_frame * 64;
-  L.J = o;    o += 6 * nt;                          // weighted Jacobian rows of ONE task, [r][nt]
+  // weighted Jacobian rows [r][j_stride]: the 6 rows of ONE task at a time (direct start, stride NT), or
+  // every task row + one vector (low-rank start, stride NR)
+  L.J = o;    o += lds_even(j_rows * j_stride);
   L.dof = o;  o += lds_even(nv * 10);
   L.com = o;  o += (n_com > 0 ? nbody * 4 : 0);
   L.col = o;  o += max_rows * 16;
@@ -97,14 +99,16 @@ __device__ __forceinline__ double fast_rcp(double d) {
 
 template <int NT>
 __device__ __forceinline__ double publish_column(const QpLane& s, int col, int lane, double* sPiv,
-                                                 PivotScalars& ps) {
+                                                 PivotScalars& ps, int nact = kWave) {
   // Column `col` equals row `col` (R is symmetric): lane i holds R[col][i] in tableau register
   // `col`.  One indexed register read (VGPR index mode on the pinned base) + ONE ds_write_b64 for
   // the whole wave.  Having lane `col` dump its 48 registers itself costs 48 single-lane LDS
   // writes = 750-1850 cycles (measured, tools/ubench) — half of the whole pivot.  The pivot lane's
   // scalars ride along in the same LDS round trip (a v_readlane chain costs ~90 cycles each).
   const double rowv = Tab<NT>::get_dyn(col);
-  const double own = (lane == col) ? 0.0 : rowv;
+  // lanes ≥ nact hold dropped indices (task residuals of the low-rank start): they publish 0, so
+  // their columns stop changing and the rows they own leave every other column alone
+  const double own = (lane == col || lane >= nact) ? 0.0 : rowv;
   wave_sync();                                   // earlier readers of sPiv are done
   sPiv[lane] = own;
   if (lane == col) {
@@ -120,13 +124,40 @@ __device__ __forceinline__ double publish_column(const QpLane& s, int col, int l
 }
 
 // Symmetric sweep (reverse = un-sweep) on index k (wave-uniform); sPiv holds column k.
-template <int NT>
+template <int NT, int ROWS>
+__device__ __forceinline__ void rank1_rows(unsigned addr, double g) {
+  if constexpr (ROWS >= NT) Tab<NT>::rank1_body(addr, g);
+  else if constexpr (ROWS == 16) Tab<NT>::rank1_body_16(addr, g);
+  else if constexpr (ROWS == 24) Tab<NT>::rank1_body_24(addr, g);
+  else if constexpr (ROWS == 32) Tab<NT>::rank1_body_32(addr, g);
+  else if constexpr (ROWS == 44) Tab<NT>::rank1_body_44(addr, g);
+  else if constexpr (ROWS == 48) Tab<NT>::rank1_body_48(addr, g);
+}
+template <int NT, int ROWS>
+__device__ __forceinline__ double dot_rows(unsigned addr) {
+  if constexpr (ROWS == 16 && NT >= 16) return Tab<NT>::dot_16(addr);
+  else if constexpr (ROWS == 24 && NT >= 24) return Tab<NT>::dot_24(addr);
+  else if constexpr (ROWS == 32 && NT >= 32) return Tab<NT>::dot_32(addr);
+  else if constexpr (ROWS == 44 && NT >= 44) return Tab<NT>::dot_44(addr);
+  else if constexpr (ROWS == 48 && NT >= 48) return Tab<NT>::dot_48(addr);
+  else return 0.0;   // not a low-rank variant: never called
+}
+template <int NT, int ROWS>
+__device__ __forceinline__ void load_col_rows(unsigned addr) {
+  if constexpr (ROWS == 16 && NT >= 16) Tab<NT>::load_col_16(addr);
+  else if constexpr (ROWS == 24 && NT >= 24) Tab<NT>::load_col_24(addr);
+  else if constexpr (ROWS == 32 && NT >= 32) Tab<NT>::load_col_32(addr);
+  else if constexpr (ROWS == 44 && NT >= 44) Tab<NT>::load_col_44(addr);
+  else if constexpr (ROWS == 48 && NT >= 48) Tab<NT>::load_col_48(addr);
+}
+
+template <int NT, int ROWS = NT>
 __device__ __forceinline__ void pivot(QpLane& s, int k, bool reverse, int lane, const double* sPiv,
                                       double own, const PivotScalars& ps, double inv) {
   const double sk = ps.sg;
   const double ck = s.sg * sk * own;             // true T[lane][k]
   const double g = (sk * sk) * own * inv;        // R-units multiplier of this lane's column
-  Tab<NT>::rank1_body(lds_addr(sPiv), -g);       // R[i][lane] −= R[i][k]·g   (row k: published 0)
+  rank1_rows<NT, ROWS>(lds_addr(sPiv), -g);      // R[i][lane] −= R[i][k]·g   (row k: published 0)
   if (lane == k) {
     s.D = -inv;                                  // T[k][k] = −1/d
     s.sg = (reverse ? -sk : sk) * inv;           // row/column k scaled by ±1/d
@@ -139,7 +170,10 @@ __device__ __forceinline__ void pivot(QpLane& s, int k, bool reverse, int lane, 
 // Compile-time feature set of a kernel variant.  The hot production variant (FEAT = 0) carries no
 // tap code, no RelativeFrameTask / CoM / collision branches and no fused step loop: fewer live values
 // for the compiler's 128-VGPR budget and a smaller instruction footprint.
-enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL = 31 };
+// F_WOOD: low-rank ("Woodbury") start of the QP — H = Dg + JwᵀJw is never formed; the dof indices of the
+// augmented tableau [[Dg, Jwᵀ],[Jw, −I]] are swept in closed form and only the n_μ task-residual indices
+// take rank-1 pivots (18 instead of 43 for the G1 benchmark).  tools/proto_woodbury.py states it in numpy.
+enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL = 31, F_WOOD = 32 };
 
 // P lives in device memory (not in the kernarg segment): hipcc materialises every by-value kernel
 // argument field in SGPRs at kernel entry and keeps it there, which starved the QP loop of SGPRs
@@ -151,18 +185,27 @@ enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL =
 #define MKH_TAP(f) ((kTaps && tp) ? tp->f : nullptr)
 #define MKH_CAT2(a, b, c) a##b##_##c
 #define MKH_CAT(a, b, c) MKH_CAT2(a, b, c)
+#ifndef MKH_KERNEL_NAME   // low-rank variants (MKH_NR defined) are named by their translation unit
 #define MKH_KERNEL_NAME MKH_CAT(ik_solve_kernel_, MKH_NT, MKH_FEAT)
+#endif
 static_assert(Tab<MKH_NT>::kCompilerVgprs == 256 - 2 * MKH_NT - 16, "register map of tab_asm.inc changed");
 __global__ __launch_bounds__(64, 2) __attribute__((amdgpu_num_vgpr(256 - 2 * MKH_NT - 16)))
 void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, const TapArgs* __restrict__ tp) {
   constexpr int NT = MKH_NT, FEAT = MKH_FEAT;
   constexpr bool kTaps = (FEAT & F_TAPS) != 0, kRel = (FEAT & F_REL) != 0, kCom = (FEAT & F_COM) != 0;
-  constexpr bool kColl = (FEAT & F_COLL) != 0, kSteps = (FEAT & F_STEPS) != 0;
+  constexpr bool kColl = (FEAT & F_COLL) != 0, kSteps = (FEAT & F_STEPS) != 0, kWood = (FEAT & F_WOOD) != 0;
+#ifdef MKH_NR
+  constexpr int NR = MKH_NR;                 // dof rows of the tableau (low-rank start: NR ≥ nv, NT ≥ nv + n_μ)
+#else
+  constexpr int NR = NT;
+#endif
+  static_assert(!kWood || !(kTaps || kRel || kCom || kColl), "low-rank start: lean feature sets only");
   const DeviceProblem& P0 = *Pg;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = lane_id();
   const int nq = P0.nq, nv = P0.nv, nbody = P0.nbody;
-  const LdsLayout L = lds_layout(nq, nv, nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows, P0.n_jrows, NT);
+  const LdsLayout L = lds_layout(nq, nv, nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows,
+                                 kWood ? P0.n_jrows + 1 : 6, kWood ? NR : NT);
   double* const sq = smem + L.q;
   double* const sX = smem + L.X;
   double* const sJnt = smem + L.jnt;
@@ -554,6 +597,9 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // The tableau column lives in pinned VGPRs (tab_asm.inc), outside the compiler's budget, so H is
     // accumulated right here, task by task, while the lane still holds its own weighted column.
     Tab<NT>::zero();
+    // low-rank start: 1/√Dg of this dof (Dg = damping + Σμ + posture diagonal > 0, checked on the host)
+    const double dsq = (kWood && is_dof) ? 1.0 / sqrt(hdiag_base) : 0.0;
+    double we_mu = 0.0;
     for (int t = 0; t < n_jt; ++t) {
       double Jt[6] = {0, 0, 0, 0, 0, 0}, cw[6] = {0, 0, 0, 0, 0, 0}, we6[6] = {0, 0, 0, 0, 0, 0};
       uint64_t mask;
@@ -648,8 +694,25 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         Jw[r] = cw[r] * Jt[r];                               // weighted_jacobian (task.py:129)
-        c_lane -= we6[r] * Jw[r];                            // c = −weighted_errorᵀ·weighted_jacobian
+        if (!kWood) c_lane -= we6[r] * Jw[r];                // c = −weighted_errorᵀ·weighted_jacobian
         hdiag += Jw[r] * Jw[r];
+      }
+      if (kWood) {
+        // Low-rank start: row r of Jh = Jw/√Dg is residual index nv + jrow0 + c of the tableau.  The dof
+        // lane keeps its entry in register row nv + jrow0 + c and stages it in LDS (all rows persist:
+        // the residual lanes load their columns from there, and S = I + Jh·Jhᵀ is a dot against it).
+        double* o = sJ + jrow0 * NR + lane;
+        int c = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+          if ((rowmask >> r) & 1) {
+            const double jh = is_dof ? Jw[r] * dsq : 0.0;
+            if (lane < NR) o[c * NR] = jh;
+            Tab<NT>::set_dyn(nv + jrow0 + c, jh);
+            if (lane == nv + jrow0 + c) we_mu = we6[r];       // weighted error of "my" residual
+            ++c;
+          }
+        continue;
       }
       wave_sync();                                             // previous task's rows are consumed
       if (lane < NT) {
@@ -666,6 +729,24 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
 #pragma unroll
         for (int r = 0; r < 6; ++r)
           if ((rowmask >> r) & 1) { Tab<NT>::rank1(lds_addr(sJ + c * NT), is_dof ? Jw[r] : 0.0); ++c; }
+      }
+    }
+    // ---- low-rank start: residual columns, S block, right-hand sides
+    const int n_mu = kWood ? P.n_jrows : 0;
+    const bool is_mu = kWood && lane >= nv && lane < nv + n_mu;
+    double D_mu = 1.0, w_mu = 0.0;
+    if (kWood) {
+      // x after the closed-form dof sweeps: z_k = −c_k/Dg_k (posture part of c only); staged as z_k·√Dg_k
+      if (lane < NR) sJ[n_mu * NR + lane] = is_dof ? -c_lane * dsq : 0.0;
+      wave_sync();
+      if (is_mu) load_col_rows<NT, NR>(lds_addr(sJ + (lane - nv) * NR));   // T[dof i][μ] = Jh[μ][i]
+      w_mu = dot_rows<NT, NR>(lds_addr(sJ + n_mu * NR)) - we_mu;          // Jw·z − r
+      for (int r = 0; r < n_mu; ++r) {
+        const double acc = dot_rows<NT, NR>(lds_addr(sJ + r * NR));       // (Jh·Jhᵀ)[r][lane − nv]
+        if (is_mu) {
+          if (lane - nv == r) D_mu = -(1.0 + acc);
+          Tab<NT>::set_dyn(nv + r, -acc);                                  // −S  (diagonal register unused)
+        }
       }
     }
     if (MKH_TAP(t_c) && is_dof) MKH_TAP(t_c)[(size_t)pb * nv + lane] = c_lane;
@@ -793,7 +874,18 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     s.D = is_dof ? hdiag : ((lane >= ntab) ? 1.0 : 0.0);   // true diagonal of K
     s.z = 0.0;
     double rown = 1.0;
-    if (is_dof) {
+    if (kWood) {
+      // state after the closed-form sweep of every dof of [[Dg, Jwᵀ],[Jw, −I]]
+      s.kind = is_dof ? 0 : (is_mu ? 3 : 2);
+      s.sg = is_dof ? dsq : 1.0;
+      s.D = is_dof ? -(dsq * dsq) : D_mu;
+      s.basic = is_dof ? 1 : 0;
+      s.z = is_dof ? -c_lane * (dsq * dsq) : 0.0;
+      s.w = w_mu;                                            // 0 on dof lanes (dot of zero rows) and padding
+      if (!is_mu) s.w = 0.0;
+      s.lo = is_dof ? lo : -kInf;
+      s.hi = is_dof ? hi : kInf;
+    } else if (is_dof) {
       s.kind = 0; s.w = c_lane; s.lo = lo; s.hi = hi;
     } else if (lane < nv + nrows) {
       s.kind = 1; s.lo = 0.0; s.hi = kInf;
@@ -816,11 +908,13 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // ---- phase 0: bring every dof into the basis, x0 = −H⁻¹c (Gauss–Jordan, no ratio tests).
     // Tight loop: publish row k → (LDS loads of the rank-1 update already in flight) → 1/d,
     // multipliers, z/w update → rank-1 update.
-    for (int k = 0; k < nv; ++k) {
+    // (low-rank start: the dofs are already in; the n_μ residual indices nv.. take the pivots, d < 0)
+    const int k_begin = kWood ? nv : 0, k_end = kWood ? nv + n_mu : nv;
+    for (int k = k_begin; k < k_end; ++k) {
       PivotScalars ps;
       const double own = publish_column<NT>(s, k, lane, sPiv, ps);
       Tab<NT>::rank1_prefetch(lds_addr(sPiv));
-      if (!(ps.d > 0.0)) { status |= 4; break; }
+      if (!((kWood ? -ps.d : ps.d) > 0.0)) { status |= 4; break; }
       const double inv = fast_rcp(ps.d);
       const double tau = (lane == k) ? ps.d : s.sg * ps.sg * own;     // column k of the tableau
       const double alpha = -ps.w * inv;
@@ -828,6 +922,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       if (lane == k) { s.z += alpha; s.w = 0.0; s.basic = 1; }
       pivot<NT>(s, k, false, lane, sPiv, own, ps, inv);
     }
+    if (kWood && is_mu) s.kind = 2;                          // residual indices are never touched again
+    const int nact = kWood ? nv : kWave;                     // lanes that still own a live index
     // ---- phase 1: Goldfarb–Idnani.  Each iteration publishes ONE column `col`; a blocking
     // constraint found by the ratio test becomes the column of the next iteration (`pend`).
     int p = -1;          // index being driven (−1 ⇒ select a new one)
@@ -863,7 +959,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         col = p;
       }
       PivotScalars ps;
-      const double own = publish_column<NT>(s, col, lane, sPiv, ps);
+      const double own = publish_column<NT>(s, col, lane, sPiv, ps, nact);
       Tab<NT>::rank1_prefetch(lds_addr(sPiv));
       const double inv = fast_rcp(ps.d);                         // 1 / T[col][col]
       bool rev = false;
@@ -915,7 +1011,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           continue;
         }
       }
-      pivot<NT>(s, col, rev, lane, sPiv, own, ps, inv);
+      pivot<NT, NR>(s, col, rev, lane, sPiv, own, ps, inv);
     }
     MKH_TICK();   // 7: QP done
     if (MKH_TAP(t_cycles) && lane < 8) MKH_TAP(t_cycles)[(size_t)pb * 8 + lane] = (lane == 0) ? tc[0] : (lane == 1) ? tc[1] : (lane == 2) ? tc[2] : (lane == 3) ? tc[3] : (lane == 4) ? tc[4] : (lane == 5) ? tc[5] : (lane == 6) ? tc[6] : tc[7];

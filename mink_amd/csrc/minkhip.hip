@@ -72,6 +72,12 @@ struct MkhProblem {
   int lds_bytes = 0;
   int blocks_per_cu = 1;
   bool has_relative = false;
+  // low-rank ("Woodbury") start of the QP (ik_kernel.h F_WOOD): compiled (NT, NR) pair or 0 when the
+  // problem does not qualify; lower bound of the diagonal part of H without the damping argument, and
+  // the largest squared task cost (conditioning gate, evaluated per call because damping is a call argument)
+  int wood_nt = 0, wood_nr = 0, wood_lds_bytes = 0;
+  double wood_min_diag = 0.0, wood_max_cost2 = 0.0;
+  char last_kernel[64] = "";
   // device descriptor storage
   FrameTaskDev* d_frame = nullptr;
   double* d_posture_cost = nullptr;
@@ -89,7 +95,7 @@ struct MkhProblem {
 // variant_<NT>_<FEAT>.hip per compiled combination so that they build in parallel); this is the
 // generated dispatcher.
 namespace mkh {
-int launch_variant(int nt, int feat, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
+int launch_variant(int nt, int nr, int feat, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
                    const SolveArgs& a, const TapArgs* taps);
 }
 
@@ -427,13 +433,38 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   P.vel_limit = p->d_vel; P.pairs = p->d_pairs;
 
   P.nt = p->nt;
-  const LdsLayout L = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, P.n_jrows, p->nt);
+  const LdsLayout L = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, p->nt);
   p->lds_bytes = L.total * (int)sizeof(double);
   if (p->lds_bytes > 64 * 1024) return bail(fail(MKH_E_LIMIT, "problem needs %d bytes of LDS per wavefront (> 64 KiB)", p->lds_bytes));
   // resident waves per CU: bounded by LDS (160 KiB/CU) and by VGPRs (launch_bounds: 2 waves/SIMD)
   int by_lds = (160 * 1024) / (p->lds_bytes > 0 ? p->lds_bytes : 1);
   p->blocks_per_cu = by_lds < 8 ? by_lds : 8;
   if (p->blocks_per_cu < 1) p->blocks_per_cu = 1;
+  // ---- low-rank start eligibility: box limits only, frame tasks only, few task rows relative to nv
+  if (P.n_jrows > 0 && P.n_pairs == 0 && P.n_com == 0 && !p->has_relative && 2 * P.n_jrows <= m->nv &&
+      m->nv + P.n_jrows <= kWave) {
+    static const int kWoodVariants[][2] = {{32, 16}, {32, 24}, {48, 24}, {48, 32}, {64, 32}, {64, 44}, {64, 48}};
+    for (const auto& v : kWoodVariants)
+      if (m->nv <= v[1] && m->nv + P.n_jrows <= v[0]) { p->wood_nt = v[0]; p->wood_nr = v[1]; break; }
+    if (p->wood_nt) {
+      const LdsLayout Lw = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows,
+                                      P.n_jrows + 1, p->wood_nr);
+      p->wood_lds_bytes = Lw.total * (int)sizeof(double);
+      if (p->wood_lds_bytes * 8 > 160 * 1024) p->wood_nt = 0;      // would cost residency
+      double mn = __builtin_huge_val();
+      for (int i = 0; i < m->nv; ++i) {
+        double dsum = 0.0;
+        for (int t = 0; t < d->n_posture_tasks; ++t) {
+          // free-joint dofs carry no posture term (posture_task.py:115-116,139-141)
+          const int jt = m->jnt_type[m->dof_jntid[i]];
+          if (jt != 0) dsum += pcost[t * 64 + i] * pcost[t * 64 + i];
+        }
+        mn = dsum < mn ? dsum : mn;
+      }
+      p->wood_min_diag = mn;
+      for (const auto& f : ft) for (int k = 0; k < 6; ++k) p->wood_max_cost2 = fmax(p->wood_max_cost2, f.cost[k] * f.cost[k]);
+    }
+  }
   if (hipMalloc((void**)&p->d_dev, sizeof(DeviceProblem)) != hipSuccess ||
       hipMemcpy(p->d_dev, &p->dev, sizeof(DeviceProblem), hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc((void**)&p->d_taps, sizeof(TapArgs)) != hipSuccess)
@@ -451,6 +482,7 @@ void mkh_problem_destroy(MkhProblem* p) {
   delete p;
 }
 
+const char* mkh_problem_last_kernel(const MkhProblem* p) { return p ? p->last_kernel : ""; }
 int32_t mkh_problem_num_task_rows(const MkhProblem* p) { return p ? p->dev.n_rows_tap : 0; }
 int32_t mkh_problem_num_collision_pairs(const MkhProblem* p) { return p ? p->dev.n_pairs : 0; }
 
@@ -469,7 +501,7 @@ int32_t mkh_problem_launch_info(const MkhProblem* p, int32_t B, int32_t* grid, i
   return MKH_OK;
 }
 
-static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hipStream_t stream) {
+static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hipStream_t stream, int32_t flags) {
   const TapArgs* dtaps = nullptr;
   if (taps) {
     HIP_OK(hipMemcpyAsync(p->d_taps, taps, sizeof(TapArgs), hipMemcpyHostToDevice, stream));
@@ -484,9 +516,18 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   if (p->dev.n_com > 0) need |= F_COM;
   if (p->dev.n_pairs > 0) need |= F_COLL;
   if (a.n_steps > 1 || a.q_out) need |= F_STEPS;
-  const int feat = (need == 0) ? 0 : ((need == F_STEPS) ? F_STEPS : F_ALL);
-  if (mkh::launch_variant(p->nt, feat, grid, p->lds_bytes, stream, p->d_dev, a, dtaps) != 0)
-    return fail(MKH_E_INVALID, "no kernel variant for %d tableau rows", p->nt);
+  int feat = (need == 0) ? 0 : ((need == F_STEPS) ? F_STEPS : F_ALL);
+  int nt = p->nt, nr = 0, lds = p->lds_bytes;
+  // Low-rank start when the problem qualifies and the diagonal part of H is not tiny against JwᵀJw
+  // (error amplification of the quasi-definite elimination ≈ eps·max cost²/min Dg ≤ 1e-9).
+  const double dg_min = a.damping + p->wood_min_diag;
+  if (p->wood_nt && (need & ~F_STEPS) == 0 && a.do_qp && !(flags & MKH_FLAG_DIRECT_QP) && dg_min > 0.0 &&
+      dg_min >= 1e-7 * p->wood_max_cost2) {
+    nt = p->wood_nt; nr = p->wood_nr; lds = p->wood_lds_bytes; feat |= F_WOOD;
+  }
+  snprintf(p->last_kernel, sizeof(p->last_kernel), nr ? "ik_solve_kernel_%d_%d_r%d" : "ik_solve_kernel_%d_%d", nt, feat, nr);
+  if (mkh::launch_variant(nt, nr, feat, grid, lds, stream, p->d_dev, a, dtaps) != 0)
+    return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
   HIP_OK(hipGetLastError());
   return MKH_OK;
 }
@@ -531,7 +572,7 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
       t.t_coll_h = taps->coll_h; t.t_qp_iters = taps->qp_iters; t.t_cycles = (long long*)taps->cycles;
       if (t.t_coll_G) HIP_OK(hipMemsetAsync(t.t_coll_G, 0, (size_t)B * P.n_pairs * nv * sizeof(double), stream));
     }
-    return launch(p, a, taps ? &t : nullptr, stream);
+    return launch(p, a, taps ? &t : nullptr, stream, flags);
   }
   // ---- host pointers: stage through library-owned device buffers
   if (B > p->max_batch) return fail(MKH_E_INVALID, "B=%d exceeds max_batch=%d of this problem", B, p->max_batch);
@@ -576,7 +617,7 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
     t.t_qp_iters = (int32_t*)tap(taps->qp_iters, Bz * 4, true);
     t.t_cycles = (long long*)tap(taps->cycles, Bz * 8 * 8, true);
   }
-  if (rc == MKH_OK) rc = launch(p, a, taps ? &t : nullptr, stream);
+  if (rc == MKH_OK) rc = launch(p, a, taps ? &t : nullptr, stream, flags);
   if (rc == MKH_OK) {
     hipError_t e = hipSuccess;
     if (v_out) e = hipMemcpyAsync(v_out, p->s_v, (size_t)B * nv * sizeof(double), hipMemcpyDeviceToHost, stream);

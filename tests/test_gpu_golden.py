@@ -90,3 +90,11 @@ def test_intermediates_and_velocity(nat, name):
     # sub-stream (every 8th sample, δ ~ 1e-4) is allowed 1e-5 (reference jlog noise ~5e-17/θ²)
     assert err[main].max() < 1e-8
     assert err[~main].max() < 1e-5
+    # the production call (no taps) runs the lean kernel variant — for g1_c3 with the low-rank QP start
+    v2, st2 = prob.solve(d["q"], d["frame_targets"], d["posture_target"][None, :], com, dt, damping)
+    err2 = np.abs(v2 - d["v"]) / vs
+    print(name, "production kernel", prob.last_kernel(), "max rel v err", err2.max())
+    if name == "g1_c3":
+        assert prob.last_kernel() == "ik_solve_kernel_64_32_r44"
+    assert (st2 == st).all()
+    assert err2[main].max() < 1e-8 and err2[~main].max() < 1e-5

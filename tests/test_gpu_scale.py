@@ -37,12 +37,25 @@ def test_g1_full_batch_properties(g1_setup):
     assert (dq <= hi + tol).all() and (dq >= lo - tol).all()       # primal feasibility of all 65 536
     it = taps["qp_iters"]
     print("G1 B=65536: active-set pivots after x0: mean %.1f max %d" % (it.mean(), it.max()))
+    # the tap call runs the full-feature kernel with the direct QP start, the plain call the lean kernel
+    # with the low-rank start: same optimum, different elimination order
+    v2, st2 = prob.solve(q, tg, stand[None, :], None, dt, damping)
+    assert prob.last_kernel().endswith("_r44"), prob.last_kernel()
+    assert (st2 == 0).all()
+    assert np.abs(v2 - v).max() <= 1e-8 * max(1.0, np.abs(v).max())
     # determinism + permutation equivariance (bitwise)
-    v2, _ = prob.solve(q, tg, stand[None, :], None, dt, damping)
-    np.testing.assert_array_equal(v, v2)
+    v2b, _ = prob.solve(q, tg, stand[None, :], None, dt, damping)
+    np.testing.assert_array_equal(v2, v2b)
     perm = np.random.default_rng(0).permutation(B)
     v3, _ = prob.solve(q[perm], tg[perm], stand[None, :], None, dt, damping)
-    np.testing.assert_array_equal(v3, v[perm])
+    np.testing.assert_array_equal(v3, v2[perm])
+    # ... and the lean kernel with the direct start (MKH_FLAG_DIRECT_QP)
+    v4, st4 = prob.solve(q, tg, stand[None, :], None, dt, damping, direct_qp=True)
+    assert prob.last_kernel() == "ik_solve_kernel_44_0", prob.last_kernel()
+    assert (st4 == 0).all()
+    err = np.abs(v4 - v2).max() / max(1.0, np.abs(v).max())
+    print("G1 B=65536: low-rank start vs direct start, max rel |dv| = %.2e" % err)
+    assert err <= 1e-8
     # KKT on a sample: H dq + c = −μ with μ only on active bounds and correctly signed
     idx = np.arange(0, B, 257)[:256]
     _, _, t = prob.solve(q[idx], tg[idx], stand[None, :], None, dt, damping, taps=["H", "c"])
