@@ -15,14 +15,13 @@ register numbers:
 
 Register map for NT rows (wave64, 2 waves/SIMD ⇒ 256 VGPRs per lane):
     v[256-2·NT, 256)              tableau column (NT doubles)
-    v[256-2·NT-32, 256-2·NT)      LDS staging for rank1 (8 × 128 bit in flight)
-    v[0, 256-2·NT-16)             everything the compiler allocates
+    v[256-2·NT-S, 256-2·NT)       LDS staging for rank1 (S = 32: 8 × 128 bit in flight; S = 16 for NT ≥ 56)
+    v[0, 256-2·NT-S)              everything the compiler allocates
 
-The compiler's range overlaps the UPPER half of the staging registers: those are only ever live inside
-one asm statement (rank1_body, which lists them as clobbers), so the compiler may use them for values
-that do not live across a rank-1 update (FK, task algebra).  The LOWER half carries the loads that
-rank1_prefetch leaves in flight across compiler-generated code (reciprocal, multipliers) until
-rank1_body consumes them, so it stays out of the compiler's reach.
+The staging range must stay ABOVE the compiler's cap even though half of it is only live inside one asm
+statement: the VGPRs hipcc reserves for SGPR spills are the highest ones below the cap, reserved
+registers are not preserved across an asm that lists them as clobbers (clang warns, and the spilled
+SGPRs really are lost — seen as a QP that never converges in the one variant with 400 SGPR spills).
 """
 
 import os
@@ -31,14 +30,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 NTS = (8, 16, 24, 32, 40, 44, 48, 56, 64)
 TOTAL = 256
 NRS = (16, 24, 32, 44, 48)   # dof-row counts of the low-rank start (kernel variants MKH_NR)
-NTMP = 32  # 8 x b128
+def ntmp_for(nt):
+    # staging registers: 8 x b128 in flight, or 4 for the widest tableaus (the compiler needs the
+    # 16 registers more than the rank-1 update needs the deeper pipeline: measured on G1)
+    return 16 if nt >= 56 else 32
 NPRE = 4   # loads issued by rank1_prefetch (their 16 registers are off limits to the compiler)
 
 
 def gen(nt: int) -> str:
+    NTMP = ntmp_for(nt)
     t0 = TOTAL - 2 * nt
     tmp0 = t0 - NTMP
-    budget = tmp0 + 4 * NPRE
+    budget = tmp0
     treg = lambda i: f"v[{t0 + 2 * i}:{t0 + 2 * i + 1}]"
     clob_t = ",".join(f'"v{r}"' for r in range(t0, TOTAL))
     clob_tmp = ",".join(f'"v{r}"' for r in range(tmp0, t0))
@@ -55,30 +58,37 @@ def gen(nt: int) -> str:
     # multiplier arithmetic between them so that the LDS latency of the first loads is hidden.
     nload = nt // 2
     depth = NTMP // 4
+    def slot_reg(k):
+        # staging slot of load k.  Slots 0..NPRE-1 — the ones rank1_prefetch leaves in flight across
+        # compiler-generated code — sit in the UPPER half of the staging range, which is above the
+        # compiler's cap; the other slots are only live inside one asm statement (declared clobbers).
+        return tmp0 + 4 * ((k % depth + (depth - NPRE)) % depth)
     def load(k, addr="%0"):
-        slot = k % depth
-        r = tmp0 + 4 * slot
+        r = slot_reg(k)
         return f"ds_read_b128 v[{r}:{r + 3}], {addr} offset:{16 * k}"
     lines = ["s_waitcnt lgkmcnt(0)"] + [load(k) for k in range(min(NPRE, nload))]
     body = "\\n\\t".join(lines)
-    clob_pre = ",".join(f'"v{r}"' for r in range(tmp0, tmp0 + 4 * NPRE))
+    clob_pre = ",".join(f'"v{r}"' for r in range(tmp0 + NTMP - 4 * NPRE, tmp0 + NTMP))
     out.append("  // issue the first loads of lds[0..kRows) (must be followed by rank1_body with the same address)")
     out.append("  __device__ static __forceinline__ void rank1_prefetch(unsigned lds_addr) {")
     out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_pre}, "memory");')
     out.append("  }")
-    lines = [load(k) for k in range(min(NPRE, nload), min(depth, nload))]
+    # lgkmcnt(0) first: the compiler may have put LDS / scalar-memory instructions of its own between
+    # prefetch and body (SMEM returns out of order, so only a full drain is exact).  The prefetched
+    # loads were issued ~100 cycles earlier, so this does not stall; from here on only this
+    # statement's own loads are outstanding and the counted waits below are exact.
+    lines = ["s_waitcnt lgkmcnt(0)"] + [load(k) for k in range(min(NPRE, nload), min(depth, nload))]
     for k in range(nload):
         issued = min(nload, k + depth)
-        lines.append(f"s_waitcnt lgkmcnt({issued - k - 1})")
-        slot = k % depth
-        r = tmp0 + 4 * slot
+        if k >= NPRE:
+            lines.append(f"s_waitcnt lgkmcnt({issued - k - 1})")
+        r = slot_reg(k)
         lines.append(f"v_fma_f64 {treg(2 * k)}, v[{r}:{r + 1}], %1, {treg(2 * k)}")
         lines.append(f"v_fma_f64 {treg(2 * k + 1)}, v[{r + 2}:{r + 3}], %1, {treg(2 * k + 1)}")
         if k + depth < nload:
             lines.append(load(k + depth))
     body = "\\n\\t".join(lines)
-    out.append("  // T[i] += lds[i]*g.  No LDS/scalar-memory instruction may be issued between prefetch and body")
-    out.append("  // (the body's s_waitcnt counts assume only its own loads are outstanding).")
+    out.append("  // T[i] += lds[i]*g; consumes the loads rank1_prefetch left in flight.")
     out.append("  __device__ static __forceinline__ void rank1_body(unsigned lds_addr, double g) {")
     out.append(f'    asm volatile("{body}"')
     out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
@@ -115,11 +125,12 @@ def gen(nt: int) -> str:
     for nr in [r for r in NRS if r <= nt]:
         nl = nr // 2
         # rank1 over the first nr rows (prefetch is shared: it only issues the first NPRE loads)
-        lines = [load(k) for k in range(min(NPRE, nl), min(depth, nl))]
+        lines = ["s_waitcnt lgkmcnt(0)"] + [load(k) for k in range(min(NPRE, nl), min(depth, nl))]
         for k in range(nl):
             issued = min(nl, k + depth)
-            lines.append(f"s_waitcnt lgkmcnt({issued - k - 1})")
-            r = tmp0 + 4 * (k % depth)
+            if k >= NPRE:
+                lines.append(f"s_waitcnt lgkmcnt({issued - k - 1})")
+            r = slot_reg(k)
             lines.append(f"v_fma_f64 {treg(2 * k)}, v[{r}:{r + 1}], %1, {treg(2 * k)}")
             lines.append(f"v_fma_f64 {treg(2 * k + 1)}, v[{r + 2}:{r + 3}], %1, {treg(2 * k + 1)}")
             if k + depth < nl:
@@ -135,7 +146,7 @@ def gen(nt: int) -> str:
         for k in range(nl):
             issued = min(nl, k + depth)
             lines.append(f"s_waitcnt lgkmcnt({issued - k - 1})")
-            r = tmp0 + 4 * (k % depth)
+            r = slot_reg(k)
             lines.append(f"v_fma_f64 %0, v[{r}:{r + 1}], {treg(2 * k)}, %0")
             lines.append(f"v_fma_f64 %1, v[{r + 2}:{r + 3}], {treg(2 * k + 1)}, %1")
             if k + depth < nl:

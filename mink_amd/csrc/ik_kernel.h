@@ -173,6 +173,12 @@ __device__ __forceinline__ void pivot(QpLane& s, int k, bool reverse, int lane, 
 // F_WOOD: low-rank ("Woodbury") start of the QP — H = Dg + JwᵀJw is never formed; the dof indices of the
 // augmented tableau [[Dg, Jwᵀ],[Jw, −I]] are swept in closed form and only the n_μ task-residual indices
 // take rank-1 pivots (18 instead of 43 for the G1 benchmark).  tools/proto_woodbury.py states it in numpy.
+// taps that exist in the low-rank variants (profiling only: H is never formed there)
+constexpr bool kTapIsProf_t_xpos = false, kTapIsProf_t_xquat = false, kTapIsProf_t_frame_pose = false,
+               kTapIsProf_t_subtree_com = false, kTapIsProf_t_task_e = false, kTapIsProf_t_task_J = false,
+               kTapIsProf_t_H = false, kTapIsProf_t_c = false, kTapIsProf_t_box_lo = false, kTapIsProf_t_box_hi = false,
+               kTapIsProf_t_coll_G = false, kTapIsProf_t_coll_h = false, kTapIsProf_t_qp_iters = true,
+               kTapIsProf_t_cycles = true;
 enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL = 31, F_WOOD = 32 };
 
 // P lives in device memory (not in the kernarg segment): hipcc materialises every by-value kernel
@@ -181,15 +187,25 @@ enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL =
 // One kernel per translation unit: the variant TU defines MKH_NT (tableau rows per lane) and
 // MKH_FEAT before including this header.  Not a template because `amdgpu_num_vgpr` — the cap that
 // keeps the compiler out of the pinned tableau registers — only accepts an integer literal.
+// NOTE the value: on gfx90a+ LLVM doubles the attribute (it budgets the unified VGPR+AGPR file:
+// GCNSubtarget::getBaseMaxNumVGPRs) and silently DROPS it when the doubled value exceeds what the
+// waves-per-EU bound allows (256 at 2 waves/SIMD).  So a hard limit of C architectural VGPRs is
+// requested as C/2; tools/check_vgpr_cap.py verifies on the ISA that no compiler-generated
+// instruction touches a register at or above the cap.
 #ifdef MKH_NT
+#ifdef MKH_DEBUG_ALL_TAPS
 #define MKH_TAP(f) ((kTaps && tp) ? tp->f : nullptr)
+#else
+#define MKH_TAP(f) ((kTaps && tp && (!kWood || kTapIsProf_##f)) ? tp->f : nullptr)
+#endif
 #define MKH_CAT2(a, b, c) a##b##_##c
 #define MKH_CAT(a, b, c) MKH_CAT2(a, b, c)
 #ifndef MKH_KERNEL_NAME   // low-rank variants (MKH_NR defined) are named by their translation unit
 #define MKH_KERNEL_NAME MKH_CAT(ik_solve_kernel_, MKH_NT, MKH_FEAT)
 #endif
-static_assert(Tab<MKH_NT>::kCompilerVgprs == 256 - 2 * MKH_NT - 16, "register map of tab_asm.inc changed");
-__global__ __launch_bounds__(64, 2) __attribute__((amdgpu_num_vgpr(256 - 2 * MKH_NT - 16)))
+#define MKH_STAGE (MKH_NT >= 56 ? 16 : 32)   // staging VGPRs of the rank-1 update (gen_tab_asm.py ntmp_for)
+static_assert(Tab<MKH_NT>::kCompilerVgprs == 256 - 2 * MKH_NT - MKH_STAGE, "register map of tab_asm.inc changed");
+__global__ __launch_bounds__(64, 2) __attribute__((amdgpu_num_vgpr((256 - 2 * MKH_NT - MKH_STAGE) / 2)))
 void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, const TapArgs* __restrict__ tp) {
   constexpr int NT = MKH_NT, FEAT = MKH_FEAT;
   constexpr bool kTaps = (FEAT & F_TAPS) != 0, kRel = (FEAT & F_REL) != 0, kCom = (FEAT & F_COM) != 0;
@@ -199,7 +215,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
 #else
   constexpr int NR = NT;
 #endif
-  static_assert(!kWood || !(kTaps || kRel || kCom || kColl), "low-rank start: lean feature sets only");
+  static_assert(!kWood || !(kRel || kCom || kColl), "low-rank start: frame/posture tasks + box limits only");
   const DeviceProblem& P0 = *Pg;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int lane = lane_id();
@@ -902,7 +918,6 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     const double hmax = wave_max(is_dof ? hdiag : 0.0);
     const double thr_dof = 1e-13 / (hmax * (double)nv);
 
-    MKH_TICK();   // 6: tableau built
     int iters = 0;
     const int max_iters = 8 * (ntab + 8);
     // ---- phase 0: bring every dof into the basis, x0 = −H⁻¹c (Gauss–Jordan, no ratio tests).
@@ -922,6 +937,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       if (lane == k) { s.z += alpha; s.w = 0.0; s.basic = 1; }
       pivot<NT>(s, k, false, lane, sPiv, own, ps, inv);
     }
+    MKH_TICK();   // 6: tableau built, phase 0 done
     if (kWood && is_mu) s.kind = 2;                          // residual indices are never touched again
     const int nact = kWood ? nv : kWave;                     // lanes that still own a live index
     // ---- phase 1: Goldfarb–Idnani.  Each iteration publishes ONE column `col`; a blocking

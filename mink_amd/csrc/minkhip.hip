@@ -516,14 +516,19 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   if (p->dev.n_com > 0) need |= F_COM;
   if (p->dev.n_pairs > 0) need |= F_COLL;
   if (a.n_steps > 1 || a.q_out) need |= F_STEPS;
-  int feat = (need == 0) ? 0 : ((need == F_STEPS) ? F_STEPS : F_ALL);
+  int feat = (need == 0) ? 0 : ((need == F_STEPS) ? F_STEPS : ((need & F_TAPS) ? F_ALL : (F_ALL & ~F_TAPS)));
   int nt = p->nt, nr = 0, lds = p->lds_bytes;
   // Low-rank start when the problem qualifies and the diagonal part of H is not tiny against JwᵀJw
   // (error amplification of the quasi-definite elimination ≈ eps·max cost²/min Dg ≤ 1e-9).
   const double dg_min = a.damping + p->wood_min_diag;
-  if (p->wood_nt && (need & ~F_STEPS) == 0 && a.do_qp && !(flags & MKH_FLAG_DIRECT_QP) && dg_min > 0.0 &&
-      dg_min >= 1e-7 * p->wood_max_cost2) {
-    nt = p->wood_nt; nr = p->wood_nr; lds = p->wood_lds_bytes; feat |= F_WOOD;
+  // (taps: only the cycle counters / pivot counts exist in the low-rank variant — profiling)
+  const bool prof_only = taps && !taps->t_xpos && !taps->t_xquat && !taps->t_frame_pose && !taps->t_subtree_com &&
+                         !taps->t_task_e && !taps->t_task_J && !taps->t_H && !taps->t_c && !taps->t_box_lo &&
+                         !taps->t_box_hi && !taps->t_coll_G && !taps->t_coll_h;
+  if (p->wood_nt && ((need & ~F_STEPS) == 0 || (need == F_TAPS && prof_only)) && a.do_qp &&
+      !(flags & MKH_FLAG_DIRECT_QP) && dg_min > 0.0 && dg_min >= 1e-7 * p->wood_max_cost2) {
+    nt = p->wood_nt; nr = p->wood_nr; lds = p->wood_lds_bytes;
+    feat = F_WOOD | (need & (F_STEPS | F_TAPS));
   }
   snprintf(p->last_kernel, sizeof(p->last_kernel), nr ? "ik_solve_kernel_%d_%d_r%d" : "ik_solve_kernel_%d_%d", nt, feat, nr);
   if (mkh::launch_variant(nt, nr, feat, grid, lds, stream, p->d_dev, a, dtaps) != 0)

@@ -53,3 +53,16 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip")):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_compiler_stays_below_the_vgpr_cap(lib):
+    """The QP tableau lives in pinned VGPRs above an `amdgpu_num_vgpr` cap; the cap is easy to get wrong
+    on gfx90a+ (LLVM doubles or drops the attribute) and a violation is silent.  Check the generated
+    ISA of the headline variants (tools/check_vgpr_cap.py without arguments checks all of them)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_vgpr_cap.py"),
+                          "44_0", "64_32_r44", "64_48_r44", "64_30", "8_0", "48_31"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count(" ok ") == 6, out.stdout

@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Verify on the generated ISA that hipcc stays below the VGPR cap of every kernel variant, i.e. that no
+compiler-generated instruction (anything outside the inline-asm blocks) touches the staging / tableau
+registers v[256-2·NT-S, 256), S = 32 (16 for NT ≥ 56).  `amdgpu_num_vgpr` is easy to get wrong on gfx90a+ (see ik_kernel.h), and a
+violation is silent: the kernel still runs and is only wrong when register pressure happens to be high.
+
+    python tools/check_vgpr_cap.py            # all variants in mink_amd/csrc/_build
+"""
+import glob
+import os
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(REPO, "mink_amd", "csrc", "_build")
+
+
+def max_compiler_vgpr(asm_text: str) -> int:
+    mx, skip = -1, False
+    for line in asm_text.split("\n"):
+        if "#ASMSTART" in line:
+            skip = True
+        if not skip and not line.lstrip().startswith((";", ".")):
+            code = line.split(";")[0]
+            for m in re.finditer(r"\bv(\d+)\b", code):
+                mx = max(mx, int(m.group(1)))
+            for m in re.finditer(r"\bv\[(\d+):(\d+)\]", code):
+                mx = max(mx, int(m.group(2)))
+        if "#ASMEND" in line:
+            skip = False
+    return mx
+
+
+def check(src: str):
+    sys.path.insert(0, os.path.join(REPO, "mink_amd", "csrc"))
+    import build as hipbuild
+    nt = int(re.search(r"variant_(\d+)_", os.path.basename(src)).group(1))
+    cap = 256 - 2 * nt - (16 if nt >= 56 else 32)
+    out = subprocess.run([hipbuild._hipcc()] + hipbuild.FLAGS + hipbuild.KERNEL_FLAGS +
+                         ["-S", "--cuda-device-only", "-o", "-", src], check=True, capture_output=True, text=True).stdout
+    mx = max_compiler_vgpr(out)
+    spills = re.findall(r"\.(sgpr|vgpr)_spill_count:\s+(\d+)", out)
+    scratch = re.search(r"ScratchSize: (\d+)", out)
+    return os.path.basename(src), cap, mx, dict(spills), int(scratch.group(1)) if scratch else -1
+
+
+def main():
+    srcs = sorted(glob.glob(os.path.join(BUILD, "variant_*.hip")))
+    if len(sys.argv) > 1:                       # optional name filters, e.g. 44_0 64_32_r44
+        srcs = [s for s in srcs if any(os.path.basename(s) == f"variant_{a}.hip" for a in sys.argv[1:])]
+    if not srcs:
+        raise SystemExit("run mink_amd/csrc/build.py first")
+    bad = 0
+    with ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
+        for name, cap, mx, spills, scratch in ex.map(check, srcs):
+            ok = mx < cap
+            bad += not ok
+            print(f"{name:28s} cap v{cap:<4d} highest compiler VGPR v{mx:<4d} {'ok ' if ok else 'VIOLATION'} "
+                  f"scratch {scratch:4d} B  spills sgpr {spills.get('sgpr', '?'):>4} vgpr {spills.get('vgpr', '?'):>4}")
+    if bad:
+        raise SystemExit(f"{bad} variant(s) exceed their VGPR cap")
+
+
+if __name__ == "__main__":
+    main()
