@@ -168,7 +168,9 @@ typedef struct MkhTaps {
   double *coll_G;    /* (B, n_pairs, nv) CollisionAvoidanceLimit G rows (0 when inactive) */
   double *coll_h;    /* (B, n_pairs)     and h (+inf when inactive)                   */
   int32_t *qp_iters; /* (B,)  active-set pivots after the unconstrained solve         */
-  int64_t *cycles;   /* (B, 8) shader-clock stamps at the kernel's phase boundaries (profiling) */
+  int64_t *cycles;   /* (B, 16): [0,8) shader-clock stamps at the kernel's phase boundaries, [8,16) cycles summed
+                      * over the QP iterations: phase-0 publish, phase-0 pivot, GI select, GI publish, GI ratio
+                      * test, GI pivot, 2 spare (profiling) */
 } MkhTaps;
 
 int32_t mkh_version(void);

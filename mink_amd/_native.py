@@ -313,7 +313,7 @@ class NativeProblem:
             "subtree_com": (B, 3), "task_e": (B, self.n_rows), "task_J": (B, self.n_rows, m.nv),
             "H": (B, m.nv, m.nv), "c": (B, m.nv), "box_lo": (B, m.nv), "box_hi": (B, m.nv),
             "coll_G": (B, self.n_pairs, m.nv), "coll_h": (B, self.n_pairs), "qp_iters": (B,),
-            "cycles": (B, 8),
+            "cycles": (B, 16),
         }
 
     def solve(self, q, frame_targets=None, posture_target=None, com_target=None, dt: float = 1e-2,
@@ -398,6 +398,12 @@ class NativeProblem:
             for n in taps:
                 setattr(tp, n, tapbufs[n].data_ptr() if use_torch else tapbufs[n].ctypes.data)
             _check(lib().mkh_eval(*args, C.byref(tp), flags, stream))
+            if "qp_iters" in tapbufs:
+                # packed by the kernel: active-set selections | loop iterations << 10 | rank-1 pivots << 20
+                raw = tapbufs["qp_iters"]
+                tapbufs["qp_loops"] = (raw >> 10) & 1023
+                tapbufs["qp_pivots"] = (raw >> 20) & 1023
+                tapbufs["qp_iters"] = raw & 1023
             return v, st, tapbufs
         _check(lib().mkh_solve(*args, flags, stream))
         return v, st

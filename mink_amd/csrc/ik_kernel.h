@@ -76,17 +76,22 @@ __device__ __forceinline__ unsigned lds_addr(const double* p) { return (unsigned
 // whose index depends on the runtime pivot is ever written (hipcc would send it to scratch, and a
 // scalar switch over statically named registers costs ~500 cycles of branches per access).
 struct QpLane {
-  double z, w, lo, hi, sg, D;
-  int kind;    // 0 dof, 1 half-space row, 2 padding
-  int basic;   // swept into the basis
-  int at_hi;   // nonbasic dof sitting at its upper bound (else lower)
+  double x;        // the FREE value of the index: z (dof value / multiplier) when basic, w (gradient / slack) when not.
+                   // The other one is implied: w = 0 when basic; z = bound (dof) or 0 (row) when not.
+  double lo, hi, sg, D;
+  int kind;        // 0 dof, 1 half-space row, 2 padding / dropped
+  int basic;       // swept into the basis
+  int mode;        // ratio-test role: 0 none, 1 active row (z ≥ 0), 2 dof at its upper bound (w ≤ 0), 3 at its lower (w ≥ 0)
 };
 
 // Lane `col` publishes its raw tableau column R[0..NT) in LDS (the only cross-lane transport of
 // the QP): every lane then reads its own entry (ratio test / multiplier) and streams the whole
 // vector back with broadcast reads for the rank-1 update.  Entry `col` is published as 0 so that
 // row `col` of every column is left alone by the update (its change is carried by σ_col).
-struct PivotScalars { double d, sg, w, z; };   // D, σ, w, z of the pivot lane, broadcast through LDS
+// D, σ, w, z of the pivot lane — and, for the active-set phase, its bounds, row norm and basic flag —
+// broadcast through LDS in the same round trip as the column (a v_readlane chain costs ~45-90 cycles
+// per value and sits in the pivot's dependent chain).
+struct PivotScalars { double d, sg, x, rn, lo, hi; };
 
 // 1/d without the IEEE division sequence (v_div_scale/fmas/fixup ≈ 145 cycles in the pivot's
 // dependent chain): hardware reciprocal + two Newton steps (≤ 1 ulp for normal d).
@@ -97,14 +102,13 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return r;
 }
 
-template <int NT>
+template <int NT, bool FULL = false>
 __device__ __forceinline__ double publish_column(const QpLane& s, int col, int lane, double* sPiv,
-                                                 PivotScalars& ps, int nact = kWave) {
+                                                 PivotScalars& ps, int nact = kWave, double rown = 1.0) {
   // Column `col` equals row `col` (R is symmetric): lane i holds R[col][i] in tableau register
   // `col`.  One indexed register read (VGPR index mode on the pinned base) + ONE ds_write_b64 for
   // the whole wave.  Having lane `col` dump its 48 registers itself costs 48 single-lane LDS
-  // writes = 750-1850 cycles (measured, tools/ubench) — half of the whole pivot.  The pivot lane's
-  // scalars ride along in the same LDS round trip (a v_readlane chain costs ~90 cycles each).
+  // writes = 750-1850 cycles (measured, tools/ubench) — half of the whole pivot.
   const double rowv = Tab<NT>::get_dyn(col);
   // lanes ≥ nact hold dropped indices (task residuals of the low-rank start): they publish 0, so
   // their columns stop changing and the rows they own leave every other column alone
@@ -114,12 +118,17 @@ __device__ __forceinline__ double publish_column(const QpLane& s, int col, int l
   if (lane == col) {
     double2* o = reinterpret_cast<double2*>(sPiv + kWave);
     o[0] = double2{s.D, s.sg};
-    o[1] = double2{s.w, s.z};
+    o[1] = double2{s.x, rown};
+    if (FULL) o[2] = double2{s.lo, s.hi};
   }
   wave_sync();
   const double2* o = reinterpret_cast<const double2*>(sPiv + kWave);
   const double2 a = o[0], b = o[1];
-  ps.d = a.x; ps.sg = a.y; ps.w = b.x; ps.z = b.y;
+  ps.d = a.x; ps.sg = a.y; ps.x = b.x; ps.rn = b.y;
+  if (FULL) {
+    const double2 c = o[2];
+    ps.lo = c.x; ps.hi = c.y;
+  }
   return own;                                    // raw R[lane][col] (0 for lane col)
 }
 
@@ -251,8 +260,11 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   for (int pb = pb_begin; pb < pb_end; pb += pb_stride) {
     int status_all = 0;
     long long tc[8];
+    long long ta[6] = {0, 0, 0, 0, 0, 0}, tl = 0;   // QP sub-phase cycle sums (profiling)
     int tci = 0;
 #define MKH_TICK() do { if (MKH_TAP(t_cycles)) tc[tci] = __builtin_readcyclecounter(); ++tci; } while (0)
+#define MKH_LAP0() do { if (MKH_TAP(t_cycles)) tl = __builtin_readcyclecounter(); } while (0)
+#define MKH_LAP(i) do { if (MKH_TAP(t_cycles)) { const long long n_ = __builtin_readcyclecounter(); ta[i] += n_ - tl; tl = n_; } } while (0)
     MKH_TICK();   // 0: start
     // Opaque per-iteration zero: table loads below are indexed with it so that LICM cannot hoist
     // them out of the problem loop and keep ~60 VGPRs of lane constants live through the QP.
@@ -886,32 +898,30 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // Dual active set (Goldfarb–Idnani) on the sweep tableau; see tools/proto_tableau_qp.py
     // for the numpy statement of the same algorithm.
     QpLane s;
-    s.sg = 1.0; s.basic = 0; s.at_hi = 0;
+    s.sg = 1.0; s.basic = 0; s.mode = 0;
     s.D = is_dof ? hdiag : ((lane >= ntab) ? 1.0 : 0.0);   // true diagonal of K
-    s.z = 0.0;
+    s.x = 0.0;
     double rown = 1.0;
     if (kWood) {
       // state after the closed-form sweep of every dof of [[Dg, Jwᵀ],[Jw, −I]]
-      s.kind = is_dof ? 0 : (is_mu ? 3 : 2);
+      s.kind = is_dof ? 0 : 2;                               // residual indices: no bounds, never selected
       s.sg = is_dof ? dsq : 1.0;
       s.D = is_dof ? -(dsq * dsq) : D_mu;
       s.basic = is_dof ? 1 : 0;
-      s.z = is_dof ? -c_lane * (dsq * dsq) : 0.0;
-      s.w = w_mu;                                            // 0 on dof lanes (dot of zero rows) and padding
-      if (!is_mu) s.w = 0.0;
+      s.x = is_dof ? -c_lane * (dsq * dsq) : (is_mu ? w_mu : 0.0);   // z of the dofs, w of the residuals
       s.lo = is_dof ? lo : -kInf;
       s.hi = is_dof ? hi : kInf;
     } else if (is_dof) {
-      s.kind = 0; s.w = c_lane; s.lo = lo; s.hi = hi;
+      s.kind = 0; s.x = c_lane; s.lo = lo; s.hi = hi;         // nonbasic at z = 0: w = c
     } else if (lane < nv + nrows) {
       s.kind = 1; s.lo = 0.0; s.hi = kInf;
-      s.w = -sCol[(lane - nv) * 16 + 9];                      // A·0 − h
+      s.x = -sCol[(lane - nv) * 16 + 9];                      // w = A·0 − h
       const double* o = sA + (lane - nv) * 64;
       double nn = 0.0;
       for (int i = 0; i < nv; ++i) nn += o[i] * o[i];
       rown = sqrt(nn);
     } else {
-      s.kind = 2; s.w = 0.0; s.lo = -kInf; s.hi = kInf;
+      s.kind = 2; s.lo = -kInf; s.hi = kInf;
     }
     // inconsistent box ⇒ quadprog "constraints are inconsistent"
     if (__ballot(is_dof && lo > hi + 1e-12)) status |= 2;
@@ -927,56 +937,62 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     const int k_begin = kWood ? nv : 0, k_end = kWood ? nv + n_mu : nv;
     for (int k = k_begin; k < k_end; ++k) {
       PivotScalars ps;
+      MKH_LAP0();
       const double own = publish_column<NT>(s, k, lane, sPiv, ps);
       Tab<NT>::rank1_prefetch(lds_addr(sPiv));
+      MKH_LAP(0);
       if (!((kWood ? -ps.d : ps.d) > 0.0)) { status |= 4; break; }
       const double inv = fast_rcp(ps.d);
       const double tau = (lane == k) ? ps.d : s.sg * ps.sg * own;     // column k of the tableau
-      const double alpha = -ps.w * inv;
-      if (s.basic) s.z -= alpha * tau; else s.w += alpha * tau;
-      if (lane == k) { s.z += alpha; s.w = 0.0; s.basic = 1; }
+      const double alpha = -ps.x * inv;                                // drives w_k to 0
+      s.x = fma(s.basic ? -alpha : alpha, tau, s.x);                   // basic: z −= α·τ, nonbasic: w += α·τ
+      if (lane == k) { s.x = alpha; s.basic = 1; }                     // z_k = 0 + α
       pivot<NT>(s, k, false, lane, sPiv, own, ps, inv);
+      MKH_LAP(1);
     }
     MKH_TICK();   // 6: tableau built, phase 0 done
-    if (kWood && is_mu) s.kind = 2;                          // residual indices are never touched again
     const int nact = kWood ? nv : kWave;                     // lanes that still own a live index
     // ---- phase 1: Goldfarb–Idnani.  Each iteration publishes ONE column `col`; a blocking
     // constraint found by the ratio test becomes the column of the next iteration (`pend`).
     int p = -1;          // index being driven (−1 ⇒ select a new one)
     bool p_basic = false, upper = false;
-    double beta = 0.0, sgn = 1.0, thr = 0.0;
+    double sgn = 1.0;
+    double acc = 0.0;    // step accumulated by the driven index: multiplier of a dof going to its bound / of a row coming in
     int pend = -1;       // pending sweep of a blocking index (reverse flag in pend_rev)
     bool pend_rev = false;
+    const double inv_rown = (rown > 0.0) ? 1.0 / rown : 0.0;
+    int n_loop = 0, n_piv = 0;   // profiling (qp_iters tap): loop iterations / rank-1 pivots of this phase
     while (!(status & 14)) {
+      ++n_loop;
+      MKH_LAP0();
       int col;
       if (pend >= 0) col = pend;
       else {
         if (p < 0) {
-          // ---- most violated primal condition (GI step 1)
+          // ---- most violated primal condition (GI step 1).  "Most" only steers the path (the optimum
+          // is unique), so the arg-max compares the high words of the violations: one 32-bit DPP
+          // reduction instead of a 64-bit one, no readlane chain (p's scalars come with the column).
           double viol = 0.0;
-          if (s.kind == 0 && s.basic) viol = fmax(s.z - s.hi, s.lo - s.z);
-          else if (s.kind == 1 && !s.basic && rown > 0.0) viol = s.w / rown;
-          const double vmax = wave_max(viol);
-          if (!(vmax > 1e-12)) break;
-          p = first_lane(viol == vmax);
-          p_basic = readlane_i32(s.basic, p) != 0;              // (A) basic dof  /  (B) inactive row
-          upper = false;
-          beta = 0.0;
-          if (p_basic) {
-            const double zp = readlane_f64(s.z, p), hp = readlane_f64(s.hi, p), lp = readlane_f64(s.lo, p);
-            upper = (zp - hp) > (lp - zp);
-            beta = upper ? hp : lp;
-          }
-          sgn = (p_basic && upper) ? -1.0 : 1.0;
-          const double rn = readlane_f64(rown, p);
-          thr = p_basic ? thr_dof : thr_dof * rn * rn;
+          if (s.kind == 0 && s.basic) viol = fmax(s.x - s.hi, s.lo - s.x);
+          else if (s.kind == 1 && !s.basic) viol = s.x * inv_rown;
+          const bool cand = viol > 1e-12;
+          if (!__ballot(cand)) break;
+          const unsigned vh = cand ? (unsigned)__double2hiint(viol) : 0u;
+          const unsigned mh = wave_max_u32(vh);
+          p = first_lane(cand && vh == mh);
+          p_basic = ((__ballot(s.basic != 0) >> p) & 1) != 0;  // (A) basic dof  /  (B) inactive row
+          upper = p_basic && (((__ballot((s.x - s.hi) > (s.lo - s.x)) >> p) & 1) != 0);
+          sgn = upper ? -1.0 : 1.0;
+          acc = 0.0;
         }
         if (++iters > max_iters) { status |= 8; break; }
         col = p;
       }
       PivotScalars ps;
-      const double own = publish_column<NT>(s, col, lane, sPiv, ps, nact);
+      MKH_LAP(2);
+      const double own = publish_column<NT, true>(s, col, lane, sPiv, ps, nact, rown);
       Tab<NT>::rank1_prefetch(lds_addr(sPiv));
+      MKH_LAP(3);
       const double inv = fast_rcp(ps.d);                         // 1 / T[col][col]
       bool rev = false;
       if (pend >= 0) {
@@ -985,66 +1001,81 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       } else {
         const double tau = (lane == col) ? ps.d : s.sg * ps.sg * own;   // column `col` of the tableau
         const double tpp = ps.d;
-        // full step length t2 (GI step 2b)
+        const double beta = p_basic ? (upper ? ps.hi : ps.lo) : 0.0;
+        const double thr = p_basic ? thr_dof : thr_dof * ps.rn * ps.rn;
+        // full step length t2 (GI step 2b): z_p reaches its bound / the slack w_p reaches 0
         double t2 = kInf;
-        if (p_basic) {
-          if (fabs(tpp) > thr) t2 = fabs((ps.z - beta) * inv);
-        } else {
-          if (-tpp > thr) t2 = fabs(ps.w * inv);
-        }
-        // partial step length t1: keep the multipliers of the active set dual feasible
+        if (p_basic ? (fabs(tpp) > thr) : (-tpp > thr)) t2 = fabs((ps.x - beta) * inv);
+        // partial step length t1: keep the multipliers of the active set dual feasible.  Branch-free:
+        // y = the multiplier that must stay ≥ 0 (z of an active row, −w at an upper bound, w at a lower
+        // one), rr = its rate of decrease; one reciprocal instead of three divergent divisions.
         const double r = sgn * tau;
-        double t = kInf;
-        if (lane != p) {
-          if (s.kind == 1 && s.basic) { if (r > 0.0) t = fmax(s.z, 0.0) / r; }
-          else if (s.kind == 0 && !s.basic) {
-            if (s.at_hi) { if (r > 0.0) t = fmax(-s.w, 0.0) / r; }
-            else { if (r < 0.0) t = fmax(s.w, 0.0) / (-r); }
-          }
-        }
-        const double t1 = wave_min(t);
+        const double y = (s.mode == 2) ? -s.x : s.x;
+        const double rr = (s.mode == 3) ? -r : r;
+        const bool cnd = s.mode != 0 && rr > 0.0;               // (p itself is never eligible: its mode is 0)
+        double t = fmax(y, 0.0) * fast_rcp(cnd ? rr : 1.0);
+        t = (cnd && t == t) ? t : kInf;                          // (0·∞ from a denormal direction: no block)
+        const double t1 = wave_min_nonneg(t, __ballot(cnd));
         if (!(fmin(t1, t2) < kInf)) { status |= 2; break; }     // no step possible: infeasible
         const bool full = t2 <= t1;
         const double alpha = sgn * (full ? t2 : t1);
-        if (s.basic) s.z -= alpha * tau; else s.w += alpha * tau;
-        if (lane == p) { if (p_basic) s.w += alpha; else s.z += alpha; }
+        s.x = fma(s.basic ? -alpha : alpha, tau, s.x);          // basic: z −= α·τ, nonbasic: w += α·τ  (p included)
+        acc += alpha;
         if (full) {
           if (lane == p) {
-            if (p_basic) { s.z = beta; s.basic = 0; s.at_hi = upper ? 1 : 0; }
-            else { s.w = 0.0; s.basic = 1; }
+            // dof p lands on its bound with multiplier acc  /  row p enters the active set with λ = acc
+            s.x = acc;
+            s.basic = p_basic ? 0 : 1;
+            s.mode = p_basic ? (upper ? 2 : 3) : 1;
           }
           rev = p_basic;
           p = -1;
         } else {
-          pend = first_lane(t == t1);                           // blocking index: sweep it next iteration
-          pend_rev = readlane_i32(s.basic, pend) != 0;
+          pend = first_lane(cnd && t == t1);                    // blocking index: sweep it next iteration
+          pend_rev = ((__ballot(s.basic != 0) >> pend) & 1) != 0;
           if (lane == pend) {
-            if (pend_rev) { s.z = 0.0; s.basic = 0; }           // row leaves the active set
-            else { s.w = 0.0; s.basic = 1; }                    // dof leaves its bound
+            // an active row leaves with λ = 0 (its slack w = 0 right now); a dof leaves its bound with
+            // w = 0 and z = the bound
+            s.x = pend_rev ? 0.0 : ((s.mode == 2) ? s.hi : s.lo);
+            s.basic = pend_rev ? 0 : 1;
+            s.mode = 0;
           }
           // the prefetched loads are simply abandoned: drain them before LDS is reused
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           continue;
         }
       }
+      ++n_piv;
+      MKH_LAP(4);
       pivot<NT, NR>(s, col, rev, lane, sPiv, own, ps, inv);
+      MKH_LAP(5);
     }
+    // Δq of this dof: the free value when basic, else the bound it sits on
+    const double zfin = s.basic ? s.x : ((s.mode == 2) ? s.hi : s.lo);
     MKH_TICK();   // 7: QP done
-    if (MKH_TAP(t_cycles) && lane < 8) MKH_TAP(t_cycles)[(size_t)pb * 8 + lane] = (lane == 0) ? tc[0] : (lane == 1) ? tc[1] : (lane == 2) ? tc[2] : (lane == 3) ? tc[3] : (lane == 4) ? tc[4] : (lane == 5) ? tc[5] : (lane == 6) ? tc[6] : tc[7];
-    if (MKH_TAP(t_qp_iters) && lane == 0) MKH_TAP(t_qp_iters)[pb] = iters;
+    if (MKH_TAP(t_cycles) && lane < 16) {
+      long long x = tc[0];
+#pragma unroll
+      for (int i = 1; i < 8; ++i) x = (lane == i) ? tc[i] : x;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) x = (lane == 8 + i) ? ta[i] : x;
+      if (lane >= 14) x = 0;
+      MKH_TAP(t_cycles)[(size_t)pb * 16 + lane] = x;
+    }
+    if (MKH_TAP(t_qp_iters) && lane == 0) MKH_TAP(t_qp_iters)[pb] = iters | (n_loop << 10) | (n_piv << 20);
     status_all |= status;
     const bool last = (step + 1 == n_steps) || (status & 14);
     if (last) {
       if (A.v_out && is_dof) {
         const double bad = __builtin_nan("");
-        A.v_out[(size_t)pb * nv + lane] = (status & 14) ? bad : s.z / A.dt;   // v = dq / dt (solve_ik.py:104)
+        A.v_out[(size_t)pb * nv + lane] = (status & 14) ? bad : zfin / A.dt;   // v = dq / dt (solve_ik.py:104)
       }
       if (status & 14) break;
     }
     if (kSteps && (n_steps > 1 || A.q_out)) {
       // q ← q ⊕ Δq (mj_integratePos, Configuration.integrate_inplace, mink/configuration.py:228-236)
       wave_sync();
-      if (is_dof) sDof[lane * 10 + 9] = s.z;                   // Δq of dof `lane` (slot 9 = q is dead now)
+      if (is_dof) sDof[lane * 10 + 9] = zfin;                   // Δq of dof `lane` (slot 9 = q is dead now)
       wave_sync();
       if (lane < P.njnt) {
         const int jt = P.jnt_i[lane * JI_COUNT + JI_TYPE];

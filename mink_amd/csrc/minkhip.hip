@@ -620,7 +620,7 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
     t.t_coll_G = (double*)tap(taps->coll_G, Bz * P.n_pairs * nv * 8, true);
     t.t_coll_h = (double*)tap(taps->coll_h, Bz * P.n_pairs * 8, false);
     t.t_qp_iters = (int32_t*)tap(taps->qp_iters, Bz * 4, true);
-    t.t_cycles = (long long*)tap(taps->cycles, Bz * 8 * 8, true);
+    t.t_cycles = (long long*)tap(taps->cycles, Bz * 16 * 8, true);
   }
   if (rc == MKH_OK) rc = launch(p, a, taps ? &t : nullptr, stream, flags);
   if (rc == MKH_OK) {

@@ -110,7 +110,7 @@ struct TapArgs {
   double *t_xpos, *t_xquat, *t_frame_pose, *t_subtree_com, *t_task_e, *t_task_J, *t_H, *t_c, *t_box_lo,
       *t_box_hi, *t_coll_G, *t_coll_h;
   int32_t* t_qp_iters;
-  long long* t_cycles;             // (B, 8) shader-clock stamps at phase boundaries (profiling)
+  long long* t_cycles;             // (B, 16) shader-clock stamps at phase boundaries + QP sub-phase sums (profiling)
 };
 
 }  // namespace mkh

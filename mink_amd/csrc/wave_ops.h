@@ -48,6 +48,44 @@ MKH_WAVE_REDUCE(wave_min, op_min)
 MKH_WAVE_REDUCE(wave_sum, op_add)
 #undef MKH_WAVE_REDUCE
 
+// 32-bit unsigned reductions: one v_max/min_u32 with a DPP operand per step (half the cost of the
+// 64-bit float versions above, which need two DPP moves + a 64-bit op per step).
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ unsigned umax32(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned umin32(unsigned a, unsigned b) { return a < b ? a : b; }
+#define MKH_WAVE_REDUCE_U32(NAME, OP)                                                     \
+  __device__ __forceinline__ unsigned NAME(unsigned x) {                                  \
+    x = OP(x, dpp_u32<0xB1>(x));                                                          \
+    x = OP(x, dpp_u32<0x4E>(x));                                                          \
+    x = OP(x, dpp_u32<0x141>(x));                                                         \
+    x = OP(x, dpp_u32<0x140>(x));                                                         \
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)x, 0);                    \
+    const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)x, 16);                   \
+    const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)x, 32);                   \
+    const unsigned d = (unsigned)__builtin_amdgcn_readlane((int)x, 48);                   \
+    return OP(OP(a, b), OP(c, d));                                                        \
+  }
+MKH_WAVE_REDUCE_U32(wave_max_u32, umax32)
+MKH_WAVE_REDUCE_U32(wave_min_u32, umin32)
+#undef MKH_WAVE_REDUCE_U32
+
+// Exact minimum of non-negative doubles (+inf allowed, no NaN) over the lanes in `cand` (the others
+// must hold +inf): IEEE order = unsigned integer order of the bit patterns, so reduce the high words,
+// then — only if several lanes tie on the high word — the low words among them.
+__device__ __forceinline__ double wave_min_nonneg(double x, unsigned long long cand) {
+  if (!cand) return __builtin_huge_val();
+  const unsigned h = (unsigned)__double2hiint(x), l = (unsigned)__double2loint(x);
+  const unsigned mh = wave_min_u32(h);
+  const unsigned long long tie = __ballot(h == mh);
+  unsigned ml;
+  if (__builtin_popcountll(tie) == 1) ml = (unsigned)__builtin_amdgcn_readlane((int)l, (int)__builtin_ctzll(tie));
+  else ml = wave_min_u32(h == mh ? l : 0xffffffffu);
+  return __hiloint2double((int)mh, (int)ml);
+}
+
 // Index of the first lane where pred holds (wave-uniform), or -1.
 __device__ __forceinline__ int first_lane(bool pred) {
   unsigned long long m = __ballot(pred);

@@ -14,7 +14,7 @@ q, tg = workloads.make_batch(model, nm, prob, np.random.default_rng(0), B, base_
 for _ in range(2):
     v, st, t = prob.solve(q, tg, stand[None, :], None, dt, damping, taps=["cycles", "qp_iters"])
 c = t["cycles"].astype(np.int64)
-d = np.diff(c, axis=1)
+d = np.diff(c[:, :8], axis=1)
 names = ["load+FK", "axes/dof/com", "task lanes", "posture+J cols", "limits+coll", "build T + phase 0", "GI"]
 print("kernel", prob.last_kernel())
 tot = (c[:, 7] - c[:, 0])
@@ -22,11 +22,15 @@ print("launch", prob.launch_info(B))
 print("per-problem wave cycles: mean %.0f  p50 %.0f  p99 %.0f  max %d" % (tot.mean(), np.median(tot), np.percentile(tot, 99), tot.max()))
 for k, n in enumerate(names):
     print("  %-16s mean %8.0f  (%4.1f%%)" % (n, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean()))
+sub = ["phase-0 publish", "phase-0 rcp+pivot", "GI select", "GI publish", "GI ratio test", "GI pivot"]
+for k, n in enumerate(sub):
+    print("    %-18s mean %8.0f" % (n, c[:, 8 + k].mean()))
 it = t["qp_iters"]
-print("GI selections after x0: mean %.1f; GI cycles per selection: %.0f" % (it.mean(), d[:, 6].mean() / max(it.mean(), 1e-9)))
+print("GI: selections mean %.1f, loop iterations %.1f, rank-1 pivots %.1f; cycles per loop iteration %.0f" % (
+    it.mean(), t["qp_loops"].mean(), t["qp_pivots"].mean(), d[:, 6].mean() / max(t["qp_loops"].mean(), 1e-9)))
 if "--direct" in sys.argv:
     v, st, t = prob.solve(q, tg, stand[None, :], None, dt, damping, taps=["cycles", "qp_iters"], direct_qp=True)
-    c = t["cycles"].astype(np.int64); d = np.diff(c, axis=1); tot = c[:, 7] - c[:, 0]
+    c = t["cycles"].astype(np.int64); d = np.diff(c[:, :8], axis=1); tot = c[:, 7] - c[:, 0]
     print("kernel", prob.last_kernel(), "mean cycles %.0f" % tot.mean())
     for k, n in enumerate(names):
         print("  %-16s mean %8.0f  (%4.1f%%)" % (n, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean()))
