@@ -27,7 +27,7 @@ SGPRs really are lost — seen as a QP that never converges in the one variant w
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-NTS = (8, 16, 24, 32, 40, 44, 48, 56, 64)
+NTS = (8, 16, 24, 32, 40, 44, 48, 56, 62, 64)
 TOTAL = 256
 NRS = (16, 24, 32, 44, 48)   # dof-row counts of the low-rank start (kernel variants MKH_NR)
 def ntmp_for(nt):

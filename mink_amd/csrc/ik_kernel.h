@@ -93,15 +93,6 @@ struct QpLane {
 // per value and sits in the pivot's dependent chain).
 struct PivotScalars { double d, sg, x, rn, lo, hi; };
 
-// 1/d without the IEEE division sequence (v_div_scale/fmas/fixup ≈ 145 cycles in the pivot's
-// dependent chain): hardware reciprocal + two Newton steps (≤ 1 ulp for normal d).
-__device__ __forceinline__ double fast_rcp(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  r = fma(fma(-d, r, 1.0), r, r);
-  r = fma(fma(-d, r, 1.0), r, r);
-  return r;
-}
-
 template <int NT, bool FULL = false>
 __device__ __forceinline__ double publish_column(const QpLane& s, int col, int lane, double* sPiv,
                                                  PivotScalars& ps, int nact = kWave, double rown = 1.0) {
@@ -489,7 +480,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       if (lane == 0) { bx = 0; by = 0; bz = 0; }
       V3 cs = xi;
       if (b_stmass >= 1e-15) {
-        const double im = 1.0 / b_stmass;
+        const double im = fast_rcp(b_stmass);
         cs = {(ex - bx) * im, (ey - by) * im, (ez - bz) * im};
       }
       if (is_body) {
@@ -626,7 +617,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // accumulated right here, task by task, while the lane still holds its own weighted column.
     Tab<NT>::zero();
     // low-rank start: 1/√Dg of this dof (Dg = damping + Σμ + posture diagonal > 0, checked on the host)
-    const double dsq = (kWood && is_dof) ? 1.0 / sqrt(hdiag_base) : 0.0;
+    const double dsq = (kWood && is_dof) ? fast_rcp(sqrt(hdiag_base)) : 0.0;
     double we_mu = 0.0;
     for (int t = 0; t < n_jt; ++t) {
       double Jt[6] = {0, 0, 0, 0, 0, 0}, cw[6] = {0, 0, 0, 0, 0, 0}, we6[6] = {0, 0, 0, 0, 0, 0};
@@ -635,17 +626,17 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       bool second_half;
       if (t < P.n_frame) {
         const FrameTaskDev& ft = P.frame[t];
-        mask = ft.dof_mask;
+        mask = uni((unsigned long long)ft.dof_mask);
         nrow = 6;
-        row0 = ft.row0;
-        second_half = ft.any_ori != 0;
-        rowmask = ft.rowmask;
-        jrow0 = ft.jrow0;
+        row0 = uni(ft.row0);
+        second_half = uni(ft.any_ori) != 0;
+        rowmask = uni(ft.rowmask);
+        jrow0 = uni(ft.jrow0);
         const double* o = sTask + t * 64;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) { cw[r] = ft.cost[r]; we6[r] = o[30 + r]; }
-        const bool rel = kRel && ft.relative != 0;
-        const uint64_t rmask = rel ? ft.root_mask : 0ull;
+        for (int r = 0; r < 6; ++r) { cw[r] = uni(ft.cost[r]); we6[r] = uni(o[30 + r]); }
+        const bool rel = kRel && uni(ft.relative) != 0;
+        const uint64_t rmask = rel ? uni((unsigned long long)ft.root_mask) : 0ull;
         if (is_dof && (((mask | rmask) >> lane) & 1)) {
           MKH_LOAD_DOF_AXES();
           V3 a{0, 0, 0}, w{0, 0, 0};
@@ -706,7 +697,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           const double* cd = sCom + d_body * 4;
           const int inrobot = P.body_i[BI_IN_ROBOT * 64 + d_body];
           if (inrobot) {
-            const double fac = cd[3] / sCom[P.robot_root * 4 + 3];
+            const double fac = cd[3] * fast_rcp(sCom[P.robot_root * 4 + 3]);
             MKH_LOAD_DOF_AXES();
             V3 jc = fac * (d_lin + cross(d_ang, V3{cd[0], cd[1], cd[2]} - d_anchor));
             Jt[0] = jc.x; Jt[1] = jc.y; Jt[2] = jc.z;
@@ -824,7 +815,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
             hk = (dist > cp.dmin) ? (cp.gain * (dist - cp.dmin) / A.dt) + cp.relax : cp.relax;  // :200-205
             nrm = to - from;                                   // Contact.normal (:46-50)
             const double nn = sqrt(dot(nrm, nrm));
-            nrm = (nn < 1e-15) ? V3{1.0, 0.0, 0.0} : (1.0 / nn) * nrm;
+            nrm = (nn < 1e-15) ? V3{1.0, 0.0, 0.0} : fast_rcp(nn) * nrm;
             m1 = cp.mask1;
             m2 = cp.mask2;
           }
@@ -926,7 +917,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // inconsistent box ⇒ quadprog "constraints are inconsistent"
     if (__ballot(is_dof && lo > hi + 1e-12)) status |= 2;
     const double hmax = wave_max(is_dof ? hdiag : 0.0);
-    const double thr_dof = 1e-13 / (hmax * (double)nv);
+    const double thr_dof = 1e-13 * fast_rcp(hmax * (double)nv);
 
     int iters = 0;
     const int max_iters = 8 * (ntab + 8);
@@ -960,7 +951,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     double acc = 0.0;    // step accumulated by the driven index: multiplier of a dof going to its bound / of a row coming in
     int pend = -1;       // pending sweep of a blocking index (reverse flag in pend_rev)
     bool pend_rev = false;
-    const double inv_rown = (rown > 0.0) ? 1.0 / rown : 0.0;
+    const double inv_rown = (rown > 0.0) ? fast_rcp(rown) : 0.0;
     int n_loop = 0, n_piv = 0;   // profiling (qp_iters tap): loop iterations / rank-1 pivots of this phase
     while (!(status & 14)) {
       ++n_loop;

@@ -12,6 +12,17 @@
 
 namespace mkh {
 
+// 1/d without the IEEE division sequence (v_div_scale ×2, v_rcp, 5 FMAs, v_div_fmas, v_div_fixup ≈ 11
+// instructions and ≈145 cycles of dependent latency): hardware reciprocal + two Newton steps, ≤ 1 ulp for
+// normal d.  The kernel is VALU-issue bound, so every IEEE division that is not part of the reference's
+// bit pattern (the final v = Δq/dt is) goes through this.
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
 struct V3 { double x, y, z; };
 struct Q4 { double w, x, y, z; };
 struct M3 { double m[9]; };  // row-major
@@ -36,7 +47,7 @@ __device__ __forceinline__ Q4 qconj(Q4 a) { return {a.w, -a.x, -a.y, -a.z}; }
 __device__ __forceinline__ Q4 qnormalize(Q4 q) {
   double n = sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
   if (n < 1e-15) return {1.0, 0.0, 0.0, 0.0};
-  double inv = 1.0 / n;
+  double inv = fast_rcp(n);
   return {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
 }
 // mju_quat2Mat (mink/lie/so3.py:113)
@@ -105,13 +116,14 @@ __device__ __forceinline__ V3 so3_log(Q4 q) {
   const double norm_sq = q.x * q.x + q.y * q.y + q.z * q.z;
   double factor;
   if (norm_sq < 1e-10) {
-    factor = 2.0 / w - 2.0 / 3.0 * norm_sq / (w * w * w);
+    const double iw = fast_rcp(w);
+    factor = 2.0 * iw - 2.0 / 3.0 * norm_sq * (iw * iw * iw);
   } else {
     const double nrm = sqrt(norm_sq);
     if (fabs(w) < 1e-10) {
-      factor = (w > 0.0 ? 1.0 : -1.0) * M_PI / nrm;
+      factor = (w > 0.0 ? 1.0 : -1.0) * M_PI * fast_rcp(nrm);
     } else {
-      factor = 2.0 * atan2(w < 0 ? -nrm : nrm, fabs(w)) / nrm;
+      factor = 2.0 * atan2(w < 0 ? -nrm : nrm, fabs(w)) * fast_rcp(nrm);
     }
   }
   return {factor * q.x, factor * q.y, factor * q.z};
@@ -132,7 +144,7 @@ __device__ __forceinline__ void se3_log(SE3 T, V3& v, V3& omega) {
     const double th = sqrt(th2);
     double s, c;
     sincos_cw(0.5 * th, &s, &c);
-    k = (1.0 - th * c / (2.0 * s)) / th2;
+    k = (1.0 - th * c * fast_rcp(2.0 * s)) * fast_rcp(th2);
   }
   // V⁻¹ t = t − ½ ω×t + k ω×(ω×t)
   V3 wt = cross(omega, T.p);
@@ -159,10 +171,11 @@ __device__ __forceinline__ void se3_ljacinv(V3 v, V3 w, double* J, double* Q, bo
   double s, c;
   sincos_cw(th, &s, &c);
   // SO3.ljacinv: I − ½[ω] + A[ω]²   (θ ≥ 1e-5 here, never the θ < 1e-10 Taylor branch)
-  const double A = (1.0 / th2) * (1.0 - (th * s / (2.0 * (1.0 - c))));
-  const double Bc = (th - s) / (th2 * th);
-  const double Cc = (1.0 - th2 / 2.0 - c) / (th2 * th2);
-  const double Dc = (2.0 * th - 3.0 * s + th * c) / (2.0 * th2 * th2 * th);
+  const double ith2 = fast_rcp(th2), ith = th * ith2, ith4 = ith2 * ith2;
+  const double A = ith2 * (1.0 - (th * s * fast_rcp(2.0 * (1.0 - c))));
+  const double Bc = (th - s) * (ith2 * ith);
+  const double Cc = (1.0 - th2 * 0.5 - c) * ith4;
+  const double Dc = (2.0 * th - 3.0 * s + th * c) * (0.5 * ith4 * ith);
   const double wv[3] = {w.x, w.y, w.z}, vv[3] = {v.x, v.y, v.z};
   const double sv = dot(w, v);
   const V3 u = cross(v, w);

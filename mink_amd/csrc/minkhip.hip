@@ -443,7 +443,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   // ---- low-rank start eligibility: box limits only, frame tasks only, few task rows relative to nv
   if (P.n_jrows > 0 && P.n_pairs == 0 && P.n_com == 0 && !p->has_relative && 2 * P.n_jrows <= m->nv &&
       m->nv + P.n_jrows <= kWave) {
-    static const int kWoodVariants[][2] = {{32, 16}, {32, 24}, {48, 24}, {48, 32}, {64, 32}, {64, 44}, {64, 48}};
+    static const int kWoodVariants[][2] = {{32, 16}, {32, 24}, {48, 24}, {48, 32}, {64, 32}, {62, 44}, {64, 44}, {64, 48}};
     for (const auto& v : kWoodVariants)
       if (m->nv <= v[1] && m->nv + P.n_jrows <= v[0]) { p->wood_nt = v[0]; p->wood_nr = v[1]; break; }
     if (p->wood_nt) {

@@ -19,6 +19,18 @@ __device__ __forceinline__ double readlane_f64(double x, int src) {
 }
 __device__ __forceinline__ int readlane_i32(int x, int src) { return __builtin_amdgcn_readlane(x, src); }
 
+// Tell the compiler a value is wave-uniform (it cannot prove that for loads through pointers that were
+// themselves loaded from memory, and then keeps descriptor fields in VGPRs): first lane → SGPR.
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ double uni(double x) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+__device__ __forceinline__ unsigned long long uni(unsigned long long x) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double x) {
   int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
