@@ -170,7 +170,7 @@ typedef struct MkhTaps {
   int32_t *qp_iters; /* (B,)  active-set pivots after the unconstrained solve         */
   int64_t *cycles;   /* (B, 16): [0,8) shader-clock stamps at the kernel's phase boundaries, [8,16) cycles summed
                       * over the QP iterations: phase-0 publish, phase-0 pivot, GI select, GI publish, GI ratio
-                      * test, GI pivot, 2 spare (profiling) */
+                      * test, GI pivot; [14] stamp at the end of the Jacobian-column loop (profiling) */
 } MkhTaps;
 
 int32_t mkh_version(void);

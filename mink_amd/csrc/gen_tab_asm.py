@@ -163,6 +163,14 @@ def gen(nt: int) -> str:
         lines = [f"ds_read_b128 v[{t0 + 4 * k}:{t0 + 4 * k + 3}], %0 offset:{16 * k}" for k in range(nl)]
         lines.append("s_waitcnt lgkmcnt(0)")
         body = "\\n\\t".join(lines)
+        if nr < nt:
+            lines = [f"ds_read_b128 v[{t0 + 2 * nr + 4 * k}:{t0 + 2 * nr + 4 * k + 3}], %0 offset:{16 * k}" for k in range((nt - nr) // 2)]
+            lines.append("s_waitcnt lgkmcnt(0)")
+            body = "\\n\\t".join(lines)
+            out.append(f"  // T[{nr} + i] = lds[i], i < {nt - nr}  (the residual rows of the low-rank start)")
+            out.append(f"  __device__ static __forceinline__ void load_hi_{nr}(unsigned lds_addr) {{")
+            out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_t}, "memory");')
+            out.append("  }")
         out.append(f"  // T[i] = lds[i], i < {nr}")
         out.append(f"  __device__ static __forceinline__ void load_col_{nr}(unsigned lds_addr) {{")
         out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_t}, "memory");')

@@ -33,11 +33,12 @@ constexpr int kNumXcd = 8;   // MI355X: 8 XCDs × 32 CUs, one L2 each
 
 // ------------------------------------------------------------------ LDS layout
 struct LdsLayout {
-  int q, X, jnt, tgt, task, J, dof, com, col, A, piv, total;  // offsets in doubles
+  int q, X, jnt, tgt, task, J, dof, com, col, A, piv, S, total;  // offsets in doubles
 };
 __host__ __device__ inline int lds_even(int x) { return (x + 1) & ~1; }
 __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int njnt, int n_frame,
-                                                int n_posture, int n_com, int max_rows, int j_rows, int j_stride) {
+                                                int n_posture, int n_com, int max_rows, int j_rows, int j_stride,
+                                                int s_doubles = 0) {
   LdsLayout L;
   int o = 0;
   L.q = o;    o += lds_even(nq);
@@ -53,9 +54,13 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
   L.col = o;  o += max_rows * 16;
   L.A = o;    o += max_rows * kWave;
   L.piv = o;  o += kWave + 8;      // pivot column broadcast buffer + 8 scalar slots of the pivot lane
+  L.S = o;    o += lds_even(s_doubles);   // low-rank start: columns of −Jh·Jhᵀ + right-hand sides
   L.total = o;
   return L;
 }
+
+// Low-rank start: the n_mu × (sp + 1) block of −Jh·Jhᵀ and right-hand sides fits in the dof stash?
+__host__ __device__ inline bool wood_s_aliases_dof(int nv, int n_mu, int sp) { return n_mu * (sp + 1) <= nv * 10; }
 
 // Compile-time loop: f(std::integral_constant<int, I>{}) for I in [0, N).
 template <class F, int... I>
@@ -151,6 +156,15 @@ __device__ __forceinline__ void load_col_rows(unsigned addr) {
   else if constexpr (ROWS == 48 && NT >= 48) Tab<NT>::load_col_48(addr);
 }
 
+template <int NT, int ROWS>
+__device__ __forceinline__ void load_hi_rows(unsigned addr) {
+  if constexpr (ROWS == 16 && NT > 16) Tab<NT>::load_hi_16(addr);
+  else if constexpr (ROWS == 24 && NT > 24) Tab<NT>::load_hi_24(addr);
+  else if constexpr (ROWS == 32 && NT > 32) Tab<NT>::load_hi_32(addr);
+  else if constexpr (ROWS == 44 && NT > 44) Tab<NT>::load_hi_44(addr);
+  else if constexpr (ROWS == 48 && NT > 48) Tab<NT>::load_hi_48(addr);
+}
+
 template <int NT, int ROWS = NT>
 __device__ __forceinline__ void pivot(QpLane& s, int k, bool reverse, int lane, const double* sPiv,
                                       double own, const PivotScalars& ps, double inv) {
@@ -221,7 +235,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   const int lane = lane_id();
   const int nq = P0.nq, nv = P0.nv, nbody = P0.nbody;
   const LdsLayout L = lds_layout(nq, nv, nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows,
-                                 kWood ? P0.n_jrows + 1 : 6, kWood ? NR : NT);
+                                 kWood ? P0.n_jrows + 1 : 6, kWood ? NR : NT,
+                                 (kWood && !wood_s_aliases_dof(nv, P0.n_jrows, NT - NR)) ? P0.n_jrows * (NT - NR + 1) : 0);
   double* const sq = smem + L.q;
   double* const sX = smem + L.X;
   double* const sJnt = smem + L.jnt;
@@ -717,9 +732,10 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         hdiag += Jw[r] * Jw[r];
       }
       if (kWood) {
-        // Low-rank start: row r of Jh = Jw/√Dg is residual index nv + jrow0 + c of the tableau.  The dof
-        // lane keeps its entry in register row nv + jrow0 + c and stages it in LDS (all rows persist:
-        // the residual lanes load their columns from there, and S = I + Jh·Jhᵀ is a dot against it).
+        // Low-rank start: row r of Jh = Jw/√Dg is residual index NR + jrow0 + c of the tableau (NR is a
+        // compile-time constant ≥ nv, so the residual block has static register rows).  The dof lane
+        // keeps its entry in register row NR + jrow0 + c and stages it in LDS (all rows persist: the
+        // residual lanes load their columns from there, and S = I + Jh·Jhᵀ is computed from it).
         double* o = sJ + jrow0 * NR + lane;
         int c = 0;
 #pragma unroll
@@ -727,8 +743,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           if ((rowmask >> r) & 1) {
             const double jh = is_dof ? Jw[r] * dsq : 0.0;
             if (lane < NR) o[c * NR] = jh;
-            Tab<NT>::set_dyn(nv + jrow0 + c, jh);
-            if (lane == nv + jrow0 + c) we_mu = we6[r];       // weighted error of "my" residual
+            Tab<NT>::set_dyn(NR + jrow0 + c, jh);
+            if (lane == NR + jrow0 + c) we_mu = we6[r];       // weighted error of "my" residual
             ++c;
           }
         continue;
@@ -750,22 +766,67 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           if ((rowmask >> r) & 1) { Tab<NT>::rank1(lds_addr(sJ + c * NT), is_dof ? Jw[r] : 0.0); ++c; }
       }
     }
+    const double q_dof_stash = is_dof ? my_dof[9] : 0.0;    // (the dof stash is reused below)
+    long long tj = 0;
+    if (MKH_TAP(t_cycles)) tj = __builtin_readcyclecounter();     // profiling: end of the Jacobian-column loop
     // ---- low-rank start: residual columns, S block, right-hand sides
     const int n_mu = kWood ? P.n_jrows : 0;
-    const bool is_mu = kWood && lane >= nv && lane < nv + n_mu;
+    const int mu0 = kWood ? NR : nv;                         // first residual index / lane
+    const bool is_mu = kWood && lane >= mu0 && lane < mu0 + n_mu;
     double D_mu = 1.0, w_mu = 0.0;
     if (kWood) {
-      // x after the closed-form dof sweeps: z_k = −c_k/Dg_k (posture part of c only); staged as z_k·√Dg_k
+      constexpr int SP = NT - NR;                            // register rows of the residual block
+      // [column c][SP]: −(Jh·Jhᵀ)[·][c], then [c]: (Jw·z)[c].  Lives in the dof stash (axes / anchors of the
+      // Jacobian columns: dead by now) when it fits, so that the low-rank start costs no LDS residency.
+      double* const sS = wood_s_aliases_dof(nv, n_mu, SP) ? sDof : smem + L.S;
+      double* const sW = sS + n_mu * SP;
+      for (int i = lane; i < n_mu * SP; i += kWave) sS[i] = 0.0;   // rows ≥ n_μ are loaded into unused tableau rows
+      // x after the closed-form dof sweeps: z_k = −c_k/Dg_k (posture part of c only); staged as
+      // z_k·√Dg_k in row n_mu of the Jh array, so that the right-hand side is one more row of the product
       if (lane < NR) sJ[n_mu * NR + lane] = is_dof ? -c_lane * dsq : 0.0;
       wave_sync();
-      if (is_mu) load_col_rows<NT, NR>(lds_addr(sJ + (lane - nv) * NR));   // T[dof i][μ] = Jh[μ][i]
-      w_mu = dot_rows<NT, NR>(lds_addr(sJ + n_mu * NR)) - we_mu;          // Jw·z − r
-      for (int r = 0; r < n_mu; ++r) {
-        const double acc = dot_rows<NT, NR>(lds_addr(sJ + r * NR));       // (Jh·Jhᵀ)[r][lane − nv]
-        if (is_mu) {
-          if (lane - nv == r) D_mu = -(1.0 + acc);
-          Tab<NT>::set_dyn(nv + r, -acc);                                  // −S  (diagonal register unused)
+      // Jh·Jhᵀ by (column, row-chunk) lanes: 64/n_μ chunks of rows per column, each lane a handful of
+      // 44-long dot products on its own LDS addresses.  (Having every lane run the dot of ITS tableau
+      // column against each row costs n_μ+1 full-wave passes: 16.6 k of 132 k cycles on G1.)
+      const int wc = P.wood_col[ol], wr0 = P.wood_row0[ol];
+      if (wc >= 0) {
+        const double2* a = reinterpret_cast<const double2*>(sJ + wc * NR);
+        const int rpc = P.wood_rpc;
+        // four rows per pass: the lane's own column is read once per pass, the row reads are
+        // broadcasts within a chunk (all its lanes share the row)
+        for (int i0 = 0; i0 < rpc; i0 += 4) {
+          const int row0 = wr0 + i0;
+          if (row0 > n_mu) break;
+          const double2* b0 = reinterpret_cast<const double2*>(sJ + row0 * NR);
+          const double2* b1 = reinterpret_cast<const double2*>(sJ + min(row0 + 1, n_mu) * NR);
+          const double2* b2 = reinterpret_cast<const double2*>(sJ + min(row0 + 2, n_mu) * NR);
+          const double2* b3 = reinterpret_cast<const double2*>(sJ + min(row0 + 3, n_mu) * NR);
+          double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#pragma unroll 2   // (a full unroll puts 110 b128 loads in flight and spills 300 VGPRs)
+          for (int k = 0; k < NR / 2; ++k) {
+            const double2 av = a[k], v0 = b0[k], v1 = b1[k], v2 = b2[k], v3 = b3[k];
+            acc0 = fma(av.y, v0.y, fma(av.x, v0.x, acc0));
+            acc1 = fma(av.y, v1.y, fma(av.x, v1.x, acc1));
+            acc2 = fma(av.y, v2.y, fma(av.x, v2.x, acc2));
+            acc3 = fma(av.y, v3.y, fma(av.x, v3.x, acc3));
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = row0 + j;
+            const double acc = (j == 0) ? acc0 : (j == 1) ? acc1 : (j == 2) ? acc2 : acc3;
+            if (i0 + j < rpc && row <= n_mu) {
+              if (row < n_mu) sS[wc * SP + row] = -acc; else sW[wc] = acc;
+            }
+          }
         }
+      }
+      wave_sync();
+      if (is_mu) {
+        const int c = lane - NR;
+        load_col_rows<NT, NR>(lds_addr(sJ + c * NR));         // T[dof i][μ_c] = Jh[c][i]
+        load_hi_rows<NT, NR>(lds_addr(sS + c * SP));          // T[μ_r][μ_c] = −(Jh·Jhᵀ)[r][c]  (diagonal register unused)
+        D_mu = sS[c * SP + c] - 1.0;                          // −S[c][c]
+        w_mu = sW[c] - we_mu;                                 // Jw·z − r
       }
     }
     if (MKH_TAP(t_c) && is_dof) MKH_TAP(t_c)[(size_t)pb * nv + lane] = c_lane;
@@ -775,7 +836,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // VelocityLimit rows (velocity_limit.py:96-101); never materialise the dense G.
     double lo = -kInf, hi = kInf;
     if (is_dof) {
-      const double q_dof = my_dof[9];
+      const double q_dof = q_dof_stash;
       for (int t = 0; t < P.n_cfg; ++t) {
         const double lw = P.cfg_lower[t * 64 + lane], up = P.cfg_upper[t * 64 + lane];
         if (up < kInf) hi = fmin(hi, P.cfg_gain[t] * (up - q_dof));
@@ -925,7 +986,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // Tight loop: publish row k → (LDS loads of the rank-1 update already in flight) → 1/d,
     // multipliers, z/w update → rank-1 update.
     // (low-rank start: the dofs are already in; the n_μ residual indices nv.. take the pivots, d < 0)
-    const int k_begin = kWood ? nv : 0, k_end = kWood ? nv + n_mu : nv;
+    const int k_begin = kWood ? mu0 : 0, k_end = kWood ? mu0 + n_mu : nv;
     for (int k = k_begin; k < k_end; ++k) {
       PivotScalars ps;
       MKH_LAP0();
@@ -1050,7 +1111,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       for (int i = 1; i < 8; ++i) x = (lane == i) ? tc[i] : x;
 #pragma unroll
       for (int i = 0; i < 6; ++i) x = (lane == 8 + i) ? ta[i] : x;
-      if (lane >= 14) x = 0;
+      if (lane == 14) x = tj;
+      if (lane == 15) x = 0;
       MKH_TAP(t_cycles)[(size_t)pb * 16 + lane] = x;
     }
     if (MKH_TAP(t_qp_iters) && lane == 0) MKH_TAP(t_qp_iters)[pb] = iters | (n_loop << 10) | (n_piv << 20);

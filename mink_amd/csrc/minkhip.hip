@@ -445,10 +445,19 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       m->nv + P.n_jrows <= kWave) {
     static const int kWoodVariants[][2] = {{32, 16}, {32, 24}, {48, 24}, {48, 32}, {64, 32}, {62, 44}, {64, 44}, {64, 48}};
     for (const auto& v : kWoodVariants)
-      if (m->nv <= v[1] && m->nv + P.n_jrows <= v[0]) { p->wood_nt = v[0]; p->wood_nr = v[1]; break; }
+      if (m->nv <= v[1] && v[1] + P.n_jrows <= v[0]) { p->wood_nt = v[0]; p->wood_nr = v[1]; break; }
     if (p->wood_nt) {
       const LdsLayout Lw = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows,
-                                      P.n_jrows + 1, p->wood_nr);
+                                      P.n_jrows + 1, p->wood_nr,
+                                      wood_s_aliases_dof(P.nv, P.n_jrows, p->wood_nt - p->wood_nr) ? 0 : P.n_jrows * (p->wood_nt - p->wood_nr + 1));
+      // (column, row-chunk) lanes of the Jh·Jhᵀ product: rows 0..n_jrows (the last one is the rhs)
+      const int groups = kWave / P.n_jrows;
+      P.wood_rpc = (P.n_jrows + 1 + groups - 1) / groups;
+      for (int l = 0; l < kWave; ++l) {
+        const int ch = l / P.n_jrows;
+        P.wood_col[l] = ch < groups ? l % P.n_jrows : -1;
+        P.wood_row0[l] = ch < groups ? ch * P.wood_rpc : 0;
+      }
       p->wood_lds_bytes = Lw.total * (int)sizeof(double);
       if (p->wood_lds_bytes * 8 > 160 * 1024) p->wood_nt = 0;      // would cost residency
       double mn = __builtin_huge_val();

@@ -65,6 +65,10 @@ struct DeviceProblem {
   int32_t n_frame, n_posture, n_com, n_cfg, n_vel, n_pairs, n_rows_tap;
   int32_t max_rows;      // tableau rows reserved for half-spaces (ntab = nv + max_rows)
   int32_t n_jrows;       // weighted Jacobian rows staged in LDS (Σ nonzero-cost rows of frame + CoM tasks)
+  // low-rank start: lane l computes rows [wood_row0[l], +wood_rpc) of column wood_col[l] of Jh·Jhᵀ
+  // (row n_jrows = the right-hand side); −1 = idle lane
+  int32_t wood_rpc;
+  int32_t wood_col[64], wood_row0[64];
   int32_t nt;            // tableau rows per lane of the compiled kernel variant (row stride of the J rows)
   int32_t robot_root;    // body 1 (ComTask subtree root)
   // model lane tables

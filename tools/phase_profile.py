@@ -22,6 +22,7 @@ print("launch", prob.launch_info(B))
 print("per-problem wave cycles: mean %.0f  p50 %.0f  p99 %.0f  max %d" % (tot.mean(), np.median(tot), np.percentile(tot, 99), tot.max()))
 for k, n in enumerate(names):
     print("  %-16s mean %8.0f  (%4.1f%%)" % (n, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean()))
+print("    %-18s mean %8.0f   (then low-rank S block / rhs: %.0f)" % ("J columns", (c[:, 14] - c[:, 3]).mean(), (c[:, 4] - c[:, 14]).mean()))
 sub = ["phase-0 publish", "phase-0 rcp+pivot", "GI select", "GI publish", "GI ratio test", "GI pivot"]
 for k, n in enumerate(sub):
     print("    %-18s mean %8.0f" % (n, c[:, 8 + k].mean()))
