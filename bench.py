@@ -26,7 +26,17 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 BYTES_PER_SOLVE_G1 = 44 * 8 + 4 * 7 * 8 + 43 * 8 + 4   # q + 4 frame targets + v + status = 924 B
-FLOP_PER_SOLVE_G1 = (55 + 18) * 48 * 64 * 2             # issued fp64 FMA flops of the tableau per solve (≈0.45 Mflop)
+def issued_flop_per_solve(kernel: str) -> int:
+    """Issued fp64 FMA flops of the tableau work per G1 solve (64 lanes x 2 flop per row of a rank-1 update or
+    dot), DESIGN.md §3.1.  Low-rank start (kernel name ends in _r44): 18 residual pivots x NT rows + 13.5
+    active-set pivots x 44 rows + the 19 x 18 x 44 MACs of Jh·Jhᵀ; direct start: 43 + 12.5 pivots x NT rows
+    + 18 rank-1 updates of the H accumulation."""
+    nt = int(kernel.split("_")[3])
+    if "_r" in kernel:
+        return int((18 * nt + 12.5 * 44) * 64 * 2 + 19 * 18 * 44 * 2)
+    return int((43 + 12.5 + 18) * nt * 64 * 2)
+
+
 HBM_PEAK_GBS = 8000.0                                   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6                          # MI355X fp64 vector peak (same guide, chip table)
 
@@ -162,6 +172,8 @@ def main():
         value = total / elapsed
         ach = BYTES_PER_SOLVE_G1 * B / (kern_ms * 1e-3) / 1e9
         info = prob.launch_info(B)
+        kernel = prob.last_kernel()
+        flop = issued_flop_per_solve(kernel)
         traffic = measured_traffic() if B == 65536 else None
         out = {
             "metric": "IK solves/sec (whole node), Unitree G1 4 FrameTasks + box limits, batch 65536",
@@ -176,17 +188,16 @@ def main():
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
-                         "kernel": f"ik_solve_kernel_{info['tableau_rows']}_0", "kernel_ms": kern_ms,
+                         "kernel": kernel, "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_solve": BYTES_PER_SOLVE_G1,
                          "algorithmic_bytes_per_launch": BYTES_PER_SOLVE_G1 * B,
-                         "note": "fp64 VALU/latency-bound by design (nv=43 serial pivots in one wave); "
+                         "note": "fp64 VALU-issue bound by design (serial pivots of one QP per wavefront); "
                                  "HBM fraction reported as the contract requires, fp64 view alongside",
-                         # secondary compute view: issued fp64 tableau work only (55 pivots x NT rows x
-                         # 64 lanes x 2 flop + 18 H rank-1 updates), DESIGN.md §3.1
-                         "fp64_view": {"flop_per_solve": FLOP_PER_SOLVE_G1,
-                                       "achieved_tflops": FLOP_PER_SOLVE_G1 * B / (kern_ms * 1e-3) / 1e12,
+                         # secondary compute view: issued fp64 tableau work only (issued_flop_per_solve)
+                         "fp64_view": {"flop_per_solve": flop,
+                                       "achieved_tflops": flop * B / (kern_ms * 1e-3) / 1e12,
                                        "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                                       "frac": FLOP_PER_SOLVE_G1 * B / (kern_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS}},
+                                       "frac": flop * B / (kern_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS}},
         }
         if world == 1:
             out["pcie_inclusive_value"] = pcie_inclusive(prob, q_h, tg_h, stand, dt, damping)
