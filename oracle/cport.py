@@ -1,0 +1,211 @@
+"""ORACLE (test infrastructure) — ctypes binding of oracle/c/libmink_oracle.so, the plain-C restatement of the
+reference's solve_ik pipeline (see oracle/c/mink_oracle.h for the reference citations).
+
+Takes the same spec objects as oracle/ik.py (FrameTaskSpec, PostureTaskSpec, ComTaskSpec,
+ConfigurationLimitSpec, VelocityLimitSpec).  Used by tests/ (full-batch parity of the GPU path at BASELINE
+sizes) and by bench.py's cpu_baseline leg — never by the product (mink_amd/).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import ik
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "c", "libmink_oracle.so")
+_lib = None
+
+PI32 = C.POINTER(C.c_int32)
+PF64 = C.POINTER(C.c_double)
+_INT_FIELDS = ("body_parentid", "body_rootid", "body_jntadr", "body_jntnum", "body_dofadr", "body_dofnum", "body_mocapid")
+_MODEL_FIELDS = (
+    [(n, C.c_int32) for n in ("nq", "nv", "nbody", "njnt", "ngeom", "nsite")]
+    + [(n, PI32) for n in _INT_FIELDS]
+    + [(n, PF64) for n in ("body_pos", "body_quat", "body_ipos", "body_mass", "body_subtreemass")]
+    + [(n, PI32) for n in ("jnt_type", "jnt_qposadr", "jnt_dofadr", "jnt_bodyid", "jnt_limited")]
+    + [(n, PF64) for n in ("jnt_pos", "jnt_axis", "jnt_range")]
+    + [("dof_parentid", PI32), ("qpos0", PF64), ("site_bodyid", PI32), ("site_pos", PF64), ("site_quat", PF64),
+       ("geom_bodyid", PI32), ("geom_pos", PF64), ("geom_quat", PF64), ("mocap_pos", PF64), ("mocap_quat", PF64)]
+)
+
+
+class MkoModel(C.Structure):
+    _fields_ = _MODEL_FIELDS
+
+
+class MkoFrameTask(C.Structure):
+    _fields_ = [("frame_type", C.c_int32), ("frame_id", C.c_int32), ("cost", C.c_double * 6), ("gain", C.c_double),
+                ("lm_damping", C.c_double)]
+
+
+class MkoPostureTask(C.Structure):
+    _fields_ = [("cost", PF64), ("gain", C.c_double), ("lm_damping", C.c_double)]
+
+
+class MkoComTask(C.Structure):
+    _fields_ = [("cost", C.c_double * 3), ("gain", C.c_double), ("lm_damping", C.c_double)]
+
+
+class MkoProblem(C.Structure):
+    _fields_ = [("n_frame", C.c_int32), ("frame", C.POINTER(MkoFrameTask)), ("n_posture", C.c_int32),
+                ("posture", C.POINTER(MkoPostureTask)), ("n_com", C.c_int32), ("com", C.POINTER(MkoComTask)),
+                ("has_cfg_limit", C.c_int32), ("cfg_gain", C.c_double), ("cfg_min_distance", C.c_double),
+                ("n_vel", C.c_int32), ("vel_idx", PI32), ("vel_limit", PF64)]
+
+
+def build() -> str:
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "c")], check=True)
+    return LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        src = os.path.join(HERE, "c", "mink_oracle.c")
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+            build()
+        L = C.CDLL(LIB)
+        L.mko_solve_ik_batch.restype = C.c_int32
+        L.mko_solve_ik.restype = C.c_int32
+        L.mko_solve_qp.restype = C.c_int32
+        _lib = L
+    return _lib
+
+
+_FRAME_TYPES = {"body": 0, "geom": 1, "site": 2}
+
+
+class CProblem:
+    """One solve_ik call site (model + tasks + limits) compiled into the C structs."""
+
+    def __init__(self, model, tasks: Sequence, limits: Optional[Sequence]):
+        self.model = model
+        self._keep = []          # numpy buffers the C structs point into
+        mm = MkoModel()
+        for n in ("nq", "nv", "nbody", "njnt", "ngeom", "nsite"):
+            setattr(mm, n, int(getattr(model, n)))
+        for name, typ in _MODEL_FIELDS[6:]:
+            dt = np.int32 if typ is PI32 else np.float64
+            a = np.ascontiguousarray(np.asarray(getattr(model, name), dtype=dt).ravel())
+            if a.size == 0:
+                a = np.zeros(1, dtype=dt)
+            self._keep.append(a)
+            setattr(mm, name, a.ctypes.data_as(typ))
+        self.cmodel = mm
+        frames = [t for t in tasks if isinstance(t, ik.FrameTaskSpec)]
+        postures = [t for t in tasks if isinstance(t, ik.PostureTaskSpec)]
+        coms = [t for t in tasks if isinstance(t, ik.ComTaskSpec)]
+        if len(frames) + len(postures) + len(coms) != len(tasks):
+            raise TypeError("the C restatement covers FrameTask, PostureTask and ComTask")
+        # the C side adds objectives grouped by kind; float addition is not associative, so keep the
+        # caller's order within each kind (H differs from the numpy oracle only at the 1e-16 level)
+        self.frames, self.postures, self.coms = frames, postures, coms
+        fa = (MkoFrameTask * max(1, len(frames)))()
+        for i, t in enumerate(frames):
+            fa[i].frame_type = _FRAME_TYPES[t.frame_type]
+            fa[i].frame_id = int(t.frame_id)
+            fa[i].cost[:] = [float(x) for x in t.cost]
+            fa[i].gain = float(t.gain)
+            fa[i].lm_damping = float(t.lm_damping)
+        pa = (MkoPostureTask * max(1, len(postures)))()
+        for i, t in enumerate(postures):
+            c = np.ascontiguousarray(np.asarray(t.cost, dtype=np.float64))
+            self._keep.append(c)
+            pa[i].cost = c.ctypes.data_as(PF64)
+            pa[i].gain = float(t.gain)
+            pa[i].lm_damping = float(t.lm_damping)
+        ca = (MkoComTask * max(1, len(coms)))()
+        for i, t in enumerate(coms):
+            ca[i].cost[:] = [float(x) for x in t.cost]
+            ca[i].gain = float(t.gain)
+            ca[i].lm_damping = float(t.lm_damping)
+        self._keep += [fa, pa, ca]
+        pr = MkoProblem()
+        pr.n_frame, pr.frame = len(frames), fa
+        pr.n_posture, pr.posture = len(postures), pa
+        pr.n_com, pr.com = len(coms), ca
+        if limits is None:
+            limits = [ik.ConfigurationLimitSpec()]                 # solve_ik.py:28-29
+        cfg = [l for l in limits if isinstance(l, ik.ConfigurationLimitSpec)]
+        vel = [l for l in limits if isinstance(l, ik.VelocityLimitSpec)]
+        if len(cfg) > 1 or len(vel) > 1 or len(cfg) + len(vel) != len(limits):
+            raise TypeError("the C restatement covers one ConfigurationLimit and one VelocityLimit")
+        if cfg and vel and limits.index(cfg[0]) > limits.index(vel[0]):
+            raise TypeError("row order: ConfigurationLimit first")
+        pr.has_cfg_limit = 1 if cfg else 0
+        if cfg:
+            pr.cfg_gain, pr.cfg_min_distance = float(cfg[0].gain), float(cfg[0].min_distance_from_limits)
+        if vel:
+            vi = np.ascontiguousarray(np.asarray(vel[0].indices, dtype=np.int32))
+            vl = np.ascontiguousarray(np.asarray(vel[0].limit, dtype=np.float64))
+            self._keep += [vi, vl]
+            pr.n_vel, pr.vel_idx, pr.vel_limit = len(vi), vi.ctypes.data_as(PI32), vl.ctypes.data_as(PF64)
+        self.cproblem = pr
+
+    def _targets(self):
+        ft = np.array([t.target for t in self.frames], dtype=np.float64).reshape(len(self.frames), 7)
+        pt = np.array([t.target_q for t in self.postures], dtype=np.float64).reshape(len(self.postures), self.model.nq)
+        ct = np.array([t.target for t in self.coms], dtype=np.float64).reshape(len(self.coms), 3)
+        return ft, pt, ct
+
+    def solve(self, q, dt: float, damping: float, return_problem: bool = False):
+        """One instance, targets taken from the specs (mirror of oracle.ik.solve_ik)."""
+        m = self.model
+        ft, pt, ct = self._targets()
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        v = np.empty(m.nv)
+        H = np.empty((m.nv, m.nv))
+        c = np.empty(m.nv)
+        rc = lib().mko_solve_ik(C.byref(self.cmodel), C.byref(self.cproblem), q.ctypes.data_as(PF64),
+                                ft.ctypes.data_as(PF64), pt.ctypes.data_as(PF64), ct.ctypes.data_as(PF64),
+                                C.c_double(dt), C.c_double(damping), v.ctypes.data_as(PF64), H.ctypes.data_as(PF64),
+                                c.ctypes.data_as(PF64))
+        if rc == 4:
+            raise ik.qp_gi.NotPositiveDefinite("matrix P is not positive definite")
+        if rc:
+            raise ik.qp_gi.Infeasible(f"C oracle status {rc}")
+        return (v, (H, c)) if return_problem else v
+
+    def solve_batch(self, q, frame_targets, posture_target, dt: float, damping: float, com_target=None,
+                    nthreads: int = 1):
+        """q (B, nq), frame_targets (B, n_frame, 7), posture_target (n_posture, nq) or (B, n_posture, nq)."""
+        m = self.model
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        B = q.shape[0]
+        ft = np.ascontiguousarray(frame_targets, dtype=np.float64).reshape(B, max(len(self.frames), 0) * 7) \
+            if len(self.frames) else np.zeros((B, 1))
+        pt = np.ascontiguousarray(posture_target, dtype=np.float64) if len(self.postures) else np.zeros(1)
+        batched = 1 if (len(self.postures) and pt.ndim == 3) else 0
+        ct = np.ascontiguousarray(com_target, dtype=np.float64) if len(self.coms) else np.zeros(3)
+        v = np.empty((B, m.nv))
+        st = np.empty(B, dtype=np.int32)
+        rc = lib().mko_solve_ik_batch(C.byref(self.cmodel), C.byref(self.cproblem), C.c_int32(B), q.ctypes.data_as(PF64),
+                                      ft.ctypes.data_as(PF64), pt.ctypes.data_as(PF64), C.c_int32(batched),
+                                      ct.ctypes.data_as(PF64), C.c_double(dt), C.c_double(damping), C.c_int32(nthreads),
+                                      v.ctypes.data_as(PF64), st.ctypes.data_as(PI32))
+        if rc:
+            raise RuntimeError(f"mko_solve_ik_batch: {rc}")
+        return v, st
+
+
+def solve_qp(P, q, G=None, h=None):
+    P = np.ascontiguousarray(P, dtype=np.float64)
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    n = P.shape[0]
+    m = 0 if G is None else len(G)
+    Gc = np.ascontiguousarray(G, dtype=np.float64) if m else np.zeros((1, n))
+    hc = np.ascontiguousarray(h, dtype=np.float64) if m else np.zeros(1)
+    x = np.empty(n)
+    rc = lib().mko_solve_qp(C.c_int32(n), C.c_int32(m), P.ctypes.data_as(PF64), q.ctypes.data_as(PF64),
+                            Gc.ctypes.data_as(PF64), hc.ctypes.data_as(PF64), x.ctypes.data_as(PF64))
+    if rc == 4:
+        raise ik.qp_gi.NotPositiveDefinite("matrix P is not positive definite")
+    if rc:
+        raise ik.qp_gi.Infeasible(f"status {rc}")
+    return x

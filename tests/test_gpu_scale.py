@@ -124,3 +124,20 @@ def test_other_configs_full_batch(name, B):
         worst = max(worst, np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max()))
     print(name, "oracle subsample max rel err", worst, "pivots mean", t["qp_iters"].mean())
     assert worst < 1e-7
+
+
+def test_g1_full_batch_against_c_oracle(g1_setup):
+    """Every one of the 65 536 problems of the benchmark batch against the plain-C restatement of the reference
+    pipeline (oracle/c), all host threads.  Tolerance: the stated 1e-8·max(1, ‖v_ref‖∞)."""
+    import os
+    from oracle import cport
+    model, nm, prob, dt, damping, q, tg, stand = g1_setup
+    v, st = prob.solve(q, tg, stand[None, :], None, dt, damping)
+    m, tasks, limits, dt_o, damp_o = oc.g1_c3(tg[0], stand)
+    assert dt_o == dt and damp_o == damping
+    v_ref, st_ref = cport.CProblem(m, tasks, limits).solve_batch(q, tg, stand[None, :], dt, damping,
+                                                                  nthreads=min(16, os.cpu_count() or 1))
+    assert (st == 0).all() and (st_ref == 0).all()
+    err = np.abs(v - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
+    print("G1 B=65536 vs C oracle: max rel err %.2e, p99 %.2e (kernel %s)" % (err.max(), np.percentile(err, 99), prob.last_kernel()))
+    assert err.max() < 1e-8
