@@ -124,6 +124,18 @@ def test_other_configs_full_batch(name, B):
         worst = max(worst, np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max()))
     print(name, "oracle subsample max rel err", worst, "pivots mean", t["qp_iters"].mean())
     assert worst < 1e-7
+    if not prob.n_pairs:
+        # the whole batch against the plain-C oracle (no collision rows in its scope)
+        import os
+        from oracle import cport
+        mm, tasks, limits, dt_o, damp_o = cfgfn(tg[0], base)
+        v_ref, st_ref = cport.CProblem(mm, tasks, limits).solve_batch(q, tg, base[None, :], dt_o, damp_o,
+                                                                     nthreads=min(16, os.cpu_count() or 1))
+        assert (st_ref == 0).all()
+        v2, st2 = prob.solve(q, tg, base[None, :], None, dt, damping)       # production kernel variant
+        err = np.abs(v2 - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
+        print(name, "all %d problems vs C oracle: max rel err %.2e (kernel %s)" % (B, err.max(), prob.last_kernel()))
+        assert err.max() < 1e-7
 
 
 def test_g1_full_batch_against_c_oracle(g1_setup):
