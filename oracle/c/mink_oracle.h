@@ -12,7 +12,7 @@
  *   the published algorithm — PARITY UNPINNED against the mujoco wheel itself
  *   quadprog (Goldfarb–Idnani, dense):  third-party, restated — PARITY UNPINNED
  *
- * Same operation order as oracle/*.py (the numpy restatement), which is pinned against the real mink Python
+ * Same operation order as the numpy restatement (the .py files next to this directory), which is pinned against the real mink Python
  * (tests/golden/make_golden.py); tests/test_oracle_c.py pins this file against both.  Only tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
  */
