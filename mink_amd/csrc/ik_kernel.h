@@ -993,7 +993,9 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       const double own = publish_column<NT>(s, k, lane, sPiv, ps);
       Tab<NT>::rank1_prefetch(lds_addr(sPiv));
       MKH_LAP(0);
-      if (!((kWood ? -ps.d : ps.d) > 0.0)) { status |= 4; break; }
+      // (ps.* are wave-uniform values that arrive in VGPRs: the ballot turns the test into a scalar branch,
+      // which keeps `status` in an SGPR and the QP loops free of exec-mask bookkeeping)
+      if (__ballot(!((kWood ? -ps.d : ps.d) > 0.0))) { status |= 4; break; }
       const double inv = fast_rcp(ps.d);
       const double tau = (lane == k) ? ps.d : s.sg * ps.sg * own;     // column k of the tableau
       const double alpha = -ps.x * inv;                                // drives w_k to 0
@@ -1068,8 +1070,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         double t = fmax(y, 0.0) * fast_rcp(cnd ? rr : 1.0);
         t = (cnd && t == t) ? t : kInf;                          // (0·∞ from a denormal direction: no block)
         const double t1 = wave_min_nonneg(t, __ballot(cnd));
-        if (!(fmin(t1, t2) < kInf)) { status |= 2; break; }     // no step possible: infeasible
-        const bool full = t2 <= t1;
+        if (__ballot(!(fmin(t1, t2) < kInf))) { status |= 2; break; }     // no step possible: infeasible
+        const bool full = __ballot(t2 <= t1) != 0;              // wave-uniform: scalar branch
         const double alpha = sgn * (full ? t2 : t1);
         s.x = fma(s.basic ? -alpha : alpha, tau, s.x);          // basic: z −= α·τ, nonbasic: w += α·τ  (p included)
         acc += alpha;
