@@ -84,10 +84,18 @@ struct QpLane {
   double x;        // the FREE value of the index: z (dof value / multiplier) when basic, w (gradient / slack) when not.
                    // The other one is implied: w = 0 when basic; z = bound (dof) or 0 (row) when not.
   double lo, hi, sg, D;
-  int kind;        // 0 dof, 1 half-space row, 2 padding / dropped
-  int basic;       // swept into the basis
-  int mode;        // ratio-test role: 0 none, 1 active row (z ≥ 0), 2 dof at its upper bound (w ≤ 0), 3 at its lower (w ≥ 0)
+  // Roles as sign masks / small flags so that the per-iteration arithmetic is XORs instead of compare+select
+  // pairs (the active-set loop is VALU-issue bound):
+  int usign;       // kSign when basic: the step update is x += (α ^ usign)·τ   (basic: z −= α·τ, else w += α·τ)
+  int ysign;       // kSign when the index is a dof sitting at its UPPER bound (multiplier that must stay ≥ 0 is −w)
+  int rsign;       // kSign when the index is a dof sitting at its LOWER bound (its rate of decrease is −r)
+  int sel;         // selectable by the primal test: 1 basic dof (bounds), 2 inactive half-space row (slack), 0 no
+  int elig;        // takes part in the ratio test (dof at a bound / active row)
 };
+constexpr int kSign = (int)0x80000000;
+__device__ __forceinline__ double xor_sign(double v, int mask) {
+  return __hiloint2double(__double2hiint(v) ^ mask, __double2loint(v));
+}
 
 // Lane `col` publishes its raw tableau column R[0..NT) in LDS (the only cross-lane transport of
 // the QP): every lane then reads its own entry (ratio test / multiplier) and streams the whole
@@ -949,31 +957,29 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // ====================================================================== QP
     // Dual active set (Goldfarb–Idnani) on the sweep tableau; see tools/proto_tableau_qp.py
     // for the numpy statement of the same algorithm.
+    constexpr bool kRows = kColl;                            // half-space rows exist only with collision limits
     QpLane s;
-    s.sg = 1.0; s.basic = 0; s.mode = 0;
+    s.sg = 1.0; s.usign = 0; s.ysign = 0; s.rsign = 0; s.sel = 0; s.elig = 0;
     s.D = is_dof ? hdiag : ((lane >= ntab) ? 1.0 : 0.0);   // true diagonal of K
-    s.x = 0.0;
+    s.x = 0.0; s.lo = -kInf; s.hi = kInf;
     double rown = 1.0;
     if (kWood) {
       // state after the closed-form sweep of every dof of [[Dg, Jwᵀ],[Jw, −I]]
-      s.kind = is_dof ? 0 : 2;                               // residual indices: no bounds, never selected
       s.sg = is_dof ? dsq : 1.0;
       s.D = is_dof ? -(dsq * dsq) : D_mu;
-      s.basic = is_dof ? 1 : 0;
+      s.usign = is_dof ? kSign : 0;                          // dofs basic, residuals not yet
+      s.sel = is_dof ? 1 : 0;                                // residual indices: no bounds, never selected
       s.x = is_dof ? -c_lane * (dsq * dsq) : (is_mu ? w_mu : 0.0);   // z of the dofs, w of the residuals
-      s.lo = is_dof ? lo : -kInf;
-      s.hi = is_dof ? hi : kInf;
+      if (is_dof) { s.lo = lo; s.hi = hi; }
     } else if (is_dof) {
-      s.kind = 0; s.x = c_lane; s.lo = lo; s.hi = hi;         // nonbasic at z = 0: w = c
-    } else if (lane < nv + nrows) {
-      s.kind = 1; s.lo = 0.0; s.hi = kInf;
+      s.x = c_lane; s.lo = lo; s.hi = hi;                     // nonbasic at z = 0: w = c   (sel = 1 once swept)
+    } else if (kRows && lane < nv + nrows) {
+      s.sel = 2; s.lo = 0.0;
       s.x = -sCol[(lane - nv) * 16 + 9];                      // w = A·0 − h
       const double* o = sA + (lane - nv) * 64;
       double nn = 0.0;
       for (int i = 0; i < nv; ++i) nn += o[i] * o[i];
       rown = sqrt(nn);
-    } else {
-      s.kind = 2; s.lo = -kInf; s.hi = kInf;
     }
     // inconsistent box ⇒ quadprog "constraints are inconsistent"
     if (__ballot(is_dof && lo > hi + 1e-12)) status |= 2;
@@ -985,7 +991,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // ---- phase 0: bring every dof into the basis, x0 = −H⁻¹c (Gauss–Jordan, no ratio tests).
     // Tight loop: publish row k → (LDS loads of the rank-1 update already in flight) → 1/d,
     // multipliers, z/w update → rank-1 update.
-    // (low-rank start: the dofs are already in; the n_μ residual indices nv.. take the pivots, d < 0)
+    // (low-rank start: the dofs are already in; the n_μ residual indices NR.. take the pivots, d < 0)
     const int k_begin = kWood ? mu0 : 0, k_end = kWood ? mu0 + n_mu : nv;
     for (int k = k_begin; k < k_end; ++k) {
       PivotScalars ps;
@@ -999,8 +1005,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       const double inv = fast_rcp(ps.d);
       const double tau = (lane == k) ? ps.d : s.sg * ps.sg * own;     // column k of the tableau
       const double alpha = -ps.x * inv;                                // drives w_k to 0
-      s.x = fma(s.basic ? -alpha : alpha, tau, s.x);                   // basic: z −= α·τ, nonbasic: w += α·τ
-      if (lane == k) { s.x = alpha; s.basic = 1; }                     // z_k = 0 + α
+      s.x = fma(xor_sign(alpha, s.usign), tau, s.x);                   // basic: z −= α·τ, nonbasic: w += α·τ
+      if (lane == k) { s.x = alpha; s.usign = kSign; s.sel = kWood ? 0 : 1; }   // z_k = 0 + α; now basic
       pivot<NT>(s, k, false, lane, sPiv, own, ps, inv);
       MKH_LAP(1);
     }
@@ -1009,12 +1015,12 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // ---- phase 1: Goldfarb–Idnani.  Each iteration publishes ONE column `col`; a blocking
     // constraint found by the ratio test becomes the column of the next iteration (`pend`).
     int p = -1;          // index being driven (−1 ⇒ select a new one)
-    bool p_basic = false, upper = false;
+    bool p_basic = true, upper = false;
     double sgn = 1.0;
     double acc = 0.0;    // step accumulated by the driven index: multiplier of a dof going to its bound / of a row coming in
     int pend = -1;       // pending sweep of a blocking index (reverse flag in pend_rev)
     bool pend_rev = false;
-    const double inv_rown = (rown > 0.0) ? fast_rcp(rown) : 0.0;
+    const double inv_rown = (kRows && rown > 0.0) ? fast_rcp(rown) : 0.0;
     int n_loop = 0, n_piv = 0;   // profiling (qp_iters tap): loop iterations / rank-1 pivots of this phase
     while (!(status & 14)) {
       ++n_loop;
@@ -1026,16 +1032,16 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           // ---- most violated primal condition (GI step 1).  "Most" only steers the path (the optimum
           // is unique), so the arg-max compares the high words of the violations: one 32-bit DPP
           // reduction instead of a 64-bit one, no readlane chain (p's scalars come with the column).
-          double viol = 0.0;
-          if (s.kind == 0 && s.basic) viol = fmax(s.x - s.hi, s.lo - s.x);
-          else if (s.kind == 1 && !s.basic) viol = s.x * inv_rown;
-          const bool cand = viol > 1e-12;
+          const double over = s.x - s.hi, under = s.lo - s.x;
+          double viol = fmax(over, under);
+          if (kRows) viol = (s.sel == 2) ? s.x * inv_rown : viol;
+          const bool cand = s.sel != 0 && viol > 1e-12;
           if (!__ballot(cand)) break;
           const unsigned vh = cand ? (unsigned)__double2hiint(viol) : 0u;
           const unsigned mh = wave_max_u32(vh);
           p = first_lane(cand && vh == mh);
-          p_basic = ((__ballot(s.basic != 0) >> p) & 1) != 0;  // (A) basic dof  /  (B) inactive row
-          upper = p_basic && (((__ballot((s.x - s.hi) > (s.lo - s.x)) >> p) & 1) != 0);
+          p_basic = kRows ? (((__ballot(s.usign != 0) >> p) & 1) != 0) : true;   // (A) basic dof / (B) inactive row
+          upper = p_basic && (((__ballot(over > under) >> p) & 1) != 0);
           sgn = upper ? -1.0 : 1.0;
           acc = 0.0;
         }
@@ -1056,7 +1062,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         const double tau = (lane == col) ? ps.d : s.sg * ps.sg * own;   // column `col` of the tableau
         const double tpp = ps.d;
         const double beta = p_basic ? (upper ? ps.hi : ps.lo) : 0.0;
-        const double thr = p_basic ? thr_dof : thr_dof * ps.rn * ps.rn;
+        const double thr = (!kRows || p_basic) ? thr_dof : thr_dof * ps.rn * ps.rn;
         // full step length t2 (GI step 2b): z_p reaches its bound / the slack w_p reaches 0
         double t2 = kInf;
         if (p_basic ? (fabs(tpp) > thr) : (-tpp > thr)) t2 = fabs((ps.x - beta) * inv);
@@ -1064,35 +1070,39 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         // y = the multiplier that must stay ≥ 0 (z of an active row, −w at an upper bound, w at a lower
         // one), rr = its rate of decrease; one reciprocal instead of three divergent divisions.
         const double r = sgn * tau;
-        const double y = (s.mode == 2) ? -s.x : s.x;
-        const double rr = (s.mode == 3) ? -r : r;
-        const bool cnd = s.mode != 0 && rr > 0.0;               // (p itself is never eligible: its mode is 0)
+        const double y = xor_sign(s.x, s.ysign);
+        const double rr = xor_sign(r, s.rsign);
+        const bool cnd = s.elig != 0 && rr > 0.0;               // (p itself is never eligible)
         double t = fmax(y, 0.0) * fast_rcp(cnd ? rr : 1.0);
         t = (cnd && t == t) ? t : kInf;                          // (0·∞ from a denormal direction: no block)
         const double t1 = wave_min_nonneg(t, __ballot(cnd));
         if (__ballot(!(fmin(t1, t2) < kInf))) { status |= 2; break; }     // no step possible: infeasible
         const bool full = __ballot(t2 <= t1) != 0;              // wave-uniform: scalar branch
         const double alpha = sgn * (full ? t2 : t1);
-        s.x = fma(s.basic ? -alpha : alpha, tau, s.x);          // basic: z −= α·τ, nonbasic: w += α·τ  (p included)
+        s.x = fma(xor_sign(alpha, s.usign), tau, s.x);          // basic: z −= α·τ, nonbasic: w += α·τ  (p included)
         acc += alpha;
         if (full) {
           if (lane == p) {
             // dof p lands on its bound with multiplier acc  /  row p enters the active set with λ = acc
             s.x = acc;
-            s.basic = p_basic ? 0 : 1;
-            s.mode = p_basic ? (upper ? 2 : 3) : 1;
+            s.usign = p_basic ? 0 : kSign;
+            s.sel = 0;
+            s.elig = 1;
+            s.ysign = (p_basic && upper) ? kSign : 0;
+            s.rsign = (p_basic && !upper) ? kSign : 0;
           }
           rev = p_basic;
           p = -1;
         } else {
           pend = first_lane(cnd && t == t1);                    // blocking index: sweep it next iteration
-          pend_rev = ((__ballot(s.basic != 0) >> pend) & 1) != 0;
+          pend_rev = kRows ? (((__ballot(s.usign != 0) >> pend) & 1) != 0) : false;
           if (lane == pend) {
             // an active row leaves with λ = 0 (its slack w = 0 right now); a dof leaves its bound with
             // w = 0 and z = the bound
-            s.x = pend_rev ? 0.0 : ((s.mode == 2) ? s.hi : s.lo);
-            s.basic = pend_rev ? 0 : 1;
-            s.mode = 0;
+            s.x = pend_rev ? 0.0 : (s.ysign ? s.hi : s.lo);
+            s.usign = pend_rev ? 0 : kSign;
+            s.sel = pend_rev ? 2 : 1;
+            s.elig = 0; s.ysign = 0; s.rsign = 0;
           }
           // the prefetched loads are simply abandoned: drain them before LDS is reused
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1105,7 +1115,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       MKH_LAP(5);
     }
     // Δq of this dof: the free value when basic, else the bound it sits on
-    const double zfin = s.basic ? s.x : ((s.mode == 2) ? s.hi : s.lo);
+    const double zfin = s.usign ? s.x : (s.ysign ? s.hi : s.lo);
     MKH_TICK();   // 7: QP done
     if (MKH_TAP(t_cycles) && lane < 16) {
       long long x = tc[0];
