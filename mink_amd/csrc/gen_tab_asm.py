@@ -141,24 +141,6 @@ def gen(nt: int) -> str:
         out.append(f'    asm volatile("{body}"')
         out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
         out.append("  }")
-        # dot: Σ_{i<nr} lds[i]·T[i]  (two accumulators break the FMA dependency chain)
-        lines = ["s_waitcnt lgkmcnt(0)"] + [load(k, "%2") for k in range(min(depth, nl))]
-        for k in range(nl):
-            issued = min(nl, k + depth)
-            lines.append(f"s_waitcnt lgkmcnt({issued - k - 1})")
-            r = slot_reg(k)
-            lines.append(f"v_fma_f64 %0, v[{r}:{r + 1}], {treg(2 * k)}, %0")
-            lines.append(f"v_fma_f64 %1, v[{r + 2}:{r + 3}], {treg(2 * k + 1)}, %1")
-            if k + depth < nl:
-                lines.append(load(k + depth, "%2"))
-        body = "\\n\\t".join(lines)
-        out.append(f"  // Σ_{{i<{nr}}} lds[i]·T[i]")
-        out.append(f"  __device__ static __forceinline__ double dot_{nr}(unsigned lds_addr) {{")
-        out.append("    double a0 = 0.0, a1 = 0.0;")
-        out.append(f'    asm volatile("{body}"')
-        out.append(f'                 : "+v"(a0), "+v"(a1) : "v"(lds_addr) : {clob_tmp}, "memory");')
-        out.append("    return a0 + a1;")
-        out.append("  }")
         # column load: T[i] = lds[i] for i < nr (per-lane address, not a broadcast)
         lines = [f"ds_read_b128 v[{t0 + 4 * k}:{t0 + 4 * k + 3}], %0 offset:{16 * k}" for k in range(nl)]
         lines.append("s_waitcnt lgkmcnt(0)")

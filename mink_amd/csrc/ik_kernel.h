@@ -15,9 +15,12 @@
 //   pair lane   (l < n_pairs) capsule/sphere/plane signed distance + half-space row
 //                             (mink/limits/collision_avoidance_limit.py:187-229)
 //   tableau lane(l < ntab)    one column of the symmetric sweep tableau of
-//                             K = [[H, Aᵀ],[A, 0]] held in VGPRs; the dual active-set QP
-//                             (replaces qpsolvers→quadprog, mink/solve_ik.py:101) is a
-//                             sequence of rank-1 sweeps: v_readlane broadcast + v_fma_f64.
+//                             K = [[H, Aᵀ],[A, 0]] held in pinned VGPRs (tab_asm.inc); the dual
+//                             active-set QP (replaces qpsolvers→quadprog, mink/solve_ik.py:101) is a
+//                             sequence of rank-1 sweeps: the pivot column goes through LDS once
+//                             (indexed row read + one ds_write), broadcast ds_read_b128 + v_fma_f64.
+//                             Low-rank variants (F_WOOD) start from [[Dg, Jwᵀ],[Jw, −I]] instead and
+//                             pivot only the task-residual indices.
 // Per-problem J rows, task blocks, poses and half-space rows are staged in LDS.
 #pragma once
 #include "collide_dev.h"
@@ -147,15 +150,6 @@ __device__ __forceinline__ void rank1_rows(unsigned addr, double g) {
   else if constexpr (ROWS == 48) Tab<NT>::rank1_body_48(addr, g);
 }
 template <int NT, int ROWS>
-__device__ __forceinline__ double dot_rows(unsigned addr) {
-  if constexpr (ROWS == 16 && NT >= 16) return Tab<NT>::dot_16(addr);
-  else if constexpr (ROWS == 24 && NT >= 24) return Tab<NT>::dot_24(addr);
-  else if constexpr (ROWS == 32 && NT >= 32) return Tab<NT>::dot_32(addr);
-  else if constexpr (ROWS == 44 && NT >= 44) return Tab<NT>::dot_44(addr);
-  else if constexpr (ROWS == 48 && NT >= 48) return Tab<NT>::dot_48(addr);
-  else return 0.0;   // not a low-rank variant: never called
-}
-template <int NT, int ROWS>
 __device__ __forceinline__ void load_col_rows(unsigned addr) {
   if constexpr (ROWS == 16 && NT >= 16) Tab<NT>::load_col_16(addr);
   else if constexpr (ROWS == 24 && NT >= 24) Tab<NT>::load_col_24(addr);
@@ -277,8 +271,15 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     long long ta[6] = {0, 0, 0, 0, 0, 0}, tl = 0;   // QP sub-phase cycle sums (profiling)
     int tci = 0;
 #define MKH_TICK() do { if (MKH_TAP(t_cycles)) tc[tci] = __builtin_readcyclecounter(); ++tci; } while (0)
+// ISA markers for static instruction counting (tools/isa_census.py): comments only, and only with -DMKH_MARKERS
+#ifdef MKH_MARKERS
+#define MKH_MARK(name) asm volatile("; MKH_MARK " name)
+#else
+#define MKH_MARK(name) do {} while (0)
+#endif
 #define MKH_LAP0() do { if (MKH_TAP(t_cycles)) tl = __builtin_readcyclecounter(); } while (0)
 #define MKH_LAP(i) do { if (MKH_TAP(t_cycles)) { const long long n_ = __builtin_readcyclecounter(); ta[i] += n_ - tl; tl = n_; } } while (0)
+    MKH_MARK("problem_begin");
     MKH_TICK();   // 0: start
     // Opaque per-iteration zero: table loads below are indexed with it so that LICM cannot hoist
     // them out of the problem loop and keep ~60 VGPRs of lane constants live through the QP.
@@ -374,6 +375,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       }
     }
     wave_sync();
+    MKH_MARK("fk_done");
     MKH_TICK();   // 1: FK done
     // --------------------- joint anchors / axes in the world (xanchor, xaxis)
     if (is_body && b_jnum > 0) {
@@ -516,6 +518,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       if (MKH_TAP(t_subtree_com) && lane < 3) MKH_TAP(t_subtree_com)[(size_t)pb * 3 + lane] = cr[lane];
     }
 
+    MKH_MARK("axes_done");
     MKH_TICK();   // 2: joint axes / dof lanes / com done
     // ------------------------------------------- task lanes: pose, error, jlog
     double mu_lane = 0.0;  // Levenberg–Marquardt term of the task owned by this lane
@@ -580,6 +583,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     }
     double mu_total = A.damping + wave_sum(mu_lane);         // solve_ik.py:16 + Σ μ_t
 
+    MKH_MARK("tasklanes_done");
     MKH_TICK();   // 3: task lanes done
     // ------------------------------------------- posture tasks (diagonal)
     double c_lane = 0.0;   // c[lane]
@@ -775,6 +779,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       }
     }
     const double q_dof_stash = is_dof ? my_dof[9] : 0.0;    // (the dof stash is reused below)
+    MKH_MARK("jcols_done");
     long long tj = 0;
     if (MKH_TAP(t_cycles)) tj = __builtin_readcyclecounter();     // profiling: end of the Jacobian-column loop
     // ---- low-rank start: residual columns, S block, right-hand sides
@@ -838,6 +843,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       }
     }
     if (MKH_TAP(t_c) && is_dof) MKH_TAP(t_c)[(size_t)pb * nv + lane] = c_lane;
+    MKH_MARK("jcols_s_done");
     MKH_TICK();   // 4: posture + task Jacobian columns done
     // ------------------------------------------------------------ box limits
     // lo ≤ Δq ≤ hi from ConfigurationLimit rows (configuration_limit.py:94-124) and
@@ -923,6 +929,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     }
     wave_sync();
 
+    MKH_MARK("limits_done");
     MKH_TICK();   // 5: limits + collision rows done
     if (!A.do_qp && !MKH_TAP(t_H)) break;
 
@@ -994,6 +1001,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // (low-rank start: the dofs are already in; the n_μ residual indices NR.. take the pivots, d < 0)
     const int k_begin = kWood ? mu0 : 0, k_end = kWood ? mu0 + n_mu : nv;
     for (int k = k_begin; k < k_end; ++k) {
+      MKH_MARK("p0_iter_begin");
       PivotScalars ps;
       MKH_LAP0();
       const double own = publish_column<NT>(s, k, lane, sPiv, ps);
@@ -1010,6 +1018,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       pivot<NT>(s, k, false, lane, sPiv, own, ps, inv);
       MKH_LAP(1);
     }
+    MKH_MARK("phase0_done");
     MKH_TICK();   // 6: tableau built, phase 0 done
     const int nact = kWood ? nv : kWave;                     // lanes that still own a live index
     // ---- phase 1: Goldfarb–Idnani.  Each iteration publishes ONE column `col`; a blocking
@@ -1023,6 +1032,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     const double inv_rown = (kRows && rown > 0.0) ? fast_rcp(rown) : 0.0;
     int n_loop = 0, n_piv = 0;   // profiling (qp_iters tap): loop iterations / rank-1 pivots of this phase
     while (!(status & 14)) {
+      MKH_MARK("gi_iter_begin");
       ++n_loop;
       MKH_LAP0();
       int col;
@@ -1048,6 +1058,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         if (++iters > max_iters) { status |= 8; break; }
         col = p;
       }
+      MKH_MARK("gi_publish");
       PivotScalars ps;
       MKH_LAP(2);
       const double own = publish_column<NT, true>(s, col, lane, sPiv, ps, nact, rown);
@@ -1109,6 +1120,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           continue;
         }
       }
+      MKH_MARK("gi_pivot");
       ++n_piv;
       MKH_LAP(4);
       pivot<NT, NR>(s, col, rev, lane, sPiv, own, ps, inv);
@@ -1116,6 +1128,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     }
     // Δq of this dof: the free value when basic, else the bound it sits on
     const double zfin = s.usign ? s.x : (s.ysign ? s.hi : s.lo);
+    MKH_MARK("qp_done");
     MKH_TICK();   // 7: QP done
     if (MKH_TAP(t_cycles) && lane < 16) {
       long long x = tc[0];

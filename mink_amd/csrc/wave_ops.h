@@ -53,10 +53,8 @@ __device__ __forceinline__ double dpp_f64(double x) {
     return OP(OP(a, b), OP(c, d));                                    \
   }
 __device__ __forceinline__ double op_max(double a, double b) { return fmax(a, b); }
-__device__ __forceinline__ double op_min(double a, double b) { return fmin(a, b); }
 __device__ __forceinline__ double op_add(double a, double b) { return a + b; }
 MKH_WAVE_REDUCE(wave_max, op_max)
-MKH_WAVE_REDUCE(wave_min, op_min)
 MKH_WAVE_REDUCE(wave_sum, op_add)
 #undef MKH_WAVE_REDUCE
 
