@@ -141,10 +141,6 @@ def gen(nt: int) -> str:
         out.append(f'    asm volatile("{body}"')
         out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
         out.append("  }")
-        # column load: T[i] = lds[i] for i < nr (per-lane address, not a broadcast)
-        lines = [f"ds_read_b128 v[{t0 + 4 * k}:{t0 + 4 * k + 3}], %0 offset:{16 * k}" for k in range(nl)]
-        lines.append("s_waitcnt lgkmcnt(0)")
-        body = "\\n\\t".join(lines)
         if nr < nt:
             lines = [f"ds_read_b128 v[{t0 + 2 * nr + 4 * k}:{t0 + 2 * nr + 4 * k + 3}], %0 offset:{16 * k}" for k in range((nt - nr) // 2)]
             lines.append("s_waitcnt lgkmcnt(0)")
@@ -153,10 +149,19 @@ def gen(nt: int) -> str:
             out.append(f"  __device__ static __forceinline__ void load_hi_{nr}(unsigned lds_addr) {{")
             out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_t}, "memory");')
             out.append("  }")
-        out.append(f"  // T[i] = lds[i], i < {nr}")
-        out.append(f"  __device__ static __forceinline__ void load_col_{nr}(unsigned lds_addr) {{")
-        out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_t}, "memory");')
-        out.append("  }")
+        if nr < nt:
+            sp = nt - nr
+            lines = [f"ds_read_b64 {treg(nr + r)}, %2 offset:{8 * nr * r}" for r in range(sp)]
+            lines.append("s_waitcnt lgkmcnt(0)")
+            for r in range(sp):
+                lines.append(f"v_fma_f64 %{r % 2}, {treg(nr + r)}, {treg(nr + r)}, %{r % 2}")
+            body = "\\n\\t".join(lines)
+            out.append(f"  // T[{nr} + r] = lds[r·{nr}], r < {sp} (column `lane` of the row-major Jh array, stride {nr}); returns Σ_r T[{nr}+r]²")
+            out.append(f"  __device__ static __forceinline__ double load_hi_strided_{nr}(unsigned lds_addr) {{")
+            out.append("    double a0 = 0.0, a1 = 0.0;")
+            out.append(f'    asm volatile("{body}" : "+v"(a0), "+v"(a1) : "v"(lds_addr) : {clob_t}, "memory");')
+            out.append("    return a0 + a1;")
+            out.append("  }")
     # get / set with compile-time index
     out.append("  template <int I> __device__ static __forceinline__ double get() {")
     out.append("    int lo, hi;")

@@ -150,21 +150,22 @@ __device__ __forceinline__ void rank1_rows(unsigned addr, double g) {
   else if constexpr (ROWS == 48) Tab<NT>::rank1_body_48(addr, g);
 }
 template <int NT, int ROWS>
-__device__ __forceinline__ void load_col_rows(unsigned addr) {
-  if constexpr (ROWS == 16 && NT >= 16) Tab<NT>::load_col_16(addr);
-  else if constexpr (ROWS == 24 && NT >= 24) Tab<NT>::load_col_24(addr);
-  else if constexpr (ROWS == 32 && NT >= 32) Tab<NT>::load_col_32(addr);
-  else if constexpr (ROWS == 44 && NT >= 44) Tab<NT>::load_col_44(addr);
-  else if constexpr (ROWS == 48 && NT >= 48) Tab<NT>::load_col_48(addr);
-}
-
-template <int NT, int ROWS>
 __device__ __forceinline__ void load_hi_rows(unsigned addr) {
   if constexpr (ROWS == 16 && NT > 16) Tab<NT>::load_hi_16(addr);
   else if constexpr (ROWS == 24 && NT > 24) Tab<NT>::load_hi_24(addr);
   else if constexpr (ROWS == 32 && NT > 32) Tab<NT>::load_hi_32(addr);
   else if constexpr (ROWS == 44 && NT > 44) Tab<NT>::load_hi_44(addr);
   else if constexpr (ROWS == 48 && NT > 48) Tab<NT>::load_hi_48(addr);
+}
+
+template <int NT, int ROWS>
+__device__ __forceinline__ double load_hi_strided_rows(unsigned addr) {
+  if constexpr (ROWS == 16 && NT > 16) return Tab<NT>::load_hi_strided_16(addr);
+  else if constexpr (ROWS == 24 && NT > 24) return Tab<NT>::load_hi_strided_24(addr);
+  else if constexpr (ROWS == 32 && NT > 32) return Tab<NT>::load_hi_strided_32(addr);
+  else if constexpr (ROWS == 44 && NT > 44) return Tab<NT>::load_hi_strided_44(addr);
+  else if constexpr (ROWS == 48 && NT > 48) return Tab<NT>::load_hi_strided_48(addr);
+  else return 0.0;
 }
 
 template <int NT, int ROWS = NT>
@@ -237,7 +238,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   const int lane = lane_id();
   const int nq = P0.nq, nv = P0.nv, nbody = P0.nbody;
   const LdsLayout L = lds_layout(nq, nv, nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows,
-                                 kWood ? P0.n_jrows + 1 : 6, kWood ? NR : NT,
+                                 kWood ? NT - NR + 1 : 6, kWood ? NR : NT,
                                  (kWood && !wood_s_aliases_dof(nv, P0.n_jrows, NT - NR)) ? P0.n_jrows * (NT - NR + 1) : 0);
   double* const sq = smem + L.q;
   double* const sX = smem + L.X;
@@ -646,7 +647,61 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // low-rank start: 1/√Dg of this dof (Dg = damping + Σμ + posture diagonal > 0, checked on the host)
     const double dsq = (kWood && is_dof) ? fast_rcp(sqrt(hdiag_base)) : 0.0;
     double we_mu = 0.0;
-    for (int t = 0; t < n_jt; ++t) {
+    const double q_dof_stash = is_dof ? my_dof[9] : 0.0;    // (slot 9 of the dof stash is reused below)
+    if (kWood) {
+      // Low-rank start: row r of Jh = Jw/√Dg is residual index NR + r of the tableau (NR is a compile-time
+      // constant ≥ nv, so the residual block has static register rows).  The Jacobian columns are computed
+      // by (task, dof) PAIR lanes — 56 pairs for G1's four tasks, i.e. ONE pass instead of a pass per task —
+      // into the row-major LDS array Jh[r][k]; dof lanes then load column k into their residual rows.
+      constexpr int SP = NT - NR;
+      for (int i = lane; i < SP * NR; i += kWave) sJ[i] = 0.0;    // dofs off a task's chain, rows ≥ n_μ
+      if (is_dof) sDof[lane * 10 + 9] = dsq;
+      wave_sync();
+      const int n_jp = P.n_jpairs;
+      for (int base = 0; base < n_jp; base += kWave) {
+        const int pi = base + lane;
+        if (pi < n_jp) {
+          const int t = P.jpair_task[pi], k = P.jpair_dof[pi];
+          const FrameTaskDev& ft = P.frame[t];
+          const double* o = sTask + t * 64;
+          const double* dd = sDof + k * 10;
+          const V3 d_ang{dd[0], dd[1], dd[2]}, d_lin{dd[3], dd[4], dd[5]}, d_anchor{dd[6], dd[7], dd[8]};
+          const double dsk = dd[9];
+          const V3 pf{o[27], o[28], o[29]};
+          const V3 jp = d_lin + cross(d_ang, pf - d_anchor);
+          M3 Rf;
+#pragma unroll
+          for (int i = 0; i < 9; ++i) Rf.m[i] = o[18 + i];
+          const V3 a = mulT(Rf, jp), w = mulT(Rf, d_ang);       // body-frame Jacobian (configuration.py:148-153)
+          // J = −jlog(T_tb)·ᴮJ with jlog = [[J, −J·Q·J],[0, J]]:  y = J·w;  rows 0-2 = −J·(a − Q·y), rows 3-5 = −y
+          const double wv[3] = {w.x, w.y, w.z}, av[3] = {a.x, a.y, a.z};
+          double y[3], z3[3], Jt[6];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) y[r] = o[3 * r] * wv[0] + o[3 * r + 1] * wv[1] + o[3 * r + 2] * wv[2];
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+            z3[r] = av[r] - (o[9 + 3 * r] * y[0] + o[9 + 3 * r + 1] * y[1] + o[9 + 3 * r + 2] * y[2]);
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            Jt[r] = -(o[3 * r] * z3[0] + o[3 * r + 1] * z3[1] + o[3 * r + 2] * z3[2]);
+            Jt[3 + r] = -y[r];
+          }
+          const int rowmask = ft.rowmask;
+          double* orow = sJ + ft.jrow0 * NR + k;
+          int c = 0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+            if ((rowmask >> r) & 1) { orow[c * NR] = (ft.cost[r] * Jt[r]) * dsk; ++c; }   // weighted_jacobian/√Dg
+        }
+      }
+      wave_sync();
+      if (lane < NR) {
+        const double ssq = load_hi_strided_rows<NT, NR>(lds_addr(sJ + lane));   // residual rows of column `lane`
+        hdiag = hdiag_base * (1.0 + ssq);                      // H[k][k] = Dg·(1 + Σ Jh²)  (only scales thresholds)
+      }
+      if (lane >= NR && lane < NR + P.n_jrows) we_mu = sTask[P.mu_src[lane - NR]];
+    }
+    for (int t = 0; t < (kWood ? 0 : n_jt); ++t) {
       double Jt[6] = {0, 0, 0, 0, 0, 0}, cw[6] = {0, 0, 0, 0, 0, 0}, we6[6] = {0, 0, 0, 0, 0, 0};
       uint64_t mask;
       int nrow, row0, rowmask, jrow0;
@@ -740,26 +795,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
         Jw[r] = cw[r] * Jt[r];                               // weighted_jacobian (task.py:129)
-        if (!kWood) c_lane -= we6[r] * Jw[r];                // c = −weighted_errorᵀ·weighted_jacobian
+        c_lane -= we6[r] * Jw[r];                            // c = −weighted_errorᵀ·weighted_jacobian
         hdiag += Jw[r] * Jw[r];
-      }
-      if (kWood) {
-        // Low-rank start: row r of Jh = Jw/√Dg is residual index NR + jrow0 + c of the tableau (NR is a
-        // compile-time constant ≥ nv, so the residual block has static register rows).  The dof lane
-        // keeps its entry in register row NR + jrow0 + c and stages it in LDS (all rows persist: the
-        // residual lanes load their columns from there, and S = I + Jh·Jhᵀ is computed from it).
-        double* o = sJ + jrow0 * NR + lane;
-        int c = 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-          if ((rowmask >> r) & 1) {
-            const double jh = is_dof ? Jw[r] * dsq : 0.0;
-            if (lane < NR) o[c * NR] = jh;
-            Tab<NT>::set_dyn(NR + jrow0 + c, jh);
-            if (lane == NR + jrow0 + c) we_mu = we6[r];       // weighted error of "my" residual
-            ++c;
-          }
-        continue;
       }
       wave_sync();                                             // previous task's rows are consumed
       if (lane < NT) {
@@ -778,7 +815,6 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           if ((rowmask >> r) & 1) { Tab<NT>::rank1(lds_addr(sJ + c * NT), is_dof ? Jw[r] : 0.0); ++c; }
       }
     }
-    const double q_dof_stash = is_dof ? my_dof[9] : 0.0;    // (the dof stash is reused below)
     MKH_MARK("jcols_done");
     long long tj = 0;
     if (MKH_TAP(t_cycles)) tj = __builtin_readcyclecounter();     // profiling: end of the Jacobian-column loop
@@ -795,8 +831,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       double* const sW = sS + n_mu * SP;
       for (int i = lane; i < n_mu * SP; i += kWave) sS[i] = 0.0;   // rows ≥ n_μ are loaded into unused tableau rows
       // x after the closed-form dof sweeps: z_k = −c_k/Dg_k (posture part of c only); staged as
-      // z_k·√Dg_k in row n_mu of the Jh array, so that the right-hand side is one more row of the product
-      if (lane < NR) sJ[n_mu * NR + lane] = is_dof ? -c_lane * dsq : 0.0;
+      // z_k·√Dg_k in the last row (SP) of the Jh array, so that the right-hand side is one more row of the product
+      if (lane < NR) sJ[SP * NR + lane] = is_dof ? -c_lane * dsq : 0.0;
       wave_sync();
       // Jh·Jhᵀ by (column, row-chunk) lanes: 64/n_μ chunks of rows per column, each lane a handful of
       // 44-long dot products on its own LDS addresses.  (Having every lane run the dot of ITS tableau
@@ -810,10 +846,9 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         for (int i0 = 0; i0 < rpc; i0 += 4) {
           const int row0 = wr0 + i0;
           if (row0 > n_mu) break;
-          const double2* b0 = reinterpret_cast<const double2*>(sJ + row0 * NR);
-          const double2* b1 = reinterpret_cast<const double2*>(sJ + min(row0 + 1, n_mu) * NR);
-          const double2* b2 = reinterpret_cast<const double2*>(sJ + min(row0 + 2, n_mu) * NR);
-          const double2* b3 = reinterpret_cast<const double2*>(sJ + min(row0 + 3, n_mu) * NR);
+          // product row → LDS row: Jh rows 0..n_μ−1, then the right-hand-side vector stored in row SP
+          auto rowp = [&](int r) { return reinterpret_cast<const double2*>(sJ + (r < n_mu ? r : SP) * NR); };
+          const double2 *b0 = rowp(row0), *b1 = rowp(row0 + 1), *b2 = rowp(row0 + 2), *b3 = rowp(row0 + 3);
           double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
 #pragma unroll 2   // (a full unroll puts 110 b128 loads in flight and spills 300 VGPRs)
           for (int k = 0; k < NR / 2; ++k) {
@@ -836,7 +871,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       wave_sync();
       if (is_mu) {
         const int c = lane - NR;
-        load_col_rows<NT, NR>(lds_addr(sJ + c * NR));         // T[dof i][μ_c] = Jh[c][i]
+        // (the dof rows of a residual column are never read: by symmetry every pivot takes ROW k of each
+        // lane, and residual lanes publish 0 once phase 0 is over — only the residual rows are loaded)
         load_hi_rows<NT, NR>(lds_addr(sS + c * SP));          // T[μ_r][μ_c] = −(Jh·Jhᵀ)[r][c]  (diagonal register unused)
         D_mu = sS[c * SP + c] - 1.0;                          // −S[c][c]
         w_mu = sW[c] - we_mu;                                 // Jw·z − r

@@ -448,7 +448,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       if (m->nv <= v[1] && v[1] + P.n_jrows <= v[0]) { p->wood_nt = v[0]; p->wood_nr = v[1]; break; }
     if (p->wood_nt) {
       const LdsLayout Lw = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows,
-                                      P.n_jrows + 1, p->wood_nr,
+                                      p->wood_nt - p->wood_nr + 1, p->wood_nr,
                                       wood_s_aliases_dof(P.nv, P.n_jrows, p->wood_nt - p->wood_nr) ? 0 : P.n_jrows * (p->wood_nt - p->wood_nr + 1));
       // (column, row-chunk) lanes of the Jh·Jhᵀ product: rows 0..n_jrows (the last one is the rhs)
       const int groups = kWave / P.n_jrows;
@@ -457,6 +457,18 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
         const int ch = l / P.n_jrows;
         P.wood_col[l] = ch < groups ? l % P.n_jrows : -1;
         P.wood_row0[l] = ch < groups ? ch * P.wood_rpc : 0;
+      }
+      // Jacobian columns by (task, dof) pair lanes; source of each residual's weighted error
+      P.n_jpairs = 0;
+      for (size_t t = 0; t < ft.size() && p->wood_nt; ++t) {
+        for (int k = 0; k < m->nv; ++k)
+          if ((ft[t].dof_mask >> k) & 1) {
+            if (P.n_jpairs >= 256) { p->wood_nt = 0; break; }
+            P.jpair_task[P.n_jpairs] = (int16_t)t; P.jpair_dof[P.n_jpairs] = (int16_t)k; ++P.n_jpairs;
+          }
+        int c = 0;
+        for (int r = 0; r < 6; ++r)
+          if ((ft[t].rowmask >> r) & 1) { P.mu_src[ft[t].jrow0 + c] = (int16_t)(t * 64 + 30 + r); ++c; }
       }
       p->wood_lds_bytes = Lw.total * (int)sizeof(double);
       if (p->wood_lds_bytes * 8 > 160 * 1024) p->wood_nt = 0;      // would cost residency

@@ -69,6 +69,12 @@ struct DeviceProblem {
   // (row n_jrows = the right-hand side); −1 = idle lane
   int32_t wood_rpc;
   int32_t wood_col[64], wood_row0[64];
+  // low-rank start: Jacobian columns by (task, dof) pair lanes — pair i = column jpair_dof[i] of frame task
+  // jpair_task[i] (only dofs on the task's kinematic chain); mu_src[r] = offset in the task LDS block of the
+  // weighted error of compact row r
+  int32_t n_jpairs;
+  int16_t jpair_task[256], jpair_dof[256];
+  int16_t mu_src[64];
   int32_t nt;            // tableau rows per lane of the compiled kernel variant (row stride of the J rows)
   int32_t robot_root;    // body 1 (ComTask subtree root)
   // model lane tables
