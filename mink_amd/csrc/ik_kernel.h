@@ -235,7 +235,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   static_assert(!kWood || !(kRel || kCom || kColl), "low-rank start: frame/posture tasks + box limits only");
   const DeviceProblem& P0 = *Pg;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int lane = lane_id();
+  int lane = lane_id();     // (re-laundered at every phase boundary, see MKH_TICK)
   const int nq = P0.nq, nv = P0.nv, nbody = P0.nbody;
   const LdsLayout L = lds_layout(nq, nv, nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows,
                                  kWood ? NT - NR + 1 : 6, kWood ? NR : NT,
@@ -271,7 +271,11 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     long long tc[8];
     long long ta[6] = {0, 0, 0, 0, 0, 0}, tl = 0;   // QP sub-phase cycle sums (profiling)
     int tci = 0;
-#define MKH_TICK() do { if (MKH_TAP(t_cycles)) tc[tci] = __builtin_readcyclecounter(); ++tci; } while (0)
+// Phase boundary: besides the profiling stamp, `lane` goes through an empty asm so that the compiler
+// cannot keep per-lane LDS addresses (sX + 8·lane, sPiv + lane, …) alive across phases: it computed them
+// once per kernel and then SPILLED them (9 of the 24 spills of the production variant), although each
+// is one v_lshl_add away.
+#define MKH_TICK() do { if (MKH_TAP(t_cycles)) tc[tci] = __builtin_readcyclecounter(); ++tci; asm volatile("" : "+v"(lane)); } while (0)
 // ISA markers for static instruction counting (tools/isa_census.py): comments only, and only with -DMKH_MARKERS
 #ifdef MKH_MARKERS
 #define MKH_MARK(name) asm volatile("; MKH_MARK " name)
