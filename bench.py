@@ -28,17 +28,16 @@ sys.path.insert(0, REPO)
 
 BYTES_PER_SOLVE_G1 = 44 * 8 + 4 * 7 * 8 + 43 * 8 + 4   # q + 4 frame targets + v + status = 924 B
 def issued_flop_per_solve(kernel: str) -> int:
-    """Issued fp64 FMA flops of the tableau work per G1 solve (64 lanes x 2 flop per row of a rank-1 update or
-    dot), DESIGN.md §3.1.  Low-rank start (kernel name ends in _r44): 18 residual pivots x NT rows + 13.5
-    active-set pivots x 44 rows + the 19 x 18 x 44 MACs of Jh·Jhᵀ; direct start: 43 + 12.5 pivots x NT rows
-    + 18 rank-1 updates of the H accumulation."""
+    """Issued fp64 FMA flops of the tableau work per G1 solve (64 lanes x 2 flop per row of a rank-1 update),
+    DESIGN.md §3.1.  Low-rank start (kernel name ends in _r44): 18 residual pivots x NT rows + 13.4 active-set
+    pivots x 44 rows + the 19 x 18 x 44 MACs of Jh·Jhᵀ; direct start: 43 + 13.4 pivots x NT rows + 18 rank-1
+    updates of the H accumulation."""
     nt = int(kernel.split("_")[3])
     if "_r" in kernel:
-        return int((18 * nt + 12.5 * 44) * 64 * 2 + 19 * 18 * 44 * 2)
-    return int((43 + 12.5 + 18) * nt * 64 * 2)
+        return int((18 * nt + 13.4 * 44) * 64 * 2 + 19 * 18 * 44 * 2)
+    return int((43 + 13.4 + 18) * nt * 64 * 2)
 
 
-HBM_PEAK_GBS = 8000.0                                   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6                          # MI355X fp64 vector peak (same guide, chip table)
 
 
