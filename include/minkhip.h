@@ -167,7 +167,9 @@ typedef struct MkhTaps {
   double *box_hi;    /* (B, nv)                                                        */
   double *coll_G;    /* (B, n_pairs, nv) CollisionAvoidanceLimit G rows (0 when inactive) */
   double *coll_h;    /* (B, n_pairs)     and h (+inf when inactive)                   */
-  int32_t *qp_iters; /* (B,)  active-set pivots after the unconstrained solve         */
+  int32_t *qp_iters; /* (B,)  packed counters of the active-set phase after the unconstrained solve:
+                      * bits 0-9 pivots (Goldfarb-Idnani selections when rows exist), 10-19 outer loop
+                      * iterations / block steps, 20-29 rank-1 pivots */
   int64_t *cycles;   /* (B, 16): [0,8) shader-clock stamps at the kernel's phase boundaries, [8,16) cycles summed
                       * over the QP iterations: phase-0 publish, phase-0 pivot, GI select, GI publish, GI ratio
                       * test, GI pivot; [14] stamp at the end of the Jacobian-column loop (profiling) */
@@ -177,11 +179,16 @@ int32_t mkh_version(void);
 const char *mkh_last_error(void);
 int32_t mkh_device_count(void);
 
-/* Upload the flattened kinematic tree once (replaces per-call mj_kinematics/mj_jac* reads of mjModel). */
+/* Upload the flattened kinematic tree once: the mujoco.MjModel fields mink reads per solve through
+ * Configuration.update / get_frame_jacobian (mink/configuration.py:53-64,112-155), the limits' constructors
+ * (limits/configuration_limit.py:41-67, limits/velocity_limit.py:45-69) and the collision pair filter
+ * (limits/collision_avoidance_limit.py:75-115). */
 int32_t mkh_model_create(const MkhFlatModel *host_model, int32_t device, MkhModel **out);
 void mkh_model_destroy(MkhModel *model);
 
-/* Snapshot the Task/Limit plugin objects of one solve_ik call site into a device descriptor. */
+/* Snapshot the Task/Limit plugin objects of one solve_ik call site (the `tasks` and `limits` arguments of
+ * mink/solve_ik.py:68-77; constructor state of tasks/frame_task.py:29-46, relative_frame_task.py:28-52,
+ * posture_task.py:29-52, com_task.py:25-35 and of the three limits) into a device descriptor. */
 int32_t mkh_problem_create(MkhModel *model, const MkhProblemDesc *desc, int32_t max_batch, MkhProblem **out);
 void mkh_problem_destroy(MkhProblem *problem);
 int32_t mkh_problem_num_task_rows(const MkhProblem *problem);
