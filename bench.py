@@ -38,6 +38,7 @@ def issued_flop_per_solve(kernel: str) -> int:
     return int((43 + 13.4 + 18) * nt * 64 * 2)
 
 
+HBM_PEAK_GBS = 8000.0                                   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6                          # MI355X fp64 vector peak (same guide, chip table)
 
 
