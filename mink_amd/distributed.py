@@ -27,11 +27,12 @@ def shard(array, world_size: int, rank: int):
     return array[lo:hi]
 
 
-def gather_rows(local, total_rows: int, dst: int = 0, group=None):
+def gather_rows(local, total_rows: int, dst: int = 0, group=None, out=None):
     """Gather row-sharded tensors (shards from `shard_bounds`) to rank `dst`.
 
-    Returns the (total_rows, ...) tensor on `dst`, None elsewhere.  Uneven shards are padded to the
-    largest shard for the collective and trimmed afterwards (RCCL gather wants equal counts).
+    Returns the (total_rows, ...) tensor on `dst`, None elsewhere.  With even shards the collective writes
+    straight into row blocks of the result (`out`, if given, is reused: no allocation, no concatenation);
+    uneven shards are padded to the largest shard and trimmed afterwards (RCCL gather wants equal counts).
     """
     import torch
     import torch.distributed as dist
@@ -40,6 +41,15 @@ def gather_rows(local, total_rows: int, dst: int = 0, group=None):
     rank = dist.get_rank(group)
     sizes = [shard_bounds(total_rows, world, r) for r in range(world)]
     max_rows = max(hi - lo for lo, hi in sizes)
+    even = all(hi - lo == max_rows for lo, hi in sizes)
+    if even:
+        bufs = None
+        if rank == dst:
+            if out is None:
+                out = torch.empty((total_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            bufs = [out[lo:hi] for lo, hi in sizes]           # contiguous row blocks of the result
+        dist.gather(local.contiguous(), bufs, dst=dst, group=group)
+        return out if rank == dst else None
     pad = local
     if local.shape[0] < max_rows:
         pad = torch.zeros((max_rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
