@@ -17,7 +17,7 @@ def _oracle_v(model_name, q, tasks, limits, dt, damping):
     return oik.solve_ik(oc.model(model_name), q, tasks, dt, damping, limits)
 
 
-@pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 2049, 5000])
+@pytest.mark.parametrize("B", [1, 2, 63, 64, 65, 2048, 2049, 5000, 16385])
 def test_ragged_batch_sizes(B):
     """grid-stride loop tails: every batch size gives the same per-row answers as B = 1."""
     m = workloads.load_robot("ur5e")
@@ -34,6 +34,12 @@ def test_ragged_batch_sizes(B):
     for i in {0, B // 2, B - 1}:
         v1, _ = one.solve(q[i:i + 1], tg[i:i + 1], home[None, :], None, 2e-3, 1e-3)
         np.testing.assert_array_equal(v1[0], v[i])
+    if B > 2:
+        # every row: the same batch cut at an odd place (different grid / XCD slices) gives bitwise the same rows
+        h = B // 3 + 1
+        va, _ = prob.solve(q[:h], tg[:h], home[None, :], None, 2e-3, 1e-3)
+        vb, _ = prob.solve(q[h:], tg[h:], home[None, :], None, 2e-3, 1e-3)
+        np.testing.assert_array_equal(np.concatenate([va, vb]), v)
 
 
 def test_default_damping_single_frame_task_vs_oracle():
