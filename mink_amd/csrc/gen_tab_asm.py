@@ -13,10 +13,10 @@ register numbers:
     publish(lds_addr)         lds[i] = T[i]         (caller masks exec to the owning lane)
     get<I>() / set<I>(x)      single element, compile-time index (tableau build, taps)
 
-Register map for NT rows (wave64, 2 waves/SIMD ⇒ 256 VGPRs per lane):
-    v[256-2·NT, 256)              tableau column (NT doubles)
-    v[256-2·NT-S, 256-2·NT)       LDS staging for rank1 (S = 32: 8 × 128 bit in flight; S = 16 for NT ≥ 56)
-    v[0, 256-2·NT-S)              everything the compiler allocates
+Register map for NT rows (wave64; TOP = 256 VGPRs per lane at 2 waves/SIMD, 168 at 3 (NT ≤ 24), 128 at 4 (NT ≤ 8)):
+    v[TOP-2·NT, TOP)              tableau column (NT doubles)
+    v[TOP-2·NT-S, TOP-2·NT)       LDS staging for rank1 (S = 32: 8 × 128 bit in flight; S = 16 for NT ≥ 56 or ≤ 24)
+    v[0, TOP-2·NT-S)              everything the compiler allocates
 
 The staging range must stay ABOVE the compiler's cap even though half of it is only live inside one asm
 statement: the VGPRs hipcc reserves for SGPR spills are the highest ones below the cap, reserved
@@ -28,17 +28,21 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 NTS = (8, 16, 24, 32, 40, 44, 48, 56, 62, 64)
-TOTAL = 256
+def total_for(nt):
+    # VGPRs per lane = 512 / resident waves per SIMD: small tableaus leave room for 4 (NT ≤ 8) or 3 (NT ≤ 24)
+    # waves per SIMD instead of 2 — more waves hide more of the serial pivot chain (UR5e-class arms)
+    return 128 if nt <= 8 else (168 if nt <= 24 else 256)
 NRS = (16, 24, 32, 44, 48)   # dof-row counts of the low-rank start (kernel variants MKH_NR)
 def ntmp_for(nt):
     # staging registers: 8 x b128 in flight, or 4 for the widest tableaus (the compiler needs the
     # 16 registers more than the rank-1 update needs the deeper pipeline: measured on G1)
-    return 16 if nt >= 56 else 32
+    return 16 if (nt >= 56 or nt <= 24) else 32
 NPRE = 4   # loads issued by rank1_prefetch (their 16 registers are off limits to the compiler)
 
 
 def gen(nt: int) -> str:
     NTMP = ntmp_for(nt)
+    TOTAL = total_for(nt)
     t0 = TOTAL - 2 * nt
     tmp0 = t0 - NTMP
     budget = tmp0

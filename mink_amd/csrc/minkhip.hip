@@ -71,6 +71,9 @@ struct MkhProblem {
   int max_batch = 0;
   int lds_bytes = 0;
   int blocks_per_cu = 1;
+  // feature-rich variants (taps / ComTask / collisions / RelativeFrameTask) need the compiler's full VGPR
+  // budget: they never use the high-occupancy register maps of NT ≤ 24 (ik_kernel.h MKH_WAVES)
+  int nt_full = 8, lds_bytes_full = 0;
   bool has_relative = false;
   // low-rank ("Woodbury") start of the QP (ik_kernel.h F_WOOD): compiled (NT, NR) pair or 0 when the
   // problem does not qualify; lower bound of the diagonal part of H without the damping argument, and
@@ -97,6 +100,15 @@ struct MkhProblem {
 namespace mkh {
 int launch_variant(int nt, int nr, int feat, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
                    const SolveArgs& a, const TapArgs* taps);
+}
+
+// Resident wavefronts per CU of a kernel variant: bounded by LDS (160 KiB/CU) and by the register map the
+// variant was built for (4 waves/SIMD for NT ≤ 8, 3 for NT ≤ 24, else 2 — ik_kernel.h MKH_WAVES).
+static int waves_per_cu(int nt, int lds_bytes) {
+  const int by_lds = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
+  const int by_regs = 4 * (nt <= 8 ? 4 : (nt <= 24 ? 3 : 2));
+  const int w = by_lds < by_regs ? by_lds : by_regs;
+  return w < 1 ? 1 : w;
 }
 
 template <class T>
@@ -436,9 +448,10 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   const LdsLayout L = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, p->nt);
   p->lds_bytes = L.total * (int)sizeof(double);
   if (p->lds_bytes > 64 * 1024) return bail(fail(MKH_E_LIMIT, "problem needs %d bytes of LDS per wavefront (> 64 KiB)", p->lds_bytes));
-  // resident waves per CU: bounded by LDS (160 KiB/CU) and by VGPRs (launch_bounds: 2 waves/SIMD)
-  int by_lds = (160 * 1024) / (p->lds_bytes > 0 ? p->lds_bytes : 1);
-  p->blocks_per_cu = by_lds < 8 ? by_lds : 8;
+  p->blocks_per_cu = waves_per_cu(p->nt, p->lds_bytes);
+  p->nt_full = p->nt < 32 ? 32 : p->nt;
+  p->lds_bytes_full = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, p->nt_full).total *
+                      (int)sizeof(double);
   if (p->blocks_per_cu < 1) p->blocks_per_cu = 1;
   // ---- low-rank start eligibility: box limits only, frame tasks only, few task rows relative to nv
   if (P.n_jrows > 0 && P.n_pairs == 0 && P.n_com == 0 && !p->has_relative && 2 * P.n_jrows <= m->nv &&
@@ -511,6 +524,10 @@ static int grid_for(const MkhProblem* p, int B) {
   int g = p->model->num_cus * p->blocks_per_cu;
   return B < g ? B : g;
 }
+static int grid_for_variant(const MkhProblem* p, int B, int nt, int lds) {
+  int g = p->model->num_cus * waves_per_cu(nt, lds);
+  return B < g ? B : g;
+}
 
 int32_t mkh_problem_launch_info(const MkhProblem* p, int32_t B, int32_t* grid, int32_t* block, int32_t* lds_bytes,
                                 int32_t* tableau_rows) {
@@ -529,7 +546,6 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
     HIP_OK(hipStreamSynchronize(stream));   // taps are a debug path: keep the host struct's lifetime simple
     dtaps = p->d_taps;
   }
-  const int grid = grid_for(p, a.B);
   // lean production variant unless the call needs a feature it leaves out
   int need = 0;
   if (taps) need |= F_TAPS;
@@ -538,7 +554,8 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   if (p->dev.n_pairs > 0) need |= F_COLL;
   if (a.n_steps > 1 || a.q_out) need |= F_STEPS;
   int feat = (need == 0) ? 0 : ((need == F_STEPS) ? F_STEPS : ((need & F_TAPS) ? F_ALL : (F_ALL & ~F_TAPS)));
-  int nt = p->nt, nr = 0, lds = p->lds_bytes;
+  const bool rich = (feat & (F_ALL & ~F_STEPS)) != 0;
+  int nt = rich ? p->nt_full : p->nt, nr = 0, lds = rich ? p->lds_bytes_full : p->lds_bytes;
   // Low-rank start when the problem qualifies and the diagonal part of H is not tiny against JwᵀJw
   // (error amplification of the quasi-definite elimination ≈ eps·max cost²/min Dg ≤ 1e-9).
   const double dg_min = a.damping + p->wood_min_diag;
@@ -551,6 +568,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
     nt = p->wood_nt; nr = p->wood_nr; lds = p->wood_lds_bytes;
     feat = F_WOOD | (need & (F_STEPS | F_TAPS));
   }
+  const int grid = grid_for_variant(p, a.B, nt, lds);
   snprintf(p->last_kernel, sizeof(p->last_kernel), nr ? "ik_solve_kernel_%d_%d_r%d" : "ik_solve_kernel_%d_%d", nt, feat, nr);
   if (mkh::launch_variant(nt, nr, feat, grid, lds, stream, p->d_dev, a, dtaps) != 0)
     return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
