@@ -117,6 +117,14 @@ def gen(nt: int) -> str:
     out.append('                 : "=&v"(lo), "=&v"(hi) : "s"(idx) : "m0");')
     out.append("    return __hiloint2double(hi, lo);")
     out.append("  }")
+    # whole-column load from LDS (per-lane address)
+    lines = [f"ds_read_b128 v[{t0 + 4 * k}:{t0 + 4 * k + 3}], %0 offset:{16 * k}" for k in range(nt // 2)]
+    lines.append("s_waitcnt lgkmcnt(0)")
+    body = "\\n\\t".join(lines)
+    out.append("  // T[i] = lds[i] for every row (per-lane address: a half-space row's column A[s][:])")
+    out.append("  __device__ static __forceinline__ void load_all(unsigned lds_addr) {")
+    out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_t}, "memory");')
+    out.append("  }")
     # runtime row write (VGPR index mode on the destination)
     out.append("  // T[k] = x for a wave-uniform runtime k (lanes masked off by exec keep their value).")
     out.append("  __device__ static __forceinline__ void set_dyn(int k, double x) {")

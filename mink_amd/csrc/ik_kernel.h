@@ -988,19 +988,11 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     }
     if (!A.do_qp) break;
     if (kColl && nrows > 0) {
-      // rows nv+s of the dof columns (static register index, runtime LDS address) ...
-      static_for<NT>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        if (i >= nv && i < nv + nrows) Tab<NT>::template set<i>(is_dof ? sA[(i - nv) * 64 + lane] : 0.0);
-      });
-      // ... and column nv+s (owned by lane nv+s) = A[s][:]
-      if (lane >= nv && lane < nv + nrows) {
-        const double* o = sA + (lane - nv) * 64;
-        static_for<NT>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          if (i < nv) Tab<NT>::template set<i>(o[i]);
-        });
-      }
+      // rows nv+s of the dof columns: one indexed register write per active row (a static_for over all NT
+      // rows with a runtime range test cost 860 VALU instructions and 278 spilled SGPRs) ...
+      for (int sr = 0; sr < nrows; ++sr) Tab<NT>::set_dyn(nv + sr, is_dof ? sA[sr * 64 + lane] : 0.0);
+      // ... and column nv+s (owned by lane nv+s) = A[s][:]  (entries ≥ nv of the staged row are zero)
+      if (lane >= nv && lane < nv + nrows) Tab<NT>::load_all(lds_addr(sA + (lane - nv) * 64));
     }
 
     // ====================================================================== QP
