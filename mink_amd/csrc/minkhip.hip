@@ -553,7 +553,12 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   if (p->dev.n_com > 0) need |= F_COM;
   if (p->dev.n_pairs > 0) need |= F_COLL;
   if (a.n_steps > 1 || a.q_out) need |= F_STEPS;
-  int feat = (need == 0) ? 0 : ((need == F_STEPS) ? F_STEPS : ((need == F_COLL) ? F_COLL : ((need & F_TAPS) ? F_ALL : (F_ALL & ~F_TAPS))));
+  int feat;
+  if (need == 0) feat = 0;
+  else if (need == F_STEPS) feat = F_STEPS;
+  else if (need == F_COLL) feat = F_COLL;
+  else if ((need & ~(F_REL | F_COM)) == 0) feat = F_REL | F_COM;      // box limits only: keeps the block-pivoting active set
+  else feat = (need & F_TAPS) ? F_ALL : (F_ALL & ~F_TAPS);
   const bool rich = (feat & (F_ALL & ~F_STEPS)) != 0;
   int nt = rich ? p->nt_full : p->nt, nr = 0, lds = rich ? p->lds_bytes_full : p->lds_bytes;
   // Low-rank start when the problem qualifies and the diagonal part of H is not tiny against JwᵀJw
