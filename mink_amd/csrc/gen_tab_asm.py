@@ -117,6 +117,15 @@ def gen(nt: int) -> str:
     out.append('                 : "=&v"(lo), "=&v"(hi) : "s"(idx) : "m0");')
     out.append("    return __hiloint2double(hi, lo);")
     out.append("  }")
+    # leading rows of a column from LDS (per-lane address): T[i] = lds[i], i < n
+    for n in sorted(set([r for r in NRS if r < nt])):
+        lines = [f"ds_read_b128 v[{t0 + 4 * k}:{t0 + 4 * k + 3}], %0 offset:{16 * k}" for k in range(n // 2)]
+        lines.append("s_waitcnt lgkmcnt(0)")
+        body = "\\n\\t".join(lines)
+        out.append(f"  // T[i] = lds[i], i < {n}")
+        out.append(f"  __device__ static __forceinline__ void load_lo_{n}(unsigned lds_addr) {{")
+        out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_t}, "memory");')
+        out.append("  }")
     # whole-column load from LDS (per-lane address)
     lines = [f"ds_read_b128 v[{t0 + 4 * k}:{t0 + 4 * k + 3}], %0 offset:{16 * k}" for k in range(nt // 2)]
     lines.append("s_waitcnt lgkmcnt(0)")

@@ -35,6 +35,12 @@ namespace mkh {
 constexpr int kNumXcd = 8;   // MI355X: 8 XCDs × 32 CUs, one L2 each
 
 // ------------------------------------------------------------------ LDS layout
+// Row stride of the staged half-space rows A[s][:]: the smallest column-load size ≥ nv (tab_asm.inc load_lo_*),
+// not the wave width — 40 rows × 64 doubles were 20 KB of Shadow's 37 KB and cost it a third of its occupancy.
+__host__ __device__ inline int a_stride_for(int nv) {
+  return nv <= 16 ? 16 : (nv <= 24 ? 24 : (nv <= 32 ? 32 : (nv <= 44 ? 44 : (nv <= 48 ? 48 : 64))));
+}
+
 struct LdsLayout {
   int q, X, jnt, tgt, task, J, dof, com, col, A, piv, S, total;  // offsets in doubles
 };
@@ -55,7 +61,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
   L.dof = o;  o += lds_even(nv * 10);
   L.com = o;  o += (n_com > 0 ? nbody * 4 : 0);
   L.col = o;  o += max_rows * 16;
-  L.A = o;    o += max_rows * kWave;
+  L.A = o;    o += max_rows * a_stride_for(nv);       // half-space rows A[s][0..stride)
   L.piv = o;  o += kWave + 8;      // pivot column broadcast buffer + 8 scalar slots of the pivot lane
   L.S = o;    o += lds_even(s_doubles);   // low-rank start: columns of −Jh·Jhᵀ + right-hand sides
   L.total = o;
@@ -149,6 +155,17 @@ __device__ __forceinline__ void rank1_rows(unsigned addr, double g) {
   else if constexpr (ROWS == 44) Tab<NT>::rank1_body_44(addr, g);
   else if constexpr (ROWS == 48) Tab<NT>::rank1_body_48(addr, g);
 }
+// T[i] = lds[i] for i < n (n from a_stride_for: wave-uniform, one of the generated sizes)
+template <int NT>
+__device__ __forceinline__ void load_leading_rows(unsigned addr, int n) {
+  if (n >= NT) { Tab<NT>::load_all(addr); return; }
+  if constexpr (NT > 16) { if (n == 16) Tab<NT>::load_lo_16(addr); }
+  if constexpr (NT > 24) { if (n == 24) Tab<NT>::load_lo_24(addr); }
+  if constexpr (NT > 32) { if (n == 32) Tab<NT>::load_lo_32(addr); }
+  if constexpr (NT > 44) { if (n == 44) Tab<NT>::load_lo_44(addr); }
+  if constexpr (NT > 48) { if (n == 48) Tab<NT>::load_lo_48(addr); }
+}
+
 template <int NT, int ROWS>
 __device__ __forceinline__ void load_hi_rows(unsigned addr) {
   if constexpr (ROWS == 16 && NT > 16) Tab<NT>::load_hi_16(addr);
@@ -252,6 +269,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   double* const sCom = smem + L.com;
   double* const sCol = smem + L.col;
   double* const sA = smem + L.A;
+  const int AS = a_stride_for(nv);                     // row stride of sA
   double* const sPiv = smem + L.piv;
   const double kInf = __builtin_huge_val();
 
@@ -966,7 +984,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           a = -dot(n, dj);
           if (MKH_TAP(t_coll_G)) MKH_TAP(t_coll_G)[((size_t)pb * P.n_pairs + (int)o[12]) * nv + lane] = a;
         }
-        sA[s * 64 + lane] = a;
+        if (lane < AS) sA[s * AS + lane] = a;
       }
     }
     wave_sync();
@@ -990,9 +1008,12 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     if (kColl && nrows > 0) {
       // rows nv+s of the dof columns: one indexed register write per active row (a static_for over all NT
       // rows with a runtime range test cost 860 VALU instructions and 278 spilled SGPRs) ...
-      for (int sr = 0; sr < nrows; ++sr) Tab<NT>::set_dyn(nv + sr, is_dof ? sA[sr * 64 + lane] : 0.0);
+      for (int sr = 0; sr < nrows; ++sr) Tab<NT>::set_dyn(nv + sr, is_dof ? sA[sr * AS + lane] : 0.0);
       // ... and column nv+s (owned by lane nv+s) = A[s][:]  (entries ≥ nv of the staged row are zero)
-      if (lane >= nv && lane < nv + nrows) Tab<NT>::load_all(lds_addr(sA + (lane - nv) * 64));
+      if (lane >= nv && lane < nv + nrows) {
+        const unsigned addr = lds_addr(sA + (lane - nv) * AS);
+        load_leading_rows<NT>(addr, AS);                     // (rows ≥ AS keep the zeros of Tab::zero())
+      }
     }
 
     // ====================================================================== QP
@@ -1017,7 +1038,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     } else if (kRows && lane < nv + nrows) {
       s.sel = 2; s.lo = 0.0;
       s.x = -sCol[(lane - nv) * 16 + 9];                      // w = A·0 − h
-      const double* o = sA + (lane - nv) * 64;
+      const double* o = sA + (lane - nv) * AS;
       double nn = 0.0;
       for (int i = 0; i < nv; ++i) nn += o[i] * o[i];
       rown = sqrt(nn);
