@@ -41,6 +41,9 @@ __host__ __device__ inline int a_stride_for(int nv) {
   return nv <= 16 ? 16 : (nv <= 24 ? 24 : (nv <= 32 ? 32 : (nv <= 44 ? 44 : (nv <= 48 ? 48 : 64))));
 }
 
+// Row stride of the staged Jacobian rows of the direct start: only the dof rows are read (rank1_leading_rows)
+__host__ __device__ inline int j_stride_direct(int nv, int nt) { const int a = a_stride_for(nv); return a < nt ? a : nt; }
+
 struct LdsLayout {
   int q, X, jnt, tgt, task, J, dof, com, col, A, piv, S, total;  // offsets in doubles
 };
@@ -270,7 +273,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   int lane = lane_id();     // (re-laundered at every phase boundary, see MKH_TICK)
   const int nq = P0.nq, nv = P0.nv, nbody = P0.nbody;
   const LdsLayout L = lds_layout(nq, nv, nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows,
-                                 kWood ? NT - NR + 1 : 6, kWood ? NR : NT,
+                                 kWood ? NT - NR + 1 : 6, kWood ? NR : j_stride_direct(nv, NT),
                                  (kWood && !wood_s_aliases_dof(nv, P0.n_jrows, NT - NR)) ? P0.n_jrows * (NT - NR + 1) : 0);
   double* const sq = smem + L.q;
   double* const sX = smem + L.X;
@@ -283,6 +286,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   double* const sCol = smem + L.col;
   double* const sA = smem + L.A;
   const int AS = a_stride_for(nv);                     // row stride of sA
+  const int JS = j_stride_direct(nv, NT);              // row stride of sJ (direct start)
   double* const sPiv = smem + L.piv;
   const double kInf = __builtin_huge_val();
 
@@ -836,12 +840,12 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         hdiag += Jw[r] * Jw[r];
       }
       wave_sync();                                             // previous task's rows are consumed
-      if (lane < NT) {
-        double* o = sJ + lane;                                 // compact rows of this task: sJ[c][0..NT)
+      if (lane < JS) {
+        double* o = sJ + lane;                                 // compact rows of this task: sJ[c][0..JS)
         int c = 0;
 #pragma unroll
         for (int r = 0; r < 6; ++r)
-          if ((rowmask >> r) & 1) { o[c * NT] = is_dof ? Jw[r] : 0.0; ++c; }
+          if ((rowmask >> r) & 1) { o[c * JS] = is_dof ? Jw[r] : 0.0; ++c; }
       }
       wave_sync();
       // H[:, lane] += Σ_r Jw_r · Jw_r[lane]: one rank-1 update per staged (nonzero-cost) row
@@ -849,7 +853,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         int c = 0;
 #pragma unroll
         for (int r = 0; r < 6; ++r)
-          if ((rowmask >> r) & 1) { rank1_leading_rows<NT>(lds_addr(sJ + c * NT), is_dof ? Jw[r] : 0.0, AS); ++c; }
+          if ((rowmask >> r) & 1) { rank1_leading_rows<NT>(lds_addr(sJ + c * JS), is_dof ? Jw[r] : 0.0, AS); ++c; }
       }
     }
     MKH_MARK("jcols_done");

@@ -445,12 +445,12 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   P.vel_limit = p->d_vel; P.pairs = p->d_pairs;
 
   P.nt = p->nt;
-  const LdsLayout L = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, p->nt);
+  const LdsLayout L = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, j_stride_direct(P.nv, p->nt));
   p->lds_bytes = L.total * (int)sizeof(double);
   if (p->lds_bytes > 64 * 1024) return bail(fail(MKH_E_LIMIT, "problem needs %d bytes of LDS per wavefront (> 64 KiB)", p->lds_bytes));
   p->blocks_per_cu = waves_per_cu(p->nt, p->lds_bytes);
   p->nt_full = p->nt < 32 ? 32 : p->nt;
-  p->lds_bytes_full = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, p->nt_full).total *
+  p->lds_bytes_full = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, j_stride_direct(P.nv, p->nt_full)).total *
                       (int)sizeof(double);
   if (p->blocks_per_cu < 1) p->blocks_per_cu = 1;
   // ---- low-rank start eligibility: box limits only, frame tasks only, few task rows relative to nv
