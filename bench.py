@@ -147,6 +147,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Test hook for boxes with fewer GPUs than ranks (the N > 1 control flow can then be exercised on ONE GPU:
+    # `MKH_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`): every rank
+    # uses device 0 and the process group runs on gloo, because RCCL refuses two ranks on one device.
+    share_gpu = os.environ.get("MKH_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
@@ -156,7 +162,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     B = args.batch
     model = workloads.load_robot("g1")
@@ -203,7 +212,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in kern_events) / args.steps   # average launch duration of ik_solve_kernel
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
