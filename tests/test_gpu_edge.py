@@ -115,3 +115,36 @@ def test_argument_validation():
         nat.NativeProblem(nm, collision_limits=[{"geom_id_pairs": [[m.name2id("geom", "wrist_3_link"), m.name2id("geom", "wall")]],
                                                  "gain": 0.85, "minimum_distance_from_collisions": 0.005,
                                                  "collision_detection_distance": 0.01, "bound_relaxation": 0.0}])
+
+
+def test_low_rank_start_conditioning_gate():
+    """The low-rank QP start is only used when damping + posture diagonal is not tiny against the task costs
+    (DESIGN.md §4.2); below the gate the same handle launches the direct start.  Both agree with the C oracle
+    to what the conditioning allows."""
+    import native_configs as nc
+    import oracle_configs as occ
+    from oracle import cport
+    m = workloads.load_robot("g1")
+    nm = nat.NativeModel(m)
+    B = 256
+    prob, dt, _ = nc.build("g1_c3", nm, B)
+    stand = m.key_qpos[0]
+    q, tg = workloads.make_batch(m, nm, prob, np.random.default_rng(9), B, base_q=stand)
+    # (the floating base carries no posture term: its diagonal is the damping alone; gate at 1e-7·200² = 4e-3)
+    for damping, expect_low_rank, tol in ((1e-1, True, 1e-8), (1e-2, True, 1e-8), (1e-3, False, 1e-8)):
+        v, st = prob.solve(q, tg, stand[None, :], None, dt, damping)
+        assert ("_r44" in prob.last_kernel()) == expect_low_rank, (damping, prob.last_kernel())
+        mm, tasks, limits, dt_o, _ = occ.g1_c3(tg[0], stand)
+        v_ref, _ = cport.CProblem(mm, tasks, limits).solve_batch(q, tg, stand[None, :], dt, damping)
+        err = np.abs(v - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
+        assert (st == 0).all() and err.max() < tol, (damping, err.max())
+    # posture cost 1e-3 and damping 1e-9: Dg ≈ 1e-6 < 1e-7·200² ⇒ direct start
+    weak = nat.NativeProblem(nm, frame_tasks=[{"frame_type": "site", "frame_id": m.name2id("site", "left_palm"),
+                                               "cost": [200.0] * 3 + [0.0] * 3, "lm_damping": 0.0}],
+                             posture_tasks=[{"cost": 1e-3}], max_batch=B)
+    v, st = weak.solve(q, tg[:, 2:3], stand[None, :], None, dt, 1e-9)
+    assert "_r" not in weak.last_kernel(), weak.last_kernel()
+    assert (st == 0).all() and np.isfinite(v).all()
+    v2, st2 = weak.solve(q, tg[:, 2:3], stand[None, :], None, dt, 1e-1)       # same handle, larger damping
+    assert "_r44" in weak.last_kernel(), weak.last_kernel()
+    assert (st2 == 0).all()
