@@ -196,6 +196,12 @@ def main():
         if do_gather:
             gather_rows(v, world * B, dst=0, out=v_all)   # RCCL gather of v to rank 0 (tests/test_distributed_cpu.py)
 
+    # Python's cyclic GC must not run inside the timed region: with torch loaded a generation-2 collection
+    # pauses the host for tens of ms — longer than the whole queue of launches takes to drain — and the GPU
+    # idles (measured: always at the 23rd timed step, a 10-40 ms gap that cost 20 % at --steps 30).
+    import gc
+    gc.collect()
+    gc.disable()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -210,7 +216,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     kern_ms = sum(a.elapsed_time(b) for a, b in kern_events) / args.steps   # average launch duration of ik_solve_kernel
+    if os.environ.get("MKH_BENCH_DEBUG"):
+        print("kernel ms per step:", [round(a.elapsed_time(b), 3) for a, b in kern_events], file=sys.stderr)
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -54,7 +54,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
   LdsLayout L;
   int o = 0;
   L.q = o;    o += lds_even(nq);
-  L.X = o;    o += nbody * 8;
+  L.X = o;    o += 7 * lds_even(nbody);              // body poses, component-major: X[c][body] (c = x y z qw qx qy qz)
   L.jnt = o;  o += lds_even(njnt * 6);
   L.tgt = o;  o += lds_even(n_frame * 7 + n_com * 3);
   L.task = o; o += n_frame * 64;
@@ -277,6 +277,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
                                  (kWood && !wood_s_aliases_dof(nv, P0.n_jrows, NT - NR)) ? P0.n_jrows * (NT - NR + 1) : 0);
   double* const sq = smem + L.q;
   double* const sX = smem + L.X;
+  const int XS = lds_even(nbody);                      // component stride of sX (consecutive lanes hit consecutive banks;
+                                                       // body-major with stride 8 put 16 lanes on each bank)
   double* const sJnt = smem + L.jnt;
   double* const sTgt = smem + L.tgt;
   double* const sTask = smem + L.task;
@@ -390,14 +392,14 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     for (int r = 0; r < P.nrounds; ++r) {
       wave_sync();
       if (is_body) {
-        double* o = sX + lane * 8;
-        o[0] = xp.x; o[1] = xp.y; o[2] = xp.z; o[3] = xq.w; o[4] = xq.x; o[5] = xq.y; o[6] = xq.z;
+        double* o = sX + lane;
+        o[0] = xp.x; o[XS] = xp.y; o[2 * XS] = xp.z; o[3 * XS] = xq.w; o[4 * XS] = xq.x; o[5 * XS] = xq.y; o[6 * XS] = xq.z;
       }
       wave_sync();
       if (is_body) {
-        const double* a = sX + P.body_i[(BI_ANC0 + r) * 64 + ol] * 8;
-        V3 ap{a[0], a[1], a[2]};
-        Q4 aq{a[3], a[4], a[5], a[6]};
+        const double* a = sX + P.body_i[(BI_ANC0 + r) * 64 + ol];
+        V3 ap{a[0], a[XS], a[2 * XS]};
+        Q4 aq{a[3 * XS], a[4 * XS], a[5 * XS], a[6 * XS]};
         xp = ap + qrot(aq, xp);
         xq = qmul(aq, xq);
       }
@@ -405,8 +407,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     xq = qnormalize(xq);
     wave_sync();
     if (is_body) {
-      double* o = sX + lane * 8;
-      o[0] = xp.x; o[1] = xp.y; o[2] = xp.z; o[3] = xq.w; o[4] = xq.x; o[5] = xq.y; o[6] = xq.z;
+      double* o = sX + lane;
+      o[0] = xp.x; o[XS] = xp.y; o[2 * XS] = xp.z; o[3 * XS] = xq.w; o[4 * XS] = xq.x; o[5 * XS] = xq.y; o[6 * XS] = xq.z;
       if (MKH_TAP(t_xpos)) {
         double* t = MKH_TAP(t_xpos) + ((size_t)pb * nbody + lane) * 3;
         t[0] = xp.x; t[1] = xp.y; t[2] = xp.z;
@@ -432,11 +434,11 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         o[0] = ax.x; o[1] = ax.y; o[2] = ax.z; o[3] = an.x; o[4] = an.y; o[5] = an.z;
       } else {
         // several joints in one body: replay them from the parent's world pose.
-        const double* a = sX + P.body_i[BI_PARENT * 64 + ol] * 8;
+        const double* a = sX + P.body_i[BI_PARENT * 64 + ol];
         const double* bf = P.body_f + ol;
-        V3 fp = V3{a[0], a[1], a[2]} + qrot(Q4{a[3], a[4], a[5], a[6]},
+        V3 fp = V3{a[0], a[XS], a[2 * XS]} + qrot(Q4{a[3 * XS], a[4 * XS], a[5 * XS], a[6 * XS]},
                                             V3{bf[(BF_POS + 0) * 64], bf[(BF_POS + 1) * 64], bf[(BF_POS + 2) * 64]});
-        Q4 fq = qmul(Q4{a[3], a[4], a[5], a[6]}, Q4{bf[(BF_QUAT + 0) * 64], bf[(BF_QUAT + 1) * 64],
+        Q4 fq = qmul(Q4{a[3 * XS], a[4 * XS], a[5 * XS], a[6 * XS]}, Q4{bf[(BF_QUAT + 0) * 64], bf[(BF_QUAT + 1) * 64],
                                                     bf[(BF_QUAT + 2) * 64], bf[(BF_QUAT + 3) * 64]});
         for (int jn = 0; jn < b_jnum; ++jn) {
           const int j = b_jadr + jn;
@@ -486,12 +488,12 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       } else if (d_kind == DOF_FREE_LIN) {
         d_lin = {d_k == 0 ? 1.0 : 0.0, d_k == 1 ? 1.0 : 0.0, d_k == 2 ? 1.0 : 0.0};
       } else {  // ball / free rotational dof: body-frame axis k, about the joint anchor
-        const double* xb = sX + d_body * 8;
-        M3 R = qmat(Q4{xb[3], xb[4], xb[5], xb[6]});
+        const double* xb = sX + d_body;
+        M3 R = qmat(Q4{xb[3 * XS], xb[4 * XS], xb[5 * XS], xb[6 * XS]});
         d_ang = (d_k == 0) ? V3{R.m[0], R.m[3], R.m[6]}
                            : ((d_k == 1) ? V3{R.m[1], R.m[4], R.m[7]} : V3{R.m[2], R.m[5], R.m[8]});
         if (d_kind == DOF_FREE_ANG) {
-          d_anchor = {xb[0], xb[1], xb[2]};
+          d_anchor = {xb[0], xb[XS], xb[2 * XS]};
         } else {
           const double* o = sJnt + d_jnt * 6;
           d_anchor = {o[3], o[4], o[5]};
@@ -566,10 +568,10 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     double mu_lane = 0.0;  // Levenberg–Marquardt term of the task owned by this lane
     if (lane < P.n_frame) {
       const FrameTaskDev& ft = P.frame[lane];
-      const double* xb = sX + ft.body * 8;
+      const double* xb = sX + ft.body;
       SE3 F;
-      Q4 bq{xb[3], xb[4], xb[5], xb[6]};
-      F.p = V3{xb[0], xb[1], xb[2]} + qrot(bq, V3{ft.lpos[0], ft.lpos[1], ft.lpos[2]});
+      Q4 bq{xb[3 * XS], xb[4 * XS], xb[5 * XS], xb[6 * XS]};
+      F.p = V3{xb[0], xb[XS], xb[2 * XS]} + qrot(bq, V3{ft.lpos[0], ft.lpos[1], ft.lpos[2]});
       F.q = qmul(bq, Q4{ft.lquat[0], ft.lquat[1], ft.lquat[2], ft.lquat[3]});
       const double* tg = sTgt + lane * 7;
       SE3 Tt{Q4{tg[0], tg[1], tg[2], tg[3]}, V3{tg[4], tg[5], tg[6]}};
@@ -585,10 +587,10 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       } else {
         // RelativeFrameTask (relative_frame_task.py:106-142): T_fr = T_root⁻¹·T_frame,
         // e = T_fr.rminus(target) = log(target⁻¹·T_fr),  J = jlog(T_tf)·(ᶠJ − Ad(T_fr⁻¹)·ʳJ)
-        const double* xr = sX + ft.root_body * 8;
-        Q4 rq0{xr[3], xr[4], xr[5], xr[6]};
+        const double* xr = sX + ft.root_body;
+        Q4 rq0{xr[3 * XS], xr[4 * XS], xr[5 * XS], xr[6 * XS]};
         SE3 Rt;
-        Rt.p = V3{xr[0], xr[1], xr[2]} + qrot(rq0, V3{ft.root_lpos[0], ft.root_lpos[1], ft.root_lpos[2]});
+        Rt.p = V3{xr[0], xr[XS], xr[2 * XS]} + qrot(rq0, V3{ft.root_lpos[0], ft.root_lpos[1], ft.root_lpos[2]});
         Rt.q = qmul(rq0, Q4{ft.root_lquat[0], ft.root_lquat[1], ft.root_lquat[2], ft.root_lquat[3]});
         const SE3 Tfr = se3_mul(se3_inv(Rt), F);
         se3_log(se3_mul(se3_inv(Tt), Tfr), ev, ew);
@@ -952,11 +954,11 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         uint64_t m1 = 0, m2 = 0;
         if (pi < P.n_pairs) {
           const CollisionPairDev& cp = P.pairs[pi];
-          const double* x1 = sX + cp.body1 * 8;
-          const double* x2 = sX + cp.body2 * 8;
-          Q4 bq1{x1[3], x1[4], x1[5], x1[6]}, bq2{x2[3], x2[4], x2[5], x2[6]};
-          V3 gp1 = V3{x1[0], x1[1], x1[2]} + qrot(bq1, V3{cp.lpos1[0], cp.lpos1[1], cp.lpos1[2]});
-          V3 gp2 = V3{x2[0], x2[1], x2[2]} + qrot(bq2, V3{cp.lpos2[0], cp.lpos2[1], cp.lpos2[2]});
+          const double* x1 = sX + cp.body1;
+          const double* x2 = sX + cp.body2;
+          Q4 bq1{x1[3 * XS], x1[4 * XS], x1[5 * XS], x1[6 * XS]}, bq2{x2[3 * XS], x2[4 * XS], x2[5 * XS], x2[6 * XS]};
+          V3 gp1 = V3{x1[0], x1[XS], x1[2 * XS]} + qrot(bq1, V3{cp.lpos1[0], cp.lpos1[1], cp.lpos1[2]});
+          V3 gp2 = V3{x2[0], x2[XS], x2[2 * XS]} + qrot(bq2, V3{cp.lpos2[0], cp.lpos2[1], cp.lpos2[2]});
           Q4 gq1 = qmul(bq1, Q4{cp.lquat1[0], cp.lquat1[1], cp.lquat1[2], cp.lquat1[3]});
           Q4 gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
           double dist;
