@@ -301,3 +301,23 @@ def test_relative_frame_task(g1):
     np.testing.assert_allclose(v, v_ref, atol=1e-9 * max(1.0, np.abs(v_ref).max()))
     rel.set_target_from_configuration(cfg)
     np.testing.assert_allclose(rel.compute_error(cfg), 0.0, atol=1e-14)
+
+
+def test_frame_task_remaining_reference_behaviours(g1):
+    """reference tests/test_frame_task.py:81-105,159-173."""
+    cfg = mink.Configuration(g1)
+    cfg.update_from_keyframe("stand")
+    with pytest.raises(mink.TargetNotSet):
+        mink.FrameTask("pelvis", "body", 1.0, 1.0).compute_jacobian(cfg)
+    task = mink.FrameTask("pelvis", "body", position_cost=1.0, orientation_cost=1.0)
+    task.set_target_from_configuration(cfg)
+    pose = cfg.get_transform_frame_to_world("pelvis", "body")
+    np.testing.assert_array_equal(task.transform_target_to_world.translation(), pose.translation())
+    np.testing.assert_array_equal(task.transform_target_to_world.rotation().wxyz, pose.rotation().wxyz)
+    # Levenberg–Marquardt damping has no effect when the error is zero
+    damped = mink.FrameTask("pelvis", "body", position_cost=1.0, orientation_cost=1.0, lm_damping=1e-3)
+    damped.set_target_from_configuration(cfg)
+    H0, c0 = task.compute_qp_objective(cfg)
+    H1, c1 = damped.compute_qp_objective(cfg)
+    np.testing.assert_allclose(H1, H0, atol=1e-13)
+    np.testing.assert_allclose(c1, c0, atol=1e-13)
