@@ -2,15 +2,18 @@
 //
 // Replaces mujoco.mj_geomDistance as called at
 // mink/limits/collision_avoidance_limit.py:214-229 for the analytic primitive pairs
-// (plane/sphere/capsule); semantics per MuJoCo's mj_geomDistance: geoms are ordered
-// so that type1 <= type2, the contact with the smallest distance within `distmax`
-// wins, and fromto = pos ∓ ½·dist·n is returned in the caller's geom order.
+// (plane/sphere/capsule, and box / cylinder against plane, sphere and — box only — capsule);
+// semantics per MuJoCo's mj_geomDistance: geoms are ordered so that type1 <= type2, the contact
+// with the smallest distance within `distmax` wins, and fromto = pos ∓ ½·dist·n is returned in
+// the caller's geom order.  The box / cylinder routines state the exact Euclidean distance between
+// the two convex shapes (what MuJoCo's native routines compute for separated geoms); where the closest
+// pair is not unique (an edge parallel to a face) the tie rule is ours and is documented at the routine.
 #pragma once
 #include "lie_dev.h"
 
 namespace mkh {
 
-enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3 };
+enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_CYLINDER = 5, GEOM_BOX = 6 };
 
 struct Contact { double dist; V3 pos; V3 n; bool hit; };
 
@@ -80,6 +83,137 @@ __device__ __forceinline__ Contact plane_sphere(V3 ppos, V3 pn, V3 c, double r, 
   return k;
 }
 
+
+// ---- box / cylinder routines: everything in the frame of the box (cylinder), mapped back with its rotation R
+__device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+
+// plane–box (mjc_PlaneBox): the corner furthest below the centre carries the smallest distance;
+// a face/edge parallel to the plane ties towards the −size corner (MuJoCo's enumeration order)
+__device__ __forceinline__ Contact plane_box(V3 ppos, V3 pn, V3 bpos, const M3& R, V3 s, double margin) {
+  Contact k; k.hit = false; k.dist = margin; k.pos = bpos; k.n = pn;
+  const V3 nb = mulT(R, pn);
+  const V3 vec{nb.x < 0.0 ? s.x : -s.x, nb.y < 0.0 ? s.y : -s.y, nb.z < 0.0 ? s.z : -s.z};
+  const double dist = dot(pn, bpos - ppos) + dot(nb, vec);
+  if (dist > margin) return k;
+  k.hit = true; k.dist = dist; k.pos = bpos + mul(R, vec) - (0.5 * dist) * pn;
+  return k;
+}
+
+// plane–cylinder (mjc_PlaneCylinder): lowest rim point; a cap parallel to the plane ties to the cap centre
+__device__ __forceinline__ Contact plane_cylinder(V3 ppos, V3 pn, V3 cpos, V3 axis, double rad, double half,
+                                                  double margin) {
+  Contact k; k.hit = false; k.dist = margin; k.pos = cpos; k.n = pn;
+  const double c = dot(pn, axis);
+  V3 radial = pn - c * axis;                               // plane normal projected on the cap plane
+  const double rl = sqrt(dot(radial, radial));
+  V3 pt = cpos - ((c < 0.0 ? -half : half)) * axis;
+  if (rl > 1e-15) pt = pt - (rad / rl) * radial;
+  const double dist = dot(pn, pt - ppos);
+  if (dist > margin) return k;
+  k.hit = true; k.dist = dist; k.pos = pt - (0.5 * dist) * pn;
+  return k;
+}
+
+// a point with a radius (sphere centre / capsule axis point) against a box: p is in the box frame
+// (mjc_SphereBox: clamp onto the box; centre inside ⇒ leave through the nearest face)
+__device__ __forceinline__ Contact ball_box_local(V3 p, double r, V3 s, double margin) {
+  Contact k; k.hit = false; k.dist = margin; k.pos = p; k.n = {1, 0, 0};
+  const V3 cl{clampd(p.x, -s.x, s.x), clampd(p.y, -s.y, s.y), clampd(p.z, -s.z, s.z)};
+  const V3 d = cl - p;                                     // from the ball towards the box
+  const double dl = sqrt(dot(d, d));
+  if (dl - r > margin) return k;
+  k.hit = true;
+  if (dl > 1e-15) {
+    k.dist = dl - r;
+    k.n = (1.0 / dl) * d;
+    k.pos = p + (r + 0.5 * k.dist) * k.n;
+    return k;
+  }
+  const double fx = s.x - fabs(p.x), fy = s.y - fabs(p.y), fz = s.z - fabs(p.z);
+  // nearest face in MuJoCo's order (−x, +x, −y, +y, −z, +z; strict <)
+  double closest = fx; V3 n{p.x < 0.0 ? 1.0 : -1.0, 0.0, 0.0};
+  if (p.x == 0.0) n.x = 1.0;
+  if (fy < closest) { closest = fy; n = {0.0, p.y <= 0.0 ? 1.0 : -1.0, 0.0}; }
+  if (fz < closest) { closest = fz; n = {0.0, 0.0, p.z <= 0.0 ? 1.0 : -1.0}; }
+  k.dist = -closest - r;
+  k.n = n;
+  k.pos = p + (0.5 * (r - closest)) * n;
+  return k;
+}
+
+// capsule–box: exact closest point of the segment c + t·a (|t| ≤ l) to the box.  ½·dist² is convex in t with
+// derivative g(t) = Σ aᵢ·eᵢ(t) (eᵢ = excess of coordinate i over the slab ±sᵢ), piecewise linear and
+// non-decreasing with breakpoints where the axis crosses a slab plane: bracket the root between the
+// breakpoints and interpolate.  A flat stretch (axis parallel to a face, or through the box) takes its midpoint.
+// (`on` = the axis whose slab plane t lies on: its excess is 0 by construction, not t·a + c − s up to rounding —
+// inside the box g must be exactly 0 at the entry and exit points, or rounding noise picks the point of the chord)
+__device__ __forceinline__ double seg_box_slope(V3 c, V3 a, V3 s, double t, int on = -1) {
+  const double x = fma(t, a.x, c.x), y = fma(t, a.y, c.y), z = fma(t, a.z, c.z);
+  const double ex = (on == 0) ? 0.0 : x - clampd(x, -s.x, s.x);
+  const double ey = (on == 1) ? 0.0 : y - clampd(y, -s.y, s.y);
+  const double ez = (on == 2) ? 0.0 : z - clampd(z, -s.z, s.z);
+  return a.x * ex + a.y * ey + a.z * ez;
+}
+__device__ __forceinline__ Contact capsule_box_local(V3 c, V3 a, double r, double l, V3 s, double margin) {
+  const double g0 = seg_box_slope(c, a, s, -l), g1 = seg_box_slope(c, a, s, l);
+  double t;
+  if (g0 > 0.0) t = -l;
+  else if (g1 < 0.0) t = l;
+  else {
+    // tL = last candidate with g ≤ 0, tR = first with g ≥ 0 (they cross over on a flat stretch)
+    double tL = (g1 <= 0.0) ? l : -l, gL = (g1 <= 0.0) ? g1 : g0;
+    double tR = (g0 >= 0.0) ? -l : l, gR = (g0 >= 0.0) ? g0 : g1;
+    const double av[3] = {a.x, a.y, a.z}, cv[3] = {c.x, c.y, c.z}, sv[3] = {s.x, s.y, s.z};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (fabs(av[i]) < 1e-15) continue;
+#pragma unroll
+      for (int sg = 0; sg < 2; ++sg) {
+        const double tb = ((sg ? sv[i] : -sv[i]) - cv[i]) / av[i];
+        if (!(tb > -l && tb < l)) continue;
+        const double gb = seg_box_slope(c, a, s, tb, i);
+        if (gb <= 0.0 && tb > tL) { tL = tb; gL = gb; }
+        if (gb >= 0.0 && tb < tR) { tR = tb; gR = gb; }
+      }
+    }
+    const double dg = gR - gL;
+    t = (dg > 0.0) ? tL + (tR - tL) * (-gL / dg) : 0.5 * (tL + tR);
+  }
+  return ball_box_local(c + t * a, r, s, margin);
+}
+
+// sphere–cylinder (mjc_SphereCylinder): p in the cylinder frame; side / cap / rim, centre inside ⇒ nearest exit
+__device__ __forceinline__ Contact ball_cylinder_local(V3 p, double r, double rad, double half, double margin) {
+  Contact k; k.hit = false; k.dist = margin; k.pos = p; k.n = {1, 0, 0};
+  const double rho = sqrt(p.x * p.x + p.y * p.y);
+  const double sc = (rho > rad) ? rad / rho : 1.0;
+  const V3 cl{p.x * sc, p.y * sc, clampd(p.z, -half, half)};
+  const V3 d = cl - p;
+  const double dl = sqrt(dot(d, d));
+  if (dl - r > margin) return k;
+  k.hit = true;
+  if (dl > 1e-15) {
+    k.dist = dl - r;
+    k.n = (1.0 / dl) * d;
+    k.pos = p + (r + 0.5 * k.dist) * k.n;
+    return k;
+  }
+  const double fr = rad - rho, fz = half - fabs(p.z);
+  double closest; V3 n;
+  if (fz < fr) { closest = fz; n = {0.0, 0.0, p.z <= 0.0 ? 1.0 : -1.0}; }
+  else { closest = fr; n = (rho > 1e-15) ? V3{-p.x / rho, -p.y / rho, 0.0} : V3{-1.0, 0.0, 0.0}; }
+  k.dist = -closest - r;
+  k.n = n;
+  k.pos = p + (0.5 * (r - closest)) * n;
+  return k;
+}
+
+// map a contact found in the frame of geom 2 (rotation R, origin o) back to the world
+__device__ __forceinline__ Contact to_world(Contact k, const M3& R, V3 o) {
+  if (k.hit) { k.pos = o + mul(R, k.pos); k.n = mul(R, k.n); }
+  return k;
+}
+
 // dist / fromto for one geom pair in the CALLER's order (g1 -> g2).
 // type/size/pose are those of g1 and g2 as given; returns false when the pair type
 // is not one of the analytic routines above.
@@ -106,6 +240,16 @@ __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t
   } else if (t1 == GEOM_PLANE && t2 == GEOM_CAPSULE) {
     c = better(plane_sphere(p1, z1, p2 + s2.y * z2, s2.x, distmax),
                plane_sphere(p1, z1, p2 - s2.y * z2, s2.x, distmax));
+  } else if (t1 == GEOM_PLANE && t2 == GEOM_BOX) {
+    c = plane_box(p1, z1, p2, R2, s2, distmax);
+  } else if (t1 == GEOM_PLANE && t2 == GEOM_CYLINDER) {
+    c = plane_cylinder(p1, z1, p2, z2, s2.x, s2.y, distmax);
+  } else if (t1 == GEOM_SPHERE && t2 == GEOM_BOX) {
+    c = to_world(ball_box_local(mulT(R2, p1 - p2), s1.x, s2, distmax), R2, p2);
+  } else if (t1 == GEOM_SPHERE && t2 == GEOM_CYLINDER) {
+    c = to_world(ball_cylinder_local(mulT(R2, p1 - p2), s1.x, s2.x, s2.y, distmax), R2, p2);
+  } else if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX) {
+    c = to_world(capsule_box_local(mulT(R2, p1 - p2), mulT(R2, z1), s1.x, s1.y, s2, distmax), R2, p2);
   } else {
     dist = distmax; from = {0, 0, 0}; to = {0, 0, 0};
     return false;

@@ -456,10 +456,155 @@ def _plane_capsule(pos1, mat1, pos2, mat2, size2, margin):
     return out
 
 
+# ---- box / cylinder against plane, sphere and capsule.  MuJoCo's native routines (engine_collision_primitive.c
+# mjc_PlaneBox / mjc_PlaneCylinder / mjc_SphereCylinder, engine_collision_box.c mjc_SphereBox / mjc_CapsuleBox)
+# return the Euclidean distance between the two convex shapes for separated geoms; these restate that distance
+# exactly (and are checked against a brute-force minimisation in tests/test_oracle_collision_shapes.py).  Where the
+# closest pair is not unique (an edge parallel to a face) MuJoCo reports several equally distant contacts and
+# mj_geomDistance keeps the first: the tie rule here is our own and says so.
+def _mat3(mat9):
+    return np.asarray(mat9, dtype=np.float64).reshape(3, 3)
+
+
+def _plane_box(pos1, mat1, pos2, mat2, size2, margin):
+    """Lowest corner of the box (mjc_PlaneBox keeps the corners below the centre; the lowest has the smallest
+    distance).  A face or edge parallel to the plane ties towards the −size corner, MuJoCo's enumeration order."""
+    n = np.array([mat1[2], mat1[5], mat1[8]])
+    R = _mat3(mat2)
+    nb = R.T @ n
+    vec = np.where(nb < 0.0, size2[:3], -np.asarray(size2[:3]))
+    dist = float(n @ (pos2 - pos1)) + float(nb @ vec)
+    if dist > margin:
+        return []
+    return [(dist, pos2 + R @ vec - n * (0.5 * dist), n)]
+
+
+def _plane_cylinder(pos1, mat1, pos2, mat2, size2, margin):
+    """Lowest rim point of the cylinder; a cap parallel to the plane ties to the centre of that cap."""
+    n = np.array([mat1[2], mat1[5], mat1[8]])
+    axis = np.array([mat2[2], mat2[5], mat2[8]])
+    c = float(n @ axis)
+    radial = n - c * axis
+    rl = math.sqrt(float(radial @ radial))
+    pt = pos2 - axis * (-size2[1] if c < 0.0 else size2[1])
+    if rl > mjMINVAL:
+        pt = pt - radial * (size2[0] / rl)
+    dist = float(n @ (pt - pos1))
+    if dist > margin:
+        return []
+    return [(dist, pt - n * (0.5 * dist), n)]
+
+
+def _ball_box_local(p, r, s, margin):
+    """Ball of radius r centred at p (box frame) against the box ±s (mjc_SphereBox): clamp the centre onto the
+    box; a centre inside the box leaves through the nearest face (order −x,+x,−y,+y,−z,+z, strict <)."""
+    s = np.asarray(s[:3], dtype=np.float64)
+    cl = np.minimum(np.maximum(p, -s), s)
+    d = cl - p
+    dl = math.sqrt(float(d @ d))
+    if dl - r > margin:
+        return []
+    if dl > mjMINVAL:
+        n = d / dl
+        dist = dl - r
+        return [(dist, p + n * (r + 0.5 * dist), n)]
+    face = s - np.abs(p)
+    k = 0
+    for i in (1, 2):
+        if face[i] < face[k]:
+            k = i
+    n = np.zeros(3)
+    n[k] = 1.0 if p[k] <= 0.0 else -1.0
+    closest = float(face[k])
+    return [(-closest - r, p + n * (0.5 * (r - closest)), n)]
+
+
+def _seg_box_param(c, a, l, s):
+    """argmin over |t| ≤ l of dist(c + t·a, box ±s): the derivative g(t) = Σ aᵢ·excessᵢ(t) of ½·dist² is piecewise
+    linear and non-decreasing; scan the sorted breakpoints for the interval holding its root.  A flat stretch
+    (axis parallel to a face / through the box) takes its midpoint; g > 0 at −l takes −l, g < 0 at +l takes +l."""
+    s = np.asarray(s[:3], dtype=np.float64)
+
+    def g(t, on=-1):
+        # `on`: the axis whose slab plane t lies on — its excess is 0 by construction (inside the box g must be
+        # exactly 0 at the entry and exit points, or rounding noise would pick the point of the chord)
+        p = c + t * a
+        e = p - np.minimum(np.maximum(p, -s), s)
+        if on >= 0:
+            e[on] = 0.0
+        return float(a @ e)
+
+    cand = [(-l, g(-l)), (l, g(l))]
+    for i in range(3):
+        if abs(a[i]) >= mjMINVAL:
+            for e in (-s[i], s[i]):
+                tb = (e - c[i]) / a[i]
+                if -l < tb < l:
+                    cand.append((tb, g(tb, i)))
+    cand.sort(key=lambda x: x[0])
+    ts = [x[0] for x in cand]
+    gs = [x[1] for x in cand]
+    if gs[0] > 0.0:
+        return -l
+    if gs[-1] < 0.0:
+        return l
+    lo = max(i for i in range(len(ts)) if gs[i] <= 0.0)       # last point with g ≤ 0
+    hi = min(i for i in range(len(ts)) if gs[i] >= 0.0)       # first point with g ≥ 0
+    tL, gL, tR, gR = ts[lo], gs[lo], ts[hi], gs[hi]
+    if gR - gL > 0.0:
+        return tL + (tR - tL) * (-gL / (gR - gL))
+    return 0.5 * (tL + tR)
+
+
+def _ball_cylinder_local(p, r, rad, half, margin):
+    """Ball against a cylinder (its frame; mjc_SphereCylinder): side / cap / rim; a centre inside leaves through
+    the nearer of the side wall and the caps."""
+    rho = math.hypot(p[0], p[1])
+    sc = rad / rho if rho > rad else 1.0
+    cl = np.array([p[0] * sc, p[1] * sc, min(max(p[2], -half), half)])
+    d = cl - p
+    dl = math.sqrt(float(d @ d))
+    if dl - r > margin:
+        return []
+    if dl > mjMINVAL:
+        n = d / dl
+        dist = dl - r
+        return [(dist, p + n * (r + 0.5 * dist), n)]
+    fr, fz = rad - rho, half - abs(p[2])
+    if fz < fr:
+        closest, n = fz, np.array([0.0, 0.0, 1.0 if p[2] <= 0.0 else -1.0])
+    else:
+        closest = fr
+        n = np.array([-p[0] / rho, -p[1] / rho, 0.0]) if rho > mjMINVAL else np.array([-1.0, 0.0, 0.0])
+    return [(-closest - r, p + n * (0.5 * (r - closest)), n)]
+
+
+def _to_world(cons, R, o):
+    return [(dist, o + R @ pos, R @ n) for dist, pos, n in cons]
+
+
+def _sphere_box(pos1, size1, pos2, mat2, size2, margin):
+    R = _mat3(mat2)
+    return _to_world(_ball_box_local(R.T @ (pos1 - pos2), size1[0], size2, margin), R, pos2)
+
+
+def _sphere_cylinder(pos1, size1, pos2, mat2, size2, margin):
+    R = _mat3(mat2)
+    return _to_world(_ball_cylinder_local(R.T @ (pos1 - pos2), size1[0], size2[0], size2[1], margin), R, pos2)
+
+
+def _capsule_box(pos1, mat1, size1, pos2, mat2, size2, margin):
+    R = _mat3(mat2)
+    c = R.T @ (pos1 - pos2)
+    a = R.T @ np.array([mat1[2], mat1[5], mat1[8]])
+    t = _seg_box_param(c, a, size1[1], size2)
+    return _to_world(_ball_box_local(c + t * a, size1[0], size2, margin), R, pos2)
+
+
 def mj_geomDistance(m, d: Data, geom1: int, geom2: int, distmax: float, fromto) -> float:
     """Smallest signed distance between two geoms and the connecting segment
     (mink/limits/collision_avoidance_limit.py:219); SURVEY Appendix A.8.
-    Only the analytic pairs used by the benchmark configs are restated."""
+    Restated: plane/sphere/capsule pairs, box against plane/sphere/capsule, cylinder against plane/sphere."""
     g1, g2 = int(geom1), int(geom2)
     t1, t2 = int(m.geom_type[g1]), int(m.geom_type[g2])
     flip = t1 > t2
@@ -480,6 +625,16 @@ def mj_geomDistance(m, d: Data, geom1: int, geom2: int, distmax: float, fromto) 
         cons = _plane_sphere(p1, R1, p2, s2, distmax)
     elif (t1, t2) == (GEOM_PLANE, GEOM_CAPSULE):
         cons = _plane_capsule(p1, R1, p2, R2, s2, distmax)
+    elif (t1, t2) == (GEOM_PLANE, GEOM_BOX):
+        cons = _plane_box(p1, R1, p2, R2, s2, distmax)
+    elif (t1, t2) == (GEOM_PLANE, GEOM_CYLINDER):
+        cons = _plane_cylinder(p1, R1, p2, R2, s2, distmax)
+    elif (t1, t2) == (GEOM_SPHERE, GEOM_BOX):
+        cons = _sphere_box(p1, s1, p2, R2, s2, distmax)
+    elif (t1, t2) == (GEOM_SPHERE, GEOM_CYLINDER):
+        cons = _sphere_cylinder(p1, s1, p2, R2, s2, distmax)
+    elif (t1, t2) == (GEOM_CAPSULE, GEOM_BOX):
+        cons = _capsule_box(p1, R1, s1, p2, R2, s2, distmax)
     else:
         raise NotImplementedError(f"geom pair types ({t1},{t2}) not restated")
     if fromto is not None:

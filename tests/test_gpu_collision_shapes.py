@@ -1,0 +1,174 @@
+"""CollisionAvoidanceLimit on box / cylinder pairs: device rows vs the numpy oracle.
+
+examples/arm_ur5e.py:30-37 avoids collisions between the `wrist_3_link` capsule and the `floor` plane / `wall`
+box; a synthetic scene covers every pair type the device routine knows."""
+
+import numpy as np
+import pytest
+
+import mink_amd as mink
+import oracle_configs as oc
+from oracle import ik as oik
+
+pytestmark = pytest.mark.gpu
+
+SCENE = """<mujoco><compiler angle="radian"/><worldbody>
+  <geom name="floor" type="plane" size="1 1 .1" pos="0 0 -0.35" quat="0.99 0.05 -0.08 0"/>
+  <geom name="crate" type="box" size=".12 .2 .15" pos="0.45 0.1 0.1" quat="0.9 0.1 0.3 0.2"/>
+  <geom name="drum" type="cylinder" size=".1 .15" pos="-0.1 0.45 0.0" quat="0.8 0.5 0.1 0.2"/>
+  <geom name="post" type="capsule" size=".03 .25" pos="0.1 -0.45 0.1" quat="0.9 0.3 0.2 0"/>
+  <geom name="orb" type="sphere" size=".06" pos="-0.4 -0.2 0.2"/>
+  <body name="l1" pos="0 0 0.1"><joint name="j1" type="hinge" axis="0 0 1" range="-3 3"/>
+    <geom name="l1_cap" type="capsule" size=".03 .1" pos="0.1 0 0" quat="1 0 1 0"/>
+    <body name="l2" pos="0.2 0 0"><joint name="j2" type="hinge" axis="0 1 0" range="-2 2"/>
+      <geom name="l2_box" type="box" size=".08 .03 .04" pos="0.1 0 0"/>
+      <body name="l3" pos="0.2 0 0"><joint name="j3" type="hinge" axis="0 1 0" range="-2 2"/>
+        <joint name="j3s" type="slide" axis="1 0 0" range="-0.1 0.1"/>
+        <geom name="l3_cap" type="capsule" size=".025 .08" pos="0.08 0 0" quat="1 0 1 0"/>
+        <body name="l4" pos="0.16 0 0"><joint name="j4" type="ball"/>
+          <geom name="l4_ball" type="sphere" size=".04" pos="0.05 0 0"/>
+          <geom name="l4_can" type="cylinder" size=".03 .05" pos="0.12 0 0" quat="1 0 1 0"/>
+          <site name="tip" pos="0.18 0 0"/>
+        </body>
+      </body>
+    </body>
+  </body>
+</worldbody></mujoco>"""
+
+PAIRS = [
+    (["l1_cap", "l3_cap"], ["crate", "floor"]),          # capsule–box, plane–capsule
+    (["l4_ball"], ["crate", "drum", "floor", "post"]),   # sphere–box, sphere–cylinder, plane–sphere, sphere–capsule
+    (["l2_box"], ["floor", "orb", "post"]),              # plane–box, sphere–box, capsule–box (box on the robot)
+    (["l4_can"], ["floor", "orb"]),                      # plane–cylinder, sphere–cylinder (cylinder on the robot)
+]
+
+
+def _rand_q(m, rng, n):
+    q = np.tile(m.qpos0, (n, 1))
+    q[:, 0] = rng.uniform(-3, 3, n)
+    q[:, 1] = rng.uniform(-1.5, 1.5, n)
+    q[:, 2] = rng.uniform(-1.5, 1.5, n)
+    q[:, 3] = rng.uniform(-0.1, 0.1, n)
+    quat = rng.normal(size=(n, 4))
+    q[:, 4:8] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    return q
+
+
+def test_every_box_and_cylinder_pair_type_against_the_oracle():
+    m = mink.loads_mjcf(SCENE)
+    rng = np.random.default_rng(3)
+    B = 256
+    q = _rand_q(m, rng, B)
+    cfg = mink.Configuration(m, q)
+    col = mink.CollisionAvoidanceLimit(m, PAIRS, collision_detection_distance=0.25, minimum_distance_from_collisions=0.01)
+    assert len(col.geom_id_pairs) == 11
+    dt = 0.1               # long step: h = gain·(d − d_min)/dt is small enough for the rows to bind
+    G, h = col.compute_qp_inequalities(cfg, dt)
+    assert G.shape == (B, 11, m.nv)
+    spec = oik.CollisionAvoidanceLimitSpec(col.geom_id_pairs, collision_detection_distance=0.25,
+                                           minimum_distance_from_collisions=0.01)
+    active = np.zeros(11, dtype=int)
+    for i in range(B):
+        o = oik.Configuration(m, q[i])
+        G_ref, h_ref = oik.limit_inequalities(o, spec, dt)
+        fin = np.isfinite(h_ref)
+        assert (np.isfinite(h[i]) == fin).all(), i
+        active += fin
+        np.testing.assert_allclose(h[i][fin], h_ref[fin], rtol=0, atol=1e-9 * max(1.0, np.abs(h_ref[fin]).max(initial=0.0)))
+        np.testing.assert_allclose(G[i], G_ref, atol=1e-11)
+    print("active instances per pair:", dict(zip([tuple(p) for p in col.geom_id_pairs], active)))
+    assert (active > 0).all(), active                       # every pair type was exercised inside the cut-off
+
+    # and the solve: tip task + posture + limits + these half-spaces — on the instances that start outside
+    # minimum_distance_from_collisions for every pair (random poses put some geoms deep inside each other, where the
+    # h = 0 rows of opposing contacts are inconsistent for the reference too)
+    # ... drawn from a larger sample so that many start within a few mm of d_min: those rows bind
+    q = _rand_q(m, rng, 8192)
+    G, h = col.compute_qp_inequalities(mink.Configuration(m, q), dt)
+    hmin = np.where(np.isfinite(h), h, np.inf).min(axis=1)
+    ok = np.flatnonzero(hmin > 0)
+    ok = ok[np.argsort(hmin[ok])][:192]
+    q, G, h = q[ok], G[ok], h[ok]
+    cfg = mink.Configuration(m, q)
+    tgt_cfg = mink.Configuration(m, _rand_q(m, rng, len(ok)))
+    ft = mink.FrameTask("tip", "site", position_cost=1.0, orientation_cost=0.2, lm_damping=0.0)
+    ft.set_target(tgt_cfg.get_transform_frame_to_world("tip", "site"))
+    post = mink.PostureTask(m, cost=1e-2)
+    post.set_target(m.qpos0)
+    lims = [mink.ConfigurationLimit(m), col]
+    v = mink.solve_ik(cfg, [ft, post], dt, "mi355x", 1e-3, limits=lims)
+    dq = v * dt
+    fin = np.isfinite(h)
+    Gx = np.einsum("bpj,bj->bp", G, dq)
+    assert (Gx[fin] <= h[fin] + 1e-9).all()                 # every half-space respected
+    binding = (np.abs(Gx - h) < 1e-9) & fin
+    print("instances solved: %d, binding half-spaces: %d in %d instances" % (len(ok), binding.sum(), binding.any(axis=1).sum()))
+    assert binding.any(axis=1).sum() >= 16
+    worst = 0.0
+    for i in np.concatenate([np.flatnonzero(binding.any(axis=1))[:32], np.arange(0, len(ok), 8)]):
+        ts = [oik.FrameTaskSpec(m.name2id("site", "tip"), "site", ft.cost, ft.transform_target_to_world.wxyz_xyz[i], 1.0, 0.0),
+              oik.PostureTaskSpec(post.cost, post.target_q, 1.0)]
+        v_ref = oik.solve_ik(m, q[i], ts, dt, 1e-3, [oik.ConfigurationLimitSpec(), spec])
+        worst = max(worst, np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max()))
+    print("solve with mixed-shape half-spaces vs oracle: max rel err %.2e" % worst)
+    assert worst < 1e-7
+
+
+def test_ur5e_example_wrist_against_wall_and_floor():
+    """examples/arm_ur5e.py:20-47,74: FrameTask + ConfigurationLimit + CollisionAvoidanceLimit(wrist_3_link vs floor,
+    wall) + VelocityLimit(π); the wrist capsule is driven towards the wall box and the floor plane."""
+    from mink_amd import workloads
+    m = workloads.load_robot("ur5e")
+    om = oc.model("ur5e")
+    rng = np.random.default_rng(11)
+    B = 512
+    home = m.key_qpos[m.name2id("key", "home")]
+    col = mink.CollisionAvoidanceLimit(m, [(["wrist_3_link"], ["floor", "wall"])], collision_detection_distance=0.3)
+    damping = 1e-3
+    # half of the batch starts within millimetres of d_min of the wall or the floor (those rows bind), half anywhere
+    pool = workloads.sample_q(m, rng, 16384, base_q=home)
+    pool[::2] = home + rng.normal(scale=0.4, size=(8192, m.nq))
+    _, hp = col.compute_qp_inequalities(mink.Configuration(m, pool), 2e-3)
+    hmin = np.where(np.isfinite(hp), hp, np.inf).min(axis=1)
+    near = np.flatnonzero(hmin > 0)
+    near = near[np.argsort(hmin[near])][: B // 2]
+    q = np.concatenate([pool[near], pool[rng.choice(np.flatnonzero(hmin > 0), size=B // 2, replace=False)]])
+    cfg = mink.Configuration(m, q)
+    vel = mink.VelocityLimit(m, {n: np.pi for n in ("shoulder_pan", "shoulder_lift", "elbow", "wrist_1", "wrist_2", "wrist_3")})
+    lims = [mink.ConfigurationLimit(m), col, vel]
+    ft = mink.FrameTask("attachment_site", "site", position_cost=1.0, orientation_cost=1.0, lm_damping=1.0)
+    # targets: inside / behind the wall and below the floor, so that the half-spaces bind
+    tg = cfg.get_transform_frame_to_world("attachment_site", "site").wxyz_xyz.copy()
+    wall = m.geom_names.index("wall")
+    wall_pos = m.body_pos[m.geom_bodyid[wall]] + m.geom_pos[wall]
+    tg[::2, 4:] = wall_pos + rng.normal(scale=0.05, size=(B // 2, 3))
+    tg[1::2, 6] = -0.1
+    ft.set_target(mink.SE3(tg))
+    spec = oik.CollisionAvoidanceLimitSpec(col.geom_id_pairs, collision_detection_distance=0.3)
+    vspec = oik.VelocityLimitSpec(vel.indices, vel.limit)
+    # the example's 500 Hz step (rows rarely bind: h ∝ 1/dt) and a 20 Hz step (they do)
+    for dt in (2e-3, 5e-2):
+        G, h = col.compute_qp_inequalities(cfg, dt)
+        fin = np.isfinite(h)
+        print("UR5e: active rows  floor %d  wall %d  of %d" % (fin[:, 0].sum(), fin[:, 1].sum(), B))
+        assert fin[:, 0].any() and fin[:, 1].any()
+        v = mink.solve_ik(cfg, [ft], dt, "mi355x", damping, limits=lims)
+        dq = v * dt
+        Gx = np.einsum("bpj,bj->bp", G, dq)
+        assert (Gx[fin] <= h[fin] + 1e-9).all()
+        binding = (np.abs(Gx - h) < 1e-9) & fin
+        print("UR5e dt=%g: binding half-spaces in %d instances" % (dt, binding.any(axis=1).sum()))
+        assert dt < 1e-2 or binding.any(axis=1).sum() >= 8
+        worst = 0.0
+        idx = np.concatenate([np.flatnonzero(binding.any(axis=1))[:16], np.flatnonzero(fin.any(axis=1))[:16], np.arange(0, B, 64)])
+        for i in idx:
+            o = oik.Configuration(om, q[i])
+            G_ref, h_ref = oik.limit_inequalities(o, spec, dt)
+            assert (np.isfinite(h_ref) == fin[i]).all()
+            np.testing.assert_allclose(h[i][fin[i]], h_ref[fin[i]], atol=1e-9 * max(1.0, np.abs(h_ref[fin[i]]).max(initial=0.0)))
+            np.testing.assert_allclose(G[i], G_ref, atol=1e-11)
+            ts = [oik.FrameTaskSpec(om.name2id("site", "attachment_site"), "site", ft.cost, tg[i], 1.0, 1.0)]
+            v_ref = oik.solve_ik(om, q[i], ts, dt, damping, [oik.ConfigurationLimitSpec(), spec, vspec])
+            worst = max(worst, np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max()))
+        print("UR5e example config, dt=%g, vs oracle: max rel err %.2e" % (dt, worst))
+        assert worst < 1e-7

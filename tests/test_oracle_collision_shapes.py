@@ -1,0 +1,213 @@
+"""Box / cylinder distance routines of the numpy oracle (oracle/mjmath.py) against brute force.
+
+MuJoCo is not importable here, so these routines cannot be pinned against mj_geomDistance itself ("parity
+unpinned"); what can be checked independently is that they return the Euclidean distance between
+the two convex shapes, that `fromto` connects a point on each surface, and the mj_geomDistance conventions
+(cut-off at distmax, caller's geom order)."""
+
+import math
+
+import numpy as np
+import pytest
+from scipy.optimize import minimize, minimize_scalar
+
+from oracle import mjmath as mj
+
+
+def _rand_rot(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    R = np.zeros(9)
+    mj.mju_quat2Mat(R, q)
+    return R
+
+
+def _point_box(p, s):
+    """distance of a point (box frame) to the box ±s; negative inside"""
+    d = np.abs(p) - s
+    out = np.linalg.norm(np.maximum(d, 0.0))
+    return out if out > 0 else float(d.max())
+
+
+def _best(cons):
+    return min(cons, key=lambda c: c[0])
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_capsule_box_is_the_euclidean_distance(seed):
+    rng = np.random.default_rng(seed)
+    s = rng.uniform(0.05, 0.4, size=3)
+    R2, p2 = _rand_rot(rng), rng.normal(size=3) * 0.2
+    R1 = _rand_rot(rng)
+    r, l = rng.uniform(0.01, 0.08), rng.uniform(0.05, 0.5)
+    p1 = p2 + rng.normal(size=3) * rng.uniform(0.2, 0.9)
+    cons = mj._capsule_box(p1, R1, np.array([r, l, 0.0]), p2, R2, np.r_[s], 10.0)
+    assert len(cons) == 1
+    dist, pos, n = cons[0]
+    Rb = R2.reshape(3, 3)
+    c = Rb.T @ (p1 - p2)
+    a = Rb.T @ np.array([R1[2], R1[5], R1[8]])
+    # brute force: ½dist² is convex along the axis
+    f = lambda t: _point_box(c + t * a, s)
+    ts = np.linspace(-l, l, 4001)
+    fs = np.array([f(t) for t in ts])
+    k = int(fs.argmin())
+    res = minimize_scalar(f, bounds=(ts[max(k - 1, 0)], ts[min(k + 1, len(ts) - 1)]), method="bounded",
+                          options={"xatol": 1e-13})
+    ref = min(res.fun, fs.min())
+    if ref > 0:                       # axis outside the box: exact distance
+        assert abs(dist - (ref - r)) < 1e-9, (dist, ref - r)
+        # fromto: a point on the capsule surface and a point on the box surface, |to − from| = |dist|
+        frm, to = pos - n * (0.5 * dist), pos + n * (0.5 * dist)
+        assert abs(_point_box(Rb.T @ (to - p2), s)) < 1e-9
+        w = Rb.T @ (frm - p2) - c
+        t = float(np.clip(w @ a, -l, l))
+        assert abs(np.linalg.norm(w - t * a) - r) < 1e-9
+        assert abs(np.linalg.norm(n) - 1.0) < 1e-12
+    else:                             # axis inside the box: documented rule (nearest face of the chord midpoint)
+        assert dist <= -r
+
+
+def test_capsule_parallel_to_a_face_takes_the_overlap_midpoint():
+    s = np.array([0.2, 0.3, 0.1])
+    I = np.eye(3).reshape(-1)
+    # capsule axis = z of its frame; rotate so that it lies along box x, above the +z face, overhanging on one side
+    R1 = np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]], dtype=float).reshape(-1)   # column 2 = (1,0,0)
+    cons = mj._capsule_box(np.array([0.25, 0.0, 0.35]), R1, np.array([0.05, 0.3, 0.0]), np.zeros(3), I, s, 1.0)
+    dist, pos, n = cons[0]
+    assert abs(dist - (0.25 - 0.05)) < 1e-14
+    np.testing.assert_allclose(n, [0, 0, -1], atol=1e-14)
+    # axis spans x ∈ [−0.05, 0.55]; over the face for x ∈ [−0.05, 0.2] ⇒ midpoint 0.075
+    assert abs(pos[0] - 0.075) < 1e-12
+
+
+def test_capsule_axis_through_the_box_takes_the_chord_midpoint():
+    """Deep penetration is outside what a collision-AVOIDANCE limit is meant to see, but the rule must be
+    deterministic (device and oracle agree): the midpoint of the chord inside the box leaves through its nearest face."""
+    s = np.array([0.2, 0.3, 0.1])
+    I = np.eye(3).reshape(-1)
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        R1 = _rand_rot(rng)
+        a = np.array([R1[2], R1[5], R1[8]])
+        inside = rng.uniform(-0.8, 0.8, size=3) * s
+        l = rng.uniform(0.05, 1.0)
+        p1 = inside + rng.uniform(-0.5, 0.5) * l * a
+        dist, pos, n = mj._capsule_box(p1, R1, np.array([0.03, l, 0.0]), np.zeros(3), I, s, 1.0)[0]
+        # chord: parameters where the axis is inside the box
+        ts = np.linspace(-l, l, 200001)
+        pts = p1[None] + ts[:, None] * a[None]
+        ins = (np.abs(pts) <= s + 1e-15).all(axis=1)
+        mid = 0.5 * (ts[ins][0] + ts[ins][-1])
+        pm = p1 + mid * a
+        depth = (s - np.abs(pm)).min()
+        assert abs(dist - (-depth - 0.03)) < 1e-4
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_sphere_box_and_plane_box(seed):
+    rng = np.random.default_rng(100 + seed)
+    s = rng.uniform(0.05, 0.4, size=3)
+    R2, p2 = _rand_rot(rng), rng.normal(size=3) * 0.2
+    Rb = R2.reshape(3, 3)
+    r = rng.uniform(0.01, 0.1)
+    p1 = p2 + rng.normal(size=3) * rng.uniform(0.05, 0.8)
+    cons = mj._sphere_box(p1, np.array([r, 0, 0]), p2, R2, s, 10.0)
+    dist, pos, n = cons[0]
+    c = Rb.T @ (p1 - p2)
+    # independent: bounded minimisation over the box
+    res = minimize(lambda x: ((x - c) ** 2).sum(), np.clip(c, -s, s) * 0.9, jac=lambda x: 2 * (x - c),
+                   bounds=list(zip(-s, s)), method="L-BFGS-B", options={"ftol": 1e-20, "gtol": 1e-14})
+    ref = math.sqrt(res.fun)
+    if ref > 1e-9:
+        assert abs(dist - (ref - r)) < 1e-7
+        np.testing.assert_allclose(pos + n * (0.5 * dist), p2 + Rb @ np.clip(c, -s, s), atol=1e-12)   # `to` on the box
+        np.testing.assert_allclose(np.linalg.norm(pos - n * (0.5 * dist) - p1), r, atol=1e-12)       # `from` on the sphere
+    else:
+        assert abs(dist - (-(s - np.abs(c)).min() - r)) < 1e-12
+    # plane–box: the lowest of the 8 corners
+    R1, pp = _rand_rot(rng), rng.normal(size=3) * 0.1
+    nrm = np.array([R1[2], R1[5], R1[8]])
+    corners = np.array([[sx, sy, sz] for sx in (-s[0], s[0]) for sy in (-s[1], s[1]) for sz in (-s[2], s[2])])
+    heights = (p2 + corners @ Rb.T - pp) @ nrm
+    cons = mj._plane_box(pp, R1, p2, R2, s, 10.0)
+    dist, pos, n = cons[0]
+    assert abs(dist - heights.min()) < 1e-13
+    np.testing.assert_allclose(n, nrm)
+    np.testing.assert_allclose(pos + n * (0.5 * dist), p2 + Rb @ corners[heights.argmin()], atol=1e-13)
+    assert mj._plane_box(pp, R1, p2, R2, s, heights.min() - 1e-6) == []          # beyond the cut-off: no contact
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_cylinder_against_plane_and_sphere(seed):
+    rng = np.random.default_rng(200 + seed)
+    rad, half = rng.uniform(0.03, 0.3), rng.uniform(0.03, 0.4)
+    R2, p2 = _rand_rot(rng), rng.normal(size=3) * 0.2
+    Rb = R2.reshape(3, 3)
+    phi = np.linspace(0, 2 * np.pi, 20001)
+    rim = np.concatenate([np.stack([rad * np.cos(phi), rad * np.sin(phi), np.full_like(phi, z)], axis=1) for z in (-half, half)])
+    R1, pp = _rand_rot(rng), rng.normal(size=3) * 0.1
+    nrm = np.array([R1[2], R1[5], R1[8]])
+    heights = (p2 + rim @ Rb.T - pp) @ nrm
+    dist, pos, n = mj._plane_cylinder(pp, R1, p2, R2, np.array([rad, half, 0]), 10.0)[0]
+    assert abs(dist - heights.min()) < 1e-7 and dist <= heights.min() + 1e-15
+    # sphere: dense sample of the surface (side + caps) as the reference
+    r = rng.uniform(0.01, 0.1)
+    p1 = p2 + rng.normal(size=3) * rng.uniform(0.1, 0.8)
+    c = Rb.T @ (p1 - p2)
+    rho = math.hypot(c[0], c[1])
+    dist, pos, n = mj._sphere_cylinder(p1, np.array([r, 0, 0]), p2, R2, np.array([rad, half, 0]), 10.0)[0]
+    inside = rho < rad and abs(c[2]) < half
+    if not inside:
+        # closest point of a solid cylinder: project radially and axially (independent restatement by sampling)
+        zs = np.linspace(-half, half, 401)
+        rs = np.linspace(0, rad, 201)
+        ang = math.atan2(c[1], c[0])
+        cand = [np.array([rr * math.cos(ang), rr * math.sin(ang), z]) for rr in (rad,) for z in zs]
+        cand += [np.array([rr * math.cos(ang), rr * math.sin(ang), z]) for rr in rs for z in (-half, half)]
+        ref = min(np.linalg.norm(x - c) for x in cand)
+        assert abs(dist - (ref - r)) < 2e-3 and dist <= ref - r + 1e-12
+        to = Rb.T @ (pos + n * (0.5 * dist) - p2)
+        assert math.hypot(to[0], to[1]) <= rad + 1e-12 and abs(to[2]) <= half + 1e-12
+        assert abs(np.linalg.norm(to - c) - (dist + r)) < 1e-12
+    else:
+        assert abs(dist - (-min(rad - rho, half - abs(c[2])) - r)) < 1e-12
+
+
+def test_geom_distance_conventions_for_box_pairs():
+    """mj_geomDistance conventions (collision_avoidance_limit.py:214-229): caller order decides the direction
+    of fromto, distances beyond distmax return distmax with a zero fromto."""
+    import mink_amd as mink
+    xml = """<mujoco><worldbody>
+      <geom name="floor" type="plane" size="1 1 .1"/>
+      <geom name="wall" type="box" size=".1 .2 .3" pos="0.5 0 0.3"/>
+      <body name="b" pos="0 0 0.5"><joint name="j" type="slide" axis="1 0 0"/>
+        <geom name="cap" type="capsule" size=".04 .1" quat="1 0 1 0"/>
+        <geom name="ball" type="sphere" size=".05" pos="0 0.3 0"/>
+        <geom name="can" type="cylinder" size=".05 .1" pos="0 -0.3 0"/>
+      </body></worldbody></mujoco>"""
+    m = mink.loads_mjcf(xml)
+    d = mj.Data(m)
+    d.qpos[:] = 0.0
+    mj.mj_kinematics(m, d)
+    gid = lambda n: m.name2id("geom", n)
+    ft = np.zeros(6)
+    # capsule along x from −0.1..0.1 (+0.04 radius), wall face at x = 0.4
+    dist = mj.mj_geomDistance(m, d, gid("cap"), gid("wall"), 1.0, ft)
+    assert abs(dist - (0.4 - 0.1 - 0.04)) < 1e-14
+    np.testing.assert_allclose(ft, [0.14, 0, 0.5, 0.4, 0, 0.5], atol=1e-14)
+    dist2 = mj.mj_geomDistance(m, d, gid("wall"), gid("cap"), 1.0, ft)
+    assert dist2 == dist
+    np.testing.assert_allclose(ft, [0.4, 0, 0.5, 0.14, 0, 0.5], atol=1e-14)
+    assert mj.mj_geomDistance(m, d, gid("cap"), gid("wall"), 0.2, ft) == 0.2 and not ft.any()
+    # ball: centre (0, 0.3, 0.5), closest box point (0.4, 0.2, 0.5)
+    dist = mj.mj_geomDistance(m, d, gid("wall"), gid("ball"), 1.0, ft)
+    assert abs(dist - (math.hypot(0.4, 0.1) - 0.05)) < 1e-14
+    np.testing.assert_allclose(ft[:3], [0.4, 0.2, 0.5], atol=1e-14)
+    # floor vs box (bottom face at z = 0: touching), floor vs cylinder (upright: cap centre rule), ball vs can
+    assert abs(mj.mj_geomDistance(m, d, gid("floor"), gid("wall"), 1.0, ft)) < 1e-15
+    dist = mj.mj_geomDistance(m, d, gid("floor"), gid("can"), 1.0, ft)
+    assert abs(dist - 0.4) < 1e-14
+    np.testing.assert_allclose(ft, [0, -0.3, 0, 0, -0.3, 0.4], atol=1e-14)
+    dist = mj.mj_geomDistance(m, d, gid("ball"), gid("can"), 1.0, ft)
+    assert abs(dist - (0.6 - 0.05 - 0.05)) < 1e-14
