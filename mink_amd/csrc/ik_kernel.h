@@ -878,28 +878,30 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       if (lane < NR) sJ[SP * NR + lane] = is_dof ? -c_lane * dsq : 0.0;
       wave_sync();
       // Jh·Jhᵀ by (column, row-chunk) lanes: 64/n_μ chunks of rows per column, each lane a handful of
-      // 44-long dot products on its own LDS addresses.  (Having every lane run the dot of ITS tableau
+      // dot products on its own LDS addresses.  (Having every lane run the dot of ITS tableau
       // column against each row costs n_μ+1 full-wave passes: 16.6 k of 132 k cycles on G1.)
+      // A row of Jh is nonzero only on the kinematic chain of its task (12–16 of the 43 dofs on G1): the dot
+      // products walk the set bits of the column's chain mask instead of all NR dofs.
       const int wc = P.wood_col[ol], wr0 = P.wood_row0[ol];
       if (wc >= 0) {
-        const double2* a = reinterpret_cast<const double2*>(sJ + wc * NR);
+        const double* a = sJ + wc * NR;
+        const uint64_t chain = P.wood_mask[ol];
         const int rpc = P.wood_rpc;
-        // four rows per pass: the lane's own column is read once per pass, the row reads are
-        // broadcasts within a chunk (all its lanes share the row)
+        // four rows per pass: the lane's own column entry is read once per pass
         for (int i0 = 0; i0 < rpc; i0 += 4) {
           const int row0 = wr0 + i0;
           if (row0 > n_mu) break;
           // product row → LDS row: Jh rows 0..n_μ−1, then the right-hand-side vector stored in row SP
-          auto rowp = [&](int r) { return reinterpret_cast<const double2*>(sJ + (r < n_mu ? r : SP) * NR); };
-          const double2 *b0 = rowp(row0), *b1 = rowp(row0 + 1), *b2 = rowp(row0 + 2), *b3 = rowp(row0 + 3);
+          auto rowp = [&](int r) { return sJ + (r < n_mu ? r : SP) * NR; };
+          const double *b0 = rowp(row0), *b1 = rowp(row0 + 1), *b2 = rowp(row0 + 2), *b3 = rowp(row0 + 3);
           double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-#pragma unroll 2   // (a full unroll puts 110 b128 loads in flight and spills 300 VGPRs)
-          for (int k = 0; k < NR / 2; ++k) {
-            const double2 av = a[k], v0 = b0[k], v1 = b1[k], v2 = b2[k], v3 = b3[k];
-            acc0 = fma(av.y, v0.y, fma(av.x, v0.x, acc0));
-            acc1 = fma(av.y, v1.y, fma(av.x, v1.x, acc1));
-            acc2 = fma(av.y, v2.y, fma(av.x, v2.x, acc2));
-            acc3 = fma(av.y, v3.y, fma(av.x, v3.x, acc3));
+          for (uint64_t mk = chain; mk; mk &= mk - 1) {
+            const int k = __ffsll((unsigned long long)mk) - 1;
+            const double av = a[k];
+            acc0 = fma(av, b0[k], acc0);
+            acc1 = fma(av, b1[k], acc1);
+            acc2 = fma(av, b2[k], acc2);
+            acc3 = fma(av, b3[k], acc3);
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) {

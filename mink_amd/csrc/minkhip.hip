@@ -472,6 +472,11 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
         const int ch = l / P.n_jrows;
         P.wood_col[l] = ch < groups ? l % P.n_jrows : -1;
         P.wood_row0[l] = ch < groups ? ch * P.wood_rpc : 0;
+        P.wood_mask[l] = 0;
+        if (ch < groups)
+          for (size_t t = 0; t < ft.size(); ++t)
+            if (l % P.n_jrows >= ft[t].jrow0 && l % P.n_jrows < ft[t].jrow0 + __builtin_popcount(ft[t].rowmask & 63))
+              P.wood_mask[l] = ft[t].dof_mask;
       }
       // Jacobian columns by (task, dof) pair lanes; source of each residual's weighted error
       P.n_jpairs = 0;

@@ -69,6 +69,7 @@ struct DeviceProblem {
   // (row n_jrows = the right-hand side); −1 = idle lane
   int32_t wood_rpc;
   int32_t wood_col[64], wood_row0[64];
+  uint64_t wood_mask[64];  // dofs on the kinematic chain of the task that owns column wood_col[l] (the only nonzeros of that Jh row)
   // low-rank start: Jacobian columns by (task, dof) pair lanes — pair i = column jpair_dof[i] of frame task
   // jpair_task[i] (only dofs on the task's kinematic chain); mu_src[r] = offset in the task LDS block of the
   // weighted error of compact row r
