@@ -37,6 +37,7 @@ def ntmp_for(nt):
     # staging registers: 8 x b128 in flight, or 4 for the widest tableaus (the compiler needs the
     # 16 registers more than the rank-1 update needs the deeper pipeline: measured on G1)
     return 16 if (nt >= 56 or nt <= 24) else 32
+SPLIT_PREFIXES = (16, 24, 32)   # dof-row prefixes of the split rank-1 bodies (phase 0 of the low-rank start)
 NPRE = 4   # loads issued by rank1_prefetch (their 16 registers are off limits to the compiler)
 
 
@@ -70,6 +71,27 @@ def gen(nt: int) -> str:
     def load(k, addr="%0"):
         r = slot_reg(k)
         return f"ds_read_b128 v[{r}:{r + 3}], {addr} offset:{16 * k}"
+    def load_at(j, chunk, addr="%0"):
+        # j-th load of a pipelined body (decides the staging slot), reading rows 2·chunk, 2·chunk+1
+        r = slot_reg(j)
+        return f"ds_read_b128 v[{r}:{r + 3}], {addr} offset:{16 * chunk}"
+    def rank1_lines(chunks):
+        """Software-pipelined T[i] += lds[i]·g over the given 2-row chunks (in order).  The first NPRE chunks must
+        be 0..NPRE-1: rank1_prefetch has already issued them."""
+        assert list(chunks[:NPRE]) == list(range(min(NPRE, len(chunks))))
+        n = len(chunks)
+        lines = ["s_waitcnt lgkmcnt(0)"] + [load_at(j, chunks[j]) for j in range(min(NPRE, n), min(depth, n))]
+        for j in range(n):
+            issued = min(n, j + depth)
+            if j >= NPRE:
+                lines.append(f"s_waitcnt lgkmcnt({issued - j - 1})")
+            r = slot_reg(j)
+            c = chunks[j]
+            lines.append(f"v_fma_f64 {treg(2 * c)}, v[{r}:{r + 1}], %1, {treg(2 * c)}")
+            lines.append(f"v_fma_f64 {treg(2 * c + 1)}, v[{r + 2}:{r + 3}], %1, {treg(2 * c + 1)}")
+            if j + depth < n:
+                lines.append(load_at(j + depth, chunks[j + depth]))
+        return lines
     lines = ["s_waitcnt lgkmcnt(0)"] + [load(k) for k in range(min(NPRE, nload))]
     body = "\\n\\t".join(lines)
     clob_pre = ",".join(f'"v{r}"' for r in range(tmp0 + NTMP - 4 * NPRE, tmp0 + NTMP))
@@ -162,6 +184,18 @@ def gen(nt: int) -> str:
         out.append(f'    asm volatile("{body}"')
         out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
         out.append("  }")
+        if nr < nt:
+            # phase 0 of the low-rank start: the pivot column of a task residual is zero on the dof rows outside
+            # the kinematic chains reached so far — rows [0, p) of the dof block plus the residual rows [nr, nt)
+            for pfx in SPLIT_PREFIXES:
+                if pfx >= nr:
+                    continue
+                body = "\\n\\t".join(rank1_lines(list(range(pfx // 2)) + list(range(nr // 2, nt // 2))))
+                out.append(f"  // rank1_body restricted to rows [0, {pfx}) and [{nr}, {nt})")
+                out.append(f"  __device__ static __forceinline__ void rank1_body_{pfx}_hi_{nr}(unsigned lds_addr, double g) {{")
+                out.append(f'    asm volatile("{body}"')
+                out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
+                out.append("  }")
         if nr < nt:
             lines = [f"ds_read_b128 v[{t0 + 2 * nr + 4 * k}:{t0 + 2 * nr + 4 * k + 3}], %0 offset:{16 * k}" for k in range((nt - nr) // 2)]
             lines.append("s_waitcnt lgkmcnt(0)")

@@ -201,13 +201,27 @@ __device__ __forceinline__ double load_hi_strided_rows(unsigned addr) {
   else return 0.0;
 }
 
-template <int NT, int ROWS = NT>
+// Phase 0 of the low-rank start: rows [0, hb) of the dof block (hb = one past the last nonzero dof row of the
+// pivot column, wave-uniform) and the residual rows [NR, NT).  The column of a task residual is zero outside the
+// kinematic chains swept so far, and the dofs of a limb are contiguous in MuJoCo's depth-first order.
+template <int NT, int NR>
+__device__ __forceinline__ void rank1_split_rows(unsigned addr, double g, int hb) {
+#define MKH_SPLIT(P, R) if constexpr (NR == R && NT > R && (P) < R) { if (hb <= (P)) { Tab<NT>::rank1_body_##P##_hi_##R(addr, g); return; } }
+  MKH_SPLIT(16, 24) MKH_SPLIT(16, 32) MKH_SPLIT(24, 32)
+  MKH_SPLIT(16, 44) MKH_SPLIT(24, 44) MKH_SPLIT(32, 44)
+  MKH_SPLIT(16, 48) MKH_SPLIT(24, 48) MKH_SPLIT(32, 48)
+#undef MKH_SPLIT
+  Tab<NT>::rank1_body(addr, g);
+}
+
+template <int NT, int ROWS = NT, int SPLIT_NR = 0>
 __device__ __forceinline__ void pivot(QpLane& s, int k, bool reverse, int lane, const double* sPiv,
-                                      double own, const PivotScalars& ps, double inv) {
+                                      double own, const PivotScalars& ps, double inv, int hb = 64) {
   const double sk = ps.sg;
   const double ck = s.sg * sk * own;             // true T[lane][k]
   const double g = (sk * sk) * own * inv;        // R-units multiplier of this lane's column
-  rank1_rows<NT, ROWS>(lds_addr(sPiv), -g);      // R[i][lane] −= R[i][k]·g   (row k: published 0)
+  if (SPLIT_NR > 0) rank1_split_rows<NT, SPLIT_NR>(lds_addr(sPiv), -g, hb);
+  else rank1_rows<NT, ROWS>(lds_addr(sPiv), -g);      // R[i][lane] −= R[i][k]·g   (row k: published 0)
   if (lane == k) {
     s.D = -inv;                                  // T[k][k] = −1/d
     s.sg = (reverse ? -sk : sk) * inv;           // row/column k scaled by ±1/d
@@ -1091,7 +1105,14 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       const double alpha = -ps.x * inv;                                // drives w_k to 0
       s.x = fma(xor_sign(alpha, s.usign), tau, s.x);                   // basic: z −= α·τ, nonbasic: w += α·τ
       if (lane == k) { s.x = alpha; s.usign = kSign; s.sel = kWood ? 0 : 1; }   // z_k = 0 + α; now basic
-      pivot<NT>(s, k, false, lane, sPiv, own, ps, inv);
+      if constexpr (kWood) {
+        // dof rows the pivot column reaches: [0, hb)
+        const unsigned long long nzd = __ballot(own != 0.0) & ((1ull << NR) - 1ull);
+        const int hb = nzd ? 64 - __builtin_clzll(nzd) : 0;
+        pivot<NT, NT, NR>(s, k, false, lane, sPiv, own, ps, inv, hb);
+      } else {
+        pivot<NT>(s, k, false, lane, sPiv, own, ps, inv);
+      }
       MKH_LAP(1);
     }
     MKH_MARK("phase0_done");
