@@ -75,12 +75,16 @@ def gen(nt: int) -> str:
         # j-th load of a pipelined body (decides the staging slot), reading rows 2·chunk, 2·chunk+1
         r = slot_reg(j)
         return f"ds_read_b128 v[{r}:{r + 3}], {addr} offset:{16 * chunk}"
-    def rank1_lines(chunks):
+    def rank1_lines(chunks, pub=False):
         """Software-pipelined T[i] += lds[i]·g over the given 2-row chunks (in order).  The first NPRE chunks must
-        be 0..NPRE-1: rank1_prefetch has already issued them."""
+        be 0..NPRE-1: rank1_prefetch has already issued them.
+        pub: the statement first stores %3 (this lane's entry of the NEXT pivot column) at LDS address %2 and then
+        waits for everything older than that store — LDS operations of a wave complete in order, so lgkmcnt(1)
+        means "the prefetched loads are here" without draining the store (look-ahead publishing, ik_kernel.h)."""
         assert list(chunks[:NPRE]) == list(range(min(NPRE, len(chunks))))
         n = len(chunks)
-        lines = ["s_waitcnt lgkmcnt(0)"] + [load_at(j, chunks[j]) for j in range(min(NPRE, n), min(depth, n))]
+        head = ["ds_write_b64 %2, %3", "s_waitcnt lgkmcnt(1)"] if pub else ["s_waitcnt lgkmcnt(0)"]
+        lines = head + [load_at(j, chunks[j]) for j in range(min(NPRE, n), min(depth, n))]
         for j in range(n):
             issued = min(n, j + depth)
             if j >= NPRE:
@@ -118,6 +122,12 @@ def gen(nt: int) -> str:
     out.append("  __device__ static __forceinline__ void rank1_body(unsigned lds_addr, double g) {")
     out.append(f'    asm volatile("{body}"')
     out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
+    out.append("  }")
+    body_pub = "\\n\\t".join(rank1_lines(list(range(nload)), pub=True))
+    out.append("  // rank1_body + look-ahead store of the next pivot column's entry")
+    out.append("  __device__ static __forceinline__ void rank1_body_pub(unsigned lds_addr, double g, unsigned pub_addr, double pub) {")
+    out.append(f'    asm volatile("{body_pub}"')
+    out.append(f'                 :: "v"(lds_addr), "v"(g), "v"(pub_addr), "v"(pub) : {clob_t}, {clob_tmp}, "memory");')
     out.append("  }")
     out.append("  __device__ static __forceinline__ void rank1(unsigned lds_addr, double g) {")
     out.append("    rank1_prefetch(lds_addr);")
@@ -185,16 +195,23 @@ def gen(nt: int) -> str:
         out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
         out.append("  }")
         if nr < nt:
+            body = "\\n\\t".join(rank1_lines(list(range(nl)), pub=True))
+            out.append(f"  // rank1_body_{nr} + look-ahead store")
+            out.append(f"  __device__ static __forceinline__ void rank1_body_{nr}_pub(unsigned lds_addr, double g, unsigned pub_addr, double pub) {{")
+            out.append(f'    asm volatile("{body}"')
+            out.append(f'                 :: "v"(lds_addr), "v"(g), "v"(pub_addr), "v"(pub) : {clob_t}, {clob_tmp}, "memory");')
+            out.append("  }")
+        if nr < nt:
             # phase 0 of the low-rank start: the pivot column of a task residual is zero on the dof rows outside
             # the kinematic chains reached so far — rows [0, p) of the dof block plus the residual rows [nr, nt)
             for pfx in SPLIT_PREFIXES:
                 if pfx >= nr:
                     continue
-                body = "\\n\\t".join(rank1_lines(list(range(pfx // 2)) + list(range(nr // 2, nt // 2))))
-                out.append(f"  // rank1_body restricted to rows [0, {pfx}) and [{nr}, {nt})")
-                out.append(f"  __device__ static __forceinline__ void rank1_body_{pfx}_hi_{nr}(unsigned lds_addr, double g) {{")
+                body = "\\n\\t".join(rank1_lines(list(range(pfx // 2)) + list(range(nr // 2, nt // 2)), pub=True))
+                out.append(f"  // rank1_body restricted to rows [0, {pfx}) and [{nr}, {nt}), + look-ahead store")
+                out.append(f"  __device__ static __forceinline__ void rank1_body_{pfx}_hi_{nr}(unsigned lds_addr, double g, unsigned pub_addr, double pub) {{")
                 out.append(f'    asm volatile("{body}"')
-                out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
+                out.append(f'                 :: "v"(lds_addr), "v"(g), "v"(pub_addr), "v"(pub) : {clob_t}, {clob_tmp}, "memory");')
                 out.append("  }")
         if nr < nt:
             lines = [f"ds_read_b128 v[{t0 + 2 * nr + 4 * k}:{t0 + 2 * nr + 4 * k + 3}], %0 offset:{16 * k}" for k in range((nt - nr) // 2)]

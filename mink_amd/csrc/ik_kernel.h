@@ -44,6 +44,7 @@ __host__ __device__ inline int a_stride_for(int nv) {
 // Row stride of the staged Jacobian rows of the direct start: only the dof rows are read (rank1_leading_rows)
 __host__ __device__ inline int j_stride_direct(int nv, int nt) { const int a = a_stride_for(nv); return a < nt ? a : nt; }
 
+constexpr int kPivBuf = kWave + 8;   // doubles per pivot broadcast buffer
 struct LdsLayout {
   int q, X, jnt, tgt, task, J, dof, com, col, A, piv, S, total;  // offsets in doubles
 };
@@ -65,7 +66,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
   L.com = o;  o += (n_com > 0 ? nbody * 4 : 0);
   L.col = o;  o += max_rows * 16;
   L.A = o;    o += max_rows * a_stride_for(nv);       // half-space rows A[s][0..stride)
-  L.piv = o;  o += kWave + 8;      // pivot column broadcast buffer + 8 scalar slots of the pivot lane
+  L.piv = o;  o += 2 * kPivBuf;    // two pivot column broadcast buffers (64 entries + 8 scalar slots of the pivot lane): look-ahead publishing
   L.S = o;    o += lds_even(s_doubles);   // low-rank start: columns of −Jh·Jhᵀ + right-hand sides
   L.total = o;
   return L;
@@ -148,6 +149,30 @@ __device__ __forceinline__ double publish_column(const QpLane& s, int col, int l
   return own;                                    // raw R[lane][col] (0 for lane col)
 }
 
+// The two halves of publish_column for look-ahead publishing: while the rank-1 update of pivot j streams through
+// the FMA pipe, the column of pivot j+1 (whose entries after update j are one FMA away) is already on its way
+// through LDS, so the write → read round trip leaves the pivot's dependent chain.
+template <bool FULL>
+__device__ __forceinline__ void stage_column(const QpLane& s, int col, int lane, double* buf, double own, double rown = 1.0) {
+  buf[lane] = own;
+  if (lane == col) {
+    double2* o = reinterpret_cast<double2*>(buf + kWave);
+    o[0] = double2{s.D, s.sg};
+    o[1] = double2{s.x, rown};
+    if (FULL) o[2] = double2{s.lo, s.hi};
+  }
+}
+template <bool FULL>
+__device__ __forceinline__ void read_pivot_scalars(const double* buf, PivotScalars& ps) {
+  const double2* o = reinterpret_cast<const double2*>(buf + kWave);
+  const double2 a = o[0], b = o[1];
+  ps.d = a.x; ps.sg = a.y; ps.x = b.x; ps.rn = b.y;
+  if (FULL) {
+    const double2 c = o[2];
+    ps.lo = c.x; ps.hi = c.y;
+  }
+}
+
 // Symmetric sweep (reverse = un-sweep) on index k (wave-uniform); sPiv holds column k.
 template <int NT, int ROWS>
 __device__ __forceinline__ void rank1_rows(unsigned addr, double g) {
@@ -205,23 +230,22 @@ __device__ __forceinline__ double load_hi_strided_rows(unsigned addr) {
 // pivot column, wave-uniform) and the residual rows [NR, NT).  The column of a task residual is zero outside the
 // kinematic chains swept so far, and the dofs of a limb are contiguous in MuJoCo's depth-first order.
 template <int NT, int NR>
-__device__ __forceinline__ void rank1_split_rows(unsigned addr, double g, int hb) {
-#define MKH_SPLIT(P, R) if constexpr (NR == R && NT > R && (P) < R) { if (hb <= (P)) { Tab<NT>::rank1_body_##P##_hi_##R(addr, g); return; } }
+__device__ __forceinline__ void rank1_split_rows(unsigned addr, double g, int hb, unsigned pub_addr, double pub) {
+#define MKH_SPLIT(P, R) if constexpr (NR == R && NT > R && (P) < R) { if (hb <= (P)) { Tab<NT>::rank1_body_##P##_hi_##R(addr, g, pub_addr, pub); return; } }
   MKH_SPLIT(16, 24) MKH_SPLIT(16, 32) MKH_SPLIT(24, 32)
   MKH_SPLIT(16, 44) MKH_SPLIT(24, 44) MKH_SPLIT(32, 44)
   MKH_SPLIT(16, 48) MKH_SPLIT(24, 48) MKH_SPLIT(32, 48)
 #undef MKH_SPLIT
-  Tab<NT>::rank1_body(addr, g);
+  Tab<NT>::rank1_body_pub(addr, g, pub_addr, pub);
 }
 
-template <int NT, int ROWS = NT, int SPLIT_NR = 0>
+template <int NT, int ROWS = NT>
 __device__ __forceinline__ void pivot(QpLane& s, int k, bool reverse, int lane, const double* sPiv,
-                                      double own, const PivotScalars& ps, double inv, int hb = 64) {
+                                      double own, const PivotScalars& ps, double inv) {
   const double sk = ps.sg;
   const double ck = s.sg * sk * own;             // true T[lane][k]
   const double g = (sk * sk) * own * inv;        // R-units multiplier of this lane's column
-  if (SPLIT_NR > 0) rank1_split_rows<NT, SPLIT_NR>(lds_addr(sPiv), -g, hb);
-  else rank1_rows<NT, ROWS>(lds_addr(sPiv), -g);      // R[i][lane] −= R[i][k]·g   (row k: published 0)
+  rank1_rows<NT, ROWS>(lds_addr(sPiv), -g);      // R[i][lane] −= R[i][k]·g   (row k: published 0)
   if (lane == k) {
     s.D = -inv;                                  // T[k][k] = −1/d
     s.sg = (reverse ? -sk : sk) * inv;           // row/column k scaled by ±1/d
@@ -1090,30 +1114,62 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // multipliers, z/w update → rank-1 update.
     // (low-rank start: the dofs are already in; the n_μ residual indices NR.. take the pivots, d < 0)
     const int k_begin = kWood ? mu0 : 0, k_end = kWood ? mu0 + n_mu : nv;
+    // The pivot order is known, so pivot k+1 is published BEFORE the rank-1 update of pivot k runs: its column
+    // entries after update k are one FMA on row k+1 away (stored to the second buffer by the first instruction of
+    // the update's asm statement), and D, σ, x of lane k+1 are final once the cheap per-lane updates of pivot k are
+    // done (read with v_readlane into SGPRs).  The LDS round trip and the readlane latency hide under the FMA stream.
+    double* bufc = sPiv;
+    double* bufn = sPiv + kPivBuf;
+    double own = 0.0;
+    double pd = 1.0, psg = 1.0, px = 0.0;            // D, σ, x of the pivot lane (wave-uniform)
+    if (k_begin < k_end) {
+      const double rowv = Tab<NT>::get_dyn(k_begin);
+      own = (lane == k_begin) ? 0.0 : rowv;
+      wave_sync();                                   // earlier readers of the buffer are done
+      bufc[lane] = own;
+      pd = readlane_f64(s.D, k_begin); psg = readlane_f64(s.sg, k_begin); px = readlane_f64(s.x, k_begin);
+    }
     for (int k = k_begin; k < k_end; ++k) {
       MKH_MARK("p0_iter_begin");
-      PivotScalars ps;
       MKH_LAP0();
-      const double own = publish_column<NT>(s, k, lane, sPiv, ps);
-      Tab<NT>::rank1_prefetch(lds_addr(sPiv));
+      wave_sync();
+      Tab<NT>::rank1_prefetch(lds_addr(bufc));
       MKH_LAP(0);
-      // (ps.* are wave-uniform values that arrive in VGPRs: the ballot turns the test into a scalar branch,
-      // which keeps `status` in an SGPR and the QP loops free of exec-mask bookkeeping)
-      if (__ballot(!((kWood ? -ps.d : ps.d) > 0.0))) { status |= 4; break; }
-      const double inv = fast_rcp(ps.d);
-      const double tau = (lane == k) ? ps.d : s.sg * ps.sg * own;     // column k of the tableau
-      const double alpha = -ps.x * inv;                                // drives w_k to 0
+      if (!((kWood ? -pd : pd) > 0.0)) { status |= 4; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break; }
+      const double inv = fast_rcp(pd);
+      const double sk = psg;
+      const double ck = s.sg * sk * own;                               // true T[lane][k]
+      const double tau = (lane == k) ? pd : ck;                        // column k of the tableau
+      const double alpha = -px * inv;                                  // drives w_k to 0
       s.x = fma(xor_sign(alpha, s.usign), tau, s.x);                   // basic: z −= α·τ, nonbasic: w += α·τ
-      if (lane == k) { s.x = alpha; s.usign = kSign; s.sel = kWood ? 0 : 1; }   // z_k = 0 + α; now basic
+      const double g = (sk * sk) * own * inv;                          // R-units multiplier of this lane's column
+      if (lane == k) {
+        s.x = alpha; s.usign = kSign; s.sel = kWood ? 0 : 1;           // z_k = 0 + α; now basic
+        s.D = -inv;                                                    // T[k][k] = −1/d
+        s.sg = sk * inv;                                               // row/column k scaled by 1/d
+      } else {
+        s.D = fma(-ck * inv, ck, s.D);                                 // T[j][j] −= T[j][k]²/d
+      }
+      double own_next = 0.0;
+      const int kn = (k + 1 < k_end) ? k + 1 : k;                      // (last pivot: a harmless re-publication of column k)
+      {
+        const double rn = Tab<NT>::get_dyn(kn);                        // R[kn][lane] before update k
+        const double cn = bufc[kn];                                    // R[kn][k] (broadcast)
+        own_next = (lane == kn) ? 0.0 : fma(cn, -g, rn);               // the same FMA the update applies to row kn
+        pd = readlane_f64(s.D, kn); psg = readlane_f64(s.sg, kn); px = readlane_f64(s.x, kn);
+      }
+      const unsigned pub_addr = lds_addr(bufn + lane);
       if constexpr (kWood) {
         // dof rows the pivot column reaches: [0, hb)
         const unsigned long long nzd = __ballot(own != 0.0) & ((1ull << NR) - 1ull);
         const int hb = nzd ? 64 - __builtin_clzll(nzd) : 0;
-        pivot<NT, NT, NR>(s, k, false, lane, sPiv, own, ps, inv, hb);
+        rank1_split_rows<NT, NR>(lds_addr(bufc), -g, hb, pub_addr, own_next);
       } else {
-        pivot<NT>(s, k, false, lane, sPiv, own, ps, inv);
+        Tab<NT>::rank1_body_pub(lds_addr(bufc), -g, pub_addr, own_next);   // R[i][lane] −= R[i][k]·g   (row k: published 0)
       }
       MKH_LAP(1);
+      double* t = bufc; bufc = bufn; bufn = t;
+      own = own_next;
     }
     MKH_MARK("phase0_done");
     MKH_TICK();   // 6: tableau built, phase 0 done
