@@ -334,16 +334,25 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   const bool is_dof = lane < nv;
   const int ntab = nv + P0.max_rows;                   // tableau indices in use (upper bound)
 
-  // XCD-aware problem mapping: workgroup g runs on XCD g % 8; XCD x owns rows [x·per, (x+1)·per).
-  int pb_begin = blockIdx.x, pb_end = A.B, pb_stride = gridDim.x;
-  if ((gridDim.x & (kNumXcd - 1)) == 0) {
-    const int per = (A.B + kNumXcd - 1) / kNumXcd;
-    const int xcd = blockIdx.x & (kNumXcd - 1);
-    pb_stride = gridDim.x / kNumXcd;
-    pb_begin = xcd * per + blockIdx.x / kNumXcd;
-    pb_end = min(A.B, (xcd + 1) * per);
-  }
-  for (int pb = pb_begin; pb < pb_end; pb += pb_stride) {
+  // Problem distribution.  QP work varies by ±9 % per problem (active-set pivots), and with a static 32 problems
+  // per wave the slowest wave of a 65 536 batch runs 5.5 % longer than the average one.  So only the first
+  // A.static_rounds rounds are static (problem g + round·grid); the tail of the batch is drawn one problem at a
+  // time from a device-wide ticket counter.  The problem after this one is fixed at the top of the loop, so the
+  // atomic's latency hides behind the current problem.  (Problems share no data: nothing for an XCD-local
+  // mapping to keep in its L2.  Same-address atomics retire at ≈80 M/s, which is why short problems — UR5e —
+  // stay fully static.)
+  int round = 0;
+  auto draw = [&]() -> int {
+    if (round < A.static_rounds) return (int)blockIdx.x + (round++) * (int)gridDim.x;
+    unsigned tk = 0;
+    if (lane == 0) tk = atomicAdd(A.work_counter, 1u);
+    return A.static_rounds * (int)gridDim.x + (int)((unsigned)__builtin_amdgcn_readfirstlane((int)tk) - A.work_base);
+  };
+  int pb_next = draw();
+  for (;;) {
+    const int pb = pb_next;
+    if ((unsigned)pb >= (unsigned)A.B) break;
+    pb_next = draw();
     int status_all = 0;
     long long tc[8];
     long long ta[6] = {0, 0, 0, 0, 0, 0}, tl = 0;   // QP sub-phase cycle sums (profiling)

@@ -88,6 +88,8 @@ struct MkhProblem {
   CollisionPairDev* d_pairs = nullptr;
   DeviceProblem* d_dev = nullptr;   // device copy of `dev` (the kernel reads the descriptor from memory)
   TapArgs* d_taps = nullptr;
+  uint32_t* d_work = nullptr;      // ticket counter of the dynamic problem distribution (never reset)
+  uint32_t work_base = 0;          // first ticket of the next launch
   // staging buffers for host-pointer calls
   double *s_q = nullptr, *s_ft = nullptr, *s_pt = nullptr, *s_ct = nullptr, *s_v = nullptr;
   int32_t* s_status = nullptr;
@@ -508,7 +510,8 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   }
   if (hipMalloc((void**)&p->d_dev, sizeof(DeviceProblem)) != hipSuccess ||
       hipMemcpy(p->d_dev, &p->dev, sizeof(DeviceProblem), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMalloc((void**)&p->d_taps, sizeof(TapArgs)) != hipSuccess)
+      hipMalloc((void**)&p->d_taps, sizeof(TapArgs)) != hipSuccess ||
+      hipMalloc((void**)&p->d_work, sizeof(uint32_t)) != hipSuccess || hipMemset(p->d_work, 0, sizeof(uint32_t)) != hipSuccess)
     return bail(fail(MKH_E_HIP, "descriptor upload failed"));
   *out = p;
   return MKH_OK;
@@ -518,7 +521,7 @@ void mkh_problem_destroy(MkhProblem* p) {
   if (!p) return;
   hipSetDevice(p->model->device);
   hipFree(p->d_frame); hipFree(p->d_posture_cost); hipFree(p->d_cfg_lower); hipFree(p->d_cfg_upper);
-  hipFree(p->d_vel); hipFree(p->d_pairs); hipFree(p->d_dev); hipFree(p->d_taps);
+  hipFree(p->d_vel); hipFree(p->d_pairs); hipFree(p->d_dev); hipFree(p->d_taps); hipFree(p->d_work);
   hipFree(p->s_q); hipFree(p->s_ft); hipFree(p->s_pt); hipFree(p->s_ct); hipFree(p->s_v); hipFree(p->s_status);
   delete p;
 }
@@ -582,8 +585,19 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   }
   const int grid = grid_for_variant(p, a.B, nt, lds);
   snprintf(p->last_kernel, sizeof(p->last_kernel), nr ? "ik_solve_kernel_%d_%d_r%d" : "ik_solve_kernel_%d_%d", nt, feat, nr);
-  if (mkh::launch_variant(nt, nr, feat, grid, lds, stream, p->d_dev, a, dtaps) != 0)
+  SolveArgs al = a;
+  al.work_counter = p->d_work;
+  al.work_base = p->work_base;
+  // 7/8 of each wave's share statically, the tail through the ticket counter (measured on G1, kernel ms by static
+  // sixteenths: 16 → 1.283, 15 → 1.233, 14 → 1.183, 12 → 1.185, 8 → 1.193, 4 → 1.195, 0 → 1.264: the tail needs
+  // ≈4 dynamic rounds to even out, and every wave opening with an atomic costs more than the balance returns);
+  // short problems (the 8-row variants) and thin batches stay static
+  const int per_wave = a.B / grid;
+  al.static_rounds = (nt <= 8 || per_wave < 4) ? INT32_MAX : (per_wave * 7) / 8;
+  if (mkh::launch_variant(nt, nr, feat, grid, lds, stream, p->d_dev, al, dtaps) != 0)
     return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
+  if (al.static_rounds != INT32_MAX)   // tickets: the dynamic tail + one rejected ticket per wave
+    p->work_base += (uint32_t)(a.B - al.static_rounds * grid) + (uint32_t)grid;
   HIP_OK(hipGetLastError());
   return MKH_OK;
 }

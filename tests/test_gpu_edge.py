@@ -149,3 +149,27 @@ def test_low_rank_start_conditioning_gate():
     v2, st2 = weak.solve(q, tg[:, 2:3], stand[None, :], None, dt, 1e-1)       # same handle, larger damping
     assert "_r44" in weak.last_kernel(), weak.last_kernel()
     assert (st2 == 0).all()
+
+
+def test_ticket_counter_survives_many_launches_and_odd_batches():
+    """Problem distribution: 7/8 of every wave's share is static, the tail is drawn from a ticket counter that is
+    never reset (the host advances its base by the tickets a launch consumes).  Batches of every shape, launched back
+    to back on one handle, must return what a fresh handle returns — bitwise."""
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+    import native_configs as nc
+    model = workloads.load_robot("g1")
+    nm = nat.NativeModel(model)
+    B = 40000
+    prob, dt, damping = nc.build("g1_c3", nm, B)
+    rng = np.random.default_rng(7)
+    stand = model.key_qpos[0]
+    q, tg = workloads.make_batch(model, nm, prob, rng, B, base_q=stand)
+    ref, st_ref = prob.solve(q, tg, stand[None, :], None, dt, damping)
+    assert (st_ref == 0).all()
+    for n in (B, 1, 2047, 2048, 2049, 8191, 8192, 16385, 39999, B, 3, B):
+        v, st = prob.solve(q[:n], tg[:n], stand[None, :], None, dt, damping)
+        np.testing.assert_array_equal(v, ref[:n])
+        np.testing.assert_array_equal(st, st_ref[:n])
+    fresh, _ = nc.build("g1_c3", nm, B)[0].solve(q, tg, stand[None, :], None, dt, damping)
+    np.testing.assert_array_equal(fresh, ref)
