@@ -19,7 +19,10 @@
  *     is then asynchronous on `stream`), otherwise HOST pointers (the library
  *     stages through its own pinned/device buffers and returns after completion).
  *   - the library owns everything it allocates; the caller owns every buffer it
- *     passes.  One in-flight call per MkhProblem; distinct problems are independent.
+ *     passes.  One in-flight call per MkhProblem: asynchronous calls on one handle must be
+ *     ordered (same stream, or events) — a handle carries the staging buffers and the ticket
+ *     counter that hands the tail of a batch to idle wavefronts, so two of its launches running
+ *     at the same time would corrupt each other.  Distinct problems are independent.
  *   - per-instance `status` (int32): bit flags MKH_ST_*.
  */
 #ifndef MINKHIP_H_
