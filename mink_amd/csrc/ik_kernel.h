@@ -334,24 +334,40 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   const bool is_dof = lane < nv;
   const int ntab = nv + P0.max_rows;                   // tableau indices in use (upper bound)
 
-  // Problem distribution.  QP work varies by ±9 % per problem (active-set pivots), and with a static 32 problems
-  // per wave the slowest wave of a 65 536 batch runs 5.5 % longer than the average one.  So only the first
-  // A.static_rounds rounds are static (problem g + round·grid); the tail of the batch is drawn one problem at a
-  // time from a device-wide ticket counter.  The problem after this one is fixed at the top of the loop, so the
-  // atomic's latency hides behind the current problem.  (Problems share no data: nothing for an XCD-local
-  // mapping to keep in its L2.  Same-address atomics retire at ≈80 M/s, which is why short problems — UR5e —
-  // stay fully static.)
+  // Problem distribution.  Workgroup g runs on XCD g % 8, and rows are not cache-line aligned (352 B of q, 224 B of
+  // targets, 344 B of v per G1 problem): neighbouring problems share lines, and a line should not be fetched into two
+  // L2s (a round-robin mapping measured 77 MB per launch instead of 61 MB).  So the static part of the batch — the
+  // first A.static_rounds rounds of every wave — is one contiguous row range per XCD.  The rest is drawn one problem
+  // at a time from a device-wide ticket counter: QP work varies by ±9 % per problem (active-set pivots), and with a
+  // static 32 problems per wave the slowest wave of a 65 536 batch ran 5.5 % longer than the average one.  (One
+  // counter for the whole device, not one per XCD: per-XCD tails measured 1.3 % slower — an XCD that runs behind
+  // gets no help.)  The problem after this one is fixed at the top of the loop, so the atomic's latency hides behind
+  // the current problem.  Same-address atomics retire at ≈80 M/s, which is why short problems — UR5e — stay fully
+  // static, and why every wave opening with one costs more than the balance returns.
+  const bool xcd_map = (gridDim.x & (kNumXcd - 1)) == 0;
+  const int n_share = xcd_map ? (int)gridDim.x / kNumXcd : (int)gridDim.x;     // waves that share a row range
+  const int xcd = xcd_map ? (int)blockIdx.x & (kNumXcd - 1) : 0;
+  const int w_local = xcd_map ? (int)blockIdx.x / kNumXcd : (int)blockIdx.x;
+  const bool tickets = A.static_rounds != 0x7fffffff;
+  // rows per XCD range: the static part only (tickets), or the whole batch in eighths (static only)
+  const int per = !xcd_map ? A.B : (tickets ? A.static_rounds * n_share : (A.B + kNumXcd - 1) / kNumXcd);
+  const int pb_first = xcd * per;
+  const int n_own = max(0, min(A.B, pb_first + per) - pb_first);
   int round = 0;
-  auto draw = [&]() -> int {
-    if (round < A.static_rounds) return (int)blockIdx.x + (round++) * (int)gridDim.x;
+  auto draw = [&]() -> int {                                                   // −1: nothing left for this wave
+    if (round < A.static_rounds) {
+      const int local = w_local + (round++) * n_share;
+      return local < n_own ? pb_first + local : -1;
+    }
     unsigned tk = 0;
     if (lane == 0) tk = atomicAdd(A.work_counter, 1u);
-    return A.static_rounds * (int)gridDim.x + (int)((unsigned)__builtin_amdgcn_readfirstlane((int)tk) - A.work_base);
+    const int pb = A.static_rounds * (int)gridDim.x + (int)((unsigned)__builtin_amdgcn_readfirstlane((int)tk) - A.work_base);
+    return (unsigned)pb < (unsigned)A.B ? pb : -1;
   };
   int pb_next = draw();
   for (;;) {
+    if (pb_next < 0) break;
     const int pb = pb_next;
-    if ((unsigned)pb >= (unsigned)A.B) break;
     pb_next = draw();
     int status_all = 0;
     long long tc[8];

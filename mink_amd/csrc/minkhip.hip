@@ -511,7 +511,8 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   if (hipMalloc((void**)&p->d_dev, sizeof(DeviceProblem)) != hipSuccess ||
       hipMemcpy(p->d_dev, &p->dev, sizeof(DeviceProblem), hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc((void**)&p->d_taps, sizeof(TapArgs)) != hipSuccess ||
-      hipMalloc((void**)&p->d_work, sizeof(uint32_t)) != hipSuccess || hipMemset(p->d_work, 0, sizeof(uint32_t)) != hipSuccess)
+      hipMalloc((void**)&p->d_work, 128) != hipSuccess || hipMemset(p->d_work, 0, 128) != hipSuccess ||
+      hipDeviceSynchronize() != hipSuccess)   // (hipMemset may return before the fill has run; launches may come on any stream)
     return bail(fail(MKH_E_HIP, "descriptor upload failed"));
   *out = p;
   return MKH_OK;
@@ -588,15 +589,17 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   SolveArgs al = a;
   al.work_counter = p->d_work;
   al.work_base = p->work_base;
-  // 7/8 of each wave's share statically, the tail through the ticket counter (measured on G1, kernel ms by static
-  // sixteenths: 16 → 1.283, 15 → 1.233, 14 → 1.183, 12 → 1.185, 8 → 1.193, 4 → 1.195, 0 → 1.264: the tail needs
-  // ≈4 dynamic rounds to even out, and every wave opening with an atomic costs more than the balance returns);
-  // short problems (the 8-row variants) and thin batches stay static
+  // Distribution (ik_kernel.h): 7/8 of each wave's share is static — one contiguous row range per XCD — and the tail
+  // of the batch goes through the ticket counter.  Measured on G1 (kernel ms by static sixteenths): 16 → 1.283,
+  // 15 → 1.233, 14 → 1.183, 12 → 1.185, 8 → 1.193, 4 → 1.195, 0 → 1.264: the tail needs ≈4 dynamic rounds to even
+  // out, and every wave opening with an atomic costs more than the balance returns.  Short problems (the 8-row
+  // variants) and thin batches stay static.
   const int per_wave = a.B / grid;
-  al.static_rounds = (nt <= 8 || per_wave < 4) ? INT32_MAX : (per_wave * 7) / 8;
+  const bool dynamic = nt > 8 && per_wave >= 4;
+  al.static_rounds = dynamic ? (per_wave * 7) / 8 : INT32_MAX;
   if (mkh::launch_variant(nt, nr, feat, grid, lds, stream, p->d_dev, al, dtaps) != 0)
     return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
-  if (al.static_rounds != INT32_MAX)   // tickets: the dynamic tail + one rejected ticket per wave
+  if (dynamic)   // tickets: the dynamic tail + one rejected ticket per wave
     p->work_base += (uint32_t)(a.B - al.static_rounds * grid) + (uint32_t)grid;
   HIP_OK(hipGetLastError());
   return MKH_OK;

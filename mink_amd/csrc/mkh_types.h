@@ -113,11 +113,12 @@ struct SolveArgs {
   int32_t* status_out;             // (B,)
   int32_t n_steps;                 // fused outer loop: (solve, q ← q ⊕ v·dt) repeated n_steps times
   double* q_out;                   // (B, nq) configuration after the last step (nullable)
-  // problem distribution: rounds 0..static_rounds−1 are static (wave g takes problem g + round·gridDim.x), the rest
-  // of the batch is handed out dynamically — a wave takes problem static_rounds·gridDim.x + atomicAdd(work_counter,
-  // 1) − work_base until that is ≥ B.  The counter is never reset: a launch consumes exactly
-  // (B − static_rounds·gridDim.x) + gridDim.x tickets and the host advances work_base by that much (unsigned
-  // arithmetic survives the wrap-around).  static_rounds = INT32_MAX: no tickets at all.
+  // problem distribution (ik_kernel.h): the first static_rounds·gridDim.x rows are split into one contiguous range
+  // per XCD and taken statically; the rest of the batch is handed out one problem at a time through the ticket
+  // counter — problem static_rounds·gridDim.x + atomicAdd(work_counter, 1) − work_base until that is ≥ B.  The
+  // counter is never reset: a launch consumes exactly (B − static_rounds·gridDim.x) + gridDim.x tickets and the host
+  // advances work_base by that much (unsigned arithmetic survives the wrap-around).
+  // static_rounds = INT32_MAX: no tickets at all (every XCD owns a contiguous eighth of the batch).
   uint32_t* work_counter;
   uint32_t work_base;
   int32_t static_rounds;
