@@ -30,12 +30,13 @@ sys.path.insert(0, REPO)
 BYTES_PER_SOLVE_G1 = 44 * 8 + 4 * 7 * 8 + 43 * 8 + 4   # q + 4 frame targets + v + status = 924 B
 def issued_flop_per_solve(kernel: str) -> int:
     """Issued fp64 FMA flops of the tableau work per G1 solve (64 lanes x 2 flop per row of a rank-1 update),
-    DESIGN.md §3.1.  Low-rank start (kernel name ends in _r44): 18 residual pivots x NT rows + 13.4 active-set
-    pivots x 44 rows + the 19 x 18 x 44 MACs of Jh·Jhᵀ; direct start: 43 + 13.4 pivots x NT rows + 18 rank-1
-    updates of the H accumulation."""
+    DESIGN.md §3.1.  Low-rank start (kernel name ends in _r44): the 18 residual pivots touch 6 x 34 + 6 x 42 +
+    3 x 50 + 3 x 62 = 792 rows (row-sparse updates: dof prefix 16 / 24 / 32 / 44 + 18 residual rows), 13.4
+    active-set pivots x 44 rows, and the 19 x 18 chain-sparse dot products of Jh·Jhᵀ (≈14 dofs each); direct
+    start: 43 + 13.4 pivots x NT rows + 18 rank-1 updates of the H accumulation."""
     nt = int(kernel.split("_")[3])
     if "_r" in kernel:
-        return int((18 * nt + 13.4 * 44) * 64 * 2 + 19 * 18 * 44 * 2)
+        return int((792 + 13.4 * 44) * 64 * 2 + 19 * 18 * 14 * 2)
     return int((43 + 13.4 + 18) * nt * 64 * 2)
 
 
@@ -71,6 +72,26 @@ def measured_traffic():
             if "traffic_bytes_per_launch" in hbm:
                 best = (hbm["traffic_bytes_per_launch"], os.path.relpath(path, REPO))
         except (OSError, ValueError):
+            pass
+    return best
+
+
+def measured_valu_issue():
+    """What actually bounds the kernel: VALU issue.  From the same committed PMC summary as `traffic`
+    (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the solve dispatches): the share of a wave's cycles in which it issues
+    a VALU instruction, times the two waves that share a SIMD for this kernel.  None without a summary."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "*_g1_b65536_pmc.json"))):
+        try:
+            with open(path) as fh:
+                k = json.load(fh).get("ik_solve_kernel", {})
+            act = k["SQ_ACTIVE_INST_VALU"]["per_dispatch"][1:]
+            cyc = k["SQ_WAVE_CYCLES"]["per_dispatch"][1:]
+            per_wave = sum(act) / sum(cyc)
+            best = {"valu_active_share_of_wave_cycles": per_wave, "waves_per_simd": 2,
+                    "simd_issue_slots_used": 2 * per_wave, "source": os.path.relpath(path, REPO)}
+        except (OSError, ValueError, KeyError, ZeroDivisionError):
             pass
     return best
 
@@ -257,7 +278,9 @@ def main():
                          "fp64_view": {"flop_per_solve": flop,
                                        "achieved_tflops": flop * B / (kern_ms * 1e-3) / 1e12,
                                        "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                                       "frac": flop * B / (kern_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS}},
+                                       "frac": flop * B / (kern_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
+                         # ... and every VALU instruction (PMC): the resource the kernel actually runs out of
+                         "valu_issue_view": measured_valu_issue()},
         }
         if world == 1:
             out["pcie_inclusive_value"] = pcie_inclusive(prob, q_h, tg_h, stand, dt, damping)
