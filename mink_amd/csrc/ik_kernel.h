@@ -360,8 +360,12 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       return local < n_own ? pb_first + local : -1;
     }
     unsigned tk = 0;
-    if (lane == 0) tk = atomicAdd(A.work_counter, 1u);
-    const int pb = A.static_rounds * (int)gridDim.x + (int)((unsigned)__builtin_amdgcn_readfirstlane((int)tk) - A.work_base);
+    if (lane == 0) {
+      tk = atomicAdd(A.work_counter, 1u);
+      // the launch's last ticket (every wave ends on exactly one rejected draw): nobody draws after it
+      if (tk == (unsigned)(A.B - A.static_rounds * (int)gridDim.x) + gridDim.x - 1u) atomicExch(A.work_counter, 0u);
+    }
+    const int pb = A.static_rounds * (int)gridDim.x + __builtin_amdgcn_readfirstlane((int)tk);
     return (unsigned)pb < (unsigned)A.B ? pb : -1;
   };
   int pb_next = draw();

@@ -88,8 +88,7 @@ struct MkhProblem {
   CollisionPairDev* d_pairs = nullptr;
   DeviceProblem* d_dev = nullptr;   // device copy of `dev` (the kernel reads the descriptor from memory)
   TapArgs* d_taps = nullptr;
-  uint32_t* d_work = nullptr;      // ticket counter of the dynamic problem distribution (never reset)
-  uint32_t work_base = 0;          // first ticket of the next launch
+  uint32_t* d_work = nullptr;      // ticket counter of the dynamic problem distribution (zeroed by the kernel's last draw)
   // staging buffers for host-pointer calls
   double *s_q = nullptr, *s_ft = nullptr, *s_pt = nullptr, *s_ct = nullptr, *s_v = nullptr;
   int32_t* s_status = nullptr;
@@ -588,7 +587,6 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   snprintf(p->last_kernel, sizeof(p->last_kernel), nr ? "ik_solve_kernel_%d_%d_r%d" : "ik_solve_kernel_%d_%d", nt, feat, nr);
   SolveArgs al = a;
   al.work_counter = p->d_work;
-  al.work_base = p->work_base;
   // Distribution (ik_kernel.h): 7/8 of each wave's share is static — one contiguous row range per XCD — and the tail
   // of the batch goes through the ticket counter.  Measured on G1 (kernel ms by static sixteenths): 16 → 1.283,
   // 15 → 1.233, 14 → 1.183, 12 → 1.185, 8 → 1.193, 4 → 1.195, 0 → 1.264: the tail needs ≈4 dynamic rounds to even
@@ -599,8 +597,6 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   al.static_rounds = dynamic ? (per_wave * 7) / 8 : INT32_MAX;
   if (mkh::launch_variant(nt, nr, feat, grid, lds, stream, p->d_dev, al, dtaps) != 0)
     return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
-  if (dynamic)   // tickets: the dynamic tail + one rejected ticket per wave
-    p->work_base += (uint32_t)(a.B - al.static_rounds * grid) + (uint32_t)grid;
   HIP_OK(hipGetLastError());
   return MKH_OK;
 }

@@ -115,12 +115,12 @@ struct SolveArgs {
   double* q_out;                   // (B, nq) configuration after the last step (nullable)
   // problem distribution (ik_kernel.h): the first static_rounds·gridDim.x rows are split into one contiguous range
   // per XCD and taken statically; the rest of the batch is handed out one problem at a time through the ticket
-  // counter — problem static_rounds·gridDim.x + atomicAdd(work_counter, 1) − work_base until that is ≥ B.  The
-  // counter is never reset: a launch consumes exactly (B − static_rounds·gridDim.x) + gridDim.x tickets and the host
-  // advances work_base by that much (unsigned arithmetic survives the wrap-around).
+  // counter — problem static_rounds·gridDim.x + atomicAdd(work_counter, 1) until that is ≥ B.  A launch draws
+  // exactly (B − static_rounds·gridDim.x) + gridDim.x tickets (every wave ends on one rejected draw); whoever
+  // draws the last of them knows that no draw is outstanding and zeroes the counter, so every launch starts from
+  // zero with no host-side state: a launch can be replayed (hipGraph) or fail without consequences.
   // static_rounds = INT32_MAX: no tickets at all (every XCD owns a contiguous eighth of the batch).
   uint32_t* work_counter;
-  uint32_t work_base;
   int32_t static_rounds;
 };
 

@@ -152,9 +152,9 @@ def test_low_rank_start_conditioning_gate():
 
 
 def test_ticket_counter_survives_many_launches_and_odd_batches():
-    """Problem distribution: 7/8 of every wave's share is static, the tail is drawn from a ticket counter that is
-    never reset (the host advances its base by the tickets a launch consumes).  Batches of every shape, launched back
-    to back on one handle, must return what a fresh handle returns — bitwise."""
+    """Problem distribution: 7/8 of every wave's share is static, the tail is drawn from a ticket counter that the
+    launch's last draw zeroes for the next one.  Batches of every shape, launched back to back on one handle,
+    must return what a fresh handle returns — bitwise."""
     from mink_amd import _native as nat
     from mink_amd import workloads
     import native_configs as nc
