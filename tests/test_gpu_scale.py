@@ -153,3 +153,40 @@ def test_g1_full_batch_against_c_oracle(g1_setup):
     err = np.abs(v - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
     print("G1 B=65536 vs C oracle: max rel err %.2e, p99 %.2e (kernel %s)" % (err.max(), np.percentile(err, 99), prob.last_kernel()))
     assert err.max() < 1e-8
+
+
+def test_launches_replay_inside_a_hip_graph(g1_setup):
+    """Device-pointer solves are plain asynchronous launches with no host-side state (the ticket counter of the
+    dynamic tail is zeroed by the launch's last draw): captured into a hipGraph through torch and replayed, they
+    return what the eager calls return — bitwise, every replay."""
+    torch = pytest.importorskip("torch")
+    model, nm, prob, dt, damping, q, tg, stand = g1_setup
+    dev = torch.device("cuda", 0)
+    n = 16384                                   # 8 problems per wave: static rounds + ticket tail
+    q_d = torch.from_numpy(q[:n]).to(dev)
+    tg_d = torch.from_numpy(tg[:n]).to(dev)
+    pt_d = torch.from_numpy(stand[None, :].copy()).to(dev)
+    v_ref, st_ref = prob.solve(q_d, tg_d, pt_d, None, dt, damping)
+    torch.cuda.synchronize()
+    outs = [torch.zeros_like(v_ref) for _ in range(3)]
+    sts = [torch.zeros_like(st_ref) for _ in range(3)]
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):               # warm-up on the capture stream, as torch asks
+        prob.solve(q_d, tg_d, pt_d, None, dt, damping, out=outs[0], status_out=sts[0])
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for o, s in zip(outs, sts):
+            prob.solve(q_d, tg_d, pt_d, None, dt, damping, out=o, status_out=s)
+    for _ in range(3):
+        for o in outs:
+            o.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for o, s in zip(outs, sts):
+            assert torch.equal(o, v_ref) and torch.equal(s, st_ref)
+    v_again, _ = prob.solve(q_d, tg_d, pt_d, None, dt, damping)      # and eager launches still work afterwards
+    torch.cuda.synchronize()
+    assert torch.equal(v_again, v_ref)
