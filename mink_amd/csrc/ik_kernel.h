@@ -954,28 +954,28 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         const double* a = sJ + wc * NR;
         const uint64_t chain = P.wood_mask[ol];
         const int rpc = P.wood_rpc;
-        // four rows per pass: the lane's own column entry is read once per pass
-        for (int i0 = 0; i0 < rpc; i0 += 4) {
+        // eight rows per pass (one pass for G1's 7 rows per lane): the lane's own column entry is read once per
+        // pass, and the walk over the chain bits — a dependent ffs → address → LDS read → FMA chain per bit, which
+        // is what this loop costs — runs once instead of once per four rows
+        for (int i0 = 0; i0 < rpc; i0 += 8) {
           const int row0 = wr0 + i0;
           if (row0 > n_mu) break;
           // product row → LDS row: Jh rows 0..n_μ−1, then the right-hand-side vector stored in row SP
-          auto rowp = [&](int r) { return sJ + (r < n_mu ? r : SP) * NR; };
-          const double *b0 = rowp(row0), *b1 = rowp(row0 + 1), *b2 = rowp(row0 + 2), *b3 = rowp(row0 + 3);
-          double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+          const double* b[8];
+          double acc[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { const int r = row0 + j; b[j] = sJ + (r < n_mu ? r : SP) * NR; acc[j] = 0.0; }
           for (uint64_t mk = chain; mk; mk &= mk - 1) {
             const int k = __ffsll((unsigned long long)mk) - 1;
             const double av = a[k];
-            acc0 = fma(av, b0[k], acc0);
-            acc1 = fma(av, b1[k], acc1);
-            acc2 = fma(av, b2[k], acc2);
-            acc3 = fma(av, b3[k], acc3);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fma(av, b[j][k], acc[j]);
           }
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < 8; ++j) {
             const int row = row0 + j;
-            const double acc = (j == 0) ? acc0 : (j == 1) ? acc1 : (j == 2) ? acc2 : acc3;
             if (i0 + j < rpc && row <= n_mu) {
-              if (row < n_mu) sS[wc * SP + row] = -acc; else sW[wc] = acc;
+              if (row < n_mu) sS[wc * SP + row] = -acc[j]; else sW[wc] = acc[j];
             }
           }
         }
