@@ -15,7 +15,7 @@ register numbers:
 
 Register map for NT rows (wave64; TOP = 256 VGPRs per lane at 2 waves/SIMD, 168 at 3 (NT ≤ 24), 128 at 4 (NT ≤ 8)):
     v[TOP-2·NT, TOP)              tableau column (NT doubles)
-    v[TOP-2·NT-S, TOP-2·NT)       LDS staging for rank1 (S = 32: 8 × 128 bit in flight; S = 16 for NT ≥ 56 or ≤ 24)
+    v[TOP-2·NT-S, TOP-2·NT)       LDS staging for rank1 (S = 32: 8 × 128 bit in flight; S = 24 for NT ≥ 56, 16 for NT ≤ 24)
     v[0, TOP-2·NT-S)              everything the compiler allocates
 
 The staging range must stay ABOVE the compiler's cap even though half of it is only live inside one asm
@@ -34,9 +34,10 @@ def total_for(nt):
     return 128 if nt <= 8 else (168 if nt <= 24 else 256)
 NRS = (16, 24, 32, 44, 48)   # dof-row counts of the low-rank start (kernel variants MKH_NR)
 def ntmp_for(nt):
-    # staging registers: 8 x b128 in flight, or 4 for the widest tableaus (the compiler needs the
-    # 16 registers more than the rank-1 update needs the deeper pipeline: measured on G1)
-    return 16 if (nt >= 56 or nt <= 24) else 32
+    # staging registers: 8 x b128 in flight, or 6 for the widest tableaus, where the compiler needs the registers
+    # (measured on G1, NT = 62, kernel ms: 4 in flight 1.168, 6 in flight 1.160 — still spill-free —, 8 in flight
+    # 1.167 with 6 spilled VGPRs); 4 for the narrow tableaus that run 3 or 4 waves per SIMD
+    return 24 if nt >= 56 else (16 if nt <= 24 else 32)
 SPLIT_PREFIXES = (16, 24, 32)   # dof-row prefixes of the split rank-1 bodies (phase 0 of the low-rank start)
 NPRE = 4   # loads issued by rank1_prefetch (their 16 registers are off limits to the compiler)
 

@@ -36,9 +36,10 @@ def max_compiler_vgpr(asm_text: str) -> int:
 def check(src: str):
     sys.path.insert(0, os.path.join(REPO, "mink_amd", "csrc"))
     import build as hipbuild
+    import gen_tab_asm as gen
     nt = int(re.search(r"variant_(\d+)_", os.path.basename(src)).group(1))
-    top = 128 if nt <= 8 else (168 if nt <= 24 else 256)       # gen_tab_asm.py total_for
-    cap = top - 2 * nt - (16 if (nt >= 56 or nt <= 24) else 32)
+    top = gen.total_for(nt)
+    cap = top - 2 * nt - gen.ntmp_for(nt)
     out = subprocess.run([hipbuild._hipcc()] + hipbuild.FLAGS + hipbuild.KERNEL_FLAGS +
                          ["-S", "--cuda-device-only", "-o", "-", src], check=True, capture_output=True, text=True).stdout
     mx = max_compiler_vgpr(out)
