@@ -69,7 +69,7 @@ typedef struct MkhProblem MkhProblem;
 
 /*
  * One-time flattened copy of the mjModel kinematic tree: the mjModel fields the
- * reference hot path reads (mink/configuration.py:53-155, limits/*.py constructors,
+ * reference hot path reads (mink/configuration.py:53-155, limits/ constructors,
  * tasks/posture_task.py:44).  Field names/semantics are MuJoCo's.  Host pointers;
  * copied at mkh_model_create.
  */

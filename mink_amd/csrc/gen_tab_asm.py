@@ -9,8 +9,10 @@ kernel's VGPR total), and the four operations that touch it are emitted here wit
 register numbers:
 
     zero()                    T[i] = 0
-    rank1(lds_addr, g)        T[i] += lds[i]·g      software-pipelined ds_read_b128 + v_fma_f64
-    publish(lds_addr)         lds[i] = T[i]         (caller masks exec to the owning lane)
+    rank1_prefetch / rank1_body*(lds_addr, g)   T[i] += lds[i]·g   software-pipelined ds_read_b128 + v_fma_f64
+                              (row-range variants; *_pub variants also store the next pivot column's entry)
+    load_*(lds_addr)          T[i] = lds[i]         whole column / leading rows / residual rows
+    get_dyn(k) / set_dyn(k,x) single element, wave-uniform runtime index (VGPR index mode)
     get<I>() / set<I>(x)      single element, compile-time index (tableau build, taps)
 
 Register map for NT rows (wave64; TOP = 256 VGPRs per lane at 2 waves/SIMD, 168 at 3 (NT ≤ 24), 128 at 4 (NT ≤ 8)):
@@ -129,17 +131,6 @@ def gen(nt: int) -> str:
     out.append("  __device__ static __forceinline__ void rank1_body_pub(unsigned lds_addr, double g, unsigned pub_addr, double pub) {")
     out.append(f'    asm volatile("{body_pub}"')
     out.append(f'                 :: "v"(lds_addr), "v"(g), "v"(pub_addr), "v"(pub) : {clob_t}, {clob_tmp}, "memory");')
-    out.append("  }")
-    out.append("  __device__ static __forceinline__ void rank1(unsigned lds_addr, double g) {")
-    out.append("    rank1_prefetch(lds_addr);")
-    out.append("    rank1_body(lds_addr, g);")
-    out.append("  }")
-    # publish
-    lines = [f"ds_write_b64 %0, {treg(i)} offset:{8 * i}" for i in range(nt)]
-    lines.append("s_waitcnt lgkmcnt(0)")
-    body = "\\n\\t".join(lines)
-    out.append("  __device__ static __forceinline__ void publish(unsigned lds_addr) {")
-    out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : "memory");')
     out.append("  }")
     # dynamic row read through the VGPR index mode (uniform runtime index, pinned base register)
     out.append("  // T[k] for a wave-uniform runtime k: s_set_gpr_idx_on + v_mov_b32 relative to the pinned base.")

@@ -275,9 +275,9 @@ int32_t mkh_model_create(const MkhFlatModel* h, int32_t device, MkhModel** out) 
 
 void mkh_model_destroy(MkhModel* m) {
   if (!m) return;
-  hipSetDevice(m->device);
-  hipFree(m->d_body_f); hipFree(m->d_body_i); hipFree(m->d_jnt_f); hipFree(m->d_jnt_i);
-  hipFree(m->d_dof_i); hipFree(m->d_dof_f);
+  (void)hipSetDevice(m->device);
+  (void)hipFree(m->d_body_f); (void)hipFree(m->d_body_i); (void)hipFree(m->d_jnt_f); (void)hipFree(m->d_jnt_i);
+  (void)hipFree(m->d_dof_i); (void)hipFree(m->d_dof_f);
   delete m;
 }
 
@@ -519,10 +519,10 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
 
 void mkh_problem_destroy(MkhProblem* p) {
   if (!p) return;
-  hipSetDevice(p->model->device);
-  hipFree(p->d_frame); hipFree(p->d_posture_cost); hipFree(p->d_cfg_lower); hipFree(p->d_cfg_upper);
-  hipFree(p->d_vel); hipFree(p->d_pairs); hipFree(p->d_dev); hipFree(p->d_taps); hipFree(p->d_work);
-  hipFree(p->s_q); hipFree(p->s_ft); hipFree(p->s_pt); hipFree(p->s_ct); hipFree(p->s_v); hipFree(p->s_status);
+  (void)hipSetDevice(p->model->device);
+  (void)hipFree(p->d_frame); (void)hipFree(p->d_posture_cost); (void)hipFree(p->d_cfg_lower); (void)hipFree(p->d_cfg_upper);
+  (void)hipFree(p->d_vel); (void)hipFree(p->d_pairs); (void)hipFree(p->d_dev); (void)hipFree(p->d_taps); (void)hipFree(p->d_work);
+  (void)hipFree(p->s_q); (void)hipFree(p->s_ft); (void)hipFree(p->s_pt); (void)hipFree(p->s_ct); (void)hipFree(p->s_v); (void)hipFree(p->s_status);
   delete p;
 }
 
@@ -650,8 +650,8 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
   HIP_OK(ensure(&p->s_ft, mb * P.n_frame * 7));
   HIP_OK(ensure(&p->s_v, mb * nv));
   HIP_OK(ensure(&p->s_status, mb));
-  if (n_pt > p->s_pt_cap) { hipFree(p->s_pt); p->s_pt = nullptr; HIP_OK(hipMalloc((void**)&p->s_pt, n_pt * sizeof(double))); p->s_pt_cap = n_pt; }
-  if (n_ct > p->s_ct_cap) { hipFree(p->s_ct); p->s_ct = nullptr; HIP_OK(hipMalloc((void**)&p->s_ct, n_ct * sizeof(double))); p->s_ct_cap = n_ct; }
+  if (n_pt > p->s_pt_cap) { (void)hipFree(p->s_pt); p->s_pt = nullptr; HIP_OK(hipMalloc((void**)&p->s_pt, n_pt * sizeof(double))); p->s_pt_cap = n_pt; }
+  if (n_ct > p->s_ct_cap) { (void)hipFree(p->s_ct); p->s_ct = nullptr; HIP_OK(hipMalloc((void**)&p->s_ct, n_ct * sizeof(double))); p->s_ct_cap = n_ct; }
   HIP_OK(hipMemcpyAsync(p->s_q, q, (size_t)B * nq * sizeof(double), hipMemcpyHostToDevice, stream));
   if (P.n_frame) HIP_OK(hipMemcpyAsync(p->s_ft, frame_targets, (size_t)B * P.n_frame * 7 * sizeof(double), hipMemcpyHostToDevice, stream));
   if (n_pt) HIP_OK(hipMemcpyAsync(p->s_pt, posture_target, n_pt * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -665,8 +665,8 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
     if (!host || rc != MKH_OK) return nullptr;
     void* dptr = nullptr;
     if (hipMalloc(&dptr, bytes ? bytes : 1) != hipSuccess) { rc = fail(MKH_E_HIP, "tap buffer allocation failed"); return nullptr; }
-    if (zero) hipMemsetAsync(dptr, 0, bytes, stream);
-    tb.push_back({host, dptr, bytes});
+    tb.push_back({host, dptr, bytes});               // (freed at the end of the call whatever happens next)
+    if (zero && hipMemsetAsync(dptr, 0, bytes, stream) != hipSuccess) { rc = fail(MKH_E_HIP, "tap buffer clear failed"); return nullptr; }
     return dptr;
   };
   if (taps) {
@@ -698,7 +698,7 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) rc = fail(MKH_E_HIP, "solve: %s", hipGetErrorString(e));
   }
-  for (auto& t : tb) hipFree(t.dev);
+  for (auto& t : tb) (void)hipFree(t.dev);
   return rc;
 }
 
@@ -756,7 +756,7 @@ int32_t mkh_integrate(MkhModel* m, int32_t B, const double* q, const double* v, 
   }
   if (e == hipSuccess) e = hipMemcpyAsync(q_out, dout, bq, hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
-  hipFree(dq); hipFree(dv); hipFree(dout);
+  (void)hipFree(dq); (void)hipFree(dv); (void)hipFree(dout);
   if (e != hipSuccess) return fail(MKH_E_HIP, "integrate: %s", hipGetErrorString(e));
   return MKH_OK;
 }
