@@ -173,3 +173,53 @@ def test_ticket_counter_survives_many_launches_and_odd_batches():
         np.testing.assert_array_equal(st, st_ref[:n])
     fresh, _ = nc.build("g1_c3", nm, B)[0].solve(q, tg, stand[None, :], None, dt, damping)
     np.testing.assert_array_equal(fresh, ref)
+
+
+def _chain_xml(n_links, seed=0):
+    rng = np.random.default_rng(seed)
+    xml = ['<mujoco><compiler angle="radian"/><worldbody>']
+    for i in range(n_links):
+        ax = rng.normal(size=3)
+        ax /= np.linalg.norm(ax)
+        xml.append(f'<body name="b{i}" pos="{0.03 + 0.02 * rng.uniform():.4f} {0.01 * rng.normal():.4f} {0.01 * rng.normal():.4f}">'
+                   f'<joint name="j{i}" type="hinge" axis="{ax[0]:.5f} {ax[1]:.5f} {ax[2]:.5f}" range="-1.5 1.5"/>'
+                   f'<geom type="sphere" size="0.01" mass="0.1"/>')
+    xml.append('<site name="tip" pos="0.02 0 0"/>')
+    xml.append("</body>" * n_links)
+    xml.append("</worldbody></mujoco>")
+    return "".join(xml)
+
+
+def test_maximum_sizes_of_one_wavefront():
+    """The one-wavefront limits (SURVEY §8a sizes): 64 bodies / 64 dofs.  A 63-link serial chain
+    (64 bodies with the world, nv = 63, tree depth 63 ⇒ 6 pointer-jumping rounds, 64-row tableau) solves to oracle
+    accuracy; one link more is refused with a clear error instead of a wrong answer."""
+    import mink_amd as mink
+    from oracle import cport
+    from oracle import ik as oik
+    m = mink.loads_mjcf(_chain_xml(63))
+    assert m.nbody == 64 and m.nv == 63
+    rng = np.random.default_rng(1)
+    B = 64
+    q = rng.uniform(-0.6, 0.6, size=(B, m.nq))
+    cfg = mink.Configuration(m, q)
+    tgt = mink.Configuration(m, q + rng.normal(scale=0.05, size=q.shape))
+    ft = mink.FrameTask("tip", "site", position_cost=1.0, orientation_cost=0.5, lm_damping=1.0)
+    ft.set_target(tgt.get_transform_frame_to_world("tip", "site"))
+    post = mink.PostureTask(m, cost=1e-1)
+    post.set_target(np.zeros(m.nq))
+    lims = [mink.ConfigurationLimit(m), mink.VelocityLimit(m, {f"j{i}": 2.0 for i in range(63)})]
+    dt, damping = 1e-2, 1e-3
+    v = mink.solve_ik(cfg, [ft, post], dt, "mi355x", damping, limits=lims)
+    ts = [oik.FrameTaskSpec(m.name2id("site", "tip"), "site", ft.cost, ft.transform_target_to_world.wxyz_xyz[0], 1.0, 1.0),
+          oik.PostureTaskSpec(post.cost, post.target_q, 1.0)]
+    ls = [oik.ConfigurationLimitSpec(), oik.VelocityLimitSpec(lims[1].indices, lims[1].limit)]
+    v_c, st_c = cport.CProblem(m, ts, ls).solve_batch(q, ft.transform_target_to_world.wxyz_xyz[:, None, :],
+                                                        post.target_q[None, :], dt, damping)
+    assert (st_c == 0).all()
+    err = np.abs(v - v_c).max(axis=1) / np.maximum(1.0, np.abs(v_c).max(axis=1))
+    print("63-dof chain vs C oracle: max rel err %.2e" % err.max())
+    assert err.max() < 1e-7
+    with pytest.raises(Exception, match="one-wavefront limit"):
+        big = mink.loads_mjcf(_chain_xml(64))
+        mink.Configuration(big, np.zeros((1, big.nq))).native          # the device model is created on first use
