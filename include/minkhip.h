@@ -243,7 +243,9 @@ int32_t mkh_eval(MkhProblem *problem, int32_t B, const double *q, const double *
 int32_t mkh_integrate(MkhModel *model, int32_t B, const double *q, const double *v, double dt,
                       double *q_out, int32_t flags, void *hip_stream);
 
-/* Launch geometry actually used for a batch of B (for benchmarks / occupancy reports). */
+/* Launch geometry of the most recent solve / eval on this problem (the kernel variant depends on the call; see
+ * mkh_problem_last_kernel); before any launch, that of the lean direct variant for a batch of B.  For benchmarks
+ * and occupancy reports. */
 int32_t mkh_problem_launch_info(const MkhProblem *problem, int32_t B, int32_t *grid, int32_t *block,
                                 int32_t *lds_bytes, int32_t *tableau_rows);
 

@@ -88,6 +88,7 @@ struct MkhProblem {
   CollisionPairDev* d_pairs = nullptr;
   DeviceProblem* d_dev = nullptr;   // device copy of `dev` (the kernel reads the descriptor from memory)
   TapArgs* d_taps = nullptr;
+  int last_grid = 0, last_lds = 0, last_nt = 0;   // geometry of the most recent launch (mkh_problem_launch_info)
   uint32_t* d_work = nullptr;      // ticket counter of the dynamic problem distribution (zeroed by the kernel's last draw)
   // staging buffers for host-pointer calls
   double *s_q = nullptr, *s_ft = nullptr, *s_pt = nullptr, *s_ct = nullptr, *s_v = nullptr;
@@ -542,10 +543,12 @@ static int grid_for_variant(const MkhProblem* p, int B, int nt, int lds) {
 int32_t mkh_problem_launch_info(const MkhProblem* p, int32_t B, int32_t* grid, int32_t* block, int32_t* lds_bytes,
                                 int32_t* tableau_rows) {
   if (!p) return fail(MKH_E_INVALID, "null problem");
-  if (grid) *grid = grid_for(p, B);
+  // what the most recent launch of this problem used (the variant depends on the call: taps, fused steps, the
+  // low-rank QP start); before any launch, the lean direct variant
+  if (grid) *grid = p->last_nt ? p->last_grid : grid_for(p, B);
   if (block) *block = kWave;
-  if (lds_bytes) *lds_bytes = p->lds_bytes;
-  if (tableau_rows) *tableau_rows = p->nt;
+  if (lds_bytes) *lds_bytes = p->last_nt ? p->last_lds : p->lds_bytes;
+  if (tableau_rows) *tableau_rows = p->last_nt ? p->last_nt : p->nt;
   return MKH_OK;
 }
 
@@ -584,6 +587,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
     feat = F_WOOD | (need & (F_STEPS | F_TAPS));
   }
   const int grid = grid_for_variant(p, a.B, nt, lds);
+  p->last_grid = grid; p->last_lds = lds; p->last_nt = nt;
   snprintf(p->last_kernel, sizeof(p->last_kernel), nr ? "ik_solve_kernel_%d_%d_r%d" : "ik_solve_kernel_%d_%d", nt, feat, nr);
   SolveArgs al = a;
   al.work_counter = p->d_work;
