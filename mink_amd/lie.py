@@ -8,6 +8,7 @@ SE3.wxyz_xyz (..., 7).  Tangents are (v, ω) for SE3 as in the reference (se3.py
 
 from __future__ import annotations
 
+import abc
 from dataclasses import dataclass
 
 import numpy as np
@@ -265,3 +266,45 @@ class SE3:
     def plus(self, t): return self.rplus(t)
     def lplus(self, t): return SE3.exp(t) @ self
     def lminus(self, other): return (self @ other.inverse()).log()
+
+
+class MatrixLieGroup(abc.ABC):
+    """Interface shared by SO3 and SE3 (mink/lie/base.py:8-156).  The two groups are frozen dataclasses with
+    batched parameters; they are registered as virtual subclasses, so `isinstance(x, MatrixLieGroup)` and
+    annotations written against the reference keep working."""
+
+    matrix_dim: int
+    parameters_dim: int
+    tangent_dim: int
+    space_dim: int
+
+    @classmethod
+    @abc.abstractmethod
+    def identity(cls): ...
+
+    @classmethod
+    @abc.abstractmethod
+    def from_matrix(cls, matrix): ...
+
+    @classmethod
+    @abc.abstractmethod
+    def exp(cls, tangent): ...
+
+    @abc.abstractmethod
+    def as_matrix(self): ...
+
+    @abc.abstractmethod
+    def parameters(self): ...
+
+    @abc.abstractmethod
+    def log(self): ...
+
+    @abc.abstractmethod
+    def inverse(self): ...
+
+    @abc.abstractmethod
+    def adjoint(self): ...
+
+
+MatrixLieGroup.register(SO3)
+MatrixLieGroup.register(SE3)

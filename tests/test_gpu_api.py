@@ -321,3 +321,26 @@ def test_frame_task_remaining_reference_behaviours(g1):
     H1, c1 = damped.compute_qp_objective(cfg)
     np.testing.assert_allclose(H1, H0, atol=1e-13)
     np.testing.assert_allclose(c1, c0, atol=1e-13)
+
+
+def test_move_mocap_to_frame():
+    """reference tests/test_utils.py:61-98: the mocap body lands on the frame's pose (Configuration stands where
+    the reference has MjData)."""
+    xml = """<mujoco><worldbody>
+      <body pos=".1 -.1 0"><joint type="free" name="floating"/><geom type="sphere" size=".1" mass=".1"/>
+        <body name="test"><joint type="hinge" name="hinge" range="0 1.57" limited="true"/>
+          <geom type="sphere" size=".1" mass=".1"/></body></body>
+      <body name="mocap" mocap="true" pos=".5 1 5" quat="1 1 0 0"><geom type="sphere" size=".1" mass=".1"/></body>
+    </worldbody></mujoco>"""
+    m = mink.loads_mjcf(xml)
+    q = m.qpos0.copy()
+    q[:3] = [0.3, -0.2, 0.7]
+    q[3:7] = np.array([0.8, 0.2, -0.4, 0.1]) / np.linalg.norm([0.8, 0.2, -0.4, 0.1])
+    q[7] = 0.5
+    cfg = mink.Configuration(m, q)
+    body = cfg.get_transform_frame_to_world("test", "body").wxyz_xyz
+    mid = int(m.body_mocapid[m.name2id("body", "mocap")])
+    assert not np.allclose(m.mocap_pos[mid], body[4:])
+    mink.move_mocap_to_frame(m, cfg, "mocap", "test", "body")
+    np.testing.assert_allclose(m.mocap_pos[mid], body[4:])
+    np.testing.assert_allclose(m.mocap_quat[mid], body[:4])
