@@ -23,6 +23,12 @@ def _qmul(a, b):
                      aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], axis=-1)
 
 
+def get_epsilon(dtype) -> float:
+    """mink/lie/utils.py:4-8: the small-angle threshold of the log / Jacobian branches (the device code uses the
+    float64 value)."""
+    return {np.dtype("float32"): 1e-5, np.dtype("float64"): 1e-10}[np.dtype(dtype)]
+
+
 def skew(x):
     x = np.asarray(x, dtype=np.float64)
     z = np.zeros_like(x[..., 0])
@@ -266,6 +272,9 @@ class SE3:
     def plus(self, t): return self.rplus(t)
     def lplus(self, t): return SE3.exp(t) @ self
     def lminus(self, other): return (self @ other.inverse()).log()
+
+
+__all__ = ("SE3", "SO3", "MatrixLieGroup", "get_epsilon", "skew")
 
 
 class MatrixLieGroup(abc.ABC):
