@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import abc
 from dataclasses import dataclass
+from typing import NamedTuple
 
 import numpy as np
 
@@ -34,6 +35,13 @@ def skew(x):
     z = np.zeros_like(x[..., 0])
     return np.stack([np.stack([z, -x[..., 2], x[..., 1]], -1), np.stack([x[..., 2], z, -x[..., 0]], -1),
                      np.stack([-x[..., 1], x[..., 0], z], -1)], -2)
+
+
+class RollPitchYaw(NamedTuple):
+    """Roll, pitch and yaw Euler angles (mink/lie/so3.py:16-21)."""
+    roll: float
+    pitch: float
+    yaw: float
 
 
 @dataclass(frozen=True)
@@ -149,6 +157,56 @@ class SO3:
 
     def adjoint(self):
         return self.as_matrix()
+
+    # ---- Euler angles (mink/lie/so3.py:116-134)
+    def compute_roll_radians(self):
+        q0, q1, q2, q3 = np.moveaxis(self.wxyz, -1, 0)
+        return np.arctan2(2 * (q0 * q1 + q2 * q3), 1 - 2 * (q1 ** 2 + q2 ** 2))
+
+    def compute_pitch_radians(self):
+        q0, q1, q2, q3 = np.moveaxis(self.wxyz, -1, 0)
+        return np.arcsin(2 * (q0 * q2 - q3 * q1))
+
+    def compute_yaw_radians(self):
+        q0, q1, q2, q3 = np.moveaxis(self.wxyz, -1, 0)
+        return np.arctan2(2 * (q0 * q3 + q1 * q2), 1 - 2 * (q2 ** 2 + q3 ** 2))
+
+    def as_rpy_radians(self):
+        return RollPitchYaw(roll=self.compute_roll_radians(), pitch=self.compute_pitch_radians(),
+                            yaw=self.compute_yaw_radians())
+
+    # ---- Jacobians of exp (mink/lie/so3.py:199-226, base.py:146-156); tangents may carry batch dimensions.  The
+    # Taylor branch is taken where θ < 1e-10, like the reference (θ itself, not θ²).
+    @classmethod
+    def ljac(cls, other):
+        t = np.asarray(other, dtype=np.float64)
+        th = np.sqrt((t * t).sum(-1))[..., None, None]
+        small = th < _EPS
+        ths = np.where(small, 1.0, th)
+        t2 = th * th
+        A = np.where(small, 0.5 * (1.0 - t2 / 12.0 * (1.0 - t2 / 30.0 * (1.0 - t2 / 56.0))), (1 - np.cos(ths)) / ths ** 2)
+        B = np.where(small, (1.0 / 6.0) * (1.0 - t2 / 20.0 * (1.0 - t2 / 42.0 * (1.0 - t2 / 72.0))),
+                     (ths - np.sin(ths)) / ths ** 3)
+        S = skew(t)
+        return np.eye(3) + A * S + B * (S @ S)
+
+    @classmethod
+    def ljacinv(cls, other):
+        t = np.asarray(other, dtype=np.float64)
+        th = np.sqrt((t * t).sum(-1))[..., None, None]
+        small = th < _EPS
+        ths = np.where(small, 1.0, th)
+        t2 = th * th
+        A = np.where(small, (1.0 / 12.0) * (1.0 + t2 / 60.0 * (1.0 + t2 / 42.0 * (1.0 + t2 / 40.0))),
+                     (1.0 / ths ** 2) * (1.0 - ths * np.sin(ths) / (2.0 * (1.0 - np.cos(ths)))))
+        S = skew(t)
+        return np.eye(3) - 0.5 * S + A * (S @ S)
+
+    @classmethod
+    def rjac(cls, other): return cls.ljac(-np.asarray(other, dtype=np.float64))
+    @classmethod
+    def rjacinv(cls, other): return cls.ljacinv(-np.asarray(other, dtype=np.float64))
+    def jlog(self): return SO3.rjacinv(self.log())
 
     def rminus(self, other): return (other.inverse() @ self).log()
     def minus(self, other): return self.rminus(other)
@@ -266,6 +324,62 @@ class SE3:
         A[..., 3:, 3:] = R
         return A
 
+    # ---- mocap bodies (mink/lie/se3.py:77-91): the pose of a mocap body of the model (the reference reads MjData)
+    @classmethod
+    def from_mocap_id(cls, model, mocap_id: int):
+        return cls(np.concatenate([np.asarray(model.mocap_quat[mocap_id], dtype=np.float64),
+                                   np.asarray(model.mocap_pos[mocap_id], dtype=np.float64)]))
+
+    @classmethod
+    def from_mocap_name(cls, model, mocap_name: str):
+        from .exceptions import InvalidMocapBody
+        body = model.name2id("body", mocap_name)
+        if body < 0 or int(model.body_mocapid[body]) == -1:
+            raise InvalidMocapBody(mocap_name, model)
+        return cls.from_mocap_id(model, int(model.body_mocapid[body]))
+
+    # ---- Jacobians of exp (mink/lie/se3.py:196-249): blocks [[J, Q],[0, J]] with Barfoot's Q; identity where θ² < 1e-10
+    @staticmethod
+    def _Q(c):
+        v, w = c[..., :3], c[..., 3:]
+        th2 = (w * w).sum(-1)[..., None, None]
+        small = th2 < _EPS
+        th2s = np.where(small, 1.0, th2)
+        th = np.sqrt(th2s)
+        sn, cs = np.sin(th), np.cos(th)
+        B = np.where(small, 1.0 / 6.0 + th2 / 120.0, (th - sn) / (th2s * th))
+        C = np.where(small, -1.0 / 24.0 + th2 / 720.0, (1.0 - th2s / 2.0 - cs) / (th2s * th2s))
+        D = np.where(small, -1.0 / 60.0, (2 * th - 3 * sn + th * cs) / (2 * th2s * th2s * th))
+        V, W = skew(v), skew(w)
+        VW = V @ W
+        WV = np.swapaxes(VW, -1, -2)
+        WVW = WV @ W
+        VWW = VW @ W
+        return 0.5 * V + B * (WV + VW + WVW) - C * (VWW - np.swapaxes(VWW, -1, -2) - 3 * WVW) + D * (WVW @ W + W @ WVW)
+
+    @classmethod
+    def _blocks(cls, other, inverse: bool):
+        c = np.asarray(other, dtype=np.float64)
+        w = c[..., 3:]
+        small = ((w * w).sum(-1) < _EPS)[..., None, None]
+        Q = cls._Q(c)
+        J = SO3.ljacinv(w) if inverse else SO3.ljac(w)
+        out = np.zeros(c.shape[:-1] + (6, 6))
+        out[..., :3, :3] = J
+        out[..., 3:, 3:] = J
+        out[..., :3, 3:] = -(J @ Q @ J) if inverse else Q
+        return np.where(small, np.eye(6), out)
+
+    @classmethod
+    def ljac(cls, other): return cls._blocks(other, False)
+    @classmethod
+    def ljacinv(cls, other): return cls._blocks(other, True)
+    @classmethod
+    def rjac(cls, other): return cls.ljac(-np.asarray(other, dtype=np.float64))
+    @classmethod
+    def rjacinv(cls, other): return cls.ljacinv(-np.asarray(other, dtype=np.float64))
+    def jlog(self): return SE3.rjacinv(self.log())
+
     def rminus(self, other): return (other.inverse() @ self).log()
     def minus(self, other): return self.rminus(other)
     def rplus(self, t): return self @ SE3.exp(t)
@@ -274,7 +388,7 @@ class SE3:
     def lminus(self, other): return (self @ other.inverse()).log()
 
 
-__all__ = ("SE3", "SO3", "MatrixLieGroup", "get_epsilon", "skew")
+__all__ = ("SE3", "SO3", "MatrixLieGroup", "RollPitchYaw", "get_epsilon", "skew")
 
 
 class MatrixLieGroup(abc.ABC):
