@@ -120,6 +120,30 @@ CollisionPair = tuple
 CollisionPairs = Sequence[CollisionPair]
 
 
+class Contact(NamedTuple):
+    """mink/limits/collision_avoidance_limit.py:20-56: what mj_geomDistance reports for one geom pair.  On the device
+    a pair lane holds exactly these fields for its pair (collide_dev.h, ik_kernel.h "collision half-space rows");
+    the class exists for callers that build or inspect contacts on the host."""
+    dist: float
+    fromto: np.ndarray
+    geom1: int
+    geom2: int
+    distmax: float
+
+    @property
+    def normal(self) -> np.ndarray:
+        """Unit vector from the closest point on geom1 to the one on geom2; (1, 0, 0) when they coincide
+        (mju_normalize3)."""
+        n = np.asarray(self.fromto[3:], dtype=np.float64) - np.asarray(self.fromto[:3], dtype=np.float64)
+        norm = float(np.linalg.norm(n))
+        return np.array([1.0, 0.0, 0.0]) if norm < 1e-15 else n / norm
+
+    @property
+    def inactive(self) -> bool:
+        """No distance smaller than distmax was found."""
+        return self.dist == self.distmax
+
+
 def _is_welded_together(m, g1: int, g2: int) -> bool:
     return m.body_weldid[m.geom_bodyid[g1]] == m.body_weldid[m.geom_bodyid[g2]]
 

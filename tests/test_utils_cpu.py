@@ -104,3 +104,14 @@ def test_package_surface_matches_the_reference():
     for n in names:
         assert hasattr(mink, n) and n in mink.__all__, n
     assert isinstance(mink.SE3.identity(), mink.MatrixLieGroup) and isinstance(mink.SO3.identity(), mink.MatrixLieGroup)
+
+
+def test_contact_struct():
+    """mink/limits/collision_avoidance_limit.py:20-56."""
+    from mink_amd.limits import Contact
+    c = Contact(dist=0.2, fromto=np.array([0.0, 0, 0, 0, 0, 0.2]), geom1=1, geom2=2, distmax=0.5)
+    np.testing.assert_allclose(c.normal, [0, 0, 1])
+    assert not c.inactive
+    far = Contact(dist=0.5, fromto=np.zeros(6), geom1=1, geom2=2, distmax=0.5)
+    assert far.inactive
+    np.testing.assert_allclose(far.normal, [1, 0, 0])             # mju_normalize3 of a zero vector
