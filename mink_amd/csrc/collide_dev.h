@@ -2,7 +2,7 @@
 //
 // Replaces mujoco.mj_geomDistance as called at
 // mink/limits/collision_avoidance_limit.py:214-229 for the analytic primitive pairs
-// (plane/sphere/capsule, and box / cylinder against plane, sphere and — box only — capsule);
+// (plane/sphere/capsule, box against plane/sphere/capsule/box, cylinder against plane/sphere);
 // semantics per MuJoCo's mj_geomDistance: geoms are ordered so that type1 <= type2, the contact
 // with the smallest distance within `distmax` wins, and fromto = pos ∓ ½·dist·n is returned in
 // the caller's geom order.  The box / cylinder routines state the exact Euclidean distance between
@@ -208,6 +208,103 @@ __device__ __forceinline__ Contact ball_cylinder_local(V3 p, double r, double ra
   return k;
 }
 
+// ---- box–box (mjc_BoxBox).  Separated boxes: the exact Euclidean distance as the minimum over vertex–box (both
+// ways) and edge–edge pairs; overlapping boxes (no separating axis among the 15 of the SAT): the smallest overlap
+// and its axis, one contact midway (MuJoCo clips faces and reports several — documented approximation).
+// Everything in B's frame: A has centre c, axes = columns of R, half sizes sa.  Loops are kept rolled: 144 edge
+// pairs as straight-line code would double the size of every collision-capable variant.
+__device__ __forceinline__ double comp(V3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+__device__ __forceinline__ V3 col(const M3& R, int i) { return {R.m[i], R.m[3 + i], R.m[6 + i]}; }
+__device__ __forceinline__ V3 unit(int i) { return {i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0}; }
+__device__ __forceinline__ V3 vabs(V3 v) { return {fabs(v.x), fabs(v.y), fabs(v.z)}; }
+__device__ __forceinline__ V3 vmulc(V3 a, V3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ V3 vclamp(V3 v, V3 s) { return {clampd(v.x, -s.x, s.x), clampd(v.y, -s.y, s.y), clampd(v.z, -s.z, s.z)}; }
+// endpoints of edge number e (0..11) of the box ±s: axis e/4, the sign choices of the two other axes from e%4
+__device__ __forceinline__ void box_edge(V3 s, int e, V3& a, V3& b) {
+  const int ax = e >> 2, j = (ax + 1) % 3, k = (ax + 2) % 3;
+  const double sj = (e & 1) ? comp(s, j) : -comp(s, j), sk = (e & 2) ? comp(s, k) : -comp(s, k);
+  double av[3], bv[3];
+  av[ax] = -comp(s, ax); bv[ax] = comp(s, ax);
+  av[j] = bv[j] = sj;
+  av[k] = bv[k] = sk;
+  a = {av[0], av[1], av[2]};
+  b = {bv[0], bv[1], bv[2]};
+}
+__device__ __forceinline__ Contact box_box_local(V3 c, M3 R, V3 sa, V3 sb, double margin) {
+  Contact k; k.hit = false; k.dist = margin; k.pos = c; k.n = {1, 0, 0};
+  // ---- separating-axis test
+  double best_sep = -1e300;
+  V3 best_axis{1, 0, 0};
+#pragma unroll 1
+  for (int i = 0; i < 15; ++i) {
+    V3 L;
+    if (i < 3) L = unit(i);
+    else if (i < 6) L = col(R, i - 3);
+    else {
+      L = cross(col(R, (i - 6) / 3), unit((i - 6) % 3));
+      const double n2 = dot(L, L);
+      if (n2 < 1e-18) continue;
+      L = (1.0 / sqrt(n2)) * L;
+    }
+    const double ra = dot(vabs(mulT(R, L)), sa), rb = dot(vabs(L), sb), cl = dot(c, L);
+    const double sep = fabs(cl) - (ra + rb);
+    if (sep > best_sep) { best_sep = sep; best_axis = (cl <= 0.0) ? L : -1.0 * L; }   // from A towards B
+  }
+  if (best_sep <= 0.0) {
+    if (best_sep > margin) return k;
+    const V3 n = best_axis;
+    const double cn = dot(c, n);
+    const double ca = cn + dot(vabs(mulT(R, n)), sa), cb = -dot(vabs(n), sb);
+    k.hit = true; k.dist = best_sep; k.n = n;
+    k.pos = 0.5 * c + (0.5 * (ca + cb) - 0.5 * cn) * n;
+    return k;
+  }
+  // ---- separated: closest features
+  double best = 1e300;
+  V3 pa{0, 0, 0}, pb{0, 0, 0};
+#pragma unroll 1
+  for (int i = 0; i < 8; ++i) {
+    const V3 sg{(i & 1) ? 1.0 : -1.0, (i & 2) ? 1.0 : -1.0, (i & 4) ? 1.0 : -1.0};
+    const V3 va = c + mul(R, vmulc(sg, sa));                  // vertex of A against box B
+    V3 cl = vclamp(va, sb);
+    double d2 = dot(va - cl, va - cl);
+    if (d2 < best) { best = d2; pa = va; pb = cl; }
+    const V3 ub = vmulc(sg, sb);                              // vertex of B against box A (A's frame)
+    const V3 ul = mulT(R, ub - c);
+    cl = vclamp(ul, sa);
+    d2 = dot(ul - cl, ul - cl);
+    if (d2 < best) { best = d2; pa = c + mul(R, cl); pb = ub; }
+  }
+#pragma unroll 1
+  for (int ea = 0; ea < 12; ++ea) {
+    V3 a0, a1;
+    box_edge(sa, ea, a0, a1);
+    const V3 p1 = c + mul(R, a0), d1 = mul(R, a1 - a0);
+    const double a = dot(d1, d1);
+#pragma unroll 1
+    for (int eb = 0; eb < 12; ++eb) {
+      V3 p2, q2;
+      box_edge(sb, eb, p2, q2);
+      const V3 d2v = q2 - p2, r = p1 - p2;
+      const double e = dot(d2v, d2v), f = dot(d2v, r), cc = dot(d1, r), b = dot(d1, d2v);
+      const double den = a * e - b * b;
+      double sp = (den > 1e-15 * a * e) ? clampd((b * f - cc * e) / den, 0.0, 1.0) : 0.0;
+      double t = (b * sp + f) / e;
+      if (t < 0.0) { t = 0.0; sp = clampd(-cc / a, 0.0, 1.0); }
+      else if (t > 1.0) { t = 1.0; sp = clampd((b - cc) / a, 0.0, 1.0); }
+      const V3 x1 = p1 + sp * d1, x2 = p2 + t * d2v;
+      const double dd = dot(x1 - x2, x1 - x2);
+      if (dd < best) { best = dd; pa = x1; pb = x2; }
+    }
+  }
+  const double dist = sqrt(best);
+  if (dist > margin) return k;
+  k.hit = true; k.dist = dist;
+  k.n = (dist > 1e-15) ? (1.0 / dist) * (pb - pa) : best_axis;
+  k.pos = 0.5 * (pa + pb);
+  return k;
+}
+
 // map a contact found in the frame of geom 2 (rotation R, origin o) back to the world
 __device__ __forceinline__ Contact to_world(Contact k, const M3& R, V3 o) {
   if (k.hit) { k.pos = o + mul(R, k.pos); k.n = mul(R, k.n); }
@@ -250,6 +347,14 @@ __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t
     c = to_world(ball_cylinder_local(mulT(R2, p1 - p2), s1.x, s2.x, s2.y, distmax), R2, p2);
   } else if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX) {
     c = to_world(capsule_box_local(mulT(R2, p1 - p2), mulT(R2, z1), s1.x, s1.y, s2, distmax), R2, p2);
+  } else if (t1 == GEOM_BOX && t2 == GEOM_BOX) {
+    M3 Rab;                                                   // A's axes in B's frame: R2ᵀ·R1
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        Rab.m[3 * i + j] = R2.m[i] * R1.m[j] + R2.m[3 + i] * R1.m[3 + j] + R2.m[6 + i] * R1.m[6 + j];
+    c = to_world(box_box_local(mulT(R2, p1 - p2), Rab, s1, s2, distmax), R2, p2);
   } else {
     dist = distmax; from = {0, 0, 0}; to = {0, 0, 0};
     return false;

@@ -601,10 +601,105 @@ def _capsule_box(pos1, mat1, size1, pos2, mat2, size2, margin):
     return _to_world(_ball_box_local(c + t * a, size1[0], size2, margin), R, pos2)
 
 
+def _seg_seg(p1, q1, p2, q2):
+    """Closest points of two segments of non-zero length (clamped line–line solution; Ericson, Real-Time Collision
+    Detection §5.1.9).  Returns (squared distance, point on 1, point on 2)."""
+    d1, d2, r = q1 - p1, q2 - p2, p1 - p2
+    a, e, f = float(d1 @ d1), float(d2 @ d2), float(d2 @ r)
+    c, b = float(d1 @ r), float(d1 @ d2)
+    den = a * e - b * b
+    sp = min(max((b * f - c * e) / den, 0.0), 1.0) if den > mjMINVAL * a * e else 0.0
+    t = (b * sp + f) / e
+    if t < 0.0:
+        t, sp = 0.0, min(max(-c / a, 0.0), 1.0)
+    elif t > 1.0:
+        t, sp = 1.0, min(max((b - c) / a, 0.0), 1.0)
+    x1, x2 = p1 + sp * d1, p2 + t * d2
+    return float((x1 - x2) @ (x1 - x2)), x1, x2
+
+
+def _box_edges(s):
+    """The 12 edges of the box ±s as (start, end) pairs: axis e, the four sign choices of the other two axes."""
+    out = []
+    for e in range(3):
+        j, k = (e + 1) % 3, (e + 2) % 3
+        for sj in (-1.0, 1.0):
+            for sk in (-1.0, 1.0):
+                a = np.zeros(3); b = np.zeros(3)
+                a[e], b[e] = -s[e], s[e]
+                a[j] = b[j] = sj * s[j]
+                a[k] = b[k] = sk * s[k]
+                out.append((a, b))
+    return out
+
+
+def _box_box(pos1, mat1, size1, pos2, mat2, size2, margin):
+    """Two boxes (MuJoCo: mjc_BoxBox, engine_collision_box.c).  Separated boxes: the exact Euclidean distance — the
+    minimum over vertex–box (both ways) and edge–edge pairs, which covers every closest-feature combination of two
+    convex polytopes.  Overlapping boxes (no separating axis among the 15 of the SAT): the smallest overlap and its
+    axis, with the contact placed midway between the two centres' projections — MuJoCo clips faces there and reports
+    several contacts; ours is one contact with the SAT depth (documented approximation: a collision-AVOIDANCE limit
+    only needs a sane normal once d ≤ d_min)."""
+    R1, R2 = _mat3(mat1), _mat3(mat2)
+    sa, sb = np.asarray(size1[:3], dtype=np.float64), np.asarray(size2[:3], dtype=np.float64)
+    R = R2.T @ R1                      # A's axes in B's frame
+    c = R2.T @ (pos1 - pos2)           # A's centre in B's frame
+    # ---- separating-axis test: separation along unit axis L = |c·L| − (rA + rB)
+    best_sep, best_axis = -np.inf, None
+    axes = [np.eye(3)[i] for i in range(3)] + [R[:, i] for i in range(3)]
+    for i in range(3):
+        for j in range(3):
+            ax = np.cross(R[:, i], np.eye(3)[j])
+            n = math.sqrt(float(ax @ ax))
+            if n > 1e-9:
+                axes.append(ax / n)
+    for L in axes:
+        ra = float(np.abs(R.T @ L) @ sa)
+        rb = float(np.abs(L) @ sb)
+        sep = abs(float(c @ L)) - (ra + rb)
+        if sep > best_sep:
+            best_sep, best_axis = sep, (L if float(c @ L) <= 0.0 else -L)      # from A towards B
+    if best_sep <= 0.0:
+        dist = best_sep
+        if dist > margin:
+            return []
+        n = best_axis
+        ca = float(c @ n) + float(np.abs(R.T @ n) @ sa)       # A's extent towards B along n
+        cb = -float(np.abs(n) @ sb)                            # B's extent towards A along n
+        mid = 0.5 * c + n * (0.5 * (ca + cb) - 0.5 * float(c @ n))
+        return _to_world([(dist, mid, n)], R2, pos2)
+    # ---- separated: closest features
+    best = (np.inf, None, None)
+    for i in range(8):
+        sg = np.array([1.0 if i & 1 else -1.0, 1.0 if i & 2 else -1.0, 1.0 if i & 4 else -1.0])
+        va = c + R @ (sg * sa)                                  # vertex of A against box B
+        cl = np.minimum(np.maximum(va, -sb), sb)
+        d2 = float((va - cl) @ (va - cl))
+        if d2 < best[0]:
+            best = (d2, va, cl)
+        ub = sg * sb                                            # vertex of B against box A (A's frame)
+        ul = R.T @ (ub - c)
+        cl = np.minimum(np.maximum(ul, -sa), sa)
+        d2 = float((ul - cl) @ (ul - cl))
+        if d2 < best[0]:
+            best = (d2, c + R @ cl, ub)
+    for ea0, ea1 in _box_edges(sa):
+        pa, qa = c + R @ ea0, c + R @ ea1
+        for eb0, eb1 in _box_edges(sb):
+            d2, x1, x2 = _seg_seg(pa, qa, eb0, eb1)
+            if d2 < best[0]:
+                best = (d2, x1, x2)
+    dist = math.sqrt(best[0])
+    if dist > margin:
+        return []
+    n = (best[2] - best[1]) / dist if dist > mjMINVAL else (best_axis)
+    return _to_world([(dist, 0.5 * (best[1] + best[2]), n)], R2, pos2)
+
+
 def mj_geomDistance(m, d: Data, geom1: int, geom2: int, distmax: float, fromto) -> float:
     """Smallest signed distance between two geoms and the connecting segment
     (mink/limits/collision_avoidance_limit.py:219); SURVEY Appendix A.8.
-    Restated: plane/sphere/capsule pairs, box against plane/sphere/capsule, cylinder against plane/sphere."""
+    Restated: plane/sphere/capsule pairs, box against plane/sphere/capsule/box, cylinder against plane/sphere."""
     g1, g2 = int(geom1), int(geom2)
     t1, t2 = int(m.geom_type[g1]), int(m.geom_type[g2])
     flip = t1 > t2
@@ -635,6 +730,8 @@ def mj_geomDistance(m, d: Data, geom1: int, geom2: int, distmax: float, fromto) 
         cons = _sphere_cylinder(p1, s1, p2, R2, s2, distmax)
     elif (t1, t2) == (GEOM_CAPSULE, GEOM_BOX):
         cons = _capsule_box(p1, R1, s1, p2, R2, s2, distmax)
+    elif (t1, t2) == (GEOM_BOX, GEOM_BOX):
+        cons = _box_box(p1, R1, s1, p2, R2, s2, distmax)
     else:
         raise NotImplementedError(f"geom pair types ({t1},{t2}) not restated")
     if fromto is not None:

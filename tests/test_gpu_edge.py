@@ -112,8 +112,8 @@ def test_argument_validation():
     with pytest.raises(nat.MinkHipError, match="site id"):
         nat.NativeProblem(nm, frame_tasks=[{"frame_type": "site", "frame_id": 9, "cost": [1.0] * 6}])
     with pytest.raises(nat.MinkHipError, match="no analytic distance"):
-        # box–box (the mocap target's box vs the wall) has no distance routine; capsule–box has one since r01j
-        nat.NativeProblem(nm, collision_limits=[{"geom_id_pairs": [[m.name2id("geom", "wall") - 1, m.name2id("geom", "wall")]],
+        # a mesh geom has no distance routine (the primitive pairs, box–box included, have one)
+        nat.NativeProblem(nm, collision_limits=[{"geom_id_pairs": [[1, m.name2id("geom", "wall")]],
                                                  "gain": 0.85, "minimum_distance_from_collisions": 0.005,
                                                  "collision_detection_distance": 0.01, "bound_relaxation": 0.0}])
 

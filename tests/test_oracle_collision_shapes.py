@@ -211,3 +211,52 @@ def test_geom_distance_conventions_for_box_pairs():
     np.testing.assert_allclose(ft, [0, -0.3, 0, 0, -0.3, 0.4], atol=1e-14)
     dist = mj.mj_geomDistance(m, d, gid("ball"), gid("can"), 1.0, ft)
     assert abs(dist - (0.6 - 0.05 - 0.05)) < 1e-14
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_box_box_is_the_euclidean_distance(seed):
+    """Separated boxes: against a bounded minimisation of |x − y|² over x ∈ A, y ∈ B (convex; L-BFGS-B from several
+    starts).  Overlapping boxes: the SAT depth is the smallest translation that separates them — checked by moving A
+    along the reported normal."""
+    rng = np.random.default_rng(300 + seed)
+    sa, sb = rng.uniform(0.05, 0.4, size=3), rng.uniform(0.05, 0.4, size=3)
+    R1, R2 = _rand_rot(rng), _rand_rot(rng)
+    p2 = rng.normal(size=3) * 0.2
+    p1 = p2 + rng.normal(size=3) * rng.uniform(0.1, 0.9)
+    cons = mj._box_box(p1, R1, sa, p2, R2, sb, 10.0)
+    assert len(cons) == 1
+    dist, pos, n = cons[0]
+    Ra, Rb = R1.reshape(3, 3), R2.reshape(3, 3)
+    assert abs(np.linalg.norm(n) - 1.0) < 1e-12
+
+    def f(z):
+        x, y = p1 + Ra @ z[:3], p2 + Rb @ z[3:]
+        return float((x - y) @ (x - y))
+
+    def g(z):
+        x, y = p1 + Ra @ z[:3], p2 + Rb @ z[3:]
+        return np.concatenate([2 * Ra.T @ (x - y), -2 * Rb.T @ (x - y)])
+
+    bounds = list(zip(-sa, sa)) + list(zip(-sb, sb))
+    ref = min(minimize(f, rng.uniform(-1, 1, 6) * np.r_[sa, sb], jac=g, bounds=bounds, method="L-BFGS-B",
+                       options={"ftol": 1e-22, "gtol": 1e-14, "maxiter": 2000}).fun for _ in range(6))
+    if ref > 1e-12:
+        assert abs(dist - math.sqrt(ref)) < 1e-6, (dist, math.sqrt(ref))
+        frm, to = pos - n * (0.5 * dist), pos + n * (0.5 * dist)
+        assert abs(_point_box(Ra.T @ (frm - p1), sa)) < 1e-9           # `from` on A, `to` on B
+        assert abs(_point_box(Rb.T @ (to - p2), sb)) < 1e-9
+    else:
+        assert dist <= 1e-9
+        moved = mj._box_box(p1 - n * (-dist + 1e-6), R1, sa, p2, R2, sb, 10.0)    # push A back by the depth
+        assert moved[0][0] > 0.0                                        # ... and the boxes are apart
+        still = mj._box_box(p1 - n * (-dist * 0.5), R1, sa, p2, R2, sb, 10.0)
+        assert still[0][0] <= 1e-12
+
+
+def test_box_box_plus_sign_overlap_is_detected():
+    """Two long thin boxes crossed like a plus sign: no vertex of either is inside the other and no pair of edges
+    touches, yet they overlap — only the separating-axis test sees it."""
+    I = np.eye(3).reshape(-1)
+    Rz = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], dtype=float).reshape(-1)
+    cons = mj._box_box(np.zeros(3), I, np.array([1.0, 0.1, 0.1]), np.array([0.0, 0.0, 0.05]), Rz, np.array([1.0, 0.1, 0.1]), 1.0)
+    assert cons[0][0] < 0.0
