@@ -134,8 +134,8 @@ typedef struct MkhVelocityLimitDesc {
  * collision_detection_distance, bound_relaxation) — mink/limits/collision_avoidance_limit.py:145-185;
  * geom_id_pairs is the constructor's filtered (min,max) id list (:253-278).
  * Distance routines behind mj_geomDistance (:219): plane/sphere/capsule among themselves, box against
- * plane/sphere/capsule/box, cylinder against plane/sphere; any other pair type fails mkh_problem_create with
- * MKH_E_INVALID (cylinder–box/capsule/cylinder, ellipsoid, mesh: MuJoCo uses libccd there). */
+ * plane/sphere/capsule/box, cylinder against plane/sphere/capsule; any other pair type fails mkh_problem_create
+ * with MKH_E_INVALID (cylinder–box/cylinder, ellipsoid, mesh: MuJoCo uses libccd there). */
 typedef struct MkhCollisionLimitDesc {
   int32_t n_pairs;
   const int32_t *geom_id_pairs /*n_pairs*2*/;

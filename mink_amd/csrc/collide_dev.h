@@ -2,7 +2,7 @@
 //
 // Replaces mujoco.mj_geomDistance as called at
 // mink/limits/collision_avoidance_limit.py:214-229 for the analytic primitive pairs
-// (plane/sphere/capsule, box against plane/sphere/capsule/box, cylinder against plane/sphere);
+// (plane/sphere/capsule, box against plane/sphere/capsule/box, cylinder against plane/sphere/capsule);
 // semantics per MuJoCo's mj_geomDistance: geoms are ordered so that type1 <= type2, the contact
 // with the smallest distance within `distmax` wins, and fromto = pos ∓ ½·dist·n is returned in
 // the caller's geom order.  The box / cylinder routines state the exact Euclidean distance between
@@ -305,6 +305,31 @@ __device__ __forceinline__ Contact box_box_local(V3 c, M3 R, V3 sa, V3 sb, doubl
   return k;
 }
 
+// capsule–cylinder (MuJoCo: libccd).  The squared distance from the capsule axis c + t·a to the solid cylinder is
+// convex in t, so g(t) = a·(p(t) − closest(p(t))) is non-decreasing: 64 bisection steps on g give the closest axis
+// point to the last bit, then ball-against-cylinder.  Axis through the cylinder: lower end of the g = 0 interval.
+__device__ __forceinline__ double seg_cyl_slope(V3 c, V3 a, double rad, double half, double t) {
+  const V3 p = c + t * a;
+  const double rho = sqrt(p.x * p.x + p.y * p.y);
+  const double sc = (rho > rad) ? rad / rho : 1.0;
+  return a.x * (p.x - p.x * sc) + a.y * (p.y - p.y * sc) + a.z * (p.z - clampd(p.z, -half, half));
+}
+__device__ __forceinline__ Contact capsule_cylinder_local(V3 c, V3 a, double r, double l, double rad, double half,
+                                                         double margin) {
+  double lo = -l, hi = l, t;
+  if (seg_cyl_slope(c, a, rad, half, lo) >= 0.0) t = lo;
+  else if (seg_cyl_slope(c, a, rad, half, hi) <= 0.0) t = hi;
+  else {
+#pragma unroll 1
+    for (int it = 0; it < 64; ++it) {
+      const double mid = 0.5 * (lo + hi);
+      if (seg_cyl_slope(c, a, rad, half, mid) < 0.0) lo = mid; else hi = mid;
+    }
+    t = hi;
+  }
+  return ball_cylinder_local(c + t * a, r, rad, half, margin);
+}
+
 // map a contact found in the frame of geom 2 (rotation R, origin o) back to the world
 __device__ __forceinline__ Contact to_world(Contact k, const M3& R, V3 o) {
   if (k.hit) { k.pos = o + mul(R, k.pos); k.n = mul(R, k.n); }
@@ -347,6 +372,8 @@ __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t
     c = to_world(ball_cylinder_local(mulT(R2, p1 - p2), s1.x, s2.x, s2.y, distmax), R2, p2);
   } else if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX) {
     c = to_world(capsule_box_local(mulT(R2, p1 - p2), mulT(R2, z1), s1.x, s1.y, s2, distmax), R2, p2);
+  } else if (t1 == GEOM_CAPSULE && t2 == GEOM_CYLINDER) {
+    c = to_world(capsule_cylinder_local(mulT(R2, p1 - p2), mulT(R2, z1), s1.x, s1.y, s2.x, s2.y, distmax), R2, p2);
   } else if (t1 == GEOM_BOX && t2 == GEOM_BOX) {
     M3 Rab;                                                   // A's axes in B's frame: R2ᵀ·R1
 #pragma unroll

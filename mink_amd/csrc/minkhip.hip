@@ -415,7 +415,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
         return (a == GEOM_CAPSULE && b == GEOM_CAPSULE) || (a == GEOM_SPHERE && b == GEOM_SPHERE) ||
                (a == GEOM_SPHERE && b == GEOM_CAPSULE) || (a == GEOM_PLANE && (b == GEOM_SPHERE || b == GEOM_CAPSULE)) ||
                (b == GEOM_BOX && (a == GEOM_PLANE || a == GEOM_SPHERE || a == GEOM_CAPSULE || a == GEOM_BOX)) ||
-               (b == GEOM_CYLINDER && (a == GEOM_PLANE || a == GEOM_SPHERE));
+               (b == GEOM_CYLINDER && (a == GEOM_PLANE || a == GEOM_SPHERE || a == GEOM_CAPSULE));
       };
       if (!supported(t1, t2)) return bail(fail(MKH_E_INVALID, "collision pair (%d,%d): geom types (%d,%d) have no analytic distance routine yet", g1, g2, t1, t2));
       cp.type1 = t1; cp.type2 = t2; cp.body1 = m->geom_bodyid[g1]; cp.body2 = m->geom_bodyid[g2];

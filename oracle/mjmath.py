@@ -696,10 +696,47 @@ def _box_box(pos1, mat1, size1, pos2, mat2, size2, margin):
     return _to_world([(dist, 0.5 * (best[1] + best[2]), n)], R2, pos2)
 
 
+def _cylinder_closest(p, rad, half):
+    """Closest point of the solid cylinder (radius rad, half height half, axis z) to p."""
+    rho = math.hypot(p[0], p[1])
+    sc = rad / rho if rho > rad else 1.0
+    return np.array([p[0] * sc, p[1] * sc, min(max(p[2], -half), half)])
+
+
+def _capsule_cylinder(pos1, mat1, size1, pos2, mat2, size2, margin):
+    """Capsule against cylinder (MuJoCo: libccd).  The squared distance from the capsule axis c + t·a to the solid
+    cylinder is convex in t, so its derivative g(t) = a·(p(t) − closest(p(t))) is non-decreasing: 64 bisection steps
+    on g locate the closest axis point to the last bit, then ball-against-cylinder.  Axis through the cylinder
+    (g = 0 on an interval): the bisection lands on the interval's lower end."""
+    R = _mat3(mat2)
+    c = R.T @ (pos1 - pos2)
+    a = R.T @ np.array([mat1[2], mat1[5], mat1[8]])
+    l, rad, half = size1[1], size2[0], size2[1]
+
+    def g(t):
+        p = c + t * a
+        return float(a @ (p - _cylinder_closest(p, rad, half)))
+
+    lo, hi = -l, l
+    if g(lo) >= 0.0:
+        t = lo
+    elif g(hi) <= 0.0:
+        t = hi
+    else:
+        for _ in range(64):
+            mid = 0.5 * (lo + hi)
+            if g(mid) < 0.0:
+                lo = mid
+            else:
+                hi = mid
+        t = hi
+    return _to_world(_ball_cylinder_local(c + t * a, size1[0], rad, half, margin), R, pos2)
+
+
 def mj_geomDistance(m, d: Data, geom1: int, geom2: int, distmax: float, fromto) -> float:
     """Smallest signed distance between two geoms and the connecting segment
     (mink/limits/collision_avoidance_limit.py:219); SURVEY Appendix A.8.
-    Restated: plane/sphere/capsule pairs, box against plane/sphere/capsule/box, cylinder against plane/sphere."""
+    Restated: plane/sphere/capsule pairs, box against plane/sphere/capsule/box, cylinder against plane/sphere/capsule."""
     g1, g2 = int(geom1), int(geom2)
     t1, t2 = int(m.geom_type[g1]), int(m.geom_type[g2])
     flip = t1 > t2
@@ -730,6 +767,8 @@ def mj_geomDistance(m, d: Data, geom1: int, geom2: int, distmax: float, fromto) 
         cons = _sphere_cylinder(p1, s1, p2, R2, s2, distmax)
     elif (t1, t2) == (GEOM_CAPSULE, GEOM_BOX):
         cons = _capsule_box(p1, R1, s1, p2, R2, s2, distmax)
+    elif (t1, t2) == (GEOM_CAPSULE, GEOM_CYLINDER):
+        cons = _capsule_cylinder(p1, R1, s1, p2, R2, s2, distmax)
     elif (t1, t2) == (GEOM_BOX, GEOM_BOX):
         cons = _box_box(p1, R1, s1, p2, R2, s2, distmax)
     else:

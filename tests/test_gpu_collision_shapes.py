@@ -39,7 +39,8 @@ PAIRS = [
     (["l1_cap", "l3_cap"], ["crate", "floor"]),          # capsule–box, plane–capsule
     (["l4_ball"], ["crate", "drum", "floor", "post"]),   # sphere–box, sphere–cylinder, plane–sphere, sphere–capsule
     (["l2_box"], ["floor", "orb", "post", "crate"]),     # plane–box, sphere–box, capsule–box, box–box (box on the robot)
-    (["l4_can"], ["floor", "orb"]),                      # plane–cylinder, sphere–cylinder (cylinder on the robot)
+    (["l4_can"], ["floor", "orb", "post"]),              # plane–cylinder, sphere–cylinder, capsule–cylinder (cylinder on the robot)
+    (["l1_cap", "l3_cap"], ["drum"]),                    # capsule–cylinder (capsule on the robot)
 ]
 
 
@@ -61,13 +62,13 @@ def test_every_box_and_cylinder_pair_type_against_the_oracle():
     q = _rand_q(m, rng, B)
     cfg = mink.Configuration(m, q)
     col = mink.CollisionAvoidanceLimit(m, PAIRS, collision_detection_distance=0.25, minimum_distance_from_collisions=0.01)
-    assert len(col.geom_id_pairs) == 12
+    assert len(col.geom_id_pairs) == 14
     dt = 0.1               # long step: h = gain·(d − d_min)/dt is small enough for the rows to bind
     G, h = col.compute_qp_inequalities(cfg, dt)
-    assert G.shape == (B, 12, m.nv)
+    assert G.shape == (B, 14, m.nv)
     spec = oik.CollisionAvoidanceLimitSpec(col.geom_id_pairs, collision_detection_distance=0.25,
                                            minimum_distance_from_collisions=0.01)
-    active = np.zeros(12, dtype=int)
+    active = np.zeros(14, dtype=int)
     for i in range(B):
         o = oik.Configuration(m, q[i])
         G_ref, h_ref = oik.limit_inequalities(o, spec, dt)

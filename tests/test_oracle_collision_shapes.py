@@ -260,3 +260,30 @@ def test_box_box_plus_sign_overlap_is_detected():
     Rz = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], dtype=float).reshape(-1)
     cons = mj._box_box(np.zeros(3), I, np.array([1.0, 0.1, 0.1]), np.array([0.0, 0.0, 0.05]), Rz, np.array([1.0, 0.1, 0.1]), 1.0)
     assert cons[0][0] < 0.0
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_capsule_cylinder_is_the_euclidean_distance(seed):
+    rng = np.random.default_rng(500 + seed)
+    rad, half = rng.uniform(0.03, 0.3), rng.uniform(0.03, 0.4)
+    r, l = rng.uniform(0.01, 0.08), rng.uniform(0.05, 0.5)
+    R1, R2 = _rand_rot(rng), _rand_rot(rng)
+    p2 = rng.normal(size=3) * 0.2
+    p1 = p2 + rng.normal(size=3) * rng.uniform(0.2, 0.9)
+    dist, pos, n = mj._capsule_cylinder(p1, R1, np.array([r, l, 0.0]), p2, R2, np.array([rad, half, 0.0]), 10.0)[0]
+    Rb = R2.reshape(3, 3)
+    c = Rb.T @ (p1 - p2)
+    a = Rb.T @ np.array([R1[2], R1[5], R1[8]])
+    f = lambda t: np.linalg.norm(c + t * a - mj._cylinder_closest(c + t * a, rad, half))
+    ts = np.linspace(-l, l, 4001)
+    fs = np.array([f(t) for t in ts])
+    k = int(fs.argmin())
+    res = minimize_scalar(f, bounds=(ts[max(k - 1, 0)], ts[min(k + 1, len(ts) - 1)]), method="bounded", options={"xatol": 1e-13})
+    ref = min(res.fun, fs.min())
+    if ref > 1e-9:
+        assert abs(dist - (ref - r)) < 1e-9, (dist, ref - r)
+        to = Rb.T @ (pos + n * (0.5 * dist) - p2)                       # `to` on the cylinder surface
+        assert math.hypot(to[0], to[1]) <= rad + 1e-9 and abs(to[2]) <= half + 1e-9
+        assert abs(np.linalg.norm(n) - 1.0) < 1e-12
+    else:
+        assert dist <= -r + 1e-9
