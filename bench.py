@@ -1,23 +1,32 @@
 #!/usr/bin/env python
 """Headline benchmark: batched differential-IK solves/sec on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config g1_c3|ur5e_c2|g1_full|shadow_c4] [--batch B]
 
-Workload (BASELINE.json metric, configs[2]): Unitree G1 (nq=44, nv=43), 4 FrameTasks
+Default workload (BASELINE.json metric, configs[2]): Unitree G1 (nq=44, nv=43), 4 FrameTasks
 (feet + palms) + PostureTask + ConfigurationLimit + VelocityLimit box limits, batch
-65 536 per GPU, float64.  A "step" is one batched solve_ik over the resident batch
-(inputs already in HBM).  For N > 1 the driver launches one rank per GPU via
-torch.distributed.run; the batch shards by rank (weak scaling, configs[4] = 8 x 65 536)
-with no data-path collective: the instances are independent, v stays on the GPU that produced it
-(--gather adds the RCCL gather of v to rank 0 that BASELINE configs[4] mentions).
+65 536 per GPU, float64.  --config selects the other BASELINE configs (parity-test cases; their
+lines carry the same fields).  A "step" is one batched solve_ik over the resident batch
+(inputs already in HBM).
 
-Prints ONE JSON line (rank 0) with the whole-job solves/sec, the HBM roofline of the
-kernel (algorithmic bytes / launch duration from HIP events) and a CPU baseline.
+N > 1: one rank per GPU.  The driver launches the ranks itself through torch.distributed.run; when
+WORLD_SIZE is not set, `python bench.py --gpus N` re-executes itself under torch.distributed.run with N
+ranks (and refuses to run if the box has fewer than N GPUs) — a line is never printed with n_gpus != --gpus.
+The batch shards by rank (weak scaling, configs[4] = 8 x 65 536) with no data-path collective: the
+instances are independent, v stays on the GPU that produced it.  After the compute-only timed region a
+second timed region of the same K steps ends every step with the RCCL gather of v to rank 0 that BASELINE
+configs[4] mentions; it is reported separately under "gather" (never as `value`).
+
+Prints ONE JSON line (rank 0) with the whole-job solves/sec, the HBM roofline of the kernel (algorithmic
+bytes / launch duration from HIP events on the launch stream) and CPU baselines.
 """
 
 import argparse
+import glob
 import json
 import os
+import socket
+import statistics
 import subprocess
 import sys
 import time
@@ -27,7 +36,13 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-BYTES_PER_SOLVE_G1 = 44 * 8 + 4 * 7 * 8 + 43 * 8 + 4   # q + 4 frame targets + v + status = 924 B
+HBM_PEAK_GBS = 8000.0                                   # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6                          # MI355X fp64 vector peak (same guide, chip table)
+# algorithmic fp64 flops per G1 config-3 solve, 0.10-0.15 Mflop (FK, Jacobians, log/jlog,
+# H accumulation, factorisation, active-set steps of the reference algorithm) — the midpoint
+ALGORITHMIC_FLOP_PER_SOLVE = {"g1_c3": 0.125e6}
+
+
 def issued_flop_per_solve(kernel: str) -> int:
     """Issued fp64 FMA flops of the tableau work per G1 solve (64 lanes x 2 flop per row of a rank-1 update),
     DESIGN.md §3.1.  Low-rank start (kernel name ends in _r44): the 18 residual pivots touch 6 x 34 + 6 x 42 +
@@ -38,10 +53,6 @@ def issued_flop_per_solve(kernel: str) -> int:
     if "_r" in kernel:
         return int((792 + 13.4 * 44) * 64 * 2 + 19 * 18 * 14 * 2)
     return int((43 + 13.4 + 18) * nt * 64 * 2)
-
-
-HBM_PEAK_GBS = 8000.0                                   # MI355X HBM3E spec (MI355X_MICROARCH.md)
-FP64_VECTOR_PEAK_TFLOPS = 78.6                          # MI355X fp64 vector peak (same guide, chip table)
 
 
 def usable_cpus() -> int:
@@ -58,68 +69,79 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
-def measured_traffic():
+def _newest_pmc(config: str, B: int):
+    """Newest committed PMC summary of this workload (tools/profile.sh → profiles/<tag>_<config>_b<B>_pmc.json;
+    round-1 files of the headline config are named <tag>_g1_b65536_pmc.json)."""
+    pats = [f"*_{config}_b{B}_pmc.json"] + ([f"*_g1_b{B}_pmc.json"] if config == "g1_c3" else [])
+    paths = sorted(p for pat in pats for p in glob.glob(os.path.join(REPO, "profiles", pat)))
+    for path in reversed(paths):
+        try:
+            with open(path) as fh:
+                return json.load(fh), os.path.relpath(path, REPO)
+        except (OSError, ValueError):
+            continue
+    return None, None
+
+
+def measured_traffic(config: str, B: int):
     """HBM bytes per launch of the IK kernel from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate
     rocprofv3 --pmc runs, calibrated on a known-size copy: tools/profile.sh, tools/rocprof_summary.py).
-    Counters cannot be read from inside a timed run, so this comes from the newest committed
-    profiles/*_pmc.json of the same workload; None when no calibrated summary exists."""
-    import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "*_g1_b65536_pmc.json"))):
-        try:
-            with open(path) as fh:
-                hbm = json.load(fh).get("hbm", {})
-            if "traffic_bytes_per_launch" in hbm:
-                best = (hbm["traffic_bytes_per_launch"], os.path.relpath(path, REPO))
-        except (OSError, ValueError):
-            pass
-    return best
+    Counters cannot be read from inside a timed run, so this comes from the newest committed summary of the
+    same workload; None when no calibrated summary exists."""
+    js, src = _newest_pmc(config, B)
+    hbm = (js or {}).get("hbm", {})
+    return (hbm["traffic_bytes_per_launch"], src) if "traffic_bytes_per_launch" in hbm else None
 
 
-def measured_valu_issue():
+def measured_valu_issue(config: str, B: int, waves_per_simd: int):
     """What actually bounds the kernel: VALU issue.  From the same committed PMC summary as `traffic`
     (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the solve dispatches): the share of a wave's cycles in which it issues
-    a VALU instruction, times the two waves that share a SIMD for this kernel.  None without a summary."""
-    import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "*_g1_b65536_pmc.json"))):
-        try:
-            with open(path) as fh:
-                k = json.load(fh).get("ik_solve_kernel", {})
-            act = k["SQ_ACTIVE_INST_VALU"]["per_dispatch"][1:]
-            cyc = k["SQ_WAVE_CYCLES"]["per_dispatch"][1:]
-            per_wave = sum(act) / sum(cyc)
-            best = {"valu_active_share_of_wave_cycles": per_wave, "waves_per_simd": 2,
-                    "simd_issue_slots_used": 2 * per_wave, "source": os.path.relpath(path, REPO)}
-        except (OSError, ValueError, KeyError, ZeroDivisionError):
-            pass
-    return best
+    a VALU instruction, times the waves that share a SIMD for this kernel.  None without a summary."""
+    js, src = _newest_pmc(config, B)
+    try:
+        k = js["ik_solve_kernel"]
+        act = k["SQ_ACTIVE_INST_VALU"]["per_dispatch"][1:]
+        cyc = k["SQ_WAVE_CYCLES"]["per_dispatch"][1:]
+        per_wave = sum(act) / sum(cyc)
+        return {"valu_active_share_of_wave_cycles": per_wave, "waves_per_simd": waves_per_simd,
+                "simd_issue_slots_used": waves_per_simd * per_wave, "source": src}
+    except (TypeError, KeyError, ZeroDivisionError):
+        return None
 
 
-def pcie_inclusive(prob, q_h, tg_h, stand, dt, damping, reps=3):
-    """Host-pointer call (the C ABI stages through pinned buffers: H2D q + targets, D2H v + status)."""
-    prob.solve(q_h, tg_h, stand[None, :], None, dt, damping)
+def pcie_inclusive(prob, q_h, tg_h, pt_h, ct_h, dt, damping, reps=3):
+    """Host-pointer call (the C ABI stages through its own device buffers: H2D q + targets, D2H v + status)."""
+    prob.solve(q_h, tg_h, pt_h, ct_h, dt, damping)
     t0 = time.perf_counter()
     for _ in range(reps):
-        prob.solve(q_h, tg_h, stand[None, :], None, dt, damping)
+        prob.solve(q_h, tg_h, pt_h, ct_h, dt, damping)
     return len(q_h) * reps / (time.perf_counter() - t0)
 
 
-def cpu_baseline(model, q, targets, posture_target, budget_s=20.0):
-    """Restated reference timed on the host cores over a bounded sample of the same workload: the plain-C
-    port of the reference pipeline (oracle/c: dense H, c, G, h + Goldfarb–Idnani, like mink + MuJoCo +
-    quadprog) on all host threads; falls back to the numpy port on one thread if the C oracle cannot be built."""
+def _oracle_specs(config, targets, posture_target, com_target):
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_configs as oc
 
-    m, tasks, limits, dt, damping = oc.g1_c3(targets[0], posture_target)
+    if config == "g1_full":
+        return oc.g1_full(targets, posture_target, com_target)
+    return getattr(oc, config)(targets, posture_target)
+
+
+def cpu_baseline(config, q, targets, posture_target, com_target, budget_s=20.0):
+    """Restated reference timed on the host cores over a bounded sample of the same workload: the plain-C
+    port of the reference pipeline (oracle/c: dense H, c, G, h + Goldfarb–Idnani, like mink + MuJoCo +
+    quadprog) on all host threads.  Configs the C port does not cover (collision limits) and boxes where it
+    cannot be built use the numpy port on one thread."""
+    com0 = None if com_target is None else com_target[0, 0]
     try:
+        m, tasks, limits, dt, damping = _oracle_specs(config, targets[0], posture_target[0], com0)
         from oracle import cport
         prob = cport.CProblem(m, tasks, limits)
         threads = usable_cpus()
+        ct = None if com0 is None else com0[None, :]
         n0 = min(len(q), 512 * threads)
         t0 = time.perf_counter()
-        prob.solve_batch(q[:n0], targets[:n0], posture_target[None, :], dt, damping, nthreads=threads)
+        prob.solve_batch(q[:n0], targets[:n0], posture_target, dt, damping, com_target=ct, nthreads=threads)
         rate = n0 / (time.perf_counter() - t0)
         total = max(n0, rate * budget_s / threads)        # ≈ budget_s core-seconds of CPU work in all
         n = int(min(len(q), total))
@@ -127,24 +149,66 @@ def cpu_baseline(model, q, targets, posture_target, budget_s=20.0):
         t0 = time.perf_counter()
         bad = 0
         for _ in range(reps):
-            _, st = prob.solve_batch(q[:n], targets[:n], posture_target[None, :], dt, damping, nthreads=threads)
+            _, st = prob.solve_batch(q[:n], targets[:n], posture_target, dt, damping, com_target=ct, nthreads=threads)
             bad += int((st != 0).sum())
         el = time.perf_counter() - t0
         return {"value": n * reps / el, "unit": "solves/s", "cores": threads, "kind": "port",
-                "sample": f"{reps} x {n} G1 config-3 problems from the benchmark batch ({el * threads:.0f} core-seconds), "
+                "sample": f"{reps} x {n} {config} problems from the benchmark batch ({el * threads:.0f} core-seconds), "
                           f"oracle/c/mink_oracle.c (plain-C port of mink's dense pipeline + Goldfarb-Idnani), "
                           f"{threads} OpenMP threads (host CPU quota); {bad} failed"}
-    except (OSError, ImportError, RuntimeError, subprocess.CalledProcessError):
-        from oracle import ik
-        n_done = 0
-        t0 = time.perf_counter()
-        while n_done < len(q) and time.perf_counter() - t0 < budget_s:
-            m, tasks, limits, dt, damping = oc.g1_c3(targets[n_done], posture_target)
-            ik.solve_ik(model, q[n_done], tasks, dt, damping, limits)
-            n_done += 1
-        el = time.perf_counter() - t0
-        return {"value": n_done / el, "unit": "solves/s", "cores": 1, "kind": "port",
-                "sample": f"{n_done} G1 config-3 problems from the benchmark batch, oracle/ik.py (numpy), 1 thread"}
+    except (OSError, ImportError, RuntimeError, TypeError, subprocess.CalledProcessError):
+        return cpu_baseline_numpy(config, q, targets, posture_target, com_target, budget_s)
+
+
+def cpu_baseline_numpy(config, q, targets, posture_target, com_target, budget_s=8.0):
+    """The numpy restatement (oracle/ik.py): the same per-call structure and dispatch pattern as mink's Python
+    (one Configuration update, per-task error/Jacobian, dense build_ik, one QP), one thread."""
+    from oracle import ik
+    n_done = 0
+    t0 = time.perf_counter()
+    while n_done < len(q) and time.perf_counter() - t0 < budget_s:
+        com = None if com_target is None else com_target[n_done, 0]
+        m, tasks, limits, dt, damping = _oracle_specs(config, targets[n_done], posture_target[0], com)
+        ik.solve_ik(m, q[n_done], tasks, dt, damping, limits)
+        n_done += 1
+    el = time.perf_counter() - t0
+    return {"value": n_done / el, "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": f"{n_done} {config} problems from the benchmark batch, oracle/ik.py (numpy restatement of "
+                      f"mink's per-call Python structure), 1 thread"}
+
+
+def recorded_reference_baseline(config):
+    """Real `mink.solve_ik` (the reference's own Python, /root/reference, over oracle/stubs for the absent mujoco /
+    quadprog wheels) timed in the BUILD container by tools/time_reference_mink.py — the reference cannot travel
+    to the GPU box, so this is a recorded figure from other host cores, not a live one."""
+    path = os.path.join(REPO, "profiles", "r02_cpu_reference_mink.json")
+    try:
+        with open(path) as fh:
+            js = json.load(fh)
+        return dict(js[config], source=os.path.relpath(path, REPO))
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> None:
+    """`python bench.py --gpus N` without a launcher: become N ranks under torch.distributed.run."""
+    share = os.environ.get("MKH_BENCH_SHARE_GPU") == "1"
+    if not share:
+        from mink_amd import _native as nat
+        have = nat.lib().mkh_device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} requested but only {have} GPU(s) visible; refusing to "
+                             f"report a {args.gpus}-GPU line from fewer devices")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py")] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    os.execve(sys.executable, cmd, env)
 
 
 def main():
@@ -152,13 +216,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=65536, help="problems per GPU")
+    ap.add_argument("--config", default="g1_c3", choices=["ur5e_c2", "g1_c3", "g1_full", "shadow_c4"],
+                    help="BASELINE config (default: the headline G1 config 3)")
+    ap.add_argument("--batch", type=int, default=None, help="problems per GPU (default: the config's BASELINE batch)")
     ap.add_argument("--gather", action="store_true",
-                    help="N>1: end every step with an RCCL gather of v to rank 0 (BASELINE configs[4] as written); by "
-                         "default v stays sharded on the GPU that produced it — the instances are independent, so "
-                         "the path has no exchange step")
+                    help="(kept for compatibility) N>1 always reports the RCCL-gather variant in the 'gather' object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                 # does not return
 
     import torch
 
@@ -169,13 +238,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # Test hook for boxes with fewer GPUs than ranks (the N > 1 control flow can then be exercised on ONE GPU:
-    # `MKH_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`): every rank
-    # uses device 0 and the process group runs on gloo, because RCCL refuses two ranks on one device.
+    # `MKH_BENCH_SHARE_GPU=1 python bench.py --gpus 2`): every rank uses device 0 and the process group runs on
+    # gloo, because RCCL refuses two ranks on one device.
     share_gpu = os.environ.get("MKH_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: a line must report the GPUs it ran on")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -188,34 +257,61 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    B = args.batch
-    model = workloads.load_robot("g1")
+    cfg = workloads.BENCH_CONFIGS[args.config]
+    B = args.batch or cfg["batch"]
+    model = workloads.load_robot(cfg["robot"])
     nm = nat.NativeModel(model, device=local_rank)
-    prob, dt, damping = workloads.g1_config(model, nm, B)
+    prob, dt, damping = workloads.bench_config(args.config, model, nm, B)
     rng = np.random.default_rng(1000 + rank)
-    stand = model.key_qpos[model.name2id("key", "stand")]
-    q_h, tg_h = workloads.make_batch(model, nm, prob, rng, B, base_q=stand)
+    q_h, tg_h, pt_h, ct_h = workloads.bench_batch(args.config, model, nm, prob, rng, B)
     q = torch.from_numpy(q_h).to(dev)
     tg = torch.from_numpy(tg_h).to(dev)
-    pt = torch.from_numpy(stand[None, :].copy()).to(dev)
+    pt = torch.from_numpy(pt_h).to(dev)
+    ct = None if ct_h is None else torch.from_numpy(ct_h).to(dev)
     v = torch.empty((B, model.nv), dtype=torch.float64, device=dev)
     st = torch.empty((B,), dtype=torch.int32, device=dev)
-    do_gather = world > 1 and args.gather
-    v_all = torch.empty((world * B, model.nv), dtype=torch.float64, device=dev) if (do_gather and rank == 0) else None
+    v_all = torch.empty((world * B, model.nv), dtype=torch.float64, device=dev) if (world > 1 and rank == 0) else None
     from mink_amd.distributed import gather_rows
 
-    kern_events = []
+    def timed_region(do_gather: bool):
+        """W warm-up steps, then exactly K steps between barrier + synchronize; returns (elapsed s — MAX over
+        ranks, per-step kernel ms from HIP events on the launch stream, per-step gather ms)."""
+        kern_events, gath_events = [], []
 
-    def step(timed=False):
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        prob.solve(q, tg, pt, None, dt, damping, out=v, status_out=st)
-        if timed:
-            e1.record()                                 # HIP events on the launch stream, around the kernel only
-            kern_events.append((e0, e1))
-        if do_gather:
-            gather_rows(v, world * B, dst=0, out=v_all)   # RCCL gather of v to rank 0 (tests/test_distributed_cpu.py)
+        def step(timed=False):
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            prob.solve(q, tg, pt, ct, dt, damping, out=v, status_out=st)
+            if timed:
+                e1.record()                               # HIP events on the launch stream, around the kernel only
+                kern_events.append((e0, e1))
+            if do_gather:
+                gather_rows(v, world * B, dst=0, out=v_all)   # RCCL gather of v to rank 0 (tests/test_distributed_cpu.py)
+                if timed:
+                    e2 = torch.cuda.Event(enable_timing=True)
+                    e2.record()
+                    gath_events.append((e1, e2))
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(timed=True)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        return elapsed, [a.elapsed_time(b) for a, b in kern_events], [a.elapsed_time(b) for a, b in gath_events]
 
     # Python's cyclic GC must not run inside the timed region: with torch loaded a generation-2 collection
     # pauses the host for tens of ms — longer than the whole queue of launches takes to drain — and the GPU
@@ -223,69 +319,90 @@ def main():
     import gc
     gc.collect()
     gc.disable()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(timed=True)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, kern_list, _ = timed_region(False)
+    gather = None
+    if world > 1:
+        g_el, _, g_list = timed_region(True)
+        gather = {"value": world * B * args.steps / g_el, "unit": "solves/s", "ms_per_step": 1e3 * g_el / args.steps,
+                  "gather_ms_rank0_median": statistics.median(g_list) if g_list else None,
+                  "bytes_per_step_to_rank0": (world - 1) * B * model.nv * 8,
+                  "note": "same K steps, each followed by the RCCL gather of v (B x nv f64 per rank) into rank 0"}
     gc.enable()
-    kern_ms = sum(a.elapsed_time(b) for a, b in kern_events) / args.steps   # average launch duration of ik_solve_kernel
+    kern_ms = sum(kern_list) / args.steps                 # average launch duration of ik_solve_kernel (roofline)
+    kern_ms_median = statistics.median(kern_list)
     if os.environ.get("MKH_BENCH_DEBUG"):
-        print("kernel ms per step:", [round(a.elapsed_time(b), 3) for a, b in kern_events], file=sys.stderr)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        print("kernel ms per step:", [round(x, 3) for x in kern_list], file=sys.stderr)
 
     status = st.cpu().numpy()
     n_bad = int(((status & ~1) != 0).sum())
     if rank == 0:
         total = world * B * args.steps
         value = total / elapsed
-        ach = BYTES_PER_SOLVE_G1 * B / (kern_ms * 1e-3) / 1e9
+        bps = cfg["bytes_per_solve"]
+        ach = bps * B / (kern_ms * 1e-3) / 1e9
         info = prob.launch_info(B)
         kernel = prob.last_kernel()
-        flop = issued_flop_per_solve(kernel)
-        traffic = measured_traffic() if B == 65536 else None
+        nt = info["tableau_rows"]
+        waves_per_simd = 4 if nt <= 8 else (3 if nt <= 24 else 2)
+        if kernel.endswith("_w3") or "_w3_" in kernel:
+            waves_per_simd = 3
+        traffic = measured_traffic(args.config, B)
+        valu = measured_valu_issue(args.config, B, waves_per_simd)
+        roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
+                "traffic_source": traffic[1] if traffic else None,
+                "kernel": kernel, "kernel_ms": kern_ms, "kernel_ms_median": kern_ms_median,
+                "algorithmic_bytes_per_solve": bps, "algorithmic_bytes_per_launch": bps * B,
+                # what the kernel really runs out of (PMC: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x resident waves
+                # per SIMD, from the committed summary of this workload); HBM is the contract's nominal bound
+                "binding_resource": {"name": "valu_issue", "counter": "SQ_ACTIVE_INST_VALU/SQ_WAVE_CYCLES x waves/SIMD",
+                                     "frac": valu["simd_issue_slots_used"] if valu else None,
+                                     "source": valu["source"] if valu else None},
+                "note": "fp64 VALU-issue bound by design (serial pivots of one QP per wavefront); "
+                        "HBM fraction reported as the contract requires, compute views alongside",
+                "valu_issue_view": valu}
+        if args.config in ALGORITHMIC_FLOP_PER_SOLVE:
+            af = ALGORITHMIC_FLOP_PER_SOLVE[args.config]
+            flop = issued_flop_per_solve(kernel)
+            sec = kern_ms * 1e-3
+            roof["algorithmic_flop_view"] = {"flop_per_solve": af, "achieved_tflops": af * B / sec / 1e12,
+                                             "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                                             "frac": af * B / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                             "source": "SURVEY.md §8(d): 0.10-0.15 Mflop fp64 per solve of the reference "
+                                                       "algorithm (midpoint)"}
+            # issued fp64 tableau work only (all 64 lanes of every rank-1 row, useful or not)
+            roof["fp64_view"] = {"flop_per_solve": flop, "achieved_tflops": flop * B / sec / 1e12,
+                                 "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
+                                 "frac": flop * B / sec / 1e12 / FP64_VECTOR_PEAK_TFLOPS}
+        metric = "IK solves/sec (whole node), Unitree G1 4 FrameTasks + box limits, batch 65536"
+        if args.config != "g1_c3":
+            metric = f"IK solves/sec (whole node), {args.config}, batch {B}"
         out = {
-            "metric": "IK solves/sec (whole node), Unitree G1 4 FrameTasks + box limits, batch 65536",
+            "metric": metric,
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Unitree G1 (nq=44,nv=43): 4 FrameTasks(feet+palms)+PostureTask+"
-                                   "ConfigurationLimit+VelocityLimit, dt=5e-3, damping=1e-1 (BASELINE configs[2])",
+            # median of the timed steps (per-step kernel time from HIP events); `value` above is the
+            # contract's K steps / wall time between the barriers
+            "value_median_of_steps": world * B / (kern_ms_median * 1e-3),
+            "config": {"workload": cfg["workload"], "name": args.config,
                        "batch_per_gpu": B, "global_batch": world * B,
-                       "parallelism": f"batch-sharded x{world}" + (", RCCL gather of v" if do_gather else ""),
+                       "parallelism": f"batch-sharded x{world}, no data-path collective",
                        "launch": info, "failed_instances": n_bad},
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
-                         "traffic_source": traffic[1] if traffic else None,
-                         "kernel": kernel, "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_solve": BYTES_PER_SOLVE_G1,
-                         "algorithmic_bytes_per_launch": BYTES_PER_SOLVE_G1 * B,
-                         "note": "fp64 VALU-issue bound by design (serial pivots of one QP per wavefront); "
-                                 "HBM fraction reported as the contract requires, fp64 view alongside",
-                         # secondary compute view: issued fp64 tableau work only (issued_flop_per_solve)
-                         "fp64_view": {"flop_per_solve": flop,
-                                       "achieved_tflops": flop * B / (kern_ms * 1e-3) / 1e12,
-                                       "peak_tflops": FP64_VECTOR_PEAK_TFLOPS,
-                                       "frac": flop * B / (kern_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS},
-                         # ... and every VALU instruction (PMC): the resource the kernel actually runs out of
-                         "valu_issue_view": measured_valu_issue()},
+            "roofline": roof,
         }
+        if gather is not None:
+            out["gather"] = gather
         if world == 1:
-            out["pcie_inclusive_value"] = pcie_inclusive(prob, q_h, tg_h, stand, dt, damping)
+            out["pcie_inclusive_value"] = pcie_inclusive(prob, q_h, tg_h, pt_h, ct_h, dt, damping)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, q_h, tg_h, stand)
+            out["cpu_baseline"] = cpu_baseline(args.config, q_h, tg_h, pt_h, ct_h)
+            # mink's real dispatch pattern (per-call Python over numpy), next to the optimistic C port
+            out["cpu_baseline_python"] = (out["cpu_baseline"] if "numpy" in out["cpu_baseline"]["sample"]
+                                          else cpu_baseline_numpy(args.config, q_h, tg_h, pt_h, ct_h))
+            ref = recorded_reference_baseline(args.config)
+            if ref is not None:
+                out["cpu_reference_recorded"] = ref
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

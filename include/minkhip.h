@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MKH_VERSION 101
+#define MKH_VERSION 102
 
 /* return codes */
 #define MKH_OK 0
@@ -242,6 +242,33 @@ int32_t mkh_eval(MkhProblem *problem, int32_t B, const double *q, const double *
 /* Configuration.integrate (mink/configuration.py:214-226): q_out[b] = q[b] (+) v[b]*dt. */
 int32_t mkh_integrate(MkhModel *model, int32_t B, const double *q, const double *v, double dt,
                       double *q_out, int32_t flags, void *hip_stream);
+
+/*
+ * The SO3/SE3 device functions of the hot path (mkh lie_dev.h), evaluated element-wise over n inputs — the
+ * same code the frame-task lanes run, exposed so that it can be held directly against the reference's
+ * known-answer vectors (mink/lie/so3.py, mink/lie/se3.py, mink/lie/base.py:107-156).  Poses are wxyz_xyz (7),
+ * rotations wxyz (4), tangents (v, ω) (6); matrices row-major.  `b` may be NULL for unary ops.
+ *   MKH_LIE_SE3_LOG      a (n,7)          -> out (n,6)    SE3.log            se3.py:159-185
+ *   MKH_LIE_SE3_JLOG     a (n,7)          -> out (n,36)   jlog = rjacinv(log) base.py:150-156
+ *   MKH_LIE_SE3_LJACINV  a (n,6)          -> out (n,36)   SE3.ljacinv        se3.py:210-218
+ *   MKH_LIE_SE3_MULTIPLY a (n,7), b (n,7) -> out (n,7)    a @ b              se3.py:144-151
+ *   MKH_LIE_SE3_INVERSE  a (n,7)          -> out (n,7)    se3.py:136-142
+ *   MKH_LIE_SE3_RMINUS   a (n,7), b (n,7) -> out (n,6)    a.rminus(b) = log(b^-1 a)  base.py:111-112
+ *   MKH_LIE_SO3_LOG      a (n,4)          -> out (n,3)    SO3.log            so3.py:176-191
+ *   MKH_LIE_SO3_MATRIX   a (n,4)          -> out (n,9)    SO3.as_matrix      so3.py:111-114
+ *   MKH_LIE_SE3_APPLY    a (n,7), b (n,3) -> out (n,3)    SE3.apply          se3.py:153-157
+ */
+#define MKH_LIE_SE3_LOG 0
+#define MKH_LIE_SE3_JLOG 1
+#define MKH_LIE_SE3_LJACINV 2
+#define MKH_LIE_SE3_MULTIPLY 3
+#define MKH_LIE_SE3_INVERSE 4
+#define MKH_LIE_SE3_RMINUS 5
+#define MKH_LIE_SO3_LOG 6
+#define MKH_LIE_SO3_MATRIX 7
+#define MKH_LIE_SE3_APPLY 8
+int32_t mkh_lie_eval(int32_t device, int32_t op, int32_t n, const double *a, const double *b, double *out,
+                     int32_t flags, void *hip_stream);
 
 /* Launch geometry of the most recent solve / eval on this problem (the kernel variant depends on the call; see
  * mkh_problem_last_kernel); before any launch, that of the lean direct variant for a batch of B.  For benchmarks

@@ -134,6 +134,8 @@ def lib() -> C.CDLL:
     L.mkh_solve_steps.argtypes = common[:8] + [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.mkh_integrate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                 C.c_int32, C.c_void_p]
+    L.mkh_lie_eval.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.mkh_lie_eval.restype = C.c_int32
     L.mkh_problem_launch_info.argtypes = [C.c_void_p, C.c_int32] + [C.POINTER(C.c_int32)] * 4
     for f in ("mkh_model_create", "mkh_problem_create", "mkh_problem_num_task_rows",
               "mkh_problem_num_collision_pairs", "mkh_solve", "mkh_eval", "mkh_integrate",
@@ -147,8 +149,26 @@ EXPORTED_SYMBOLS = (
     "mkh_version", "mkh_last_error", "mkh_device_count", "mkh_model_create", "mkh_model_destroy",
     "mkh_problem_create", "mkh_problem_destroy", "mkh_problem_num_task_rows",
     "mkh_problem_num_collision_pairs", "mkh_solve", "mkh_eval", "mkh_integrate", "mkh_problem_launch_info",
-    "mkh_solve_steps", "mkh_problem_last_kernel",
+    "mkh_solve_steps", "mkh_problem_last_kernel", "mkh_lie_eval",
 )
+
+LIE_OPS = {"se3_log": (0, 7, 0, (6,)), "se3_jlog": (1, 7, 0, (6, 6)), "se3_ljacinv": (2, 6, 0, (6, 6)),
+           "se3_multiply": (3, 7, 7, (7,)), "se3_inverse": (4, 7, 0, (7,)), "se3_rminus": (5, 7, 7, (6,)),
+           "so3_log": (6, 4, 0, (3,)), "so3_matrix": (7, 4, 0, (3, 3)), "se3_apply": (8, 7, 3, (3,))}
+
+
+def lie_eval(op: str, a, b=None, device: int = 0) -> np.ndarray:
+    """The device SO3/SE3 functions of the hot path over a batch of inputs (mkh_lie_eval; host arrays)."""
+    code, na, nb, oshape = LIE_OPS[op]
+    a = _f64(a).reshape(-1, na)
+    n = len(a)
+    if nb:
+        b = _f64(b).reshape(-1, nb)
+        if len(b) != n:
+            raise ValueError("a and b must have the same leading dimension")
+    out = np.empty((n,) + oshape)
+    _check(lib().mkh_lie_eval(int(device), code, n, a.ctypes.data, b.ctypes.data if nb else None, out.ctypes.data, 0, None))
+    return out
 
 
 def _check(rc: int) -> None:

@@ -766,3 +766,107 @@ int32_t mkh_integrate(MkhModel* m, int32_t B, const double* q, const double* v, 
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ mkh_lie_eval
+namespace {
+__device__ void assemble_ljacinv(V3 v, V3 w, double* o) {
+  double J[9], Q[9];
+  bool ident;
+  se3_ljacinv(v, w, J, Q, ident);
+  // [[J, −J·Q·J],[0, J]]  (se3.py:217-218; identity when θ² < 1e-10)
+  double JQ[9], B[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) JQ[3 * i + j] = J[3 * i] * Q[j] + J[3 * i + 1] * Q[3 + j] + J[3 * i + 2] * Q[6 + j];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) B[3 * i + j] = -(JQ[3 * i] * J[j] + JQ[3 * i + 1] * J[3 + j] + JQ[3 * i + 2] * J[6 + j]);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      o[6 * i + j] = J[3 * i + j];
+      o[6 * i + 3 + j] = ident ? 0.0 : B[3 * i + j];
+      o[6 * (i + 3) + j] = 0.0;
+      o[6 * (i + 3) + 3 + j] = J[3 * i + j];
+    }
+}
+__device__ SE3 load_se3(const double* p) { return SE3{Q4{p[0], p[1], p[2], p[3]}, V3{p[4], p[5], p[6]}}; }
+__device__ void store_se3(double* o, SE3 T) {
+  o[0] = T.q.w; o[1] = T.q.x; o[2] = T.q.y; o[3] = T.q.z; o[4] = T.p.x; o[5] = T.p.y; o[6] = T.p.z;
+}
+__global__ __launch_bounds__(64) void lie_eval_kernel(int op, int n, const double* __restrict__ a,
+                                                      const double* __restrict__ b, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  V3 v, w;
+  switch (op) {
+    case MKH_LIE_SE3_LOG: {
+      se3_log(load_se3(a + 7 * i), v, w);
+      double* o = out + 6 * i;
+      o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = w.x; o[4] = w.y; o[5] = w.z;
+    } break;
+    case MKH_LIE_SE3_JLOG: {
+      se3_log(load_se3(a + 7 * i), v, w);
+      assemble_ljacinv(-1.0 * v, -1.0 * w, out + 36 * i);      // jlog(T) = ljacinv(−log T)
+    } break;
+    case MKH_LIE_SE3_LJACINV: {
+      const double* t = a + 6 * i;
+      assemble_ljacinv(V3{t[0], t[1], t[2]}, V3{t[3], t[4], t[5]}, out + 36 * i);
+    } break;
+    case MKH_LIE_SE3_MULTIPLY: store_se3(out + 7 * i, se3_mul(load_se3(a + 7 * i), load_se3(b + 7 * i))); break;
+    case MKH_LIE_SE3_INVERSE: store_se3(out + 7 * i, se3_inv(load_se3(a + 7 * i))); break;
+    case MKH_LIE_SE3_RMINUS: {
+      se3_log(se3_mul(se3_inv(load_se3(b + 7 * i)), load_se3(a + 7 * i)), v, w);
+      double* o = out + 6 * i;
+      o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = w.x; o[4] = w.y; o[5] = w.z;
+    } break;
+    case MKH_LIE_SO3_LOG: {
+      const double* q = a + 4 * i;
+      w = so3_log(Q4{q[0], q[1], q[2], q[3]});
+      out[3 * i] = w.x; out[3 * i + 1] = w.y; out[3 * i + 2] = w.z;
+    } break;
+    case MKH_LIE_SO3_MATRIX: {
+      const double* q = a + 4 * i;
+      const M3 R = qmat(Q4{q[0], q[1], q[2], q[3]});
+      for (int k = 0; k < 9; ++k) out[9 * i + k] = R.m[k];
+    } break;
+    case MKH_LIE_SE3_APPLY: {
+      const SE3 T = load_se3(a + 7 * i);
+      const V3 r = qrot(T.q, V3{b[3 * i], b[3 * i + 1], b[3 * i + 2]}) + T.p;
+      out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    } break;
+  }
+}
+}  // namespace
+
+extern "C" int32_t mkh_lie_eval(int32_t device, int32_t op, int32_t n, const double* a, const double* b, double* out,
+                                int32_t flags, void* hip_stream) {
+  static const int in_a[] = {7, 7, 6, 7, 7, 7, 4, 4, 7}, in_b[] = {0, 0, 0, 7, 0, 7, 0, 0, 3},
+                   n_out[] = {6, 36, 36, 7, 7, 6, 3, 9, 3};
+  if (op < 0 || op > MKH_LIE_SE3_APPLY) return fail(MKH_E_INVALID, "mkh_lie_eval: unknown op %d", op);
+  if (n < 1 || !a || !out || (in_b[op] && !b)) return fail(MKH_E_INVALID, "mkh_lie_eval: null argument or n < 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MKH_E_NOGPU, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(MKH_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+  HIP_OK(hipSetDevice(device));
+  hipStream_t stream = (hipStream_t)hip_stream;
+  const int grid = (n + 63) / 64;
+  if (flags & MKH_FLAG_DEVICE_PTRS) {
+    hipLaunchKernelGGL(lie_eval_kernel, dim3(grid), dim3(64), 0, stream, op, n, a, b, out);
+    HIP_OK(hipGetLastError());
+    return MKH_OK;
+  }
+  double *da = nullptr, *db = nullptr, *dout = nullptr;
+  const size_t ba = (size_t)n * in_a[op] * 8, bb = (size_t)n * in_b[op] * 8, bo = (size_t)n * n_out[op] * 8;
+  hipError_t e = hipMalloc((void**)&da, ba);
+  if (e == hipSuccess) e = hipMalloc((void**)&db, bb ? bb : 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&dout, bo);
+  if (e == hipSuccess) e = hipMemcpyAsync(da, a, ba, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess && bb) e = hipMemcpyAsync(db, b, bb, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(lie_eval_kernel, dim3(grid), dim3(64), 0, stream, op, n, da, db, dout);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, dout, bo, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+  if (e != hipSuccess) return fail(MKH_E_HIP, "lie_eval: %s", hipGetErrorString(e));
+  return MKH_OK;
+}

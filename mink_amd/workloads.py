@@ -73,6 +73,90 @@ def g1_config(model: FlatModel, nmodel: "nat.NativeModel", max_batch: int):
     return prob, 5e-3, 1e-1
 
 
+def _frame_desc(model: FlatModel, name: str, ftype: str, pos: float, ori: float, lm: float = 0.0) -> dict:
+    return {"frame_type": ftype, "frame_id": model.name2id(ftype, name), "cost": [pos] * 3 + [ori] * 3,
+            "gain": 1.0, "lm_damping": lm}
+
+
+def _hinge_velocities(model: FlatModel, vmax: float = np.pi) -> dict:
+    return {model.jnt_names[j]: vmax for j in range(model.njnt) if model.jnt_type[j] != JNT_FREE}
+
+
+SHADOW_FINGERS = ("thumb", "first", "middle", "ring", "little")
+
+# BASELINE.json configs: robot, keyframe, default batch, algorithmic bytes per solve
+# (q + frame targets + v + status, shared posture target; G1 full adds nothing per instance when the
+# CoM target is shared)
+BENCH_CONFIGS: Dict[str, dict] = {
+    "ur5e_c2": {"robot": "ur5e", "key": "home", "batch": 4096, "bytes_per_solve": 6 * 8 + 7 * 8 + 6 * 8 + 4,
+                "workload": "UR5e (nq=nv=6): FrameTask(attachment_site)+PostureTask+ConfigurationLimit+"
+                            "VelocityLimit, dt=2e-3, damping=1e-3 (BASELINE configs[1])"},
+    "g1_c3": {"robot": "g1", "key": "stand", "batch": 65536, "bytes_per_solve": 44 * 8 + 4 * 7 * 8 + 43 * 8 + 4,
+              "workload": "Unitree G1 (nq=44,nv=43): 4 FrameTasks(feet+palms)+PostureTask+"
+                          "ConfigurationLimit+VelocityLimit, dt=5e-3, damping=1e-1 (BASELINE configs[2])"},
+    "g1_full": {"robot": "g1", "key": "stand", "batch": 65536,
+                "bytes_per_solve": 44 * 8 + 5 * 7 * 8 + 3 * 8 + 43 * 8 + 4,
+                "workload": "Unitree G1 full example: pelvis-orientation + 4 FrameTasks + PostureTask + "
+                            "ComTask(per-instance target) + box limits (examples/humanoid_g1.py:22-52)"},
+    "shadow_c4": {"robot": "shadow_left", "key": "grasp hard", "batch": 16384,
+                  "bytes_per_solve": 24 * 8 + 5 * 7 * 8 + 24 * 8 + 4,
+                  "workload": "Shadow Hand left (nq=nv=24): 5 fingertip FrameTasks+PostureTask+ConfigurationLimit+"
+                              "CollisionAvoidanceLimit(40 capsule pairs, detect 30 mm), dt=2e-3, damping=1e-5 "
+                              "(BASELINE configs[3])"},
+}
+
+
+def bench_config(name: str, model: FlatModel, nmodel: "nat.NativeModel", max_batch: int):
+    """NativeProblem, dt, damping of a BASELINE config (same descriptors as tests/native_configs.py, built from
+    the product's own constructors so that bench.py does not touch tests/ or oracle/)."""
+    from .api_specs import configuration_limit_desc, velocity_limit_desc
+
+    cfg = [configuration_limit_desc(model)]
+    if name == "g1_c3":
+        return g1_config(model, nmodel, max_batch)
+    if name == "ur5e_c2":
+        prob = nat.NativeProblem(nmodel, frame_tasks=[_frame_desc(model, "attachment_site", "site", 1.0, 1.0, 1.0)],
+                                 posture_tasks=[{"cost": 1e-2}], configuration_limits=cfg,
+                                 velocity_limits=[velocity_limit_desc(model, _hinge_velocities(model))],
+                                 max_batch=max_batch)
+        return prob, 2e-3, 1e-3
+    if name == "g1_full":
+        fts = [_frame_desc(model, "pelvis", "body", 0.0, 10.0)] + \
+              [_frame_desc(model, s, "site", 200.0, 10.0, 1.0) for s in ("left_foot", "right_foot")] + \
+              [_frame_desc(model, s, "site", 200.0, 0.0, 1.0) for s in ("left_palm", "right_palm")]
+        prob = nat.NativeProblem(nmodel, frame_tasks=fts, posture_tasks=[{"cost": 1.0}], com_tasks=[{"cost": 200.0}],
+                                 configuration_limits=cfg,
+                                 velocity_limits=[velocity_limit_desc(model, _hinge_velocities(model))],
+                                 max_batch=max_batch)
+        return prob, 5e-3, 1e-1
+    if name == "shadow_c4":
+        from .limits import CollisionAvoidanceLimit
+
+        groups = [[f"{f}_1", f"{f}_2"] for f in SHADOW_FINGERS]
+        pairs = [(groups[i], groups[j]) for i in range(5) for j in range(i + 1, 5)]
+        col = CollisionAvoidanceLimit(model, pairs, collision_detection_distance=0.03)
+        fts = [_frame_desc(model, f, "site", 1.0, 0.0, 1.0) for f in SHADOW_FINGERS]
+        prob = nat.NativeProblem(nmodel, frame_tasks=fts, posture_tasks=[{"cost": 1e-2}], configuration_limits=cfg,
+                                 collision_limits=[col._native_desc()[1]], max_batch=max_batch)
+        return prob, 2e-3, 1e-5
+    raise KeyError(name)
+
+
+def bench_batch(name: str, model: FlatModel, nmodel, prob, rng: np.random.Generator, n: int):
+    """(q, frame_targets, posture_target, com_target) of a BASELINE config, host arrays (SURVEY §8d distributions);
+    com_target is per instance (the instance's own CoM + 1 cm) for the G1 full example, else None."""
+    c = BENCH_CONFIGS[name]
+    base = model.key_qpos[model.name2id("key", c["key"])]
+    q, tg = make_batch(model, nmodel, prob, rng, n, base_q=base)
+    if c["robot"] == "shadow_left":
+        q[::2] = 0.5 * (q[::2] + base)            # half of the samples near the grasp: fingers come close
+    com = None
+    if prob.n_com:
+        _, _, t = prob.solve(q, tg, base[None, :], np.zeros((1, 3)), 1.0, 1.0, taps=["subtree_com"], solve_qp=False)
+        com = t["subtree_com"][:, None, :] + 0.01
+    return q, tg, base[None, :].copy(), com
+
+
 def make_batch(model: FlatModel, nmodel, prob, rng: np.random.Generator, n: int, base_q=None,
                sigma: float = 0.15) -> Tuple[np.ndarray, np.ndarray]:
     """q and reachable frame targets = FK(q ⊕ δ), δ ~ N(0, σ²) per dof (device FK)."""

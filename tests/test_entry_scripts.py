@@ -63,7 +63,23 @@ def test_bench_helpers():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    assert b.BYTES_PER_SOLVE_G1 == 924 and b.HBM_PEAK_GBS == 8000.0
+    from mink_amd import workloads
+    assert workloads.BENCH_CONFIGS["g1_c3"]["bytes_per_solve"] == 924 and b.HBM_PEAK_GBS == 8000.0
+    assert workloads.BENCH_CONFIGS["ur5e_c2"]["bytes_per_solve"] == 156
+    assert workloads.BENCH_CONFIGS["shadow_c4"]["bytes_per_solve"] == 668
     assert b.issued_flop_per_solve("ik_solve_kernel_62_32_r44") > b.issued_flop_per_solve("ik_solve_kernel_8_0") > 0
     assert 1 <= b.usable_cpus() <= (os.cpu_count() or 1)
-    assert b.measured_traffic() is None or b.measured_traffic()[0] > 0
+    t = b.measured_traffic("g1_c3", 65536)
+    assert t is None or t[0] > 0
+    assert b.measured_traffic("g1_c3", 12345) is None
+    assert b._free_port() > 0
+
+
+def test_bench_refuses_wrong_world(monkeypatch):
+    """--gpus N must never print a line from a different number of ranks (round-1 finding)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and "{" not in r.stdout

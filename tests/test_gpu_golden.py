@@ -98,3 +98,72 @@ def test_intermediates_and_velocity(nat, name):
         assert prob.last_kernel().endswith("_32_r44"), prob.last_kernel()   # low-rank start, NT rows, 44 dof rows
     assert (st2 == st).all()
     assert err2[main].max() < 1e-8 and err2[~main].max() < 1e-5
+
+
+def _box_from_rows(G, h, nv):
+    """lo ≤ Δq ≤ hi implied by the ±unit rows of a reference (G, h) (configuration / velocity limit rows)."""
+    lo, hi = np.full(nv, -np.inf), np.full(nv, np.inf)
+    used = np.zeros(len(h), bool)
+    for r in range(len(h)):
+        nz = np.flatnonzero(G[r])
+        if len(nz) == 1 and abs(G[r, nz[0]]) == 1.0:
+            k = nz[0]
+            used[r] = True
+            if G[r, k] > 0:
+                hi[k] = min(hi[k], h[r])
+            else:
+                lo[k] = max(lo[k], -h[r])
+    return lo, hi, used
+
+
+@pytest.mark.parametrize("name", ["g1_ext", "ur5e_coll", "ballslide"])
+def test_round2_fixtures(nat, name):
+    """Fixtures recorded from the real mink by tests/golden/make_golden_ext.py: RelativeFrameTask (moving roots),
+    DampingTask, body/geom frames, PER-INSTANCE posture and CoM targets (MKH_FLAG_POSTURE_BATCHED / _COM_BATCHED),
+    the arm_ur5e.py collision set-up (capsule vs plane / box, half-spaces binding), ball + slide joints."""
+    d = _golden(name)
+    m = oc.model(nc.ROBOT_OF[name])
+    nm = nat.NativeModel(m)
+    B = len(d["q"])
+    prob, (ft, pt, ct), rows, dt, damping = nc.build_ext(name, nm, d, B)
+    assert dt == float(d["dt"]) and damping == float(d["damping"])
+    taps = ["task_e", "task_J", "H", "c", "box_lo", "box_hi"] + (["coll_G", "coll_h"] if prob.n_pairs else [])
+    v, st, t = prob.solve(d["q"], ft, pt, ct, dt, damping, taps=taps)
+    e_ref = d["task_e"] if rows is None else d["task_e"][:, rows]
+    np.testing.assert_allclose(t["task_e"], e_ref, rtol=0, atol=1e-12)
+    J_ref = d["task_J"] if rows is None else d["task_J"][:, rows]
+    np.testing.assert_allclose(t["task_J"][:len(J_ref)], J_ref, rtol=0, atol=1e-9)
+    main = np.ones(B, bool)
+    if name != "ur5e_coll":
+        main[7::8] = False                                    # small-angle sub-stream (δ ~ 1e-4)
+    dH = np.abs(t["H"] - d["H"]) / np.abs(d["H"]).max(axis=(1, 2), keepdims=True)
+    dc = np.abs(t["c"] - d["c"]) / np.abs(d["c"]).max(axis=1, keepdims=True)
+    print(name, "H err main/small", dH[main].max(), dH[~main].max(initial=0), "c err", dc[main].max(), dc[~main].max(initial=0))
+    assert dH[main].max() < 1e-11 and dc[main].max() < 1e-11
+    assert dH[~main].max(initial=0) < 1e-6 and dc[~main].max(initial=0) < 1e-6
+    nG = len(d["G"])
+    for i in range(nG):
+        lo, hi, used = _box_from_rows(d["G"][i], d["h"][i], m.nv)
+        np.testing.assert_allclose(t["box_lo"][i], lo, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(t["box_hi"][i], hi, rtol=0, atol=1e-13)
+        if prob.n_pairs:
+            hc, Gc = d["h"][i][~used], d["G"][i][~used]
+            fin = np.isfinite(hc)
+            assert (np.isfinite(t["coll_h"][i]) == fin).all()
+            np.testing.assert_allclose(t["coll_h"][i][fin], hc[fin], rtol=0, atol=1e-9)
+            np.testing.assert_allclose(t["coll_G"][i], Gc, rtol=0, atol=1e-10)
+    assert (st & ~1 == 0).all(), st
+    vs = np.maximum(1.0, np.abs(d["v"]).max(axis=1, keepdims=True))
+    err = np.abs(v - d["v"]) / vs
+    print(name, "max rel v err main/small", err[main].max(), err[~main].max(initial=0))
+    assert err[main].max() < 1e-8 and err[~main].max(initial=0) < 1e-5
+    v2, st2 = prob.solve(d["q"], ft, pt, ct, dt, damping)       # the production call (no taps)
+    err2 = np.abs(v2 - d["v"]) / vs
+    print(name, "production kernel", prob.last_kernel(), "max rel v err", err2.max())
+    assert (st2 == st).all() and err2[main].max() < 1e-8 and err2[~main].max(initial=0) < 1e-5
+    if name == "ur5e_coll":
+        # the fixture is only worth its name if half-spaces really bind
+        n = 6
+        hc = d["h"][:, 2 * n:2 * n + 2]
+        Gx = np.einsum("bpj,bj->bp", d["G"][:, 2 * n:2 * n + 2], v * dt)
+        assert ((np.abs(Gx - hc) < 1e-9) & np.isfinite(hc)).sum() >= 2

@@ -72,3 +72,28 @@ def test_ur5e_c1_trajectory(golden_dir):
     assert all(b < a for a, b in zip(errs[:4], errs[1:5]))
     assert errs[-1] < 2e-4
     np.testing.assert_allclose(cfg.q, d["q_final"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["g1_ext", "ur5e_coll", "ballslide"])
+def test_round2_fixtures(golden_dir, name):
+    """RelativeFrameTask / DampingTask / body- and geom-frame tasks / per-instance posture and CoM targets /
+    the arm_ur5e.py collision set-up / ball + slide joints, recorded from the real mink by make_golden_ext.py."""
+    d = _load(golden_dir, name)
+    for i in range(len(d["q"])):
+        m, tasks, limits, dt, damping = oc.EXT[name](d, i)
+        assert dt == float(d["dt"]) and damping == float(d["damping"])
+        cfg = ik.Configuration(m, d["q"][i])
+        P, c, G, h = ik.build_ik(cfg, tasks, dt, damping, limits)
+        np.testing.assert_allclose(P, d["H"][i], rtol=0, atol=1e-12 * max(1.0, np.abs(d["H"][i]).max()))
+        np.testing.assert_allclose(c, d["c"][i], rtol=0, atol=1e-12 * max(1.0, np.abs(d["c"][i]).max()))
+        fin = np.isfinite(d["h"][i])
+        assert (np.isfinite(h) == fin).all()
+        np.testing.assert_allclose(h[fin], d["h"][i][fin], rtol=0, atol=1e-12 * max(1.0, np.abs(d["h"][i][fin]).max()))
+        if i < len(d["G"]):
+            np.testing.assert_allclose(G, d["G"][i], rtol=0, atol=1e-13)
+            J = np.vstack([ik.task_error_jacobian(cfg, t)[1] for t in tasks])
+            np.testing.assert_allclose(J, d["task_J"][i], rtol=0, atol=1e-11)
+        e = np.concatenate([ik.task_error_jacobian(cfg, t)[0] for t in tasks])
+        np.testing.assert_allclose(e, d["task_e"][i], rtol=0, atol=1e-13)
+        v = ik.solve_ik(m, cfg, tasks, dt, damping, limits)
+        np.testing.assert_allclose(v, d["v"][i], rtol=0, atol=1e-9 * max(1.0, np.abs(d["v"][i]).max()))

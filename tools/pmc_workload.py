@@ -7,7 +7,9 @@ Dispatch sequence, in order:
      FETCH_SIZE / WRITE_SIZE can be turned into bytes for THIS access width on gfx950
      (MI355X_MICROARCH.md, HBM section: the counters are uncalibrated for anything but wide reads);
   2. the FK-only launch that manufactures reachable targets (workloads.make_batch);
-  3. N timed-style solves of the bench workload (G1 config 3, batch 65 536, device-resident).
+  3. N timed-style solves of the bench workload (device-resident).
+
+    python tools/pmc_workload.py [n_solves] [batch] [config]      (defaults: 4, the config's batch, g1_c3)
 """
 import os
 import sys
@@ -20,7 +22,7 @@ sys.path.insert(0, REPO)
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-    B = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+    config = sys.argv[3] if len(sys.argv) > 3 else "g1_c3"
     import torch
 
     from mink_amd import _native as nat
@@ -33,19 +35,21 @@ def main():
     torch.cuda.synchronize()
     del src, dst
 
-    model = workloads.load_robot("g1")
+    cfg = workloads.BENCH_CONFIGS[config]
+    B = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else cfg["batch"]
+    model = workloads.load_robot(cfg["robot"])
     nm = nat.NativeModel(model, device=0)
-    prob, dt, damping = workloads.g1_config(model, nm, B)
+    prob, dt, damping = workloads.bench_config(config, model, nm, B)
     rng = np.random.default_rng(1000)
-    stand = model.key_qpos[model.name2id("key", "stand")]
-    q_h, tg_h = workloads.make_batch(model, nm, prob, rng, B, base_q=stand)
+    q_h, tg_h, pt_h, ct_h = workloads.bench_batch(config, model, nm, prob, rng, B)
     q = torch.from_numpy(q_h).to(dev)
     tg = torch.from_numpy(tg_h).to(dev)
-    pt = torch.from_numpy(stand[None, :].copy()).to(dev)
+    pt = torch.from_numpy(pt_h).to(dev)
+    ct = None if ct_h is None else torch.from_numpy(ct_h).to(dev)
     v = torch.empty((B, model.nv), dtype=torch.float64, device=dev)
     st = torch.empty((B,), dtype=torch.int32, device=dev)
     for _ in range(n):
-        prob.solve(q, tg, pt, None, dt, damping, out=v, status_out=st)
+        prob.solve(q, tg, pt, ct, dt, damping, out=v, status_out=st)
     torch.cuda.synchronize()
 
 

@@ -1,29 +1,36 @@
 #!/bin/bash
 # rocprofv3 evidence for profiles/: run on the GPU box through gpurun, e.g.
-#   gpurun --timeout 900 -- 'bash tools/profile.sh r01c'
+#   gpurun --timeout 900 -- 'bash tools/profile.sh r02a g1_c3'        (config defaults to g1_c3)
+#   MKH_PROFILE_LIGHT=1 bash tools/profile.sh r02a ur5e_c2            (kernel trace + HBM counters only)
 # then copy gpurun_out/<tag>_* into profiles/.  Kernel trace/stats and each --pmc group are separate
 # passes (counters are never combined with sys/runtime/hip traces).  Every rocprofv3 pass runs under a hard timeout:
 # a profiler that fails to finalise (seen once after a GPU fault report inside the tool) must not eat the GPU budget.
 set -u
 TAG=${1:-rXX}
+CFG=${2:-g1_c3}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/prof_$TAG
+B=$(python -c "import sys; sys.path.insert(0, '$R'); from mink_amd import workloads as w; print(w.BENCH_CONFIGS['$CFG']['batch'])")
+NAME=${CFG}_b${B}
+O=$R/gpurun_out/prof_${TAG}_$CFG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 
-timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o g1 -- \
-  python "$R/bench.py" --steps 10 --warmup 2 --no-cpu-baseline > "$O/bench_under_trace.json" 2> "$O/trace.log"
-python "$R/tools/rocprof_summary.py" stats "$R/gpurun_out/${TAG}_g1_b65536_kernel_stats.csv" "$O/trace" > /dev/null
+timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o k -- \
+  python "$R/bench.py" --config $CFG --steps 20 --warmup 3 --no-cpu-baseline > "$O/bench_under_trace.json" 2> "$O/trace.log"
+python "$R/tools/rocprof_summary.py" stats "$R/gpurun_out/${TAG}_${NAME}_kernel_stats.csv" "$O/trace" > /dev/null
 
 i=0
-for grp in "FETCH_SIZE" "WRITE_SIZE" \
-           "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
-           "SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU"; do
+PMC_GROUPS=("FETCH_SIZE" "WRITE_SIZE" \
+        "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
+        "SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU")
+DIRS=()
+for grp in "${PMC_GROUPS[@]}"; do
   i=$((i + 1))
-  timeout -s KILL 180 rocprofv3 --pmc $grp --output-format csv -d "$O/pmc$i" -o g1 -- \
-    python "$R/tools/pmc_workload.py" 4 > "$O/pmc$i.log" 2>&1
+  timeout -s KILL 180 rocprofv3 --pmc $grp --output-format csv -d "$O/pmc$i" -o k -- \
+    python "$R/tools/pmc_workload.py" 4 0 $CFG > "$O/pmc$i.log" 2>&1
+  DIRS+=("$O/pmc$i")
 done
-python "$R/tools/rocprof_summary.py" pmc "$R/gpurun_out/${TAG}_g1_b65536_pmc.json" "$O"/pmc1 "$O"/pmc2 "$O"/pmc3 "$O"/pmc4
-python "$R/bench.py" --steps 20 --warmup 3 > "$R/gpurun_out/${TAG}_bench.json"
-cat "$R/gpurun_out/${TAG}_bench.json"
-head -5 "$R/gpurun_out/${TAG}_g1_b65536_kernel_stats.csv"
+python "$R/tools/rocprof_summary.py" pmc "$R/gpurun_out/${TAG}_${NAME}_pmc.json" "${DIRS[@]}"
+python "$R/bench.py" --config $CFG --steps 20 --warmup 3 > "$R/gpurun_out/${TAG}_${CFG}_bench.json" 2> "$O/bench.err"
+cat "$R/gpurun_out/${TAG}_${CFG}_bench.json"
+head -5 "$R/gpurun_out/${TAG}_${NAME}_kernel_stats.csv"
