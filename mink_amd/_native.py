@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -300,6 +301,10 @@ class NativeProblem:
         h = C.c_void_p()
         _check(lib().mkh_problem_create(nmodel.handle, C.byref(d), int(max_batch), C.byref(h)))
         self.handle = h
+        # one in-flight call per handle (it owns the staging buffers and the ticket counter): host-pointer calls are
+        # synchronous, so a lock makes them safe from several threads; device-pointer calls are asynchronous and must
+        # be ordered by the caller (same stream or events) — include/minkhip.h
+        self._lock = threading.Lock()
         self.max_batch = int(max_batch)
         self.n_frame, self.n_posture, self.n_com = len(frame_tasks), len(posture_tasks), len(com_tasks)
         self.n_rows = lib().mkh_problem_num_task_rows(h)
@@ -341,6 +346,12 @@ class NativeProblem:
               out=None, status_out=None, n_steps: Optional[int] = None, q_out=None, direct_qp: bool = False):
         """Returns (v, status[, taps dict]).  numpy in → numpy out (synchronous);
         torch CUDA tensors in → torch tensors out (asynchronous on the current stream)."""
+        with self._lock:
+            return self._solve(q, frame_targets, posture_target, com_target, dt, damping, taps, solve_qp, out,
+                               status_out, n_steps, q_out, direct_qp)
+
+    def _solve(self, q, frame_targets, posture_target, com_target, dt, damping, taps, solve_qp, out, status_out,
+               n_steps, q_out, direct_qp):
         m = self.nmodel.model
         use_torch = _is_torch(q)
         B = int(q.shape[0])

@@ -42,6 +42,9 @@ class Configuration:
     def __init__(self, model, q: Optional[np.ndarray] = None, device: int = 0):
         self.model = as_flat_model(model)
         self.device = int(device)
+        # compiled device descriptors of this configuration's call sites (insertion-ordered: LRU in solve_ik._compile).
+        # A descriptor owns one ticket counter and one set of staging buffers, so calls on ONE Configuration must not
+        # run concurrently from several threads/streams (include/minkhip.h "One in-flight call per MkhProblem").
         self._problems = {}
         self._q = None
         self.update(q if q is not None else self.model.qpos0)
@@ -125,6 +128,12 @@ class Configuration:
         fid = self.model.name2id(frame_type, frame_name)
         if fid == -1:
             raise exceptions.InvalidFrame(frame_name=frame_name, frame_type=frame_type, model=self.model)
+        if frame_type == "geom" and not self.model.geom_valid[fid]:
+            # primitive fitted to a mesh (type="capsule" mesh=...): its frame comes from the mesh asset, which the
+            # MJCF subset reader does not have — refuse rather than report a pose computed from placeholder values
+            raise exceptions.InvalidFrame(frame_name=frame_name, frame_type=frame_type, model=self.model,
+                                          reason="its local frame is derived from a mesh asset that was not available "
+                                                 "when the model was read")
         return fid
 
     def _frame_problem(self, fid: int, frame_type: str) -> "nat.NativeProblem":
@@ -164,6 +173,7 @@ class Configuration:
 
     def subtree_com(self) -> np.ndarray:
         """data.subtree_com[1] (used by ComTask.set_target_from_configuration)."""
+        self.model.require_valid_masses("subtree_com")
         key = ("com", self._q.shape[0])
         if key not in self._problems:
             self._problems[key] = nat.NativeProblem(self.native, com_tasks=[{"cost": 1.0}],

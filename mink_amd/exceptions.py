@@ -15,8 +15,11 @@ class UnsupportedFrame(MinkError):
 
 
 class InvalidFrame(MinkError):
-    def __init__(self, frame_name: str, frame_type: str, model):
+    def __init__(self, frame_name: str, frame_type: str, model, reason: str = None):
         names = {"body": model.body_names, "site": model.site_names, "geom": model.geom_names}[frame_type]
+        if reason is not None:
+            super().__init__(f"{frame_type} '{frame_name}' cannot be used as a frame: {reason}")
+            return
         super().__init__(f"{frame_type} '{frame_name}' does not exist in the model. "
                          f"Available {frame_type} names: {list(names)}")
 

@@ -50,7 +50,7 @@ _INT_FIELDS = (
     "body_jntadr", "body_dofnum", "body_dofadr", "body_geomnum", "body_geomadr",
     "jnt_type", "jnt_qposadr", "jnt_dofadr", "jnt_bodyid", "jnt_limited",
     "dof_bodyid", "dof_jntid", "dof_parentid", "site_bodyid", "geom_bodyid",
-    "geom_type", "geom_contype", "geom_conaffinity", "geom_valid",
+    "geom_type", "geom_contype", "geom_conaffinity", "geom_valid", "body_mass_valid",
 )
 _F64_FIELDS = (
     "body_pos", "body_quat", "body_ipos", "body_mass", "body_subtreemass",
@@ -90,6 +90,7 @@ class FlatModel:
     body_ipos: np.ndarray = None
     body_mass: np.ndarray = None
     body_subtreemass: np.ndarray = None
+    body_mass_valid: np.ndarray = None  # 0 for bodies whose mass / inertial frame needs mesh data (no <inertial>)
     # joints / dofs
     jnt_type: np.ndarray = None
     jnt_qposadr: np.ndarray = None
@@ -128,6 +129,8 @@ class FlatModel:
 
     # ------------------------------------------------------------------ setup
     def finalize(self) -> "FlatModel":
+        if self.body_mass_valid is None:        # (models serialised before the field existed; real MjModels)
+            self.body_mass_valid = np.ones(self.nbody, dtype=np.int32)
         for f in _INT_FIELDS:
             setattr(self, f, np.ascontiguousarray(getattr(self, f), dtype=np.int32))
         for f in _F64_FIELDS:
@@ -212,6 +215,16 @@ class FlatModel:
             mask |= 1 << i
             i = int(self.dof_parentid[i])
         return mask
+
+    def require_valid_masses(self, what: str) -> None:
+        """Mass-dependent quantities (subtree CoM, ComTask) of a model whose MJCF leaves a body's inertia to its
+        mesh geoms cannot be computed without the mesh assets: fail instead of using mass 0."""
+        bad = [self.body_names[b] or f"#{b}" for b in range(1, self.nbody)
+               if not self.body_mass_valid[b] and self.body_rootid[b] == 1]
+        if bad:
+            raise ValueError(f"{what} needs body masses, but {bad[:4]}{' ...' if len(bad) > 4 else ''} have no "
+                             "<inertial> and mesh geoms (mesh-derived inertia is not available to the MJCF subset "
+                             "reader): give those bodies an <inertial> element or ingest a compiled mujoco.MjModel")
 
     def freejoint_dims(self):
         """mink/utils.py:38-56."""

@@ -234,6 +234,7 @@ def load_mjcf(path: str) -> FlatModel:
     G: Dict[str, list] = {k: [] for k in (
         "body", "type", "size", "pos", "quat", "contype", "conaffinity", "name", "valid")}
 
+    mass_valid: Dict[int, int] = {}
     # world body
     for k, v in (("parent", 0), ("pos", np.zeros(3)), ("quat", np.array([1.0, 0, 0, 0])),
                  ("ipos", np.zeros(3)), ("mass", 0.0), ("mocap", False), ("name", "world"),
@@ -276,11 +277,15 @@ def load_mjcf(path: str) -> FlatModel:
         G["contype"].append(int(a.get("contype", 1)))
         G["conaffinity"].append(int(a.get("conaffinity", 1)))
         G["name"].append(a.get("name", "")); G["valid"].append(valid)
+        unknown = False
         if "mass" in a:
             m = float(a["mass"])
+        elif valid:
+            m = float(a.get("density", 1000.0)) * _geom_volume(gtype, size)
         else:
-            m = float(a.get("density", 1000.0)) * _geom_volume(gtype, size) if valid else 0.0
-        gmass_acc.append((m, pos))
+            m = 0.0
+            unknown = float(a.get("density", 1000.0)) != 0.0     # mass = density x (mesh volume): needs the asset
+        gmass_acc.append((m, pos, unknown))
 
     def add_site(el, body_id, childclass):
         a = defaults.resolve("site", el, childclass)
@@ -345,10 +350,14 @@ def load_mjcf(path: str) -> FlatModel:
             B["mass"][body_id] = float(inertial.get("mass"))
             B["ipos"][body_id] = _vec(inertial.get("pos"), 3, [0, 0, 0])
         elif body_id != 0:
-            mt = sum(m for m, _ in gmass)
+            mt = sum(m for m, _, _ in gmass)
             B["mass"][body_id] = mt
             if mt > mjMINVAL:
-                B["ipos"][body_id] = sum(m * p for m, p in gmass) / mt
+                B["ipos"][body_id] = sum(m * p for m, p, _ in gmass) / mt
+            if any(u for _, _, u in gmass):
+                # no <inertial> and a mesh geom with non-zero density: MuJoCo derives mass and inertial frame from
+                # the mesh.  Not available here — flag the body (FlatModel.require_valid_masses) instead of using 0.
+                mass_valid[body_id] = 0
         for ch in el:
             if ch.tag == "body":
                 visit_body(ch, body_id, childclass)
@@ -466,6 +475,7 @@ def load_mjcf(path: str) -> FlatModel:
         body_dofnum=body_dofnum, body_dofadr=body_dofadr, body_geomnum=B["geomnum"],
         body_geomadr=B["geomadr"], body_pos=arr(B["pos"], 3), body_quat=arr(B["quat"], 4),
         body_ipos=arr(B["ipos"], 3), body_mass=np.array(B["mass"]), body_subtreemass=subtreemass,
+        body_mass_valid=np.array([mass_valid.get(b, 1) for b in range(len(B["parent"]))], dtype=np.int32),
         jnt_type=J["type"], jnt_qposadr=jnt_qposadr, jnt_dofadr=jnt_dofadr,
         jnt_bodyid=J["body"], jnt_limited=J["limited"], jnt_pos=arr(J["pos"], 3),
         jnt_axis=arr(J["axis"], 3), jnt_range=arr(J["range"], 2), dof_bodyid=dof_bodyid,

@@ -17,6 +17,7 @@ from .configuration import Configuration
 from .flatmodel import JNT_FREE
 
 DEVICE_SOLVERS = ("mi355x", "hip", "quadprog")
+PROBLEM_CACHE_SIZE = 16       # compiled descriptors kept per Configuration (least recently used are destroyed)
 
 
 class Problem(NamedTuple):
@@ -55,12 +56,19 @@ def _compile(configuration: Configuration, tasks: Sequence, limits: Optional[Seq
         groups[kind].append(desc)
     key = (_key(groups), batch)
     cache = configuration._problems
-    if key not in cache:
-        cache[key] = nat.NativeProblem(
+    prob = cache.pop(key, None)
+    if prob is None:
+        prob = nat.NativeProblem(
             configuration.native, frame_tasks=groups["frame"], posture_tasks=groups["posture"],
             com_tasks=groups["com"], configuration_limits=groups["cfg"], velocity_limits=groups["vel"],
             collision_limits=groups["col"], max_batch=batch)
-    return cache[key], layout
+    cache[key] = prob                                               # (re)insert as most recently used
+    # Costs, gains and lm_damping are part of the device descriptor, so a caller that retunes a cost every control
+    # step compiles a new descriptor every step: bound the cache (LRU) and free the evicted device buffers.
+    while len(cache) > PROBLEM_CACHE_SIZE:
+        old = next(iter(cache))
+        cache.pop(old).close()
+    return prob, layout
 
 
 def _gather_targets(configuration: Configuration, layout):
@@ -150,8 +158,14 @@ def solve_ik_steps(configuration: Configuration, tasks: Sequence, dt: float, n_s
     prob, layout = _compile(configuration, tasks, limits, configuration.batch_size)
     ft, pt, ct = _gather_targets(configuration, layout)
     q, v, status = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping, n_steps=int(n_steps))
-    if (status & nat.ST_OUTSIDE_LIMITS).any() and safety_break:
-        configuration.check_limits(safety_break=True)
+    if (status & nat.ST_OUTSIDE_LIMITS).any():
+        # The bit is the OR over the fused steps (the reference loop checks every iteration, solve_ik.py:97): the
+        # start configuration first, then — a violation that appeared at step k > 0 — the last one.  An instance
+        # that left and re-entered its limits in between only warns.
+        configuration.check_limits(safety_break=safety_break)
+        Configuration(configuration.model, q, device=configuration.device).check_limits(safety_break=safety_break)
+        logging.warning("solve_ik_steps: %d instance(s) were outside their configuration limits at some fused step",
+                        int(((status & nat.ST_OUTSIDE_LIMITS) != 0).sum()))
     bad = np.nonzero(status & ~nat.ST_OUTSIDE_LIMITS)[0]
     if len(bad):
         raise exceptions.SolverError(f"QP failed for {len(bad)} of {len(status)} instances "

@@ -212,6 +212,7 @@ class ComTask(Task):
         self.set_target(configuration.subtree_com())
 
     def _native_desc(self, configuration):
+        configuration.model.require_valid_masses("ComTask")
         return "com", {"cost": self.cost.tolist(), "gain": self.gain, "lm_damping": self.lm_damping}
 
     def _native_target(self, configuration):

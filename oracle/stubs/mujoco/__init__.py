@@ -129,3 +129,37 @@ def mju_mulQuat(res, a, b):
 
 def mju_normalize3(v):
     return _mj.mju_normalize3(v)
+
+
+_NAMES = {mjtObj.mjOBJ_BODY: "body_names", mjtObj.mjOBJ_JOINT: "jnt_names", mjtObj.mjOBJ_GEOM: "geom_names",
+          mjtObj.mjOBJ_SITE: "site_names", mjtObj.mjOBJ_KEY: "key_names"}
+
+
+def mj_id2name(m, kind, i):
+    """None for unnamed objects, like the real binding."""
+    names = getattr(m, "_names")[_NAMES[mjtObj(kind)]] if hasattr(m, "_names") else getattr(m, _NAMES[mjtObj(kind)])
+    return names[i] or None
+
+
+class RawMjModel:
+    """A plain attribute bag with the REAL ``mujoco.MjModel`` field names, shapes and dtypes (int32 ids, uint8
+    ``jnt_limited``, float64 reals, names only through ``mj_id2name``) — and nothing of FlatModel's own interface —
+    so that the production ingest ``FlatModel.from_mjmodel`` can be executed without the wheel
+    (tests/test_api_cpu.py::test_from_mjmodel_ingest)."""
+
+    _INT = ("body_parentid", "body_rootid", "body_weldid", "body_mocapid", "body_jntnum", "body_jntadr", "body_dofnum",
+            "body_dofadr", "body_geomnum", "body_geomadr", "jnt_type", "jnt_qposadr", "jnt_dofadr", "jnt_bodyid",
+            "dof_bodyid", "dof_jntid", "dof_parentid", "site_bodyid", "geom_bodyid", "geom_type", "geom_contype",
+            "geom_conaffinity")
+    _F64 = ("body_pos", "body_quat", "body_ipos", "body_mass", "body_subtreemass", "jnt_pos", "jnt_axis", "jnt_range",
+            "qpos0", "site_pos", "site_quat", "geom_size", "geom_pos", "geom_quat", "key_qpos")
+
+    def __init__(self, flat: FlatModel):
+        for n in ("nq", "nv", "nbody", "njnt", "ngeom", "nsite", "nmocap", "nkey"):
+            setattr(self, n, int(getattr(flat, n)))
+        for n in self._INT:
+            setattr(self, n, np.array(getattr(flat, n), dtype=np.int32))
+        for n in self._F64:
+            setattr(self, n, np.array(getattr(flat, n), dtype=np.float64))
+        self.jnt_limited = np.array(flat.jnt_limited, dtype=np.uint8)       # mjtByte in the real struct
+        self._names = {k: list(getattr(flat, k)) for k in _NAMES.values()}

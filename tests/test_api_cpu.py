@@ -153,3 +153,65 @@ def test_exception_messages(g1):
     e = mink.NotWithinConfigurationLimits(joint_id=1, value=9.0, lower=-1.0, upper=1.0, model=g1)
     assert "Joint 1 (left_hip_pitch_joint) violates configuration limits -1.0 <= 9.0 <= 1.0" in str(e)
     assert "No target set for FrameTask" in str(mink.TargetNotSet("FrameTask"))
+
+
+def test_mesh_dependent_geometry_and_mass_are_refused():
+    """Round-1 advisor findings: a primitive fitted to a mesh (Shadow `*_3` geoms) has no usable size/frame without
+    the mesh asset, and a body without <inertial> whose geoms are meshes has no usable mass: both must fail loudly,
+    not compute from placeholders."""
+    import mink_amd as mink
+    from mink_amd import workloads
+    from mink_amd.mjcf import loads_mjcf
+
+    m = workloads.load_robot("shadow_left")
+    with pytest.raises(mink.LimitDefinitionError, match="mesh asset"):
+        mink.CollisionAvoidanceLimit(m, [(["first_3"], ["thumb_2"])])
+    mink.CollisionAvoidanceLimit(m, [(["first_2"], ["thumb_2"])])            # explicit-size capsules are fine
+    xml = """<mujoco><asset><mesh name="link" file="link.stl"/></asset><worldbody>
+      <body name="a"><joint type="hinge"/><geom type="mesh" mesh="link"/>
+        <body name="b" pos="0 0 1"><joint type="hinge"/><geom type="sphere" size=".1"/></body></body>
+      </worldbody></mujoco>"""
+    mm = loads_mjcf(xml)
+    assert mm.body_mass_valid.tolist() == [1, 0, 1]
+    with pytest.raises(ValueError, match="<inertial>"):
+        mm.require_valid_masses("ComTask")
+    workloads.load_robot("g1").require_valid_masses("ComTask")              # explicit <inertial> everywhere
+
+
+def test_from_mjmodel_ingest(monkeypatch):
+    """`Configuration(model: mujoco.MjModel)` (mink/configuration.py:37-51) → FlatModel.from_mjmodel, the production
+    ingest: executed on an object that exposes exactly the real MjModel attribute names / dtypes (oracle/stubs's
+    RawMjModel; the wheel itself is absent).  Every array the device library receives must come out identical to
+    the MJCF reader's model the raw object was filled from."""
+    import sys
+    monkeypatch.syspath_prepend(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "stubs"))
+    monkeypatch.delitem(sys.modules, "mujoco", raising=False)
+    import mujoco
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+    from mink_amd.configuration import as_flat_model
+    from mink_amd.flatmodel import FlatModel
+
+    try:
+        for robot in ("ur5e", "g1", "shadow_left"):
+            src = workloads.load_robot(robot)
+            raw = mujoco.RawMjModel(src)
+            assert not isinstance(raw, FlatModel) and type(raw).__module__ == "mujoco"
+            fm = as_flat_model(raw)                     # what Configuration.__init__ / PostureTask / the limits call
+            assert isinstance(fm, FlatModel) and fm is not src
+            for name, ctype in nat.MkhFlatModel._fields_:
+                a, b = getattr(fm, name), getattr(src, name)
+                if isinstance(a, np.ndarray):
+                    assert a.dtype == b.dtype and a.shape == b.shape, name
+                    np.testing.assert_array_equal(a, b, err_msg=name)
+                else:
+                    assert a == b, name
+            for name in ("body_names", "jnt_names", "site_names", "geom_names", "key_names"):
+                assert getattr(fm, name) == getattr(src, name), name
+            np.testing.assert_array_equal(fm.key_qpos, src.key_qpos)
+            np.testing.assert_array_equal(fm.mocap_pos, src.mocap_pos)
+            np.testing.assert_array_equal(fm.body_weldid, src.body_weldid)
+            assert fm.geom_valid.all() and fm.body_mass_valid.all()       # a compiled MjModel has every field
+            assert fm.name2id("site", src.site_names[0]) == 0
+    finally:
+        sys.modules.pop("mujoco", None)
