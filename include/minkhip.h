@@ -142,6 +142,20 @@ typedef struct MkhCollisionLimitDesc {
   double gain, minimum_distance_from_collisions, collision_detection_distance, bound_relaxation;
 } MkhCollisionLimitDesc;
 
+/*
+ * Plugin route: a caller-defined mink.Task subclass — anything that implements the reference's extension point
+ * Task.compute_error / Task.compute_jacobian (mink/tasks/task.py:81-103) — reaches the device as DENSE ROWS: the
+ * descriptor holds its constructor state (cost per row, gain, lm_damping: task.py:48-62), the per-call arrays hold
+ * what its two methods return for every instance (MkhDenseRows).  The kernel folds them into the objective exactly
+ * like Task.compute_qp_objective does (task.py:105-138): weighted rows W·J, weighted error W·(−gain·e),
+ * H += (WJ)ᵀ(WJ) + lm_damping·‖W·(−gain·e)‖²·I, c −= (W·(−gain·e))ᵀ·WJ.
+ */
+typedef struct MkhDenseTaskDesc {
+  int32_t k;            /* rows of compute_error / compute_jacobian */
+  const double *cost;   /* (k,) */
+  double gain, lm_damping;
+} MkhDenseTaskDesc;
+
 /* The task/limit lists solve_ik receives (mink/solve_ik.py:68-77).  The QP objective is a
  * sum, so list order only affects rounding; limits=[] disables limits, the Python layer
  * materialises mink's limits=None default (a fresh ConfigurationLimit, solve_ik.py:28-29). */
@@ -158,7 +172,22 @@ typedef struct MkhProblemDesc {
   const MkhVelocityLimitDesc *velocity_limits;
   int32_t n_collision_limits;
   const MkhCollisionLimitDesc *collision_limits;
+  /* plugin route (mkh_solve_dense): user Task subclasses, and the total number of rows G·Δq ≤ h that user Limit
+   * subclasses return from Limit.compute_qp_inequalities (mink/limits/limit.py:34-57) */
+  int32_t n_dense_tasks;
+  const MkhDenseTaskDesc *dense_tasks;
+  int32_t n_dense_limit_rows;
 } MkhProblemDesc;
+
+/* Per-call arrays of the plugin route (same host/device pointer convention as q).  K = Σ k over the dense tasks (in
+ * descriptor order), M = n_dense_limit_rows.  A limit row with h = +inf is inactive (mink's Constraint.inactive,
+ * limit.py:19-23, per row); at most 64 − nv rows (collision + dense) can be active in one instance. */
+typedef struct MkhDenseRows {
+  const double *task_e; /* (B, K)      compute_error per instance                    */
+  const double *task_J; /* (B, K, nv)  compute_jacobian per instance                 */
+  const double *limit_G;/* (B, M, nv)  compute_qp_inequalities(...).G per instance   */
+  const double *limit_h;/* (B, M)      compute_qp_inequalities(...).h per instance   */
+} MkhDenseRows;
 
 /* Optional debug/parity taps: any non-NULL pointer receives that intermediate for the
  * whole batch (same host/device convention as the other data pointers). */
@@ -230,6 +259,15 @@ int32_t mkh_solve(MkhProblem *problem, int32_t B, const double *q, const double 
 int32_t mkh_solve_steps(MkhProblem *problem, int32_t B, const double *q, const double *frame_targets,
                         const double *posture_target, const double *com_target, double dt, double damping,
                         int32_t n_steps, double *q_out, double *v_out, int32_t *status_out, int32_t flags,
+                        void *hip_stream);
+
+/*
+ * mkh_solve / mkh_eval for a problem with dense (plugin) rows: same arguments plus the per-call dense arrays.
+ * `taps` may be NULL (plain solve); task_e / task_J tap rows of the dense tasks follow the built-in ones.
+ */
+int32_t mkh_solve_dense(MkhProblem *problem, int32_t B, const double *q, const double *frame_targets,
+                        const double *posture_target, const double *com_target, const MkhDenseRows *dense, double dt,
+                        double damping, double *v_out, int32_t *status_out, const MkhTaps *taps, int32_t flags,
                         void *hip_stream);
 
 /* Same inputs; additionally writes the requested intermediates (build_ik / compute_error /

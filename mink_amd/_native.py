@@ -72,6 +72,14 @@ class MkhCollisionLimitDesc(C.Structure):
                 ("collision_detection_distance", C.c_double), ("bound_relaxation", C.c_double)]
 
 
+class MkhDenseTaskDesc(C.Structure):
+    _fields_ = [("k", C.c_int32), ("cost", _pd), ("gain", C.c_double), ("lm_damping", C.c_double)]
+
+
+class MkhDenseRows(C.Structure):
+    _fields_ = [("task_e", C.c_void_p), ("task_J", C.c_void_p), ("limit_G", C.c_void_p), ("limit_h", C.c_void_p)]
+
+
 class MkhProblemDesc(C.Structure):
     _fields_ = [
         ("n_frame_tasks", C.c_int32), ("frame_tasks", C.POINTER(MkhFrameTaskDesc)),
@@ -80,6 +88,8 @@ class MkhProblemDesc(C.Structure):
         ("n_configuration_limits", C.c_int32), ("configuration_limits", C.POINTER(MkhConfigurationLimitDesc)),
         ("n_velocity_limits", C.c_int32), ("velocity_limits", C.POINTER(MkhVelocityLimitDesc)),
         ("n_collision_limits", C.c_int32), ("collision_limits", C.POINTER(MkhCollisionLimitDesc)),
+        ("n_dense_tasks", C.c_int32), ("dense_tasks", C.POINTER(MkhDenseTaskDesc)),
+        ("n_dense_limit_rows", C.c_int32),
     ]
 
 
@@ -132,6 +142,9 @@ def lib() -> C.CDLL:
               C.c_void_p, C.c_void_p]
     L.mkh_solve.argtypes = common + [C.c_int32, C.c_void_p]
     L.mkh_eval.argtypes = common + [C.POINTER(MkhTaps), C.c_int32, C.c_void_p]
+    L.mkh_solve_dense.argtypes = common[:6] + [C.POINTER(MkhDenseRows), C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                               C.POINTER(MkhTaps), C.c_int32, C.c_void_p]
+    L.mkh_solve_dense.restype = C.c_int32
     L.mkh_solve_steps.argtypes = common[:8] + [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.mkh_integrate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                 C.c_int32, C.c_void_p]
@@ -150,7 +163,7 @@ EXPORTED_SYMBOLS = (
     "mkh_version", "mkh_last_error", "mkh_device_count", "mkh_model_create", "mkh_model_destroy",
     "mkh_problem_create", "mkh_problem_destroy", "mkh_problem_num_task_rows",
     "mkh_problem_num_collision_pairs", "mkh_solve", "mkh_eval", "mkh_integrate", "mkh_problem_launch_info",
-    "mkh_solve_steps", "mkh_problem_last_kernel", "mkh_lie_eval",
+    "mkh_solve_steps", "mkh_problem_last_kernel", "mkh_lie_eval", "mkh_solve_dense",
 )
 
 LIE_OPS = {"se3_log": (0, 7, 0, (6,)), "se3_jlog": (1, 7, 0, (6, 6)), "se3_ljacinv": (2, 6, 0, (6, 6)),
@@ -245,7 +258,7 @@ class NativeProblem:
     def __init__(self, nmodel: NativeModel, frame_tasks: Sequence[dict] = (), posture_tasks: Sequence[dict] = (),
                  com_tasks: Sequence[dict] = (), configuration_limits: Sequence[dict] = (),
                  velocity_limits: Sequence[dict] = (), collision_limits: Sequence[dict] = (),
-                 max_batch: int = 1):
+                 max_batch: int = 1, dense_tasks: Sequence[dict] = (), dense_limit_rows: int = 0):
         self.nmodel = nmodel
         m = nmodel.model
         keep = []
@@ -298,6 +311,15 @@ class NativeProblem:
         d.n_configuration_limits, d.configuration_limits = len(configuration_limits), cl
         d.n_velocity_limits, d.velocity_limits = len(velocity_limits), vl
         d.n_collision_limits, d.collision_limits = len(collision_limits), co
+        dn = arr(MkhDenseTaskDesc, dense_tasks)
+        for i, t in enumerate(dense_tasks):
+            c = _f64(np.atleast_1d(t["cost"])); keep.append(c)
+            dn[i].k = len(c); dn[i].cost = c.ctypes.data_as(_pd)
+            dn[i].gain = float(t.get("gain", 1.0)); dn[i].lm_damping = float(t.get("lm_damping", 0.0))
+        d.n_dense_tasks, d.dense_tasks = len(dense_tasks), dn
+        d.n_dense_limit_rows = int(dense_limit_rows)
+        self.n_dense_rows = int(sum(len(np.atleast_1d(t["cost"])) for t in dense_tasks))
+        self.n_dense_limit_rows = int(dense_limit_rows)
         h = C.c_void_p()
         _check(lib().mkh_problem_create(nmodel.handle, C.byref(d), int(max_batch), C.byref(h)))
         self.handle = h
@@ -343,15 +365,18 @@ class NativeProblem:
 
     def solve(self, q, frame_targets=None, posture_target=None, com_target=None, dt: float = 1e-2,
               damping: float = 1e-12, taps: Sequence[str] = (), solve_qp: bool = True,
-              out=None, status_out=None, n_steps: Optional[int] = None, q_out=None, direct_qp: bool = False):
+              out=None, status_out=None, n_steps: Optional[int] = None, q_out=None, direct_qp: bool = False,
+              dense: Optional[dict] = None):
         """Returns (v, status[, taps dict]).  numpy in → numpy out (synchronous);
-        torch CUDA tensors in → torch tensors out (asynchronous on the current stream)."""
+        torch CUDA tensors in → torch tensors out (asynchronous on the current stream).
+        `dense`: the plugin rows of a problem created with dense_tasks / dense_limit_rows —
+        {"task_e": (B, K), "task_J": (B, K, nv), "limit_G": (B, M, nv), "limit_h": (B, M)} (mkh_solve_dense)."""
         with self._lock:
             return self._solve(q, frame_targets, posture_target, com_target, dt, damping, taps, solve_qp, out,
-                               status_out, n_steps, q_out, direct_qp)
+                               status_out, n_steps, q_out, direct_qp, dense)
 
     def _solve(self, q, frame_targets, posture_target, com_target, dt, damping, taps, solve_qp, out, status_out,
-               n_steps, q_out, direct_qp):
+               n_steps, q_out, direct_qp, dense=None):
         m = self.nmodel.model
         use_torch = _is_torch(q)
         B = int(q.shape[0])
@@ -415,6 +440,30 @@ class NativeProblem:
                 raise ValueError(f"com_target must have shape ({self.n_com}, 3) or (B, ...)")
         args = [self.handle, B, ptr(q), ptr(frame_targets), ptr(posture_target), ptr(com_target), float(dt),
                 float(damping), ptr(v), ptr(st)]
+        if self.n_dense_rows or self.n_dense_limit_rows:
+            if n_steps is not None:
+                raise ValueError("dense (plugin) rows are evaluated by the caller at q: no fused steps")
+            dense = dense or {}
+            shapes_d = {"task_e": (B, self.n_dense_rows), "task_J": (B, self.n_dense_rows, m.nv),
+                        "limit_G": (B, self.n_dense_limit_rows, m.nv), "limit_h": (B, self.n_dense_limit_rows)}
+            dr, keep_d = MkhDenseRows(), []
+            for name, shp in shapes_d.items():
+                if 0 in shp:
+                    continue
+                x = dense.get(name)
+                if x is None or tuple(x.shape) != shp:
+                    raise ValueError(f"dense['{name}'] must have shape {shp}")
+                x = prep(x) if use_torch else _f64(x)
+                keep_d.append(x)
+                setattr(dr, name, x.data_ptr() if use_torch else x.ctypes.data)
+            tp = None
+            if taps or not solve_qp:
+                tp = MkhTaps()
+                for n in taps:
+                    setattr(tp, n, tapbufs[n].data_ptr() if use_torch else tapbufs[n].ctypes.data)
+            _check(lib().mkh_solve_dense(*args[:6], C.byref(dr), float(dt), float(damping), ptr(v), ptr(st),
+                                         C.byref(tp) if tp is not None else None, flags, stream))
+            return (v, st, tapbufs) if tp is not None else (v, st)
         if n_steps is not None:
             # fused (solve, integrate) x n_steps on the device: returns (q_final, v_last, status)
             if use_torch:

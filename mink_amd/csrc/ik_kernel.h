@@ -300,6 +300,9 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   constexpr int NT = MKH_NT, FEAT = MKH_FEAT;
   constexpr bool kTaps = (FEAT & F_TAPS) != 0, kRel = (FEAT & F_REL) != 0, kCom = (FEAT & F_COM) != 0;
   constexpr bool kColl = (FEAT & F_COLL) != 0, kSteps = (FEAT & F_STEPS) != 0, kWood = (FEAT & F_WOOD) != 0;
+  // plugin route (caller-defined Task / Limit subclasses as dense rows): only in the variants that carry every
+  // feature (FEAT 30 / 31) — it is the general path, not a tuned one
+  constexpr bool kDense = (FEAT & (F_ALL & ~F_TAPS)) == (F_ALL & ~F_TAPS) && !kWood;
 #ifdef MKH_NR
   constexpr int NR = MKH_NR;                 // dof rows of the tableau (low-rank start: NR ≥ nv, NT ≥ nv + n_μ)
 #else
@@ -746,6 +749,20 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       mu_total += P.com_lm[t] * ss;
     }
 
+    // caller-defined tasks (dense rows): Levenberg–Marquardt term lm·‖W·(−gain·e)‖² of each (task.py:129-131)
+    if (kDense && P.n_dense_rows > 0) {
+      const double* de = A.dense_e + (size_t)pb * P.n_dense_rows;
+      for (int t = 0; t < P.n_dense_tasks; ++t) {
+        const int k0 = P.dense_row0[t], kt = P.dense_k[t];
+        double ss = 0.0;
+        for (int r = lane; r < kt; r += kWave) {
+          const double we = P.dense_wgain[k0 + r] * de[k0 + r];
+          ss += we * we;
+        }
+        mu_total += P.dense_lm[t] * wave_sum(ss);
+      }
+    }
+
     hdiag += mu_total;
     const double hdiag_base = hdiag;   // damping + Σμ + posture diagonal: the explicit diagonal of H
 
@@ -925,6 +942,41 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           if ((rowmask >> r) & 1) { rank1_leading_rows<NT>(lds_addr(sJ + c * JS), is_dof ? Jw[r] : 0.0, AS); ++c; }
       }
     }
+    // caller-defined tasks: rows of W·J straight from memory (row r is contiguous over the dofs: one coalesced load
+    // per row), six at a time through the same staged rank-1 path as the built-in tasks
+    if (kDense && !kWood) {
+      const int K = P.n_dense_rows;
+      const double* de = A.dense_e + (size_t)pb * K;
+      const double* dJ = A.dense_J + (size_t)pb * K * nv;
+      for (int r0 = 0; r0 < K; r0 += 6) {
+        const int nr = min(6, K - r0);
+        double Jw[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          Jw[r] = 0.0;
+          if (r < nr) {
+            const double cw = P.dense_cost[r0 + r], we = P.dense_wgain[r0 + r] * de[r0 + r];
+            const double jr = is_dof ? dJ[(size_t)(r0 + r) * nv + lane] : 0.0;
+            Jw[r] = cw * jr;                                   // weighted_jacobian (task.py:129)
+            c_lane -= we * Jw[r];                              // c = −weighted_errorᵀ·weighted_jacobian
+            hdiag += Jw[r] * Jw[r];
+            if (MKH_TAP(t_task_J) && is_dof)
+              MKH_TAP(t_task_J)[((size_t)pb * P.n_rows_tap + P.dense_tap_row0 + r0 + r) * nv + lane] = jr;
+            if (MKH_TAP(t_task_e) && lane == 0)
+              MKH_TAP(t_task_e)[(size_t)pb * P.n_rows_tap + P.dense_tap_row0 + r0 + r] = de[r0 + r];
+          }
+        }
+        wave_sync();                                           // previous rows are consumed
+        if (lane < JS) {
+#pragma unroll
+          for (int r = 0; r < 6; ++r) sJ[r * JS + lane] = Jw[r];
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+          if (r < nr) rank1_leading_rows<NT>(lds_addr(sJ + r * JS), Jw[r], AS);
+      }
+    }
     MKH_MARK("jcols_done");
     long long tj = 0;
     if (MKH_TAP(t_cycles)) tj = __builtin_readcyclecounter();     // profiling: end of the Jacobian-column loop
@@ -1073,6 +1125,33 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           if (MKH_TAP(t_coll_G)) MKH_TAP(t_coll_G)[((size_t)pb * P.n_pairs + (int)o[12]) * nv + lane] = a;
         }
         if (lane < AS) sA[s * AS + lane] = a;
+      }
+    }
+    // caller-defined limits (Limit.compute_qp_inequalities, limits/limit.py:34-57): rows G·Δq ≤ h of this instance,
+    // appended to the half-space rows; h = +inf marks an inactive row
+    if (kDense && kColl && P.n_dense_limit_rows > 0) {
+      const int M = P.n_dense_limit_rows;
+      const double* dh = A.dense_h + (size_t)pb * M;
+      const double* dG = A.dense_G + (size_t)pb * M * nv;
+      const int first = nrows;
+      for (int base = 0; base < M; base += kWave) {
+        const int r = base + lane;
+        const double hr = r < M ? dh[r] : kInf;
+        const bool active = hr < kInf;
+        const unsigned long long am = __ballot(active);
+        const int slot = nrows + __popcll(am & ((1ull << lane) - 1ull));
+        if (active && slot < P.max_rows) {
+          double* o = sCol + slot * 16;
+          o[9] = hr;
+          o[12] = (double)r;
+        }
+        nrows += __popcll(am);
+      }
+      if (nrows > P.max_rows) { status |= 16; nrows = P.max_rows; }
+      wave_sync();
+      for (int s = first; s < nrows; ++s) {
+        const int r = (int)sCol[s * 16 + 12];
+        if (lane < AS) sA[s * AS + lane] = is_dof ? dG[(size_t)r * nv + lane] : 0.0;
       }
     }
     wave_sync();

@@ -86,6 +86,7 @@ struct MkhProblem {
   double* d_posture_cost = nullptr;
   double *d_cfg_lower = nullptr, *d_cfg_upper = nullptr, *d_vel = nullptr;
   CollisionPairDev* d_pairs = nullptr;
+  double *d_dense_cost = nullptr, *d_dense_wgain = nullptr;
   DeviceProblem* d_dev = nullptr;   // device copy of `dev` (the kernel reads the descriptor from memory)
   TapArgs* d_taps = nullptr;
   int last_grid = 0, last_lds = 0, last_nt = 0;   // geometry of the most recent launch (mkh_problem_launch_info)
@@ -94,6 +95,7 @@ struct MkhProblem {
   double *s_q = nullptr, *s_ft = nullptr, *s_pt = nullptr, *s_ct = nullptr, *s_v = nullptr;
   int32_t* s_status = nullptr;
   size_t s_pt_cap = 0, s_ct_cap = 0;
+  double *s_de = nullptr, *s_dJ = nullptr, *s_dG = nullptr, *s_dh = nullptr;   // dense (plugin) rows
 };
 
 // Kernel variants live in their own translation units (mink_amd/csrc/build.py generates one
@@ -296,6 +298,8 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   if (d->n_frame_tasks > kMaxFrameTasks) return fail(MKH_E_LIMIT, "at most %d frame tasks", kMaxFrameTasks);
   if (d->n_posture_tasks > kMaxPostureTasks) return fail(MKH_E_LIMIT, "at most %d posture tasks", kMaxPostureTasks);
   if (d->n_com_tasks > kMaxComTasks) return fail(MKH_E_LIMIT, "at most %d CoM tasks", kMaxComTasks);
+  if (d->n_dense_tasks < 0 || d->n_dense_tasks > kMaxDenseTasks) return fail(MKH_E_LIMIT, "at most %d dense (plugin) tasks", kMaxDenseTasks);
+  if (d->n_dense_limit_rows < 0) return fail(MKH_E_INVALID, "n_dense_limit_rows must be >= 0");
   if (d->n_configuration_limits > kMaxBoxTerms || d->n_velocity_limits > kMaxBoxTerms)
     return fail(MKH_E_LIMIT, "at most %d configuration and %d velocity limits", kMaxBoxTerms, kMaxBoxTerms);
   HIP_OK(hipSetDevice(m->device));
@@ -372,6 +376,25 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     P.com_jrow0[t] = jrows;
     jrows += __builtin_popcount(P.com_rowmask[t]);
   }
+  // ---- plugin route: caller-defined tasks as dense rows (tap rows follow the built-in ones)
+  std::vector<double> dcost, dwgain;
+  P.n_dense_tasks = d->n_dense_tasks;
+  P.dense_tap_row0 = row;
+  for (int t = 0; t < d->n_dense_tasks; ++t) {
+    const MkhDenseTaskDesc& s = d->dense_tasks[t];
+    if (s.k < 1 || !s.cost) return bail(fail(MKH_E_INVALID, "dense task %d: k must be >= 1 and cost non-null", t));
+    if (!(s.gain >= 0.0 && s.gain <= 1.0) || !(s.lm_damping >= 0.0))
+      return bail(fail(MKH_E_INVALID, "dense task %d: gain must be in [0, 1] and lm_damping >= 0", t));
+    P.dense_row0[t] = (int)dcost.size(); P.dense_k[t] = s.k; P.dense_lm[t] = s.lm_damping;
+    for (int r = 0; r < s.k; ++r) {
+      if (!(s.cost[r] >= 0.0)) return bail(fail(MKH_E_INVALID, "dense task %d: cost must be >= 0", t));
+      dcost.push_back(s.cost[r]);
+      dwgain.push_back(s.cost[r] * -s.gain);
+    }
+    row += s.k;
+  }
+  P.n_dense_rows = (int)dcost.size();
+  P.n_dense_limit_rows = d->n_dense_limit_rows;
   P.n_rows_tap = row;
   P.n_jrows = jrows;
 
@@ -429,7 +452,10 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     }
   }
   P.n_pairs = (int)pairs.size();
-  P.max_rows = P.n_pairs < (kWave - m->nv) ? P.n_pairs : (kWave - m->nv);
+  {
+    const int want = P.n_pairs + P.n_dense_limit_rows;          // half-space rows that can be active at once
+    P.max_rows = want < (kWave - m->nv) ? want : (kWave - m->nv);
+  }
   const int ntab = m->nv + P.max_rows;
   {
     static const int kVariants[] = {8, 16, 24, 32, 44, 48, 64};
@@ -444,9 +470,12 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   if (e == hipSuccess) e = upload(chi, &p->d_cfg_upper);
   if (e == hipSuccess) e = upload(vlim, &p->d_vel);
   if (e == hipSuccess) e = upload(pairs, &p->d_pairs);
+  if (e == hipSuccess) e = upload(dcost, &p->d_dense_cost);
+  if (e == hipSuccess) e = upload(dwgain, &p->d_dense_wgain);
   if (e != hipSuccess) return bail(fail(MKH_E_HIP, "problem upload: %s", hipGetErrorString(e)));
   P.frame = p->d_frame; P.posture_cost = p->d_posture_cost; P.cfg_lower = p->d_cfg_lower; P.cfg_upper = p->d_cfg_upper;
   P.vel_limit = p->d_vel; P.pairs = p->d_pairs;
+  P.dense_cost = p->d_dense_cost; P.dense_wgain = p->d_dense_wgain;
 
   P.nt = p->nt;
   const LdsLayout L = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, j_stride_direct(P.nv, p->nt));
@@ -458,7 +487,8 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
                       (int)sizeof(double);
   if (p->blocks_per_cu < 1) p->blocks_per_cu = 1;
   // ---- low-rank start eligibility: box limits only, frame tasks only, few task rows relative to nv
-  if (P.n_jrows > 0 && P.n_pairs == 0 && P.n_com == 0 && !p->has_relative && 2 * P.n_jrows <= m->nv &&
+  if (P.n_jrows > 0 && P.n_pairs == 0 && P.n_com == 0 && !p->has_relative && P.n_dense_rows == 0 &&
+      P.n_dense_limit_rows == 0 && 2 * P.n_jrows <= m->nv &&
       m->nv + P.n_jrows <= kWave) {
     static const int kWoodVariants[][2] = {{32, 16}, {32, 24}, {48, 24}, {48, 32}, {64, 32}, {62, 44}, {64, 44}, {64, 48}};
     for (const auto& v : kWoodVariants)
@@ -523,6 +553,8 @@ void mkh_problem_destroy(MkhProblem* p) {
   (void)hipSetDevice(p->model->device);
   (void)hipFree(p->d_frame); (void)hipFree(p->d_posture_cost); (void)hipFree(p->d_cfg_lower); (void)hipFree(p->d_cfg_upper);
   (void)hipFree(p->d_vel); (void)hipFree(p->d_pairs); (void)hipFree(p->d_dev); (void)hipFree(p->d_taps); (void)hipFree(p->d_work);
+  (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain);
+  (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh);
   (void)hipFree(p->s_q); (void)hipFree(p->s_ft); (void)hipFree(p->s_pt); (void)hipFree(p->s_ct); (void)hipFree(p->s_v); (void)hipFree(p->s_status);
   delete p;
 }
@@ -566,6 +598,8 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   if (p->dev.n_com > 0) need |= F_COM;
   if (p->dev.n_pairs > 0) need |= F_COLL;
   if (a.n_steps > 1 || a.q_out) need |= F_STEPS;
+  const bool dense = p->dev.n_dense_rows > 0 || p->dev.n_dense_limit_rows > 0;
+  if (dense) need |= 64;                                              // plugin rows: only the all-feature variants have them
   int feat;
   if (need == 0) feat = 0;
   else if (need == F_STEPS) feat = F_STEPS;
@@ -611,7 +645,8 @@ struct TapBuf {
 
 static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* frame_targets, const double* posture_target,
                    const double* com_target, double dt, double damping, double* v_out, int32_t* status_out,
-                   const MkhTaps* taps, int32_t flags, void* hip_stream, int32_t n_steps, double* q_out) {
+                   const MkhTaps* taps, int32_t flags, void* hip_stream, int32_t n_steps, double* q_out,
+                   const MkhDenseRows* dense = nullptr) {
   if (!p) return fail(MKH_E_INVALID, "null problem");
   if (B < 1) return fail(MKH_E_INVALID, "B must be >= 1");
   const DeviceProblem& P = p->dev;
@@ -621,6 +656,13 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
   if (P.n_com > 0 && !com_target) return fail(MKH_E_INVALID, "com_target is null (TargetNotSet)");
   if (!(dt > 0.0)) return fail(MKH_E_INVALID, "dt must be > 0");
   if (n_steps < 1) return fail(MKH_E_INVALID, "n_steps must be >= 1");
+  const size_t Kd = P.n_dense_rows, Md = P.n_dense_limit_rows;
+  if (Kd || Md) {
+    if (!dense) return fail(MKH_E_INVALID, "this problem has dense (plugin) rows: call mkh_solve_dense");
+    if (Kd && (!dense->task_e || !dense->task_J)) return fail(MKH_E_INVALID, "dense task_e / task_J is null");
+    if (Md && (!dense->limit_G || !dense->limit_h)) return fail(MKH_E_INVALID, "dense limit_G / limit_h is null");
+    if (n_steps > 1 || q_out) return fail(MKH_E_INVALID, "dense (plugin) rows are evaluated by the caller at q: no fused steps");
+  }
   HIP_OK(hipSetDevice(p->model->device));
   hipStream_t stream = (hipStream_t)hip_stream;
   const bool devp = (flags & MKH_FLAG_DEVICE_PTRS) != 0;
@@ -638,6 +680,8 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
   if (devp) {
     a.q = q; a.frame_targets = frame_targets; a.posture_target = posture_target; a.com_target = com_target;
     a.v_out = v_out; a.status_out = status_out; a.q_out = q_out;
+    if (Kd) { a.dense_e = dense->task_e; a.dense_J = dense->task_J; }
+    if (Md) { a.dense_G = dense->limit_G; a.dense_h = dense->limit_h; }
     if (taps) {
       t.t_xpos = taps->xpos; t.t_xquat = taps->xquat; t.t_frame_pose = taps->frame_pose;
       t.t_subtree_com = taps->subtree_com; t.t_task_e = taps->task_e; t.t_task_J = taps->task_J; t.t_H = taps->H;
@@ -660,6 +704,20 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
   if (P.n_frame) HIP_OK(hipMemcpyAsync(p->s_ft, frame_targets, (size_t)B * P.n_frame * 7 * sizeof(double), hipMemcpyHostToDevice, stream));
   if (n_pt) HIP_OK(hipMemcpyAsync(p->s_pt, posture_target, n_pt * sizeof(double), hipMemcpyHostToDevice, stream));
   if (n_ct) HIP_OK(hipMemcpyAsync(p->s_ct, com_target, n_ct * sizeof(double), hipMemcpyHostToDevice, stream));
+  if (Kd) {
+    HIP_OK(ensure(&p->s_de, mb * Kd));
+    HIP_OK(ensure(&p->s_dJ, mb * Kd * nv));
+    HIP_OK(hipMemcpyAsync(p->s_de, dense->task_e, (size_t)B * Kd * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_OK(hipMemcpyAsync(p->s_dJ, dense->task_J, (size_t)B * Kd * nv * sizeof(double), hipMemcpyHostToDevice, stream));
+    a.dense_e = p->s_de; a.dense_J = p->s_dJ;
+  }
+  if (Md) {
+    HIP_OK(ensure(&p->s_dG, mb * Md * nv));
+    HIP_OK(ensure(&p->s_dh, mb * Md));
+    HIP_OK(hipMemcpyAsync(p->s_dG, dense->limit_G, (size_t)B * Md * nv * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_OK(hipMemcpyAsync(p->s_dh, dense->limit_h, (size_t)B * Md * sizeof(double), hipMemcpyHostToDevice, stream));
+    a.dense_G = p->s_dG; a.dense_h = p->s_dh;
+  }
   a.q = p->s_q; a.frame_targets = p->s_ft; a.posture_target = p->s_pt; a.com_target = p->s_ct;
   a.v_out = v_out ? p->s_v : nullptr;
   a.status_out = p->s_status;
@@ -719,6 +777,14 @@ int32_t mkh_solve(MkhProblem* p, int32_t B, const double* q, const double* frame
   if (!v_out) return fail(MKH_E_INVALID, "v_out is null");
   return run(p, B, q, frame_targets, posture_target, com_target, dt, damping, v_out, status_out, nullptr, flags,
              hip_stream, 1, nullptr);
+}
+
+int32_t mkh_solve_dense(MkhProblem* p, int32_t B, const double* q, const double* frame_targets,
+                        const double* posture_target, const double* com_target, const MkhDenseRows* dense, double dt,
+                        double damping, double* v_out, int32_t* status_out, const MkhTaps* taps, int32_t flags,
+                        void* hip_stream) {
+  return run(p, B, q, frame_targets, posture_target, com_target, dt, damping, v_out, status_out, taps, flags, hip_stream,
+             1, nullptr, dense);
 }
 
 int32_t mkh_solve_steps(MkhProblem* p, int32_t B, const double* q, const double* frame_targets,

@@ -11,6 +11,7 @@ constexpr int kMaxRounds = 6;      // pointer-jumping rounds: tree depth <= 64
 constexpr int kMaxFrameTasks = 16;
 constexpr int kMaxPostureTasks = 4;
 constexpr int kMaxComTasks = 2;
+constexpr int kMaxDenseTasks = 8;  // caller-defined Task subclasses (dense rows)
 constexpr int kMaxBoxTerms = 4;    // ConfigurationLimit / VelocityLimit instances each
 
 // dof kinds
@@ -99,6 +100,12 @@ struct DeviceProblem {
   double cfg_gain[kMaxBoxTerms];
   const double* vel_limit;         // [n_vel][64], +inf when absent
   const CollisionPairDev* pairs;   // [n_pairs]
+  // plugin route: caller-defined tasks as dense rows (e, J per instance in SolveArgs) and caller-defined limit rows
+  int32_t n_dense_tasks, n_dense_rows, n_dense_limit_rows, dense_tap_row0;
+  int32_t dense_row0[kMaxDenseTasks], dense_k[kMaxDenseTasks];
+  double dense_lm[kMaxDenseTasks];
+  const double* dense_cost;        // [n_dense_rows] cost of each row
+  const double* dense_wgain;       // [n_dense_rows] cost·(−gain) of each row: weighted error = wgain·e
 };
 
 struct SolveArgs {
@@ -122,6 +129,11 @@ struct SolveArgs {
   // static_rounds = INT32_MAX: no tickets at all (every XCD owns a contiguous eighth of the batch).
   uint32_t* work_counter;
   int32_t static_rounds;
+  // plugin route (variants with every feature): dense task rows and dense limit rows of every instance
+  const double* dense_e;           // (B, n_dense_rows)
+  const double* dense_J;           // (B, n_dense_rows, nv)
+  const double* dense_G;           // (B, n_dense_limit_rows, nv)
+  const double* dense_h;           // (B, n_dense_limit_rows)
 };
 
 // Debug/parity taps (nullable pointers).  Lives in device memory and is passed by pointer so

@@ -26,11 +26,18 @@ class Constraint(NamedTuple):
 
 
 class Limit(abc.ABC):
-    """mink/limits/limit.py:26-57."""
+    """mink/limits/limit.py:26-57.  A subclass that only implements the reference's extension point
+    `compute_qp_inequalities(configuration, dt)` → Constraint(G, h) with G (m, nv) or (B, m, nv) and h (m,) or (B, m)
+    (h = +inf: row inactive) reaches the device as dense half-space rows (mkh_solve_dense); the built-in limits
+    override `_native_desc` and are evaluated on the device."""
 
-    @abc.abstractmethod
     def _native_desc(self):
         """(kind, descriptor dict) for mkh_problem_create."""
+        return "dense_limit", None
+
+    def _is_dense(self) -> bool:
+        return type(self)._native_desc is Limit._native_desc or \
+            type(self).compute_qp_inequalities not in _BUILTIN_INEQUALITIES
 
     def _eval(self, configuration: Configuration, dt: float, taps):
         from .solve_ik import _compile
@@ -207,3 +214,7 @@ class CollisionAvoidanceLimit(Limit):
     def compute_qp_inequalities(self, configuration: Configuration, dt: float) -> Constraint:
         out = self._eval(configuration, dt, ["coll_G", "coll_h"])
         return Constraint(G=configuration._unbatch(out["coll_G"]), h=configuration._unbatch(out["coll_h"]))
+
+
+_BUILTIN_INEQUALITIES = (ConfigurationLimit.compute_qp_inequalities, VelocityLimit.compute_qp_inequalities,
+                         CollisionAvoidanceLimit.compute_qp_inequalities)

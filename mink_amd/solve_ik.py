@@ -38,30 +38,75 @@ def _key(x):
     return x
 
 
-def _compile(configuration: Configuration, tasks: Sequence, limits: Optional[Sequence], batch: int):
+def _limit_rows(configuration: Configuration, lim, dt: float):
+    """(G, h) of a caller-defined limit for every instance: (B, m, nv), (B, m); m = 0 when inactive."""
+    B, nv = configuration.batch_size, configuration.nv
+    c = lim.compute_qp_inequalities(configuration, dt)
+    if c.inactive:
+        return np.zeros((B, 0, nv)), np.zeros((B, 0))
+    G, h = np.asarray(c.G, dtype=np.float64), np.asarray(c.h, dtype=np.float64)
+    m = h.shape[-1]
+    if G.shape not in ((m, nv), (B, m, nv)) or h.shape not in ((m,), (B, m)):
+        raise exceptions.LimitDefinitionError(
+            f"{type(lim).__name__}.compute_qp_inequalities must return G ({m}, {nv}) or ({B}, {m}, {nv}) and h ({m},) "
+            f"or ({B}, {m}); got {G.shape}, {h.shape}")
+    return np.broadcast_to(G, (B, m, nv)), np.broadcast_to(h, (B, m))
+
+
+def _dense_inputs(configuration: Configuration, layout, dt: float):
+    """Per-call arrays of the plugin route (mkh_solve_dense), None when the call site has no caller-defined rows."""
+    if not layout["dense"] and not layout["dense_limits"]:
+        return None
+    out = {}
+    if layout["dense"]:
+        rows = [t._dense_rows(configuration) for t in layout["dense"]]
+        out["task_e"] = np.ascontiguousarray(np.concatenate([e for e, _ in rows], axis=1))
+        out["task_J"] = np.ascontiguousarray(np.concatenate([J for _, J in rows], axis=1))
+    if layout["dense_limit_rows"]:
+        rows = layout["dense_limit_data"]                             # evaluated by _compile at this call's dt
+        out["limit_G"] = np.ascontiguousarray(np.concatenate([G for G, _ in rows], axis=1))
+        out["limit_h"] = np.ascontiguousarray(np.concatenate([h for _, h in rows], axis=1))
+    return out
+
+
+def _compile(configuration: Configuration, tasks: Sequence, limits: Optional[Sequence], batch: int,
+             dense_dt: float = 1.0):
     from .limits import ConfigurationLimit
+    from .tasks import Task
 
     if limits is None:
         limits = [ConfigurationLimit(configuration.model)]          # mink/solve_ik.py:28-29
-    groups = {"frame": [], "posture": [], "com": [], "cfg": [], "vel": [], "col": []}
-    layout = {"frame": [], "posture": [], "com": []}
+    groups = {"frame": [], "posture": [], "com": [], "cfg": [], "vel": [], "col": [], "dense": []}
+    layout = {"frame": [], "posture": [], "com": [], "dense": [], "dense_limits": [], "dense_limit_rows": 0}
     for t in tasks:
-        kind, desc = t._native_desc(configuration)
+        if t._is_dense():                                           # caller-defined Task subclass: dense rows
+            kind, desc = Task._native_desc(t, configuration)
+        else:
+            kind, desc = t._native_desc(configuration)
         groups[kind].append(desc)
         layout[kind].append(t)
     for lim in limits:
+        if lim._is_dense():                                         # caller-defined Limit subclass: dense rows
+            layout["dense_limits"].append(lim)
+            continue
         kind, desc = lim._native_desc()
         if kind in ("cfg", "vel") and len(desc["indices"]) == 0:
             continue                                                # inactive Constraint() (solve_ik.py:34)
         groups[kind].append(desc)
-    key = (_key(groups), batch)
+    if layout["dense_limits"]:
+        # the row count of a plugin limit is only known from what it returns: evaluate once here (dt does not change
+        # the shape), keep the rows for this call
+        layout["dense_limit_data"] = [_limit_rows(configuration, lim, dense_dt) for lim in layout["dense_limits"]]
+        layout["dense_limit_rows"] = sum(h.shape[-1] for _, h in layout["dense_limit_data"])
+    key = (_key(groups), batch, layout["dense_limit_rows"])
     cache = configuration._problems
     prob = cache.pop(key, None)
     if prob is None:
         prob = nat.NativeProblem(
             configuration.native, frame_tasks=groups["frame"], posture_tasks=groups["posture"],
             com_tasks=groups["com"], configuration_limits=groups["cfg"], velocity_limits=groups["vel"],
-            collision_limits=groups["col"], max_batch=batch)
+            collision_limits=groups["col"], max_batch=batch, dense_tasks=groups["dense"],
+            dense_limit_rows=layout["dense_limit_rows"])
     cache[key] = prob                                               # (re)insert as most recently used
     # Costs, gains and lm_damping are part of the device descriptor, so a caller that retunes a cost every control
     # step compiles a new descriptor every step: bound the cache (LRU) and free the evicted device buffers.
@@ -97,9 +142,10 @@ def build_ik(configuration: Configuration, tasks: Sequence, dt: float, damping: 
     inspection.  G/h stack the limits in list order exactly like the reference."""
     from .limits import ConfigurationLimit
 
-    prob, layout = _compile(configuration, tasks, limits, configuration.batch_size)
+    prob, layout = _compile(configuration, tasks, limits, configuration.batch_size, dt)
     ft, pt, ct = _gather_targets(configuration, layout)
-    _, _, out = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping, taps=["H", "c"], solve_qp=False)
+    _, _, out = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping, taps=["H", "c"], solve_qp=False,
+                           dense=_dense_inputs(configuration, layout, dt))
     lims = [ConfigurationLimit(configuration.model)] if limits is None else limits
     G_list, h_list = [], []
     for lim in lims:
@@ -128,9 +174,10 @@ def solve_ik(configuration: Configuration, tasks: Sequence, dt: float, solver: s
     solver (the reference forwards the string to qpsolvers).  Returns v of shape (nv,) or (B, nv).
     """
     del kwargs
-    prob, layout = _compile(configuration, tasks, limits, configuration.batch_size)
+    prob, layout = _compile(configuration, tasks, limits, configuration.batch_size, dt)
     ft, pt, ct = _gather_targets(configuration, layout)
-    v, status = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping)
+    v, status = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping,
+                           dense=_dense_inputs(configuration, layout, dt))
     if (status & nat.ST_OUTSIDE_LIMITS).any():
         configuration.check_limits(safety_break=safety_break)      # raises / warns like the reference
     bad = np.nonzero(status & ~nat.ST_OUTSIDE_LIMITS)[0]
@@ -155,7 +202,11 @@ def solve_ik_steps(configuration: Configuration, tasks: Sequence, dt: float, n_s
     kernel launch (the loop mink's callers write themselves, e.g. examples/arm_ur5e_actuators.py:88-97).
 
     Returns (q_final, v_last); with `update` the configuration is advanced in place."""
-    prob, layout = _compile(configuration, tasks, limits, configuration.batch_size)
+    prob, layout = _compile(configuration, tasks, limits, configuration.batch_size, dt)
+    if layout["dense"] or layout["dense_limits"]:
+        raise exceptions.TaskDefinitionError(
+            "solve_ik_steps fuses the outer loop on the device; caller-defined Task / Limit subclasses are evaluated on "
+            "the host at every step: call solve_ik + integrate_inplace in a loop instead")
     ft, pt, ct = _gather_targets(configuration, layout)
     q, v, status = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping, n_steps=int(n_steps))
     if (status & nat.ST_OUTSIDE_LIMITS).any():

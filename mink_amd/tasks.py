@@ -37,19 +37,43 @@ class Task(abc.ABC):
         self.lm_damping = lm_damping
 
     # -- device plumbing -------------------------------------------------
-    @abc.abstractmethod
+    # The extension point is the reference's (mink/tasks/task.py:81-103): a subclass that implements
+    # `compute_error(configuration)` → (k,) or (B, k) and `compute_jacobian(configuration)` → (k, nv) or (B, k, nv)
+    # — with numpy, for the whole batch of the Configuration — reaches the device as DENSE ROWS (mkh_solve_dense,
+    # include/minkhip.h) and is folded into the QP by the kernel like any built-in task.  The built-in classes below
+    # override `_native_desc` / `_native_target` instead: their error and Jacobian are computed on the device.
     def _native_desc(self, configuration: Configuration):
         """(kind, descriptor dict) for mkh_problem_create."""
+        return "dense", {"cost": np.array(self.cost, dtype=np.float64).reshape(-1), "gain": float(self.gain),
+                         "lm_damping": float(self.lm_damping)}
 
-    @abc.abstractmethod
     def _native_target(self, configuration: Configuration) -> np.ndarray:
-        """Target rows for mkh_solve."""
+        """Target rows for mkh_solve (built-in tasks only)."""
+        raise NotImplementedError
+
+    def _is_dense(self) -> bool:
+        """A caller-defined task: its own compute_error, or no device descriptor of its own."""
+        return type(self).compute_error is not Task.compute_error or type(self)._native_desc is Task._native_desc
+
+    def _dense_rows(self, configuration: Configuration):
+        """(e, J) of this caller-defined task for every instance: (B, k), (B, k, nv)."""
+        if type(self).compute_error is Task.compute_error or type(self).compute_jacobian is Task.compute_jacobian:
+            raise TaskDefinitionError(f"{type(self).__name__} must implement compute_error and compute_jacobian "
+                                      "(mink's Task plugin interface)")
+        B, nv, k = configuration.batch_size, configuration.nv, len(np.atleast_1d(self.cost))
+        e = np.asarray(self.compute_error(configuration), dtype=np.float64)
+        J = np.asarray(self.compute_jacobian(configuration), dtype=np.float64)
+        if e.shape not in ((k,), (B, k)) or J.shape not in ((k, nv), (B, k, nv)):
+            raise TaskDefinitionError(f"{type(self).__name__}: compute_error must return ({k},) or ({B}, {k}) and "
+                                      f"compute_jacobian ({k}, {nv}) or ({B}, {k}, {nv}); got {e.shape}, {J.shape}")
+        return np.broadcast_to(e, (B, k)), np.broadcast_to(J, (B, k, nv))
 
     def _eval(self, configuration: Configuration, taps):
-        from .solve_ik import _compile, _gather_targets
+        from .solve_ik import _compile, _dense_inputs, _gather_targets
         prob, layout = _compile(configuration, [self], limits=[], batch=configuration.batch_size)
         ft, pt, ct = _gather_targets(configuration, layout)
-        _, _, out = prob.solve(configuration.q_batch, ft, pt, ct, 1.0, 0.0, taps=taps, solve_qp=False)
+        _, _, out = prob.solve(configuration.q_batch, ft, pt, ct, 1.0, 0.0, taps=taps, solve_qp=False,
+                               dense=_dense_inputs(configuration, layout, 1.0))
         return out
 
     def compute_error(self, configuration: Configuration) -> np.ndarray:

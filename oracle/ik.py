@@ -96,6 +96,25 @@ class CollisionAvoidanceLimitSpec:
     bound_relaxation: float = 0.0
 
 
+@dataclass
+class DenseTaskSpec:
+    """A caller-defined mink.Task subclass reduced to what the reference's base class consumes
+    (mink/tasks/task.py:81-138): the values of compute_error / compute_jacobian at this configuration."""
+    e: np.ndarray                   # (k,)
+    J: np.ndarray                   # (k, nv)
+    cost: np.ndarray                # (k,)
+    gain: float = 1.0
+    lm_damping: float = 0.0
+
+
+@dataclass
+class DenseLimitSpec:
+    """A caller-defined mink.Limit subclass: the (G, h) its compute_qp_inequalities returns
+    (mink/limits/limit.py:34-57); rows with h = +inf are inactive."""
+    G: np.ndarray                   # (m, nv)
+    h: np.ndarray                   # (m,)
+
+
 # ----------------------------------------------------------- configuration
 class Configuration:
     """mink/configuration.py:21-64."""
@@ -202,6 +221,8 @@ def task_error_jacobian(cfg: Configuration, task) -> Tuple[np.ndarray, np.ndarra
                 qvel[va:va + 6] = 0.0
                 jac[:, va:va + 6] = 0.0
         return qvel, jac
+    if isinstance(task, DenseTaskSpec):
+        return np.asarray(task.e, dtype=np.float64), np.asarray(task.J, dtype=np.float64)
     if isinstance(task, ComTaskSpec):
         # mink/tasks/com_task.py:71-97 (subtree of body 1)
         e = cfg.data.subtree_com[1] - task.target
@@ -258,6 +279,8 @@ def limit_inequalities(cfg: Configuration, spec, dt: float):
         G = np.vstack([Pm, -Pm])
         h = np.hstack([spec.gain * delta_q_max[idx], spec.gain * delta_q_min[idx]])
         return G, h
+    if isinstance(spec, DenseLimitSpec):
+        return np.asarray(spec.G, dtype=np.float64), np.asarray(spec.h, dtype=np.float64)
     if isinstance(spec, VelocityLimitSpec):
         # mink/limits/velocity_limit.py:71-101
         if len(spec.indices) == 0:

@@ -43,19 +43,26 @@ def test_se3_group_operations(lie, g):
 
 def test_jlog_and_ljacinv(lie, g):
     np.testing.assert_allclose(lie("se3_jlog", g["se3_params"]), g["se3_jlog"], rtol=0, atol=1e-12)
-    np.testing.assert_allclose(lie("se3_ljacinv", g["tangent"]), g["se3_ljacinv"], rtol=0, atol=5e-9)
-    # the Taylor band: the reference's closed forms cancel catastrophically for small θ (noise ≈ 5e-17/θ²,
-    # SURVEY §7 hard part 3), so each sample is held to that bound instead of one flat tolerance
+    # The reference's closed forms cancel catastrophically for small θ (its own float64 output is off by
+    # ≈5e-17·(1+|v|)/θ², 4e-7 at θ = 1.2e-5 — SURVEY §7 hard part 3), so a direct comparison cannot be tighter than
+    # that noise.  lie_exact.npz holds the 60-digit values (tests/golden/make_lie_exact.py): the device must be at
+    # least as accurate as the reference is (factor 4, floor 2e-12), sample by sample.
+    ex = np.load(os.path.join(oc.GOLDEN, "lie_exact.npz"))
     th = np.linalg.norm(g["tangent"][:, 3:], axis=1)
-    err = np.abs(lie("se3_ljacinv", g["tangent"]) - g["se3_ljacinv"]).max(axis=(1, 2))
-    ok = th > 1e-5
-    assert (err[ok] <= 1e-12 + 2e-16 / th[ok] ** 2 * (1.0 + np.abs(g["tangent"][ok, :3]).max(axis=1))).all(), (err, th)
-    small = th < 1e-5            # θ² < 1e-10: both sides return the identity
+    for op, arg, ref, exact in (("se3_ljacinv", g["tangent"], g["se3_ljacinv"], ex["se3_ljacinv"]),
+                                ("se3_jlog", g["se3_exp"], g["se3_jlog_of_exp"], ex["se3_jlog_of_exp"])):
+        out = lie(op, arg)
+        err_dev = np.abs(out - exact).max(axis=(1, 2))
+        err_ref = np.abs(ref - exact).max(axis=(1, 2))
+        print(op, "max err vs exact: device %.2e, reference %.2e" % (err_dev.max(), err_ref.max()))
+        bad = err_dev > 4.0 * err_ref + 2e-12
+        assert not bad.any(), (op, err_dev[bad], err_ref[bad], th[bad])
+        # and, for rotations that are not small, plain agreement with the reference
+        big = th > 1e-2
+        np.testing.assert_allclose(out[big], ref[big], rtol=0, atol=1e-11)
+    small = th < 1e-5                                   # θ² < 1e-10: both sides return the identity
     assert small.any()
     np.testing.assert_array_equal(lie("se3_ljacinv", g["tangent"][small]), g["se3_ljacinv"][small])
-    out = lie("se3_jlog", g["se3_exp"])
-    errj = np.abs(out - g["se3_jlog_of_exp"]).max(axis=(1, 2))
-    assert (errj[ok] <= 1e-12 + 4e-16 / th[ok] ** 2 * (1.0 + np.abs(g["tangent"][ok, :3]).max(axis=1))).all(), (errj, th)
 
 
 def test_so3_log_special_quaternions(lie, g):

@@ -15,9 +15,11 @@ O=$R/gpurun_out/prof_${TAG}_$CFG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 
+if [ -z "${MKH_PROFILE_PMC_ONLY:-}" ]; then
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o k -- \
   python "$R/bench.py" --config $CFG --steps 20 --warmup 3 --no-cpu-baseline > "$O/bench_under_trace.json" 2> "$O/trace.log"
 python "$R/tools/rocprof_summary.py" stats "$R/gpurun_out/${TAG}_${NAME}_kernel_stats.csv" "$O/trace" > /dev/null
+fi
 
 i=0
 PMC_GROUPS=("FETCH_SIZE" "WRITE_SIZE" \
@@ -31,6 +33,8 @@ for grp in "${PMC_GROUPS[@]}"; do
   DIRS+=("$O/pmc$i")
 done
 python "$R/tools/rocprof_summary.py" pmc "$R/gpurun_out/${TAG}_${NAME}_pmc.json" "${DIRS[@]}"
+if [ -z "${MKH_PROFILE_PMC_ONLY:-}" ]; then
 python "$R/bench.py" --config $CFG --steps 20 --warmup 3 > "$R/gpurun_out/${TAG}_${CFG}_bench.json" 2> "$O/bench.err"
 cat "$R/gpurun_out/${TAG}_${CFG}_bench.json"
 head -5 "$R/gpurun_out/${TAG}_${NAME}_kernel_stats.csv"
+fi
