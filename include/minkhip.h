@@ -270,6 +270,23 @@ int32_t mkh_solve_dense(MkhProblem *problem, int32_t B, const double *q, const d
                         double damping, double *v_out, int32_t *status_out, const MkhTaps *taps, int32_t flags,
                         void *hip_stream);
 
+/*
+ * The same loop as the reference's callers REALLY write it (examples/arm_ur5e_actuators.py:88-97,
+ * examples/arm_aloha.py:146-169):
+ *   for i in range(max_iters):
+ *       v = solve_ik(cfg, ...); cfg.integrate_inplace(v, dt)
+ *       err = task.compute_error(cfg)
+ *       if norm(err[:3]) <= pos_threshold and norm(err[3:]) <= ori_threshold: break      (for every frame task)
+ * per instance, in one launch.  The position (orientation) test of a frame task only counts when it has a nonzero
+ * position (orientation) cost.  iters_out (B,) = iterations performed (1..max_iters), converged_out (B,) = 1 when the
+ * loop ended on the thresholds; q_out / v_out / status_out as in mkh_solve_steps.  iters_out / converged_out may be NULL.
+ */
+int32_t mkh_solve_until(MkhProblem *problem, int32_t B, const double *q, const double *frame_targets,
+                        const double *posture_target, const double *com_target, double dt, double damping,
+                        int32_t max_iters, double pos_threshold, double ori_threshold, double *q_out, double *v_out,
+                        int32_t *status_out, int32_t *iters_out, int32_t *converged_out, int32_t flags,
+                        void *hip_stream);
+
 /* Same inputs; additionally writes the requested intermediates (build_ik / compute_error /
  * compute_jacobian / get_transform_frame_to_world parity taps).  v_out/status_out may be NULL
  * to skip the QP. */

@@ -142,6 +142,8 @@ def lib() -> C.CDLL:
               C.c_void_p, C.c_void_p]
     L.mkh_solve.argtypes = common + [C.c_int32, C.c_void_p]
     L.mkh_eval.argtypes = common + [C.POINTER(MkhTaps), C.c_int32, C.c_void_p]
+    L.mkh_solve_until.argtypes = common[:8] + [C.c_int32, C.c_double, C.c_double] + [C.c_void_p] * 5 + [C.c_int32, C.c_void_p]
+    L.mkh_solve_until.restype = C.c_int32
     L.mkh_solve_dense.argtypes = common[:6] + [C.POINTER(MkhDenseRows), C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                                C.POINTER(MkhTaps), C.c_int32, C.c_void_p]
     L.mkh_solve_dense.restype = C.c_int32
@@ -163,7 +165,7 @@ EXPORTED_SYMBOLS = (
     "mkh_version", "mkh_last_error", "mkh_device_count", "mkh_model_create", "mkh_model_destroy",
     "mkh_problem_create", "mkh_problem_destroy", "mkh_problem_num_task_rows",
     "mkh_problem_num_collision_pairs", "mkh_solve", "mkh_eval", "mkh_integrate", "mkh_problem_launch_info",
-    "mkh_solve_steps", "mkh_problem_last_kernel", "mkh_lie_eval", "mkh_solve_dense",
+    "mkh_solve_steps", "mkh_problem_last_kernel", "mkh_lie_eval", "mkh_solve_dense", "mkh_solve_until",
 )
 
 LIE_OPS = {"se3_log": (0, 7, 0, (6,)), "se3_jlog": (1, 7, 0, (6, 6)), "se3_ljacinv": (2, 6, 0, (6, 6)),
@@ -366,17 +368,19 @@ class NativeProblem:
     def solve(self, q, frame_targets=None, posture_target=None, com_target=None, dt: float = 1e-2,
               damping: float = 1e-12, taps: Sequence[str] = (), solve_qp: bool = True,
               out=None, status_out=None, n_steps: Optional[int] = None, q_out=None, direct_qp: bool = False,
-              dense: Optional[dict] = None):
+              dense: Optional[dict] = None, until: Optional[tuple] = None):
         """Returns (v, status[, taps dict]).  numpy in → numpy out (synchronous);
         torch CUDA tensors in → torch tensors out (asynchronous on the current stream).
+        `until` = (pos_threshold, ori_threshold) with n_steps = max_iters: the threshold-terminated loop
+        (mkh_solve_until), returns (q_final, v_last, status, iters, converged).
         `dense`: the plugin rows of a problem created with dense_tasks / dense_limit_rows —
         {"task_e": (B, K), "task_J": (B, K, nv), "limit_G": (B, M, nv), "limit_h": (B, M)} (mkh_solve_dense)."""
         with self._lock:
             return self._solve(q, frame_targets, posture_target, com_target, dt, damping, taps, solve_qp, out,
-                               status_out, n_steps, q_out, direct_qp, dense)
+                               status_out, n_steps, q_out, direct_qp, dense, until)
 
     def _solve(self, q, frame_targets, posture_target, com_target, dt, damping, taps, solve_qp, out, status_out,
-               n_steps, q_out, direct_qp, dense=None):
+               n_steps, q_out, direct_qp, dense=None, until=None):
         m = self.nmodel.model
         use_torch = _is_torch(q)
         B = int(q.shape[0])
@@ -471,6 +475,14 @@ class NativeProblem:
                 qo = torch.empty_like(q) if q_out is None else q_out
             else:
                 qo = np.empty_like(q) if q_out is None else q_out
+            if until is not None:
+                if use_torch:
+                    it = torch.empty((B,), dtype=torch.int32, device=dev); cv = torch.empty_like(it)
+                else:
+                    it = np.zeros((B,), dtype=np.int32); cv = np.zeros((B,), dtype=np.int32)
+                _check(lib().mkh_solve_until(*args[:8], int(n_steps), float(until[0]), float(until[1]), ptr(qo), ptr(v),
+                                             ptr(st), ptr(it), ptr(cv), flags, stream))
+                return qo, v, st, it, cv
             _check(lib().mkh_solve_steps(*args[:8], int(n_steps), ptr(qo), ptr(v), ptr(st), flags, stream))
             return qo, v, st
         if taps or not solve_qp:

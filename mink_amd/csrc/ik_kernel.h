@@ -416,7 +416,13 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // Fused outer loop (mink's callers iterate solve_ik + integrate_inplace, e.g.
     // examples/arm_ur5e_actuators.py:88-97): q stays in LDS between steps.
     const int n_steps = kSteps ? A.n_steps : 1;
-    for (int step = 0; step < n_steps; ++step) {
+    // Threshold-terminated loop (mkh_solve_until): the callers' loop breaks as soon as every end-effector error is
+    // below (pos_threshold, ori_threshold) AFTER the integration (examples/arm_ur5e_actuators.py:88-97,
+    // examples/arm_aloha.py:146-169).  Here the error at the integrated q is the first thing the next step computes
+    // (FK + task lanes), so the test sits there; one extra check-only pass follows the last allowed iteration.
+    const bool until = kSteps && A.pos_threshold >= 0.0;
+    int it_done = 0, conv_flag = 0;
+    for (int step = 0; step < n_steps + (until ? 1 : 0); ++step) {
     int status = 0;
     tci = 1;                                                 // phase stamps 1..7 belong to the current step
 
@@ -636,6 +642,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     MKH_TICK();   // 2: joint axes / dof lanes / com done
     // ------------------------------------------- task lanes: pose, error, jlog
     double mu_lane = 0.0;  // Levenberg–Marquardt term of the task owned by this lane
+    bool conv_lane = true; // this lane's frame task is within the thresholds (rows with a nonzero cost only)
     if (lane < P.n_frame) {
       const FrameTaskDev& ft = P.frame[lane];
       const double* xb = sX + ft.body;
@@ -690,10 +697,19 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         if (MKH_TAP(t_task_e)) MKH_TAP(t_task_e)[(size_t)pb * P.n_rows_tap + ft.row0 + r] = e6[r];
       }
       mu_lane = ft.lm_damping * ss;                          // task.py:131
+      if (kSteps && until) {
+        const double pt = A.pos_threshold, ot = A.ori_threshold;
+        conv_lane = (!(ft.rowmask & 7) || dot(ev, ev) <= pt * pt) && (!(ft.rowmask & 56) || dot(ew, ew) <= ot * ot);
+      }
       if (MKH_TAP(t_frame_pose) && !(kRel && ft.relative)) {
         double* t = MKH_TAP(t_frame_pose) + ((size_t)pb * P.n_frame + lane) * 7;
         t[0] = F.q.w; t[1] = F.q.x; t[2] = F.q.y; t[3] = F.q.z; t[4] = F.p.x; t[5] = F.p.y; t[6] = F.p.z;
       }
+    }
+    if (kSteps && until && step > 0) {
+      it_done = step;
+      if (!__ballot(!conv_lane)) { conv_flag = 1; status_all |= status; break; }   // every frame task achieved
+      if (step == n_steps) { status_all |= status; break; }                        // iteration budget spent
     }
     double mu_total = A.damping + wave_sum(mu_lane);         // solve_ik.py:16 + Σ μ_t
 
@@ -1470,7 +1486,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     }
     if (MKH_TAP(t_qp_iters) && lane == 0) MKH_TAP(t_qp_iters)[pb] = (kRows ? iters : n_piv) | (n_loop << 10) | (n_piv << 20);
     status_all |= status;
-    const bool last = (step + 1 == n_steps) || (status & 14);
+    const bool last = until || (step + 1 == n_steps) || (status & 14);   // (until: v of every step — the loop may end at the next check)
     if (last) {
       if (A.v_out && is_dof) {
         const double bad = __builtin_nan("");
@@ -1507,6 +1523,10 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     }  // step loop
     if (kSteps && A.q_out) {
       for (int i = lane; i < nq; i += 64) A.q_out[(size_t)pb * nq + i] = sq[i];
+    }
+    if (kSteps && until && lane == 0) {
+      if (A.iters_out) A.iters_out[pb] = it_done;
+      if (A.converged_out) A.converged_out[pb] = conv_flag;
     }
     if (A.status_out && lane == 0) A.status_out[pb] = status_all;
   }

@@ -94,6 +94,7 @@ struct MkhProblem {
   // staging buffers for host-pointer calls
   double *s_q = nullptr, *s_ft = nullptr, *s_pt = nullptr, *s_ct = nullptr, *s_v = nullptr;
   int32_t* s_status = nullptr;
+  int32_t* s_iters = nullptr;      // [2][max_batch]: iterations, converged (mkh_solve_until, host-pointer calls)
   size_t s_pt_cap = 0, s_ct_cap = 0;
   double *s_de = nullptr, *s_dJ = nullptr, *s_dG = nullptr, *s_dh = nullptr;   // dense (plugin) rows
 };
@@ -553,7 +554,7 @@ void mkh_problem_destroy(MkhProblem* p) {
   (void)hipSetDevice(p->model->device);
   (void)hipFree(p->d_frame); (void)hipFree(p->d_posture_cost); (void)hipFree(p->d_cfg_lower); (void)hipFree(p->d_cfg_upper);
   (void)hipFree(p->d_vel); (void)hipFree(p->d_pairs); (void)hipFree(p->d_dev); (void)hipFree(p->d_taps); (void)hipFree(p->d_work);
-  (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain);
+  (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain); (void)hipFree(p->s_iters);
   (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh);
   (void)hipFree(p->s_q); (void)hipFree(p->s_ft); (void)hipFree(p->s_pt); (void)hipFree(p->s_ct); (void)hipFree(p->s_v); (void)hipFree(p->s_status);
   delete p;
@@ -597,7 +598,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   if (p->has_relative) need |= F_REL;
   if (p->dev.n_com > 0) need |= F_COM;
   if (p->dev.n_pairs > 0) need |= F_COLL;
-  if (a.n_steps > 1 || a.q_out) need |= F_STEPS;
+  if (a.n_steps > 1 || a.q_out || a.pos_threshold >= 0.0) need |= F_STEPS;
   const bool dense = p->dev.n_dense_rows > 0 || p->dev.n_dense_limit_rows > 0;
   if (dense) need |= 64;                                              // plugin rows: only the all-feature variants have them
   int feat;
@@ -646,7 +647,8 @@ struct TapBuf {
 static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* frame_targets, const double* posture_target,
                    const double* com_target, double dt, double damping, double* v_out, int32_t* status_out,
                    const MkhTaps* taps, int32_t flags, void* hip_stream, int32_t n_steps, double* q_out,
-                   const MkhDenseRows* dense = nullptr) {
+                   const MkhDenseRows* dense = nullptr, double pos_threshold = -1.0, double ori_threshold = -1.0,
+                   int32_t* iters_out = nullptr, int32_t* converged_out = nullptr) {
   if (!p) return fail(MKH_E_INVALID, "null problem");
   if (B < 1) return fail(MKH_E_INVALID, "B must be >= 1");
   const DeviceProblem& P = p->dev;
@@ -674,12 +676,16 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
   bool any_tap = false;
   a.B = B; a.posture_batched = pbat; a.com_batched = cbat; a.do_qp = (v_out != nullptr);
   a.dt = dt; a.damping = damping; a.n_steps = n_steps;
+  a.pos_threshold = pos_threshold; a.ori_threshold = ori_threshold;
+  const bool until = pos_threshold >= 0.0;
+  if (until && P.n_frame < 1) return fail(MKH_E_INVALID, "mkh_solve_until needs at least one frame task to test the thresholds on");
   const size_t nq = P.nq, nv = P.nv;
   const size_t n_pt = (size_t)P.n_posture * nq * (pbat ? B : 1), n_ct = (size_t)P.n_com * 3 * (cbat ? B : 1);
   std::vector<TapBuf> tb;
   if (devp) {
     a.q = q; a.frame_targets = frame_targets; a.posture_target = posture_target; a.com_target = com_target;
     a.v_out = v_out; a.status_out = status_out; a.q_out = q_out;
+    a.iters_out = iters_out; a.converged_out = converged_out;
     if (Kd) { a.dense_e = dense->task_e; a.dense_J = dense->task_J; }
     if (Md) { a.dense_G = dense->limit_G; a.dense_h = dense->limit_h; }
     if (taps) {
@@ -722,6 +728,10 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
   a.v_out = v_out ? p->s_v : nullptr;
   a.status_out = p->s_status;
   a.q_out = q_out ? p->s_q : nullptr;               // in place in the staging buffer
+  if (until) {
+    HIP_OK(ensure(&p->s_iters, mb * 2));
+    a.iters_out = p->s_iters; a.converged_out = p->s_iters + mb;
+  }
   int32_t rc = MKH_OK;
   auto tap = [&](void* host, size_t bytes, bool zero) -> void* {
     if (!host || rc != MKH_OK) return nullptr;
@@ -755,6 +765,10 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
     if (e == hipSuccess && q_out) e = hipMemcpyAsync(q_out, p->s_q, (size_t)B * nq * sizeof(double), hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess && status_out && v_out)
       e = hipMemcpyAsync(status_out, p->s_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && until && iters_out)
+      e = hipMemcpyAsync(iters_out, p->s_iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && until && converged_out)
+      e = hipMemcpyAsync(converged_out, p->s_iters + mb, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
     for (auto& t : tb)
       if (e == hipSuccess) e = hipMemcpyAsync(t.host, t.dev, t.bytes, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -794,6 +808,16 @@ int32_t mkh_solve_steps(MkhProblem* p, int32_t B, const double* q, const double*
   if (!v_out || !q_out) return fail(MKH_E_INVALID, "v_out / q_out is null");
   return run(p, B, q, frame_targets, posture_target, com_target, dt, damping, v_out, status_out, nullptr, flags,
              hip_stream, n_steps, q_out);
+}
+
+int32_t mkh_solve_until(MkhProblem* p, int32_t B, const double* q, const double* frame_targets,
+                        const double* posture_target, const double* com_target, double dt, double damping,
+                        int32_t max_iters, double pos_threshold, double ori_threshold, double* q_out, double* v_out,
+                        int32_t* status_out, int32_t* iters_out, int32_t* converged_out, int32_t flags, void* hip_stream) {
+  if (!v_out || !q_out) return fail(MKH_E_INVALID, "v_out / q_out is null");
+  if (!(pos_threshold >= 0.0) || !(ori_threshold >= 0.0)) return fail(MKH_E_INVALID, "thresholds must be >= 0");
+  return run(p, B, q, frame_targets, posture_target, com_target, dt, damping, v_out, status_out, nullptr, flags,
+             hip_stream, max_iters, q_out, nullptr, pos_threshold, ori_threshold, iters_out, converged_out);
 }
 
 int32_t mkh_integrate(MkhModel* m, int32_t B, const double* q, const double* v, double dt, double* q_out,

@@ -129,6 +129,10 @@ struct SolveArgs {
   // static_rounds = INT32_MAX: no tickets at all (every XCD owns a contiguous eighth of the batch).
   uint32_t* work_counter;
   int32_t static_rounds;
+  // threshold-terminated fused loop (mkh_solve_until): pos_threshold < 0 disables it (fixed n_steps)
+  double pos_threshold, ori_threshold;
+  int32_t* iters_out;              // (B,) solve + integrate iterations performed
+  int32_t* converged_out;          // (B,) 1 when every frame task ended within the thresholds
   // plugin route (variants with every feature): dense task rows and dense limit rows of every instance
   const double* dense_e;           // (B, n_dense_rows)
   const double* dense_J;           // (B, n_dense_rows, nv)

@@ -197,18 +197,28 @@ def solve_ik(configuration: Configuration, tasks: Sequence, dt: float, solver: s
 
 def solve_ik_steps(configuration: Configuration, tasks: Sequence, dt: float, n_steps: int,
                    solver: str = "mi355x", damping: float = 1e-12, safety_break: bool = False,
-                   limits: Optional[Sequence] = None, update: bool = True):
+                   limits: Optional[Sequence] = None, update: bool = True,
+                   pos_threshold: Optional[float] = None, ori_threshold: Optional[float] = None):
     """`n_steps` iterations of  v = solve_ik(...); configuration.integrate_inplace(v, dt)  fused in one
     kernel launch (the loop mink's callers write themselves, e.g. examples/arm_ur5e_actuators.py:88-97).
 
-    Returns (q_final, v_last); with `update` the configuration is advanced in place."""
+    Returns (q_final, v_last); with `update` the configuration is advanced in place.
+
+    With `pos_threshold` / `ori_threshold` the loop is the callers' real one — it breaks, per instance, as soon as
+    every frame task's error is within the thresholds after the integration (arm_ur5e_actuators.py:93-97), `n_steps`
+    is max_iters — and the return value is (q_final, v_last, iters, converged)."""
+    until = None
+    if pos_threshold is not None or ori_threshold is not None:
+        until = (float(pos_threshold if pos_threshold is not None else np.inf),
+                 float(ori_threshold if ori_threshold is not None else np.inf))
     prob, layout = _compile(configuration, tasks, limits, configuration.batch_size, dt)
     if layout["dense"] or layout["dense_limits"]:
         raise exceptions.TaskDefinitionError(
             "solve_ik_steps fuses the outer loop on the device; caller-defined Task / Limit subclasses are evaluated on "
             "the host at every step: call solve_ik + integrate_inplace in a loop instead")
     ft, pt, ct = _gather_targets(configuration, layout)
-    q, v, status = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping, n_steps=int(n_steps))
+    res = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping, n_steps=int(n_steps), until=until)
+    q, v, status = res[:3]
     if (status & nat.ST_OUTSIDE_LIMITS).any():
         # The bit is the OR over the fused steps (the reference loop checks every iteration, solve_ik.py:97): the
         # start configuration first, then — a violation that appeared at step k > 0 — the last one.  An instance
@@ -223,4 +233,7 @@ def solve_ik_steps(configuration: Configuration, tasks: Sequence, dt: float, n_s
                                      f"(first: index {int(bad[0])}, status {int(status[bad[0]])})")
     if update:
         configuration.update(q if configuration.batched else q[0])
+    if until is not None:
+        return (configuration._unbatch(q), configuration._unbatch(v), configuration._unbatch(res[3]),
+                configuration._unbatch(res[4].astype(bool)))
     return configuration._unbatch(q), configuration._unbatch(v)

@@ -56,3 +56,59 @@ def test_api_convergence_in_one_launch():
     assert np.linalg.norm(task.compute_error(cfg)) < 1e-6
     np.testing.assert_allclose(cfg.get_transform_frame_to_world("attachment_site", "site").as_matrix(),
                                target.as_matrix(), atol=1e-6)
+
+
+def test_threshold_terminated_loop_matches_the_callers_loop():
+    """mkh_solve_until = the loop of examples/arm_ur5e_actuators.py:88-97 (solve, integrate, compute_error, break on
+    pos/ori thresholds, max_iters) per instance: final q, last v, iteration count and converged flag against the
+    same loop run on the oracle."""
+    model = workloads.load_robot("ur5e")
+    om = oc.model("ur5e")
+    nm = nat.NativeModel(model)
+    B, max_iters, pos_thr, ori_thr = 48, 20, 1e-4, 1e-4
+    prob, dt, damping = nc.build("ur5e_c2", nm, B)
+    home = model.key_qpos[0]
+    rng = np.random.default_rng(21)
+    q0 = np.tile(home, (B, 1)) + rng.normal(scale=0.05, size=(B, model.nq))
+    # targets at very different distances: some converge in 2-3 iterations, some never within max_iters
+    scale = np.repeat([1e-3, 1e-2, 0.05, 0.3], B // 4)[:, None]
+    q_t = nm.integrate(q0, rng.normal(size=(B, model.nv)) * scale, 1.0)
+    dummy = np.zeros((B, 1, 7)); dummy[:, :, 0] = 1
+    _, _, t = prob.solve(q_t, dummy, home[None, :], None, 1.0, 1.0, taps=["frame_pose"], solve_qp=False)
+    tg = t["frame_pose"]
+    dt = 2e-2                                                   # (a coarser step than the example's 2 ms: more spread in the counts)
+    q, v, st, iters, conv = prob.solve(q0, tg, home[None, :], None, dt, damping, n_steps=max_iters, until=(pos_thr, ori_thr))
+    assert (st & ~1 == 0).all()
+    print("iterations:", np.bincount(iters, minlength=max_iters + 1).tolist(), "converged:", int(conv.sum()), "of", B)
+    assert conv.sum() >= B // 4 and (conv == 0).sum() >= 4 and len(set(iters[conv == 1].tolist())) >= 3
+    for i in range(B):
+        cfg = oik.Configuration(om, q0[i])
+        m, tasks, limits, _, damp_o = oc.ur5e_c2(tg[i], home)
+        done, n = False, 0
+        for n in range(1, max_iters + 1):
+            v_ref = oik.solve_ik(om, cfg, tasks, dt, damp_o, limits)
+            cfg.update(cfg.integrate(v_ref, dt))
+            err = oik.task_error_jacobian(cfg, tasks[0])[0]
+            if np.linalg.norm(err[:3]) <= pos_thr and np.linalg.norm(err[3:]) <= ori_thr:
+                done = True
+                break
+        assert (iters[i], bool(conv[i])) == (n, done), (i, iters[i], conv[i], n, done)
+        np.testing.assert_allclose(q[i], cfg.q, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(v[i], v_ref, rtol=0, atol=1e-7 * max(1.0, np.abs(v_ref).max()))
+    # the public API
+    cfg = mink.Configuration(model, q0)
+    ft = mink.FrameTask("attachment_site", "site", position_cost=1.0, orientation_cost=1.0, lm_damping=1.0)
+    ft.set_target(mink.SE3(tg[:, 0]))
+    post = mink.PostureTask(model, cost=1e-2); post.set_target(home)
+    lims = [mink.ConfigurationLimit(model), mink.VelocityLimit(model, {n: np.pi for n in model.jnt_names})]
+    q2, v2, it2, cv2 = mink.solve_ik_steps(cfg, [ft, post], dt, max_iters, damping=damping, limits=lims,
+                                           pos_threshold=pos_thr, ori_threshold=ori_thr)
+    np.testing.assert_array_equal(it2, iters); np.testing.assert_array_equal(cv2, conv.astype(bool))
+    np.testing.assert_allclose(q2, q, rtol=0, atol=1e-12)
+    # fixed-count calls are untouched by the feature
+    qf, vf, stf = prob.solve(q0, tg, home[None, :], None, dt, damping, n_steps=3)
+    qs = q0.copy()
+    for _ in range(3):
+        vs, _ = prob.solve(qs, tg, home[None, :], None, dt, damping)
+        qs = nm.integrate(qs, vs, dt)
+    np.testing.assert_allclose(qf, qs, rtol=0, atol=1e-10)
