@@ -46,9 +46,9 @@ def sample_q(model: FlatModel, rng: np.random.Generator, n: int, base_q=None) ->
             q[:, a] = rng.uniform(lo + 0.05 * w, hi - 0.05 * w, size=n)
             if model.jnt_limited[j]:
                 limited.append(j)
-    near = np.nonzero(rng.uniform(size=n) < 0.10)[0]
+    near = np.nonzero(rng.uniform(size=n) < 0.10)[0] if limited else []
     for i in near:
-        for j in rng.choice(limited, size=int(rng.integers(1, 4)), replace=False):
+        for j in rng.choice(limited, size=min(len(limited), int(rng.integers(1, 4))), replace=False):
             lo, hi = model.jnt_range[j]
             eps = 1e-3 * (hi - lo) * rng.uniform()
             q[i, int(model.jnt_qposadr[j])] = (lo + eps) if rng.uniform() < 0.5 else (hi - eps)
