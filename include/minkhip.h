@@ -58,6 +58,9 @@ extern "C" {
 #define MKH_FLAG_POSTURE_BATCHED 2  /* posture_target is (B, nq) instead of (nq,)       */
 #define MKH_FLAG_COM_BATCHED 4      /* com_target is (B, 3) instead of (3,)             */
 #define MKH_FLAG_DIRECT_QP 8        /* never use the low-rank start of the QP (parity/diagnostic switch) */
+#define MKH_FLAG_WAVE_KERNEL 16     /* never use the lane-per-problem kernel of small arms (parity/diagnostic switch) */
+#define MKH_FLAG_LANE_KERNEL 32     /* use the lane-per-problem kernel whenever the problem qualifies, whatever the batch
+                                     * size (default: from 8192 instances; parity/diagnostic switch) */
 
 /* frame types (mink/constants.py:3 SUPPORTED_FRAMES) */
 #define MKH_FRAME_BODY 0

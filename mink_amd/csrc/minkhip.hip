@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "ik_kernel.h"
+#include "lane_kernel.h"
 
 using namespace mkh;
 
@@ -54,6 +55,7 @@ struct MkhModel {
   std::vector<int32_t> jnt_type, jnt_qposadr, jnt_dofadr, jnt_bodyid, jnt_limited;
   std::vector<int32_t> dof_bodyid, dof_jntid, dof_parentid, site_bodyid, geom_bodyid, geom_type;
   std::vector<double> body_pos, body_quat, site_pos, site_quat, geom_size, geom_pos, geom_quat, jnt_range;
+  std::vector<double> jnt_pos, jnt_axis, jnt_qpos0;   // (per joint; qpos0 at the joint's first qpos address)
   // device tables
   double* d_body_f = nullptr;
   int32_t* d_body_i = nullptr;
@@ -66,6 +68,7 @@ struct MkhModel {
 
 struct MkhProblem {
   MkhModel* model = nullptr;
+  int device = 0;                  // (copied: the destructor must not depend on the model still being alive)
   DeviceProblem dev{};
   int nt = 8;  // tableau rows per lane (compiled variants: multiples of 8)
   int max_batch = 0;
@@ -80,6 +83,9 @@ struct MkhProblem {
   // the largest squared task cost (conditioning gate, evaluated per call because damping is a call argument)
   int wood_nt = 0, wood_nr = 0, wood_lds_bytes = 0;
   double wood_min_diag = 0.0, wood_max_cost2 = 0.0;
+  // lane-per-problem kernel for small arms (lane_kernel.h): template size (0 = the problem does not qualify)
+  int lane_nv = 0, lane_lds = 0;
+  LaneProblem* d_lane = nullptr;
   char last_kernel[64] = "";
   // device descriptor storage
   FrameTaskDev* d_frame = nullptr;
@@ -105,6 +111,111 @@ struct MkhProblem {
 namespace mkh {
 int launch_variant(int nt, int nr, int feat, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
                    const SolveArgs& a, const TapArgs* taps);
+int launch_lane(int nv_max, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);
+}
+
+// Lane-per-problem descriptor (lane_kernel.h) of a problem that qualifies: nv ≤ 8, hinge / slide joints only,
+// plain FrameTasks (≤ 4) + PostureTasks + box limits.  Returns the template
+// size, 0 when the problem stays on the wavefront kernel.
+static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const DeviceProblem& P,
+                              const std::vector<FrameTaskDev>& ft, const std::vector<double>& pcost,
+                              const std::vector<double>& clo, const std::vector<double>& chi,
+                              const std::vector<double>& vlim, bool has_relative, LaneProblem& L) {
+  const double inf = std::numeric_limits<double>::infinity();
+  if (m->nv > kLaneMaxDofs || m->nq != m->nv) return 0;
+  if (P.n_frame < 1 || P.n_frame > kLaneMaxFrames || has_relative || P.n_com || P.n_pairs || P.n_dense_rows ||
+      P.n_dense_limit_rows)
+    return 0;
+  for (int j = 0; j < m->njnt; ++j)
+    if (m->jnt_type[j] != JNT_HINGE && m->jnt_type[j] != JNT_SLIDE) return 0;
+  memset(&L, 0, sizeof L);
+  L.nq = m->nq; L.nv = m->nv; L.n_frame = P.n_frame; L.n_posture = P.n_posture; L.n_cfg = P.n_cfg; L.n_vel = P.n_vel;
+  // links = the bodies on the chains world → frame bodies, in body-id order (parents first)
+  std::vector<int> need(m->nbody, 0), link_of(m->nbody, -1);
+  for (int t = 0; t < P.n_frame; ++t)
+    for (int b = ft[t].body; b > 0; b = m->body_parentid[b]) need[b] = 1;
+  int nl = 0;
+  std::vector<int> link_of_jnt(m->njnt, -1);
+  // Pose of a jointless body relative to its nearest ancestor that is a link (or the world): folded into the local
+  // transforms of its children and of the frames attached to it, so that it costs neither a link nor LDS.
+  struct Xf { double p[3], q[4]; };
+  auto compose = [](const Xf& a, const double* p, const double* q) {     // a ∘ (p, q)
+    Xf r;
+    const double w = a.q[0], x = a.q[1], y = a.q[2], z = a.q[3];
+    const double tx = 2 * (y * p[2] - z * p[1]), ty = 2 * (z * p[0] - x * p[2]), tz = 2 * (x * p[1] - y * p[0]);
+    r.p[0] = a.p[0] + p[0] + w * tx + (y * tz - z * ty);
+    r.p[1] = a.p[1] + p[1] + w * ty + (z * tx - x * tz);
+    r.p[2] = a.p[2] + p[2] + w * tz + (x * ty - y * tx);
+    r.q[0] = w * q[0] - x * q[1] - y * q[2] - z * q[3];
+    r.q[1] = w * q[1] + x * q[0] + y * q[3] - z * q[2];
+    r.q[2] = w * q[2] - x * q[3] + y * q[0] + z * q[1];
+    r.q[3] = w * q[3] + x * q[2] - y * q[1] + z * q[0];
+    return r;
+  };
+  const Xf ident{{0, 0, 0}, {1, 0, 0, 0}};
+  std::vector<Xf> fold(m->nbody, ident);
+  std::vector<char> folded(m->nbody, 0);
+  folded[0] = 1;                                      // the world: identity, link −1
+  for (int b = 1; b < m->nbody; ++b) {
+    if (!need[b]) continue;
+    const int pb = m->body_parentid[b];
+    const Xf local = folded[pb] ? compose(fold[pb], &m->body_pos[3 * b], &m->body_quat[4 * b])
+                                : compose(ident, &m->body_pos[3 * b], &m->body_quat[4 * b]);
+    if (m->body_jntnum[b] == 0) {                     // jointless: fold
+      fold[b] = local; folded[b] = 1; link_of[b] = link_of[pb];
+      continue;
+    }
+    // A body with k > 1 joints becomes a chain of k links with identity offsets: mj_kinematics applies a body's
+    // joints one after the other in the moving body frame, which is exactly a serial chain of coincident frames.
+    for (int i = 0; i < m->body_jntnum[b]; ++i) {
+      if (nl >= kLaneMaxLinks) return 0;
+      LaneLink& k = L.link[nl];
+      k.parent = i == 0 ? link_of[pb] : nl - 1;
+      k.quat[0] = 1.0;
+      if (i == 0) {
+        for (int c = 0; c < 3; ++c) k.pos[c] = local.p[c];
+        for (int c = 0; c < 4; ++c) k.quat[c] = local.q[c];
+      }
+      const int jj = m->body_jntadr[b] + i;
+      k.jtype = m->jnt_type[jj]; k.dof = m->jnt_dofadr[jj]; k.qpos0 = m->jnt_qpos0[jj];
+      for (int c = 0; c < 3; ++c) { k.axis[c] = m->jnt_axis[3 * jj + c]; k.jpos[c] = m->jnt_pos[3 * jj + c]; }
+      link_of_jnt[jj] = nl;
+      link_of[b] = nl++;
+    }
+  }
+  L.nlink = nl;
+  for (int dd = 0; dd < kLaneMaxDofs; ++dd) { L.dof_link[dd] = -1; L.dof_qadr[dd] = 0; L.range_lo[dd] = -inf; L.range_hi[dd] = inf; }
+  for (int dd = 0; dd < m->nv; ++dd) {
+    const int j = m->dof_jntid[dd];
+    L.dof_link[dd] = link_of_jnt[j];
+    L.dof_qadr[dd] = m->jnt_qposadr[j];
+    if (m->jnt_limited[j]) { L.range_lo[dd] = m->jnt_range[2 * j]; L.range_hi[dd] = m->jnt_range[2 * j + 1]; }
+  }
+  for (int t = 0; t < P.n_frame; ++t) {
+    LaneFrame& f = L.frame[t];
+    f.link = link_of[ft[t].body];
+    f.chain = (uint32_t)ft[t].dof_mask;
+    f.rowmask = ft[t].rowmask;
+    const Xf fl = folded[ft[t].body] ? compose(fold[ft[t].body], ft[t].lpos, ft[t].lquat) : compose(ident, ft[t].lpos, ft[t].lquat);
+    for (int i = 0; i < 3; ++i) f.lpos[i] = fl.p[i];
+    for (int i = 0; i < 4; ++i) f.lquat[i] = fl.q[i];
+    for (int i = 0; i < 6; ++i) f.cost[i] = ft[t].cost[i];
+    f.gain = ft[t].gain; f.lm_damping = ft[t].lm_damping;
+  }
+  for (int t = 0; t < P.n_posture; ++t) {
+    for (int dd = 0; dd < m->nv; ++dd) L.posture_cost[t][dd] = pcost[t * 64 + dd];
+    L.posture_gain[t] = P.posture_gain[t]; L.posture_lm[t] = P.posture_lm[t];
+  }
+  for (int t = 0; t < kMaxBoxTerms; ++t)
+    for (int dd = 0; dd < kLaneMaxDofs; ++dd) { L.cfg_lower[t][dd] = -inf; L.cfg_upper[t][dd] = inf; L.vel_limit[t][dd] = inf; }
+  for (int t = 0; t < P.n_cfg; ++t) {
+    L.cfg_gain[t] = P.cfg_gain[t];
+    for (int dd = 0; dd < m->nv; ++dd) { L.cfg_lower[t][dd] = clo[t * 64 + dd]; L.cfg_upper[t][dd] = chi[t * 64 + dd]; }
+  }
+  for (int t = 0; t < P.n_vel; ++t)
+    for (int dd = 0; dd < m->nv; ++dd) L.vel_limit[t][dd] = vlim[t * 64 + dd];
+  (void)d;
+  return m->nv <= 4 ? 4 : (m->nv <= 6 ? 6 : (m->nv == 7 ? 7 : 8));
 }
 
 // Resident wavefronts per CU of a kernel variant: bounded by LDS (160 KiB/CU) and by the register map the
@@ -166,6 +277,8 @@ int32_t mkh_model_create(const MkhFlatModel* h, int32_t device, MkhModel** out) 
   m->jnt_type = cpi(h->jnt_type, h->njnt); m->jnt_qposadr = cpi(h->jnt_qposadr, h->njnt);
   m->jnt_dofadr = cpi(h->jnt_dofadr, h->njnt); m->jnt_bodyid = cpi(h->jnt_bodyid, h->njnt);
   m->jnt_limited = cpi(h->jnt_limited, h->njnt); m->jnt_range = cpd(h->jnt_range, h->njnt * 2);
+  m->jnt_pos = cpd(h->jnt_pos, h->njnt * 3); m->jnt_axis = cpd(h->jnt_axis, h->njnt * 3);
+  for (int j = 0; j < h->njnt; ++j) m->jnt_qpos0.push_back(h->qpos0[h->jnt_qposadr[j]]);
   m->dof_bodyid = cpi(h->dof_bodyid, h->nv); m->dof_jntid = cpi(h->dof_jntid, h->nv);
   m->dof_parentid = cpi(h->dof_parentid, h->nv);
   m->site_bodyid = cpi(h->site_bodyid, h->nsite); m->geom_bodyid = cpi(h->geom_bodyid, h->ngeom);
@@ -307,6 +420,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   const double inf = std::numeric_limits<double>::infinity();
   MkhProblem* p = new MkhProblem();
   p->model = m;
+  p->device = m->device;
   p->max_batch = max_batch;
   DeviceProblem& P = p->dev;
   fill_base(m, P);
@@ -539,6 +653,16 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       for (const auto& f : ft) for (int k = 0; k < 6; ++k) p->wood_max_cost2 = fmax(p->wood_max_cost2, f.cost[k] * f.cost[k]);
     }
   }
+  {
+    LaneProblem lp;
+    p->lane_nv = build_lane_problem(m, d, P, ft, pcost, clo, chi, vlim, p->has_relative, lp);
+    if (p->lane_nv) {
+      p->lane_lds = lane_lds_bytes(lp.nlink);
+      if (hipMalloc((void**)&p->d_lane, sizeof(LaneProblem)) != hipSuccess ||
+          hipMemcpy(p->d_lane, &lp, sizeof(LaneProblem), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(MKH_E_HIP, "lane descriptor upload failed"));
+    }
+  }
   if (hipMalloc((void**)&p->d_dev, sizeof(DeviceProblem)) != hipSuccess ||
       hipMemcpy(p->d_dev, &p->dev, sizeof(DeviceProblem), hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc((void**)&p->d_taps, sizeof(TapArgs)) != hipSuccess ||
@@ -551,9 +675,10 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
 
 void mkh_problem_destroy(MkhProblem* p) {
   if (!p) return;
-  (void)hipSetDevice(p->model->device);
+  (void)hipSetDevice(p->device);
   (void)hipFree(p->d_frame); (void)hipFree(p->d_posture_cost); (void)hipFree(p->d_cfg_lower); (void)hipFree(p->d_cfg_upper);
   (void)hipFree(p->d_vel); (void)hipFree(p->d_pairs); (void)hipFree(p->d_dev); (void)hipFree(p->d_taps); (void)hipFree(p->d_work);
+  (void)hipFree(p->d_lane);
   (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain); (void)hipFree(p->s_iters);
   (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh);
   (void)hipFree(p->s_q); (void)hipFree(p->s_ft); (void)hipFree(p->s_pt); (void)hipFree(p->s_ct); (void)hipFree(p->s_v); (void)hipFree(p->s_status);
@@ -586,11 +711,29 @@ int32_t mkh_problem_launch_info(const MkhProblem* p, int32_t B, int32_t* grid, i
 }
 
 static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hipStream_t stream, int32_t flags) {
+  (void)hipGetLastError();          // a stale error of an unrelated earlier runtime call must not be blamed on this launch
   const TapArgs* dtaps = nullptr;
   if (taps) {
     HIP_OK(hipMemcpyAsync(p->d_taps, taps, sizeof(TapArgs), hipMemcpyHostToDevice, stream));
     HIP_OK(hipStreamSynchronize(stream));   // taps are a debug path: keep the host struct's lifetime simple
     dtaps = p->d_taps;
+  }
+  // Small arms (nv ≤ 8, box limits): one LANE per problem instead of one wavefront (lane_kernel.h) — 64 problems per
+  // wavefront with every lane busy.  Plain solves only (no taps / fused steps); MKH_FLAG_WAVE_KERNEL forces the
+  // wavefront kernel, MKH_FLAG_LANE_KERNEL this one (parity switches).  Default: by batch size.  A lane runs the whole
+  // problem as one dependent instruction stream (≈48 µs for a UR5e problem, whatever the batch), the wavefront kernel
+  // takes ≈38 µs for the 4 096 problems that fit the chip at once and ≈9 µs more per further 1 024: measured on
+  // MI355X the curves cross between 4 096 and 8 192 problems (UR5e config 2: 90 vs 73 M solves/s at 4 096,
+  // 152 vs 744 M/s at 65 536, 0.15 vs 2.65 G/s at 1 048 576).
+  if (p->lane_nv && !taps && a.do_qp && a.n_steps == 1 && !a.q_out && a.pos_threshold < 0.0 &&
+      !(flags & MKH_FLAG_WAVE_KERNEL) && (a.B >= 8192 || (flags & MKH_FLAG_LANE_KERNEL))) {
+    const int grid = (a.B + kWave - 1) / kWave;
+    p->last_grid = grid; p->last_lds = p->lane_lds; p->last_nt = p->lane_nv;
+    snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_lane_kernel_%d", p->lane_nv);
+    if (mkh::launch_lane(p->lane_nv, grid, p->lane_lds, stream, p->d_lane, a) != 0)
+      return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
+    HIP_OK(hipGetLastError());
+    return MKH_OK;
   }
   // lean production variant unless the call needs a feature it leaves out
   int need = 0;

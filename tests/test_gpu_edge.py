@@ -27,8 +27,14 @@ def test_ragged_batch_sizes(B):
                              posture_tasks=[{"cost": 1e-2}], max_batch=B)
     rng = np.random.default_rng(B)
     q, tg = workloads.make_batch(m, nm, prob, rng, B, base_q=home)
-    v, st = prob.solve(q, tg, home[None, :], None, 2e-3, 1e-3)
+    # (the wavefront kernel: from 8192 instances the default dispatch for this arm is the lane-per-problem kernel,
+    # whose own equivariance test is tests/test_gpu_lane_kernel.py)
+    v, st = prob.solve(q, tg, home[None, :], None, 2e-3, 1e-3, wave_kernel=True)
     assert (st == 0).all()
+    if B >= 8192:
+        vl, stl = prob.solve(q, tg, home[None, :], None, 2e-3, 1e-3)
+        assert prob.last_kernel().startswith("ik_lane_kernel") and (stl == 0).all()
+        np.testing.assert_allclose(vl, v, rtol=0, atol=1e-9 * max(1.0, np.abs(v).max()))
     one = nat.NativeProblem(nm, frame_tasks=[{"frame_type": "site", "frame_id": 0, "cost": [1.0] * 6, "lm_damping": 1.0}],
                             posture_tasks=[{"cost": 1e-2}], max_batch=1)
     for i in {0, B // 2, B - 1}:
@@ -37,8 +43,8 @@ def test_ragged_batch_sizes(B):
     if B > 2:
         # every row: the same batch cut at an odd place (different grid / XCD slices) gives bitwise the same rows
         h = B // 3 + 1
-        va, _ = prob.solve(q[:h], tg[:h], home[None, :], None, 2e-3, 1e-3)
-        vb, _ = prob.solve(q[h:], tg[h:], home[None, :], None, 2e-3, 1e-3)
+        va, _ = prob.solve(q[:h], tg[:h], home[None, :], None, 2e-3, 1e-3, wave_kernel=True)
+        vb, _ = prob.solve(q[h:], tg[h:], home[None, :], None, 2e-3, 1e-3, wave_kernel=True)
         np.testing.assert_array_equal(np.concatenate([va, vb]), v)
 
 
