@@ -100,8 +100,9 @@ def measured_valu_issue(config: str, B: int, waves_per_simd: int):
     js, src = _newest_pmc(config, B)
     try:
         k = js["ik_solve_kernel"]
-        act = k["SQ_ACTIVE_INST_VALU"]["per_dispatch"][1:]
-        cyc = k["SQ_WAVE_CYCLES"]["per_dispatch"][1:]
+        skip = 0 if "solve_kernel" in js else 1          # (round-1 summaries list the FK-only setup launch first)
+        act = k["SQ_ACTIVE_INST_VALU"]["per_dispatch"][skip:]
+        cyc = k["SQ_WAVE_CYCLES"]["per_dispatch"][skip:]
         per_wave = sum(act) / sum(cyc)
         return {"valu_active_share_of_wave_cycles": per_wave, "waves_per_simd": waves_per_simd,
                 "simd_issue_slots_used": waves_per_simd * per_wave, "source": src}
@@ -344,8 +345,8 @@ def main():
         kernel = prob.last_kernel()
         nt = info["tableau_rows"]
         waves_per_simd = 4 if nt <= 8 else (3 if nt <= 24 else 2)
-        if kernel.endswith("_w3") or "_w3_" in kernel:
-            waves_per_simd = 3
+        if kernel.startswith("ik_lane_kernel"):
+            waves_per_simd = 2                            # lane_kernel.h: amdgpu_waves_per_eu(2, 2)
         traffic = measured_traffic(args.config, B)
         valu = measured_valu_issue(args.config, B, waves_per_simd)
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -339,6 +339,10 @@ __device__ __forceinline__ Contact to_world(Contact k, const M3& R, V3 o) {
 // dist / fromto for one geom pair in the CALLER's order (g1 -> g2).
 // type/size/pose are those of g1 and g2 as given; returns false when the pair type
 // is not one of the analytic routines above.
+// SIMPLE: only planes, spheres and capsules can occur (checked on the host for the whole pair list) — the box and
+// cylinder routines are not even compiled in: the capsule-only Shadow-hand variant needs a fraction of the registers
+// (62 spilled VGPRs → 0) and a seventh of the instructions of the general collision phase.
+template <bool SIMPLE = false>
 __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t2, V3 s2, V3 p2, Q4 q2,
                                               double distmax, double& dist, V3& from, V3& to) {
   const bool flip = t1 > t2;
@@ -362,6 +366,9 @@ __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t
   } else if (t1 == GEOM_PLANE && t2 == GEOM_CAPSULE) {
     c = better(plane_sphere(p1, z1, p2 + s2.y * z2, s2.x, distmax),
                plane_sphere(p1, z1, p2 - s2.y * z2, s2.x, distmax));
+  } else if (SIMPLE) {
+    dist = distmax; from = {0, 0, 0}; to = {0, 0, 0};
+    return false;
   } else if (t1 == GEOM_PLANE && t2 == GEOM_BOX) {
     c = plane_box(p1, z1, p2, R2, s2, distmax);
   } else if (t1 == GEOM_PLANE && t2 == GEOM_CYLINDER) {

@@ -267,7 +267,7 @@ constexpr bool kTapIsProf_t_xpos = false, kTapIsProf_t_xquat = false, kTapIsProf
                kTapIsProf_t_H = false, kTapIsProf_t_c = false, kTapIsProf_t_box_lo = false, kTapIsProf_t_box_hi = false,
                kTapIsProf_t_coll_G = false, kTapIsProf_t_coll_h = false, kTapIsProf_t_qp_iters = true,
                kTapIsProf_t_cycles = true;
-enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL = 31, F_WOOD = 32 };
+enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL = 31, F_WOOD = 32, F_SIMPLE_COLL = 64 };
 
 // P lives in device memory (not in the kernarg segment): hipcc materialises every by-value kernel
 // argument field in SGPRs at kernel entry and keeps it there, which starved the QP loop of SGPRs
@@ -303,6 +303,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   // plugin route (caller-defined Task / Limit subclasses as dense rows): only in the variants that carry every
   // feature (FEAT 30 / 31) — it is the general path, not a tuned one
   constexpr bool kDense = (FEAT & (F_ALL & ~F_TAPS)) == (F_ALL & ~F_TAPS) && !kWood;
+  constexpr bool kSimpleColl = (FEAT & F_SIMPLE_COLL) != 0;     // every collision pair is plane / sphere / capsule
 #ifdef MKH_NR
   constexpr int NR = MKH_NR;                 // dof rows of the tableau (low-rank start: NR ≥ nv, NT ≥ nv + n_μ)
 #else
@@ -1061,25 +1062,6 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     if (MKH_TAP(t_c) && is_dof) MKH_TAP(t_c)[(size_t)pb * nv + lane] = c_lane;
     MKH_MARK("jcols_s_done");
     MKH_TICK();   // 4: posture + task Jacobian columns done
-    // ------------------------------------------------------------ box limits
-    // lo ≤ Δq ≤ hi from ConfigurationLimit rows (configuration_limit.py:94-124) and
-    // VelocityLimit rows (velocity_limit.py:96-101); never materialise the dense G.
-    double lo = -kInf, hi = kInf;
-    if (is_dof) {
-      const double q_dof = q_dof_stash;
-      for (int t = 0; t < P.n_cfg; ++t) {
-        const double lw = P.cfg_lower[t * 64 + lane], up = P.cfg_upper[t * 64 + lane];
-        if (up < kInf) hi = fmin(hi, P.cfg_gain[t] * (up - q_dof));
-        if (lw > -kInf) lo = fmax(lo, -(P.cfg_gain[t] * (q_dof - lw)));
-      }
-      for (int t = 0; t < P.n_vel; ++t) {
-        const double vm = P.vel_limit[t * 64 + lane];
-        if (vm < kInf) { hi = fmin(hi, A.dt * vm); lo = fmax(lo, -(A.dt * vm)); }
-      }
-      if (MKH_TAP(t_box_lo)) MKH_TAP(t_box_lo)[(size_t)pb * nv + lane] = lo;
-      if (MKH_TAP(t_box_hi)) MKH_TAP(t_box_hi)[(size_t)pb * nv + lane] = hi;
-    }
-
     // ------------------------------------------- collision half-space rows
     int nrows = 0;
     if (kColl && P.n_pairs > 0) {
@@ -1099,7 +1081,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           Q4 gq1 = qmul(bq1, Q4{cp.lquat1[0], cp.lquat1[1], cp.lquat1[2], cp.lquat1[3]});
           Q4 gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
           double dist;
-          geom_distance(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
+          geom_distance<kSimpleColl>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
                         V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to);
           active = dist != cp.ddetect;                         // Contact.inactive (:52-56)
           if (active) {
@@ -1170,6 +1152,26 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         if (lane < AS) sA[s * AS + lane] = is_dof ? dG[(size_t)r * nv + lane] : 0.0;
       }
     }
+    // ------------------------------------------------------------ box limits
+    // (after the collision rows: lo / hi are not live while the distance routines run)
+    // lo ≤ Δq ≤ hi from ConfigurationLimit rows (configuration_limit.py:94-124) and
+    // VelocityLimit rows (velocity_limit.py:96-101); never materialise the dense G.
+    double lo = -kInf, hi = kInf;
+    if (is_dof) {
+      const double q_dof = q_dof_stash;
+      for (int t = 0; t < P.n_cfg; ++t) {
+        const double lw = P.cfg_lower[t * 64 + lane], up = P.cfg_upper[t * 64 + lane];
+        if (up < kInf) hi = fmin(hi, P.cfg_gain[t] * (up - q_dof));
+        if (lw > -kInf) lo = fmax(lo, -(P.cfg_gain[t] * (q_dof - lw)));
+      }
+      for (int t = 0; t < P.n_vel; ++t) {
+        const double vm = P.vel_limit[t * 64 + lane];
+        if (vm < kInf) { hi = fmin(hi, A.dt * vm); lo = fmax(lo, -(A.dt * vm)); }
+      }
+      if (MKH_TAP(t_box_lo)) MKH_TAP(t_box_lo)[(size_t)pb * nv + lane] = lo;
+      if (MKH_TAP(t_box_hi)) MKH_TAP(t_box_hi)[(size_t)pb * nv + lane] = hi;
+    }
+
     wave_sync();
 
     MKH_MARK("limits_done");

@@ -78,6 +78,7 @@ struct MkhProblem {
   // budget: they never use the high-occupancy register maps of NT ≤ 24 (ik_kernel.h MKH_WAVES)
   int nt_full = 8, lds_bytes_full = 0;
   bool has_relative = false;
+  bool simple_pairs = false;       // every collision pair is plane / sphere / capsule (F_SIMPLE_COLL variants)
   // low-rank ("Woodbury") start of the QP (ik_kernel.h F_WOOD): compiled (NT, NR) pair or 0 when the
   // problem does not qualify; lower bound of the diagonal part of H without the damping argument, and
   // the largest squared task cost (conditioning gate, evaluated per call because damping is a call argument)
@@ -567,6 +568,10 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     }
   }
   P.n_pairs = (int)pairs.size();
+  p->simple_pairs = !pairs.empty();
+  for (const auto& cp : pairs)
+    for (int ty : {cp.type1, cp.type2})
+      if (ty != GEOM_PLANE && ty != GEOM_SPHERE && ty != GEOM_CAPSULE) p->simple_pairs = false;
   {
     const int want = P.n_pairs + P.n_dense_limit_rows;          // half-space rows that can be active at once
     P.max_rows = want < (kWave - m->nv) ? want : (kWave - m->nv);
@@ -747,7 +752,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   int feat;
   if (need == 0) feat = 0;
   else if (need == F_STEPS) feat = F_STEPS;
-  else if (need == F_COLL) feat = F_COLL;
+  else if (need == F_COLL) feat = p->simple_pairs ? (F_COLL | F_SIMPLE_COLL) : F_COLL;
   else if ((need & ~(F_REL | F_COM)) == 0) feat = F_REL | F_COM;      // box limits only: keeps the block-pivoting active set
   else feat = (need & F_TAPS) ? F_ALL : (F_ALL & ~F_TAPS);
   const bool rich = (feat & (F_ALL & ~F_STEPS)) != 0;

@@ -1,7 +1,8 @@
 #!/bin/bash
 # rocprofv3 evidence for profiles/: run on the GPU box through gpurun, e.g.
 #   gpurun --timeout 900 -- 'bash tools/profile.sh r02a g1_c3'        (config defaults to g1_c3)
-#   MKH_PROFILE_LIGHT=1 bash tools/profile.sh r02a ur5e_c2            (kernel trace + HBM counters only)
+#   MKH_PROFILE_BATCH=1048576 bash tools/profile.sh r02b ur5e_c2      (a batch other than the config's own)
+#   MKH_PROFILE_PMC_ONLY=1 bash tools/profile.sh r02a ur5e_c2         (the four counter passes only)
 # then copy gpurun_out/<tag>_* into profiles/.  Kernel trace/stats and each --pmc group are separate
 # passes (counters are never combined with sys/runtime/hip traces).  Every rocprofv3 pass runs under a hard timeout:
 # a profiler that fails to finalise (seen once after a GPU fault report inside the tool) must not eat the GPU budget.
@@ -9,7 +10,7 @@ set -u
 TAG=${1:-rXX}
 CFG=${2:-g1_c3}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-B=$(python -c "import sys; sys.path.insert(0, '$R'); from mink_amd import workloads as w; print(w.BENCH_CONFIGS['$CFG']['batch'])")
+B=${MKH_PROFILE_BATCH:-$(python -c "import sys; sys.path.insert(0, '$R'); from mink_amd import workloads as w; print(w.BENCH_CONFIGS['$CFG']['batch'])")}
 NAME=${CFG}_b${B}
 O=$R/gpurun_out/prof_${TAG}_$CFG
 mkdir -p "$O"
@@ -17,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 
 if [ -z "${MKH_PROFILE_PMC_ONLY:-}" ]; then
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o k -- \
-  python "$R/bench.py" --config $CFG --steps 20 --warmup 3 --no-cpu-baseline > "$O/bench_under_trace.json" 2> "$O/trace.log"
+  python "$R/bench.py" --config $CFG --batch $B --steps 20 --warmup 3 --no-cpu-baseline > "$O/bench_under_trace.json" 2> "$O/trace.log"
 python "$R/tools/rocprof_summary.py" stats "$R/gpurun_out/${TAG}_${NAME}_kernel_stats.csv" "$O/trace" > /dev/null
 fi
 
@@ -29,12 +30,12 @@ DIRS=()
 for grp in "${PMC_GROUPS[@]}"; do
   i=$((i + 1))
   timeout -s KILL 180 rocprofv3 --pmc $grp --output-format csv -d "$O/pmc$i" -o k -- \
-    python "$R/tools/pmc_workload.py" 4 0 $CFG > "$O/pmc$i.log" 2>&1
+    python "$R/tools/pmc_workload.py" 4 $B $CFG > "$O/pmc$i.log" 2>&1
   DIRS+=("$O/pmc$i")
 done
 python "$R/tools/rocprof_summary.py" pmc "$R/gpurun_out/${TAG}_${NAME}_pmc.json" "${DIRS[@]}"
 if [ -z "${MKH_PROFILE_PMC_ONLY:-}" ]; then
-python "$R/bench.py" --config $CFG --steps 20 --warmup 3 > "$R/gpurun_out/${TAG}_${CFG}_bench.json" 2> "$O/bench.err"
-cat "$R/gpurun_out/${TAG}_${CFG}_bench.json"
+python "$R/bench.py" --config $CFG --batch $B --steps 20 --warmup 3 > "$R/gpurun_out/${TAG}_${NAME}_bench.json" 2> "$O/bench.err"
+cat "$R/gpurun_out/${TAG}_${NAME}_bench.json"
 head -5 "$R/gpurun_out/${TAG}_${NAME}_kernel_stats.csv"
 fi

@@ -35,13 +35,21 @@ def read_counters(d):
 
 
 def pmc(out_path, dirs):
-    ik, copy, resources = defaultdict(list), defaultdict(list), {}
+    """The timed solves are the dispatches of the IK kernel that was launched most often in a pass; the one or two
+    launches of a tap variant before them (FK-only target generation, CoM targets: workloads.bench_batch) are listed
+    under "setup_dispatches" and do not enter any per-launch figure."""
+    ik, setup, copy, resources = defaultdict(list), defaultdict(list), defaultdict(list), {}
+    solve_kernel = None
     for d in dirs:
         counters, res = read_counters(d)
+        iks = {k: cs for k, cs in counters.items() if "ik_solve_kernel" in k or "ik_lane_kernel" in k}
+        if iks:
+            main = max(iks, key=lambda k: max(len(per) for per in iks[k].values()))
+            solve_kernel = main
         for k, cs in counters.items():
-            if k.startswith("ik_solve_kernel") or "ik_solve_kernel" in k:
-                tgt = ik
+            if k in iks:
                 resources[k] = res[k]
+                tgt = ik if k == main else setup
             elif "copy" in k.lower() or "elementwise" in k.lower():
                 tgt = copy
             else:
@@ -53,7 +61,9 @@ def pmc(out_path, dirs):
                     tgt[c] = [max(vals + tgt.get(c, []))]
                 else:
                     tgt[c] = tgt.get(c, []) + vals
-    summary = {"ik_solve_kernel": {c: {"per_dispatch": v} for c, v in sorted(ik.items())},
+    summary = {"solve_kernel": solve_kernel,
+               "ik_solve_kernel": {c: {"per_dispatch": v} for c, v in sorted(ik.items())},
+               "setup_dispatches": {c: {"per_dispatch": v} for c, v in sorted(setup.items())},
                "calibration_copy_512MiB": {c: v[0] for c, v in sorted(copy.items())},
                "kernel_resources": resources}
     # HBM bytes per IK launch.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB; the calibration
@@ -62,8 +72,7 @@ def pmc(out_path, dirs):
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if c in ik and c in copy and copy[c][0] > 0:
             cal = COPY_BYTES / (copy[c][0] * 1024.0)
-            solves = ik[c][1:] if len(ik[c]) > 1 else ik[c]      # dispatch 0 = FK-only target launch
-            raw = sum(solves) / len(solves) * 1024.0
+            raw = sum(ik[c]) / len(ik[c]) * 1024.0
             hbm[c] = {"raw_bytes_per_launch": raw, "calibration_factor": cal, "bytes_per_launch": raw * cal}
     if len(hbm) == 2:
         hbm["traffic_bytes_per_launch"] = hbm["FETCH_SIZE"]["bytes_per_launch"] + hbm["WRITE_SIZE"]["bytes_per_launch"]
