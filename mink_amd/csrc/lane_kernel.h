@@ -60,8 +60,13 @@ struct LaneProblem {
 // Jacobian column needs them: ~40 flops instead of 6 more doubles of LDS per link and lane, i.e. residency)
 __host__ __device__ inline int lane_lds_bytes(int nlink) { return nlink * 7 * kWave * (int)sizeof(double); }
 
-template <int NV>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void ik_lane_kernel(const LaneProblem* __restrict__ Pg, const SolveArgs A) {
+// LOOP: the fused caller loop (mkh_solve_steps / mkh_solve_until, ik_kernel.h "Fused outer loop"): every lane iterates
+// (solve, q ← q + Δq) on its own problem — hinge / slide joints only, so the integration is an addition — until its
+// frame tasks are within the thresholds (until) or the iteration budget is spent; lanes that are finished idle through
+// the remaining iterations of their wavefront (masked commits).  A separate instantiation: the single-solve kernel
+// keeps its register budget.
+template <int NV, bool LOOP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LOOP ? 1 : 2, 2))) void ik_lane_kernel(const LaneProblem* __restrict__ Pg, const SolveArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const LaneProblem& P = *Pg;
   const int lane = (int)threadIdx.x;
@@ -71,12 +76,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const int nv = P.nv, nq = P.nq, nlink = P.nlink;
   const double kInf = __builtin_huge_val();
   double* const sX = smem + lane;                     // sX[(l·7 + c)·64]
-  int status = 0;
+  int status_all = 0;
 
   // ------------------------------------------------------------------ q
   double q[NV];
 #pragma unroll
   for (int d = 0; d < NV; ++d) q[d] = d < nv ? A.q[(size_t)pb * nq + P.dof_qadr[d]] : 0.0;
+  const bool until = LOOP && A.pos_threshold >= 0.0;
+  const int n_steps = LOOP ? A.n_steps : 1;
+  bool fin = false;                                  // this lane's loop is over (converged / failed / budget spent)
+  int it_done = 0, conv_flag = 0;
+  double vlast[NV];
+#pragma unroll
+  for (int d = 0; d < NV; ++d) vlast[d] = 0.0;
+  double x[NV];
+  int status = 0;
+  for (int step = 0; step < n_steps + (until ? 1 : 0); ++step) {
+  if (LOOP && !__ballot(!fin)) break;
+  status = 0;
+  bool conv_now = true;                              // every frame task within the thresholds at the current q
   // Configuration.check_limits (mink/configuration.py:77-110), tol = 1e-6
 #pragma unroll
   for (int d = 0; d < NV; ++d)
@@ -152,6 +170,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       ss += we[r] * we[r];
     }
     mu_total += ft.lm_damping * ss;
+    if (LOOP && until) {
+      const double pt = A.pos_threshold, ot = A.ori_threshold;
+      conv_now = conv_now && (!(ft.rowmask & 7) || dot(ev, ev) <= pt * pt) && (!(ft.rowmask & 56) || dot(ew, ew) <= ot * ot);
+    }
     // Weighted task Jacobian column of a dof with world motion axis (lin, ang) at the frame:
     //   ᴮJ = [Rfᵀ·lin; Rfᵀ·ang]  (configuration.py:148-153),  J = −jlog·ᴮJ,  jlog = [[J, −J·Q·J],[0, J]]
     //   ⇒ rows 0-2 = A1·lin + A2·ang,  rows 3-5 = A1·ang   with  A1 = −J·Rfᵀ,  A2 = J·Q·J·Rfᵀ
@@ -274,8 +296,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
   }
 
+  if (LOOP && until && step > 0 && !fin) {
+    it_done = step;
+    if (conv_now) { conv_flag = 1; fin = true; status_all |= status; }        // the callers' break (after the integration)
+    else if (step == n_steps) { fin = true; status_all |= status; }           // budget spent: this pass only tested
+  }
+
   // ------------------------------------------------------------------- QP
-  double x[NV];
   int st[NV];                                        // 0 free, 1 at lower, 2 at upper
 #pragma unroll
   for (int d = 0; d < NV; ++d) { x[d] = 0.0; st[d] = 0; }
@@ -368,14 +395,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
   }
   if (!done) status |= 8;
+  if (!LOOP) { status_all = status; break; }
+  if (!fin) {                                        // commit this iteration
+    status_all |= status;
+    if (status & 14) {
+      fin = true;                                    // an instance stops at the first step whose QP fails
+    } else {
+#pragma unroll
+      for (int d = 0; d < NV; ++d) {
+        vlast[d] = x[d] / A.dt;
+        q[d] += x[d];                                // mj_integratePos for hinge / slide joints (configuration.py:228-236)
+      }
+      if (!until) { it_done = step + 1; fin = step + 1 == n_steps; }
+    }
+  }
+  }  // step loop
 
   // ------------------------------------------------------------------ out
   if (live) {
     const double bad = __builtin_nan("");
 #pragma unroll
-    for (int d = 0; d < NV; ++d)
-      if (d < nv) A.v_out[(size_t)pb * nv + d] = (status & 14) ? bad : x[d] / A.dt;   // v = Δq / dt (solve_ik.py:104)
-    if (A.status_out) A.status_out[pb] = status;
+    for (int d = 0; d < NV; ++d) {
+      if (d < nv) {
+        const double vd = LOOP ? vlast[d] : x[d] / A.dt;                              // v = Δq / dt (solve_ik.py:104)
+        A.v_out[(size_t)pb * nv + d] = (status_all & 14) ? bad : vd;
+        if (LOOP && A.q_out) A.q_out[(size_t)pb * nq + P.dof_qadr[d]] = q[d];
+      }
+    }
+    if (A.status_out) A.status_out[pb] = status_all;
+    if (LOOP && until) {
+      if (A.iters_out) A.iters_out[pb] = it_done;
+      if (A.converged_out) A.converged_out[pb] = conv_flag;
+    }
   }
 }
 

@@ -5,13 +5,19 @@
 
 namespace mkh {
 
-int launch_lane(int nv_max, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a) {
+int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a) {
+#define MKH_LANE_CASE(N)                                                                                          \
+  case N:                                                                                                         \
+    if (loop) hipLaunchKernelGGL((ik_lane_kernel<N, true>), dim3(grid), dim3(kWave), lds_bytes, stream, P, a);    \
+    else hipLaunchKernelGGL((ik_lane_kernel<N, false>), dim3(grid), dim3(kWave), lds_bytes, stream, P, a);        \
+    return 0;
   switch (nv_max) {
-    case 4: hipLaunchKernelGGL(ik_lane_kernel<4>, dim3(grid), dim3(kWave), lds_bytes, stream, P, a); return 0;
-    case 6: hipLaunchKernelGGL(ik_lane_kernel<6>, dim3(grid), dim3(kWave), lds_bytes, stream, P, a); return 0;
-    case 7: hipLaunchKernelGGL(ik_lane_kernel<7>, dim3(grid), dim3(kWave), lds_bytes, stream, P, a); return 0;
-    case 8: hipLaunchKernelGGL(ik_lane_kernel<8>, dim3(grid), dim3(kWave), lds_bytes, stream, P, a); return 0;
+    MKH_LANE_CASE(4)
+    MKH_LANE_CASE(6)
+    MKH_LANE_CASE(7)
+    MKH_LANE_CASE(8)
   }
+#undef MKH_LANE_CASE
   return -1;
 }
 

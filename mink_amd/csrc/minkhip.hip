@@ -112,7 +112,7 @@ struct MkhProblem {
 namespace mkh {
 int launch_variant(int nt, int nr, int feat, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
                    const SolveArgs& a, const TapArgs* taps);
-int launch_lane(int nv_max, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);
+int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);
 }
 
 // Lane-per-problem descriptor (lane_kernel.h) of a problem that qualifies: nv ≤ 8, hinge / slide joints only,
@@ -730,12 +730,13 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   // takes ≈38 µs for the 4 096 problems that fit the chip at once and ≈9 µs more per further 1 024: measured on
   // MI355X the curves cross between 4 096 and 8 192 problems (UR5e config 2: 90 vs 73 M solves/s at 4 096,
   // 152 vs 744 M/s at 65 536, 0.15 vs 2.65 G/s at 1 048 576).
-  if (p->lane_nv && !taps && a.do_qp && a.n_steps == 1 && !a.q_out && a.pos_threshold < 0.0 &&
-      !(flags & MKH_FLAG_WAVE_KERNEL) && (a.B >= 8192 || (flags & MKH_FLAG_LANE_KERNEL))) {
+  if (p->lane_nv && !taps && a.do_qp && !(flags & MKH_FLAG_WAVE_KERNEL) &&
+      (a.B >= 8192 || (flags & MKH_FLAG_LANE_KERNEL))) {
+    const bool loop = a.n_steps > 1 || a.q_out || a.pos_threshold >= 0.0;     // fused caller loop (steps / until)
     const int grid = (a.B + kWave - 1) / kWave;
     p->last_grid = grid; p->last_lds = p->lane_lds; p->last_nt = p->lane_nv;
-    snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_lane_kernel_%d", p->lane_nv);
-    if (mkh::launch_lane(p->lane_nv, grid, p->lane_lds, stream, p->d_lane, a) != 0)
+    snprintf(p->last_kernel, sizeof(p->last_kernel), loop ? "ik_lane_kernel_%d_loop" : "ik_lane_kernel_%d", p->lane_nv);
+    if (mkh::launch_lane(p->lane_nv, loop, grid, p->lane_lds, stream, p->d_lane, a) != 0)
       return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
     HIP_OK(hipGetLastError());
     return MKH_OK;

@@ -95,6 +95,13 @@ def test_threshold_terminated_loop_matches_the_callers_loop():
         assert (iters[i], bool(conv[i])) == (n, done), (i, iters[i], conv[i], n, done)
         np.testing.assert_allclose(q[i], cfg.q, rtol=0, atol=1e-10)
         np.testing.assert_allclose(v[i], v_ref, rtol=0, atol=1e-7 * max(1.0, np.abs(v_ref).max()))
+    # the same loop in the lane-per-problem kernel (small arms, large batches): identical iteration counts and flags
+    ql, vl, stl, itl, cvl = prob.solve(q0, tg, home[None, :], None, dt, damping, n_steps=max_iters, until=(pos_thr, ori_thr),
+                                       lane_kernel=True)
+    assert prob.last_kernel() == "ik_lane_kernel_6_loop", prob.last_kernel()
+    np.testing.assert_array_equal(itl, iters); np.testing.assert_array_equal(cvl, conv); np.testing.assert_array_equal(stl, st)
+    np.testing.assert_allclose(ql, q, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(vl, v, rtol=0, atol=1e-7 * max(1.0, np.abs(v).max()))
     # the public API
     cfg = mink.Configuration(model, q0)
     ft = mink.FrameTask("attachment_site", "site", position_cost=1.0, orientation_cost=1.0, lm_damping=1.0)
@@ -112,3 +119,7 @@ def test_threshold_terminated_loop_matches_the_callers_loop():
         vs, _ = prob.solve(qs, tg, home[None, :], None, dt, damping)
         qs = nm.integrate(qs, vs, dt)
     np.testing.assert_allclose(qf, qs, rtol=0, atol=1e-10)
+    qfl, vfl, stfl = prob.solve(q0, tg, home[None, :], None, dt, damping, n_steps=3, lane_kernel=True)
+    assert prob.last_kernel() == "ik_lane_kernel_6_loop"
+    np.testing.assert_allclose(qfl, qs, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(vfl, vs, rtol=0, atol=1e-8 * max(1.0, np.abs(vs).max()))
