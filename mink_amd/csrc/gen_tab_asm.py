@@ -9,15 +9,15 @@ kernel's VGPR total), and the four operations that touch it are emitted here wit
 register numbers:
 
     zero()                    T[i] = 0
-    rank1_prefetch / rank1_body*(lds_addr, g)   T[i] += lds[i]·g   software-pipelined ds_read_b128 + v_fma_f64
-                              (row-range variants; *_pub variants also store the next pivot column's entry)
+    rank1_prefetch / rank1_body*(lds_addr, g)   T[i] += lds[i]·g   four lane-indexed ds_read_b64 + v_fmac_f64_dpp
+                              row_newbcast (row-range variants; *_pub variants also store the next pivot column's entry)
     load_*(lds_addr)          T[i] = lds[i]         whole column / leading rows / residual rows
     get_dyn(k) / set_dyn(k,x) single element, wave-uniform runtime index (VGPR index mode)
     get<I>() / set<I>(x)      single element, compile-time index (tableau build, taps)
 
 Register map for NT rows (wave64; TOP = 256 VGPRs per lane at 2 waves/SIMD, 168 at 3 (NT ≤ 24), 128 at 4 (NT ≤ 8)):
     v[TOP-2·NT, TOP)              tableau column (NT doubles)
-    v[TOP-2·NT-S, TOP-2·NT)       LDS staging for rank1 (S = 32: 8 × 128 bit in flight; S = 24 for NT ≥ 56, 16 for NT ≤ 24)
+    v[TOP-2·NT-8, TOP-2·NT)       the pivot column in four 16-lane "planes" (S = 8 registers, see rank1 below)
     v[0, TOP-2·NT-S)              everything the compiler allocates
 
 The staging range must stay ABOVE the compiler's cap even though half of it is only live inside one asm
@@ -36,12 +36,14 @@ def total_for(nt):
     return 128 if nt <= 8 else (168 if nt <= 24 else 256)
 NRS = (16, 24, 32, 44, 48)   # dof-row counts of the low-rank start (kernel variants MKH_NR)
 def ntmp_for(nt):
-    # staging registers: 8 x b128 in flight, or 6 for the widest tableaus, where the compiler needs the registers
-    # (measured on G1, NT = 62, kernel ms: 4 in flight 1.168, 6 in flight 1.160 — still spill-free —, 8 in flight
-    # 1.167 with 6 spilled VGPRs); 4 for the narrow tableaus that run 3 or 4 waves per SIMD
-    return 24 if nt >= 56 else (16 if nt <= 24 else 32)
+    # Staging registers of the rank-1 update.  Round 1 streamed the pivot column through broadcast ds_read_b128 (two rows
+    # per read, 6-8 reads in flight = 24-32 registers).  A broadcast read returns 1 KiB to the wave whatever its address
+    # pattern, and at the kernel's residency those returns saturate the CU's LDS path (tools/ubench/gen_rank1_mix.py:
+    # 998 ticks per 62-row update against 496 for its FMAs).  Now lane l of every 16-lane row fetches u[16p + l % 16] for
+    # the four "planes" p with ONE lane-indexed ds_read_b64 each (4 x 512 B), and the broadcast happens in the DPP operand
+    # network: v_fmac_f64_dpp T[i], plane[i / 16], g row_newbcast:(i % 16) — 531 ticks in the same benchmark.
+    return 8
 SPLIT_PREFIXES = (16, 24, 32)   # dof-row prefixes of the split rank-1 bodies (phase 0 of the low-rank start)
-NPRE = 4   # loads issued by rank1_prefetch (their 16 registers are off limits to the compiler)
 
 
 def gen(nt: int) -> str:
@@ -62,71 +64,40 @@ def gen(nt: int) -> str:
     out.append("  __device__ static __forceinline__ void zero() {")
     out.append(f'    asm volatile("{body}" ::: {clob_t});')
     out.append("  }")
-    # rank1 = prefetch (first `depth` loads) + body; the split lets the caller put the reciprocal /
-    # multiplier arithmetic between them so that the LDS latency of the first loads is hidden.
-    nload = nt // 2
-    depth = NTMP // 4
-    def slot_reg(k):
-        # staging slot of load k.  Slots 0..NPRE-1 — the ones rank1_prefetch leaves in flight across
-        # compiler-generated code — sit in the UPPER half of the staging range, which is above the
-        # compiler's cap; the other slots are only live inside one asm statement (declared clobbers).
-        return tmp0 + 4 * ((k % depth + (depth - NPRE)) % depth)
-    def load(k, addr="%0"):
-        r = slot_reg(k)
-        return f"ds_read_b128 v[{r}:{r + 3}], {addr} offset:{16 * k}"
-    def load_at(j, chunk, addr="%0"):
-        # j-th load of a pipelined body (decides the staging slot), reading rows 2·chunk, 2·chunk+1
-        r = slot_reg(j)
-        return f"ds_read_b128 v[{r}:{r + 3}], {addr} offset:{16 * chunk}"
-    def rank1_lines(chunks, pub=False):
-        """Software-pipelined T[i] += lds[i]·g over the given 2-row chunks (in order).  The first NPRE chunks must
-        be 0..NPRE-1: rank1_prefetch has already issued them.
+    # rank1 = prefetch (the four plane loads) + body; the split lets the caller put the reciprocal / multiplier
+    # arithmetic between them so that the LDS latency is hidden.
+    nplanes = (nt + 15) // 16
+    def plane_reg(p):
+        return tmp0 + 2 * p
+    def fmac(i):
+        r = plane_reg(i // 16)
+        return f"v_fmac_f64_dpp {treg(i)}, v[{r}:{r + 1}], %1 row_newbcast:{i % 16} row_mask:0xf bank_mask:0xf"
+    def rank1_lines(rows, pub=False):
+        """T[i] += u[i]·g for the given rows; the planes were requested by rank1_prefetch.
         pub: the statement first stores %3 (this lane's entry of the NEXT pivot column) at LDS address %2 and then
         waits for everything older than that store — LDS operations of a wave complete in order, so lgkmcnt(1)
-        means "the prefetched loads are here" without draining the store (look-ahead publishing, ik_kernel.h)."""
-        assert list(chunks[:NPRE]) == list(range(min(NPRE, len(chunks))))
-        n = len(chunks)
+        means "the plane loads are here" without draining the store (look-ahead publishing, ik_kernel.h).
+        Otherwise lgkmcnt(0): the compiler may have put LDS / scalar-memory instructions of its own between prefetch and
+        body (SMEM returns out of order, so only a full drain is exact); the loads were issued ~100 cycles earlier.
+        s_nop 4: a DPP operand must not be read within 5 wait states of an EXEC write by the code before the statement."""
         head = ["ds_write_b64 %2, %3", "s_waitcnt lgkmcnt(1)"] if pub else ["s_waitcnt lgkmcnt(0)"]
-        lines = head + [load_at(j, chunks[j]) for j in range(min(NPRE, n), min(depth, n))]
-        for j in range(n):
-            issued = min(n, j + depth)
-            if j >= NPRE:
-                lines.append(f"s_waitcnt lgkmcnt({issued - j - 1})")
-            r = slot_reg(j)
-            c = chunks[j]
-            lines.append(f"v_fma_f64 {treg(2 * c)}, v[{r}:{r + 1}], %1, {treg(2 * c)}")
-            lines.append(f"v_fma_f64 {treg(2 * c + 1)}, v[{r + 2}:{r + 3}], %1, {treg(2 * c + 1)}")
-            if j + depth < n:
-                lines.append(load_at(j + depth, chunks[j + depth]))
-        return lines
-    lines = ["s_waitcnt lgkmcnt(0)"] + [load(k) for k in range(min(NPRE, nload))]
+        return head + ["s_nop 4"] + [fmac(i) for i in rows]
+    lines = ["s_waitcnt lgkmcnt(0)"] + [f"ds_read_b64 v[{plane_reg(p)}:{plane_reg(p) + 1}], %0 offset:{128 * p}" for p in range(nplanes)]
     body = "\\n\\t".join(lines)
-    clob_pre = ",".join(f'"v{r}"' for r in range(tmp0 + NTMP - 4 * NPRE, tmp0 + NTMP))
-    out.append("  // issue the first loads of lds[0..kRows) (must be followed by rank1_body with the same address)")
+    clob_pre = ",".join(f'"v{r}"' for r in range(tmp0, tmp0 + 2 * nplanes))
+    out.append("  // request the pivot column lds[0..kRows): lane l gets lds[16·p + l % 16] in plane p (must be followed by a")
+    out.append("  // rank1_body* with the same column)")
     out.append("  __device__ static __forceinline__ void rank1_prefetch(unsigned lds_addr) {")
-    out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_pre}, "memory");')
+    out.append("    const unsigned lane_addr = lds_addr + ((threadIdx.x & 15u) << 3);")
+    out.append(f'    asm volatile("{body}" :: "v"(lane_addr) : {clob_pre}, "memory");')
     out.append("  }")
-    # lgkmcnt(0) first: the compiler may have put LDS / scalar-memory instructions of its own between
-    # prefetch and body (SMEM returns out of order, so only a full drain is exact).  The prefetched
-    # loads were issued ~100 cycles earlier, so this does not stall; from here on only this
-    # statement's own loads are outstanding and the counted waits below are exact.
-    lines = ["s_waitcnt lgkmcnt(0)"] + [load(k) for k in range(min(NPRE, nload), min(depth, nload))]
-    for k in range(nload):
-        issued = min(nload, k + depth)
-        if k >= NPRE:
-            lines.append(f"s_waitcnt lgkmcnt({issued - k - 1})")
-        r = slot_reg(k)
-        lines.append(f"v_fma_f64 {treg(2 * k)}, v[{r}:{r + 1}], %1, {treg(2 * k)}")
-        lines.append(f"v_fma_f64 {treg(2 * k + 1)}, v[{r + 2}:{r + 3}], %1, {treg(2 * k + 1)}")
-        if k + depth < nload:
-            lines.append(load(k + depth))
-    body = "\\n\\t".join(lines)
-    out.append("  // T[i] += lds[i]*g; consumes the loads rank1_prefetch left in flight.")
+    body = "\\n\\t".join(rank1_lines(range(nt)))
+    out.append("  // T[i] += lds[i]*g; consumes the planes rank1_prefetch requested.")
     out.append("  __device__ static __forceinline__ void rank1_body(unsigned lds_addr, double g) {")
     out.append(f'    asm volatile("{body}"')
     out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
     out.append("  }")
-    body_pub = "\\n\\t".join(rank1_lines(list(range(nload)), pub=True))
+    body_pub = "\\n\\t".join(rank1_lines(range(nt), pub=True))
     out.append("  // rank1_body + look-ahead store of the next pivot column's entry")
     out.append("  __device__ static __forceinline__ void rank1_body_pub(unsigned lds_addr, double g, unsigned pub_addr, double pub) {")
     out.append(f'    asm volatile("{body_pub}"')
@@ -168,26 +139,14 @@ def gen(nt: int) -> str:
     out.append("  }")
     # partial-row primitives for the low-rank start (rows [0, NR) = the dof rows)
     for nr in [r for r in NRS if r <= nt]:
-        nl = nr // 2
-        # rank1 over the first nr rows (prefetch is shared: it only issues the first NPRE loads)
-        lines = ["s_waitcnt lgkmcnt(0)"] + [load(k) for k in range(min(NPRE, nl), min(depth, nl))]
-        for k in range(nl):
-            issued = min(nl, k + depth)
-            if k >= NPRE:
-                lines.append(f"s_waitcnt lgkmcnt({issued - k - 1})")
-            r = slot_reg(k)
-            lines.append(f"v_fma_f64 {treg(2 * k)}, v[{r}:{r + 1}], %1, {treg(2 * k)}")
-            lines.append(f"v_fma_f64 {treg(2 * k + 1)}, v[{r + 2}:{r + 3}], %1, {treg(2 * k + 1)}")
-            if k + depth < nl:
-                lines.append(load(k + depth))
-        body = "\\n\\t".join(lines)
+        body = "\\n\\t".join(rank1_lines(range(nr)))
         out.append(f"  // rank1_body restricted to rows [0, {nr})")
         out.append(f"  __device__ static __forceinline__ void rank1_body_{nr}(unsigned lds_addr, double g) {{")
         out.append(f'    asm volatile("{body}"')
         out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
         out.append("  }")
         if nr < nt:
-            body = "\\n\\t".join(rank1_lines(list(range(nl)), pub=True))
+            body = "\\n\\t".join(rank1_lines(range(nr), pub=True))
             out.append(f"  // rank1_body_{nr} + look-ahead store")
             out.append(f"  __device__ static __forceinline__ void rank1_body_{nr}_pub(unsigned lds_addr, double g, unsigned pub_addr, double pub) {{")
             out.append(f'    asm volatile("{body}"')
@@ -199,7 +158,7 @@ def gen(nt: int) -> str:
             for pfx in SPLIT_PREFIXES:
                 if pfx >= nr:
                     continue
-                body = "\\n\\t".join(rank1_lines(list(range(pfx // 2)) + list(range(nr // 2, nt // 2)), pub=True))
+                body = "\\n\\t".join(rank1_lines(list(range(pfx)) + list(range(nr, nt)), pub=True))
                 out.append(f"  // rank1_body restricted to rows [0, {pfx}) and [{nr}, {nt}), + look-ahead store")
                 out.append(f"  __device__ static __forceinline__ void rank1_body_{pfx}_hi_{nr}(unsigned lds_addr, double g, unsigned pub_addr, double pub) {{")
                 out.append(f'    asm volatile("{body}"')

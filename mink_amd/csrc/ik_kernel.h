@@ -291,7 +291,7 @@ enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL =
 #ifndef MKH_KERNEL_NAME   // low-rank variants (MKH_NR defined) are named by their translation unit
 #define MKH_KERNEL_NAME MKH_CAT(ik_solve_kernel_, MKH_NT, MKH_FEAT)
 #endif
-#define MKH_STAGE (MKH_NT >= 56 ? 24 : (MKH_NT <= 24 ? 16 : 32))   // staging VGPRs of the rank-1 update (gen_tab_asm.py ntmp_for)
+#define MKH_STAGE 8   // staging VGPRs of the rank-1 update: four 16-lane planes of the pivot column (gen_tab_asm.py ntmp_for)
 #define MKH_WAVES (MKH_NT <= 8 ? 4 : (MKH_NT <= 24 ? 3 : 2))   // resident waves per SIMD the register map is built for
 #define MKH_TOP (MKH_NT <= 8 ? 128 : (MKH_NT <= 24 ? 168 : 256))  // VGPRs per lane at that occupancy (gen_tab_asm.py total_for)
 static_assert(Tab<MKH_NT>::kCompilerVgprs == MKH_TOP - 2 * MKH_NT - MKH_STAGE, "register map of tab_asm.inc changed");
