@@ -388,9 +388,9 @@ def main():
                                      "frac": valu["simd_issue_slots_used"] if valu else None,
                                      "lds_pipe_busy_share": valu.get("lds_pipe_busy_share") if valu else None,
                                      "source": valu["source"] if valu else None},
-                "note": "not HBM bound by design (one QP per wavefront / lane): the wavefront kernel's rank-1 tableau updates "
-                        "saturate the CU's LDS return path (profiles/r02_ubench_rank1_mix.txt), its other phases and the "
-                        "lane kernel are fp64 VALU issue / latency bound; HBM fraction reported as the contract requires",
+                "note": "not HBM bound by design (one QP per wavefront / lane): fp64 VALU issue + the serial latency of a pivot "
+                        "(round 1's LDS-return-bandwidth bound on the rank-1 updates was removed in round 2, "
+                        "profiles/r02_ubench_rank1_mix.txt); HBM fraction reported as the contract requires",
                 "valu_issue_view": valu}
         if args.config in ALGORITHMIC_FLOP_PER_SOLVE:
             af = ALGORITHMIC_FLOP_PER_SOLVE[args.config]
