@@ -46,12 +46,12 @@ __host__ __device__ inline int j_stride_direct(int nv, int nt) { const int a = a
 
 constexpr int kPivBuf = kWave + 8;   // doubles per pivot broadcast buffer
 struct LdsLayout {
-  int q, X, jnt, tgt, task, J, dof, com, col, A, piv, S, total;  // offsets in doubles
+  int q, X, jnt, tgt, task, J, dof, com, col, A, piv, S, q2, tgt2, total;  // offsets in doubles
 };
 __host__ __device__ inline int lds_even(int x) { return (x + 1) & ~1; }
 __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int njnt, int n_frame,
                                                 int n_posture, int n_com, int max_rows, int j_rows, int j_stride,
-                                                int s_doubles = 0) {
+                                                int s_doubles = 0, bool prefetch = false) {
   LdsLayout L;
   int o = 0;
   L.q = o;    o += lds_even(nq);
@@ -68,6 +68,11 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
   L.A = o;    o += max_rows * a_stride_for(nv);       // half-space rows A[s][0..stride)
   L.piv = o;  o += 2 * kPivBuf;    // two pivot column broadcast buffers (64 entries + 8 scalar slots of the pivot lane): look-ahead publishing
   L.S = o;    o += lds_even(s_doubles);   // low-rank start: columns of −Jh·Jhᵀ + right-hand sides
+  // second buffers of the per-problem inputs: the next problem's q / targets are fetched straight into LDS
+  // (global_load_lds) while the current problem is being solved
+  // (only when the host found that they do not cost a resident wave: DeviceProblem::prefetch)
+  L.q2 = prefetch ? o : L.q;     o += prefetch ? lds_even(nq) : 0;
+  L.tgt2 = prefetch ? o : L.tgt; o += prefetch ? lds_even(n_frame * 7 + n_com * 3) : 0;
   L.total = o;
   return L;
 }
@@ -316,13 +321,15 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   const int nq = P0.nq, nv = P0.nv, nbody = P0.nbody;
   const LdsLayout L = lds_layout(nq, nv, nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows,
                                  kWood ? NT - NR + 1 : 6, kWood ? NR : j_stride_direct(nv, NT),
-                                 (kWood && !wood_s_aliases_dof(nv, P0.n_jrows, NT - NR)) ? P0.n_jrows * (NT - NR + 1) : 0);
-  double* const sq = smem + L.q;
+                                 (kWood && !wood_s_aliases_dof(nv, P0.n_jrows, NT - NR)) ? P0.n_jrows * (NT - NR + 1) : 0,
+                                 P0.prefetch != 0);
+  const bool prefetch = P0.prefetch != 0;
+  double* sq = smem + L.q;            // (sq / sTgt alternate between two buffers, see "load inputs")
   double* const sX = smem + L.X;
   const int XS = lds_even(nbody);                      // component stride of sX (consecutive lanes hit consecutive banks;
                                                        // body-major with stride 8 put 16 lanes on each bank)
   double* const sJnt = smem + L.jnt;
-  double* const sTgt = smem + L.tgt;
+  double* sTgt = smem + L.tgt;
   double* const sTask = smem + L.task;
   double* const sJ = smem + L.J;
   double* const sDof = smem + L.dof;
@@ -373,6 +380,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     return (unsigned)pb < (unsigned)A.B ? pb : -1;
   };
   int pb_next = draw();
+  bool have_inputs = false;                            // the rows of `pb` are already on their way into (sq, sTgt)
   for (;;) {
     if (pb_next < 0) break;
     const int pb = pb_next;
@@ -406,10 +414,30 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     const DeviceProblem& P = *Pq;
     wave_sync();  // previous problem's LDS readers are done
     // ------------------------------------------------------------ load inputs
-    for (int i = lane; i < nq; i += 64) sq[i] = A.q[(size_t)pb * nq + i];
+    // Double-buffered in LDS.  The rows of the NEXT problem (known since the top of the loop) are requested now with
+    // global_load_lds — memory → LDS without passing through registers, so nothing stays live across the QP — into the
+    // buffer this problem does not use; a wave's first problem fetches its own rows the same way.  The ≈3 k cycles of HBM
+    // latency per problem (tools/phase_profile.py) disappear behind the previous problem's work.
     {
+      typedef const __attribute__((address_space(1))) void* gptr_t;
+      typedef __attribute__((address_space(3))) void* lptr_t;
+      const int ndq = 2 * nq, ndt = 2 * P.n_frame * 7;                 // dwords per row
+      auto fetch = [&](int pbn, double* dq, double* dt) {
+        const char* gq = reinterpret_cast<const char*>(A.q + (size_t)pbn * nq);
+        for (int b0 = 0; b0 < ndq; b0 += kWave)
+          if (b0 + lane < ndq)
+            __builtin_amdgcn_global_load_lds((gptr_t)(gq + 4 * (b0 + lane)), (lptr_t)(reinterpret_cast<char*>(dq) + 4 * b0), 4, 0, 0);
+        const char* gt = reinterpret_cast<const char*>(A.frame_targets + (size_t)pbn * (ndt / 2));
+        for (int b0 = 0; b0 < ndt; b0 += kWave)
+          if (b0 + lane < ndt)
+            __builtin_amdgcn_global_load_lds((gptr_t)(gt + 4 * (b0 + lane)), (lptr_t)(reinterpret_cast<char*>(dt) + 4 * b0), 4, 0, 0);
+      };
+      if (!have_inputs) { fetch(pb, sq, sTgt); have_inputs = prefetch; }
+      double* const nq_buf = (sq == smem + L.q) ? smem + L.q2 : smem + L.q;
+      double* const nt_buf = (sTgt == smem + L.tgt) ? smem + L.tgt2 : smem + L.tgt;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this problem's rows are in LDS
+      if (prefetch && pb_next >= 0) fetch(pb_next, nq_buf, nt_buf);
       const int nt = P.n_frame * 7;
-      for (int i = lane; i < nt; i += 64) sTgt[i] = A.frame_targets[(size_t)pb * nt + i];
       const int nc = P.n_com * 3;
       if (lane < nc) sTgt[nt + lane] = A.com_target[(A.com_batched ? (size_t)pb * nc : 0) + lane];
     }
@@ -432,8 +460,10 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // (mj_kinematics).
     V3 xp{0, 0, 0};
     Q4 xq{1, 0, 0, 0};
-    int b_jadr = 0, b_jnum = 0;
+    int b_jadr = 0, b_jnum = 0, anc_lo = 0, anc_hi = 0;
     if (is_body) {
+      anc_lo = P.body_i[BI_ANCPACK0 * 64 + ol];
+      anc_hi = P.body_i[BI_ANCPACK1 * 64 + ol];
       const double* bf = P.body_f + ol;
       xp = {bf[(BF_POS + 0) * 64], bf[(BF_POS + 1) * 64], bf[(BF_POS + 2) * 64]};
       xq = {bf[(BF_QUAT + 0) * 64], bf[(BF_QUAT + 1) * 64], bf[(BF_QUAT + 2) * 64], bf[(BF_QUAT + 3) * 64]};
@@ -474,7 +504,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       }
       wave_sync();
       if (is_body) {
-        const double* a = sX + P.body_i[(BI_ANC0 + r) * 64 + ol];
+        const double* a = sX + (((r < 5) ? (anc_lo >> (6 * r)) : anc_hi) & 63);
         V3 ap{a[0], a[XS], a[2 * XS]};
         Q4 aq{a[3 * XS], a[4 * XS], a[5 * XS], a[6 * XS]};
         xp = ap + qrot(aq, xp);
@@ -1531,6 +1561,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       if (A.converged_out) A.converged_out[pb] = conv_flag;
     }
     if (A.status_out && lane == 0) A.status_out[pb] = status_all;
+    sq = (sq == smem + L.q) ? smem + L.q2 : smem + L.q;           // the next problem's rows are (being) fetched there
+    sTgt = (sTgt == smem + L.tgt) ? smem + L.tgt2 : smem + L.tgt;
   }
 }
 

@@ -331,6 +331,12 @@ int32_t mkh_model_create(const MkhFlatModel* h, int32_t device, MkhModel** out) 
       a = x;
     }
   }
+  for (int b = 0; b < h->nbody; ++b) {
+    int lo = 0;
+    for (int r = 0; r < 5 && r < kMaxRounds; ++r) lo |= (body_i[(BI_ANC0 + r) * 64 + b] & 63) << (6 * r);
+    body_i[BI_ANCPACK0 * 64 + b] = lo;
+    body_i[BI_ANCPACK1 * 64 + b] = kMaxRounds > 5 ? (body_i[(BI_ANC0 + 5) * 64 + b] & 63) : 0;
+  }
   // the anc recurrence above must satisfy anc_{r+1}(b) = anc_r(anc_r(b)); verify
   for (int b = 0; b < h->nbody; ++b)
     for (int r = 0; r + 1 < kMaxRounds; ++r) {
@@ -598,13 +604,19 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   P.dense_cost = p->d_dense_cost; P.dense_wgain = p->d_dense_wgain;
 
   P.nt = p->nt;
-  const LdsLayout L = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, j_stride_direct(P.nv, p->nt));
-  p->lds_bytes = L.total * (int)sizeof(double);
+  p->nt_full = p->nt < 32 ? 32 : p->nt;
+  // Second LDS buffers for the next problem's inputs (ik_kernel.h "load inputs") only where they do not cost a
+  // resident wave in the lean or the all-feature variant of this problem (the low-rank variant is checked below).
+  auto lds_of = [&](int nt, bool pre) {
+    return lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, j_stride_direct(P.nv, nt), 0, pre).total *
+           (int)sizeof(double);
+  };
+  P.prefetch = (waves_per_cu(p->nt, lds_of(p->nt, true)) == waves_per_cu(p->nt, lds_of(p->nt, false)) &&
+                waves_per_cu(p->nt_full, lds_of(p->nt_full, true)) == waves_per_cu(p->nt_full, lds_of(p->nt_full, false))) ? 1 : 0;
+  p->lds_bytes = lds_of(p->nt, P.prefetch != 0);
   if (p->lds_bytes > 64 * 1024) return bail(fail(MKH_E_LIMIT, "problem needs %d bytes of LDS per wavefront (> 64 KiB)", p->lds_bytes));
   p->blocks_per_cu = waves_per_cu(p->nt, p->lds_bytes);
-  p->nt_full = p->nt < 32 ? 32 : p->nt;
-  p->lds_bytes_full = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, j_stride_direct(P.nv, p->nt_full)).total *
-                      (int)sizeof(double);
+  p->lds_bytes_full = lds_of(p->nt_full, P.prefetch != 0);
   if (p->blocks_per_cu < 1) p->blocks_per_cu = 1;
   // ---- low-rank start eligibility: box limits only, frame tasks only, few task rows relative to nv
   if (P.n_jrows > 0 && P.n_pairs == 0 && P.n_com == 0 && !p->has_relative && P.n_dense_rows == 0 &&
@@ -616,7 +628,8 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     if (p->wood_nt) {
       const LdsLayout Lw = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows,
                                       p->wood_nt - p->wood_nr + 1, p->wood_nr,
-                                      wood_s_aliases_dof(P.nv, P.n_jrows, p->wood_nt - p->wood_nr) ? 0 : P.n_jrows * (p->wood_nt - p->wood_nr + 1));
+                                      wood_s_aliases_dof(P.nv, P.n_jrows, p->wood_nt - p->wood_nr) ? 0 : P.n_jrows * (p->wood_nt - p->wood_nr + 1),
+                                      P.prefetch != 0);
       // (column, row-chunk) lanes of the Jh·Jhᵀ product: rows 0..n_jrows (the last one is the rhs)
       const int groups = kWave / P.n_jrows;
       P.wood_rpc = (P.n_jrows + 1 + groups - 1) / groups;

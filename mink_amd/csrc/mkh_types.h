@@ -23,7 +23,9 @@ enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
 enum { BF_POS = 0, BF_QUAT = 3, BF_IPOS = 7, BF_MASS = 10, BF_SUBTREEMASS = 11, BF_COUNT = 12 };
 // body lane table fields (int)
 enum { BI_PARENT = 0, BI_JNTADR = 1, BI_JNTNUM = 2, BI_SUBTREE_LAST = 3, BI_IN_ROBOT = 4, BI_ANC0 = 5,
-       BI_COUNT = BI_ANC0 + kMaxRounds };
+       // the pointer-jumping ancestors once more, 6 bits each (bodies < 64): rounds 0-4 in one word, round 5 in the next —
+       // one load at the start of FK instead of one dependent L2 round trip per round
+       BI_ANCPACK0 = BI_ANC0 + kMaxRounds, BI_ANCPACK1 = BI_ANCPACK0 + 1, BI_COUNT = BI_ANCPACK1 + 1 };
 // joint arrays (indexed by joint id, double)
 enum { JF_AXIS = 0, JF_POS = 3, JF_QPOS0 = 6, JF_COUNT = 7 };
 enum { JI_TYPE = 0, JI_QADR = 1, JI_DADR = 2, JI_COUNT = 3 };
@@ -78,6 +80,7 @@ struct DeviceProblem {
   int16_t jpair_task[256], jpair_dof[256];
   int16_t mu_src[64];
   int32_t nt;            // tableau rows per lane of the compiled kernel variant (row stride of the J rows)
+  int32_t prefetch;      // the next problem's q / targets are fetched into second LDS buffers (host: only if that costs no residency)
   int32_t robot_root;    // body 1 (ComTask subtree root)
   // model lane tables
   const double* body_f;  // [BF_COUNT][64]
