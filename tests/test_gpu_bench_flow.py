@@ -1,0 +1,42 @@
+"""bench.py's own multi-rank control flow on the 1-GPU box: `python bench.py --gpus 2` launches its two ranks itself
+(torch.distributed.run, 127.0.0.1), MKH_BENCH_SHARE_GPU=1 lets both use device 0 over gloo (RCCL refuses two ranks on
+one device) — timings are meaningless, the flow is what is tested: self-launch, barriers, MAX-reduced time, the compute-only
+region and the gather region in ONE line whose n_gpus equals --gpus; and without the hook a 2-GPU line is refused."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_self_launched_two_rank_line():
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "4096", "--no-cpu-baseline"], env=_env(MKH_BENCH_SHARE_GPU="1"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["global_batch"] == 2 * 4096
+    assert d["value"] > 0 and d["gather"]["value"] > 0 and d["gather"]["bytes_per_step_to_rank0"] == 4096 * 43 * 8
+    assert "roofline" in d and d["scaling"] == "weak" and "cpu_baseline" not in d
+
+
+def test_two_gpu_line_is_refused_on_one_gpu():
+    from mink_amd import _native as nat
+    if nat.lib().mkh_device_count() >= 2:
+        pytest.skip("box has two GPUs")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "only 1 GPU(s) visible" in r.stderr and "{" not in r.stdout
