@@ -612,6 +612,12 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       bool viol = false;
       if (is_dof && (d_kind == DOF_HINGE || d_kind == DOF_SLIDE))
         viol = q_dof < P.dof_f[DF_RANGE_LO * 64 + ol] - 1e-6 || q_dof > P.dof_f[DF_RANGE_HI * 64 + ol] + 1e-6;
+      // a limited ball joint: the reference's loop compares q[jnt_qposadr] — the quaternion's w — with the range
+      // (configuration.py:92-99); the range sits on the joint's first dof lane only
+      if (is_dof && d_kind == DOF_BALL && d_k == 0) {
+        const double qw = sq[d_qadr];
+        viol = qw < P.dof_f[DF_RANGE_LO * 64 + ol] - 1e-6 || qw > P.dof_f[DF_RANGE_HI * 64 + ol] + 1e-6;
+      }
       if (__ballot(viol)) status |= 1;
     }
     // stash the dof's motion axis in LDS; phases below reload it instead of keeping 20 VGPRs live
@@ -761,13 +767,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           // ball joint: qvel = quat2Vel(conj(q1) ⊗ q2)      (posture_task.py:107)
           const int qa = d_qadr;
           Q4 q1{sq[qa], sq[qa + 1], sq[qa + 2], sq[qa + 3]}, q2{tq[qa], tq[qa + 1], tq[qa + 2], tq[qa + 3]};
-          Q4 df = qmul(qconj(q1), q2);
-          double ax[3] = {df.x, df.y, df.z};
-          double sn = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-          if (sn < 1e-15) { ax[0] = 1; ax[1] = 0; ax[2] = 0; } else { ax[0] /= sn; ax[1] /= sn; ax[2] /= sn; }
-          double sp = 2.0 * atan2(sn, df.w);
-          if (sp > M_PI) sp -= 2.0 * M_PI;
-          e = ((d_k == 0) ? ax[0] : ((d_k == 1) ? ax[1] : ax[2])) * sp;
+          const V3 dv = quat2vel(qmul(qconj(q1), q2));
+          e = (d_k == 0) ? dv.x : ((d_k == 1) ? dv.y : dv.z);
           jd = -1.0;
         }  // free-joint dofs: error and Jacobian column zeroed (posture_task.py:115-116,139-141)
       }
@@ -1191,6 +1192,21 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       const double q_dof = q_dof_stash;
       for (int t = 0; t < P.n_cfg; ++t) {
         const double lw = P.cfg_lower[t * 64 + lane], up = P.cfg_upper[t * 64 + lane];
+        if (d_kind == DOF_BALL) {
+          // A limited ball joint.  The reference fills the joint's four qpos slots of `lower` / `upper` with the scalar
+          // range ends and differentiates quaternions (configuration_limit.py:46-52, 94-112: mj_differentiatePos →
+          // mju_subQuat → mju_quat2Vel, nothing normalised): Δq_max = quat2vel(q̄ ⊗ (u,u,u,u)), Δq_min = quat2vel((l,l,l,l)‾ ⊗ q).
+          const Q4 qc{sq[d_qadr], sq[d_qadr + 1], sq[d_qadr + 2], sq[d_qadr + 3]};
+          if (up < kInf) {
+            const V3 dv = quat2vel(qmul(qconj(qc), Q4{up, up, up, up}));
+            hi = fmin(hi, P.cfg_gain[t] * ((d_k == 0) ? dv.x : ((d_k == 1) ? dv.y : dv.z)));
+          }
+          if (lw > -kInf) {
+            const V3 dv = quat2vel(qmul(qconj(Q4{lw, lw, lw, lw}), qc));
+            lo = fmax(lo, -(P.cfg_gain[t] * ((d_k == 0) ? dv.x : ((d_k == 1) ? dv.y : dv.z))));
+          }
+          continue;
+        }
         if (up < kInf) hi = fmin(hi, P.cfg_gain[t] * (up - q_dof));
         if (lw > -kInf) lo = fmax(lo, -(P.cfg_gain[t] * (q_dof - lw)));
       }

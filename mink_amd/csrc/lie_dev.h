@@ -129,6 +129,17 @@ __device__ __forceinline__ V3 so3_log(Q4 q) {
   return {factor * q.x, factor * q.y, factor * q.z};
 }
 
+// mju_quat2Vel(quat, dt = 1): rotation vector of a (not necessarily unit) quaternion — axis = normalised vector part
+// ((1,0,0) when it vanishes), angle = 2·atan2(|vector part|, w) wrapped to (−π, π]
+__device__ __forceinline__ V3 quat2vel(Q4 q) {
+  double ax[3] = {q.x, q.y, q.z};
+  const double sn = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+  if (sn < 1e-15) { ax[0] = 1; ax[1] = 0; ax[2] = 0; } else { ax[0] /= sn; ax[1] /= sn; ax[2] /= sn; }
+  double sp = 2.0 * atan2(sn, q.w);
+  if (sp > M_PI) sp -= 2.0 * M_PI;
+  return V3{ax[0] * sp, ax[1] * sp, ax[2] * sp};
+}
+
 struct SE3 { Q4 q; V3 p; };
 __device__ __forceinline__ SE3 se3_mul(SE3 a, SE3 b) { return {qmul(a.q, b.q), qrot(a.q, b.p) + a.p}; }
 __device__ __forceinline__ SE3 se3_inv(SE3 a) { Q4 qi = qconj(a.q); return {qi, -1.0 * qrot(qi, a.p)}; }

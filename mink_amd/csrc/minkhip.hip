@@ -377,7 +377,8 @@ int32_t mkh_model_create(const MkhFlatModel* h, int32_t device, MkhModel** out) 
     dof_i[DI_BODY * 64 + d] = h->dof_bodyid[d];
     dof_i[DI_QADR * 64 + d] = qadr;
     dof_i[DI_JIDX * 64 + d] = j - h->body_jntadr[h->jnt_bodyid[j]];
-    if ((jt == JNT_HINGE || jt == JNT_SLIDE) && h->jnt_limited[j]) {
+    // (a limited ball joint: the reference's check_limits compares the quaternion's w with the range — first dof lane)
+    if (((jt == JNT_HINGE || jt == JNT_SLIDE) || (jt == JNT_BALL && k == 0)) && h->jnt_limited[j]) {
       dof_f[DF_RANGE_LO * 64 + d] = h->jnt_range[2 * j];
       dof_f[DF_RANGE_HI * 64 + d] = h->jnt_range[2 * j + 1];
     }
@@ -530,7 +531,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       const int dof = c.indices[k];
       if (dof < 0 || dof >= m->nv) return bail(fail(MKH_E_INVALID, "configuration limit: dof %d out of range", dof));
       const int jt = m->jnt_type[m->dof_jntid[dof]];
-      if (jt != JNT_HINGE && jt != JNT_SLIDE) return bail(fail(MKH_E_INVALID, "configuration limit on ball/free dof %d is not supported", dof));
+      if (jt == JNT_FREE) return bail(fail(MKH_E_INVALID, "configuration limit on free-joint dof %d (the reference skips free joints)", dof));
       const int qa = m->jnt_qposadr[m->dof_jntid[dof]];
       clo[t * 64 + dof] = c.lower[qa];
       chi[t * 64 + dof] = c.upper[qa];

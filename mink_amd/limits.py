@@ -58,9 +58,6 @@ class ConfigurationLimit(Limit):
             raise LimitDefinitionError(f"{self.__class__.__name__} gain must be in the range (0, 1]")
         m = as_flat_model(model)
         d = api_specs.configuration_limit_desc(m, gain, min_distance_from_limits)
-        for j in range(m.njnt):
-            if m.jnt_limited[j] and m.jnt_type[j] == 1:
-                raise LimitDefinitionError("limited ball joints are not supported on the device path")
         self.indices = d["indices"].astype(np.int64)
         self.indices.setflags(write=False)
         dim = len(self.indices)

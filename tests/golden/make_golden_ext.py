@@ -15,6 +15,8 @@ Outputs (np.savez_compressed, next to this file):
   ik_ballslide.npz   inline MJCF with ball + hinge + slide joints (cf. tests/test_velocity_limit.py:65-89): FrameTask +
                      PostureTask (ball-joint error), VelocityLimit with a 3-vector for the ball joint, ConfigurationLimit
   models/ballslide.json   FlatModel of that MJCF (tests/golden/ballslide.xml is the source text)
+  ik_balllimit.npz   the same chain with a LIMITED ball joint (tests/golden/balllimit.xml) under the default
+                     ConfigurationLimit: the reference's quaternion-slot arithmetic for limited ball joints
 """
 
 import os
@@ -177,11 +179,43 @@ def ballslide(rng):
                   "vel_indices": np.array(vel.indices), "vel_limit": np.array(vel.limit)})
 
 
+def balllimit(rng):
+    """A LIMITED ball joint under the default ConfigurationLimit.  The reference writes the scalar range ends into the
+    joint's four qpos slots and differentiates quaternions (configuration_limit.py:46-52, 94-112), and its check_limits
+    compares the quaternion's w with the range (configuration.py:92-99: a warning with safety_break=False) — quirks
+    the device path reproduces instead of refusing the model."""
+    m = mujoco.MjModel.from_xml_string(open(os.path.join(HERE, "balllimit.xml")).read())
+    m.save(os.path.join(HERE, "models", "balllimit.json"))
+    ft = mink.FrameTask("tip", "site", position_cost=2.0, orientation_cost=0.5, lm_damping=0.1)
+    post = mink.PostureTask(m, cost=0.1)
+    post.set_target(m.qpos0)
+    lims = [mink.ConfigurationLimit(m, gain=0.9)]
+    assert len(lims[0].indices) == 2 + 3            # hinge, slide, and the three dofs of the limited ball joint
+    qb = []
+    while len(qb) < 16:
+        q = perturbed(m, m.qpos0, rng, 0.3)
+        for j in range(m.njnt):
+            if m.jnt_limited[j] and m.jnt_type[j] in (2, 3):
+                lo, hi = m.jnt_range[j]
+                q[m.jnt_qposadr[j]] = rng.uniform(lo + 0.02 * (hi - lo), hi - 0.02 * (hi - lo))
+        qb.append(q)
+    qb = np.array(qb)
+
+    def set_targets(i, q):
+        ct = mink.Configuration(m, perturbed(m, q, rng, 0.2))
+        ft.set_target(ct.get_transform_frame_to_world("tip", "site"))
+        return {"frame_targets": [ft.transform_target_to_world.wxyz_xyz]}
+
+    record("balllimit", m, [ft, post], lims, 1e-2, 1e-4, qb, set_targets, store_G=16,
+           extra={"posture_target": m.qpos0.copy(), "cfg_indices": np.array(lims[0].indices)})
+
+
 def main():
     rng = np.random.default_rng(2)
     g1_ext(rng)
     ur5e_coll(rng)
     ballslide(rng)
+    balllimit(np.random.default_rng(5))
 
 
 if __name__ == "__main__":

@@ -104,7 +104,11 @@ def build_ext(name, nmodel, d, max_batch):
                                  max_batch=max_batch)
         rows = list(range(0, 6)) + list(range(6 + nv, 12 + nv)) + list(range(6, 6 + nv))
         return prob, (d["frame_targets"], d["posture_target"][None, :], None), np.array(rows), 1e-2, 1e-4
+    if name == "balllimit":
+        prob = nat.NativeProblem(nmodel, frame_tasks=[_ft(m, "tip", "site", 2.0, 0.5, 0.1)], posture_tasks=[{"cost": 0.1}],
+                                 configuration_limits=[_cfg_limit(m, 0.9)], max_batch=max_batch)
+        return prob, (d["frame_targets"], d["posture_target"][None, :], None), None, 1e-2, 1e-4
     raise KeyError(name)
 
 
-ROBOT_OF.update({"g1_ext": "g1", "ur5e_coll": "ur5e", "ballslide": "ballslide"})
+ROBOT_OF.update({"g1_ext": "g1", "ur5e_coll": "ur5e", "ballslide": "ballslide", "balllimit": "balllimit"})

@@ -132,4 +132,11 @@ def ballslide(d, i):
     return m, tasks, limits, 1e-2, 1e-4
 
 
-EXT = {"g1_ext": g1_ext, "ur5e_coll": ur5e_coll, "ballslide": ballslide}
+def balllimit(d, i):
+    m = model("balllimit")
+    tasks = [ik.FrameTaskSpec(m.name2id("site", "tip"), "site", _cost6(2.0, 0.5), d["frame_targets"][i][0], lm_damping=0.1),
+             ik.PostureTaskSpec(np.full(m.nv, 0.1), d["posture_target"])]
+    return m, tasks, [ik.ConfigurationLimitSpec(gain=0.9)], 1e-2, 1e-4
+
+
+EXT = {"g1_ext": g1_ext, "ur5e_coll": ur5e_coll, "ballslide": ballslide, "balllimit": balllimit}

@@ -116,7 +116,7 @@ def _box_from_rows(G, h, nv):
     return lo, hi, used
 
 
-@pytest.mark.parametrize("name", ["g1_ext", "ur5e_coll", "ballslide"])
+@pytest.mark.parametrize("name", ["g1_ext", "ur5e_coll", "ballslide", "balllimit"])
 def test_round2_fixtures(nat, name):
     """Fixtures recorded from the real mink by tests/golden/make_golden_ext.py: RelativeFrameTask (moving roots),
     DampingTask, body/geom frames, PER-INSTANCE posture and CoM targets (MKH_FLAG_POSTURE_BATCHED / _COM_BATCHED),
@@ -134,7 +134,7 @@ def test_round2_fixtures(nat, name):
     J_ref = d["task_J"] if rows is None else d["task_J"][:, rows]
     np.testing.assert_allclose(t["task_J"][:len(J_ref)], J_ref, rtol=0, atol=1e-9)
     main = np.ones(B, bool)
-    if name != "ur5e_coll":
+    if name not in ("ur5e_coll", "balllimit"):
         main[7::8] = False                                    # small-angle sub-stream (δ ~ 1e-4)
     dH = np.abs(t["H"] - d["H"]) / np.abs(d["H"]).max(axis=(1, 2), keepdims=True)
     dc = np.abs(t["c"] - d["c"]) / np.abs(d["c"]).max(axis=1, keepdims=True)
@@ -153,6 +153,14 @@ def test_round2_fixtures(nat, name):
             np.testing.assert_allclose(t["coll_h"][i][fin], hc[fin], rtol=0, atol=1e-9)
             np.testing.assert_allclose(t["coll_G"][i], Gc, rtol=0, atol=1e-10)
     assert (st & ~1 == 0).all(), st
+    if name == "balllimit":
+        # the reference's check_limits compares the limited ball joint's quaternion w with its range (a warning under
+        # safety_break=False): the device sets the same per-instance bit
+        m_ = oc.model("balllimit")
+        j = m_.name2id("joint", "ball2")
+        qw = d["q"][:, m_.jnt_qposadr[j]]
+        expect = (qw < m_.jnt_range[j, 0] - 1e-6) | (qw > m_.jnt_range[j, 1] + 1e-6)
+        assert ((st & 1).astype(bool) == expect).all() and expect.any()
     vs = np.maximum(1.0, np.abs(d["v"]).max(axis=1, keepdims=True))
     err = np.abs(v - d["v"]) / vs
     print(name, "max rel v err main/small", err[main].max(), err[~main].max(initial=0))

@@ -74,7 +74,7 @@ def test_ur5e_c1_trajectory(golden_dir):
     np.testing.assert_allclose(cfg.q, d["q_final"], rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("name", ["g1_ext", "ur5e_coll", "ballslide"])
+@pytest.mark.parametrize("name", ["g1_ext", "ur5e_coll", "ballslide", "balllimit"])
 def test_round2_fixtures(golden_dir, name):
     """RelativeFrameTask / DampingTask / body- and geom-frame tasks / per-instance posture and CoM targets /
     the arm_ur5e.py collision set-up / ball + slide joints, recorded from the real mink by make_golden_ext.py."""
