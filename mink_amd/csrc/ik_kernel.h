@@ -45,13 +45,15 @@ __host__ __device__ inline int a_stride_for(int nv) {
 __host__ __device__ inline int j_stride_direct(int nv, int nt) { const int a = a_stride_for(nv); return a < nt ? a : nt; }
 
 constexpr int kPivBuf = kWave + 8;   // doubles per pivot broadcast buffer
+constexpr int kBlk = 6;              // low-rank start, phase 0: task-residual indices enter the basis in blocks of kBlk
+constexpr int kBlkLds = 2 * kBlk * kWave + 8;   // doubles of the block buffer: [kBlk][64] block rows + [kBlk][64] multipliers (aliases the dead Jh rows)
 struct LdsLayout {
   int q, X, jnt, tgt, task, J, dof, com, col, A, piv, S, q2, tgt2, total;  // offsets in doubles
 };
 __host__ __device__ inline int lds_even(int x) { return (x + 1) & ~1; }
 __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int njnt, int n_frame,
                                                 int n_posture, int n_com, int max_rows, int j_rows, int j_stride,
-                                                int s_doubles = 0, bool prefetch = false) {
+                                                int s_doubles = 0, bool prefetch = false, int j_min = 0) {
   LdsLayout L;
   int o = 0;
   L.q = o;    o += lds_even(nq);
@@ -61,7 +63,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
   L.task = o; o += n_frame * 64;
   // weighted Jacobian rows [r][j_stride]: the 6 rows of ONE task at a time (direct start, stride NT), or
   // every task row + one vector (low-rank start, stride NR)
-  L.J = o;    o += lds_even(j_rows * j_stride);
+  L.J = o;    o += lds_even(j_rows * j_stride > j_min ? j_rows * j_stride : j_min);   // (j_min: block buffer of the low-rank start's phase 0)
   L.dof = o;  o += lds_even(nv * 10);
   L.com = o;  o += (n_com > 0 ? nbody * 4 : 0);
   L.col = o;  o += max_rows * 16;
@@ -322,7 +324,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   const LdsLayout L = lds_layout(nq, nv, nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows,
                                  kWood ? NT - NR + 1 : 6, kWood ? NR : j_stride_direct(nv, NT),
                                  (kWood && !wood_s_aliases_dof(nv, P0.n_jrows, NT - NR)) ? P0.n_jrows * (NT - NR + 1) : 0,
-                                 P0.prefetch != 0);
+                                 P0.prefetch != 0, kWood ? kBlkLds : 0);
   const bool prefetch = P0.prefetch != 0;
   double* sq = smem + L.q;            // (sq / sTgt alternate between two buffers, see "load inputs")
   double* const sX = smem + L.X;
@@ -1290,18 +1292,111 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // entries after update k are one FMA on row k+1 away (stored to the second buffer by the first instruction of
     // the update's asm statement), and D, σ, x of lane k+1 are final once the cheap per-lane updates of pivot k are
     // done (read with v_readlane into SGPRs).  The LDS round trip and the readlane latency hide under the FMA stream.
+    if constexpr (kWood) {
+      // Low-rank start: the n_μ residual indices enter in BLOCKS of kBlk (block Gauss–Jordan).  One index at a time
+      // every pivot is a dependent chain — publish the column, read it back, 1/d, multipliers, rank-1 update —
+      // of which only the last part is FMA-pipe work; a block B shares the chain: with u(j) = R[B][j] (kBlk
+      // registers of lane j), M = T[B][B] (kBlk × kBlk, wave-uniform, ≺ 0) and A = −M = L·D·Lᵀ,
+      //   R[i][j] += Σ_r u_r(i)·y_r(j),  y(j) = A⁻¹u(j);   D_j += σ_j²·uᵀA⁻¹u;   x_j ∓= σ_j·uᵀA⁻¹w_B
+      // — every lane factorises the tiny A itself (no cross-lane traffic after one LDS round trip) and the kBlk
+      // rank-1 updates run back to back off the block's LDS rows.  Indices of a swept block are dropped (nact below):
+      // their lanes and rows are not maintained.
+      double* const sU = sJ;                           // [kBlk][64]: row B_r of every lane (the Jh rows are dead by now)
+      for (int r0 = 0; r0 < n_mu && !(status & 4); r0 += kBlk) {
+        MKH_MARK("p0_iter_begin");
+        MKH_LAP0();
+        const int m = (n_mu - r0 < kBlk) ? n_mu - r0 : kBlk;
+        const int b0 = mu0 + r0;
+        double u[kBlk], w[kBlk], a[kBlk][kBlk], dinv[kBlk];
+#pragma unroll
+        for (int r = 0; r < kBlk; ++r) {
+          const int row = (b0 + r < NT) ? b0 + r : NT - 1;
+          const double v = Tab<NT>::get_dyn(row);
+          u[r] = (r < m) ? v : 0.0;
+        }
+        unsigned long long nzd;
+        {
+          bool nz = false;
+#pragma unroll
+          for (int r = 0; r < kBlk; ++r) nz = nz || (u[r] != 0.0);
+          nzd = __ballot(nz) & ((1ull << NR) - 1ull);
+        }
+        const int hb = nzd ? 64 - __builtin_clzll(nzd) : 0;    // dof rows the block's columns reach: [0, hb)
+        wave_sync();                                   // earlier readers of the buffers are done
+#pragma unroll
+        for (int r = 0; r < kBlk; ++r) sU[r * kWave + lane] = u[r];
+        // D and w of the block's lanes; a short last block is padded with identity rows (D = −1, w = 0, u = 0)
+        if (lane >= b0 && lane < b0 + kBlk) {
+          const bool in = lane < b0 + m;
+          sPiv[lane - b0] = in ? s.D : -1.0;
+          sPiv[8 + lane - b0] = in ? s.x : 0.0;
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < kBlk; ++r) {
+          w[r] = sPiv[8 + r];
+#pragma unroll
+          for (int c = 0; c < r; ++c) a[r][c] = -sU[r * kWave + b0 + c];
+          a[r][r] = -sPiv[r];
+        }
+        MKH_LAP(0);
+        // A = L·D·Lᵀ in place (L below the diagonal), y ← L⁻¹u
+        double y[kBlk];
+#pragma unroll
+        for (int r = 0; r < kBlk; ++r) y[r] = u[r];
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < kBlk; ++r) {
+          bad = bad || !(a[r][r] > 0.0);
+          dinv[r] = fast_rcp(a[r][r]);
+#pragma unroll
+          for (int c = r + 1; c < kBlk; ++c) {
+            const double l = a[c][r] * dinv[r];
+#pragma unroll
+            for (int t = r + 1; t <= c; ++t) a[c][t] = fma(-l, a[t][r], a[c][t]);   // (column r still holds A, see below)
+            y[c] = fma(-l, y[r], y[c]);
+          }
+#pragma unroll
+          for (int c = r + 1; c < kBlk; ++c) a[c][r] *= dinv[r];                    // L[c][r]
+        }
+        if (bad) { status |= 4; break; }
+#pragma unroll
+        for (int r = kBlk - 1; r >= 0; --r) {
+          y[r] *= dinv[r];
+#pragma unroll
+          for (int c = r + 1; c < kBlk; ++c) y[r] = fma(-a[c][r], y[c], y[r]);      // y = L⁻ᵀD⁻¹L⁻¹u = A⁻¹u
+        }
+        double quad = 0.0, zw = 0.0;
+#pragma unroll
+        for (int r = 0; r < kBlk; ++r) { quad = fma(u[r], y[r], quad); zw = fma(w[r], y[r], zw); }
+        s.D = fma(s.sg * s.sg, quad, s.D);             // uᵀA⁻¹u
+        s.x += xor_sign(s.sg * zw, s.usign);           // basic dof: z −= σ·w_BᵀA⁻¹u, residual still outside: w += …
+        // the kBlk rank-1 updates, rolled (six copies of the generated bodies are 45 KB of code); y_r from LDS
+        const unsigned scratch = lds_addr(sPiv + kPivBuf + lane);
+#pragma unroll
+        for (int r = 0; r < kBlk; ++r) sU[(kBlk + r) * kWave + lane] = y[r];
+#pragma nounroll
+        for (int r = 0; r < m; ++r) {
+          const double yr = sU[(kBlk + r) * kWave + lane];
+          Tab<NT>::rank1_prefetch(lds_addr(sU + r * kWave));
+          rank1_split_rows<NT, NR>(lds_addr(sU + r * kWave), yr, hb, scratch, 0.0);
+        }
+        MKH_LAP(1);
+      }
+      if (is_mu) { s.usign = kSign; s.x = 0.0; }       // (dropped indices: inert from here on)
+    }
     double* bufc = sPiv;
     double* bufn = sPiv + kPivBuf;
     double own = 0.0;
     double pd = 1.0, psg = 1.0, px = 0.0;            // D, σ, x of the pivot lane (wave-uniform)
-    if (k_begin < k_end) {
+    if (!kWood && k_begin < k_end) {
       const double rowv = Tab<NT>::get_dyn(k_begin);
       own = (lane == k_begin) ? 0.0 : rowv;
       wave_sync();                                   // earlier readers of the buffer are done
       bufc[lane] = own;
       pd = readlane_f64(s.D, k_begin); psg = readlane_f64(s.sg, k_begin); px = readlane_f64(s.x, k_begin);
     }
-    for (int k = k_begin; k < k_end; ++k) {
+    for (int k = k_begin; !kWood && k < k_end; ++k) {
       MKH_MARK("p0_iter_begin");
       MKH_LAP0();
       wave_sync();

@@ -630,7 +630,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       const LdsLayout Lw = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows,
                                       p->wood_nt - p->wood_nr + 1, p->wood_nr,
                                       wood_s_aliases_dof(P.nv, P.n_jrows, p->wood_nt - p->wood_nr) ? 0 : P.n_jrows * (p->wood_nt - p->wood_nr + 1),
-                                      P.prefetch != 0);
+                                      P.prefetch != 0, kBlkLds);
       // (column, row-chunk) lanes of the Jh·Jhᵀ product: rows 0..n_jrows (the last one is the rhs)
       const int groups = kWave / P.n_jrows;
       P.wood_rpc = (P.n_jrows + 1 + groups - 1) / groups;
