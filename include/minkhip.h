@@ -51,7 +51,8 @@ extern "C" {
 #define MKH_ST_INFEASIBLE 2      /* constraints inconsistent (quadprog "no solution" → mink/solve_ik.py:103 assert) */
 #define MKH_ST_NOT_PD 4          /* H not positive definite (quadprog "matrix G is not positive definite") */
 #define MKH_ST_ITER_LIMIT 8      /* active-set iteration cap hit */
-#define MKH_ST_ROW_OVERFLOW 16   /* more simultaneously detected contacts than tableau rows */
+#define MKH_ST_ROW_OVERFLOW 16   /* more simultaneously detected contacts than tableau rows (64 - nv) AND a contact that found no
+                                    row is violated at the solution (the tightest contacts get the rows; the rest are checked) */
 
 /* flags */
 #define MKH_FLAG_DEVICE_PTRS 1   /* data pointers are device pointers; async on stream */

@@ -1097,7 +1097,50 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     MKH_TICK();   // 4: posture + task Jacobian columns done
     // ------------------------------------------- collision half-space rows
     int nrows = 0;
+    // More detected contacts than tableau rows (64 − nv): the reference hands every row to quadprog
+    // (collision_avoidance_limit.py:187-210); here the max_rows TIGHTEST (smallest h, ties by pair index) become rows and
+    // the solution is checked against the rest after the QP — a dropped row that holds at the solution was inactive, so
+    // the result is the reference's; one that does not hold sets MKH_ST_ROW_OVERFLOW.
+    bool rows_dropped = false;
+    double* const sH = sJ;                                    // h of every pair (the staged Jacobian rows are dead by now)
+    const bool can_select = kColl && P.n_pairs > P.max_rows && P.n_pairs <= 6 * (kWood ? NR : j_stride_direct(nv, NT));
+    // contact of pair pi at the current poses: active, h, unit normal, witness points, dof chains
+    auto contact_of = [&](int pi, double& hk, V3& nrm, V3& from, V3& to, uint64_t& m1, uint64_t& m2) -> bool {
+      const CollisionPairDev& cp = P.pairs[pi];
+      const double* x1 = sX + cp.body1;
+      const double* x2 = sX + cp.body2;
+      Q4 bq1{x1[3 * XS], x1[4 * XS], x1[5 * XS], x1[6 * XS]}, bq2{x2[3 * XS], x2[4 * XS], x2[5 * XS], x2[6 * XS]};
+      V3 gp1 = V3{x1[0], x1[XS], x1[2 * XS]} + qrot(bq1, V3{cp.lpos1[0], cp.lpos1[1], cp.lpos1[2]});
+      V3 gp2 = V3{x2[0], x2[XS], x2[2 * XS]} + qrot(bq2, V3{cp.lpos2[0], cp.lpos2[1], cp.lpos2[2]});
+      Q4 gq1 = qmul(bq1, Q4{cp.lquat1[0], cp.lquat1[1], cp.lquat1[2], cp.lquat1[3]});
+      Q4 gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
+      double dist;
+      geom_distance<kSimpleColl>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
+                    V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to);
+      const bool active = dist != cp.ddetect;                  // Contact.inactive (:52-56)
+      hk = kInf;
+      if (active) {
+        hk = (dist > cp.dmin) ? (cp.gain * (dist - cp.dmin) / A.dt) + cp.relax : cp.relax;  // :200-205
+        nrm = to - from;                                       // Contact.normal (:46-50)
+        const double nn = sqrt(dot(nrm, nrm));
+        nrm = (nn < 1e-15) ? V3{1.0, 0.0, 0.0} : fast_rcp(nn) * nrm;
+        m1 = cp.mask1;
+        m2 = cp.mask2;
+      }
+      return active;
+    };
+    // position of pair pi in the order (h, index) among all pairs (h = +inf: not detected)
+    auto rank_of = [&](int pi, double hk) -> int {
+      int rank = 0;
+      for (int j = 0; j < P.n_pairs; ++j) {
+        const double hj = sH[j];
+        rank += (hj < hk || (hj == hk && j < pi)) ? 1 : 0;
+      }
+      return rank;
+    };
     if (kColl && P.n_pairs > 0) {
+      for (int pass = 0; pass < 2; ++pass) {
+      nrows = 0;
       for (int base = 0; base < P.n_pairs; base += 64) {
         const int pi = base + lane;
         bool active = false;
@@ -1105,27 +1148,13 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         V3 nrm{1, 0, 0}, from{0, 0, 0}, to{0, 0, 0};
         uint64_t m1 = 0, m2 = 0;
         if (pi < P.n_pairs) {
-          const CollisionPairDev& cp = P.pairs[pi];
-          const double* x1 = sX + cp.body1;
-          const double* x2 = sX + cp.body2;
-          Q4 bq1{x1[3 * XS], x1[4 * XS], x1[5 * XS], x1[6 * XS]}, bq2{x2[3 * XS], x2[4 * XS], x2[5 * XS], x2[6 * XS]};
-          V3 gp1 = V3{x1[0], x1[XS], x1[2 * XS]} + qrot(bq1, V3{cp.lpos1[0], cp.lpos1[1], cp.lpos1[2]});
-          V3 gp2 = V3{x2[0], x2[XS], x2[2 * XS]} + qrot(bq2, V3{cp.lpos2[0], cp.lpos2[1], cp.lpos2[2]});
-          Q4 gq1 = qmul(bq1, Q4{cp.lquat1[0], cp.lquat1[1], cp.lquat1[2], cp.lquat1[3]});
-          Q4 gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
-          double dist;
-          geom_distance<kSimpleColl>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
-                        V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to);
-          active = dist != cp.ddetect;                         // Contact.inactive (:52-56)
-          if (active) {
-            hk = (dist > cp.dmin) ? (cp.gain * (dist - cp.dmin) / A.dt) + cp.relax : cp.relax;  // :200-205
-            nrm = to - from;                                   // Contact.normal (:46-50)
-            const double nn = sqrt(dot(nrm, nrm));
-            nrm = (nn < 1e-15) ? V3{1.0, 0.0, 0.0} : fast_rcp(nn) * nrm;
-            m1 = cp.mask1;
-            m2 = cp.mask2;
+          active = contact_of(pi, hk, nrm, from, to, m1, m2);
+          if (pass == 0) {
+            if (can_select) sH[pi] = hk;
+            if (MKH_TAP(t_coll_h)) MKH_TAP(t_coll_h)[(size_t)pb * P.n_pairs + pi] = hk;
+          } else if (active) {
+            active = rank_of(pi, hk) < P.max_rows;
           }
-          if (MKH_TAP(t_coll_h)) MKH_TAP(t_coll_h)[(size_t)pb * P.n_pairs + pi] = hk;
         }
         const unsigned long long am = __ballot(active);
         const int slot = nrows + __popcll(am & ((1ull << lane) - 1ull));
@@ -1138,6 +1167,9 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           o[12] = (double)pi;
         }
         nrows += __popcll(am);
+      }
+      if (pass == 0 && can_select && nrows > P.max_rows) { rows_dropped = true; wave_sync(); continue; }   // select, then refill
+      break;
       }
       if (nrows > P.max_rows) { status |= 16; nrows = P.max_rows; }
       wave_sync();
@@ -1628,6 +1660,38 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       MKH_TAP(t_cycles)[(size_t)pb * 16 + lane] = x;
     }
     if (MKH_TAP(t_qp_iters) && lane == 0) MKH_TAP(t_qp_iters)[pb] = (kRows ? iters : n_piv) | (n_loop << 10) | (n_piv << 20);
+    if (kColl && rows_dropped && !(status & 14)) {
+      // the contacts that found no tableau row: G·Δq ≤ h at the solution?  (G·Δq = −nᵀ(ṗ₂(to) − ṗ₁(from)) for joint
+      // displacements Δq, the dofs of each geom's chain only)
+      wave_sync();
+      if (is_dof) sDof[lane * 10 + 9] = zfin;                  // (slot 9 = q is dead now)
+      wave_sync();
+      bool viol = false;
+      for (int base = 0; base < P.n_pairs; base += 64) {
+        const int pi = base + lane;
+        if (pi < P.n_pairs) {
+          const double hs = sH[pi];
+          if (hs < kInf && rank_of(pi, hs) >= P.max_rows) {
+            double hk;
+            V3 nrm{1, 0, 0}, from{0, 0, 0}, to{0, 0, 0};
+            uint64_t m1 = 0, m2 = 0;
+            if (contact_of(pi, hk, nrm, from, to, m1, m2)) {
+              V3 vel{0, 0, 0};
+              for (uint64_t mm = m1 | m2; mm; mm &= mm - 1) {
+                const int d = __builtin_ctzll(mm);
+                const double* dd = sDof + d * 10;
+                const V3 a_ang{dd[0], dd[1], dd[2]}, a_lin{dd[3], dd[4], dd[5]}, a_anchor{dd[6], dd[7], dd[8]};
+                const double dq = dd[9];
+                if ((m2 >> d) & 1) vel = vel + dq * (a_lin + cross(a_ang, to - a_anchor));
+                if ((m1 >> d) & 1) vel = vel - dq * (a_lin + cross(a_ang, from - a_anchor));
+              }
+              viol = viol || (-dot(nrm, vel) > hk + 1e-9 * (1.0 + fabs(hk)));
+            }
+          }
+        }
+      }
+      if (__ballot(viol)) status |= 16;
+    }
     status_all |= status;
     const bool last = until || (step + 1 == n_steps) || (status & 14);   // (until: v of every step — the loop may end at the next check)
     if (last) {

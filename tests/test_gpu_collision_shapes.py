@@ -173,3 +173,71 @@ def test_ur5e_example_wrist_against_wall_and_floor():
             worst = max(worst, np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max()))
         print("UR5e example config, dt=%g, vs oracle: max rel err %.2e" % (dt, worst))
         assert worst < 1e-7
+
+
+def test_more_contacts_than_tableau_rows_keeps_the_tightest():
+    """More detected contacts than the tableau has rows (64 − nv): the reference hands every row to quadprog
+    (collision_avoidance_limit.py:187-210).  The device keeps the max_rows tightest and checks the rest at the
+    solution: unflagged instances equal the oracle's solve with ALL rows; a dropped row that does not hold is flagged."""
+    from mink_amd import _native as nat, workloads
+    import native_configs as nc
+    m = workloads.load_robot("shadow_left")
+    om = oc.model("shadow_left")
+    nm = nat.NativeModel(m)
+    fingers = oc.SHADOW_FINGERS
+    groups = [[f"{f}_1", f"{f}_2"] for f in fingers]
+    pairs = [(groups[i], groups[j]) for i in range(5) for j in range(i + 1, 5)] + [(sum(groups, []), ["floor"])]
+    col = mink.CollisionAvoidanceLimit(m, pairs, collision_detection_distance=0.5, minimum_distance_from_collisions=0.004)
+    assert len(col.geom_id_pairs) == 50 and m.nv == 24        # 50 contacts detected, 40 tableau rows
+    fts = [nc._ft(m, f, "site", 1.0, 0.0, 1.0) for f in fingers]
+    B = 256
+    prob = nat.NativeProblem(nm, frame_tasks=fts, posture_tasks=[{"cost": 1e-2}], configuration_limits=[nc._cfg_limit(m)],
+                             collision_limits=[col._native_desc()[1]], max_batch=B)
+    rng = np.random.default_rng(5)
+    dt, damping = 0.25, 1e-5   # a long step, so that h = gain·(d − d_min)/dt is small and many rows bind
+    # instances that start outside minimum_distance_from_collisions for every pair (opposing h = 0 rows of geoms that
+    # start inside each other are inconsistent for the reference too)
+    prob0 = nat.NativeProblem(nm, frame_tasks=fts, max_batch=4096)
+    qp, tgp = workloads.make_batch(m, nm, prob0, rng, 4096, base_q=m.qpos0, sigma=0.3)
+    prob0.close()
+    _, hp = col.compute_qp_inequalities(mink.Configuration(m, qp), dt)
+    assert np.isfinite(hp).sum(axis=1).max() > 40
+    hmin = np.where(np.isfinite(hp), hp, np.inf).min(axis=1)
+    ok = np.flatnonzero(hmin > 0)
+    ok = ok[np.argsort(hmin[ok])][:B]                         # ... and the closest of those: their rows bind
+    assert len(ok) == B
+    q, tg = qp[ok], tgp[ok]
+    spec = oik.CollisionAvoidanceLimitSpec(col.geom_id_pairs, collision_detection_distance=0.5,
+                                           minimum_distance_from_collisions=0.004)
+    tasks_of = lambda i, tg: [oik.PostureTaskSpec(np.full(m.nv, 1e-2), m.qpos0)] + \
+        [oik.FrameTaskSpec(om.name2id("site", f), "site", np.array([1.0, 1, 1, 0, 0, 0]), tg[i, k], lm_damping=1.0)
+         for k, f in enumerate(fingers)]
+    # (1) targets a short way off: the dropped rows hold at the solution, nothing is flagged
+    # (2) targets far off (fingers sweep centimetres in one step): some dropped rows do not hold — flagged, and rightly so
+    far = nm.integrate(q, rng.normal(scale=1.0, size=(B, m.nv)), 1.0)
+    dummy = np.zeros((B, 5, 7)); dummy[:, :, 0] = 1.0
+    prob1 = nat.NativeProblem(nm, frame_tasks=fts, max_batch=B)
+    tg_far = prob1.solve(far, dummy, None, None, 1.0, 1.0, taps=["frame_pose"], solve_qp=False)[2]["frame_pose"]
+    prob1.close()
+    for regime, tgr, dt in (("near", tg, dt), ("far", tg_far, 8 * dt)):   # (h ∝ 1/dt: the long step shrinks every slack)
+        v, st = prob.solve(q, tgr, m.qpos0[None, :], None, dt, damping)
+        assert ((st & ~(1 | 16)) == 0).all(), st
+        flagged = (st & 16) != 0
+        print("%s targets: instances with a violated dropped row: %d of %d" % (regime, flagged.sum(), B))
+        assert flagged.sum() == 0 if regime == "near" else 0 < flagged.sum() < B
+        worst, n_over, n_bind = 0.0, 0, 0
+        for i in list(np.flatnonzero(~flagged)[:16]) + list(np.flatnonzero(flagged)[:6]):
+            G_ref, h_ref = oik.limit_inequalities(oik.Configuration(om, q[i]), spec, dt)
+            n_over += int(np.isfinite(h_ref).sum() > 40)
+            v_ref = oik.solve_ik(om, q[i], tasks_of(i, tgr), dt, damping, [oik.ConfigurationLimitSpec(), spec])
+            err = np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max())
+            fin = np.isfinite(h_ref)
+            n_bind += int((np.abs(G_ref[fin] @ (v_ref * dt) - h_ref[fin]) < 1e-9).sum())
+            if flagged[i]:
+                assert err > 1e-9                               # (not a false alarm: the all-rows answer differs)
+            else:
+                worst = max(worst, err)
+        print("%s targets: overflowing instances checked: %d, binding rows: %d, unflagged max rel err vs all-rows oracle: %.2e"
+              % (regime, n_over, n_bind, worst))
+        assert n_over >= 16 and n_bind > 0
+        assert worst < 1e-7
