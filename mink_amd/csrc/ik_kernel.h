@@ -878,11 +878,113 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       }
       if (lane >= NR && lane < NR + P.n_jrows) we_mu = sTask[P.mu_src[lane - NR]];
     }
+    // Column `k` of frame task t's Jacobian (6 rows, unweighted): dof k must be on the chain of the frame (or of the
+    // root frame of a RelativeFrameTask).
+    auto frame_column = [&](int t, int k, uint64_t mask, uint64_t rmask, bool rel, double (&Jt)[6]) {
+      const double* o = sTask + t * 64;
+      const double* kd = sDof + k * 10;
+      const V3 d_ang{kd[0], kd[1], kd[2]}, d_lin{kd[3], kd[4], kd[5]}, d_anchor{kd[6], kd[7], kd[8]};
+      V3 a{0, 0, 0}, w{0, 0, 0};
+      if ((mask >> k) & 1) {
+        V3 pf{o[27], o[28], o[29]};
+        V3 jp = d_lin + cross(d_ang, pf - d_anchor);
+        M3 Rf;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rf.m[i] = o[18 + i];
+        a = mulT(Rf, jp); w = mulT(Rf, d_ang);             // body-frame Jacobian (configuration.py:148-153)
+      }
+      double sign = -1.0;                                   // FrameTask: J = −jlog(T_tb)·ᴮJ
+      if (kRel && rel) {
+        sign = 1.0;                                         // RelativeFrameTask: J = +jlog(T_tf)·(ᶠJ − Ad·ʳJ)
+        if ((rmask >> k) & 1) {
+          V3 pr{o[45], o[46], o[47]};
+          V3 jp = d_lin + cross(d_ang, pr - d_anchor);
+          M3 Rr, Rrf;
+#pragma unroll
+          for (int i = 0; i < 9; ++i) { Rr.m[i] = o[36 + i]; Rrf.m[i] = o[48 + i]; }
+          V3 ar = mulT(Rr, jp), wr = mulT(Rr, d_ang);       // root's body-frame column
+          V3 Rw = mul(Rrf, wr);                             // Ad(T_fr⁻¹) = [[R, [t]×R],[0, R]]
+          a = a - (mul(Rrf, ar) + cross(V3{o[57], o[58], o[59]}, Rw));
+          w = w - Rw;
+        }
+      }
+      // jlog = [[J, −J·Q·J],[0, J]]:  y = J·w;  rows 0-2 = ±J·(a − Q·y), rows 3-5 = ±y
+      const double wv[3] = {w.x, w.y, w.z};
+      double y[3], z3[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) y[r] = o[3 * r] * wv[0] + o[3 * r + 1] * wv[1] + o[3 * r + 2] * wv[2];
+      const double av[3] = {a.x, a.y, a.z};
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        z3[r] = av[r] - (o[9 + 3 * r] * y[0] + o[9 + 3 * r + 1] * y[1] + o[9 + 3 * r + 2] * y[2]);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        Jt[r] = sign * (o[3 * r] * z3[0] + o[3 * r + 1] * z3[1] + o[3 * r + 2] * z3[2]);
+        Jt[3 + r] = sign * y[r];
+      }
+    };
+    // Direct start, production variants: the columns of EVERY frame task at once, one (task, dof) pair per lane (the
+    // per-task loop below used to compute them task after task on the dof lanes: n_frame dependent passes of ≈150
+    // fp64 operations each); the loop only stages the pair lanes' weighted rows and runs the rank-1 updates.
+    const bool pair_path = !kWood && !kTaps && P.n_dpairs > 0;
+    int p_task = -1, p_dof = 0;
+    double Jp[6] = {0, 0, 0, 0, 0, 0};                      // weighted rows of this lane's pair
+    if (pair_path && lane < P.n_dpairs) {
+      p_task = P.dpair_task[lane]; p_dof = P.dpair_dof[lane];
+      const FrameTaskDev& ft = P.frame[p_task];
+      const bool rel = kRel && ft.relative != 0;
+      double Jt[6];
+      frame_column(p_task, p_dof, ft.dof_mask, rel ? ft.root_mask : 0ull, rel, Jt);
+#pragma unroll
+      for (int r = 0; r < 6; ++r) Jp[r] = ft.cost[r] * Jt[r];   // weighted_jacobian (task.py:129)
+    }
     for (int t = 0; t < (kWood ? 0 : n_jt); ++t) {
       double Jt[6] = {0, 0, 0, 0, 0, 0}, cw[6] = {0, 0, 0, 0, 0, 0}, we6[6] = {0, 0, 0, 0, 0, 0};
       uint64_t mask;
       int nrow, row0, rowmask, jrow0;
       bool second_half;
+      if (t < P.n_frame && pair_path) {
+        const FrameTaskDev& ft = P.frame[t];
+        const uint64_t cmask = uni((unsigned long long)ft.dof_mask) |
+                               ((kRel && uni(ft.relative) != 0) ? uni((unsigned long long)ft.root_mask) : 0ull);
+        rowmask = uni(ft.rowmask);
+        const double* o = sTask + t * 64;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) we6[r] = uni(o[30 + r]);
+        wave_sync();                                           // previous task's rows are consumed
+        {
+          // compact rows of this task, sJ[c][0..JS): the pair lanes of the task write their dof's entries, dof lanes
+          // off the chain write zeros (disjoint addresses)
+          const bool off = lane < JS && !((cmask >> lane) & 1);
+          int c = 0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+            if ((rowmask >> r) & 1) {
+              if (off) sJ[c * JS + lane] = 0.0;
+              if (p_task == t) sJ[c * JS + p_dof] = Jp[r];
+              ++c;
+            }
+        }
+        wave_sync();
+        double Jw[6];
+        {
+          int c = 0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r) {
+            Jw[r] = 0.0;
+            if ((rowmask >> r) & 1) { if (is_dof) Jw[r] = sJ[c * JS + lane]; ++c; }
+            c_lane -= we6[r] * Jw[r];                          // c = −weighted_errorᵀ·weighted_jacobian
+            hdiag += Jw[r] * Jw[r];
+          }
+        }
+        {
+          int c = 0;
+#pragma unroll
+          for (int r = 0; r < 6; ++r)
+            if ((rowmask >> r) & 1) { rank1_leading_rows<NT>(lds_addr(sJ + c * JS), Jw[r], AS); ++c; }
+        }
+        continue;
+      }
       if (t < P.n_frame) {
         const FrameTaskDev& ft = P.frame[t];
         mask = uni((unsigned long long)ft.dof_mask);
@@ -896,47 +998,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         for (int r = 0; r < 6; ++r) { cw[r] = uni(ft.cost[r]); we6[r] = uni(o[30 + r]); }
         const bool rel = kRel && uni(ft.relative) != 0;
         const uint64_t rmask = rel ? uni((unsigned long long)ft.root_mask) : 0ull;
-        if (is_dof && (((mask | rmask) >> lane) & 1)) {
-          MKH_LOAD_DOF_AXES();
-          V3 a{0, 0, 0}, w{0, 0, 0};
-          if ((mask >> lane) & 1) {
-            V3 pf{o[27], o[28], o[29]};
-            V3 jp = d_lin + cross(d_ang, pf - d_anchor);
-            M3 Rf;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) Rf.m[i] = o[18 + i];
-            a = mulT(Rf, jp); w = mulT(Rf, d_ang);             // body-frame Jacobian (configuration.py:148-153)
-          }
-          double sign = -1.0;                                   // FrameTask: J = −jlog(T_tb)·ᴮJ
-          if (rel) {
-            sign = 1.0;                                         // RelativeFrameTask: J = +jlog(T_tf)·(ᶠJ − Ad·ʳJ)
-            if ((rmask >> lane) & 1) {
-              V3 pr{o[45], o[46], o[47]};
-              V3 jp = d_lin + cross(d_ang, pr - d_anchor);
-              M3 Rr, Rrf;
-#pragma unroll
-              for (int i = 0; i < 9; ++i) { Rr.m[i] = o[36 + i]; Rrf.m[i] = o[48 + i]; }
-              V3 ar = mulT(Rr, jp), wr = mulT(Rr, d_ang);       // root's body-frame column
-              V3 Rw = mul(Rrf, wr);                             // Ad(T_fr⁻¹) = [[R, [t]×R],[0, R]]
-              a = a - (mul(Rrf, ar) + cross(V3{o[57], o[58], o[59]}, Rw));
-              w = w - Rw;
-            }
-          }
-          // jlog = [[J, −J·Q·J],[0, J]]:  y = J·w;  rows 0-2 = ±J·(a − Q·y), rows 3-5 = ±y
-          const double wv[3] = {w.x, w.y, w.z};
-          double y[3], z3[3];
-#pragma unroll
-          for (int r = 0; r < 3; ++r) y[r] = o[3 * r] * wv[0] + o[3 * r + 1] * wv[1] + o[3 * r + 2] * wv[2];
-          const double av[3] = {a.x, a.y, a.z};
-#pragma unroll
-          for (int r = 0; r < 3; ++r)
-            z3[r] = av[r] - (o[9 + 3 * r] * y[0] + o[9 + 3 * r + 1] * y[1] + o[9 + 3 * r + 2] * y[2]);
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            Jt[r] = sign * (o[3 * r] * z3[0] + o[3 * r + 1] * z3[1] + o[3 * r + 2] * z3[2]);
-            Jt[3 + r] = sign * y[r];
-          }
-        }
+        if (is_dof && (((mask | rmask) >> lane) & 1)) frame_column(t, lane, mask, rmask, rel, Jt);
       } else {
         // CoM Jacobian column (mj_jacSubtreeCom closed form)
         const int tc = t - P.n_frame;

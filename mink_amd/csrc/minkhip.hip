@@ -619,7 +619,21 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   p->blocks_per_cu = waves_per_cu(p->nt, p->lds_bytes);
   p->lds_bytes_full = lds_of(p->nt_full, P.prefetch != 0);
   if (p->blocks_per_cu < 1) p->blocks_per_cu = 1;
-  // ---- low-rank start eligibility: box limits only, frame tasks only, few task rows relative to nv
+  // ---- direct start: Jacobian columns by (task, dof) pair lanes when they fit one wavefront
+  P.n_dpairs = 0;
+  {
+    int n = 0;
+    bool fits = true;
+    for (size_t t = 0; t < ft.size() && fits; ++t) {
+      const uint64_t cm = ft[t].dof_mask | (ft[t].relative ? ft[t].root_mask : 0ull);
+      for (int k = 0; k < m->nv && fits; ++k)
+        if ((cm >> k) & 1) {
+          if (n >= kWave) { fits = false; break; }
+          P.dpair_task[n] = (int16_t)t; P.dpair_dof[n] = (int16_t)k; ++n;
+        }
+    }
+    if (fits) P.n_dpairs = n;
+  }
   if (P.n_jrows > 0 && P.n_pairs == 0 && P.n_com == 0 && !p->has_relative && P.n_dense_rows == 0 &&
       P.n_dense_limit_rows == 0 && 2 * P.n_jrows <= m->nv &&
       m->nv + P.n_jrows <= kWave) {

@@ -79,6 +79,10 @@ struct DeviceProblem {
   int32_t n_jpairs;
   int16_t jpair_task[256], jpair_dof[256];
   int16_t mu_src[64];
+  // direct start: (task, dof) pair lanes of every frame task's Jacobian (dofs on the chain of the frame or of the root
+  // frame of a RelativeFrameTask); 0 when there are more than 64 pairs (then the dof lanes compute task after task)
+  int32_t n_dpairs;
+  int16_t dpair_task[64], dpair_dof[64];
   int32_t nt;            // tableau rows per lane of the compiled kernel variant (row stride of the J rows)
   int32_t prefetch;      // the next problem's q / targets are fetched into second LDS buffers (host: only if that costs no residency)
   int32_t robot_root;    // body 1 (ComTask subtree root)
