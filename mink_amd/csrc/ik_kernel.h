@@ -1236,20 +1236,30 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       if (nrows > P.max_rows) { status |= 16; nrows = P.max_rows; }
       wave_sync();
       // G[s][lane] = −nᵀ(jacp₂(to) − jacp₁(from))   (compute_contact_normal_jacobian :59-72)
-      for (int s = 0; s < nrows; ++s) {
-        const double* o = sCol + s * 16;
-        double a = 0.0;
-        if (is_dof) {
+      // (two rows per trip: the rows are independent chains of ≈40 dependent fp64 operations)
+      {
+        const double* ax = sDof + (is_dof ? lane : 0) * 10;
+        const V3 d_ang{ax[0], ax[1], ax[2]}, d_lin{ax[3], ax[4], ax[5]}, d_anchor{ax[6], ax[7], ax[8]};
+        auto row_entry = [&](int s) -> double {
+          const double* o = sCol + s * 16;
           const uint64_t m1 = (uint64_t)__double_as_longlong(o[10]), m2 = (uint64_t)__double_as_longlong(o[11]);
           V3 n{o[0], o[1], o[2]};
           V3 dj{0, 0, 0};
-          MKH_LOAD_DOF_AXES();
           if ((m2 >> lane) & 1) dj = dj + d_lin + cross(d_ang, V3{o[6], o[7], o[8]} - d_anchor);
           if ((m1 >> lane) & 1) dj = dj - (d_lin + cross(d_ang, V3{o[3], o[4], o[5]} - d_anchor));
-          a = -dot(n, dj);
-          if (MKH_TAP(t_coll_G)) MKH_TAP(t_coll_G)[((size_t)pb * P.n_pairs + (int)o[12]) * nv + lane] = a;
+          const double a = is_dof ? -dot(n, dj) : 0.0;
+          if (MKH_TAP(t_coll_G) && is_dof) MKH_TAP(t_coll_G)[((size_t)pb * P.n_pairs + (int)o[12]) * nv + lane] = a;
+          return a;
+        };
+        int s = 0;
+        for (; s + 1 < nrows; s += 2) {
+          const double a0 = row_entry(s), a1 = row_entry(s + 1);
+          if (lane < AS) { sA[s * AS + lane] = a0; sA[(s + 1) * AS + lane] = a1; }
         }
-        if (lane < AS) sA[s * AS + lane] = a;
+        if (s < nrows) {
+          const double a0 = row_entry(s);
+          if (lane < AS) sA[s * AS + lane] = a0;
+        }
       }
     }
     // caller-defined limits (Limit.compute_qp_inequalities, limits/limit.py:34-57): rows G·Δq ≤ h of this instance,
