@@ -62,6 +62,7 @@ extern "C" {
 #define MKH_FLAG_WAVE_KERNEL 16     /* never use the lane-per-problem kernel of small arms (parity/diagnostic switch) */
 #define MKH_FLAG_LANE_KERNEL 32     /* use the lane-per-problem kernel whenever the problem qualifies, whatever the batch
                                      * size (default: from 8192 instances; parity/diagnostic switch) */
+#define MKH_FLAG_TWO_WAVES 64       /* never use the 3-waves-per-SIMD kernel variants (parity/diagnostic switch) */
 
 /* frame types (mink/constants.py:3 SUPPORTED_FRAMES) */
 #define MKH_FRAME_BODY 0

@@ -3,10 +3,8 @@
 Why: hipcc cannot keep a 48-double per-lane array in registers through a loop with control flow —
 it copies the array between register sets at block boundaries and spills loop-invariant values
 into the pivot's critical path (scratch reloads of an LDS address cost ~500 cycles each).  So the
-tableau lives in a fixed physical register range the compiler never allocates
-(`amdgpu_num_vgpr` caps the compiler below it; asm clobbers make the range count towards the
-kernel's VGPR total), and the four operations that touch it are emitted here with literal
-register numbers:
+tableau lives in a fixed physical register range and the operations that touch it are emitted here
+with literal register numbers:
 
     zero()                    T[i] = 0
     rank1_prefetch / rank1_body*(lds_addr, g)   T[i] += lds[i]·g   four lane-indexed ds_read_b64 + v_fmac_f64_dpp
@@ -15,21 +13,36 @@ register numbers:
     get_dyn(k) / set_dyn(k,x) single element, wave-uniform runtime index (VGPR index mode)
     get<I>() / set<I>(x)      single element, compile-time index (tableau build, taps)
 
-Register map for NT rows (wave64; TOP = 256 VGPRs per lane at 2 waves/SIMD, 168 at 3 (NT ≤ 24), 128 at 4 (NT ≤ 8)):
-    v[TOP-2·NT, TOP)              tableau column (NT doubles)
+Two register maps (every primitive takes a `Regs&` first, an empty struct in the first map):
+
+Tab<NT> — RESERVED range (wave64; TOP = 256 VGPRs per lane at 2 waves/SIMD, 168 at 3 (NT ≤ 24), 128 at 4 (NT ≤ 8)):
+    v[TOP-2·NT, TOP)              tableau column (NT doubles): never allocated by the compiler (`amdgpu_num_vgpr` caps it
+                                  below the range; asm clobbers make the range count towards the kernel's VGPR total)
     v[TOP-2·NT-8, TOP-2·NT)       the pivot column in four 16-lane "planes" (S = 8 registers, see rank1 below)
-    v[0, TOP-2·NT-S)              everything the compiler allocates
+    v[0, TOP-2·NT-S)              everything the compiler allocates — through the WHOLE kernel, also where the tableau is dead
+
+TabW3<NT> — OPERAND range, TOP = 168 (3 waves/SIMD for tableaus of 32–44 rows):
+    v[160, 168)                   the planes, reserved above the cap as before
+    v[160-2·NT, 160)              tableau column, handed to every asm statement as "+{v[a:b]}" operands on 32/16/8-register
+                                  tuples (Regs): the compiler knows where the column is alive and where it is dead, so
+                                  forward kinematics, Lie algebra and Jacobian phases use all 160 registers and only the
+                                  QP runs in the 160 − 2·NT below the column.  (With the reserved map a 44-row tableau
+                                  left the compiler 72 registers for the whole kernel: 83–236 spilled VGPRs.)
+    Correctness does not rest on the compiler leaving the range alone between statements: it may move a tuple, the
+    operand constraints bring it back.  tools/check_vgpr_cap.py reports such moves (they would be slow, not wrong).
 
 The staging range must stay ABOVE the compiler's cap even though half of it is only live inside one asm
 statement: the VGPRs hipcc reserves for SGPR spills are the highest ones below the cap, reserved
 registers are not preserved across an asm that lists them as clobbers (clang warns, and the spilled
-SGPRs really are lost — seen as a QP that never converges in the one variant with 400 SGPR spills).
+SGPRs really are lost — seen as a QP that never converges in the one variant with 400 SGPR spills); and the plane
+loads are asynchronous, the compiler must never touch their destination between prefetch and body.
 """
 
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 NTS = (8, 16, 24, 32, 40, 44, 48, 56, 62, 64)
+W3_NTS = (32, 40, 44)   # tableaus that also get the 3-waves-per-SIMD operand map (TabW3<NT>: TOP = 168)
 def total_for(nt):
     # VGPRs per lane = 512 / resident waves per SIMD: small tableaus leave room for 4 (NT ≤ 8) or 3 (NT ≤ 24)
     # waves per SIMD instead of 2 — more waves hide more of the serial pivot chain (UR5e-class arms)
@@ -46,24 +59,80 @@ def ntmp_for(nt):
 SPLIT_PREFIXES = (16, 24, 32)   # dof-row prefixes of the split rank-1 bodies (phase 0 of the low-rank start)
 
 
-def gen(nt: int) -> str:
-    NTMP = ntmp_for(nt)
-    TOTAL = total_for(nt)
-    t0 = TOTAL - 2 * nt
-    tmp0 = t0 - NTMP
-    budget = tmp0
-    treg = lambda i: f"v[{t0 + 2 * i}:{t0 + 2 * i + 1}]"
-    clob_t = ",".join(f'"v{r}"' for r in range(t0, TOTAL))
-    clob_tmp = ",".join(f'"v{r}"' for r in range(tmp0, t0))
+def chunks_for(nregs):
+    """Tuple sizes (registers) that tile the tableau range of the operand map: 32 / 16 / 8 / 4 / 2."""
     out = []
-    out.append(f"template <> struct Tab<{nt}> {{")
+    for size in (32, 16, 8, 4, 2):
+        while nregs >= size:
+            out.append(size)
+            nregs -= size
+    assert nregs == 0
+    return out
+
+
+def gen(nt: int, total: int = 0, name: str = "Tab", operand_map: bool = False, fence: bool = False) -> str:
+    NTMP = ntmp_for(nt)
+    TOTAL = total or total_for(nt)
+    if TOTAL == 168 and nt > 24:
+        NTMP = 2 * ((nt + 15) // 16)         # 3-waves maps: only the planes the column has (44 rows: 3 planes, 6 registers)
+    if operand_map:
+        tmp0 = TOTAL - NTMP                  # planes at the top, reserved
+        t0 = tmp0 - 2 * nt                   # tableau below them, operands
+        budget = tmp0                        # the compiler's cap: everything below the planes
+    else:
+        t0 = TOTAL - 2 * nt
+        tmp0 = t0 - NTMP
+        budget = tmp0
+    t1 = t0 + 2 * nt
+    treg = lambda i: f"v[{t0 + 2 * i}:{t0 + 2 * i + 1}]"
+    clob_tmp = ",".join(f'"v{r}"' for r in range(tmp0, tmp0 + NTMP))
+    if operand_map:
+        tuples, r = [], t0
+        for k, size in enumerate(chunks_for(2 * nt)):
+            tuples.append((f"r{k}", size, r))
+            r += size
+        clob_t = ""
+
+        def tab_ops(write_only=False):
+            c = "=" if write_only else "+"
+            return ", ".join(f'"{c}{{v[{a}:{a + size - 1}]}}"(t.{nm})' for nm, size, a in tuples)
+    else:
+        clob_t = ",".join(f'"v{r}"' for r in range(t0, t1))
+
+    def stmt(body, outs="", ins="", clob="", write_only=False, indent="    ", is_fence=False):
+        """One asm statement.  outs / ins: operand lists with [names]; clob: further clobbers (besides the tableau range in
+        the reserved map)."""
+        if operand_map and fence and not (write_only or is_fence):
+            o, c = outs, clob          # fence map: ordinary statements do not mention the column at all
+        elif operand_map:
+            o = tab_ops(write_only) + (", " + outs if outs else "")
+            c = clob
+        else:
+            o = outs
+            c = ", ".join(x for x in (clob_t, clob) if x)
+        return f'{indent}asm volatile("{body}" : {o} : {ins} : {c});' if c else f'{indent}asm volatile("{body}" : {o} : {ins});'
+
+    J = "\\n\\t".join
+    out = []
+    out.append(f"template <> struct {name}<{nt}> {{")
     out.append(f"  static constexpr int kRows = {nt};")
     out.append(f"  static constexpr int kCompilerVgprs = {budget};")
+    if operand_map:
+        out.append("  // the tableau column as asm operands: tuples pinned to " + ", ".join(f"v[{a}:{a + s - 1}]" for _, s, a in tuples))
+        out.append("  struct Regs { " + " ".join(f"int __attribute__((ext_vector_type({s}))) {nm};" for nm, s, _ in tuples) + " };")
+    else:
+        out.append("  struct Regs {};   // (reserved map: the column is not a compiler-visible value)")
     # zero
-    body = "\\n\\t".join(f"v_mov_b32 v{r}, 0" for r in range(t0, TOTAL))
-    out.append("  __device__ static __forceinline__ void zero() {")
-    out.append(f'    asm volatile("{body}" ::: {clob_t});')
+    out.append("  __device__ static __forceinline__ void zero(Regs& t) {")
+    out.append(stmt(J(f"v_mov_b32 v{r}, 0" for r in range(t0, t1)), write_only=True))
     out.append("  }")
+    if operand_map:
+        out.append("  // no instruction: tells the compiler that the column is (still) alive here")
+        out.append("  __device__ static __forceinline__ void touch(Regs& t) {")
+        out.append(stmt("", is_fence=True))
+        out.append("  }")
+    else:
+        out.append("  __device__ static __forceinline__ void touch(Regs&) {}")
     # rank1 = prefetch (the four plane loads) + body; the split lets the caller put the reciprocal / multiplier
     # arithmetic between them so that the LDS latency is hidden.
     nplanes = (nt + 15) // 16
@@ -71,86 +140,90 @@ def gen(nt: int) -> str:
         return tmp0 + 2 * p
     def fmac(i):
         r = plane_reg(i // 16)
-        return f"v_fmac_f64_dpp {treg(i)}, v[{r}:{r + 1}], %1 row_newbcast:{i % 16} row_mask:0xf bank_mask:0xf"
+        return f"v_fmac_f64_dpp {treg(i)}, v[{r}:{r + 1}], %[g] row_newbcast:{i % 16} row_mask:0xf bank_mask:0xf"
     def rank1_lines(rows, pub=False):
         """T[i] += u[i]·g for the given rows; the planes were requested by rank1_prefetch.
-        pub: the statement first stores %3 (this lane's entry of the NEXT pivot column) at LDS address %2 and then
+        pub: the statement first stores %[pub] (this lane's entry of the NEXT pivot column) at LDS address %[pa] and then
         waits for everything older than that store — LDS operations of a wave complete in order, so lgkmcnt(1)
         means "the plane loads are here" without draining the store (look-ahead publishing, ik_kernel.h).
         Otherwise lgkmcnt(0): the compiler may have put LDS / scalar-memory instructions of its own between prefetch and
         body (SMEM returns out of order, so only a full drain is exact); the loads were issued ~100 cycles earlier.
         s_nop 4: a DPP operand must not be read within 5 wait states of an EXEC write by the code before the statement."""
-        head = ["ds_write_b64 %2, %3", "s_waitcnt lgkmcnt(1)"] if pub else ["s_waitcnt lgkmcnt(0)"]
+        head = ["ds_write_b64 %[pa], %[pub]", "s_waitcnt lgkmcnt(1)"] if pub else ["s_waitcnt lgkmcnt(0)"]
         return head + ["s_nop 4"] + [fmac(i) for i in rows]
-    lines = ["s_waitcnt lgkmcnt(0)"] + [f"ds_read_b64 v[{plane_reg(p)}:{plane_reg(p) + 1}], %0 offset:{128 * p}" for p in range(nplanes)]
-    body = "\\n\\t".join(lines)
+    IN_G = '[g] "v"(g)'
+    IN_PUB = '[g] "v"(g), [pa] "v"(pub_addr), [pub] "v"(pub)'
+    lines = ["s_waitcnt lgkmcnt(0)"] + [f"ds_read_b64 v[{plane_reg(p)}:{plane_reg(p) + 1}], %[a] offset:{128 * p}" for p in range(nplanes)]
     clob_pre = ",".join(f'"v{r}"' for r in range(tmp0, tmp0 + 2 * nplanes))
     out.append("  // request the pivot column lds[0..kRows): lane l gets lds[16·p + l % 16] in plane p (must be followed by a")
     out.append("  // rank1_body* with the same column)")
-    out.append("  __device__ static __forceinline__ void rank1_prefetch(unsigned lds_addr) {")
-    out.append("    const unsigned lane_addr = lds_addr + ((threadIdx.x & 15u) << 3);")
-    out.append(f'    asm volatile("{body}" :: "v"(lane_addr) : {clob_pre}, "memory");')
+    out.append("  __device__ static __forceinline__ void rank1_prefetch(Regs&, unsigned lds_addr) {")
+    if TOTAL == 168 and nt > 24:
+        # 3-waves maps: the lane's plane address is computed inside the statement (mbcnt = lane id), in the first plane's own
+        # destination register — as a C++ value it is loop-invariant, lives through the whole QP and, with 72 registers for
+        # the compiler, was the value hipcc chose to spill: one scratch reload at the head of every pivot's dependent chain
+        pr = plane_reg(0)
+        pre = [f"v_mbcnt_lo_u32_b32 v{pr}, -1, 0", f"v_mbcnt_hi_u32_b32 v{pr}, -1, v{pr}", f"v_and_b32 v{pr}, 15, v{pr}",
+               f"v_lshl_add_u32 v{pr}, v{pr}, 3, %[a]", "s_waitcnt lgkmcnt(0)"]
+        lines2 = pre + [f"ds_read_b64 v[{plane_reg(p)}:{plane_reg(p) + 1}], v{pr} offset:{128 * p}" for p in reversed(range(nplanes))]
+        out.append(f'    asm volatile("{J(lines2)}" :: [a] "v"(lds_addr) : {clob_pre}, "memory");')
+    else:
+        out.append("    const unsigned lane_addr = lds_addr + ((threadIdx.x & 15u) << 3);")
+        out.append(f'    asm volatile("{J(lines)}" :: [a] "v"(lane_addr) : {clob_pre}, "memory");')
     out.append("  }")
-    body = "\\n\\t".join(rank1_lines(range(nt)))
     out.append("  // T[i] += lds[i]*g; consumes the planes rank1_prefetch requested.")
-    out.append("  __device__ static __forceinline__ void rank1_body(unsigned lds_addr, double g) {")
-    out.append(f'    asm volatile("{body}"')
-    out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
+    out.append("  __device__ static __forceinline__ void rank1_body(Regs& t, unsigned, double g) {")
+    out.append(stmt(J(rank1_lines(range(nt))), ins=IN_G, clob=clob_tmp + ', "memory"'))
     out.append("  }")
-    body_pub = "\\n\\t".join(rank1_lines(range(nt), pub=True))
     out.append("  // rank1_body + look-ahead store of the next pivot column's entry")
-    out.append("  __device__ static __forceinline__ void rank1_body_pub(unsigned lds_addr, double g, unsigned pub_addr, double pub) {")
-    out.append(f'    asm volatile("{body_pub}"')
-    out.append(f'                 :: "v"(lds_addr), "v"(g), "v"(pub_addr), "v"(pub) : {clob_t}, {clob_tmp}, "memory");')
+    out.append("  __device__ static __forceinline__ void rank1_body_pub(Regs& t, unsigned, double g, unsigned pub_addr, double pub) {")
+    out.append(stmt(J(rank1_lines(range(nt), pub=True)), ins=IN_PUB, clob=clob_tmp + ', "memory"'))
     out.append("  }")
     # dynamic row read through the VGPR index mode (uniform runtime index, pinned base register)
     out.append("  // T[k] for a wave-uniform runtime k: s_set_gpr_idx_on + v_mov_b32 relative to the pinned base.")
-    out.append("  __device__ static __forceinline__ double get_dyn(int k) {")
+    out.append("  __device__ static __forceinline__ double get_dyn(Regs& t, int k) {")
     out.append("    int lo, hi;")
     out.append("    const int idx = __builtin_amdgcn_readfirstlane(2 * k);")
-    out.append(f'    asm volatile("s_set_gpr_idx_on %2, gpr_idx(SRC0)\\n\\tv_mov_b32 %0, v{t0}\\n\\tv_mov_b32 %1, v{t0 + 1}\\n\\ts_set_gpr_idx_off"')
-    out.append('                 : "=&v"(lo), "=&v"(hi) : "s"(idx) : "m0");')
+    body = f"s_set_gpr_idx_on %[i], gpr_idx(SRC0)\\n\\tv_mov_b32 %[lo], v{t0}\\n\\tv_mov_b32 %[hi], v{t0 + 1}\\n\\ts_set_gpr_idx_off"
+    if operand_map:
+        out.append(stmt(body, outs='[lo] "=&v"(lo), [hi] "=&v"(hi)', ins='[i] "s"(idx)', clob='"m0"'))
+    else:
+        out.append(f'    asm volatile("{body}" : [lo] "=&v"(lo), [hi] "=&v"(hi) : [i] "s"(idx) : "m0");')
     out.append("    return __hiloint2double(hi, lo);")
     out.append("  }")
     # leading rows of a column from LDS (per-lane address): T[i] = lds[i], i < n
     for n in sorted(set([r for r in NRS if r < nt])):
-        lines = [f"ds_read_b128 v[{t0 + 4 * k}:{t0 + 4 * k + 3}], %0 offset:{16 * k}" for k in range(n // 2)]
+        lines = [f"ds_read_b128 v[{t0 + 4 * k}:{t0 + 4 * k + 3}], %[a] offset:{16 * k}" for k in range(n // 2)]
         lines.append("s_waitcnt lgkmcnt(0)")
-        body = "\\n\\t".join(lines)
         out.append(f"  // T[i] = lds[i], i < {n}")
-        out.append(f"  __device__ static __forceinline__ void load_lo_{n}(unsigned lds_addr) {{")
-        out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_t}, "memory");')
+        out.append(f"  __device__ static __forceinline__ void load_lo_{n}(Regs& t, unsigned lds_addr) {{")
+        out.append(stmt(J(lines), ins='[a] "v"(lds_addr)', clob='"memory"'))
         out.append("  }")
     # whole-column load from LDS (per-lane address)
-    lines = [f"ds_read_b128 v[{t0 + 4 * k}:{t0 + 4 * k + 3}], %0 offset:{16 * k}" for k in range(nt // 2)]
+    lines = [f"ds_read_b128 v[{t0 + 4 * k}:{t0 + 4 * k + 3}], %[a] offset:{16 * k}" for k in range(nt // 2)]
     lines.append("s_waitcnt lgkmcnt(0)")
-    body = "\\n\\t".join(lines)
     out.append("  // T[i] = lds[i] for every row (per-lane address: a half-space row's column A[s][:])")
-    out.append("  __device__ static __forceinline__ void load_all(unsigned lds_addr) {")
-    out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_t}, "memory");')
+    out.append("  __device__ static __forceinline__ void load_all(Regs& t, unsigned lds_addr) {")
+    out.append(stmt(J(lines), ins='[a] "v"(lds_addr)', clob='"memory"'))
     out.append("  }")
     # runtime row write (VGPR index mode on the destination)
     out.append("  // T[k] = x for a wave-uniform runtime k (lanes masked off by exec keep their value).")
-    out.append("  __device__ static __forceinline__ void set_dyn(int k, double x) {")
+    out.append("  __device__ static __forceinline__ void set_dyn(Regs& t, int k, double x) {")
     out.append("    const int lo = __double2loint(x), hi = __double2hiint(x);")
     out.append("    const int idx = __builtin_amdgcn_readfirstlane(2 * k);")
-    out.append(f'    asm volatile("s_set_gpr_idx_on %2, gpr_idx(DST)\\n\\tv_mov_b32 v{t0}, %0\\n\\tv_mov_b32 v{t0 + 1}, %1\\n\\ts_set_gpr_idx_off"')
-    out.append(f'                 :: "v"(lo), "v"(hi), "s"(idx) : "m0", {clob_t});')
+    out.append(stmt(f"s_set_gpr_idx_on %[i], gpr_idx(DST)\\n\\tv_mov_b32 v{t0}, %[lo]\\n\\tv_mov_b32 v{t0 + 1}, %[hi]\\n\\ts_set_gpr_idx_off",
+                    ins='[lo] "v"(lo), [hi] "v"(hi), [i] "s"(idx)', clob='"m0"'))
     out.append("  }")
     # partial-row primitives for the low-rank start (rows [0, NR) = the dof rows)
     for nr in [r for r in NRS if r <= nt]:
-        body = "\\n\\t".join(rank1_lines(range(nr)))
         out.append(f"  // rank1_body restricted to rows [0, {nr})")
-        out.append(f"  __device__ static __forceinline__ void rank1_body_{nr}(unsigned lds_addr, double g) {{")
-        out.append(f'    asm volatile("{body}"')
-        out.append(f'                 :: "v"(lds_addr), "v"(g) : {clob_t}, {clob_tmp}, "memory");')
+        out.append(f"  __device__ static __forceinline__ void rank1_body_{nr}(Regs& t, unsigned, double g) {{")
+        out.append(stmt(J(rank1_lines(range(nr))), ins=IN_G, clob=clob_tmp + ', "memory"'))
         out.append("  }")
         if nr < nt:
-            body = "\\n\\t".join(rank1_lines(range(nr), pub=True))
             out.append(f"  // rank1_body_{nr} + look-ahead store")
-            out.append(f"  __device__ static __forceinline__ void rank1_body_{nr}_pub(unsigned lds_addr, double g, unsigned pub_addr, double pub) {{")
-            out.append(f'    asm volatile("{body}"')
-            out.append(f'                 :: "v"(lds_addr), "v"(g), "v"(pub_addr), "v"(pub) : {clob_t}, {clob_tmp}, "memory");')
+            out.append(f"  __device__ static __forceinline__ void rank1_body_{nr}_pub(Regs& t, unsigned, double g, unsigned pub_addr, double pub) {{")
+            out.append(stmt(J(rank1_lines(range(nr), pub=True)), ins=IN_PUB, clob=clob_tmp + ', "memory"'))
             out.append("  }")
         if nr < nt:
             # phase 0 of the low-rank start: the pivot column of a task residual is zero on the dof rows outside
@@ -158,56 +231,85 @@ def gen(nt: int) -> str:
             for pfx in SPLIT_PREFIXES:
                 if pfx >= nr:
                     continue
-                body = "\\n\\t".join(rank1_lines(list(range(pfx)) + list(range(nr, nt)), pub=True))
                 out.append(f"  // rank1_body restricted to rows [0, {pfx}) and [{nr}, {nt}), + look-ahead store")
-                out.append(f"  __device__ static __forceinline__ void rank1_body_{pfx}_hi_{nr}(unsigned lds_addr, double g, unsigned pub_addr, double pub) {{")
-                out.append(f'    asm volatile("{body}"')
-                out.append(f'                 :: "v"(lds_addr), "v"(g), "v"(pub_addr), "v"(pub) : {clob_t}, {clob_tmp}, "memory");')
+                out.append(f"  __device__ static __forceinline__ void rank1_body_{pfx}_hi_{nr}(Regs& t, unsigned, double g, unsigned pub_addr, double pub) {{")
+                out.append(stmt(J(rank1_lines(list(range(pfx)) + list(range(nr, nt)), pub=True)), ins=IN_PUB, clob=clob_tmp + ', "memory"'))
                 out.append("  }")
         if nr < nt:
-            lines = [f"ds_read_b128 v[{t0 + 2 * nr + 4 * k}:{t0 + 2 * nr + 4 * k + 3}], %0 offset:{16 * k}" for k in range((nt - nr) // 2)]
+            lines = [f"ds_read_b128 v[{t0 + 2 * nr + 4 * k}:{t0 + 2 * nr + 4 * k + 3}], %[a] offset:{16 * k}" for k in range((nt - nr) // 2)]
             lines.append("s_waitcnt lgkmcnt(0)")
-            body = "\\n\\t".join(lines)
             out.append(f"  // T[{nr} + i] = lds[i], i < {nt - nr}  (the residual rows of the low-rank start)")
-            out.append(f"  __device__ static __forceinline__ void load_hi_{nr}(unsigned lds_addr) {{")
-            out.append(f'    asm volatile("{body}" :: "v"(lds_addr) : {clob_t}, "memory");')
+            out.append(f"  __device__ static __forceinline__ void load_hi_{nr}(Regs& t, unsigned lds_addr) {{")
+            out.append(stmt(J(lines), ins='[a] "v"(lds_addr)', clob='"memory"'))
             out.append("  }")
         if nr < nt:
             sp = nt - nr
-            lines = [f"ds_read_b64 {treg(nr + r)}, %2 offset:{8 * nr * r}" for r in range(sp)]
+            lines = [f"ds_read_b64 {treg(nr + r)}, %[a] offset:{8 * nr * r}" for r in range(sp)]
             lines.append("s_waitcnt lgkmcnt(0)")
             for r in range(sp):
-                lines.append(f"v_fma_f64 %{r % 2}, {treg(nr + r)}, {treg(nr + r)}, %{r % 2}")
-            body = "\\n\\t".join(lines)
+                lines.append(f"v_fma_f64 %[s{r % 2}], {treg(nr + r)}, {treg(nr + r)}, %[s{r % 2}]")
             out.append(f"  // T[{nr} + r] = lds[r·{nr}], r < {sp} (column `lane` of the row-major Jh array, stride {nr}); returns Σ_r T[{nr}+r]²")
-            out.append(f"  __device__ static __forceinline__ double load_hi_strided_{nr}(unsigned lds_addr) {{")
+            out.append(f"  __device__ static __forceinline__ double load_hi_strided_{nr}(Regs& t, unsigned lds_addr) {{")
             out.append("    double a0 = 0.0, a1 = 0.0;")
-            out.append(f'    asm volatile("{body}" : "+v"(a0), "+v"(a1) : "v"(lds_addr) : {clob_t}, "memory");')
+            out.append(stmt(J(lines), outs='[s0] "+v"(a0), [s1] "+v"(a1)', ins='[a] "v"(lds_addr)', clob='"memory"'))
             out.append("    return a0 + a1;")
             out.append("  }")
     # get / set with compile-time index
-    out.append("  template <int I> __device__ static __forceinline__ double get() {")
+    out.append("  template <int I> __device__ static __forceinline__ double get(Regs& t) {")
     out.append("    int lo, hi;")
     for i in range(nt):
         kw = "if" if i == 0 else "else if"
-        out.append(f'    {kw} constexpr (I == {i}) asm volatile("v_mov_b32 %0, v{t0 + 2 * i}\\n\\tv_mov_b32 %1, v{t0 + 2 * i + 1}" : "=v"(lo), "=v"(hi));')
+        body = f"v_mov_b32 %[lo], v{t0 + 2 * i}\\n\\tv_mov_b32 %[hi], v{t0 + 2 * i + 1}"
+        if operand_map:
+            out.append(f"    {kw} constexpr (I == {i}) {{ " + stmt(body, outs='[lo] "=v"(lo), [hi] "=v"(hi)', indent="") + " }")
+        else:
+            out.append(f'    {kw} constexpr (I == {i}) asm volatile("{body}" : [lo] "=v"(lo), [hi] "=v"(hi));')
     out.append("    else { lo = 0; hi = 0; }")
     out.append("    return __hiloint2double(hi, lo);")
     out.append("  }")
-    out.append("  template <int I> __device__ static __forceinline__ void set(double x) {")
+    out.append("  template <int I> __device__ static __forceinline__ void set(Regs& t, double x) {")
     out.append("    const int lo = __double2loint(x), hi = __double2hiint(x);")
     for i in range(nt):
         kw = "if" if i == 0 else "else if"
-        out.append(f'    {kw} constexpr (I == {i}) asm volatile("v_mov_b32 v{t0 + 2 * i}, %0\\n\\tv_mov_b32 v{t0 + 2 * i + 1}, %1" :: "v"(lo), "v"(hi) : "v{t0 + 2 * i}", "v{t0 + 2 * i + 1}");')
+        body = f"v_mov_b32 v{t0 + 2 * i}, %[lo]\\n\\tv_mov_b32 v{t0 + 2 * i + 1}, %[hi]"
+        if operand_map:
+            out.append(f"    {kw} constexpr (I == {i}) {{ " + stmt(body, ins='[lo] "v"(lo), [hi] "v"(hi)', indent="") + " }")
+        else:
+            out.append(f'    {kw} constexpr (I == {i}) asm volatile("{body}" :: [lo] "v"(lo), [hi] "v"(hi) : "v{t0 + 2 * i}", "v{t0 + 2 * i + 1}");')
     out.append("  }")
     out.append("};")
     return "\n".join(out)
 
 
+KMU = 18   # rows of the low-rank start's elimination (ik_kernel.h kMu): task residuals of one problem
+
+
+def gen_wood_elim() -> str:
+    """Low-rank start (ik_kernel.h wood_start): step R of the LDLᵀ elimination of [S | Jh | w] with one COLUMN per lane in
+    compiler-allocated registers z[0..KMU): z[i] += S[i][R]·g for the rows below R, where the wave-uniform multipliers
+    S[i][R] sit in two 16-lane planes (lane l holds entry 16p + l % 16) and are broadcast by the DPP operand network."""
+    out = [f"template <int R> __device__ __forceinline__ void wood_elim_step(double (&z)[{KMU}], double p0, double p1, double g);"]
+    for r in range(KMU):
+        rows = list(range(r + 1, KMU))
+        if not rows:
+            out.append(f"template <> __device__ __forceinline__ void wood_elim_step<{r}>(double (&)[{KMU}], double, double, double) {{}}")
+            continue
+        ops = ", ".join(f'[z{i}] "+v"(z[{i}])' for i in rows)
+        body = "\\n\\t".join(["s_nop 4"] + [f"v_fmac_f64_dpp %[z{i}], %[p{i // 16}], %[g] row_newbcast:{i % 16} row_mask:0xf bank_mask:0xf" for i in rows])
+        out.append(f"template <> __device__ __forceinline__ void wood_elim_step<{r}>(double (&z)[{KMU}], double p0, double p1, double g) {{")
+        out.append(f'  asm volatile("{body}" : {ops} : [p0] "v"(p0), [p1] "v"(p1), [g] "v"(g));')
+        out.append("}")
+    return "\n".join(out)
+
+
 def main():
     parts = ["// GENERATED by gen_tab_asm.py — do not edit.  Pinned-VGPR tableau primitives (see the generator's docstring).",
-             "#pragma once", "#include <hip/hip_runtime.h>", "namespace mkh {", "template <int NT> struct Tab;"]
+             "#pragma once", "#include <hip/hip_runtime.h>", "namespace mkh {", "template <int NT> struct Tab;", "template <int NT> struct TabW3;",
+             "template <int NT> struct TabW3R;"]
     parts += [gen(nt) for nt in NTS]
+    parts += [gen(nt, 168, "TabW3", True, True) for nt in W3_NTS]
+    parts += [gen(nt, 168, "TabW3R") for nt in W3_NTS]     # reserved map at 168 registers (experiments)
+    parts.append(gen_wood_elim())
     parts.append("}  // namespace mkh")
     with open(os.path.join(HERE, "tab_asm.inc"), "w") as fh:
         fh.write("\n".join(parts) + "\n")

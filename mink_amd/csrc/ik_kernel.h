@@ -30,6 +30,16 @@
 #include "tab_asm.inc"
 #include <utility>
 
+// Register map of the tableau: Tab<NT> (2 resident waves per SIMD for NT > 24) or, in the variant TUs that define
+// MKH_W3, TabW3<NT> — the same primitives pinned below 168 VGPRs, i.e. 3 resident waves per SIMD.
+#if defined(MKH_W3) && defined(MKH_W3_RESERVED)
+#define MKH_TAB TabW3R
+#elif defined(MKH_W3)
+#define MKH_TAB TabW3
+#else
+#define MKH_TAB Tab
+#endif
+
 namespace mkh {
 
 constexpr int kNumXcd = 8;   // MI355X: 8 XCDs × 32 CUs, one L2 each
@@ -45,30 +55,48 @@ __host__ __device__ inline int a_stride_for(int nv) {
 __host__ __device__ inline int j_stride_direct(int nv, int nt) { const int a = a_stride_for(nv); return a < nt ? a : nt; }
 
 constexpr int kPivBuf = kWave + 8;   // doubles per pivot broadcast buffer
-constexpr int kBlk = 6;              // low-rank start, phase 0: task-residual indices enter the basis in blocks of kBlk
-constexpr int kBlkLds = 2 * kBlk * kWave + 8;   // doubles of the block buffer: [kBlk][64] block rows + [kBlk][64] multipliers (aliases the dead Jh rows)
+constexpr int kMu = 18;              // low-rank start: task-residual rows of one problem (wood_elim_step in tab_asm.inc)
+constexpr int kWoodRow = 32;         // low-rank start: doubles of the published-row buffer (in the pivot buffers, followed by 1/d_r)
 struct LdsLayout {
   int q, X, jnt, tgt, task, J, dof, com, col, A, piv, S, q2, tgt2, total;  // offsets in doubles
 };
 __host__ __device__ inline int lds_even(int x) { return (x + 1) & ~1; }
 __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int njnt, int n_frame,
                                                 int n_posture, int n_com, int max_rows, int j_rows, int j_stride,
-                                                int s_doubles = 0, bool prefetch = false, int j_min = 0) {
+                                                int s_doubles = 0, bool prefetch = false, int j_min = 0,
+                                                bool compact = false, bool wood = false) {
   LdsLayout L;
   int o = 0;
+  const int x_sz = 7 * lds_even(nbody), jnt_sz = lds_even(njnt * 6);
+  const int j_sz = lds_even(j_rows * j_stride > j_min ? j_rows * j_stride : j_min);   // (j_min: block buffer of the low-rank start's phase 0)
   L.q = o;    o += lds_even(nq);
-  L.X = o;    o += 7 * lds_even(nbody);              // body poses, component-major: X[c][body] (c = x y z qw qx qy qz)
-  L.jnt = o;  o += lds_even(njnt * 6);
-  L.tgt = o;  o += lds_even(n_frame * 7 + n_com * 3);
-  L.task = o; o += n_frame * 64;
+  // compact (3-waves-per-SIMD variants, no collision rows): ranges that are not alive at the same time share storage.
+  //   direct start:   {body poses, joint axes}              | {staged Jacobian rows of one task, pivot buffers}
+  //   low-rank start: {body poses, joint axes, task blocks} | {all Jacobian rows} — the pair lanes hold their entries in
+  //                   registers until every lane has read its task block (wood_start); the pivot buffers stay apart
+  //                   (they carry the published rows and 1/d_r of the elimination)
+  const int task_sz = n_frame * 64;
+  if (compact && wood) { L.tgt = o; o += lds_even(n_frame * 7 + n_com * 3); }
+  const int u0 = o;
+  L.X = o;    o += x_sz;                             // body poses, component-major: X[c][body] (c = x y z qw qx qy qz)
+  L.jnt = o;  o += jnt_sz;
+  if (compact && wood) {
+    L.task = o; o += task_sz;
+    if (o - u0 < j_sz) o = u0 + j_sz;
+  } else {
+    if (compact) { const int need = j_sz + 2 * kPivBuf; o = u0 + (x_sz + jnt_sz > need ? x_sz + jnt_sz : need); }
+    L.tgt = o;  o += lds_even(n_frame * 7 + n_com * 3);
+    L.task = o; o += task_sz;
+  }
   // weighted Jacobian rows [r][j_stride]: the 6 rows of ONE task at a time (direct start, stride NT), or
   // every task row + one vector (low-rank start, stride NR)
-  L.J = o;    o += lds_even(j_rows * j_stride > j_min ? j_rows * j_stride : j_min);   // (j_min: block buffer of the low-rank start's phase 0)
+  L.J = compact ? u0 : o;    o += compact ? 0 : j_sz;
   L.dof = o;  o += lds_even(nv * 10);
   L.com = o;  o += (n_com > 0 ? nbody * 4 : 0);
   L.col = o;  o += max_rows * 16;
   L.A = o;    o += max_rows * a_stride_for(nv);       // half-space rows A[s][0..stride)
-  L.piv = o;  o += 2 * kPivBuf;    // two pivot column broadcast buffers (64 entries + 8 scalar slots of the pivot lane): look-ahead publishing
+  const bool piv_apart = !compact || wood;
+  L.piv = piv_apart ? o : u0 + j_sz;  o += piv_apart ? 2 * kPivBuf : 0;    // two pivot column broadcast buffers (64 entries + 8 scalar slots of the pivot lane): look-ahead publishing
   L.S = o;    o += lds_even(s_doubles);   // low-rank start: columns of −Jh·Jhᵀ + right-hand sides
   // second buffers of the per-problem inputs: the next problem's q / targets are fetched straight into LDS
   // (global_load_lds) while the current problem is being solved
@@ -127,13 +155,13 @@ __device__ __forceinline__ double xor_sign(double v, int mask) {
 struct PivotScalars { double d, sg, x, rn, lo, hi; };
 
 template <int NT, bool FULL = false>
-__device__ __forceinline__ double publish_column(const QpLane& s, int col, int lane, double* sPiv,
+__device__ __forceinline__ double publish_column(typename MKH_TAB<NT>::Regs& ts, const QpLane& s, int col, int lane, double* sPiv,
                                                  PivotScalars& ps, int nact = kWave, double rown = 1.0) {
   // Column `col` equals row `col` (R is symmetric): lane i holds R[col][i] in tableau register
   // `col`.  One indexed register read (VGPR index mode on the pinned base) + ONE ds_write_b64 for
   // the whole wave.  Having lane `col` dump its 48 registers itself costs 48 single-lane LDS
   // writes = 750-1850 cycles (measured, tools/ubench) — half of the whole pivot.
-  const double rowv = Tab<NT>::get_dyn(col);
+  const double rowv = MKH_TAB<NT>::get_dyn(ts, col);
   // lanes ≥ nact hold dropped indices (task residuals of the low-rank start): they publish 0, so
   // their columns stop changing and the rows they own leave every other column alone
   const double own = (lane == col || lane >= nact) ? 0.0 : rowv;
@@ -182,54 +210,54 @@ __device__ __forceinline__ void read_pivot_scalars(const double* buf, PivotScala
 
 // Symmetric sweep (reverse = un-sweep) on index k (wave-uniform); sPiv holds column k.
 template <int NT, int ROWS>
-__device__ __forceinline__ void rank1_rows(unsigned addr, double g) {
-  if constexpr (ROWS >= NT) Tab<NT>::rank1_body(addr, g);
-  else if constexpr (ROWS == 16) Tab<NT>::rank1_body_16(addr, g);
-  else if constexpr (ROWS == 24) Tab<NT>::rank1_body_24(addr, g);
-  else if constexpr (ROWS == 32) Tab<NT>::rank1_body_32(addr, g);
-  else if constexpr (ROWS == 44) Tab<NT>::rank1_body_44(addr, g);
-  else if constexpr (ROWS == 48) Tab<NT>::rank1_body_48(addr, g);
+__device__ __forceinline__ void rank1_rows(typename MKH_TAB<NT>::Regs& ts, unsigned addr, double g) {
+  if constexpr (ROWS >= NT) MKH_TAB<NT>::rank1_body(ts, addr, g);
+  else if constexpr (ROWS == 16) MKH_TAB<NT>::rank1_body_16(ts, addr, g);
+  else if constexpr (ROWS == 24) MKH_TAB<NT>::rank1_body_24(ts, addr, g);
+  else if constexpr (ROWS == 32) MKH_TAB<NT>::rank1_body_32(ts, addr, g);
+  else if constexpr (ROWS == 44) MKH_TAB<NT>::rank1_body_44(ts, addr, g);
+  else if constexpr (ROWS == 48) MKH_TAB<NT>::rank1_body_48(ts, addr, g);
 }
 // T[i] += lds[i]·g for i < n (n from a_stride_for ≥ nv): the H accumulation only touches the dof rows, the rows
 // of the half-space block stay zero — 24 instead of 64 FMAs per staged Jacobian row for the Shadow hand
 template <int NT>
-__device__ __forceinline__ void rank1_leading_rows(unsigned addr, double g, int n) {
-  Tab<NT>::rank1_prefetch(addr);
-  if (n >= NT) { Tab<NT>::rank1_body(addr, g); return; }
-  if constexpr (NT > 16) { if (n == 16) Tab<NT>::rank1_body_16(addr, g); }
-  if constexpr (NT > 24) { if (n == 24) Tab<NT>::rank1_body_24(addr, g); }
-  if constexpr (NT > 32) { if (n == 32) Tab<NT>::rank1_body_32(addr, g); }
-  if constexpr (NT > 44) { if (n == 44) Tab<NT>::rank1_body_44(addr, g); }
-  if constexpr (NT > 48) { if (n == 48) Tab<NT>::rank1_body_48(addr, g); }
+__device__ __forceinline__ void rank1_leading_rows(typename MKH_TAB<NT>::Regs& ts, unsigned addr, double g, int n) {
+  MKH_TAB<NT>::rank1_prefetch(ts, addr);
+  if (n >= NT) { MKH_TAB<NT>::rank1_body(ts, addr, g); return; }
+  if constexpr (NT > 16) { if (n == 16) MKH_TAB<NT>::rank1_body_16(ts, addr, g); }
+  if constexpr (NT > 24) { if (n == 24) MKH_TAB<NT>::rank1_body_24(ts, addr, g); }
+  if constexpr (NT > 32) { if (n == 32) MKH_TAB<NT>::rank1_body_32(ts, addr, g); }
+  if constexpr (NT > 44) { if (n == 44) MKH_TAB<NT>::rank1_body_44(ts, addr, g); }
+  if constexpr (NT > 48) { if (n == 48) MKH_TAB<NT>::rank1_body_48(ts, addr, g); }
 }
 
 // T[i] = lds[i] for i < n (n from a_stride_for: wave-uniform, one of the generated sizes)
 template <int NT>
-__device__ __forceinline__ void load_leading_rows(unsigned addr, int n) {
-  if (n >= NT) { Tab<NT>::load_all(addr); return; }
-  if constexpr (NT > 16) { if (n == 16) Tab<NT>::load_lo_16(addr); }
-  if constexpr (NT > 24) { if (n == 24) Tab<NT>::load_lo_24(addr); }
-  if constexpr (NT > 32) { if (n == 32) Tab<NT>::load_lo_32(addr); }
-  if constexpr (NT > 44) { if (n == 44) Tab<NT>::load_lo_44(addr); }
-  if constexpr (NT > 48) { if (n == 48) Tab<NT>::load_lo_48(addr); }
+__device__ __forceinline__ void load_leading_rows(typename MKH_TAB<NT>::Regs& ts, unsigned addr, int n) {
+  if (n >= NT) { MKH_TAB<NT>::load_all(ts, addr); return; }
+  if constexpr (NT > 16) { if (n == 16) MKH_TAB<NT>::load_lo_16(ts, addr); }
+  if constexpr (NT > 24) { if (n == 24) MKH_TAB<NT>::load_lo_24(ts, addr); }
+  if constexpr (NT > 32) { if (n == 32) MKH_TAB<NT>::load_lo_32(ts, addr); }
+  if constexpr (NT > 44) { if (n == 44) MKH_TAB<NT>::load_lo_44(ts, addr); }
+  if constexpr (NT > 48) { if (n == 48) MKH_TAB<NT>::load_lo_48(ts, addr); }
 }
 
 template <int NT, int ROWS>
-__device__ __forceinline__ void load_hi_rows(unsigned addr) {
-  if constexpr (ROWS == 16 && NT > 16) Tab<NT>::load_hi_16(addr);
-  else if constexpr (ROWS == 24 && NT > 24) Tab<NT>::load_hi_24(addr);
-  else if constexpr (ROWS == 32 && NT > 32) Tab<NT>::load_hi_32(addr);
-  else if constexpr (ROWS == 44 && NT > 44) Tab<NT>::load_hi_44(addr);
-  else if constexpr (ROWS == 48 && NT > 48) Tab<NT>::load_hi_48(addr);
+__device__ __forceinline__ void load_hi_rows(typename MKH_TAB<NT>::Regs& ts, unsigned addr) {
+  if constexpr (ROWS == 16 && NT > 16) MKH_TAB<NT>::load_hi_16(ts, addr);
+  else if constexpr (ROWS == 24 && NT > 24) MKH_TAB<NT>::load_hi_24(ts, addr);
+  else if constexpr (ROWS == 32 && NT > 32) MKH_TAB<NT>::load_hi_32(ts, addr);
+  else if constexpr (ROWS == 44 && NT > 44) MKH_TAB<NT>::load_hi_44(ts, addr);
+  else if constexpr (ROWS == 48 && NT > 48) MKH_TAB<NT>::load_hi_48(ts, addr);
 }
 
 template <int NT, int ROWS>
-__device__ __forceinline__ double load_hi_strided_rows(unsigned addr) {
-  if constexpr (ROWS == 16 && NT > 16) return Tab<NT>::load_hi_strided_16(addr);
-  else if constexpr (ROWS == 24 && NT > 24) return Tab<NT>::load_hi_strided_24(addr);
-  else if constexpr (ROWS == 32 && NT > 32) return Tab<NT>::load_hi_strided_32(addr);
-  else if constexpr (ROWS == 44 && NT > 44) return Tab<NT>::load_hi_strided_44(addr);
-  else if constexpr (ROWS == 48 && NT > 48) return Tab<NT>::load_hi_strided_48(addr);
+__device__ __forceinline__ double load_hi_strided_rows(typename MKH_TAB<NT>::Regs& ts, unsigned addr) {
+  if constexpr (ROWS == 16 && NT > 16) return MKH_TAB<NT>::load_hi_strided_16(ts, addr);
+  else if constexpr (ROWS == 24 && NT > 24) return MKH_TAB<NT>::load_hi_strided_24(ts, addr);
+  else if constexpr (ROWS == 32 && NT > 32) return MKH_TAB<NT>::load_hi_strided_32(ts, addr);
+  else if constexpr (ROWS == 44 && NT > 44) return MKH_TAB<NT>::load_hi_strided_44(ts, addr);
+  else if constexpr (ROWS == 48 && NT > 48) return MKH_TAB<NT>::load_hi_strided_48(ts, addr);
   else return 0.0;
 }
 
@@ -237,22 +265,22 @@ __device__ __forceinline__ double load_hi_strided_rows(unsigned addr) {
 // pivot column, wave-uniform) and the residual rows [NR, NT).  The column of a task residual is zero outside the
 // kinematic chains swept so far, and the dofs of a limb are contiguous in MuJoCo's depth-first order.
 template <int NT, int NR>
-__device__ __forceinline__ void rank1_split_rows(unsigned addr, double g, int hb, unsigned pub_addr, double pub) {
-#define MKH_SPLIT(P, R) if constexpr (NR == R && NT > R && (P) < R) { if (hb <= (P)) { Tab<NT>::rank1_body_##P##_hi_##R(addr, g, pub_addr, pub); return; } }
+__device__ __forceinline__ void rank1_split_rows(typename MKH_TAB<NT>::Regs& ts, unsigned addr, double g, int hb, unsigned pub_addr, double pub) {
+#define MKH_SPLIT(P, R) if constexpr (NR == R && NT > R && (P) < R) { if (hb <= (P)) { MKH_TAB<NT>::rank1_body_##P##_hi_##R(ts, addr, g, pub_addr, pub); return; } }
   MKH_SPLIT(16, 24) MKH_SPLIT(16, 32) MKH_SPLIT(24, 32)
   MKH_SPLIT(16, 44) MKH_SPLIT(24, 44) MKH_SPLIT(32, 44)
   MKH_SPLIT(16, 48) MKH_SPLIT(24, 48) MKH_SPLIT(32, 48)
 #undef MKH_SPLIT
-  Tab<NT>::rank1_body_pub(addr, g, pub_addr, pub);
+  MKH_TAB<NT>::rank1_body_pub(ts, addr, g, pub_addr, pub);
 }
 
 template <int NT, int ROWS = NT>
-__device__ __forceinline__ void pivot(QpLane& s, int k, bool reverse, int lane, const double* sPiv,
+__device__ __forceinline__ void pivot(typename MKH_TAB<NT>::Regs& ts, QpLane& s, int k, bool reverse, int lane, const double* sPiv,
                                       double own, const PivotScalars& ps, double inv) {
   const double sk = ps.sg;
   const double ck = s.sg * sk * own;             // true T[lane][k]
   const double g = (sk * sk) * own * inv;        // R-units multiplier of this lane's column
-  rank1_rows<NT, ROWS>(lds_addr(sPiv), -g);      // R[i][lane] −= R[i][k]·g   (row k: published 0)
+  rank1_rows<NT, ROWS>(ts, lds_addr(sPiv), -g);      // R[i][lane] −= R[i][k]·g   (row k: published 0)
   if (lane == k) {
     s.D = -inv;                                  // T[k][k] = −1/d
     s.sg = (reverse ? -sk : sk) * inv;           // row/column k scaled by ±1/d
@@ -298,11 +326,609 @@ enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL =
 #ifndef MKH_KERNEL_NAME   // low-rank variants (MKH_NR defined) are named by their translation unit
 #define MKH_KERNEL_NAME MKH_CAT(ik_solve_kernel_, MKH_NT, MKH_FEAT)
 #endif
+
+// ISA markers for static instruction counting (tools/isa_census.py): comments only, and only with -DMKH_MARKERS
+#ifdef MKH_MARKERS
+#define MKH_MARK(name) asm volatile("; MKH_MARK " name)
+#else
+#define MKH_MARK(name) do {} while (0)
+#endif
+
+// ---------------------------------------------------------------- kinematics and task lanes (per problem and step)
+// Forward kinematics, joint axes / dof lanes, subtree CoM and the frame-task lanes: everything up to the first use of the
+// tableau, handed over through LDS plus the few per-lane values of PreOut.  In the 3-waves-per-SIMD variants (MKH_W3) this is
+// a real function call: the kernel itself is capped below the pinned tableau range (72 VGPRs for 44 rows) all the way
+// through, which these phases do not fit in (83–236 spilled VGPRs when inlined); as a callee they get the whole 168-register
+// file — the tableau is dead while they run — and the kernel keeps only what is live across the call.
+struct PreOut { int status, d_kind, d_k, d_body, d_qadr, conv; double mu_lane; V3 com_root; };
+#ifdef MKH_W3
+#define MKH_PRE_ATTR __attribute__((noinline))
+#define MKH_PRE_TC_PARAMS
+#define MKH_PRE_TC_ARGS
+#define MKH_PRE_TICK() do { asm volatile("" : "+v"(lane)); } while (0)
+#else
+#define MKH_PRE_ATTR __forceinline__
+#define MKH_PRE_TC_PARAMS , long long (&tc)[8], int& tci
+#define MKH_PRE_TC_ARGS , tc, tci
+#define MKH_PRE_TICK() do { if (MKH_TAP(t_cycles)) tc[tci] = __builtin_readcyclecounter(); ++tci; asm volatile("" : "+v"(lane)); } while (0)
+#endif
+// The descriptor fields pre_phases reads, loaded through the constant address space (scalar loads) with the table pointers
+// typed as global memory: inside a real function the compiler has to treat pointers that arrive as arguments or come out
+// of memory as flat, i.e. per-lane flat_load instructions even for wave-uniform fields (83 of them in the first build).
+#define MKH_GLOBAL __attribute__((address_space(1)))
+#define MKH_CONSTANT __attribute__((address_space(4)))
+struct PreView {
+  const MKH_GLOBAL double *body_f, *jnt_f, *dof_f;
+  const MKH_GLOBAL int32_t *body_i, *jnt_i, *dof_i;
+  const MKH_GLOBAL FrameTaskDev* frame;
+  int nbody, nv, nq, njnt, n_frame, n_posture, n_com, max_rows, n_jrows, prefetch, prefetch_w3, prefetch_w3w, n_rows_tap, nrounds, robot_root;
+  __device__ __forceinline__ explicit PreView(const DeviceProblem* Pq) {
+    const MKH_CONSTANT DeviceProblem* c = (const MKH_CONSTANT DeviceProblem*)Pq;
+    body_f = (const MKH_GLOBAL double*)c->body_f; jnt_f = (const MKH_GLOBAL double*)c->jnt_f; dof_f = (const MKH_GLOBAL double*)c->dof_f;
+    body_i = (const MKH_GLOBAL int32_t*)c->body_i; jnt_i = (const MKH_GLOBAL int32_t*)c->jnt_i; dof_i = (const MKH_GLOBAL int32_t*)c->dof_i;
+    frame = (const MKH_GLOBAL FrameTaskDev*)c->frame;
+    nbody = c->nbody; nv = c->nv; nq = c->nq; njnt = c->njnt; n_frame = c->n_frame; n_posture = c->n_posture; n_com = c->n_com;
+    max_rows = c->max_rows; n_jrows = c->n_jrows; prefetch = c->prefetch; prefetch_w3 = c->prefetch_w3; prefetch_w3w = c->prefetch_w3w;
+    n_rows_tap = c->n_rows_tap; nrounds = c->nrounds; robot_root = c->robot_root;
+  }
+};
+template <class PT>
+__device__ __forceinline__ LdsLayout kernel_lds_layout(const PT& P0) {
+  constexpr int NT = MKH_NT, FEAT = MKH_FEAT;
+  constexpr bool kWood = (FEAT & F_WOOD) != 0;
+#ifdef MKH_NR
+  constexpr int NR = MKH_NR;
+#else
+  constexpr int NR = NT;
+#endif
+#ifdef MKH_W3
+  constexpr bool kCompact = true;            // LDS ranges aliased by phase (lds_layout): 12 waves per CU need ≤ 13.3 KB each
+#else
+  constexpr bool kCompact = false;
+#endif
+  return lds_layout(P0.nq, P0.nv, P0.nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows,
+                    kWood ? kMu + 1 : 6, kWood ? NR : j_stride_direct(P0.nv, NT),
+                    (kWood && !wood_s_aliases_dof(P0.nv, P0.n_jrows, kMu)) ? P0.n_jrows * (kMu + 1) : 0,
+                    (kCompact ? (kWood ? P0.prefetch_w3w : P0.prefetch_w3) : P0.prefetch) != 0, 0, kCompact, kWood);
+}
+__device__ MKH_PRE_ATTR PreOut pre_phases(const DeviceProblem* Pq, const TapArgs* tp, int pb, int oz, int off_q, int off_tgt,
+                                          bool until, double pos_thr, double ori_thr MKH_PRE_TC_PARAMS) {
+  constexpr int FEAT = MKH_FEAT;
+  constexpr bool kTaps = (FEAT & F_TAPS) != 0, kRel = (FEAT & F_REL) != 0, kCom = (FEAT & F_COM) != 0;
+  constexpr bool kSteps = (FEAT & F_STEPS) != 0, kWood = (FEAT & F_WOOD) != 0;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+#ifdef MKH_W3
+  // arguments of a real call arrive in VGPRs: make the wave-uniform ones scalar again
+  pb = uni(pb); oz = uni(oz); off_q = uni(off_q); off_tgt = uni(off_tgt);
+  until = uni((int)until) != 0; pos_thr = uni(pos_thr); ori_thr = uni(ori_thr);
+  Pq = reinterpret_cast<const DeviceProblem*>(uni((unsigned long long)reinterpret_cast<size_t>(Pq)));
+  tp = reinterpret_cast<const TapArgs*>(uni((unsigned long long)reinterpret_cast<size_t>(tp)));
+#endif
+#ifdef MKH_W3
+  const PreView P(Pq);          // (a callee cannot assume that pointers loaded from the descriptor are global memory)
+#else
+  const DeviceProblem& P = *Pq;
+#endif
+  int lane = lane_id();
+  const int ol = lane + oz;
+  const int nbody = P.nbody, nv = P.nv;
+  const LdsLayout L = kernel_lds_layout(P);
+  double* const sq = smem + off_q;
+  double* const sX = smem + L.X;
+  const int XS = lds_even(nbody);
+  double* const sJnt = smem + L.jnt;
+  double* const sTgt = smem + off_tgt;
+  double* const sTask = smem + L.task;
+  double* const sDof = smem + L.dof;
+  double* const sCom = smem + L.com;
+  const bool is_body = lane < nbody;
+  const bool is_dof = lane < nv;
+  int status = 0;
+    // ------------------------------------------------- FK: local transforms
+    // X = pose of body `lane` relative to its parent, joints applied
+    // (mj_kinematics, SURVEY Appendix A.1).
+    V3 xp{0, 0, 0};
+    Q4 xq{1, 0, 0, 0};
+    int b_jadr = 0, b_jnum = 0, anc_lo = 0, anc_hi = 0;
+    if (is_body) {
+      anc_lo = P.body_i[BI_ANCPACK0 * 64 + ol];
+      anc_hi = P.body_i[BI_ANCPACK1 * 64 + ol];
+      const auto* bf = P.body_f + ol;
+      xp = {bf[(BF_POS + 0) * 64], bf[(BF_POS + 1) * 64], bf[(BF_POS + 2) * 64]};
+      xq = {bf[(BF_QUAT + 0) * 64], bf[(BF_QUAT + 1) * 64], bf[(BF_QUAT + 2) * 64], bf[(BF_QUAT + 3) * 64]};
+      b_jadr = P.body_i[BI_JNTADR * 64 + ol];
+      b_jnum = P.body_i[BI_JNTNUM * 64 + ol];
+      for (int jn = 0; jn < b_jnum; ++jn) {
+        const int j = b_jadr + jn;
+        const int jt = P.jnt_i[j * JI_COUNT + JI_TYPE];
+        const int qa = P.jnt_i[j * JI_COUNT + JI_QADR];
+        const auto* jf = P.jnt_f + j * JF_COUNT;
+        if (jt == JNT_FREE) {
+          xp = {sq[qa], sq[qa + 1], sq[qa + 2]};
+          xq = qnormalize(Q4{sq[qa + 3], sq[qa + 4], sq[qa + 5], sq[qa + 6]});
+        } else if (jt == JNT_SLIDE) {
+          V3 ax{jf[JF_AXIS], jf[JF_AXIS + 1], jf[JF_AXIS + 2]};
+          xp = xp + (sq[qa] - jf[JF_QPOS0]) * qrot(xq, ax);
+        } else {
+          V3 jp{jf[JF_POS], jf[JF_POS + 1], jf[JF_POS + 2]};
+          Q4 qloc;
+          if (jt == JNT_HINGE) {
+            V3 ax{jf[JF_AXIS], jf[JF_AXIS + 1], jf[JF_AXIS + 2]};
+            qloc = axis_angle(ax, sq[qa] - jf[JF_QPOS0]);
+          } else {
+            qloc = qnormalize(Q4{sq[qa], sq[qa + 1], sq[qa + 2], sq[qa + 3]});
+          }
+          V3 anchor = xp + qrot(xq, jp);
+          xq = qmul(xq, qloc);
+          xp = anchor - qrot(xq, jp);
+        }
+      }
+    }
+    // ---------------------------------------- FK: pointer jumping to the root
+    for (int r = 0; r < P.nrounds; ++r) {
+      wave_sync();
+      if (is_body) {
+        double* o = sX + lane;
+        o[0] = xp.x; o[XS] = xp.y; o[2 * XS] = xp.z; o[3 * XS] = xq.w; o[4 * XS] = xq.x; o[5 * XS] = xq.y; o[6 * XS] = xq.z;
+      }
+      wave_sync();
+      if (is_body) {
+        const double* a = sX + (((r < 5) ? (anc_lo >> (6 * r)) : anc_hi) & 63);
+        V3 ap{a[0], a[XS], a[2 * XS]};
+        Q4 aq{a[3 * XS], a[4 * XS], a[5 * XS], a[6 * XS]};
+        xp = ap + qrot(aq, xp);
+        xq = qmul(aq, xq);
+      }
+    }
+    xq = qnormalize(xq);
+    wave_sync();
+    if (is_body) {
+      double* o = sX + lane;
+      o[0] = xp.x; o[XS] = xp.y; o[2 * XS] = xp.z; o[3 * XS] = xq.w; o[4 * XS] = xq.x; o[5 * XS] = xq.y; o[6 * XS] = xq.z;
+      if (MKH_TAP(t_xpos)) {
+        double* t = MKH_TAP(t_xpos) + ((size_t)pb * nbody + lane) * 3;
+        t[0] = xp.x; t[1] = xp.y; t[2] = xp.z;
+      }
+      if (MKH_TAP(t_xquat)) {
+        double* t = MKH_TAP(t_xquat) + ((size_t)pb * nbody + lane) * 4;
+        t[0] = xq.w; t[1] = xq.x; t[2] = xq.y; t[3] = xq.z;
+      }
+    }
+    wave_sync();
+    MKH_MARK("fk_done");
+    MKH_PRE_TICK();   // 1: FK done
+    // --------------------- joint anchors / axes in the world (xanchor, xaxis)
+    if (is_body && b_jnum > 0) {
+      if (b_jnum == 1) {
+        // single joint: rotation about its own axis/anchor leaves both invariant, so the
+        // final body frame gives them directly.
+        const int j = b_jadr;
+        const auto* jf = P.jnt_f + j * JF_COUNT;
+        V3 ax = qrot(xq, V3{jf[JF_AXIS], jf[JF_AXIS + 1], jf[JF_AXIS + 2]});
+        V3 an = xp + qrot(xq, V3{jf[JF_POS], jf[JF_POS + 1], jf[JF_POS + 2]});
+        double* o = sJnt + j * 6;
+        o[0] = ax.x; o[1] = ax.y; o[2] = ax.z; o[3] = an.x; o[4] = an.y; o[5] = an.z;
+      } else {
+        // several joints in one body: replay them from the parent's world pose.
+        const double* a = sX + P.body_i[BI_PARENT * 64 + ol];
+        const auto* bf = P.body_f + ol;
+        V3 fp = V3{a[0], a[XS], a[2 * XS]} + qrot(Q4{a[3 * XS], a[4 * XS], a[5 * XS], a[6 * XS]},
+                                            V3{bf[(BF_POS + 0) * 64], bf[(BF_POS + 1) * 64], bf[(BF_POS + 2) * 64]});
+        Q4 fq = qmul(Q4{a[3 * XS], a[4 * XS], a[5 * XS], a[6 * XS]}, Q4{bf[(BF_QUAT + 0) * 64], bf[(BF_QUAT + 1) * 64],
+                                                    bf[(BF_QUAT + 2) * 64], bf[(BF_QUAT + 3) * 64]});
+        for (int jn = 0; jn < b_jnum; ++jn) {
+          const int j = b_jadr + jn;
+          const int jt = P.jnt_i[j * JI_COUNT + JI_TYPE];
+          const int qa = P.jnt_i[j * JI_COUNT + JI_QADR];
+          const auto* jf = P.jnt_f + j * JF_COUNT;
+          V3 axl{jf[JF_AXIS], jf[JF_AXIS + 1], jf[JF_AXIS + 2]};
+          V3 jp{jf[JF_POS], jf[JF_POS + 1], jf[JF_POS + 2]};
+          V3 ax = qrot(fq, axl);
+          V3 an = fp + qrot(fq, jp);
+          double* o = sJnt + j * 6;
+          o[0] = ax.x; o[1] = ax.y; o[2] = ax.z; o[3] = an.x; o[4] = an.y; o[5] = an.z;
+          if (jt == JNT_SLIDE) {
+            fp = fp + (sq[qa] - jf[JF_QPOS0]) * ax;
+          } else if (jt == JNT_HINGE || jt == JNT_BALL) {
+            Q4 qloc = (jt == JNT_HINGE) ? axis_angle(axl, sq[qa] - jf[JF_QPOS0])
+                                        : qnormalize(Q4{sq[qa], sq[qa + 1], sq[qa + 2], sq[qa + 3]});
+            fq = qmul(fq, qloc);
+            fp = an - qrot(fq, jp);
+          }
+        }
+      }
+    }
+    wave_sync();
+    // --------------------------- dof lane: motion axis of dof `lane` (cdof)
+    // jacp(p) = lin + ang × (p − anchor), jacr = ang  (mj_jac, SURVEY Appendix A.2/A.3)
+    int d_kind = DOF_HINGE, d_k = 0, d_body = 0, d_qadr = -1;
+    {
+    V3 d_ang{0, 0, 0}, d_lin{0, 0, 0}, d_anchor{0, 0, 0};
+    double q_dof = 0.0;  // joint coordinate for hinge/slide dofs
+    if (is_dof) {
+      const auto* di = P.dof_i + ol;
+      const int d_jnt = di[DI_JNT * 64];
+      d_kind = di[DI_KIND * 64];
+      d_k = di[DI_K * 64];
+      d_body = di[DI_BODY * 64];
+      d_qadr = di[DI_QADR * 64];
+      if (d_kind == DOF_HINGE) {
+        const double* o = sJnt + d_jnt * 6;
+        d_ang = {o[0], o[1], o[2]};
+        d_anchor = {o[3], o[4], o[5]};
+        q_dof = sq[d_qadr];
+      } else if (d_kind == DOF_SLIDE) {
+        const double* o = sJnt + d_jnt * 6;
+        d_lin = {o[0], o[1], o[2]};
+        q_dof = sq[d_qadr];
+      } else if (d_kind == DOF_FREE_LIN) {
+        d_lin = {d_k == 0 ? 1.0 : 0.0, d_k == 1 ? 1.0 : 0.0, d_k == 2 ? 1.0 : 0.0};
+      } else {  // ball / free rotational dof: body-frame axis k, about the joint anchor
+        const double* xb = sX + d_body;
+        M3 R = qmat(Q4{xb[3 * XS], xb[4 * XS], xb[5 * XS], xb[6 * XS]});
+        d_ang = (d_k == 0) ? V3{R.m[0], R.m[3], R.m[6]}
+                           : ((d_k == 1) ? V3{R.m[1], R.m[4], R.m[7]} : V3{R.m[2], R.m[5], R.m[8]});
+        if (d_kind == DOF_FREE_ANG) {
+          d_anchor = {xb[0], xb[XS], xb[2 * XS]};
+        } else {
+          const double* o = sJnt + d_jnt * 6;
+          d_anchor = {o[3], o[4], o[5]};
+        }
+      }
+    }
+    // Configuration.check_limits (mink/configuration.py:77-110), tol = 1e-6
+    {
+      bool viol = false;
+      if (is_dof && (d_kind == DOF_HINGE || d_kind == DOF_SLIDE))
+        viol = q_dof < P.dof_f[DF_RANGE_LO * 64 + ol] - 1e-6 || q_dof > P.dof_f[DF_RANGE_HI * 64 + ol] + 1e-6;
+      // a limited ball joint: the reference's loop compares q[jnt_qposadr] — the quaternion's w — with the range
+      // (configuration.py:92-99); the range sits on the joint's first dof lane only
+      if (is_dof && d_kind == DOF_BALL && d_k == 0) {
+        const double qw = sq[d_qadr];
+        viol = qw < P.dof_f[DF_RANGE_LO * 64 + ol] - 1e-6 || qw > P.dof_f[DF_RANGE_HI * 64 + ol] + 1e-6;
+      }
+      if (__ballot(viol)) status |= 1;
+    }
+    // stash the dof's motion axis in LDS; phases below reload it instead of keeping 20 VGPRs live
+    if (is_dof) {
+      double* o = sDof + lane * 10;
+      o[0] = d_ang.x; o[1] = d_ang.y; o[2] = d_ang.z; o[3] = d_lin.x; o[4] = d_lin.y; o[5] = d_lin.z;
+      o[6] = d_anchor.x; o[7] = d_anchor.y; o[8] = d_anchor.z; o[9] = q_dof;
+    }
+    }
+
+    // -------------------------------------- subtree CoM (mj_comPos) for ComTask
+    V3 com_root{0, 0, 0};
+    if (kCom && P.n_com > 0) {
+      V3 b_ipos{0, 0, 0};
+      double b_mass = 0.0, b_stmass = 0.0;
+      int b_last = 0, b_inrobot = 0;
+      if (is_body) {
+        const auto* bf = P.body_f + ol;
+        b_ipos = {bf[(BF_IPOS + 0) * 64], bf[(BF_IPOS + 1) * 64], bf[(BF_IPOS + 2) * 64]};
+        b_mass = bf[BF_MASS * 64];
+        b_stmass = bf[BF_SUBTREEMASS * 64];
+        b_last = P.body_i[BI_SUBTREE_LAST * 64 + ol];
+        b_inrobot = P.body_i[BI_IN_ROBOT * 64 + ol];
+      }
+      V3 xi = xp + qrot(xq, b_ipos);
+      const double m = (is_body && b_inrobot) ? b_mass : 0.0;
+      double sx = m * xi.x, sy = m * xi.y, sz = m * xi.z;
+      // inclusive scan over body ids (a subtree is a contiguous id range in MuJoCo's DFS order)
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        double tx = __shfl_up(sx, o), ty = __shfl_up(sy, o), tz = __shfl_up(sz, o);
+        if (lane >= o) { sx += tx; sy += ty; sz += tz; }
+      }
+      const int hi_l = is_body ? b_last : 0, lo_l = lane - 1;
+      double ex = __shfl(sx, hi_l), ey = __shfl(sy, hi_l), ez = __shfl(sz, hi_l);
+      double bx = __shfl(sx, lo_l < 0 ? 0 : lo_l), by = __shfl(sy, lo_l < 0 ? 0 : lo_l),
+             bz = __shfl(sz, lo_l < 0 ? 0 : lo_l);
+      if (lane == 0) { bx = 0; by = 0; bz = 0; }
+      V3 cs = xi;
+      if (b_stmass >= 1e-15) {
+        const double im = fast_rcp(b_stmass);
+        cs = {(ex - bx) * im, (ey - by) * im, (ez - bz) * im};
+      }
+      if (is_body) {
+        double* o = sCom + lane * 4;
+        o[0] = cs.x; o[1] = cs.y; o[2] = cs.z; o[3] = b_stmass;
+      }
+      wave_sync();
+      const double* cr = sCom + P.robot_root * 4;
+      com_root = {cr[0], cr[1], cr[2]};
+      if (MKH_TAP(t_subtree_com) && lane < 3) MKH_TAP(t_subtree_com)[(size_t)pb * 3 + lane] = cr[lane];
+    }
+
+    MKH_MARK("axes_done");
+    MKH_PRE_TICK();   // 2: joint axes / dof lanes / com done
+    // ------------------------------------------- task lanes: pose, error, jlog
+    double mu_lane = 0.0;  // Levenberg–Marquardt term of the task owned by this lane
+    bool conv_lane = true; // this lane's frame task is within the thresholds (rows with a nonzero cost only)
+    if (lane < P.n_frame) {
+      const auto& ft = P.frame[lane];
+      const double* xb = sX + ft.body;
+      SE3 F;
+      Q4 bq{xb[3 * XS], xb[4 * XS], xb[5 * XS], xb[6 * XS]};
+      F.p = V3{xb[0], xb[XS], xb[2 * XS]} + qrot(bq, V3{ft.lpos[0], ft.lpos[1], ft.lpos[2]});
+      F.q = qmul(bq, Q4{ft.lquat[0], ft.lquat[1], ft.lquat[2], ft.lquat[3]});
+      const double* tg = sTgt + lane * 7;
+      SE3 Tt{Q4{tg[0], tg[1], tg[2], tg[3]}, V3{tg[4], tg[5], tg[6]}};
+      double* o = sTask + lane * 64;
+      V3 ev, ew;
+      double Jm[9], Qm[9];
+      bool ident;
+      if (!(kRel && ft.relative)) {
+        // e = target.minus(frame) = log(T_frame⁻¹ · T_target)          (frame_task.py:119-122)
+        se3_log(se3_mul(se3_inv(F), Tt), ev, ew);
+        // jlog(T_tb) = ljacinv(−log(T_tb)) = ljacinv(e)   since T_tb = T_bt⁻¹   (frame_task.py:144-146)
+        se3_ljacinv(ev, ew, Jm, Qm, ident);
+      } else {
+        // RelativeFrameTask (relative_frame_task.py:106-142): T_fr = T_root⁻¹·T_frame,
+        // e = T_fr.rminus(target) = log(target⁻¹·T_fr),  J = jlog(T_tf)·(ᶠJ − Ad(T_fr⁻¹)·ʳJ)
+        const double* xr = sX + ft.root_body;
+        Q4 rq0{xr[3 * XS], xr[4 * XS], xr[5 * XS], xr[6 * XS]};
+        SE3 Rt;
+        Rt.p = V3{xr[0], xr[XS], xr[2 * XS]} + qrot(rq0, V3{ft.root_lpos[0], ft.root_lpos[1], ft.root_lpos[2]});
+        Rt.q = qmul(rq0, Q4{ft.root_lquat[0], ft.root_lquat[1], ft.root_lquat[2], ft.root_lquat[3]});
+        const SE3 Tfr = se3_mul(se3_inv(Rt), F);
+        se3_log(se3_mul(se3_inv(Tt), Tfr), ev, ew);
+        se3_ljacinv(-1.0 * ev, -1.0 * ew, Jm, Qm, ident);       // jlog(T) = ljacinv(−log T)
+        const SE3 Trf = se3_inv(Tfr);
+        const M3 Rr = qmat(Rt.q), Rrf = qmat(Trf.q);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { o[36 + i] = Rr.m[i]; o[48 + i] = Rrf.m[i]; }
+        o[45] = Rt.p.x; o[46] = Rt.p.y; o[47] = Rt.p.z;
+        o[57] = Trf.p.x; o[58] = Trf.p.y; o[59] = Trf.p.z;
+        if (MKH_TAP(t_frame_pose)) {                            // tap: pose of the frame in the root
+          double* t = MKH_TAP(t_frame_pose) + ((size_t)pb * P.n_frame + lane) * 7;
+          t[0] = Tfr.q.w; t[1] = Tfr.q.x; t[2] = Tfr.q.y; t[3] = Tfr.q.z; t[4] = Tfr.p.x; t[5] = Tfr.p.y; t[6] = Tfr.p.z;
+        }
+      }
+      M3 Rf = qmat(F.q);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { o[i] = Jm[i]; o[9 + i] = Qm[i]; o[18 + i] = Rf.m[i]; }
+      o[27] = F.p.x; o[28] = F.p.y; o[29] = F.p.z;
+      const double e6[6] = {ev.x, ev.y, ev.z, ew.x, ew.y, ew.z};
+      double ss = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double we = ft.cost[r] * (-ft.gain * e6[r]);  // weighted_error (task.py:129-130)
+        o[30 + r] = we;
+        ss += we * we;
+        if (MKH_TAP(t_task_e)) MKH_TAP(t_task_e)[(size_t)pb * P.n_rows_tap + ft.row0 + r] = e6[r];
+      }
+      mu_lane = ft.lm_damping * ss;                          // task.py:131
+      if (kSteps && until) {
+        const double pt = pos_thr, ot = ori_thr;
+        conv_lane = (!(ft.rowmask & 7) || dot(ev, ev) <= pt * pt) && (!(ft.rowmask & 56) || dot(ew, ew) <= ot * ot);
+      }
+      if (MKH_TAP(t_frame_pose) && !(kRel && ft.relative)) {
+        double* t = MKH_TAP(t_frame_pose) + ((size_t)pb * P.n_frame + lane) * 7;
+        t[0] = F.q.w; t[1] = F.q.x; t[2] = F.q.y; t[3] = F.q.z; t[4] = F.p.x; t[5] = F.p.y; t[6] = F.p.z;
+      }
+    }
+  PreOut po;
+  po.status = status; po.d_kind = d_kind; po.d_k = d_k; po.d_body = d_body; po.d_qadr = d_qadr;
+  po.conv = conv_lane ? 1 : 0; po.mu_lane = mu_lane; po.com_root = com_root;
+  return po;
+}
+
+#if (MKH_FEAT & 32)
+// ---------------------------------------------------------------- low-rank start of the QP (F_WOOD)
+// H = Dg + JwᵀJw with Dg diagonal (damping + Σ LM terms + posture tasks) and Jw the n_μ weighted frame-task rows.  With
+// σ = 1/√Dg, Jh = Jw·σ and S = I + Jh·Jhᵀ = L·D·Lᵀ (n_μ × n_μ, SPD, diagonal ≥ 1 — no pivoting needed):
+//     −H⁻¹ = −σσᵀ∘(I − JhᵀS⁻¹Jh),   JhᵀS⁻¹Jh = ZᵀD⁻¹Z  with  Z = L⁻¹Jh.
+// One COLUMN of the augmented matrix [S | Jh | w] per lane — dof lanes [0, NR), S lanes [NR, NR + n_μ), one right-hand-side
+// lane — in kMu compiler-allocated registers; step r publishes row r (the dof lanes' part is row r of Z, written to its
+// final place in LDS), every lane reads the n_μ − r − 1 multipliers S[i][r] as two 16-lane planes and updates its rows
+// below r with DPP-broadcast FMAs (tab_asm.inc wood_elim_step).  The chain per step is one LDS round trip + one
+// reciprocal + ≤ 17 FMAs, and it never touches the tableau: the kernel then builds the dof block with n_μ rank-1 updates
+// R[i][j] += Z[r][i]·Z[r][j]/d_r that do not depend on each other.  (Round 2's first version swept the residual indices on
+// the tableau itself — every pivot a publish / reciprocal / multiplier chain in front of a 62-row update, later six at a
+// time with a per-lane 6 × 6 LDLᵀ: 30 % of a G1 solve.)
+// Outputs per dof lane: D = −H⁻¹[j][j] = σ²(Σ_r z_r²/d_r − 1),  x0 = −H⁻¹c = z − σ·Σ_r z_r·ω_r/d_r  (ω = L⁻¹w, w = Jw·z − r).
+struct WoodOut { double hdiag, dsq, x, D; int status; };
+__device__ MKH_PRE_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, double c_lane, double hdiag_base) {
+  constexpr int NR = MKH_NT, SP = kMu;
+  static_assert(MKH_NR == MKH_NT, "low-rank start: the residual rows are not tableau rows any more");
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+#ifdef MKH_W3
+  oz = uni(oz);
+  Pq = reinterpret_cast<const DeviceProblem*>(uni((unsigned long long)reinterpret_cast<size_t>(Pq)));
+  const MKH_CONSTANT DeviceProblem& P = *(const MKH_CONSTANT DeviceProblem*)Pq;
+  const MKH_GLOBAL FrameTaskDev* const frames = (const MKH_GLOBAL FrameTaskDev*)P.frame;
+#else
+  const DeviceProblem& P = *Pq;
+  const FrameTaskDev* const frames = P.frame;
+#endif
+  int lane = lane_id();
+  const int ol = lane + oz;
+  const int nv = P.nv, n_mu = P.n_jrows;
+  const LdsLayout L = kernel_lds_layout(P);
+  double* const sTask = smem + L.task;
+  double* const sJ = smem + L.J;
+  double* const sDof = smem + L.dof;
+  double* const sRow = smem + L.piv;                  // published row: S part at [0, n_μ), right-hand side at [n_μ]
+  double* const sDinv = sRow + kWoodRow;              // 1/d_r for the kernel's rank-1 updates
+  const bool is_dof = lane < nv;
+  int status = 0;
+  // 1/√Dg of this dof (Dg = damping + Σμ + posture diagonal > 0, checked on the host)
+  const double dsq = is_dof ? fast_rcp(sqrt(hdiag_base)) : 0.0;
+  // weighted error of residual row c (read before the Jacobian rows may overwrite the task blocks)
+  double we_mu = 0.0;
+  if (lane >= NR && lane < NR + n_mu) we_mu = sTask[P.mu_src[lane - NR]];
+  if (is_dof) sDof[lane * 10 + 9] = dsq;
+  wave_sync();
+  // ---- Jacobian columns by (task, dof) PAIR lanes — 56 pairs for G1's four tasks, one pass — into the row-major array
+  // Jh[r][k] = weighted_jacobian/√Dg (stride NR).  A pass keeps its entries in registers until every lane has read its
+  // task block and dof axes: in the compact layout the rows overwrite both.
+  const int n_jp = P.n_jpairs;
+  for (int base = 0; base < n_jp || base == 0; base += kWave) {
+    const int pi = base + lane;
+    double Jo[6] = {0, 0, 0, 0, 0, 0};
+    int rowmask = 0, o0 = 0;
+    if (pi < n_jp) {
+      const int t = P.jpair_task[pi], k = P.jpair_dof[pi];
+      const auto& ft = frames[t];
+      const double* o = sTask + t * 64;
+      const double* dd = sDof + k * 10;
+      const V3 d_ang{dd[0], dd[1], dd[2]}, d_lin{dd[3], dd[4], dd[5]}, d_anchor{dd[6], dd[7], dd[8]};
+      const double dsk = dd[9];
+      const V3 pf{o[27], o[28], o[29]};
+      const V3 jp = d_lin + cross(d_ang, pf - d_anchor);
+      M3 Rf;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rf.m[i] = o[18 + i];
+      const V3 a = mulT(Rf, jp), w = mulT(Rf, d_ang);       // body-frame Jacobian (configuration.py:148-153)
+      // J = −jlog(T_tb)·ᴮJ with jlog = [[J, −J·Q·J],[0, J]]:  y = J·w;  rows 0-2 = −J·(a − Q·y), rows 3-5 = −y
+      const double wv[3] = {w.x, w.y, w.z}, av[3] = {a.x, a.y, a.z};
+      double y[3], z3[3], Jt[6];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) y[r] = o[3 * r] * wv[0] + o[3 * r + 1] * wv[1] + o[3 * r + 2] * wv[2];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        z3[r] = av[r] - (o[9 + 3 * r] * y[0] + o[9 + 3 * r + 1] * y[1] + o[9 + 3 * r + 2] * y[2]);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        Jt[r] = -(o[3 * r] * z3[0] + o[3 * r + 1] * z3[1] + o[3 * r + 2] * z3[2]);
+        Jt[3 + r] = -y[r];
+      }
+      rowmask = ft.rowmask;
+      o0 = ft.jrow0 * NR + k;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) Jo[r] = (ft.cost[r] * Jt[r]) * dsk;                // weighted_jacobian/√Dg
+    }
+    if (base == 0) {
+      wave_sync();                                               // every pair of a one-pass problem has read its inputs
+      for (int i = lane; i < SP * NR; i += kWave) sJ[i] = 0.0;   // dofs off a task's chain, rows ≥ n_μ
+      // x after the closed-form dof sweeps: z_k = −c_k/Dg_k (posture part of c only), staged as z_k·√Dg_k in row SP of
+      // the array so that the right-hand side Jw·z is one more row of the product below
+      if (lane < NR) sJ[SP * NR + lane] = is_dof ? -c_lane * dsq : 0.0;
+      wave_sync();
+    }
+    {
+      int c = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+        if ((rowmask >> r) & 1) { sJ[o0 + c * NR] = Jo[r]; ++c; }                     // (nonzero-cost rows only)
+    }
+  }
+  wave_sync();
+  // ---- S = I + Jh·Jhᵀ and Jw·z by (column, row-chunk) lanes: 64/n_μ chunks of rows per column, each lane a handful of
+  // dot products on its own LDS addresses.  A row of Jh is nonzero only on the kinematic chain of its task (12–16 of the
+  // 43 dofs on G1): the dot products walk the set bits of the column's chain mask instead of all NR dofs.
+  // [column c][SP]: S[·][c], then [c]: (Jw·z)[c] − weighted error.  Lives in the dof stash (axes / anchors of the Jacobian
+  // columns: dead by now) when it fits, so that the low-rank start costs no LDS residency.
+  double* const sS = wood_s_aliases_dof(nv, n_mu, SP) ? sDof : smem + L.S;
+  double* const sW = sS + n_mu * SP;
+  for (int i = lane; i < n_mu * SP; i += kWave) sS[i] = 0.0;
+  wave_sync();
+  {
+    const int wc = P.wood_col[ol], wr0 = P.wood_row0[ol];
+    if (wc >= 0) {
+      const double* a = sJ + wc * NR;
+      const uint64_t chain = P.wood_mask[ol];
+      const int rpc = P.wood_rpc;
+      // eight rows per pass (one pass for G1's 7 rows per lane): the lane's own column entry is read once per pass, and
+      // the walk over the chain bits — a dependent ffs → address → LDS read → FMA chain per bit — runs once
+      for (int i0 = 0; i0 < rpc; i0 += 8) {
+        const int row0 = wr0 + i0;
+        if (row0 > n_mu) break;
+        const double* b[8];
+        double acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int r = row0 + j; b[j] = sJ + (r < n_mu ? r : SP) * NR; acc[j] = 0.0; }
+        for (uint64_t mk = chain; mk; mk &= mk - 1) {
+          const int k = __ffsll((unsigned long long)mk) - 1;
+          const double av = a[k];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = fma(av, b[j][k], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int row = row0 + j;
+          if (i0 + j < rpc && row <= n_mu) {
+            if (row < n_mu) sS[wc * SP + row] = acc[j] + (row == wc ? 1.0 : 0.0); else sW[wc] = acc[j];
+          }
+        }
+      }
+    }
+  }
+  wave_sync();
+  if (lane >= NR && lane < NR + n_mu) sW[lane - NR] -= we_mu;          // w = Jw·z − r
+  wave_sync();
+  // ---- this lane's column of [S | Jh | w]
+  double z[kMu];
+  {
+    const double* src = sW;                                            // right-hand-side lane
+    int stride = 1;
+    if (lane < NR) { src = sJ + lane; stride = NR; }
+    else if (lane < NR + n_mu) src = sS + (lane - NR) * SP;
+    const bool live = lane <= NR + n_mu;
+#pragma unroll
+    for (int r = 0; r < kMu; ++r) z[r] = (live && r < n_mu) ? src[r * stride] : 0.0;
+  }
+  double ssq = 0.0;
+#pragma unroll
+  for (int r = 0; r < kMu; ++r) ssq = fma(z[r], z[r], ssq);
+  const double hdiag = hdiag_base * (1.0 + ssq);                       // H[k][k] = Dg·(1 + Σ Jh²)  (only scales thresholds)
+  // ---- elimination
+  double quad = 0.0, zw = 0.0;
+  const unsigned plane_off = (unsigned)(lane & 15);
+  static_for<kMu>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if (r < n_mu) {
+      wave_sync();                                                     // the previous row's readers are done
+      if (lane < NR) sJ[r * NR + lane] = z[r];                         // row r of Z, final
+      else if (lane - NR < kWoodRow) sRow[lane - NR] = z[r];
+      wave_sync();
+      const double d = sRow[r], om = sRow[n_mu];
+      const double p0 = sRow[plane_off], p1 = (kMu > 16) ? sRow[16 + plane_off] : 0.0;
+      if (!(d > 0.0)) status |= 4;
+      const double inv = fast_rcp(d);
+      if (lane == 0) sDinv[r] = inv;
+      const double zi = z[r] * inv;
+      quad = fma(z[r], zi, quad);
+      zw = fma(om, zi, zw);
+      wood_elim_step<r>(z, p0, p1, -zi);                               // z[i] −= S[i][r]·z[r]/d   (i > r)
+    }
+  });
+  wave_sync();
+  WoodOut wo;
+  wo.hdiag = hdiag; wo.dsq = dsq; wo.status = __ballot(status != 0) ? 4 : 0;
+  wo.D = (dsq * dsq) * (quad - 1.0);
+  wo.x = -c_lane * (dsq * dsq) - dsq * zw;
+  return wo;
+}
+#else
+struct WoodOut { double hdiag, dsq, x, D; int status; };
+__device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, double, double) { return WoodOut{0.0, 0.0, 0.0, 0.0, 0}; }
+#endif
+#ifdef MKH_W3
+#define MKH_STAGE (2 * ((MKH_NT + 15) / 16))   // 3-waves maps: only the planes the column has (gen_tab_asm.py)
+#else
 #define MKH_STAGE 8   // staging VGPRs of the rank-1 update: four 16-lane planes of the pivot column (gen_tab_asm.py ntmp_for)
+#endif
+#ifdef MKH_W3
+#define MKH_WAVES 3
+#define MKH_TOP 168
+#else
 #define MKH_WAVES (MKH_NT <= 8 ? 4 : (MKH_NT <= 24 ? 3 : 2))   // resident waves per SIMD the register map is built for
 #define MKH_TOP (MKH_NT <= 8 ? 128 : (MKH_NT <= 24 ? 168 : 256))  // VGPRs per lane at that occupancy (gen_tab_asm.py total_for)
-static_assert(Tab<MKH_NT>::kCompilerVgprs == MKH_TOP - 2 * MKH_NT - MKH_STAGE, "register map of tab_asm.inc changed");
-__global__ __launch_bounds__(64, MKH_WAVES) __attribute__((amdgpu_num_vgpr((MKH_TOP - 2 * MKH_NT - MKH_STAGE) / 2)))
+#endif
+#if defined(MKH_W3) && !defined(MKH_W3_RESERVED)   // operand map: the compiler owns everything below the planes, the column included (gen_tab_asm.py)
+#define MKH_CAP (MKH_TOP - MKH_STAGE)
+#else
+#define MKH_CAP (MKH_TOP - 2 * MKH_NT - MKH_STAGE)
+#endif
+#ifdef MKH_CAP_PROBE     // (pressure probing only: the code is wrong when the cap reaches into the pinned range)
+#undef MKH_CAP
+#define MKH_CAP MKH_CAP_PROBE
+#else
+static_assert(MKH_TAB<MKH_NT>::kCompilerVgprs == MKH_CAP, "register map of tab_asm.inc changed");
+#endif
+__global__ __launch_bounds__(64, MKH_WAVES) __attribute__((amdgpu_num_vgpr(MKH_CAP / 2)))
 void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, const TapArgs* __restrict__ tp) {
   constexpr int NT = MKH_NT, FEAT = MKH_FEAT;
   constexpr bool kTaps = (FEAT & F_TAPS) != 0, kRel = (FEAT & F_REL) != 0, kCom = (FEAT & F_COM) != 0;
@@ -317,15 +943,18 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   constexpr int NR = NT;
 #endif
   static_assert(!kWood || !(kRel || kCom || kColl), "low-rank start: frame/posture tasks + box limits only");
+#ifdef MKH_W3
+  constexpr bool kCompact = true;            // LDS ranges aliased by phase (lds_layout): 12 waves per CU need ≤ 13.3 KB each
+  static_assert(!kColl, "compact LDS layout: the collision phase reads the body poses after the Jacobian rows");
+#else
+  constexpr bool kCompact = false;
+#endif
   const DeviceProblem& P0 = *Pg;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   int lane = lane_id();     // (re-laundered at every phase boundary, see MKH_TICK)
   const int nq = P0.nq, nv = P0.nv, nbody = P0.nbody;
-  const LdsLayout L = lds_layout(nq, nv, nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows,
-                                 kWood ? NT - NR + 1 : 6, kWood ? NR : j_stride_direct(nv, NT),
-                                 (kWood && !wood_s_aliases_dof(nv, P0.n_jrows, NT - NR)) ? P0.n_jrows * (NT - NR + 1) : 0,
-                                 P0.prefetch != 0, kWood ? kBlkLds : 0);
-  const bool prefetch = P0.prefetch != 0;
+  const LdsLayout L = kernel_lds_layout(P0);
+  const bool prefetch = (kCompact ? (kWood ? P0.prefetch_w3w : P0.prefetch_w3) : P0.prefetch) != 0;
   double* sq = smem + L.q;            // (sq / sTgt alternate between two buffers, see "load inputs")
   double* const sX = smem + L.X;
   const int XS = lds_even(nbody);                      // component stride of sX (consecutive lanes hit consecutive banks;
@@ -388,6 +1017,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     const int pb = pb_next;
     pb_next = draw();
     int status_all = 0;
+    typename MKH_TAB<NT>::Regs ts;   // the tableau column (operand map: compiler-visible register tuples; else empty)
     long long tc[8];
     long long ta[6] = {0, 0, 0, 0, 0, 0}, tl = 0;   // QP sub-phase cycle sums (profiling)
     int tci = 0;
@@ -396,12 +1026,6 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
 // once per kernel and then SPILLED them (9 of the 24 spills of the production variant), although each
 // is one v_lshl_add away.
 #define MKH_TICK() do { if (MKH_TAP(t_cycles)) tc[tci] = __builtin_readcyclecounter(); ++tci; asm volatile("" : "+v"(lane)); } while (0)
-// ISA markers for static instruction counting (tools/isa_census.py): comments only, and only with -DMKH_MARKERS
-#ifdef MKH_MARKERS
-#define MKH_MARK(name) asm volatile("; MKH_MARK " name)
-#else
-#define MKH_MARK(name) do {} while (0)
-#endif
 #define MKH_LAP0() do { if (MKH_TAP(t_cycles)) tl = __builtin_readcyclecounter(); } while (0)
 #define MKH_LAP(i) do { if (MKH_TAP(t_cycles)) { const long long n_ = __builtin_readcyclecounter(); ta[i] += n_ - tl; tl = n_; } } while (0)
     MKH_MARK("problem_begin");
@@ -457,294 +1081,21 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     int status = 0;
     tci = 1;                                                 // phase stamps 1..7 belong to the current step
 
-    // ------------------------------------------------- FK: local transforms
-    // X = pose of body `lane` relative to its parent, joints applied
-    // (mj_kinematics, SURVEY Appendix A.1).
-    V3 xp{0, 0, 0};
-    Q4 xq{1, 0, 0, 0};
-    int b_jadr = 0, b_jnum = 0, anc_lo = 0, anc_hi = 0;
-    if (is_body) {
-      anc_lo = P.body_i[BI_ANCPACK0 * 64 + ol];
-      anc_hi = P.body_i[BI_ANCPACK1 * 64 + ol];
-      const double* bf = P.body_f + ol;
-      xp = {bf[(BF_POS + 0) * 64], bf[(BF_POS + 1) * 64], bf[(BF_POS + 2) * 64]};
-      xq = {bf[(BF_QUAT + 0) * 64], bf[(BF_QUAT + 1) * 64], bf[(BF_QUAT + 2) * 64], bf[(BF_QUAT + 3) * 64]};
-      b_jadr = P.body_i[BI_JNTADR * 64 + ol];
-      b_jnum = P.body_i[BI_JNTNUM * 64 + ol];
-      for (int jn = 0; jn < b_jnum; ++jn) {
-        const int j = b_jadr + jn;
-        const int jt = P.jnt_i[j * JI_COUNT + JI_TYPE];
-        const int qa = P.jnt_i[j * JI_COUNT + JI_QADR];
-        const double* jf = P.jnt_f + j * JF_COUNT;
-        if (jt == JNT_FREE) {
-          xp = {sq[qa], sq[qa + 1], sq[qa + 2]};
-          xq = qnormalize(Q4{sq[qa + 3], sq[qa + 4], sq[qa + 5], sq[qa + 6]});
-        } else if (jt == JNT_SLIDE) {
-          V3 ax{jf[JF_AXIS], jf[JF_AXIS + 1], jf[JF_AXIS + 2]};
-          xp = xp + (sq[qa] - jf[JF_QPOS0]) * qrot(xq, ax);
-        } else {
-          V3 jp{jf[JF_POS], jf[JF_POS + 1], jf[JF_POS + 2]};
-          Q4 qloc;
-          if (jt == JNT_HINGE) {
-            V3 ax{jf[JF_AXIS], jf[JF_AXIS + 1], jf[JF_AXIS + 2]};
-            qloc = axis_angle(ax, sq[qa] - jf[JF_QPOS0]);
-          } else {
-            qloc = qnormalize(Q4{sq[qa], sq[qa + 1], sq[qa + 2], sq[qa + 3]});
-          }
-          V3 anchor = xp + qrot(xq, jp);
-          xq = qmul(xq, qloc);
-          xp = anchor - qrot(xq, jp);
-        }
-      }
-    }
-    // ---------------------------------------- FK: pointer jumping to the root
-    for (int r = 0; r < P.nrounds; ++r) {
-      wave_sync();
-      if (is_body) {
-        double* o = sX + lane;
-        o[0] = xp.x; o[XS] = xp.y; o[2 * XS] = xp.z; o[3 * XS] = xq.w; o[4 * XS] = xq.x; o[5 * XS] = xq.y; o[6 * XS] = xq.z;
-      }
-      wave_sync();
-      if (is_body) {
-        const double* a = sX + (((r < 5) ? (anc_lo >> (6 * r)) : anc_hi) & 63);
-        V3 ap{a[0], a[XS], a[2 * XS]};
-        Q4 aq{a[3 * XS], a[4 * XS], a[5 * XS], a[6 * XS]};
-        xp = ap + qrot(aq, xp);
-        xq = qmul(aq, xq);
-      }
-    }
-    xq = qnormalize(xq);
-    wave_sync();
-    if (is_body) {
-      double* o = sX + lane;
-      o[0] = xp.x; o[XS] = xp.y; o[2 * XS] = xp.z; o[3 * XS] = xq.w; o[4 * XS] = xq.x; o[5 * XS] = xq.y; o[6 * XS] = xq.z;
-      if (MKH_TAP(t_xpos)) {
-        double* t = MKH_TAP(t_xpos) + ((size_t)pb * nbody + lane) * 3;
-        t[0] = xp.x; t[1] = xp.y; t[2] = xp.z;
-      }
-      if (MKH_TAP(t_xquat)) {
-        double* t = MKH_TAP(t_xquat) + ((size_t)pb * nbody + lane) * 4;
-        t[0] = xq.w; t[1] = xq.x; t[2] = xq.y; t[3] = xq.z;
-      }
-    }
-    wave_sync();
-    MKH_MARK("fk_done");
-    MKH_TICK();   // 1: FK done
-    // --------------------- joint anchors / axes in the world (xanchor, xaxis)
-    if (is_body && b_jnum > 0) {
-      if (b_jnum == 1) {
-        // single joint: rotation about its own axis/anchor leaves both invariant, so the
-        // final body frame gives them directly.
-        const int j = b_jadr;
-        const double* jf = P.jnt_f + j * JF_COUNT;
-        V3 ax = qrot(xq, V3{jf[JF_AXIS], jf[JF_AXIS + 1], jf[JF_AXIS + 2]});
-        V3 an = xp + qrot(xq, V3{jf[JF_POS], jf[JF_POS + 1], jf[JF_POS + 2]});
-        double* o = sJnt + j * 6;
-        o[0] = ax.x; o[1] = ax.y; o[2] = ax.z; o[3] = an.x; o[4] = an.y; o[5] = an.z;
-      } else {
-        // several joints in one body: replay them from the parent's world pose.
-        const double* a = sX + P.body_i[BI_PARENT * 64 + ol];
-        const double* bf = P.body_f + ol;
-        V3 fp = V3{a[0], a[XS], a[2 * XS]} + qrot(Q4{a[3 * XS], a[4 * XS], a[5 * XS], a[6 * XS]},
-                                            V3{bf[(BF_POS + 0) * 64], bf[(BF_POS + 1) * 64], bf[(BF_POS + 2) * 64]});
-        Q4 fq = qmul(Q4{a[3 * XS], a[4 * XS], a[5 * XS], a[6 * XS]}, Q4{bf[(BF_QUAT + 0) * 64], bf[(BF_QUAT + 1) * 64],
-                                                    bf[(BF_QUAT + 2) * 64], bf[(BF_QUAT + 3) * 64]});
-        for (int jn = 0; jn < b_jnum; ++jn) {
-          const int j = b_jadr + jn;
-          const int jt = P.jnt_i[j * JI_COUNT + JI_TYPE];
-          const int qa = P.jnt_i[j * JI_COUNT + JI_QADR];
-          const double* jf = P.jnt_f + j * JF_COUNT;
-          V3 axl{jf[JF_AXIS], jf[JF_AXIS + 1], jf[JF_AXIS + 2]};
-          V3 jp{jf[JF_POS], jf[JF_POS + 1], jf[JF_POS + 2]};
-          V3 ax = qrot(fq, axl);
-          V3 an = fp + qrot(fq, jp);
-          double* o = sJnt + j * 6;
-          o[0] = ax.x; o[1] = ax.y; o[2] = ax.z; o[3] = an.x; o[4] = an.y; o[5] = an.z;
-          if (jt == JNT_SLIDE) {
-            fp = fp + (sq[qa] - jf[JF_QPOS0]) * ax;
-          } else if (jt == JNT_HINGE || jt == JNT_BALL) {
-            Q4 qloc = (jt == JNT_HINGE) ? axis_angle(axl, sq[qa] - jf[JF_QPOS0])
-                                        : qnormalize(Q4{sq[qa], sq[qa + 1], sq[qa + 2], sq[qa + 3]});
-            fq = qmul(fq, qloc);
-            fp = an - qrot(fq, jp);
-          }
-        }
-      }
-    }
-    wave_sync();
-    // --------------------------- dof lane: motion axis of dof `lane` (cdof)
-    // jacp(p) = lin + ang × (p − anchor), jacr = ang  (mj_jac, SURVEY Appendix A.2/A.3)
-    int d_kind = DOF_HINGE, d_k = 0, d_body = 0, d_qadr = -1;
-    {
-    V3 d_ang{0, 0, 0}, d_lin{0, 0, 0}, d_anchor{0, 0, 0};
-    double q_dof = 0.0;  // joint coordinate for hinge/slide dofs
-    if (is_dof) {
-      const int32_t* di = P.dof_i + ol;
-      const int d_jnt = di[DI_JNT * 64];
-      d_kind = di[DI_KIND * 64];
-      d_k = di[DI_K * 64];
-      d_body = di[DI_BODY * 64];
-      d_qadr = di[DI_QADR * 64];
-      if (d_kind == DOF_HINGE) {
-        const double* o = sJnt + d_jnt * 6;
-        d_ang = {o[0], o[1], o[2]};
-        d_anchor = {o[3], o[4], o[5]};
-        q_dof = sq[d_qadr];
-      } else if (d_kind == DOF_SLIDE) {
-        const double* o = sJnt + d_jnt * 6;
-        d_lin = {o[0], o[1], o[2]};
-        q_dof = sq[d_qadr];
-      } else if (d_kind == DOF_FREE_LIN) {
-        d_lin = {d_k == 0 ? 1.0 : 0.0, d_k == 1 ? 1.0 : 0.0, d_k == 2 ? 1.0 : 0.0};
-      } else {  // ball / free rotational dof: body-frame axis k, about the joint anchor
-        const double* xb = sX + d_body;
-        M3 R = qmat(Q4{xb[3 * XS], xb[4 * XS], xb[5 * XS], xb[6 * XS]});
-        d_ang = (d_k == 0) ? V3{R.m[0], R.m[3], R.m[6]}
-                           : ((d_k == 1) ? V3{R.m[1], R.m[4], R.m[7]} : V3{R.m[2], R.m[5], R.m[8]});
-        if (d_kind == DOF_FREE_ANG) {
-          d_anchor = {xb[0], xb[XS], xb[2 * XS]};
-        } else {
-          const double* o = sJnt + d_jnt * 6;
-          d_anchor = {o[3], o[4], o[5]};
-        }
-      }
-    }
-    // Configuration.check_limits (mink/configuration.py:77-110), tol = 1e-6
-    {
-      bool viol = false;
-      if (is_dof && (d_kind == DOF_HINGE || d_kind == DOF_SLIDE))
-        viol = q_dof < P.dof_f[DF_RANGE_LO * 64 + ol] - 1e-6 || q_dof > P.dof_f[DF_RANGE_HI * 64 + ol] + 1e-6;
-      // a limited ball joint: the reference's loop compares q[jnt_qposadr] — the quaternion's w — with the range
-      // (configuration.py:92-99); the range sits on the joint's first dof lane only
-      if (is_dof && d_kind == DOF_BALL && d_k == 0) {
-        const double qw = sq[d_qadr];
-        viol = qw < P.dof_f[DF_RANGE_LO * 64 + ol] - 1e-6 || qw > P.dof_f[DF_RANGE_HI * 64 + ol] + 1e-6;
-      }
-      if (__ballot(viol)) status |= 1;
-    }
-    // stash the dof's motion axis in LDS; phases below reload it instead of keeping 20 VGPRs live
-    if (is_dof) {
-      double* o = sDof + lane * 10;
-      o[0] = d_ang.x; o[1] = d_ang.y; o[2] = d_ang.z; o[3] = d_lin.x; o[4] = d_lin.y; o[5] = d_lin.z;
-      o[6] = d_anchor.x; o[7] = d_anchor.y; o[8] = d_anchor.z; o[9] = q_dof;
-    }
-    }
+    // FK, joint axes / dof lanes, subtree CoM, frame-task lanes (pre_phases above)
+    const PreOut po = pre_phases(Pq, tp, pb, oz, (int)(sq - smem), (int)(sTgt - smem), until, A.pos_threshold, A.ori_threshold MKH_PRE_TC_ARGS);
+#ifdef MKH_W3
+    tci = 4;
+#endif
+    asm volatile("" : "+v"(lane));
+    status |= po.status;
+    const int d_kind = po.d_kind, d_k = po.d_k, d_body = po.d_body, d_qadr = po.d_qadr;
+    const bool conv_lane = po.conv != 0;
+    const double mu_lane = po.mu_lane;
+    const V3 com_root = po.com_root;
     const double* const my_dof = sDof + lane * 10;   // {ang, lin, anchor, q} of dof `lane`
 #define MKH_LOAD_DOF_AXES()                                                        \
   const V3 d_ang{my_dof[0], my_dof[1], my_dof[2]}, d_lin{my_dof[3], my_dof[4], my_dof[5]}, \
       d_anchor{my_dof[6], my_dof[7], my_dof[8]}
-
-    // -------------------------------------- subtree CoM (mj_comPos) for ComTask
-    V3 com_root{0, 0, 0};
-    if (kCom && P.n_com > 0) {
-      V3 b_ipos{0, 0, 0};
-      double b_mass = 0.0, b_stmass = 0.0;
-      int b_last = 0, b_inrobot = 0;
-      if (is_body) {
-        const double* bf = P.body_f + ol;
-        b_ipos = {bf[(BF_IPOS + 0) * 64], bf[(BF_IPOS + 1) * 64], bf[(BF_IPOS + 2) * 64]};
-        b_mass = bf[BF_MASS * 64];
-        b_stmass = bf[BF_SUBTREEMASS * 64];
-        b_last = P.body_i[BI_SUBTREE_LAST * 64 + ol];
-        b_inrobot = P.body_i[BI_IN_ROBOT * 64 + ol];
-      }
-      V3 xi = xp + qrot(xq, b_ipos);
-      const double m = (is_body && b_inrobot) ? b_mass : 0.0;
-      double sx = m * xi.x, sy = m * xi.y, sz = m * xi.z;
-      // inclusive scan over body ids (a subtree is a contiguous id range in MuJoCo's DFS order)
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        double tx = __shfl_up(sx, o), ty = __shfl_up(sy, o), tz = __shfl_up(sz, o);
-        if (lane >= o) { sx += tx; sy += ty; sz += tz; }
-      }
-      const int hi_l = is_body ? b_last : 0, lo_l = lane - 1;
-      double ex = __shfl(sx, hi_l), ey = __shfl(sy, hi_l), ez = __shfl(sz, hi_l);
-      double bx = __shfl(sx, lo_l < 0 ? 0 : lo_l), by = __shfl(sy, lo_l < 0 ? 0 : lo_l),
-             bz = __shfl(sz, lo_l < 0 ? 0 : lo_l);
-      if (lane == 0) { bx = 0; by = 0; bz = 0; }
-      V3 cs = xi;
-      if (b_stmass >= 1e-15) {
-        const double im = fast_rcp(b_stmass);
-        cs = {(ex - bx) * im, (ey - by) * im, (ez - bz) * im};
-      }
-      if (is_body) {
-        double* o = sCom + lane * 4;
-        o[0] = cs.x; o[1] = cs.y; o[2] = cs.z; o[3] = b_stmass;
-      }
-      wave_sync();
-      const double* cr = sCom + P.robot_root * 4;
-      com_root = {cr[0], cr[1], cr[2]};
-      if (MKH_TAP(t_subtree_com) && lane < 3) MKH_TAP(t_subtree_com)[(size_t)pb * 3 + lane] = cr[lane];
-    }
-
-    MKH_MARK("axes_done");
-    MKH_TICK();   // 2: joint axes / dof lanes / com done
-    // ------------------------------------------- task lanes: pose, error, jlog
-    double mu_lane = 0.0;  // Levenberg–Marquardt term of the task owned by this lane
-    bool conv_lane = true; // this lane's frame task is within the thresholds (rows with a nonzero cost only)
-    if (lane < P.n_frame) {
-      const FrameTaskDev& ft = P.frame[lane];
-      const double* xb = sX + ft.body;
-      SE3 F;
-      Q4 bq{xb[3 * XS], xb[4 * XS], xb[5 * XS], xb[6 * XS]};
-      F.p = V3{xb[0], xb[XS], xb[2 * XS]} + qrot(bq, V3{ft.lpos[0], ft.lpos[1], ft.lpos[2]});
-      F.q = qmul(bq, Q4{ft.lquat[0], ft.lquat[1], ft.lquat[2], ft.lquat[3]});
-      const double* tg = sTgt + lane * 7;
-      SE3 Tt{Q4{tg[0], tg[1], tg[2], tg[3]}, V3{tg[4], tg[5], tg[6]}};
-      double* o = sTask + lane * 64;
-      V3 ev, ew;
-      double Jm[9], Qm[9];
-      bool ident;
-      if (!(kRel && ft.relative)) {
-        // e = target.minus(frame) = log(T_frame⁻¹ · T_target)          (frame_task.py:119-122)
-        se3_log(se3_mul(se3_inv(F), Tt), ev, ew);
-        // jlog(T_tb) = ljacinv(−log(T_tb)) = ljacinv(e)   since T_tb = T_bt⁻¹   (frame_task.py:144-146)
-        se3_ljacinv(ev, ew, Jm, Qm, ident);
-      } else {
-        // RelativeFrameTask (relative_frame_task.py:106-142): T_fr = T_root⁻¹·T_frame,
-        // e = T_fr.rminus(target) = log(target⁻¹·T_fr),  J = jlog(T_tf)·(ᶠJ − Ad(T_fr⁻¹)·ʳJ)
-        const double* xr = sX + ft.root_body;
-        Q4 rq0{xr[3 * XS], xr[4 * XS], xr[5 * XS], xr[6 * XS]};
-        SE3 Rt;
-        Rt.p = V3{xr[0], xr[XS], xr[2 * XS]} + qrot(rq0, V3{ft.root_lpos[0], ft.root_lpos[1], ft.root_lpos[2]});
-        Rt.q = qmul(rq0, Q4{ft.root_lquat[0], ft.root_lquat[1], ft.root_lquat[2], ft.root_lquat[3]});
-        const SE3 Tfr = se3_mul(se3_inv(Rt), F);
-        se3_log(se3_mul(se3_inv(Tt), Tfr), ev, ew);
-        se3_ljacinv(-1.0 * ev, -1.0 * ew, Jm, Qm, ident);       // jlog(T) = ljacinv(−log T)
-        const SE3 Trf = se3_inv(Tfr);
-        const M3 Rr = qmat(Rt.q), Rrf = qmat(Trf.q);
-#pragma unroll
-        for (int i = 0; i < 9; ++i) { o[36 + i] = Rr.m[i]; o[48 + i] = Rrf.m[i]; }
-        o[45] = Rt.p.x; o[46] = Rt.p.y; o[47] = Rt.p.z;
-        o[57] = Trf.p.x; o[58] = Trf.p.y; o[59] = Trf.p.z;
-        if (MKH_TAP(t_frame_pose)) {                            // tap: pose of the frame in the root
-          double* t = MKH_TAP(t_frame_pose) + ((size_t)pb * P.n_frame + lane) * 7;
-          t[0] = Tfr.q.w; t[1] = Tfr.q.x; t[2] = Tfr.q.y; t[3] = Tfr.q.z; t[4] = Tfr.p.x; t[5] = Tfr.p.y; t[6] = Tfr.p.z;
-        }
-      }
-      M3 Rf = qmat(F.q);
-#pragma unroll
-      for (int i = 0; i < 9; ++i) { o[i] = Jm[i]; o[9 + i] = Qm[i]; o[18 + i] = Rf.m[i]; }
-      o[27] = F.p.x; o[28] = F.p.y; o[29] = F.p.z;
-      const double e6[6] = {ev.x, ev.y, ev.z, ew.x, ew.y, ew.z};
-      double ss = 0.0;
-#pragma unroll
-      for (int r = 0; r < 6; ++r) {
-        const double we = ft.cost[r] * (-ft.gain * e6[r]);  // weighted_error (task.py:129-130)
-        o[30 + r] = we;
-        ss += we * we;
-        if (MKH_TAP(t_task_e)) MKH_TAP(t_task_e)[(size_t)pb * P.n_rows_tap + ft.row0 + r] = e6[r];
-      }
-      mu_lane = ft.lm_damping * ss;                          // task.py:131
-      if (kSteps && until) {
-        const double pt = A.pos_threshold, ot = A.ori_threshold;
-        conv_lane = (!(ft.rowmask & 7) || dot(ev, ev) <= pt * pt) && (!(ft.rowmask & 56) || dot(ew, ew) <= ot * ot);
-      }
-      if (MKH_TAP(t_frame_pose) && !(kRel && ft.relative)) {
-        double* t = MKH_TAP(t_frame_pose) + ((size_t)pb * P.n_frame + lane) * 7;
-        t[0] = F.q.w; t[1] = F.q.x; t[2] = F.q.y; t[3] = F.q.z; t[4] = F.p.x; t[5] = F.p.y; t[6] = F.p.z;
-      }
-    }
     if (kSteps && until && step > 0) {
       it_done = step;
       if (!__ballot(!conv_lane)) { conv_flag = 1; status_all |= status; break; }   // every frame task achieved
@@ -820,63 +1171,29 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     const int n_jt = P.n_frame + (kCom ? P.n_com : 0);
     // The tableau column lives in pinned VGPRs (tab_asm.inc), outside the compiler's budget, so H is
     // accumulated right here, task by task, while the lane still holds its own weighted column.
-    Tab<NT>::zero();
-    // low-rank start: 1/√Dg of this dof (Dg = damping + Σμ + posture diagonal > 0, checked on the host)
-    const double dsq = (kWood && is_dof) ? fast_rcp(sqrt(hdiag_base)) : 0.0;
-    double we_mu = 0.0;
+    // (zeroed as late as possible: in the operand map the column's registers belong to the compiler until then)
+    if constexpr (!kWood) { if (!(!kTaps && P.n_dpairs > 0)) MKH_TAB<NT>::zero(ts); }
     const double q_dof_stash = is_dof ? my_dof[9] : 0.0;    // (slot 9 of the dof stash is reused below)
-    if (kWood) {
-      // Low-rank start: row r of Jh = Jw/√Dg is residual index NR + r of the tableau (NR is a compile-time
-      // constant ≥ nv, so the residual block has static register rows).  The Jacobian columns are computed
-      // by (task, dof) PAIR lanes — 56 pairs for G1's four tasks, i.e. ONE pass instead of a pass per task —
-      // into the row-major LDS array Jh[r][k]; dof lanes then load column k into their residual rows.
-      constexpr int SP = NT - NR;
-      for (int i = lane; i < SP * NR; i += kWave) sJ[i] = 0.0;    // dofs off a task's chain, rows ≥ n_μ
-      if (is_dof) sDof[lane * 10 + 9] = dsq;
-      wave_sync();
-      const int n_jp = P.n_jpairs;
-      for (int base = 0; base < n_jp; base += kWave) {
-        const int pi = base + lane;
-        if (pi < n_jp) {
-          const int t = P.jpair_task[pi], k = P.jpair_dof[pi];
-          const FrameTaskDev& ft = P.frame[t];
-          const double* o = sTask + t * 64;
-          const double* dd = sDof + k * 10;
-          const V3 d_ang{dd[0], dd[1], dd[2]}, d_lin{dd[3], dd[4], dd[5]}, d_anchor{dd[6], dd[7], dd[8]};
-          const double dsk = dd[9];
-          const V3 pf{o[27], o[28], o[29]};
-          const V3 jp = d_lin + cross(d_ang, pf - d_anchor);
-          M3 Rf;
-#pragma unroll
-          for (int i = 0; i < 9; ++i) Rf.m[i] = o[18 + i];
-          const V3 a = mulT(Rf, jp), w = mulT(Rf, d_ang);       // body-frame Jacobian (configuration.py:148-153)
-          // J = −jlog(T_tb)·ᴮJ with jlog = [[J, −J·Q·J],[0, J]]:  y = J·w;  rows 0-2 = −J·(a − Q·y), rows 3-5 = −y
-          const double wv[3] = {w.x, w.y, w.z}, av[3] = {a.x, a.y, a.z};
-          double y[3], z3[3], Jt[6];
-#pragma unroll
-          for (int r = 0; r < 3; ++r) y[r] = o[3 * r] * wv[0] + o[3 * r + 1] * wv[1] + o[3 * r + 2] * wv[2];
-#pragma unroll
-          for (int r = 0; r < 3; ++r)
-            z3[r] = av[r] - (o[9 + 3 * r] * y[0] + o[9 + 3 * r + 1] * y[1] + o[9 + 3 * r + 2] * y[2]);
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            Jt[r] = -(o[3 * r] * z3[0] + o[3 * r + 1] * z3[1] + o[3 * r + 2] * z3[2]);
-            Jt[3 + r] = -y[r];
-          }
-          const int rowmask = ft.rowmask;
-          double* orow = sJ + ft.jrow0 * NR + k;
-          int c = 0;
-#pragma unroll
-          for (int r = 0; r < 6; ++r)
-            if ((rowmask >> r) & 1) { orow[c * NR] = (ft.cost[r] * Jt[r]) * dsk; ++c; }   // weighted_jacobian/√Dg
-        }
+    // ---- low-rank start: Jacobian rows, S = I + Jh·Jhᵀ, LDLᵀ elimination (wood_start above), then the dof block of the
+    // tableau by n_μ rank-1 updates that do not depend on each other:  R[i][j] = Σ_r Z[r][i]·Z[r][j]/d_r
+    WoodOut wo{0.0, 0.0, 0.0, 0.0, 0};
+    if constexpr (kWood) {
+      wo = wood_start(Pq, oz, c_lane, hdiag_base);
+      asm volatile("" : "+v"(lane));
+      status |= wo.status;
+      hdiag = wo.hdiag;
+      MKH_TAB<NT>::zero(ts);
+      const int n_mu = P.n_jrows;
+      const double* const sDinv = sPiv + kWoodRow;
+#pragma nounroll
+      for (int r = 0; r < n_mu; ++r) {
+        const double zr = (lane < NT) ? sJ[r * NT + lane] : 0.0;
+        const double g = zr * sDinv[r];
+        // dof rows the row reaches: [0, hb) (zero outside the kinematic chains eliminated so far)
+        const unsigned long long nzd = __ballot(zr != 0.0);
+        const int hb = nzd ? 64 - __builtin_clzll(nzd) : 0;
+        rank1_leading_rows<NT>(ts, lds_addr(sJ + r * NT), g, hb <= 16 ? 16 : (hb <= 24 ? 24 : (hb <= 32 ? 32 : NT)));
       }
-      wave_sync();
-      if (lane < NR) {
-        const double ssq = load_hi_strided_rows<NT, NR>(lds_addr(sJ + lane));   // residual rows of column `lane`
-        hdiag = hdiag_base * (1.0 + ssq);                      // H[k][k] = Dg·(1 + Σ Jh²)  (only scales thresholds)
-      }
-      if (lane >= NR && lane < NR + P.n_jrows) we_mu = sTask[P.mu_src[lane - NR]];
     }
     // Column `k` of frame task t's Jacobian (6 rows, unweighted): dof k must be on the chain of the frame (or of the
     // root frame of a RelativeFrameTask).
@@ -938,6 +1255,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
 #pragma unroll
       for (int r = 0; r < 6; ++r) Jp[r] = ft.cost[r] * Jt[r];   // weighted_jacobian (task.py:129)
     }
+    if constexpr (!kWood) { if (pair_path) MKH_TAB<NT>::zero(ts); }
     for (int t = 0; t < (kWood ? 0 : n_jt); ++t) {
       double Jt[6] = {0, 0, 0, 0, 0, 0}, cw[6] = {0, 0, 0, 0, 0, 0}, we6[6] = {0, 0, 0, 0, 0, 0};
       uint64_t mask;
@@ -981,8 +1299,9 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           int c = 0;
 #pragma unroll
           for (int r = 0; r < 6; ++r)
-            if ((rowmask >> r) & 1) { rank1_leading_rows<NT>(lds_addr(sJ + c * JS), Jw[r], AS); ++c; }
+            if ((rowmask >> r) & 1) { rank1_leading_rows<NT>(ts, lds_addr(sJ + c * JS), Jw[r], AS); ++c; }
         }
+        MKH_TAB<NT>::touch(ts);
         continue;
       }
       if (t < P.n_frame) {
@@ -1051,7 +1370,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         int c = 0;
 #pragma unroll
         for (int r = 0; r < 6; ++r)
-          if ((rowmask >> r) & 1) { rank1_leading_rows<NT>(lds_addr(sJ + c * JS), is_dof ? Jw[r] : 0.0, AS); ++c; }
+          if ((rowmask >> r) & 1) { rank1_leading_rows<NT>(ts, lds_addr(sJ + c * JS), is_dof ? Jw[r] : 0.0, AS); ++c; }
       }
     }
     // caller-defined tasks: rows of W·J straight from memory (row r is contiguous over the dofs: one coalesced load
@@ -1086,74 +1405,12 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         wave_sync();
 #pragma unroll
         for (int r = 0; r < 6; ++r)
-          if (r < nr) rank1_leading_rows<NT>(lds_addr(sJ + r * JS), Jw[r], AS);
+          if (r < nr) rank1_leading_rows<NT>(ts, lds_addr(sJ + r * JS), Jw[r], AS);
       }
     }
     MKH_MARK("jcols_done");
     long long tj = 0;
     if (MKH_TAP(t_cycles)) tj = __builtin_readcyclecounter();     // profiling: end of the Jacobian-column loop
-    // ---- low-rank start: residual columns, S block, right-hand sides
-    const int n_mu = kWood ? P.n_jrows : 0;
-    const int mu0 = kWood ? NR : nv;                         // first residual index / lane
-    const bool is_mu = kWood && lane >= mu0 && lane < mu0 + n_mu;
-    double D_mu = 1.0, w_mu = 0.0;
-    if (kWood) {
-      constexpr int SP = NT - NR;                            // register rows of the residual block
-      // [column c][SP]: −(Jh·Jhᵀ)[·][c], then [c]: (Jw·z)[c].  Lives in the dof stash (axes / anchors of the
-      // Jacobian columns: dead by now) when it fits, so that the low-rank start costs no LDS residency.
-      double* const sS = wood_s_aliases_dof(nv, n_mu, SP) ? sDof : smem + L.S;
-      double* const sW = sS + n_mu * SP;
-      for (int i = lane; i < n_mu * SP; i += kWave) sS[i] = 0.0;   // rows ≥ n_μ are loaded into unused tableau rows
-      // x after the closed-form dof sweeps: z_k = −c_k/Dg_k (posture part of c only); staged as
-      // z_k·√Dg_k in the last row (SP) of the Jh array, so that the right-hand side is one more row of the product
-      if (lane < NR) sJ[SP * NR + lane] = is_dof ? -c_lane * dsq : 0.0;
-      wave_sync();
-      // Jh·Jhᵀ by (column, row-chunk) lanes: 64/n_μ chunks of rows per column, each lane a handful of
-      // dot products on its own LDS addresses.  (Having every lane run the dot of ITS tableau
-      // column against each row costs n_μ+1 full-wave passes: 16.6 k of 132 k cycles on G1.)
-      // A row of Jh is nonzero only on the kinematic chain of its task (12–16 of the 43 dofs on G1): the dot
-      // products walk the set bits of the column's chain mask instead of all NR dofs.
-      const int wc = P.wood_col[ol], wr0 = P.wood_row0[ol];
-      if (wc >= 0) {
-        const double* a = sJ + wc * NR;
-        const uint64_t chain = P.wood_mask[ol];
-        const int rpc = P.wood_rpc;
-        // eight rows per pass (one pass for G1's 7 rows per lane): the lane's own column entry is read once per
-        // pass, and the walk over the chain bits — a dependent ffs → address → LDS read → FMA chain per bit, which
-        // is what this loop costs — runs once instead of once per four rows
-        for (int i0 = 0; i0 < rpc; i0 += 8) {
-          const int row0 = wr0 + i0;
-          if (row0 > n_mu) break;
-          // product row → LDS row: Jh rows 0..n_μ−1, then the right-hand-side vector stored in row SP
-          const double* b[8];
-          double acc[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { const int r = row0 + j; b[j] = sJ + (r < n_mu ? r : SP) * NR; acc[j] = 0.0; }
-          for (uint64_t mk = chain; mk; mk &= mk - 1) {
-            const int k = __ffsll((unsigned long long)mk) - 1;
-            const double av = a[k];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = fma(av, b[j][k], acc[j]);
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int row = row0 + j;
-            if (i0 + j < rpc && row <= n_mu) {
-              if (row < n_mu) sS[wc * SP + row] = -acc[j]; else sW[wc] = acc[j];
-            }
-          }
-        }
-      }
-      wave_sync();
-      if (is_mu) {
-        const int c = lane - NR;
-        // (the dof rows of a residual column are never read: by symmetry every pivot takes ROW k of each
-        // lane, and residual lanes publish 0 once phase 0 is over — only the residual rows are loaded)
-        load_hi_rows<NT, NR>(lds_addr(sS + c * SP));          // T[μ_r][μ_c] = −(Jh·Jhᵀ)[r][c]  (diagonal register unused)
-        D_mu = sS[c * SP + c] - 1.0;                          // −S[c][c]
-        w_mu = sW[c] - we_mu;                                 // Jw·z − r
-      }
-    }
     if (MKH_TAP(t_c) && is_dof) MKH_TAP(t_c)[(size_t)pb * nv + lane] = c_lane;
     MKH_MARK("jcols_s_done");
     MKH_TICK();   // 4: posture + task Jacobian columns done
@@ -1338,18 +1595,18 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       double* hrow = MKH_TAP(t_H) + (size_t)pb * nv * nv + lane;
       static_for<NT>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if (i < nv) hrow[(size_t)i * nv] = (i == lane) ? hdiag : Tab<NT>::template get<i>();
+        if (i < nv) hrow[(size_t)i * nv] = (i == lane) ? hdiag : MKH_TAB<NT>::template get<i>(ts);
       });
     }
     if (!A.do_qp) break;
     if (kColl && nrows > 0) {
       // rows nv+s of the dof columns: one indexed register write per active row (a static_for over all NT
       // rows with a runtime range test cost 860 VALU instructions and 278 spilled SGPRs) ...
-      for (int sr = 0; sr < nrows; ++sr) Tab<NT>::set_dyn(nv + sr, is_dof ? sA[sr * AS + lane] : 0.0);
+      for (int sr = 0; sr < nrows; ++sr) MKH_TAB<NT>::set_dyn(ts, nv + sr, is_dof ? sA[sr * AS + lane] : 0.0);
       // ... and column nv+s (owned by lane nv+s) = A[s][:]  (entries ≥ nv of the staged row are zero)
       if (lane >= nv && lane < nv + nrows) {
         const unsigned addr = lds_addr(sA + (lane - nv) * AS);
-        load_leading_rows<NT>(addr, AS);                     // (rows ≥ AS keep the zeros of Tab::zero())
+        load_leading_rows<NT>(ts, addr, AS);                     // (rows ≥ AS keep the zeros of Tab::zero())
       }
     }
 
@@ -1363,12 +1620,12 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     s.x = 0.0; s.lo = -kInf; s.hi = kInf;
     double rown = 1.0;
     if (kWood) {
-      // state after the closed-form sweep of every dof of [[Dg, Jwᵀ],[Jw, −I]]
-      s.sg = is_dof ? dsq : 1.0;
-      s.D = is_dof ? -(dsq * dsq) : D_mu;
-      s.usign = is_dof ? kSign : 0;                          // dofs basic, residuals not yet
-      s.sel = is_dof ? 1 : 0;                                // residual indices: no bounds, never selected
-      s.x = is_dof ? -c_lane * (dsq * dsq) : (is_mu ? w_mu : 0.0);   // z of the dofs, w of the residuals
+      // state after phase 0 (wood_start + the rank-1 updates above): every dof swept, the dof block is −H⁻¹
+      s.sg = is_dof ? wo.dsq : 1.0;
+      s.D = is_dof ? wo.D : 1.0;                             // −H⁻¹[j][j]
+      s.usign = is_dof ? kSign : 0;                          // every dof basic
+      s.sel = is_dof ? 1 : 0;
+      s.x = is_dof ? wo.x : 0.0;                             // x0 = −H⁻¹c
       if (is_dof) { s.lo = lo; s.hi = hi; }
     } else if (is_dof) {
       s.x = c_lane; s.lo = lo; s.hi = hi;                     // nonbasic at z = 0: w = c   (sel = 1 once swept)
@@ -1391,110 +1648,17 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // Tight loop: publish row k → (LDS loads of the rank-1 update already in flight) → 1/d,
     // multipliers, z/w update → rank-1 update.
     // (low-rank start: the dofs are already in; the n_μ residual indices NR.. take the pivots, d < 0)
-    const int k_begin = kWood ? mu0 : 0, k_end = kWood ? mu0 + n_mu : nv;
+    const int k_begin = 0, k_end = kWood ? 0 : nv;           // (low-rank start: phase 0 is done)
     // The pivot order is known, so pivot k+1 is published BEFORE the rank-1 update of pivot k runs: its column
     // entries after update k are one FMA on row k+1 away (stored to the second buffer by the first instruction of
     // the update's asm statement), and D, σ, x of lane k+1 are final once the cheap per-lane updates of pivot k are
     // done (read with v_readlane into SGPRs).  The LDS round trip and the readlane latency hide under the FMA stream.
-    if constexpr (kWood) {
-      // Low-rank start: the n_μ residual indices enter in BLOCKS of kBlk (block Gauss–Jordan).  One index at a time
-      // every pivot is a dependent chain — publish the column, read it back, 1/d, multipliers, rank-1 update —
-      // of which only the last part is FMA-pipe work; a block B shares the chain: with u(j) = R[B][j] (kBlk
-      // registers of lane j), M = T[B][B] (kBlk × kBlk, wave-uniform, ≺ 0) and A = −M = L·D·Lᵀ,
-      //   R[i][j] += Σ_r u_r(i)·y_r(j),  y(j) = A⁻¹u(j);   D_j += σ_j²·uᵀA⁻¹u;   x_j ∓= σ_j·uᵀA⁻¹w_B
-      // — every lane factorises the tiny A itself (no cross-lane traffic after one LDS round trip) and the kBlk
-      // rank-1 updates run back to back off the block's LDS rows.  Indices of a swept block are dropped (nact below):
-      // their lanes and rows are not maintained.
-      double* const sU = sJ;                           // [kBlk][64]: row B_r of every lane (the Jh rows are dead by now)
-      for (int r0 = 0; r0 < n_mu && !(status & 4); r0 += kBlk) {
-        MKH_MARK("p0_iter_begin");
-        MKH_LAP0();
-        const int m = (n_mu - r0 < kBlk) ? n_mu - r0 : kBlk;
-        const int b0 = mu0 + r0;
-        double u[kBlk], w[kBlk], a[kBlk][kBlk], dinv[kBlk];
-#pragma unroll
-        for (int r = 0; r < kBlk; ++r) {
-          const int row = (b0 + r < NT) ? b0 + r : NT - 1;
-          const double v = Tab<NT>::get_dyn(row);
-          u[r] = (r < m) ? v : 0.0;
-        }
-        unsigned long long nzd;
-        {
-          bool nz = false;
-#pragma unroll
-          for (int r = 0; r < kBlk; ++r) nz = nz || (u[r] != 0.0);
-          nzd = __ballot(nz) & ((1ull << NR) - 1ull);
-        }
-        const int hb = nzd ? 64 - __builtin_clzll(nzd) : 0;    // dof rows the block's columns reach: [0, hb)
-        wave_sync();                                   // earlier readers of the buffers are done
-#pragma unroll
-        for (int r = 0; r < kBlk; ++r) sU[r * kWave + lane] = u[r];
-        // D and w of the block's lanes; a short last block is padded with identity rows (D = −1, w = 0, u = 0)
-        if (lane >= b0 && lane < b0 + kBlk) {
-          const bool in = lane < b0 + m;
-          sPiv[lane - b0] = in ? s.D : -1.0;
-          sPiv[8 + lane - b0] = in ? s.x : 0.0;
-        }
-        wave_sync();
-#pragma unroll
-        for (int r = 0; r < kBlk; ++r) {
-          w[r] = sPiv[8 + r];
-#pragma unroll
-          for (int c = 0; c < r; ++c) a[r][c] = -sU[r * kWave + b0 + c];
-          a[r][r] = -sPiv[r];
-        }
-        MKH_LAP(0);
-        // A = L·D·Lᵀ in place (L below the diagonal), y ← L⁻¹u
-        double y[kBlk];
-#pragma unroll
-        for (int r = 0; r < kBlk; ++r) y[r] = u[r];
-        bool bad = false;
-#pragma unroll
-        for (int r = 0; r < kBlk; ++r) {
-          bad = bad || !(a[r][r] > 0.0);
-          dinv[r] = fast_rcp(a[r][r]);
-#pragma unroll
-          for (int c = r + 1; c < kBlk; ++c) {
-            const double l = a[c][r] * dinv[r];
-#pragma unroll
-            for (int t = r + 1; t <= c; ++t) a[c][t] = fma(-l, a[t][r], a[c][t]);   // (column r still holds A, see below)
-            y[c] = fma(-l, y[r], y[c]);
-          }
-#pragma unroll
-          for (int c = r + 1; c < kBlk; ++c) a[c][r] *= dinv[r];                    // L[c][r]
-        }
-        if (bad) { status |= 4; break; }
-#pragma unroll
-        for (int r = kBlk - 1; r >= 0; --r) {
-          y[r] *= dinv[r];
-#pragma unroll
-          for (int c = r + 1; c < kBlk; ++c) y[r] = fma(-a[c][r], y[c], y[r]);      // y = L⁻ᵀD⁻¹L⁻¹u = A⁻¹u
-        }
-        double quad = 0.0, zw = 0.0;
-#pragma unroll
-        for (int r = 0; r < kBlk; ++r) { quad = fma(u[r], y[r], quad); zw = fma(w[r], y[r], zw); }
-        s.D = fma(s.sg * s.sg, quad, s.D);             // uᵀA⁻¹u
-        s.x += xor_sign(s.sg * zw, s.usign);           // basic dof: z −= σ·w_BᵀA⁻¹u, residual still outside: w += …
-        // the kBlk rank-1 updates, rolled (six copies of the generated bodies are 45 KB of code); y_r from LDS
-        const unsigned scratch = lds_addr(sPiv + kPivBuf + lane);
-#pragma unroll
-        for (int r = 0; r < kBlk; ++r) sU[(kBlk + r) * kWave + lane] = y[r];
-#pragma nounroll
-        for (int r = 0; r < m; ++r) {
-          const double yr = sU[(kBlk + r) * kWave + lane];
-          Tab<NT>::rank1_prefetch(lds_addr(sU + r * kWave));
-          rank1_split_rows<NT, NR>(lds_addr(sU + r * kWave), yr, hb, scratch, 0.0);
-        }
-        MKH_LAP(1);
-      }
-      if (is_mu) { s.usign = kSign; s.x = 0.0; }       // (dropped indices: inert from here on)
-    }
     double* bufc = sPiv;
     double* bufn = sPiv + kPivBuf;
     double own = 0.0;
     double pd = 1.0, psg = 1.0, px = 0.0;            // D, σ, x of the pivot lane (wave-uniform)
     if (!kWood && k_begin < k_end) {
-      const double rowv = Tab<NT>::get_dyn(k_begin);
+      const double rowv = MKH_TAB<NT>::get_dyn(ts, k_begin);
       own = (lane == k_begin) ? 0.0 : rowv;
       wave_sync();                                   // earlier readers of the buffer are done
       bufc[lane] = own;
@@ -1502,9 +1666,10 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     }
     for (int k = k_begin; !kWood && k < k_end; ++k) {
       MKH_MARK("p0_iter_begin");
+      MKH_TAB<NT>::touch(ts);
       MKH_LAP0();
       wave_sync();
-      Tab<NT>::rank1_prefetch(lds_addr(bufc));
+      MKH_TAB<NT>::rank1_prefetch(ts, lds_addr(bufc));
       MKH_LAP(0);
       if (!((kWood ? -pd : pd) > 0.0)) { status |= 4; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break; }
       const double inv = fast_rcp(pd);
@@ -1524,7 +1689,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       double own_next = 0.0;
       const int kn = (k + 1 < k_end) ? k + 1 : k;                      // (last pivot: a harmless re-publication of column k)
       {
-        const double rn = Tab<NT>::get_dyn(kn);                        // R[kn][lane] before update k
+        const double rn = MKH_TAB<NT>::get_dyn(ts, kn);                        // R[kn][lane] before update k
         const double cn = bufc[kn];                                    // R[kn][k] (broadcast)
         own_next = (lane == kn) ? 0.0 : fma(cn, -g, rn);               // the same FMA the update applies to row kn
         pd = readlane_f64(s.D, kn); psg = readlane_f64(s.sg, kn); px = readlane_f64(s.x, kn);
@@ -1534,9 +1699,9 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         // dof rows the pivot column reaches: [0, hb)
         const unsigned long long nzd = __ballot(own != 0.0) & ((1ull << NR) - 1ull);
         const int hb = nzd ? 64 - __builtin_clzll(nzd) : 0;
-        rank1_split_rows<NT, NR>(lds_addr(bufc), -g, hb, pub_addr, own_next);
+        rank1_split_rows<NT, NR>(ts, lds_addr(bufc), -g, hb, pub_addr, own_next);
       } else {
-        Tab<NT>::rank1_body_pub(lds_addr(bufc), -g, pub_addr, own_next);   // R[i][lane] −= R[i][k]·g   (row k: published 0)
+        MKH_TAB<NT>::rank1_body_pub(ts, lds_addr(bufc), -g, pub_addr, own_next);   // R[i][lane] −= R[i][k]·g   (row k: published 0)
       }
       MKH_LAP(1);
       double* t = bufc; bufc = bufn; bufn = t;
@@ -1565,9 +1730,10 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       // one flip: clamp a basic dof k onto its violated bound (kb) / release a bound dof k into the basis
       auto flip = [&](int k, bool kb, bool up) {
         PivotScalars ps;
+        MKH_TAB<NT>::touch(ts);
         MKH_LAP0();
-        const double own = publish_column<NT, true>(s, k, lane, sPiv, ps, nact, 1.0);
-        Tab<NT>::rank1_prefetch(lds_addr(sPiv));
+        const double own = publish_column<NT, true>(ts, s, k, lane, sPiv, ps, nact, 1.0);
+        MKH_TAB<NT>::rank1_prefetch(ts, lds_addr(sPiv));
         MKH_LAP(3);
         if (__ballot(!((kb ? -ps.d : ps.d) > 0.0))) { status |= 4; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return; }
         const double inv = fast_rcp(ps.d);
@@ -1581,7 +1747,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         }
         ++n_piv;
         MKH_LAP(4);
-        pivot<NT, NR>(s, k, kb, lane, sPiv, own, ps, inv);
+        pivot<NT, NR>(ts, s, k, kb, lane, sPiv, own, ps, inv);
         MKH_LAP(5);
       };
       int best = 4 * kWave;
@@ -1624,6 +1790,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     const double inv_rown = (kRows && rown > 0.0) ? fast_rcp(rown) : 0.0;
     while (need_gi && !(status & 14)) {
       MKH_MARK("gi_iter_begin");
+      MKH_TAB<NT>::touch(ts);
       ++n_loop;
       MKH_LAP0();
       int col;
@@ -1652,8 +1819,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       MKH_MARK("gi_publish");
       PivotScalars ps;
       MKH_LAP(2);
-      const double own = publish_column<NT, true>(s, col, lane, sPiv, ps, nact, rown);
-      Tab<NT>::rank1_prefetch(lds_addr(sPiv));
+      const double own = publish_column<NT, true>(ts, s, col, lane, sPiv, ps, nact, rown);
+      MKH_TAB<NT>::rank1_prefetch(ts, lds_addr(sPiv));
       MKH_LAP(3);
       const double inv = fast_rcp(ps.d);                         // 1 / T[col][col]
       bool rev = false;
@@ -1714,7 +1881,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       MKH_MARK("gi_pivot");
       ++n_piv;
       MKH_LAP(4);
-      pivot<NT, NR>(s, col, rev, lane, sPiv, own, ps, inv);
+      pivot<NT, NR>(ts, s, col, rev, lane, sPiv, own, ps, inv);
       MKH_LAP(5);
     }
     // Δq of this dof: the free value when basic, else the bound it sits on

@@ -6,6 +6,7 @@
 #include "../../include/minkhip.h"
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cmath>
 #include <cstdarg>
@@ -77,12 +78,15 @@ struct MkhProblem {
   // feature-rich variants (taps / ComTask / collisions / RelativeFrameTask) need the compiler's full VGPR
   // budget: they never use the high-occupancy register maps of NT ≤ 24 (ik_kernel.h MKH_WAVES)
   int nt_full = 8, lds_bytes_full = 0;
+  // 3-waves-per-SIMD register map + compact LDS layout (ik_kernel.h MKH_W3; variants without collision rows):
+  // LDS bytes per wavefront, 0 when no such variant is compiled for this tableau size or it would not reach 12 waves per CU
+  int lds_bytes_w3 = 0;
   bool has_relative = false;
   bool simple_pairs = false;       // every collision pair is plane / sphere / capsule (F_SIMPLE_COLL variants)
   // low-rank ("Woodbury") start of the QP (ik_kernel.h F_WOOD): compiled (NT, NR) pair or 0 when the
   // problem does not qualify; lower bound of the diagonal part of H without the damping argument, and
   // the largest squared task cost (conditioning gate, evaluated per call because damping is a call argument)
-  int wood_nt = 0, wood_nr = 0, wood_lds_bytes = 0;
+  int wood_nt = 0, wood_nr = 0, wood_lds_bytes = 0, wood_lds_bytes_w3 = 0;
   double wood_min_diag = 0.0, wood_max_cost2 = 0.0;
   // lane-per-problem kernel for small arms (lane_kernel.h): template size (0 = the problem does not qualify)
   int lane_nv = 0, lane_lds = 0;
@@ -110,7 +114,7 @@ struct MkhProblem {
 // variant_<NT>_<FEAT>.hip per compiled combination so that they build in parallel); this is the
 // generated dispatcher.
 namespace mkh {
-int launch_variant(int nt, int nr, int feat, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
+int launch_variant(int nt, int nr, int feat, bool w3, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
                    const SolveArgs& a, const TapArgs* taps);
 int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);
 }
@@ -221,9 +225,9 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
 
 // Resident wavefronts per CU of a kernel variant: bounded by LDS (160 KiB/CU) and by the register map the
 // variant was built for (4 waves/SIMD for NT ≤ 8, 3 for NT ≤ 24, else 2 — ik_kernel.h MKH_WAVES).
-static int waves_per_cu(int nt, int lds_bytes) {
+static int waves_per_cu(int nt, int lds_bytes, bool w3 = false) {
   const int by_lds = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
-  const int by_regs = 4 * (nt <= 8 ? 4 : (nt <= 24 ? 3 : 2));
+  const int by_regs = 4 * (nt <= 8 ? 4 : ((nt <= 24 || w3) ? 3 : 2));
   const int w = by_lds < by_regs ? by_lds : by_regs;
   return w < 1 ? 1 : w;
 }
@@ -619,6 +623,19 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   p->blocks_per_cu = waves_per_cu(p->nt, p->lds_bytes);
   p->lds_bytes_full = lds_of(p->nt_full, P.prefetch != 0);
   if (p->blocks_per_cu < 1) p->blocks_per_cu = 1;
+  // 3 waves per SIMD: tableau sizes with a TabW3 map (build.py W3), no half-space rows (the compact layout lets the
+  // Jacobian rows reuse the body poses, which the collision phase still reads), and 12 wavefronts' LDS must fit the CU
+  P.prefetch_w3 = 0;
+  if (p->nt == 44 && P.max_rows == 0 && P.n_dense_rows == 0) {
+    auto lds_w3 = [&](bool pre) {
+      return lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, j_stride_direct(P.nv, p->nt), 0,
+                        pre, 0, true).total * (int)sizeof(double);
+    };
+    if (waves_per_cu(p->nt, lds_w3(false), true) == 12) {
+      P.prefetch_w3 = waves_per_cu(p->nt, lds_w3(true), true) == 12 ? 1 : 0;
+      p->lds_bytes_w3 = lds_w3(P.prefetch_w3 != 0);
+    }
+  }
   // ---- direct start: Jacobian columns by (task, dof) pair lanes when they fit one wavefront
   P.n_dpairs = 0;
   {
@@ -635,16 +652,17 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     if (fits) P.n_dpairs = n;
   }
   if (P.n_jrows > 0 && P.n_pairs == 0 && P.n_com == 0 && !p->has_relative && P.n_dense_rows == 0 &&
-      P.n_dense_limit_rows == 0 && 2 * P.n_jrows <= m->nv &&
-      m->nv + P.n_jrows <= kWave) {
-    static const int kWoodVariants[][2] = {{32, 16}, {32, 24}, {48, 24}, {48, 32}, {64, 32}, {62, 44}, {64, 44}, {64, 48}};
-    for (const auto& v : kWoodVariants)
-      if (m->nv <= v[1] && v[1] + P.n_jrows <= v[0]) { p->wood_nt = v[0]; p->wood_nr = v[1]; break; }
+      P.n_dense_limit_rows == 0 && 2 * P.n_jrows <= m->nv && P.n_jrows <= kMu) {
+    // (NT = NR: the task residuals are eliminated outside the tableau, one column of [S | Jh | w] per lane — wood_start)
+    static const int kWoodVariants[] = {16, 24, 32, 44, 48};
+    for (int v : kWoodVariants)
+      if (m->nv <= v && v + P.n_jrows + 1 <= kWave) { p->wood_nt = v; p->wood_nr = v; break; }
     if (p->wood_nt) {
-      const LdsLayout Lw = lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows,
-                                      p->wood_nt - p->wood_nr + 1, p->wood_nr,
-                                      wood_s_aliases_dof(P.nv, P.n_jrows, p->wood_nt - p->wood_nr) ? 0 : P.n_jrows * (p->wood_nt - p->wood_nr + 1),
-                                      P.prefetch != 0, kBlkLds);
+      auto lds_wood = [&](bool pre, bool compact) {
+        return lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, kMu + 1, p->wood_nr,
+                          wood_s_aliases_dof(P.nv, P.n_jrows, kMu) ? 0 : P.n_jrows * (kMu + 1), pre, 0, compact, true);
+      };
+      const LdsLayout Lw = lds_wood(P.prefetch != 0, false);
       // (column, row-chunk) lanes of the Jh·Jhᵀ product: rows 0..n_jrows (the last one is the rhs)
       const int groups = kWave / P.n_jrows;
       P.wood_rpc = (P.n_jrows + 1 + groups - 1) / groups;
@@ -672,6 +690,14 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       }
       p->wood_lds_bytes = Lw.total * (int)sizeof(double);
       if (p->wood_lds_bytes * 8 > 160 * 1024) p->wood_nt = 0;      // would cost residency
+      // 3 waves per SIMD (compact layout: the Jacobian rows overwrite the task blocks, so the pair lanes need one pass)
+      P.prefetch_w3w = 0;
+      if (p->wood_nt == 44 && P.n_jpairs <= kWave) {
+        if (waves_per_cu(44, lds_wood(false, true).total * (int)sizeof(double), true) == 12) {
+          P.prefetch_w3w = waves_per_cu(44, lds_wood(true, true).total * (int)sizeof(double), true) == 12 ? 1 : 0;
+          p->wood_lds_bytes_w3 = lds_wood(P.prefetch_w3w != 0, true).total * (int)sizeof(double);
+        }
+      }
       double mn = __builtin_huge_val();
       for (int i = 0; i < m->nv; ++i) {
         double dsum = 0.0;
@@ -726,8 +752,12 @@ static int grid_for(const MkhProblem* p, int B) {
   int g = p->model->num_cus * p->blocks_per_cu;
   return B < g ? B : g;
 }
-static int grid_for_variant(const MkhProblem* p, int B, int nt, int lds) {
-  int g = p->model->num_cus * waves_per_cu(nt, lds);
+static int grid_for_variant(const MkhProblem* p, int B, int nt, int lds, bool w3 = false) {
+  int wpc = waves_per_cu(nt, lds, w3);
+  // diagnostic: cap the resident waves per CU (occupancy experiments); never raises it
+  static const int dbg = getenv("MKH_DEBUG_WAVES_PER_CU") ? atoi(getenv("MKH_DEBUG_WAVES_PER_CU")) : 0;
+  if (dbg > 0 && dbg < wpc) wpc = dbg;
+  int g = p->model->num_cus * wpc;
   return B < g ? B : g;
 }
 
@@ -798,9 +828,18 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
     nt = p->wood_nt; nr = p->wood_nr; lds = p->wood_lds_bytes;
     feat = F_WOOD | (need & (F_STEPS | F_TAPS));
   }
-  const int grid = grid_for_variant(p, a.B, nt, lds);
+  // three resident waves per SIMD where a variant exists (FrameTask / PostureTask / RelativeFrameTask / ComTask, box limits)
+  static const int kW3Variants[][2] = {{44, 0}};
+  bool w3 = false;
+  if (!nr && p->lds_bytes_w3 && !(flags & MKH_FLAG_TWO_WAVES))
+    for (const auto& v : kW3Variants) w3 = w3 || (v[0] == nt && v[1] == feat);
+  if (w3) lds = p->lds_bytes_w3;
+  if (nr == 44 && p->wood_lds_bytes_w3 && !(flags & MKH_FLAG_TWO_WAVES) && (feat == F_WOOD || feat == (F_WOOD | F_STEPS))) {
+    w3 = true; lds = p->wood_lds_bytes_w3;
+  }
+  const int grid = grid_for_variant(p, a.B, nt, lds, w3);
   p->last_grid = grid; p->last_lds = lds; p->last_nt = nt;
-  snprintf(p->last_kernel, sizeof(p->last_kernel), nr ? "ik_solve_kernel_%d_%d_r%d" : "ik_solve_kernel_%d_%d", nt, feat, nr);
+  snprintf(p->last_kernel, sizeof(p->last_kernel), nr ? (w3 ? "ik_solve_kernel_%d_%d_r%d_w3" : "ik_solve_kernel_%d_%d_r%d") : (w3 ? "ik_solve_kernel_%d_%d_w3" : "ik_solve_kernel_%d_%d"), nt, feat, nr);
   SolveArgs al = a;
   al.work_counter = p->d_work;
   // Distribution (ik_kernel.h): 7/8 of each wave's share is static — one contiguous row range per XCD — and the tail
@@ -811,7 +850,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   const int per_wave = a.B / grid;
   const bool dynamic = nt > 8 && per_wave >= 4;
   al.static_rounds = dynamic ? (per_wave * 7) / 8 : INT32_MAX;
-  if (mkh::launch_variant(nt, nr, feat, grid, lds, stream, p->d_dev, al, dtaps) != 0)
+  if (mkh::launch_variant(nt, nr, feat, w3, grid, lds, stream, p->d_dev, al, dtaps) != 0)
     return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
   HIP_OK(hipGetLastError());
   return MKH_OK;

@@ -84,6 +84,8 @@ struct DeviceProblem {
   int32_t n_dpairs;
   int16_t dpair_task[64], dpair_dof[64];
   int32_t nt;            // tableau rows per lane of the compiled kernel variant (row stride of the J rows)
+  int32_t prefetch_w3;   // the same decision for the 3-waves-per-SIMD variants (compact LDS layout), direct start
+  int32_t prefetch_w3w;  // ... and low-rank start
   int32_t prefetch;      // the next problem's q / targets are fetched into second LDS buffers (host: only if that costs no residency)
   int32_t robot_root;    // body 1 (ComTask subtree root)
   // model lane tables

@@ -95,7 +95,7 @@ def test_intermediates_and_velocity(nat, name):
     err2 = np.abs(v2 - d["v"]) / vs
     print(name, "production kernel", prob.last_kernel(), "max rel v err", err2.max())
     if name == "g1_c3":
-        assert prob.last_kernel().endswith("_32_r44"), prob.last_kernel()   # low-rank start, NT rows, 44 dof rows
+        assert prob.last_kernel().endswith("_32_r44_w3"), prob.last_kernel()   # low-rank start, 44 dof rows, 3 waves per SIMD
     assert (st2 == st).all()
     assert err2[main].max() < 1e-8 and err2[~main].max() < 1e-5
 

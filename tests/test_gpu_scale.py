@@ -40,9 +40,15 @@ def test_g1_full_batch_properties(g1_setup):
     # the tap call runs the full-feature kernel with the direct QP start, the plain call the lean kernel
     # with the low-rank start: same optimum, different elimination order
     v2, st2 = prob.solve(q, tg, stand[None, :], None, dt, damping)
-    assert prob.last_kernel().endswith("_r44"), prob.last_kernel()
+    assert prob.last_kernel() == "ik_solve_kernel_44_32_r44_w3", prob.last_kernel()   # low-rank start, 3 waves per SIMD
     assert (st2 == 0).all()
     assert np.abs(v2 - v).max() <= 1e-8 * max(1.0, np.abs(v).max())
+    # the same algorithm on the 2-waves register map (pre-QP phases inlined instead of called): bitwise equal or not,
+    # the optimum is the same
+    v2w, st2w = prob.solve(q, tg, stand[None, :], None, dt, damping, two_waves=True)
+    assert prob.last_kernel() == "ik_solve_kernel_44_32_r44", prob.last_kernel()
+    assert (st2w == 0).all()
+    assert np.abs(v2w - v2).max() <= 1e-9 * max(1.0, np.abs(v).max())
     # determinism + permutation equivariance (bitwise)
     v2b, _ = prob.solve(q, tg, stand[None, :], None, dt, damping)
     np.testing.assert_array_equal(v2, v2b)
@@ -51,7 +57,10 @@ def test_g1_full_batch_properties(g1_setup):
     np.testing.assert_array_equal(v3, v2[perm])
     # ... and the lean kernel with the direct start (MKH_FLAG_DIRECT_QP)
     v4, st4 = prob.solve(q, tg, stand[None, :], None, dt, damping, direct_qp=True)
+    assert prob.last_kernel() == "ik_solve_kernel_44_0_w3", prob.last_kernel()
+    v4w, st4w = prob.solve(q, tg, stand[None, :], None, dt, damping, direct_qp=True, two_waves=True)
     assert prob.last_kernel() == "ik_solve_kernel_44_0", prob.last_kernel()
+    np.testing.assert_array_equal(v4w, v4)                 # same arithmetic, different register map
     assert (st4 == 0).all()
     err = np.abs(v4 - v2).max() / max(1.0, np.abs(v).max())
     print("G1 B=65536: low-rank start vs direct start, max rel |dv| = %.2e" % err)

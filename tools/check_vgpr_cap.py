@@ -18,8 +18,16 @@ BUILD = os.path.join(REPO, "mink_amd", "csrc", "_build")
 
 
 def max_compiler_vgpr(asm_text: str) -> int:
-    mx, skip = -1, False
+    """Highest VGPR a compiler-generated instruction of the KERNEL touches.  The 3-waves-per-SIMD variants call real
+    functions (ik_kernel.h pre_phases, ...) that run while the tableau is dead and may use the whole register file: their
+    bodies (between `.type <name>,@function` and `.Lfunc_end`) are skipped unless the symbol is the kernel's."""
+    mx, skip, in_callee = -1, False, False
     for line in asm_text.split("\n"):
+        m = re.match(r"\s*\.type\s+(\S+),@function", line)
+        if m:
+            in_callee = "ik_solve_kernel" not in m.group(1)
+        if in_callee:
+            continue
         if "#ASMSTART" in line:
             skip = True
         if not skip and not line.lstrip().startswith((";", ".")):
@@ -38,14 +46,15 @@ def check(src: str):
     import build as hipbuild
     import gen_tab_asm as gen
     nt = int(re.search(r"variant_(\d+)_", os.path.basename(src)).group(1))
-    top = gen.total_for(nt)
-    cap = top - 2 * nt - gen.ntmp_for(nt)
+    top = 168 if os.path.basename(src).endswith("_w3.hip") else gen.total_for(nt)   # (TabW3: 3 waves per SIMD)
+    w3 = os.path.basename(src).endswith("_w3.hip")
+    cap = top - 2 * nt - (2 * ((nt + 15) // 16) if w3 else gen.ntmp_for(nt))
     out = subprocess.run([hipbuild._hipcc()] + hipbuild.FLAGS + hipbuild.KERNEL_FLAGS +
                          ["-S", "--cuda-device-only", "-o", "-", src], check=True, capture_output=True, text=True).stdout
     mx = max_compiler_vgpr(out)
     spills = re.findall(r"\.(sgpr|vgpr)_spill_count:\s+(\d+)", out)
-    scratch = re.search(r"ScratchSize: (\d+)", out)
-    return os.path.basename(src), cap, mx, dict(spills), int(scratch.group(1)) if scratch else -1
+    scratch = [int(x) for x in re.findall(r"ScratchSize: (\d+)", out)]     # (one per function: callees first)
+    return os.path.basename(src), cap, mx, dict(spills), max(scratch) if scratch else -1
 
 
 def main():
