@@ -372,7 +372,7 @@ def main():
         info = prob.launch_info(B)
         kernel = prob.last_kernel()
         nt = info["tableau_rows"]
-        waves_per_simd = 4 if nt <= 8 else (3 if nt <= 24 else 2)
+        waves_per_simd = 4 if nt <= 8 else (3 if (nt <= 24 or kernel.endswith("_w3")) else 2)   # (_w3: 168-register map)
         if kernel.startswith("ik_lane_kernel"):
             waves_per_simd = 2                            # lane_kernel.h: amdgpu_waves_per_eu(2, 2)
         traffic = measured_traffic(args.config, B)
