@@ -13,23 +13,22 @@ with literal register numbers:
     get_dyn(k) / set_dyn(k,x) single element, wave-uniform runtime index (VGPR index mode)
     get<I>() / set<I>(x)      single element, compile-time index (tableau build, taps)
 
-Two register maps (every primitive takes a `Regs&` first, an empty struct in the first map):
+Register maps (every primitive takes a `Regs&` first — an empty struct, kept so that call sites do not depend on the map):
 
-Tab<NT> — RESERVED range (wave64; TOP = 256 VGPRs per lane at 2 waves/SIMD, 168 at 3 (NT ≤ 24), 128 at 4 (NT ≤ 8)):
+Tab<NT> (wave64; TOP = 256 VGPRs per lane at 2 waves/SIMD, 168 at 3 (NT ≤ 24), 128 at 4 (NT ≤ 8)):
     v[TOP-2·NT, TOP)              tableau column (NT doubles): never allocated by the compiler (`amdgpu_num_vgpr` caps it
                                   below the range; asm clobbers make the range count towards the kernel's VGPR total)
-    v[TOP-2·NT-8, TOP-2·NT)       the pivot column in four 16-lane "planes" (S = 8 registers, see rank1 below)
+    v[TOP-2·NT-S, TOP-2·NT)       the pivot column in 16-lane "planes" (S = 8 registers, see rank1 below)
     v[0, TOP-2·NT-S)              everything the compiler allocates — through the WHOLE kernel, also where the tableau is dead
 
-TabW3<NT> — OPERAND range, TOP = 168 (3 waves/SIMD for tableaus of 32–44 rows):
-    v[160, 168)                   the planes, reserved above the cap as before
-    v[160-2·NT, 160)              tableau column, handed to every asm statement as "+{v[a:b]}" operands on 32/16/8-register
-                                  tuples (Regs): the compiler knows where the column is alive and where it is dead, so
-                                  forward kinematics, Lie algebra and Jacobian phases use all 160 registers and only the
-                                  QP runs in the 160 − 2·NT below the column.  (With the reserved map a 44-row tableau
-                                  left the compiler 72 registers for the whole kernel: 83–236 spilled VGPRs.)
-    Correctness does not rest on the compiler leaving the range alone between statements: it may move a tuple, the
-    operand constraints bring it back.  tools/check_vgpr_cap.py reports such moves (they would be slow, not wrong).
+TabW3<NT> (NT = 32 / 40 / 44): the same with TOP = 168, i.e. 3 waves/SIMD for the 44-row tableau of a humanoid, and S = two
+    registers per plane the column really has (6 for 44 rows).  That leaves the compiler 74 registers: enough for the QP
+    loops, far too few for forward kinematics / Lie algebra / Jacobian columns (83–236 spilled VGPRs when everything is
+    one function) — which therefore run as REAL function calls in these variants (ik_kernel.h pre_phases, wood_start):
+    a callee is not bound by the kernel's `amdgpu_num_vgpr` and may use the whole 168-register file, the tableau being
+    dead while it runs.  (Tried first and dropped: handing the column to the compiler as pinned "+{v[a:b]}" tuple
+    operands of every statement, or of fence statements only, so that it would know where the range is free — hipcc's
+    allocator splits and spills 1024-bit pinned tuples at the slightest pressure: 295–2171 spilled VGPRs.)
 
 The staging range must stay ABOVE the compiler's cap even though half of it is only live inside one asm
 statement: the VGPRs hipcc reserves for SGPR spills are the highest ones below the cap, reserved
@@ -42,7 +41,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 NTS = (8, 16, 24, 32, 40, 44, 48, 56, 62, 64)
-W3_NTS = (32, 40, 44)   # tableaus that also get the 3-waves-per-SIMD operand map (TabW3<NT>: TOP = 168)
+W3_NTS = (32, 40, 44)   # tableaus that also get the 3-waves-per-SIMD map (TabW3<NT>: TOP = 168)
 def total_for(nt):
     # VGPRs per lane = 512 / resident waves per SIMD: small tableaus leave room for 4 (NT ≤ 8) or 3 (NT ≤ 24)
     # waves per SIMD instead of 2 — more waves hide more of the serial pivot chain (UR5e-class arms)
@@ -59,80 +58,34 @@ def ntmp_for(nt):
 SPLIT_PREFIXES = (16, 24, 32)   # dof-row prefixes of the split rank-1 bodies (phase 0 of the low-rank start)
 
 
-def chunks_for(nregs):
-    """Tuple sizes (registers) that tile the tableau range of the operand map: 32 / 16 / 8 / 4 / 2."""
-    out = []
-    for size in (32, 16, 8, 4, 2):
-        while nregs >= size:
-            out.append(size)
-            nregs -= size
-    assert nregs == 0
-    return out
-
-
-def gen(nt: int, total: int = 0, name: str = "Tab", operand_map: bool = False, fence: bool = False) -> str:
+def gen(nt: int, total: int = 0, name: str = "Tab") -> str:
     NTMP = ntmp_for(nt)
     TOTAL = total or total_for(nt)
     if TOTAL == 168 and nt > 24:
         NTMP = 2 * ((nt + 15) // 16)         # 3-waves maps: only the planes the column has (44 rows: 3 planes, 6 registers)
-    if operand_map:
-        tmp0 = TOTAL - NTMP                  # planes at the top, reserved
-        t0 = tmp0 - 2 * nt                   # tableau below them, operands
-        budget = tmp0                        # the compiler's cap: everything below the planes
-    else:
-        t0 = TOTAL - 2 * nt
-        tmp0 = t0 - NTMP
-        budget = tmp0
+    t0 = TOTAL - 2 * nt
+    tmp0 = t0 - NTMP
+    budget = tmp0
     t1 = t0 + 2 * nt
     treg = lambda i: f"v[{t0 + 2 * i}:{t0 + 2 * i + 1}]"
     clob_tmp = ",".join(f'"v{r}"' for r in range(tmp0, tmp0 + NTMP))
-    if operand_map:
-        tuples, r = [], t0
-        for k, size in enumerate(chunks_for(2 * nt)):
-            tuples.append((f"r{k}", size, r))
-            r += size
-        clob_t = ""
+    clob_t = ",".join(f'"v{r}"' for r in range(t0, t1))
 
-        def tab_ops(write_only=False):
-            c = "=" if write_only else "+"
-            return ", ".join(f'"{c}{{v[{a}:{a + size - 1}]}}"(t.{nm})' for nm, size, a in tuples)
-    else:
-        clob_t = ",".join(f'"v{r}"' for r in range(t0, t1))
-
-    def stmt(body, outs="", ins="", clob="", write_only=False, indent="    ", is_fence=False):
-        """One asm statement.  outs / ins: operand lists with [names]; clob: further clobbers (besides the tableau range in
-        the reserved map)."""
-        if operand_map and fence and not (write_only or is_fence):
-            o, c = outs, clob          # fence map: ordinary statements do not mention the column at all
-        elif operand_map:
-            o = tab_ops(write_only) + (", " + outs if outs else "")
-            c = clob
-        else:
-            o = outs
-            c = ", ".join(x for x in (clob_t, clob) if x)
-        return f'{indent}asm volatile("{body}" : {o} : {ins} : {c});' if c else f'{indent}asm volatile("{body}" : {o} : {ins});'
+    def stmt(body, outs="", ins="", clob="", indent="    "):
+        """One asm statement.  outs / ins: operand lists with [names]; clob: further clobbers besides the tableau range."""
+        c = ", ".join(x for x in (clob_t, clob) if x)
+        return f'{indent}asm volatile("{body}" : {outs} : {ins} : {c});'
 
     J = "\\n\\t".join
     out = []
     out.append(f"template <> struct {name}<{nt}> {{")
     out.append(f"  static constexpr int kRows = {nt};")
     out.append(f"  static constexpr int kCompilerVgprs = {budget};")
-    if operand_map:
-        out.append("  // the tableau column as asm operands: tuples pinned to " + ", ".join(f"v[{a}:{a + s - 1}]" for _, s, a in tuples))
-        out.append("  struct Regs { " + " ".join(f"int __attribute__((ext_vector_type({s}))) {nm};" for nm, s, _ in tuples) + " };")
-    else:
-        out.append("  struct Regs {};   // (reserved map: the column is not a compiler-visible value)")
+    out.append("  struct Regs {};   // (the column is not a compiler-visible value)")
     # zero
     out.append("  __device__ static __forceinline__ void zero(Regs& t) {")
-    out.append(stmt(J(f"v_mov_b32 v{r}, 0" for r in range(t0, t1)), write_only=True))
+    out.append(stmt(J(f"v_mov_b32 v{r}, 0" for r in range(t0, t1))))
     out.append("  }")
-    if operand_map:
-        out.append("  // no instruction: tells the compiler that the column is (still) alive here")
-        out.append("  __device__ static __forceinline__ void touch(Regs& t) {")
-        out.append(stmt("", is_fence=True))
-        out.append("  }")
-    else:
-        out.append("  __device__ static __forceinline__ void touch(Regs&) {}")
     # rank1 = prefetch (the four plane loads) + body; the split lets the caller put the reciprocal / multiplier
     # arithmetic between them so that the LDS latency is hidden.
     nplanes = (nt + 15) // 16
@@ -185,10 +138,7 @@ def gen(nt: int, total: int = 0, name: str = "Tab", operand_map: bool = False, f
     out.append("    int lo, hi;")
     out.append("    const int idx = __builtin_amdgcn_readfirstlane(2 * k);")
     body = f"s_set_gpr_idx_on %[i], gpr_idx(SRC0)\\n\\tv_mov_b32 %[lo], v{t0}\\n\\tv_mov_b32 %[hi], v{t0 + 1}\\n\\ts_set_gpr_idx_off"
-    if operand_map:
-        out.append(stmt(body, outs='[lo] "=&v"(lo), [hi] "=&v"(hi)', ins='[i] "s"(idx)', clob='"m0"'))
-    else:
-        out.append(f'    asm volatile("{body}" : [lo] "=&v"(lo), [hi] "=&v"(hi) : [i] "s"(idx) : "m0");')
+    out.append(f'    asm volatile("{body}" : [lo] "=&v"(lo), [hi] "=&v"(hi) : [i] "s"(idx) : "m0");')
     out.append("    return __hiloint2double(hi, lo);")
     out.append("  }")
     # leading rows of a column from LDS (per-lane address): T[i] = lds[i], i < n
@@ -260,10 +210,7 @@ def gen(nt: int, total: int = 0, name: str = "Tab", operand_map: bool = False, f
     for i in range(nt):
         kw = "if" if i == 0 else "else if"
         body = f"v_mov_b32 %[lo], v{t0 + 2 * i}\\n\\tv_mov_b32 %[hi], v{t0 + 2 * i + 1}"
-        if operand_map:
-            out.append(f"    {kw} constexpr (I == {i}) {{ " + stmt(body, outs='[lo] "=v"(lo), [hi] "=v"(hi)', indent="") + " }")
-        else:
-            out.append(f'    {kw} constexpr (I == {i}) asm volatile("{body}" : [lo] "=v"(lo), [hi] "=v"(hi));')
+        out.append(f'    {kw} constexpr (I == {i}) asm volatile("{body}" : [lo] "=v"(lo), [hi] "=v"(hi));')
     out.append("    else { lo = 0; hi = 0; }")
     out.append("    return __hiloint2double(hi, lo);")
     out.append("  }")
@@ -272,10 +219,7 @@ def gen(nt: int, total: int = 0, name: str = "Tab", operand_map: bool = False, f
     for i in range(nt):
         kw = "if" if i == 0 else "else if"
         body = f"v_mov_b32 v{t0 + 2 * i}, %[lo]\\n\\tv_mov_b32 v{t0 + 2 * i + 1}, %[hi]"
-        if operand_map:
-            out.append(f"    {kw} constexpr (I == {i}) {{ " + stmt(body, ins='[lo] "v"(lo), [hi] "v"(hi)', indent="") + " }")
-        else:
-            out.append(f'    {kw} constexpr (I == {i}) asm volatile("{body}" :: [lo] "v"(lo), [hi] "v"(hi) : "v{t0 + 2 * i}", "v{t0 + 2 * i + 1}");')
+        out.append(f'    {kw} constexpr (I == {i}) asm volatile("{body}" :: [lo] "v"(lo), [hi] "v"(hi) : "v{t0 + 2 * i}", "v{t0 + 2 * i + 1}");')
     out.append("  }")
     out.append("};")
     return "\n".join(out)
@@ -304,11 +248,9 @@ def gen_wood_elim() -> str:
 
 def main():
     parts = ["// GENERATED by gen_tab_asm.py — do not edit.  Pinned-VGPR tableau primitives (see the generator's docstring).",
-             "#pragma once", "#include <hip/hip_runtime.h>", "namespace mkh {", "template <int NT> struct Tab;", "template <int NT> struct TabW3;",
-             "template <int NT> struct TabW3R;"]
+             "#pragma once", "#include <hip/hip_runtime.h>", "namespace mkh {", "template <int NT> struct Tab;", "template <int NT> struct TabW3;"]
     parts += [gen(nt) for nt in NTS]
-    parts += [gen(nt, 168, "TabW3", True, True) for nt in W3_NTS]
-    parts += [gen(nt, 168, "TabW3R") for nt in W3_NTS]     # reserved map at 168 registers (experiments)
+    parts += [gen(nt, 168, "TabW3") for nt in W3_NTS]
     parts.append(gen_wood_elim())
     parts.append("}  // namespace mkh")
     with open(os.path.join(HERE, "tab_asm.inc"), "w") as fh:

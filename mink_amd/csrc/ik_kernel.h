@@ -32,9 +32,7 @@
 
 // Register map of the tableau: Tab<NT> (2 resident waves per SIMD for NT > 24) or, in the variant TUs that define
 // MKH_W3, TabW3<NT> — the same primitives pinned below 168 VGPRs, i.e. 3 resident waves per SIMD.
-#if defined(MKH_W3) && defined(MKH_W3_RESERVED)
-#define MKH_TAB TabW3R
-#elif defined(MKH_W3)
+#ifdef MKH_W3
 #define MKH_TAB TabW3
 #else
 #define MKH_TAB Tab
@@ -917,11 +915,7 @@ __device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, double,
 #define MKH_WAVES (MKH_NT <= 8 ? 4 : (MKH_NT <= 24 ? 3 : 2))   // resident waves per SIMD the register map is built for
 #define MKH_TOP (MKH_NT <= 8 ? 128 : (MKH_NT <= 24 ? 168 : 256))  // VGPRs per lane at that occupancy (gen_tab_asm.py total_for)
 #endif
-#if defined(MKH_W3) && !defined(MKH_W3_RESERVED)   // operand map: the compiler owns everything below the planes, the column included (gen_tab_asm.py)
-#define MKH_CAP (MKH_TOP - MKH_STAGE)
-#else
 #define MKH_CAP (MKH_TOP - 2 * MKH_NT - MKH_STAGE)
-#endif
 #ifdef MKH_CAP_PROBE     // (pressure probing only: the code is wrong when the cap reaches into the pinned range)
 #undef MKH_CAP
 #define MKH_CAP MKH_CAP_PROBE
@@ -1301,8 +1295,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           for (int r = 0; r < 6; ++r)
             if ((rowmask >> r) & 1) { rank1_leading_rows<NT>(ts, lds_addr(sJ + c * JS), Jw[r], AS); ++c; }
         }
-        MKH_TAB<NT>::touch(ts);
-        continue;
+                continue;
       }
       if (t < P.n_frame) {
         const FrameTaskDev& ft = P.frame[t];
@@ -1666,8 +1659,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     }
     for (int k = k_begin; !kWood && k < k_end; ++k) {
       MKH_MARK("p0_iter_begin");
-      MKH_TAB<NT>::touch(ts);
-      MKH_LAP0();
+            MKH_LAP0();
       wave_sync();
       MKH_TAB<NT>::rank1_prefetch(ts, lds_addr(bufc));
       MKH_LAP(0);
@@ -1730,8 +1722,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       // one flip: clamp a basic dof k onto its violated bound (kb) / release a bound dof k into the basis
       auto flip = [&](int k, bool kb, bool up) {
         PivotScalars ps;
-        MKH_TAB<NT>::touch(ts);
-        MKH_LAP0();
+                MKH_LAP0();
         const double own = publish_column<NT, true>(ts, s, k, lane, sPiv, ps, nact, 1.0);
         MKH_TAB<NT>::rank1_prefetch(ts, lds_addr(sPiv));
         MKH_LAP(3);
@@ -1790,8 +1781,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     const double inv_rown = (kRows && rown > 0.0) ? fast_rcp(rown) : 0.0;
     while (need_gi && !(status & 14)) {
       MKH_MARK("gi_iter_begin");
-      MKH_TAB<NT>::touch(ts);
-      ++n_loop;
+            ++n_loop;
       MKH_LAP0();
       int col;
       if (pend >= 0) col = pend;
