@@ -712,6 +712,84 @@ __device__ MKH_PRE_ATTR PreOut pre_phases(const DeviceProblem* Pq, const TapArgs
   return po;
 }
 
+// Column `k` of frame task t's Jacobian (6 rows, unweighted): dof k must be on the chain of the frame (or of the
+// root frame of a RelativeFrameTask).  sTask / sDof: the task blocks and dof axes in LDS.
+template <bool kRel>
+__device__ __forceinline__ void frame_column_fn(const double* sTask, const double* sDof, int t, int k, uint64_t mask,
+                                                uint64_t rmask, bool rel, double (&Jt)[6]) {
+    const double* o = sTask + t * 64;
+    const double* kd = sDof + k * 10;
+    const V3 d_ang{kd[0], kd[1], kd[2]}, d_lin{kd[3], kd[4], kd[5]}, d_anchor{kd[6], kd[7], kd[8]};
+    V3 a{0, 0, 0}, w{0, 0, 0};
+    if ((mask >> k) & 1) {
+      V3 pf{o[27], o[28], o[29]};
+      V3 jp = d_lin + cross(d_ang, pf - d_anchor);
+      M3 Rf;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Rf.m[i] = o[18 + i];
+      a = mulT(Rf, jp); w = mulT(Rf, d_ang);             // body-frame Jacobian (configuration.py:148-153)
+    }
+    double sign = -1.0;                                   // FrameTask: J = −jlog(T_tb)·ᴮJ
+    if (kRel && rel) {
+      sign = 1.0;                                         // RelativeFrameTask: J = +jlog(T_tf)·(ᶠJ − Ad·ʳJ)
+      if ((rmask >> k) & 1) {
+        V3 pr{o[45], o[46], o[47]};
+        V3 jp = d_lin + cross(d_ang, pr - d_anchor);
+        M3 Rr, Rrf;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { Rr.m[i] = o[36 + i]; Rrf.m[i] = o[48 + i]; }
+        V3 ar = mulT(Rr, jp), wr = mulT(Rr, d_ang);       // root's body-frame column
+        V3 Rw = mul(Rrf, wr);                             // Ad(T_fr⁻¹) = [[R, [t]×R],[0, R]]
+        a = a - (mul(Rrf, ar) + cross(V3{o[57], o[58], o[59]}, Rw));
+        w = w - Rw;
+      }
+    }
+    // jlog = [[J, −J·Q·J],[0, J]]:  y = J·w;  rows 0-2 = ±J·(a − Q·y), rows 3-5 = ±y
+    const double wv[3] = {w.x, w.y, w.z};
+    double y[3], z3[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) y[r] = o[3 * r] * wv[0] + o[3 * r + 1] * wv[1] + o[3 * r + 2] * wv[2];
+    const double av[3] = {a.x, a.y, a.z};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      z3[r] = av[r] - (o[9 + 3 * r] * y[0] + o[9 + 3 * r + 1] * y[1] + o[9 + 3 * r + 2] * y[2]);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      Jt[r] = sign * (o[3 * r] * z3[0] + o[3 * r + 1] * z3[1] + o[3 * r + 2] * z3[2]);
+      Jt[3 + r] = sign * y[r];
+    }
+  }
+
+// Direct start: the Jacobian columns of EVERY frame task at once, one (task, dof) pair per lane — weighted rows of this
+// lane's pair.  A real call in the 3-waves-per-SIMD variants (see pre_phases).
+struct DirectPairs { double Jp[6]; int p_task, p_dof; };
+__device__ MKH_PRE_ATTR DirectPairs direct_pairs(const DeviceProblem* Pq) {
+  constexpr bool kRel = (MKH_FEAT & F_REL) != 0;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+#ifdef MKH_W3
+  Pq = reinterpret_cast<const DeviceProblem*>(uni((unsigned long long)reinterpret_cast<size_t>(Pq)));
+  const MKH_CONSTANT DeviceProblem& P = *(const MKH_CONSTANT DeviceProblem*)Pq;
+  const MKH_GLOBAL FrameTaskDev* const frames = (const MKH_GLOBAL FrameTaskDev*)P.frame;
+#else
+  const DeviceProblem& P = *Pq;
+  const FrameTaskDev* const frames = P.frame;
+#endif
+  const int lane = lane_id();
+  const LdsLayout L = kernel_lds_layout(P);
+  DirectPairs dp{{0, 0, 0, 0, 0, 0}, -1, 0};
+  if (lane < P.n_dpairs) {
+    dp.p_task = P.dpair_task[lane]; dp.p_dof = P.dpair_dof[lane];
+    const auto& ft = frames[dp.p_task];
+    const bool rel = kRel && ft.relative != 0;
+    double Jt[6];
+    frame_column_fn<kRel>(smem + L.task, smem + L.dof, dp.p_task, dp.p_dof, ft.dof_mask, rel ? ft.root_mask : 0ull, rel, Jt);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) dp.Jp[r] = ft.cost[r] * Jt[r];   // weighted_jacobian (task.py:129)
+  }
+  return dp;
+}
+
+
 #if (MKH_FEAT & 32)
 // ---------------------------------------------------------------- low-rank start of the QP (F_WOOD)
 // H = Dg + JwᵀJw with Dg diagonal (damping + Σ LM terms + posture tasks) and Jw the n_μ weighted frame-task rows.  With
@@ -1189,50 +1267,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         rank1_leading_rows<NT>(ts, lds_addr(sJ + r * NT), g, hb <= 16 ? 16 : (hb <= 24 ? 24 : (hb <= 32 ? 32 : NT)));
       }
     }
-    // Column `k` of frame task t's Jacobian (6 rows, unweighted): dof k must be on the chain of the frame (or of the
-    // root frame of a RelativeFrameTask).
     auto frame_column = [&](int t, int k, uint64_t mask, uint64_t rmask, bool rel, double (&Jt)[6]) {
-      const double* o = sTask + t * 64;
-      const double* kd = sDof + k * 10;
-      const V3 d_ang{kd[0], kd[1], kd[2]}, d_lin{kd[3], kd[4], kd[5]}, d_anchor{kd[6], kd[7], kd[8]};
-      V3 a{0, 0, 0}, w{0, 0, 0};
-      if ((mask >> k) & 1) {
-        V3 pf{o[27], o[28], o[29]};
-        V3 jp = d_lin + cross(d_ang, pf - d_anchor);
-        M3 Rf;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Rf.m[i] = o[18 + i];
-        a = mulT(Rf, jp); w = mulT(Rf, d_ang);             // body-frame Jacobian (configuration.py:148-153)
-      }
-      double sign = -1.0;                                   // FrameTask: J = −jlog(T_tb)·ᴮJ
-      if (kRel && rel) {
-        sign = 1.0;                                         // RelativeFrameTask: J = +jlog(T_tf)·(ᶠJ − Ad·ʳJ)
-        if ((rmask >> k) & 1) {
-          V3 pr{o[45], o[46], o[47]};
-          V3 jp = d_lin + cross(d_ang, pr - d_anchor);
-          M3 Rr, Rrf;
-#pragma unroll
-          for (int i = 0; i < 9; ++i) { Rr.m[i] = o[36 + i]; Rrf.m[i] = o[48 + i]; }
-          V3 ar = mulT(Rr, jp), wr = mulT(Rr, d_ang);       // root's body-frame column
-          V3 Rw = mul(Rrf, wr);                             // Ad(T_fr⁻¹) = [[R, [t]×R],[0, R]]
-          a = a - (mul(Rrf, ar) + cross(V3{o[57], o[58], o[59]}, Rw));
-          w = w - Rw;
-        }
-      }
-      // jlog = [[J, −J·Q·J],[0, J]]:  y = J·w;  rows 0-2 = ±J·(a − Q·y), rows 3-5 = ±y
-      const double wv[3] = {w.x, w.y, w.z};
-      double y[3], z3[3];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) y[r] = o[3 * r] * wv[0] + o[3 * r + 1] * wv[1] + o[3 * r + 2] * wv[2];
-      const double av[3] = {a.x, a.y, a.z};
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-        z3[r] = av[r] - (o[9 + 3 * r] * y[0] + o[9 + 3 * r + 1] * y[1] + o[9 + 3 * r + 2] * y[2]);
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        Jt[r] = sign * (o[3 * r] * z3[0] + o[3 * r + 1] * z3[1] + o[3 * r + 2] * z3[2]);
-        Jt[3 + r] = sign * y[r];
-      }
+      frame_column_fn<kRel>(sTask, sDof, t, k, mask, rmask, rel, Jt);
     };
     // Direct start, production variants: the columns of EVERY frame task at once, one (task, dof) pair per lane (the
     // per-task loop below used to compute them task after task on the dof lanes: n_frame dependent passes of ≈150
@@ -1240,14 +1276,12 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     const bool pair_path = !kWood && !kTaps && P.n_dpairs > 0;
     int p_task = -1, p_dof = 0;
     double Jp[6] = {0, 0, 0, 0, 0, 0};                      // weighted rows of this lane's pair
-    if (pair_path && lane < P.n_dpairs) {
-      p_task = P.dpair_task[lane]; p_dof = P.dpair_dof[lane];
-      const FrameTaskDev& ft = P.frame[p_task];
-      const bool rel = kRel && ft.relative != 0;
-      double Jt[6];
-      frame_column(p_task, p_dof, ft.dof_mask, rel ? ft.root_mask : 0ull, rel, Jt);
+    if (pair_path) {
+      const DirectPairs dp = direct_pairs(Pq);
+      asm volatile("" : "+v"(lane));
+      p_task = dp.p_task; p_dof = dp.p_dof;
 #pragma unroll
-      for (int r = 0; r < 6; ++r) Jp[r] = ft.cost[r] * Jt[r];   // weighted_jacobian (task.py:129)
+      for (int r = 0; r < 6; ++r) Jp[r] = dp.Jp[r];
     }
     if constexpr (!kWood) { if (pair_path) MKH_TAB<NT>::zero(ts); }
     for (int t = 0; t < (kWood ? 0 : n_jt); ++t) {

@@ -829,7 +829,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
     feat = F_WOOD | (need & (F_STEPS | F_TAPS));
   }
   // three resident waves per SIMD where a variant exists (FrameTask / PostureTask / RelativeFrameTask / ComTask, box limits)
-  static const int kW3Variants[][2] = {{44, 0}};
+  static const int kW3Variants[][2] = {{44, 0}};   // (44_6 and 44_16 still spill 34–76 VGPRs at 74 registers: scratch traffic makes them slower than their 2-waves builds)
   bool w3 = false;
   if (!nr && p->lds_bytes_w3 && !(flags & MKH_FLAG_TWO_WAVES))
     for (const auto& v : kW3Variants) w3 = w3 || (v[0] == nt && v[1] == feat);
