@@ -138,9 +138,11 @@ typedef struct MkhVelocityLimitDesc {
 /* mink.CollisionAvoidanceLimit(model, geom_pairs, gain, minimum_distance_from_collisions,
  * collision_detection_distance, bound_relaxation) — mink/limits/collision_avoidance_limit.py:145-185;
  * geom_id_pairs is the constructor's filtered (min,max) id list (:253-278).
- * Distance routines behind mj_geomDistance (:219): plane/sphere/capsule among themselves, box against
- * plane/sphere/capsule/box, cylinder against plane/sphere/capsule; any other pair type fails mkh_problem_create
- * with MKH_E_INVALID (cylinder–box/cylinder, ellipsoid, mesh: MuJoCo uses libccd there). */
+ * Distance routines behind mj_geomDistance (:219): analytic for plane/sphere/capsule among themselves, box against
+ * plane/sphere/capsule/box, cylinder against plane/sphere/capsule, plane–ellipsoid; every other pair of the convex
+ * primitives sphere / capsule / ellipsoid / cylinder / box (cylinder–box, cylinder–cylinder, ellipsoid–*) through a
+ * general convex distance routine (GJK on support mappings — MuJoCo uses libccd there).  Mesh and height-field geoms
+ * fail mkh_problem_create with MKH_E_INVALID. */
 typedef struct MkhCollisionLimitDesc {
   int32_t n_pairs;
   const int32_t *geom_id_pairs /*n_pairs*2*/;

@@ -10,10 +10,11 @@
 // pair is not unique (an edge parallel to a face) the tie rule is ours and is documented at the routine.
 #pragma once
 #include "lie_dev.h"
+#include "convex_dev.h"
 
 namespace mkh {
 
-enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_CYLINDER = 5, GEOM_BOX = 6 };
+enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_ELLIPSOID = 4, GEOM_CYLINDER = 5, GEOM_BOX = 6 };
 
 struct Contact { double dist; V3 pos; V3 n; bool hit; };
 
@@ -342,7 +343,9 @@ __device__ __forceinline__ Contact to_world(Contact k, const M3& R, V3 o) {
 // SIMPLE: only planes, spheres and capsules can occur (checked on the host for the whole pair list) — the box and
 // cylinder routines are not even compiled in: the capsule-only Shadow-hand variant needs a fraction of the registers
 // (62 spilled VGPRs → 0) and a seventh of the instructions of the general collision phase.
-template <bool SIMPLE = false>
+// CONVEX: the pair list contains pairs without an analytic routine (cylinder–box, cylinder–cylinder, ellipsoid–*): the
+// general convex routine of convex_dev.h is compiled in (its own kernel variants: it costs registers and scratch).
+template <bool SIMPLE = false, bool CONVEX = false>
 __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t2, V3 s2, V3 p2, Q4 q2,
                                               double distmax, double& dist, V3& from, V3& to) {
   const bool flip = t1 > t2;
@@ -389,6 +392,14 @@ __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t
       for (int j = 0; j < 3; ++j)
         Rab.m[3 * i + j] = R2.m[i] * R1.m[j] + R2.m[3 + i] * R1.m[3 + j] + R2.m[6 + i] * R1.m[6 + j];
     c = to_world(box_box_local(mulT(R2, p1 - p2), Rab, s1, s2, distmax), R2, p2);
+  } else if (CONVEX && t1 == GEOM_PLANE && t2 == GEOM_ELLIPSOID) {
+    // lowest point of the ellipsoid: its support point against the plane normal
+    const V3 e = vmulc(s2, mulT(R2, z1));
+    const V3 pt = p2 - (1.0 / sqrt(dot(e, e))) * mul(R2, vmulc(s2, e));
+    c.dist = dot(z1, pt - p1); c.hit = c.dist <= distmax; c.n = z1; c.pos = pt - (0.5 * c.dist) * z1;
+  } else if (CONVEX && t1 >= GEOM_SPHERE && t1 <= GEOM_BOX && t2 >= GEOM_SPHERE && t2 <= GEOM_BOX) {
+    const ConvexGeom g1{t1, s1, p1, R1}, g2{t2, s2, p2, R2};
+    c.hit = cvx_distance(g1, g2, distmax, c.dist, c.pos, c.n);
   } else {
     dist = distmax; from = {0, 0, 0}; to = {0, 0, 0};
     return false;

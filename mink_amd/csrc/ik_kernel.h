@@ -300,7 +300,7 @@ constexpr bool kTapIsProf_t_xpos = false, kTapIsProf_t_xquat = false, kTapIsProf
                kTapIsProf_t_H = false, kTapIsProf_t_c = false, kTapIsProf_t_box_lo = false, kTapIsProf_t_box_hi = false,
                kTapIsProf_t_coll_G = false, kTapIsProf_t_coll_h = false, kTapIsProf_t_qp_iters = true,
                kTapIsProf_t_cycles = true;
-enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL = 31, F_WOOD = 32, F_SIMPLE_COLL = 64 };
+enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL = 31, F_WOOD = 32, F_SIMPLE_COLL = 64, F_CONVEX_COLL = 128 };
 
 // P lives in device memory (not in the kernarg segment): hipcc materialises every by-value kernel
 // argument field in SGPRs at kernel entry and keeps it there, which starved the QP loop of SGPRs
@@ -1009,6 +1009,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   // feature (FEAT 30 / 31) — it is the general path, not a tuned one
   constexpr bool kDense = (FEAT & (F_ALL & ~F_TAPS)) == (F_ALL & ~F_TAPS) && !kWood;
   constexpr bool kSimpleColl = (FEAT & F_SIMPLE_COLL) != 0;     // every collision pair is plane / sphere / capsule
+  // pairs without an analytic routine (convex_dev.h): their own collision variants, and the all-feature ones
+  constexpr bool kConvexColl = (FEAT & F_CONVEX_COLL) != 0 || (FEAT & (F_ALL & ~F_TAPS)) == (F_ALL & ~F_TAPS);
 #ifdef MKH_NR
   constexpr int NR = MKH_NR;                 // dof rows of the tableau (low-rank start: NR ≥ nv, NT ≥ nv + n_μ)
 #else
@@ -1461,7 +1463,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       Q4 gq1 = qmul(bq1, Q4{cp.lquat1[0], cp.lquat1[1], cp.lquat1[2], cp.lquat1[3]});
       Q4 gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
       double dist;
-      geom_distance<kSimpleColl>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
+      geom_distance<kSimpleColl, kConvexColl>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
                     V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to);
       const bool active = dist != cp.ddetect;                  // Contact.inactive (:52-56)
       hk = kInf;

@@ -83,6 +83,7 @@ struct MkhProblem {
   int lds_bytes_w3 = 0;
   bool has_relative = false;
   bool simple_pairs = false;       // every collision pair is plane / sphere / capsule (F_SIMPLE_COLL variants)
+  bool convex_pairs = false;       // some pair has no analytic routine: general convex distance (F_CONVEX_COLL variants)
   // low-rank ("Woodbury") start of the QP (ik_kernel.h F_WOOD): compiled (NT, NR) pair or 0 when the
   // problem does not qualify; lower bound of the diagonal part of H without the damping argument, and
   // the largest squared task cost (conditioning gate, evaluated per call because damping is a call argument)
@@ -560,14 +561,24 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       CollisionPairDev cp;
       memset(&cp, 0, sizeof cp);
       int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
-      auto supported = [](int a, int b) {
+      // pairs with an analytic routine (collide_dev.h) ...
+      auto analytic = [](int a, int b) {
         if (a > b) { int x = a; a = b; b = x; }
         return (a == GEOM_CAPSULE && b == GEOM_CAPSULE) || (a == GEOM_SPHERE && b == GEOM_SPHERE) ||
                (a == GEOM_SPHERE && b == GEOM_CAPSULE) || (a == GEOM_PLANE && (b == GEOM_SPHERE || b == GEOM_CAPSULE)) ||
                (b == GEOM_BOX && (a == GEOM_PLANE || a == GEOM_SPHERE || a == GEOM_CAPSULE || a == GEOM_BOX)) ||
                (b == GEOM_CYLINDER && (a == GEOM_PLANE || a == GEOM_SPHERE || a == GEOM_CAPSULE));
       };
-      if (!supported(t1, t2)) return bail(fail(MKH_E_INVALID, "collision pair (%d,%d): geom types (%d,%d) have no analytic distance routine yet", g1, g2, t1, t2));
+      // ... and the ones that go through the general convex routine (convex_dev.h): cylinder–box, cylinder–cylinder,
+      // ellipsoid against any primitive
+      auto convex = [](int a, int b) {
+        if (a > b) { int x = a; a = b; b = x; }
+        const bool cb = b == GEOM_SPHERE || b == GEOM_CAPSULE || b == GEOM_ELLIPSOID || b == GEOM_CYLINDER || b == GEOM_BOX;
+        return cb && (a == GEOM_PLANE ? b == GEOM_ELLIPSOID : (a >= GEOM_SPHERE && a <= GEOM_BOX));
+      };
+      auto supported = [&](int a, int b) { return analytic(a, b) || convex(a, b); };
+      if (!analytic(t1, t2) && convex(t1, t2)) p->convex_pairs = true;
+      if (!supported(t1, t2)) return bail(fail(MKH_E_INVALID, "collision pair (%d,%d): geom types (%d,%d) are not supported (meshes, height fields)", g1, g2, t1, t2));
       cp.type1 = t1; cp.type2 = t2; cp.body1 = m->geom_bodyid[g1]; cp.body2 = m->geom_bodyid[g2];
       for (int i = 0; i < 3; ++i) { cp.size1[i] = m->geom_size[3 * g1 + i]; cp.size2[i] = m->geom_size[3 * g2 + i];
                                     cp.lpos1[i] = m->geom_pos[3 * g1 + i]; cp.lpos2[i] = m->geom_pos[3 * g2 + i]; }
@@ -811,7 +822,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   int feat;
   if (need == 0) feat = 0;
   else if (need == F_STEPS) feat = F_STEPS;
-  else if (need == F_COLL) feat = p->simple_pairs ? (F_COLL | F_SIMPLE_COLL) : F_COLL;
+  else if (need == F_COLL) feat = p->simple_pairs ? (F_COLL | F_SIMPLE_COLL) : (p->convex_pairs ? (F_COLL | F_CONVEX_COLL) : F_COLL);
   else if ((need & ~(F_REL | F_COM)) == 0) feat = F_REL | F_COM;      // box limits only: keeps the block-pivoting active set
   else feat = (need & F_TAPS) ? F_ALL : (F_ALL & ~F_TAPS);
   const bool rich = (feat & (F_ALL & ~F_STEPS)) != 0;

@@ -1,0 +1,226 @@
+"""TEST INFRASTRUCTURE — distance between two convex primitives by GJK on support mappings.
+
+MuJoCo's mj_geomDistance (called at mink/limits/collision_avoidance_limit.py:214-229) sends every pair without a native
+analytic routine — cylinder–box, cylinder–cylinder, ellipsoid against anything but a plane — to its general convex
+collider (libccd in the pinned mujoco >= 3.1.6: MPR on the shapes inflated by half the margin each, tolerance 1e-6).  The
+wheel is absent here, so this is not a restatement of libccd but of the quantity it approximates: the Euclidean distance
+between the two convex sets and its witness points (Gilbert–Johnson–Keerthi 1988, closest-point sub-algorithm after
+Ericson, Real-Time Collision Detection §5.1): the distance of separated shapes to ~1e-13 relative, witness points and
+normal to ~1e-7 (the support-gap test |v|² − v·w ≤ 1e-14·|v|² bounds the angle of v by its square root).  Spheres and capsules enter as their
+core (point / segment) plus a radius.  Overlapping shapes: the penetration depth min_|d|=1 h_{A⊖B}(d) by projected
+descent on the sphere from the best of the centre-to-centre direction and the shapes' axes — a local minimum (libccd's MPR is an approximation there
+too); mink only uses the sign of such a distance (h = bound_relaxation) and the direction.
+
+tests/test_oracle_gjk.py pins the separated case against bounded minimisation over both shapes (scipy).
+"""
+
+import numpy as np
+
+GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX = 0, 2, 3, 4, 5, 6
+MAX_ITERS = 128
+
+
+def core_radius(gtype, size):
+    """Radius of the spherical shell around the core the support mapping describes."""
+    return float(size[0]) if gtype in (GEOM_SPHERE, GEOM_CAPSULE) else 0.0
+
+
+def support_local(gtype, size, d):
+    """Support point of the CORE of a primitive in its own frame: argmax_x d·x."""
+    if gtype == GEOM_SPHERE:
+        return np.zeros(3)
+    if gtype == GEOM_CAPSULE:
+        return np.array([0.0, 0.0, size[1] if d[2] >= 0.0 else -size[1]])
+    if gtype == GEOM_BOX:
+        return np.array([size[i] if d[i] >= 0.0 else -size[i] for i in range(3)])
+    if gtype == GEOM_CYLINDER:
+        n = np.hypot(d[0], d[1])
+        z = size[1] if d[2] >= 0.0 else -size[1]
+        if n < 1e-300:
+            return np.array([0.0, 0.0, z])
+        return np.array([size[0] * d[0] / n, size[0] * d[1] / n, z])
+    if gtype == GEOM_ELLIPSOID:
+        e = np.array([size[0] * d[0], size[1] * d[1], size[2] * d[2]])
+        n = np.sqrt(e @ e)
+        if n < 1e-300:
+            return np.array([size[0], 0.0, 0.0])
+        return np.array([size[0] * e[0], size[1] * e[1], size[2] * e[2]]) / n
+    raise NotImplementedError(gtype)
+
+
+def support(gtype, size, pos, R, d):
+    return pos + R @ support_local(gtype, size, R.T @ d)
+
+
+def _closest_segment(P):
+    a, b = P
+    ab = b - a
+    den = ab @ ab
+    t = 0.0 if den <= 0.0 else -(a @ ab) / den
+    if t <= 0.0:
+        return [0], [1.0]
+    if t >= 1.0:
+        return [1], [1.0]
+    return [0, 1], [1.0 - t, t]
+
+
+def _closest_triangle(P):
+    """Ericson 5.1.5 with the origin as the query point: (indices kept, barycentric weights)."""
+    a, b, c = P
+    ab, ac = b - a, c - a
+    d1, d2 = -(ab @ a), -(ac @ a)
+    if d1 <= 0.0 and d2 <= 0.0:
+        return [0], [1.0]
+    d3, d4 = -(ab @ b), -(ac @ b)
+    if d3 >= 0.0 and d4 <= d3:
+        return [1], [1.0]
+    vc = d1 * d4 - d3 * d2
+    if vc <= 0.0 and d1 >= 0.0 and d3 <= 0.0:
+        v = d1 / (d1 - d3)
+        return [0, 1], [1.0 - v, v]
+    d5, d6 = -(ab @ c), -(ac @ c)
+    if d6 >= 0.0 and d5 <= d6:
+        return [2], [1.0]
+    vb = d5 * d2 - d1 * d6
+    if vb <= 0.0 and d2 >= 0.0 and d6 <= 0.0:
+        w = d2 / (d2 - d6)
+        return [0, 2], [1.0 - w, w]
+    va = d3 * d6 - d5 * d4
+    if va <= 0.0 and (d4 - d3) >= 0.0 and (d5 - d6) >= 0.0:
+        w = (d4 - d3) / ((d4 - d3) + (d5 - d6))
+        return [1, 2], [1.0 - w, w]
+    den = 1.0 / (va + vb + vc)
+    v, w = vb * den, vc * den
+    return [0, 1, 2], [1.0 - v - w, v, w]
+
+
+_FACES = ((0, 1, 2, 3), (0, 2, 3, 1), (0, 3, 1, 2), (1, 3, 2, 0))   # (face, opposite vertex)
+
+
+def _closest_tetrahedron(P):
+    """Closest point of a tetrahedron to the origin; ([], []) when the origin is inside."""
+    best, best_d2 = None, np.inf
+    for i, j, k, o in _FACES:
+        a, b, c, dv = P[i], P[j], P[k], P[o]
+        n = np.cross(b - a, c - a)
+        sp, sd = -(a @ n), (dv - a) @ n
+        if sp * sd < 0.0 or sd == 0.0:                # the origin is on the far side of this face (or the tetrahedron is flat)
+            idx, lam = _closest_triangle([a, b, c])
+            glob = [(i, j, k)[t] for t in idx]
+            pt = sum(l * P[g] for l, g in zip(lam, glob))
+            d2 = pt @ pt
+            if d2 < best_d2:
+                best, best_d2 = (glob, lam), d2
+    if best is None:
+        return [], []
+    return best
+
+
+def gjk_cores(t1, s1, p1, R1, t2, s2, p2, R2):
+    """Closest points of the two cores: (distance, point on 1, point on 2, overlapping)."""
+    d = p1 - p2
+    if d @ d < 1e-30:
+        d = np.array([1.0, 0.0, 0.0])
+    a = support(t1, s1, p1, R1, -d)
+    b = support(t2, s2, p2, R2, d)
+    W, A = [a - b], [a]
+    lam = lam_prev = [1.0]
+    v = W[0]
+    lb = 0.0
+    for _ in range(MAX_ITERS):
+        vv = v @ v
+        scale = max(max(w @ w for w in W), 1e-300)
+        if vv <= 1e-28 * scale:
+            return 0.0, None, None, True
+        a = support(t1, s1, p1, R1, -v)
+        b = support(t2, s2, p2, R2, v)
+        w = a - b
+        if vv - v @ w <= 1e-14 * vv:                  # no support point is closer to the origin along v: converged
+            break
+        lb = max(lb, (v @ w) / np.sqrt(vv))           # every point of the difference is at least this far: a certified bound
+        if any(((w - x) @ (w - x)) <= 1e-28 * scale for x in W):
+            break                                     # the same vertex again (polytopes): converged
+        W.append(w)
+        A.append(a)
+        if len(W) == 2:
+            idx, lam = _closest_segment(W)
+        elif len(W) == 3:
+            idx, lam = _closest_triangle(W)
+        else:
+            idx, lam = _closest_tetrahedron(W)
+            if not idx:
+                if lb > 0.0:                          # "origin inside" against a certified separation: a flat tetrahedron
+                    W, A, lam = W[:-1], A[:-1], lam_prev
+                    break
+                return 0.0, None, None, True
+        Wn = [W[i] for i in idx]
+        An = [A[i] for i in idx]
+        v_new = sum(l * x for l, x in zip(lam, Wn))
+        # no progress, or a point closer than the certified bound: a thin simplex misclassified by rounding —
+        if v_new @ v_new >= vv or v_new @ v_new < lb * lb * (1.0 - 1e-10):
+            W, A, lam = W[:-1], A[:-1], lam_prev      # the previous simplex is the answer
+            break
+        W, A, v = Wn, An, v_new
+        lam_prev = lam
+    pa = sum(l * x for l, x in zip(lam, A))
+    pb = pa - v
+    return float(np.sqrt(v @ v)), pa, pb, False
+
+
+def penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2):
+    """Depth and direction (from 1 to 2) of the smallest translation that separates two overlapping shapes, by projected
+    descent of h(d) = h₁(d) + h₂(−d) over unit d from the centre-to-centre direction."""
+    def h_and_s(d):
+        s = support(t1, s1, p1, R1, d) - support(t2, s2, p2, R2, -d)
+        return float(d @ s) + r1 + r2, s
+
+    # start: the best of the centre-to-centre direction and the ± axes of both shapes (the face normals of boxes and
+    # cylinder caps: for polytopes the minimum sits on a face normal of the Minkowski difference)
+    d0 = p2 - p1
+    n = np.sqrt(d0 @ d0)
+    cands = [d0 / n if n > 1e-12 else np.array([1.0, 0.0, 0.0])]
+    for R in (R1, R2):
+        for k in range(3):
+            cands += [R[:, k].copy(), -R[:, k]]
+    h, s, d = np.inf, None, None
+    for c in cands:
+        hc, sc = h_and_s(c)
+        if hc < h:
+            h, s, d = hc, sc, c
+    step = 1.0
+    for _ in range(MAX_ITERS):
+        g = s - (s @ d) * d                            # gradient of d·s(d) on the sphere
+        gn = np.sqrt(g @ g)
+        if gn < 1e-12 * max(1.0, abs(h)):
+            break
+        ok = False
+        for _ in range(20):
+            dn = d - (step / max(np.sqrt(s @ s), 1e-300)) * g
+            dn = dn / np.sqrt(dn @ dn)
+            hn, sn = h_and_s(dn)
+            if hn < h:
+                d, h, s, ok = dn, hn, sn, True
+                step = min(step * 1.5, 4.0)
+                break
+            step *= 0.5
+        if not ok:
+            break
+    return h, d
+
+
+def convex_distance(t1, s1, p1, R1, t2, s2, p2, R2, margin):
+    """One contact (dist, pos, n) in mj_geomDistance's convention — n from geom 1 to geom 2, pos the midpoint of the
+    witness points — or None beyond `margin`."""
+    r1, r2 = core_radius(t1, s1), core_radius(t2, s2)
+    dist_c, pa, pb, overlap = gjk_cores(t1, s1, p1, R1, t2, s2, p2, R2)
+    if not overlap and dist_c > 1e-9:                 # cores apart (also when only the spherical shells overlap)
+        dist = dist_c - r1 - r2
+        if dist > margin:
+            return None
+        n = (pb - pa) / dist_c
+        a, b = pa + r1 * n, pb - r2 * n
+        return dist, 0.5 * (a + b), n
+    depth, n = penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2)
+    a = support(t1, s1, p1, R1, n) + r1 * n           # deepest point of 1 along n
+    b = support(t2, s2, p2, R2, -n) - r2 * n          # deepest point of 2 against n
+    return -depth, 0.5 * (a + b), n

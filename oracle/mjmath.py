@@ -27,7 +27,7 @@ mjMAXVAL = 1e10
 mjPI = math.pi
 
 JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
-GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX = 0, 2, 3, 5, 6
+GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX = 0, 2, 3, 4, 5, 6
 
 
 # ------------------------------------------------------------- mju_* helpers
@@ -495,6 +495,22 @@ def _plane_cylinder(pos1, mat1, pos2, mat2, size2, margin):
     return [(dist, pt - n * (0.5 * dist), n)]
 
 
+_CONVEX = (GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX)
+
+
+def _plane_ellipsoid(pos1, mat1, pos2, mat2, size2, margin):
+    """Lowest point of the ellipsoid: its support point against the plane normal (mjc_PlaneConvex with the ellipsoid's
+    support mapping)."""
+    n = np.array([mat1[2], mat1[5], mat1[8]])
+    R = _mat3(mat2)
+    e = np.asarray(size2[:3]) * (R.T @ n)
+    pt = pos2 - R @ (np.asarray(size2[:3]) * e) / math.sqrt(float(e @ e))
+    dist = float(n @ (pt - pos1))
+    if dist > margin:
+        return []
+    return [(dist, pt - n * (0.5 * dist), n)]
+
+
 def _ball_box_local(p, r, s, margin):
     """Ball of radius r centred at p (box frame) against the box ±s (mjc_SphereBox): clamp the centre onto the
     box; a centre inside the box leaves through the nearest face (order −x,+x,−y,+y,−z,+z, strict <)."""
@@ -736,7 +752,9 @@ def _capsule_cylinder(pos1, mat1, size1, pos2, mat2, size2, margin):
 def mj_geomDistance(m, d: Data, geom1: int, geom2: int, distmax: float, fromto) -> float:
     """Smallest signed distance between two geoms and the connecting segment
     (mink/limits/collision_avoidance_limit.py:219); SURVEY Appendix A.8.
-    Restated: plane/sphere/capsule pairs, box against plane/sphere/capsule/box, cylinder against plane/sphere/capsule."""
+    Restated: plane/sphere/capsule pairs, box against plane/sphere/capsule/box, cylinder against plane/sphere/capsule,
+    plane–ellipsoid; every other pair of convex primitives (cylinder–box, cylinder–cylinder, ellipsoid–*) through the
+    general convex routine of oracle/gjk.py."""
     g1, g2 = int(geom1), int(geom2)
     t1, t2 = int(m.geom_type[g1]), int(m.geom_type[g2])
     flip = t1 > t2
@@ -771,6 +789,13 @@ def mj_geomDistance(m, d: Data, geom1: int, geom2: int, distmax: float, fromto) 
         cons = _capsule_cylinder(p1, R1, s1, p2, R2, s2, distmax)
     elif (t1, t2) == (GEOM_BOX, GEOM_BOX):
         cons = _box_box(p1, R1, s1, p2, R2, s2, distmax)
+    elif (t1, t2) == (GEOM_PLANE, GEOM_ELLIPSOID):
+        cons = _plane_ellipsoid(p1, R1, p2, R2, s2, distmax)
+    elif t1 in _CONVEX and t2 in _CONVEX:
+        # no native pair routine in MuJoCo either: the general convex collider (oracle/gjk.py states what it approximates)
+        from . import gjk
+        c = gjk.convex_distance(t1, s1, p1, _mat3(R1), t2, s2, p2, _mat3(R2), distmax)
+        cons = [c] if c is not None else []
     else:
         raise NotImplementedError(f"geom pair types ({t1},{t2}) not restated")
     if fromto is not None:

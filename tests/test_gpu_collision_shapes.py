@@ -241,3 +241,77 @@ def test_more_contacts_than_tableau_rows_keeps_the_tightest():
               % (regime, n_over, n_bind, worst))
         assert n_over >= 16 and n_bind > 0
         assert worst < 1e-7
+
+
+CONVEX_SCENE = SCENE.replace('<geom name="orb"', '<geom name="egg" type="ellipsoid" size=".1 .06 .15" pos="0.35 -0.3 0.05" quat="0.7 0.2 0.5 0.1"/>\n  <geom name="orb"') \
+    .replace('<geom name="l3_cap"', '<geom name="l3_egg" type="ellipsoid" size=".05 .03 .07" pos="0.02 0.05 0"/>\n        <geom name="l3_cap"')
+
+CONVEX_PAIRS = [
+    (["l4_can"], ["crate", "drum", "egg"]),                              # cylinder–box, cylinder–cylinder, ellipsoid–cylinder
+    (["l3_egg"], ["floor", "crate", "drum", "post", "orb", "egg"]),      # plane– / box– / cylinder– / capsule– / sphere– / ellipsoid–ellipsoid
+]
+
+
+def test_general_convex_pairs_against_the_oracle():
+    """The pairs MuJoCo sends to its general convex collider (no native routine): cylinder–box, cylinder–cylinder and the
+    ellipsoid against every primitive — device (GJK on support mappings, convex_dev.h) against the numpy statement
+    (oracle/gjk.py, pinned against bounded minimisation in tests/test_oracle_gjk.py).  h to 1e-9; the rows of G to 1e-5:
+    the distance of a GJK run converges quadratically faster than its witness points (a support gap ε leaves an angle
+    √ε in the normal — 1e-7 at best, a few 1e-6 where a run ends on a thin simplex), and the two implementations may stop
+    one iteration apart.  (MuJoCo's own routine for these pairs, libccd MPR, runs to a tolerance of 1e-6.)"""
+    m = mink.loads_mjcf(CONVEX_SCENE)
+    rng = np.random.default_rng(4)
+    B = 192
+    q = _rand_q(m, rng, B)
+    cfg = mink.Configuration(m, q)
+    col = mink.CollisionAvoidanceLimit(m, CONVEX_PAIRS, collision_detection_distance=0.3, minimum_distance_from_collisions=0.01)
+    assert len(col.geom_id_pairs) == 9
+    dt = 0.1
+    G, h = col.compute_qp_inequalities(cfg, dt)
+    spec = oik.CollisionAvoidanceLimitSpec(col.geom_id_pairs, collision_detection_distance=0.3,
+                                           minimum_distance_from_collisions=0.01)
+    active = np.zeros(9, dtype=int)
+    apart = np.zeros(9, dtype=int)
+    for i in range(B):
+        o = oik.Configuration(m, q[i])
+        G_ref, h_ref = oik.limit_inequalities(o, spec, dt)
+        fin = np.isfinite(h_ref)
+        assert (np.isfinite(h[i]) == fin).all(), i
+        active += fin
+        sep = fin & (h_ref > 0.0)                       # separated by more than d_min: the Euclidean distance, exactly
+        apart += sep
+        np.testing.assert_allclose(h[i][sep], h_ref[sep], rtol=0, atol=1e-9 * max(1.0, np.abs(h_ref[sep]).max(initial=0.0)))
+        np.testing.assert_allclose(G[i][sep], G_ref[sep], atol=1e-5)
+        np.testing.assert_array_equal(h[i][fin & ~sep], h_ref[fin & ~sep])      # closer than d_min (or overlapping): h = relaxation
+    print("active / separated instances per pair:", list(zip([tuple(p) for p in col.geom_id_pairs], active, apart)))
+    assert (apart > 0).all(), apart
+    # the solve on instances that start outside d_min for every pair (the lean collision variant with the convex routine)
+    q = _rand_q(m, rng, 4096)
+    G, h = col.compute_qp_inequalities(mink.Configuration(m, q), dt)
+    hmin = np.where(np.isfinite(h), h, np.inf).min(axis=1)
+    ok = np.flatnonzero(hmin > 0)
+    ok = ok[np.argsort(hmin[ok])][:128]
+    q, G, h = q[ok], G[ok], h[ok]
+    cfg = mink.Configuration(m, q)
+    ft = mink.FrameTask("tip", "site", position_cost=1.0, orientation_cost=0.2, lm_damping=0.0)
+    ft.set_target(mink.Configuration(m, _rand_q(m, rng, len(ok))).get_transform_frame_to_world("tip", "site"))
+    post = mink.PostureTask(m, cost=1e-2)
+    post.set_target(m.qpos0)
+    v = mink.solve_ik(cfg, [ft, post], dt, "mi355x", 1e-3, limits=[mink.ConfigurationLimit(m), col])
+    last = list(cfg._problems.values())[-1].last_kernel()          # (most recently used descriptor of the cache)
+    assert last.endswith("_136"), last
+    dq = v * dt
+    fin = np.isfinite(h)
+    Gx = np.einsum("bpj,bj->bp", G, dq)
+    assert (Gx[fin] <= h[fin] + 1e-8).all()
+    binding = (np.abs(Gx - h) < 1e-8) & fin
+    print("binding convex half-spaces: %d in %d instances" % (binding.sum(), binding.any(axis=1).sum()))
+    assert binding.any(axis=1).sum() >= 8
+    worst = 0.0
+    for i in np.flatnonzero(binding.any(axis=1))[:24]:
+        ts = [oik.FrameTaskSpec(m.name2id("site", "tip"), "site", ft.cost, ft.transform_target_to_world.wxyz_xyz[i], 1.0, 0.0),
+              oik.PostureTaskSpec(post.cost, post.target_q, 1.0)]
+        v_ref = oik.solve_ik(m, q[i], ts, dt, 1e-3, [oik.ConfigurationLimitSpec(), spec])
+        worst = max(worst, np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max()))
+    print("solve with general convex half-spaces vs oracle: max rel err %.2e" % worst)
+    assert worst < 1e-5

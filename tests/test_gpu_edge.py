@@ -117,8 +117,8 @@ def test_argument_validation():
         prob.solve(np.zeros((2, 6)), np.zeros((2, 1, 7)), None, None, 0.0, 1e-3)
     with pytest.raises(nat.MinkHipError, match="site id"):
         nat.NativeProblem(nm, frame_tasks=[{"frame_type": "site", "frame_id": 9, "cost": [1.0] * 6}])
-    with pytest.raises(nat.MinkHipError, match="no analytic distance"):
-        # a mesh geom has no distance routine (the primitive pairs, box–box included, have one)
+    with pytest.raises(nat.MinkHipError, match="not supported"):
+        # a mesh geom has no distance routine (every pair of primitives has one: analytic or the general convex routine)
         nat.NativeProblem(nm, collision_limits=[{"geom_id_pairs": [[1, m.name2id("geom", "wall")]],
                                                  "gain": 0.85, "minimum_distance_from_collisions": 0.005,
                                                  "collision_detection_distance": 0.01, "bound_relaxation": 0.0}])
