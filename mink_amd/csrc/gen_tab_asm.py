@@ -225,24 +225,37 @@ def gen(nt: int, total: int = 0, name: str = "Tab") -> str:
     return "\n".join(out)
 
 
-KMU = 18   # rows of the low-rank start's elimination (ik_kernel.h kMu): task residuals of one problem
+KMUS = (18, 24)   # row capacities of the low-rank start's elimination (ik_kernel.h kMu*): task residuals of one problem
 
 
 def gen_wood_elim() -> str:
-    """Low-rank start (ik_kernel.h wood_start): step R of the LDLᵀ elimination of [S | Jh | w] with one COLUMN per lane in
-    compiler-allocated registers z[0..KMU): z[i] += S[i][R]·g for the rows below R, where the wave-uniform multipliers
+    """Low-rank start (ik_kernel.h wood_start): step R of the LDLᵀ elimination of [S | Jh] with one COLUMN per lane in
+    compiler-allocated registers z[0..K): z[i] += S[i][R]·g for the rows below R, where the wave-uniform multipliers
     S[i][R] sit in two 16-lane planes (lane l holds entry 16p + l % 16) and are broadcast by the DPP operand network."""
-    out = [f"template <int R> __device__ __forceinline__ void wood_elim_step(double (&z)[{KMU}], double p0, double p1, double g);"]
-    for r in range(KMU):
-        rows = list(range(r + 1, KMU))
-        if not rows:
-            out.append(f"template <> __device__ __forceinline__ void wood_elim_step<{r}>(double (&)[{KMU}], double, double, double) {{}}")
-            continue
-        ops = ", ".join(f'[z{i}] "+v"(z[{i}])' for i in rows)
-        body = "\\n\\t".join(["s_nop 4"] + [f"v_fmac_f64_dpp %[z{i}], %[p{i // 16}], %[g] row_newbcast:{i % 16} row_mask:0xf bank_mask:0xf" for i in rows])
-        out.append(f"template <> __device__ __forceinline__ void wood_elim_step<{r}>(double (&z)[{KMU}], double p0, double p1, double g) {{")
-        out.append(f'  asm volatile("{body}" : {ops} : [p0] "v"(p0), [p1] "v"(p1), [g] "v"(g));')
-        out.append("}")
+    out = ["template <int R, int K> struct WoodElim;"]
+    for K in KMUS:
+        for r in range(K):
+            rows = list(range(r + 1, K))
+            out.append(f"template <> struct WoodElim<{r}, {K}> {{")
+            if not rows:
+                out.append(f"  __device__ static __forceinline__ void step(double (&)[{K}], double, double, double) {{}}")
+            else:
+                ops = ", ".join(f'[z{i}] "+v"(z[{i}])' for i in rows)
+                body = "\\n\\t".join(["s_nop 4"] + [f"v_fmac_f64_dpp %[z{i}], %[p{i // 16}], %[g] row_newbcast:{i % 16} row_mask:0xf bank_mask:0xf" for i in rows])
+                out.append(f"  __device__ static __forceinline__ void step(double (&z)[{K}], double p0, double p1, double g) {{")
+                out.append(f'    asm volatile("{body}" : {ops} : [p0] "v"(p0), [p1] "v"(p1), [g] "v"(g));')
+                out.append("  }")
+            out.append("};")
+    # acc[r] += plane[r]·g for every row (the dense Jh·Jhᵀ product of the F_COM builds, ik_kernel.h wood_start)
+    out.append("template <int K> struct WoodAll;")
+    for K in KMUS:
+        ops = ", ".join(f'[z{i}] "+v"(z[{i}])' for i in range(K))
+        body = "\\n\\t".join(["s_nop 4"] + [f"v_fmac_f64_dpp %[z{i}], %[p{i // 16}], %[g] row_newbcast:{i % 16} row_mask:0xf bank_mask:0xf" for i in range(K)])
+        out.append(f"template <> struct WoodAll<{K}> {{")
+        out.append(f"  __device__ static __forceinline__ void step(double (&z)[{K}], double p0, double p1, double g) {{")
+        out.append(f'    asm volatile("{body}" : {ops} : [p0] "v"(p0), [p1] "v"(p1), [g] "v"(g));')
+        out.append("  }")
+        out.append("};")
     return "\n".join(out)
 
 

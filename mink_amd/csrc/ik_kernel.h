@@ -53,8 +53,8 @@ __host__ __device__ inline int a_stride_for(int nv) {
 __host__ __device__ inline int j_stride_direct(int nv, int nt) { const int a = a_stride_for(nv); return a < nt ? a : nt; }
 
 constexpr int kPivBuf = kWave + 8;   // doubles per pivot broadcast buffer
-constexpr int kMu = 18;              // low-rank start: task-residual rows of one problem (wood_elim_step in tab_asm.inc)
-constexpr int kWoodRow = 32;         // low-rank start: doubles of the published-row buffer (in the pivot buffers, followed by 1/d_r)
+constexpr int kMu = 18, kMuBig = 24; // low-rank start: compiled capacities of task-residual rows of one problem (WoodElim in tab_asm.inc)
+constexpr int kWoodRow = 64;         // low-rank start: doubles of the published-row buffer — (S[r][c], w_c) pairs — in the pivot buffers, followed by 1/d_r
 struct LdsLayout {
   int q, X, jnt, tgt, task, J, dof, com, col, A, piv, S, q2, tgt2, total;  // offsets in doubles
 };
@@ -106,7 +106,10 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
 }
 
 // Low-rank start: the n_mu × (sp + 1) block of −Jh·Jhᵀ and right-hand sides fits in the dof stash?
-__host__ __device__ inline bool wood_s_aliases_dof(int nv, int n_mu, int sp) { return n_mu * (sp + 1) <= nv * 10; }
+// (n_com_bodies: the subtree-CoM array that follows the dof stash — nbody when the problem has ComTasks, else 0)
+__host__ __device__ inline bool wood_s_aliases_dof(int nv, int n_mu, int sp, int n_com_bodies = 0) {
+  return n_mu * (sp + 1) <= lds_even(nv * 10) + n_com_bodies * 4;
+}
 
 // Compile-time loop: f(std::integral_constant<int, I>{}) for I in [0, N).
 template <class F, int... I>
@@ -359,7 +362,7 @@ struct PreView {
   const MKH_GLOBAL double *body_f, *jnt_f, *dof_f;
   const MKH_GLOBAL int32_t *body_i, *jnt_i, *dof_i;
   const MKH_GLOBAL FrameTaskDev* frame;
-  int nbody, nv, nq, njnt, n_frame, n_posture, n_com, max_rows, n_jrows, prefetch, prefetch_w3, prefetch_w3w, n_rows_tap, nrounds, robot_root;
+  int nbody, nv, nq, njnt, n_frame, n_posture, n_com, max_rows, n_jrows, prefetch, prefetch_w3, prefetch_w3w, wood_compact, prefetch_wc, n_rows_tap, nrounds, robot_root;
   __device__ __forceinline__ explicit PreView(const DeviceProblem* Pq) {
     const MKH_CONSTANT DeviceProblem* c = (const MKH_CONSTANT DeviceProblem*)Pq;
     body_f = (const MKH_GLOBAL double*)c->body_f; jnt_f = (const MKH_GLOBAL double*)c->jnt_f; dof_f = (const MKH_GLOBAL double*)c->dof_f;
@@ -367,9 +370,20 @@ struct PreView {
     frame = (const MKH_GLOBAL FrameTaskDev*)c->frame;
     nbody = c->nbody; nv = c->nv; nq = c->nq; njnt = c->njnt; n_frame = c->n_frame; n_posture = c->n_posture; n_com = c->n_com;
     max_rows = c->max_rows; n_jrows = c->n_jrows; prefetch = c->prefetch; prefetch_w3 = c->prefetch_w3; prefetch_w3w = c->prefetch_w3w;
+    wood_compact = c->wood_compact; prefetch_wc = c->prefetch_wc;
     n_rows_tap = c->n_rows_tap; nrounds = c->nrounds; robot_root = c->robot_root;
   }
 };
+// second LDS buffers for the next problem's inputs: decided on the host per LDS layout (only where they cost no resident wave)
+template <class PT>
+__device__ __forceinline__ bool kernel_prefetch(const PT& P0) {
+  constexpr bool kWood = (MKH_FEAT & F_WOOD) != 0;
+#ifdef MKH_W3
+  return (kWood ? P0.prefetch_w3w : P0.prefetch_w3) != 0;
+#else
+  return ((kWood && P0.wood_compact != 0) ? P0.prefetch_wc : P0.prefetch) != 0;
+#endif
+}
 template <class PT>
 __device__ __forceinline__ LdsLayout kernel_lds_layout(const PT& P0) {
   constexpr int NT = MKH_NT, FEAT = MKH_FEAT;
@@ -385,9 +399,10 @@ __device__ __forceinline__ LdsLayout kernel_lds_layout(const PT& P0) {
   constexpr bool kCompact = false;
 #endif
   return lds_layout(P0.nq, P0.nv, P0.nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows,
-                    kWood ? kMu + 1 : 6, kWood ? NR : j_stride_direct(P0.nv, NT),
-                    (kWood && !wood_s_aliases_dof(P0.nv, P0.n_jrows, kMu)) ? P0.n_jrows * (kMu + 1) : 0,
-                    (kCompact ? (kWood ? P0.prefetch_w3w : P0.prefetch_w3) : P0.prefetch) != 0, 0, kCompact, kWood);
+                    kWood ? P0.n_jrows + 1 : 6, kWood ? NR : j_stride_direct(P0.nv, NT),
+                    (kWood && !wood_s_aliases_dof(P0.nv, P0.n_jrows, lds_even(P0.n_jrows), P0.n_com > 0 ? P0.nbody : 0))
+                        ? P0.n_jrows * (lds_even(P0.n_jrows) + 1) : 0,
+                    kernel_prefetch(P0), 0, kCompact || (kWood && P0.wood_compact != 0), kWood);
 }
 __device__ MKH_PRE_ATTR PreOut pre_phases(const DeviceProblem* Pq, const TapArgs* tp, int pb, int oz, int off_q, int off_tgt,
                                           bool until, double pos_thr, double ori_thr MKH_PRE_TC_PARAMS) {
@@ -792,48 +807,184 @@ __device__ MKH_PRE_ATTR DirectPairs direct_pairs(const DeviceProblem* Pq) {
 
 #if (MKH_FEAT & 32)
 // ---------------------------------------------------------------- low-rank start of the QP (F_WOOD)
-// H = Dg + JwᵀJw with Dg diagonal (damping + Σ LM terms + posture tasks) and Jw the n_μ weighted frame-task rows.  With
-// σ = 1/√Dg, Jh = Jw·σ and S = I + Jh·Jhᵀ = L·D·Lᵀ (n_μ × n_μ, SPD, diagonal ≥ 1 — no pivoting needed):
+// H = Dg + JwᵀJw with Dg diagonal (damping + Σ LM terms + posture tasks) and Jw the n_μ weighted rows of the frame tasks
+// (and of the ComTasks).  With σ = 1/√Dg, Jh = Jw·σ and S = I + Jh·Jhᵀ = L·D·Lᵀ (n_μ × n_μ, SPD, diagonal ≥ 1 — no pivoting
+// needed):
 //     −H⁻¹ = −σσᵀ∘(I − JhᵀS⁻¹Jh),   JhᵀS⁻¹Jh = ZᵀD⁻¹Z  with  Z = L⁻¹Jh.
-// One COLUMN of the augmented matrix [S | Jh | w] per lane — dof lanes [0, NR), S lanes [NR, NR + n_μ), one right-hand-side
-// lane — in kMu compiler-allocated registers; step r publishes row r (the dof lanes' part is row r of Z, written to its
-// final place in LDS), every lane reads the n_μ − r − 1 multipliers S[i][r] as two 16-lane planes and updates its rows
-// below r with DPP-broadcast FMAs (tab_asm.inc wood_elim_step).  The chain per step is one LDS round trip + one
-// reciprocal + ≤ 17 FMAs, and it never touches the tableau: the kernel then builds the dof block with n_μ rank-1 updates
-// R[i][j] += Z[r][i]·Z[r][j]/d_r that do not depend on each other.  (Round 2's first version swept the residual indices on
-// the tableau itself — every pivot a publish / reciprocal / multiplier chain in front of a 62-row update, later six at a
-// time with a per-lane 6 × 6 LDLᵀ: 30 % of a G1 solve.)
+// One COLUMN of the augmented matrix [S | Jh] per lane in K compiler-allocated registers: dof lanes [0, NR) carry a column
+// of Jh, n_μ lanes a column of S together with their entry of the right-hand side w — lanes [NR, NR + n_μ) in the same
+// registers, or, when NR + n_μ exceeds the wavefront (the G1 full example: 44 + 24), lanes [0, n_μ) in a second set (DUAL).
+// Step r publishes row r (the dof part is row r of Z, written to its final place in LDS), every lane reads the
+// n_μ − r − 1 multipliers S[i][r] as two 16-lane planes and updates its rows below r with DPP-broadcast FMAs (tab_asm.inc
+// WoodElim).  The chain per step is one LDS round trip + one reciprocal + ≤ K − 1 FMAs and never touches the tableau:
+// the kernel then builds the dof block with n_μ rank-1 updates R[i][j] += Z[r][i]·Z[r][j]/d_r that do not depend on each
+// other.  (Round 2's first version swept the residual indices on the tableau itself — every pivot a publish /
+// reciprocal / multiplier chain in front of a 62-row update, later six at a time with a per-lane 6 × 6 LDLᵀ: 30 % of a
+// G1 solve.)
 // Outputs per dof lane: D = −H⁻¹[j][j] = σ²(Σ_r z_r²/d_r − 1),  x0 = −H⁻¹c = z − σ·Σ_r z_r·ω_r/d_r  (ω = L⁻¹w, w = Jw·z − r).
 struct WoodOut { double hdiag, dsq, x, D; int status; };
-__device__ MKH_PRE_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, double c_lane, double hdiag_base) {
-  constexpr int NR = MKH_NT, SP = kMu;
+
+template <int K, bool DUAL>
+__device__ __forceinline__ void wood_eliminate(int n_mu, int NR, int lane, double* sJ, double* sS, int SP, const double* sW,
+                                               double* sRow, double* sDinv, double& ssq, double& quad, double& zw, int& status) {
+  const unsigned plane_off = (unsigned)(lane & 15);
+  if constexpr (!DUAL) {
+    // ONE pass: lanes [0, NR) carry a column of Jh, lanes [NR, NR + n_μ) a column of S and their entry w_c
+    const int my_c = lane - NR;                                          // S column of this lane (if 0 ≤ my_c < n_μ)
+    const bool is_s = my_c >= 0 && my_c < n_mu;
+    double z[K];
+    {
+      const double* src = sJ + lane;
+      int stride = NR;
+      bool live = lane < NR;
+      if (is_s) { src = sS + my_c * SP; stride = 1; live = true; }
+#pragma unroll
+      for (int r = 0; r < K; ++r) z[r] = (live && r < n_mu) ? src[r * stride] : 0.0;
+    }
+    double ws = is_s ? sW[my_c] : 0.0;
+    {
+      double q = 0.0;
+#pragma unroll
+      for (int r = 0; r < K; ++r) q = fma(z[r], z[r], q);                // Σ Jh² of a dof lane (before the elimination):
+      if (lane < NR) sJ[n_mu * NR + lane] = q;                           // parked in LDS (the right-hand-side row of the product
+    }                                                                    // is dead), not in two registers through the loop
+    static_for<K>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      if (r < n_mu) {
+        wave_sync();                                                     // the previous row's readers are done
+        if (lane < NR) sJ[r * NR + lane] = z[r];                         // row r of Z, final
+        if (is_s) *reinterpret_cast<double2*>(sRow + 2 * my_c) = double2{z[r], ws};   // (S[r][c], w_c) in one write
+        wave_sync();
+        const double2 dw = *reinterpret_cast<const double2*>(sRow + 2 * r);            // d_r and ω_r
+        const double d = dw.x, om = dw.y;
+        const double p0 = sRow[2 * plane_off], p1 = (K > 16) ? sRow[2 * (16 + plane_off)] : 0.0;
+        if (!(d > 0.0)) status |= 4;
+        const double inv = fast_rcp(d);
+        if (lane == 0) sDinv[r] = inv;
+        const double zi = z[r] * inv;
+        quad = fma(z[r], zi, quad);
+        zw = fma(om, zi, zw);
+        WoodElim<r, K>::step(z, p0, p1, -zi);                            // z[i] −= S[i][r]·z[r]/d   (i > r)
+        ws = fma(-zi, om, ws);                                           // w_c −= S[c][r]·ω_r/d  (S lanes; harmless on dof lanes)
+      }
+    });
+  } else {
+    // TWO passes (NR + n_μ lanes do not exist): first the S columns on lanes [0, n_μ) — the chained part; row r, 1/d_r and ω_r
+    // stay in LDS (S is loaded into registers first, its storage takes the rows) — then the Jh columns on the dof lanes, which
+    // only read multipliers: no publish / read-back chain at all.
+    const bool is_s = lane < n_mu;
+    double* const sOm = sDinv + kMuBig;
+    {
+      double z[K];
+#pragma unroll
+      for (int r = 0; r < K; ++r) z[r] = (is_s && r < n_mu) ? sS[lane * SP + r] : 0.0;
+      double ws = is_s ? sW[lane] : 0.0;
+      wave_sync();                                                       // every column is in registers: sS takes the rows
+      static_for<K>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        if (r < n_mu) {
+          wave_sync();
+          if (is_s) { *reinterpret_cast<double2*>(sRow + 2 * lane) = double2{z[r], ws}; sS[r * SP + lane] = z[r]; }
+          wave_sync();
+          const double2 dw = *reinterpret_cast<const double2*>(sRow + 2 * r);
+          const double d = dw.x, om = dw.y;
+          const double p0 = sRow[2 * plane_off], p1 = (K > 16) ? sRow[2 * (16 + plane_off)] : 0.0;
+          if (!(d > 0.0)) status |= 4;
+          const double inv = fast_rcp(d);
+          if (lane == 0) { sDinv[r] = inv; sOm[r] = om; }
+          const double zi = z[r] * inv;
+          WoodElim<r, K>::step(z, p0, p1, -zi);
+          ws = fma(-zi, om, ws);
+        }
+      });
+    }
+    wave_sync();
+    {
+      double z[K];
+      const bool live = lane < NR;
+#pragma unroll
+      for (int r = 0; r < K; ++r) z[r] = (live && r < n_mu) ? sJ[r * NR + lane] : 0.0;
+      {
+        double q = 0.0;
+#pragma unroll
+        for (int r = 0; r < K; ++r) q = fma(z[r], z[r], q);
+        wave_sync();
+        if (live) sJ[n_mu * NR + lane] = q;
+      }
+      static_for<K>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        if (r < n_mu) {
+          const double inv = sDinv[r], om = sOm[r];
+          const double p0 = sS[r * SP + plane_off], p1 = (K > 16) ? sS[r * SP + 16 + plane_off] : 0.0;
+          if (live) sJ[r * NR + lane] = z[r];                            // row r of Z, final
+          const double zi = z[r] * inv;
+          quad = fma(z[r], zi, quad);
+          zw = fma(om, zi, zw);
+          WoodElim<r, K>::step(z, p0, p1, -zi);
+        }
+      });
+    }
+  }
+  wave_sync();
+  ssq = lane < NR ? sJ[n_mu * NR + lane] : 0.0;
+}
+
+// A real call in the 3-waves variants (see pre_phases) and in the F_COM builds, whose 24-row / two-pass instantiations do not
+// fit next to the kernel's own live values (86 spilled VGPRs when inlined).
+#if defined(MKH_W3) || (MKH_FEAT & 4)
+#define MKH_WOOD_CALL 1
+#define MKH_WOOD_ATTR __attribute__((noinline))
+#else
+#define MKH_WOOD_ATTR __forceinline__
+#endif
+__device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int off_q, int off_tgt, double c_lane, double hdiag_base) {
+  constexpr int NR = MKH_NT;
+  constexpr bool kCom = (MKH_FEAT & F_COM) != 0;
   static_assert(MKH_NR == MKH_NT, "low-rank start: the residual rows are not tableau rows any more");
   extern __shared__ __attribute__((aligned(16))) double smem[];
-#ifdef MKH_W3
-  oz = uni(oz);
+#ifdef MKH_WOOD_CALL
+  oz = uni(oz); off_q = uni(off_q); off_tgt = uni(off_tgt);
   Pq = reinterpret_cast<const DeviceProblem*>(uni((unsigned long long)reinterpret_cast<size_t>(Pq)));
   const MKH_CONSTANT DeviceProblem& P = *(const MKH_CONSTANT DeviceProblem*)Pq;
   const MKH_GLOBAL FrameTaskDev* const frames = (const MKH_GLOBAL FrameTaskDev*)P.frame;
+  const MKH_GLOBAL int32_t* const dof_i = (const MKH_GLOBAL int32_t*)P.dof_i;
+  const MKH_GLOBAL int32_t* const body_i = (const MKH_GLOBAL int32_t*)P.body_i;
 #else
   const DeviceProblem& P = *Pq;
   const FrameTaskDev* const frames = P.frame;
+  const int32_t* const dof_i = P.dof_i;
+  const int32_t* const body_i = P.body_i;
 #endif
   int lane = lane_id();
   const int ol = lane + oz;
   const int nv = P.nv, n_mu = P.n_jrows;
+  const int SP = lds_even(n_mu);                      // stride of a column of S
   const LdsLayout L = kernel_lds_layout(P);
   double* const sTask = smem + L.task;
+  double* const sTgt = smem + off_tgt;
   double* const sJ = smem + L.J;
   double* const sDof = smem + L.dof;
-  double* const sRow = smem + L.piv;                  // published row: S part at [0, n_μ), right-hand side at [n_μ]
+  double* const sCom = smem + L.com;
+  double* const sRow = smem + L.piv;                  // published row: pairs (S[r][c], w_c) for c < n_μ
   double* const sDinv = sRow + kWoodRow;              // 1/d_r for the kernel's rank-1 updates
   const bool is_dof = lane < nv;
+  const bool dual = NR + n_mu > kWave;
+  const int my_c = dual ? lane : lane - NR;
+  const bool is_s = my_c >= 0 && my_c < n_mu;
   int status = 0;
   // 1/√Dg of this dof (Dg = damping + Σμ + posture diagonal > 0, checked on the host)
   const double dsq = is_dof ? fast_rcp(sqrt(hdiag_base)) : 0.0;
-  // weighted error of residual row c (read before the Jacobian rows may overwrite the task blocks)
+  // weighted error of residual row my_c (read before the Jacobian rows may overwrite the task blocks):
+  // a frame-task row, or (−1 − 3·t − r) row r of ComTask t: cost·(−gain·(com − target))   (com_task.py:71-82)
   double we_mu = 0.0;
-  if (lane >= NR && lane < NR + n_mu) we_mu = sTask[P.mu_src[lane - NR]];
+  if (is_s) {
+    const int src = P.mu_src[my_c];
+    if (src >= 0) we_mu = sTask[src];
+    else if (kCom) {
+      const int t = (-1 - src) / 3, r = (-1 - src) % 3;
+      we_mu = P.com_cost[t][r] * (-P.com_gain[t] * (sCom[P.robot_root * 4 + r] - sTgt[P.n_frame * 7 + t * 3 + r]));
+    }
+  }
   if (is_dof) sDof[lane * 10 + 9] = dsq;
   wave_sync();
   // ---- Jacobian columns by (task, dof) PAIR lanes — 56 pairs for G1's four tasks, one pass — into the row-major array
@@ -877,10 +1028,10 @@ __device__ MKH_PRE_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, doub
     }
     if (base == 0) {
       wave_sync();                                               // every pair of a one-pass problem has read its inputs
-      for (int i = lane; i < SP * NR; i += kWave) sJ[i] = 0.0;   // dofs off a task's chain, rows ≥ n_μ
-      // x after the closed-form dof sweeps: z_k = −c_k/Dg_k (posture part of c only), staged as z_k·√Dg_k in row SP of
+      for (int i = lane; i < n_mu * NR; i += kWave) sJ[i] = 0.0;   // dofs off a task's chain
+      // x after the closed-form dof sweeps: z_k = −c_k/Dg_k (posture part of c only), staged as z_k·√Dg_k in row n_μ of
       // the array so that the right-hand side Jw·z is one more row of the product below
-      if (lane < NR) sJ[SP * NR + lane] = is_dof ? -c_lane * dsq : 0.0;
+      if (lane < NR) sJ[n_mu * NR + lane] = is_dof ? -c_lane * dsq : 0.0;
       wave_sync();
     }
     {
@@ -890,17 +1041,62 @@ __device__ MKH_PRE_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, doub
         if ((rowmask >> r) & 1) { sJ[o0 + c * NR] = Jo[r]; ++c; }                     // (nonzero-cost rows only)
     }
   }
+  // ComTask rows: CoM Jacobian column of this dof (mj_jacSubtreeCom closed form), weighted / √Dg
+  if (kCom && is_dof) {
+    const int d_body = dof_i[DI_BODY * 64 + ol];
+    const double* cd = sCom + d_body * 4;
+    V3 jc{0, 0, 0};
+    if (body_i[BI_IN_ROBOT * 64 + d_body]) {
+      const double* dd = sDof + lane * 10;
+      const V3 d_ang{dd[0], dd[1], dd[2]}, d_lin{dd[3], dd[4], dd[5]}, d_anchor{dd[6], dd[7], dd[8]};
+      const double fac = cd[3] * fast_rcp(sCom[P.robot_root * 4 + 3]);
+      jc = fac * (d_lin + cross(d_ang, V3{cd[0], cd[1], cd[2]} - d_anchor));
+    }
+    const double jv[3] = {jc.x, jc.y, jc.z};
+    for (int t = 0; t < P.n_com; ++t) {
+      int c = 0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        if ((P.com_rowmask[t] >> r) & 1) { sJ[(P.com_jrow0[t] + c) * NR + lane] = (P.com_cost[t][r] * jv[r]) * dsq; ++c; }
+    }
+  }
   wave_sync();
   // ---- S = I + Jh·Jhᵀ and Jw·z by (column, row-chunk) lanes: 64/n_μ chunks of rows per column, each lane a handful of
   // dot products on its own LDS addresses.  A row of Jh is nonzero only on the kinematic chain of its task (12–16 of the
   // 43 dofs on G1): the dot products walk the set bits of the column's chain mask instead of all NR dofs.
-  // [column c][SP]: S[·][c], then [c]: (Jw·z)[c] − weighted error.  Lives in the dof stash (axes / anchors of the Jacobian
-  // columns: dead by now) when it fits, so that the low-rank start costs no LDS residency.
-  double* const sS = wood_s_aliases_dof(nv, n_mu, SP) ? sDof : smem + L.S;
+  // [column c][SP]: S[·][c], then [c]: (Jw·z)[c] − weighted error.  Lives in the dof stash (+ the subtree CoMs behind it:
+  // axes / anchors / CoMs of the Jacobian columns are dead by now) when it fits, so that the low-rank start costs no LDS.
+  double* const sS = wood_s_aliases_dof(nv, n_mu, SP, P.n_com > 0 ? P.nbody : 0) ? sDof : smem + L.S;
   double* const sW = sS + n_mu * SP;
   for (int i = lane; i < n_mu * SP; i += kWave) sS[i] = 0.0;
   wave_sync();
-  {
+  if constexpr (kCom) {
+    // Dense product (F_COM builds: ComTask rows reach every dof, and with 24 rows the chain walk below — a dependent
+    // ffs → address → LDS read per bit, 43 bits × 2 passes for a CoM column — took 39 k cycles): lane c accumulates column c
+    // of Jh·Jhᵀ and (Jw·z)[c] over the dofs; column k of Jh arrives as two 16-lane planes, broadcast by the DPP network.
+    double acc[kMuBig];
+#pragma unroll
+    for (int r = 0; r < kMuBig; ++r) acc[r] = 0.0;
+    double wacc = 0.0;
+    const int rows0 = (int)(lane & 15), rows1 = 16 + (int)(lane & 15);
+    const bool has0 = rows0 < n_mu, has1 = rows1 < n_mu, mine = lane < n_mu;
+    const double* c0 = sJ + (has0 ? rows0 : 0) * NR;
+    const double* c1 = sJ + (has1 ? rows1 : 0) * NR;
+    const double* cm = sJ + (mine ? lane : 0) * NR;
+    const double* zs = sJ + n_mu * NR;
+    for (int k = 0; k < nv; ++k) {
+      const double p0 = has0 ? c0[k] : 0.0, p1 = has1 ? c1[k] : 0.0;
+      const double g = mine ? cm[k] : 0.0;
+      WoodAll<kMuBig>::step(acc, p0, p1, g);                   // acc[r] += Jh[r][k]·Jh[c][k]
+      wacc = fma(g, zs[k], wacc);
+    }
+    if (mine) {
+#pragma unroll
+      for (int r = 0; r < kMuBig; ++r)
+        if (r < n_mu) sS[lane * SP + r] = acc[r] + (r == lane ? 1.0 : 0.0);
+      sW[lane] = wacc;
+    }
+  } else {
     const int wc = P.wood_col[ol], wr0 = P.wood_row0[ol];
     if (wc >= 0) {
       const double* a = sJ + wc * NR;
@@ -914,7 +1110,7 @@ __device__ MKH_PRE_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, doub
         const double* b[8];
         double acc[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const int r = row0 + j; b[j] = sJ + (r < n_mu ? r : SP) * NR; acc[j] = 0.0; }
+        for (int j = 0; j < 8; ++j) { const int r = row0 + j; b[j] = sJ + (r < n_mu ? r : n_mu) * NR; acc[j] = 0.0; }
         for (uint64_t mk = chain; mk; mk &= mk - 1) {
           const int k = __ffsll((unsigned long long)mk) - 1;
           const double av = a[k];
@@ -932,54 +1128,30 @@ __device__ MKH_PRE_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, doub
     }
   }
   wave_sync();
-  if (lane >= NR && lane < NR + n_mu) sW[lane - NR] -= we_mu;          // w = Jw·z − r
+  if (is_s) sW[my_c] -= we_mu;                                         // w = Jw·z − r
   wave_sync();
-  // ---- this lane's column of [S | Jh | w]
-  double z[kMu];
-  {
-    const double* src = sW;                                            // right-hand-side lane
-    int stride = 1;
-    if (lane < NR) { src = sJ + lane; stride = NR; }
-    else if (lane < NR + n_mu) src = sS + (lane - NR) * SP;
-    const bool live = lane <= NR + n_mu;
-#pragma unroll
-    for (int r = 0; r < kMu; ++r) z[r] = (live && r < n_mu) ? src[r * stride] : 0.0;
+  // ---- elimination (K = the smallest compiled row capacity that holds n_μ)
+  double ssq = 0.0, quad = 0.0, zw = 0.0;
+  // (the 24-row and two-register-set instantiations only exist in the F_COM variants, which the host also picks for
+  //  problems without a ComTask that need them: 48 + 48 column registers cost the lean variant its spill-free build)
+  if constexpr (kCom) {
+    if (dual) wood_eliminate<kMuBig, true>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status);
+    else if (n_mu <= kMu) wood_eliminate<kMu, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status);
+    else wood_eliminate<kMuBig, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status);
+  } else {
+    wood_eliminate<kMu, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status);
   }
-  double ssq = 0.0;
-#pragma unroll
-  for (int r = 0; r < kMu; ++r) ssq = fma(z[r], z[r], ssq);
-  const double hdiag = hdiag_base * (1.0 + ssq);                       // H[k][k] = Dg·(1 + Σ Jh²)  (only scales thresholds)
-  // ---- elimination
-  double quad = 0.0, zw = 0.0;
-  const unsigned plane_off = (unsigned)(lane & 15);
-  static_for<kMu>([&](auto rc) {
-    constexpr int r = decltype(rc)::value;
-    if (r < n_mu) {
-      wave_sync();                                                     // the previous row's readers are done
-      if (lane < NR) sJ[r * NR + lane] = z[r];                         // row r of Z, final
-      else if (lane - NR < kWoodRow) sRow[lane - NR] = z[r];
-      wave_sync();
-      const double d = sRow[r], om = sRow[n_mu];
-      const double p0 = sRow[plane_off], p1 = (kMu > 16) ? sRow[16 + plane_off] : 0.0;
-      if (!(d > 0.0)) status |= 4;
-      const double inv = fast_rcp(d);
-      if (lane == 0) sDinv[r] = inv;
-      const double zi = z[r] * inv;
-      quad = fma(z[r], zi, quad);
-      zw = fma(om, zi, zw);
-      wood_elim_step<r>(z, p0, p1, -zi);                               // z[i] −= S[i][r]·z[r]/d   (i > r)
-    }
-  });
   wave_sync();
   WoodOut wo;
-  wo.hdiag = hdiag; wo.dsq = dsq; wo.status = __ballot(status != 0) ? 4 : 0;
+  wo.hdiag = hdiag_base * (1.0 + ssq);                                 // H[k][k] = Dg·(1 + Σ Jh²)  (only scales thresholds)
+  wo.dsq = dsq; wo.status = __ballot(status != 0) ? 4 : 0;
   wo.D = (dsq * dsq) * (quad - 1.0);
   wo.x = -c_lane * (dsq * dsq) - dsq * zw;
   return wo;
 }
 #else
 struct WoodOut { double hdiag, dsq, x, D; int status; };
-__device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, double, double) { return WoodOut{0.0, 0.0, 0.0, 0.0, 0}; }
+__device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, int, int, double, double) { return WoodOut{0.0, 0.0, 0.0, 0.0, 0}; }
 #endif
 #ifdef MKH_W3
 #define MKH_STAGE (2 * ((MKH_NT + 15) / 16))   // 3-waves maps: only the planes the column has (gen_tab_asm.py)
@@ -1016,7 +1188,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
 #else
   constexpr int NR = NT;
 #endif
-  static_assert(!kWood || !(kRel || kCom || kColl), "low-rank start: frame/posture tasks + box limits only");
+  static_assert(!kWood || !(kRel || kColl), "low-rank start: frame / posture / CoM tasks + box limits only");
 #ifdef MKH_W3
   constexpr bool kCompact = true;            // LDS ranges aliased by phase (lds_layout): 12 waves per CU need ≤ 13.3 KB each
   static_assert(!kColl, "compact LDS layout: the collision phase reads the body poses after the Jacobian rows");
@@ -1028,7 +1200,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
   int lane = lane_id();     // (re-laundered at every phase boundary, see MKH_TICK)
   const int nq = P0.nq, nv = P0.nv, nbody = P0.nbody;
   const LdsLayout L = kernel_lds_layout(P0);
-  const bool prefetch = (kCompact ? (kWood ? P0.prefetch_w3w : P0.prefetch_w3) : P0.prefetch) != 0;
+  const bool prefetch = kernel_prefetch(P0);
   double* sq = smem + L.q;            // (sq / sTgt alternate between two buffers, see "load inputs")
   double* const sX = smem + L.X;
   const int XS = lds_even(nbody);                      // component stride of sX (consecutive lanes hit consecutive banks;
@@ -1252,7 +1424,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // tableau by n_μ rank-1 updates that do not depend on each other:  R[i][j] = Σ_r Z[r][i]·Z[r][j]/d_r
     WoodOut wo{0.0, 0.0, 0.0, 0.0, 0};
     if constexpr (kWood) {
-      wo = wood_start(Pq, oz, c_lane, hdiag_base);
+      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base);
       asm volatile("" : "+v"(lane));
       status |= wo.status;
       hdiag = wo.hdiag;

@@ -88,6 +88,7 @@ struct MkhProblem {
   // problem does not qualify; lower bound of the diagonal part of H without the damping argument, and
   // the largest squared task cost (conditioning gate, evaluated per call because damping is a call argument)
   int wood_nt = 0, wood_nr = 0, wood_lds_bytes = 0, wood_lds_bytes_w3 = 0;
+  bool wood_big = false;           // more than kMu task rows, or S columns in a second register set: the F_COM builds carry those
   double wood_min_diag = 0.0, wood_max_cost2 = 0.0;
   // lane-per-problem kernel for small arms (lane_kernel.h): template size (0 = the problem does not qualify)
   int lane_nv = 0, lane_lds = 0;
@@ -662,18 +663,36 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     }
     if (fits) P.n_dpairs = n;
   }
-  if (P.n_jrows > 0 && P.n_pairs == 0 && P.n_com == 0 && !p->has_relative && P.n_dense_rows == 0 &&
-      P.n_dense_limit_rows == 0 && 2 * P.n_jrows <= m->nv && P.n_jrows <= kMu) {
-    // (NT = NR: the task residuals are eliminated outside the tableau, one column of [S | Jh | w] per lane — wood_start)
+  if (P.n_jrows > 0 && P.n_pairs == 0 && !p->has_relative && P.n_dense_rows == 0 &&
+      P.n_dense_limit_rows == 0 && 4 * P.n_jrows <= 3 * m->nv && P.n_jrows <= kMuBig) {
+    // (NT = NR: the task residuals are eliminated outside the tableau, one column of [S | Jh] per lane — wood_start; the
+    //  S columns sit on lanes [NR, NR + n_μ) or, when those do not exist, on lanes [0, n_μ) in a second register set)
     static const int kWoodVariants[] = {16, 24, 32, 44, 48};
     for (int v : kWoodVariants)
-      if (m->nv <= v && v + P.n_jrows + 1 <= kWave) { p->wood_nt = v; p->wood_nr = v; break; }
+      if (m->nv <= v && (v + P.n_jrows <= kWave || P.n_jrows <= v)) { p->wood_nt = v; p->wood_nr = v; break; }
     if (p->wood_nt) {
+      p->wood_big = P.n_jrows > kMu || p->wood_nr + P.n_jrows > kWave;
+      const int sp = lds_even(P.n_jrows);
       auto lds_wood = [&](bool pre, bool compact) {
-        return lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, kMu + 1, p->wood_nr,
-                          wood_s_aliases_dof(P.nv, P.n_jrows, kMu) ? 0 : P.n_jrows * (kMu + 1), pre, 0, compact, true);
+        return lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, P.n_jrows + 1, p->wood_nr,
+                          wood_s_aliases_dof(P.nv, P.n_jrows, sp, P.n_com > 0 ? P.nbody : 0) ? 0 : P.n_jrows * (sp + 1),
+                          pre, 0, compact, true);
       };
-      const LdsLayout Lw = lds_wood(P.prefetch != 0, false);
+      // 2-waves map: the plain layout, or — when that would cost a resident wave and the pair lanes need one pass only (the
+      // compact layout lets the Jacobian rows overwrite the task blocks) — the compact one
+      P.wood_compact = 0; P.prefetch_wc = 0;
+      {
+        auto bytes = [&](bool pre, bool compact) { return lds_wood(pre, compact).total * (int)sizeof(double); };
+        if (waves_per_cu(p->wood_nt, bytes(false, false)) < waves_per_cu(p->wood_nt, 1) && P.n_jrows > 0) {
+          int n_jp = 0;
+          for (size_t t = 0; t < ft.size(); ++t) n_jp += __builtin_popcountll(ft[t].dof_mask);
+          if (n_jp <= kWave && waves_per_cu(p->wood_nt, bytes(false, true)) > waves_per_cu(p->wood_nt, bytes(false, false))) {
+            P.wood_compact = 1;
+            P.prefetch_wc = waves_per_cu(p->wood_nt, bytes(true, true)) == waves_per_cu(p->wood_nt, bytes(false, true)) ? 1 : 0;
+          }
+        }
+      }
+      const LdsLayout Lw = P.wood_compact ? lds_wood(P.prefetch_wc != 0, true) : lds_wood(P.prefetch != 0, false);
       // (column, row-chunk) lanes of the Jh·Jhᵀ product: rows 0..n_jrows (the last one is the rhs)
       const int groups = kWave / P.n_jrows;
       P.wood_rpc = (P.n_jrows + 1 + groups - 1) / groups;
@@ -699,11 +718,20 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
         for (int r = 0; r < 6; ++r)
           if ((ft[t].rowmask >> r) & 1) { P.mu_src[ft[t].jrow0 + c] = (int16_t)(t * 64 + 30 + r); ++c; }
       }
+      // ComTask rows: dense over the robot's dofs; their weighted error is computed on the device (mu_src < 0)
+      for (int t = 0; t < P.n_com; ++t) {
+        int c = 0;
+        for (int r = 0; r < 3; ++r)
+          if ((P.com_rowmask[t] >> r) & 1) { P.mu_src[P.com_jrow0[t] + c] = (int16_t)(-1 - 3 * t - r); ++c; }
+        for (int l = 0; l < kWave; ++l)
+          if (P.wood_col[l] >= P.com_jrow0[t] && P.wood_col[l] < P.com_jrow0[t] + c)
+            P.wood_mask[l] = m->nv >= 64 ? ~0ull : ((1ull << m->nv) - 1ull);
+      }
       p->wood_lds_bytes = Lw.total * (int)sizeof(double);
       if (p->wood_lds_bytes * 8 > 160 * 1024) p->wood_nt = 0;      // would cost residency
       // 3 waves per SIMD (compact layout: the Jacobian rows overwrite the task blocks, so the pair lanes need one pass)
       P.prefetch_w3w = 0;
-      if (p->wood_nt == 44 && P.n_jpairs <= kWave) {
+      if (p->wood_nt == 44 && P.n_jpairs <= kWave && P.n_com == 0 && !p->wood_big) {
         if (waves_per_cu(44, lds_wood(false, true).total * (int)sizeof(double), true) == 12) {
           P.prefetch_w3w = waves_per_cu(44, lds_wood(true, true).total * (int)sizeof(double), true) == 12 ? 1 : 0;
           p->wood_lds_bytes_w3 = lds_wood(P.prefetch_w3w != 0, true).total * (int)sizeof(double);
@@ -721,6 +749,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       }
       p->wood_min_diag = mn;
       for (const auto& f : ft) for (int k = 0; k < 6; ++k) p->wood_max_cost2 = fmax(p->wood_max_cost2, f.cost[k] * f.cost[k]);
+      for (int t = 0; t < P.n_com; ++t) for (int k = 0; k < 3; ++k) p->wood_max_cost2 = fmax(p->wood_max_cost2, P.com_cost[t][k] * P.com_cost[t][k]);
     }
   }
   {
@@ -834,10 +863,10 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   const bool prof_only = taps && !taps->t_xpos && !taps->t_xquat && !taps->t_frame_pose && !taps->t_subtree_com &&
                          !taps->t_task_e && !taps->t_task_J && !taps->t_H && !taps->t_c && !taps->t_box_lo &&
                          !taps->t_box_hi && !taps->t_coll_G && !taps->t_coll_h;
-  if (p->wood_nt && ((need & ~F_STEPS) == 0 || (need == F_TAPS && prof_only)) && a.do_qp &&
+  if (p->wood_nt && ((need & ~(F_STEPS | F_COM)) == 0 || (need == F_TAPS && prof_only)) && a.do_qp &&
       !(flags & MKH_FLAG_DIRECT_QP) && dg_min > 0.0 && dg_min >= 1e-7 * p->wood_max_cost2) {
     nt = p->wood_nt; nr = p->wood_nr; lds = p->wood_lds_bytes;
-    feat = F_WOOD | (need & (F_STEPS | F_TAPS));
+    feat = F_WOOD | (need & (F_STEPS | F_TAPS | F_COM)) | (p->wood_big ? F_COM : 0);
   }
   // three resident waves per SIMD where a variant exists (FrameTask / PostureTask / RelativeFrameTask / ComTask, box limits)
   static const int kW3Variants[][2] = {{44, 0}};   // (44_6 and 44_16 still spill 34–76 VGPRs at 74 registers: scratch traffic makes them slower than their 2-waves builds)
