@@ -42,6 +42,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 NTS = (8, 16, 24, 32, 40, 44, 48, 56, 62, 64)
 W3_NTS = (32, 40, 44)   # tableaus that also get the 3-waves-per-SIMD map (TabW3<NT>: TOP = 168)
+W4_NTS = (16, 24)       # ... and the 4-waves-per-SIMD map (TabW4<NT>: TOP = 128; Tab<16> / Tab<24> are 3-waves maps)
 def total_for(nt):
     # VGPRs per lane = 512 / resident waves per SIMD: small tableaus leave room for 4 (NT ≤ 8) or 3 (NT ≤ 24)
     # waves per SIMD instead of 2 — more waves hide more of the serial pivot chain (UR5e-class arms)
@@ -61,8 +62,9 @@ SPLIT_PREFIXES = (16, 24, 32)   # dof-row prefixes of the split rank-1 bodies (p
 def gen(nt: int, total: int = 0, name: str = "Tab") -> str:
     NTMP = ntmp_for(nt)
     TOTAL = total or total_for(nt)
-    if TOTAL == 168 and nt > 24:
-        NTMP = 2 * ((nt + 15) // 16)         # 3-waves maps: only the planes the column has (44 rows: 3 planes, 6 registers)
+    hi_map = name != "Tab"                   # TabW3 / TabW4: one more resident wave per SIMD than Tab<NT>, callee structure
+    if hi_map:
+        NTMP = 2 * ((nt + 15) // 16)         # only the planes the column has (44 rows: 3 planes, 6 registers)
     t0 = TOTAL - 2 * nt
     tmp0 = t0 - NTMP
     budget = tmp0
@@ -111,8 +113,8 @@ def gen(nt: int, total: int = 0, name: str = "Tab") -> str:
     out.append("  // request the pivot column lds[0..kRows): lane l gets lds[16·p + l % 16] in plane p (must be followed by a")
     out.append("  // rank1_body* with the same column)")
     out.append("  __device__ static __forceinline__ void rank1_prefetch(Regs&, unsigned lds_addr) {")
-    if TOTAL == 168 and nt > 24:
-        # 3-waves maps: the lane's plane address is computed inside the statement (mbcnt = lane id), in the first plane's own
+    if hi_map:
+        # high-occupancy maps: the lane's plane address is computed inside the statement (mbcnt = lane id), in the first plane's own
         # destination register — as a C++ value it is loop-invariant, lives through the whole QP and, with 72 registers for
         # the compiler, was the value hipcc chose to spill: one scratch reload at the head of every pivot's dependent chain
         pr = plane_reg(0)
@@ -261,9 +263,10 @@ def gen_wood_elim() -> str:
 
 def main():
     parts = ["// GENERATED by gen_tab_asm.py — do not edit.  Pinned-VGPR tableau primitives (see the generator's docstring).",
-             "#pragma once", "#include <hip/hip_runtime.h>", "namespace mkh {", "template <int NT> struct Tab;", "template <int NT> struct TabW3;"]
+             "#pragma once", "#include <hip/hip_runtime.h>", "namespace mkh {", "template <int NT> struct Tab;", "template <int NT> struct TabW3;", "template <int NT> struct TabW4;"]
     parts += [gen(nt) for nt in NTS]
     parts += [gen(nt, 168, "TabW3") for nt in W3_NTS]
+    parts += [gen(nt, 128, "TabW4") for nt in W4_NTS]
     parts.append(gen_wood_elim())
     parts.append("}  // namespace mkh")
     with open(os.path.join(HERE, "tab_asm.inc"), "w") as fh:

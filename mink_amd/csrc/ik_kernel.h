@@ -32,7 +32,9 @@
 
 // Register map of the tableau: Tab<NT> (2 resident waves per SIMD for NT > 24) or, in the variant TUs that define
 // MKH_W3, TabW3<NT> — the same primitives pinned below 168 VGPRs, i.e. 3 resident waves per SIMD.
-#ifdef MKH_W3
+#if defined(MKH_W4)     // (a W4 translation unit also defines MKH_W3: the same call structure and compact LDS layout)
+#define MKH_TAB TabW4
+#elif defined(MKH_W3)
 #define MKH_TAB TabW3
 #else
 #define MKH_TAB Tab
@@ -937,7 +939,8 @@ __device__ __forceinline__ void wood_eliminate(int n_mu, int NR, int lane, doubl
 #else
 #define MKH_WOOD_ATTR __forceinline__
 #endif
-__device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int off_q, int off_tgt, double c_lane, double hdiag_base) {
+__device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int off_q, int off_tgt, double c_lane, double hdiag_base,
+                                             long long* prof = nullptr) {   // prof (inlined profiling build only): cycle stamps
   constexpr int NR = MKH_NT;
   constexpr bool kCom = (MKH_FEAT & F_COM) != 0;
   static_assert(MKH_NR == MKH_NT, "low-rank start: the residual rows are not tableau rows any more");
@@ -1061,6 +1064,7 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
     }
   }
   wave_sync();
+  if (prof) prof[0] = __builtin_readcyclecounter();                    // Jacobian rows staged
   // ---- S = I + Jh·Jhᵀ and Jw·z by (column, row-chunk) lanes: 64/n_μ chunks of rows per column, each lane a handful of
   // dot products on its own LDS addresses.  A row of Jh is nonzero only on the kinematic chain of its task (12–16 of the
   // 43 dofs on G1): the dot products walk the set bits of the column's chain mask instead of all NR dofs.
@@ -1130,6 +1134,7 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
   wave_sync();
   if (is_s) sW[my_c] -= we_mu;                                         // w = Jw·z − r
   wave_sync();
+  if (prof) prof[1] = __builtin_readcyclecounter();                    // S and w ready
   // ---- elimination (K = the smallest compiled row capacity that holds n_μ)
   double ssq = 0.0, quad = 0.0, zw = 0.0;
   // (the 24-row and two-register-set instantiations only exist in the F_COM variants, which the host also picks for
@@ -1151,14 +1156,17 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
 }
 #else
 struct WoodOut { double hdiag, dsq, x, D; int status; };
-__device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, int, int, double, double) { return WoodOut{0.0, 0.0, 0.0, 0.0, 0}; }
+__device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, int, int, double, double, long long* = nullptr) { return WoodOut{0.0, 0.0, 0.0, 0.0, 0}; }
 #endif
 #ifdef MKH_W3
 #define MKH_STAGE (2 * ((MKH_NT + 15) / 16))   // 3-waves maps: only the planes the column has (gen_tab_asm.py)
 #else
 #define MKH_STAGE 8   // staging VGPRs of the rank-1 update: four 16-lane planes of the pivot column (gen_tab_asm.py ntmp_for)
 #endif
-#ifdef MKH_W3
+#if defined(MKH_W4)
+#define MKH_WAVES 4
+#define MKH_TOP 128
+#elif defined(MKH_W3)
 #define MKH_WAVES 3
 #define MKH_TOP 168
 #else
@@ -1424,10 +1432,21 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // tableau by n_μ rank-1 updates that do not depend on each other:  R[i][j] = Σ_r Z[r][i]·Z[r][j]/d_r
     WoodOut wo{0.0, 0.0, 0.0, 0.0, 0};
     if constexpr (kWood) {
+#ifdef MKH_WOOD_CALL
       wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base);
+#else
+      long long wprof[2] = {0, 0};
+      const long long wt0 = MKH_TAP(t_cycles) ? __builtin_readcyclecounter() : 0;
+      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, MKH_TAP(t_cycles) ? wprof : nullptr);
+      if (MKH_TAP(t_cycles)) {                 // phase_profile.py: Jacobian rows | S and w | elimination  (slots 0, 1, 2)
+        const long long wt1 = __builtin_readcyclecounter();
+        ta[0] += wprof[0] - wt0; ta[1] += wprof[1] - wprof[0]; ta[2] += wt1 - wprof[1];
+      }
+#endif
       asm volatile("" : "+v"(lane));
       status |= wo.status;
       hdiag = wo.hdiag;
+      if (MKH_TAP(t_cycles)) ta[3] -= __builtin_readcyclecounter();
       MKH_TAB<NT>::zero(ts);
       const int n_mu = P.n_jrows;
       const double* const sDinv = sPiv + kWoodRow;
@@ -1440,6 +1459,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         const int hb = nzd ? 64 - __builtin_clzll(nzd) : 0;
         rank1_leading_rows<NT>(ts, lds_addr(sJ + r * NT), g, hb <= 16 ? 16 : (hb <= 24 ? 24 : (hb <= 32 ? 32 : NT)));
       }
+      if (MKH_TAP(t_cycles)) { asm volatile("s_waitcnt lgkmcnt(0)"); ta[3] += __builtin_readcyclecounter(); }   // (− start below)
     }
     auto frame_column = [&](int t, int k, uint64_t mask, uint64_t rmask, bool rel, double (&Jt)[6]) {
       frame_column_fn<kRel>(sTask, sDof, t, k, mask, rmask, rel, Jt);

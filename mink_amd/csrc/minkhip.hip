@@ -229,7 +229,8 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
 // variant was built for (4 waves/SIMD for NT ≤ 8, 3 for NT ≤ 24, else 2 — ik_kernel.h MKH_WAVES).
 static int waves_per_cu(int nt, int lds_bytes, bool w3 = false) {
   const int by_lds = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
-  const int by_regs = 4 * (nt <= 8 ? 4 : ((nt <= 24 || w3) ? 3 : 2));
+  // (w3: the high-occupancy build of the variant — one more resident wave per SIMD than its plain register map)
+  const int by_regs = 4 * (nt <= 8 ? 4 : (nt <= 24 ? (w3 ? 4 : 3) : (w3 ? 3 : 2)));
   const int w = by_lds < by_regs ? by_lds : by_regs;
   return w < 1 ? 1 : w;
 }
@@ -664,7 +665,9 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     if (fits) P.n_dpairs = n;
   }
   if (P.n_jrows > 0 && P.n_pairs == 0 && !p->has_relative && P.n_dense_rows == 0 &&
-      P.n_dense_limit_rows == 0 && 4 * P.n_jrows <= 3 * m->nv && P.n_jrows <= kMuBig) {
+      P.n_dense_limit_rows == 0 && P.n_jrows <= kMuBig &&
+      // fewer task rows than dofs by a margin: half (measured on arms and hands), three quarters for humanoid-size tableaus
+      (2 * P.n_jrows <= m->nv || (m->nv >= 32 && 4 * P.n_jrows <= 3 * m->nv))) {
     // (NT = NR: the task residuals are eliminated outside the tableau, one column of [S | Jh] per lane — wood_start; the
     //  S columns sit on lanes [NR, NR + n_μ) or, when those do not exist, on lanes [0, n_μ) in a second register set)
     static const int kWoodVariants[] = {16, 24, 32, 44, 48};
@@ -731,9 +734,10 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       if (p->wood_lds_bytes * 8 > 160 * 1024) p->wood_nt = 0;      // would cost residency
       // 3 waves per SIMD (compact layout: the Jacobian rows overwrite the task blocks, so the pair lanes need one pass)
       P.prefetch_w3w = 0;
-      if (p->wood_nt == 44 && P.n_jpairs <= kWave && P.n_com == 0 && !p->wood_big) {
-        if (waves_per_cu(44, lds_wood(false, true).total * (int)sizeof(double), true) == 12) {
-          P.prefetch_w3w = waves_per_cu(44, lds_wood(true, true).total * (int)sizeof(double), true) == 12 ? 1 : 0;
+      if (p->wood_nt != 48 && P.n_jpairs <= kWave && P.n_com == 0 && !p->wood_big) {   // (build.py W3_WOOD: 16, 24, 32, 44)
+        const int full = waves_per_cu(p->wood_nt, 1, true);     // 16 waves per CU for NT ≤ 24, else 12
+        if (waves_per_cu(p->wood_nt, lds_wood(false, true).total * (int)sizeof(double), true) == full) {
+          P.prefetch_w3w = waves_per_cu(p->wood_nt, lds_wood(true, true).total * (int)sizeof(double), true) == full ? 1 : 0;
           p->wood_lds_bytes_w3 = lds_wood(P.prefetch_w3w != 0, true).total * (int)sizeof(double);
         }
       }
@@ -874,7 +878,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   if (!nr && p->lds_bytes_w3 && !(flags & MKH_FLAG_TWO_WAVES))
     for (const auto& v : kW3Variants) w3 = w3 || (v[0] == nt && v[1] == feat);
   if (w3) lds = p->lds_bytes_w3;
-  if (nr == 44 && p->wood_lds_bytes_w3 && !(flags & MKH_FLAG_TWO_WAVES) && (feat == F_WOOD || feat == (F_WOOD | F_STEPS))) {
+  if (nr && p->wood_lds_bytes_w3 && !(flags & MKH_FLAG_TWO_WAVES) && (feat == F_WOOD || feat == (F_WOOD | F_STEPS))) {
     w3 = true; lds = p->wood_lds_bytes_w3;
   }
   const int grid = grid_for_variant(p, a.B, nt, lds, w3);

@@ -60,7 +60,7 @@ def main():
             li = prob.launch_info(B)
             grid, lds = li["grid"], li["lds_bytes"]
             print("%-8s %-12s %-28s grid %5d lds %6d  %8.3f ms  %7.2f M solves/s  failed %d" %
-                  (name, "2 waves" if two else "default", prob.last_kernel(), grid, lds, ms, B / ms / 1e3, bad), flush=True)
+                  (name, "plain map" if two else "default", prob.last_kernel(), grid, lds, ms, B / ms / 1e3, bad), flush=True)
         d = np.abs(res[True] - res[False]).max()
         print("   max |v(default) - v(2 waves)| = %.3e" % d)
         # C oracle on a sample of the default result

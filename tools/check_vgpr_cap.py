@@ -46,7 +46,8 @@ def check(src: str):
     import build as hipbuild
     import gen_tab_asm as gen
     nt = int(re.search(r"variant_(\d+)_", os.path.basename(src)).group(1))
-    top = 168 if os.path.basename(src).endswith("_w3.hip") else gen.total_for(nt)   # (TabW3: 3 waves per SIMD)
+    # (_w3: the high-occupancy build — TabW3, 168 registers, for NT > 24; TabW4, 128 registers, for NT ≤ 24)
+    top = (128 if nt <= 24 else 168) if os.path.basename(src).endswith("_w3.hip") else gen.total_for(nt)
     w3 = os.path.basename(src).endswith("_w3.hip")
     cap = top - 2 * nt - (2 * ((nt + 15) // 16) if w3 else gen.ntmp_for(nt))
     out = subprocess.run([hipbuild._hipcc()] + hipbuild.FLAGS + hipbuild.KERNEL_FLAGS +

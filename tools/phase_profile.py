@@ -26,6 +26,8 @@ for k, n in enumerate(names):
     print("  %-16s mean %8.0f  (%4.1f%%)" % (n, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean()))
 print("    %-18s mean %8.0f   (then low-rank S block / rhs: %.0f)" % ("J columns", (c[:, 14] - c[:, 3]).mean(), (c[:, 4] - c[:, 14]).mean()))
 sub = ["phase-0 publish", "phase-0 rcp+pivot", "GI select", "GI publish", "GI ratio test", "GI pivot"]
+if "_r" in prob.last_kernel():      # low-rank start: slots 0-3 are the stages of wood_start and the rank-1 updates that follow
+    sub = ["low-rank: J rows", "low-rank: S, w", "low-rank: elimination", "low-rank: rank-1 dof block (+GI publish)", "GI ratio test", "GI pivot"]
 for k, n in enumerate(sub):
     print("    %-18s mean %8.0f" % (n, c[:, 8 + k].mean()))
 it = t["qp_iters"]
