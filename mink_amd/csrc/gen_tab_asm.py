@@ -40,14 +40,14 @@ loads are asynchronous, the compiler must never touch their destination between 
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-NTS = (8, 16, 24, 32, 40, 44, 48, 56, 62, 64)
-W3_NTS = (32, 40, 44)   # tableaus that also get the 3-waves-per-SIMD map (TabW3<NT>: TOP = 168)
+NTS = (8, 16, 24, 32, 44, 48, 64)
+W3_NTS = (32, 44)   # tableaus that also get the 3-waves-per-SIMD map (TabW3<NT>: TOP = 168)
 W4_NTS = (16, 24)       # ... and the 4-waves-per-SIMD map (TabW4<NT>: TOP = 128; Tab<16> / Tab<24> are 3-waves maps)
 def total_for(nt):
     # VGPRs per lane = 512 / resident waves per SIMD: small tableaus leave room for 4 (NT ≤ 8) or 3 (NT ≤ 24)
     # waves per SIMD instead of 2 — more waves hide more of the serial pivot chain (UR5e-class arms)
     return 128 if nt <= 8 else (168 if nt <= 24 else 256)
-NRS = (16, 24, 32, 44, 48)   # dof-row counts of the low-rank start (kernel variants MKH_NR)
+NRS = (16, 24, 32, 44, 48)   # leading-row counts of the partial loads / updates (a_stride_for in ik_kernel.h; dof-row prefixes of the low-rank start)
 def ntmp_for(nt):
     # Staging registers of the rank-1 update.  Round 1 streamed the pivot column through broadcast ds_read_b128 (two rows
     # per read, 6-8 reads in flight = 24-32 registers).  A broadcast read returns 1 KiB to the wave whatever its address
@@ -56,7 +56,6 @@ def ntmp_for(nt):
     # the four "planes" p with ONE lane-indexed ds_read_b64 each (4 x 512 B), and the broadcast happens in the DPP operand
     # network: v_fmac_f64_dpp T[i], plane[i / 16], g row_newbcast:(i % 16) — 531 ticks in the same benchmark.
     return 8
-SPLIT_PREFIXES = (16, 24, 32)   # dof-row prefixes of the split rank-1 bodies (phase 0 of the low-rank start)
 
 
 def gen(nt: int, total: int = 0, name: str = "Tab") -> str:
@@ -172,40 +171,6 @@ def gen(nt: int, total: int = 0, name: str = "Tab") -> str:
         out.append(f"  __device__ static __forceinline__ void rank1_body_{nr}(Regs& t, unsigned, double g) {{")
         out.append(stmt(J(rank1_lines(range(nr))), ins=IN_G, clob=clob_tmp + ', "memory"'))
         out.append("  }")
-        if nr < nt:
-            out.append(f"  // rank1_body_{nr} + look-ahead store")
-            out.append(f"  __device__ static __forceinline__ void rank1_body_{nr}_pub(Regs& t, unsigned, double g, unsigned pub_addr, double pub) {{")
-            out.append(stmt(J(rank1_lines(range(nr), pub=True)), ins=IN_PUB, clob=clob_tmp + ', "memory"'))
-            out.append("  }")
-        if nr < nt:
-            # phase 0 of the low-rank start: the pivot column of a task residual is zero on the dof rows outside
-            # the kinematic chains reached so far — rows [0, p) of the dof block plus the residual rows [nr, nt)
-            for pfx in SPLIT_PREFIXES:
-                if pfx >= nr:
-                    continue
-                out.append(f"  // rank1_body restricted to rows [0, {pfx}) and [{nr}, {nt}), + look-ahead store")
-                out.append(f"  __device__ static __forceinline__ void rank1_body_{pfx}_hi_{nr}(Regs& t, unsigned, double g, unsigned pub_addr, double pub) {{")
-                out.append(stmt(J(rank1_lines(list(range(pfx)) + list(range(nr, nt)), pub=True)), ins=IN_PUB, clob=clob_tmp + ', "memory"'))
-                out.append("  }")
-        if nr < nt:
-            lines = [f"ds_read_b128 v[{t0 + 2 * nr + 4 * k}:{t0 + 2 * nr + 4 * k + 3}], %[a] offset:{16 * k}" for k in range((nt - nr) // 2)]
-            lines.append("s_waitcnt lgkmcnt(0)")
-            out.append(f"  // T[{nr} + i] = lds[i], i < {nt - nr}  (the residual rows of the low-rank start)")
-            out.append(f"  __device__ static __forceinline__ void load_hi_{nr}(Regs& t, unsigned lds_addr) {{")
-            out.append(stmt(J(lines), ins='[a] "v"(lds_addr)', clob='"memory"'))
-            out.append("  }")
-        if nr < nt:
-            sp = nt - nr
-            lines = [f"ds_read_b64 {treg(nr + r)}, %[a] offset:{8 * nr * r}" for r in range(sp)]
-            lines.append("s_waitcnt lgkmcnt(0)")
-            for r in range(sp):
-                lines.append(f"v_fma_f64 %[s{r % 2}], {treg(nr + r)}, {treg(nr + r)}, %[s{r % 2}]")
-            out.append(f"  // T[{nr} + r] = lds[r·{nr}], r < {sp} (column `lane` of the row-major Jh array, stride {nr}); returns Σ_r T[{nr}+r]²")
-            out.append(f"  __device__ static __forceinline__ double load_hi_strided_{nr}(Regs& t, unsigned lds_addr) {{")
-            out.append("    double a0 = 0.0, a1 = 0.0;")
-            out.append(stmt(J(lines), outs='[s0] "+v"(a0), [s1] "+v"(a1)', ins='[a] "v"(lds_addr)', clob='"memory"'))
-            out.append("    return a0 + a1;")
-            out.append("  }")
     # get / set with compile-time index
     out.append("  template <int I> __device__ static __forceinline__ double get(Regs& t) {")
     out.append("    int lo, hi;")

@@ -63,12 +63,12 @@ struct LdsLayout {
 __host__ __device__ inline int lds_even(int x) { return (x + 1) & ~1; }
 __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int njnt, int n_frame,
                                                 int n_posture, int n_com, int max_rows, int j_rows, int j_stride,
-                                                int s_doubles = 0, bool prefetch = false, int j_min = 0,
-                                                bool compact = false, bool wood = false) {
+                                                int s_doubles = 0, bool prefetch = false, bool compact = false,
+                                                bool wood = false) {
   LdsLayout L;
   int o = 0;
   const int x_sz = 7 * lds_even(nbody), jnt_sz = lds_even(njnt * 6);
-  const int j_sz = lds_even(j_rows * j_stride > j_min ? j_rows * j_stride : j_min);   // (j_min: block buffer of the low-rank start's phase 0)
+  const int j_sz = lds_even(j_rows * j_stride);
   L.q = o;    o += lds_even(nq);
   // compact (3-waves-per-SIMD variants, no collision rows): ranges that are not alive at the same time share storage.
   //   direct start:   {body poses, joint axes}              | {staged Jacobian rows of one task, pivot buffers}
@@ -245,38 +245,6 @@ __device__ __forceinline__ void load_leading_rows(typename MKH_TAB<NT>::Regs& ts
   if constexpr (NT > 48) { if (n == 48) MKH_TAB<NT>::load_lo_48(ts, addr); }
 }
 
-template <int NT, int ROWS>
-__device__ __forceinline__ void load_hi_rows(typename MKH_TAB<NT>::Regs& ts, unsigned addr) {
-  if constexpr (ROWS == 16 && NT > 16) MKH_TAB<NT>::load_hi_16(ts, addr);
-  else if constexpr (ROWS == 24 && NT > 24) MKH_TAB<NT>::load_hi_24(ts, addr);
-  else if constexpr (ROWS == 32 && NT > 32) MKH_TAB<NT>::load_hi_32(ts, addr);
-  else if constexpr (ROWS == 44 && NT > 44) MKH_TAB<NT>::load_hi_44(ts, addr);
-  else if constexpr (ROWS == 48 && NT > 48) MKH_TAB<NT>::load_hi_48(ts, addr);
-}
-
-template <int NT, int ROWS>
-__device__ __forceinline__ double load_hi_strided_rows(typename MKH_TAB<NT>::Regs& ts, unsigned addr) {
-  if constexpr (ROWS == 16 && NT > 16) return MKH_TAB<NT>::load_hi_strided_16(ts, addr);
-  else if constexpr (ROWS == 24 && NT > 24) return MKH_TAB<NT>::load_hi_strided_24(ts, addr);
-  else if constexpr (ROWS == 32 && NT > 32) return MKH_TAB<NT>::load_hi_strided_32(ts, addr);
-  else if constexpr (ROWS == 44 && NT > 44) return MKH_TAB<NT>::load_hi_strided_44(ts, addr);
-  else if constexpr (ROWS == 48 && NT > 48) return MKH_TAB<NT>::load_hi_strided_48(ts, addr);
-  else return 0.0;
-}
-
-// Phase 0 of the low-rank start: rows [0, hb) of the dof block (hb = one past the last nonzero dof row of the
-// pivot column, wave-uniform) and the residual rows [NR, NT).  The column of a task residual is zero outside the
-// kinematic chains swept so far, and the dofs of a limb are contiguous in MuJoCo's depth-first order.
-template <int NT, int NR>
-__device__ __forceinline__ void rank1_split_rows(typename MKH_TAB<NT>::Regs& ts, unsigned addr, double g, int hb, unsigned pub_addr, double pub) {
-#define MKH_SPLIT(P, R) if constexpr (NR == R && NT > R && (P) < R) { if (hb <= (P)) { MKH_TAB<NT>::rank1_body_##P##_hi_##R(ts, addr, g, pub_addr, pub); return; } }
-  MKH_SPLIT(16, 24) MKH_SPLIT(16, 32) MKH_SPLIT(24, 32)
-  MKH_SPLIT(16, 44) MKH_SPLIT(24, 44) MKH_SPLIT(32, 44)
-  MKH_SPLIT(16, 48) MKH_SPLIT(24, 48) MKH_SPLIT(32, 48)
-#undef MKH_SPLIT
-  MKH_TAB<NT>::rank1_body_pub(ts, addr, g, pub_addr, pub);
-}
-
 template <int NT, int ROWS = NT>
 __device__ __forceinline__ void pivot(typename MKH_TAB<NT>::Regs& ts, QpLane& s, int k, bool reverse, int lane, const double* sPiv,
                                       double own, const PivotScalars& ps, double inv) {
@@ -404,7 +372,7 @@ __device__ __forceinline__ LdsLayout kernel_lds_layout(const PT& P0) {
                     kWood ? P0.n_jrows + 1 : 6, kWood ? NR : j_stride_direct(P0.nv, NT),
                     (kWood && !wood_s_aliases_dof(P0.nv, P0.n_jrows, lds_even(P0.n_jrows), P0.n_com > 0 ? P0.nbody : 0))
                         ? P0.n_jrows * (lds_even(P0.n_jrows) + 1) : 0,
-                    kernel_prefetch(P0), 0, kCompact || (kWood && P0.wood_compact != 0), kWood);
+                    kernel_prefetch(P0), kCompact || (kWood && P0.wood_compact != 0), kWood);
 }
 __device__ MKH_PRE_ATTR PreOut pre_phases(const DeviceProblem* Pq, const TapArgs* tp, int pb, int oz, int off_q, int off_tgt,
                                           bool until, double pos_thr, double ori_thr MKH_PRE_TC_PARAMS) {
@@ -1915,12 +1883,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         pd = readlane_f64(s.D, kn); psg = readlane_f64(s.sg, kn); px = readlane_f64(s.x, kn);
       }
       const unsigned pub_addr = lds_addr(bufn + lane);
-      if constexpr (kWood) {
-        // dof rows the pivot column reaches: [0, hb)
-        const unsigned long long nzd = __ballot(own != 0.0) & ((1ull << NR) - 1ull);
-        const int hb = nzd ? 64 - __builtin_clzll(nzd) : 0;
-        rank1_split_rows<NT, NR>(ts, lds_addr(bufc), -g, hb, pub_addr, own_next);
-      } else {
+      {
         MKH_TAB<NT>::rank1_body_pub(ts, lds_addr(bufc), -g, pub_addr, own_next);   // R[i][lane] −= R[i][k]·g   (row k: published 0)
       }
       MKH_LAP(1);

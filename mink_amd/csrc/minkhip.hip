@@ -642,7 +642,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   if (p->nt == 44 && P.max_rows == 0 && P.n_dense_rows == 0) {
     auto lds_w3 = [&](bool pre) {
       return lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, j_stride_direct(P.nv, p->nt), 0,
-                        pre, 0, true).total * (int)sizeof(double);
+                        pre, true).total * (int)sizeof(double);
     };
     if (waves_per_cu(p->nt, lds_w3(false), true) == 12) {
       P.prefetch_w3 = waves_per_cu(p->nt, lds_w3(true), true) == 12 ? 1 : 0;
@@ -679,7 +679,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       auto lds_wood = [&](bool pre, bool compact) {
         return lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, P.n_jrows + 1, p->wood_nr,
                           wood_s_aliases_dof(P.nv, P.n_jrows, sp, P.n_com > 0 ? P.nbody : 0) ? 0 : P.n_jrows * (sp + 1),
-                          pre, 0, compact, true);
+                          pre, compact, true);
       };
       // 2-waves map: the plain layout, or — when that would cost a resident wave and the pair lanes need one pass only (the
       // compact layout lets the Jacobian rows overwrite the task blocks) — the compact one
