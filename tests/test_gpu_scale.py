@@ -199,3 +199,50 @@ def test_launches_replay_inside_a_hip_graph(g1_setup):
     v_again, _ = prob.solve(q_d, tg_d, pt_d, None, dt, damping)      # and eager launches still work afterwards
     torch.cuda.synchronize()
     assert torch.equal(v_again, v_ref)
+
+
+def test_low_rank_start_with_com_rows_and_many_task_rows():
+    """The F_COM builds of the low-rank start: ComTask rows, more than 18 task rows, and the two-pass
+    elimination when NR + n_μ lanes do not exist — each against the direct start of the same problem and the C oracle."""
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+    from oracle import cport
+    model = workloads.load_robot("g1")
+    nm = nat.NativeModel(model)
+    stand = model.key_qpos[0]
+    B = 4096
+    # (a) the G1 full example: 21 frame-task rows + 3 ComTask rows = 24 > 64 − 44 lanes: two passes
+    prob, dt, damping = nc.build("g1_full", nm, B)
+    q, tg = workloads.make_batch(model, nm, prob, np.random.default_rng(3), B, base_q=stand)
+    _, _, t = prob.solve(q, tg, stand[None, :], np.zeros((1, 3)), dt, damping, taps=["subtree_com"], solve_qp=False)
+    com = t["subtree_com"][:, None, :] + 0.01
+    v, st = prob.solve(q, tg, stand[None, :], com, dt, damping)
+    assert prob.last_kernel() == "ik_solve_kernel_44_36_r44", prob.last_kernel()
+    vd, std = prob.solve(q, tg, stand[None, :], com, dt, damping, direct_qp=True)
+    assert prob.last_kernel() == "ik_solve_kernel_44_6", prob.last_kernel()
+    assert (st == 0).all() and (std == 0).all()
+    err = np.abs(v - vd).max() / max(1.0, np.abs(vd).max())
+    print("G1 full example: low-rank (two-pass) vs direct start, max rel |dv| = %.2e" % err)
+    assert err < 1e-9
+    n = 512                                            # (the C oracle takes one CoM target for the whole batch)
+    vs, sts = prob.solve(q[:n], tg[:n], stand[None, :], com[0], dt, damping)
+    assert prob.last_kernel() == "ik_solve_kernel_44_36_r44" and (sts == 0).all()
+    m, tasks, limits, dt_o, damp_o = oc.g1_full(tg[0], stand, com[0, 0])
+    v_c, st_c = cport.CProblem(m, tasks, limits).solve_batch(q[:n], tg[:n], stand[None, :], dt_o, damp_o, com_target=com[0, 0])
+    assert (st_c == 0).all()
+    assert (np.abs(vs - v_c).max(axis=1) / np.maximum(1.0, np.abs(v_c).max(axis=1))).max() < 1e-8
+    # (b) 20 task rows without a ComTask: one pass with the 24-row instantiation (44 + 20 lanes exist)
+    fts = [nc._ft(model, s, "site", 200.0, 10.0, 1.0) for s in ("left_foot", "right_foot", "left_palm")]
+    fts.append({"frame_type": "site", "frame_id": model.name2id("site", "right_palm"), "cost": [150.0, 150.0, 0, 0, 0, 0],
+                "gain": 1.0, "lm_damping": 1.0})
+    p20 = nat.NativeProblem(nm, frame_tasks=fts, posture_tasks=[{"cost": 1.0}], configuration_limits=[nc._cfg_limit(model)],
+                            velocity_limits=[nc._vel_limit(model)], max_batch=B)
+    q2, tg2 = workloads.make_batch(model, nm, p20, np.random.default_rng(4), B, base_q=stand)
+    v2, st2 = p20.solve(q2, tg2, stand[None, :], None, 5e-3, 1e-1)
+    assert p20.last_kernel() == "ik_solve_kernel_44_36_r44", p20.last_kernel()
+    v2d, st2d = p20.solve(q2, tg2, stand[None, :], None, 5e-3, 1e-1, direct_qp=True)
+    assert "_r" not in p20.last_kernel()
+    assert (st2 == 0).all() and (st2d == 0).all()
+    err2 = np.abs(v2 - v2d).max() / max(1.0, np.abs(v2d).max())
+    print("G1, 20 task rows: low-rank (24-row columns) vs direct start, max rel |dv| = %.2e" % err2)
+    assert err2 < 1e-9
