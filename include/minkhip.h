@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MKH_VERSION 102
+#define MKH_VERSION 103
 
 /* return codes */
 #define MKH_OK 0

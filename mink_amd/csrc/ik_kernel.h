@@ -18,10 +18,16 @@
 //                             K = [[H, Aᵀ],[A, 0]] held in pinned VGPRs (tab_asm.inc); the dual
 //                             active-set QP (replaces qpsolvers→quadprog, mink/solve_ik.py:101) is a
 //                             sequence of rank-1 sweeps: the pivot column goes through LDS once
-//                             (indexed row read + one ds_write), broadcast ds_read_b128 + v_fma_f64.
-//                             Low-rank variants (F_WOOD) start from [[Dg, Jwᵀ],[Jw, −I]] instead and
-//                             pivot only the task-residual indices.
+//                             (indexed row read + one ds_write), comes back as 16-lane planes and is
+//                             broadcast by the DPP operand network (v_fmac_f64_dpp row_newbcast).
+//                             Low-rank variants (F_WOOD) never sweep a dof: H = Dg + JwᵀJw, the task
+//                             residuals are eliminated outside the tableau — one column of [S | Jh]
+//                             per lane — and the dof block −H⁻¹ is built by rank-1 updates that do not
+//                             depend on each other (wood_start).
 // Per-problem J rows, task blocks, poses and half-space rows are staged in LDS.
+// Kernel builds with one more resident wave per SIMD (_w3: 168 / 128 registers) run the phases that need many
+// registers — kinematics, Lie algebra, Jacobian rows, the elimination — as real function calls (pre_phases,
+// wood_start, direct_pairs), which are not bound by the kernel's register cap.
 #pragma once
 #include "collide_dev.h"
 #include "lie_dev.h"
@@ -264,9 +270,9 @@ __device__ __forceinline__ void pivot(typename MKH_TAB<NT>::Regs& ts, QpLane& s,
 // Compile-time feature set of a kernel variant.  The hot production variant (FEAT = 0) carries no
 // tap code, no RelativeFrameTask / CoM / collision branches and no fused step loop: fewer live values
 // for the compiler's 128-VGPR budget and a smaller instruction footprint.
-// F_WOOD: low-rank ("Woodbury") start of the QP — H = Dg + JwᵀJw is never formed; the dof indices of the
-// augmented tableau [[Dg, Jwᵀ],[Jw, −I]] are swept in closed form and only the n_μ task-residual indices
-// take rank-1 pivots (18 instead of 43 for the G1 benchmark).  tools/proto_woodbury.py states it in numpy.
+// F_WOOD: low-rank ("Woodbury") start of the QP — H = Dg + JwᵀJw is never formed and no dof index is ever swept on the
+// tableau: with S = I + Jh·Jhᵀ = L·D·Lᵀ and Z = L⁻¹Jh the dof block after phase 0 is −σσᵀ∘(I − ZᵀD⁻¹Z) (wood_start below;
+// tools/proto_woodbury.py states the algebra in numpy).  F_WOOD | F_COM: + ComTask rows, up to 24 task rows.
 // taps that exist in the low-rank variants (profiling only: H is never formed there)
 constexpr bool kTapIsProf_t_xpos = false, kTapIsProf_t_xquat = false, kTapIsProf_t_frame_pose = false,
                kTapIsProf_t_subtree_com = false, kTapIsProf_t_task_e = false, kTapIsProf_t_task_J = false,
