@@ -171,6 +171,19 @@ def gen(nt: int, total: int = 0, name: str = "Tab") -> str:
         out.append(f"  __device__ static __forceinline__ void rank1_body_{nr}(Regs& t, unsigned, double g) {{")
         out.append(stmt(J(rank1_lines(range(nr))), ins=IN_G, clob=clob_tmp + ', "memory"'))
         out.append("  }")
+    # streamed rank-1 updates (the chain-free dof-block updates of the low-rank start): the statement consumes the planes of
+    # THIS row and, as soon as the last FMA that reads a plane has issued, requests that plane of the NEXT row (per-lane
+    # address %[an] = next row + 8·(lane % 16)) — the LDS latency of row r + 1 hides under the FMAs of row r.  (An in-flight
+    # load only writes its destination long after the FMAs issued before it have read theirs.)
+    for nr in sorted(set([r for r in NRS if r < nt] + [nt])):
+        lines = ["s_waitcnt lgkmcnt(0)", "s_nop 4"]
+        for p in range(nplanes):
+            lines += [fmac(i) for i in range(16 * p, min(16 * p + 16, nr))]
+            lines.append(f"ds_read_b64 v[{plane_reg(p)}:{plane_reg(p) + 1}], %[an] offset:{128 * p}")
+        out.append(f"  // T[i] += lds[i]·g for i < {nr} with the planes already requested; requests the planes at lane address `next`")
+        out.append(f"  __device__ static __forceinline__ void rank1_stream_{nr}(Regs& t, unsigned next, double g) {{")
+        out.append(stmt(J(lines), ins='[g] "v"(g), [an] "v"(next)', clob=clob_tmp + ', "memory"'))
+        out.append("  }")
     # get / set with compile-time index
     out.append("  template <int I> __device__ static __forceinline__ double get(Regs& t) {")
     out.append("    int lo, hi;")

@@ -240,6 +240,21 @@ __device__ __forceinline__ void rank1_leading_rows(typename MKH_TAB<NT>::Regs& t
   if constexpr (NT > 48) { if (n == 48) MKH_TAB<NT>::rank1_body_48(ts, addr, g); }
 }
 
+// streamed update of the rows [0, hb) (rounded up to a generated prefix); see gen_tab_asm.py rank1_stream_*
+template <int NT>
+__device__ __forceinline__ void rank1_stream_rows(typename MKH_TAB<NT>::Regs& ts, unsigned next, double g, int hb) {
+  if constexpr (NT > 16) { if (hb <= 16) { MKH_TAB<NT>::rank1_stream_16(ts, next, g); return; } }
+  if constexpr (NT > 24) { if (hb <= 24) { MKH_TAB<NT>::rank1_stream_24(ts, next, g); return; } }
+  if constexpr (NT > 32) { if (hb <= 32) { MKH_TAB<NT>::rank1_stream_32(ts, next, g); return; } }
+  if constexpr (NT == 8) MKH_TAB<NT>::rank1_stream_8(ts, next, g);
+  else if constexpr (NT == 16) MKH_TAB<NT>::rank1_stream_16(ts, next, g);
+  else if constexpr (NT == 24) MKH_TAB<NT>::rank1_stream_24(ts, next, g);
+  else if constexpr (NT == 32) MKH_TAB<NT>::rank1_stream_32(ts, next, g);
+  else if constexpr (NT == 44) MKH_TAB<NT>::rank1_stream_44(ts, next, g);
+  else if constexpr (NT == 48) MKH_TAB<NT>::rank1_stream_48(ts, next, g);
+  else MKH_TAB<NT>::rank1_stream_64(ts, next, g);
+}
+
 // T[i] = lds[i] for i < n (n from a_stride_for: wave-uniform, one of the generated sizes)
 template <int NT>
 __device__ __forceinline__ void load_leading_rows(typename MKH_TAB<NT>::Regs& ts, unsigned addr, int n) {
@@ -1424,15 +1439,21 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       MKH_TAB<NT>::zero(ts);
       const int n_mu = P.n_jrows;
       const double* const sDinv = sPiv + kWoodRow;
+      // (streamed: the statement of row r requests the planes of row r + 1 behind its own FMAs, Z[r + 1][lane] is read one
+      //  trip ahead — 18 updates × (LDS round trip + 44 FMAs) back to back were 14 % of a G1 solve)
+      const unsigned lane_off = (unsigned)(lane & 15) << 3;
+      double zr = (lane < NT && n_mu > 0) ? sJ[lane] : 0.0;
+      MKH_TAB<NT>::rank1_prefetch(ts, lds_addr(sJ));
 #pragma nounroll
       for (int r = 0; r < n_mu; ++r) {
-        const double zr = (lane < NT) ? sJ[r * NT + lane] : 0.0;
         const double g = zr * sDinv[r];
         // dof rows the row reaches: [0, hb) (zero outside the kinematic chains eliminated so far)
         const unsigned long long nzd = __ballot(zr != 0.0);
         const int hb = nzd ? 64 - __builtin_clzll(nzd) : 0;
-        rank1_leading_rows<NT>(ts, lds_addr(sJ + r * NT), g, hb <= 16 ? 16 : (hb <= 24 ? 24 : (hb <= 32 ? 32 : NT)));
+        zr = (lane < NT) ? sJ[(r + 1) * NT + lane] : 0.0;          // (row n_μ exists: the parked Σ Jh²)
+        rank1_stream_rows<NT>(ts, lds_addr(sJ + (r + 1) * NT) + lane_off, g, hb);
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the planes requested by the last statement are not used
       if (MKH_TAP(t_cycles)) { asm volatile("s_waitcnt lgkmcnt(0)"); ta[3] += __builtin_readcyclecounter(); }   // (− start below)
     }
     auto frame_column = [&](int t, int k, uint64_t mask, uint64_t rmask, bool rel, double (&Jt)[6]) {
@@ -1492,10 +1513,14 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
           }
         }
         {
+          // (streamed: each statement requests the planes of the task's next row behind its own FMAs)
+          const unsigned lane_off = (unsigned)(lane & 15) << 3;
+          MKH_TAB<NT>::rank1_prefetch(ts, lds_addr(sJ));
           int c = 0;
 #pragma unroll
           for (int r = 0; r < 6; ++r)
-            if ((rowmask >> r) & 1) { rank1_leading_rows<NT>(ts, lds_addr(sJ + c * JS), Jw[r], AS); ++c; }
+            if ((rowmask >> r) & 1) { rank1_stream_rows<NT>(ts, lds_addr(sJ + (c + 1) * JS) + lane_off, Jw[r], AS); ++c; }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (the planes requested last are not used)
         }
                 continue;
       }
