@@ -1320,6 +1320,9 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // (FK + task lanes), so the test sits there; one extra check-only pass follows the last allowed iteration.
     const bool until = kSteps && A.pos_threshold >= 0.0;
     int it_done = 0, conv_flag = 0;
+    // fused loop: where this lane's dof ended the previous step's QP (0 free, 1 at its lower bound, 2 at its upper): the next
+    // step's active set is almost the same, so its first block step starts from there (phase 1a)
+    int prev_bound = 0;
     for (int step = 0; step < n_steps + (until ? 1 : 0); ++step) {
     int status = 0;
     tci = 1;                                                 // phase stamps 1..7 belong to the current step
@@ -1976,11 +1979,23 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         const int cnt = __builtin_popcountll(todo);
         if (2 * cnt > best || outer >= 3) { need_gi = true; break; }
         best = cnt;
-        const unsigned long long m_basic = m_over | m_under;
+        unsigned long long m_basic = m_over | m_under, m_up = m_over;
+        if (kSteps && outer == 0 && step >= 2) {
+          // Warm start of a fused step.  Along an IK loop the active set grows to ≈26 of G1's 43 dofs and then changes by
+          // ≈4 dofs per step, while the unconstrained step violates more bounds than end up active (28 against 21 on a
+          // typical problem): cold, block pivoting over-clamps, releases, re-clamps — ≈54 pivots per solve from step 10 on,
+          // against 13 on the first step.  So from the third step on the FIRST block step clamps exactly the dofs that sat on
+          // a bound at the end of the previous step, onto that bound, violated or not; what that guess misses shows up as an
+          // infeasibility or a wrong-signed multiplier in the next block step (numpy replay of the kernel's rules on
+          // dumped problems: 54 → 34 pivots at step 10, Goldfarb–Idnani hand-overs 63 → 42 of 64; worse on step 1, where
+          // the set still changes by ≈10 dofs).
+          const unsigned long long w_any = __ballot(is_b && prev_bound != 0);
+          if (w_any) { m_basic = w_any; m_up = __ballot(is_b && prev_bound == 2); todo = w_any; }
+        }
         while (todo && !(status & 14)) {
           const int k = (int)__builtin_ctzll(todo);
           todo &= todo - 1;
-          flip(k, ((m_basic >> k) & 1) != 0, ((m_over >> k) & 1) != 0);
+          flip(k, ((m_basic >> k) & 1) != 0, ((m_up >> k) & 1) != 0);
         }
         if (status & 14) break;
       }
@@ -2098,6 +2113,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     }
     // Δq of this dof: the free value when basic, else the bound it sits on
     const double zfin = s.usign ? s.x : (s.ysign ? s.hi : s.lo);
+    if (kSteps) prev_bound = (is_dof && !s.usign) ? (s.ysign ? 2 : 1) : 0;
     MKH_MARK("qp_done");
     MKH_TICK();   // 7: QP done
     if (MKH_TAP(t_cycles) && lane < 16) {

@@ -90,6 +90,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LOOP ? 1 : 2
 #pragma unroll
   for (int d = 0; d < NV; ++d) vlast[d] = 0.0;
   double x[NV];
+  int st[NV];                                        // QP partition: 0 free, 1 at lower, 2 at upper (kept across fused steps)
+#pragma unroll
+  for (int d = 0; d < NV; ++d) st[d] = 0;
   int status = 0;
   for (int step = 0; step < n_steps + (until ? 1 : 0); ++step) {
   if (LOOP && !__ballot(!fin)) break;
@@ -303,9 +306,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LOOP ? 1 : 2
   }
 
   // ------------------------------------------------------------------- QP
-  int st[NV];                                        // 0 free, 1 at lower, 2 at upper
+  // (fused loop, from the third step on: the partition starts where the previous step's QP ended — along an IK loop the
+  //  active set changes little from step to step; see the warm start of phase 1a in ik_kernel.h)
 #pragma unroll
-  for (int d = 0; d < NV; ++d) { x[d] = 0.0; st[d] = 0; }
+  for (int d = 0; d < NV; ++d) { x[d] = 0.0; if (!(LOOP && step >= 2)) st[d] = 0; }
   double hmax = 0.0;
 #pragma unroll
   for (int d = 0; d < NV; ++d) hmax = fmax(hmax, H[d][d]);
