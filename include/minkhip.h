@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define MKH_VERSION 103
+#define MKH_VERSION 104
 
 /* return codes */
 #define MKH_OK 0
@@ -63,6 +63,12 @@ extern "C" {
 #define MKH_FLAG_LANE_KERNEL 32     /* use the lane-per-problem kernel whenever the problem qualifies, whatever the batch
                                      * size (default: from 8192 instances; parity/diagnostic switch) */
 #define MKH_FLAG_TWO_WAVES 64       /* never use the 3-waves-per-SIMD kernel variants (parity/diagnostic switch) */
+#define MKH_FLAG_WARM_START 128     /* closed-loop callers: start the QP's active-set phase from where the previous solve of
+                                     * THIS problem handle (same batch size, instance i = instance i) ended.  The state lives
+                                     * in the handle; it is used from its third solve on and reset when the batch size
+                                     * changes.  Same optimum as a cold solve (the QP is strictly convex), fewer pivots:
+                                     * along an IK loop the active set changes by a few dofs per step.  The wavefront kernels
+                                     * only (the lane kernel keeps its partition inside mkh_solve_steps / _until). */
 
 /* frame types (mink/constants.py:3 SUPPORTED_FRAMES) */
 #define MKH_FRAME_BODY 0

@@ -1323,6 +1323,10 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // fused loop: where this lane's dof ended the previous step's QP (0 free, 1 at its lower bound, 2 at its upper): the next
     // step's active set is almost the same, so its first block step starts from there (phase 1a)
     int prev_bound = 0;
+    // ... or the previous CALL on this handle (closed-loop callers: MKH_FLAG_WARM_START, SolveArgs::warm)
+    // (variants with half-space rows run Goldfarb–Idnani only: no block step to seed)
+    const bool warm_in = !kColl && A.warm != nullptr && A.warm_age >= 2;
+    if (!kColl && warm_in && lane < nv) prev_bound = A.warm[(size_t)pb * nv + lane];
     for (int step = 0; step < n_steps + (until ? 1 : 0); ++step) {
     int status = 0;
     tci = 1;                                                 // phase stamps 1..7 belong to the current step
@@ -1980,7 +1984,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         if (2 * cnt > best || outer >= 3) { need_gi = true; break; }
         best = cnt;
         unsigned long long m_basic = m_over | m_under, m_up = m_over;
-        if (kSteps && outer == 0 && step >= 2) {
+        if (outer == 0 && ((kSteps && step >= 2) || (warm_in && step == 0))) {
           // Warm start of a fused step.  Along an IK loop the active set grows to ≈26 of G1's 43 dofs and then changes by
           // ≈4 dofs per step, while the unconstrained step violates more bounds than end up active (28 against 21 on a
           // typical problem): cold, block pivoting over-clamps, releases, re-clamps — ≈54 pivots per solve from step 10 on,
@@ -2113,7 +2117,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     }
     // Δq of this dof: the free value when basic, else the bound it sits on
     const double zfin = s.usign ? s.x : (s.ysign ? s.hi : s.lo);
-    if (kSteps) prev_bound = (is_dof && !s.usign) ? (s.ysign ? 2 : 1) : 0;
+    if (!kColl && (kSteps || A.warm)) prev_bound = (is_dof && !s.usign) ? (s.ysign ? 2 : 1) : 0;
     MKH_MARK("qp_done");
     MKH_TICK();   // 7: QP done
     if (MKH_TAP(t_cycles) && lane < 16) {
@@ -2202,6 +2206,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
       if (A.iters_out) A.iters_out[pb] = it_done;
       if (A.converged_out) A.converged_out[pb] = conv_flag;
     }
+    if (!kColl && A.warm && lane < nv) A.warm[(size_t)pb * nv + lane] = (int8_t)((status_all & 14) ? 0 : prev_bound);
     if (A.status_out && lane == 0) A.status_out[pb] = status_all;
     sq = (sq == smem + L.q) ? smem + L.q2 : smem + L.q;           // the next problem's rows are (being) fetched there
     sTgt = (sTgt == smem + L.tgt) ? smem + L.tgt2 : smem + L.tgt;

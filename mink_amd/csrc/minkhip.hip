@@ -103,6 +103,8 @@ struct MkhProblem {
   DeviceProblem* d_dev = nullptr;   // device copy of `dev` (the kernel reads the descriptor from memory)
   TapArgs* d_taps = nullptr;
   int last_grid = 0, last_lds = 0, last_nt = 0;   // geometry of the most recent launch (mkh_problem_launch_info)
+  int8_t* d_warm = nullptr;        // MKH_FLAG_WARM_START: active set of every instance after the previous solve (max_batch × nv)
+  int warm_age = 0, warm_B = 0;    // solves since the state was reset / the batch size it belongs to
   uint32_t* d_work = nullptr;      // ticket counter of the dynamic problem distribution (zeroed by the kernel's last draw)
   // staging buffers for host-pointer calls
   double *s_q = nullptr, *s_ft = nullptr, *s_pt = nullptr, *s_ct = nullptr, *s_v = nullptr;
@@ -781,7 +783,7 @@ void mkh_problem_destroy(MkhProblem* p) {
   (void)hipSetDevice(p->device);
   (void)hipFree(p->d_frame); (void)hipFree(p->d_posture_cost); (void)hipFree(p->d_cfg_lower); (void)hipFree(p->d_cfg_upper);
   (void)hipFree(p->d_vel); (void)hipFree(p->d_pairs); (void)hipFree(p->d_dev); (void)hipFree(p->d_taps); (void)hipFree(p->d_work);
-  (void)hipFree(p->d_lane);
+  (void)hipFree(p->d_lane); (void)hipFree(p->d_warm);
   (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain); (void)hipFree(p->s_iters);
   (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh);
   (void)hipFree(p->s_q); (void)hipFree(p->s_ft); (void)hipFree(p->s_pt); (void)hipFree(p->s_ct); (void)hipFree(p->s_v); (void)hipFree(p->s_status);
@@ -937,6 +939,13 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
   a.B = B; a.posture_batched = pbat; a.com_batched = cbat; a.do_qp = (v_out != nullptr);
   a.dt = dt; a.damping = damping; a.n_steps = n_steps;
   a.pos_threshold = pos_threshold; a.ori_threshold = ori_threshold;
+  if (flags & MKH_FLAG_WARM_START) {
+    // closed-loop callers solve the same instances again and again: keep each instance's active set on the device
+    if (!p->d_warm) HIP_OK(hipMalloc((void**)&p->d_warm, (size_t)p->max_batch * P.nv));
+    if (p->warm_B != B) { HIP_OK(hipMemsetAsync(p->d_warm, 0, (size_t)p->max_batch * P.nv, stream)); p->warm_B = B; p->warm_age = 0; }
+    a.warm = p->d_warm; a.warm_age = p->warm_age;
+    if (v_out) ++p->warm_age;
+  }
   const bool until = pos_threshold >= 0.0;
   if (until && P.n_frame < 1) return fail(MKH_E_INVALID, "mkh_solve_until needs at least one frame task to test the thresholds on");
   const size_t nq = P.nq, nv = P.nv;

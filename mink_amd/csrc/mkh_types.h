@@ -149,6 +149,11 @@ struct SolveArgs {
   const double* dense_J;           // (B, n_dense_rows, nv)
   const double* dense_G;           // (B, n_dense_limit_rows, nv)
   const double* dense_h;           // (B, n_dense_limit_rows)
+  // warm start across CALLS (MKH_FLAG_WARM_START): where every dof of every instance ended the previous solve of this
+  // problem handle (0 free, 1 at its lower bound, 2 at its upper), read at the start of the active-set phase when the
+  // state is at least two solves old and written at its end; nullptr = cold
+  int8_t* warm;                    // (B, nv)
+  int32_t warm_age;
 };
 
 // Debug/parity taps (nullable pointers).  Lives in device memory and is passed by pointer so

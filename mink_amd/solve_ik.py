@@ -172,12 +172,18 @@ def solve_ik(configuration: Configuration, tasks: Sequence, dt: float, solver: s
 
     `solver` is kept for signature compatibility; every value selects the device active-set
     solver (the reference forwards the string to qpsolvers).  Returns v of shape (nv,) or (B, nv).
+
+    The reference forwards `**kwargs` to the QP solver; the one understood here is `warm_start=True` for closed loops
+    (solve, integrate, solve again on the same batch): the active-set phase starts from where the previous solve of the
+    same tasks / limits on this configuration ended (MKH_FLAG_WARM_START) — same optimum, fewer pivots once the loop has
+    run for a few steps.  Other solver keywords are accepted and ignored.
     """
+    warm_start = bool(kwargs.pop("warm_start", False))
     del kwargs
     prob, layout = _compile(configuration, tasks, limits, configuration.batch_size, dt)
     ft, pt, ct = _gather_targets(configuration, layout)
     v, status = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping,
-                           dense=_dense_inputs(configuration, layout, dt))
+                           dense=_dense_inputs(configuration, layout, dt), warm_start=warm_start)
     if (status & nat.ST_OUTSIDE_LIMITS).any():
         configuration.check_limits(safety_break=safety_break)      # raises / warns like the reference
     bad = np.nonzero(status & ~nat.ST_OUTSIDE_LIMITS)[0]

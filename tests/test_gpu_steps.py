@@ -123,3 +123,37 @@ def test_threshold_terminated_loop_matches_the_callers_loop():
     assert prob.last_kernel() == "ik_lane_kernel_6_loop"
     np.testing.assert_allclose(qfl, qs, rtol=0, atol=1e-10)
     np.testing.assert_allclose(vfl, vs, rtol=0, atol=1e-8 * max(1.0, np.abs(vs).max()))
+
+
+def test_warm_start_across_calls_gives_the_cold_answers():
+    """MKH_FLAG_WARM_START (solve_ik(..., warm_start=True)): a closed loop of single solves on the same batch — every step's v
+    equals the cold solve's (the optimum is unique; the pivot order differs, so to rounding), fewer pivots once the loop runs."""
+    import time
+    import native_configs as nc
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+    model = workloads.load_robot("g1")
+    nm = nat.NativeModel(model)
+    B = 2048
+    prob, dt, damping = nc.build("g1_c3", nm, B)
+    cold, _, _ = nc.build("g1_c3", nm, B)
+    stand = model.key_qpos[0]
+    q, tg = workloads.make_batch(model, nm, prob, np.random.default_rng(8), B, base_q=stand)
+    qw = q.copy()
+    worst = 0.0
+    for step in range(12):
+        vw, stw = prob.solve(qw, tg, stand[None, :], None, dt, damping, warm_start=True)
+        vc, stc = cold.solve(qw, tg, stand[None, :], None, dt, damping)
+        assert (stw & ~1 == 0).all() and (stc & ~1 == 0).all()
+        worst = max(worst, np.abs(vw - vc).max() / max(1.0, np.abs(vc).max()))
+        qw = nm.integrate(qw, vw, dt)
+    print("closed loop of 12 warm-started solves vs cold solves: max rel |dv| = %.2e" % worst)
+    assert worst < 1e-9
+    # a different batch size resets the state; a permuted batch still gets the right answers (only slower)
+    perm = np.random.default_rng(0).permutation(B)
+    vp, stp = prob.solve(qw[perm], tg[perm], stand[None, :], None, dt, damping, warm_start=True)
+    vc, _ = cold.solve(qw[perm], tg[perm], stand[None, :], None, dt, damping)
+    assert np.abs(vp - vc).max() / max(1.0, np.abs(vc).max()) < 1e-9
+    vh, sth = prob.solve(qw[:100], tg[:100], stand[None, :], None, dt, damping, warm_start=True)
+    vc, _ = cold.solve(qw[:100], tg[:100], stand[None, :], None, dt, damping)
+    assert np.abs(vh - vc).max() / max(1.0, np.abs(vc).max()) < 1e-9
