@@ -928,7 +928,15 @@ __device__ __forceinline__ void wood_eliminate(int n_mu, int NR, int lane, doubl
 #else
 #define MKH_WOOD_ATTR __forceinline__
 #endif
+// clamp / beta: the PREDICTED active set — this dof is expected on a bound (1 lower, 2 upper; 0 free) of value beta.  The
+// tableau is then built directly in the state "free dofs swept, predicted dofs not": with S summed over the FREE columns
+// only, Z = L⁻¹Jh over ALL columns and the lazy scale 1/σ instead of σ on a predicted dof, every off-diagonal entry is
+// still R[i][j] = Σ_r Z[r][i]·Z[r][j]/d_r (T_FF = −H_FF⁻¹, T_AF = H_AF·H_FF⁻¹, T_AA = H_AA − H_AF·H_FF⁻¹·H_FA all reduce to
+// it through (I − Jh_FᵀS⁻¹Jh_F)·Jh_Fᵀ = Jh_FᵀS⁻¹ and I − Jh_F·H̃_FF⁻¹·Jh_Fᵀ = S⁻¹); a predicted dof gets the diagonal
+// Dg·(1 + Σ z_r²/d_r) and its gradient Dg·β + c + √Dg·Σ z_r·ω_r/d_r, the right-hand side takes z̃ = β on predicted dofs.
+// No un-sweep pivot at all for a correct prediction: the warm starts of the fused loop and of MKH_FLAG_WARM_START.
 __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int off_q, int off_tgt, double c_lane, double hdiag_base,
+                                             int clamp, double beta,
                                              long long* prof = nullptr) {   // prof (inlined profiling build only): cycle stamps
   constexpr int NR = MKH_NT;
   constexpr bool kCom = (MKH_FEAT & F_COM) != 0;
@@ -966,6 +974,8 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
   int status = 0;
   // 1/√Dg of this dof (Dg = damping + Σμ + posture diagonal > 0, checked on the host)
   const double dsq = is_dof ? fast_rcp(sqrt(hdiag_base)) : 0.0;
+  const bool clamped = is_dof && clamp != 0;
+  const unsigned long long a_mask = __ballot(clamped);                 // predicted active set (wave-uniform)
   // weighted error of residual row my_c (read before the Jacobian rows may overwrite the task blocks):
   // a frame-task row, or (−1 − 3·t − r) row r of ComTask t: cost·(−gain·(com − target))   (com_task.py:71-82)
   double we_mu = 0.0;
@@ -1023,7 +1033,8 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
       for (int i = lane; i < n_mu * NR; i += kWave) sJ[i] = 0.0;   // dofs off a task's chain
       // x after the closed-form dof sweeps: z_k = −c_k/Dg_k (posture part of c only), staged as z_k·√Dg_k in row n_μ of
       // the array so that the right-hand side Jw·z is one more row of the product below
-      if (lane < NR) sJ[n_mu * NR + lane] = is_dof ? -c_lane * dsq : 0.0;
+      // (a predicted dof contributes its bound: z̃_k = β_k)
+      if (lane < NR) sJ[n_mu * NR + lane] = is_dof ? (clamped ? beta * hdiag_base * dsq : -c_lane * dsq) : 0.0;
       wave_sync();
     }
     {
@@ -1080,7 +1091,7 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
     for (int k = 0; k < nv; ++k) {
       const double p0 = has0 ? c0[k] : 0.0, p1 = has1 ? c1[k] : 0.0;
       const double g = mine ? cm[k] : 0.0;
-      WoodAll<kMuBig>::step(acc, p0, p1, g);                   // acc[r] += Jh[r][k]·Jh[c][k]
+      WoodAll<kMuBig>::step(acc, p0, p1, ((a_mask >> k) & 1) ? 0.0 : g);   // acc[r] += Jh[r][k]·Jh[c][k], free dofs only
       wacc = fma(g, zs[k], wacc);
     }
     if (mine) {
@@ -1104,11 +1115,21 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
         double acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const int r = row0 + j; b[j] = sJ + (r < n_mu ? r : n_mu) * NR; acc[j] = 0.0; }
-        for (uint64_t mk = chain; mk; mk &= mk - 1) {
+        for (uint64_t mk = chain & ~a_mask; mk; mk &= mk - 1) {        // S: the free dofs of the chain
           const int k = __ffsll((unsigned long long)mk) - 1;
           const double av = a[k];
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc[j] = fma(av, b[j][k], acc[j]);
+        }
+        if (chain & a_mask) {                                          // Jw·z̃ also takes the predicted dofs (z̃ = β)
+          const int jr = n_mu - row0;                                  // the right-hand-side row of this pass, if any
+          double extra = 0.0;
+          for (uint64_t mk = chain & a_mask; mk; mk &= mk - 1) {
+            const int k = __ffsll((unsigned long long)mk) - 1;
+            extra = fma(a[k], sJ[n_mu * NR + k], extra);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += (j == jr) ? extra : 0.0;
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1139,13 +1160,14 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
   WoodOut wo;
   wo.hdiag = hdiag_base * (1.0 + ssq);                                 // H[k][k] = Dg·(1 + Σ Jh²)  (only scales thresholds)
   wo.dsq = dsq; wo.status = __ballot(status != 0) ? 4 : 0;
-  wo.D = (dsq * dsq) * (quad - 1.0);
-  wo.x = -c_lane * (dsq * dsq) - dsq * zw;
+  // free dof: −H⁻¹[j][j] and x;  predicted dof (not swept): its diagonal of the Schur complement and its gradient
+  wo.D = clamped ? hdiag_base * (1.0 + quad) : (dsq * dsq) * (quad - 1.0);
+  wo.x = clamped ? fma(hdiag_base, beta, c_lane) + hdiag_base * dsq * zw : -c_lane * (dsq * dsq) - dsq * zw;
   return wo;
 }
 #else
 struct WoodOut { double hdiag, dsq, x, D; int status; };
-__device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, int, int, double, double, long long* = nullptr) { return WoodOut{0.0, 0.0, 0.0, 0.0, 0}; }
+__device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, int, int, double, double, int, double, long long* = nullptr) { return WoodOut{0.0, 0.0, 0.0, 0.0, 0}; }
 #endif
 #ifdef MKH_W3
 #define MKH_STAGE (2 * ((MKH_NT + 15) / 16))   // 3-waves maps: only the planes the column has (gen_tab_asm.py)
@@ -1424,16 +1446,63 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     // (zeroed as late as possible: in the operand map the column's registers belong to the compiler until then)
     if constexpr (!kWood) { if (!(!kTaps && P.n_dpairs > 0)) MKH_TAB<NT>::zero(ts); }
     const double q_dof_stash = is_dof ? my_dof[9] : 0.0;    // (slot 9 of the dof stash is reused below)
+    // ------------------------------------------------------------ box limits
+    // lo ≤ Δq ≤ hi from ConfigurationLimit rows (configuration_limit.py:94-124) and
+    // VelocityLimit rows (velocity_limit.py:96-101); never materialise the dense G.
+    // (direct start: evaluated after the collision rows — lo / hi are not live while the distance routines run; low-rank
+    //  start: before wood_start, which builds the tableau with the predicted active set already on its bounds)
+    double lo = -kInf, hi = kInf;
+    auto box_limits = [&]() {
+    if (is_dof) {
+        const double q_dof = q_dof_stash;
+        for (int t = 0; t < P.n_cfg; ++t) {
+          const double lw = P.cfg_lower[t * 64 + lane], up = P.cfg_upper[t * 64 + lane];
+          if (d_kind == DOF_BALL) {
+            // A limited ball joint.  The reference fills the joint's four qpos slots of `lower` / `upper` with the scalar
+            // range ends and differentiates quaternions (configuration_limit.py:46-52, 94-112: mj_differentiatePos →
+            // mju_subQuat → mju_quat2Vel, nothing normalised): Δq_max = quat2vel(q̄ ⊗ (u,u,u,u)), Δq_min = quat2vel((l,l,l,l)‾ ⊗ q).
+            const Q4 qc{sq[d_qadr], sq[d_qadr + 1], sq[d_qadr + 2], sq[d_qadr + 3]};
+            if (up < kInf) {
+              const V3 dv = quat2vel(qmul(qconj(qc), Q4{up, up, up, up}));
+              hi = fmin(hi, P.cfg_gain[t] * ((d_k == 0) ? dv.x : ((d_k == 1) ? dv.y : dv.z)));
+            }
+            if (lw > -kInf) {
+              const V3 dv = quat2vel(qmul(qconj(Q4{lw, lw, lw, lw}), qc));
+              lo = fmax(lo, -(P.cfg_gain[t] * ((d_k == 0) ? dv.x : ((d_k == 1) ? dv.y : dv.z))));
+            }
+            continue;
+          }
+          if (up < kInf) hi = fmin(hi, P.cfg_gain[t] * (up - q_dof));
+          if (lw > -kInf) lo = fmax(lo, -(P.cfg_gain[t] * (q_dof - lw)));
+        }
+        for (int t = 0; t < P.n_vel; ++t) {
+          const double vm = P.vel_limit[t * 64 + lane];
+          if (vm < kInf) { hi = fmin(hi, A.dt * vm); lo = fmax(lo, -(A.dt * vm)); }
+        }
+        if (MKH_TAP(t_box_lo)) MKH_TAP(t_box_lo)[(size_t)pb * nv + lane] = lo;
+        if (MKH_TAP(t_box_hi)) MKH_TAP(t_box_hi)[(size_t)pb * nv + lane] = hi;
+      }
+    };
+    if constexpr (kWood) box_limits();
     // ---- low-rank start: Jacobian rows, S = I + Jh·Jhᵀ, LDLᵀ elimination (wood_start above), then the dof block of the
     // tableau by n_μ rank-1 updates that do not depend on each other:  R[i][j] = Σ_r Z[r][i]·Z[r][j]/d_r
     WoodOut wo{0.0, 0.0, 0.0, 0.0, 0};
+    // predicted active set (warm starts: the previous fused step from the third step on / the previous call): the low-rank
+    // start builds the tableau with these dofs already on their bounds
+    int pred = 0;
+    double pred_beta = 0.0;
+    if constexpr (kWood) {
+      if ((kSteps && step >= 2) || (warm_in && step == 0)) pred = prev_bound;
+      if ((pred == 2 && !(hi < kInf)) || (pred == 1 && !(lo > -kInf)) || !is_dof) pred = 0;
+      pred_beta = (pred == 2) ? hi : ((pred == 1) ? lo : 0.0);
+    }
     if constexpr (kWood) {
 #ifdef MKH_WOOD_CALL
-      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base);
+      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta);
 #else
       long long wprof[2] = {0, 0};
       const long long wt0 = MKH_TAP(t_cycles) ? __builtin_readcyclecounter() : 0;
-      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, MKH_TAP(t_cycles) ? wprof : nullptr);
+      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta, MKH_TAP(t_cycles) ? wprof : nullptr);
       if (MKH_TAP(t_cycles)) {                 // phase_profile.py: Jacobian rows | S and w | elimination  (slots 0, 1, 2)
         const long long wt1 = __builtin_readcyclecounter();
         ta[0] += wprof[0] - wt0; ta[1] += wprof[1] - wprof[0]; ta[2] += wt1 - wprof[1];
@@ -1773,41 +1842,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         if (lane < AS) sA[s * AS + lane] = is_dof ? dG[(size_t)r * nv + lane] : 0.0;
       }
     }
-    // ------------------------------------------------------------ box limits
-    // (after the collision rows: lo / hi are not live while the distance routines run)
-    // lo ≤ Δq ≤ hi from ConfigurationLimit rows (configuration_limit.py:94-124) and
-    // VelocityLimit rows (velocity_limit.py:96-101); never materialise the dense G.
-    double lo = -kInf, hi = kInf;
-    if (is_dof) {
-      const double q_dof = q_dof_stash;
-      for (int t = 0; t < P.n_cfg; ++t) {
-        const double lw = P.cfg_lower[t * 64 + lane], up = P.cfg_upper[t * 64 + lane];
-        if (d_kind == DOF_BALL) {
-          // A limited ball joint.  The reference fills the joint's four qpos slots of `lower` / `upper` with the scalar
-          // range ends and differentiates quaternions (configuration_limit.py:46-52, 94-112: mj_differentiatePos →
-          // mju_subQuat → mju_quat2Vel, nothing normalised): Δq_max = quat2vel(q̄ ⊗ (u,u,u,u)), Δq_min = quat2vel((l,l,l,l)‾ ⊗ q).
-          const Q4 qc{sq[d_qadr], sq[d_qadr + 1], sq[d_qadr + 2], sq[d_qadr + 3]};
-          if (up < kInf) {
-            const V3 dv = quat2vel(qmul(qconj(qc), Q4{up, up, up, up}));
-            hi = fmin(hi, P.cfg_gain[t] * ((d_k == 0) ? dv.x : ((d_k == 1) ? dv.y : dv.z)));
-          }
-          if (lw > -kInf) {
-            const V3 dv = quat2vel(qmul(qconj(Q4{lw, lw, lw, lw}), qc));
-            lo = fmax(lo, -(P.cfg_gain[t] * ((d_k == 0) ? dv.x : ((d_k == 1) ? dv.y : dv.z))));
-          }
-          continue;
-        }
-        if (up < kInf) hi = fmin(hi, P.cfg_gain[t] * (up - q_dof));
-        if (lw > -kInf) lo = fmax(lo, -(P.cfg_gain[t] * (q_dof - lw)));
-      }
-      for (int t = 0; t < P.n_vel; ++t) {
-        const double vm = P.vel_limit[t * 64 + lane];
-        if (vm < kInf) { hi = fmin(hi, A.dt * vm); lo = fmax(lo, -(A.dt * vm)); }
-      }
-      if (MKH_TAP(t_box_lo)) MKH_TAP(t_box_lo)[(size_t)pb * nv + lane] = lo;
-      if (MKH_TAP(t_box_hi)) MKH_TAP(t_box_hi)[(size_t)pb * nv + lane] = hi;
-    }
-
+    if constexpr (!kWood) box_limits();
     wave_sync();
 
     MKH_MARK("limits_done");
@@ -1848,11 +1883,15 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     double rown = 1.0;
     if (kWood) {
       // state after phase 0 (wood_start + the rank-1 updates above): every dof swept, the dof block is −H⁻¹
-      s.sg = is_dof ? wo.dsq : 1.0;
-      s.D = is_dof ? wo.D : 1.0;                             // −H⁻¹[j][j]
-      s.usign = is_dof ? kSign : 0;                          // every dof basic
-      s.sel = is_dof ? 1 : 0;
-      s.x = is_dof ? wo.x : 0.0;                             // x0 = −H⁻¹c
+      // free dofs are basic (swept); the predicted ones sit on their bound, not swept: scale 1/σ, x = their gradient
+      s.sg = is_dof ? (pred ? hdiag_base * wo.dsq : wo.dsq) : 1.0;
+      s.D = is_dof ? wo.D : 1.0;                             // −H_FF⁻¹[j][j]  /  Schur complement diagonal
+      s.usign = (is_dof && !pred) ? kSign : 0;
+      s.sel = (is_dof && !pred) ? 1 : 0;
+      s.elig = pred ? 1 : 0;
+      s.ysign = (pred == 2) ? kSign : 0;
+      s.rsign = (pred == 1) ? kSign : 0;
+      s.x = is_dof ? wo.x : 0.0;                             // x_F = −H_FF⁻¹(c_F + H_FA·β)  /  w_A
       if (is_dof) { s.lo = lo; s.hi = hi; }
     } else if (is_dof) {
       s.x = c_lane; s.lo = lo; s.hi = hi;                     // nonbasic at z = 0: w = c   (sel = 1 once swept)
@@ -1984,7 +2023,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
         if (2 * cnt > best || outer >= 3) { need_gi = true; break; }
         best = cnt;
         unsigned long long m_basic = m_over | m_under, m_up = m_over;
-        if (outer == 0 && ((kSteps && step >= 2) || (warm_in && step == 0))) {
+        if (!kWood && outer == 0 && ((kSteps && step >= 2) || (warm_in && step == 0))) {
           // Warm start of a fused step.  Along an IK loop the active set grows to ≈26 of G1's 43 dofs and then changes by
           // ≈4 dofs per step, while the unconstrained step violates more bounds than end up active (28 against 21 on a
           // typical problem): cold, block pivoting over-clamps, releases, re-clamps — ≈54 pivots per solve from step 10 on,
