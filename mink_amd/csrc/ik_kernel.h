@@ -813,11 +813,14 @@ __device__ MKH_PRE_ATTR DirectPairs direct_pairs(const DeviceProblem* Pq) {
 // reciprocal / multiplier chain in front of a 62-row update, later six at a time with a per-lane 6 × 6 LDLᵀ: 30 % of a
 // G1 solve.)
 // Outputs per dof lane: D = −H⁻¹[j][j] = σ²(Σ_r z_r²/d_r − 1),  x0 = −H⁻¹c = z − σ·Σ_r z_r·ω_r/d_r  (ω = L⁻¹w, w = Jw·z − r).
-struct WoodOut { double hdiag, dsq, x, D; int status; };
+struct WoodOut { double hdiag, dsq, x, D; int status, clamp; };
 
+// cold-start refinement of wood_eliminate (single-pass lane layout): bounds, the dof's closed-form point and scales
+struct WoodRefine { bool on; int nv; double lo, hi, zfree, dsq, sqdg, zsq; };
 template <int K, bool DUAL>
 __device__ __forceinline__ void wood_eliminate(int n_mu, int NR, int lane, double* sJ, double* sS, int SP, const double* sW,
-                                               double* sRow, double* sDinv, double& ssq, double& quad, double& zw, int& status) {
+                                               double* sRow, double* sDinv, double& ssq, double& quad, double& zw, int& status,
+                                               const WoodRefine& rf, int& clamp, double& beta) {
   const unsigned plane_off = (unsigned)(lane & 15);
   if constexpr (!DUAL) {
     // ONE pass: lanes [0, NR) carry a column of Jh, lanes [NR, NR + n_μ) a column of S and their entry w_c
@@ -839,26 +842,70 @@ __device__ __forceinline__ void wood_eliminate(int n_mu, int NR, int lane, doubl
       for (int r = 0; r < K; ++r) q = fma(z[r], z[r], q);                // Σ Jh² of a dof lane (before the elimination):
       if (lane < NR) sJ[n_mu * NR + lane] = q;                           // parked in LDS (the right-hand-side row of the product
     }                                                                    // is dead), not in two registers through the loop
-    static_for<K>([&](auto rc) {
-      constexpr int r = decltype(rc)::value;
-      if (r < n_mu) {
-        wave_sync();                                                     // the previous row's readers are done
-        if (lane < NR) sJ[r * NR + lane] = z[r];                         // row r of Z, final
-        if (is_s) *reinterpret_cast<double2*>(sRow + 2 * my_c) = double2{z[r], ws};   // (S[r][c], w_c) in one write
-        wave_sync();
-        const double2 dw = *reinterpret_cast<const double2*>(sRow + 2 * r);            // d_r and ω_r
-        const double d = dw.x, om = dw.y;
-        const double p0 = sRow[2 * plane_off], p1 = (K > 16) ? sRow[2 * (16 + plane_off)] : 0.0;
-        if (!(d > 0.0)) status |= 4;
-        const double inv = fast_rcp(d);
-        if (lane == 0) sDinv[r] = inv;
-        const double zi = z[r] * inv;
-        quad = fma(z[r], zi, quad);
-        zw = fma(om, zi, zw);
-        WoodElim<r, K>::step(z, p0, p1, -zi);                            // z[i] −= S[i][r]·z[r]/d   (i > r)
-        ws = fma(-zi, om, ws);                                           // w_c −= S[c][r]·ω_r/d  (S lanes; harmless on dof lanes)
+    double* const sOm = sDinv + kMuBig;
+#pragma nounroll
+    for (int pass = 0;; ++pass) {
+      quad = 0.0; zw = 0.0;
+      static_for<K>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        if (r < n_mu) {
+          // row r of S straight from the S lanes' registers: d_r and ω_r by v_readlane (the reciprocal starts at once),
+          // the two 16-lane planes through the LDS crossbar (a store → wait → load round trip per step doubled the chain)
+          const double d = readlane_f64(z[r], NR + r), om = readlane_f64(ws, NR + r);
+          const double p0 = bperm_f64(z[r], NR + (int)plane_off);
+          // (unconditional: a permute under a lane condition would not see the source lanes the condition switches off)
+          const double p1 = (K > 16) ? bperm_f64(z[r], (NR + 16 + (int)plane_off) & 63) : 0.0;   // rows ≥ n_μ: never used
+          if (lane < NR) sJ[r * NR + lane] = z[r];                       // row r of Z, final (read after the loop)
+          if (!(d > 0.0)) status |= 4;
+          const double inv = fast_rcp(d);
+          if (lane == 0) { sDinv[r] = inv; sOm[r] = om; }
+          const double zi = z[r] * inv;
+          quad = fma(z[r], zi, quad);
+          zw = fma(om, zi, zw);
+          WoodElim<r, K>::step(z, p0, p1, -zi);                          // z[i] −= S[i][r]·z[r]/d   (i > r)
+          ws = fma(-zi, om, ws);                                         // w_c −= S[c][r]·ω_r/d  (S lanes; harmless on dof lanes)
+        }
+      });
+      if (pass == 1 || !rf.on) break;
+      // ---- cold start: the bounds the unconstrained minimiser x⁰ violates are (nearly) the optimal active set — block
+      // principal pivoting would put exactly these dofs on their bounds, one un-sweep pivot of the whole tableau each.
+      // Cheaper here, where the tableau does not exist yet: with A the violated set, S_F = S − Jh_A·Jh_Aᵀ = L·(D − Z_A·Z_Aᵀ)·Lᵀ,
+      // so a second elimination of the n_μ × n_μ matrix M = D − Z_A·Z_Aᵀ = L_M·D_M·L_Mᵀ — columns on the S lanes again, summed
+      // over the |A| violated dofs only — carries Z to L_M⁻¹·Z and ω to L_M⁻¹·(ω + Σ_A Z[·][k]·(β_k − z_k)·√Dg_k): the state of
+      // the predicted-set start (wood_start), from what the first pass left in registers and LDS.
+      const double x0 = rf.zfree - rf.dsq * zw;
+      const int viol = (lane < rf.nv) ? ((x0 > rf.hi) ? 2 : ((x0 < rf.lo) ? 1 : 0)) : 0;
+      const unsigned long long am = __ballot(viol != 0);
+      if (!am) break;
+      clamp = viol;
+      beta = (viol == 2) ? rf.hi : ((viol == 1) ? rf.lo : 0.0);
+      double dself = 0.0;
+#pragma unroll
+      for (int r = 0; r < K; ++r) dself = (r == my_c) ? z[r] : dself;    // d_c: entry c of an S column is final after step c
+      double om_c = is_s ? sOm[my_c] : 0.0;
+      wave_sync();                                                       // the last row's readers are done
+      if (viol) sRow[lane] = beta * rf.sqdg - rf.zsq;                    // (β_k − z_k)·√Dg_k
+      if (is_s) {
+#pragma unroll
+        for (int r = 0; r < K; ++r) z[r] = (r == my_c) ? dself : 0.0;
       }
-    });
+      wave_sync();
+      {
+        const int rows0 = (int)plane_off, rows1 = 16 + (int)plane_off;
+        const bool has0 = rows0 < n_mu, has1 = (K > 16) && rows1 < n_mu;
+        const double* c0 = sJ + (has0 ? rows0 : 0) * NR;
+        const double* c1 = sJ + (has1 ? rows1 : 0) * NR;
+        const double* cm = sJ + (is_s ? my_c : 0) * NR;
+        for (unsigned long long mk = am; mk; mk &= mk - 1) {
+          const int k = __ffsll(mk) - 1;
+          const double p0 = has0 ? c0[k] : 0.0, p1 = has1 ? c1[k] : 0.0;
+          const double g = is_s ? cm[k] : 0.0;
+          WoodAll<K>::step(z, p0, p1, -g);                               // M[r][c] −= Z[r][k]·Z[c][k]  (dof lanes: g = 0)
+          om_c = fma(g, sRow[k], om_c);
+        }
+      }
+      ws = om_c;
+    }
   } else {
     // TWO passes (NR + n_μ lanes do not exist): first the S columns on lanes [0, n_μ) — the chained part; row r, 1/d_r and ω_r
     // stay in LDS (S is loaded into registers first, its storage takes the rows) — then the Jh columns on the dof lanes, which
@@ -874,12 +921,10 @@ __device__ __forceinline__ void wood_eliminate(int n_mu, int NR, int lane, doubl
       static_for<K>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
         if (r < n_mu) {
-          wave_sync();
-          if (is_s) { *reinterpret_cast<double2*>(sRow + 2 * lane) = double2{z[r], ws}; sS[r * SP + lane] = z[r]; }
-          wave_sync();
-          const double2 dw = *reinterpret_cast<const double2*>(sRow + 2 * r);
-          const double d = dw.x, om = dw.y;
-          const double p0 = sRow[2 * plane_off], p1 = (K > 16) ? sRow[2 * (16 + plane_off)] : 0.0;
+          const double d = readlane_f64(z[r], r), om = readlane_f64(ws, r);      // (as in the one-pass layout)
+          const double p0 = bperm_f64(z[r], (int)plane_off);
+          const double p1 = (K > 16) ? bperm_f64(z[r], 16 + (int)plane_off) : 0.0;
+          if (is_s) sS[r * SP + lane] = z[r];                                    // row r for the dof lanes' pass
           if (!(d > 0.0)) status |= 4;
           const double inv = fast_rcp(d);
           if (lane == 0) { sDinv[r] = inv; sOm[r] = om; }
@@ -936,7 +981,7 @@ __device__ __forceinline__ void wood_eliminate(int n_mu, int NR, int lane, doubl
 // Dg·(1 + Σ z_r²/d_r) and its gradient Dg·β + c + √Dg·Σ z_r·ω_r/d_r, the right-hand side takes z̃ = β on predicted dofs.
 // No un-sweep pivot at all for a correct prediction: the warm starts of the fused loop and of MKH_FLAG_WARM_START.
 __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int off_q, int off_tgt, double c_lane, double hdiag_base,
-                                             int clamp, double beta,
+                                             int clamp, double beta, double lo, double hi,
                                              long long* prof = nullptr) {   // prof (inlined profiling build only): cycle stamps
   constexpr int NR = MKH_NT;
   constexpr bool kCom = (MKH_FEAT & F_COM) != 0;
@@ -1149,25 +1194,29 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
   double ssq = 0.0, quad = 0.0, zw = 0.0;
   // (the 24-row and two-register-set instantiations only exist in the F_COM variants, which the host also picks for
   //  problems without a ComTask that need them: 48 + 48 column registers cost the lean variant its spill-free build)
+  // (cold start only: a warm start brings its own prediction)
+  const WoodRefine rf{a_mask == 0 && !dual && P.wood_refine != 0, nv, lo, hi, -c_lane * (dsq * dsq), dsq, hdiag_base * dsq, -c_lane * dsq};
   if constexpr (kCom) {
-    if (dual) wood_eliminate<kMuBig, true>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status);
-    else if (n_mu <= kMu) wood_eliminate<kMu, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status);
-    else wood_eliminate<kMuBig, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status);
+    if (dual) wood_eliminate<kMuBig, true>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status, rf, clamp, beta);
+    else if (n_mu <= kMu) wood_eliminate<kMu, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status, rf, clamp, beta);
+    else wood_eliminate<kMuBig, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status, rf, clamp, beta);
   } else {
-    wood_eliminate<kMu, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status);
+    wood_eliminate<kMu, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status, rf, clamp, beta);
   }
   wave_sync();
   WoodOut wo;
   wo.hdiag = hdiag_base * (1.0 + ssq);                                 // H[k][k] = Dg·(1 + Σ Jh²)  (only scales thresholds)
   wo.dsq = dsq; wo.status = __ballot(status != 0) ? 4 : 0;
   // free dof: −H⁻¹[j][j] and x;  predicted dof (not swept): its diagonal of the Schur complement and its gradient
-  wo.D = clamped ? hdiag_base * (1.0 + quad) : (dsq * dsq) * (quad - 1.0);
-  wo.x = clamped ? fma(hdiag_base, beta, c_lane) + hdiag_base * dsq * zw : -c_lane * (dsq * dsq) - dsq * zw;
+  const bool on_bound = is_dof && clamp != 0;                          // (predicted by the caller, or by the refinement pass)
+  wo.clamp = on_bound ? clamp : 0;
+  wo.D = on_bound ? hdiag_base * (1.0 + quad) : (dsq * dsq) * (quad - 1.0);
+  wo.x = on_bound ? fma(hdiag_base, beta, c_lane) + hdiag_base * dsq * zw : -c_lane * (dsq * dsq) - dsq * zw;
   return wo;
 }
 #else
-struct WoodOut { double hdiag, dsq, x, D; int status; };
-__device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, int, int, double, double, int, double, long long* = nullptr) { return WoodOut{0.0, 0.0, 0.0, 0.0, 0}; }
+struct WoodOut { double hdiag, dsq, x, D; int status, clamp; };
+__device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, int, int, double, double, int, double, double, double, long long* = nullptr) { return WoodOut{0.0, 0.0, 0.0, 0.0, 0, 0}; }
 #endif
 #ifdef MKH_W3
 #define MKH_STAGE (2 * ((MKH_NT + 15) / 16))   // 3-waves maps: only the planes the column has (gen_tab_asm.py)
@@ -1486,7 +1535,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     if constexpr (kWood) box_limits();
     // ---- low-rank start: Jacobian rows, S = I + Jh·Jhᵀ, LDLᵀ elimination (wood_start above), then the dof block of the
     // tableau by n_μ rank-1 updates that do not depend on each other:  R[i][j] = Σ_r Z[r][i]·Z[r][j]/d_r
-    WoodOut wo{0.0, 0.0, 0.0, 0.0, 0};
+    WoodOut wo{0.0, 0.0, 0.0, 0.0, 0, 0};
     // predicted active set (warm starts: the previous fused step from the third step on / the previous call): the low-rank
     // start builds the tableau with these dofs already on their bounds
     int pred = 0;
@@ -1498,11 +1547,11 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     }
     if constexpr (kWood) {
 #ifdef MKH_WOOD_CALL
-      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta);
+      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta, lo, hi);
 #else
       long long wprof[2] = {0, 0};
       const long long wt0 = MKH_TAP(t_cycles) ? __builtin_readcyclecounter() : 0;
-      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta, MKH_TAP(t_cycles) ? wprof : nullptr);
+      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta, lo, hi, MKH_TAP(t_cycles) ? wprof : nullptr);
       if (MKH_TAP(t_cycles)) {                 // phase_profile.py: Jacobian rows | S and w | elimination  (slots 0, 1, 2)
         const long long wt1 = __builtin_readcyclecounter();
         ta[0] += wprof[0] - wt0; ta[1] += wprof[1] - wprof[0]; ta[2] += wt1 - wprof[1];
@@ -1510,6 +1559,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
 #endif
       asm volatile("" : "+v"(lane));
       status |= wo.status;
+      pred = wo.clamp;                         // (cold start: the bounds the unconstrained minimiser violates)
       hdiag = wo.hdiag;
       if (MKH_TAP(t_cycles)) ta[3] -= __builtin_readcyclecounter();
       MKH_TAB<NT>::zero(ts);

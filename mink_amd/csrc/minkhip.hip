@@ -686,6 +686,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       // 2-waves map: the plain layout, or — when that would cost a resident wave and the pair lanes need one pass only (the
       // compact layout lets the Jacobian rows overwrite the task blocks) — the compact one
       P.wood_compact = 0; P.prefetch_wc = 0;
+      P.wood_refine = getenv("MKH_DEBUG_NO_REFINE") ? 0 : 1;
       {
         auto bytes = [&](bool pre, bool compact) { return lds_wood(pre, compact).total * (int)sizeof(double); };
         if (waves_per_cu(p->wood_nt, bytes(false, false)) < waves_per_cu(p->wood_nt, 1) && P.n_jrows > 0) {

@@ -86,6 +86,7 @@ struct DeviceProblem {
   int32_t nt;            // tableau rows per lane of the compiled kernel variant (row stride of the J rows)
   int32_t prefetch_w3;   // the same decision for the 3-waves-per-SIMD variants (compact LDS layout), direct start
   int32_t prefetch_w3w;  // ... and low-rank start
+  int32_t wood_refine;   // low-rank cold start: second elimination on the bounds the unconstrained minimiser violates
   int32_t wood_compact;  // low-rank start on the 2-waves map: use the compact LDS layout too (the plain one would cost a resident wave)
   int32_t prefetch_wc;   // ... and the prefetch decision for that layout
   int32_t prefetch;      // the next problem's q / targets are fetched into second LDS buffers (host: only if that costs no residency)

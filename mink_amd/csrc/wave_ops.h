@@ -17,6 +17,12 @@ __device__ __forceinline__ double readlane_f64(double x, int src) {
   int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
   return __hiloint2double(hi, lo);
 }
+// Lane `src` (per lane) of x through the LDS crossbar (ds_bpermute_b32 × 2): no store → wait → load round trip.
+__device__ __forceinline__ double bperm_f64(double x, int src) {
+  const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(x));
+  const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ int readlane_i32(int x, int src) { return __builtin_amdgcn_readlane(x, src); }
 
 // Tell the compiler a value is wave-uniform (it cannot prove that for loads through pointers that were
