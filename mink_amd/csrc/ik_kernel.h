@@ -1197,7 +1197,7 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
   // (cold start only: a warm start brings its own prediction)
   // (compiled into the lean 44- / 48-row builds only: its code costs the others — register pressure of this function, scalar
   //  spills — more than the pivots it saves: G1 +1.5 %, but H1 / hands / quadrupeds −10 % and the G1 full example −4.5 %)
-  constexpr bool kRefine = !kCom && NR >= 44;
+  constexpr bool kRefine = !kCom && NR >= 44 && !(MKH_FEAT & F_STEPS);
   const WoodRefine rf{kRefine && a_mask == 0 && !dual && P.wood_refine != 0, nv, lo, hi, -c_lane * (dsq * dsq), dsq, hdiag_base * dsq, -c_lane * dsq};
   if constexpr (kCom) {
     if (dual) wood_eliminate<kMuBig, true>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status, rf, clamp, beta);
