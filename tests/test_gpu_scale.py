@@ -246,3 +246,40 @@ def test_low_rank_start_with_com_rows_and_many_task_rows():
     err2 = np.abs(v2 - v2d).max() / max(1.0, np.abs(v2d).max())
     print("G1, 20 task rows: low-rank (24-row columns) vs direct start, max rel |dv| = %.2e" % err2)
     assert err2 < 1e-9
+
+
+def test_cold_start_refinement_agrees_with_the_plain_low_rank_start(monkeypatch):
+    """the lean 44-row build re-factorises for the bounds the unconstrained minimiser violates before the
+    tableau exists.  Same optimum with the pass switched off (MKH_DEBUG_NO_REFINE, read when the handle is created), on
+    ordinary problems, on heavily saturated ones (dt × 8: most dofs end on a velocity bound) and on instances that start ON
+    their joint limits (bounds of exactly 0: the violated set is decided by rounding); C oracle on a sample."""
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+    from oracle import cport
+    model = workloads.load_robot("g1")
+    nm = nat.NativeModel(model)
+    B = 4096
+    prob, dt, damping = nc.build("g1_c3", nm, B)
+    monkeypatch.setenv("MKH_DEBUG_NO_REFINE", "1")
+    plain, _, _ = nc.build("g1_c3", nm, B)
+    monkeypatch.delenv("MKH_DEBUG_NO_REFINE")
+    stand = model.key_qpos[0]
+    q, tg = workloads.make_batch(model, nm, prob, np.random.default_rng(77), B, base_q=stand)
+    # a quarter of the batch on its joint limits
+    lim = np.asarray(model.jnt_range, dtype=np.float64)
+    for j in range(model.njnt):
+        if model.jnt_type[j] in (2, 3) and model.jnt_limited[j]:
+            a = int(model.jnt_qposadr[j])
+            q[: B // 4, a] = np.where(np.arange(B // 4) % 2 == 0, lim[j, 0], lim[j, 1])
+    for scale in (1.0, 8.0):
+        v, st = prob.solve(q, tg, stand[None, :], None, dt * scale, damping)
+        assert prob.last_kernel() == "ik_solve_kernel_44_32_r44_w3", prob.last_kernel()
+        vp, stp = plain.solve(q, tg, stand[None, :], None, dt * scale, damping)
+        assert (st == 0).all() and (stp == 0).all()
+        err = np.abs(v - vp).max() / max(1.0, np.abs(vp).max())
+        idx = np.arange(0, B, 16)
+        mm, tasks, limits, _, _ = oc.g1_c3(tg[0], stand)
+        v_ref, _ = cport.CProblem(mm, tasks, limits).solve_batch(q[idx], tg[idx], stand[None, :], dt * scale, damping)
+        err_o = (np.abs(v[idx] - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))).max()
+        print("dt x %g: refinement vs none %.2e, vs C oracle %.2e" % (scale, err, err_o))
+        assert err < 1e-9 and err_o < 1e-9
