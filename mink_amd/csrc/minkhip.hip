@@ -108,6 +108,9 @@ struct MkhProblem {
   uint32_t* d_work = nullptr;      // ticket counter of the dynamic problem distribution (zeroed by the kernel's last draw)
   // staging buffers for host-pointer calls
   double *s_q = nullptr, *s_ft = nullptr, *s_pt = nullptr, *s_ct = nullptr, *s_v = nullptr;
+  // host-pointer calls on large batches: copies of chunk c + 1 / c − 1 run beside the kernel of chunk c
+  hipStream_t st_in = nullptr, st_out = nullptr;
+  hipEvent_t ev_start = nullptr, ev_in[4] = {nullptr, nullptr, nullptr, nullptr}, ev_k[4] = {nullptr, nullptr, nullptr, nullptr};
   int32_t* s_status = nullptr;
   int32_t* s_iters = nullptr;      // [2][max_batch]: iterations, converged (mkh_solve_until, host-pointer calls)
   size_t s_pt_cap = 0, s_ct_cap = 0;
@@ -788,6 +791,10 @@ void mkh_problem_destroy(MkhProblem* p) {
   (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain); (void)hipFree(p->s_iters);
   (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh);
   (void)hipFree(p->s_q); (void)hipFree(p->s_ft); (void)hipFree(p->s_pt); (void)hipFree(p->s_ct); (void)hipFree(p->s_v); (void)hipFree(p->s_status);
+  if (p->st_in) (void)hipStreamDestroy(p->st_in);
+  if (p->st_out) (void)hipStreamDestroy(p->st_out);
+  if (p->ev_start) (void)hipEventDestroy(p->ev_start);
+  for (int i = 0; i < 4; ++i) { if (p->ev_in[i]) (void)hipEventDestroy(p->ev_in[i]); if (p->ev_k[i]) (void)hipEventDestroy(p->ev_k[i]); }
   delete p;
 }
 
@@ -976,6 +983,65 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
   HIP_OK(ensure(&p->s_status, mb));
   if (n_pt > p->s_pt_cap) { (void)hipFree(p->s_pt); p->s_pt = nullptr; HIP_OK(hipMalloc((void**)&p->s_pt, n_pt * sizeof(double))); p->s_pt_cap = n_pt; }
   if (n_ct > p->s_ct_cap) { (void)hipFree(p->s_ct); p->s_ct = nullptr; HIP_OK(hipMalloc((void**)&p->s_ct, n_ct * sizeof(double))); p->s_ct_cap = n_ct; }
+  // Large plain solves in chunks: the host → device copy of chunk c + 1 and the device → host copy of chunk c − 1 run on
+  // streams of their own beside the kernel of chunk c (the single-shot sequence copy in, solve, copy out left the GPU idle
+  // for more than half of a 65 536-instance G1 call).  Chunks of at least 8 192 instances: the kernel choice by batch size
+  // (lane / wavefront kernel) stays what it is for the whole batch.
+  const int n_chunks = (!taps && !Kd && !Md && v_out && B >= 2 * 8192) ? (B / 8192 < 4 ? B / 8192 : 4) : 1;
+  if (n_chunks > 1) {
+    if (!p->st_in) {
+      HIP_OK(hipStreamCreateWithFlags(&p->st_in, hipStreamNonBlocking));
+      HIP_OK(hipStreamCreateWithFlags(&p->st_out, hipStreamNonBlocking));
+      HIP_OK(hipEventCreateWithFlags(&p->ev_start, hipEventDisableTiming));
+      for (int i = 0; i < 4; ++i) {
+        HIP_OK(hipEventCreateWithFlags(&p->ev_in[i], hipEventDisableTiming));
+        HIP_OK(hipEventCreateWithFlags(&p->ev_k[i], hipEventDisableTiming));
+      }
+    }
+    if (until) HIP_OK(ensure(&p->s_iters, mb * 2));
+    // (shared targets on the caller's stream, ahead of the first kernel; the side streams start behind the caller's work)
+    if (n_pt && !pbat) HIP_OK(hipMemcpyAsync(p->s_pt, posture_target, n_pt * sizeof(double), hipMemcpyHostToDevice, stream));
+    if (n_ct && !cbat) HIP_OK(hipMemcpyAsync(p->s_ct, com_target, n_ct * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_OK(hipEventRecord(p->ev_start, stream));
+    HIP_OK(hipStreamWaitEvent(p->st_in, p->ev_start, 0));
+    const size_t chunk = ((size_t)B / n_chunks) / 64 * 64;          // ≥ 8 192; the last chunk takes the remainder
+    const size_t ft_w = (size_t)P.n_frame * 7, pt_w = (size_t)P.n_posture * nq, ct_w = (size_t)P.n_com * 3;
+    int32_t rc = MKH_OK;
+    for (int c = 0; c < n_chunks && rc == MKH_OK; ++c) {
+      const size_t off = c * chunk, Bc = (c + 1 < n_chunks) ? chunk : (size_t)B - off;
+      HIP_OK(hipMemcpyAsync(p->s_q + off * nq, q + off * nq, Bc * nq * sizeof(double), hipMemcpyHostToDevice, p->st_in));
+      if (ft_w) HIP_OK(hipMemcpyAsync(p->s_ft + off * ft_w, frame_targets + off * ft_w, Bc * ft_w * sizeof(double), hipMemcpyHostToDevice, p->st_in));
+      if (n_pt && pbat) HIP_OK(hipMemcpyAsync(p->s_pt + off * pt_w, posture_target + off * pt_w, Bc * pt_w * sizeof(double), hipMemcpyHostToDevice, p->st_in));
+      if (n_ct && cbat) HIP_OK(hipMemcpyAsync(p->s_ct + off * ct_w, com_target + off * ct_w, Bc * ct_w * sizeof(double), hipMemcpyHostToDevice, p->st_in));
+      HIP_OK(hipEventRecord(p->ev_in[c], p->st_in));
+      HIP_OK(hipStreamWaitEvent(stream, p->ev_in[c], 0));
+      SolveArgs ac = a;
+      ac.B = (int32_t)Bc;
+      ac.q = p->s_q + off * nq; ac.frame_targets = p->s_ft + off * ft_w;
+      ac.posture_target = p->s_pt + (pbat ? off * pt_w : 0); ac.com_target = p->s_ct + (cbat ? off * ct_w : 0);
+      ac.v_out = p->s_v + off * nv; ac.status_out = p->s_status + off;
+      ac.q_out = q_out ? p->s_q + off * nq : nullptr;
+      if (until) { ac.iters_out = p->s_iters + off; ac.converged_out = p->s_iters + mb + off; }
+      if (a.warm) ac.warm = a.warm + off * nv;
+      rc = launch(p, ac, nullptr, stream, flags);
+      if (rc == MKH_OK) HIP_OK(hipEventRecord(p->ev_k[c], stream));
+    }
+    hipError_t e = hipSuccess;
+    for (int c = 0; c < n_chunks && rc == MKH_OK && e == hipSuccess; ++c) {
+      const size_t off = c * chunk, Bc = (c + 1 < n_chunks) ? chunk : (size_t)B - off;
+      e = hipStreamWaitEvent(p->st_out, p->ev_k[c], 0);
+      if (e == hipSuccess) e = hipMemcpyAsync(v_out + off * nv, p->s_v + off * nv, Bc * nv * sizeof(double), hipMemcpyDeviceToHost, p->st_out);
+      if (e == hipSuccess && q_out) e = hipMemcpyAsync(q_out + off * nq, p->s_q + off * nq, Bc * nq * sizeof(double), hipMemcpyDeviceToHost, p->st_out);
+      if (e == hipSuccess && status_out) e = hipMemcpyAsync(status_out + off, p->s_status + off, Bc * sizeof(int32_t), hipMemcpyDeviceToHost, p->st_out);
+      if (e == hipSuccess && until && iters_out) e = hipMemcpyAsync(iters_out + off, p->s_iters + off, Bc * sizeof(int32_t), hipMemcpyDeviceToHost, p->st_out);
+      if (e == hipSuccess && until && converged_out) e = hipMemcpyAsync(converged_out + off, p->s_iters + mb + off, Bc * sizeof(int32_t), hipMemcpyDeviceToHost, p->st_out);
+    }
+    // (a failed call still drains what it started: the staging buffers belong to the handle)
+    const hipError_t e1 = hipStreamSynchronize(p->st_in), e2 = hipStreamSynchronize(stream), e3 = hipStreamSynchronize(p->st_out);
+    if (e == hipSuccess) e = e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3);
+    if (rc == MKH_OK && e != hipSuccess) rc = fail(MKH_E_HIP, "solve: %s", hipGetErrorString(e));
+    return rc;
+  }
   HIP_OK(hipMemcpyAsync(p->s_q, q, (size_t)B * nq * sizeof(double), hipMemcpyHostToDevice, stream));
   if (P.n_frame) HIP_OK(hipMemcpyAsync(p->s_ft, frame_targets, (size_t)B * P.n_frame * 7 * sizeof(double), hipMemcpyHostToDevice, stream));
   if (n_pt) HIP_OK(hipMemcpyAsync(p->s_pt, posture_target, n_pt * sizeof(double), hipMemcpyHostToDevice, stream));

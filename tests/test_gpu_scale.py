@@ -98,6 +98,21 @@ def test_device_pointer_path_matches_host_path(g1_setup):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(v_d.cpu().numpy(), v_h)
     np.testing.assert_array_equal(st_d.cpu().numpy(), st_h)
+    # from 16 384 instances on a host-pointer call runs in up to four chunks whose copies overlap the kernels of their
+    # neighbours (minkhip.hip run()): same answers, ragged last chunk included, fused steps and their outputs too
+    n = 40001
+    to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    v_h, st_h = prob.solve(q[:n], tg[:n], stand[None, :], None, dt, damping)
+    v_d, st_d = prob.solve(to(q[:n]), to(tg[:n]), to(stand[None, :]), None, dt, damping)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(v_d.cpu().numpy(), v_h)
+    np.testing.assert_array_equal(st_d.cpu().numpy(), st_h)
+    qf_h, vf_h, sf_h = prob.solve(q[:n], tg[:n], stand[None, :], None, dt, damping, n_steps=3)
+    qf_d, vf_d, sf_d = prob.solve(to(q[:n]), to(tg[:n]), to(stand[None, :]), None, dt, damping, n_steps=3)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(qf_d.cpu().numpy(), qf_h)
+    np.testing.assert_array_equal(vf_d.cpu().numpy(), vf_h)
+    np.testing.assert_array_equal(sf_d.cpu().numpy(), sf_h)
 
 
 @pytest.mark.parametrize("name,B", [("ur5e_c2", 4096), ("shadow_c4", 16384)])
