@@ -113,6 +113,14 @@ def test_device_pointer_path_matches_host_path(g1_setup):
     np.testing.assert_array_equal(qf_d.cpu().numpy(), qf_h)
     np.testing.assert_array_equal(vf_d.cpu().numpy(), vf_h)
     np.testing.assert_array_equal(sf_d.cpu().numpy(), sf_h)
+    # ... and the threshold-terminated loop with its per-instance iteration counts, with per-instance posture targets
+    n = 20000
+    pt = np.repeat(stand[None, None, :], n, axis=0) + 0.01 * np.random.default_rng(3).standard_normal((n, 1, len(stand)))
+    out_h = prob.solve(q[:n], tg[:n], pt, None, dt, damping, n_steps=4, until=(1e-2, 5e-2))
+    out_d = prob.solve(to(q[:n]), to(tg[:n]), to(pt), None, dt, damping, n_steps=4, until=(1e-2, 5e-2))
+    torch.cuda.synchronize()
+    for a_h, a_d in zip(out_h, out_d):
+        np.testing.assert_array_equal(a_d.cpu().numpy(), a_h)
 
 
 @pytest.mark.parametrize("name,B", [("ur5e_c2", 4096), ("shadow_c4", 16384)])
