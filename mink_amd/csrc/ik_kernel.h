@@ -1244,7 +1244,16 @@ __device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, int, in
 static_assert(MKH_TAB<MKH_NT>::kCompilerVgprs == MKH_CAP, "register map of tab_asm.inc changed");
 #endif
 __global__ __launch_bounds__(64, MKH_WAVES) __attribute__((amdgpu_num_vgpr(MKH_CAP / 2)))
-void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, const TapArgs* __restrict__ tp) {
+void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, const TapArgs* __restrict__ tp) {
+  // The call arguments are read from the kernarg segment WHERE they are used (as the descriptor is, see Pq below): as a
+  // by-value struct hipcc loads all of it into s[12:27] at entry, spills that 16-register tuple, and reloads the whole
+  // tuple — 16 v_readlane, VALU instructions — for every field it touches: ≈ 300 VALU instructions per problem.
+  struct KernArgs { const DeviceProblem* P; SolveArgs A; const TapArgs* tp; };
+  const MKH_CONSTANT SolveArgs* A_p = (const MKH_CONSTANT SolveArgs*)((const MKH_CONSTANT char*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                                                      offsetof(KernArgs, A));
+  asm volatile("" : "+s"(A_p));
+  const MKH_CONSTANT SolveArgs& A = *A_p;
+  (void)A_k;
   constexpr int NT = MKH_NT, FEAT = MKH_FEAT;
   constexpr bool kTaps = (FEAT & F_TAPS) != 0, kRel = (FEAT & F_REL) != 0, kCom = (FEAT & F_COM) != 0;
   constexpr bool kColl = (FEAT & F_COLL) != 0, kSteps = (FEAT & F_STEPS) != 0, kWood = (FEAT & F_WOOD) != 0;
@@ -1355,6 +1364,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A, co
     const DeviceProblem* Pq = Pg;
     asm volatile("" : "+s"(Pq));          // opaque: descriptor fields are (re)loaded where they are used
     const DeviceProblem& P = *Pq;
+    asm volatile("" : "+s"(A_p));         // ... and so are the call arguments
+    const MKH_CONSTANT SolveArgs& A = *A_p;
     wave_sync();  // previous problem's LDS readers are done
     // ------------------------------------------------------------ load inputs
     // Double-buffered in LDS.  The rows of the NEXT problem (known since the top of the loop) are requested now with
