@@ -17,8 +17,8 @@
  *   - data pointers of the per-call functions are DEVICE pointers when
  *     MKH_FLAG_DEVICE_PTRS is set (e.g. torch.Tensor.data_ptr() on ROCm; the call
  *     is then asynchronous on `stream`), otherwise HOST pointers (the library
- *     stages through its own device buffers and returns after completion; from 16 384
- *     instances on in up to four chunks whose copies run beside the kernels of their
+ *     stages through its own device buffers and returns after completion; from 32 MB
+ *     of staged data on in up to four chunks whose copies run beside the kernels of their
  *     neighbours, on streams of the handle ordered by events against `stream`).
  *   - the library owns everything it allocates; the caller owns every buffer it
  *     passes.  One in-flight call per MkhProblem: asynchronous calls on one handle must be

@@ -987,7 +987,14 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
   // streams of their own beside the kernel of chunk c (the single-shot sequence copy in, solve, copy out left the GPU idle
   // for more than half of a 65 536-instance G1 call).  Chunks of at least 8 192 instances: the kernel choice by batch size
   // (lane / wavefront kernel) stays what it is for the whole batch.
-  const int n_chunks = (!taps && !Kd && !Md && v_out && B >= 2 * 8192) ? (B / 8192 < 4 ? B / 8192 : 4) : 1;
+  // Only where the copies are worth overlapping (≥ 32 MB staged: tools/bench_host_path.py — G1 at 65 536 instances
+  // 2.02 → 1.72 ms per call, the G1 full example 2.79 → 2.19 ms; a 65 536-instance UR5e call moves 10 MB around a 0.08 ms
+  // kernel and LOSES 0.15 ms to the events and the three extra launches).
+  static const bool no_chunks = getenv("MKH_DEBUG_NO_CHUNKS") != nullptr;      // (A/B of this path)
+  const size_t staged_bytes = (size_t)B * sizeof(double) *
+      (nq + (size_t)P.n_frame * 7 + nv + (pbat ? (size_t)P.n_posture * nq : 0) + (cbat ? (size_t)P.n_com * 3 : 0) + (q_out ? nq : 0));
+  const int n_chunks = (!no_chunks && !taps && !Kd && !Md && v_out && B >= 2 * 8192 && staged_bytes >= ((size_t)32 << 20))
+                           ? (B / 8192 < 4 ? B / 8192 : 4) : 1;
   if (n_chunks > 1) {
     if (!p->st_in) {
       HIP_OK(hipStreamCreateWithFlags(&p->st_in, hipStreamNonBlocking));

@@ -98,7 +98,7 @@ def test_device_pointer_path_matches_host_path(g1_setup):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(v_d.cpu().numpy(), v_h)
     np.testing.assert_array_equal(st_d.cpu().numpy(), st_h)
-    # from 16 384 instances on a host-pointer call runs in up to four chunks whose copies overlap the kernels of their
+    # a host-pointer call that stages 32 MB or more runs in up to four chunks whose copies overlap the kernels of their
     # neighbours (minkhip.hip run()): same answers, ragged last chunk included, fused steps and their outputs too
     n = 40001
     to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
@@ -114,7 +114,7 @@ def test_device_pointer_path_matches_host_path(g1_setup):
     np.testing.assert_array_equal(vf_d.cpu().numpy(), vf_h)
     np.testing.assert_array_equal(sf_d.cpu().numpy(), sf_h)
     # ... and the threshold-terminated loop with its per-instance iteration counts, with per-instance posture targets
-    n = 20000
+    n = 26000                # (≥ 32 MB staged: the chunked path)
     pt = np.repeat(stand[None, None, :], n, axis=0) + 0.01 * np.random.default_rng(3).standard_normal((n, 1, len(stand)))
     out_h = prob.solve(q[:n], tg[:n], pt, None, dt, damping, n_steps=4, until=(1e-2, 5e-2))
     out_d = prob.solve(to(q[:n]), to(tg[:n]), to(pt), None, dt, damping, n_steps=4, until=(1e-2, 5e-2))

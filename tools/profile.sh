@@ -18,7 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 
 if [ -z "${MKH_PROFILE_PMC_ONLY:-}" ]; then
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o k -- \
-  python "$R/bench.py" --config $CFG --batch $B --steps 20 --warmup 3 --no-cpu-baseline > "$O/bench_under_trace.json" 2> "$O/trace.log"
+  python "$R/bench.py" --config $CFG --batch $B --steps 20 --warmup 3 --no-cpu-baseline --no-pcie-leg > "$O/bench_under_trace.json" 2> "$O/trace.log"
 python "$R/tools/rocprof_summary.py" stats "$R/gpurun_out/${TAG}_${NAME}_kernel_stats.csv" "$O/trace" > /dev/null
 fi
 
