@@ -1248,12 +1248,21 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
   // The call arguments are read from the kernarg segment WHERE they are used (as the descriptor is, see Pq below): as a
   // by-value struct hipcc loads all of it into s[12:27] at entry, spills that 16-register tuple, and reloads the whole
   // tuple — 16 v_readlane, VALU instructions — for every field it touches: ≈ 300 VALU instructions per problem.
+  // (Low-rank variants only: G1 config 3 0.831 → 0.822 ms.  In the direct-start and all-feature builds, whose compiler
+  //  budgets are tighter, the same change trades the scalar spills for vector ones — `8_0`: 0 → 20 spilled VGPRs, UR5e at
+  //  4 096 instances −5 %; `64_30`: 447 → 534, the Shadow hand's fused loop 9.4 → 13.9 ms — so they keep the by-value struct.)
+#if (MKH_FEAT & 32)
   struct KernArgs { const DeviceProblem* P; SolveArgs A; const TapArgs* tp; };
   const MKH_CONSTANT SolveArgs* A_p = (const MKH_CONSTANT SolveArgs*)((const MKH_CONSTANT char*)__builtin_amdgcn_kernarg_segment_ptr() +
                                                                       offsetof(KernArgs, A));
   asm volatile("" : "+s"(A_p));
   const MKH_CONSTANT SolveArgs& A = *A_p;
   (void)A_k;
+#define MKH_ARGS_AT_USE() asm volatile("" : "+s"(A_p)); const MKH_CONSTANT SolveArgs& A = *A_p
+#else
+  const SolveArgs& A = A_k;
+#define MKH_ARGS_AT_USE() do {} while (0)
+#endif
   constexpr int NT = MKH_NT, FEAT = MKH_FEAT;
   constexpr bool kTaps = (FEAT & F_TAPS) != 0, kRel = (FEAT & F_REL) != 0, kCom = (FEAT & F_COM) != 0;
   constexpr bool kColl = (FEAT & F_COLL) != 0, kSteps = (FEAT & F_STEPS) != 0, kWood = (FEAT & F_WOOD) != 0;
@@ -1364,8 +1373,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     const DeviceProblem* Pq = Pg;
     asm volatile("" : "+s"(Pq));          // opaque: descriptor fields are (re)loaded where they are used
     const DeviceProblem& P = *Pq;
-    asm volatile("" : "+s"(A_p));         // ... and so are the call arguments
-    const MKH_CONSTANT SolveArgs& A = *A_p;
+    MKH_ARGS_AT_USE();                     // ... and so are the call arguments (low-rank variants)
     wave_sync();  // previous problem's LDS readers are done
     // ------------------------------------------------------------ load inputs
     // Double-buffered in LDS.  The rows of the NEXT problem (known since the top of the loop) are requested now with
