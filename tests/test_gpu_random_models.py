@@ -3,6 +3,8 @@ instance).  The hand-written robots share structure (serial limbs off a floating
 joint types, several joints per body, frames on bodies/sites and random costs exercise what they do not —
 ancestor/dof masks, pointer-jumping depth, qpos/dof address bookkeeping, the low-rank vs direct QP start."""
 
+import os
+
 import numpy as np
 import pytest
 
@@ -15,7 +17,8 @@ from random_models import random_mjcf, rand_q as _rand_q
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("seed", range(12))
+# (MKH_FUZZ_SEEDS=200 python -m pytest tests/test_gpu_random_models.py for a longer run)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MKH_FUZZ_SEEDS", "12"))))
 def test_random_tree(seed):
     rng = np.random.default_rng(1000 + seed)
     nbody = int(rng.integers(3, 40))
