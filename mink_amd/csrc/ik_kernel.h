@@ -23,7 +23,9 @@
 //                             Low-rank variants (F_WOOD) never sweep a dof: H = Dg + JwᵀJw, the task
 //                             residuals are eliminated outside the tableau — one column of [S | Jh]
 //                             per lane — and the dof block −H⁻¹ is built by rank-1 updates that do not
-//                             depend on each other (wood_start).
+//                             depend on each other (wood_start); a cold G1-size solve first
+//                             re-eliminates for the bounds its unconstrained minimiser violates, so that the
+//                             tableau starts with those dofs on their bounds (wood_eliminate).
 // Per-problem J rows, task blocks, poses and half-space rows are staged in LDS.
 // Kernel builds with one more resident wave per SIMD (_w3: 168 / 128 registers) run the phases that need many
 // registers — kinematics, Lie algebra, Jacobian rows, the elimination — as real function calls (pre_phases,
