@@ -866,6 +866,9 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   if (need == 0) feat = 0;
   else if (need == F_STEPS) feat = F_STEPS;
   else if (need == F_COLL) feat = p->simple_pairs ? (F_COLL | F_SIMPLE_COLL) : (p->convex_pairs ? (F_COLL | F_CONVEX_COLL) : F_COLL);
+  // (fused loops over capsule-only collision sets — the Shadow hand's closed loop — have a build of their own: the
+  //  all-feature one spills 534 VGPRs at this tableau size)
+  else if (need == (F_COLL | F_STEPS) && p->simple_pairs) feat = F_COLL | F_SIMPLE_COLL | F_STEPS;
   else if ((need & ~(F_REL | F_COM)) == 0) feat = F_REL | F_COM;      // box limits only: keeps the block-pivoting active set
   else feat = (need & F_TAPS) ? F_ALL : (F_ALL & ~F_TAPS);
   const bool rich = (feat & (F_ALL & ~F_STEPS)) != 0;
