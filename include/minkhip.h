@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MKH_VERSION 104
+#define MKH_VERSION 105
 
 /* return codes */
 #define MKH_OK 0
@@ -192,6 +192,10 @@ typedef struct MkhProblemDesc {
   int32_t n_dense_tasks;
   const MkhDenseTaskDesc *dense_tasks;
   int32_t n_dense_limit_rows;
+  /* 1: user Limit subclasses also contribute per-instance BOX rows (rows of G with a single nonzero entry — e.g. an
+   * acceleration limit [I; −I] — folded by the caller into lo ≤ Δq ≤ hi): MkhDenseRows.limit_lo / limit_hi.  Box rows cost no
+   * tableau row, so a limit with 2·nv of them fits any robot (general rows are capped at 64 − nv per instance). */
+  int32_t dense_limit_box;
 } MkhProblemDesc;
 
 /* Per-call arrays of the plugin route (same host/device pointer convention as q).  K = Σ k over the dense tasks (in
@@ -202,6 +206,8 @@ typedef struct MkhDenseRows {
   const double *task_J; /* (B, K, nv)  compute_jacobian per instance                 */
   const double *limit_G;/* (B, M, nv)  compute_qp_inequalities(...).G per instance   */
   const double *limit_h;/* (B, M)      compute_qp_inequalities(...).h per instance   */
+  const double *limit_lo;/* (B, nv) or NULL: per-instance lower bounds on Δq from single-entry rows (−inf = none);   */
+  const double *limit_hi;/* (B, nv) or NULL: upper bounds; both need MkhProblemDesc.dense_limit_box = 1             */
 } MkhDenseRows;
 
 /* Optional debug/parity taps: any non-NULL pointer receives that intermediate for the
@@ -241,6 +247,9 @@ void mkh_model_destroy(MkhModel *model);
 /* Snapshot the Task/Limit plugin objects of one solve_ik call site (the `tasks` and `limits` arguments of
  * mink/solve_ik.py:68-77; constructor state of tasks/frame_task.py:29-46, relative_frame_task.py:28-52,
  * posture_task.py:29-52, com_task.py:25-35 and of the three limits) into a device descriptor. */
+/* max_batch: the largest B any later call on this handle may pass — with host OR device pointers: it sizes everything the
+ * handle owns per instance (staging buffers, the active sets kept for MKH_FLAG_WARM_START).  A call with B > max_batch
+ * returns MKH_E_INVALID before anything is launched. */
 int32_t mkh_problem_create(MkhModel *model, const MkhProblemDesc *desc, int32_t max_batch, MkhProblem **out);
 void mkh_problem_destroy(MkhProblem *problem);
 int32_t mkh_problem_num_task_rows(const MkhProblem *problem);

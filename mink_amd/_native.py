@@ -79,7 +79,8 @@ class MkhDenseTaskDesc(C.Structure):
 
 
 class MkhDenseRows(C.Structure):
-    _fields_ = [("task_e", C.c_void_p), ("task_J", C.c_void_p), ("limit_G", C.c_void_p), ("limit_h", C.c_void_p)]
+    _fields_ = [("task_e", C.c_void_p), ("task_J", C.c_void_p), ("limit_G", C.c_void_p), ("limit_h", C.c_void_p),
+                ("limit_lo", C.c_void_p), ("limit_hi", C.c_void_p)]
 
 
 class MkhProblemDesc(C.Structure):
@@ -91,7 +92,7 @@ class MkhProblemDesc(C.Structure):
         ("n_velocity_limits", C.c_int32), ("velocity_limits", C.POINTER(MkhVelocityLimitDesc)),
         ("n_collision_limits", C.c_int32), ("collision_limits", C.POINTER(MkhCollisionLimitDesc)),
         ("n_dense_tasks", C.c_int32), ("dense_tasks", C.POINTER(MkhDenseTaskDesc)),
-        ("n_dense_limit_rows", C.c_int32),
+        ("n_dense_limit_rows", C.c_int32), ("dense_limit_box", C.c_int32),
     ]
 
 
@@ -262,7 +263,8 @@ class NativeProblem:
     def __init__(self, nmodel: NativeModel, frame_tasks: Sequence[dict] = (), posture_tasks: Sequence[dict] = (),
                  com_tasks: Sequence[dict] = (), configuration_limits: Sequence[dict] = (),
                  velocity_limits: Sequence[dict] = (), collision_limits: Sequence[dict] = (),
-                 max_batch: int = 1, dense_tasks: Sequence[dict] = (), dense_limit_rows: int = 0):
+                 max_batch: int = 1, dense_tasks: Sequence[dict] = (), dense_limit_rows: int = 0,
+                 dense_limit_box: bool = False):
         self.nmodel = nmodel
         m = nmodel.model
         keep = []
@@ -322,6 +324,8 @@ class NativeProblem:
             dn[i].gain = float(t.get("gain", 1.0)); dn[i].lm_damping = float(t.get("lm_damping", 0.0))
         d.n_dense_tasks, d.dense_tasks = len(dense_tasks), dn
         d.n_dense_limit_rows = int(dense_limit_rows)
+        d.dense_limit_box = 1 if dense_limit_box else 0
+        self.dense_limit_box = bool(dense_limit_box)
         self.n_dense_rows = int(sum(len(np.atleast_1d(t["cost"])) for t in dense_tasks))
         self.n_dense_limit_rows = int(dense_limit_rows)
         h = C.c_void_p()
@@ -388,6 +392,8 @@ class NativeProblem:
         m = self.nmodel.model
         use_torch = _is_torch(q)
         B = int(q.shape[0])
+        if B > self.max_batch:      # the handle's per-instance state (staging, warm-start sets) is sized by max_batch
+            raise MinkHipError(f"B={B} exceeds max_batch={self.max_batch} of this problem")
         flags = (FLAG_DIRECT_QP if direct_qp else 0) | (FLAG_WAVE_KERNEL if wave_kernel else 0) | \
             (FLAG_LANE_KERNEL if lane_kernel else 0) | (FLAG_TWO_WAVES if two_waves else 0) | \
             (FLAG_WARM_START if warm_start else 0)
@@ -450,17 +456,21 @@ class NativeProblem:
                 raise ValueError(f"com_target must have shape ({self.n_com}, 3) or (B, ...)")
         args = [self.handle, B, ptr(q), ptr(frame_targets), ptr(posture_target), ptr(com_target), float(dt),
                 float(damping), ptr(v), ptr(st)]
-        if self.n_dense_rows or self.n_dense_limit_rows:
+        if self.n_dense_rows or self.n_dense_limit_rows or self.dense_limit_box:
             if n_steps is not None:
                 raise ValueError("dense (plugin) rows are evaluated by the caller at q: no fused steps")
             dense = dense or {}
             shapes_d = {"task_e": (B, self.n_dense_rows), "task_J": (B, self.n_dense_rows, m.nv),
                         "limit_G": (B, self.n_dense_limit_rows, m.nv), "limit_h": (B, self.n_dense_limit_rows)}
+            if self.dense_limit_box:
+                shapes_d.update({"limit_lo": (B, m.nv), "limit_hi": (B, m.nv)})
             dr, keep_d = MkhDenseRows(), []
             for name, shp in shapes_d.items():
                 if 0 in shp:
                     continue
                 x = dense.get(name)
+                if x is None and name in ("limit_lo", "limit_hi"):
+                    continue                                   # one-sided box rows
                 if x is None or tuple(x.shape) != shp:
                     raise ValueError(f"dense['{name}'] must have shape {shp}")
                 x = prep(x) if use_torch else _f64(x)

@@ -46,6 +46,7 @@ class Configuration:
         # A descriptor owns one ticket counter and one set of staging buffers, so calls on ONE Configuration must not
         # run concurrently from several threads/streams (include/minkhip.h "One in-flight call per MkhProblem").
         self._problems = {}
+        self._pinned_problems = {}       # cache key → nesting count of callers about to solve on that handle (never evicted)
         self._q = None
         self.update(q if q is not None else self.model.qpos0)
 
@@ -138,11 +139,18 @@ class Configuration:
 
     def _frame_problem(self, fid: int, frame_type: str) -> "nat.NativeProblem":
         key = ("frame", fid, frame_type, self._q.shape[0])
-        if key not in self._problems:
-            self._problems[key] = nat.NativeProblem(
-                self.native, frame_tasks=[{"frame_type": frame_type, "frame_id": fid, "cost": [1.0] * 6}],
-                max_batch=self._q.shape[0])
-        return self._problems[key]
+        return self._cached_problem(key, lambda: nat.NativeProblem(
+            self.native, frame_tasks=[{"frame_type": frame_type, "frame_id": fid, "cost": [1.0] * 6}],
+            max_batch=self._q.shape[0]))
+
+    def _cached_problem(self, key, make) -> "nat.NativeProblem":
+        """Helper descriptors share the LRU cache of solve_ik._compile: every use re-inserts the entry as most recently
+        used, so that a control loop which retunes task costs every step does not evict and rebuild them each time."""
+        prob = self._problems.pop(key, None)
+        if prob is None:
+            prob = make()
+        self._problems[key] = prob
+        return prob
 
     def _frame_pose_batch(self, frame_name: str, frame_type: str) -> np.ndarray:
         fid = self._frame_id(frame_name, frame_type)
@@ -175,10 +183,9 @@ class Configuration:
         """data.subtree_com[1] (used by ComTask.set_target_from_configuration)."""
         self.model.require_valid_masses("subtree_com")
         key = ("com", self._q.shape[0])
-        if key not in self._problems:
-            self._problems[key] = nat.NativeProblem(self.native, com_tasks=[{"cost": 1.0}],
-                                                    max_batch=self._q.shape[0])
-        _, _, taps = self._problems[key].solve(self._q, None, None, np.zeros((1, 3)), 1.0, 1.0,
+        prob = self._cached_problem(key, lambda: nat.NativeProblem(self.native, com_tasks=[{"cost": 1.0}],
+                                                                   max_batch=self._q.shape[0]))
+        _, _, taps = prob.solve(self._q, None, None, np.zeros((1, 3)), 1.0, 1.0,
                                                taps=["subtree_com"], solve_qp=False)
         return self._unbatch(taps["subtree_com"])
 

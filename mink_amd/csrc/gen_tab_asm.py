@@ -247,8 +247,11 @@ def main():
     parts += [gen(nt, 128, "TabW4") for nt in W4_NTS]
     parts.append(gen_wood_elim())
     parts.append("}  // namespace mkh")
-    with open(os.path.join(HERE, "tab_asm.inc"), "w") as fh:
-        fh.write("\n".join(parts) + "\n")
+    path, text = os.path.join(HERE, "tab_asm.inc"), "\n".join(parts) + "\n"
+    if os.path.exists(path) and open(path).read() == text:
+        return                       # (unchanged: keep the timestamp, build.py recompiles what is newer than its object)
+    with open(path, "w") as fh:
+        fh.write(text)
 
 
 if __name__ == "__main__":

@@ -1552,6 +1552,10 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
           const double vm = P.vel_limit[t * 64 + lane];
           if (vm < kInf) { hi = fmin(hi, A.dt * vm); lo = fmax(lo, -(A.dt * vm)); }
         }
+        if constexpr (kDense) {     // single-entry rows of caller-defined limits (e.g. an acceleration limit [I; −I]): no tableau row
+          if (A.dense_lo) lo = fmax(lo, A.dense_lo[(size_t)pb * nv + lane]);
+          if (A.dense_hi) hi = fmin(hi, A.dense_hi[(size_t)pb * nv + lane]);
+        }
         if (MKH_TAP(t_box_lo)) MKH_TAP(t_box_lo)[(size_t)pb * nv + lane] = lo;
         if (MKH_TAP(t_box_hi)) MKH_TAP(t_box_hi)[(size_t)pb * nv + lane] = hi;
       }

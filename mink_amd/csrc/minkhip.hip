@@ -114,7 +114,7 @@ struct MkhProblem {
   int32_t* s_status = nullptr;
   int32_t* s_iters = nullptr;      // [2][max_batch]: iterations, converged (mkh_solve_until, host-pointer calls)
   size_t s_pt_cap = 0, s_ct_cap = 0;
-  double *s_de = nullptr, *s_dJ = nullptr, *s_dG = nullptr, *s_dh = nullptr;   // dense (plugin) rows
+  double *s_de = nullptr, *s_dJ = nullptr, *s_dG = nullptr, *s_dh = nullptr, *s_dbox = nullptr;   // dense (plugin) rows
 };
 
 // Kernel variants live in their own translation units (mink_amd/csrc/build.py generates one
@@ -530,6 +530,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   }
   P.n_dense_rows = (int)dcost.size();
   P.n_dense_limit_rows = d->n_dense_limit_rows;
+  P.dense_box = d->dense_limit_box ? 1 : 0;
   P.n_rows_tap = row;
   P.n_jrows = jrows;
 
@@ -789,7 +790,7 @@ void mkh_problem_destroy(MkhProblem* p) {
   (void)hipFree(p->d_vel); (void)hipFree(p->d_pairs); (void)hipFree(p->d_dev); (void)hipFree(p->d_taps); (void)hipFree(p->d_work);
   (void)hipFree(p->d_lane); (void)hipFree(p->d_warm);
   (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain); (void)hipFree(p->s_iters);
-  (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh);
+  (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh); (void)hipFree(p->s_dbox);
   (void)hipFree(p->s_q); (void)hipFree(p->s_ft); (void)hipFree(p->s_pt); (void)hipFree(p->s_ct); (void)hipFree(p->s_v); (void)hipFree(p->s_status);
   if (p->st_in) (void)hipStreamDestroy(p->st_in);
   if (p->st_out) (void)hipStreamDestroy(p->st_out);
@@ -860,7 +861,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   if (p->dev.n_com > 0) need |= F_COM;
   if (p->dev.n_pairs > 0) need |= F_COLL;
   if (a.n_steps > 1 || a.q_out || a.pos_threshold >= 0.0) need |= F_STEPS;
-  const bool dense = p->dev.n_dense_rows > 0 || p->dev.n_dense_limit_rows > 0;
+  const bool dense = p->dev.n_dense_rows > 0 || p->dev.n_dense_limit_rows > 0 || p->dev.dense_box;
   if (dense) need |= 64;                                              // plugin rows: only the all-feature variants have them
   int feat;
   if (need == 0) feat = 0;
@@ -881,7 +882,8 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
                          !taps->t_task_e && !taps->t_task_J && !taps->t_H && !taps->t_c && !taps->t_box_lo &&
                          !taps->t_box_hi && !taps->t_coll_G && !taps->t_coll_h;
   if (p->wood_nt && ((need & ~(F_STEPS | F_COM)) == 0 || (need == F_TAPS && prof_only)) && a.do_qp &&
-      !(flags & MKH_FLAG_DIRECT_QP) && dg_min > 0.0 && dg_min >= 1e-7 * p->wood_max_cost2) {
+      !(flags & MKH_FLAG_DIRECT_QP) && dg_min > 0.0 && dg_min >= 1e-7 * p->wood_max_cost2 &&
+      !((need & F_TAPS) && ((need & F_COM) || p->wood_big))) {   // (no profiling build of the F_COM low-rank start: direct variant)
     nt = p->wood_nt; nr = p->wood_nr; lds = p->wood_lds_bytes;
     feat = F_WOOD | (need & (F_STEPS | F_TAPS | F_COM)) | (p->wood_big ? F_COM : 0);
   }
@@ -932,12 +934,18 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
   if (!(dt > 0.0)) return fail(MKH_E_INVALID, "dt must be > 0");
   if (n_steps < 1) return fail(MKH_E_INVALID, "n_steps must be >= 1");
   const size_t Kd = P.n_dense_rows, Md = P.n_dense_limit_rows;
-  if (Kd || Md) {
+  const bool Bd = P.dense_box != 0;
+  if (!Bd && dense && (dense->limit_lo || dense->limit_hi))
+    return fail(MKH_E_INVALID, "limit_lo / limit_hi need a problem created with dense_limit_box = 1");
+  if (Kd || Md || Bd) {
     if (!dense) return fail(MKH_E_INVALID, "this problem has dense (plugin) rows: call mkh_solve_dense");
     if (Kd && (!dense->task_e || !dense->task_J)) return fail(MKH_E_INVALID, "dense task_e / task_J is null");
     if (Md && (!dense->limit_G || !dense->limit_h)) return fail(MKH_E_INVALID, "dense limit_G / limit_h is null");
     if (n_steps > 1 || q_out) return fail(MKH_E_INVALID, "dense (plugin) rows are evaluated by the caller at q: no fused steps");
   }
+  // max_batch bounds everything the handle owns per instance — staging buffers, the warm-start active sets — whichever
+  // kind of pointer the caller passes (a device-pointer warm start used to write past d_warm here)
+  if (B > p->max_batch) return fail(MKH_E_INVALID, "B=%d exceeds max_batch=%d of this problem", B, p->max_batch);
   HIP_OK(hipSetDevice(p->model->device));
   hipStream_t stream = (hipStream_t)hip_stream;
   const bool devp = (flags & MKH_FLAG_DEVICE_PTRS) != 0;
@@ -968,6 +976,7 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
     a.iters_out = iters_out; a.converged_out = converged_out;
     if (Kd) { a.dense_e = dense->task_e; a.dense_J = dense->task_J; }
     if (Md) { a.dense_G = dense->limit_G; a.dense_h = dense->limit_h; }
+    if (Bd) { a.dense_lo = dense->limit_lo; a.dense_hi = dense->limit_hi; }
     if (taps) {
       t.t_xpos = taps->xpos; t.t_xquat = taps->xquat; t.t_frame_pose = taps->frame_pose;
       t.t_subtree_com = taps->subtree_com; t.t_task_e = taps->task_e; t.t_task_J = taps->task_J; t.t_H = taps->H;
@@ -978,7 +987,6 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
     return launch(p, a, taps ? &t : nullptr, stream, flags);
   }
   // ---- host pointers: stage through library-owned device buffers
-  if (B > p->max_batch) return fail(MKH_E_INVALID, "B=%d exceeds max_batch=%d of this problem", B, p->max_batch);
   const size_t mb = p->max_batch;
   HIP_OK(ensure(&p->s_q, mb * nq));
   HIP_OK(ensure(&p->s_ft, mb * P.n_frame * 7));
@@ -996,7 +1004,7 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
   static const bool no_chunks = getenv("MKH_DEBUG_NO_CHUNKS") != nullptr;      // (A/B of this path)
   const size_t staged_bytes = (size_t)B * sizeof(double) *
       (nq + (size_t)P.n_frame * 7 + nv + (pbat ? (size_t)P.n_posture * nq : 0) + (cbat ? (size_t)P.n_com * 3 : 0) + (q_out ? nq : 0));
-  const int n_chunks = (!no_chunks && !taps && !Kd && !Md && v_out && B >= 2 * 8192 && staged_bytes >= ((size_t)32 << 20))
+  const int n_chunks = (!no_chunks && !taps && !Kd && !Md && !Bd && v_out && B >= 2 * 8192 && staged_bytes >= ((size_t)32 << 20))
                            ? (B / 8192 < 4 ? B / 8192 : 4) : 1;
   if (n_chunks > 1) {
     if (!p->st_in) {
@@ -1017,14 +1025,17 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
     const size_t chunk = ((size_t)B / n_chunks) / 64 * 64;          // ≥ 8 192; the last chunk takes the remainder
     const size_t ft_w = (size_t)P.n_frame * 7, pt_w = (size_t)P.n_posture * nq, ct_w = (size_t)P.n_com * 3;
     int32_t rc = MKH_OK;
-    for (int c = 0; c < n_chunks && rc == MKH_OK; ++c) {
+    hipError_t e = hipSuccess;
+    // (an error inside the loop must not return: copies that read the caller's q / targets may be in flight on st_in)
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    for (int c = 0; c < n_chunks && rc == MKH_OK && e == hipSuccess; ++c) {
       const size_t off = c * chunk, Bc = (c + 1 < n_chunks) ? chunk : (size_t)B - off;
-      HIP_OK(hipMemcpyAsync(p->s_q + off * nq, q + off * nq, Bc * nq * sizeof(double), hipMemcpyHostToDevice, p->st_in));
-      if (ft_w) HIP_OK(hipMemcpyAsync(p->s_ft + off * ft_w, frame_targets + off * ft_w, Bc * ft_w * sizeof(double), hipMemcpyHostToDevice, p->st_in));
-      if (n_pt && pbat) HIP_OK(hipMemcpyAsync(p->s_pt + off * pt_w, posture_target + off * pt_w, Bc * pt_w * sizeof(double), hipMemcpyHostToDevice, p->st_in));
-      if (n_ct && cbat) HIP_OK(hipMemcpyAsync(p->s_ct + off * ct_w, com_target + off * ct_w, Bc * ct_w * sizeof(double), hipMemcpyHostToDevice, p->st_in));
-      HIP_OK(hipEventRecord(p->ev_in[c], p->st_in));
-      HIP_OK(hipStreamWaitEvent(stream, p->ev_in[c], 0));
+      ok(hipMemcpyAsync(p->s_q + off * nq, q + off * nq, Bc * nq * sizeof(double), hipMemcpyHostToDevice, p->st_in));
+      if (ft_w) ok(hipMemcpyAsync(p->s_ft + off * ft_w, frame_targets + off * ft_w, Bc * ft_w * sizeof(double), hipMemcpyHostToDevice, p->st_in));
+      if (n_pt && pbat) ok(hipMemcpyAsync(p->s_pt + off * pt_w, posture_target + off * pt_w, Bc * pt_w * sizeof(double), hipMemcpyHostToDevice, p->st_in));
+      if (n_ct && cbat) ok(hipMemcpyAsync(p->s_ct + off * ct_w, com_target + off * ct_w, Bc * ct_w * sizeof(double), hipMemcpyHostToDevice, p->st_in));
+      ok(hipEventRecord(p->ev_in[c], p->st_in));
+      if (!ok(hipStreamWaitEvent(stream, p->ev_in[c], 0))) break;
       SolveArgs ac = a;
       ac.B = (int32_t)Bc;
       ac.q = p->s_q + off * nq; ac.frame_targets = p->s_ft + off * ft_w;
@@ -1034,9 +1045,8 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
       if (until) { ac.iters_out = p->s_iters + off; ac.converged_out = p->s_iters + mb + off; }
       if (a.warm) ac.warm = a.warm + off * nv;
       rc = launch(p, ac, nullptr, stream, flags);
-      if (rc == MKH_OK) HIP_OK(hipEventRecord(p->ev_k[c], stream));
+      if (rc == MKH_OK) ok(hipEventRecord(p->ev_k[c], stream));
     }
-    hipError_t e = hipSuccess;
     for (int c = 0; c < n_chunks && rc == MKH_OK && e == hipSuccess; ++c) {
       const size_t off = c * chunk, Bc = (c + 1 < n_chunks) ? chunk : (size_t)B - off;
       e = hipStreamWaitEvent(p->st_out, p->ev_k[c], 0);
@@ -1069,6 +1079,11 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
     HIP_OK(hipMemcpyAsync(p->s_dG, dense->limit_G, (size_t)B * Md * nv * sizeof(double), hipMemcpyHostToDevice, stream));
     HIP_OK(hipMemcpyAsync(p->s_dh, dense->limit_h, (size_t)B * Md * sizeof(double), hipMemcpyHostToDevice, stream));
     a.dense_G = p->s_dG; a.dense_h = p->s_dh;
+  }
+  if (Bd && (dense->limit_lo || dense->limit_hi)) {
+    HIP_OK(ensure(&p->s_dbox, mb * nv * 2));
+    if (dense->limit_lo) { HIP_OK(hipMemcpyAsync(p->s_dbox, dense->limit_lo, (size_t)B * nv * sizeof(double), hipMemcpyHostToDevice, stream)); a.dense_lo = p->s_dbox; }
+    if (dense->limit_hi) { HIP_OK(hipMemcpyAsync(p->s_dbox + mb * nv, dense->limit_hi, (size_t)B * nv * sizeof(double), hipMemcpyHostToDevice, stream)); a.dense_hi = p->s_dbox + mb * nv; }
   }
   a.q = p->s_q; a.frame_targets = p->s_ft; a.posture_target = p->s_pt; a.com_target = p->s_ct;
   a.v_out = v_out ? p->s_v : nullptr;

@@ -114,6 +114,7 @@ struct DeviceProblem {
   const CollisionPairDev* pairs;   // [n_pairs]
   // plugin route: caller-defined tasks as dense rows (e, J per instance in SolveArgs) and caller-defined limit rows
   int32_t n_dense_tasks, n_dense_rows, n_dense_limit_rows, dense_tap_row0;
+  int32_t dense_box;               // caller-defined limits also hand over per-instance box rows (SolveArgs::dense_lo / dense_hi)
   int32_t dense_row0[kMaxDenseTasks], dense_k[kMaxDenseTasks];
   double dense_lm[kMaxDenseTasks];
   const double* dense_cost;        // [n_dense_rows] cost of each row
@@ -150,6 +151,8 @@ struct SolveArgs {
   const double* dense_J;           // (B, n_dense_rows, nv)
   const double* dense_G;           // (B, n_dense_limit_rows, nv)
   const double* dense_h;           // (B, n_dense_limit_rows)
+  const double* dense_lo;          // (B, nv) or nullptr: box rows of caller-defined limits (single-entry rows of G, folded by the caller)
+  const double* dense_hi;          // (B, nv) or nullptr
   // warm start across CALLS (MKH_FLAG_WARM_START): where every dof of every instance ended the previous solve of this
   // problem handle (0 free, 1 at its lower bound, 2 at its upper), read at the start of the active-set phase when the
   // state is at least two solves old and written at its end; nullptr = cold

@@ -53,10 +53,42 @@ def _limit_rows(configuration: Configuration, lim, dt: float):
     return np.broadcast_to(G, (B, m, nv)), np.broadcast_to(h, (B, m))
 
 
+def _fold_box_rows(G: np.ndarray, h: np.ndarray):
+    """Split the rows G·Δq ≤ h of a caller-defined limit into per-dof BOX bounds and general half-spaces.
+
+    A row whose only nonzero entry (over the whole batch) sits in one column k is g·Δq_k ≤ h: an upper bound h / g for
+    g > 0, a lower bound for g < 0.  The reference stacks such rows into its dense G like any other
+    (mink/solve_ik.py:25-40) and quadprog treats them as general constraints; on the device they join lo ≤ Δq ≤ hi and
+    cost no tableau row — an acceleration-style limit [I; −I] (2·nv rows) would otherwise never fit next to
+    64 − nv half-space rows.  Returns (lo, hi, G_rest, h_rest): (B, nv), (B, nv), (B, m', nv), (B, m')."""
+    B, m, nv = G.shape
+    lo, hi = np.full((B, nv), -np.inf), np.full((B, nv), np.inf)
+    if m == 0:
+        return lo, hi, G, h
+    pattern = (G != 0.0).any(axis=0)                                # (m, nv): columns a row ever touches
+    single = pattern.sum(axis=1) == 1
+    for r in np.flatnonzero(single):
+        k = int(np.flatnonzero(pattern[r])[0])
+        g, hr = G[:, r, k], h[:, r]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            b = hr / g
+        pos, neg, zero = g > 0.0, g < 0.0, g == 0.0
+        hi[pos, k] = np.minimum(hi[pos, k], b[pos])
+        lo[neg, k] = np.maximum(lo[neg, k], b[neg])
+        bad = zero & (hr < 0.0)                                     # 0·Δq ≤ h < 0: infeasible, as the reference would find
+        hi[bad, k], lo[bad, k] = -np.inf, np.inf
+    keep = ~single
+    return lo, hi, G[:, keep], h[:, keep]
+
+
 def _dense_inputs(configuration: Configuration, layout, dt: float):
     """Per-call arrays of the plugin route (mkh_solve_dense), None when the call site has no caller-defined rows."""
     if not layout["dense"] and not layout["dense_limits"]:
         return None
+    if layout.get("dense_box") is not None:
+        out_box = {"limit_lo": np.ascontiguousarray(layout["dense_box"][0]), "limit_hi": np.ascontiguousarray(layout["dense_box"][1])}
+    else:
+        out_box = {}
     out = {}
     if layout["dense"]:
         rows = [t._dense_rows(configuration) for t in layout["dense"]]
@@ -66,6 +98,7 @@ def _dense_inputs(configuration: Configuration, layout, dt: float):
         rows = layout["dense_limit_data"]                             # evaluated by _compile at this call's dt
         out["limit_G"] = np.ascontiguousarray(np.concatenate([G for G, _ in rows], axis=1))
         out["limit_h"] = np.ascontiguousarray(np.concatenate([h for _, h in rows], axis=1))
+    out.update(out_box)
     return out
 
 
@@ -96,9 +129,21 @@ def _compile(configuration: Configuration, tasks: Sequence, limits: Optional[Seq
     if layout["dense_limits"]:
         # the row count of a plugin limit is only known from what it returns: evaluate once here (dt does not change
         # the shape), keep the rows for this call
-        layout["dense_limit_data"] = [_limit_rows(configuration, lim, dense_dt) for lim in layout["dense_limits"]]
+        raw = [_limit_rows(configuration, lim, dense_dt) for lim in layout["dense_limits"]]
+        folded = [_fold_box_rows(np.asarray(G), np.asarray(h)) for G, h in raw]
+        layout["dense_limit_data"] = [(G, h) for _, _, G, h in folded]
         layout["dense_limit_rows"] = sum(h.shape[-1] for _, h in layout["dense_limit_data"])
-    key = (_key(groups), batch, layout["dense_limit_rows"])
+        lo = np.maximum.reduce([f[0] for f in folded]); hi = np.minimum.reduce([f[1] for f in folded])
+        if np.isfinite(lo).any() or np.isfinite(hi).any() or (lo > hi).any():
+            layout["dense_box"] = (lo, hi)
+        cap = 64 - configuration.nv
+        if layout["dense_limit_rows"] > cap:
+            names = ", ".join(type(lim).__name__ for lim in layout["dense_limits"])
+            raise exceptions.LimitDefinitionError(
+                f"caller-defined limits ({names}) contribute {layout['dense_limit_rows']} general rows G·Δq ≤ h (rows with a "
+                f"single nonzero entry are folded into the per-dof box and do not count); one wavefront holds at most "
+                f"64 − nv = {cap} half-space rows per instance for this model, shared with collision contacts")
+    key = (_key(groups), batch, layout["dense_limit_rows"], layout.get("dense_box") is not None)
     cache = configuration._problems
     prob = cache.pop(key, None)
     if prob is None:
@@ -106,14 +151,34 @@ def _compile(configuration: Configuration, tasks: Sequence, limits: Optional[Seq
             configuration.native, frame_tasks=groups["frame"], posture_tasks=groups["posture"],
             com_tasks=groups["com"], configuration_limits=groups["cfg"], velocity_limits=groups["vel"],
             collision_limits=groups["col"], max_batch=batch, dense_tasks=groups["dense"],
-            dense_limit_rows=layout["dense_limit_rows"])
+            dense_limit_rows=layout["dense_limit_rows"], dense_limit_box=layout.get("dense_box") is not None)
     cache[key] = prob                                               # (re)insert as most recently used
     # Costs, gains and lm_damping are part of the device descriptor, so a caller that retunes a cost every control
-    # step compiles a new descriptor every step: bound the cache (LRU) and free the evicted device buffers.
-    while len(cache) > PROBLEM_CACHE_SIZE:
-        old = next(iter(cache))
+    # step compiles a new descriptor every step: bound the cache (LRU) and free the evicted device buffers.  A handle
+    # that a caller up the stack is about to solve on is pinned: caller-defined tasks evaluate built-in ones
+    # (Task._eval → _compile) between the outer _compile and its solve, and must not evict the outer handle.
+    pinned = configuration._pinned_problems
+    for old in [k for k in cache if k not in pinned][:max(0, len(cache) - PROBLEM_CACHE_SIZE)]:
         cache.pop(old).close()
+    layout["cache_key"] = key
     return prob, layout
+
+
+class _pin:
+    """Keep a compiled handle out of LRU eviction while its caller still has to solve on it."""
+
+    def __init__(self, configuration: Configuration, layout):
+        self.pins, self.key = configuration._pinned_problems, layout["cache_key"]
+
+    def __enter__(self):
+        self.pins[self.key] = self.pins.get(self.key, 0) + 1
+
+    def __exit__(self, *exc):
+        n = self.pins[self.key] - 1
+        if n:
+            self.pins[self.key] = n
+        else:
+            del self.pins[self.key]
 
 
 def _gather_targets(configuration: Configuration, layout):
@@ -144,8 +209,9 @@ def build_ik(configuration: Configuration, tasks: Sequence, dt: float, damping: 
 
     prob, layout = _compile(configuration, tasks, limits, configuration.batch_size, dt)
     ft, pt, ct = _gather_targets(configuration, layout)
-    _, _, out = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping, taps=["H", "c"], solve_qp=False,
-                           dense=_dense_inputs(configuration, layout, dt))
+    with _pin(configuration, layout):
+        _, _, out = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping, taps=["H", "c"], solve_qp=False,
+                               dense=_dense_inputs(configuration, layout, dt))
     lims = [ConfigurationLimit(configuration.model)] if limits is None else limits
     G_list, h_list = [], []
     for lim in lims:
@@ -182,8 +248,9 @@ def solve_ik(configuration: Configuration, tasks: Sequence, dt: float, solver: s
     del kwargs
     prob, layout = _compile(configuration, tasks, limits, configuration.batch_size, dt)
     ft, pt, ct = _gather_targets(configuration, layout)
-    v, status = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping,
-                           dense=_dense_inputs(configuration, layout, dt), warm_start=warm_start)
+    with _pin(configuration, layout):
+        v, status = prob.solve(configuration.q_batch, ft, pt, ct, dt, damping,
+                               dense=_dense_inputs(configuration, layout, dt), warm_start=warm_start)
     if (status & nat.ST_OUTSIDE_LIMITS).any():
         configuration.check_limits(safety_break=safety_break)      # raises / warns like the reference
     bad = np.nonzero(status & ~nat.ST_OUTSIDE_LIMITS)[0]
@@ -229,8 +296,11 @@ def solve_ik_steps(configuration: Configuration, tasks: Sequence, dt: float, n_s
         # The bit is the OR over the fused steps (the reference loop checks every iteration, solve_ik.py:97): the
         # start configuration first, then — a violation that appeared at step k > 0 — the last one.  An instance
         # that left and re-entered its limits in between only warns.
-        configuration.check_limits(safety_break=safety_break)
-        Configuration(configuration.model, q, device=configuration.device).check_limits(safety_break=safety_break)
+        # With safety_break the two check_limits calls raise NotWithinConfigurationLimits like the reference; without
+        # it ONE warning is logged (a control loop calls this every tick: no fresh Configuration, no warning per joint).
+        if safety_break:
+            configuration.check_limits(safety_break=True)
+            Configuration(configuration.model, q, device=configuration.device).check_limits(safety_break=True)
         logging.warning("solve_ik_steps: %d instance(s) were outside their configuration limits at some fused step",
                         int(((status & nat.ST_OUTSIDE_LIMITS) != 0).sum()))
     bad = np.nonzero(status & ~nat.ST_OUTSIDE_LIMITS)[0]

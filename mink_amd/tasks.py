@@ -51,36 +51,70 @@ class Task(abc.ABC):
         """Target rows for mkh_solve (built-in tasks only)."""
         raise NotImplementedError
 
+    _PLUGIN_METHODS = ("compute_error", "compute_jacobian", "compute_qp_objective")
+
+    def _builtin_class(self) -> type:
+        """The class whose device descriptor this task uses: the nearest one in the MRO that defines `_native_desc`
+        (FrameTask for a caller's FrameTask subclass; Task itself for a task written from scratch)."""
+        for c in type(self).__mro__:
+            if "_native_desc" in c.__dict__:
+                return c
+        return Task
+
     def _is_dense(self) -> bool:
-        """A caller-defined task: its own compute_error, or no device descriptor of its own."""
-        return type(self).compute_error is not Task.compute_error or type(self)._native_desc is Task._native_desc
+        """Does this task reach the device as dense rows?  Yes for a task written from scratch, and for a subclass of a
+        built-in task that overrides ANY of compute_error / compute_jacobian / compute_qp_objective: the reference calls
+        those through the instance (mink/solve_ik.py:13-22 → tasks/task.py:105-138), so an override must change the
+        answer here too — the built-in device descriptor would silently ignore it."""
+        if getattr(self, "_force_builtin", 0):
+            return False
+        base, cls = self._builtin_class(), type(self)
+        return base is Task or any(getattr(cls, n) is not getattr(base, n) for n in Task._PLUGIN_METHODS)
 
     def _dense_rows(self, configuration: Configuration):
-        """(e, J) of this caller-defined task for every instance: (B, k), (B, k, nv)."""
-        if type(self).compute_error is Task.compute_error or type(self).compute_jacobian is Task.compute_jacobian:
-            raise TaskDefinitionError(f"{type(self).__name__} must implement compute_error and compute_jacobian "
+        """(e, J) of this caller-defined task for every instance: (B, k), (B, k, nv).  A half the subclass inherits from a
+        built-in task (say, compute_jacobian of FrameTask under an overridden compute_error) is evaluated on the device
+        through the built-in descriptor (Task.compute_error / compute_jacobian below)."""
+        base, cls = self._builtin_class(), type(self)
+        if cls.compute_qp_objective is not base.compute_qp_objective:
+            raise TaskDefinitionError(
+                f"{cls.__name__} overrides compute_qp_objective: the device folds a task into the QP from its rows "
+                "(e, J) with mink's own formula (tasks/task.py:105-138) and cannot take an arbitrary (H, c); override "
+                "compute_error / compute_jacobian instead")
+        if base is Task and (cls.compute_error is Task.compute_error or cls.compute_jacobian is Task.compute_jacobian):
+            raise TaskDefinitionError(f"{cls.__name__} must implement compute_error and compute_jacobian "
                                       "(mink's Task plugin interface)")
         B, nv, k = configuration.batch_size, configuration.nv, len(np.atleast_1d(self.cost))
         e = np.asarray(self.compute_error(configuration), dtype=np.float64)
         J = np.asarray(self.compute_jacobian(configuration), dtype=np.float64)
         if e.shape not in ((k,), (B, k)) or J.shape not in ((k, nv), (B, k, nv)):
-            raise TaskDefinitionError(f"{type(self).__name__}: compute_error must return ({k},) or ({B}, {k}) and "
+            raise TaskDefinitionError(f"{cls.__name__}: compute_error must return ({k},) or ({B}, {k}) and "
                                       f"compute_jacobian ({k}, {nv}) or ({B}, {k}, {nv}); got {e.shape}, {J.shape}")
         return np.broadcast_to(e, (B, k)), np.broadcast_to(J, (B, k, nv))
 
-    def _eval(self, configuration: Configuration, taps):
-        from .solve_ik import _compile, _dense_inputs, _gather_targets
-        prob, layout = _compile(configuration, [self], limits=[], batch=configuration.batch_size)
-        ft, pt, ct = _gather_targets(configuration, layout)
-        _, _, out = prob.solve(configuration.q_batch, ft, pt, ct, 1.0, 0.0, taps=taps, solve_qp=False,
-                               dense=_dense_inputs(configuration, layout, 1.0))
+    def _eval(self, configuration: Configuration, taps, builtin: bool = False):
+        """Evaluate this task alone on the device.  `builtin`: through the built-in descriptor even when the instance
+        overrides a plugin method (the inherited half of a partially overridden built-in task)."""
+        from .solve_ik import _compile, _dense_inputs, _gather_targets, _pin
+        force = builtin and self._builtin_class() is not Task
+        if force:
+            self._force_builtin = getattr(self, "_force_builtin", 0) + 1
+        try:
+            prob, layout = _compile(configuration, [self], limits=[], batch=configuration.batch_size)
+            ft, pt, ct = _gather_targets(configuration, layout)
+            with _pin(configuration, layout):
+                _, _, out = prob.solve(configuration.q_batch, ft, pt, ct, 1.0, 0.0, taps=taps, solve_qp=False,
+                                       dense=_dense_inputs(configuration, layout, 1.0))
+        finally:
+            if force:
+                self._force_builtin -= 1
         return out
 
     def compute_error(self, configuration: Configuration) -> np.ndarray:
-        return configuration._unbatch(self._eval(configuration, ["task_e"])["task_e"])
+        return configuration._unbatch(self._eval(configuration, ["task_e"], builtin=True)["task_e"])
 
     def compute_jacobian(self, configuration: Configuration) -> np.ndarray:
-        return configuration._unbatch(self._eval(configuration, ["task_J"])["task_J"])
+        return configuration._unbatch(self._eval(configuration, ["task_J"], builtin=True)["task_J"])
 
     def compute_qp_objective(self, configuration: Configuration) -> Objective:
         out = self._eval(configuration, ["H", "c"])   # damping = 0 ⇒ exactly this task's (H, c)

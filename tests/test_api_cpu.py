@@ -253,3 +253,51 @@ def test_plugin_detection():
     assert MyLimit()._is_dense() and MyVel(m, {"elbow": 1.0})._is_dense()
     kind, desc = mink.Task._native_desc(Mine(cost=np.array([1.0, 2.0]), gain=0.5, lm_damping=0.1), None)
     assert kind == "dense" and desc["cost"].tolist() == [1.0, 2.0] and desc["gain"] == 0.5 and desc["lm_damping"] == 0.1
+
+
+def test_fold_box_rows_of_caller_defined_limits():
+    """solve_ik._fold_box_rows: single-entry rows of a plugin limit become per-dof bounds, the rest stay half-spaces."""
+    from mink_amd.solve_ik import _fold_box_rows
+    B, nv = 3, 5
+    G = np.zeros((B, 6, nv)); h = np.zeros((B, 6))
+    G[:, 0, 1] = 2.0; h[:, 0] = [1.0, 2.0, np.inf]            # x1 ≤ h/2 (inactive in the last instance)
+    G[:, 1, 1] = -1.0; h[:, 1] = 0.25                          # x1 ≥ −0.25
+    G[:, 2, :] = 1.0; h[:, 2] = 3.0                            # general row
+    G[0, 3, 4] = 1.0; G[1, 3, 4] = -1.0; h[:, 3] = 0.5         # sign differs per instance; instance 2 has g = 0
+    G[:, 4, 0] = 1.0; G[:, 4, 2] = 1.0; h[:, 4] = 1.0          # two entries: general
+    h[:, 5] = [1.0, 1.0, -1.0]                                 # all-zero row: general (the solver reports 0 ≤ −1 infeasible)
+    lo, hi, Gr, hr = _fold_box_rows(G, h)
+    assert Gr.shape == (B, 3, nv) and hr.shape == (B, 3)
+    np.testing.assert_array_equal(hi[:, 1], [0.5, 1.0, np.inf])
+    np.testing.assert_array_equal(lo[:, 1], [-0.25] * 3)
+    np.testing.assert_array_equal(hi[:, 4], [0.5, np.inf, np.inf])
+    np.testing.assert_array_equal(lo[:, 4], [-np.inf, -0.5, -np.inf])
+    assert np.isinf(lo[:, [0, 2, 3]]).all() and np.isinf(hi[:, [0, 2, 3]]).all()
+    # g = 0 with h < 0 in one instance of a single-entry row: infeasible box for that instance only
+    G2 = np.zeros((2, 1, nv)); G2[0, 0, 3] = 1.0; h2 = np.array([[1.0], [-1.0]])
+    lo2, hi2, _, _ = _fold_box_rows(G2, h2)
+    assert hi2[0, 3] == 1.0 and lo2[1, 3] > hi2[1, 3]
+
+
+def test_partial_override_detection():
+    import mink_amd as mink
+
+    class JOnly(mink.FrameTask):
+        def compute_jacobian(self, configuration):
+            return super().compute_jacobian(configuration)
+
+    class ObjOnly(mink.PostureTask):
+        def compute_qp_objective(self, configuration):
+            return super().compute_qp_objective(configuration)
+
+    class Plain(mink.FrameTask):                  # extra state / helpers only: still the built-in device path
+        def helper(self):
+            return 1
+
+    from mink_amd import workloads
+    m = workloads.load_robot("ur5e")
+    assert JOnly("attachment_site", "site", 1.0, 1.0)._is_dense()
+    assert ObjOnly(m, 1.0)._is_dense()
+    p = Plain("attachment_site", "site", 1.0, 1.0)
+    assert not p._is_dense() and p._builtin_class() is mink.FrameTask
+    assert not mink.DampingTask(m, 1.0)._is_dense() and mink.DampingTask(m, 1.0)._builtin_class() is mink.PostureTask

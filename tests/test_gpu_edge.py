@@ -113,6 +113,21 @@ def test_argument_validation():
         prob.solve(np.zeros((2, 6)), np.zeros((2, 2, 7)), None, None, 1e-2, 1e-3)
     with pytest.raises(nat.MinkHipError, match="max_batch"):
         prob.solve(np.zeros((8, 6)), np.zeros((8, 1, 7)), None, None, 1e-2, 1e-3)
+    # ... on every path: device pointers too (a warm start used to write past the handle's max_batch × nv active sets),
+    # checked by the library itself (ctypes call below) and by the binding
+    import ctypes as C
+    import torch
+    qd = torch.zeros((8, 6), dtype=torch.float64, device="cuda"); td = torch.zeros((8, 1, 7), dtype=torch.float64, device="cuda")
+    td[:, :, 0] = 1.0
+    vd = torch.zeros((8, 6), dtype=torch.float64, device="cuda"); sd = torch.zeros((8,), dtype=torch.int32, device="cuda")
+    for flags in (nat.FLAG_DEVICE_PTRS, nat.FLAG_DEVICE_PTRS | nat.FLAG_WARM_START):
+        rc = nat.lib().mkh_solve(prob.handle, 8, C.c_void_p(qd.data_ptr()), C.c_void_p(td.data_ptr()), None, None,
+                                 C.c_double(1e-2), C.c_double(1e-3), C.c_void_p(vd.data_ptr()), C.c_void_p(sd.data_ptr()), flags, None)
+        assert rc == -1 and b"max_batch" in nat.lib().mkh_last_error(), rc       # MKH_E_INVALID
+    torch.cuda.synchronize()
+    assert float(vd.abs().max()) == 0.0                     # nothing was launched
+    with pytest.raises(nat.MinkHipError, match="max_batch"):
+        prob.solve(qd, td, None, None, 1e-2, 1e-3, warm_start=True)
     with pytest.raises(nat.MinkHipError, match="dt must be"):
         prob.solve(np.zeros((2, 6)), np.zeros((2, 1, 7)), None, None, 0.0, 1e-3)
     with pytest.raises(nat.MinkHipError, match="site id"):

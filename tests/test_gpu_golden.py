@@ -175,3 +175,74 @@ def test_round2_fixtures(nat, name):
         hc = d["h"][:, 2 * n:2 * n + 2]
         Gx = np.einsum("bpj,bj->bp", d["G"][:, 2 * n:2 * n + 2], v * dt)
         assert ((np.abs(Gx - hc) < 1e-9) & np.isfinite(hc)).sum() >= 2
+
+
+def test_ur5e_c1_trajectory_replay(nat):
+    """BASELINE configs[0]: the real mink's 20-step closed loop on one UR5e instance, `limits=None`
+    (⇒ a fresh ConfigurationLimit, /root/reference/mink/solve_ik.py:28-29; the convergence test of the reference,
+    tests/test_solve_ik.py:95-148).  Every recorded (q_k → v_k) through mkh_solve at B = 1, then the whole loop through
+    mkh_solve_steps(20) → q_final."""
+    d = _golden("ur5e_c1")
+    m = oc.model("ur5e")
+    nm = nat.NativeModel(m)
+    prob, dt, damping = nc.build("ur5e_c1", nm, 1)
+    assert dt == float(d["dt"]) and damping == float(d["damping"])
+    tgt = d["frame_target"][None, None, :]
+    post = d["posture_target"][None, :]
+    worst = 0.0
+    for k in range(len(d["q"])):
+        v, st = prob.solve(d["q"][k][None, :], tgt, post, None, dt, damping)
+        assert st[0] == 0
+        worst = max(worst, float(np.abs(v[0] - d["v"][k]).max() / max(1.0, np.abs(d["v"][k]).max())))
+    assert worst < 1e-8, worst
+    qf, v_last, st = prob.solve(d["q"][0][None, :], tgt, post, None, dt, damping, n_steps=len(d["q"]))
+    assert st[0] == 0
+    np.testing.assert_allclose(qf[0], d["q_final"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(v_last[0], d["v"][-1], rtol=0, atol=1e-8 * max(1.0, np.abs(d["v"][-1]).max()))
+    # the same trajectory with the same B through the lane-per-problem kernel family (pinned by flag)
+    qf2, _, st2 = prob.solve(d["q"][0][None, :], tgt, post, None, dt, damping, n_steps=len(d["q"]), lane_kernel=True)
+    assert st2[0] == 0
+    np.testing.assert_allclose(qf2[0], d["q_final"], rtol=0, atol=1e-9)
+    print("ur5e_c1 replay: max rel |v - mink| over 20 steps", worst, "| q_final err", float(np.abs(qf[0] - d["q_final"]).max()))
+
+
+def test_production_kernel_against_2048_real_mink_instances(nat):
+    """tests/golden/ik_g1_c3_big.npz (make_golden_big.py: the REAL mink on 2 048 instances of config 3) against the
+    production kernel — low-rank start + cold-start refinement, 3 waves per SIMD — at a size the small fixtures never reach: several
+    problems per persistent wavefront and the ticket-counter tail.  Then the other
+    routes to the same answer: direct QP start, 2-waves register map, device pointers."""
+    d = _golden("g1_c3_big")
+    m = oc.model("g1")
+    nm = nat.NativeModel(m)
+    B = len(d["q"])
+    prob, dt, damping = nc.build("g1_c3", nm, B)
+    assert dt == float(d["dt"]) and damping == float(d["damping"])
+    main = np.ones(B, bool); main[7::8] = False
+    vs = np.maximum(1.0, np.abs(d["v"]).max(axis=1, keepdims=True))
+
+    def check(v, st, what):
+        assert (st & ~1 == 0).all(), (what, np.flatnonzero(st & ~1)[:10])
+        err = np.abs(v - d["v"]) / vs
+        print(f"g1_c3_big {what} ({prob.last_kernel()}): max rel v err main {err[main].max():.2e} small-angle {err[~main].max():.2e}")
+        assert err[main].max() < 1e-8 and err[~main].max() < 1e-5
+
+    v, st = prob.solve(d["q"], d["frame_targets"], d["posture_target"][None, :], None, dt, damping)
+    assert prob.last_kernel() == "ik_solve_kernel_44_32_r44_w3", prob.last_kernel()
+    check(v, st, "production")
+    v2, st2 = prob.solve(d["q"], d["frame_targets"], d["posture_target"][None, :], None, dt, damping, direct_qp=True)
+    check(v2, st2, "direct start")
+    v3, st3 = prob.solve(d["q"], d["frame_targets"], d["posture_target"][None, :], None, dt, damping, two_waves=True)
+    check(v3, st3, "2-waves map")
+    np.testing.assert_array_equal(v3, v)          # the two register maps run the same arithmetic
+    # 2 048 problems are one per resident wavefront: tile the fixture so that every persistent wavefront runs several
+    # rounds and the last eighth of the batch goes through the ticket counter — same inputs, so the same real-mink answers
+    R = 8
+    probR, _, _ = nc.build("g1_c3", nm, R * B)
+    vR, stR = probR.solve(np.tile(d["q"], (R, 1)), np.tile(d["frame_targets"], (R, 1, 1)), d["posture_target"][None, :],
+                          None, dt, damping)
+    assert probR.last_kernel() == "ik_solve_kernel_44_32_r44_w3"
+    info = probR.launch_info(R * B)
+    assert R * B >= 4 * info["grid"], info                 # ⇒ dynamic tail (minkhip.hip::launch)
+    for r in range(R):
+        np.testing.assert_array_equal(vR[r * B:(r + 1) * B], v)
+        assert (stR[r * B:(r + 1) * B] == st).all()

@@ -191,3 +191,151 @@ def test_plugin_errors():
     user.set_target(tg)
     with pytest.raises(mink.TaskDefinitionError, match="solve_ik_steps"):
         mink.solve_ik_steps(cfg, [user], 1e-2, 3, damping=1e-3)
+
+
+def test_partial_overrides_of_builtin_tasks():
+    """The reference calls compute_error / compute_jacobian / compute_qp_objective through the instance
+    (/root/reference/mink/solve_ik.py:13-22, tasks/task.py:105-138), so a subclass of a built-in task that overrides
+    only ONE of them changes the answer; the half it inherits is the built-in's (round-2 advisor finding: the override
+    of compute_jacobian alone used to be ignored, the override of compute_error alone raised)."""
+    B = 64
+    m, cfg, tg, home = _ur5e_batch(B, seed=11)
+    post = mink.PostureTask(m, cost=1e-2); post.set_target(home)
+    lims = [mink.ConfigurationLimit(m), mink.VelocityLimit(m, {n: np.pi for n in m.jnt_names})]
+
+    class HalfJacobian(mink.FrameTask):                    # J only
+        def compute_jacobian(self, configuration):
+            return 0.5 * super().compute_jacobian(configuration)
+
+    class PositionError(mink.FrameTask):                   # e only
+        def compute_error(self, configuration):
+            e = np.array(super().compute_error(configuration))
+            e[..., 3:] = 0.0
+            return e
+
+    builtin = mink.FrameTask("attachment_site", "site", 1.0, 0.7, gain=0.9, lm_damping=1.0); builtin.set_target(tg)
+    e_b, J_b = builtin.compute_error(cfg), builtin.compute_jacobian(cfg)
+
+    class Scratch(mink.Task):                              # the same rows written from scratch: the expected answer
+        def __init__(self, e, J, cost, **kw):
+            super().__init__(cost=cost, **kw)
+            self.e, self.J = e, J
+
+        def compute_error(self, configuration):
+            return self.e
+
+        def compute_jacobian(self, configuration):
+            return self.J
+
+    for cls, e_x, J_x in ((HalfJacobian, e_b, 0.5 * J_b),
+                          (PositionError, np.concatenate([e_b[:, :3], np.zeros((B, 3))], axis=1), J_b)):
+        t = cls("attachment_site", "site", 1.0, 0.7, gain=0.9, lm_damping=1.0); t.set_target(tg)
+        assert t._is_dense() and t._builtin_class() is mink.FrameTask
+        np.testing.assert_allclose(t.compute_error(cfg), e_x, rtol=0, atol=1e-14)
+        np.testing.assert_allclose(t.compute_jacobian(cfg), J_x, rtol=0, atol=1e-14)
+        v = mink.solve_ik(cfg, [t, post], 2e-3, "mi355x", 1e-3, limits=lims)
+        ref = Scratch(e_x, J_x, builtin.cost.copy(), gain=0.9, lm_damping=1.0)
+        v_ref = mink.solve_ik(cfg, [ref, post], 2e-3, "mi355x", 1e-3, limits=lims)
+        np.testing.assert_allclose(v, v_ref, rtol=0, atol=1e-11 * max(1.0, np.abs(v_ref).max()))
+        v_builtin = mink.solve_ik(cfg, [builtin, post], 2e-3, "mi355x", 1e-3, limits=lims)
+        assert np.abs(v - v_builtin).max() > 1e-3          # the override is not ignored
+        H, c = t.compute_qp_objective(cfg)                 # inherited objective: from the overridden rows
+        Hr, cr = ref.compute_qp_objective(cfg)
+        np.testing.assert_allclose(H, Hr, rtol=0, atol=1e-12 * np.abs(Hr).max())
+        np.testing.assert_allclose(c, cr, rtol=0, atol=1e-12 * max(1.0, np.abs(cr).max()))
+
+    class OwnObjective(mink.FrameTask):
+        def compute_qp_objective(self, configuration):
+            return mink.Objective(np.eye(configuration.nv), np.zeros(configuration.nv))
+
+    t = OwnObjective("attachment_site", "site", 1.0, 1.0); t.set_target(tg)
+    assert t._is_dense()
+    with pytest.raises(mink.TaskDefinitionError, match="overrides compute_qp_objective"):
+        mink.solve_ik(cfg, [t, post], 2e-3, "mi355x", 1e-3, limits=lims)
+
+
+def test_user_box_rows_on_g1_do_not_use_tableau_rows():
+    """A caller-defined limit [I; −I] on G1 is 74 rows against 64 − 43 = 21 half-space rows per wavefront (round-2 advisor
+    finding: it always failed with ROW_OVERFLOW).  Single-entry rows are folded into lo ≤ Δq ≤ hi on the host
+    (MkhDenseRows.limit_lo / limit_hi); a few general rows ride along as half-spaces."""
+    B = 48
+    m = workloads.load_robot("g1")
+    rng = np.random.default_rng(4)
+    stand = m.key_qpos[m.name2id("key", "stand")]
+    q = workloads.sample_q(m, rng, B, base_q=stand)
+    cfg = mink.Configuration(m, q)
+    tgt = mink.Configuration(m, cfg.integrate(rng.normal(scale=0.15, size=(B, m.nv)), 1.0))
+    tasks = []
+    for s, ori in (("left_foot", 10.0), ("right_foot", 10.0), ("left_palm", 0.0), ("right_palm", 0.0)):
+        t = mink.FrameTask(s, "site", 200.0, ori, lm_damping=1.0)
+        t.set_target(tgt.get_transform_frame_to_world(s, "site"))
+        tasks.append(t)
+    post = mink.PostureTask(m, cost=1.0); post.set_target(stand); tasks.append(post)
+    hinge = [m.jnt_names[j] for j in range(m.njnt) if m.jnt_type[j] != 0]
+    vmax = 1.5
+    ref = mink.solve_ik(cfg, tasks, 5e-3, "mi355x", 1e-1,
+                        limits=[mink.ConfigurationLimit(m), mink.VelocityLimit(m, {n: vmax for n in hinge})])
+    user = UserVelocityLimit(m, vmax)
+    assert len(user.idx) == 37 and 2 * len(user.idx) > 64 - m.nv
+    v = mink.solve_ik(cfg, tasks, 5e-3, "mi355x", 1e-1, limits=[mink.ConfigurationLimit(m), user])
+    assert (np.abs(np.abs(ref[:, 6:]) - vmax) < 1e-9).sum() > 4 * B      # many dofs sit on the user's bound
+    np.testing.assert_allclose(v, ref, rtol=0, atol=1e-9 * max(1.0, np.abs(ref).max()))
+
+    class Mixed(mink.Limit):                   # box rows + 3 general rows, one of them inactive
+        def compute_qp_inequalities(self, configuration, dt):
+            P = np.eye(m.nv)[user.idx]
+            Gg = np.zeros((3, m.nv)); Gg[0, 6:12] = 1.0; Gg[1, 12:18] = -1.0; Gg[2, 20:24] = 1.0
+            return mink.Constraint(G=np.vstack([P, Gg, -P]), h=np.concatenate([np.full(37, dt * vmax), [1e-3, 2e-3, np.inf],
+                                                                               np.full(37, dt * vmax)]))
+
+    v_m, st = mink.solve_ik(cfg, tasks, 5e-3, "mi355x", 1e-1, limits=[mink.ConfigurationLimit(m), Mixed()], return_status=True)
+    assert (st & ~1 == 0).all()
+    dq = v_m * 5e-3
+    assert (dq[:, 6:12].sum(axis=1) <= 1e-3 + 1e-12).all() and (-dq[:, 12:18].sum(axis=1) <= 2e-3 + 1e-12).all()
+    assert (np.abs(dq[:, 6:]) <= 5e-3 * vmax + 1e-12).all()
+    from oracle import ik as oik2
+    import oracle_configs as oc2
+    # the oracle's dense pipeline on a few instances: every row as a general constraint, like the reference
+    om = oc2.model("g1")
+    for i in range(0, B, 12):
+        fts = np.stack([t.transform_target_to_world.wxyz_xyz[i] for t in tasks[:4]])
+        mo, otasks, olims, dt_o, damp_o = oc2.g1_c3(fts, stand)
+        c = Mixed().compute_qp_inequalities(cfg, dt_o)
+        olims = [olims[0], oik2.DenseLimitSpec(c.G, c.h)]
+        v_ref = oik2.solve_ik(mo, q[i], otasks, dt_o, damp_o, olims)
+        np.testing.assert_allclose(v_m[i], v_ref, rtol=0, atol=1e-8 * max(1.0, np.abs(v_ref).max()))
+
+    class TooMany(mink.Limit):
+        def compute_qp_inequalities(self, configuration, dt):
+            rng2 = np.random.default_rng(0)
+            return mink.Constraint(G=rng2.normal(size=(30, m.nv)), h=np.ones(30))
+
+    with pytest.raises(mink.LimitDefinitionError, match="general rows"):
+        mink.solve_ik(cfg, tasks, 5e-3, "mi355x", 1e-1, limits=[TooMany()])
+
+
+def test_nested_evaluations_do_not_evict_the_outer_handle():
+    """A caller-defined task may evaluate many built-in ones inside compute_error (each a compiled descriptor in the
+    Configuration's LRU cache); the handle of the outer solve must survive that (round-2 advisor finding)."""
+    import sys
+    sik = sys.modules["mink_amd.solve_ik"]                 # (the package attribute of that name is the function)
+    B = 8
+    m, cfg, tg, home = _ur5e_batch(B, seed=2)
+
+    class Busy(mink.Task):
+        def compute_error(self, configuration):
+            acc = np.zeros((configuration.batch_size, 6))
+            for i in range(sik.PROBLEM_CACHE_SIZE + 4):            # distinct costs ⇒ distinct descriptors
+                t = mink.FrameTask("attachment_site", "site", 1.0 + 0.01 * i, 1.0); t.set_target(tg)
+                acc += t.compute_error(configuration)
+            return acc / (sik.PROBLEM_CACHE_SIZE + 4)
+
+        def compute_jacobian(self, configuration):
+            t = mink.FrameTask("attachment_site", "site", 1.0, 1.0); t.set_target(tg)
+            return t.compute_jacobian(configuration)
+
+    builtin = mink.FrameTask("attachment_site", "site", 1.0, 1.0); builtin.set_target(tg)
+    v_ref = mink.solve_ik(cfg, [builtin], 2e-3, "mi355x", 1e-3)
+    v = mink.solve_ik(cfg, [Busy(cost=np.ones(6))], 2e-3, "mi355x", 1e-3)
+    np.testing.assert_allclose(v, v_ref, rtol=0, atol=1e-10 * max(1.0, np.abs(v_ref).max()))
+    assert len(cfg._problems) <= sik.PROBLEM_CACHE_SIZE and not cfg._pinned_problems

@@ -73,3 +73,16 @@ def test_c_batch_equals_single_and_threads(golden_dir):
     assert (st1 == 0).all() and (st2 == 0).all()
     np.testing.assert_array_equal(v1, v2)
     np.testing.assert_allclose(v1, d["v"], rtol=0, atol=1e-9 * max(1.0, np.abs(d["v"]).max()))
+
+
+def test_c_oracle_vs_2048_real_mink_instances(golden_dir):
+    """The BASELINE-sized real-mink slice (tests/golden/make_golden_big.py) pins the checker itself at that size."""
+    d = _load(golden_dir, "g1_c3_big")
+    m, tasks, limits, dt, damping = oc.g1_c3(d["frame_targets"][0], d["posture_target"])
+    prob = cport.CProblem(m, tasks, limits)
+    v, st = prob.solve_batch(d["q"], d["frame_targets"], d["posture_target"][None, :], dt, damping)
+    assert (st == 0).all()
+    vs = np.maximum(1.0, np.abs(d["v"]).max(axis=1, keepdims=True))
+    err = np.abs(v - d["v"]) / vs
+    main = np.ones(len(v), bool); main[7::8] = False
+    assert err[main].max() < 1e-8 and err[~main].max() < 1e-5, (err[main].max(), err[~main].max())
