@@ -118,6 +118,86 @@ def measured_valu_issue(config: str, B: int, waves_per_simd: int):
         return None
 
 
+def kernel_resources(kernel: str):
+    """Registers / spills / scratch of a kernel as the compiler reported them when the library was built
+    (mink_amd/kernel_resources.json, written by mink_amd/csrc/build.py)."""
+    try:
+        with open(os.path.join(REPO, "mink_amd", "kernel_resources.json")) as fh:
+            table = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    key = kernel
+    if kernel.startswith("ik_lane_kernel_"):
+        nv = kernel.split("_")[3]
+        key = f"ik_lane_kernel<{nv},{1 if kernel.endswith('_loop') else 0}>"
+    e = table.get(key)
+    if e is None:
+        return None
+    return {"vgprs": e.get("vgprs"), "vgpr_spills": e.get("vgpr_spills_with_callees"), "sgpr_spills": e.get("sgpr_spills_with_callees"),
+            "scratch_bytes_per_lane": e.get("scratch_bytes_per_lane"), "occupancy_waves_per_simd": e.get("occupancy_waves_per_simd")}
+
+
+def measure_side_config(name, dev, steps=20, warmup=3, batch=None, seed=2000):
+    """One more workload on the same device, in the same process: W warm-up + K timed launches with inputs resident in
+    HBM, HIP events on the launch stream around every launch.  Returns the compact record of `other_configs`."""
+    import torch
+
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+
+    cfg = workloads.BENCH_CONFIGS[name]
+    B = batch or cfg["batch"]
+    model = workloads.load_bench_robot(name)
+    nm = nat.NativeModel(model, device=dev.index or 0)
+    prob, dt, damping = workloads.bench_config(name, model, nm, B)
+    rng = np.random.default_rng(seed)
+    q_h, tg_h, pt_h, ct_h = workloads.bench_batch(name, model, nm, prob, rng, B)
+    dense_h = workloads.bench_dense(name, model, nm, q_h, rng)
+    to = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    q, tg, pt, ct = to(q_h), to(tg_h), to(pt_h if prob.n_posture else None), to(ct_h)
+    dense = None if dense_h is None else {k: to(x) for k, x in dense_h.items()}
+    v = torch.empty((B, model.nv), dtype=torch.float64, device=dev)
+    st = torch.empty((B,), dtype=torch.int32, device=dev)
+    ev = []
+    for i in range(warmup + steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        prob.solve(q, tg, pt, ct, dt, damping, out=v, status_out=st, dense=dense)
+        e1.record()
+        if i >= warmup:
+            ev.append((e0, e1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        prob.solve(q, tg, pt, ct, dt, damping, out=v, status_out=st, dense=dense)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms = [a.elapsed_time(b) for a, b in ev]
+    kern_ms = sum(ms) / len(ms)
+    status = st.cpu().numpy()
+    kernel = prob.last_kernel()
+    bps = cfg["bytes_per_solve"]
+    ach = bps * B / (kern_ms * 1e-3) / 1e9
+    traffic = measured_traffic(name, B)
+    res = kernel_resources(kernel) or {}
+    out = {"name": name, "batch": B, "kernel": kernel, "value": B * steps / wall, "unit": "solves/s", "steps": steps,
+           "kernel_ms": kern_ms, "kernel_ms_median": statistics.median(ms),
+           "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "algorithmic_bytes_per_launch": bps * B,
+                        "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None},
+           "traffic_over_algorithmic": (traffic[0] / (bps * B)) if traffic else None,
+           "vgpr_spills": res.get("vgpr_spills"), "sgpr_spills": res.get("sgpr_spills"),
+           "scratch_bytes_per_lane": res.get("scratch_bytes_per_lane"), "waves_per_simd": res.get("occupancy_waves_per_simd"),
+           "failed_instances": int(((status & ~1) != 0).sum()),
+           "active_half_spaces_note": None, "workload": cfg["workload"]}
+    out.pop("active_half_spaces_note")
+    prob.close()
+    return out
+
+
+SIDE_CONFIGS = ("ur5e_c2", "shadow_c4", "g1_full", "g1_plugin", "ur5e_convex")
+
+
 def pcie_inclusive(prob, q_h, tg_h, pt_h, ct_h, dt, damping, reps=5):
     """Host-pointer call (the C ABI stages through its own device buffers: H2D q + targets, D2H v + status; from 32 MB on in
     chunks whose copies overlap the kernels of their neighbours)."""
@@ -247,8 +327,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="g1_c3", choices=["ur5e_c2", "g1_c3", "g1_full", "shadow_c4"],
-                    help="BASELINE config (default: the headline G1 config 3)")
+    ap.add_argument("--config", default="g1_c3", choices=["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin", "ur5e_convex"],
+                    help="BASELINE config (default: the headline G1 config 3), or one of the two general routes of the "
+                         "boundary: g1_plugin (caller-defined Task + Limit rows, mkh_solve_dense), ur5e_convex (a collision "
+                         "pair on the general convex routine)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default g1_c3 line only: skip the `other_configs` records (every other named workload, 20 steps each)")
     ap.add_argument("--batch", type=int, default=None, help="problems per GPU (default: the config's BASELINE batch)")
     ap.add_argument("--gather", action="store_true",
                     help="(kept for compatibility) N>1 always reports the RCCL-gather variant in the 'gather' object")
@@ -293,15 +377,18 @@ def main():
 
     cfg = workloads.BENCH_CONFIGS[args.config]
     B = args.batch or cfg["batch"]
-    model = workloads.load_robot(cfg["robot"])
+    model = workloads.load_bench_robot(args.config)
     nm = nat.NativeModel(model, device=local_rank)
     prob, dt, damping = workloads.bench_config(args.config, model, nm, B)
     rng = np.random.default_rng(1000 + rank)
     q_h, tg_h, pt_h, ct_h = workloads.bench_batch(args.config, model, nm, prob, rng, B)
+    dense_h = workloads.bench_dense(args.config, model, nm, q_h, rng)
     q = torch.from_numpy(q_h).to(dev)
     tg = torch.from_numpy(tg_h).to(dev)
-    pt = torch.from_numpy(pt_h).to(dev)
+    pt = torch.from_numpy(pt_h).to(dev) if prob.n_posture else None
     ct = None if ct_h is None else torch.from_numpy(ct_h).to(dev)
+    dense = None if dense_h is None else {k: torch.from_numpy(np.ascontiguousarray(x)).to(dev) for k, x in dense_h.items()}
+    plain = dense is None and args.config != "ur5e_convex"      # configs the fused loop / host-path / oracle legs cover
     v = torch.empty((B, model.nv), dtype=torch.float64, device=dev)
     st = torch.empty((B,), dtype=torch.int32, device=dev)
     v_all = torch.empty((world * B, model.nv), dtype=torch.float64, device=dev) if (world > 1 and rank == 0) else None
@@ -316,7 +403,7 @@ def main():
             if timed:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            prob.solve(q, tg, pt, ct, dt, damping, out=v, status_out=st)
+            prob.solve(q, tg, pt, ct, dt, damping, out=v, status_out=st, dense=dense)
             if timed:
                 e1.record()                               # HIP events on the launch stream, around the kernel only
                 kern_events.append((e0, e1))
@@ -429,11 +516,18 @@ def main():
         }
         if gather is not None:
             out["gather"] = gather
-        if world == 1:
+        res = kernel_resources(kernel)
+        if res is not None:
+            out["kernel_resources"] = res
+        if world == 1 and plain:
             out["converged_targets"] = converged_targets(prob, q, tg, pt, ct, dt, damping, B)
             if not args.no_pcie_leg:
                 out["pcie_inclusive_value"] = pcie_inclusive(prob, q_h, tg_h, pt_h, ct_h, dt, damping)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and args.config == "g1_c3" and args.batch is None and not args.no_other_configs:
+            # every other named workload behind the boundary, measured by the same command (20 launches each, < 0.2 s of
+            # GPU time per config): the three other single-GPU BASELINE configs and the two general routes
+            out["other_configs"] = [measure_side_config(name, dev) for name in SIDE_CONFIGS]
+        if world == 1 and plain and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.config, q_h, tg_h, pt_h, ct_h)
             # mink's real dispatch pattern (per-call Python over numpy), next to the optimistic C port
             out["cpu_baseline_python"] = (out["cpu_baseline"] if "numpy" in out["cpu_baseline"]["sample"]

@@ -103,7 +103,29 @@ BENCH_CONFIGS: Dict[str, dict] = {
                   "workload": "Shadow Hand left (nq=nv=24): 5 fingertip FrameTasks+PostureTask+ConfigurationLimit+"
                               "CollisionAvoidanceLimit(40 capsule pairs, detect 30 mm), dt=2e-3, damping=1e-5 "
                               "(BASELINE configs[3])"},
+    # The two general routes of the boundary (not BASELINE configs; measured so that no path behind the C ABI is untimed):
+    # the plugin route of mink's Task / Limit API, and a collision pair that needs the general convex routine.
+    "g1_plugin": {"robot": "g1", "key": "stand", "batch": 65536,
+                  "bytes_per_solve": 44 * 8 + 4 * 7 * 8 + 43 * 8 + 4 + 8 * (3 + 3 * 43 + 2 * 43 + 2),
+                  "workload": "G1 config 3 + one caller-defined Task (3 rows: head position, e and J handed over per instance) + "
+                              "one caller-defined Limit (2 general rows G·Δq ≤ h per instance) through mkh_solve_dense "
+                              "(mink/tasks/task.py:81-138, limits/limit.py:34-57)"},
+    "ur5e_convex": {"robot": "ur5e", "key": "home", "batch": 4096, "bytes_per_solve": 6 * 8 + 7 * 8 + 6 * 8 + 4,
+                    "workload": "UR5e, the collision set-up of examples/arm_ur5e.py:20-47 with the wrist_3_link geom as a "
+                                "CYLINDER (menagerie's eef_collision class): FrameTask + ConfigurationLimit + "
+                                "CollisionAvoidanceLimit(cylinder-plane floor, cylinder-box wall: general convex routine) + "
+                                "VelocityLimit, dt=5e-2, damping=1e-3"},
 }
+
+
+def load_bench_robot(name: str) -> FlatModel:
+    """FlatModel of a bench config (BENCH_CONFIGS key); `ur5e_convex` turns the wrist_3_link capsule into a cylinder."""
+    model = load_robot(BENCH_CONFIGS[name]["robot"])
+    if name == "ur5e_convex":
+        from .flatmodel import GEOM_CYLINDER
+        model.geom_type = model.geom_type.copy()
+        model.geom_type[model.name2id("geom", "wrist_3_link")] = GEOM_CYLINDER
+    return model
 
 
 def bench_config(name: str, model: FlatModel, nmodel: "nat.NativeModel", max_batch: int):
@@ -139,7 +161,48 @@ def bench_config(name: str, model: FlatModel, nmodel: "nat.NativeModel", max_bat
         prob = nat.NativeProblem(nmodel, frame_tasks=fts, posture_tasks=[{"cost": 1e-2}], configuration_limits=cfg,
                                  collision_limits=[col._native_desc()[1]], max_batch=max_batch)
         return prob, 2e-3, 1e-5
+    if name == "g1_plugin":
+        fts = [_frame_desc(model, s, "site", 200.0, 10.0, 1.0) for s in ("left_foot", "right_foot")] + \
+              [_frame_desc(model, s, "site", 200.0, 0.0, 1.0) for s in ("left_palm", "right_palm")]
+        prob = nat.NativeProblem(nmodel, frame_tasks=fts, posture_tasks=[{"cost": 1.0}], configuration_limits=cfg,
+                                 velocity_limits=[velocity_limit_desc(model, _hinge_velocities(model))],
+                                 dense_tasks=[{"cost": np.full(3, 50.0), "gain": 1.0, "lm_damping": 0.0}],
+                                 dense_limit_rows=2, max_batch=max_batch)
+        return prob, 5e-3, 1e-1
+    if name == "ur5e_convex":
+        from .limits import CollisionAvoidanceLimit
+
+        col = CollisionAvoidanceLimit(model, [(["wrist_3_link"], ["floor", "wall"])], collision_detection_distance=0.3)
+        prob = nat.NativeProblem(nmodel, frame_tasks=[_frame_desc(model, "attachment_site", "site", 1.0, 1.0, 1.0)],
+                                 configuration_limits=cfg, collision_limits=[col._native_desc()[1]],
+                                 velocity_limits=[velocity_limit_desc(model, _hinge_velocities(model))],
+                                 max_batch=max_batch)
+        return prob, 5e-2, 1e-3
     raise KeyError(name)
+
+
+def plugin_rows(model: FlatModel, nmodel, q: np.ndarray, rng: np.random.Generator) -> dict:
+    """Per-call arrays of the `g1_plugin` workload, as a caller of mkh_solve_dense would hand them over: a user task
+    "bring the head site 5 cm forward" (e, J = position rows of the head frame's task, evaluated by the caller at q — here
+    through the taps of a one-task problem) and a user limit with two general rows (the summed joint steps of each arm)."""
+    B = len(q)
+    head = nat.NativeProblem(nmodel, frame_tasks=[_frame_desc(model, "head", "site", 1.0, 1.0)], max_batch=B)
+    dummy = np.zeros((B, 1, 7)); dummy[:, :, 0] = 1.0
+    _, _, t = head.solve(q, dummy, None, None, 1.0, 1.0, taps=["frame_pose"], solve_qp=False)
+    tgt = t["frame_pose"].copy()
+    tgt[:, 0, 4] += 0.05
+    _, _, t = head.solve(q, tgt, None, None, 1.0, 1.0, taps=["task_e", "task_J"], solve_qp=False)
+    head.close()
+    G = np.zeros((B, 2, model.nv))
+    names = list(model.jnt_names)
+    for r, side in enumerate(("left", "right")):
+        for j, n in enumerate(names):
+            if n.startswith(side) and ("shoulder" in n or "elbow" in n):
+                G[:, r, int(model.jnt_dofadr[j])] = 1.0
+    assert (G != 0).sum(axis=2).min() >= 2, "arm rows must be general (multi-entry) rows"
+    h = np.full((B, 2), 8e-3) + 1e-3 * rng.uniform(size=(B, 2))
+    return {"task_e": np.ascontiguousarray(t["task_e"][:, :3]), "task_J": np.ascontiguousarray(t["task_J"][:, :3]),
+            "limit_G": G, "limit_h": h}
 
 
 def bench_batch(name: str, model: FlatModel, nmodel, prob, rng: np.random.Generator, n: int):
@@ -147,9 +210,11 @@ def bench_batch(name: str, model: FlatModel, nmodel, prob, rng: np.random.Genera
     com_target is per instance (the instance's own CoM + 1 cm) for the G1 full example, else None."""
     c = BENCH_CONFIGS[name]
     base = model.key_qpos[model.name2id("key", c["key"])]
-    q, tg = make_batch(model, nmodel, prob, rng, n, base_q=base)
+    q, tg = make_batch(model, nmodel, prob, rng, n, base_q=base, dense=name == "g1_plugin")
     if c["robot"] == "shadow_left":
         q[::2] = 0.5 * (q[::2] + base)            # half of the samples near the grasp: fingers come close
+    if name == "ur5e_convex":
+        q[::2] = base + rng.normal(scale=0.4, size=q[::2].shape)     # half of the samples around `home`: near wall and floor
     com = None
     if prob.n_com:
         _, _, t = prob.solve(q, tg, base[None, :], np.zeros((1, 3)), 1.0, 1.0, taps=["subtree_com"], solve_qp=False)
@@ -157,8 +222,13 @@ def bench_batch(name: str, model: FlatModel, nmodel, prob, rng: np.random.Genera
     return q, tg, base[None, :].copy(), com
 
 
+def bench_dense(name: str, model: FlatModel, nmodel, q: np.ndarray, rng: np.random.Generator):
+    """Per-call plugin arrays of a bench config (None for every config but `g1_plugin`)."""
+    return plugin_rows(model, nmodel, q, rng) if name == "g1_plugin" else None
+
+
 def make_batch(model: FlatModel, nmodel, prob, rng: np.random.Generator, n: int, base_q=None,
-               sigma: float = 0.15) -> Tuple[np.ndarray, np.ndarray]:
+               sigma: float = 0.15, dense: bool = False) -> Tuple[np.ndarray, np.ndarray]:
     """q and reachable frame targets = FK(q ⊕ δ), δ ~ N(0, σ²) per dof (device FK)."""
     q = sample_q(model, rng, n, base_q)
     delta = rng.normal(scale=sigma, size=(n, model.nv))
@@ -167,5 +237,12 @@ def make_batch(model: FlatModel, nmodel, prob, rng: np.random.Generator, n: int,
     ct = np.zeros((prob.n_com, 3)) if prob.n_com else None
     dummy = np.zeros((n, prob.n_frame, 7))
     dummy[:, :, 0] = 1.0
+    if dense:        # (a problem with plugin rows only runs through mkh_solve_dense: FK of the targets on a plain twin)
+        twin = nat.NativeProblem(nmodel, frame_tasks=[{"frame_type": "site", "frame_id": model.name2id("site", s),
+                                                       "cost": [1.0] * 6} for s in ("left_foot", "right_foot", "left_palm", "right_palm")],
+                                 max_batch=n)
+        _, _, taps = twin.solve(q2, dummy, None, None, 1.0, 1.0, taps=["frame_pose"], solve_qp=False)
+        twin.close()
+        return q, taps["frame_pose"]
     _, _, taps = prob.solve(q2, dummy, pt, ct, 1.0, 1.0, taps=["frame_pose"], solve_qp=False)
     return q, taps["frame_pose"]
