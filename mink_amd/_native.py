@@ -18,7 +18,10 @@ import numpy as np
 
 from .flatmodel import FlatModel
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libminkhip.so")
+# (MKH_LIB_TAG: an experiment build made with MKH_BUILD_TAG, mink_amd/csrc/build.py — same-box A/B runs only)
+_LIB_TAG = os.environ.get("MKH_LIB_TAG", "")
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                         f"libminkhip_{_LIB_TAG}.so" if _LIB_TAG else "libminkhip.so")
 
 MKH_OK = 0
 FLAG_DEVICE_PTRS, FLAG_POSTURE_BATCHED, FLAG_COM_BATCHED, FLAG_DIRECT_QP, FLAG_WAVE_KERNEL, FLAG_LANE_KERNEL = 1, 2, 4, 8, 16, 32

@@ -48,6 +48,19 @@
 #define MKH_TAB Tab
 #endif
 
+// Phases as REAL CALLS (MKH_CALLS): the phases that run while the tableau is dead — kinematics and task lanes (pre_phases), the
+// (task, dof) pair lanes (direct_pairs), the collision rows (collision_phase), the low-rank elimination (wood_start) — are
+// noinline functions.  The kernel's own register cap (amdgpu_num_vgpr: everything below the pinned tableau) does not bind a
+// callee, which may use the whole file of the occupancy; the kernel keeps only what is live across the call.  Round 2 built
+// this for the one-more-wave register maps (MKH_W3); round 3 turns it on for every build whose phases do not fit next to
+// the kernel's own values either: the general collision builds (FEAT 8, FEAT 136 with the convex routine) and the all-feature
+// one (FEAT 30).  Measured and kept inlined: the plane / sphere / capsule builds (FEAT 72 / 88: the Shadow hand, whose phases
+// fit — as calls 0.402 → 0.472 ms, prologues and callee-saved registers); FEAT 31, every feature + taps, is the parity build
+// and its cycle stamps sit inside the phases.
+#if defined(MKH_W3) || (defined(MKH_FEAT) && (MKH_FEAT & 8) && !(MKH_FEAT & 1) && !(MKH_FEAT & 64))
+#define MKH_CALLS 1
+#endif
+
 namespace mkh {
 
 constexpr int kNumXcd = 8;   // MI355X: 8 XCDs × 32 CUs, one L2 each
@@ -296,7 +309,8 @@ constexpr bool kTapIsProf_t_xpos = false, kTapIsProf_t_xquat = false, kTapIsProf
                kTapIsProf_t_H = false, kTapIsProf_t_c = false, kTapIsProf_t_box_lo = false, kTapIsProf_t_box_hi = false,
                kTapIsProf_t_coll_G = false, kTapIsProf_t_coll_h = false, kTapIsProf_t_qp_iters = true,
                kTapIsProf_t_cycles = true;
-enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL = 31, F_WOOD = 32, F_SIMPLE_COLL = 64, F_CONVEX_COLL = 128 };
+enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL = 31, F_WOOD = 32, F_SIMPLE_COLL = 64, F_CONVEX_COLL = 128,
+              F_DENSE = 256 };   // F_DENSE alone: the lean build of the plugin route (dense task / limit rows next to frame + posture tasks and box limits)
 
 // P lives in device memory (not in the kernarg segment): hipcc materialises every by-value kernel
 // argument field in SGPRs at kernel entry and keeps it there, which starved the QP loop of SGPRs
@@ -335,7 +349,7 @@ enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL =
 // through, which these phases do not fit in (83–236 spilled VGPRs when inlined); as a callee they get the whole 168-register
 // file — the tableau is dead while they run — and the kernel keeps only what is live across the call.
 struct PreOut { int status, d_kind, d_k, d_body, d_qadr, conv; double mu_lane; V3 com_root; };
-#ifdef MKH_W3
+#ifdef MKH_CALLS
 #define MKH_PRE_ATTR __attribute__((noinline))
 #define MKH_PRE_TC_PARAMS
 #define MKH_PRE_TC_ARGS
@@ -344,7 +358,11 @@ struct PreOut { int status, d_kind, d_k, d_body, d_qadr, conv; double mu_lane; V
 #define MKH_PRE_ATTR __forceinline__
 #define MKH_PRE_TC_PARAMS , long long (&tc)[8], int& tci
 #define MKH_PRE_TC_ARGS , tc, tci
+#ifdef MKH_CLOCKS
+#define MKH_PRE_TICK() do { tc[tci] = __builtin_readcyclecounter(); ++tci; asm volatile("" : "+v"(lane)); } while (0)
+#else
 #define MKH_PRE_TICK() do { if (MKH_TAP(t_cycles)) tc[tci] = __builtin_readcyclecounter(); ++tci; asm volatile("" : "+v"(lane)); } while (0)
+#endif
 #endif
 // The descriptor fields pre_phases reads, loaded through the constant address space (scalar loads) with the table pointers
 // typed as global memory: inside a real function the compiler has to treat pointers that arrive as arguments or come out
@@ -403,14 +421,14 @@ __device__ MKH_PRE_ATTR PreOut pre_phases(const DeviceProblem* Pq, const TapArgs
   constexpr bool kTaps = (FEAT & F_TAPS) != 0, kRel = (FEAT & F_REL) != 0, kCom = (FEAT & F_COM) != 0;
   constexpr bool kSteps = (FEAT & F_STEPS) != 0, kWood = (FEAT & F_WOOD) != 0;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-#ifdef MKH_W3
+#ifdef MKH_CALLS
   // arguments of a real call arrive in VGPRs: make the wave-uniform ones scalar again
   pb = uni(pb); oz = uni(oz); off_q = uni(off_q); off_tgt = uni(off_tgt);
   until = uni((int)until) != 0; pos_thr = uni(pos_thr); ori_thr = uni(ori_thr);
   Pq = reinterpret_cast<const DeviceProblem*>(uni((unsigned long long)reinterpret_cast<size_t>(Pq)));
   tp = reinterpret_cast<const TapArgs*>(uni((unsigned long long)reinterpret_cast<size_t>(tp)));
 #endif
-#ifdef MKH_W3
+#ifdef MKH_CALLS
   const PreView P(Pq);          // (a callee cannot assume that pointers loaded from the descriptor are global memory)
 #else
   const DeviceProblem& P = *Pq;
@@ -774,7 +792,7 @@ struct DirectPairs { double Jp[6]; int p_task, p_dof; };
 __device__ MKH_PRE_ATTR DirectPairs direct_pairs(const DeviceProblem* Pq) {
   constexpr bool kRel = (MKH_FEAT & F_REL) != 0;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-#ifdef MKH_W3
+#ifdef MKH_CALLS
   Pq = reinterpret_cast<const DeviceProblem*>(uni((unsigned long long)reinterpret_cast<size_t>(Pq)));
   const MKH_CONSTANT DeviceProblem& P = *(const MKH_CONSTANT DeviceProblem*)Pq;
   const MKH_GLOBAL FrameTaskDev* const frames = (const MKH_GLOBAL FrameTaskDev*)P.frame;
@@ -969,7 +987,7 @@ __device__ __forceinline__ void wood_eliminate(int n_mu, int NR, int lane, doubl
 
 // A real call in the 3-waves variants (see pre_phases) and in the F_COM builds, whose 24-row / two-pass instantiations do not
 // fit next to the kernel's own live values (86 spilled VGPRs when inlined).
-#if defined(MKH_W3) || (MKH_FEAT & 4)
+#if defined(MKH_CALLS) || (MKH_FEAT & 4)
 #define MKH_WOOD_CALL 1
 #define MKH_WOOD_ATTR __attribute__((noinline))
 #else
@@ -1223,6 +1241,193 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
 struct WoodOut { double hdiag, dsq, x, D; int status, clamp; };
 __device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, int, int, double, double, int, double, double, double, long long* = nullptr) { return WoodOut{0.0, 0.0, 0.0, 0.0, 0, 0}; }
 #endif
+// ---------------------------------------------------------------- collision half-space rows (CollisionAvoidanceLimit)
+// mode 0: the contacts of this problem's geom pairs (mj_geomDistance, collision_avoidance_limit.py:187-229) become half-space
+// rows: sCol[slot] = {n, from, to, h, dof chains, pair}, sA[slot][·] = −nᵀ(jacp₂(to) − jacp₁(from)); returns
+// nrows | status bits << 8 | rows_dropped << 16.  mode 1 (after the QP, only when rows were dropped): does a contact that
+// found no tableau row hold at the solution Δq (sDof slot 9)?  Returns 1 when one does not (MKH_ST_ROW_OVERFLOW).
+// Both calls run while the tableau is dead — the rows are evaluated BEFORE the H accumulation — so in the builds where the
+// distance routines do not fit next to the kernel's own values (general convex pairs, the all-feature builds, the
+// one-more-wave register maps) this is a real call and owns the whole register file (see pre_phases).
+#if (MKH_FEAT & 8)
+#if defined(MKH_CALLS) || defined(MKH_FORCE_COLL_CALL)
+#define MKH_COLL_CALL 1
+#define MKH_COLL_ATTR __attribute__((noinline))
+#else
+#define MKH_COLL_ATTR __forceinline__
+#endif
+__device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapArgs* tp, int pb, double dt, int mode,
+                                              const LdsLayout& Lk) {
+  constexpr int NT = MKH_NT, FEAT = MKH_FEAT;
+  constexpr bool kTaps = (FEAT & F_TAPS) != 0, kWood = false;
+  constexpr bool kSimpleColl = (FEAT & F_SIMPLE_COLL) != 0;     // every collision pair is plane / sphere / capsule
+  // pairs without an analytic routine (convex_dev.h): their own collision variants, and the all-feature ones
+  constexpr bool kConvexColl = (FEAT & F_CONVEX_COLL) != 0 || (FEAT & (F_ALL & ~F_TAPS)) == (F_ALL & ~F_TAPS);
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+#ifdef MKH_COLL_CALL
+  pb = uni(pb); mode = uni(mode); dt = uni(dt);
+  Pq = reinterpret_cast<const DeviceProblem*>(uni((unsigned long long)reinterpret_cast<size_t>(Pq)));
+  tp = reinterpret_cast<const TapArgs*>(uni((unsigned long long)reinterpret_cast<size_t>(tp)));
+  const MKH_CONSTANT DeviceProblem& P = *(const MKH_CONSTANT DeviceProblem*)Pq;
+  const MKH_GLOBAL CollisionPairDev* const pairs = (const MKH_GLOBAL CollisionPairDev*)P.pairs;
+#else
+  const DeviceProblem& P = *Pq;
+  const CollisionPairDev* const pairs = P.pairs;
+#endif
+  const int lane = lane_id();
+  const int nv = P.nv, n_pairs = P.n_pairs, max_rows = P.max_rows;
+#ifdef MKH_COLL_CALL
+  const LdsLayout L = kernel_lds_layout(P);                  // (a reference argument would travel through scratch)
+  (void)Lk;
+#else
+  const LdsLayout& L = Lk;
+#endif
+  const double* const sX = smem + L.X;
+  const int XS = lds_even(P.nbody);
+  const double* const sDof = smem + L.dof;
+  double* const sCol = smem + L.col;
+  double* const sA = smem + L.A;
+  const int AS = a_stride_for(nv);
+  const bool is_dof = lane < nv;
+  const double kInf = __builtin_huge_val();
+  // More detected contacts than tableau rows (64 − nv): the reference hands every row to quadprog
+  // (collision_avoidance_limit.py:187-210); here the max_rows TIGHTEST (smallest h, ties by pair index) become rows and
+  // the solution is checked against the rest after the QP — a dropped row that holds at the solution was inactive, so
+  // the result is the reference's; one that does not hold sets MKH_ST_ROW_OVERFLOW.
+  double* const sH = smem + L.jnt;                          // h of every pair (the joint axes are dead once the dof stash is written)
+  const bool can_select = n_pairs > max_rows && n_pairs <= lds_even(P.njnt * 6);
+  // contact of pair pi at the current poses: active, h, unit normal, witness points, dof chains
+  auto contact_of = [&](int pi, double& hk, V3& nrm, V3& from, V3& to, uint64_t& m1, uint64_t& m2) -> bool {
+    const auto& cp = pairs[pi];
+    const double* x1 = sX + cp.body1;
+    const double* x2 = sX + cp.body2;
+    Q4 bq1{x1[3 * XS], x1[4 * XS], x1[5 * XS], x1[6 * XS]}, bq2{x2[3 * XS], x2[4 * XS], x2[5 * XS], x2[6 * XS]};
+    V3 gp1 = V3{x1[0], x1[XS], x1[2 * XS]} + qrot(bq1, V3{cp.lpos1[0], cp.lpos1[1], cp.lpos1[2]});
+    V3 gp2 = V3{x2[0], x2[XS], x2[2 * XS]} + qrot(bq2, V3{cp.lpos2[0], cp.lpos2[1], cp.lpos2[2]});
+    Q4 gq1 = qmul(bq1, Q4{cp.lquat1[0], cp.lquat1[1], cp.lquat1[2], cp.lquat1[3]});
+    Q4 gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
+    double dist;
+    geom_distance<kSimpleColl, kConvexColl>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
+                  V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to);
+    const bool active = dist != cp.ddetect;                  // Contact.inactive (:52-56)
+    hk = kInf;
+    if (active) {
+      hk = (dist > cp.dmin) ? (cp.gain * (dist - cp.dmin) / dt) + cp.relax : cp.relax;  // :200-205
+      nrm = to - from;                                       // Contact.normal (:46-50)
+      const double nn = sqrt(dot(nrm, nrm));
+      nrm = (nn < 1e-15) ? V3{1.0, 0.0, 0.0} : fast_rcp(nn) * nrm;
+      m1 = cp.mask1;
+      m2 = cp.mask2;
+    }
+    return active;
+  };
+  // position of pair pi in the order (h, index) among all pairs (h = +inf: not detected)
+  auto rank_of = [&](int pi, double hk) -> int {
+    int rank = 0;
+    for (int j = 0; j < n_pairs; ++j) {
+      const double hj = sH[j];
+      rank += (hj < hk || (hj == hk && j < pi)) ? 1 : 0;
+    }
+    return rank;
+  };
+  if (mode != 0) {
+    // the contacts that found no tableau row: G·Δq ≤ h at the solution?  (G·Δq = −nᵀ(ṗ₂(to) − ṗ₁(from)) for joint
+    // displacements Δq, the dofs of each geom's chain only)
+    bool viol = false;
+    for (int base = 0; base < n_pairs; base += 64) {
+      const int pi = base + lane;
+      if (pi < n_pairs) {
+        const double hs = sH[pi];
+        if (hs < kInf && rank_of(pi, hs) >= max_rows) {
+          double hk;
+          V3 nrm{1, 0, 0}, from{0, 0, 0}, to{0, 0, 0};
+          uint64_t m1 = 0, m2 = 0;
+          if (contact_of(pi, hk, nrm, from, to, m1, m2)) {
+            V3 vel{0, 0, 0};
+            for (uint64_t mm = m1 | m2; mm; mm &= mm - 1) {
+              const int d = __builtin_ctzll(mm);
+              const double* dd = sDof + d * 10;
+              const V3 a_ang{dd[0], dd[1], dd[2]}, a_lin{dd[3], dd[4], dd[5]}, a_anchor{dd[6], dd[7], dd[8]};
+              const double dq = dd[9];
+              if ((m2 >> d) & 1) vel = vel + dq * (a_lin + cross(a_ang, to - a_anchor));
+              if ((m1 >> d) & 1) vel = vel - dq * (a_lin + cross(a_ang, from - a_anchor));
+            }
+            viol = viol || (-dot(nrm, vel) > hk + 1e-9 * (1.0 + fabs(hk)));
+          }
+        }
+      }
+    }
+    return __ballot(viol) ? 1 : 0;
+  }
+  int nrows = 0, status = 0;
+  bool rows_dropped = false;
+  for (int pass = 0; pass < 2; ++pass) {
+    nrows = 0;
+    for (int base = 0; base < n_pairs; base += 64) {
+      const int pi = base + lane;
+      bool active = false;
+      double hk = kInf;
+      V3 nrm{1, 0, 0}, from{0, 0, 0}, to{0, 0, 0};
+      uint64_t m1 = 0, m2 = 0;
+      if (pi < n_pairs) {
+        active = contact_of(pi, hk, nrm, from, to, m1, m2);
+        if (pass == 0) {
+          if (can_select) sH[pi] = hk;
+          if (MKH_TAP(t_coll_h)) MKH_TAP(t_coll_h)[(size_t)pb * n_pairs + pi] = hk;
+        } else if (active) {
+          active = rank_of(pi, hk) < max_rows;
+        }
+      }
+      const unsigned long long am = __ballot(active);
+      const int slot = nrows + __popcll(am & ((1ull << lane) - 1ull));
+      if (active && slot < max_rows) {
+        double* o = sCol + slot * 16;
+        o[0] = nrm.x; o[1] = nrm.y; o[2] = nrm.z; o[3] = from.x; o[4] = from.y; o[5] = from.z;
+        o[6] = to.x; o[7] = to.y; o[8] = to.z; o[9] = hk;
+        o[10] = __longlong_as_double((long long)m1);
+        o[11] = __longlong_as_double((long long)m2);
+        o[12] = (double)pi;
+      }
+      nrows += __popcll(am);
+    }
+    if (pass == 0 && can_select && nrows > max_rows) { rows_dropped = true; wave_sync(); continue; }   // select, then refill
+    break;
+  }
+  if (nrows > max_rows) { status |= 16; nrows = max_rows; }
+  wave_sync();
+  // G[s][lane] = −nᵀ(jacp₂(to) − jacp₁(from))   (compute_contact_normal_jacobian :59-72)
+  // (two rows per trip: the rows are independent chains of ≈40 dependent fp64 operations)
+  {
+    const double* ax = sDof + (is_dof ? lane : 0) * 10;
+    const V3 d_ang{ax[0], ax[1], ax[2]}, d_lin{ax[3], ax[4], ax[5]}, d_anchor{ax[6], ax[7], ax[8]};
+    auto row_entry = [&](int s) -> double {
+      const double* o = sCol + s * 16;
+      const uint64_t m1 = (uint64_t)__double_as_longlong(o[10]), m2 = (uint64_t)__double_as_longlong(o[11]);
+      V3 n{o[0], o[1], o[2]};
+      V3 dj{0, 0, 0};
+      if ((m2 >> lane) & 1) dj = dj + d_lin + cross(d_ang, V3{o[6], o[7], o[8]} - d_anchor);
+      if ((m1 >> lane) & 1) dj = dj - (d_lin + cross(d_ang, V3{o[3], o[4], o[5]} - d_anchor));
+      const double a = is_dof ? -dot(n, dj) : 0.0;
+      if (MKH_TAP(t_coll_G) && is_dof) MKH_TAP(t_coll_G)[((size_t)pb * n_pairs + (int)o[12]) * nv + lane] = a;
+      return a;
+    };
+    int s = 0;
+    for (; s + 1 < nrows; s += 2) {
+      const double a0 = row_entry(s), a1 = row_entry(s + 1);
+      if (lane < AS) { sA[s * AS + lane] = a0; sA[(s + 1) * AS + lane] = a1; }
+    }
+    if (s < nrows) {
+      const double a0 = row_entry(s);
+      if (lane < AS) sA[s * AS + lane] = a0;
+    }
+  }
+  (void)NT;
+  return nrows | (status << 8) | ((rows_dropped ? 1 : 0) << 16);
+}
+#else
+__device__ __forceinline__ int collision_phase(const DeviceProblem*, const TapArgs*, int, double, int, const LdsLayout&) { return 0; }
+#endif
+
 #ifdef MKH_W3
 #define MKH_STAGE (2 * ((MKH_NT + 15) / 16))   // 3-waves maps: only the planes the column has (gen_tab_asm.py)
 #else
@@ -1270,7 +1475,9 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
   constexpr bool kColl = (FEAT & F_COLL) != 0, kSteps = (FEAT & F_STEPS) != 0, kWood = (FEAT & F_WOOD) != 0;
   // plugin route (caller-defined Task / Limit subclasses as dense rows): only in the variants that carry every
   // feature (FEAT 30 / 31) — it is the general path, not a tuned one
-  constexpr bool kDense = (FEAT & (F_ALL & ~F_TAPS)) == (F_ALL & ~F_TAPS) && !kWood;
+  constexpr bool kDense = ((FEAT & F_DENSE) != 0 || (FEAT & (F_ALL & ~F_TAPS)) == (F_ALL & ~F_TAPS)) && !kWood;
+  // half-space rows in the tableau: collision contacts and / or general rows of caller-defined limits
+  constexpr bool kRows = kColl || (FEAT & F_DENSE) != 0;
   constexpr bool kSimpleColl = (FEAT & F_SIMPLE_COLL) != 0;     // every collision pair is plane / sphere / capsule
   // pairs without an analytic routine (convex_dev.h): their own collision variants, and the all-feature ones
   constexpr bool kConvexColl = (FEAT & F_CONVEX_COLL) != 0 || (FEAT & (F_ALL & ~F_TAPS)) == (F_ALL & ~F_TAPS);
@@ -1362,9 +1569,16 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
 // cannot keep per-lane LDS addresses (sX + 8·lane, sPiv + lane, …) alive across phases: it computed them
 // once per kernel and then SPILLED them (9 of the 24 spills of the production variant), although each
 // is one v_lshl_add away.
-#define MKH_TICK() do { if (MKH_TAP(t_cycles)) tc[tci] = __builtin_readcyclecounter(); ++tci; asm volatile("" : "+v"(lane)); } while (0)
-#define MKH_LAP0() do { if (MKH_TAP(t_cycles)) tl = __builtin_readcyclecounter(); } while (0)
-#define MKH_LAP(i) do { if (MKH_TAP(t_cycles)) { const long long n_ = __builtin_readcyclecounter(); ta[i] += n_ - tl; tl = n_; } } while (0)
+// MKH_CLK: the (B, 16) sink of the cycle stamps — the t_cycles tap of the builds with taps, or, in a -DMKH_CLOCKS experiment
+// build of ANY variant (tools/phase_clocks.py: the production kernels cannot be tapped), SolveArgs::clk
+#ifdef MKH_CLOCKS
+#define MKH_CLK (A.clk)
+#else
+#define MKH_CLK MKH_TAP(t_cycles)
+#endif
+#define MKH_TICK() do { if (MKH_CLK) tc[tci] = __builtin_readcyclecounter(); ++tci; asm volatile("" : "+v"(lane)); } while (0)
+#define MKH_LAP0() do { if (MKH_CLK) tl = __builtin_readcyclecounter(); } while (0)
+#define MKH_LAP(i) do { if (MKH_CLK) { const long long n_ = __builtin_readcyclecounter(); ta[i] += n_ - tl; tl = n_; } } while (0)
     MKH_MARK("problem_begin");
     MKH_TICK();   // 0: start
     // Opaque per-iteration zero: table loads below are indexed with it so that LICM cannot hoist
@@ -1420,16 +1634,16 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     int prev_bound = 0;
     // ... or the previous CALL on this handle (closed-loop callers: MKH_FLAG_WARM_START, SolveArgs::warm)
     // (variants with half-space rows run Goldfarb–Idnani only: no block step to seed)
-    const bool warm_in = !kColl && A.warm != nullptr && A.warm_age >= 2;
-    if (!kColl && warm_in && lane < nv) prev_bound = A.warm[(size_t)pb * nv + lane];
+    const bool warm_in = !kRows && A.warm != nullptr && A.warm_age >= 2;
+    if (!kRows && warm_in && lane < nv) prev_bound = A.warm[(size_t)pb * nv + lane];
     for (int step = 0; step < n_steps + (until ? 1 : 0); ++step) {
     int status = 0;
     tci = 1;                                                 // phase stamps 1..7 belong to the current step
 
     // FK, joint axes / dof lanes, subtree CoM, frame-task lanes (pre_phases above)
     const PreOut po = pre_phases(Pq, tp, pb, oz, (int)(sq - smem), (int)(sTgt - smem), until, A.pos_threshold, A.ori_threshold MKH_PRE_TC_ARGS);
-#ifdef MKH_W3
-    tci = 4;
+#ifdef MKH_CALLS
+    tci = 3;                                                  // (a callee has no stamps: phases 1 and 2 read as 0)
 #endif
     asm volatile("" : "+v"(lane));
     status |= po.status;
@@ -1512,6 +1726,52 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     hdiag += mu_total;
     const double hdiag_base = hdiag;   // damping + Σμ + posture diagonal: the explicit diagonal of H
 
+    // ------------------------------------------- collision half-space rows
+    // BEFORE the tableau comes alive (round 3; they used to follow the H accumulation): the distance routines — the general
+    // convex one above all — want registers, and while the pinned range is dead a real callee may use the whole file
+    // (collision_phase above).  Rows go to sCol / sA, which nothing touches until the QP.
+    int nrows = 0;
+    bool rows_dropped = false;
+    auto collision_rows = [&]() {
+      if (kColl && P.n_pairs > 0) {
+        const int r = collision_phase(Pq, tp, pb, A.dt, 0, L);
+        asm volatile("" : "+v"(lane));
+        nrows = r & 0xff; status |= (r >> 8) & 0xff; rows_dropped = ((r >> 16) & 1) != 0;
+      }
+    // caller-defined limits (Limit.compute_qp_inequalities, limits/limit.py:34-57): rows G·Δq ≤ h of this instance,
+    // appended to the half-space rows; h = +inf marks an inactive row
+    if (kDense && kRows && P.n_dense_limit_rows > 0) {
+      const int M = P.n_dense_limit_rows;
+      const double* dh = A.dense_h + (size_t)pb * M;
+      const double* dG = A.dense_G + (size_t)pb * M * nv;
+      const int first = nrows;
+      for (int base = 0; base < M; base += kWave) {
+        const int r = base + lane;
+        const double hr = r < M ? dh[r] : kInf;
+        const bool active = hr < kInf;
+        const unsigned long long am = __ballot(active);
+        const int slot = nrows + __popcll(am & ((1ull << lane) - 1ull));
+        if (active && slot < P.max_rows) {
+          double* o = sCol + slot * 16;
+          o[9] = hr;
+          o[12] = (double)r;
+        }
+        nrows += __popcll(am);
+      }
+      if (nrows > P.max_rows) { status |= 16; nrows = P.max_rows; }
+      wave_sync();
+      for (int s = first; s < nrows; ++s) {
+        const int r = (int)sCol[s * 16 + 12];
+        if (lane < AS) sA[s * AS + lane] = is_dof ? dG[(size_t)r * nv + lane] : 0.0;
+      }
+    }
+    };
+#ifdef MKH_COLL_CALL
+    constexpr bool kCollFirst = true;      // a real callee: while the tableau is dead
+#else
+    constexpr bool kCollFirst = false;     // inlined (plane / sphere / capsule builds): after the H accumulation, as in round 2
+#endif
+    if constexpr (kCollFirst) collision_rows();
     // ------------------------------ frame + CoM tasks: Jacobian columns, H, c
     const int n_jt = P.n_frame + (kCom ? P.n_com : 0);
     // The tableau column lives in pinned VGPRs (tab_asm.inc), outside the compiler's budget, so H is
@@ -1589,7 +1849,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       status |= wo.status;
       pred = wo.clamp;                         // (cold start: the bounds the unconstrained minimiser violates)
       hdiag = wo.hdiag;
-      if (MKH_TAP(t_cycles)) ta[3] -= __builtin_readcyclecounter();
+      if (MKH_CLK) ta[3] -= __builtin_readcyclecounter();
       MKH_TAB<NT>::zero(ts);
       const int n_mu = P.n_jrows;
       const double* const sDinv = sPiv + kWoodRow;
@@ -1608,7 +1868,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
         rank1_stream_rows<NT>(ts, lds_addr(sJ + (r + 1) * NT) + lane_off, g, hb);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the planes requested by the last statement are not used
-      if (MKH_TAP(t_cycles)) { asm volatile("s_waitcnt lgkmcnt(0)"); ta[3] += __builtin_readcyclecounter(); }   // (− start below)
+      if (MKH_CLK) { asm volatile("s_waitcnt lgkmcnt(0)"); ta[3] += __builtin_readcyclecounter(); }   // (− start below)
     }
     auto frame_column = [&](int t, int k, uint64_t mask, uint64_t rmask, bool rel, double (&Jt)[6]) {
       frame_column_fn<kRel>(sTask, sDof, t, k, mask, rmask, rel, Jt);
@@ -1784,142 +2044,11 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     }
     MKH_MARK("jcols_done");
     long long tj = 0;
-    if (MKH_TAP(t_cycles)) tj = __builtin_readcyclecounter();     // profiling: end of the Jacobian-column loop
+    if (MKH_CLK) tj = __builtin_readcyclecounter();     // profiling: end of the Jacobian-column loop
     if (MKH_TAP(t_c) && is_dof) MKH_TAP(t_c)[(size_t)pb * nv + lane] = c_lane;
     MKH_MARK("jcols_s_done");
     MKH_TICK();   // 4: posture + task Jacobian columns done
-    // ------------------------------------------- collision half-space rows
-    int nrows = 0;
-    // More detected contacts than tableau rows (64 − nv): the reference hands every row to quadprog
-    // (collision_avoidance_limit.py:187-210); here the max_rows TIGHTEST (smallest h, ties by pair index) become rows and
-    // the solution is checked against the rest after the QP — a dropped row that holds at the solution was inactive, so
-    // the result is the reference's; one that does not hold sets MKH_ST_ROW_OVERFLOW.
-    bool rows_dropped = false;
-    double* const sH = sJ;                                    // h of every pair (the staged Jacobian rows are dead by now)
-    const bool can_select = kColl && P.n_pairs > P.max_rows && P.n_pairs <= 6 * (kWood ? NR : j_stride_direct(nv, NT));
-    // contact of pair pi at the current poses: active, h, unit normal, witness points, dof chains
-    auto contact_of = [&](int pi, double& hk, V3& nrm, V3& from, V3& to, uint64_t& m1, uint64_t& m2) -> bool {
-      const CollisionPairDev& cp = P.pairs[pi];
-      const double* x1 = sX + cp.body1;
-      const double* x2 = sX + cp.body2;
-      Q4 bq1{x1[3 * XS], x1[4 * XS], x1[5 * XS], x1[6 * XS]}, bq2{x2[3 * XS], x2[4 * XS], x2[5 * XS], x2[6 * XS]};
-      V3 gp1 = V3{x1[0], x1[XS], x1[2 * XS]} + qrot(bq1, V3{cp.lpos1[0], cp.lpos1[1], cp.lpos1[2]});
-      V3 gp2 = V3{x2[0], x2[XS], x2[2 * XS]} + qrot(bq2, V3{cp.lpos2[0], cp.lpos2[1], cp.lpos2[2]});
-      Q4 gq1 = qmul(bq1, Q4{cp.lquat1[0], cp.lquat1[1], cp.lquat1[2], cp.lquat1[3]});
-      Q4 gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
-      double dist;
-      geom_distance<kSimpleColl, kConvexColl>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
-                    V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to);
-      const bool active = dist != cp.ddetect;                  // Contact.inactive (:52-56)
-      hk = kInf;
-      if (active) {
-        hk = (dist > cp.dmin) ? (cp.gain * (dist - cp.dmin) / A.dt) + cp.relax : cp.relax;  // :200-205
-        nrm = to - from;                                       // Contact.normal (:46-50)
-        const double nn = sqrt(dot(nrm, nrm));
-        nrm = (nn < 1e-15) ? V3{1.0, 0.0, 0.0} : fast_rcp(nn) * nrm;
-        m1 = cp.mask1;
-        m2 = cp.mask2;
-      }
-      return active;
-    };
-    // position of pair pi in the order (h, index) among all pairs (h = +inf: not detected)
-    auto rank_of = [&](int pi, double hk) -> int {
-      int rank = 0;
-      for (int j = 0; j < P.n_pairs; ++j) {
-        const double hj = sH[j];
-        rank += (hj < hk || (hj == hk && j < pi)) ? 1 : 0;
-      }
-      return rank;
-    };
-    if (kColl && P.n_pairs > 0) {
-      for (int pass = 0; pass < 2; ++pass) {
-      nrows = 0;
-      for (int base = 0; base < P.n_pairs; base += 64) {
-        const int pi = base + lane;
-        bool active = false;
-        double hk = kInf;
-        V3 nrm{1, 0, 0}, from{0, 0, 0}, to{0, 0, 0};
-        uint64_t m1 = 0, m2 = 0;
-        if (pi < P.n_pairs) {
-          active = contact_of(pi, hk, nrm, from, to, m1, m2);
-          if (pass == 0) {
-            if (can_select) sH[pi] = hk;
-            if (MKH_TAP(t_coll_h)) MKH_TAP(t_coll_h)[(size_t)pb * P.n_pairs + pi] = hk;
-          } else if (active) {
-            active = rank_of(pi, hk) < P.max_rows;
-          }
-        }
-        const unsigned long long am = __ballot(active);
-        const int slot = nrows + __popcll(am & ((1ull << lane) - 1ull));
-        if (active && slot < P.max_rows) {
-          double* o = sCol + slot * 16;
-          o[0] = nrm.x; o[1] = nrm.y; o[2] = nrm.z; o[3] = from.x; o[4] = from.y; o[5] = from.z;
-          o[6] = to.x; o[7] = to.y; o[8] = to.z; o[9] = hk;
-          o[10] = __longlong_as_double((long long)m1);
-          o[11] = __longlong_as_double((long long)m2);
-          o[12] = (double)pi;
-        }
-        nrows += __popcll(am);
-      }
-      if (pass == 0 && can_select && nrows > P.max_rows) { rows_dropped = true; wave_sync(); continue; }   // select, then refill
-      break;
-      }
-      if (nrows > P.max_rows) { status |= 16; nrows = P.max_rows; }
-      wave_sync();
-      // G[s][lane] = −nᵀ(jacp₂(to) − jacp₁(from))   (compute_contact_normal_jacobian :59-72)
-      // (two rows per trip: the rows are independent chains of ≈40 dependent fp64 operations)
-      {
-        const double* ax = sDof + (is_dof ? lane : 0) * 10;
-        const V3 d_ang{ax[0], ax[1], ax[2]}, d_lin{ax[3], ax[4], ax[5]}, d_anchor{ax[6], ax[7], ax[8]};
-        auto row_entry = [&](int s) -> double {
-          const double* o = sCol + s * 16;
-          const uint64_t m1 = (uint64_t)__double_as_longlong(o[10]), m2 = (uint64_t)__double_as_longlong(o[11]);
-          V3 n{o[0], o[1], o[2]};
-          V3 dj{0, 0, 0};
-          if ((m2 >> lane) & 1) dj = dj + d_lin + cross(d_ang, V3{o[6], o[7], o[8]} - d_anchor);
-          if ((m1 >> lane) & 1) dj = dj - (d_lin + cross(d_ang, V3{o[3], o[4], o[5]} - d_anchor));
-          const double a = is_dof ? -dot(n, dj) : 0.0;
-          if (MKH_TAP(t_coll_G) && is_dof) MKH_TAP(t_coll_G)[((size_t)pb * P.n_pairs + (int)o[12]) * nv + lane] = a;
-          return a;
-        };
-        int s = 0;
-        for (; s + 1 < nrows; s += 2) {
-          const double a0 = row_entry(s), a1 = row_entry(s + 1);
-          if (lane < AS) { sA[s * AS + lane] = a0; sA[(s + 1) * AS + lane] = a1; }
-        }
-        if (s < nrows) {
-          const double a0 = row_entry(s);
-          if (lane < AS) sA[s * AS + lane] = a0;
-        }
-      }
-    }
-    // caller-defined limits (Limit.compute_qp_inequalities, limits/limit.py:34-57): rows G·Δq ≤ h of this instance,
-    // appended to the half-space rows; h = +inf marks an inactive row
-    if (kDense && kColl && P.n_dense_limit_rows > 0) {
-      const int M = P.n_dense_limit_rows;
-      const double* dh = A.dense_h + (size_t)pb * M;
-      const double* dG = A.dense_G + (size_t)pb * M * nv;
-      const int first = nrows;
-      for (int base = 0; base < M; base += kWave) {
-        const int r = base + lane;
-        const double hr = r < M ? dh[r] : kInf;
-        const bool active = hr < kInf;
-        const unsigned long long am = __ballot(active);
-        const int slot = nrows + __popcll(am & ((1ull << lane) - 1ull));
-        if (active && slot < P.max_rows) {
-          double* o = sCol + slot * 16;
-          o[9] = hr;
-          o[12] = (double)r;
-        }
-        nrows += __popcll(am);
-      }
-      if (nrows > P.max_rows) { status |= 16; nrows = P.max_rows; }
-      wave_sync();
-      for (int s = first; s < nrows; ++s) {
-        const int r = (int)sCol[s * 16 + 12];
-        if (lane < AS) sA[s * AS + lane] = is_dof ? dG[(size_t)r * nv + lane] : 0.0;
-      }
-    }
+    if constexpr (!kCollFirst) collision_rows();
     if constexpr (!kWood) box_limits();
     wave_sync();
 
@@ -1939,7 +2068,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       });
     }
     if (!A.do_qp) break;
-    if (kColl && nrows > 0) {
+    if (kRows && nrows > 0) {
       // rows nv+s of the dof columns: one indexed register write per active row (a static_for over all NT
       // rows with a runtime range test cost 860 VALU instructions and 278 spilled SGPRs) ...
       for (int sr = 0; sr < nrows; ++sr) MKH_TAB<NT>::set_dyn(ts, nv + sr, is_dof ? sA[sr * AS + lane] : 0.0);
@@ -1953,7 +2082,6 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     // ====================================================================== QP
     // Dual active set (Goldfarb–Idnani) on the sweep tableau; see tools/proto_tableau_qp.py
     // for the numpy statement of the same algorithm.
-    constexpr bool kRows = kColl;                            // half-space rows exist only with collision limits
     QpLane s;
     s.sg = 1.0; s.usign = 0; s.ysign = 0; s.rsign = 0; s.sel = 0; s.elig = 0;
     s.D = is_dof ? hdiag : ((lane >= ntab) ? 1.0 : 0.0);   // true diagonal of K
@@ -2060,8 +2188,14 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     // accuracy (measured: 1e-6 instead of 1e-12 after ~100 pivots at cond(H) ≈ 1e5).  Then wrong-signed
     // multipliers are released one by one — the state becomes dual feasible — and Goldfarb–Idnani finishes from
     // there (tools/proto_bpp.py is the numpy statement and has the statistics).
-    bool need_gi = kRows;        // half-space rows: Goldfarb–Idnani only
-    if (!kRows && !(status & 14)) {
+    // With half-space rows (round 3): the same block steps on the BOX first, the rows passive — their slacks ride along in the
+    // updates like any nonbasic index — and Goldfarb–Idnani then adds the violated rows from a state that is dual feasible
+    // for the box (it used to do the ≈13 bound activations of a G1 solve itself: select, publish, ratio test, pivot each).
+    bool need_gi = kRows;        // half-space rows: always finish with Goldfarb–Idnani
+    // (in the builds of the plugin route: the collision builds' boxes are ConfigurationLimit rows that seldom bind, and the
+    //  block-step code costs them registers — 64_72: 0 → 38 spilled VGPRs)
+    constexpr bool kBoxSteps = !kRows || kDense;
+    if (kBoxSteps && !(status & 14)) {
       // Multipliers are sums of terms ≲ hmax·|Δq| ≈ hmax·1e-2: rounding noise ≈ 1e-16·hmax.  A bound dof whose
       // wrong-signed multiplier is below the threshold stays put (Δq error ≤ tolw / λ_min(H) ≈ 1e-12).
       const double tolw = 1e-16 * hmax;
@@ -2234,10 +2368,10 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     }
     // Δq of this dof: the free value when basic, else the bound it sits on
     const double zfin = s.usign ? s.x : (s.ysign ? s.hi : s.lo);
-    if (!kColl && (kSteps || A.warm)) prev_bound = (is_dof && !s.usign) ? (s.ysign ? 2 : 1) : 0;
+    if (!kRows && (kSteps || A.warm)) prev_bound = (is_dof && !s.usign) ? (s.ysign ? 2 : 1) : 0;
     MKH_MARK("qp_done");
     MKH_TICK();   // 7: QP done
-    if (MKH_TAP(t_cycles) && lane < 16) {
+    if (MKH_CLK && lane < 16) {
       long long x = tc[0];
 #pragma unroll
       for (int i = 1; i < 8; ++i) x = (lane == i) ? tc[i] : x;
@@ -2245,40 +2379,16 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       for (int i = 0; i < 6; ++i) x = (lane == 8 + i) ? ta[i] : x;
       if (lane == 14) x = tj;
       if (lane == 15) x = 0;
-      MKH_TAP(t_cycles)[(size_t)pb * 16 + lane] = x;
+      MKH_CLK[(size_t)pb * 16 + lane] = x;
     }
     if (MKH_TAP(t_qp_iters) && lane == 0) MKH_TAP(t_qp_iters)[pb] = (kRows ? iters : n_piv) | (n_loop << 10) | (n_piv << 20);
     if (kColl && rows_dropped && !(status & 14)) {
-      // the contacts that found no tableau row: G·Δq ≤ h at the solution?  (G·Δq = −nᵀ(ṗ₂(to) − ṗ₁(from)) for joint
-      // displacements Δq, the dofs of each geom's chain only)
+      // the contacts that found no tableau row: G·Δq ≤ h at the solution?  (collision_phase, mode 1)
       wave_sync();
       if (is_dof) sDof[lane * 10 + 9] = zfin;                  // (slot 9 = q is dead now)
       wave_sync();
-      bool viol = false;
-      for (int base = 0; base < P.n_pairs; base += 64) {
-        const int pi = base + lane;
-        if (pi < P.n_pairs) {
-          const double hs = sH[pi];
-          if (hs < kInf && rank_of(pi, hs) >= P.max_rows) {
-            double hk;
-            V3 nrm{1, 0, 0}, from{0, 0, 0}, to{0, 0, 0};
-            uint64_t m1 = 0, m2 = 0;
-            if (contact_of(pi, hk, nrm, from, to, m1, m2)) {
-              V3 vel{0, 0, 0};
-              for (uint64_t mm = m1 | m2; mm; mm &= mm - 1) {
-                const int d = __builtin_ctzll(mm);
-                const double* dd = sDof + d * 10;
-                const V3 a_ang{dd[0], dd[1], dd[2]}, a_lin{dd[3], dd[4], dd[5]}, a_anchor{dd[6], dd[7], dd[8]};
-                const double dq = dd[9];
-                if ((m2 >> d) & 1) vel = vel + dq * (a_lin + cross(a_ang, to - a_anchor));
-                if ((m1 >> d) & 1) vel = vel - dq * (a_lin + cross(a_ang, from - a_anchor));
-              }
-              viol = viol || (-dot(nrm, vel) > hk + 1e-9 * (1.0 + fabs(hk)));
-            }
-          }
-        }
-      }
-      if (__ballot(viol)) status |= 16;
+      if (collision_phase(Pq, tp, pb, A.dt, 1, L)) status |= 16;
+      asm volatile("" : "+v"(lane));
     }
     status_all |= status;
     const bool last = until || (step + 1 == n_steps) || (status & 14);   // (until: v of every step — the loop may end at the next check)
@@ -2323,7 +2433,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       if (A.iters_out) A.iters_out[pb] = it_done;
       if (A.converged_out) A.converged_out[pb] = conv_flag;
     }
-    if (!kColl && A.warm && lane < nv) A.warm[(size_t)pb * nv + lane] = (int8_t)((status_all & 14) ? 0 : prev_bound);
+    if (!kRows && A.warm && lane < nv) A.warm[(size_t)pb * nv + lane] = (int8_t)((status_all & 14) ? 0 : prev_bound);
     if (A.status_out && lane == 0) A.status_out[pb] = status_all;
     sq = (sq == smem + L.q) ? smem + L.q2 : smem + L.q;           // the next problem's rows are (being) fetched there
     sTgt = (sTgt == smem + L.tgt) ? smem + L.tgt2 : smem + L.tgt;

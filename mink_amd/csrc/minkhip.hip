@@ -103,6 +103,7 @@ struct MkhProblem {
   DeviceProblem* d_dev = nullptr;   // device copy of `dev` (the kernel reads the descriptor from memory)
   TapArgs* d_taps = nullptr;
   int last_grid = 0, last_lds = 0, last_nt = 0;   // geometry of the most recent launch (mkh_problem_launch_info)
+  long long* d_clk = nullptr;      // MKH_DEBUG_CLOCKS (experiment builds): cycle stamps of the last launch
   int8_t* d_warm = nullptr;        // MKH_FLAG_WARM_START: active set of every instance after the previous solve (max_batch × nv)
   int warm_age = 0, warm_B = 0;    // solves since the state was reset / the batch size it belongs to
   uint32_t* d_work = nullptr;      // ticket counter of the dynamic problem distribution (zeroed by the kernel's last draw)
@@ -790,7 +791,7 @@ void mkh_problem_destroy(MkhProblem* p) {
   (void)hipFree(p->d_vel); (void)hipFree(p->d_pairs); (void)hipFree(p->d_dev); (void)hipFree(p->d_taps); (void)hipFree(p->d_work);
   (void)hipFree(p->d_lane); (void)hipFree(p->d_warm);
   (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain); (void)hipFree(p->s_iters);
-  (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh); (void)hipFree(p->s_dbox);
+  (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh); (void)hipFree(p->s_dbox); (void)hipFree(p->d_clk);
   (void)hipFree(p->s_q); (void)hipFree(p->s_ft); (void)hipFree(p->s_pt); (void)hipFree(p->s_ct); (void)hipFree(p->s_v); (void)hipFree(p->s_status);
   if (p->st_in) (void)hipStreamDestroy(p->st_in);
   if (p->st_out) (void)hipStreamDestroy(p->st_out);
@@ -865,6 +866,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   if (dense) need |= 64;                                              // plugin rows: only the all-feature variants have them
   int feat;
   if (need == 0) feat = 0;
+  else if (need == 64) feat = F_DENSE;                                // plugin rows next to frame / posture tasks and box limits: lean build
   else if (need == F_STEPS) feat = F_STEPS;
   else if (need == F_COLL) feat = p->simple_pairs ? (F_COLL | F_SIMPLE_COLL) : (p->convex_pairs ? (F_COLL | F_CONVEX_COLL) : F_COLL);
   // (fused loops over capsule-only collision sets — the Shadow hand's closed loop — have a build of their own: the
@@ -909,9 +911,23 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   const int per_wave = a.B / grid;
   const bool dynamic = nt > 8 && per_wave >= 4;
   al.static_rounds = dynamic ? (per_wave * 7) / 8 : INT32_MAX;
+  // Experiment builds with -DMKH_CLOCKS (tools/phase_clocks.py): MKH_DEBUG_CLOCKS=<file> makes every launch of this process
+  // synchronous and writes its (B, 16) cycle stamps to <file> — phase profile of kernels that cannot be tapped
+  static const char* const clk_path = getenv("MKH_DEBUG_CLOCKS");
+  if (clk_path) {
+    if (!p->d_clk) HIP_OK(hipMalloc((void**)&p->d_clk, (size_t)p->max_batch * 16 * sizeof(long long)));
+    HIP_OK(hipMemsetAsync(p->d_clk, 0, (size_t)a.B * 16 * sizeof(long long), stream));
+    al.clk = p->d_clk;
+  }
   if (mkh::launch_variant(nt, nr, feat, w3, grid, lds, stream, p->d_dev, al, dtaps) != 0)
     return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
   HIP_OK(hipGetLastError());
+  if (clk_path) {
+    std::vector<long long> h((size_t)a.B * 16);
+    HIP_OK(hipMemcpyAsync(h.data(), p->d_clk, h.size() * sizeof(long long), hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    if (FILE* f = fopen(clk_path, "wb")) { fwrite(h.data(), sizeof(long long), h.size(), f); fclose(f); }
+  }
   return MKH_OK;
 }
 

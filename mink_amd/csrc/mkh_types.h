@@ -158,6 +158,9 @@ struct SolveArgs {
   // state is at least two solves old and written at its end; nullptr = cold
   int8_t* warm;                    // (B, nv)
   int32_t warm_age;
+  // cycle stamps of every problem, (B, 16) as the `cycles` tap — read only by kernels compiled with -DMKH_CLOCKS (experiment
+  // builds, tools/phase_clocks.py); nullptr otherwise
+  long long* clk;
 };
 
 // Debug/parity taps (nullable pointers).  Lives in device memory and is passed by pointer so

@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Per-phase shader-clock breakdown of the PRODUCTION kernels (no taps): needs an experiment build of the library compiled
+with -DMKH_CLOCKS, in which every variant stamps its phase boundaries into SolveArgs::clk.  GPU only.
+
+    MKH_BUILD_TAG=clk MKH_EXTRA_FLAGS=-DMKH_CLOCKS python -m mink_amd.csrc.build      # (build container)
+    MKH_LIB_TAG=clk python tools/phase_clocks.py g1_c3 [shadow_c4 ur5e_c2:4096 ...]   # (GPU box)
+
+The stamps cost a few s_memtime + one store per problem; phases inside real callees (MKH_CALLS builds: FK, axes, task lanes)
+are lumped into the first interval."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+path = os.path.join(tempfile.gettempdir(), "mkh_clocks.bin")
+os.environ["MKH_DEBUG_CLOCKS"] = path
+
+import torch  # noqa: E402
+
+from mink_amd import _native as nat  # noqa: E402
+from mink_amd import workloads  # noqa: E402
+
+NAMES = ["load+FK", "axes/dof/com", "task lanes", "posture+coll+J cols", "limits", "build T + phase 0", "active set"]
+
+
+def run(name, B=None):
+    cfg = workloads.BENCH_CONFIGS[name]
+    B = B or cfg["batch"]
+    model = workloads.load_bench_robot(name)
+    nm = nat.NativeModel(model)
+    prob, dt, damping = workloads.bench_config(name, model, nm, B)
+    rng = np.random.default_rng(0)
+    q, tg, pt, ct = workloads.bench_batch(name, model, nm, prob, rng, B)
+    dense = workloads.bench_dense(name, model, nm, q, rng)
+    dev = torch.device("cuda", 0)
+    to = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    args = (to(q), to(tg), to(pt if prob.n_posture else None), to(ct), dt, damping)
+    dn = None if dense is None else {k: to(x) for k, x in dense.items()}
+    for _ in range(3):
+        prob.solve(*args, dense=dn)
+    torch.cuda.synchronize()
+    c = np.fromfile(path, dtype=np.int64).reshape(-1, 16)[:B]
+    ok = c[:, 0] != 0
+    c = c[ok]
+    tot = c[:, 7] - c[:, 0]
+    print(f"{name} B={B} kernel {prob.last_kernel()} launch {prob.launch_info(B)}")
+    print("  per-problem wave cycles: mean %.0f  p50 %.0f  p99 %.0f  max %d   (%d problems stamped)" % (
+        tot.mean(), np.median(tot), np.percentile(tot, 99), tot.max(), len(c)))
+    st = c[:, :8].copy()
+    for k in range(1, 8):                       # stamps a callee build never wrote: carry the previous one
+        z = st[:, k] == 0
+        st[z, k] = st[z, k - 1]
+    d = np.diff(st, axis=1)
+    for k, n in enumerate(NAMES):
+        print("    %-22s mean %8.0f  (%4.1f%%)" % (n, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean()))
+    sub = ["phase-0 publish", "phase-0 rcp+pivot", "GI select", "flip/GI publish", "flip/GI ratio test", "flip/GI pivot"]
+    if "_r" in prob.last_kernel():
+        sub = ["low-rank: J rows", "low-rank: S, w", "low-rank: elimination", "low-rank: rank-1 dof block (+publish)", "ratio test", "pivot"]
+    for k, n in enumerate(sub):
+        print("      %-36s mean %8.0f" % (n, c[:, 8 + k].mean()))
+    prob.close()
+
+
+if __name__ == "__main__":
+    for a in sys.argv[1:] or ["g1_c3"]:
+        n, _, b = a.partition(":")
+        run(n, int(b) if b else None)
