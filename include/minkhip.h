@@ -98,6 +98,15 @@ typedef struct MkhFlatModel {
   const double *site_pos /*nsite*3*/, *site_quat /*nsite*4*/;
   const int32_t *geom_bodyid, *geom_type;
   const double *geom_size /*ngeom*3*/, *geom_pos /*ngeom*3*/, *geom_quat /*ngeom*4*/;
+  /* Mesh geoms (mjGEOM_MESH = 7) as mj_geomDistance sees them: their CONVEX HULL.  geom_dataid[g] = mesh of geom g (−1: not
+   * a mesh geom); the hull vertices of mesh k, in the geom frame (the compiler re-expresses a mesh in its inertial frame and
+   * folds that frame into geom_pos / geom_quat), are mesh_vert[3·mesh_vertadr[k] …), mesh_vertnum[k] of them — MuJoCo's
+   * field names; from a real MjModel: the vertices mesh_graph lists (FlatModel.from_mjmodel).  nmesh = 0 / NULL pointers:
+   * a model without mesh geoms.  A primitive FITTED to a mesh (<geom type="capsule" mesh=…>) is an ordinary primitive
+   * here: its compiled geom_size / geom_pos / geom_quat say everything. */
+  int32_t nmesh, nmeshvert;
+  const int32_t *geom_dataid /*ngeom*/, *mesh_vertadr /*nmesh*/, *mesh_vertnum /*nmesh*/;
+  const double *mesh_vert /*nmeshvert*3*/;
 } MkhFlatModel;
 
 /* mink.FrameTask(frame_name, frame_type, position_cost, orientation_cost, gain, lm_damping)
@@ -149,8 +158,20 @@ typedef struct MkhVelocityLimitDesc {
  * Distance routines behind mj_geomDistance (:219): analytic for plane/sphere/capsule among themselves, box against
  * plane/sphere/capsule/box, cylinder against plane/sphere/capsule, plane–ellipsoid; every other pair of the convex
  * primitives sphere / capsule / ellipsoid / cylinder / box (cylinder–box, cylinder–cylinder, ellipsoid–*) through a
- * general convex distance routine (GJK on support mappings — MuJoCo uses libccd there).  Mesh and height-field geoms
- * fail mkh_problem_create with MKH_E_INVALID. */
+ * general convex distance routine (GJK on support mappings — MuJoCo uses libccd there).  A MESH geom takes part through its
+ * convex hull (MkhFlatModel.mesh_vert): plane–mesh analytically (the hull's lowest vertex), mesh against any primitive or
+ * mesh through the general convex routine with the hull's vertices as the support mapping.  Height fields — and mesh geoms
+ * of a model that carries no hull for them — fail mkh_problem_create with MKH_E_INVALID.
+ *
+ * Two places where the contact differs from mujoco 3.1.6's by construction (no test against the wheel can exist here):
+ *  (i) TIES.  Where the closest pair of points is not unique — a capsule parallel to a box face, face-to-face boxes —
+ *      MuJoCo returns several contacts of equal distance and mj_geomDistance keeps the first; the routines here return the
+ *      MIDPOINT of the flat stretch of closest points (capsule ∥ face, ∥ capsules) or the centre of the overlap of the two
+ *      faces (box–box).  The distance h is the same; the witness points feed mj_jac, so the row of G differs by the lever arm
+ *      between the two choices.  tests/test_gpu_collision_shapes.py::test_tie_rule_is_pinned holds the rule in place.
+ *  (ii) GENERAL CONVEX PAIRS.  The nine primitive pair types without an analytic routine, and every mesh pair, get the exact
+ *      Euclidean distance of the two convex sets (GJK, ~1e-13) where MuJoCo answers with libccd's MPR on shapes inflated by
+ *      half the margin each, to a tolerance of 1e-6: h agrees to that tolerance, not to 1e-9. */
 typedef struct MkhCollisionLimitDesc {
   int32_t n_pairs;
   const int32_t *geom_id_pairs /*n_pairs*2*/;

@@ -46,6 +46,9 @@ class MkhFlatModel(C.Structure):
         + [(n, _pd) for n in ("site_pos", "site_quat")]
         + [(n, _pi) for n in ("geom_bodyid", "geom_type")]
         + [(n, _pd) for n in ("geom_size", "geom_pos", "geom_quat")]
+        + [("nmesh", C.c_int32), ("nmeshvert", C.c_int32)]
+        + [(n, _pi) for n in ("geom_dataid", "mesh_vertadr", "mesh_vertnum")]
+        + [("mesh_vert", _pd)]
     )
 
 
@@ -221,7 +224,11 @@ class NativeModel:
         fm = MkhFlatModel()
         for n in ("nq", "nv", "nbody", "njnt", "ngeom", "nsite"):
             setattr(fm, n, int(getattr(m, n)))
+        fm.nmesh = int(len(m.mesh_vertnum))
+        fm.nmeshvert = int(len(m.mesh_vert))
         for n, ctype in MkhFlatModel._fields_[6:]:
+            if n in ("nmesh", "nmeshvert"):
+                continue
             arr = getattr(m, n)
             arr = _i32(arr) if ctype is _pi else _f64(arr)
             if arr.size == 0:

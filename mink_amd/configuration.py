@@ -129,7 +129,7 @@ class Configuration:
         fid = self.model.name2id(frame_type, frame_name)
         if fid == -1:
             raise exceptions.InvalidFrame(frame_name=frame_name, frame_type=frame_type, model=self.model)
-        if frame_type == "geom" and not self.model.geom_valid[fid]:
+        if frame_type == "geom" and self.model.geom_valid[fid] != 1:     # (2: a mesh-derived frame of the MJCF reader, see mjcf.py)
             # primitive fitted to a mesh (type="capsule" mesh=...): its frame comes from the mesh asset, which the
             # MJCF subset reader does not have — refuse rather than report a pose computed from placeholder values
             raise exceptions.InvalidFrame(frame_name=frame_name, frame_type=frame_type, model=self.model,

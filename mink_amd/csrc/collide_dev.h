@@ -14,7 +14,7 @@
 
 namespace mkh {
 
-enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_ELLIPSOID = 4, GEOM_CYLINDER = 5, GEOM_BOX = 6 };
+enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_ELLIPSOID = 4, GEOM_CYLINDER = 5, GEOM_BOX = 6, GEOM_MESH = 7 };
 
 struct Contact { double dist; V3 pos; V3 n; bool hit; };
 
@@ -347,12 +347,15 @@ __device__ __forceinline__ Contact to_world(Contact k, const M3& R, V3 o) {
 // general convex routine of convex_dev.h is compiled in (its own kernel variants: it costs registers and scratch).
 template <bool SIMPLE = false, bool CONVEX = false>
 __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t2, V3 s2, V3 p2, Q4 q2,
-                                              double distmax, double& dist, V3& from, V3& to) {
+                                              double distmax, double& dist, V3& from, V3& to,
+                                              const double* hv1 = nullptr, int hn1 = 0, const double* hv2 = nullptr, int hn2 = 0) {
+  // hv / hn: hull vertices (geom frame) of a mesh geom
   const bool flip = t1 > t2;
   if (flip) {
     int ti = t1; t1 = t2; t2 = ti;
     V3 tv = s1; s1 = s2; s2 = tv; tv = p1; p1 = p2; p2 = tv;
     Q4 tq = q1; q1 = q2; q2 = tq;
+    const double* th = hv1; hv1 = hv2; hv2 = th; ti = hn1; hn1 = hn2; hn2 = ti;
   }
   M3 R1 = qmat(q1), R2 = qmat(q2);
   V3 z1{R1.m[2], R1.m[5], R1.m[8]}, z2{R2.m[2], R2.m[5], R2.m[8]};
@@ -397,8 +400,13 @@ __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t
     const V3 e = vmulc(s2, mulT(R2, z1));
     const V3 pt = p2 - (1.0 / sqrt(dot(e, e))) * mul(R2, vmulc(s2, e));
     c.dist = dot(z1, pt - p1); c.hit = c.dist <= distmax; c.n = z1; c.pos = pt - (0.5 * c.dist) * z1;
-  } else if (CONVEX && t1 >= GEOM_SPHERE && t1 <= GEOM_BOX && t2 >= GEOM_SPHERE && t2 <= GEOM_BOX) {
-    const ConvexGeom g1{t1, s1, p1, R1}, g2{t2, s2, p2, R2};
+  } else if (CONVEX && t1 == GEOM_PLANE && t2 == GEOM_MESH) {
+    // lowest point of the hull: its support point against the plane normal (mjc_PlaneConvex keeps the deepest vertex)
+    const ConvexGeom g2{t2, s2, p2, R2, hv2, hn2};
+    const V3 pt = cvx_support(g2, -1.0 * z1);
+    c.dist = dot(z1, pt - p1); c.hit = c.dist <= distmax; c.n = z1; c.pos = pt - (0.5 * c.dist) * z1;
+  } else if (CONVEX && t1 >= GEOM_SPHERE && t1 <= GEOM_MESH && t2 >= GEOM_SPHERE && t2 <= GEOM_MESH) {
+    const ConvexGeom g1{t1, s1, p1, R1, hv1, hn1}, g2{t2, s2, p2, R2, hv2, hn2};
     c.hit = cvx_distance(g1, g2, distmax, c.dist, c.pos, c.n);
   } else {
     dist = distmax; from = {0, 0, 0}; to = {0, 0, 0};

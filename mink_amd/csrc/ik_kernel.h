@@ -79,13 +79,13 @@ constexpr int kPivBuf = kWave + 8;   // doubles per pivot broadcast buffer
 constexpr int kMu = 18, kMuBig = 24; // low-rank start: compiled capacities of task-residual rows of one problem (WoodElim in tab_asm.inc)
 constexpr int kWoodRow = 64;         // low-rank start: doubles of the published-row buffer — (S[r][c], w_c) pairs — in the pivot buffers, followed by 1/d_r
 struct LdsLayout {
-  int q, X, jnt, tgt, task, J, dof, com, col, A, piv, S, q2, tgt2, total;  // offsets in doubles
+  int q, X, jnt, tgt, task, J, dof, com, col, A, piv, S, q2, tgt2, hsel, total;  // offsets in doubles
 };
 __host__ __device__ inline int lds_even(int x) { return (x + 1) & ~1; }
 __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int njnt, int n_frame,
                                                 int n_posture, int n_com, int max_rows, int j_rows, int j_stride,
                                                 int s_doubles = 0, bool prefetch = false, bool compact = false,
-                                                bool wood = false) {
+                                                bool wood = false, int n_hsel = 0) {
   LdsLayout L;
   int o = 0;
   const int x_sz = 7 * lds_even(nbody), jnt_sz = lds_even(njnt * 6);
@@ -124,6 +124,9 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
   // (only when the host found that they do not cost a resident wave: DeviceProblem::prefetch)
   L.q2 = prefetch ? o : L.q;     o += prefetch ? lds_even(nq) : 0;
   L.tgt2 = prefetch ? o : L.tgt; o += prefetch ? lds_even(n_frame * 7 + n_com * 3) : 0;
+  // more collision pairs than tableau rows: h of EVERY pair, for the selection of the tightest rows and the check of the
+  // dropped ones at the solution (collision_phase) — the ALOHA pair set of the reference is 1 104 pairs for 48 rows
+  L.hsel = o; o += lds_even(n_hsel);
   L.total = o;
   return L;
 }
@@ -373,7 +376,7 @@ struct PreView {
   const MKH_GLOBAL double *body_f, *jnt_f, *dof_f;
   const MKH_GLOBAL int32_t *body_i, *jnt_i, *dof_i;
   const MKH_GLOBAL FrameTaskDev* frame;
-  int nbody, nv, nq, njnt, n_frame, n_posture, n_com, max_rows, n_jrows, prefetch, prefetch_w3, prefetch_w3w, wood_compact, prefetch_wc, n_rows_tap, nrounds, robot_root;
+  int nbody, nv, nq, njnt, n_frame, n_posture, n_com, max_rows, n_jrows, prefetch, prefetch_w3, prefetch_w3w, wood_compact, prefetch_wc, n_rows_tap, nrounds, robot_root, n_hsel;
   __device__ __forceinline__ explicit PreView(const DeviceProblem* Pq) {
     const MKH_CONSTANT DeviceProblem* c = (const MKH_CONSTANT DeviceProblem*)Pq;
     body_f = (const MKH_GLOBAL double*)c->body_f; jnt_f = (const MKH_GLOBAL double*)c->jnt_f; dof_f = (const MKH_GLOBAL double*)c->dof_f;
@@ -382,7 +385,7 @@ struct PreView {
     nbody = c->nbody; nv = c->nv; nq = c->nq; njnt = c->njnt; n_frame = c->n_frame; n_posture = c->n_posture; n_com = c->n_com;
     max_rows = c->max_rows; n_jrows = c->n_jrows; prefetch = c->prefetch; prefetch_w3 = c->prefetch_w3; prefetch_w3w = c->prefetch_w3w;
     wood_compact = c->wood_compact; prefetch_wc = c->prefetch_wc;
-    n_rows_tap = c->n_rows_tap; nrounds = c->nrounds; robot_root = c->robot_root;
+    n_rows_tap = c->n_rows_tap; nrounds = c->nrounds; robot_root = c->robot_root; n_hsel = c->n_hsel;
   }
 };
 // second LDS buffers for the next problem's inputs: decided on the host per LDS layout (only where they cost no resident wave)
@@ -413,7 +416,7 @@ __device__ __forceinline__ LdsLayout kernel_lds_layout(const PT& P0) {
                     kWood ? P0.n_jrows + 1 : 6, kWood ? NR : j_stride_direct(P0.nv, NT),
                     (kWood && !wood_s_aliases_dof(P0.nv, P0.n_jrows, lds_even(P0.n_jrows), P0.n_com > 0 ? P0.nbody : 0))
                         ? P0.n_jrows * (lds_even(P0.n_jrows) + 1) : 0,
-                    kernel_prefetch(P0), kCompact || (kWood && P0.wood_compact != 0), kWood);
+                    kernel_prefetch(P0), kCompact || (kWood && P0.wood_compact != 0), kWood, P0.n_hsel);
 }
 __device__ MKH_PRE_ATTR PreOut pre_phases(const DeviceProblem* Pq, const TapArgs* tp, int pb, int oz, int off_q, int off_tgt,
                                           bool until, double pos_thr, double ori_thr MKH_PRE_TC_PARAMS) {
@@ -1294,8 +1297,8 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
   // (collision_avoidance_limit.py:187-210); here the max_rows TIGHTEST (smallest h, ties by pair index) become rows and
   // the solution is checked against the rest after the QP — a dropped row that holds at the solution was inactive, so
   // the result is the reference's; one that does not hold sets MKH_ST_ROW_OVERFLOW.
-  double* const sH = smem + L.jnt;                          // h of every pair (the joint axes are dead once the dof stash is written)
-  const bool can_select = n_pairs > max_rows && n_pairs <= lds_even(P.njnt * 6);
+  double* const sH = smem + L.hsel;                         // h of every pair (only laid out when n_pairs > max_rows)
+  const bool can_select = n_pairs > max_rows;
   // contact of pair pi at the current poses: active, h, unit normal, witness points, dof chains
   auto contact_of = [&](int pi, double& hk, V3& nrm, V3& from, V3& to, uint64_t& m1, uint64_t& m2) -> bool {
     const auto& cp = pairs[pi];
@@ -1308,7 +1311,8 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
     Q4 gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
     double dist;
     geom_distance<kSimpleColl, kConvexColl>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
-                  V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to);
+                  V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to,
+                  cp.vert1, cp.nvert1, cp.vert2, cp.nvert2);
     const bool active = dist != cp.ddetect;                  // Contact.inactive (:52-56)
     hk = kInf;
     if (active) {
@@ -1374,6 +1378,20 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
         if (pass == 0) {
           if (can_select) sH[pi] = hk;
           if (MKH_TAP(t_coll_h)) MKH_TAP(t_coll_h)[(size_t)pb * n_pairs + pi] = hk;
+          if (MKH_TAP(t_coll_G) && active) {
+            // the tap holds the row of EVERY detected contact (Limit.compute_qp_inequalities / build_ik return them all),
+            // also of those that find no tableau row below: the pair lane walks its two dof chains itself
+            double* g = MKH_TAP(t_coll_G) + ((size_t)pb * n_pairs + pi) * nv;
+            for (uint64_t mm = m1 | m2; mm; mm &= mm - 1) {
+              const int d = __builtin_ctzll(mm);
+              const double* dd = sDof + d * 10;
+              const V3 a_ang{dd[0], dd[1], dd[2]}, a_lin{dd[3], dd[4], dd[5]}, a_anchor{dd[6], dd[7], dd[8]};
+              V3 dj{0, 0, 0};
+              if ((m2 >> d) & 1) dj = dj + a_lin + cross(a_ang, to - a_anchor);
+              if ((m1 >> d) & 1) dj = dj - (a_lin + cross(a_ang, from - a_anchor));
+              g[d] = -dot(nrm, dj);
+            }
+          }
         } else if (active) {
           active = rank_of(pi, hk) < max_rows;
         }
@@ -1408,7 +1426,6 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
       if ((m2 >> lane) & 1) dj = dj + d_lin + cross(d_ang, V3{o[6], o[7], o[8]} - d_anchor);
       if ((m1 >> lane) & 1) dj = dj - (d_lin + cross(d_ang, V3{o[3], o[4], o[5]} - d_anchor));
       const double a = is_dof ? -dot(n, dj) : 0.0;
-      if (MKH_TAP(t_coll_G) && is_dof) MKH_TAP(t_coll_G)[((size_t)pb * n_pairs + (int)o[12]) * nv + lane] = a;
       return a;
     };
     int s = 0;

@@ -57,6 +57,8 @@ struct MkhModel {
   std::vector<int32_t> dof_bodyid, dof_jntid, dof_parentid, site_bodyid, geom_bodyid, geom_type;
   std::vector<double> body_pos, body_quat, site_pos, site_quat, geom_size, geom_pos, geom_quat, jnt_range;
   std::vector<double> jnt_pos, jnt_axis, jnt_qpos0;   // (per joint; qpos0 at the joint's first qpos address)
+  std::vector<int32_t> geom_dataid, mesh_vertadr, mesh_vertnum;   // mesh geoms: hull vertices (geom frame) in d_mesh_vert
+  double* d_mesh_vert = nullptr;
   // device tables
   double* d_body_f = nullptr;
   int32_t* d_body_i = nullptr;
@@ -301,6 +303,20 @@ int32_t mkh_model_create(const MkhFlatModel* h, int32_t device, MkhModel** out) 
   m->site_pos = cpd(h->site_pos, h->nsite * 3); m->site_quat = cpd(h->site_quat, h->nsite * 4);
   m->geom_size = cpd(h->geom_size, h->ngeom * 3); m->geom_pos = cpd(h->geom_pos, h->ngeom * 3);
   m->geom_quat = cpd(h->geom_quat, h->ngeom * 4);
+  m->geom_dataid.assign(h->ngeom, -1);
+  if (h->nmesh > 0) {
+    if (!h->geom_dataid || !h->mesh_vertadr || !h->mesh_vertnum || !h->mesh_vert || h->nmeshvert < 1) {
+      delete m; return fail(MKH_E_INVALID, "nmesh = %d but a mesh array is null", h->nmesh);
+    }
+    m->geom_dataid = cpi(h->geom_dataid, h->ngeom);
+    m->mesh_vertadr = cpi(h->mesh_vertadr, h->nmesh); m->mesh_vertnum = cpi(h->mesh_vertnum, h->nmesh);
+    for (int k = 0; k < h->nmesh; ++k)
+      if (m->mesh_vertadr[k] < 0 || m->mesh_vertnum[k] < 1 || m->mesh_vertadr[k] + m->mesh_vertnum[k] > h->nmeshvert) {
+        delete m; return fail(MKH_E_INVALID, "mesh %d: vertex range out of bounds", k);
+      }
+    for (int g = 0; g < h->ngeom; ++g)
+      if (m->geom_dataid[g] >= h->nmesh) { delete m; return fail(MKH_E_INVALID, "geom %d: mesh id out of range", g); }
+  }
 
   const double inf = std::numeric_limits<double>::infinity();
   // ---- body tables
@@ -405,6 +421,7 @@ int32_t mkh_model_create(const MkhFlatModel* h, int32_t device, MkhModel** out) 
   if (e == hipSuccess) e = upload(dof_f, &m->d_dof_f);
   hipDeviceProp_t prop;
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+  if (e == hipSuccess && h->nmesh > 0) e = upload(std::vector<double>(h->mesh_vert, h->mesh_vert + (size_t)h->nmeshvert * 3), &m->d_mesh_vert);
   if (e != hipSuccess) { mkh_model_destroy(m); return fail(MKH_E_HIP, "model upload: %s", hipGetErrorString(e)); }
   m->num_cus = prop.multiProcessorCount;
   *out = m;
@@ -415,7 +432,7 @@ void mkh_model_destroy(MkhModel* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   (void)hipFree(m->d_body_f); (void)hipFree(m->d_body_i); (void)hipFree(m->d_jnt_f); (void)hipFree(m->d_jnt_i);
-  (void)hipFree(m->d_dof_i); (void)hipFree(m->d_dof_f);
+  (void)hipFree(m->d_dof_i); (void)hipFree(m->d_dof_f); (void)hipFree(m->d_mesh_vert);
   delete m;
 }
 
@@ -580,14 +597,24 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       };
       // ... and the ones that go through the general convex routine (convex_dev.h): cylinder–box, cylinder–cylinder,
       // ellipsoid against any primitive
+      // ellipsoid against any primitive, and every pair with a mesh geom (its hull: plane–mesh analytically)
       auto convex = [](int a, int b) {
         if (a > b) { int x = a; a = b; b = x; }
-        const bool cb = b == GEOM_SPHERE || b == GEOM_CAPSULE || b == GEOM_ELLIPSOID || b == GEOM_CYLINDER || b == GEOM_BOX;
-        return cb && (a == GEOM_PLANE ? b == GEOM_ELLIPSOID : (a >= GEOM_SPHERE && a <= GEOM_BOX));
+        const bool cb = b == GEOM_SPHERE || b == GEOM_CAPSULE || b == GEOM_ELLIPSOID || b == GEOM_CYLINDER || b == GEOM_BOX || b == GEOM_MESH;
+        return cb && (a == GEOM_PLANE ? (b == GEOM_ELLIPSOID || b == GEOM_MESH) : (a >= GEOM_SPHERE && a <= GEOM_MESH));
       };
       auto supported = [&](int a, int b) { return analytic(a, b) || convex(a, b); };
       if (!analytic(t1, t2) && convex(t1, t2)) p->convex_pairs = true;
-      if (!supported(t1, t2)) return bail(fail(MKH_E_INVALID, "collision pair (%d,%d): geom types (%d,%d) are not supported (meshes, height fields)", g1, g2, t1, t2));
+      if (!supported(t1, t2)) return bail(fail(MKH_E_INVALID, "collision pair (%d,%d): geom types (%d,%d) are not supported (height fields)", g1, g2, t1, t2));
+      for (int side = 0; side < 2; ++side) {
+        const int g = side ? g2 : g1;
+        if (m->geom_type[g] != GEOM_MESH) continue;
+        const int k = m->geom_dataid[g];
+        if (k < 0 || !m->d_mesh_vert)
+          return bail(fail(MKH_E_INVALID, "collision pair (%d,%d): mesh geom %d has no hull in the model (geom_dataid / mesh_vert)", g1, g2, g));
+        (side ? cp.vert2 : cp.vert1) = m->d_mesh_vert + 3 * (size_t)m->mesh_vertadr[k];
+        (side ? cp.nvert2 : cp.nvert1) = m->mesh_vertnum[k];
+      }
       cp.type1 = t1; cp.type2 = t2; cp.body1 = m->geom_bodyid[g1]; cp.body2 = m->geom_bodyid[g2];
       for (int i = 0; i < 3; ++i) { cp.size1[i] = m->geom_size[3 * g1 + i]; cp.size2[i] = m->geom_size[3 * g2 + i];
                                     cp.lpos1[i] = m->geom_pos[3 * g1 + i]; cp.lpos2[i] = m->geom_pos[3 * g2 + i]; }
@@ -606,6 +633,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   {
     const int want = P.n_pairs + P.n_dense_limit_rows;          // half-space rows that can be active at once
     P.max_rows = want < (kWave - m->nv) ? want : (kWave - m->nv);
+    P.n_hsel = P.n_pairs > P.max_rows ? P.n_pairs : 0;
   }
   const int ntab = m->nv + P.max_rows;
   {
@@ -633,7 +661,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   // Second LDS buffers for the next problem's inputs (ik_kernel.h "load inputs") only where they do not cost a
   // resident wave in the lean or the all-feature variant of this problem (the low-rank variant is checked below).
   auto lds_of = [&](int nt, bool pre) {
-    return lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, j_stride_direct(P.nv, nt), 0, pre).total *
+    return lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, j_stride_direct(P.nv, nt), 0, pre, false, false, P.n_hsel).total *
            (int)sizeof(double);
   };
   P.prefetch = (waves_per_cu(p->nt, lds_of(p->nt, true)) == waves_per_cu(p->nt, lds_of(p->nt, false)) &&

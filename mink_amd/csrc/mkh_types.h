@@ -60,6 +60,10 @@ struct CollisionPairDev {
   double lquat1[4], lquat2[4];
   uint64_t mask1, mask2;
   double gain, dmin, ddetect, relax;
+  // mesh geoms: hull vertices in the geom frame (device memory of the model, 3 doubles each); nullptr / 0 for primitives
+  const double* vert1;
+  const double* vert2;
+  int32_t nvert1, nvert2;
 };
 
 struct DeviceProblem {
@@ -67,6 +71,7 @@ struct DeviceProblem {
   int32_t nq, nv, nbody, njnt, nrounds;
   int32_t n_frame, n_posture, n_com, n_cfg, n_vel, n_pairs, n_rows_tap;
   int32_t max_rows;      // tableau rows reserved for half-spaces (ntab = nv + max_rows)
+  int32_t n_hsel;        // n_pairs when there are more pairs than rows (LDS for the h of every pair: row selection), else 0
   int32_t n_jrows;       // weighted Jacobian rows staged in LDS (Σ nonzero-cost rows of frame + CoM tasks)
   // low-rank start: lane l computes rows [wood_row0[l], +wood_rpc) of column wood_col[l] of Jh·Jhᵀ
   // (row n_jrows = the right-hand side); −1 = idle lane

@@ -51,11 +51,12 @@ _INT_FIELDS = (
     "jnt_type", "jnt_qposadr", "jnt_dofadr", "jnt_bodyid", "jnt_limited",
     "dof_bodyid", "dof_jntid", "dof_parentid", "site_bodyid", "geom_bodyid",
     "geom_type", "geom_contype", "geom_conaffinity", "geom_valid", "body_mass_valid",
+    "geom_dataid", "mesh_vertadr", "mesh_vertnum",
 )
 _F64_FIELDS = (
     "body_pos", "body_quat", "body_ipos", "body_mass", "body_subtreemass",
     "jnt_pos", "jnt_axis", "jnt_range", "qpos0", "site_pos", "site_quat",
-    "geom_size", "geom_pos", "geom_quat", "key_qpos", "mocap_pos", "mocap_quat",
+    "geom_size", "geom_pos", "geom_quat", "key_qpos", "mocap_pos", "mocap_quat", "mesh_vert",
 )
 _NAME_FIELDS = ("body_names", "jnt_names", "site_names", "geom_names", "key_names")
 
@@ -116,6 +117,14 @@ class FlatModel:
     geom_size: np.ndarray = None
     geom_pos: np.ndarray = None
     geom_quat: np.ndarray = None
+    # mesh geoms (MuJoCo's names; what the collision path reads of a mesh is its CONVEX HULL — mj_geomDistance collides
+    # the hull): geom_dataid = mesh of a type-mesh geom (−1 else); hull vertices of mesh k in the geom frame (MuJoCo
+    # re-expresses a mesh in its inertial frame and folds that frame into geom_pos / geom_quat) are
+    # mesh_vert[mesh_vertadr[k] : + mesh_vertnum[k]].  Here mesh_vert holds the hull's vertices only, as float64.
+    geom_dataid: np.ndarray = None
+    mesh_vertadr: np.ndarray = None
+    mesh_vertnum: np.ndarray = None
+    mesh_vert: np.ndarray = None
     # keyframes / mocap
     key_qpos: np.ndarray = None
     mocap_pos: np.ndarray = None
@@ -131,6 +140,10 @@ class FlatModel:
     def finalize(self) -> "FlatModel":
         if self.body_mass_valid is None:        # (models serialised before the field existed; real MjModels)
             self.body_mass_valid = np.ones(self.nbody, dtype=np.int32)
+        if self.geom_dataid is None:            # (models serialised before the mesh fields existed)
+            self.geom_dataid = -np.ones(self.ngeom, dtype=np.int32)
+        if self.mesh_vertadr is None:
+            self.mesh_vertadr, self.mesh_vertnum, self.mesh_vert = np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 3))
         for f in _INT_FIELDS:
             setattr(self, f, np.ascontiguousarray(getattr(self, f), dtype=np.int32))
         for f in _F64_FIELDS:
@@ -142,10 +155,13 @@ class FlatModel:
             "site_pos": (self.nsite, 3), "site_quat": (self.nsite, 4),
             "geom_size": (self.ngeom, 3), "geom_pos": (self.ngeom, 3),
             "geom_quat": (self.ngeom, 4), "key_qpos": (self.nkey, self.nq),
-            "mocap_pos": (self.nmocap, 3), "mocap_quat": (self.nmocap, 4),
+            "mocap_pos": (self.nmocap, 3), "mocap_quat": (self.nmocap, 4), "mesh_vert": (-1, 3),
         }
         for k, shp in shapes.items():
             setattr(self, k, getattr(self, k).reshape(shp))
+        # hull vertices carry the precision of the compiled model (mjModel.mesh_vert is float32): a value that went
+        # through the short decimals of to_json comes back as exactly the same float32
+        self.mesh_vert = np.ascontiguousarray(self.mesh_vert.astype(np.float32).astype(np.float64))
         self._name_maps: Dict[str, Dict[str, int]] = {
             "body": {n: i for i, n in enumerate(self.body_names) if n},
             "joint": {n: i for i, n in enumerate(self.jnt_names) if n},
@@ -241,6 +257,8 @@ class FlatModel:
         out = {}
         for f in fields(self):
             v = getattr(self, f.name)
+            if f.name == "mesh_vert":      # float32 values: their shortest decimals (a third of the file size of float64 reprs)
+                v = [[float(str(x)) for x in row] for row in np.asarray(v, dtype=np.float32)]
             out[f.name] = v.tolist() if isinstance(v, np.ndarray) else v
         return json.dumps(out)
 
@@ -260,6 +278,44 @@ class FlatModel:
             return cls.from_json(fh.read())
 
     # ------------------------------------------------------ real mujoco ingest
+    @staticmethod
+    def _hulls_of_mjmodel(m) -> dict:
+        """Convex-hull vertices of the meshes that type-mesh geoms refer to, from the compiled model: `mesh_graph` lists
+        the hull's vertices (layout at mesh_graphadr[k]: numvert, numface, vert_edgeadr[numvert], vert_globalid[numvert],
+        …); a mesh without a graph is collided with all of its vertices."""
+        ngeom = int(m.ngeom)
+        dataid = -np.ones(ngeom, dtype=np.int32)
+        if not hasattr(m, "mesh_vert") or int(getattr(m, "nmesh", 0)) == 0:
+            return dict(geom_dataid=dataid, mesh_vertadr=np.zeros(0, np.int32), mesh_vertnum=np.zeros(0, np.int32),
+                        mesh_vert=np.zeros((0, 3)))
+        verts_all = np.asarray(m.mesh_vert, dtype=np.float64).reshape(-1, 3)
+        graph = np.asarray(getattr(m, "mesh_graph", np.zeros(0, np.int32)), dtype=np.int64).reshape(-1)
+        remap, hulls = {}, []
+        for g in range(ngeom):
+            k = int(m.geom_dataid[g])
+            if int(m.geom_type[g]) != GEOM_MESH or k < 0:
+                continue
+            if k not in remap:
+                v = verts_all[int(m.mesh_vertadr[k]): int(m.mesh_vertadr[k]) + int(m.mesh_vertnum[k])]
+                ga = int(m.mesh_graphadr[k]) if hasattr(m, "mesh_graphadr") else -1
+                if ga >= 0:
+                    nvh = int(graph[ga])
+                    v = v[graph[ga + 2 + nvh: ga + 2 + 2 * nvh]]
+                remap[k] = len(hulls)
+                hulls.append(np.ascontiguousarray(v))
+            dataid[g] = remap[k]
+        num = np.array([len(h) for h in hulls], dtype=np.int32)
+        return dict(geom_dataid=dataid, mesh_vertadr=(np.cumsum(num) - num).astype(np.int32), mesh_vertnum=num,
+                    mesh_vert=np.concatenate(hulls, axis=0) if hulls else np.zeros((0, 3)))
+
+    def mesh_hull(self, geom_id: int) -> np.ndarray:
+        """Hull vertices (n, 3) of a type-mesh geom in the geom's frame."""
+        k = int(self.geom_dataid[geom_id])
+        if k < 0:
+            raise ValueError(f"geom {geom_id} is not a mesh geom (or its mesh asset was not available)")
+        a = int(self.mesh_vertadr[k])
+        return self.mesh_vert[a: a + int(self.mesh_vertnum[k])]
+
     @classmethod
     def from_mjmodel(cls, m) -> "FlatModel":
         """Field-for-field copy of a real ``mujoco.MjModel`` (production ingest)."""
@@ -287,6 +343,7 @@ class FlatModel:
             geom_contype=m.geom_contype, geom_conaffinity=m.geom_conaffinity,
             geom_valid=np.ones(m.ngeom, dtype=np.int32),
             geom_size=m.geom_size, geom_pos=m.geom_pos, geom_quat=m.geom_quat,
+            **cls._hulls_of_mjmodel(m),
             key_qpos=m.key_qpos,
             mocap_pos=np.array([m.body_pos[b] for b in range(m.nbody) if m.body_mocapid[b] >= 0]).reshape(-1, 3),
             mocap_quat=np.array([m.body_quat[b] for b in range(m.nbody) if m.body_mocapid[b] >= 0]).reshape(-1, 4),

@@ -190,14 +190,18 @@ class CollisionAvoidanceLimit(Limit):
         for pair in geom_pairs:
             a = list(set(self._homogenize_geom_id_list(pair[0])))
             b = list(set(self._homogenize_geom_id_list(pair[1])))
-            for g in a + b:
-                if not m.geom_valid[g]:
-                    raise LimitDefinitionError(
-                        f"geom {g} ('{m.geom_names[g]}') takes its size and frame from a mesh asset that was not "
-                        "available when the model was read (MJCF subset reader): it cannot be a collision candidate")
             for ga, gb in itertools.product(a, b):
                 if (not _is_welded_together(m, ga, gb) and not _are_geom_bodies_parent_child(m, ga, gb)
                         and _is_pass_contype_conaffinity_check(m, ga, gb)):
+                    # (checked on the pairs that survive the filters only: the reference's examples hand over whole
+                    #  subtrees, visual mesh geoms included — examples/arm_aloha.py:95-104 — which contype / conaffinity
+                    #  = 0 then drops)
+                    for g in (ga, gb):
+                        if not m.geom_valid[g]:
+                            raise LimitDefinitionError(
+                                f"geom {g} ('{m.geom_names[g]}') takes its size and frame from a mesh asset that was "
+                                "not available when the model was read (MJCF subset reader): it cannot be a collision "
+                                "candidate")
                     pairs.append((min(ga, gb), max(ga, gb)))
         return pairs
 

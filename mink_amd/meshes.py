@@ -1,0 +1,211 @@
+"""Mesh assets → what the collision path needs (host side, setup time only; used by the MJCF subset reader).
+
+A `mujoco.MjModel` already carries all of this (`FlatModel.from_mjmodel` reads the compiled `geom_size` / `geom_pos` /
+`geom_quat` and the hull from `mesh_graph`); this module restates the part of MuJoCo's model COMPILER that the examples of
+the reference rely on, because the wheel is absent here:
+
+  * STL (binary / ASCII) and OBJ readers, `<mesh scale>` (examples/aloha/aloha.xml:9-20, shadow_hand/left_hand.xml:8);
+  * the mesh's inertial frame — centre of mass and principal axes of the enclosed volume at unit density — in which the
+    compiler re-expresses the vertices, and the half-sizes of the box with the same inertia ("inertia box");
+  * a primitive FITTED to a mesh, `<geom type="capsule" mesh="...">` (shadow_hand/left_hand.xml:149, every collision geom
+    of the ALOHA pair set, examples/arm_aloha.py:95-109): size from the inertia box, frame = the mesh's inertial frame;
+  * the convex hull's vertices (MuJoCo collides the hull of a mesh geom; scipy's qhull here).
+
+[upstream-recall: src/user/user_mesh.cc `mjCMesh::Process`, `mjCMesh::FitGeom`, mujoco 3.1.x; parity unpinned against the
+wheel — the restatement is pinned by its own properties in tests/test_meshes_cpu.py: exact mass properties of boxes,
+cylinders and capsules tessellated on the spot, invariance under rigid motions of the input.]
+"""
+
+from __future__ import annotations
+
+import os
+import struct
+from typing import Dict, Tuple
+
+import numpy as np
+
+from .flatmodel import GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_ELLIPSOID, GEOM_SPHERE
+
+
+class MeshError(ValueError):
+    pass
+
+
+# ------------------------------------------------------------------ readers
+def _read_stl(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    with open(path, "rb") as fh:
+        data = fh.read()
+    if len(data) >= 84:
+        (n,) = struct.unpack_from("<I", data, 80)
+        if 84 + 50 * n == len(data):                                     # binary STL
+            rec = np.frombuffer(data, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]), count=n, offset=84)
+            tri = rec["v"].astype(np.float64)
+            return tri.reshape(-1, 3), np.arange(3 * n).reshape(-1, 3)
+    verts = [[float(x) for x in ln.split()[1:4]] for ln in data.decode("ascii", "replace").splitlines()
+             if ln.strip().startswith("vertex")]
+    if not verts or len(verts) % 3:
+        raise MeshError(f"{path}: neither a binary nor an ASCII STL")
+    v = np.array(verts, dtype=np.float64)
+    return v, np.arange(len(v)).reshape(-1, 3)
+
+
+def _read_obj(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    verts, faces = [], []
+    with open(path, "r", errors="replace") as fh:
+        for ln in fh:
+            t = ln.split()
+            if not t:
+                continue
+            if t[0] == "v":
+                verts.append([float(x) for x in t[1:4]])
+            elif t[0] == "f":
+                idx = [int(w.split("/")[0]) for w in t[1:]]
+                idx = [i - 1 if i > 0 else len(verts) + i for i in idx]
+                for k in range(1, len(idx) - 1):                          # fan triangulation of polygons
+                    faces.append([idx[0], idx[k], idx[k + 1]])
+    if not verts or not faces:
+        raise MeshError(f"{path}: no vertices / faces")
+    return np.array(verts, dtype=np.float64), np.array(faces, dtype=np.int64)
+
+
+def load_mesh_file(path: str) -> Tuple[np.ndarray, np.ndarray]:
+    """(vertices (n, 3), triangles (m, 3)); repeated vertices merged (an STL lists every triangle's corners)."""
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".stl":
+        v, f = _read_stl(path)
+    elif ext == ".obj":
+        v, f = _read_obj(path)
+    else:
+        raise MeshError(f"{path}: mesh format '{ext}' is not read here (STL and OBJ are)")
+    uniq, inv = np.unique(v, axis=0, return_inverse=True)
+    f = inv.reshape(-1)[f]
+    f = f[(f[:, 0] != f[:, 1]) & (f[:, 1] != f[:, 2]) & (f[:, 0] != f[:, 2])]   # degenerate triangles carry no volume
+    return uniq, f
+
+
+# ------------------------------------------------------------------ mass properties
+def mass_properties(verts: np.ndarray, faces: np.ndarray):
+    """Volume, centre of mass and second-moment matrix ∫ (x − com)(x − com)ᵀ dV of the volume enclosed by the triangles
+    (unit density): signed tetrahedra from the area-weighted centroid of the surface, as the compiler does — exact for a
+    closed, consistently oriented surface whatever the apex, and well behaved for the slightly open ones of real assets."""
+    a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
+    nrm = np.cross(b - a, c - a)
+    area = 0.5 * np.linalg.norm(nrm, axis=1)
+    if area.sum() <= 0.0:
+        raise MeshError("mesh has no area")
+    apex = ((a + b + c) / 3.0 * area[:, None]).sum(axis=0) / area.sum()
+    a, b, c = a - apex, b - apex, c - apex
+    det = np.einsum("ij,ij->i", a, np.cross(b, c))                        # 6 × signed volume of (apex, a, b, c)
+    vol = det.sum() / 6.0
+    if vol < 0.0:                                                         # triangles wound inwards: same solid
+        det, vol = -det, -vol
+    if vol <= 1e-18:
+        raise MeshError("mesh encloses no volume")
+    com = (det[:, None] * (a + b + c)).sum(axis=0) / 24.0 / vol           # (relative to the apex)
+    s = a + b + c
+    C = (np.einsum("i,ij,ik->jk", det, a, a) + np.einsum("i,ij,ik->jk", det, b, b) + np.einsum("i,ij,ik->jk", det, c, c) +
+         np.einsum("i,ij,ik->jk", det, s, s)) / 120.0                     # ∫ x xᵀ dV about the apex
+    C -= vol * np.outer(com, com)
+    return vol, com + apex, C
+
+
+def inertial_frame(verts: np.ndarray, faces: np.ndarray):
+    """(pos, R, boxsz, volume): centre of mass, principal axes (columns of R, right-handed, principal inertias in
+    decreasing order — so the LONGEST extent of the solid is along z, the axis of a fitted capsule / cylinder) and the
+    half-sizes of the box of the same volume-inertia."""
+    vol, com, C = mass_properties(verts, faces)
+    inertia = np.trace(C) * np.eye(3) - C
+    w, V = np.linalg.eigh(inertia)
+    order = np.argsort(-w)                                                # decreasing principal inertias
+    w, V = w[order], V[:, order]
+    if np.linalg.det(V) < 0.0:
+        V[:, 2] = -V[:, 2]
+    # box of half-sizes (sx, sy, sz), mass m: I_x = m (sy² + sz²) / 3, ...  ⇒  s_x² = 3 (I_y + I_z − I_x) / (2 m)
+    box = np.sqrt(np.maximum(0.0, 1.5 * (np.array([w[1] + w[2] - w[0], w[0] + w[2] - w[1], w[0] + w[1] - w[2]])) / vol))
+    return com, V, box, vol
+
+
+def fit_primitive(gtype: int, boxsz: np.ndarray) -> np.ndarray:
+    """geom_size of a primitive fitted to a mesh's inertia box (compiler default, fitaabb = false)."""
+    size = np.zeros(3)
+    if gtype == GEOM_SPHERE:
+        size[0] = boxsz.mean()
+    elif gtype == GEOM_CAPSULE:
+        size[0] = 0.5 * (boxsz[0] + boxsz[1])
+        size[1] = max(0.0, boxsz[2] - 0.5 * size[0])
+    elif gtype == GEOM_CYLINDER:
+        size[0] = 0.5 * (boxsz[0] + boxsz[1])
+        size[1] = boxsz[2]
+    elif gtype in (GEOM_BOX, GEOM_ELLIPSOID):
+        size[:] = boxsz
+    else:
+        raise MeshError(f"geom type {gtype} cannot be fitted to a mesh")
+    return size
+
+
+def mat2quat(R: np.ndarray) -> np.ndarray:
+    """Rotation matrix → unit quaternion (w, x, y, z), w ≥ 0."""
+    t = np.trace(R)
+    if t > 0.0:
+        s = np.sqrt(t + 1.0) * 2.0
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2.0
+        q = np.zeros(4)
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    q /= np.linalg.norm(q)
+    return q if q[0] >= 0.0 else -q
+
+
+class MeshAsset:
+    """One `<mesh>` asset compiled: inertial frame (pos, quat), inertia box, hull vertices in the inertial frame."""
+
+    def __init__(self, path: str, scale=(1.0, 1.0, 1.0)):
+        v, f = load_mesh_file(path)
+        v = v * np.asarray(scale, dtype=np.float64)
+        self.path = path
+        self.pos, R, self.boxsz, self.volume = inertial_frame(v, f)
+        self.R = R
+        self.quat = mat2quat(R)
+        # vertices in the inertial frame, at the precision the compiled model stores them in (mjModel.mesh_vert is float32)
+        self.vert = ((v - self.pos) @ R).astype(np.float32).astype(np.float64)
+        self._hull = None
+
+    @property
+    def hull_vert(self) -> np.ndarray:
+        """Vertices of the convex hull (inertial frame), in increasing vertex order."""
+        if self._hull is None:
+            from scipy.spatial import ConvexHull
+
+            self._hull = np.ascontiguousarray(self.vert[np.sort(ConvexHull(self.vert).vertices)])
+        return self._hull
+
+
+def load_assets(mesh_elems, meshdir: str, resolve_attrs) -> Dict[str, MeshAsset]:
+    """name → MeshAsset for the `<mesh>` elements of an MJCF `<asset>` section (name defaults to the file's stem)."""
+    out: Dict[str, MeshAsset] = {}
+    for el in mesh_elems:
+        a = resolve_attrs(el)
+        if "file" not in a:
+            continue                                                      # (vertex data inlined in the XML: not read here)
+        name = a.get("name") or os.path.splitext(os.path.basename(a["file"]))[0]
+        scale = [float(x) for x in a.get("scale", "1 1 1").split()]
+        out[name] = _LazyAsset(os.path.join(meshdir, a["file"]), scale)
+    return out
+
+
+class _LazyAsset:
+    """A mesh asset that is only read when a geom that matters (collision candidate / fitted primitive) refers to it."""
+
+    def __init__(self, path, scale):
+        self.path, self.scale, self._asset = path, scale, None
+
+    def get(self) -> MeshAsset:
+        if self._asset is None:
+            self._asset = MeshAsset(self.path, self.scale)
+        return self._asset

@@ -84,6 +84,12 @@ def _mat_quat(R: np.ndarray) -> np.ndarray:
     return _normalize(q)
 
 
+def _quat_rotate(q, v) -> np.ndarray:
+    w, u = q[0], np.asarray(q[1:], dtype=np.float64)
+    t = 2.0 * np.cross(u, v)
+    return np.asarray(v, dtype=np.float64) + w * t + np.cross(u, t)
+
+
 def _z2quat(vec) -> np.ndarray:
     """Quaternion rotating +z onto ``vec`` (MuJoCo ``zaxis`` / ``fromto`` rule)."""
     vec = _normalize(np.asarray(vec, dtype=np.float64))
@@ -101,8 +107,12 @@ class _Compiler:
         self.angle_scale = math.pi / 180.0  # MJCF default: degrees
         self.autolimits = True  # MuJoCo >= 3.0 default
         self.eulerseq = "xyz"
+        self.meshdir = ""
 
     def update(self, el: ET.Element):
+        md = el.get("meshdir")
+        if md is not None:
+            self.meshdir = md
         a = el.get("angle")
         if a is not None:
             self.angle_scale = 1.0 if a == "radian" else math.pi / 180.0
@@ -232,7 +242,15 @@ def load_mjcf(path: str) -> FlatModel:
         "type", "body", "pos", "axis", "range", "limited", "name", "ref")}
     S: Dict[str, list] = {k: [] for k in ("body", "pos", "quat", "name")}
     G: Dict[str, list] = {k: [] for k in (
-        "body", "type", "size", "pos", "quat", "contype", "conaffinity", "name", "valid")}
+        "body", "type", "size", "pos", "quat", "contype", "conaffinity", "name", "valid", "dataid")}
+    # mesh assets (mink_amd/meshes.py): read lazily — only when a collision candidate refers to one (a visual geom,
+    # contype = conaffinity = 0, can never be in a pair: mink/limits/collision_avoidance_limit.py:109-115)
+    from . import meshes as _meshes
+    mesh_elems = [m for asset in root.findall("asset") for m in asset.findall("mesh")]
+    assets = _meshes.load_assets(mesh_elems, os.path.join(os.path.dirname(os.path.abspath(path)), comp.meshdir),
+                                 lambda el: defaults.resolve("mesh", el, None))
+    mesh_ids: Dict[str, int] = {}          # asset name → index in the FlatModel's mesh arrays (meshes of type="mesh" geoms)
+    mesh_hulls: List[np.ndarray] = []
 
     mass_valid: Dict[int, int] = {}
     # world body
@@ -265,8 +283,29 @@ def load_mjcf(path: str) -> FlatModel:
                 size[1] = half
             else:
                 size[2] = half
+        contype, conaff = int(a.get("contype", 1)), int(a.get("conaffinity", 1))
+        dataid = -1
         if gtype == GEOM_MESH or has_mesh:
             valid = 0  # local frame / fitted size need the mesh asset
+            lazy = assets.get(a.get("mesh", ""))
+            if lazy is not None and (contype or conaff) and os.path.exists(lazy.path):
+                # The compiler re-expresses a mesh in its inertial frame (centre of mass, principal axes) and composes
+                # that frame into the geom's; a primitive with a mesh attribute is FITTED to the mesh's inertia box
+                # (mink_amd/meshes.py).  valid = 2: usable as a collision geom — the axes of the inertial frame are
+                # only defined up to half turns (eigenvectors), which no primitive and no hull distance can see, but a
+                # FrameTask on this geom could: frames on it stay refused (Configuration._frame_id).
+                asset = lazy.get()
+                pos = pos + _quat_rotate(quat, asset.pos)
+                quat = _normalize(_quat_mul(quat, asset.quat))
+                if gtype == GEOM_MESH:
+                    name_m = a["mesh"]
+                    if name_m not in mesh_ids:
+                        mesh_ids[name_m] = len(mesh_hulls)
+                        mesh_hulls.append(asset.hull_vert)
+                    dataid = mesh_ids[name_m]
+                else:
+                    size = _meshes.fit_primitive(gtype, asset.boxsz) * float(a.get("fitscale", 1.0))
+                valid = 2
         if gtype not in (GEOM_MESH, GEOM_PLANE) and valid:
             need = {GEOM_SPHERE: 1, GEOM_CAPSULE: 2, GEOM_CYLINDER: 2,
                     GEOM_BOX: 3, GEOM_ELLIPSOID: 3}[gtype]
@@ -274,13 +313,13 @@ def load_mjcf(path: str) -> FlatModel:
                 raise MjcfError(f"geom size missing for type '{tname}'")
         G["body"].append(body_id); G["type"].append(gtype); G["size"].append(size)
         G["pos"].append(pos); G["quat"].append(quat)
-        G["contype"].append(int(a.get("contype", 1)))
-        G["conaffinity"].append(int(a.get("conaffinity", 1)))
-        G["name"].append(a.get("name", "")); G["valid"].append(valid)
+        G["contype"].append(contype)
+        G["conaffinity"].append(conaff)
+        G["name"].append(a.get("name", "")); G["valid"].append(valid); G["dataid"].append(dataid)
         unknown = False
         if "mass" in a:
             m = float(a["mass"])
-        elif valid:
+        elif valid == 1:
             m = float(a.get("density", 1000.0)) * _geom_volume(gtype, size)
         else:
             m = 0.0
@@ -484,6 +523,10 @@ def load_mjcf(path: str) -> FlatModel:
         geom_bodyid=G["body"], geom_type=G["type"], geom_contype=G["contype"],
         geom_conaffinity=G["conaffinity"], geom_valid=G["valid"], geom_size=arr(G["size"], 3),
         geom_pos=arr(G["pos"], 3), geom_quat=arr(G["quat"], 4),
+        geom_dataid=np.array(G["dataid"], dtype=np.int32),
+        mesh_vertadr=np.cumsum([0] + [len(h) for h in mesh_hulls[:-1]]).astype(np.int32) if mesh_hulls else np.zeros(0, np.int32),
+        mesh_vertnum=np.array([len(h) for h in mesh_hulls], dtype=np.int32),
+        mesh_vert=np.concatenate(mesh_hulls, axis=0) if mesh_hulls else np.zeros((0, 3)),
         key_qpos=arr(key_qpos, nq) if key_qpos else np.zeros((0, nq)),
         mocap_pos=arr(mocap_pos, 3), mocap_quat=arr(mocap_quat, 4),
         body_names=B["name"], jnt_names=J["name"], site_names=S["name"],

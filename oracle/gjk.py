@@ -16,17 +16,22 @@ tests/test_oracle_gjk.py pins the separated case against bounded minimisation ov
 
 import numpy as np
 
-GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX = 0, 2, 3, 4, 5, 6
+GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = 0, 2, 3, 4, 5, 6, 7
 MAX_ITERS = 128
 
 
 def core_radius(gtype, size):
     """Radius of the spherical shell around the core the support mapping describes."""
-    return float(size[0]) if gtype in (GEOM_SPHERE, GEOM_CAPSULE) else 0.0
+    return float(np.asarray(size).reshape(-1)[0]) if gtype in (GEOM_SPHERE, GEOM_CAPSULE) else 0.0
 
 
 def support_local(gtype, size, d):
     """Support point of the CORE of a primitive in its own frame: argmax_x d·x."""
+    if gtype == GEOM_MESH:
+        # a mesh geom is collided as its convex hull: `size` carries the hull's vertices (n, 3) in the geom frame;
+        # the first maximiser of d·x
+        verts = np.asarray(size, dtype=np.float64).reshape(-1, 3)
+        return verts[int(np.argmax(verts @ d))].copy()
     if gtype == GEOM_SPHERE:
         return np.zeros(3)
     if gtype == GEOM_CAPSULE:

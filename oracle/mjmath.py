@@ -495,7 +495,20 @@ def _plane_cylinder(pos1, mat1, pos2, mat2, size2, margin):
     return [(dist, pt - n * (0.5 * dist), n)]
 
 
-_CONVEX = (GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX)
+GEOM_MESH = 7
+_CONVEX = (GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH)
+
+
+def _plane_mesh(pos1, mat1, pos2, mat2, hull, margin):
+    """Lowest vertex of the hull against the plane normal (mjc_PlaneConvex keeps the deepest point)."""
+    n = np.array([mat1[2], mat1[5], mat1[8]])
+    R = _mat3(mat2)
+    hull = np.asarray(hull, dtype=np.float64).reshape(-1, 3)
+    pt = pos2 + R @ hull[int(np.argmax(hull @ (R.T @ -n)))]
+    dist = float(n @ (pt - pos1))
+    if dist > margin:
+        return []
+    return [(dist, pt - n * (0.5 * dist), n)]
 
 
 def _plane_ellipsoid(pos1, mat1, pos2, mat2, size2, margin):
@@ -765,6 +778,11 @@ def mj_geomDistance(m, d: Data, geom1: int, geom2: int, distmax: float, fromto) 
     s1, s2 = m.geom_size[g1], m.geom_size[g2]
     if not (m.geom_valid[g1] and m.geom_valid[g2]):
         raise NotImplementedError("geom needs mesh data")
+    # a mesh geom is its convex hull: the hull's vertices (geom frame) stand in for the size
+    if t1 == GEOM_MESH:
+        s1 = m.mesh_hull(g1)
+    if t2 == GEOM_MESH:
+        s2 = m.mesh_hull(g2)
     if (t1, t2) == (GEOM_CAPSULE, GEOM_CAPSULE):
         cons = _capsule_capsule(p1, R1, s1, p2, R2, s2, distmax)
     elif (t1, t2) == (GEOM_SPHERE, GEOM_SPHERE):
@@ -791,6 +809,8 @@ def mj_geomDistance(m, d: Data, geom1: int, geom2: int, distmax: float, fromto) 
         cons = _box_box(p1, R1, s1, p2, R2, s2, distmax)
     elif (t1, t2) == (GEOM_PLANE, GEOM_ELLIPSOID):
         cons = _plane_ellipsoid(p1, R1, p2, R2, s2, distmax)
+    elif (t1, t2) == (GEOM_PLANE, GEOM_MESH):
+        cons = _plane_mesh(p1, R1, p2, R2, s2, distmax)
     elif t1 in _CONVEX and t2 in _CONVEX:
         # no native pair routine in MuJoCo either: the general convex collider (oracle/gjk.py states what it approximates)
         from . import gjk

@@ -162,4 +162,23 @@ class RawMjModel:
         for n in self._F64:
             setattr(self, n, np.array(getattr(flat, n), dtype=np.float64))
         self.jnt_limited = np.array(flat.jnt_limited, dtype=np.uint8)       # mjtByte in the real struct
+        # meshes in the real layout: float32 vertices, per-mesh address / count, the convex-hull graph (here: a graph
+        # whose vertex list is the identity — the FlatModel's mesh_vert ARE the hull's vertices — preceded, for the
+        # first mesh, by a dummy interior vertex that only the graph can tell apart)
+        self.nmesh = int(len(flat.mesh_vertnum))
+        self.geom_dataid = np.array(flat.geom_dataid, dtype=np.int32)
+        verts, adr, num, graph, gadr = [], [], [], [], []
+        for k in range(self.nmesh):
+            hull = flat.mesh_vert[int(flat.mesh_vertadr[k]): int(flat.mesh_vertadr[k]) + int(flat.mesh_vertnum[k])]
+            extra = 1 if k == 0 else 0
+            adr.append(sum(len(v) for v in verts)); num.append(len(hull) + extra)
+            if extra:
+                verts.append(hull.mean(axis=0, keepdims=True))
+            verts.append(hull)
+            gadr.append(len(graph))
+            nvh = len(hull)
+            graph += [nvh, 0] + [0] * nvh + list(range(extra, extra + nvh))
+        self.mesh_vertadr = np.array(adr, dtype=np.int32); self.mesh_vertnum = np.array(num, dtype=np.int32)
+        self.mesh_vert = (np.concatenate(verts, axis=0) if verts else np.zeros((0, 3))).astype(np.float32)
+        self.mesh_graph = np.array(graph, dtype=np.int32); self.mesh_graphadr = np.array(gadr, dtype=np.int32)
         self._names = {k: list(getattr(flat, k)) for k in _NAMES.values()}

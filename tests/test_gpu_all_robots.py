@@ -70,3 +70,105 @@ def test_solve_matches_oracle(path):
     print("%-40s nv %2d  %-28s max rel err: C oracle %.1e, numpy oracle %.1e" %
           (os.path.basename(path)[:-5], m.nv, prob.last_kernel(), err, worst))
     assert err < 1e-8 and worst < 1e-8
+
+
+def _solve_with_collisions(m, frame_sites, pairs_fn, q0, B, seed, col_kw, sigma=0.1, n_check=4):
+    """Shared body of the two mesh-dependent set-ups below: frame tasks on sites + posture + ConfigurationLimit +
+    CollisionAvoidanceLimit, device against the numpy oracle on a few instances (the oracle walks every pair in Python)."""
+    import mink_amd as mink
+    rng = np.random.default_rng(seed)
+    q = q0 + rng.normal(scale=sigma, size=(B, m.nq))
+    q = np.clip(q, np.where(np.isfinite(_qlo(m)), _qlo(m) + 1e-3, -np.inf), np.where(np.isfinite(_qhi(m)), _qhi(m) - 1e-3, np.inf))
+    cfg = mink.Configuration(m, q)
+    col = mink.CollisionAvoidanceLimit(m, pairs_fn(mink, m), **col_kw)
+    tg_cfg = mink.Configuration(m, cfg.integrate(rng.normal(scale=0.1, size=(B, m.nv)), 1.0))
+    tasks = []
+    for s in frame_sites:
+        t = mink.FrameTask(s, "site", position_cost=1.0, orientation_cost=0.5, lm_damping=1.0)
+        t.set_target(tg_cfg.get_transform_frame_to_world(s, "site"))
+        tasks.append(t)
+    post = mink.PostureTask(m, cost=1e-2); post.set_target(q0)
+    dt, damping = 2e-2, 1e-4
+    v, st = mink.solve_ik(cfg, tasks + [post], dt, "mi355x", damping, limits=[mink.ConfigurationLimit(m), col], return_status=True)
+    G, h = col.compute_qp_inequalities(cfg, dt)
+    spec = oik.CollisionAvoidanceLimitSpec(col.geom_id_pairs, **{k: v_ for k, v_ in col_kw.items()})
+    worst, binding, active = 0.0, 0, int(np.isfinite(h).sum())
+    print("detected contacts per instance: max %d (rows available: %d)" % (np.isfinite(h).sum(axis=1).max(), 64 - m.nv))
+    for i in np.argsort(-np.isfinite(h).sum(axis=1))[:n_check]:       # the instances with the most contacts
+        ots = [oik.FrameTaskSpec(m.name2id("site", s), "site", np.array([1, 1, 1, .5, .5, .5]), t.transform_target_to_world.wxyz_xyz[i], 1.0, 1.0)
+               for s, t in zip(frame_sites, tasks)] + [oik.PostureTaskSpec(np.full(m.nv, 1e-2), q0)]
+        G_ref, h_ref = oik.limit_inequalities(oik.Configuration(m, q[i]), spec, dt)
+        fin = np.isfinite(h_ref)
+        assert (np.isfinite(h[i]) == fin).all()
+        np.testing.assert_allclose(h[i][fin], h_ref[fin], rtol=0, atol=1e-9 * max(1.0, np.abs(h_ref[fin]).max(initial=0)))
+        np.testing.assert_allclose(G[i][fin], G_ref[fin], atol=2e-5)
+        v_ref = oik.solve_ik(m, q[i], ots, dt, damping, [oik.ConfigurationLimitSpec(), spec])
+        worst = max(worst, np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max()))
+        binding += int((np.abs(G_ref[fin] @ (v_ref * dt) - h_ref[fin]) < 1e-8).sum())
+    return col, st, worst, binding, active
+
+
+def _qlo(m):
+    lo = np.full(m.nq, -np.inf)
+    for j in range(m.njnt):
+        if m.jnt_limited[j] and m.jnt_type[j] in (2, 3):
+            lo[m.jnt_qposadr[j]] = m.jnt_range[j][0]
+    return lo
+
+
+def _qhi(m):
+    hi = np.full(m.nq, np.inf)
+    for j in range(m.njnt):
+        if m.jnt_limited[j] and m.jnt_type[j] in (2, 3):
+            hi[m.jnt_qposadr[j]] = m.jnt_range[j][1]
+    return hi
+
+
+def test_aloha_collision_setup_of_the_reference():
+    """examples/arm_aloha.py:95-109: wrist subtree against wrist subtree, both arms against the metal frame and the table —
+    1 104 geom pairs, every arm / frame collision geom a capsule FITTED to its mesh (aloha.xml:86-87, scene.xml:44-46: sizes
+    and frames from the assets' inertia boxes, mink_amd/meshes.py).  More pairs than the 48 rows a 16-dof tableau leaves: the
+    tightest are rows, the rest is checked at the solution."""
+    m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", "aloha__scene.json"))
+    assert m.nv == 16 and (m.geom_valid == 2).sum() >= 40
+
+    def pairs(mink, m):
+        lw = mink.get_subtree_geom_ids(m, m.body("left/wrist_link").id)
+        rw = mink.get_subtree_geom_ids(m, m.body("right/wrist_link").id)
+        lg = mink.get_subtree_geom_ids(m, m.body("left/upper_arm_link").id)
+        rg = mink.get_subtree_geom_ids(m, m.body("right/upper_arm_link").id)
+        fg = mink.get_body_geom_ids(m, m.body("metal_frame").id)
+        return [(lw, rw), (lg + rg, fg + ["table"])]
+
+    q0 = m.key_qpos[m.name2id("key", "neutral_pose")] if m.name2id("key", "neutral_pose") >= 0 else m.qpos0
+    col, st, worst, binding, active = _solve_with_collisions(
+        m, ["left/gripper", "right/gripper"], pairs, q0, 48, 5,
+        dict(minimum_distance_from_collisions=0.05, collision_detection_distance=0.1), sigma=0.5, n_check=6)
+    assert len(col.geom_id_pairs) == 1104
+    print("aloha: %d pairs, %d detected contacts over the batch, %d binding rows in the checked instances, max rel err %.2e, "
+          "status bits %s" % (len(col.geom_id_pairs), active, binding, worst, sorted(set(st.tolist()))))
+    assert (st & ~1 == 0).all() and worst < 1e-7 and active > 0
+
+
+def test_shadow_hand_with_mesh_fitted_fingertips_and_the_forearm_mesh():
+    """The `*_3` fingertip capsules of the Shadow hand are fitted to f_distal_pst / th_distal_pst (left_hand.xml:149,175,
+    201,232,263) and the forearm's collision geom is a MESH (left_hand.xml:101): fingertips against each other, against the
+    other fingers' middle phalanges, and against the forearm hull (general convex routine with the hull's vertices)."""
+    m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", "shadow_hand__scene_left.json"))
+    fore = [g for g in range(m.ngeom) if m.geom_type[g] == 7 and m.geom_dataid[g] >= 0]
+    assert len(fore) == 1
+
+    def pairs(mink, m):
+        tips = [f"{f}_3" for f in oc.SHADOW_FINGERS]
+        mids = [f"{f}_2" for f in oc.SHADOW_FINGERS]
+        return [(tips, tips), (tips, mids), (tips, fore)]
+
+    grasp = m.key_qpos[m.name2id("key", "grasp hard")]
+    col, st, worst, binding, active = _solve_with_collisions(
+        m, list(oc.SHADOW_FINGERS), pairs, grasp, 32, 9,
+        dict(minimum_distance_from_collisions=0.004, collision_detection_distance=0.06), sigma=0.15)
+    types = {(int(m.geom_type[a]), int(m.geom_type[b])) for a, b in col.geom_id_pairs}
+    assert (3, 7) in types or (7, 3) in types
+    print("shadow *_3 + forearm mesh: %d pairs, %d detected contacts, %d binding rows, max rel err %.2e" %
+          (len(col.geom_id_pairs), active, binding, worst))
+    assert (st & ~1 == 0).all() and worst < 2e-5 and active > 0

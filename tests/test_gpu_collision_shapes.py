@@ -3,6 +3,8 @@
 examples/arm_ur5e.py:30-37 avoids collisions between the `wrist_3_link` capsule and the `floor` plane / `wall`
 box; a synthetic scene covers every pair type the device routine knows."""
 
+import copy
+
 import numpy as np
 import pytest
 
@@ -315,3 +317,99 @@ def test_general_convex_pairs_against_the_oracle():
         worst = max(worst, np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max()))
     print("solve with general convex half-spaces vs oracle: max rel err %.2e" % worst)
     assert worst < 1e-5
+
+
+def _with_mesh_geoms(m, rng):
+    """CONVEX_SCENE with three geoms turned into MESH geoms (hull vertices in the geom frame, as a compiled model carries
+    them): `crate` → the 8 corners of the same box (every answer must be the box's), `l4_can` → a 40-vertex hull of the same
+    cylinder's rim points + noise, `egg` → a random 24-point hull.  The GPU box has no asset files: the hulls are made here."""
+    from scipy.spatial import ConvexHull
+    m = copy.deepcopy(m)
+    hulls = []
+
+    def to_mesh(name, pts):
+        g = m.name2id("geom", name)
+        pts = np.asarray(pts, dtype=np.float32).astype(np.float64)
+        pts = pts[np.sort(ConvexHull(pts).vertices)]
+        m.geom_type[g] = 7
+        m.geom_dataid[g] = len(hulls)
+        hulls.append(pts)
+        return g
+
+    g = m.name2id("geom", "crate")
+    sb = m.geom_size[g].copy()
+    to_mesh("crate", [[sx * sb[0], sy * sb[1], sz * sb[2]] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+    g = m.name2id("geom", "l4_can")
+    r, hl = m.geom_size[g][:2]
+    ang = 2 * np.pi * np.arange(20) / 20
+    rim = np.concatenate([np.c_[r * np.cos(ang), r * np.sin(ang), np.full(20, s * hl)] for s in (-1, 1)])
+    to_mesh("l4_can", rim * rng.uniform(0.9, 1.0, size=(40, 1)))
+    to_mesh("egg", rng.normal(size=(24, 3)) * np.array([0.1, 0.06, 0.15]))
+    num = np.array([len(h) for h in hulls], dtype=np.int32)
+    m.mesh_vertnum, m.mesh_vertadr, m.mesh_vert = num, (np.cumsum(num) - num).astype(np.int32), np.concatenate(hulls)
+    return m.finalize()
+
+
+def test_mesh_geoms_against_the_oracle():
+    """(f)-3, meshes: a mesh geom takes part in CollisionAvoidanceLimit through its convex hull, as in mj_geomDistance
+    (/root/reference/mink/limits/collision_avoidance_limit.py:214-229) — plane–mesh by the hull's lowest vertex, mesh against
+    primitives and meshes through the general convex routine with the hull's vertices as the support mapping.  Device
+    against the numpy statement (oracle/gjk.py, pinned against bounded minimisation over hull points in
+    tests/test_oracle_gjk.py); the box-corner mesh against the analytic box routines of the primitive model."""
+    base = mink.loads_mjcf(CONVEX_SCENE)
+    rng = np.random.default_rng(14)
+    m = _with_mesh_geoms(base, rng)
+    pairs = [(["l4_can"], ["crate", "drum", "egg", "floor"]),            # mesh–mesh, mesh–cylinder, mesh–mesh, plane–mesh
+             (["l3_egg"], ["crate", "egg"]), (["l3_cap"], ["crate", "egg"])]   # ellipsoid–mesh, capsule–mesh
+    col = mink.CollisionAvoidanceLimit(m, pairs, collision_detection_distance=0.3, minimum_distance_from_collisions=0.01)
+    npair = len(col.geom_id_pairs)
+    assert npair == 8
+    B = 160
+    q = _rand_q(m, rng, B)
+    dt = 0.1
+    G, h = col.compute_qp_inequalities(mink.Configuration(m, q), dt)
+    spec = oik.CollisionAvoidanceLimitSpec(col.geom_id_pairs, collision_detection_distance=0.3, minimum_distance_from_collisions=0.01)
+    apart = np.zeros(npair, dtype=int)
+    for i in range(B):
+        G_ref, h_ref = oik.limit_inequalities(oik.Configuration(m, q[i]), spec, dt)
+        fin = np.isfinite(h_ref)
+        assert (np.isfinite(h[i]) == fin).all(), i
+        sep = fin & (h_ref > 0.0)
+        apart += sep
+        np.testing.assert_allclose(h[i][sep], h_ref[sep], rtol=0, atol=1e-9 * max(1.0, np.abs(h_ref[sep]).max(initial=0.0)))
+        np.testing.assert_allclose(G[i][sep], G_ref[sep], atol=2e-5)
+    print("separated instances per mesh pair:", list(zip([tuple(p) for p in col.geom_id_pairs], apart)))
+    assert (apart > 0).all(), apart
+    # the crate as a mesh of its corners = the crate as a box, pair by pair (capsule–box is analytic in the primitive model)
+    col_m = mink.CollisionAvoidanceLimit(m, [(["l3_cap"], ["crate"])], collision_detection_distance=0.3)
+    col_b = mink.CollisionAvoidanceLimit(base, [(["l3_cap"], ["crate"])], collision_detection_distance=0.3)
+    Gm, hm = col_m.compute_qp_inequalities(mink.Configuration(m, q), dt)
+    Gb, hb = col_b.compute_qp_inequalities(mink.Configuration(base, q), dt)
+    fin = np.isfinite(hb[:, 0]) & (hb[:, 0] > 0)
+    assert fin.sum() > 10 and (np.isfinite(hm[:, 0]) == np.isfinite(hb[:, 0])).all()
+    np.testing.assert_allclose(hm[fin], hb[fin], rtol=0, atol=1e-6)     # (hull vertices are float32, as in a compiled model: 1e-8 in the sizes)
+    # a solve with mesh half-spaces binding
+    hmin = np.where(np.isfinite(h), h, np.inf).min(axis=1)
+    ok = np.flatnonzero(hmin > 0)
+    ok = ok[np.argsort(hmin[ok])][:64]
+    cfg = mink.Configuration(m, q[ok])
+    ft = mink.FrameTask("tip", "site", position_cost=1.0, orientation_cost=0.2)
+    ft.set_target(mink.Configuration(m, _rand_q(m, rng, len(ok))).get_transform_frame_to_world("tip", "site"))
+    post = mink.PostureTask(m, cost=1e-2); post.set_target(m.qpos0)
+    v = mink.solve_ik(cfg, [ft, post], dt, "mi355x", 1e-3, limits=[mink.ConfigurationLimit(m), col])
+    assert list(cfg._problems.values())[-1].last_kernel().endswith("_136")
+    worst, binding = 0.0, 0
+    for j, i in enumerate(ok[:24]):
+        tasks = [oik.FrameTaskSpec(m.name2id("site", "tip"), "site", np.array([1.0, 1.0, 1.0, 0.2, 0.2, 0.2]), ft.transform_target_to_world.wxyz_xyz[j]),
+                 oik.PostureTaskSpec(np.full(m.nv, 1e-2), m.qpos0)]
+        v_ref = oik.solve_ik(m, q[i], tasks, dt, 1e-3, [oik.ConfigurationLimitSpec(), spec])
+        worst = max(worst, np.abs(v[j] - v_ref).max() / max(1.0, np.abs(v_ref).max()))
+        fin = np.isfinite(h[i])
+        binding += int((np.abs(G[i][fin] @ (v_ref * dt) - h[i][fin]) < 1e-7).sum())
+    print("solve with mesh half-spaces: max rel err %.2e, binding rows %d" % (worst, binding))
+    assert worst < 2e-5 and binding > 0
+    # a model whose mesh geom carries no hull is refused at problem creation, with the reason
+    bad = copy.deepcopy(m); bad.geom_dataid[bad.name2id("geom", "egg")] = -1; bad.finalize()
+    with pytest.raises(Exception, match="hull"):
+        mink.solve_ik(mink.Configuration(bad, q[:2]), [post], dt, "mi355x", 1e-3,
+                      limits=[mink.CollisionAvoidanceLimit(bad, [(["l3_cap"], ["egg"])])])

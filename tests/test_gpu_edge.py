@@ -132,7 +132,7 @@ def test_argument_validation():
         prob.solve(np.zeros((2, 6)), np.zeros((2, 1, 7)), None, None, 0.0, 1e-3)
     with pytest.raises(nat.MinkHipError, match="site id"):
         nat.NativeProblem(nm, frame_tasks=[{"frame_type": "site", "frame_id": 9, "cost": [1.0] * 6}])
-    with pytest.raises(nat.MinkHipError, match="not supported"):
+    with pytest.raises(nat.MinkHipError, match="no hull in the model"):     # (a visual mesh geom of the packaged UR5e: no hull was kept for it)
         # a mesh geom has no distance routine (every pair of primitives has one: analytic or the general convex routine)
         nat.NativeProblem(nm, collision_limits=[{"geom_id_pairs": [[1, m.name2id("geom", "wall")]],
                                                  "gain": 0.85, "minimum_distance_from_collisions": 0.005,

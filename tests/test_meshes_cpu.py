@@ -1,0 +1,120 @@
+"""mink_amd/meshes.py — the restated slice of MuJoCo's mesh compiler (inertial frame, inertia box, primitive fit, hull) —
+pinned by properties that do not need the wheel: exact mass properties of solids tessellated on the spot, invariance under
+rigid motions, file readers on files written here; FlatModel.from_mjmodel's hull extraction on an object with the real
+MjModel mesh field layout.  CPU only."""
+
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from mink_amd import meshes
+from mink_amd.flatmodel import GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_SPHERE, FlatModel
+
+
+def _box(hx, hy, hz):
+    v = np.array([[sx * hx, sy * hy, sz * hz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], dtype=float)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    f = []
+    for a, b, c, d in quads:
+        f += [(a, b, c), (a, c, d)]
+    return v, np.array(f)
+
+
+def _cylinder(r, h, n=256):
+    ang = 2 * np.pi * np.arange(n) / n
+    ring = np.stack([r * np.cos(ang), r * np.sin(ang)], axis=1)
+    v = np.concatenate([np.c_[ring, np.full(n, -h)], np.c_[ring, np.full(n, h)], [[0, 0, -h], [0, 0, h]]])
+    f = []
+    for i in range(n):
+        j = (i + 1) % n
+        f += [(i, j, n + j), (i, n + j, n + i), (2 * n, j, i), (2 * n + 1, n + i, n + j)]
+    return v, np.array(f)
+
+
+def _random_rotation(rng):
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def test_box_mass_properties_and_fit_are_exact():
+    rng = np.random.default_rng(0)
+    hx, hy, hz = 0.03, 0.05, 0.11
+    v, f = _box(hx, hy, hz)
+    R, t = _random_rotation(rng), rng.normal(size=3)
+    pos, A, box, vol = meshes.inertial_frame(v @ R.T + t, f)
+    np.testing.assert_allclose(vol, 8 * hx * hy * hz, rtol=1e-12)
+    np.testing.assert_allclose(pos, t, atol=1e-13)
+    # principal inertias decreasing ⇒ box half-sizes increasing: (x, y, z) = (smallest … largest extent)
+    np.testing.assert_allclose(box, [hx, hy, hz], rtol=1e-10)
+    # axes: the box's own, up to sign
+    np.testing.assert_allclose(np.abs(A.T @ R), np.eye(3), atol=1e-9)
+    assert np.linalg.det(A) > 0
+    np.testing.assert_allclose(meshes.fit_primitive(GEOM_BOX, box), box)
+    np.testing.assert_allclose(meshes.fit_primitive(GEOM_SPHERE, box)[0], (hx + hy + hz) / 3)
+    cap = meshes.fit_primitive(GEOM_CAPSULE, box)
+    np.testing.assert_allclose(cap[:2], [(hx + hy) / 2, hz - (hx + hy) / 4])
+    np.testing.assert_allclose(meshes.fit_primitive(GEOM_CYLINDER, box)[:2], [(hx + hy) / 2, hz])
+    # inward-wound triangles describe the same solid
+    pos2, _, box2, vol2 = meshes.inertial_frame(v, f[:, ::-1])
+    np.testing.assert_allclose([vol2, *box2], [vol, *box], rtol=1e-12)
+
+
+def test_cylinder_inertia_box():
+    r, h = 0.02, 0.09
+    v, f = _cylinder(r, h, 720)
+    pos, A, box, vol = meshes.inertial_frame(v, f)
+    np.testing.assert_allclose(vol, np.pi * r * r * 2 * h, rtol=1e-4)
+    # solid cylinder: I_z = m r²/2, I_x = m (3 r² + (2h)²)/12 ⇒ box with the same inertia: sx = sy = r·√3/2, sz = h
+    np.testing.assert_allclose(box, [r * np.sqrt(3) / 2, r * np.sqrt(3) / 2, h], rtol=2e-4)
+    assert abs(abs(A[2, 2]) - 1.0) < 1e-9                       # long axis → z
+
+
+def test_mesh_files_and_asset(tmp_path):
+    v, f = _box(0.01, 0.02, 0.04)
+    tri = v[f]
+    stl = tmp_path / "b.stl"
+    with open(stl, "wb") as fh:
+        fh.write(b"\0" * 80 + struct.pack("<I", len(tri)))
+        for t in tri:
+            fh.write(struct.pack("<12fH", 0, 0, 0, *t.reshape(-1), 0))
+    obj = tmp_path / "b.obj"
+    with open(obj, "w") as fh:
+        for p in v * 1000.0:
+            fh.write("v %.9g %.9g %.9g\n" % tuple(p))
+        for a, b, c in f:
+            fh.write(f"f {a + 1}//1 {b + 1}//1 {c + 1}//1\n")
+    a1 = meshes.MeshAsset(str(stl))
+    a2 = meshes.MeshAsset(str(obj), scale=(0.001, 0.001, 0.001))
+    for a in (a1, a2):
+        assert len(a.vert) == 8 and len(a.hull_vert) == 8        # an STL's repeated corners are merged
+        np.testing.assert_allclose(a.boxsz, [0.01, 0.02, 0.04], rtol=1e-6)
+        np.testing.assert_allclose(np.sort(np.abs(a.vert), axis=0)[-1], [0.01, 0.02, 0.04], rtol=1e-6)
+    with pytest.raises(meshes.MeshError):
+        meshes.load_mesh_file(str(tmp_path / "b.msh"))
+
+
+def test_from_mjmodel_takes_the_hull_from_mesh_graph():
+    """mjModel layout: mesh_vert float32 (nmeshvert, 3); mesh_graph at mesh_graphadr[k] = [numvert, numface,
+    vert_edgeadr[numvert], vert_globalid[numvert], edge_localid[...], face_globalid[3·numface]]."""
+    class Raw:
+        pass
+    m = Raw()
+    m.ngeom, m.nmesh = 3, 2
+    m.geom_type = np.array([7, 3, 7], dtype=np.int32)
+    m.geom_dataid = np.array([1, -1, 0], dtype=np.int32)
+    m.mesh_vertadr = np.array([0, 5], dtype=np.int32); m.mesh_vertnum = np.array([5, 4], dtype=np.int32)
+    m.mesh_vert = np.arange(27, dtype=np.float32).reshape(9, 3)
+    # mesh 0: hull = vertices 0, 2, 3, 4 (vertex 1 interior); mesh 1: no graph ⇒ all four vertices
+    g0 = [4, 4] + [0, 0, 0, 0] + [0, 2, 3, 4] + [0] * (4 + 12) + [0] * 12
+    m.mesh_graph = np.array(g0, dtype=np.int32)
+    m.mesh_graphadr = np.array([0, -1], dtype=np.int32)
+    out = FlatModel._hulls_of_mjmodel(m)
+    assert out["geom_dataid"].tolist() == [0, -1, 1]            # renumbered in geom order
+    assert out["mesh_vertnum"].tolist() == [4, 4] and out["mesh_vertadr"].tolist() == [0, 4]
+    np.testing.assert_array_equal(out["mesh_vert"][:4], m.mesh_vert[5:9])
+    np.testing.assert_array_equal(out["mesh_vert"][4:], m.mesh_vert[[0, 2, 3, 4]])

@@ -248,8 +248,22 @@ def test_shadow_left(source):
         assert m.geom_type[g] == 3 and m.body_names[m.geom_bodyid[g]] == body and m.geom_valid[g] == 1
         np.testing.assert_array_equal(m.geom_size[g], size)
         np.testing.assert_array_equal(m.geom_pos[g], pos)
-    # mesh-fitted capsule (type="capsule" mesh=...): size and frame need the mesh asset — flagged, never silently used
-    assert m.geom_valid[m.name2id("geom", "first_3")] == 0
+    # mesh-fitted capsule (left_hand.xml:149 `type="capsule" mesh="f_distal_pst"`): fitted to the asset's inertia box when the
+    # model was compiled (mink_amd/meshes.py; flag 2 = usable as a collision geom, its frame's axes only up to half turns).
+    # f_distal_pst.obj is a ≈26 mm fingertip, ≈14 mm across: radius and half-length of the fit must be of that size, the
+    # capsule must sit in the distal body with its axis along the finger (body z)
+    g = m.name2id("geom", "first_3")
+    assert m.geom_valid[g] == 2 and m.geom_type[g] == 3 and m.body_names[m.geom_bodyid[g]] == "lh_ffdistal"
+    assert 0.005 < m.geom_size[g][0] < 0.009 and 0.005 < m.geom_size[g][1] < 0.012
+    assert abs(m.geom_pos[g][0]) < 1e-3 and abs(m.geom_pos[g][1]) < 2e-3 and 0.010 < m.geom_pos[g][2] < 0.025
+    qw, qx, qy, qz = m.geom_quat[g]
+    zaxis = np.array([2 * (qx * qz + qw * qy), 2 * (qy * qz - qw * qx), 1 - 2 * (qx * qx + qy * qy)])
+    assert abs(abs(zaxis[2]) - 1.0) < 0.02, zaxis                         # capsule axis ∥ finger axis
+    # the one true mesh collision geom of the hand (left_hand.xml:101 `type="mesh" mesh="forearm_collision"`): its hull
+    fm = [k for k in range(m.ngeom) if m.geom_type[k] == 7 and m.geom_dataid[k] >= 0]
+    assert len(fm) == 1 and m.body_names[m.geom_bodyid[fm[0]]] == "lh_forearm"
+    hull = m.mesh_hull(fm[0])
+    assert 20 < len(hull) < 400 and 0.05 < np.ptp(hull, axis=0).max() < 0.3
     g = m.name2id("geom", "floor")                          # scene_left.xml: pos="0 0 -0.1" size="0 0 0.05"
     np.testing.assert_array_equal(m.geom_pos[g], (0, 0, -0.1))
     np.testing.assert_array_equal(m.geom_size[g], (0, 0, 0.05))

@@ -116,3 +116,90 @@ def test_overlapping_pairs_report_a_negative_distance_that_separates():
             # translating geom 2 by (−dist + ε)·n separates the shapes
             c = gjk.convex_distance(t1, s1, p1, R1, t2, s2, p2 + (-dist + 1e-6) * n, R2, 10.0)
             assert c is not None and c[0] > 0.0        # (an upper bound of the depth: the descent finds a local minimum)
+
+
+# ------------------------------------------------------------------ mesh geoms (their convex hull: vertices as the support mapping)
+def _hull_points(rng, n=24, scale=0.2):
+    from scipy.spatial import ConvexHull
+    pts = rng.normal(size=(n, 3)) * rng.uniform(0.4, 1.0, 3) * scale
+    return np.ascontiguousarray(pts[np.sort(ConvexHull(pts).vertices)])
+
+
+def _brute_hull(hull, p1, R1, other, rng):
+    """min |x − y|, x a convex combination of the hull's vertices (simplex weights), y in the other shape."""
+    n = len(hull)
+    W = p1 + hull @ R1.T
+    if other[0] == "hull":
+        V = other[2] + other[1] @ other[3].T
+        m = len(V)
+        fun = lambda z: float(np.sum((z[:n] @ W - z[n:] @ V) ** 2))
+        cons = [{"type": "eq", "fun": lambda z: z[:n].sum() - 1.0}, {"type": "eq", "fun": lambda z: z[n:].sum() - 1.0}]
+        z0, bounds = np.concatenate([np.full(n, 1.0 / n), np.full(m, 1.0 / m)]), [(0, 1)] * (n + m)
+    else:
+        _, t2, s2, p2, R2 = other
+        g2 = _inside(t2, s2)
+        fun = lambda z: float(np.sum((z[:n] @ W - z[n:]) ** 2))
+        cons = [{"type": "eq", "fun": lambda z: z[:n].sum() - 1.0}, {"type": "ineq", "fun": lambda z: g2(R2.T @ (z[n:] - p2))}]
+        z0, bounds = np.concatenate([np.full(n, 1.0 / n), p2]), [(0, 1)] * n + [(None, None)] * 3
+    r = minimize(fun, z0, constraints=cons, bounds=bounds, method="SLSQP", options={"ftol": 1e-16, "maxiter": 1000})
+    return np.sqrt(max(r.fun, 0.0))
+
+
+def test_mesh_as_box_corners_is_the_box():
+    rng = np.random.default_rng(21)
+    for _ in range(30):
+        sb = rng.uniform(0.05, 0.25, 3)
+        corners = np.array([[sx * sb[0], sy * sb[1], sz * sb[2]] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)])
+        p1, p2 = rng.uniform(-0.3, 0.3, 3), rng.uniform(-0.3, 0.3, 3) + np.array([0.7, 0.0, 0.0])
+        R1, R2 = _rand_rot(rng), _rand_rot(rng)
+        for t2 in (gjk.GEOM_BOX, gjk.GEOM_CYLINDER, gjk.GEOM_SPHERE, gjk.GEOM_CAPSULE, gjk.GEOM_ELLIPSOID):
+            s2 = SIZES[t2](rng)
+            a = gjk.convex_distance(gjk.GEOM_MESH, corners, p1, R1, t2, s2, p2, R2, 10.0)
+            b = gjk.convex_distance(gjk.GEOM_BOX, sb, p1, R1, t2, s2, p2, R2, 10.0)
+            assert abs(a[0] - b[0]) < 1e-12 and np.abs(a[2] - b[2]).max() < 1e-6
+        cons = mj._box_box(p1, R1.reshape(-1), sb, p2, R2.reshape(-1), sb, 10.0)
+        d = gjk.convex_distance(gjk.GEOM_MESH, corners, p1, R1, gjk.GEOM_MESH, corners, p2, R2, 10.0)[0]
+        d_ref = min(c[0] for c in cons)
+        if d_ref > 0.0:                                  # (overlapping: a local estimate of the depth, see the test below)
+            assert abs(d - d_ref) < 1e-10
+        else:
+            assert d < 0.0
+
+
+@pytest.mark.parametrize("other", ["hull", gjk.GEOM_SPHERE, gjk.GEOM_CAPSULE, gjk.GEOM_BOX, gjk.GEOM_CYLINDER])
+def test_mesh_hull_distance_against_bounded_minimisation(other):
+    rng = np.random.default_rng(31 + (0 if other == "hull" else other))
+    n = 0
+    while n < 8:
+        hull = _hull_points(rng)
+        p1, R1 = rng.uniform(-0.3, 0.3, 3), _rand_rot(rng)
+        p2, R2 = rng.uniform(-0.3, 0.3, 3) + np.array([0.5, 0.2, 0.0]), _rand_rot(rng)
+        if other == "hull":
+            h2 = _hull_points(rng)
+            c = gjk.convex_distance(gjk.GEOM_MESH, hull, p1, R1, gjk.GEOM_MESH, h2, p2, R2, 10.0)
+            ref = _brute_hull(hull, p1, R1, ("hull", h2, p2, R2), rng)
+        else:
+            s2 = SIZES[other](rng)
+            c = gjk.convex_distance(gjk.GEOM_MESH, hull, p1, R1, other, s2, p2, R2, 10.0)
+            ref = _brute_hull(hull, p1, R1, ("prim", other, s2, p2, R2), rng)
+        if c is None or c[0] <= 1e-3:
+            continue
+        n += 1
+        assert abs(c[0] - ref) < 5e-6 * max(1.0, ref), (other, c[0], ref)
+        # the witness point on the hull side is in the hull: it supports the separating direction
+        nrm, a = c[2], c[1] - 0.5 * c[0] * c[2]
+        # (the direction of a GJK run is good to ~1e-7 — the support gap ε leaves an angle √ε — times the shape's size)
+        assert abs(nrm @ (gjk.support(gjk.GEOM_MESH, hull, p1, R1, nrm) - a)) < 2e-6
+
+
+def test_plane_mesh_is_the_lowest_hull_vertex():
+    rng = np.random.default_rng(41)
+    for _ in range(20):
+        hull = _hull_points(rng)
+        p2, R2 = rng.uniform(-0.2, 0.2, 3) + np.array([0, 0, 0.5]), _rand_rot(rng)
+        Rp = _rand_rot(rng)
+        pp = rng.uniform(-0.1, 0.1, 3)
+        cons = mj._plane_mesh(pp, Rp.reshape(-1), p2, R2.reshape(-1), hull, 10.0)
+        n = Rp[:, 2]
+        heights = (p2 + hull @ R2.T - pp) @ n
+        assert len(cons) == 1 and abs(cons[0][0] - heights.min()) < 1e-14
