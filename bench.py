@@ -209,10 +209,13 @@ def pcie_inclusive(prob, q_h, tg_h, pt_h, ct_h, dt, damping, reps=5):
     return len(q_h) * reps / (time.perf_counter() - t0)
 
 
-def converged_targets(prob, q, tg, pt, ct, dt, damping, B, max_iters=20, pos_threshold=1e-3, ori_threshold=1e-2, reps=3):
+def loop_targets(prob, q, tg, pt, ct, dt, damping, B, max_iters=20, pos_threshold=1e-3, ori_threshold=1e-2, reps=3):
     """Secondary metric: the callers' whole loop — solve, integrate, break when every frame task is
     within (pos_threshold, ori_threshold), at most max_iters times (examples/arm_ur5e_actuators.py:88-97) — as ONE
-    launch per batch (mkh_solve_until): IK targets brought to convergence per second, device-resident inputs."""
+    launch per batch (mkh_solve_until), device-resident inputs.  Reported twice by main(): `loop20_targets_per_s` with the
+    examples' max_iters = 20 (at this workload's velocity limits — π rad/s × 5 ms per step against targets 0.15 rad away — nine
+    instances in ten leave on the iteration cap: a 20-step-loop rate), and `converged_targets` with the budget it takes for
+    ≥ 90 % of the instances to reach the thresholds."""
     import torch
     res = prob.solve(q, tg, pt, ct, dt, damping, n_steps=max_iters, until=(pos_threshold, ori_threshold))
     torch.cuda.synchronize()
@@ -520,7 +523,21 @@ def main():
         if res is not None:
             out["kernel_resources"] = res
         if world == 1 and plain:
-            out["converged_targets"] = converged_targets(prob, q, tg, pt, ct, dt, damping, B)
+            out["loop20_targets_per_s"] = loop_targets(prob, q, tg, pt, ct, dt, damping, B, max_iters=20)
+            # ... and a figure that deserves the name: targets that lie inside the joint ranges (the SURVEY §8(d) distribution of
+            # the headline batch leaves most G1 targets just outside them, workloads.make_batch), the iteration budget raised
+            # until ≥ 90 % of the instances are within the thresholds
+            q_r, tg_r, pt_r, _ = workloads.bench_batch(args.config, model, nm, prob, np.random.default_rng(1000 + rank), B, reachable=True)
+            q_r, tg_r, pt_r = torch.from_numpy(q_r).to(dev), torch.from_numpy(tg_r).to(dev), torch.from_numpy(pt_r).to(dev)
+            conv = None
+            for budget in (40, 80, 160, 320):
+                conv = loop_targets(prob, q_r, tg_r, pt_r if prob.n_posture else None, ct, dt, damping, B, max_iters=budget, reps=1)
+                if conv["converged_fraction"] >= 0.9:
+                    break
+            conv["note"] = ("consistent, reachable targets: frame targets = FK of a configuration inside the joint ranges, which is also "
+                            "the instance's posture target (per-instance posture targets, +nq·8 B per solve); iteration budget "
+                            "raised until converged_fraction >= 0.9 (or 320); " + conv["note"])
+            out["converged_targets"] = conv
             if not args.no_pcie_leg:
                 out["pcie_inclusive_value"] = pcie_inclusive(prob, q_h, tg_h, pt_h, ct_h, dt, damping)
         if world == 1 and args.config == "g1_c3" and args.batch is None and not args.no_other_configs:

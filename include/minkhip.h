@@ -165,10 +165,12 @@ typedef struct MkhVelocityLimitDesc {
  *
  * Two places where the contact differs from mujoco 3.1.6's by construction (no test against the wheel can exist here):
  *  (i) TIES.  Where the closest pair of points is not unique — a capsule parallel to a box face, face-to-face boxes —
- *      MuJoCo returns several contacts of equal distance and mj_geomDistance keeps the first; the routines here return the
- *      MIDPOINT of the flat stretch of closest points (capsule ∥ face, ∥ capsules) or the centre of the overlap of the two
- *      faces (box–box).  The distance h is the same; the witness points feed mj_jac, so the row of G differs by the lever arm
- *      between the two choices.  tests/test_gpu_collision_shapes.py::test_tie_rule_is_pinned holds the rule in place.
+ *      MuJoCo returns several contacts of equal distance and mj_geomDistance keeps the first of ITS enumeration.  The routines
+ *      here: capsule ∥ box face — the midpoint of the stretch of the capsule's axis that lies over the face; parallel capsules —
+ *      the two ends of the overlapping stretch as two contacts, the first kept (mjc_CapsuleCapsule's shape); boxes face to
+ *      face — the first closest (vertex, face) pair in the routine's own vertex order.  The distance h is the same as MuJoCo's;
+ *      the witness points feed mj_jac, so the row of G may differ by the lever arm between two equally close points.
+ *      tests/test_gpu_collision_shapes.py::test_tie_rule_is_pinned holds these three rules in place.
  *  (ii) GENERAL CONVEX PAIRS.  The nine primitive pair types without an analytic routine, and every mesh pair, get the exact
  *      Euclidean distance of the two convex sets (GJK, ~1e-13) where MuJoCo answers with libccd's MPR on shapes inflated by
  *      half the margin each, to a tolerance of 1e-6: h agrees to that tolerance, not to 1e-9. */

@@ -39,9 +39,17 @@ def native_model(model: FlatModel, device: int = 0) -> "nat.NativeModel":
 
 
 class Configuration:
-    def __init__(self, model, q: Optional[np.ndarray] = None, device: int = 0):
+    def __init__(self, model, q: Optional[np.ndarray] = None, device=0):
+        """`device`: a device index, or — one process driving several GPUs — a sequence of indices or "all"
+        (every visible device): solve_ik / solve_ik_steps / build_ik then split the batch into contiguous row blocks, one
+        per listed device (mink_amd.distributed.ShardedProblem; a device may be listed more than once)."""
         self.model = as_flat_model(model)
-        self.device = int(device)
+        if isinstance(device, str):
+            if device != "all":
+                raise ValueError("device must be an index, a sequence of indices or 'all'")
+            device = list(range(max(1, nat.lib().mkh_device_count())))
+        self.devices = [int(d) for d in device] if isinstance(device, (list, tuple)) else [int(device)]
+        self.device = self.devices[0]             # kinematics queries (frame poses, Jacobians, CoM) run on the first one
         # compiled device descriptors of this configuration's call sites (insertion-ordered: LRU in solve_ik._compile).
         # A descriptor owns one ticket counter and one set of staging buffers, so calls on ONE Configuration must not
         # run concurrently from several threads/streams (include/minkhip.h "One in-flight call per MkhProblem").

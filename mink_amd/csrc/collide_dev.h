@@ -155,8 +155,13 @@ __device__ __forceinline__ double seg_box_slope(V3 c, V3 a, V3 s, double t, int 
   const double ez = (on == 2) ? 0.0 : z - clampd(z, -s.z, s.z);
   return a.x * ex + a.y * ey + a.z * ez;
 }
+// A slope below 1e-13 of the problem's size counts as zero: an axis "parallel" to a face up to rounding (a component of
+// 1e-16 from the quaternion products) must land on the flat-stretch rule, not on whichever end the noise favours
+// (tests/test_gpu_collision_shapes.py::test_tie_rule_is_pinned).
+__device__ __forceinline__ double seg_box_flat(double g, double tol) { return fabs(g) <= tol ? 0.0 : g; }
 __device__ __forceinline__ Contact capsule_box_local(V3 c, V3 a, double r, double l, V3 s, double margin) {
-  const double g0 = seg_box_slope(c, a, s, -l), g1 = seg_box_slope(c, a, s, l);
+  const double tol = 1e-13 * (l + fmax(fmax(fabs(c.x), fabs(c.y)), fabs(c.z)) + fmax(fmax(s.x, s.y), s.z));
+  const double g0 = seg_box_flat(seg_box_slope(c, a, s, -l), tol), g1 = seg_box_flat(seg_box_slope(c, a, s, l), tol);
   double t;
   if (g0 > 0.0) t = -l;
   else if (g1 < 0.0) t = l;
@@ -172,7 +177,7 @@ __device__ __forceinline__ Contact capsule_box_local(V3 c, V3 a, double r, doubl
       for (int sg = 0; sg < 2; ++sg) {
         const double tb = ((sg ? sv[i] : -sv[i]) - cv[i]) / av[i];
         if (!(tb > -l && tb < l)) continue;
-        const double gb = seg_box_slope(c, a, s, tb, i);
+        const double gb = seg_box_flat(seg_box_slope(c, a, s, tb, i), tol);
         if (gb <= 0.0 && tb > tL) { tL = tb; gL = gb; }
         if (gb >= 0.0 && tb < tR) { tR = tb; gR = gb; }
       }

@@ -1,4 +1,5 @@
-"""Batch sharding across the GPUs of one node: one process per GPU, RCCL gather of v.
+"""Batch sharding across the GPUs of one node: one process per GPU with an RCCL gather of v (bench.py --gpus N,
+solve_ik_sharded), or ONE process that drives every device (ShardedProblem: SURVEY §8(e)'s second host model).
 
 The IK instances are independent (no cross-instance term anywhere in mink/solve_ik.py:13-40), so
 rank r owns the contiguous rows [r·B/N, (r+1)·B/N) and the model constants are replicated at handle
@@ -74,3 +75,93 @@ def solve_ik_sharded(solve_local, q, frame_targets, total_rows: Optional[int] = 
     if total_rows is None:
         total_rows = int(q.shape[0]) * world
     return gather_rows(v, total_rows, dst, group), gather_rows(status, total_rows, dst, group)
+
+
+class ShardedProblem:
+    """One `NativeProblem` per device and a HOST batch split into contiguous row blocks (`shard_bounds`): the single-process
+    host model of SURVEY §8(e).  `devices` lists the device of every shard — repeats allowed: N handles on ONE device is how
+    this path is exercised on a 1-GPU box.  The shards' host-pointer calls are issued from N threads: a libminkhip call
+    releases the GIL and is synchronous per handle (its own staging buffers and streams), so the devices copy and compute
+    concurrently; results land in row blocks of one output.  Same `solve` signature and return values as
+    `NativeProblem.solve` for numpy inputs (taps, fused steps, plugin rows included).  No collective: the instances are
+    independent, and here the rows come home over PCIe anyway."""
+
+    def __init__(self, model, devices, max_batch: int, **problem_kwargs):
+        from concurrent.futures import ThreadPoolExecutor
+
+        from . import _native as nat
+
+        self.devices = [int(d) for d in devices]
+        if not self.devices:
+            raise ValueError("ShardedProblem needs at least one device")
+        n = len(self.devices)
+        self.max_batch = int(max_batch)
+        shard_max = -(-self.max_batch // n)
+        self.models = [nat.NativeModel(model, d) for d in self.devices]            # one handle per shard, also on a shared device
+        self.shards = [nat.NativeProblem(nm, max_batch=shard_max, **problem_kwargs) for nm in self.models]
+        self._pool = ThreadPoolExecutor(max_workers=n)
+        p0 = self.shards[0]
+        self.n_frame, self.n_posture, self.n_com, self.n_rows, self.n_pairs = p0.n_frame, p0.n_posture, p0.n_com, p0.n_rows, p0.n_pairs
+        self.n_dense_rows, self.n_dense_limit_rows, self.dense_limit_box = p0.n_dense_rows, p0.n_dense_limit_rows, p0.dense_limit_box
+
+    def close(self):
+        for p in getattr(self, "shards", []):
+            p.close()
+        for m in getattr(self, "models", []):
+            m.close()
+        self.shards, self.models = [], []
+        if getattr(self, "_pool", None) is not None:
+            self._pool.shutdown(wait=False)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_kernel(self) -> str:
+        return self.shards[0].last_kernel()
+
+    def launch_info(self, B: int):
+        return self.shards[0].launch_info(-(-int(B) // len(self.shards)))
+
+    def solve(self, q, frame_targets=None, posture_target=None, com_target=None, dt: float = 1e-2, damping: float = 1e-12,
+              **kw):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        B, n = int(q.shape[0]), len(self.shards)
+        if B > self.max_batch:
+            from ._native import MinkHipError
+            raise MinkHipError(f"B={B} exceeds max_batch={self.max_batch} of this problem")
+        for bad in ("out", "status_out", "q_out"):
+            if kw.get(bad) is not None:
+                raise ValueError(f"ShardedProblem.solve allocates its outputs ('{bad}' is not supported)")
+        bounds = [shard_bounds(B, n, r) for r in range(n)]
+
+        # posture / CoM targets: batched iff they carry the extra leading axis
+        def tgt(x, per):
+            if x is None:
+                return [None] * n
+            x = np.asarray(x)
+            return [x[lo:hi] if x.ndim == per + 1 else x for lo, hi in bounds]
+
+        pts, cts = tgt(posture_target, 2), tgt(com_target, 2)
+        dense = kw.pop("dense", None)
+        jobs = []
+        for r, (lo, hi) in enumerate(bounds):
+            if hi == lo:
+                jobs.append(None)
+                continue
+            d_r = None if dense is None else {k: np.ascontiguousarray(np.asarray(v)[lo:hi]) for k, v in dense.items()}
+            jobs.append(self._pool.submit(self.shards[r].solve, q[lo:hi], None if frame_targets is None else np.asarray(frame_targets)[lo:hi],
+                                          pts[r], cts[r], dt, damping, dense=d_r, **kw))
+        parts = [j.result() for j in jobs if j is not None]
+
+        def join(items):
+            if items[0] is None:
+                return None
+            if isinstance(items[0], dict):
+                return {k: join([it[k] for it in items]) for k in items[0]}
+            return np.concatenate(items, axis=0)
+
+        return tuple(join([p[i] for p in parts]) for i in range(len(parts[0])))

@@ -147,11 +147,15 @@ def _compile(configuration: Configuration, tasks: Sequence, limits: Optional[Seq
     cache = configuration._problems
     prob = cache.pop(key, None)
     if prob is None:
-        prob = nat.NativeProblem(
-            configuration.native, frame_tasks=groups["frame"], posture_tasks=groups["posture"],
-            com_tasks=groups["com"], configuration_limits=groups["cfg"], velocity_limits=groups["vel"],
-            collision_limits=groups["col"], max_batch=batch, dense_tasks=groups["dense"],
-            dense_limit_rows=layout["dense_limit_rows"], dense_limit_box=layout.get("dense_box") is not None)
+        kwargs = dict(frame_tasks=groups["frame"], posture_tasks=groups["posture"],
+                      com_tasks=groups["com"], configuration_limits=groups["cfg"], velocity_limits=groups["vel"],
+                      collision_limits=groups["col"], max_batch=batch, dense_tasks=groups["dense"],
+                      dense_limit_rows=layout["dense_limit_rows"], dense_limit_box=layout.get("dense_box") is not None)
+        if len(configuration.devices) > 1 and batch >= len(configuration.devices):
+            from .distributed import ShardedProblem                  # one handle per listed device, rows split among them
+            prob = ShardedProblem(configuration.model, configuration.devices, **kwargs)
+        else:
+            prob = nat.NativeProblem(configuration.native, **kwargs)
     cache[key] = prob                                               # (re)insert as most recently used
     # Costs, gains and lm_damping are part of the device descriptor, so a caller that retunes a cost every control
     # step compiles a new descriptor every step: bound the cache (LRU) and free the evicted device buffers.  A handle

@@ -205,12 +205,16 @@ def plugin_rows(model: FlatModel, nmodel, q: np.ndarray, rng: np.random.Generato
             "limit_G": G, "limit_h": h}
 
 
-def bench_batch(name: str, model: FlatModel, nmodel, prob, rng: np.random.Generator, n: int):
+def bench_batch(name: str, model: FlatModel, nmodel, prob, rng: np.random.Generator, n: int, reachable: bool = False):
     """(q, frame_targets, posture_target, com_target) of a BASELINE config, host arrays (SURVEY §8d distributions);
     com_target is per instance (the instance's own CoM + 1 cm) for the G1 full example, else None."""
     c = BENCH_CONFIGS[name]
     base = model.key_qpos[model.name2id("key", c["key"])]
-    q, tg = make_batch(model, nmodel, prob, rng, n, base_q=base, dense=name == "g1_plugin")
+    q, tg = make_batch(model, nmodel, prob, rng, n, base_q=base, dense=name == "g1_plugin", reachable=reachable)
+    if reachable:
+        # (consistent targets: the posture target is the configuration the frame targets were taken from — per instance)
+        tg, q2 = tg
+        return q, tg, q2[:, None, :].copy(), None
     if c["robot"] == "shadow_left":
         q[::2] = 0.5 * (q[::2] + base)            # half of the samples near the grasp: fingers come close
     if name == "ur5e_convex":
@@ -228,11 +232,21 @@ def bench_dense(name: str, model: FlatModel, nmodel, q: np.ndarray, rng: np.rand
 
 
 def make_batch(model: FlatModel, nmodel, prob, rng: np.random.Generator, n: int, base_q=None,
-               sigma: float = 0.15, dense: bool = False) -> Tuple[np.ndarray, np.ndarray]:
-    """q and reachable frame targets = FK(q ⊕ δ), δ ~ N(0, σ²) per dof (device FK)."""
+               sigma: float = 0.15, dense: bool = False, reachable: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+    """q and frame targets = FK(q ⊕ δ), δ ~ N(0, σ²) per dof (device FK).  SURVEY §8(d)'s distribution does not keep q ⊕ δ
+    inside the joint ranges (with 37 limited hinges some joint of almost every G1 instance ends outside: the target is then
+    not exactly attainable under ConfigurationLimit); `reachable` clips the perturbed configuration into 96 % of every
+    range — the targets of the convergence figure of bench.py."""
     q = sample_q(model, rng, n, base_q)
     delta = rng.normal(scale=sigma, size=(n, model.nv))
     q2 = nmodel.integrate(q, delta, 1.0)
+    if reachable:
+        for j in range(model.njnt):
+            if model.jnt_type[j] != JNT_FREE and model.jnt_limited[j] and model.jnt_type[j] in (2, 3):
+                a = int(model.jnt_qposadr[j])
+                lo, hi = model.jnt_range[j]
+                q2[:, a] = np.clip(q2[:, a], lo + 0.02 * (hi - lo), hi - 0.02 * (hi - lo))
+    q2_keep = q2.copy()
     pt = np.zeros((prob.n_posture, model.nq)) if prob.n_posture else None
     ct = np.zeros((prob.n_com, 3)) if prob.n_com else None
     dummy = np.zeros((n, prob.n_frame, 7))
@@ -245,4 +259,6 @@ def make_batch(model: FlatModel, nmodel, prob, rng: np.random.Generator, n: int,
         twin.close()
         return q, taps["frame_pose"]
     _, _, taps = prob.solve(q2, dummy, pt, ct, 1.0, 1.0, taps=["frame_pose"], solve_qp=False)
+    if reachable:
+        return q, (taps["frame_pose"], q2_keep)
     return q, taps["frame_pose"]

@@ -561,7 +561,10 @@ def _seg_box_param(c, a, l, s):
         e = p - np.minimum(np.maximum(p, -s), s)
         if on >= 0:
             e[on] = 0.0
-        return float(a @ e)
+        v = float(a @ e)
+        return 0.0 if abs(v) <= tol else v     # parallel up to rounding is parallel: the flat-stretch rule, not the noise's pick
+
+    tol = 1e-13 * (l + float(np.max(np.abs(c))) + float(np.max(s)))
 
     cand = [(-l, g(-l)), (l, g(l))]
     for i in range(3):

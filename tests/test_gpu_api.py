@@ -344,3 +344,45 @@ def test_move_mocap_to_frame():
     mink.move_mocap_to_frame(m, cfg, "mocap", "test", "body")
     np.testing.assert_allclose(m.mocap_pos[mid], body[4:])
     np.testing.assert_allclose(m.mocap_quat[mid], body[:4])
+
+
+def test_one_process_drives_several_devices():
+    """SURVEY §8(e), second host model: one process, one handle per device, the host batch in contiguous row blocks
+    (mink_amd.distributed.ShardedProblem).  A 1-GPU box lists device 0 several times: N handles, N threads, same rows.
+    Results must be those of the single-handle call bit for bit (every instance is independent) — plain solve, fused loop,
+    per-instance posture targets, taps."""
+    import mink_amd as mink
+    from mink_amd import _native as nat, workloads
+    from mink_amd.distributed import ShardedProblem
+
+    m = workloads.load_robot("g1")
+    rng = np.random.default_rng(3)
+    stand = m.key_qpos[m.name2id("key", "stand")]
+    B = 1003                                               # uneven shards
+    q = workloads.sample_q(m, rng, B, base_q=stand)
+    one = mink.Configuration(m, q)
+    many = mink.Configuration(m, q, device=[0, 0, 0])
+    assert many.devices == [0, 0, 0]
+    tgt = mink.Configuration(m, one.integrate(rng.normal(scale=0.15, size=(B, m.nv)), 1.0))
+    tasks = []
+    for s, ori in (("left_foot", 10.0), ("right_foot", 10.0), ("left_palm", 0.0), ("right_palm", 0.0)):
+        t = mink.FrameTask(s, "site", 200.0, ori, lm_damping=1.0)
+        t.set_target(tgt.get_transform_frame_to_world(s, "site"))
+        tasks.append(t)
+    post = mink.PostureTask(m, cost=1.0)
+    post.set_target(np.tile(stand, (B, 1)) + 0.01 * rng.normal(size=(B, m.nq)))      # per-instance posture target
+    tasks.append(post)
+    hinge = {m.jnt_names[j]: np.pi for j in range(m.njnt) if m.jnt_type[j] != 0}
+    lims = [mink.ConfigurationLimit(m), mink.VelocityLimit(m, hinge)]
+    v1 = mink.solve_ik(one, tasks, 5e-3, "mi355x", 1e-1, limits=lims)
+    vN = mink.solve_ik(many, tasks, 5e-3, "mi355x", 1e-1, limits=lims)
+    assert any(isinstance(p, ShardedProblem) for p in many._problems.values())
+    np.testing.assert_array_equal(vN, v1)
+    p1, pN = mink.build_ik(one, tasks, 5e-3, 1e-1, lims), mink.build_ik(many, tasks, 5e-3, 1e-1, lims)
+    np.testing.assert_array_equal(pN.P, p1.P); np.testing.assert_array_equal(pN.q, p1.q)
+    q1, _ = mink.solve_ik_steps(one, tasks, 5e-3, 5, damping=1e-1, limits=lims, update=False)
+    qN, _ = mink.solve_ik_steps(many, tasks, 5e-3, 5, damping=1e-1, limits=lims, update=False)
+    np.testing.assert_array_equal(qN, q1)
+    assert mink.Configuration(m, q[:4], device="all").devices == list(range(nat.lib().mkh_device_count()))
+    with pytest.raises(nat.MinkHipError, match="max_batch"):
+        list(many._problems.values())[-1].solve(np.tile(q, (2, 1)), None, None, None, 1e-2, 1e-3)

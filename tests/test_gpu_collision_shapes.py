@@ -413,3 +413,49 @@ def test_mesh_geoms_against_the_oracle():
     with pytest.raises(Exception, match="hull"):
         mink.solve_ik(mink.Configuration(bad, q[:2]), [post], dt, "mi355x", 1e-3,
                       limits=[mink.CollisionAvoidanceLimit(bad, [(["l3_cap"], ["egg"])])])
+
+
+TIE_SCENE = """<mujoco><worldbody>
+  <geom name="slab" type="box" size=".3 .2 .05"/>
+  <geom name="rail" type="capsule" size=".05 .2" pos=".1 0 0" quat="1 0 1 0"/>
+  <body name="carrier"><joint type="slide" axis="1 0 0"/><joint type="slide" axis="0 1 0"/><joint type="slide" axis="0 0 1"/>
+    <inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/>
+    <body name="mover"><joint type="ball"/>
+      <geom name="brick" type="box" size=".1 .1 .05"/>
+      <geom name="rod" type="capsule" size=".04 .15" quat="1 0 1 0"/>
+    </body>
+  </body>
+</worldbody></mujoco>"""
+
+
+def test_tie_rule_is_pinned():
+    """Where the closest pair of points is not unique, mujoco 3.1.6 keeps the first of several equal contacts and this
+    library follows a rule of its own (include/minkhip.h at MkhCollisionLimitDesc).  The rule is pinned here so that it
+    cannot drift: the witness point of three tie configurations, stated as numbers, on the oracle — and the device's rows
+    of G against the oracle's on the same configurations (the witness point is the lever arm of the angular dofs)."""
+    from oracle import mjmath as mj
+    I = np.eye(3).reshape(-1)
+    Rx = np.array([[0, 0, 1], [0, 1, 0], [-1, 0, 0]], float).reshape(-1)          # capsule axis (local z) along world x
+    # boxes face to face, partial overlap: the first closest (vertex, face) pair — the brick's (−, −) corner
+    (d, pos, n), = mj._box_box(np.zeros(3), I, np.array([.3, .2, .05]), np.array([.25, .05, .2]), I, np.array([.1, .1, .05]), 1.0)
+    assert abs(d - 0.1) < 1e-15 and np.allclose(pos, [0.15, -0.05, 0.1], atol=1e-15) and np.allclose(n, [0, 0, 1])
+    # capsule parallel to a box face: midpoint of the stretch of the axis over the face ([.05, .35] ∩ [−.3, .3] → .175)
+    (d, pos, n), = mj._capsule_box(np.array([.2, 0, .3]), Rx, np.array([.04, .15, 0]), np.zeros(3), I, np.array([.3, .2, .05]), 1.0)
+    assert abs(d - 0.21) < 1e-15 and np.allclose(pos, [0.175, 0.0, 0.155], atol=1e-15)
+    # parallel capsules: the two ends of the overlapping stretch ([−.15, .15] ∩ [−.1, .3]), the first kept
+    cons = mj._capsule_capsule(np.array([0, 0, .3]), Rx, np.array([.04, .15, 0]), np.array([.1, 0, 0]), Rx, np.array([.05, .2, 0]), 1.0)
+    assert len(cons) == 2 and np.allclose(cons[0][1], [0.15, 0, 0.155]) and np.allclose(cons[1][1], [-0.1, 0, 0.155])
+    assert min(cons, key=lambda c: c[0]) is cons[0]
+    # the device on the same three configurations (three slides + a ball joint: G's angular columns carry the witness point;
+    # a free body directly under the world would be filtered out as parent and child, collision_avoidance_limit.py:85-106)
+    m = mink.loads_mjcf(TIE_SCENE)
+    q = np.array([[.25, .05, .2, 1, 0, 0, 0], [.2, 0, .3, 1, 0, 0, 0], [0, 0, .3, 1, 0, 0, 0]], dtype=np.float64)
+    pairs = [(["brick"], ["slab"]), (["rod"], ["slab"]), (["rod"], ["rail"])]
+    for i, pr in enumerate(pairs):
+        col = mink.CollisionAvoidanceLimit(m, [pr], collision_detection_distance=0.5)
+        G, h = col.compute_qp_inequalities(mink.Configuration(m, q[i:i + 1]), 0.1)
+        spec = oik.CollisionAvoidanceLimitSpec(col.geom_id_pairs, collision_detection_distance=0.5)
+        G_ref, h_ref = oik.limit_inequalities(oik.Configuration(m, q[i]), spec, 0.1)
+        assert np.isfinite(h_ref).all() and np.abs(G_ref[0, 3:]).max() > 1e-3      # the lever arm is visible in the row
+        np.testing.assert_allclose(h[0], h_ref, rtol=0, atol=1e-12)
+        np.testing.assert_allclose(G[0], G_ref, rtol=0, atol=1e-12)
