@@ -416,7 +416,8 @@ __device__ __forceinline__ LdsLayout kernel_lds_layout(const PT& P0) {
                     kWood ? P0.n_jrows + 1 : 6, kWood ? NR : j_stride_direct(P0.nv, NT),
                     (kWood && !wood_s_aliases_dof(P0.nv, P0.n_jrows, lds_even(P0.n_jrows), P0.n_com > 0 ? P0.nbody : 0))
                         ? P0.n_jrows * (lds_even(P0.n_jrows) + 1) : 0,
-                    kernel_prefetch(P0), kCompact || (kWood && P0.wood_compact != 0), kWood, P0.n_hsel);
+                    kernel_prefetch(P0), kCompact || (kWood && P0.wood_compact != 0), kWood,
+                    (FEAT & F_COLL) ? P0.n_hsel : 0);       // (a compile-time 0 without collision rows: one value less to keep)
 }
 __device__ MKH_PRE_ATTR PreOut pre_phases(const DeviceProblem* Pq, const TapArgs* tp, int pb, int oz, int off_q, int off_tgt,
                                           bool until, double pos_thr, double ori_thr MKH_PRE_TC_PARAMS) {

@@ -71,7 +71,6 @@ struct DeviceProblem {
   int32_t nq, nv, nbody, njnt, nrounds;
   int32_t n_frame, n_posture, n_com, n_cfg, n_vel, n_pairs, n_rows_tap;
   int32_t max_rows;      // tableau rows reserved for half-spaces (ntab = nv + max_rows)
-  int32_t n_hsel;        // n_pairs when there are more pairs than rows (LDS for the h of every pair: row selection), else 0
   int32_t n_jrows;       // weighted Jacobian rows staged in LDS (Σ nonzero-cost rows of frame + CoM tasks)
   // low-rank start: lane l computes rows [wood_row0[l], +wood_rpc) of column wood_col[l] of Jh·Jhᵀ
   // (row n_jrows = the right-hand side); −1 = idle lane
@@ -124,6 +123,9 @@ struct DeviceProblem {
   double dense_lm[kMaxDenseTasks];
   const double* dense_cost;        // [n_dense_rows] cost of each row
   const double* dense_wgain;       // [n_dense_rows] cost·(−gain) of each row: weighted error = wgain·e
+  // (appended last: the offsets of the fields above are what the register allocation of the W3 builds was tuned on —
+  //  one int32 in the middle cost the headline kernel 25 spilled VGPRs)
+  int32_t n_hsel;        // n_pairs when there are more pairs than rows (LDS for the h of every pair: row selection), else 0
 };
 
 struct SolveArgs {

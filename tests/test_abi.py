@@ -66,3 +66,22 @@ def test_compiler_stays_below_the_vgpr_cap(lib):
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count(" ok ") == 8, out.stdout
+
+
+def test_production_kernels_do_not_spill_vector_registers():
+    """mink_amd/kernel_resources.json (the compiler's own remarks, written at build time): the kernels behind the BASELINE
+    configs must stay free of VGPR spills.  The register allocation of the one-more-wave builds is fragile — an int32 added
+    in the middle of DeviceProblem once cost the headline kernel 25 spilled VGPRs and 2 % without any test noticing."""
+    import json
+    from mink_amd.csrc import build as hipbuild
+
+    with open(hipbuild.RESOURCES) as fh:
+        table = json.load(fh)
+    limits = {"ik_solve_kernel_44_32_r44_w3": 0,      # G1 config 3 (headline)
+              "ik_solve_kernel_8_0": 0,               # UR5e config 2 at its own batch
+              "ik_solve_kernel_44_36_r44": 0,         # G1 full example
+              "ik_solve_kernel_44_0": 0, "ik_solve_kernel_48_256": 0,
+              "ik_solve_kernel_64_72": 12}            # Shadow config 4 (a dozen cold spills outside the QP loops)
+    for k, cap in limits.items():
+        assert k in table, k
+        assert table[k]["vgpr_spills"] <= cap, (k, table[k])
