@@ -354,9 +354,15 @@ enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL =
 struct PreOut { int status, d_kind, d_k, d_body, d_qadr, conv; double mu_lane; V3 com_root; };
 #ifdef MKH_CALLS
 #define MKH_PRE_ATTR __attribute__((noinline))
+#ifdef MKH_CLOCKS     // experiment builds: the callee stamps slots 20.. of the problem's (B, 24) clock row itself
+#define MKH_PRE_TC_PARAMS , long long* clk_row
+#define MKH_PRE_TC_ARGS , (A.clk ? A.clk + (size_t)pb * 24 + 20 : nullptr)
+#define MKH_PRE_TICK() do { if (clk_row) { *clk_row = __builtin_readcyclecounter(); ++clk_row; } asm volatile("" : "+v"(lane)); } while (0)
+#else
 #define MKH_PRE_TC_PARAMS
 #define MKH_PRE_TC_ARGS
 #define MKH_PRE_TICK() do { asm volatile("" : "+v"(lane)); } while (0)
+#endif
 #else
 #define MKH_PRE_ATTR __forceinline__
 #define MKH_PRE_TC_PARAMS , long long (&tc)[8], int& tci
@@ -1852,7 +1858,12 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       pred_beta = (pred == 2) ? hi : ((pred == 1) ? lo : 0.0);
     }
     if constexpr (kWood) {
-#ifdef MKH_WOOD_CALL
+#if defined(MKH_WOOD_CALL) && defined(MKH_CLOCKS)
+      if (A.clk && lane == 0) A.clk[(size_t)pb * 24 + 16] = __builtin_readcyclecounter();          // [16] entry, [17] J rows, [18] S / w
+      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta, lo, hi,
+                      A.clk ? A.clk + (size_t)pb * 24 + 17 : nullptr);
+      if (A.clk && lane == 0) A.clk[(size_t)pb * 24 + 19] = __builtin_readcyclecounter();          // [19] back in the kernel
+#elif defined(MKH_WOOD_CALL)
       wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta, lo, hi);
 #else
       long long wprof[2] = {0, 0};
@@ -2397,7 +2408,11 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       for (int i = 0; i < 6; ++i) x = (lane == 8 + i) ? ta[i] : x;
       if (lane == 14) x = tj;
       if (lane == 15) x = 0;
+#ifdef MKH_CLOCKS
+      MKH_CLK[(size_t)pb * 24 + lane] = x;
+#else
       MKH_CLK[(size_t)pb * 16 + lane] = x;
+#endif
     }
     if (MKH_TAP(t_qp_iters) && lane == 0) MKH_TAP(t_qp_iters)[pb] = (kRows ? iters : n_piv) | (n_loop << 10) | (n_piv << 20);
     if (kColl && rows_dropped && !(status & 14)) {

@@ -943,15 +943,15 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   // synchronous and writes its (B, 16) cycle stamps to <file> — phase profile of kernels that cannot be tapped
   static const char* const clk_path = getenv("MKH_DEBUG_CLOCKS");
   if (clk_path) {
-    if (!p->d_clk) HIP_OK(hipMalloc((void**)&p->d_clk, (size_t)p->max_batch * 16 * sizeof(long long)));
-    HIP_OK(hipMemsetAsync(p->d_clk, 0, (size_t)a.B * 16 * sizeof(long long), stream));
+    if (!p->d_clk) HIP_OK(hipMalloc((void**)&p->d_clk, (size_t)p->max_batch * 24 * sizeof(long long)));
+    HIP_OK(hipMemsetAsync(p->d_clk, 0, (size_t)a.B * 24 * sizeof(long long), stream));
     al.clk = p->d_clk;
   }
   if (mkh::launch_variant(nt, nr, feat, w3, grid, lds, stream, p->d_dev, al, dtaps) != 0)
     return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
   HIP_OK(hipGetLastError());
   if (clk_path) {
-    std::vector<long long> h((size_t)a.B * 16);
+    std::vector<long long> h((size_t)a.B * 24);
     HIP_OK(hipMemcpyAsync(h.data(), p->d_clk, h.size() * sizeof(long long), hipMemcpyDeviceToHost, stream));
     HIP_OK(hipStreamSynchronize(stream));
     if (FILE* f = fopen(clk_path, "wb")) { fwrite(h.data(), sizeof(long long), h.size(), f); fclose(f); }

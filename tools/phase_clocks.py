@@ -42,7 +42,7 @@ def run(name, B=None):
     for _ in range(3):
         prob.solve(*args, dense=dn)
     torch.cuda.synchronize()
-    c = np.fromfile(path, dtype=np.int64).reshape(-1, 16)[:B]
+    c = np.fromfile(path, dtype=np.int64).reshape(-1, 24)[:B]
     ok = c[:, 0] != 0
     c = c[ok]
     tot = c[:, 7] - c[:, 0]
@@ -61,6 +61,13 @@ def run(name, B=None):
         sub = ["low-rank: J rows", "low-rank: S, w", "low-rank: elimination", "low-rank: rank-1 dof block (+publish)", "ratio test", "pivot"]
     for k, n in enumerate(sub):
         print("      %-36s mean %8.0f" % (n, c[:, 8 + k].mean()))
+    if (c[:, 20] != 0).any():                   # callee builds: pre_phases stamps its own phases
+        print("      pre_phases: FK %8.0f | axes / dof / com %8.0f | task lanes %8.0f" % (
+            (c[:, 20] - c[:, 0]).mean(), (c[:, 21] - c[:, 20]).mean(), (st[:, 3] - c[:, 21]).mean()))
+    if (c[:, 16] != 0).any():
+        print("      wood_start: posture / box %8.0f | J rows %8.0f | S, w %8.0f | elimination %8.0f | then rank-1 block … to tick 4: %8.0f" % (
+            (c[:, 16] - st[:, 3]).mean(), (c[:, 17] - c[:, 16]).mean(), (c[:, 18] - c[:, 17]).mean(), (c[:, 19] - c[:, 18]).mean(),
+            (st[:, 4] - c[:, 19]).mean()))
     prob.close()
 
 
