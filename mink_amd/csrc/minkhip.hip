@@ -836,6 +836,14 @@ static int grid_for(const MkhProblem* p, int B) {
   int g = p->model->num_cus * p->blocks_per_cu;
   return B < g ? B : g;
 }
+// LDS bytes of the plain (direct-start) layout of this problem with an nt-row tableau (the kernel computes the same layout
+// from its own NT: ik_kernel.h kernel_lds_layout)
+static int lds_for_nt(const MkhProblem* p, int nt) {
+  const DeviceProblem& P = p->dev;
+  return lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, 6, j_stride_direct(P.nv, nt), 0,
+                    P.prefetch != 0, false, false, P.n_hsel).total * (int)sizeof(double);
+}
+
 static int grid_for_variant(const MkhProblem* p, int B, int nt, int lds, bool w3 = false) {
   int wpc = waves_per_cu(nt, lds, w3);
   // diagnostic: cap the resident waves per CU (occupancy experiments); never raises it
@@ -904,6 +912,20 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   else feat = (need & F_TAPS) ? F_ALL : (F_ALL & ~F_TAPS);
   const bool rich = (feat & (F_ALL & ~F_STEPS)) != 0;
   int nt = rich ? p->nt_full : p->nt, nr = 0, lds = rich ? p->lds_bytes_full : p->lds_bytes;
+  // Builds whose register-hungry phases are real calls (ik_kernel.h MKH_CALLS: FEAT 8 / 136 / 30) do not need the 256-register
+  // map of a 32-row tableau for the compiler's sake: a small arm keeps a small tableau (UR5e + 2 collision rows: phase 0 on
+  // 32 rows was a third of the solve) — at least `calls_nt_min` rows, so that the callees still find a usable register file
+  // Measured (UR5e + 2 collision rows, 4 096 instances): analytic pairs 0.060 ms on 32 rows, 0.049 on 16 and on 8; with a
+  // cylinder–box pair on the general convex routine 0.174 ms on 32 rows, 0.213 on 16, 0.372 on 8 — GJK wants the 256-register
+  // file of the 2-waves map, so those builds keep 32.
+  static const int dbg_min = getenv("MKH_DEBUG_CALLS_NT") ? atoi(getenv("MKH_DEBUG_CALLS_NT")) : 0;
+  const int calls_nt_min = dbg_min ? dbg_min : 16;
+  const bool calls = feat == F_COLL || feat == (F_ALL & ~F_TAPS) || (dbg_min && feat == (F_COLL | F_CONVEX_COLL));
+  if (calls && p->nt < 32) {
+    static const int kV[] = {8, 16, 24, 32};
+    for (int v : kV) if (v >= p->nt && v >= calls_nt_min) { nt = v; break; }
+    lds = nt == p->nt ? p->lds_bytes : lds_for_nt(p, nt);
+  }
   // Low-rank start when the problem qualifies and the diagonal part of H is not tiny against JwᵀJw
   // (error amplification of the quasi-definite elimination ≈ eps·max cost²/min Dg ≤ 1e-9).
   const double dg_min = a.damping + p->wood_min_diag;

@@ -115,6 +115,10 @@ BENCH_CONFIGS: Dict[str, dict] = {
                                 "CYLINDER (menagerie's eef_collision class): FrameTask + ConfigurationLimit + "
                                 "CollisionAvoidanceLimit(cylinder-plane floor, cylinder-box wall: general convex routine) + "
                                 "VelocityLimit, dt=5e-2, damping=1e-3"},
+    # the same set-up with the packaged model's CAPSULE wrist geom (analytic pairs only): the reference point of ur5e_convex
+    "ur5e_coll": {"robot": "ur5e", "key": "home", "batch": 4096, "bytes_per_solve": 6 * 8 + 7 * 8 + 6 * 8 + 4,
+                  "workload": "UR5e, the collision set-up of examples/arm_ur5e.py:20-47 (capsule-plane floor, capsule-box wall), "
+                              "dt=5e-2, damping=1e-3"},
 }
 
 
@@ -169,7 +173,7 @@ def bench_config(name: str, model: FlatModel, nmodel: "nat.NativeModel", max_bat
                                  dense_tasks=[{"cost": np.full(3, 50.0), "gain": 1.0, "lm_damping": 0.0}],
                                  dense_limit_rows=2, max_batch=max_batch)
         return prob, 5e-3, 1e-1
-    if name == "ur5e_convex":
+    if name in ("ur5e_convex", "ur5e_coll"):
         from .limits import CollisionAvoidanceLimit
 
         col = CollisionAvoidanceLimit(model, [(["wrist_3_link"], ["floor", "wall"])], collision_detection_distance=0.3)
@@ -217,7 +221,7 @@ def bench_batch(name: str, model: FlatModel, nmodel, prob, rng: np.random.Genera
         return q, tg, q2[:, None, :].copy(), None
     if c["robot"] == "shadow_left":
         q[::2] = 0.5 * (q[::2] + base)            # half of the samples near the grasp: fingers come close
-    if name == "ur5e_convex":
+    if name in ("ur5e_convex", "ur5e_coll"):
         q[::2] = base + rng.normal(scale=0.4, size=q[::2].shape)     # half of the samples around `home`: near wall and floor
     com = None
     if prob.n_com:

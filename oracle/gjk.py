@@ -18,6 +18,7 @@ import numpy as np
 
 GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = 0, 2, 3, 4, 5, 6, 7
 MAX_ITERS = 128
+PEN_MAX_ITERS, PEN_MAX_HALVINGS, PEN_TOL = 40, 10, 1e-7      # overlapping shapes: only the sign and the direction are used
 
 
 def core_radius(gtype, size):
@@ -193,13 +194,13 @@ def penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2):
         if hc < h:
             h, s, d = hc, sc, c
     step = 1.0
-    for _ in range(MAX_ITERS):
+    for _ in range(PEN_MAX_ITERS):
         g = s - (s @ d) * d                            # gradient of d·s(d) on the sphere
         gn = np.sqrt(g @ g)
-        if gn < 1e-12 * max(1.0, abs(h)):
+        if gn < PEN_TOL * max(1.0, abs(h)):
             break
         ok = False
-        for _ in range(20):
+        for _ in range(PEN_MAX_HALVINGS):
             dn = d - (step / max(np.sqrt(s @ s), 1e-300)) * g
             dn = dn / np.sqrt(dn @ dn)
             hn, sn = h_and_s(dn)

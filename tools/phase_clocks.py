@@ -39,8 +39,9 @@ def run(name, B=None):
     to = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     args = (to(q), to(tg), to(pt if prob.n_posture else None), to(ct), dt, damping)
     dn = None if dense is None else {k: to(x) for k, x in dense.items()}
+    kw = {k: True for k in os.environ.get("MKH_PC_FLAGS", "").split(",") if k}      # e.g. MKH_PC_FLAGS=direct_qp,two_waves
     for _ in range(3):
-        prob.solve(*args, dense=dn)
+        prob.solve(*args, dense=dn, **kw)
     torch.cuda.synchronize()
     c = np.fromfile(path, dtype=np.int64).reshape(-1, 24)[:B]
     ok = c[:, 0] != 0
