@@ -94,28 +94,47 @@ def measured_traffic(config: str, B: int):
 
 
 def measured_valu_issue(config: str, B: int, waves_per_simd: int):
-    """What actually bounds the kernel: VALU issue.  From the same committed PMC summary as `traffic`
-    (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES of the solve dispatches): the share of a wave's cycles in which it issues
-    a VALU instruction, times the waves that share a SIMD for this kernel.  None without a summary."""
+    """What the kernel runs out of, from the same committed PMC summary as `traffic` (tools/profile.sh →
+    tools/rocprof_summary.py "derived"): VALU issue = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of a wave's cycles in which
+    it issues a VALU instruction) × the waves that share a SIMD; LDS pipe = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES (the CU's one
+    LDS index unit, bank-conflict replays included).  None without a summary."""
     js, src = _newest_pmc(config, B)
     try:
         k = js["ik_solve_kernel"]
-        skip = 0 if "solve_kernel" in js else 1          # (round-1 summaries list the FK-only setup launch first)
-        act = k["SQ_ACTIVE_INST_VALU"]["per_dispatch"][skip:]
-        cyc = k["SQ_WAVE_CYCLES"]["per_dispatch"][skip:]
-        per_wave = sum(act) / sum(cyc)
+        d = js.get("derived") or {}
+        per_wave = d.get("valu_active_per_wave_cycle")
+        if per_wave is None:                                 # summaries of rounds 1 and 2
+            skip = 0 if "solve_kernel" in js else 1          # (round-1 summaries list the FK-only setup launch first)
+            per_wave = sum(k["SQ_ACTIVE_INST_VALU"]["per_dispatch"][skip:]) / sum(k["SQ_WAVE_CYCLES"]["per_dispatch"][skip:])
         out = {"valu_active_share_of_wave_cycles": per_wave, "waves_per_simd": waves_per_simd,
                "simd_issue_slots_used": waves_per_simd * per_wave, "source": src}
-        try:
-            lds = k["SQ_ACTIVE_INST_LDS"]["per_dispatch"][skip:]
-            cy2 = k["SQ_WAVE_CYCLES"]["per_dispatch"][skip:]          # (the counters of one pass share its dispatches)
-            # every resident wave of the CU (4 SIMDs x waves/SIMD) feeds ONE LDS pipe
-            out["lds_pipe_busy_share"] = 4 * waves_per_simd * sum(lds) / sum(cy2)
-        except (KeyError, ZeroDivisionError):
-            pass
+        for key in ("lds_pipe_busy_per_cu_cycle", "lds_bank_conflict_per_lds_inst_active", "lds_bank_conflict_per_cu_cycle",
+                    "wait_any_per_wave_cycle", "any_inst_active_per_wave_cycle", "wait_inst_any_per_wave_cycle",
+                    "salu_cycles_per_wave_cycle"):
+            if d.get(key) is not None:
+                out[key] = d[key]
+        if d.get("wave_cycles_per_dispatch"):
+            out["per_solve"] = {"wave_quad_cycles": d["wave_cycles_per_dispatch"] / B,
+                                "valu_insts": (d.get("valu_insts_per_dispatch") or 0) / B,
+                                "salu_insts": (d.get("salu_insts_per_dispatch") or 0) / B,
+                                "lds_insts": (d.get("lds_insts_per_dispatch") or 0) / B}
         return out
     except (TypeError, KeyError, ZeroDivisionError):
         return None
+
+
+def binding_resource(valu):
+    """The busier of the two candidates the counters can name: the SIMDs' VALU issue slots and the CU's LDS pipe."""
+    if not valu:
+        return {"name": None, "frac": None, "source": None}
+    cands = {"valu_issue": valu["simd_issue_slots_used"]}
+    if valu.get("lds_pipe_busy_per_cu_cycle") is not None:
+        cands["lds_pipe"] = valu["lds_pipe_busy_per_cu_cycle"]
+    name = max(cands, key=cands.get)
+    return {"name": name, "frac": cands[name], "candidates": cands,
+            "counters": {"valu_issue": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves per SIMD",
+                         "lds_pipe": "SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES"},
+            "source": valu["source"]}
 
 
 def kernel_resources(kernel: str):
@@ -479,10 +498,7 @@ def main():
                 "algorithmic_bytes_per_solve": bps, "algorithmic_bytes_per_launch": bps * B,
                 # what the kernel really runs out of (PMC: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x resident waves
                 # per SIMD, from the committed summary of this workload); HBM is the contract's nominal bound
-                "binding_resource": {"name": "valu_issue", "counter": "SQ_ACTIVE_INST_VALU/SQ_WAVE_CYCLES x waves/SIMD",
-                                     "frac": valu["simd_issue_slots_used"] if valu else None,
-                                     "lds_pipe_busy_share": valu.get("lds_pipe_busy_share") if valu else None,
-                                     "source": valu["source"] if valu else None},
+                "binding_resource": binding_resource(valu),
                 "note": "not HBM bound by design (one QP per wavefront / lane): fp64 VALU issue + the serial latency of a pivot "
                         "(round 1's LDS-return-bandwidth bound on the rank-1 updates was removed in round 2, "
                         "profiles/r02_ubench_rank1_mix.txt); HBM fraction reported as the contract requires",

@@ -77,6 +77,31 @@ def pmc(out_path, dirs):
     if len(hbm) == 2:
         hbm["traffic_bytes_per_launch"] = hbm["FETCH_SIZE"]["bytes_per_launch"] + hbm["WRITE_SIZE"]["bytes_per_launch"]
     summary["hbm"] = hbm
+    # Shares that say what the kernel waits for / runs out of (sums over the solve dispatches; a ratio is only formed from
+    # counters of ONE pass, or against SQ_WAVE_CYCLES of the same workload, which every SQ pass of tools/profile.sh carries).
+    def tot(c):      # mean per dispatch (a counter collected in two passes lists twice as many dispatches)
+        return float(sum(ik[c])) / len(ik[c]) if c in ik and ik[c] else None
+
+    def ratio(a, b):
+        x, y = tot(a), tot(b)
+        return (x / y) if (x is not None and y) else None
+
+    summary["derived"] = {
+        "valu_active_per_wave_cycle": ratio("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES"),
+        "any_inst_active_per_wave_cycle": ratio("SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES"),
+        "wait_any_per_wave_cycle": ratio("SQ_WAIT_ANY", "SQ_WAVE_CYCLES"),
+        "wait_inst_any_per_wave_cycle": ratio("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES"),
+        "lds_inst_active_per_wave_cycle": ratio("SQ_ACTIVE_INST_LDS", "SQ_WAVE_CYCLES"),
+        "wait_inst_lds_per_wave_cycle": ratio("SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES"),
+        "salu_cycles_per_wave_cycle": ratio("SQ_INST_CYCLES_SALU", "SQ_WAVE_CYCLES"),
+        "lds_bank_conflict_per_lds_inst_active": ratio("SQ_LDS_BANK_CONFLICT", "SQ_ACTIVE_INST_LDS"),
+        # the CU's one LDS pipe: cycles its index unit is busy (bank-conflict replays included) per busy CU cycle
+        "lds_pipe_busy_per_cu_cycle": ratio("SQ_LDS_IDX_ACTIVE", "SQ_BUSY_CU_CYCLES"),
+        "lds_bank_conflict_per_cu_cycle": ratio("SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CU_CYCLES"),
+        "lds_addr_conflict_per_lds_idx_active": ratio("SQ_LDS_ADDR_CONFLICT", "SQ_LDS_IDX_ACTIVE"),
+        "wave_cycles_per_dispatch": tot("SQ_WAVE_CYCLES"), "valu_insts_per_dispatch": tot("SQ_INSTS_VALU"),
+        "salu_insts_per_dispatch": tot("SQ_INSTS_SALU"), "lds_insts_per_dispatch": tot("SQ_INSTS_LDS"),
+    }
     with open(out_path, "w") as fh:
         json.dump(summary, fh, indent=1)
     print(json.dumps(hbm, indent=1))
