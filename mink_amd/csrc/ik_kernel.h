@@ -1341,37 +1341,9 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
     }
     return rank;
   };
-  if (mode != 0) {
-    // the contacts that found no tableau row: G·Δq ≤ h at the solution?  (G·Δq = −nᵀ(ṗ₂(to) − ṗ₁(from)) for joint
-    // displacements Δq, the dofs of each geom's chain only)
-    bool viol = false;
-    for (int base = 0; base < n_pairs; base += 64) {
-      const int pi = base + lane;
-      if (pi < n_pairs) {
-        const double hs = sH[pi];
-        if (hs < kInf && rank_of(pi, hs) >= max_rows) {
-          double hk;
-          V3 nrm{1, 0, 0}, from{0, 0, 0}, to{0, 0, 0};
-          uint64_t m1 = 0, m2 = 0;
-          if (contact_of(pi, hk, nrm, from, to, m1, m2)) {
-            V3 vel{0, 0, 0};
-            for (uint64_t mm = m1 | m2; mm; mm &= mm - 1) {
-              const int d = __builtin_ctzll(mm);
-              const double* dd = sDof + d * 10;
-              const V3 a_ang{dd[0], dd[1], dd[2]}, a_lin{dd[3], dd[4], dd[5]}, a_anchor{dd[6], dd[7], dd[8]};
-              const double dq = dd[9];
-              if ((m2 >> d) & 1) vel = vel + dq * (a_lin + cross(a_ang, to - a_anchor));
-              if ((m1 >> d) & 1) vel = vel - dq * (a_lin + cross(a_ang, from - a_anchor));
-            }
-            viol = viol || (-dot(nrm, vel) > hk + 1e-9 * (1.0 + fabs(hk)));
-          }
-        }
-      }
-    }
-    return __ballot(viol) ? 1 : 0;
-  }
+  // ONE call site of contact_of for both modes (the distance routines — the general convex one above all — are inlined once)
   int nrows = 0, status = 0;
-  bool rows_dropped = false;
+  bool rows_dropped = false, viol = false;
   for (int pass = 0; pass < 2; ++pass) {
     nrows = 0;
     for (int base = 0; base < n_pairs; base += 64) {
@@ -1380,8 +1352,29 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
       double hk = kInf;
       V3 nrm{1, 0, 0}, from{0, 0, 0}, to{0, 0, 0};
       uint64_t m1 = 0, m2 = 0;
+      bool want = pi < n_pairs;
+      if (mode != 0 && want) {                               // mode 1: only the contacts that found no tableau row
+        const double hs = sH[pi];
+        want = hs < kInf && rank_of(pi, hs) >= max_rows;
+      }
+      if (want) active = contact_of(pi, hk, nrm, from, to, m1, m2);
+      if (mode != 0) {
+        // G·Δq ≤ h at the solution?  (G·Δq = −nᵀ(ṗ₂(to) − ṗ₁(from)) for joint displacements Δq, the dofs of each geom's chain)
+        if (active) {
+          V3 vel{0, 0, 0};
+          for (uint64_t mm = m1 | m2; mm; mm &= mm - 1) {
+            const int d = __builtin_ctzll(mm);
+            const double* dd = sDof + d * 10;
+            const V3 a_ang{dd[0], dd[1], dd[2]}, a_lin{dd[3], dd[4], dd[5]}, a_anchor{dd[6], dd[7], dd[8]};
+            const double dq = dd[9];
+            if ((m2 >> d) & 1) vel = vel + dq * (a_lin + cross(a_ang, to - a_anchor));
+            if ((m1 >> d) & 1) vel = vel - dq * (a_lin + cross(a_ang, from - a_anchor));
+          }
+          viol = viol || (-dot(nrm, vel) > hk + 1e-9 * (1.0 + fabs(hk)));
+        }
+        continue;
+      }
       if (pi < n_pairs) {
-        active = contact_of(pi, hk, nrm, from, to, m1, m2);
         if (pass == 0) {
           if (can_select) sH[pi] = hk;
           if (MKH_TAP(t_coll_h)) MKH_TAP(t_coll_h)[(size_t)pb * n_pairs + pi] = hk;
@@ -1415,6 +1408,7 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
       }
       nrows += __popcll(am);
     }
+    if (mode != 0) return __ballot(viol) ? 1 : 0;
     if (pass == 0 && can_select && nrows > max_rows) { rows_dropped = true; wave_sync(); continue; }   // select, then refill
     break;
   }

@@ -37,19 +37,21 @@ def main():
 
     cfg = workloads.BENCH_CONFIGS[config]
     B = int(sys.argv[2]) if len(sys.argv) > 2 and int(sys.argv[2]) > 0 else cfg["batch"]
-    model = workloads.load_robot(cfg["robot"])
+    model = workloads.load_bench_robot(config)
     nm = nat.NativeModel(model, device=0)
     prob, dt, damping = workloads.bench_config(config, model, nm, B)
     rng = np.random.default_rng(1000)
     q_h, tg_h, pt_h, ct_h = workloads.bench_batch(config, model, nm, prob, rng, B)
     q = torch.from_numpy(q_h).to(dev)
     tg = torch.from_numpy(tg_h).to(dev)
-    pt = torch.from_numpy(pt_h).to(dev)
+    pt = torch.from_numpy(pt_h).to(dev) if prob.n_posture else None
     ct = None if ct_h is None else torch.from_numpy(ct_h).to(dev)
+    dense_h = workloads.bench_dense(config, model, nm, q_h, rng)
+    dense = None if dense_h is None else {k: torch.from_numpy(np.ascontiguousarray(x)).to(dev) for k, x in dense_h.items()}
     v = torch.empty((B, model.nv), dtype=torch.float64, device=dev)
     st = torch.empty((B,), dtype=torch.int32, device=dev)
     for _ in range(n):
-        prob.solve(q, tg, pt, ct, dt, damping, out=v, status_out=st)
+        prob.solve(q, tg, pt, ct, dt, damping, out=v, status_out=st, dense=dense)
     torch.cuda.synchronize()
 
 
