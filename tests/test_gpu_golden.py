@@ -246,3 +246,64 @@ def test_production_kernel_against_2048_real_mink_instances(nat):
     for r in range(R):
         np.testing.assert_array_equal(vR[r * B:(r + 1) * B], v)
         assert (stR[r * B:(r + 1) * B] == st).all()
+
+
+@pytest.mark.parametrize("name", ["aloha_coll", "shadow_tips"])
+def test_mesh_dependent_collision_setups_against_real_mink(nat, name):
+    """tests/golden/make_golden_mesh.py: the REAL mink on the two set-ups whose collision geoms come from mesh assets —
+    examples/arm_aloha.py:76-121 as written (1 104 pairs of mesh-fitted capsules, filtered by mink's own constructor out of
+    whole subtrees) and the Shadow hand's `*_3` fingertips + forearm MESH geom.  Same pair list in the same order, h of every
+    pair, the rows of G, v."""
+    import mink_amd as mink
+    from mink_amd.flatmodel import FlatModel
+    d = _golden(name)
+    scene = {"aloha_coll": "aloha__scene", "shadow_tips": "shadow_hand__scene_left"}[name]
+    m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", scene + ".json"))
+    B = len(d["q"])
+    cfg = mink.Configuration(m, d["q"])
+    if name == "aloha_coll":
+        sites, post_cost = ["left/gripper", "right/gripper"], 1e-4
+        lw = mink.get_subtree_geom_ids(m, m.body("left/wrist_link").id); rw = mink.get_subtree_geom_ids(m, m.body("right/wrist_link").id)
+        lg = mink.get_subtree_geom_ids(m, m.body("left/upper_arm_link").id); rg = mink.get_subtree_geom_ids(m, m.body("right/upper_arm_link").id)
+        fg = mink.get_body_geom_ids(m, m.body("metal_frame").id)
+        col = mink.CollisionAvoidanceLimit(m, [(lw, rw), (lg + rg, fg + ["table"])], minimum_distance_from_collisions=0.05,
+                                           collision_detection_distance=0.1)
+        vel = mink.VelocityLimit(m, {f"{p}/{n}": np.pi for p in ("left", "right")
+                                     for n in ("waist", "shoulder", "elbow", "forearm_roll", "wrist_angle", "wrist_rotate")})
+        lims = [mink.ConfigurationLimit(m), vel, col]
+        fts = [mink.FrameTask(s, "site", 1.0, 1.0, lm_damping=1.0) for s in sites]
+        tasks_order = lambda fts, post: fts + [post]
+    else:
+        sites, post_cost = list(oc.SHADOW_FINGERS), 1e-2
+        fore = [g for g in range(m.ngeom) if m.geom_type[g] == 7 and m.geom_dataid[g] >= 0]
+        tips, mids = [f"{f}_3" for f in sites], [f"{f}_2" for f in sites]
+        col = mink.CollisionAvoidanceLimit(m, [(tips, tips), (tips, mids), (tips, fore)], minimum_distance_from_collisions=0.004,
+                                           collision_detection_distance=0.06)
+        lims = [mink.ConfigurationLimit(m), col]
+        fts = [mink.FrameTask(s, "site", 1.0, 0.0, lm_damping=1.0) for s in sites]
+        tasks_order = lambda fts, post: [post] + fts
+    np.testing.assert_array_equal(np.array(col.geom_id_pairs), d["geom_id_pairs"])      # mink's constructor, pair for pair
+    for k, t in enumerate(fts):
+        t.set_target(mink.SE3(d["frame_targets"][:, k]))
+    post = mink.PostureTask(m, cost=post_cost); post.set_target(d["posture_target"])
+    tasks = tasks_order(fts, post)
+    dt, damping = float(d["dt"]), float(d["damping"])
+    G, h = col.compute_qp_inequalities(cfg, dt)
+    n_box = d["h"].shape[1] - len(col.geom_id_pairs)
+    h_ref = d["h"][:, n_box:] if name == "shadow_tips" else d["h"][:, -len(col.geom_id_pairs):]
+    fin = np.isfinite(h_ref)
+    assert (np.isfinite(h) == fin).all()
+    np.testing.assert_allclose(h[fin], h_ref[fin], rtol=0, atol=1e-9 * max(1.0, np.abs(h_ref[fin]).max()))
+    G_ref = d["G"][:, n_box:] if name == "shadow_tips" else d["G"][:, -len(col.geom_id_pairs):]
+    mesh_rows = np.array([m.geom_type[a] == 7 or m.geom_type[b] == 7 for a, b in col.geom_id_pairs])
+    nG = len(G_ref)
+    np.testing.assert_allclose(G[:nG][:, ~mesh_rows], G_ref[:, ~mesh_rows], rtol=0, atol=1e-9)      # analytic pairs
+    if mesh_rows.any():
+        np.testing.assert_allclose(G[:nG][:, mesh_rows], G_ref[:, mesh_rows], rtol=0, atol=2e-5)  # GJK: direction to ~1e-6
+    prob = mink.build_ik(cfg, tasks, dt, damping, lims)
+    np.testing.assert_allclose(prob.P, d["H"], rtol=0, atol=1e-11 * np.abs(d["H"]).max())
+    v, st = mink.solve_ik(cfg, tasks, dt, "mi355x", damping, limits=lims, return_status=True)
+    assert (st & ~1 == 0).all(), st
+    err = np.abs(v - d["v"]).max(axis=1) / np.maximum(1.0, np.abs(d["v"]).max(axis=1))
+    print(name, "pairs", len(col.geom_id_pairs), "contacts per instance", fin.sum(axis=1).tolist(), "max rel v err %.2e" % err.max())
+    assert err.max() < (1e-8 if not mesh_rows.any() else 5e-6)

@@ -97,3 +97,41 @@ def test_round2_fixtures(golden_dir, name):
         np.testing.assert_allclose(e, d["task_e"][i], rtol=0, atol=1e-13)
         v = ik.solve_ik(m, cfg, tasks, dt, damping, limits)
         np.testing.assert_allclose(v, d["v"][i], rtol=0, atol=1e-9 * max(1.0, np.abs(d["v"][i]).max()))
+
+
+@pytest.mark.parametrize("name,scene", [("aloha_coll", "aloha__scene"), ("shadow_tips", "shadow_hand__scene_left")])
+def test_oracle_vs_real_mink_on_the_mesh_dependent_collision_setups(golden_dir, name, scene):
+    """tests/golden/make_golden_mesh.py (the real mink: 1 104 ALOHA pairs of mesh-fitted capsules; Shadow fingertips + forearm
+    mesh): the numpy oracle's own pipeline — its limit rows and its Goldfarb–Idnani solve — against mink's Python on the same
+    model and the same distance routine."""
+    from mink_amd.flatmodel import FlatModel
+    d = np.load(os.path.join(golden_dir, f"ik_{name}.npz"))
+    m = FlatModel.load(os.path.join(golden_dir, "models", "all", scene + ".json"))
+    dt, damping = float(d["dt"]), float(d["damping"])
+    if name == "aloha_coll":
+        names = ["left/gripper", "right/gripper"]
+        mk = lambda i: [ik.FrameTaskSpec(m.name2id("site", s), "site", np.ones(6), d["frame_targets"][i, k], 1.0, 1.0) for k, s in enumerate(names)] + \
+            [ik.PostureTaskSpec(np.full(m.nv, 1e-4), d["posture_target"])]
+        vidx = [int(m.jnt_dofadr[m.name2id("joint", f"{p}/{n}")]) for p in ("left", "right")
+                for n in ("waist", "shoulder", "elbow", "forearm_roll", "wrist_angle", "wrist_rotate")]
+        col = ik.CollisionAvoidanceLimitSpec([tuple(p) for p in d["geom_id_pairs"]], minimum_distance_from_collisions=0.05,
+                                             collision_detection_distance=0.1)
+        limits = [ik.ConfigurationLimitSpec(), ik.VelocityLimitSpec(np.array(vidx), np.full(12, np.pi)), col]
+    else:
+        names = ["thumb", "first", "middle", "ring", "little"]
+        mk = lambda i: [ik.PostureTaskSpec(np.full(m.nv, 1e-2), d["posture_target"])] + \
+            [ik.FrameTaskSpec(m.name2id("site", s), "site", np.array([1, 1, 1, 0, 0, 0.0]), d["frame_targets"][i, k], 1.0, 1.0) for k, s in enumerate(names)]
+        col = ik.CollisionAvoidanceLimitSpec([tuple(p) for p in d["geom_id_pairs"]], minimum_distance_from_collisions=0.004,
+                                             collision_detection_distance=0.06)
+        limits = [ik.ConfigurationLimitSpec(), col]
+    for i in (0, 5, 11):
+        cfg = ik.Configuration(m, d["q"][i])
+        P, c, G, h = ik.build_ik(cfg, mk(i), dt, damping, limits)
+        np.testing.assert_allclose(P, d["H"][i], rtol=0, atol=1e-12 * np.abs(d["H"][i]).max())
+        fin = np.isfinite(d["h"][i])
+        assert (np.isfinite(h) == fin).all()
+        np.testing.assert_allclose(h[fin], d["h"][i][fin], rtol=0, atol=1e-12 * max(1.0, np.abs(d["h"][i][fin]).max()))
+        if i < len(d["G"]):
+            np.testing.assert_allclose(G, d["G"][i], rtol=0, atol=1e-12)
+        v = ik.solve_ik(m, d["q"][i], mk(i), dt, damping, limits)
+        np.testing.assert_allclose(v, d["v"][i], rtol=0, atol=1e-8 * max(1.0, np.abs(d["v"][i]).max()))
