@@ -1,7 +1,8 @@
-// Instantiations of the lane-per-problem kernel (lane_kernel.h) and their launcher.
+// Instantiations of the lane-per-problem kernel (lane_kernel.h), the row-per-problem kernel (quad_kernel.h) and their launchers.
 #include <hip/hip_runtime.h>
 
 #include "lane_kernel.h"
+#include "quad_kernel.h"
 
 namespace mkh {
 
@@ -19,6 +20,11 @@ int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stre
   }
 #undef MKH_LANE_CASE
   return -1;
+}
+
+int launch_quad(int grid, hipStream_t stream, const LaneProblem* P, const SolveArgs& a) {
+  hipLaunchKernelGGL(ik_quad_kernel, dim3(grid), dim3(kWave), quad_lds_bytes(), stream, P, a);
+  return quad_lds_bytes();
 }
 
 }  // namespace mkh

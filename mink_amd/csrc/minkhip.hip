@@ -127,6 +127,8 @@ namespace mkh {
 int launch_variant(int nt, int nr, int feat, bool w3, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
                    const SolveArgs& a, const TapArgs* taps);
 int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);
+int launch_quad(int grid, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);   // returns its LDS bytes per wavefront
+constexpr int kLaneMinBatch = 49152;  // plain solves of a small arm: row kernel below, lane kernel from here (launch())
 }
 
 // Lane-per-problem descriptor (lane_kernel.h) of a problem that qualifies: nv ≤ 8, hinge / slide joints only,
@@ -139,7 +141,7 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
   const double inf = std::numeric_limits<double>::infinity();
   if (m->nv > kLaneMaxDofs || m->nq != m->nv) return 0;
   if (P.n_frame < 1 || P.n_frame > kLaneMaxFrames || has_relative || P.n_com || P.n_pairs || P.n_dense_rows ||
-      P.n_dense_limit_rows)
+      P.n_dense_limit_rows || P.dense_box)       // (dense_box: per-instance box rows of a plugin limit, wavefront kernels only)
     return 0;
   for (int j = 0; j < m->njnt; ++j)
     if (m->jnt_type[j] != JNT_HINGE && m->jnt_type[j] != JNT_SLIDE) return 0;
@@ -873,16 +875,29 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
     HIP_OK(hipStreamSynchronize(stream));   // taps are a debug path: keep the host struct's lifetime simple
     dtaps = p->d_taps;
   }
-  // Small arms (nv ≤ 8, box limits): one LANE per problem instead of one wavefront (lane_kernel.h) — 64 problems per
-  // wavefront with every lane busy.  Plain solves only (no taps / fused steps); MKH_FLAG_WAVE_KERNEL forces the
-  // wavefront kernel, MKH_FLAG_LANE_KERNEL this one (parity switches).  Default: by batch size.  A lane runs the whole
-  // problem as one dependent instruction stream (≈48 µs for a UR5e problem, whatever the batch), the wavefront kernel
-  // takes ≈38 µs for the 4 096 problems that fit the chip at once and ≈9 µs more per further 1 024: measured on
-  // MI355X the curves cross between 4 096 and 8 192 problems (UR5e config 2: 90 vs 73 M solves/s at 4 096,
-  // 152 vs 744 M/s at 65 536, 0.15 vs 2.65 G/s at 1 048 576).
-  if (p->lane_nv && !taps && a.do_qp && !(flags & MKH_FLAG_WAVE_KERNEL) &&
-      (a.B >= 8192 || (flags & MKH_FLAG_LANE_KERNEL))) {
-    const bool loop = a.n_steps > 1 || a.q_out || a.pos_threshold >= 0.0;     // fused caller loop (steps / until)
+  // Small arms (nv ≤ 8, hinge / slide joints, box limits) have two kernels of their own (plain solves without taps):
+  //   * a 16-lane ROW per problem (quad_kernel.h): four problems per wavefront, so 4 096 problems put one wavefront on
+  //     every SIMD and each problem still spreads its phases over its lanes.  Single solves only (no fused loop, no warm
+  //     start);
+  //   * one LANE per problem (lane_kernel.h): 64 problems per wavefront with every lane busy, one ≈48 µs dependent
+  //     instruction stream per problem whatever the batch — the best use of the machine once every SIMD has several
+  //     wavefronts to interleave.  Also the fused caller loop (steps / until) from 8 192 instances.
+  // Measured on MI355X, UR5e config 2, M solves/s (tools/bench_small_arm.py; wavefront / row / lane kernel):
+  //   B = 256: 12 / 16.5 / 7.6    4 096: 116 / 195 / 90    8 192: 128 / 319 / 151    32 768: 148 / 576 / 527
+  //   65 536: 153 / 627 / 855 — the row kernel up to kLaneMinBatch, the lane kernel beyond.
+  // MKH_FLAG_WAVE_KERNEL / _QUAD_KERNEL / _LANE_KERNEL force one of the three (parity switches).
+  const bool small_arm = p->lane_nv && !taps && a.do_qp && !(flags & MKH_FLAG_WAVE_KERNEL);
+  const bool loop = a.n_steps > 1 || a.q_out || a.pos_threshold >= 0.0;       // fused caller loop (steps / until)
+  if (small_arm && !loop && !(flags & (MKH_FLAG_WARM_START | MKH_FLAG_LANE_KERNEL)) &&
+      (a.B < mkh::kLaneMinBatch || (flags & MKH_FLAG_QUAD_KERNEL))) {
+    const int grid = (a.B + 3) / 4;
+    p->last_grid = grid; p->last_nt = 8;
+    snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_quad_kernel");
+    p->last_lds = mkh::launch_quad(grid, stream, p->d_lane, a);
+    HIP_OK(hipGetLastError());
+    return MKH_OK;
+  }
+  if (small_arm && (a.B >= (loop ? 8192 : mkh::kLaneMinBatch) || (flags & MKH_FLAG_LANE_KERNEL))) {
     const int grid = (a.B + kWave - 1) / kWave;
     p->last_grid = grid; p->last_lds = p->lane_lds; p->last_nt = p->lane_nv;
     snprintf(p->last_kernel, sizeof(p->last_kernel), loop ? "ik_lane_kernel_%d_loop" : "ik_lane_kernel_%d", p->lane_nv);

@@ -1,0 +1,369 @@
+// One 16-LANE ROW per problem: differential IK for small arms (nv ≤ 8, hinge / slide joints) at mid-size batches.
+//
+// The wavefront kernel (ik_kernel.h) gives a 6-dof arm 64 lanes of which 6-10 work; the lane kernel (lane_kernel.h)
+// gives it one lane, i.e. one ≈48 µs dependent instruction stream — right for ≥ 8 192 problems, where every SIMD
+// has several wavefronts to interleave, wrong for the 1 024-4 096 instances of a typical parallel-environment batch
+// (BASELINE.json configs[2] at its quoted batch): 4 096 problems are 64 lane-kernel wavefronts on 1 024 SIMDs.
+// Here a problem owns one DPP row (16 lanes) of a wavefront, four problems per wavefront, so that 4 096 problems put one
+// wavefront on every SIMD of the chip and each problem still spreads its work over its lanes:
+//
+//   lanes as LINKS   forward kinematics: local joint transforms, then world poses by pointer jumping up the parent
+//                    chain (⌈log₂ depth⌉ rounds through LDS instead of `depth` dependent compositions);
+//   lanes as TASKS   frame-task error, log / jlog and the two 3×3 blocks every Jacobian column needs (lie_dev.h — the same
+//                    functions the other two kernels run);
+//   lanes as DOFS    Jacobian columns, H = Σ JᵀW²J + (λ + Σμ)I one COLUMN per lane in eight registers, box limits, the QP.
+//
+// The 16-lane row is the unit the DPP operand network broadcasts in: `v_fmac_f64_dpp T[i], u, g row_newbcast:i` adds
+// u(lane i of MY row)·g to T[i] — a rank-1 update of four 8×8 matrices, one per row, in eight instructions without a
+// byte of LDS traffic.  H assembly, the pivots of the QP and its matrix-vector products are all that instruction.
+//
+// QP: the lane kernel's algorithm (block principal pivoting, Murty's rule once the block steps stop making progress) on
+// a SWEEP tableau instead of a fresh factorisation per iteration: sweeping index k in or out of the free set is one
+// principal pivot of the symmetric matrix [[H, c], [cᵀ, ·]]; with the free set swept, column j holds −x_j (free) or the
+// multiplier w_j (bound) as  ĉ_j + Σ_b T[b][j]·x_b  over the bound indices b.  Unique optimum of a strictly convex QP ⇒
+// quadprog's answer (tests/test_gpu_quad_kernel.py: against the wavefront kernel, the lane kernel and both oracles).
+// Same reference path: mink/solve_ik.py:68-105 and what it calls (see ik_kernel.h).
+#pragma once
+#include "lane_kernel.h"
+#include "wave_ops.h"
+
+namespace mkh {
+
+constexpr int kQuadRow = 16;                                  // lanes per problem
+constexpr int kQuadPerWave = kWave / kQuadRow;
+constexpr int kQuadPoseDoubles = 7 * kQuadRow;                // link poses [component][link]
+constexpr int kQuadAncDoubles = kQuadRow / 2;                 // ancestor index per link (int32)
+constexpr int kQuadTaskDoubles = 28;                          // per frame task: A1 (9), A2 (9), frame position (3), W·e (6), μ
+constexpr int kQuadRowDoubles = kQuadPoseDoubles + kQuadAncDoubles + kLaneMaxFrames * kQuadTaskDoubles;
+static_assert(kLaneMaxLinks <= kQuadRow && kLaneMaxDofs <= 8, "a problem must fit one DPP row");
+__host__ __device__ inline int quad_lds_bytes() { return kQuadPerWave * kQuadRowDoubles * (int)sizeof(double); }
+
+// ---------------------------------------------------------------- DPP row primitives (all 64 lanes must be active)
+// s_nop 4: a DPP operand must not be read within 5 wait states of an EXEC write (and 2 of a VALU write of that register)
+// by the compiler's code before the statement.
+#define MKH_QFMAC(D, I) "v_fmac_f64_dpp " D ", %[u], %[g] row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
+// T[i] += u(lane i of this row) · g
+__device__ __forceinline__ void quad_rank1(double (&T)[8], const double u, const double g) {
+  asm volatile("s_nop 4\n\t" MKH_QFMAC("%[t0]", 0) MKH_QFMAC("%[t1]", 1) MKH_QFMAC("%[t2]", 2) MKH_QFMAC("%[t3]", 3)
+               MKH_QFMAC("%[t4]", 4) MKH_QFMAC("%[t5]", 5) MKH_QFMAC("%[t6]", 6) MKH_QFMAC("%[t7]", 7)
+               : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [t4] "+v"(T[4]), [t5] "+v"(T[5]),
+                 [t6] "+v"(T[6]), [t7] "+v"(T[7])
+               : [u] "v"(u), [g] "v"(g));
+}
+#undef MKH_QFMAC
+// acc + Σ_i u(lane i of this row) · T[i]   (two accumulators: half the dependent chain)
+#define MKH_QDOT(A, I) "v_fmac_f64_dpp " A ", %[u], %[t" #I "] row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ double quad_dot(const double (&T)[8], const double u, const double acc) {
+  double a = acc, b = 0.0;
+  asm volatile("s_nop 4\n\t" MKH_QDOT("%[a]", 0) MKH_QDOT("%[b]", 1) MKH_QDOT("%[a]", 2) MKH_QDOT("%[b]", 3)
+               MKH_QDOT("%[a]", 4) MKH_QDOT("%[b]", 5) MKH_QDOT("%[a]", 6) MKH_QDOT("%[b]", 7)
+               : [a] "+v"(a), [b] "+v"(b)
+               : [u] "v"(u), [t0] "v"(T[0]), [t1] "v"(T[1]), [t2] "v"(T[2]), [t3] "v"(T[3]), [t4] "v"(T[4]), [t5] "v"(T[5]),
+                 [t6] "v"(T[6]), [t7] "v"(T[7]));
+  return a + b;
+}
+#undef MKH_QDOT
+// u of lane K of this row
+template <int K> __device__ __forceinline__ double quad_bcast(double u);
+#define MKH_QBCAST(K)                                                                                              \
+  template <> __device__ __forceinline__ double quad_bcast<K>(const double u) {                                     \
+    double r = 0.0;                                                                                                 \
+    asm volatile("s_nop 4\n\tv_fmac_f64_dpp %[r], %[u], %[one] row_newbcast:" #K " row_mask:0xf bank_mask:0xf"     \
+                 : [r] "+v"(r) : [u] "v"(u), [one] "v"(1.0));                                                      \
+    return r;                                                                                                       \
+  }
+MKH_QBCAST(0) MKH_QBCAST(1) MKH_QBCAST(2) MKH_QBCAST(3) MKH_QBCAST(4) MKH_QBCAST(5) MKH_QBCAST(6) MKH_QBCAST(7)
+#undef MKH_QBCAST
+// Σ / max over the 16 lanes of each row (every lane gets its row's value)
+__device__ __forceinline__ double quad_sum(double x) {
+  x += dpp_f64<0xB1>(x); x += dpp_f64<0x4E>(x); x += dpp_f64<0x141>(x); x += dpp_f64<0x140>(x);
+  return x;
+}
+__device__ __forceinline__ double quad_max(double x) {
+  x = fmax(x, dpp_f64<0xB1>(x)); x = fmax(x, dpp_f64<0x4E>(x)); x = fmax(x, dpp_f64<0x141>(x)); x = fmax(x, dpp_f64<0x140>(x));
+  return x;
+}
+
+// Principal pivot on index K of the rows whose `act` is set: s = +1 sweeps K INTO the free set (pivot element: a Schur
+// complement diagonal of H, > 0), s = −1 sweeps it OUT (−(H_FF⁻¹)_KK < 0).  Lane j holds column j: T[i] = a_ij, cc = ĉ_j.
+//   a_ij ← a_ij − a_iK·a_Kj / d (i, j ≠ K),   a_Kj ← s·a_Kj / d,   a_KK ← −1/d;   the matrix stays symmetric, so row K is
+// register K of every lane, and the new column K (lane K) is that row again: lane K clears its column and takes part in
+// the same rank-1 update with the multiplier −s/d.  Returns "the pivot element had the wrong sign" (H is not ≻ 0).
+template <int K>
+__device__ __forceinline__ bool quad_pivot(double (&T)[8], double& cc, const int l, const bool act, const double s) {
+  const double rowk = T[K];
+  const double d = quad_bcast<K>(rowk), ck = quad_bcast<K>(cc);
+  const bool ok = s * d > 0.0, go = act && ok, isk = l == K;
+  const double inv = go ? fast_rcp(go ? d : 1.0) : 0.0;
+  const double g = rowk * inv;
+  const double gg = isk ? -s * inv : g;
+  if (go && isk) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) T[i] = 0.0;
+    cc = 0.0;
+  }
+  quad_rank1(T, rowk, -gg);
+  cc = fma(-ck, gg, cc);
+  T[K] = go ? (isk ? -inv : s * g) : T[K];
+  return act && !ok;
+}
+
+__global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restrict__ Pg, const SolveArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const LaneProblem& P = *Pg;
+  const int lane = (int)threadIdx.x, row = lane >> 4, l = lane & 15, rbase = lane & 48;
+  const int pb_raw = (int)blockIdx.x * kQuadPerWave + row;
+  const bool live = pb_raw < A.B;
+  const int pb = live ? pb_raw : A.B - 1;            // idle rows of the last wave redo the last problem, store nothing
+  const int nv = P.nv, nq = P.nq, nlink = P.nlink, nf = P.n_frame;
+  const double kInf = __builtin_huge_val();
+  double* const S = smem + row * kQuadRowDoubles;
+  double* const sX = S;                               // sX[c·16 + link]
+  int* const sAnc = (int*)(S + kQuadPoseDoubles);
+  double* const sT = S + kQuadPoseDoubles + kQuadAncDoubles;
+  auto row_mask = [&](const bool p) -> unsigned { return (unsigned)(__ballot(p) >> rbase) & 0xffffu; };
+  int status = 0;
+
+  // ------------------------------------------------------------------ q (lane = dof)
+  const bool dv = l < nv;
+  const int ld = dv ? l : 0;
+  const int qadr = P.dof_qadr[ld];
+  const double qd = dv ? A.q[(size_t)pb * nq + qadr] : 0.0;
+  // Configuration.check_limits (mink/configuration.py:77-110), tol = 1e-6
+  if (row_mask(dv && (qd < P.range_lo[ld] - 1e-6 || qd > P.range_hi[ld] + 1e-6))) status |= 1;
+
+  // ----------------------------------------------------------------- FK (lane = link)
+  {
+    const bool lv = l < nlink;
+    const LaneLink& L = P.link[lv ? l : 0];
+    const int jt = L.jtype;
+    const double qv = bperm_f64(qd, rbase + (jt >= 0 ? L.dof : 0)) - L.qpos0;
+    V3 xp{L.pos[0], L.pos[1], L.pos[2]};
+    Q4 xq{L.quat[0], L.quat[1], L.quat[2], L.quat[3]};
+    if (jt >= 0) {
+      const V3 ax{L.axis[0], L.axis[1], L.axis[2]};
+      if (jt == JNT_SLIDE) {
+        xp = xp + qv * qrot(xq, ax);
+      } else {
+        const V3 jp{L.jpos[0], L.jpos[1], L.jpos[2]};
+        const V3 anchor = xp + qrot(xq, jp);
+        xq = qmul(xq, axis_angle(ax, qv));
+        xp = anchor - qrot(xq, jp);
+      }
+    }
+    xq = qnormalize(xq);
+    // pose relative to the ancestor `anc` (−1: the world); every round composes with that ancestor's pose and moves
+    // the pointer to the ancestor's ancestor: depth d → ⌈log₂ d⌉ rounds
+    int anc = lv ? L.parent : -1;
+    auto put = [&]() {
+      sX[0 * kQuadRow + l] = xp.x; sX[1 * kQuadRow + l] = xp.y; sX[2 * kQuadRow + l] = xp.z;
+      sX[3 * kQuadRow + l] = xq.w; sX[4 * kQuadRow + l] = xq.x; sX[5 * kQuadRow + l] = xq.y; sX[6 * kQuadRow + l] = xq.z;
+      sAnc[l] = anc;
+    };
+    if (lv) put();
+    wave_sync();
+    while (__ballot(anc >= 0)) {
+      const int a = anc >= 0 ? anc : 0;
+      const V3 ap{sX[a], sX[kQuadRow + a], sX[2 * kQuadRow + a]};
+      const Q4 aq{sX[3 * kQuadRow + a], sX[4 * kQuadRow + a], sX[5 * kQuadRow + a], sX[6 * kQuadRow + a]};
+      const int aanc = sAnc[a];
+      wave_sync();                                   // every read of this round before any write
+      if (anc >= 0) {
+        xp = ap + qrot(aq, xp);
+        xq = qnormalize(qmul(aq, xq));
+        anc = aanc;
+        put();
+      }
+      wave_sync();
+    }
+  }
+
+  // ------------------------------------------------- frame tasks (lane = task; frame_task.py:95-146)
+  if (l < nf) {
+    const LaneFrame& ft = P.frame[l];
+    SE3 F;
+    {
+      V3 bp{0, 0, 0};
+      Q4 bq{1, 0, 0, 0};
+      if (ft.link >= 0) {
+        const int a = ft.link;
+        bp = V3{sX[a], sX[kQuadRow + a], sX[2 * kQuadRow + a]};
+        bq = Q4{sX[3 * kQuadRow + a], sX[4 * kQuadRow + a], sX[5 * kQuadRow + a], sX[6 * kQuadRow + a]};
+      }
+      F.p = bp + qrot(bq, V3{ft.lpos[0], ft.lpos[1], ft.lpos[2]});
+      F.q = qmul(bq, Q4{ft.lquat[0], ft.lquat[1], ft.lquat[2], ft.lquat[3]});
+    }
+    const double* tg = A.frame_targets + ((size_t)pb * nf + l) * 7;
+    const SE3 Tt{Q4{tg[0], tg[1], tg[2], tg[3]}, V3{tg[4], tg[5], tg[6]}};
+    V3 ev, ew;
+    double Jm[9], Qm[9];
+    bool ident;
+    se3_log(se3_mul(se3_inv(F), Tt), ev, ew);        // e = target.minus(frame)
+    se3_ljacinv(ev, ew, Jm, Qm, ident);              // jlog(T_tb) = ljacinv(e)
+    const double e6[6] = {ev.x, ev.y, ev.z, ew.x, ew.y, ew.z};
+    double* const t = sT + l * kQuadTaskDoubles;
+    double ss = 0.0;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const double we = ft.cost[r] * (-ft.gain * e6[r]);
+      t[21 + r] = we;
+      ss += we * we;
+    }
+    t[27] = ft.lm_damping * ss;
+    t[18] = F.p.x; t[19] = F.p.y; t[20] = F.p.z;
+    // J = −jlog·ᴮJ with jlog = [[J, −J·Q·J], [0, J]] and ᴮJ = [Rfᵀ·lin; Rfᵀ·ang] (configuration.py:148-153):
+    // rows 0-2 = A1·lin + A2·ang, rows 3-5 = A1·ang,  A1 = −J·Rfᵀ,  A2 = J·Q·J·Rfᵀ   (lane_kernel.h, same blocks)
+    double A1[9];
+    {
+      const M3 Rf = qmat(F.q);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          A1[3 * i + j] = -(Jm[3 * i] * Rf.m[3 * j] + Jm[3 * i + 1] * Rf.m[3 * j + 1] + Jm[3 * i + 2] * Rf.m[3 * j + 2]);
+          t[3 * i + j] = A1[3 * i + j];
+        }
+    }
+    double JQ[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) JQ[3 * i + j] = Jm[3 * i] * Qm[j] + Jm[3 * i + 1] * Qm[3 + j] + Jm[3 * i + 2] * Qm[6 + j];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) t[9 + 3 * i + j] = -(JQ[3 * i] * A1[j] + JQ[3 * i + 1] * A1[3 + j] + JQ[3 * i + 2] * A1[6 + j]);
+  }
+  wave_sync();
+
+  // ------------------------------------------------- objective (lane = dof: column l of H in T[0..8), c_l in cc)
+  double T[8], cc = 0.0, mu_total = A.damping;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) T[i] = 0.0;
+  {
+    const int dl = dv ? P.dof_link[ld] : -1;
+    const bool has = dl >= 0;
+    const int a = has ? dl : 0;
+    const LaneLink& DL = P.link[a];
+    // a joint's axis and anchor are invariant under its own motion: the final body frame gives them
+    const Q4 lq{sX[3 * kQuadRow + a], sX[4 * kQuadRow + a], sX[5 * kQuadRow + a], sX[6 * kQuadRow + a]};
+    const V3 axw = qrot(lq, V3{DL.axis[0], DL.axis[1], DL.axis[2]});
+    const V3 an = V3{sX[a], sX[kQuadRow + a], sX[2 * kQuadRow + a]} + qrot(lq, V3{DL.jpos[0], DL.jpos[1], DL.jpos[2]});
+    const bool slide = DL.jtype == JNT_SLIDE;
+    for (int f = 0; f < nf; ++f) {
+      const LaneFrame& ft = P.frame[f];
+      const double* const t = sT + f * kQuadTaskDoubles;
+      const bool on = has && ((ft.chain >> l) & 1u);
+      const V3 Fp{t[18], t[19], t[20]};
+      const V3 lin = slide ? axw : cross(axw, Fp - an);
+      double Jw[6];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const double a1l = t[3 * r] * lin.x + t[3 * r + 1] * lin.y + t[3 * r + 2] * lin.z;
+        const double a1a = t[3 * r] * axw.x + t[3 * r + 1] * axw.y + t[3 * r + 2] * axw.z;
+        const double a2a = t[9 + 3 * r] * axw.x + t[9 + 3 * r + 1] * axw.y + t[9 + 3 * r + 2] * axw.z;
+        Jw[r] = on ? ft.cost[r] * (slide ? a1l : a1l + a2a) : 0.0;           // weighted_jacobian (task.py:129)
+        Jw[3 + r] = on && !slide ? ft.cost[3 + r] * a1a : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        if ((ft.rowmask >> r) & 1) {                 // (uniform: rows with zero cost contribute nothing)
+          cc = fma(-t[21 + r], Jw[r], cc);
+          quad_rank1(T, Jw[r], Jw[r]);
+        }
+      }
+      mu_total += t[27];
+    }
+  }
+  // posture tasks (posture_task.py:87-142): e = target − q, J = −I  (hinge / slide dofs)
+  double diag = 0.0;
+  for (int t = 0; t < P.n_posture; ++t) {
+    const double* tq = A.posture_target + (A.posture_batched ? ((size_t)pb * P.n_posture + t) * nq : (size_t)t * nq);
+    const double cost = dv ? P.posture_cost[t][ld] : 0.0;
+    const double we = cost * (-P.posture_gain[t] * (tq[qadr] - qd));
+    diag = fma(cost, cost, diag);
+    cc = fma(we, cost, cc);                          // c −= (W·e)·(−cost)
+    mu_total += P.posture_lm[t] * quad_sum(we * we);
+  }
+  diag += dv ? mu_total : 1.0;                       // padded dofs: identity, x = 0
+#pragma unroll
+  for (int i = 0; i < 8; ++i) T[i] += (l == i) ? diag : 0.0;
+  double hdiag = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) hdiag = (l == i) ? T[i] : hdiag;
+
+  // ------------------------------------------------------------ box limits (lane = dof)
+  double lo = 0.0, hi = 0.0;
+  if (dv) {
+    lo = -kInf; hi = kInf;
+    for (int t = 0; t < P.n_cfg; ++t) {              // configuration_limit.py:94-124
+      const double lw = P.cfg_lower[t][l], up = P.cfg_upper[t][l];
+      if (up < kInf) hi = fmin(hi, P.cfg_gain[t] * (up - qd));
+      if (lw > -kInf) lo = fmax(lo, -(P.cfg_gain[t] * (qd - lw)));
+    }
+    for (int t = 0; t < P.n_vel; ++t) {              // velocity_limit.py:96-101
+      const double vm = P.vel_limit[t][l];
+      if (vm < kInf) { hi = fmin(hi, A.dt * vm); lo = fmax(lo, -(A.dt * vm)); }
+    }
+  }
+  if (row_mask(dv && lo > hi + 1e-12)) status |= 2;  // quadprog: "constraints are inconsistent"
+
+  // ------------------------------------------------------------------- QP
+  const double tolw = 1e-16 * quad_max(l < 8 ? hdiag : 0.0);      // (the wavefront kernel's multiplier threshold)
+  bool done = (status & 2) != 0;
+  // every dof enters the free set
+#define MKH_QP0(K)                                                                    \
+  if (K < nv) { if (quad_pivot<K>(T, cc, l, !done, 1.0)) { status |= 4; done = true; } }
+  MKH_QP0(0) MKH_QP0(1) MKH_QP0(2) MKH_QP0(3) MKH_QP0(4) MKH_QP0(5) MKH_QP0(6) MKH_QP0(7)
+#undef MKH_QP0
+  int st = dv ? 0 : 1;                               // 0 free, 1 at lower, 2 at upper (padded lanes: bound at 0, never flip)
+  double x = 0.0;
+  int best = 9, budget = 3;
+  for (int it = 0; it < 10 * 8 + 10; ++it) {
+    if (!__ballot(!done)) break;                     // every row of the wave has its optimum
+    const double xb = st == 1 ? lo : (st == 2 ? hi : 0.0);
+    const double val = quad_dot(T, xb, cc);          // −x_l of a free index, the multiplier w_l of a bound one
+    const double xn = st ? xb : -val;
+    int f = 0;                                       // 0 keep, 1 → lower, 2 → upper, 3 → free
+    if (!st) {
+      if (lo - xn > 1e-12) f = 1;
+      else if (xn - hi > 1e-12) f = 2;
+    } else if (dv && ((st == 1 && val < -tolw) || (st == 2 && val > tolw))) {
+      f = 3;
+    }
+    const unsigned fm = row_mask(f != 0);
+    bool flip = false;
+    if (!done) {
+      x = xn;
+      if (!fm) {
+        done = true;
+      } else {
+        const int cnt = __builtin_popcount(fm), last = 31 - __builtin_clz(fm);
+        bool all = true;
+        if (cnt < best) { best = cnt; budget = 3; }
+        else if (budget > 0) --budget;
+        else all = false;                            // Murty: only the infeasible index with the largest number
+        flip = f && (all || l == last);
+      }
+    }
+    const unsigned long long flips = __ballot(flip);
+    const unsigned mine = (unsigned)(flips >> rbase) & 0xffffu, freem = row_mask(st == 0);
+    const unsigned any = (unsigned)(flips | (flips >> 16) | (flips >> 32) | (flips >> 48)) & 0xffu;
+#define MKH_QPK(K)                                                                                                   \
+  if ((any >> K) & 1u) {                                                                                             \
+    if (quad_pivot<K>(T, cc, l, ((mine >> K) & 1u) != 0, ((freem >> K) & 1u) ? -1.0 : 1.0)) { status |= 4; done = true; } \
+  }
+    MKH_QPK(0) MKH_QPK(1) MKH_QPK(2) MKH_QPK(3) MKH_QPK(4) MKH_QPK(5) MKH_QPK(6) MKH_QPK(7)
+#undef MKH_QPK
+    if (flip) st = (f == 3) ? 0 : f;
+  }
+  if (!done) status |= 8;
+
+  // ------------------------------------------------------------------ out
+  if (live) {
+    if (dv) A.v_out[(size_t)pb * nv + l] = (status & 14) ? __builtin_nan("") : x / A.dt;      // v = Δq / dt (solve_ik.py:104)
+    if (l == 0 && A.status_out) A.status_out[pb] = status;
+  }
+}
+
+}  // namespace mkh

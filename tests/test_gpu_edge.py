@@ -27,19 +27,20 @@ def test_ragged_batch_sizes(B):
                              posture_tasks=[{"cost": 1e-2}], max_batch=B)
     rng = np.random.default_rng(B)
     q, tg = workloads.make_batch(m, nm, prob, rng, B, base_q=home)
-    # (the wavefront kernel: from 8192 instances the default dispatch for this arm is the lane-per-problem kernel,
-    # whose own equivariance test is tests/test_gpu_lane_kernel.py)
+    # (the wavefront kernel: the default dispatch of a plain solve for this arm is the row-per-problem kernel, whose own
+    # equivariance test is tests/test_gpu_quad_kernel.py)
     v, st = prob.solve(q, tg, home[None, :], None, 2e-3, 1e-3, wave_kernel=True)
     assert (st == 0).all()
-    if B >= 8192:
-        vl, stl = prob.solve(q, tg, home[None, :], None, 2e-3, 1e-3)
-        assert prob.last_kernel().startswith("ik_lane_kernel") and (stl == 0).all()
-        np.testing.assert_allclose(vl, v, rtol=0, atol=1e-9 * max(1.0, np.abs(v).max()))
+    vl, stl = prob.solve(q, tg, home[None, :], None, 2e-3, 1e-3)
+    assert prob.last_kernel() == "ik_quad_kernel" and (stl == 0).all()
+    np.testing.assert_allclose(vl, v, rtol=0, atol=1e-9 * max(1.0, np.abs(v).max()))
     one = nat.NativeProblem(nm, frame_tasks=[{"frame_type": "site", "frame_id": 0, "cost": [1.0] * 6, "lm_damping": 1.0}],
                             posture_tasks=[{"cost": 1e-2}], max_batch=1)
     for i in {0, B // 2, B - 1}:
-        v1, _ = one.solve(q[i:i + 1], tg[i:i + 1], home[None, :], None, 2e-3, 1e-3)
+        v1, _ = one.solve(q[i:i + 1], tg[i:i + 1], home[None, :], None, 2e-3, 1e-3, wave_kernel=True)
         np.testing.assert_array_equal(v1[0], v[i])
+        v1, _ = one.solve(q[i:i + 1], tg[i:i + 1], home[None, :], None, 2e-3, 1e-3)
+        np.testing.assert_array_equal(v1[0], vl[i])
     if B > 2:
         # every row: the same batch cut at an odd place (different grid / XCD slices) gives bitwise the same rows
         h = B // 3 + 1

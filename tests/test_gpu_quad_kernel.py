@@ -1,0 +1,211 @@
+"""The row-per-problem kernel for small arms (mink_amd/csrc/quad_kernel.h): one 16-lane DPP row solves one problem,
+four problems per wavefront.  Parity against the real-mink fixture, both oracles, the wavefront kernel
+(MKH_FLAG_WAVE_KERNEL) and the lane kernel (MKH_FLAG_LANE_KERNEL) on the same inputs: heavily saturated boxes (many
+principal pivots in and out of the free set), 7-dof arms, slide joints, branching trees, several frame tasks, status bits,
+ragged last wavefront, batch-permutation equivariance, and the default dispatch by batch size."""
+
+import os
+
+import numpy as np
+import pytest
+
+import native_configs as nc
+import oracle_configs as oc
+from mink_amd import workloads
+from mink_amd.flatmodel import FlatModel
+from oracle import cport
+from oracle import ik as oik
+
+pytestmark = pytest.mark.gpu
+QUAD = "ik_quad_kernel"
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from mink_amd import _native
+    assert _native.lib().mkh_device_count() >= 1
+    return _native
+
+
+def _rel(v, ref):
+    return np.abs(v - ref) / np.maximum(1.0, np.abs(ref).max(axis=1, keepdims=True))
+
+
+def test_real_mink_fixture(nat):
+    d = np.load(os.path.join(oc.GOLDEN, "ik_ur5e_c2.npz"))
+    m = oc.model("ur5e")
+    nm = nat.NativeModel(m)
+    B = len(d["q"])
+    prob, dt, damping = nc.build("ur5e_c2", nm, B)
+    v, st = prob.solve(d["q"], d["frame_targets"], d["posture_target"][None, :], None, dt, damping, quad_kernel=True)
+    assert prob.last_kernel() == QUAD, prob.last_kernel()
+    assert (st & ~1 == 0).all()
+    main = np.ones(B, bool); main[7::8] = False
+    err = _rel(v, d["v"])
+    print("quad kernel vs real-mink fixture: max rel err main %.1e small-angle %.1e" % (err[main].max(), err[~main].max()))
+    assert err[main].max() < 1e-8 and err[~main].max() < 1e-5
+    vw, stw = prob.solve(d["q"], d["frame_targets"], d["posture_target"][None, :], None, dt, damping, wave_kernel=True)
+    assert prob.last_kernel() == "ik_solve_kernel_8_0" and (stw == st).all()
+    assert _rel(v, vw).max() < 1e-9
+    # default dispatch of a plain solve: by batch size — row kernel, then lane kernel
+    for n, kernel in ((1, QUAD), (255, QUAD), (4096, QUAD), (8192, QUAD), (49151, QUAD), (49152, "ik_lane_kernel_6")):
+        p = nc.build("ur5e_c2", nm, n)[0]
+        rep = -(-n // B)
+        qn, tn = np.tile(d["q"], (rep, 1))[:n], np.tile(d["frame_targets"], (rep, 1, 1))[:n]
+        vn, stn = p.solve(qn, tn, d["posture_target"][None, :], None, dt, damping)
+        assert p.last_kernel() == kernel, (n, p.last_kernel())
+        if kernel == QUAD:                           # bitwise: a problem's answer does not depend on its row / wavefront
+            k = min(n, B)
+            assert np.array_equal(vn[:k], v[:k])
+            if n > B:
+                r = n % B or B
+                assert np.array_equal(vn[n - r:], v[:r])
+    # a fused loop, taps or a warm start are not this kernel's: the call falls through to the kernels that have them
+    p = nc.build("ur5e_c2", nm, 1024)[0]
+    qn, tn = np.tile(d["q"], (4, 1))[:1024], np.tile(d["frame_targets"], (4, 1, 1))[:1024]
+    p.solve(qn, tn, d["posture_target"][None, :], None, dt, damping, n_steps=3, quad_kernel=True)
+    assert p.last_kernel() == "ik_solve_kernel_8_16", p.last_kernel()
+    p.solve(qn, tn, d["posture_target"][None, :], None, dt, damping, taps=("H",))
+    assert p.last_kernel().endswith("_31"), p.last_kernel()
+    p.solve(qn, tn, d["posture_target"][None, :], None, dt, damping, warm_start=True)
+    assert p.last_kernel() == "ik_solve_kernel_8_0", p.last_kernel()
+
+
+@pytest.mark.parametrize("vmax,dt", [(np.pi, 2e-3), (0.3, 5e-2)])
+def test_ur5e_batch_vs_other_kernels_and_c_oracle(nat, vmax, dt):
+    """B = 4096 (BASELINE config 2) + a ragged last wavefront; the second parameter set saturates most dofs: several
+    rounds of principal pivots, rows of one wavefront finish at different iterations."""
+    m = workloads.load_robot("ur5e")
+    om = oc.model("ur5e")
+    nm = nat.NativeModel(m)
+    B = 4096 + 3
+    idx = [int(m.jnt_dofadr[j]) for j in range(m.njnt)]
+    prob = nat.NativeProblem(nm, frame_tasks=[nc._ft(m, "attachment_site", "site", 1.0, 1.0, 1.0)],
+                             posture_tasks=[{"cost": 1e-2}], configuration_limits=[nc._cfg_limit(m)],
+                             velocity_limits=[{"indices": idx, "limit": np.full(6, vmax)}], max_batch=B)
+    home = m.key_qpos[0]
+    q, tg = workloads.make_batch(m, nm, prob, np.random.default_rng(4), B, base_q=home)
+    q[5] = home; q[5, 2] = 3.1415 + 2e-3                # outside the elbow range [-3.1415, 3.1415]: status bit 1, still solved
+    v, st = prob.solve(q, tg, home[None, :], None, dt, 1e-3)
+    assert prob.last_kernel() == QUAD
+    assert st[5] == 1 and (np.delete(st, 5) == 0).all()
+    vw, stw = prob.solve(q, tg, home[None, :], None, dt, 1e-3, wave_kernel=True)
+    vl, stl = prob.solve(q, tg, home[None, :], None, dt, 1e-3, lane_kernel=True)
+    assert (stw == st).all() and (stl == st).all()
+    print("quad vs wavefront kernel: max rel diff %.1e, vs lane kernel %.1e; saturated dofs per instance %.2f" %
+          (_rel(v, vw).max(), _rel(v, vl).max(), (np.abs(np.abs(v) - vmax) < 1e-9).sum() / B))
+    assert _rel(v, vw).max() < 1e-9 and _rel(v, vl).max() < 1e-9
+    mm, tasks, _, _, _ = oc.ur5e_c2(tg[0], home)
+    limits = [oik.ConfigurationLimitSpec(), oik.VelocityLimitSpec(np.array(idx), np.full(6, vmax))]
+    v_c, st_c = cport.CProblem(om, tasks, limits).solve_batch(q, tg, home[None, :], dt, 1e-3)
+    assert (st_c == 0).all()
+    err = _rel(v, v_c).max()
+    print("quad kernel vs C oracle on %d instances: max rel err %.1e" % (B, err))
+    assert err < 1e-8
+    perm = np.random.default_rng(0).permutation(B)
+    vp, _ = prob.solve(q[perm], tg[perm], home[None, :], None, dt, 1e-3)
+    assert np.array_equal(vp, v[perm])
+
+
+@pytest.mark.parametrize("scene,qualifies", [("kuka_iiwa_14__scene", True), ("ufactory_xarm7__scene", True),
+                                             ("stanford_tidybot__scene_base", True),
+                                             ("stanford_tidybot__scene_mobile_kinova", False)])
+def test_other_small_robots(nat, scene, qualifies):
+    """7-dof arms, a 3-dof base with slide joints and a body frame; the 10-dof mobile arm does not qualify (nv > 8)."""
+    m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", scene + ".json"))
+    nm = nat.NativeModel(m)
+    B = 514
+    sites = [i for i, n in enumerate(m.site_names) if n and m.site_bodyid[i] > 0]
+    frame = ("site", sites[-1]) if sites else ("body", int(np.argmax(m.body_depth)))
+    ft = {"frame_type": frame[0], "frame_id": frame[1], "cost": [1.0, 1.0, 1.0, 0.3, 0.3, 0.3], "gain": 0.9, "lm_damping": 0.5}
+    vidx = [int(m.jnt_dofadr[j]) for j in range(m.njnt)]
+    vlim = np.where([m.jnt_type[j] == 2 for j in range(m.njnt)], 0.2, 1.0)
+    prob = nat.NativeProblem(nm, frame_tasks=[ft], posture_tasks=[{"cost": 3e-2, "gain": 0.5, "lm_damping": 0.1}],
+                             configuration_limits=[nc._cfg_limit(m)], velocity_limits=[{"indices": vidx, "limit": vlim}],
+                             max_batch=B)
+    q, tg = workloads.make_batch(m, nm, prob, np.random.default_rng(9), B, base_q=m.qpos0)
+    ptg = np.tile(m.qpos0, (B, 1, 1)) + np.random.default_rng(1).normal(scale=0.1, size=(B, 1, m.nq))   # per-instance posture target
+    dt, damping = 2e-2, 1e-4
+    v, st = prob.solve(q, tg, ptg, None, dt, damping)
+    assert (prob.last_kernel() == QUAD) == qualifies, prob.last_kernel()
+    assert (st & ~1 == 0).all()
+    tasks = [oik.FrameTaskSpec(frame[1], frame[0], np.array(ft["cost"]), tg[0, 0], 0.9, 0.5),
+             oik.PostureTaskSpec(np.full(m.nv, 3e-2), ptg[0, 0], 0.5, 0.1)]
+    limits = [oik.ConfigurationLimitSpec(), oik.VelocityLimitSpec(np.array(vidx), vlim)]
+    v_c, st_c = cport.CProblem(m, tasks, limits).solve_batch(q, tg, ptg, dt, damping)
+    assert (st_c == 0).all()
+    err = _rel(v, v_c).max()
+    print("%s (%s): max rel err vs C oracle %.1e" % (scene, prob.last_kernel(), err))
+    assert err < 1e-8
+    for i in (0, 77, B - 1):
+        tasks[0].target = tg[i, 0]; tasks[1].target_q = ptg[i, 0]
+        v_ref = oik.solve_ik(m, q[i], tasks, dt, damping, limits)
+        assert np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max()) < 1e-8
+
+
+def test_branching_tree_and_several_frame_tasks(nat):
+    """A two-fingered 8-dof tree (slide base, hinge arm, two branches) with a frame task on each branch tip, one on the
+    palm and one with zero orientation cost: pointer jumping over a tree whose links have different depths, chains that
+    share dofs, rows left out of H by their zero cost."""
+    from mink_amd.mjcf import loads_mjcf
+    xml = """
+    <mujoco><worldbody>
+      <body name="base" pos="0 0 0.1"><joint name="s" type="slide" axis="1 0 0" range="-1 1"/><geom size="0.05"/>
+        <body name="l1" pos="0 0 0.2"><joint name="h1" type="hinge" axis="0 1 0" range="-2 2"/><geom size="0.04"/>
+          <body name="l2" pos="0.3 0 0" quat="0.9239 0 0 0.3827"><joint name="h2" type="hinge" axis="0 0 1" pos="0.01 0.02 0" range="-2 2"/><geom size="0.04"/>
+            <body name="palm" pos="0.25 0 0"><joint name="h3" type="hinge" axis="1 0 0" range="-2 2"/><geom size="0.03"/>
+              <site name="palm_site" pos="0.02 0 0.01" quat="0.7071 0 0.7071 0"/>
+              <body name="fa1" pos="0.05 0.03 0"><joint name="a1" type="hinge" axis="0 0 1" range="-1 1"/><geom size="0.01"/>
+                <body name="fa2" pos="0.06 0 0"><joint name="a2" type="hinge" axis="0 0 1" range="-1 1"/><geom size="0.01"/>
+                  <site name="tip_a" pos="0.04 0 0"/></body></body>
+              <body name="fb1" pos="0.05 -0.03 0"><joint name="b1" type="hinge" axis="0 0 1" range="-1 1"/><geom size="0.01"/>
+                <body name="fb2" pos="0.06 0 0"><joint name="b2" type="slide" axis="1 0 0" range="-0.03 0.03"/><geom size="0.01"/>
+                  <site name="tip_b" pos="0.04 0 0"/></body></body>
+            </body></body></body></body>
+    </worldbody></mujoco>"""
+    m = loads_mjcf(xml)
+    assert m.nv == 8
+    nm = nat.NativeModel(m)
+    B = 640
+    sid = {n: i for i, n in enumerate(m.site_names)}
+    fts = [{"frame_type": "site", "frame_id": sid["tip_a"], "cost": [1.0, 1.0, 1.0, 0.0, 0.0, 0.0], "gain": 1.0, "lm_damping": 1.0},
+           {"frame_type": "site", "frame_id": sid["tip_b"], "cost": [1.0, 1.0, 1.0, 0.2, 0.2, 0.2], "gain": 0.8, "lm_damping": 0.0},
+           {"frame_type": "site", "frame_id": sid["palm_site"], "cost": [0.5, 0.5, 0.5, 1.0, 1.0, 1.0], "gain": 1.0, "lm_damping": 0.3},
+           {"frame_type": "body", "frame_id": m.body_names.index("l2"), "cost": [0.1, 0.1, 0.1, 0.1, 0.1, 0.1], "gain": 0.5, "lm_damping": 0.0}]
+    vidx = list(range(8))
+    vlim = np.array([0.5, 1.0, 1.0, 1.0, 2.0, 2.0, 2.0, 0.1])
+    prob = nat.NativeProblem(nm, frame_tasks=fts, posture_tasks=[{"cost": 1e-2}], configuration_limits=[nc._cfg_limit(m)],
+                             velocity_limits=[{"indices": vidx, "limit": vlim}], max_batch=B)
+    q, tg = workloads.make_batch(m, nm, prob, np.random.default_rng(2), B, base_q=m.qpos0)
+    dt, damping = 3e-2, 1e-6
+    v, st = prob.solve(q, tg, m.qpos0[None, :], None, dt, damping)
+    assert prob.last_kernel() == QUAD and (st == 0).all()
+    vw, stw = prob.solve(q, tg, m.qpos0[None, :], None, dt, damping, wave_kernel=True)
+    vl, stl = prob.solve(q, tg, m.qpos0[None, :], None, dt, damping, lane_kernel=True)
+    assert prob.last_kernel() == "ik_lane_kernel_8" and (stw == 0).all() and (stl == 0).all()
+    print("tree, 4 frame tasks: quad vs wavefront %.1e, vs lane %.1e; saturated dofs per instance %.2f" %
+          (_rel(v, vw).max(), _rel(v, vl).max(), (np.abs(np.abs(v) - vlim) < 1e-9).sum() / B))
+    assert _rel(v, vw).max() < 1e-8 and _rel(v, vl).max() < 1e-8
+    tasks = [oik.FrameTaskSpec(f["frame_id"], f["frame_type"], np.array(f["cost"]), tg[0, k], f["gain"], f["lm_damping"]) for k, f in enumerate(fts)]
+    tasks.append(oik.PostureTaskSpec(np.full(m.nv, 1e-2), m.qpos0))
+    limits = [oik.ConfigurationLimitSpec(), oik.VelocityLimitSpec(np.array(vidx), vlim)]
+    v_c, st_c = cport.CProblem(m, tasks, limits).solve_batch(q, tg, m.qpos0[None, :], dt, damping)
+    assert (st_c == 0).all() and _rel(v, v_c).max() < 1e-8
+
+
+def test_failure_status(nat):
+    """Inconsistent box (velocity window that excludes the configuration-limit window) → MKH_ST_INFEASIBLE and NaN for
+    that row only, like the other kernels (quadprog: "constraints are inconsistent")."""
+    m = workloads.load_robot("ur5e")
+    nm = nat.NativeModel(m)
+    B = 66
+    prob, dt, damping = nc.build("ur5e_c2", nm, B)
+    home = m.key_qpos[0]
+    q = np.tile(home, (B, 1))
+    q[3, 2] = 3.1415 + 0.5                             # far outside the range: the box lo ≤ Δq ≤ hi becomes empty with the velocity limit
+    tg = np.zeros((B, 1, 7)); tg[:, :, 0] = 1; tg[:, :, 4:] = [0.4, 0.1, 0.4]
+    v, st = prob.solve(q, tg, home[None, :], None, dt, damping, quad_kernel=True)
+    assert prob.last_kernel() == QUAD
+    vw, stw = prob.solve(q, tg, home[None, :], None, dt, damping, wave_kernel=True)
+    assert (st == stw).all() and st[3] & 2 and np.isnan(v[3]).all() and np.isfinite(np.delete(v, 3, axis=0)).all()
+    assert _rel(np.delete(v, 3, axis=0), np.delete(vw, 3, axis=0)).max() < 1e-9
