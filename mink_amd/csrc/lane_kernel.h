@@ -54,7 +54,15 @@ struct LaneProblem {
   double posture_cost[kMaxPostureTasks][kLaneMaxDofs], posture_gain[kMaxPostureTasks], posture_lm[kMaxPostureTasks];
   double cfg_gain[kMaxBoxTerms], cfg_lower[kMaxBoxTerms][kLaneMaxDofs], cfg_upper[kMaxBoxTerms][kLaneMaxDofs];
   double vel_limit[kMaxBoxTerms][kLaneMaxDofs];
+  // per dof, for the row kernel (quad_kernel.h: one load level less than dof_link → link): the joint's axis and anchor in its
+  // body frame, and whether it is a slide joint
+  double dof_axis[kLaneMaxDofs][3], dof_jpos[kLaneMaxDofs][3];
+  int32_t dof_slide[kLaneMaxDofs];
 };
+
+// The sizes of a LaneProblem, by value in the row kernel's arguments (SGPRs at wave start instead of a dependent load).
+// `qadr_identity`: dof d reads q[d] (always the case for nq = nv with hinge / slide joints only; checked on the host).
+struct LaneDims { int32_t nq, nv, nlink, n_frame, n_posture, n_cfg, n_vel, qadr_identity; };
 
 // bytes of LDS per wavefront: link poses [nlink][7][64] (joint axes and anchors are recomputed from the pose where a
 // Jacobian column needs them: ~40 flops instead of 6 more doubles of LDS per link and lane, i.e. residency)

@@ -22,8 +22,8 @@ int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stre
   return -1;
 }
 
-int launch_quad(int grid, hipStream_t stream, const LaneProblem* P, const SolveArgs& a) {
-  hipLaunchKernelGGL(ik_quad_kernel, dim3(grid), dim3(kWave), quad_lds_bytes(), stream, P, a);
+int launch_quad(int grid, hipStream_t stream, const LaneProblem* P, const LaneDims& dims, const SolveArgs& a) {
+  hipLaunchKernelGGL(ik_quad_kernel, dim3(grid), dim3(kWave), quad_lds_bytes(), stream, P, dims, a);
   return quad_lds_bytes();
 }
 

@@ -95,6 +95,7 @@ struct MkhProblem {
   // lane-per-problem kernel for small arms (lane_kernel.h): template size (0 = the problem does not qualify)
   int lane_nv = 0, lane_lds = 0;
   LaneProblem* d_lane = nullptr;
+  LaneDims lane_dims{};
   char last_kernel[64] = "";
   // device descriptor storage
   FrameTaskDev* d_frame = nullptr;
@@ -127,8 +128,8 @@ namespace mkh {
 int launch_variant(int nt, int nr, int feat, bool w3, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
                    const SolveArgs& a, const TapArgs* taps);
 int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);
-int launch_quad(int grid, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);   // returns its LDS bytes per wavefront
-constexpr int kLaneMinBatch = 49152;  // plain solves of a small arm: row kernel below, lane kernel from here (launch())
+int launch_quad(int grid, hipStream_t stream, const LaneProblem* P, const LaneDims& dims, const SolveArgs& a);   // returns its LDS bytes per wavefront
+constexpr int kLaneMinBatch = 73728;  // plain solves of a small arm: row kernel below, lane kernel from here (launch())
 }
 
 // Lane-per-problem descriptor (lane_kernel.h) of a problem that qualifies: nv ≤ 8, hinge / slide joints only,
@@ -206,6 +207,8 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
     const int j = m->dof_jntid[dd];
     L.dof_link[dd] = link_of_jnt[j];
     L.dof_qadr[dd] = m->jnt_qposadr[j];
+    for (int c = 0; c < 3; ++c) { L.dof_axis[dd][c] = m->jnt_axis[3 * j + c]; L.dof_jpos[dd][c] = m->jnt_pos[3 * j + c]; }
+    L.dof_slide[dd] = m->jnt_type[j] == JNT_SLIDE;
     if (m->jnt_limited[j]) { L.range_lo[dd] = m->jnt_range[2 * j]; L.range_hi[dd] = m->jnt_range[2 * j + 1]; }
   }
   for (int t = 0; t < P.n_frame; ++t) {
@@ -799,6 +802,9 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     p->lane_nv = build_lane_problem(m, d, P, ft, pcost, clo, chi, vlim, p->has_relative, lp);
     if (p->lane_nv) {
       p->lane_lds = lane_lds_bytes(lp.nlink);
+      bool ident = true;
+      for (int dd = 0; dd < lp.nv; ++dd) ident = ident && lp.dof_qadr[dd] == dd;
+      p->lane_dims = LaneDims{lp.nq, lp.nv, lp.nlink, lp.n_frame, lp.n_posture, lp.n_cfg, lp.n_vel, ident ? 1 : 0};
       if (hipMalloc((void**)&p->d_lane, sizeof(LaneProblem)) != hipSuccess ||
           hipMemcpy(p->d_lane, &lp, sizeof(LaneProblem), hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(MKH_E_HIP, "lane descriptor upload failed"));
@@ -867,6 +873,25 @@ int32_t mkh_problem_launch_info(const MkhProblem* p, int32_t B, int32_t* grid, i
   return MKH_OK;
 }
 
+// Experiment builds with -DMKH_CLOCKS (tools/phase_clocks.py): MKH_DEBUG_CLOCKS=<file> makes every launch of this process
+// synchronous and writes its (B, 24) cycle stamps to <file> — phase profile of kernels that cannot be tapped
+static const char* clk_path() { static const char* const s = getenv("MKH_DEBUG_CLOCKS"); return s; }
+static hipError_t clk_begin(MkhProblem* p, SolveArgs& a, hipStream_t stream) {
+  if (!clk_path()) return hipSuccess;
+  if (!p->d_clk)
+    if (hipError_t e = hipMalloc((void**)&p->d_clk, (size_t)p->max_batch * 24 * sizeof(long long))) return e;
+  a.clk = p->d_clk;
+  return hipMemsetAsync(p->d_clk, 0, (size_t)a.B * 24 * sizeof(long long), stream);
+}
+static hipError_t clk_end(MkhProblem* p, int B, hipStream_t stream) {
+  if (!clk_path()) return hipSuccess;
+  std::vector<long long> h((size_t)B * 24);
+  if (hipError_t e = hipMemcpyAsync(h.data(), p->d_clk, h.size() * sizeof(long long), hipMemcpyDeviceToHost, stream)) return e;
+  if (hipError_t e = hipStreamSynchronize(stream)) return e;
+  if (FILE* f = fopen(clk_path(), "wb")) { fwrite(h.data(), sizeof(long long), h.size(), f); fclose(f); }
+  return hipSuccess;
+}
+
 static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hipStream_t stream, int32_t flags) {
   (void)hipGetLastError();          // a stale error of an unrelated earlier runtime call must not be blamed on this launch
   const TapArgs* dtaps = nullptr;
@@ -883,8 +908,9 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   //     instruction stream per problem whatever the batch — the best use of the machine once every SIMD has several
   //     wavefronts to interleave.  Also the fused caller loop (steps / until) from 8 192 instances.
   // Measured on MI355X, UR5e config 2, M solves/s (tools/bench_small_arm.py; wavefront / row / lane kernel):
-  //   B = 256: 12 / 16.5 / 7.6    4 096: 116 / 195 / 90    8 192: 128 / 319 / 151    32 768: 148 / 576 / 527
-  //   65 536: 153 / 627 / 855 — the row kernel up to kLaneMinBatch, the lane kernel beyond.
+  //   B = 256: 12 / 25 / 7.6    4 096: 119 / 219 / 90    8 192: 130 / 449 / 152    32 768: 150 / 839 / 528
+  //   65 536: 155 / 900 / 855    131 072: 158 / 1 169 / 1 506    1 048 576: 160 / 1 331 / 2 897
+  // — the row kernel up to kLaneMinBatch, the lane kernel beyond.
   // MKH_FLAG_WAVE_KERNEL / _QUAD_KERNEL / _LANE_KERNEL force one of the three (parity switches).
   const bool small_arm = p->lane_nv && !taps && a.do_qp && !(flags & MKH_FLAG_WAVE_KERNEL);
   const bool loop = a.n_steps > 1 || a.q_out || a.pos_threshold >= 0.0;       // fused caller loop (steps / until)
@@ -893,8 +919,11 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
     const int grid = (a.B + 3) / 4;
     p->last_grid = grid; p->last_nt = 8;
     snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_quad_kernel");
-    p->last_lds = mkh::launch_quad(grid, stream, p->d_lane, a);
+    SolveArgs aq = a;
+    HIP_OK(clk_begin(p, aq, stream));
+    p->last_lds = mkh::launch_quad(grid, stream, p->d_lane, p->lane_dims, aq);
     HIP_OK(hipGetLastError());
+    HIP_OK(clk_end(p, a.B, stream));
     return MKH_OK;
   }
   if (small_arm && (a.B >= (loop ? 8192 : mkh::kLaneMinBatch) || (flags & MKH_FLAG_LANE_KERNEL))) {
@@ -976,23 +1005,11 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   const int per_wave = a.B / grid;
   const bool dynamic = nt > 8 && per_wave >= 4;
   al.static_rounds = dynamic ? (per_wave * 7) / 8 : INT32_MAX;
-  // Experiment builds with -DMKH_CLOCKS (tools/phase_clocks.py): MKH_DEBUG_CLOCKS=<file> makes every launch of this process
-  // synchronous and writes its (B, 16) cycle stamps to <file> — phase profile of kernels that cannot be tapped
-  static const char* const clk_path = getenv("MKH_DEBUG_CLOCKS");
-  if (clk_path) {
-    if (!p->d_clk) HIP_OK(hipMalloc((void**)&p->d_clk, (size_t)p->max_batch * 24 * sizeof(long long)));
-    HIP_OK(hipMemsetAsync(p->d_clk, 0, (size_t)a.B * 24 * sizeof(long long), stream));
-    al.clk = p->d_clk;
-  }
+  HIP_OK(clk_begin(p, al, stream));
   if (mkh::launch_variant(nt, nr, feat, w3, grid, lds, stream, p->d_dev, al, dtaps) != 0)
     return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
   HIP_OK(hipGetLastError());
-  if (clk_path) {
-    std::vector<long long> h((size_t)a.B * 24);
-    HIP_OK(hipMemcpyAsync(h.data(), p->d_clk, h.size() * sizeof(long long), hipMemcpyDeviceToHost, stream));
-    HIP_OK(hipStreamSynchronize(stream));
-    if (FILE* f = fopen(clk_path, "wb")) { fwrite(h.data(), sizeof(long long), h.size(), f); fclose(f); }
-  }
+  HIP_OK(clk_end(p, a.B, stream));
   return MKH_OK;
 }
 

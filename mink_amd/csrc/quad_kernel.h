@@ -108,14 +108,14 @@ __device__ __forceinline__ bool quad_pivot(double (&T)[8], double& cc, const int
   return act && !ok;
 }
 
-__global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restrict__ Pg, const SolveArgs A) {
+__global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restrict__ Pg, const LaneDims D, const SolveArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const LaneProblem& P = *Pg;
   const int lane = (int)threadIdx.x, row = lane >> 4, l = lane & 15, rbase = lane & 48;
   const int pb_raw = (int)blockIdx.x * kQuadPerWave + row;
   const bool live = pb_raw < A.B;
   const int pb = live ? pb_raw : A.B - 1;            // idle rows of the last wave redo the last problem, store nothing
-  const int nv = P.nv, nq = P.nq, nlink = P.nlink, nf = P.n_frame;
+  const int nv = D.nv, nq = D.nq, nlink = D.nlink, nf = D.n_frame;
   const double kInf = __builtin_huge_val();
   double* const S = smem + row * kQuadRowDoubles;
   double* const sX = S;                               // sX[c·16 + link]
@@ -123,15 +123,57 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
   double* const sT = S + kQuadPoseDoubles + kQuadAncDoubles;
   auto row_mask = [&](const bool p) -> unsigned { return (unsigned)(__ballot(p) >> rbase) & 0xffffu; };
   int status = 0;
+#ifdef MKH_CLOCKS   // experiment builds (tools/phase_clocks.py): cycle stamps at the phase boundaries, row 24·pb of SolveArgs::clk
+  long long tc[8];
+  int tci = 0;
+#define MKH_QTICK() do { tc[tci++] = __builtin_readcyclecounter(); asm volatile("" : "+v"(status)); } while (0)
+#else
+#define MKH_QTICK() do {} while (0)
+#endif
+  MKH_QTICK();
 
   // ------------------------------------------------------------------ q (lane = dof)
   const bool dv = l < nv;
   const int ld = dv ? l : 0;
-  const int qadr = P.dof_qadr[ld];
+  const int qadr = D.qadr_identity ? ld : P.dof_qadr[ld];
   const double qd = dv ? A.q[(size_t)pb * nq + qadr] : 0.0;
   // Configuration.check_limits (mink/configuration.py:77-110), tol = 1e-6
   if (row_mask(dv && (qd < P.range_lo[ld] - 1e-6 || qd > P.range_hi[ld] + 1e-6))) status |= 1;
+  // (everything below that needs q only comes first: its descriptor loads are in flight together with the links')
+  // the link whose joint moves this lane's dof: axis and anchor of the Jacobian column
+  const int dl = dv ? P.dof_link[ld] : -1;
+  const bool has = dl >= 0;
+  const int dla = has ? dl : 0;
+  const V3 d_axis{P.dof_axis[ld][0], P.dof_axis[ld][1], P.dof_axis[ld][2]};
+  const V3 d_jpos{P.dof_jpos[ld][0], P.dof_jpos[ld][1], P.dof_jpos[ld][2]};
+  const bool slide = P.dof_slide[ld] != 0;
+  // posture tasks (posture_task.py:87-142): e = target − q, J = −I  (hinge / slide dofs)
+  double diag = 0.0, cc = 0.0, mu_total = A.damping;
+  for (int t = 0; t < D.n_posture; ++t) {
+    const double* tq = A.posture_target + (A.posture_batched ? ((size_t)pb * D.n_posture + t) * nq : (size_t)t * nq);
+    const double cost = dv ? P.posture_cost[t][ld] : 0.0;
+    const double we = cost * (-P.posture_gain[t] * (tq[qadr] - qd));
+    diag = fma(cost, cost, diag);
+    cc = fma(we, cost, cc);                          // c −= (W·e)·(−cost)
+    mu_total += P.posture_lm[t] * quad_sum(we * we);
+  }
+  // box limits
+  double lo = 0.0, hi = 0.0;
+  if (dv) {
+    lo = -kInf; hi = kInf;
+    for (int t = 0; t < D.n_cfg; ++t) {              // configuration_limit.py:94-124
+      const double lw = P.cfg_lower[t][l], up = P.cfg_upper[t][l];
+      if (up < kInf) hi = fmin(hi, P.cfg_gain[t] * (up - qd));
+      if (lw > -kInf) lo = fmax(lo, -(P.cfg_gain[t] * (qd - lw)));
+    }
+    for (int t = 0; t < D.n_vel; ++t) {              // velocity_limit.py:96-101
+      const double vm = P.vel_limit[t][l];
+      if (vm < kInf) { hi = fmin(hi, A.dt * vm); lo = fmax(lo, -(A.dt * vm)); }
+    }
+  }
+  if (row_mask(dv && lo > hi + 1e-12)) status |= 2;  // quadprog: "constraints are inconsistent"
 
+  MKH_QTICK();
   // ----------------------------------------------------------------- FK (lane = link)
   {
     const bool lv = l < nlink;
@@ -170,7 +212,7 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
       wave_sync();                                   // every read of this round before any write
       if (anc >= 0) {
         xp = ap + qrot(aq, xp);
-        xq = qnormalize(qmul(aq, xq));
+        xq = qmul(aq, xq);                           // (unit × unit: the local quaternions were normalised above)
         anc = aanc;
         put();
       }
@@ -178,6 +220,7 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
     }
   }
 
+  MKH_QTICK();
   // ------------------------------------------------- frame tasks (lane = task; frame_task.py:95-146)
   if (l < nf) {
     const LaneFrame& ft = P.frame[l];
@@ -235,21 +278,18 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
       for (int j = 0; j < 3; ++j) t[9 + 3 * i + j] = -(JQ[3 * i] * A1[j] + JQ[3 * i + 1] * A1[3 + j] + JQ[3 * i + 2] * A1[6 + j]);
   }
   wave_sync();
+  MKH_QTICK();
 
   // ------------------------------------------------- objective (lane = dof: column l of H in T[0..8), c_l in cc)
-  double T[8], cc = 0.0, mu_total = A.damping;
+  double T[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) T[i] = 0.0;
   {
-    const int dl = dv ? P.dof_link[ld] : -1;
-    const bool has = dl >= 0;
-    const int a = has ? dl : 0;
-    const LaneLink& DL = P.link[a];
     // a joint's axis and anchor are invariant under its own motion: the final body frame gives them
+    const int a = dla;
     const Q4 lq{sX[3 * kQuadRow + a], sX[4 * kQuadRow + a], sX[5 * kQuadRow + a], sX[6 * kQuadRow + a]};
-    const V3 axw = qrot(lq, V3{DL.axis[0], DL.axis[1], DL.axis[2]});
-    const V3 an = V3{sX[a], sX[kQuadRow + a], sX[2 * kQuadRow + a]} + qrot(lq, V3{DL.jpos[0], DL.jpos[1], DL.jpos[2]});
-    const bool slide = DL.jtype == JNT_SLIDE;
+    const V3 axw = qrot(lq, d_axis);
+    const V3 an = V3{sX[a], sX[kQuadRow + a], sX[2 * kQuadRow + a]} + qrot(lq, d_jpos);
     for (int f = 0; f < nf; ++f) {
       const LaneFrame& ft = P.frame[f];
       const double* const t = sT + f * kQuadTaskDoubles;
@@ -275,48 +315,35 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
       mu_total += t[27];
     }
   }
-  // posture tasks (posture_task.py:87-142): e = target − q, J = −I  (hinge / slide dofs)
-  double diag = 0.0;
-  for (int t = 0; t < P.n_posture; ++t) {
-    const double* tq = A.posture_target + (A.posture_batched ? ((size_t)pb * P.n_posture + t) * nq : (size_t)t * nq);
-    const double cost = dv ? P.posture_cost[t][ld] : 0.0;
-    const double we = cost * (-P.posture_gain[t] * (tq[qadr] - qd));
-    diag = fma(cost, cost, diag);
-    cc = fma(we, cost, cc);                          // c −= (W·e)·(−cost)
-    mu_total += P.posture_lm[t] * quad_sum(we * we);
-  }
   diag += dv ? mu_total : 1.0;                       // padded dofs: identity, x = 0
 #pragma unroll
   for (int i = 0; i < 8; ++i) T[i] += (l == i) ? diag : 0.0;
-  double hdiag = 0.0;
+  double hdiag = 1.0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) hdiag = (l == i) ? T[i] : hdiag;
 
-  // ------------------------------------------------------------ box limits (lane = dof)
-  double lo = 0.0, hi = 0.0;
-  if (dv) {
-    lo = -kInf; hi = kInf;
-    for (int t = 0; t < P.n_cfg; ++t) {              // configuration_limit.py:94-124
-      const double lw = P.cfg_lower[t][l], up = P.cfg_upper[t][l];
-      if (up < kInf) hi = fmin(hi, P.cfg_gain[t] * (up - qd));
-      if (lw > -kInf) lo = fmax(lo, -(P.cfg_gain[t] * (qd - lw)));
-    }
-    for (int t = 0; t < P.n_vel; ++t) {              // velocity_limit.py:96-101
-      const double vm = P.vel_limit[t][l];
-      if (vm < kInf) { hi = fmin(hi, A.dt * vm); lo = fmax(lo, -(A.dt * vm)); }
-    }
-  }
-  if (row_mask(dv && lo > hi + 1e-12)) status |= 2;  // quadprog: "constraints are inconsistent"
-
+  MKH_QTICK();
   // ------------------------------------------------------------------- QP
-  const double tolw = 1e-16 * quad_max(l < 8 ? hdiag : 0.0);      // (the wavefront kernel's multiplier threshold)
+  const double tolw = 1e-16 * quad_max(dv ? hdiag : 0.0);         // (the wavefront kernel's multiplier threshold)
   bool done = (status & 2) != 0;
-  // every dof enters the free set
-#define MKH_QP0(K)                                                                    \
-  if (K < nv) { if (quad_pivot<K>(T, cc, l, !done, 1.0)) { status |= 4; done = true; } }
-  MKH_QP0(0) MKH_QP0(1) MKH_QP0(2) MKH_QP0(3) MKH_QP0(4) MKH_QP0(5) MKH_QP0(6) MKH_QP0(7)
+  // Starting partition from the diagonal estimate x_l ≈ −c_l / H_ll: dofs it puts outside the box start AT that bound
+  // (any partition is a valid start of block principal pivoting; the benchmark's velocity limits saturate most dofs of
+  // most instances, and a dof that starts at its bound saves the pivot in and the pivot out again)
+  int st = 1;                                        // 0 free, 1 at lower, 2 at upper (padded lanes: bound at 0, never flip)
+  if (dv) {
+    const double xd = -cc * fast_rcp(hdiag);
+    st = xd > hi ? 2 : (xd < lo ? 1 : 0);
+  }
+  {
+    const unsigned long long fr = __ballot(st == 0 && !done);
+    const unsigned mine = (unsigned)(fr >> rbase) & 0xffu;
+    const unsigned any = (unsigned)(fr | (fr >> 16) | (fr >> 32) | (fr >> 48)) & 0xffu;
+#define MKH_QP0(K)                                                                                          \
+  if ((any >> K) & 1u) { if (quad_pivot<K>(T, cc, l, ((mine >> K) & 1u) != 0, 1.0)) { status |= 4; done = true; } }
+    MKH_QP0(0) MKH_QP0(1) MKH_QP0(2) MKH_QP0(3) MKH_QP0(4) MKH_QP0(5) MKH_QP0(6) MKH_QP0(7)
 #undef MKH_QP0
-  int st = dv ? 0 : 1;                               // 0 free, 1 at lower, 2 at upper (padded lanes: bound at 0, never flip)
+  }
+  MKH_QTICK();
   double x = 0.0;
   int best = 9, budget = 3;
   for (int it = 0; it < 10 * 8 + 10; ++it) {
@@ -358,6 +385,14 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
     if (flip) st = (f == 3) ? 0 : f;
   }
   if (!done) status |= 8;
+  MKH_QTICK();
+#ifdef MKH_CLOCKS
+  if (A.clk && live && l == 0) {
+    for (int k = 0; k < 7; ++k) A.clk[(size_t)pb * 24 + k] = tc[k];
+    A.clk[(size_t)pb * 24 + 7] = tc[6];
+  }
+#endif
+#undef MKH_QTICK
 
   // ------------------------------------------------------------------ out
   if (live) {

@@ -40,11 +40,11 @@ def test_real_mink_fixture(nat):
     assert err[main].max() < 1e-8 and err[~main].max() < 1e-5
     vw, stw = prob.solve(d["q"], d["frame_targets"], d["posture_target"][None, :], None, dt, damping, wave_kernel=True)
     assert prob.last_kernel() == "ik_solve_kernel_8_0" and (stw == st).all()
-    # default dispatch: by batch size (below 49 152 plain solves go to the row kernel, tests/test_gpu_quad_kernel.py)
+    # default dispatch: by batch size (below 73 728 plain solves go to the row kernel, tests/test_gpu_quad_kernel.py)
     prob.solve(d["q"], d["frame_targets"], d["posture_target"][None, :], None, dt, damping)
     assert prob.last_kernel() == "ik_quad_kernel"
-    big = nc.build("ur5e_c2", nm, 49152)[0]
-    rep = 49152 // B
+    big = nc.build("ur5e_c2", nm, 73728)[0]
+    rep = 73728 // B
     vb, _ = big.solve(np.tile(d["q"], (rep, 1)), np.tile(d["frame_targets"], (rep, 1, 1)), d["posture_target"][None, :], None, dt, damping)
     assert big.last_kernel() == "ik_lane_kernel_6" and np.array_equal(vb[:B], v) and np.array_equal(vb[-B:], v)
 

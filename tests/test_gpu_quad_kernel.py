@@ -48,7 +48,7 @@ def test_real_mink_fixture(nat):
     assert prob.last_kernel() == "ik_solve_kernel_8_0" and (stw == st).all()
     assert _rel(v, vw).max() < 1e-9
     # default dispatch of a plain solve: by batch size — row kernel, then lane kernel
-    for n, kernel in ((1, QUAD), (255, QUAD), (4096, QUAD), (8192, QUAD), (49151, QUAD), (49152, "ik_lane_kernel_6")):
+    for n, kernel in ((1, QUAD), (255, QUAD), (4096, QUAD), (8192, QUAD), (73727, QUAD), (73728, "ik_lane_kernel_6")):
         p = nc.build("ur5e_c2", nm, n)[0]
         rep = -(-n // B)
         qn, tn = np.tile(d["q"], (rep, 1))[:n], np.tile(d["frame_targets"], (rep, 1, 1))[:n]

@@ -28,7 +28,7 @@ def main():
     model = workloads.load_bench_robot(config)
     nm = nat.NativeModel(model, device=0)
     print("%8s  %10s %10s %10s   (M solves/s; default dispatch marked *)" % ("B", "wavefront", "row", "lane"))
-    for B in (16, 64, 128, 256, 512, 1024, 2048, 4096, 6144, 8192, 16384, 32768, 65536):
+    for B in (16, 256, 1024, 2048, 4096, 6144, 8192, 16384, 32768, 65536, 131072, 262144, 1048576):
         prob, dt, damping = workloads.bench_config(config, model, nm, B)
         q_h, tg_h, pt_h, ct_h = workloads.bench_batch(config, model, nm, prob, np.random.default_rng(1000), B)
         q, tg, pt = torch.from_numpy(q_h).to(dev), torch.from_numpy(tg_h).to(dev), torch.from_numpy(pt_h).to(dev)
@@ -38,15 +38,16 @@ def main():
         default = prob.last_kernel()
         cells = []
         for kw in ({"wave_kernel": True}, {"quad_kernel": True}, {"lane_kernel": True}):
-            for _ in range(3):
+            for _ in range(20):
                 prob.solve(q, tg, pt, None, dt, damping, out=v, status_out=st, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(reps):
+            n = max(reps, min(1000, (1 << 20) // B))   # (short kernels: enough launches for the clocks to settle)
+            for _ in range(n):
                 prob.solve(q, tg, pt, None, dt, damping, out=v, status_out=st, **kw)
             e1.record()
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / reps
+            ms = e0.elapsed_time(e1) / n
             bad = int(((st.cpu().numpy() & ~1) != 0).sum())
             cells.append("%9.1f%s" % (B / ms / 1e3, "*" if prob.last_kernel() == default else ("!" if bad else " ")))
         print("%8d  %s" % (B, " ".join(cells)), flush=True)
