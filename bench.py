@@ -36,6 +36,7 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+N_SIMDS = 1024                       # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0                                   # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6                          # MI355X fp64 vector peak (same guide, chip table)
 # algorithmic fp64 flops per G1 config-3 solve, 0.10-0.15 Mflop (FK, Jacobians, log/jlog,
@@ -420,10 +421,13 @@ def main():
         """W warm-up steps, then exactly K steps between barrier + synchronize; returns (elapsed s — MAX over
         ranks, per-step kernel ms from HIP events on the launch stream, per-step gather ms)."""
         kern_events, gath_events = [], []
+        # (events are created before the timed region: on the short kernels — UR5e at 4 096 instances is 19 µs — creating
+        #  two per step inside it costs as much host time as the launch itself)
+        pool = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
         def step(timed=False):
             if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0, e1 = pool[len(kern_events)]
                 e0.record()
             prob.solve(q, tg, pt, ct, dt, damping, out=v, status_out=st, dense=dense)
             if timed:
@@ -489,6 +493,9 @@ def main():
         waves_per_simd = 4 if nt <= 8 else (3 if (nt <= 24 or kernel.endswith("_w3")) else 2)   # (_w3: 168-register map)
         if kernel.startswith("ik_lane_kernel"):
             waves_per_simd = 2                            # lane_kernel.h: amdgpu_waves_per_eu(2, 2)
+        # (a launch with fewer wavefronts than the register map allows — the row kernel at 4 096 instances is one wavefront
+        #  per SIMD — cannot use more issue slots than it has wavefronts)
+        waves_per_simd = min(waves_per_simd, max(1.0, info["grid"] / float(N_SIMDS)))
         traffic = measured_traffic(args.config, B)
         valu = measured_valu_issue(args.config, B, waves_per_simd)
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -214,6 +214,14 @@ def _is_torch(x) -> bool:
     return type(x).__module__.split(".")[0] == "torch"
 
 
+def _raw_stream(torch, dev) -> int:
+    """hipStream_t of torch's current stream on `dev` (the private accessor costs a tenth of building a Stream object)."""
+    try:
+        return torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+    except AttributeError:
+        return torch.cuda.current_stream(dev).cuda_stream
+
+
 class NativeModel:
     """Device copy of a FlatModel (mkh_model_create)."""
 
@@ -419,8 +427,13 @@ class NativeProblem:
             import torch
             dev = q.device
 
-            def prep(x):
-                return None if x is None else x.to(device=dev, dtype=torch.float64).contiguous()
+            f64 = torch.float64
+
+            def prep(x):     # (the common case — already float64, on the device, contiguous — must cost nothing: a UR5e
+                #              solve of 4 096 instances is a 19 µs kernel, the host side of this call has to stay below it)
+                if x is None or (x.dtype is f64 and x.device == dev and x.is_contiguous()):
+                    return x
+                return x.to(device=dev, dtype=f64).contiguous()
 
             q = prep(q); frame_targets = prep(frame_targets); posture_target = prep(posture_target)
             com_target = prep(com_target)
@@ -428,9 +441,9 @@ class NativeProblem:
             flags |= FLAG_DEVICE_PTRS
             v = (torch.empty((B, m.nv), dtype=torch.float64, device=dev) if out is None else out) if solve_qp else None
             st = (torch.empty((B,), dtype=torch.int32, device=dev) if status_out is None else status_out) if solve_qp else None
-            stream = torch.cuda.current_stream(dev).cuda_stream
+            stream = _raw_stream(torch, dev)
             tapbufs = {}
-            shapes = self._tap_shapes(B)
+            shapes = self._tap_shapes(B) if taps else None
             for n in taps:
                 dt_ = torch.int32 if n == "qp_iters" else (torch.int64 if n == "cycles" else torch.float64)
                 tapbufs[n] = torch.empty(shapes[n], dtype=dt_, device=dev)

@@ -158,7 +158,10 @@ __device__ __forceinline__ CvxW4 cvx_closest_tetrahedron(V3 p0, V3 p1, V3 p2, V3
 }
 
 // Closest points of the two cores: distance, point on 1, point on 2; returns false when the cores overlap.
-__device__ __forceinline__ bool cvx_gjk(const ConvexGeom& g1, const ConvexGeom& g2, double& dist, V3& pa, V3& pb) {
+// `cutoff`: the caller discards the pair when the cores are farther apart than this — the loop stops as soon as its
+// certified lower bound says so (dist = that bound, no witness points): two or three iterations instead of ~9 for the
+// pairs of a batch that are nowhere near each other.
+__device__ __forceinline__ bool cvx_gjk(const ConvexGeom& g1, const ConvexGeom& g2, const double cutoff, double& dist, V3& pa, V3& pb) {
   V3 d = g1.pos - g2.pos;
   if (dot(d, d) < 1e-30) d = {1.0, 0.0, 0.0};
   const V3 zero{0.0, 0.0, 0.0};
@@ -181,6 +184,7 @@ __device__ __forceinline__ bool cvx_gjk(const ConvexGeom& g1, const ConvexGeom& 
     const double vw = dot(v, w);
     if (vv - vw <= 1e-14 * vv) break;             // no support point is closer to the origin along v: converged
     lb = fmax(lb, vw / sqrt(vv));                 // every point of the difference is at least this far: a certified bound
+    if (lb > cutoff) { dist = lb; return true; }
     const double tol = 1e-28 * scale;
     bool same = dot(w - W0, w - W0) <= tol;
     same = same || (n > 1 && dot(w - W1, w - W1) <= tol);
@@ -290,7 +294,7 @@ __device__ __forceinline__ bool cvx_distance(const ConvexGeom& g1, const ConvexG
   const double r1 = cvx_core_radius(g1), r2 = cvx_core_radius(g2);
   double dc = 0.0;
   V3 pa{0, 0, 0}, pb{0, 0, 0};
-  const bool apart = cvx_gjk(g1, g2, dc, pa, pb);
+  const bool apart = cvx_gjk(g1, g2, margin + r1 + r2, dc, pa, pb);
   if (apart && dc > 1e-9) {                       // (cores apart: also when only the spherical shells overlap)
     dist = dc - r1 - r2;
     if (dist > margin) return false;

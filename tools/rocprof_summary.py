@@ -42,7 +42,7 @@ def pmc(out_path, dirs):
     solve_kernel = None
     for d in dirs:
         counters, res = read_counters(d)
-        iks = {k: cs for k, cs in counters.items() if "ik_solve_kernel" in k or "ik_lane_kernel" in k}
+        iks = {k: cs for k, cs in counters.items() if "ik_solve_kernel" in k or "ik_lane_kernel" in k or "ik_quad_kernel" in k}
         if iks:
             main = max(iks, key=lambda k: max(len(per) for per in iks[k].values()))
             solve_kernel = main
