@@ -63,7 +63,7 @@ extern "C" {
 #define MKH_FLAG_DIRECT_QP 8        /* never use the low-rank start of the QP (parity/diagnostic switch) */
 #define MKH_FLAG_WAVE_KERNEL 16     /* never use the row- / lane-per-problem kernels of small arms (parity/diagnostic switch) */
 #define MKH_FLAG_LANE_KERNEL 32     /* use the lane-per-problem kernel whenever the problem qualifies, whatever the batch
-                                     * size (default: plain solves from 73728 instances, fused loops from 8192;
+                                     * size (default: plain solves from 73728 instances, fused loops from 28672;
                                      * parity/diagnostic switch) */
 #define MKH_FLAG_TWO_WAVES 64       /* never use the 3-waves-per-SIMD kernel variants (parity/diagnostic switch) */
 #define MKH_FLAG_WARM_START 128     /* closed-loop callers: start the QP's active-set phase from where the previous solve of
@@ -73,8 +73,8 @@ extern "C" {
                                      * along an IK loop the active set changes by a few dofs per step.  The wavefront kernels
                                      * only (the lane kernel keeps its partition inside mkh_solve_steps / _until). */
 #define MKH_FLAG_QUAD_KERNEL 256    /* use the row-per-problem kernel of small arms (16 lanes per problem) whenever the problem
-                                     * qualifies and the call is a plain solve, whatever the batch size (default: below
-                                     * 73728 instances; parity/diagnostic switch) */
+                                     * qualifies, whatever the batch size (default: plain solves below 73728 instances, fused
+                                     * loops below 28672; parity/diagnostic switch) */
 
 /* frame types (mink/constants.py:3 SUPPORTED_FRAMES) */
 #define MKH_FRAME_BODY 0

@@ -22,8 +22,9 @@ int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stre
   return -1;
 }
 
-int launch_quad(int grid, hipStream_t stream, const LaneProblem* P, const LaneDims& dims, const SolveArgs& a) {
-  hipLaunchKernelGGL(ik_quad_kernel, dim3(grid), dim3(kWave), quad_lds_bytes(), stream, P, dims, a);
+int launch_quad(bool loop, int grid, hipStream_t stream, const LaneProblem* P, const LaneDims& dims, const SolveArgs& a) {
+  if (loop) hipLaunchKernelGGL(ik_quad_kernel<true>, dim3(grid), dim3(kWave), quad_lds_bytes(), stream, P, dims, a);
+  else hipLaunchKernelGGL(ik_quad_kernel<false>, dim3(grid), dim3(kWave), quad_lds_bytes(), stream, P, dims, a);
   return quad_lds_bytes();
 }
 

@@ -128,7 +128,8 @@ namespace mkh {
 int launch_variant(int nt, int nr, int feat, bool w3, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
                    const SolveArgs& a, const TapArgs* taps);
 int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);
-int launch_quad(int grid, hipStream_t stream, const LaneProblem* P, const LaneDims& dims, const SolveArgs& a);   // returns its LDS bytes per wavefront
+int launch_quad(bool loop, int grid, hipStream_t stream, const LaneProblem* P, const LaneDims& dims, const SolveArgs& a);   // returns its LDS bytes per wavefront
+constexpr int kLaneMinBatchLoop = 28672;  // fused loops of a small arm: row kernel below, lane kernel from here (M targets/s at 16 384: 39.7 vs 24.1, at 32 768: 42.4 vs 48.2)
 constexpr int kLaneMinBatch = 73728;  // plain solves of a small arm: row kernel below, lane kernel from here (launch())
 }
 
@@ -902,11 +903,12 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   }
   // Small arms (nv ≤ 8, hinge / slide joints, box limits) have two kernels of their own (plain solves without taps):
   //   * a 16-lane ROW per problem (quad_kernel.h): four problems per wavefront, so 4 096 problems put one wavefront on
-  //     every SIMD and each problem still spreads its phases over its lanes.  Single solves only (no fused loop, no warm
-  //     start);
+  //     every SIMD and each problem still spreads its phases over its lanes.  No warm start; its fused loop below
+  //     kLaneMinBatchLoop instances (threshold-terminated UR5e loop at 4 096: 22.4 M targets/s against 8.4 on the
+  //     wavefront kernel and 6.0 on the lane kernel);
   //   * one LANE per problem (lane_kernel.h): 64 problems per wavefront with every lane busy, one ≈48 µs dependent
   //     instruction stream per problem whatever the batch — the best use of the machine once every SIMD has several
-  //     wavefronts to interleave.  Also the fused caller loop (steps / until) from 8 192 instances.
+  //     wavefronts to interleave.  Also the fused caller loop (steps / until) from kLaneMinBatchLoop instances.
   // Measured on MI355X, UR5e config 2, M solves/s (tools/bench_small_arm.py; wavefront / row / lane kernel):
   //   B = 256: 12 / 25 / 7.6    4 096: 119 / 219 / 90    8 192: 130 / 449 / 152    32 768: 150 / 839 / 528
   //   65 536: 155 / 900 / 855    131 072: 158 / 1 169 / 1 506    1 048 576: 160 / 1 331 / 2 897
@@ -914,19 +916,19 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   // MKH_FLAG_WAVE_KERNEL / _QUAD_KERNEL / _LANE_KERNEL force one of the three (parity switches).
   const bool small_arm = p->lane_nv && !taps && a.do_qp && !(flags & MKH_FLAG_WAVE_KERNEL);
   const bool loop = a.n_steps > 1 || a.q_out || a.pos_threshold >= 0.0;       // fused caller loop (steps / until)
-  if (small_arm && !loop && !(flags & (MKH_FLAG_WARM_START | MKH_FLAG_LANE_KERNEL)) &&
-      (a.B < mkh::kLaneMinBatch || (flags & MKH_FLAG_QUAD_KERNEL))) {
+  if (small_arm && !(flags & (MKH_FLAG_WARM_START | MKH_FLAG_LANE_KERNEL)) &&
+      (a.B < (loop ? mkh::kLaneMinBatchLoop : mkh::kLaneMinBatch) || (flags & MKH_FLAG_QUAD_KERNEL))) {
     const int grid = (a.B + 3) / 4;
     p->last_grid = grid; p->last_nt = 8;
-    snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_quad_kernel");
+    snprintf(p->last_kernel, sizeof(p->last_kernel), loop ? "ik_quad_kernel_loop" : "ik_quad_kernel");
     SolveArgs aq = a;
     HIP_OK(clk_begin(p, aq, stream));
-    p->last_lds = mkh::launch_quad(grid, stream, p->d_lane, p->lane_dims, aq);
+    p->last_lds = mkh::launch_quad(loop, grid, stream, p->d_lane, p->lane_dims, aq);
     HIP_OK(hipGetLastError());
     HIP_OK(clk_end(p, a.B, stream));
     return MKH_OK;
   }
-  if (small_arm && (a.B >= (loop ? 8192 : mkh::kLaneMinBatch) || (flags & MKH_FLAG_LANE_KERNEL))) {
+  if (small_arm && (a.B >= (loop ? mkh::kLaneMinBatchLoop : mkh::kLaneMinBatch) || (flags & MKH_FLAG_LANE_KERNEL))) {
     const int grid = (a.B + kWave - 1) / kWave;
     p->last_grid = grid; p->last_lds = p->lane_lds; p->last_nt = p->lane_nv;
     snprintf(p->last_kernel, sizeof(p->last_kernel), loop ? "ik_lane_kernel_%d_loop" : "ik_lane_kernel_%d", p->lane_nv);

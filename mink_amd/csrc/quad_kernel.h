@@ -108,6 +108,10 @@ __device__ __forceinline__ bool quad_pivot(double (&T)[8], double& cc, const int
   return act && !ok;
 }
 
+// LOOP: the fused caller loop (mkh_solve_steps / mkh_solve_until; lane_kernel.h, same semantics): every ROW iterates
+// (solve, q ← q + Δq) on its own problem until its frame tasks are within the thresholds or the budget is spent; rows
+// that are finished idle through the remaining iterations of their wavefront (masked commits).
+template <bool LOOP>
 __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restrict__ Pg, const LaneDims D, const SolveArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const LaneProblem& P = *Pg;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
 #ifdef MKH_CLOCKS   // experiment builds (tools/phase_clocks.py): cycle stamps at the phase boundaries, row 24·pb of SolveArgs::clk
   long long tc[8];
   int tci = 0;
-#define MKH_QTICK() do { tc[tci++] = __builtin_readcyclecounter(); asm volatile("" : "+v"(status)); } while (0)
+#define MKH_QTICK() do { if (!LOOP) { tc[tci++] = __builtin_readcyclecounter(); asm volatile("" : "+v"(status)); } } while (0)
 #else
 #define MKH_QTICK() do {} while (0)
 #endif
@@ -136,7 +140,29 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
   const bool dv = l < nv;
   const int ld = dv ? l : 0;
   const int qadr = D.qadr_identity ? ld : P.dof_qadr[ld];
-  const double qd = dv ? A.q[(size_t)pb * nq + qadr] : 0.0;
+  double qd = dv ? A.q[(size_t)pb * nq + qadr] : 0.0;
+  // per-call inputs that do not change over a fused loop: posture targets (lane = dof), frame target (lane = task)
+  double ptq[kMaxPostureTasks], pcost[kMaxPostureTasks];
+#pragma unroll
+  for (int t = 0; t < kMaxPostureTasks; ++t) {
+    ptq[t] = 0.0; pcost[t] = 0.0;
+    if (t < D.n_posture) {
+      const double* tq = A.posture_target + (A.posture_batched ? ((size_t)pb * D.n_posture + t) * nq : (size_t)t * nq);
+      ptq[t] = tq[qadr];
+      pcost[t] = dv ? P.posture_cost[t][ld] : 0.0;
+    }
+  }
+  const double* const tgp = A.frame_targets + ((size_t)pb * nf + (l < nf ? l : 0)) * 7;
+  const SE3 Tt{Q4{tgp[0], tgp[1], tgp[2], tgp[3]}, V3{tgp[4], tgp[5], tgp[6]}};
+  const bool until = LOOP && A.pos_threshold >= 0.0;
+  const int n_steps = LOOP ? A.n_steps : 1;
+  bool fin = false;                                  // this row's loop is over (converged / failed / budget spent)
+  int it_done = 0, conv_flag = 0, status_all = 0;
+  double vlast = 0.0, x = 0.0;
+  int st = 1;                                        // QP partition: 0 free, 1 at lower, 2 at upper (padded lanes: bound at 0, never flip)
+  for (int step = 0; step < n_steps + (until ? 1 : 0); ++step) {
+  if (LOOP && !__ballot(!fin)) break;
+  status = 0;
   // Configuration.check_limits (mink/configuration.py:77-110), tol = 1e-6
   if (row_mask(dv && (qd < P.range_lo[ld] - 1e-6 || qd > P.range_hi[ld] + 1e-6))) status |= 1;
   // (everything below that needs q only comes first: its descriptor loads are in flight together with the links')
@@ -149,13 +175,15 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
   const bool slide = P.dof_slide[ld] != 0;
   // posture tasks (posture_task.py:87-142): e = target − q, J = −I  (hinge / slide dofs)
   double diag = 0.0, cc = 0.0, mu_total = A.damping;
-  for (int t = 0; t < D.n_posture; ++t) {
-    const double* tq = A.posture_target + (A.posture_batched ? ((size_t)pb * D.n_posture + t) * nq : (size_t)t * nq);
-    const double cost = dv ? P.posture_cost[t][ld] : 0.0;
-    const double we = cost * (-P.posture_gain[t] * (tq[qadr] - qd));
-    diag = fma(cost, cost, diag);
-    cc = fma(we, cost, cc);                          // c −= (W·e)·(−cost)
-    mu_total += P.posture_lm[t] * quad_sum(we * we);
+#pragma unroll
+  for (int t = 0; t < kMaxPostureTasks; ++t) {
+    if (t < D.n_posture) {
+      const double cost = pcost[t];
+      const double we = cost * (-P.posture_gain[t] * (ptq[t] - qd));
+      diag = fma(cost, cost, diag);
+      cc = fma(we, cost, cc);                        // c −= (W·e)·(−cost)
+      mu_total += P.posture_lm[t] * quad_sum(we * we);
+    }
   }
   // box limits
   double lo = 0.0, hi = 0.0;
@@ -222,6 +250,7 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
 
   MKH_QTICK();
   // ------------------------------------------------- frame tasks (lane = task; frame_task.py:95-146)
+  bool far_lane = false;                             // this task lane's frame is outside the callers' thresholds
   if (l < nf) {
     const LaneFrame& ft = P.frame[l];
     SE3 F;
@@ -236,14 +265,16 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
       F.p = bp + qrot(bq, V3{ft.lpos[0], ft.lpos[1], ft.lpos[2]});
       F.q = qmul(bq, Q4{ft.lquat[0], ft.lquat[1], ft.lquat[2], ft.lquat[3]});
     }
-    const double* tg = A.frame_targets + ((size_t)pb * nf + l) * 7;
-    const SE3 Tt{Q4{tg[0], tg[1], tg[2], tg[3]}, V3{tg[4], tg[5], tg[6]}};
     V3 ev, ew;
     double Jm[9], Qm[9];
     bool ident;
     se3_log(se3_mul(se3_inv(F), Tt), ev, ew);        // e = target.minus(frame)
     se3_ljacinv(ev, ew, Jm, Qm, ident);              // jlog(T_tb) = ljacinv(e)
     const double e6[6] = {ev.x, ev.y, ev.z, ew.x, ew.y, ew.z};
+    if (LOOP && until) {
+      const double pt = A.pos_threshold, ot = A.ori_threshold;
+      far_lane = !((!(ft.rowmask & 7) || dot(ev, ev) <= pt * pt) && (!(ft.rowmask & 56) || dot(ew, ew) <= ot * ot));
+    }
     double* const t = sT + l * kQuadTaskDoubles;
     double ss = 0.0;
 #pragma unroll
@@ -322,17 +353,29 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
 #pragma unroll
   for (int i = 0; i < 8; ++i) hdiag = (l == i) ? T[i] : hdiag;
 
+  if (LOOP && until && step > 0 && !fin) {
+    it_done = step;
+    if (!row_mask(far_lane)) { conv_flag = 1; fin = true; status_all |= status; }     // the callers' break (after the integration)
+    else if (step == n_steps) { fin = true; status_all |= status; }                    // budget spent: this pass only tested
+  }
+
   MKH_QTICK();
   // ------------------------------------------------------------------- QP
   const double tolw = 1e-16 * quad_max(dv ? hdiag : 0.0);         // (the wavefront kernel's multiplier threshold)
-  bool done = (status & 2) != 0;
+  bool done = (status & 2) != 0 || (LOOP && fin);
   // Starting partition from the diagonal estimate x_l ≈ −c_l / H_ll: dofs it puts outside the box start AT that bound
   // (any partition is a valid start of block principal pivoting; the benchmark's velocity limits saturate most dofs of
   // most instances, and a dof that starts at its bound saves the pivot in and the pivot out again)
-  int st = 1;                                        // 0 free, 1 at lower, 2 at upper (padded lanes: bound at 0, never flip)
-  if (dv) {
-    const double xd = -cc * fast_rcp(hdiag);
-    st = xd > hi ? 2 : (xd < lo ? 1 : 0);
+  // (fused loop, from the third step on: the partition the previous step's QP ended with — along an IK loop the active
+  //  set changes little from step to step, the diagonal estimate is at its worst when only some dofs saturate:
+  //  block principal pivoting then takes 3 iterations on average instead of 1.2, and a wavefront waits for the slowest
+  //  of its four rows)
+  if (!(LOOP && step >= 2)) {
+    st = 1;
+    if (dv) {
+      const double xd = -cc * fast_rcp(hdiag);
+      st = xd > hi ? 2 : (xd < lo ? 1 : 0);
+    }
   }
   {
     const unsigned long long fr = __ballot(st == 0 && !done);
@@ -344,7 +387,6 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
 #undef MKH_QP0
   }
   MKH_QTICK();
-  double x = 0.0;
   int best = 9, budget = 3;
   for (int it = 0; it < 10 * 8 + 10; ++it) {
     if (!__ballot(!done)) break;                     // every row of the wave has its optimum
@@ -385,6 +427,18 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
     if (flip) st = (f == 3) ? 0 : f;
   }
   if (!done) status |= 8;
+  if (!LOOP) { status_all = status; break; }
+  if (!fin) {                                        // commit this iteration
+    status_all |= status;
+    if (status & 14) {
+      fin = true;                                    // an instance stops at the first step whose QP fails
+    } else {
+      vlast = x / A.dt;
+      qd += x;                                       // mj_integratePos for hinge / slide joints (configuration.py:228-236)
+      if (!until) { it_done = step + 1; fin = step + 1 == n_steps; }
+    }
+  }
+  }  // step loop
   MKH_QTICK();
 #ifdef MKH_CLOCKS
   if (A.clk && live && l == 0) {
@@ -396,8 +450,18 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
 
   // ------------------------------------------------------------------ out
   if (live) {
-    if (dv) A.v_out[(size_t)pb * nv + l] = (status & 14) ? __builtin_nan("") : x / A.dt;      // v = Δq / dt (solve_ik.py:104)
-    if (l == 0 && A.status_out) A.status_out[pb] = status;
+    if (dv) {
+      const double vd = LOOP ? vlast : x / A.dt;                                              // v = Δq / dt (solve_ik.py:104)
+      A.v_out[(size_t)pb * nv + l] = (status_all & 14) ? __builtin_nan("") : vd;
+      if (LOOP && A.q_out) A.q_out[(size_t)pb * nq + qadr] = qd;
+    }
+    if (l == 0) {
+      if (A.status_out) A.status_out[pb] = status_all;
+      if (LOOP && until) {
+        if (A.iters_out) A.iters_out[pb] = it_done;
+        if (A.converged_out) A.converged_out[pb] = conv_flag;
+      }
+    }
   }
 }
 

@@ -60,11 +60,12 @@ def test_real_mink_fixture(nat):
             if n > B:
                 r = n % B or B
                 assert np.array_equal(vn[n - r:], v[:r])
-    # a fused loop, taps or a warm start are not this kernel's: the call falls through to the kernels that have them
+    # taps or a warm start are not this kernel's: the call falls through to the kernels that have them; fused loops are
+    # its own below 8 192 instances (tests/test_gpu_steps.py, test_fused_loop_* below)
     p = nc.build("ur5e_c2", nm, 1024)[0]
-    qn, tn = np.tile(d["q"], (4, 1))[:1024], np.tile(d["frame_targets"], (4, 1, 1))[:1024]
-    p.solve(qn, tn, d["posture_target"][None, :], None, dt, damping, n_steps=3, quad_kernel=True)
-    assert p.last_kernel() == "ik_solve_kernel_8_16", p.last_kernel()
+    qn, tn = np.tile(d["q"], (32, 1))[:1024], np.tile(d["frame_targets"], (32, 1, 1))[:1024]
+    p.solve(qn, tn, d["posture_target"][None, :], None, dt, damping, n_steps=3)
+    assert p.last_kernel() == "ik_quad_kernel_loop", p.last_kernel()
     p.solve(qn, tn, d["posture_target"][None, :], None, dt, damping, taps=("H",))
     assert p.last_kernel().endswith("_31"), p.last_kernel()
     p.solve(qn, tn, d["posture_target"][None, :], None, dt, damping, warm_start=True)
@@ -209,3 +210,40 @@ def test_failure_status(nat):
     vw, stw = prob.solve(q, tg, home[None, :], None, dt, damping, wave_kernel=True)
     assert (st == stw).all() and st[3] & 2 and np.isnan(v[3]).all() and np.isfinite(np.delete(v, 3, axis=0)).all()
     assert _rel(np.delete(v, 3, axis=0), np.delete(vw, 3, axis=0)).max() < 1e-9
+
+
+@pytest.mark.parametrize("until", [False, True])
+def test_fused_loop_against_the_other_kernels(nat, until):
+    """mkh_solve_steps / mkh_solve_until on the row kernel: final q, last v, status, iteration counts and converged flags
+    against the lane kernel's and the wavefront kernel's loops on 1 027 instances (a ragged last wavefront, rows of one
+    wavefront finishing at different iterations), including an instance whose box becomes inconsistent mid-loop."""
+    m = workloads.load_robot("ur5e")
+    nm = nat.NativeModel(m)
+    B = 1027
+    prob, dt, damping = nc.build("ur5e_c2", nm, B)
+    home = m.key_qpos[0]
+    rng = np.random.default_rng(8)
+    q0 = np.tile(home, (B, 1)) + rng.normal(scale=0.05, size=(B, m.nq))
+    scale = np.repeat([1e-3, 1e-2, 0.05, 0.3], -(-B // 4))[:B, None]
+    q_t = nm.integrate(q0, rng.normal(size=(B, m.nv)) * scale, 1.0)
+    dummy = np.zeros((B, 1, 7)); dummy[:, :, 0] = 1
+    _, _, t = prob.solve(q_t, dummy, home[None, :], None, 1.0, 1.0, taps=["frame_pose"], solve_qp=False)
+    tg = t["frame_pose"]
+    q0[11, 2] = 3.1415 + 0.5                           # outside the range by more than a step: inconsistent box, NaN, status 2
+    kw = {"n_steps": 12, "until": (1e-4, 1e-4)} if until else {"n_steps": 5}
+    ref = prob.solve(q0, tg, home[None, :], None, 2e-2, damping, wave_kernel=True, **kw)
+    assert prob.last_kernel() == "ik_solve_kernel_8_16"
+    got = prob.solve(q0, tg, home[None, :], None, 2e-2, damping, **kw)
+    assert prob.last_kernel() == "ik_quad_kernel_loop"
+    lane = prob.solve(q0, tg, home[None, :], None, 2e-2, damping, lane_kernel=True, **kw)
+    for other in (ref, lane):
+        np.testing.assert_array_equal(got[2], other[2])                                  # status
+        ok = (got[2] & 14) == 0
+        assert not ok[11] and ok.sum() == B - 1 and np.isnan(got[1][11]).all()
+        np.testing.assert_allclose(got[0][ok], other[0][ok], rtol=0, atol=1e-10)           # q
+        np.testing.assert_allclose(got[1][ok], other[1][ok], rtol=0, atol=1e-7 * max(1.0, np.abs(other[1][ok]).max()))
+        if until:
+            np.testing.assert_array_equal(got[3], other[3]); np.testing.assert_array_equal(got[4], other[4])
+    if until:
+        print("iterations:", np.bincount(got[3], minlength=13).tolist(), "converged:", int(got[4].sum()), "of", B)
+        assert 0 < got[4].sum() < B

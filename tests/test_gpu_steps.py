@@ -78,6 +78,7 @@ def test_threshold_terminated_loop_matches_the_callers_loop():
     tg = t["frame_pose"]
     dt = 2e-2                                                   # (a coarser step than the example's 2 ms: more spread in the counts)
     q, v, st, iters, conv = prob.solve(q0, tg, home[None, :], None, dt, damping, n_steps=max_iters, until=(pos_thr, ori_thr))
+    assert prob.last_kernel() == "ik_quad_kernel_loop", prob.last_kernel()   # default for a small arm below 28 672 instances
     assert (st & ~1 == 0).all()
     print("iterations:", np.bincount(iters, minlength=max_iters + 1).tolist(), "converged:", int(conv.sum()), "of", B)
     assert conv.sum() >= B // 4 and (conv == 0).sum() >= 4 and len(set(iters[conv == 1].tolist())) >= 3
@@ -95,13 +96,14 @@ def test_threshold_terminated_loop_matches_the_callers_loop():
         assert (iters[i], bool(conv[i])) == (n, done), (i, iters[i], conv[i], n, done)
         np.testing.assert_allclose(q[i], cfg.q, rtol=0, atol=1e-10)
         np.testing.assert_allclose(v[i], v_ref, rtol=0, atol=1e-7 * max(1.0, np.abs(v_ref).max()))
-    # the same loop in the lane-per-problem kernel (small arms, large batches): identical iteration counts and flags
-    ql, vl, stl, itl, cvl = prob.solve(q0, tg, home[None, :], None, dt, damping, n_steps=max_iters, until=(pos_thr, ori_thr),
-                                       lane_kernel=True)
-    assert prob.last_kernel() == "ik_lane_kernel_6_loop", prob.last_kernel()
-    np.testing.assert_array_equal(itl, iters); np.testing.assert_array_equal(cvl, conv); np.testing.assert_array_equal(stl, st)
-    np.testing.assert_allclose(ql, q, rtol=0, atol=1e-10)
-    np.testing.assert_allclose(vl, v, rtol=0, atol=1e-7 * max(1.0, np.abs(v).max()))
+    # the same loop in the lane-per-problem kernel (small arms, large batches) and in the wavefront kernel: identical
+    # iteration counts and flags
+    for kw, kernel in (({"lane_kernel": True}, "ik_lane_kernel_6_loop"), ({"wave_kernel": True}, "ik_solve_kernel_8_16")):
+        ql, vl, stl, itl, cvl = prob.solve(q0, tg, home[None, :], None, dt, damping, n_steps=max_iters, until=(pos_thr, ori_thr), **kw)
+        assert prob.last_kernel() == kernel, prob.last_kernel()
+        np.testing.assert_array_equal(itl, iters); np.testing.assert_array_equal(cvl, conv); np.testing.assert_array_equal(stl, st)
+        np.testing.assert_allclose(ql, q, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(vl, v, rtol=0, atol=1e-7 * max(1.0, np.abs(v).max()))
     # the public API
     cfg = mink.Configuration(model, q0)
     ft = mink.FrameTask("attachment_site", "site", position_cost=1.0, orientation_cost=1.0, lm_damping=1.0)
@@ -114,15 +116,18 @@ def test_threshold_terminated_loop_matches_the_callers_loop():
     np.testing.assert_allclose(q2, q, rtol=0, atol=1e-12)
     # fixed-count calls are untouched by the feature
     qf, vf, stf = prob.solve(q0, tg, home[None, :], None, dt, damping, n_steps=3)
+    assert prob.last_kernel() == "ik_quad_kernel_loop"
     qs = q0.copy()
     for _ in range(3):
         vs, _ = prob.solve(qs, tg, home[None, :], None, dt, damping)
         qs = nm.integrate(qs, vs, dt)
     np.testing.assert_allclose(qf, qs, rtol=0, atol=1e-10)
-    qfl, vfl, stfl = prob.solve(q0, tg, home[None, :], None, dt, damping, n_steps=3, lane_kernel=True)
-    assert prob.last_kernel() == "ik_lane_kernel_6_loop"
-    np.testing.assert_allclose(qfl, qs, rtol=0, atol=1e-10)
-    np.testing.assert_allclose(vfl, vs, rtol=0, atol=1e-8 * max(1.0, np.abs(vs).max()))
+    np.testing.assert_allclose(vf, vs, rtol=0, atol=1e-8 * max(1.0, np.abs(vs).max()))
+    for kw, kernel in (({"lane_kernel": True}, "ik_lane_kernel_6_loop"), ({"wave_kernel": True}, "ik_solve_kernel_8_16")):
+        qfl, vfl, stfl = prob.solve(q0, tg, home[None, :], None, dt, damping, n_steps=3, **kw)
+        assert prob.last_kernel() == kernel
+        np.testing.assert_allclose(qfl, qs, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(vfl, vs, rtol=0, atol=1e-8 * max(1.0, np.abs(vs).max()))
 
 
 def test_warm_start_across_calls_gives_the_cold_answers():

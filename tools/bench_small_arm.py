@@ -4,7 +4,8 @@ on — wavefront per problem (ik_kernel.h), 16-lane row per problem (quad_kernel
 device-resident inputs, HIP-event timing of back-to-back solves.  Where the dispatch thresholds in minkhip.hip
 (`launch`) come from.
 
-    python tools/bench_small_arm.py [reps] [config]
+    python tools/bench_small_arm.py [reps] [config] [loop]      (loop: the threshold-terminated caller loop, max_iters 20,
+                                                                 1 mm / 0.01 rad — M targets/s instead of M solves/s)
 """
 import os
 import sys
@@ -24,6 +25,8 @@ def main():
 
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     config = sys.argv[2] if len(sys.argv) > 2 else "ur5e_c2"
+    loop = len(sys.argv) > 3 and sys.argv[3] == "loop"
+    extra = {"n_steps": 20, "until": (1e-3, 1e-2)} if loop else {}
     dev = torch.device("cuda", 0)
     model = workloads.load_bench_robot(config)
     nm = nat.NativeModel(model, device=0)
@@ -34,17 +37,17 @@ def main():
         q, tg, pt = torch.from_numpy(q_h).to(dev), torch.from_numpy(tg_h).to(dev), torch.from_numpy(pt_h).to(dev)
         v = torch.empty((B, model.nv), dtype=torch.float64, device=dev)
         st = torch.empty((B,), dtype=torch.int32, device=dev)
-        prob.solve(q, tg, pt, None, dt, damping, out=v, status_out=st)
+        prob.solve(q, tg, pt, None, dt, damping, out=v, status_out=st, **extra)
         default = prob.last_kernel()
         cells = []
         for kw in ({"wave_kernel": True}, {"quad_kernel": True}, {"lane_kernel": True}):
             for _ in range(20):
-                prob.solve(q, tg, pt, None, dt, damping, out=v, status_out=st, **kw)
+                prob.solve(q, tg, pt, None, dt, damping, out=v, status_out=st, **kw, **extra)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            n = max(reps, min(1000, (1 << 20) // B))   # (short kernels: enough launches for the clocks to settle)
+            n = max(reps, min(1000, (1 << 20) // B)) // (10 if loop else 1)   # (short kernels: enough launches for the clocks to settle)
             for _ in range(n):
-                prob.solve(q, tg, pt, None, dt, damping, out=v, status_out=st, **kw)
+                prob.solve(q, tg, pt, None, dt, damping, out=v, status_out=st, **kw, **extra)
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / n
