@@ -1742,6 +1742,9 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     }
 
     hdiag += mu_total;
+#if defined(MKH_WOOD_CALL) && defined(MKH_CLOCKS)
+    if (A.clk && lane == 0) A.clk[(size_t)pb * 24 + 22] = __builtin_readcyclecounter();            // [22] posture / damping / dense tasks done
+#endif
     const double hdiag_base = hdiag;   // damping + Σμ + posture diagonal: the explicit diagonal of H
 
     // ------------------------------------------- collision half-space rows
@@ -1839,6 +1842,9 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       }
     };
     if constexpr (kWood) box_limits();
+#if defined(MKH_WOOD_CALL) && defined(MKH_CLOCKS)
+    if (A.clk && lane == 0) A.clk[(size_t)pb * 24 + 23] = __builtin_readcyclecounter();            // [23] box limits done
+#endif
     // ---- low-rank start: Jacobian rows, S = I + Jh·Jhᵀ, LDLᵀ elimination (wood_start above), then the dof block of the
     // tableau by n_μ rank-1 updates that do not depend on each other:  R[i][j] = Σ_r Z[r][i]·Z[r][j]/d_r
     WoodOut wo{0.0, 0.0, 0.0, 0.0, 0, 0};

@@ -73,6 +73,9 @@ def run(name, B=None):
     if (c[:, 20] != 0).any():                   # callee builds: pre_phases stamps its own phases
         print("      pre_phases: FK %8.0f | axes / dof / com %8.0f | task lanes %8.0f" % (
             (c[:, 20] - c[:, 0]).mean(), (c[:, 21] - c[:, 20]).mean(), (st[:, 3] - c[:, 21]).mean()))
+    if (c[:, 22] != 0).any():
+        print("      after the task lanes: posture / damping tasks %8.0f | box limits %8.0f | to the callee's entry %8.0f" % (
+            (c[:, 22] - st[:, 3]).mean(), (c[:, 23] - c[:, 22]).mean(), (c[:, 16] - c[:, 23]).mean()))
     if (c[:, 16] != 0).any():
         print("      wood_start: posture / box %8.0f | J rows %8.0f | S, w %8.0f | elimination %8.0f | then rank-1 block … to tick 4: %8.0f" % (
             (c[:, 16] - st[:, 3]).mean(), (c[:, 17] - c[:, 16]).mean(), (c[:, 18] - c[:, 17]).mean(), (c[:, 19] - c[:, 18]).mean(),
