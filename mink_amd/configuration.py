@@ -54,6 +54,8 @@ class Configuration:
         # A descriptor owns one ticket counter and one set of staging buffers, so calls on ONE Configuration must not
         # run concurrently from several threads/streams (include/minkhip.h "One in-flight call per MkhProblem").
         self._problems = {}
+        self._compile_memo = {}          # (task / limit fingerprints, batch) → (cache key, layout): solve_ik._compile's shortcut
+        self._default_limits = None      # the [ConfigurationLimit(model)] of solve_ik(limits=None), built once
         self._pinned_problems = {}       # cache key → nesting count of callers about to solve on that handle (never evicted)
         self._q = None
         self.update(q if q is not None else self.model.qpos0)

@@ -48,8 +48,25 @@ static hipError_t upload(const std::vector<T>& h, T** d) {
   return e;
 }
 
+// Small host-pointer calls (a control loop's single configuration: the reference's everyday use) go through ONE pinned,
+// device-visible host buffer: the kernel reads its inputs and writes its outputs across the bus itself — a launch and a
+// synchronize instead of five staged copies of ≈8 µs host time each, whatever their size.
+constexpr size_t kSmallCallBytes = 64 << 10;
+struct PinnedScratch {
+  char* host = nullptr;
+  char* dev = nullptr;
+  hipError_t ensure() {
+    if (host) return hipSuccess;
+    if (hipError_t e = hipHostMalloc((void**)&host, kSmallCallBytes, hipHostMallocDefault)) { host = nullptr; return e; }
+    if (hipError_t e = hipHostGetDevicePointer((void**)&dev, host, 0)) { (void)hipHostFree(host); host = nullptr; return e; }
+    return hipSuccess;
+  }
+  void release() { if (host) (void)hipHostFree(host); host = dev = nullptr; }
+};
+
 struct MkhModel {
   int device = 0;
+  PinnedScratch small;             // mkh_integrate, host pointers
   int nq = 0, nv = 0, nbody = 0, njnt = 0, ngeom = 0, nsite = 0, nrounds = 0;
   // host copies needed when problems are created
   std::vector<int32_t> body_parentid, body_rootid, body_jntnum, body_jntadr, body_dofnum, body_dofadr;
@@ -70,6 +87,7 @@ struct MkhModel {
 };
 
 struct MkhProblem {
+  PinnedScratch small;             // run(), host pointers
   MkhModel* model = nullptr;
   int device = 0;                  // (copied: the destructor must not depend on the model still being alive)
   DeviceProblem dev{};
@@ -439,6 +457,7 @@ void mkh_model_destroy(MkhModel* m) {
   (void)hipSetDevice(m->device);
   (void)hipFree(m->d_body_f); (void)hipFree(m->d_body_i); (void)hipFree(m->d_jnt_f); (void)hipFree(m->d_jnt_i);
   (void)hipFree(m->d_dof_i); (void)hipFree(m->d_dof_f); (void)hipFree(m->d_mesh_vert);
+  m->small.release();
   delete m;
 }
 
@@ -830,6 +849,7 @@ void mkh_problem_destroy(MkhProblem* p) {
   (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain); (void)hipFree(p->s_iters);
   (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh); (void)hipFree(p->s_dbox); (void)hipFree(p->d_clk);
   (void)hipFree(p->s_q); (void)hipFree(p->s_ft); (void)hipFree(p->s_pt); (void)hipFree(p->s_ct); (void)hipFree(p->s_v); (void)hipFree(p->s_status);
+  p->small.release();
   if (p->st_in) (void)hipStreamDestroy(p->st_in);
   if (p->st_out) (void)hipStreamDestroy(p->st_out);
   if (p->ev_start) (void)hipEventDestroy(p->ev_start);
@@ -1086,6 +1106,47 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
     }
     return launch(p, a, taps ? &t : nullptr, stream, flags);
   }
+  // ---- host pointers, small call: everything through the pinned scratch (see PinnedScratch)
+  {
+    const size_t Bz = B;
+    const size_t d_q = Bz * nq, d_ft = Bz * P.n_frame * 7, d_v = v_out ? Bz * nv : 0;
+    const size_t doubles = d_q + d_ft + n_pt + n_ct + d_v;
+    const size_t bytes = doubles * sizeof(double) + Bz * (until ? 3 : 1) * sizeof(int32_t);
+    if (!taps && !Kd && !Md && !Bd && bytes <= kSmallCallBytes) {
+      HIP_OK(p->small.ensure());
+      double* h = (double*)p->small.host;
+      double* d = (double*)p->small.dev;
+      size_t o = 0;
+      auto put = [&](const double* src, size_t n) -> const double* {
+        if (!n) return nullptr;
+        memcpy(h + o, src, n * sizeof(double));
+        const double* r = d + o;
+        o += n;
+        return r;
+      };
+      a.q = put(q, d_q);
+      a.frame_targets = put(frame_targets, d_ft);
+      a.posture_target = put(posture_target, n_pt);
+      a.com_target = put(com_target, n_ct);
+      const size_t o_v = o;
+      a.v_out = v_out ? d + o_v : nullptr;
+      o += d_v;
+      int32_t* const hi32 = (int32_t*)(h + o);
+      int32_t* const di32 = (int32_t*)(d + o);
+      a.status_out = di32;
+      a.q_out = q_out ? (double*)a.q : nullptr;        // in place, as in the staged path
+      if (until) { a.iters_out = di32 + Bz; a.converged_out = di32 + 2 * Bz; }
+      const int32_t rc = launch(p, a, nullptr, stream, flags);
+      if (rc != MKH_OK) return rc;
+      HIP_OK(hipStreamSynchronize(stream));
+      if (v_out) memcpy(v_out, h + o_v, d_v * sizeof(double));
+      if (q_out) memcpy(q_out, h, d_q * sizeof(double));
+      if (status_out) memcpy(status_out, hi32, Bz * sizeof(int32_t));
+      if (until && iters_out) memcpy(iters_out, hi32 + Bz, Bz * sizeof(int32_t));
+      if (until && converged_out) memcpy(converged_out, hi32 + 2 * Bz, Bz * sizeof(int32_t));
+      return MKH_OK;
+    }
+  }
   // ---- host pointers: stage through library-owned device buffers
   const size_t mb = p->max_batch;
   HIP_OK(ensure(&p->s_q, mb * nq));
@@ -1298,8 +1359,21 @@ int32_t mkh_integrate(MkhModel* m, int32_t B, const double* q, const double* v, 
     HIP_OK(hipGetLastError());
     return MKH_OK;
   }
-  double *dq = nullptr, *dv = nullptr, *dout = nullptr;
   const size_t bq = (size_t)B * m->nq * 8, bv = (size_t)B * m->nv * 8;
+  if (2 * bq + bv <= kSmallCallBytes) {               // small call: through the pinned scratch (see PinnedScratch)
+    HIP_OK(m->small.ensure());
+    char* const h = m->small.host;
+    char* const d = m->small.dev;
+    memcpy(h, q, bq);
+    memcpy(h + bq, v, bv);
+    hipLaunchKernelGGL(integrate_kernel, dim3(grid), dim3(block), 0, stream, P, B, (const double*)d, (const double*)(d + bq), dt,
+                       (double*)(d + bq + bv));
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipStreamSynchronize(stream));
+    memcpy(q_out, h + bq + bv, bq);
+    return MKH_OK;
+  }
+  double *dq = nullptr, *dv = nullptr, *dout = nullptr;
   HIP_OK(hipMalloc((void**)&dq, bq));
   hipError_t e = hipMalloc((void**)&dv, bv);
   if (e == hipSuccess) e = hipMalloc((void**)&dout, bq);

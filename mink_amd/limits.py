@@ -35,6 +35,10 @@ class Limit(abc.ABC):
         """(kind, descriptor dict) for mkh_problem_create."""
         return "dense_limit", None
 
+    def _fingerprint(self):
+        """Cheap hashable stand-in for the device descriptor (see Task._fingerprint); None: no shortcut."""
+        return None
+
     def _is_dense(self) -> bool:
         return type(self)._native_desc is Limit._native_desc or \
             type(self).compute_qp_inequalities not in _BUILTIN_INEQUALITIES
@@ -69,6 +73,11 @@ class ConfigurationLimit(Limit):
 
     def _native_desc(self):
         return "cfg", {"gain": self.gain, "lower": self.lower, "upper": self.upper, "indices": self.indices}
+
+    def _fingerprint(self):
+        if self._is_dense():
+            return None
+        return (id(self), float(self.gain), self.lower.tobytes(), self.upper.tobytes(), np.asarray(self.indices).tobytes())
 
     def compute_qp_inequalities(self, configuration: Configuration, dt: float) -> Constraint:
         if self.projection_matrix is None:
@@ -109,6 +118,11 @@ class VelocityLimit(Limit):
 
     def _native_desc(self):
         return "vel", {"indices": self.indices, "limit": self.limit}
+
+    def _fingerprint(self):
+        if self._is_dense():
+            return None
+        return (id(self), np.asarray(self.indices).tobytes(), np.asarray(self.limit, dtype=np.float64).tobytes())
 
     def compute_qp_inequalities(self, configuration: Configuration, dt: float) -> Constraint:
         if self.projection_matrix is None:
@@ -211,6 +225,13 @@ class CollisionAvoidanceLimit(Limit):
                        "minimum_distance_from_collisions": self.minimum_distance_from_collisions,
                        "collision_detection_distance": self.collision_detection_distance,
                        "bound_relaxation": self.bound_relaxation}
+
+    def _fingerprint(self):
+        if self._is_dense():
+            return None
+        return (id(self), float(self.gain), float(self.minimum_distance_from_collisions),
+                float(self.collision_detection_distance), float(self.bound_relaxation),
+                np.asarray(self.geom_id_pairs, dtype=np.int32).tobytes())
 
     def compute_qp_inequalities(self, configuration: Configuration, dt: float) -> Constraint:
         out = self._eval(configuration, dt, ["coll_G", "coll_h"])

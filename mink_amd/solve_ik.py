@@ -108,7 +108,19 @@ def _compile(configuration: Configuration, tasks: Sequence, limits: Optional[Seq
     from .tasks import Task
 
     if limits is None:
-        limits = [ConfigurationLimit(configuration.model)]          # mink/solve_ik.py:28-29
+        limits = configuration._default_limits                       # mink/solve_ik.py:28-29
+        if limits is None:
+            limits = configuration._default_limits = [ConfigurationLimit(configuration.model)]
+    # Memo for control loops: the same task / limit objects with the same costs → the same handle and layout, without
+    # rebuilding and hashing every descriptor (78 µs of a 185 µs G1 iteration; tools/bench_control_loop.py).
+    fps = [x._fingerprint() for x in tasks] + [x._fingerprint() for x in limits]
+    memo_key = None if any(f is None for f in fps) else (tuple(fps), len(tasks), batch)
+    if memo_key is not None:
+        hit = configuration._compile_memo.get(memo_key)
+        if hit is not None and hit[0] in configuration._problems:
+            prob = configuration._problems.pop(hit[0])
+            configuration._problems[hit[0]] = prob                   # most recently used
+            return prob, hit[1]
     groups = {"frame": [], "posture": [], "com": [], "cfg": [], "vel": [], "col": [], "dense": []}
     layout = {"frame": [], "posture": [], "com": [], "dense": [], "dense_limits": [], "dense_limit_rows": 0}
     for t in tasks:
@@ -165,6 +177,10 @@ def _compile(configuration: Configuration, tasks: Sequence, limits: Optional[Seq
     for old in [k for k in cache if k not in pinned][:max(0, len(cache) - PROBLEM_CACHE_SIZE)]:
         cache.pop(old).close()
     layout["cache_key"] = key
+    if memo_key is not None:
+        if len(configuration._compile_memo) >= 4 * PROBLEM_CACHE_SIZE:
+            configuration._compile_memo.clear()
+        configuration._compile_memo[memo_key] = (key, layout)
     return prob, layout
 
 

@@ -24,6 +24,9 @@ class Objective(NamedTuple):
         return x.T @ self.H @ x + self.c @ x
 
 
+_DENSE_BY_CLASS: dict = {}
+
+
 class Task(abc.ABC):
     """mink/tasks/task.py:25-138."""
 
@@ -51,6 +54,17 @@ class Task(abc.ABC):
         """Target rows for mkh_solve (built-in tasks only)."""
         raise NotImplementedError
 
+    def _fingerprint(self):
+        """A cheap, hashable stand-in for this task's device descriptor (solve_ik._compile's memo: a control loop calls
+        solve_ik with the same task objects thousands of times a second, and building + hashing the descriptors cost more
+        than the launch).  Everything `_native_desc` reads must be in it BY VALUE — costs are arrays the setters modify in
+        place.  None: no shortcut for this task (caller-defined tasks: their rows are evaluated per call anyway)."""
+        return None
+
+    def _fp_common(self):
+        return (id(self), np.asarray(self.cost, dtype=np.float64).tobytes(), float(self.gain), float(self.lm_damping),
+                getattr(self, "_force_builtin", 0))
+
     _PLUGIN_METHODS = ("compute_error", "compute_jacobian", "compute_qp_objective")
 
     def _builtin_class(self) -> type:
@@ -68,8 +82,14 @@ class Task(abc.ABC):
         answer here too — the built-in device descriptor would silently ignore it."""
         if getattr(self, "_force_builtin", 0):
             return False
-        base, cls = self._builtin_class(), type(self)
-        return base is Task or any(getattr(cls, n) is not getattr(base, n) for n in Task._PLUGIN_METHODS)
+        cls = type(self)
+        hit = _DENSE_BY_CLASS.get(cls)
+        if hit is None or hit[0] != tuple(getattr(cls, n) for n in Task._PLUGIN_METHODS):     # (methods patched onto a class: re-derive)
+            base = self._builtin_class()
+            methods = tuple(getattr(cls, n) for n in Task._PLUGIN_METHODS)
+            hit = (methods, base is Task or any(m is not getattr(base, n) for m, n in zip(methods, Task._PLUGIN_METHODS)))
+            _DENSE_BY_CLASS[cls] = hit
+        return hit[1]
 
     def _dense_rows(self, configuration: Configuration):
         """(e, J) of this caller-defined task for every instance: (B, k), (B, k, nv).  A half the subclass inherits from a
@@ -171,6 +191,9 @@ class FrameTask(Task):
         return "frame", {"frame_type": self.frame_type, "frame_id": fid, "cost": self.cost.tolist(),
                          "gain": self.gain, "lm_damping": self.lm_damping}
 
+    def _fingerprint(self):
+        return None if self._is_dense() else self._fp_common() + (self.frame_name, self.frame_type)
+
     def _native_target(self, configuration):
         if self.transform_target_to_world is None:
             raise TargetNotSet(self.__class__.__name__)
@@ -220,6 +243,9 @@ class PostureTask(Task):
 
     def _native_desc(self, configuration):
         return "posture", {"cost": self.cost.copy(), "gain": self.gain, "lm_damping": self.lm_damping}
+
+    def _fingerprint(self):
+        return None if self._is_dense() else self._fp_common()
 
     def _native_target(self, configuration):
         if self.target_q is None:
@@ -273,6 +299,9 @@ class ComTask(Task):
         configuration.model.require_valid_masses("ComTask")
         return "com", {"cost": self.cost.tolist(), "gain": self.gain, "lm_damping": self.lm_damping}
 
+    def _fingerprint(self):
+        return None if self._is_dense() else self._fp_common()
+
     def _native_target(self, configuration):
         if self.target_com is None:
             raise TargetNotSet(self.__class__.__name__)
@@ -294,6 +323,10 @@ class RelativeFrameTask(FrameTask):
 
     def set_target_from_configuration(self, configuration: Configuration) -> None:
         self.set_target(configuration.get_transform(self.frame_name, self.frame_type, self.root_name, self.root_type))
+
+    def _fingerprint(self):
+        fp = super()._fingerprint()
+        return None if fp is None else fp + (self.root_name, self.root_type)
 
     def _native_desc(self, configuration):
         kind, d = super()._native_desc(configuration)
