@@ -386,3 +386,73 @@ def test_one_process_drives_several_devices():
     assert mink.Configuration(m, q[:4], device="all").devices == list(range(nat.lib().mkh_device_count()))
     with pytest.raises(nat.MinkHipError, match="max_batch"):
         list(many._problems.values())[-1].solve(np.tile(q, (2, 1)), None, None, None, 1e-2, 1e-3)
+
+
+def test_compile_memo_sees_costs_changed_in_place(g1):
+    """solve_ik memoises the compiled handle on the task / limit OBJECTS (control loops call it thousands of times a second
+    with the same ones) — by VALUE of everything the device descriptor holds: the reference's setters modify `cost` in place
+    (tasks/frame_task.py set_position_cost), and a retuned task must not get the old descriptor."""
+    rng = np.random.default_rng(3)
+    from mink_amd import workloads
+    q = workloads.sample_q(g1, rng, 4, base_q=g1.key_qpos[0])
+    cfg = mink.Configuration(g1, q)
+    tgt = mink.Configuration(g1, cfg.integrate(rng.normal(scale=0.1, size=(4, g1.nv)), 1.0))
+
+    def make(pos_cost, gain, lm, posture_cost):
+        ts = [mink.FrameTask(s, "site", pos_cost, 10.0, gain=gain, lm_damping=lm) for s in ("left_foot", "right_palm")]
+        for t in ts:
+            t.set_target(tgt.get_transform_frame_to_world(t.frame_name, "site"))
+        post = mink.PostureTask(g1, posture_cost); post.set_target(g1.key_qpos[0])
+        return ts + [post]
+
+    lims = [mink.ConfigurationLimit(g1)]
+    tasks = make(200.0, 1.0, 1.0, 1.0)
+    v0 = mink.solve_ik(cfg, tasks, 5e-3, "mi355x", 1e-1, limits=lims)
+    assert len(cfg._compile_memo) == 1
+    np.testing.assert_array_equal(mink.solve_ik(cfg, tasks, 5e-3, "mi355x", 1e-1, limits=lims), v0)     # memo hit: same handle
+    assert len(cfg._compile_memo) == 1 and len(cfg._problems) == 1
+    tasks[0].set_position_cost(20.0)                   # in place
+    tasks[1].gain = 0.5
+    tasks[1].lm_damping = 0.0
+    tasks[2].set_cost(0.1)
+    v1 = mink.solve_ik(cfg, tasks, 5e-3, "mi355x", 1e-1, limits=lims)
+    fresh = make(200.0, 1.0, 1.0, 0.1)
+    fresh[0].set_position_cost(20.0); fresh[1].gain = 0.5; fresh[1].lm_damping = 0.0
+    v_ref = mink.solve_ik(mink.Configuration(g1, q), fresh, 5e-3, "mi355x", 1e-1, limits=lims)
+    np.testing.assert_array_equal(v1, v_ref)
+    assert np.abs(v1 - v0).max() > 1e-3
+    # a limit retuned in place, and limits=None (the default ConfigurationLimit is built once per configuration)
+    lims[0].gain = 0.5
+    v2 = mink.solve_ik(cfg, tasks, 5e-3, "mi355x", 1e-1, limits=lims)
+    v2_ref = mink.solve_ik(mink.Configuration(g1, q), fresh, 5e-3, "mi355x", 1e-1, limits=[mink.ConfigurationLimit(g1, gain=0.5)])
+    np.testing.assert_array_equal(v2, v2_ref)
+    d0 = mink.solve_ik(cfg, tasks, 5e-3, "mi355x", 1e-1)
+    d1 = mink.solve_ik(cfg, tasks, 5e-3, "mi355x", 1e-1)
+    np.testing.assert_array_equal(d0, d1)
+    assert cfg._default_limits is not None and len(cfg._default_limits) == 1
+
+
+def test_small_host_calls_equal_staged_calls(g1):
+    """Host-pointer calls below 64 KB go through one pinned, device-visible buffer (the kernel reads and writes it across the
+    bus), larger ones through staged copies: the same rows either way, bitwise — single solves, fused steps and the
+    threshold-terminated loop."""
+    from mink_amd import _native as nat, workloads
+    import native_configs as nc
+    nm = nat.NativeModel(g1)
+    B = 96                                             # 96 x 924 B: staged; halves of 48 and single rows: pinned
+    prob, dt, damping = nc.build("g1_c3", nm, B)
+    rng = np.random.default_rng(12)
+    base = g1.key_qpos[g1.name2id("key", "stand")]
+    q, tg = workloads.make_batch(g1, nm, prob, rng, B, base_q=base)
+    pt = base[None, :]
+    for kw in ({}, {"n_steps": 3}, {"n_steps": 6, "until": (1e-3, 1e-2)}):
+        big = prob.solve(q, tg, pt, None, dt, damping, **kw)
+        for lo, hi in ((0, 48), (48, 96), (7, 8)):
+            small = prob.solve(q[lo:hi], tg[lo:hi], pt, None, dt, damping, **kw)
+            for a, b in zip(small, big):
+                np.testing.assert_array_equal(a, b[lo:hi])
+    # mkh_integrate: small (pinned) against large (staged) calls
+    v = rng.normal(size=(B, g1.nv))
+    qi = nm.integrate(np.tile(q, (2, 1)), np.tile(v, (2, 1)), 0.1)      # 192 rows: staged
+    np.testing.assert_array_equal(nm.integrate(q[:20], v[:20], 0.1), qi[:20])
+    np.testing.assert_array_equal(qi[:B], qi[B:])
