@@ -273,6 +273,27 @@ static hipError_t ensure(T** buf, size_t n) {
   return hipMalloc((void**)buf, (n ? n : 1) * sizeof(T));
 }
 
+// The debug / plugin taps of a call: `alloc(host pointer, bytes, zero first)` returns the device-visible buffer the kernel
+// writes (nullptr for a tap the caller did not ask for).
+template <typename Alloc>
+static void assign_taps(const MkhTaps* taps, const DeviceProblem& P, size_t Bz, TapArgs& t, Alloc&& alloc) {
+  const size_t nv = P.nv;
+  t.t_xpos = (double*)alloc(taps->xpos, Bz * P.nbody * 3 * 8, false);
+  t.t_xquat = (double*)alloc(taps->xquat, Bz * P.nbody * 4 * 8, false);
+  t.t_frame_pose = (double*)alloc(taps->frame_pose, Bz * P.n_frame * 7 * 8, false);
+  t.t_subtree_com = (double*)alloc(taps->subtree_com, Bz * 3 * 8, true);
+  t.t_task_e = (double*)alloc(taps->task_e, Bz * P.n_rows_tap * 8, true);
+  t.t_task_J = (double*)alloc(taps->task_J, Bz * P.n_rows_tap * nv * 8, true);
+  t.t_H = (double*)alloc(taps->H, Bz * nv * nv * 8, false);
+  t.t_c = (double*)alloc(taps->c, Bz * nv * 8, false);
+  t.t_box_lo = (double*)alloc(taps->box_lo, Bz * nv * 8, false);
+  t.t_box_hi = (double*)alloc(taps->box_hi, Bz * nv * 8, false);
+  t.t_coll_G = (double*)alloc(taps->coll_G, Bz * P.n_pairs * nv * 8, true);
+  t.t_coll_h = (double*)alloc(taps->coll_h, Bz * P.n_pairs * 8, false);
+  t.t_qp_iters = (int32_t*)alloc(taps->qp_iters, Bz * 4, true);
+  t.t_cycles = (long long*)alloc(taps->cycles, Bz * 16 * 8, true);
+}
+
 extern "C" {
 
 int32_t mkh_version(void) { return MKH_VERSION; }
@@ -1106,22 +1127,25 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
     }
     return launch(p, a, taps ? &t : nullptr, stream, flags);
   }
-  // ---- host pointers, small call: everything through the pinned scratch (see PinnedScratch)
+  // ---- host pointers, small call: everything through the pinned scratch (see PinnedScratch) — inputs, outputs and taps
   {
     const size_t Bz = B;
     const size_t d_q = Bz * nq, d_ft = Bz * P.n_frame * 7, d_v = v_out ? Bz * nv : 0;
-    const size_t doubles = d_q + d_ft + n_pt + n_ct + d_v;
-    const size_t bytes = doubles * sizeof(double) + Bz * (until ? 3 : 1) * sizeof(int32_t);
-    if (!taps && !Kd && !Md && !Bd && bytes <= kSmallCallBytes) {
+    size_t bytes = (d_q + d_ft + n_pt + n_ct + d_v) * sizeof(double) + ((Bz * (until ? 3 : 1) * sizeof(int32_t) + 7) & ~(size_t)7);
+    if (taps) {
+      TapArgs sizes;
+      assign_taps(taps, P, Bz, sizes, [&](void* host, size_t n, bool) -> void* { if (host) bytes += (n + 7) & ~(size_t)7; return nullptr; });
+    }
+    if (!Kd && !Md && !Bd && bytes <= kSmallCallBytes) {
       HIP_OK(p->small.ensure());
-      double* h = (double*)p->small.host;
-      double* d = (double*)p->small.dev;
-      size_t o = 0;
+      char* const h = p->small.host;
+      char* const d = p->small.dev;
+      size_t o = 0;                                    // (bytes; every block a multiple of 8)
       auto put = [&](const double* src, size_t n) -> const double* {
         if (!n) return nullptr;
         memcpy(h + o, src, n * sizeof(double));
-        const double* r = d + o;
-        o += n;
+        const double* r = (const double*)(d + o);
+        o += n * sizeof(double);
         return r;
       };
       a.q = put(q, d_q);
@@ -1129,21 +1153,35 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
       a.posture_target = put(posture_target, n_pt);
       a.com_target = put(com_target, n_ct);
       const size_t o_v = o;
-      a.v_out = v_out ? d + o_v : nullptr;
-      o += d_v;
-      int32_t* const hi32 = (int32_t*)(h + o);
-      int32_t* const di32 = (int32_t*)(d + o);
+      a.v_out = v_out ? (double*)(d + o_v) : nullptr;
+      o += d_v * sizeof(double);
+      const size_t o_i = o;
+      int32_t* const di32 = (int32_t*)(d + o_i);
       a.status_out = di32;
       a.q_out = q_out ? (double*)a.q : nullptr;        // in place, as in the staged path
       if (until) { a.iters_out = di32 + Bz; a.converged_out = di32 + 2 * Bz; }
-      const int32_t rc = launch(p, a, nullptr, stream, flags);
+      o += (Bz * (until ? 3 : 1) * sizeof(int32_t) + 7) & ~(size_t)7;
+      struct Back { void* host; size_t off, n; };
+      std::vector<Back> back;
+      if (taps)
+        assign_taps(taps, P, Bz, t, [&](void* host, size_t n, bool zero) -> void* {
+          if (!host) return nullptr;
+          if (zero) memset(h + o, 0, n);
+          back.push_back({host, o, n});
+          void* r = d + o;
+          o += (n + 7) & ~(size_t)7;
+          return r;
+        });
+      const int32_t rc = launch(p, a, taps ? &t : nullptr, stream, flags);
       if (rc != MKH_OK) return rc;
       HIP_OK(hipStreamSynchronize(stream));
+      const int32_t* const hi32 = (const int32_t*)(h + o_i);
       if (v_out) memcpy(v_out, h + o_v, d_v * sizeof(double));
       if (q_out) memcpy(q_out, h, d_q * sizeof(double));
-      if (status_out) memcpy(status_out, hi32, Bz * sizeof(int32_t));
+      if (status_out && v_out) memcpy(status_out, hi32, Bz * sizeof(int32_t));
       if (until && iters_out) memcpy(iters_out, hi32 + Bz, Bz * sizeof(int32_t));
       if (until && converged_out) memcpy(converged_out, hi32 + 2 * Bz, Bz * sizeof(int32_t));
+      for (const Back& b : back) memcpy(b.host, h + b.off, b.n);
       return MKH_OK;
     }
   }
@@ -1263,23 +1301,7 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
     if (zero && hipMemsetAsync(dptr, 0, bytes, stream) != hipSuccess) { rc = fail(MKH_E_HIP, "tap buffer clear failed"); return nullptr; }
     return dptr;
   };
-  if (taps) {
-    const size_t Bz = B;
-    t.t_xpos = (double*)tap(taps->xpos, Bz * P.nbody * 3 * 8, false);
-    t.t_xquat = (double*)tap(taps->xquat, Bz * P.nbody * 4 * 8, false);
-    t.t_frame_pose = (double*)tap(taps->frame_pose, Bz * P.n_frame * 7 * 8, false);
-    t.t_subtree_com = (double*)tap(taps->subtree_com, Bz * 3 * 8, true);
-    t.t_task_e = (double*)tap(taps->task_e, Bz * P.n_rows_tap * 8, true);
-    t.t_task_J = (double*)tap(taps->task_J, Bz * P.n_rows_tap * nv * 8, true);
-    t.t_H = (double*)tap(taps->H, Bz * nv * nv * 8, false);
-    t.t_c = (double*)tap(taps->c, Bz * nv * 8, false);
-    t.t_box_lo = (double*)tap(taps->box_lo, Bz * nv * 8, false);
-    t.t_box_hi = (double*)tap(taps->box_hi, Bz * nv * 8, false);
-    t.t_coll_G = (double*)tap(taps->coll_G, Bz * P.n_pairs * nv * 8, true);
-    t.t_coll_h = (double*)tap(taps->coll_h, Bz * P.n_pairs * 8, false);
-    t.t_qp_iters = (int32_t*)tap(taps->qp_iters, Bz * 4, true);
-    t.t_cycles = (long long*)tap(taps->cycles, Bz * 16 * 8, true);
-  }
+  if (taps) assign_taps(taps, P, (size_t)B, t, tap);
   if (rc == MKH_OK) rc = launch(p, a, taps ? &t : nullptr, stream, flags);
   if (rc == MKH_OK) {
     hipError_t e = hipSuccess;
