@@ -316,8 +316,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LOOP ? 1 : 2
   // ------------------------------------------------------------------- QP
   // (fused loop, from the third step on: the partition starts where the previous step's QP ended — along an IK loop the
   //  active set changes little from step to step; see the warm start of phase 1a in ik_kernel.h)
+  // Cold start: the partition of the diagonal estimate x_d ≈ −c_d / H_dd — a dof it puts outside its box starts AT that
+  // bound (any partition is a valid start).  On saturated problems (the benchmark's velocity limits: 5.8 of 6 dofs on a
+  // bound) block principal pivoting then needs 1.2 factorisations on average instead of 3.4 from the all-free start
+  // (counted on the tapped H, c, box of the benchmark batch; quad_kernel.h uses the same start).
 #pragma unroll
-  for (int d = 0; d < NV; ++d) { x[d] = 0.0; if (!(LOOP && step >= 2)) st[d] = 0; }
+  for (int d = 0; d < NV; ++d) {
+    x[d] = 0.0;
+    if (!(LOOP && step >= 2)) {
+      const double xd = -c[d] * fast_rcp(H[d][d]);
+      st[d] = (d < nv) ? (xd > hi[d] ? 2 : (xd < lo[d] ? 1 : 0)) : 0;
+    }
+  }
   double hmax = 0.0;
 #pragma unroll
   for (int d = 0; d < NV; ++d) hmax = fmax(hmax, H[d][d]);

@@ -952,7 +952,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   //     wavefronts to interleave.  Also the fused caller loop (steps / until) from kLaneMinBatchLoop instances.
   // Measured on MI355X, UR5e config 2, M solves/s (tools/bench_small_arm.py; wavefront / row / lane kernel):
   //   B = 256: 12 / 25 / 7.6    4 096: 119 / 219 / 90    8 192: 130 / 449 / 152    32 768: 150 / 839 / 528
-  //   65 536: 155 / 900 / 855    131 072: 158 / 1 169 / 1 506    1 048 576: 160 / 1 331 / 2 897
+  //   65 536: 155 / 900 / 855    131 072: 158 / 1 169 / 1 609    1 048 576: 160 / 1 331 / 3 510
   // — the row kernel up to kLaneMinBatch, the lane kernel beyond.
   // MKH_FLAG_WAVE_KERNEL / _QUAD_KERNEL / _LANE_KERNEL force one of the three (parity switches).
   const bool small_arm = p->lane_nv && !taps && a.do_qp && !(flags & MKH_FLAG_WAVE_KERNEL);
