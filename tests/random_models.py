@@ -5,8 +5,9 @@ import numpy as np
 from oracle import lie as olie
 
 
-def random_mjcf(rng, nbody, free_root):
-    """A random tree of `nbody` moving bodies as MJCF text (+ the list of site names)."""
+def random_mjcf(rng, nbody, free_root, no_ball=False):
+    """A random tree of `nbody` moving bodies as MJCF text (+ the list of site names).  no_ball: hinge / slide joints
+    only (what the row- and lane-per-problem kernels of small arms take)."""
     parent = [-1] + [int(rng.integers(0, i)) for i in range(1, nbody)]
     if rng.uniform() < 0.5:                       # a long chain somewhere: depth matters for pointer jumping
         for i in range(1, nbody // 2):
@@ -29,6 +30,8 @@ def random_mjcf(rng, nbody, free_root):
             out.append(f'{pad}  <freejoint name="root"/>')
         else:
             kinds = rng.choice(["hinge", "hinge", "hinge", "slide", "ball", "fixed", "two"], p=[.3, .2, .1, .12, .1, .08, .1])
+            if no_ball and kinds == "ball":
+                kinds = "slide"
             if kinds == "ball":
                 out.append(f'{pad}  <joint name="j{i}" type="ball" pos="{fmt(rng.normal(scale=0.02, size=3))}"/>')
             elif kinds == "fixed" and i > 0:

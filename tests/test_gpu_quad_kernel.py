@@ -247,3 +247,61 @@ def test_fused_loop_against_the_other_kernels(nat, until):
     if until:
         print("iterations:", np.bincount(got[3], minlength=13).tolist(), "converged:", int(got[4].sum()), "of", B)
         assert 0 < got[4].sum() < B
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MKH_FUZZ_SEEDS", "10"))))
+def test_random_small_trees_on_all_three_kernels(nat, seed):
+    """Random hinge / slide trees with nv ≤ 8 — branching, fixed bodies, two joints on one body, frames on sites and
+    bodies, zero cost rows, per-dof posture costs, random gains / LM damping / limits — through the public API on the default
+    dispatch (row kernel), then the same compiled problem on the lane and wavefront kernels and the C oracle."""
+    import mink_amd as mink
+    from random_models import random_mjcf, rand_q
+    rng = np.random.default_rng(7000 + seed)
+    for _ in range(50):
+        nbody = int(rng.integers(2, 9))
+        xml, sites = random_mjcf(rng, nbody, free_root=False, no_ball=True)
+        m = mink.loads_mjcf(xml)
+        if 1 <= m.nv <= 8:
+            break
+    else:
+        pytest.skip("no draw with 1 <= nv <= 8")
+    B = 67
+    q = np.stack([rand_q(m, rng) for _ in range(B)])
+    cfg = mink.Configuration(m, q)
+    tgt_cfg = mink.Configuration(m, cfg.integrate(rng.normal(scale=0.2, size=(B, m.nv)), 1.0))
+    frames = [(s, "site") for s in sites] + [(f"b{i}", "body") for i in range(nbody)]
+    picks = [frames[i] for i in rng.choice(len(frames), size=min(int(rng.integers(1, 5)), len(frames)), replace=False)]
+    tasks, specs = [], []
+    for name, typ in picks:
+        pc = rng.uniform(0.5, 20.0) * (rng.uniform(size=3) < 0.8)
+        oc_ = rng.uniform(0.1, 5.0) * (rng.uniform() < 0.6)
+        if not pc.any() and oc_ == 0.0:
+            pc = np.ones(3)
+        gain, lm = float(rng.uniform(0.3, 1.0)), float(rng.uniform(0.0, 1.0))
+        ft = mink.FrameTask(name, typ, position_cost=pc, orientation_cost=oc_, gain=gain, lm_damping=lm)
+        ft.set_target(tgt_cfg.get_transform_frame_to_world(name, typ))
+        tasks.append(ft)
+        specs.append((m.name2id(typ, name), typ, ft.cost.copy(), gain, lm))
+    post = mink.PostureTask(m, cost=rng.uniform(0.0, 1.0, size=m.nv) * (rng.uniform(size=m.nv) < 0.8), gain=float(rng.uniform(0.2, 1.0)),
+                            lm_damping=float(rng.uniform(0.0, 0.5)))
+    post.set_target(rand_q(m, rng))
+    vel = {m.jnt_names[j]: float(rng.uniform(0.2, 3.0)) for j in range(m.njnt) if rng.uniform() < 0.7}
+    lims = [mink.ConfigurationLimit(m, gain=float(rng.uniform(0.5, 1.0)))] + ([mink.VelocityLimit(m, vel)] if vel else [])
+    dt, damping = float(rng.choice([2e-3, 1e-2, 5e-2])), float(rng.choice([1e-6, 1e-3, 1e-1]))
+    v = mink.solve_ik(cfg, tasks + [post], dt, "mi355x", damping, limits=lims)
+    prob = list(cfg._problems.values())[-1]
+    assert prob.last_kernel() == QUAD, prob.last_kernel()
+    ftg = np.stack([ft.transform_target_to_world.wxyz_xyz for ft in tasks], axis=1)
+    ptq = post.target_q[None, :]
+    vl, stl = prob.solve(q, ftg, ptq, None, dt, damping, lane_kernel=True)
+    vw, stw = prob.solve(q, ftg, ptq, None, dt, damping, wave_kernel=True)
+    assert prob.last_kernel().startswith("ik_solve_kernel") and (stl & ~1 == 0).all() and (stw & ~1 == 0).all()
+    ts = [oik.FrameTaskSpec(fid, typ, cost, ft.transform_target_to_world.wxyz_xyz[0], gain, lm) for (fid, typ, cost, gain, lm), ft in zip(specs, tasks)]
+    ts.append(oik.PostureTaskSpec(post.cost, post.target_q, post.gain, post.lm_damping))
+    ls = [oik.ConfigurationLimitSpec(lims[0].gain)] + ([oik.VelocityLimitSpec(lims[1].indices, lims[1].limit)] if vel else [])
+    v_c, st_c = cport.CProblem(m, ts, ls).solve_batch(q, ftg, ptq, dt, damping)
+    assert (st_c == 0).all()
+    sat = 0 if not vel else int((np.abs(np.abs(v[:, lims[1].indices]) - lims[1].limit) < 1e-9).sum())
+    print("seed %d: nv %d, %d bodies, %d frame tasks, saturated velocity bounds %d: row vs wavefront %.1e, vs lane %.1e, vs C oracle %.1e" % (
+        seed, m.nv, nbody, len(tasks), sat, _rel(v, vw).max(), _rel(v, vl).max(), _rel(v, v_c).max()))
+    assert _rel(v, vw).max() < 1e-8 and _rel(v, vl).max() < 1e-8 and _rel(v, v_c).max() < 1e-7
