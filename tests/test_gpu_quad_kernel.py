@@ -305,3 +305,15 @@ def test_random_small_trees_on_all_three_kernels(nat, seed):
     print("seed %d: nv %d, %d bodies, %d frame tasks, saturated velocity bounds %d: row vs wavefront %.1e, vs lane %.1e, vs C oracle %.1e" % (
         seed, m.nv, nbody, len(tasks), sat, _rel(v, vw).max(), _rel(v, vl).max(), _rel(v, v_c).max()))
     assert _rel(v, vw).max() < 1e-8 and _rel(v, vl).max() < 1e-8 and _rel(v, v_c).max() < 1e-7
+    # the fused loops of the three kernels on the same tree (4 steps, and until with loose thresholds)
+    for kw in ({"n_steps": 4}, {"n_steps": 6, "until": (2e-2, 5e-2)}):
+        r = prob.solve(q, ftg, ptq, None, dt, damping, **kw)
+        assert prob.last_kernel() == QUAD + "_loop", prob.last_kernel()
+        for other in (prob.solve(q, ftg, ptq, None, dt, damping, wave_kernel=True, **kw),
+                      prob.solve(q, ftg, ptq, None, dt, damping, lane_kernel=True, **kw)):
+            np.testing.assert_array_equal(r[2], other[2])
+            ok = (r[2] & 14) == 0
+            np.testing.assert_allclose(r[0][ok], other[0][ok], rtol=0, atol=1e-9)
+            if "until" in kw:
+                # (an instance whose error sits within rounding of a threshold may break one iteration apart)
+                assert (r[3] != other[3]).sum() <= 1 and (r[4] != other[4]).sum() <= 1
