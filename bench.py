@@ -148,7 +148,7 @@ def kernel_resources(kernel: str):
         return None
     key = kernel
     if kernel.startswith("ik_quad_kernel"):
-        key = f"ik_quad_kernel<{1 if kernel.endswith('_loop') else 0}>"
+        key = f"ik_quad_kernel<{16 if '_16' in kernel else 8},{1 if kernel.endswith('_loop') else 0}>"
     if kernel.startswith("ik_lane_kernel_"):
         nv = kernel.split("_")[3]
         key = f"ik_lane_kernel<{nv},{1 if kernel.endswith('_loop') else 0}>"

@@ -25,7 +25,8 @@
 namespace mkh {
 
 constexpr int kLaneMaxLinks = 16;
-constexpr int kLaneMaxDofs = 8;
+constexpr int kLaneMaxDofs = 8;         // the lane kernel's own limit (its register arrays)
+constexpr int kLaneDescDofs = 16;       // capacity of the shared descriptor (the row kernel takes up to 16 dofs)
 constexpr int kLaneMaxFrames = 4;
 
 struct LaneLink {
@@ -47,17 +48,17 @@ struct LaneFrame {
 struct LaneProblem {
   int32_t nq, nv, nlink, n_frame, n_posture, n_cfg, n_vel, pad;
   LaneLink link[kLaneMaxLinks];
-  int32_t dof_link[kLaneMaxDofs];   // link whose joint moves dof d (−1: not on any task chain)
-  int32_t dof_qadr[kLaneMaxDofs];
-  double range_lo[kLaneMaxDofs], range_hi[kLaneMaxDofs];    // joint range for check_limits (±inf)
+  int32_t dof_link[kLaneDescDofs];   // link whose joint moves dof d (−1: not on any task chain)
+  int32_t dof_qadr[kLaneDescDofs];
+  double range_lo[kLaneDescDofs], range_hi[kLaneDescDofs];    // joint range for check_limits (±inf)
   LaneFrame frame[kLaneMaxFrames];
-  double posture_cost[kMaxPostureTasks][kLaneMaxDofs], posture_gain[kMaxPostureTasks], posture_lm[kMaxPostureTasks];
-  double cfg_gain[kMaxBoxTerms], cfg_lower[kMaxBoxTerms][kLaneMaxDofs], cfg_upper[kMaxBoxTerms][kLaneMaxDofs];
-  double vel_limit[kMaxBoxTerms][kLaneMaxDofs];
+  double posture_cost[kMaxPostureTasks][kLaneDescDofs], posture_gain[kMaxPostureTasks], posture_lm[kMaxPostureTasks];
+  double cfg_gain[kMaxBoxTerms], cfg_lower[kMaxBoxTerms][kLaneDescDofs], cfg_upper[kMaxBoxTerms][kLaneDescDofs];
+  double vel_limit[kMaxBoxTerms][kLaneDescDofs];
   // per dof, for the row kernel (quad_kernel.h: one load level less than dof_link → link): the joint's axis and anchor in its
   // body frame, and whether it is a slide joint
-  double dof_axis[kLaneMaxDofs][3], dof_jpos[kLaneMaxDofs][3];
-  int32_t dof_slide[kLaneMaxDofs];
+  double dof_axis[kLaneDescDofs][3], dof_jpos[kLaneDescDofs][3];
+  int32_t dof_slide[kLaneDescDofs];
 };
 
 // The sizes of a LaneProblem, by value in the row kernel's arguments (SGPRs at wave start instead of a dependent load).

@@ -22,9 +22,11 @@ int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stre
   return -1;
 }
 
-int launch_quad(bool loop, int grid, hipStream_t stream, const LaneProblem* P, const LaneDims& dims, const SolveArgs& a) {
-  if (loop) hipLaunchKernelGGL(ik_quad_kernel<true>, dim3(grid), dim3(kWave), quad_lds_bytes(), stream, P, dims, a);
-  else hipLaunchKernelGGL(ik_quad_kernel<false>, dim3(grid), dim3(kWave), quad_lds_bytes(), stream, P, dims, a);
+int launch_quad(int nt, bool loop, int grid, hipStream_t stream, const LaneProblem* P, const LaneDims& dims, const SolveArgs& a) {
+#define MKH_QUAD_LAUNCH(NT, LOOP) hipLaunchKernelGGL((ik_quad_kernel<NT, LOOP>), dim3(grid), dim3(kWave), quad_lds_bytes(), stream, P, dims, a)
+  if (nt == 8) { if (loop) MKH_QUAD_LAUNCH(8, true); else MKH_QUAD_LAUNCH(8, false); }
+  else { if (loop) MKH_QUAD_LAUNCH(16, true); else MKH_QUAD_LAUNCH(16, false); }
+#undef MKH_QUAD_LAUNCH
   return quad_lds_bytes();
 }
 

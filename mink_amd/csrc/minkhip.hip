@@ -111,7 +111,8 @@ struct MkhProblem {
   bool wood_big = false;           // more than kMu task rows, or S columns in a second register set: the F_COM builds carry those
   double wood_min_diag = 0.0, wood_max_cost2 = 0.0;
   // lane-per-problem kernel for small arms (lane_kernel.h): template size (0 = the problem does not qualify)
-  int lane_nv = 0, lane_lds = 0;
+  int lane_nv = 0, lane_lds = 0;   // lane kernel's template size (0: not eligible)
+  int quad_nt = 0;                 // row kernel's column registers, 8 or 16 (0: not eligible)
   LaneProblem* d_lane = nullptr;
   LaneDims lane_dims{};
   char last_kernel[64] = "";
@@ -146,20 +147,21 @@ namespace mkh {
 int launch_variant(int nt, int nr, int feat, bool w3, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
                    const SolveArgs& a, const TapArgs* taps);
 int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);
-int launch_quad(bool loop, int grid, hipStream_t stream, const LaneProblem* P, const LaneDims& dims, const SolveArgs& a);   // returns its LDS bytes per wavefront
+int launch_quad(int nt, bool loop, int grid, hipStream_t stream, const LaneProblem* P, const LaneDims& dims, const SolveArgs& a);   // returns its LDS bytes per wavefront
 constexpr int kLaneMinBatchLoop = 28672;  // fused loops of a small arm: row kernel below, lane kernel from here (M targets/s at 16 384: 39.7 vs 24.1, at 32 768: 42.4 vs 48.2)
 constexpr int kLaneMinBatch = 73728;  // plain solves of a small arm: row kernel below, lane kernel from here (launch())
 }
 
-// Lane-per-problem descriptor (lane_kernel.h) of a problem that qualifies: nv ≤ 8, hinge / slide joints only,
-// plain FrameTasks (≤ 4) + PostureTasks + box limits.  Returns the template
-// size, 0 when the problem stays on the wavefront kernel.
+// Descriptor of the row- and lane-per-problem kernels (quad_kernel.h, lane_kernel.h) of a problem that qualifies: nv ≤ 16
+// (row kernel; the lane kernel: nv ≤ 8), at most 16 links on the frames' chains, hinge / slide joints only, plain
+// FrameTasks (≤ 4) + PostureTasks + box limits.  Returns the size class (4 / 6 / 7 / 8: both kernels, 16: the row
+// kernel only), 0 when the problem stays on the wavefront kernel.
 static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const DeviceProblem& P,
                               const std::vector<FrameTaskDev>& ft, const std::vector<double>& pcost,
                               const std::vector<double>& clo, const std::vector<double>& chi,
                               const std::vector<double>& vlim, bool has_relative, LaneProblem& L) {
   const double inf = std::numeric_limits<double>::infinity();
-  if (m->nv > kLaneMaxDofs || m->nq != m->nv) return 0;
+  if (m->nv > kLaneDescDofs || m->nq != m->nv) return 0;
   if (P.n_frame < 1 || P.n_frame > kLaneMaxFrames || has_relative || P.n_com || P.n_pairs || P.n_dense_rows ||
       P.n_dense_limit_rows || P.dense_box)       // (dense_box: per-instance box rows of a plugin limit, wavefront kernels only)
     return 0;
@@ -221,7 +223,7 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
     }
   }
   L.nlink = nl;
-  for (int dd = 0; dd < kLaneMaxDofs; ++dd) { L.dof_link[dd] = -1; L.dof_qadr[dd] = 0; L.range_lo[dd] = -inf; L.range_hi[dd] = inf; }
+  for (int dd = 0; dd < kLaneDescDofs; ++dd) { L.dof_link[dd] = -1; L.dof_qadr[dd] = 0; L.range_lo[dd] = -inf; L.range_hi[dd] = inf; }
   for (int dd = 0; dd < m->nv; ++dd) {
     const int j = m->dof_jntid[dd];
     L.dof_link[dd] = link_of_jnt[j];
@@ -246,7 +248,7 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
     L.posture_gain[t] = P.posture_gain[t]; L.posture_lm[t] = P.posture_lm[t];
   }
   for (int t = 0; t < kMaxBoxTerms; ++t)
-    for (int dd = 0; dd < kLaneMaxDofs; ++dd) { L.cfg_lower[t][dd] = -inf; L.cfg_upper[t][dd] = inf; L.vel_limit[t][dd] = inf; }
+    for (int dd = 0; dd < kLaneDescDofs; ++dd) { L.cfg_lower[t][dd] = -inf; L.cfg_upper[t][dd] = inf; L.vel_limit[t][dd] = inf; }
   for (int t = 0; t < P.n_cfg; ++t) {
     L.cfg_gain[t] = P.cfg_gain[t];
     for (int dd = 0; dd < m->nv; ++dd) { L.cfg_lower[t][dd] = clo[t * 64 + dd]; L.cfg_upper[t][dd] = chi[t * 64 + dd]; }
@@ -254,7 +256,7 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
   for (int t = 0; t < P.n_vel; ++t)
     for (int dd = 0; dd < m->nv; ++dd) L.vel_limit[t][dd] = vlim[t * 64 + dd];
   (void)d;
-  return m->nv <= 4 ? 4 : (m->nv <= 6 ? 6 : (m->nv == 7 ? 7 : 8));
+  return m->nv <= 4 ? 4 : (m->nv <= 6 ? 6 : (m->nv == 7 ? 7 : (m->nv == 8 ? 8 : 16)));   // (16: the row kernel only)
 }
 
 // Resident wavefronts per CU of a kernel variant: bounded by LDS (160 KiB/CU) and by the register map the
@@ -840,8 +842,10 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   }
   {
     LaneProblem lp;
-    p->lane_nv = build_lane_problem(m, d, P, ft, pcost, clo, chi, vlim, p->has_relative, lp);
-    if (p->lane_nv) {
+    const int small_cls = build_lane_problem(m, d, P, ft, pcost, clo, chi, vlim, p->has_relative, lp);
+    p->lane_nv = small_cls <= 8 ? small_cls : 0;
+    p->quad_nt = small_cls ? (small_cls <= 8 ? 8 : 16) : 0;
+    if (small_cls) {
       p->lane_lds = lane_lds_bytes(lp.nlink);
       bool ident = true;
       for (int dd = 0; dd < lp.nv; ++dd) ident = ident && lp.dof_qadr[dd] == dd;
@@ -955,16 +959,20 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   //   65 536: 155 / 900 / 855    131 072: 158 / 1 169 / 1 609    1 048 576: 160 / 1 331 / 3 510
   // — the row kernel up to kLaneMinBatch, the lane kernel beyond.
   // MKH_FLAG_WAVE_KERNEL / _QUAD_KERNEL / _LANE_KERNEL force one of the three (parity switches).
-  const bool small_arm = p->lane_nv && !taps && a.do_qp && !(flags & MKH_FLAG_WAVE_KERNEL);
+  const bool small_ok = !taps && a.do_qp && !(flags & MKH_FLAG_WAVE_KERNEL);
+  const bool small_arm = p->lane_nv && small_ok;                               // (nv ≤ 8: both kernels)
   const bool loop = a.n_steps > 1 || a.q_out || a.pos_threshold >= 0.0;       // fused caller loop (steps / until)
-  if (small_arm && !(flags & (MKH_FLAG_WARM_START | MKH_FLAG_LANE_KERNEL)) &&
-      (a.B < (loop ? mkh::kLaneMinBatchLoop : mkh::kLaneMinBatch) || (flags & MKH_FLAG_QUAD_KERNEL))) {
+  // (9 … 16 dofs — hands, mobile arms: the row kernel with sixteen column registers, whatever the batch; there is no lane
+  //  kernel of that size to hand over to)
+  if (p->quad_nt && small_ok && !(flags & MKH_FLAG_WARM_START) && !((flags & MKH_FLAG_LANE_KERNEL) && p->lane_nv) &&
+      (!p->lane_nv || a.B < (loop ? mkh::kLaneMinBatchLoop : mkh::kLaneMinBatch) || (flags & MKH_FLAG_QUAD_KERNEL))) {
     const int grid = (a.B + 3) / 4;
-    p->last_grid = grid; p->last_nt = 8;
-    snprintf(p->last_kernel, sizeof(p->last_kernel), loop ? "ik_quad_kernel_loop" : "ik_quad_kernel");
+    p->last_grid = grid; p->last_nt = p->quad_nt;
+    snprintf(p->last_kernel, sizeof(p->last_kernel), p->quad_nt == 8 ? (loop ? "ik_quad_kernel_loop" : "ik_quad_kernel")
+                                                                      : (loop ? "ik_quad_kernel_16_loop" : "ik_quad_kernel_16"));
     SolveArgs aq = a;
     HIP_OK(clk_begin(p, aq, stream));
-    p->last_lds = mkh::launch_quad(loop, grid, stream, p->d_lane, p->lane_dims, aq);
+    p->last_lds = mkh::launch_quad(p->quad_nt, loop, grid, stream, p->d_lane, p->lane_dims, aq);
     HIP_OK(hipGetLastError());
     HIP_OK(clk_end(p, a.B, stream));
     return MKH_OK;

@@ -26,6 +26,7 @@
 #pragma once
 #include "lane_kernel.h"
 #include "wave_ops.h"
+#include <utility>
 
 namespace mkh {
 
@@ -35,19 +36,29 @@ constexpr int kQuadPoseDoubles = 7 * kQuadRow;                // link poses [com
 constexpr int kQuadAncDoubles = kQuadRow / 2;                 // ancestor index per link (int32)
 constexpr int kQuadTaskDoubles = 28;                          // per frame task: A1 (9), A2 (9), frame position (3), W·e (6), μ
 constexpr int kQuadRowDoubles = kQuadPoseDoubles + kQuadAncDoubles + kLaneMaxFrames * kQuadTaskDoubles;
-static_assert(kLaneMaxLinks <= kQuadRow && kLaneMaxDofs <= 8, "a problem must fit one DPP row");
+static_assert(kLaneMaxLinks <= kQuadRow && kLaneDescDofs <= kQuadRow, "a problem must fit one DPP row");
 __host__ __device__ inline int quad_lds_bytes() { return kQuadPerWave * kQuadRowDoubles * (int)sizeof(double); }
 
 // ---------------------------------------------------------------- DPP row primitives (all 64 lanes must be active)
 // s_nop 4: a DPP operand must not be read within 5 wait states of an EXEC write (and 2 of a VALU write of that register)
 // by the compiler's code before the statement.
 #define MKH_QFMAC(D, I) "v_fmac_f64_dpp " D ", %[u], %[g] row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
-// T[i] += u(lane i of this row) · g
+// T[i] += u(lane i of this row) · g   (8 or 16 column registers)
 __device__ __forceinline__ void quad_rank1(double (&T)[8], const double u, const double g) {
   asm volatile("s_nop 4\n\t" MKH_QFMAC("%[t0]", 0) MKH_QFMAC("%[t1]", 1) MKH_QFMAC("%[t2]", 2) MKH_QFMAC("%[t3]", 3)
                MKH_QFMAC("%[t4]", 4) MKH_QFMAC("%[t5]", 5) MKH_QFMAC("%[t6]", 6) MKH_QFMAC("%[t7]", 7)
                : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [t4] "+v"(T[4]), [t5] "+v"(T[5]),
                  [t6] "+v"(T[6]), [t7] "+v"(T[7])
+               : [u] "v"(u), [g] "v"(g));
+}
+__device__ __forceinline__ void quad_rank1(double (&T)[16], const double u, const double g) {
+  asm volatile("s_nop 4\n\t" MKH_QFMAC("%[t0]", 0) MKH_QFMAC("%[t1]", 1) MKH_QFMAC("%[t2]", 2) MKH_QFMAC("%[t3]", 3)
+               MKH_QFMAC("%[t4]", 4) MKH_QFMAC("%[t5]", 5) MKH_QFMAC("%[t6]", 6) MKH_QFMAC("%[t7]", 7)
+               MKH_QFMAC("%[t8]", 8) MKH_QFMAC("%[t9]", 9) MKH_QFMAC("%[t10]", 10) MKH_QFMAC("%[t11]", 11)
+               MKH_QFMAC("%[t12]", 12) MKH_QFMAC("%[t13]", 13) MKH_QFMAC("%[t14]", 14) MKH_QFMAC("%[t15]", 15)
+               : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [t4] "+v"(T[4]), [t5] "+v"(T[5]),
+                 [t6] "+v"(T[6]), [t7] "+v"(T[7]), [t8] "+v"(T[8]), [t9] "+v"(T[9]), [t10] "+v"(T[10]), [t11] "+v"(T[11]),
+                 [t12] "+v"(T[12]), [t13] "+v"(T[13]), [t14] "+v"(T[14]), [t15] "+v"(T[15])
                : [u] "v"(u), [g] "v"(g));
 }
 #undef MKH_QFMAC
@@ -62,6 +73,18 @@ __device__ __forceinline__ double quad_dot(const double (&T)[8], const double u,
                  [t6] "v"(T[6]), [t7] "v"(T[7]));
   return a + b;
 }
+__device__ __forceinline__ double quad_dot(const double (&T)[16], const double u, const double acc) {
+  double a = acc, b = 0.0;
+  asm volatile("s_nop 4\n\t" MKH_QDOT("%[a]", 0) MKH_QDOT("%[b]", 1) MKH_QDOT("%[a]", 2) MKH_QDOT("%[b]", 3)
+               MKH_QDOT("%[a]", 4) MKH_QDOT("%[b]", 5) MKH_QDOT("%[a]", 6) MKH_QDOT("%[b]", 7)
+               MKH_QDOT("%[a]", 8) MKH_QDOT("%[b]", 9) MKH_QDOT("%[a]", 10) MKH_QDOT("%[b]", 11)
+               MKH_QDOT("%[a]", 12) MKH_QDOT("%[b]", 13) MKH_QDOT("%[a]", 14) MKH_QDOT("%[b]", 15)
+               : [a] "+v"(a), [b] "+v"(b)
+               : [u] "v"(u), [t0] "v"(T[0]), [t1] "v"(T[1]), [t2] "v"(T[2]), [t3] "v"(T[3]), [t4] "v"(T[4]), [t5] "v"(T[5]),
+                 [t6] "v"(T[6]), [t7] "v"(T[7]), [t8] "v"(T[8]), [t9] "v"(T[9]), [t10] "v"(T[10]), [t11] "v"(T[11]),
+                 [t12] "v"(T[12]), [t13] "v"(T[13]), [t14] "v"(T[14]), [t15] "v"(T[15]));
+  return a + b;
+}
 #undef MKH_QDOT
 // u of lane K of this row
 template <int K> __device__ __forceinline__ double quad_bcast(double u);
@@ -73,7 +96,12 @@ template <int K> __device__ __forceinline__ double quad_bcast(double u);
     return r;                                                                                                       \
   }
 MKH_QBCAST(0) MKH_QBCAST(1) MKH_QBCAST(2) MKH_QBCAST(3) MKH_QBCAST(4) MKH_QBCAST(5) MKH_QBCAST(6) MKH_QBCAST(7)
+MKH_QBCAST(8) MKH_QBCAST(9) MKH_QBCAST(10) MKH_QBCAST(11) MKH_QBCAST(12) MKH_QBCAST(13) MKH_QBCAST(14) MKH_QBCAST(15)
 #undef MKH_QBCAST
+template <int N, typename F, int... I>
+__device__ __forceinline__ void quad_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void quad_for(F&& f) { quad_for_impl<N>(f, std::make_integer_sequence<int, N>{}); }
 // Σ / max over the 16 lanes of each row (every lane gets its row's value)
 __device__ __forceinline__ double quad_sum(double x) {
   x += dpp_f64<0xB1>(x); x += dpp_f64<0x4E>(x); x += dpp_f64<0x141>(x); x += dpp_f64<0x140>(x);
@@ -89,8 +117,8 @@ __device__ __forceinline__ double quad_max(double x) {
 //   a_ij ← a_ij − a_iK·a_Kj / d (i, j ≠ K),   a_Kj ← s·a_Kj / d,   a_KK ← −1/d;   the matrix stays symmetric, so row K is
 // register K of every lane, and the new column K (lane K) is that row again: lane K clears its column and takes part in
 // the same rank-1 update with the multiplier −s/d.  Returns "the pivot element had the wrong sign" (H is not ≻ 0).
-template <int K>
-__device__ __forceinline__ bool quad_pivot(double (&T)[8], double& cc, const int l, const bool act, const double s) {
+template <int K, int NT>
+__device__ __forceinline__ bool quad_pivot(double (&T)[NT], double& cc, const int l, const bool act, const double s) {
   const double rowk = T[K];
   const double d = quad_bcast<K>(rowk), ck = quad_bcast<K>(cc);
   const bool ok = s * d > 0.0, go = act && ok, isk = l == K;
@@ -99,7 +127,7 @@ __device__ __forceinline__ bool quad_pivot(double (&T)[8], double& cc, const int
   const double gg = isk ? -s * inv : g;
   if (go && isk) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) T[i] = 0.0;
+    for (int i = 0; i < NT; ++i) T[i] = 0.0;
     cc = 0.0;
   }
   quad_rank1(T, rowk, -gg);
@@ -111,7 +139,8 @@ __device__ __forceinline__ bool quad_pivot(double (&T)[8], double& cc, const int
 // LOOP: the fused caller loop (mkh_solve_steps / mkh_solve_until; lane_kernel.h, same semantics): every ROW iterates
 // (solve, q ← q + Δq) on its own problem until its frame tasks are within the thresholds or the budget is spent; rows
 // that are finished idle through the remaining iterations of their wavefront (masked commits).
-template <bool LOOP>
+// NT: column registers per lane = the largest nv the instantiation takes (8: arms; 16: hands, mobile arms).
+template <int NT, bool LOOP>
 __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restrict__ Pg, const LaneDims D, const SolveArgs A) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const LaneProblem& P = *Pg;
@@ -312,9 +341,9 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
   MKH_QTICK();
 
   // ------------------------------------------------- objective (lane = dof: column l of H in T[0..8), c_l in cc)
-  double T[8];
+  double T[NT];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) T[i] = 0.0;
+  for (int i = 0; i < NT; ++i) T[i] = 0.0;
   {
     // a joint's axis and anchor are invariant under its own motion: the final body frame gives them
     const int a = dla;
@@ -348,10 +377,10 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
   }
   diag += dv ? mu_total : 1.0;                       // padded dofs: identity, x = 0
 #pragma unroll
-  for (int i = 0; i < 8; ++i) T[i] += (l == i) ? diag : 0.0;
+  for (int i = 0; i < NT; ++i) T[i] += (l == i) ? diag : 0.0;
   double hdiag = 1.0;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) hdiag = (l == i) ? T[i] : hdiag;
+  for (int i = 0; i < NT; ++i) hdiag = (l == i) ? T[i] : hdiag;
 
   if (LOOP && until && step > 0 && !fin) {
     it_done = step;
@@ -379,16 +408,16 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
   }
   {
     const unsigned long long fr = __ballot(st == 0 && !done);
-    const unsigned mine = (unsigned)(fr >> rbase) & 0xffu;
-    const unsigned any = (unsigned)(fr | (fr >> 16) | (fr >> 32) | (fr >> 48)) & 0xffu;
-#define MKH_QP0(K)                                                                                          \
-  if ((any >> K) & 1u) { if (quad_pivot<K>(T, cc, l, ((mine >> K) & 1u) != 0, 1.0)) { status |= 4; done = true; } }
-    MKH_QP0(0) MKH_QP0(1) MKH_QP0(2) MKH_QP0(3) MKH_QP0(4) MKH_QP0(5) MKH_QP0(6) MKH_QP0(7)
-#undef MKH_QP0
+    const unsigned mine = (unsigned)(fr >> rbase) & 0xffffu;
+    const unsigned any = (unsigned)(fr | (fr >> 16) | (fr >> 32) | (fr >> 48)) & 0xffffu;
+    quad_for<NT>([&](auto kc) {
+      constexpr int K = decltype(kc)::value;
+      if ((any >> K) & 1u) { if (quad_pivot<K, NT>(T, cc, l, ((mine >> K) & 1u) != 0, 1.0)) { status |= 4; done = true; } }
+    });
   }
   MKH_QTICK();
-  int best = 9, budget = 3;
-  for (int it = 0; it < 10 * 8 + 10; ++it) {
+  int best = NT + 1, budget = 3;
+  for (int it = 0; it < 10 * NT + 10; ++it) {
     if (!__ballot(!done)) break;                     // every row of the wave has its optimum
     const double xb = st == 1 ? lo : (st == 2 ? hi : 0.0);
     const double val = quad_dot(T, xb, cc);          // −x_l of a free index, the multiplier w_l of a bound one
@@ -417,13 +446,13 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
     }
     const unsigned long long flips = __ballot(flip);
     const unsigned mine = (unsigned)(flips >> rbase) & 0xffffu, freem = row_mask(st == 0);
-    const unsigned any = (unsigned)(flips | (flips >> 16) | (flips >> 32) | (flips >> 48)) & 0xffu;
-#define MKH_QPK(K)                                                                                                   \
-  if ((any >> K) & 1u) {                                                                                             \
-    if (quad_pivot<K>(T, cc, l, ((mine >> K) & 1u) != 0, ((freem >> K) & 1u) ? -1.0 : 1.0)) { status |= 4; done = true; } \
-  }
-    MKH_QPK(0) MKH_QPK(1) MKH_QPK(2) MKH_QPK(3) MKH_QPK(4) MKH_QPK(5) MKH_QPK(6) MKH_QPK(7)
-#undef MKH_QPK
+    const unsigned any = (unsigned)(flips | (flips >> 16) | (flips >> 32) | (flips >> 48)) & 0xffffu;
+    quad_for<NT>([&](auto kc) {
+      constexpr int K = decltype(kc)::value;
+      if ((any >> K) & 1u) {
+        if (quad_pivot<K, NT>(T, cc, l, ((mine >> K) & 1u) != 0, ((freem >> K) & 1u) ? -1.0 : 1.0)) { status |= 4; done = true; }
+      }
+    });
     if (flip) st = (f == 3) ? 0 : f;
   }
   if (!done) status |= 8;

@@ -88,10 +88,10 @@ def test_ur5e_batch_vs_wave_kernel_and_c_oracle(nat, vmax, dt):
 
 @pytest.mark.parametrize("scene,kernel", [("kuka_iiwa_14__scene", "ik_lane_kernel_7"), ("ufactory_xarm7__scene", "ik_lane_kernel_7"),
                                           ("stanford_tidybot__scene_base", "ik_lane_kernel_4"),
-                                          ("stanford_tidybot__scene_mobile_kinova", "ik_solve_kernel_16_0")])
+                                          ("stanford_tidybot__scene_mobile_kinova", "ik_quad_kernel_16")])
 def test_other_small_robots(nat, scene, kernel):
     """7-dof arms (NV = 7), a 3-dof base with slide joints and a body frame (NV = 4); the 10-dof mobile arm does not
-    qualify (nv > 8) and stays on the wavefront kernel."""
+    qualify for the lane kernel (nv > 8): MKH_FLAG_LANE_KERNEL leaves it where the dispatch puts it, on the row kernel."""
     m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", scene + ".json"))
     nm = nat.NativeModel(m)
     B = 512

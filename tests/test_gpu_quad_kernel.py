@@ -108,11 +108,14 @@ def test_ur5e_batch_vs_other_kernels_and_c_oracle(nat, vmax, dt):
     assert np.array_equal(vp, v[perm])
 
 
-@pytest.mark.parametrize("scene,qualifies", [("kuka_iiwa_14__scene", True), ("ufactory_xarm7__scene", True),
-                                             ("stanford_tidybot__scene_base", True),
-                                             ("stanford_tidybot__scene_mobile_kinova", False)])
-def test_other_small_robots(nat, scene, qualifies):
-    """7-dof arms, a 3-dof base with slide joints and a body frame; the 10-dof mobile arm does not qualify (nv > 8)."""
+@pytest.mark.parametrize("scene,kernel", [("kuka_iiwa_14__scene", QUAD), ("ufactory_xarm7__scene", QUAD),
+                                          ("stanford_tidybot__scene_base", QUAD),
+                                          ("stanford_tidybot__scene_mobile_kinova", QUAD + "_16"),
+                                          ("leap_hand__scene_right", QUAD + "_16"), ("leap_hand__scene_left", QUAD + "_16"),
+                                          ("stanford_tidybot__scene", "ik_solve_kernel")])
+def test_other_small_robots(nat, scene, kernel):
+    """7-dof arms, a 3-dof base with slide joints and a body frame; 9 … 16 dofs on sixteen column registers: the 10-dof mobile
+    arm (three joints on its base body) and the 16-dof LEAP hands (a tree of four fingers); 18 dofs stay on the wavefront kernel."""
     m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", scene + ".json"))
     nm = nat.NativeModel(m)
     B = 514
@@ -128,8 +131,11 @@ def test_other_small_robots(nat, scene, qualifies):
     ptg = np.tile(m.qpos0, (B, 1, 1)) + np.random.default_rng(1).normal(scale=0.1, size=(B, 1, m.nq))   # per-instance posture target
     dt, damping = 2e-2, 1e-4
     v, st = prob.solve(q, tg, ptg, None, dt, damping)
-    assert (prob.last_kernel() == QUAD) == qualifies, prob.last_kernel()
+    assert prob.last_kernel() == kernel or (kernel == "ik_solve_kernel" and prob.last_kernel().startswith(kernel)), prob.last_kernel()
     assert (st & ~1 == 0).all()
+    if kernel.startswith(QUAD):
+        vw, stw = prob.solve(q, tg, ptg, None, dt, damping, wave_kernel=True)
+        assert prob.last_kernel().startswith("ik_solve_kernel") and (stw == st).all() and _rel(v, vw).max() < 1e-8
     tasks = [oik.FrameTaskSpec(frame[1], frame[0], np.array(ft["cost"]), tg[0, 0], 0.9, 0.5),
              oik.PostureTaskSpec(np.full(m.nv, 3e-2), ptg[0, 0], 0.5, 0.1)]
     limits = [oik.ConfigurationLimitSpec(), oik.VelocityLimitSpec(np.array(vidx), vlim)]
@@ -251,20 +257,21 @@ def test_fused_loop_against_the_other_kernels(nat, until):
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MKH_FUZZ_SEEDS", "10"))))
 def test_random_small_trees_on_all_three_kernels(nat, seed):
-    """Random hinge / slide trees with nv ≤ 8 — branching, fixed bodies, two joints on one body, frames on sites and
+    """Random hinge / slide trees with nv ≤ 16 — branching, fixed bodies, two joints on one body, frames on sites and
     bodies, zero cost rows, per-dof posture costs, random gains / LM damping / limits — through the public API on the default
     dispatch (row kernel), then the same compiled problem on the lane and wavefront kernels and the C oracle."""
     import mink_amd as mink
     from random_models import random_mjcf, rand_q
     rng = np.random.default_rng(7000 + seed)
     for _ in range(50):
-        nbody = int(rng.integers(2, 9))
+        nbody = int(rng.integers(2, 9 if seed % 2 else 15))
         xml, sites = random_mjcf(rng, nbody, free_root=False, no_ball=True)
         m = mink.loads_mjcf(xml)
-        if 1 <= m.nv <= 8:
+        if 1 <= m.nv <= 16:
             break
     else:
-        pytest.skip("no draw with 1 <= nv <= 8")
+        pytest.skip("no draw with 1 <= nv <= 16")
+    Q = QUAD if m.nv <= 8 else QUAD + "_16"
     B = 67
     q = np.stack([rand_q(m, rng) for _ in range(B)])
     cfg = mink.Configuration(m, q)
@@ -290,10 +297,13 @@ def test_random_small_trees_on_all_three_kernels(nat, seed):
     dt, damping = float(rng.choice([2e-3, 1e-2, 5e-2])), float(rng.choice([1e-6, 1e-3, 1e-1]))
     v = mink.solve_ik(cfg, tasks + [post], dt, "mi355x", damping, limits=lims)
     prob = list(cfg._problems.values())[-1]
-    assert prob.last_kernel() == QUAD, prob.last_kernel()
+    if prob.last_kernel().startswith("ik_solve_kernel"):
+        pytest.skip("more than 16 links on the frames' chains: wavefront kernel")
+    assert prob.last_kernel() == Q, prob.last_kernel()
     ftg = np.stack([ft.transform_target_to_world.wxyz_xyz for ft in tasks], axis=1)
     ptq = post.target_q[None, :]
-    vl, stl = prob.solve(q, ftg, ptq, None, dt, damping, lane_kernel=True)
+    vl, stl = prob.solve(q, ftg, ptq, None, dt, damping, lane_kernel=True)      # (no lane kernel above 8 dofs: the row kernel again)
+    assert prob.last_kernel().startswith("ik_lane_kernel") == (m.nv <= 8)
     vw, stw = prob.solve(q, ftg, ptq, None, dt, damping, wave_kernel=True)
     assert prob.last_kernel().startswith("ik_solve_kernel") and (stl & ~1 == 0).all() and (stw & ~1 == 0).all()
     ts = [oik.FrameTaskSpec(fid, typ, cost, ft.transform_target_to_world.wxyz_xyz[0], gain, lm) for (fid, typ, cost, gain, lm), ft in zip(specs, tasks)]
@@ -308,7 +318,7 @@ def test_random_small_trees_on_all_three_kernels(nat, seed):
     # the fused loops of the three kernels on the same tree (4 steps, and until with loose thresholds)
     for kw in ({"n_steps": 4}, {"n_steps": 6, "until": (2e-2, 5e-2)}):
         r = prob.solve(q, ftg, ptq, None, dt, damping, **kw)
-        assert prob.last_kernel() == QUAD + "_loop", prob.last_kernel()
+        assert prob.last_kernel() == Q + "_loop", prob.last_kernel()
         for other in (prob.solve(q, ftg, ptq, None, dt, damping, wave_kernel=True, **kw),
                       prob.solve(q, ftg, ptq, None, dt, damping, lane_kernel=True, **kw)):
             np.testing.assert_array_equal(r[2], other[2])
