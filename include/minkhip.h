@@ -61,7 +61,7 @@ extern "C" {
 #define MKH_FLAG_POSTURE_BATCHED 2  /* posture_target is (B, nq) instead of (nq,)       */
 #define MKH_FLAG_COM_BATCHED 4      /* com_target is (B, 3) instead of (3,)             */
 #define MKH_FLAG_DIRECT_QP 8        /* never use the low-rank start of the QP (parity/diagnostic switch) */
-#define MKH_FLAG_WAVE_KERNEL 16     /* never use the row- / lane-per-problem kernels of small arms (parity/diagnostic switch) */
+#define MKH_FLAG_WAVE_KERNEL 16     /* never use the row- / lane-per-problem kernels of small robots (parity/diagnostic switch) */
 #define MKH_FLAG_LANE_KERNEL 32     /* use the lane-per-problem kernel whenever the problem qualifies, whatever the batch
                                      * size (default: plain solves from 73728 instances, fused loops from 28672;
                                      * parity/diagnostic switch) */
@@ -72,7 +72,7 @@ extern "C" {
                                      * changes.  Same optimum as a cold solve (the QP is strictly convex), fewer pivots:
                                      * along an IK loop the active set changes by a few dofs per step.  The wavefront kernels
                                      * only (the lane kernel keeps its partition inside mkh_solve_steps / _until). */
-#define MKH_FLAG_QUAD_KERNEL 256    /* use the row-per-problem kernel of small arms (16 lanes per problem) whenever the problem
+#define MKH_FLAG_QUAD_KERNEL 256    /* use the row-per-problem kernel of small robots (16 lanes per problem, nv <= 16) whenever the problem
                                      * qualifies, whatever the batch size (default: plain solves below 73728 instances, fused
                                      * loops below 28672; parity/diagnostic switch) */
 

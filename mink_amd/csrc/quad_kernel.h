@@ -1,4 +1,5 @@
-// One 16-LANE ROW per problem: differential IK for small arms (nv ≤ 8, hinge / slide joints) at mid-size batches.
+// One 16-LANE ROW per problem: differential IK for small robots (nv ≤ 16, hinge / slide joints): arms at small and mid-size
+// batches, hands and mobile arms (9 … 16 dofs) at every batch size.
 //
 // The wavefront kernel (ik_kernel.h) gives a 6-dof arm 64 lanes of which 6-10 work; the lane kernel (lane_kernel.h)
 // gives it one lane, i.e. one ≈48 µs dependent instruction stream — right for ≥ 8 192 problems, where every SIMD
