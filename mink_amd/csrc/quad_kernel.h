@@ -108,6 +108,10 @@ __device__ __forceinline__ double quad_sum(double x) {
   x += dpp_f64<0xB1>(x); x += dpp_f64<0x4E>(x); x += dpp_f64<0x141>(x); x += dpp_f64<0x140>(x);
   return x;
 }
+__device__ __forceinline__ double quad_min(double x) {
+  x = fmin(x, dpp_f64<0xB1>(x)); x = fmin(x, dpp_f64<0x4E>(x)); x = fmin(x, dpp_f64<0x141>(x)); x = fmin(x, dpp_f64<0x140>(x));
+  return x;
+}
 __device__ __forceinline__ double quad_max(double x) {
   x = fmax(x, dpp_f64<0xB1>(x)); x = fmax(x, dpp_f64<0x4E>(x)); x = fmax(x, dpp_f64<0x141>(x)); x = fmax(x, dpp_f64<0x140>(x));
   return x;
@@ -417,7 +421,15 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
     });
   }
   MKH_QTICK();
-  int best = NT + 1, budget = 3;
+  // Block principal pivoting (mode 0) settles 99.9 % of the rows in a handful of iterations — and leaves a tail: rows on which
+  // the block steps stall and Murty's single flips then wander for 20 … 50 iterations (counted on tapped H, c, box of 4 096
+  // mobile-arm instances: worst 47), at a batch that fits the chip once the launch waits for that row.  So the first stall
+  // hands the row to a MONOTONE method (mode 1): the primal active-set iteration from the clipped point — step towards
+  // the free set's Newton point (the tableau's own evaluation), stop at the first bound in the way and put that dof on it
+  // (one pivot out); at the Newton point release the bound dof with the worst multiplier (one pivot in), or finish.  The
+  // same instances: worst 15 iterations in total.  Murty's rule (mode 2) stays behind it as the finite last resort.
+  int best = NT + 1, budget = 3, mode = 0, primal_left = 3 * NT;
+  double xc = 0.0;                                   // mode 1: this dof's coordinate of the current feasible point
   for (int it = 0; it < 10 * NT + 10; ++it) {
     if (!__ballot(!done)) break;                     // every row of the wave has its optimum
     const double xb = st == 1 ? lo : (st == 2 ? hi : 0.0);
@@ -431,18 +443,46 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
       f = 3;
     }
     const unsigned fm = row_mask(f != 0);
+    // (mode 1, evaluated by every row — the DPP reductions need all lanes — and used by the rows that are in it)
+    const double dstep = st ? 0.0 : xn - xc;
+    const double aj = (f == 2) ? (hi - xc) / dstep : ((f == 1) ? (lo - xc) / dstep : 1.0);     // (|dstep| > 1e-12 where f is 1 or 2)
+    const double amin = quad_min((mode == 1 && !st) ? aj : 1.0);
+    const double viol = (dv && st == 1) ? -val : ((dv && st == 2) ? val : 0.0);
+    const double vmax = quad_max(viol);
+    const unsigned blockm = row_mask(mode == 1 && !st && f != 0 && aj == amin);
+    const unsigned relm = row_mask(st != 0 && viol == vmax && vmax > tolw);
     bool flip = false;
     if (!done) {
-      x = xn;
-      if (!fm) {
-        done = true;
+      if (mode != 1) {
+        x = xn;
+        if (!fm) {
+          done = true;
+        } else {
+          const int cnt = __builtin_popcount(fm), last = 31 - __builtin_clz(fm);
+          bool all = true;
+          if (cnt < best) { best = cnt; budget = 3; }
+          else if (budget > 0) --budget;
+          else all = false;
+          if (!all && mode == 0) {
+            // first stall: the clipped point is feasible; the free dofs it moved onto a bound leave the free set
+            mode = 1;
+            xc = st ? xb : fmin(fmax(xn, lo), hi);
+            flip = f == 1 || f == 2;
+          } else {
+            flip = f && (all || l == last);          // (mode 2 — Murty: only the infeasible index with the largest number)
+          }
+        }
       } else {
-        const int cnt = __builtin_popcount(fm), last = 31 - __builtin_clz(fm);
-        bool all = true;
-        if (cnt < best) { best = cnt; budget = 3; }
-        else if (budget > 0) --budget;
-        else all = false;                            // Murty: only the infeasible index with the largest number
-        flip = f && (all || l == last);
+        if (--primal_left < 0) mode = 2;             // (degenerate zero-length steps could cycle: hand over to Murty)
+        if (amin < 1.0) {
+          xc = st ? xc : fma(amin, dstep, xc);
+          if (l == __builtin_ctz(blockm)) { flip = true; xc = (f == 2) ? hi : lo; }     // the first bound in the way
+        } else {
+          xc = st ? xc : xn;                         // at the Newton point of this free set
+          x = xc;
+          if (!relm) done = true;
+          else if (l == __builtin_ctz(relm)) { flip = true; f = 3; }                   // release the worst multiplier
+        }
       }
     }
     const unsigned long long flips = __ballot(flip);
