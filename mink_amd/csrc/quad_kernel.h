@@ -443,14 +443,19 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
       f = 3;
     }
     const unsigned fm = row_mask(f != 0);
-    // (mode 1, evaluated by every row — the DPP reductions need all lanes — and used by the rows that are in it)
+    // (mode 1: evaluated by every row of a wavefront that has a row in it — the DPP reductions need all lanes — under a
+    //  wave-uniform branch, so the common case pays nothing)
     const double dstep = st ? 0.0 : xn - xc;
-    const double aj = (f == 2) ? (hi - xc) / dstep : ((f == 1) ? (lo - xc) / dstep : 1.0);     // (|dstep| > 1e-12 where f is 1 or 2)
-    const double amin = quad_min((mode == 1 && !st) ? aj : 1.0);
-    const double viol = (dv && st == 1) ? -val : ((dv && st == 2) ? val : 0.0);
-    const double vmax = quad_max(viol);
-    const unsigned blockm = row_mask(mode == 1 && !st && f != 0 && aj == amin);
-    const unsigned relm = row_mask(st != 0 && viol == vmax && vmax > tolw);
+    double amin = 1.0;
+    unsigned blockm = 0, relm = 0;
+    if (__ballot(mode == 1 && !done)) {
+      const double aj = (f == 2) ? (hi - xc) / dstep : ((f == 1) ? (lo - xc) / dstep : 1.0);   // (|dstep| > 1e-12 where f is 1 or 2)
+      amin = quad_min((mode == 1 && !st) ? aj : 1.0);
+      const double viol = (dv && st == 1) ? -val : ((dv && st == 2) ? val : 0.0);
+      const double vmax = quad_max(viol);
+      blockm = row_mask(mode == 1 && !st && f != 0 && aj == amin);
+      relm = row_mask(st != 0 && viol == vmax && vmax > tolw);
+    }
     bool flip = false;
     if (!done) {
       if (mode != 1) {
