@@ -1203,8 +1203,8 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
   if (n_ct > p->s_ct_cap) { (void)hipFree(p->s_ct); p->s_ct = nullptr; HIP_OK(hipMalloc((void**)&p->s_ct, n_ct * sizeof(double))); p->s_ct_cap = n_ct; }
   // Large plain solves in chunks: the host → device copy of chunk c + 1 and the device → host copy of chunk c − 1 run on
   // streams of their own beside the kernel of chunk c (the single-shot sequence copy in, solve, copy out left the GPU idle
-  // for more than half of a 65 536-instance G1 call).  Chunks of at least 8 192 instances: the kernel choice by batch size
-  // (lane / wavefront kernel) stays what it is for the whole batch.
+  // for more than half of a 65 536-instance G1 call).  Chunks of at least 8 192 instances; each is dispatched by its own
+  // size (a small arm's chunk may run the row kernel where the whole batch would have taken the lane kernel: same optimum).
   // Only where the copies are worth overlapping (≥ 32 MB staged: tools/bench_host_path.py — G1 at 65 536 instances
   // 2.02 → 1.72 ms per call, the G1 full example 2.79 → 2.19 ms; a 65 536-instance UR5e call moves 10 MB around a 0.08 ms
   // kernel and LOSES 0.15 ms to the events and the three extra launches).
