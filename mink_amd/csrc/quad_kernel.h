@@ -12,13 +12,14 @@
 //                    chain (⌈log₂ depth⌉ rounds through LDS instead of `depth` dependent compositions);
 //   lanes as TASKS   frame-task error, log / jlog and the two 3×3 blocks every Jacobian column needs (lie_dev.h — the same
 //                    functions the other two kernels run);
-//   lanes as DOFS    Jacobian columns, H = Σ JᵀW²J + (λ + Σμ)I one COLUMN per lane in eight registers, box limits, the QP.
+//   lanes as DOFS    Jacobian columns, H = Σ JᵀW²J + (λ + Σμ)I one COLUMN per lane in NT = 8 or 16 registers, box limits, the QP.
 //
 // The 16-lane row is the unit the DPP operand network broadcasts in: `v_fmac_f64_dpp T[i], u, g row_newbcast:i` adds
-// u(lane i of MY row)·g to T[i] — a rank-1 update of four 8×8 matrices, one per row, in eight instructions without a
+// u(lane i of MY row)·g to T[i] — a rank-1 update of four NT×NT matrices, one per row, in NT instructions without a
 // byte of LDS traffic.  H assembly, the pivots of the QP and its matrix-vector products are all that instruction.
 //
-// QP: the lane kernel's algorithm (block principal pivoting, Murty's rule once the block steps stop making progress) on
+// QP: block principal pivoting from the partition of the diagonal estimate; at its first stall the primal active-set
+// iteration from the clipped point (monotone), Murty's rule behind it as the finite last resort (see the loop) — on
 // a SWEEP tableau instead of a fresh factorisation per iteration: sweeping index k in or out of the free set is one
 // principal pivot of the symmetric matrix [[H, c], [cᵀ, ·]]; with the free set swept, column j holds −x_j (free) or the
 // multiplier w_j (bound) as  ĉ_j + Σ_b T[b][j]·x_b  over the bound indices b.  Unique optimum of a strictly convex QP ⇒
