@@ -27,7 +27,7 @@ namespace mkh {
 constexpr int kLaneMaxLinks = 16;
 constexpr int kLaneMaxDofs = 8;         // the lane kernel's own limit (its register arrays)
 constexpr int kLaneDescDofs = 16;       // capacity of the shared descriptor (the row kernel takes up to 16 dofs)
-constexpr int kLaneMaxFrames = 4;
+constexpr int kLaneMaxFrames = 8;       // frame tasks of a problem (round 3: 4 → 8, a hand's fingertips + its palm)
 
 struct LaneLink {
   int32_t parent;        // link index of the parent body, −1 = world

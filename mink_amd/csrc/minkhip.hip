@@ -154,7 +154,7 @@ constexpr int kLaneMinBatch = 73728;  // plain solves of a small arm: row kernel
 
 // Descriptor of the row- and lane-per-problem kernels (quad_kernel.h, lane_kernel.h) of a problem that qualifies: nv ≤ 16
 // (row kernel; the lane kernel: nv ≤ 8), at most 16 links on the frames' chains, hinge / slide joints only, plain
-// FrameTasks (≤ 4) + PostureTasks + box limits.  Returns the size class (4 / 6 / 7 / 8: both kernels, 16: the row
+// FrameTasks (≤ 8) + PostureTasks + box limits.  Returns the size class (4 / 6 / 7 / 8: both kernels, 16: the row
 // kernel only), 0 when the problem stays on the wavefront kernel.
 static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const DeviceProblem& P,
                               const std::vector<FrameTaskDev>& ft, const std::vector<double>& pcost,
