@@ -308,3 +308,59 @@ def test_partial_override_detection():
     p = Plain("attachment_site", "site", 1.0, 1.0)
     assert not p._is_dense() and p._builtin_class() is mink.FrameTask
     assert not mink.DampingTask(m, 1.0)._is_dense() and mink.DampingTask(m, 1.0)._builtin_class() is mink.PostureTask
+
+
+def test_fingerprints_follow_what_the_device_descriptor_reads():
+    """solve_ik._compile memoises on `_fingerprint()` (control loops): it must change with everything `_native_desc` reads —
+    costs are arrays the reference's setters modify IN PLACE — stay equal otherwise (targets are per-call data, not part of
+    the descriptor), differ between objects, and be None for caller-defined tasks / limits (their rows are per-call)."""
+    m = mink.load_robot("ur5e")
+    t = mink.FrameTask("attachment_site", "site", position_cost=1.0, orientation_cost=1.0, lm_damping=1.0)
+    f0 = t._fingerprint()
+    assert f0 is not None and f0 == t._fingerprint() and hash(f0) is not None
+    t.set_target(mink.SE3.identity())
+    assert t._fingerprint() == f0                                    # a target is not part of the descriptor
+    t.set_position_cost(2.0)                                         # in place
+    f1 = t._fingerprint()
+    assert f1 != f0
+    t.cost[5] = 0.25                                                 # even behind the setters' back
+    assert t._fingerprint() != f1
+    t2 = mink.FrameTask("attachment_site", "site", position_cost=1.0, orientation_cost=1.0, lm_damping=1.0)
+    t3 = mink.FrameTask("attachment_site", "site", position_cost=1.0, orientation_cost=1.0, lm_damping=1.0)
+    assert t2._fingerprint() != t3._fingerprint()                    # (layouts hold the objects: identity is part of it)
+    for attr, val in (("gain", 0.5), ("lm_damping", 0.0), ("frame_name", "wrist_3_link"), ("frame_type", "body")):
+        before = t2._fingerprint()
+        setattr(t2, attr, val)
+        assert t2._fingerprint() != before, attr
+    p = mink.PostureTask(m, cost=1e-2)
+    fp = p._fingerprint()
+    p.set_target(m.key_qpos[0])
+    assert p._fingerprint() == fp
+    p.set_cost(np.linspace(0.1, 0.6, m.nv))
+    assert p._fingerprint() != fp
+    r = mink.RelativeFrameTask("attachment_site", "site", "base", "body", 1.0, 1.0)
+    fr = r._fingerprint()
+    r.root_name = "shoulder_link"
+    assert r._fingerprint() != fr
+    lim = mink.ConfigurationLimit(m)
+    fl = lim._fingerprint()
+    lim.gain = 0.5
+    assert lim._fingerprint() != fl
+    fl = lim._fingerprint()
+    lim.upper[2] -= 0.1
+    assert lim._fingerprint() != fl
+    vl = mink.VelocityLimit(m, {n: 1.0 for n in m.jnt_names})
+    fv = vl._fingerprint()
+    vl.limit = np.full(m.nv, 2.0)                                    # (the array itself is read-only, as in the reference)
+    assert vl._fingerprint() != fv
+
+    class MyTask(mink.FrameTask):
+        def compute_error(self, configuration):
+            return super().compute_error(configuration)
+
+    class MyLimit(mink.Limit):
+        def compute_qp_inequalities(self, configuration, dt):
+            return mink.Constraint()
+
+    assert MyTask("attachment_site", "site", 1.0, 1.0)._fingerprint() is None
+    assert MyLimit()._fingerprint() is None
