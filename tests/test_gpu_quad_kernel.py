@@ -327,3 +327,45 @@ def test_random_small_trees_on_all_three_kernels(nat, seed):
             if "until" in kw:
                 # (an instance whose error sits within rounding of a threshold may break one iteration apart)
                 assert (r[3] != other[3]).sum() <= 1 and (r[4] != other[4]).sum() <= 1
+
+
+@pytest.mark.parametrize("name,scene", [("leap_c", "leap_hand__scene_right"), ("kinova_c", "stanford_tidybot__scene_mobile_kinova")])
+def test_real_mink_fixtures_of_the_sixteen_register_build(nat, name, scene):
+    """The REAL mink (tests/golden/make_golden_small.py) on the LEAP hand — four fingertip tasks on a tree of four fingers —
+    and on the mobile Kinova with the tasks of examples/mobile_kinova.py (DampingTask holding the base, a posture cost on
+    one dof): the public API on its default dispatch (`ik_quad_kernel_16`) against the recorded v; every eighth instance is
+    the small-angle stream (tolerance 1e-5)."""
+    import mink_amd as mink
+    d = np.load(os.path.join(oc.GOLDEN, f"ik_{name}.npz"))
+    m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", scene + ".json"))
+    B = len(d["q"])
+    cfg = mink.Configuration(m, d["q"])
+    if name == "leap_c":
+        tasks = [mink.FrameTask(s, "site", position_cost=1.0, orientation_cost=0.0, lm_damping=1.0) for s in ("tip_1", "tip_2", "tip_3", "th_tip")]
+        for k, t in enumerate(tasks):
+            t.set_target(mink.SE3(d["frame_targets"][:, k]))
+        post = mink.PostureTask(m, cost=1e-2); post.set_target(d["posture_target"])
+        tasks.append(post)
+        vel = {n: np.pi for n in m.jnt_names}
+    else:
+        ee = mink.FrameTask("pinch_site", "site", position_cost=1.0, orientation_cost=1.0, lm_damping=1.0)
+        ee.set_target(mink.SE3(d["frame_targets"][:, 0]))
+        pc = np.zeros(m.nv); pc[2] = 1e-3
+        post = mink.PostureTask(m, cost=pc); post.set_target(d["posture_targets"][0, 0])
+        dc = np.zeros(m.nv); dc[:2] = 100.0; dc[2] = 1e-3
+        tasks = [ee, post, mink.DampingTask(m, dc)]
+        vel = {m.jnt_names[j]: (0.5 if m.jnt_type[j] == 2 else np.pi) for j in range(m.njnt)}
+    lims = [mink.ConfigurationLimit(m), mink.VelocityLimit(m, vel)]
+    v = mink.solve_ik(cfg, tasks, float(d["dt"]), "quadprog", float(d["damping"]), limits=lims)
+    prob = list(cfg._problems.values())[-1]
+    assert prob.last_kernel() == QUAD + "_16", prob.last_kernel()
+    main = np.ones(B, bool); main[7::8] = False
+    err = _rel(v, d["v"])
+    print("%s: row kernel (16 registers) vs real mink: max rel err main %.1e small-angle %.1e; dofs on a velocity bound %d" % (
+        name, err[main].max(), err[~main].max(), int((np.abs(np.abs(v) - np.array([vel[n] for n in m.jnt_names])) < 1e-9).sum())))
+    assert err[main].max() < 1e-8 and err[~main].max() < 1e-5
+    # H and c of the same problems (wavefront kernel's taps) against the reference's build_ik
+    pr = mink.build_ik(cfg, tasks, float(d["dt"]), float(d["damping"]), lims)
+    np.testing.assert_allclose(pr.P[main], d["H"][main], rtol=0, atol=1e-10 * np.abs(d["H"]).max())
+    np.testing.assert_allclose(pr.q[main], d["c"][main], rtol=0, atol=1e-10 * max(1.0, np.abs(d["c"]).max()))
+    np.testing.assert_allclose(pr.P[~main], d["H"][~main], rtol=0, atol=1e-6 * np.abs(d["H"]).max())      # (small-angle stream)
