@@ -948,7 +948,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   }
   // Small arms (nv ≤ 8, hinge / slide joints, box limits) have two kernels of their own (plain solves without taps):
   //   * a 16-lane ROW per problem (quad_kernel.h): four problems per wavefront, so 4 096 problems put one wavefront on
-  //     every SIMD and each problem still spreads its phases over its lanes.  No warm start; its fused loop below
+  //     every SIMD and each problem still spreads its phases over its lanes.  Its fused loop below
   //     kLaneMinBatchLoop instances (threshold-terminated UR5e loop at 4 096: 22.4 M targets/s against 8.4 on the
   //     wavefront kernel and 6.0 on the lane kernel);
   //   * one LANE per problem (lane_kernel.h): 64 problems per wavefront with every lane busy, one ≈48 µs dependent
@@ -964,7 +964,9 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   const bool loop = a.n_steps > 1 || a.q_out || a.pos_threshold >= 0.0;       // fused caller loop (steps / until)
   // (9 … 16 dofs — hands, mobile arms: the row kernel with sixteen column registers, whatever the batch; there is no lane
   //  kernel of that size to hand over to)
-  if (p->quad_nt && small_ok && !(flags & MKH_FLAG_WARM_START) && !((flags & MKH_FLAG_LANE_KERNEL) && p->lane_nv) &&
+  // (MKH_FLAG_WARM_START is a hint: the row kernel starts cold and is still the faster call — 17 µs against the wavefront
+  //  kernel's 36 µs for 4 096 UR5e problems — so it does not change the choice)
+  if (p->quad_nt && small_ok && !((flags & MKH_FLAG_LANE_KERNEL) && p->lane_nv) &&
       (!p->lane_nv || a.B < (loop ? mkh::kLaneMinBatchLoop : mkh::kLaneMinBatch) || (flags & MKH_FLAG_QUAD_KERNEL))) {
     const int grid = (a.B + 3) / 4;
     p->last_grid = grid; p->last_nt = p->quad_nt;
