@@ -71,8 +71,8 @@ extern "C" {
                                      * in the handle; it is used from its third solve on and reset when the batch size
                                      * changes.  Same optimum as a cold solve (the QP is strictly convex), fewer pivots:
                                      * along an IK loop the active set changes by a few dofs per step.  The wavefront kernels
-                                     * only (the row / lane kernels of small robots start cold — they are the faster call
-                                     * either way — and keep their partition inside mkh_solve_steps / _until). */
+                                     * and the row kernel of small robots (the lane kernel starts cold; both keep their
+                                     * partition inside mkh_solve_steps / _until). */
 #define MKH_FLAG_QUAD_KERNEL 256    /* use the row-per-problem kernel of small robots (16 lanes per problem, nv <= 16) whenever the problem
                                      * qualifies, whatever the batch size (default: plain solves below 73728 instances, fused
                                      * loops below 28672; parity/diagnostic switch) */

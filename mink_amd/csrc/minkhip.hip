@@ -964,8 +964,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   const bool loop = a.n_steps > 1 || a.q_out || a.pos_threshold >= 0.0;       // fused caller loop (steps / until)
   // (9 … 16 dofs — hands, mobile arms: the row kernel with sixteen column registers, whatever the batch; there is no lane
   //  kernel of that size to hand over to)
-  // (MKH_FLAG_WARM_START is a hint: the row kernel starts cold and is still the faster call — 17 µs against the wavefront
-  //  kernel's 36 µs for 4 096 UR5e problems — so it does not change the choice)
+  // (MKH_FLAG_WARM_START: the row kernel keeps its partition in the handle's warm-start buffer like the wavefront kernels)
   if (p->quad_nt && small_ok && !((flags & MKH_FLAG_LANE_KERNEL) && p->lane_nv) &&
       (!p->lane_nv || a.B < (loop ? mkh::kLaneMinBatchLoop : mkh::kLaneMinBatch) || (flags & MKH_FLAG_QUAD_KERNEL))) {
     const int grid = (a.B + 3) / 4;

@@ -405,7 +405,13 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
   //  set changes little from step to step, the diagonal estimate is at its worst when only some dofs saturate:
   //  block principal pivoting then takes 3 iterations on average instead of 1.2, and a wavefront waits for the slowest
   //  of its four rows)
-  if (!(LOOP && step >= 2)) {
+  // (the same across CALLS on one handle — MKH_FLAG_WARM_START, SolveArgs::warm: closed-loop callers solve the same
+  //  instances again and again; from the handle's third call on, like the wavefront kernels)
+  const bool warm_in = !LOOP && A.warm != nullptr && A.warm_age >= 2;
+  if (warm_in) {
+    st = dv ? (int)A.warm[(size_t)pb * nv + l] : 1;
+    if ((st == 2 && !(hi < kInf)) || (st == 1 && !(lo > -kInf))) st = 0;       // (a bound that is not there any more)
+  } else if (!(LOOP && step >= 2)) {
     st = 1;
     if (dv) {
       const double xd = -cc * fast_rcp(hdiag);
@@ -503,6 +509,7 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
     if (flip) st = (f == 3) ? 0 : f;
   }
   if (!done) status |= 8;
+  if (!LOOP && A.warm != nullptr && live && dv) A.warm[(size_t)pb * nv + l] = (int8_t)((status & 14) ? 0 : st);
   if (!LOOP) { status_all = status; break; }
   if (!fin) {                                        // commit this iteration
     status_all |= status;

@@ -69,8 +69,8 @@ def test_real_mink_fixture(nat):
     p.solve(qn, tn, d["posture_target"][None, :], None, dt, damping, taps=("H",))
     assert p.last_kernel().endswith("_31"), p.last_kernel()
     vws, _ = p.solve(qn, tn, d["posture_target"][None, :], None, dt, damping, warm_start=True)
-    assert p.last_kernel() == QUAD, p.last_kernel()      # (a hint: the row kernel starts cold and is still the faster call)
-    assert np.array_equal(vws[:B], v)
+    assert p.last_kernel() == QUAD, p.last_kernel()      # (warm starts are its own: test_warm_start_across_calls below)
+    assert np.array_equal(vws[:B], v)                    # (the handle's first warm call starts cold)
 
 
 @pytest.mark.parametrize("vmax,dt", [(np.pi, 2e-3), (0.3, 5e-2)])
@@ -370,3 +370,39 @@ def test_real_mink_fixtures_of_the_sixteen_register_build(nat, name, scene):
     np.testing.assert_allclose(pr.P[main], d["H"][main], rtol=0, atol=1e-10 * np.abs(d["H"]).max())
     np.testing.assert_allclose(pr.q[main], d["c"][main], rtol=0, atol=1e-10 * max(1.0, np.abs(d["c"]).max()))
     np.testing.assert_allclose(pr.P[~main], d["H"][~main], rtol=0, atol=1e-6 * np.abs(d["H"]).max())      # (small-angle stream)
+
+
+@pytest.mark.parametrize("scene", ["universal_robots_ur5e__scene", "leap_hand__scene_right"])
+def test_warm_start_across_calls(nat, scene):
+    """MKH_FLAG_WARM_START on the row kernel: a closed loop of single solves on the same batch — every step's v equals the
+    cold solve's (the optimum is unique), whatever partition the previous call left in the handle; a permuted batch (a wrong
+    prediction for every instance) and a changed batch size (state reset) still give the right answers."""
+    m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", scene + ".json"))
+    nm = nat.NativeModel(m)
+    B = 1500
+    sites = [i for i, n in enumerate(m.site_names) if n and m.site_bodyid[i] > 0]
+    tips = sites[-4:] if m.nv > 8 else sites[-1:]
+    fts = [{"frame_type": "site", "frame_id": i, "cost": [1.0, 1.0, 1.0, 0.2, 0.2, 0.2], "gain": 1.0, "lm_damping": 1.0} for i in tips]
+    vidx = [int(m.jnt_dofadr[j]) for j in range(m.njnt)]
+    kw = dict(frame_tasks=fts, posture_tasks=[{"cost": 1e-2}], configuration_limits=[nc._cfg_limit(m)],
+              velocity_limits=[{"indices": vidx, "limit": np.full(len(vidx), 1.0)}], max_batch=B)
+    prob, cold = nat.NativeProblem(nm, **kw), nat.NativeProblem(nm, **kw)
+    q, tg = workloads.make_batch(m, nm, prob, np.random.default_rng(8), B, base_q=m.qpos0)
+    pt = m.qpos0[None, :]
+    dt, damping = 2e-2, 1e-3
+    qw, worst = q.copy(), 0.0
+    for step in range(10):
+        vw, stw = prob.solve(qw, tg, pt, None, dt, damping, warm_start=True)
+        assert prob.last_kernel().startswith(QUAD)
+        vc, stc = cold.solve(qw, tg, pt, None, dt, damping)
+        assert (stw == stc).all() and (stw & ~1 == 0).all()
+        worst = max(worst, _rel(vw, vc).max())
+        qw = nm.integrate(qw, vw, dt)
+    print("%s: closed loop of 10 warm-started solves vs cold solves: max rel |dv| = %.2e" % (scene, worst))
+    assert worst < 1e-9
+    perm = np.random.default_rng(0).permutation(B)
+    vp, _ = prob.solve(qw[perm], tg[perm], pt, None, dt, damping, warm_start=True)
+    vc, _ = cold.solve(qw[perm], tg[perm], pt, None, dt, damping)
+    assert _rel(vp, vc).max() < 1e-9
+    vh, _ = prob.solve(qw[:100], tg[:100], pt, None, dt, damping, warm_start=True)
+    assert _rel(vh, cold.solve(qw[:100], tg[:100], pt, None, dt, damping)[0]).max() < 1e-9
