@@ -146,7 +146,7 @@ def kernel_resources(kernel: str):
             table = json.load(fh)
     except (OSError, ValueError):
         return None
-    key = kernel
+    key = kernel.split("+")[0]                       # ("…_48_72+redo_64": the tight-rows build does the work)
     if kernel.startswith("ik_quad_kernel"):
         key = f"ik_quad_kernel<{16 if '_16' in kernel else 8},{1 if kernel.endswith('_loop') else 0}>"
     if kernel.startswith("ik_lane_kernel_"):

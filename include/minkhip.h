@@ -73,6 +73,9 @@ extern "C" {
                                      * along an IK loop the active set changes by a few dofs per step.  The wavefront kernels
                                      * and the row kernel of small robots (the lane kernel starts cold; both keep their
                                      * partition inside mkh_solve_steps / _until). */
+#define MKH_FLAG_FULL_ROWS 512      /* collision problems: never launch the tight-rows variant first (fewer half-space rows than
+                                     * geom pairs, the tightest contacts get them, flagged instances re-solved on the full-row
+                                     * variant behind it) — parity/diagnostic switch */
 #define MKH_FLAG_QUAD_KERNEL 256    /* use the row-per-problem kernel of small robots (16 lanes per problem, nv <= 16) whenever the problem
                                      * qualifies, whatever the batch size (default: plain solves below 73728 instances, fused
                                      * loops below 28672; parity/diagnostic switch) */

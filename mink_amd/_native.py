@@ -28,6 +28,7 @@ FLAG_DEVICE_PTRS, FLAG_POSTURE_BATCHED, FLAG_COM_BATCHED, FLAG_DIRECT_QP, FLAG_W
 FLAG_TWO_WAVES = 64
 FLAG_WARM_START = 128
 FLAG_QUAD_KERNEL = 256
+FLAG_FULL_ROWS = 512
 ST_OUTSIDE_LIMITS, ST_INFEASIBLE, ST_NOT_PD, ST_ITER_LIMIT, ST_ROW_OVERFLOW = 1, 2, 4, 8, 16
 FRAME_TYPE_ID = {"body": 0, "geom": 1, "site": 2}
 
@@ -394,7 +395,7 @@ class NativeProblem:
               damping: float = 1e-12, taps: Sequence[str] = (), solve_qp: bool = True,
               out=None, status_out=None, n_steps: Optional[int] = None, q_out=None, direct_qp: bool = False,
               dense: Optional[dict] = None, until: Optional[tuple] = None, wave_kernel: bool = False, lane_kernel: bool = False,
-              two_waves: bool = False, warm_start: bool = False, quad_kernel: bool = False):
+              two_waves: bool = False, warm_start: bool = False, quad_kernel: bool = False, full_rows: bool = False):
         """Returns (v, status[, taps dict]).  numpy in → numpy out (synchronous);
         torch CUDA tensors in → torch tensors out (asynchronous on the current stream).
         `until` = (pos_threshold, ori_threshold) with n_steps = max_iters: the threshold-terminated loop
@@ -403,11 +404,11 @@ class NativeProblem:
         {"task_e": (B, K), "task_J": (B, K, nv), "limit_G": (B, M, nv), "limit_h": (B, M)} (mkh_solve_dense)."""
         with self._lock:
             return self._solve(q, frame_targets, posture_target, com_target, dt, damping, taps, solve_qp, out,
-                               status_out, n_steps, q_out, direct_qp, dense, until, wave_kernel, lane_kernel, two_waves, warm_start, quad_kernel)
+                               status_out, n_steps, q_out, direct_qp, dense, until, wave_kernel, lane_kernel, two_waves, warm_start, quad_kernel, full_rows)
 
     def _solve(self, q, frame_targets, posture_target, com_target, dt, damping, taps, solve_qp, out, status_out,
                n_steps, q_out, direct_qp, dense=None, until=None, wave_kernel=False, lane_kernel=False, two_waves=False,
-               warm_start=False, quad_kernel=False):
+               warm_start=False, quad_kernel=False, full_rows=False):
         m = self.nmodel.model
         use_torch = _is_torch(q)
         B = int(q.shape[0])
@@ -415,7 +416,8 @@ class NativeProblem:
             raise MinkHipError(f"B={B} exceeds max_batch={self.max_batch} of this problem")
         flags = (FLAG_DIRECT_QP if direct_qp else 0) | (FLAG_WAVE_KERNEL if wave_kernel else 0) | \
             (FLAG_LANE_KERNEL if lane_kernel else 0) | (FLAG_TWO_WAVES if two_waves else 0) | \
-            (FLAG_WARM_START if warm_start else 0) | (FLAG_QUAD_KERNEL if quad_kernel else 0)
+            (FLAG_WARM_START if warm_start else 0) | (FLAG_QUAD_KERNEL if quad_kernel else 0) | \
+            (FLAG_FULL_ROWS if full_rows else 0)
 
         def tgt(x, per, name):
             nonlocal flags

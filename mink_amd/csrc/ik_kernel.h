@@ -1558,7 +1558,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
   const int pb_first = xcd * per;
   const int n_own = max(0, min(A.B, pb_first + per) - pb_first);
   int round = 0;
-  auto draw = [&]() -> int {                                                   // −1: nothing left for this wave
+  auto draw_any = [&]() -> int {                                               // −1: nothing left for this wave
     if (round < A.static_rounds) {
       const int local = w_local + (round++) * n_share;
       return local < n_own ? pb_first + local : -1;
@@ -1571,6 +1571,33 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     }
     const int pb = A.static_rounds * (int)gridDim.x + __builtin_amdgcn_readfirstlane((int)tk);
     return (unsigned)pb < (unsigned)A.B ? pb : -1;
+  };
+  // (collision builds, redo launch — SolveArgs::redo_mask: the problems the tight-rows launch before this one flagged.  Static
+  //  distribution only (the host sets static_rounds = INT32_MAX): the wave reads the status of its next 64 candidates at once,
+  //  one per lane, and walks the flagged ones — one load latency for a wave that has nothing to do, which is nearly all of them)
+  unsigned long long redo_flags = 0;
+  int redo_next = 0, redo_cur = 0;
+  auto draw = [&]() -> int {
+    if constexpr (!kColl) {
+      return draw_any();
+    } else {
+      if (!A.redo_mask) return draw_any();
+      for (;;) {
+        if (!redo_flags) {
+          const int local = w_local + (redo_next + lane) * n_share;
+          const bool in = local < n_own;
+          const int st = in ? A.status_out[pb_first + local] : 0;
+          redo_flags = __ballot(in && (st & A.redo_mask) != 0);
+          const bool any_in = __ballot(in) != 0;
+          redo_cur = redo_next;
+          redo_next += kWave;
+          if (!redo_flags) { if (!any_in) return -1; continue; }
+        }
+        const int k = redo_cur + (int)__builtin_ctzll(redo_flags);
+        redo_flags &= redo_flags - 1;
+        return pb_first + w_local + k * n_share;
+      }
+    }
   };
   int pb_next = draw();
   bool have_inputs = false;                            // the rows of `pb` are already on their way into (sq, sTgt)

@@ -98,6 +98,11 @@ struct MkhProblem {
   // feature-rich variants (taps / ComTask / collisions / RelativeFrameTask) need the compiler's full VGPR
   // budget: they never use the high-occupancy register maps of NT ≤ 24 (ik_kernel.h MKH_WAVES)
   int nt_full = 8, lds_bytes_full = 0;
+  // tight rows (capsule-only collision sets on a small tableau): the same problem with fewer half-space rows than pairs — the
+  // tightest contacts get them, dropped ones are checked at the solution — launched first; the full-row variant then re-solves
+  // what it flagged (SolveArgs::redo_mask)
+  DeviceProblem* d_dev_tight = nullptr;
+  int nt_tight = 0, lds_tight = 0;
   // 3-waves-per-SIMD register map + compact LDS layout (ik_kernel.h MKH_W3; variants without collision rows):
   // LDS bytes per wavefront, 0 when no such variant is compiled for this tableau size or it would not reach 12 waves per CU
   int lds_bytes_w3 = 0;
@@ -681,6 +686,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   {
     const int want = P.n_pairs + P.n_dense_limit_rows;          // half-space rows that can be active at once
     P.max_rows = want < (kWave - m->nv) ? want : (kWave - m->nv);
+    if (const char* cap = getenv("MKH_DEBUG_MAX_ROWS")) { const int c = atoi(cap); if (c > 0 && c < P.max_rows) P.max_rows = c; }   // (experiments)
     P.n_hsel = P.n_pairs > P.max_rows ? P.n_pairs : 0;
   }
   const int ntab = m->nv + P.max_rows;
@@ -855,6 +861,32 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
         return bail(fail(MKH_E_HIP, "lane descriptor upload failed"));
     }
   }
+  // Tight rows: a hand with 40 capsule pairs has ≈17 contacts inside the detection distance at a time, but 40 rows put it
+  // on the 64-row tableau (128 pinned VGPRs, 23 KB of LDS: 7 wavefronts per CU).  With 48 − nv rows it runs on the 48-row
+  // build — Shadow config 4: 0.398 → 0.343 ms — and the rare instance with a violated dropped contact is solved again on
+  // the full-row build (launch()).
+  {
+    const DeviceProblem& P0 = p->dev;
+    const int cap = 48 - m->nv;
+    static const bool no_tight = getenv("MKH_DEBUG_NO_TIGHT_ROWS") != nullptr;      // (A/B of this path)
+    if (!no_tight && p->simple_pairs && P0.n_dense_limit_rows == 0 && P0.n_dense_rows == 0 && !P0.dense_box && p->nt == 64 &&
+        cap >= 16 && P0.n_pairs > cap) {
+      DeviceProblem T = P0;
+      T.max_rows = cap;
+      T.n_hsel = T.n_pairs;
+      T.nt = 48;
+      auto lds_t = [&](bool pre) {
+        return lds_layout(T.nq, T.nv, T.nbody, T.njnt, T.n_frame, T.n_posture, T.n_com, T.max_rows, 6, j_stride_direct(T.nv, 48), 0, pre,
+                          false, false, T.n_hsel).total * (int)sizeof(double);
+      };
+      T.prefetch = waves_per_cu(48, lds_t(true)) == waves_per_cu(48, lds_t(false)) ? 1 : 0;
+      p->nt_tight = 48;
+      p->lds_tight = lds_t(T.prefetch != 0);
+      if (hipMalloc((void**)&p->d_dev_tight, sizeof(DeviceProblem)) != hipSuccess ||
+          hipMemcpy(p->d_dev_tight, &T, sizeof(DeviceProblem), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(MKH_E_HIP, "descriptor upload failed"));
+    }
+  }
   if (hipMalloc((void**)&p->d_dev, sizeof(DeviceProblem)) != hipSuccess ||
       hipMemcpy(p->d_dev, &p->dev, sizeof(DeviceProblem), hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc((void**)&p->d_taps, sizeof(TapArgs)) != hipSuccess ||
@@ -870,7 +902,7 @@ void mkh_problem_destroy(MkhProblem* p) {
   (void)hipSetDevice(p->device);
   (void)hipFree(p->d_frame); (void)hipFree(p->d_posture_cost); (void)hipFree(p->d_cfg_lower); (void)hipFree(p->d_cfg_upper);
   (void)hipFree(p->d_vel); (void)hipFree(p->d_pairs); (void)hipFree(p->d_dev); (void)hipFree(p->d_taps); (void)hipFree(p->d_work);
-  (void)hipFree(p->d_lane); (void)hipFree(p->d_warm);
+  (void)hipFree(p->d_lane); (void)hipFree(p->d_warm); (void)hipFree(p->d_dev_tight);
   (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain); (void)hipFree(p->s_iters);
   (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh); (void)hipFree(p->s_dbox); (void)hipFree(p->d_clk);
   (void)hipFree(p->s_q); (void)hipFree(p->s_ft); (void)hipFree(p->s_pt); (void)hipFree(p->s_ct); (void)hipFree(p->s_v); (void)hipFree(p->s_status);
@@ -1044,18 +1076,48 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   if (nr && p->wood_lds_bytes_w3 && !(flags & MKH_FLAG_TWO_WAVES) && (feat == F_WOOD || feat == (F_WOOD | F_STEPS))) {
     w3 = true; lds = p->wood_lds_bytes_w3;
   }
+  // tight rows first (see mkh_problem_create): plain solves on the capsule-only collision build whose caller takes the status
+  const bool tight = p->d_dev_tight && feat == (F_COLL | F_SIMPLE_COLL) && !nr && !w3 && a.do_qp && a.status_out && !taps &&
+                     !(flags & MKH_FLAG_FULL_ROWS);
+  static const bool no_redo = getenv("MKH_DEBUG_NO_REDO") != nullptr;       // (tests: what the tight launch alone leaves flagged)
+  if (tight && no_redo) {
+    const int gt = grid_for_variant(p, a.B, p->nt_tight, p->lds_tight, false);
+    SolveArgs at = a;
+    at.work_counter = p->d_work;
+    at.static_rounds = INT32_MAX;
+    if (mkh::launch_variant(p->nt_tight, 0, feat, false, gt, p->lds_tight, stream, p->d_dev_tight, at, nullptr) != 0)
+      return fail(MKH_E_INVALID, "no kernel variant ik_solve_kernel_%d_%d", p->nt_tight, feat);
+    HIP_OK(hipGetLastError());
+    snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_solve_kernel_%d_%d", p->nt_tight, feat);
+    return MKH_OK;
+  }
+  if (tight) {
+    const int gt = grid_for_variant(p, a.B, p->nt_tight, p->lds_tight, false);
+    SolveArgs at = a;
+    at.work_counter = p->d_work;
+    const int pw = a.B / gt;
+    at.static_rounds = (pw >= 4) ? (pw * 7) / 8 : INT32_MAX;
+    if (mkh::launch_variant(p->nt_tight, 0, feat, false, gt, p->lds_tight, stream, p->d_dev_tight, at, nullptr) != 0)
+      return fail(MKH_E_INVALID, "no kernel variant ik_solve_kernel_%d_%d", p->nt_tight, feat);
+    HIP_OK(hipGetLastError());
+  }
   const int grid = grid_for_variant(p, a.B, nt, lds, w3);
   p->last_grid = grid; p->last_lds = lds; p->last_nt = nt;
   snprintf(p->last_kernel, sizeof(p->last_kernel), nr ? (w3 ? "ik_solve_kernel_%d_%d_r%d_w3" : "ik_solve_kernel_%d_%d_r%d") : (w3 ? "ik_solve_kernel_%d_%d_w3" : "ik_solve_kernel_%d_%d"), nt, feat, nr);
   SolveArgs al = a;
   al.work_counter = p->d_work;
+  if (tight) {
+    al.redo_mask = MKH_ST_ROW_OVERFLOW;              // the full-row build: only what the tight launch flagged
+    snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_solve_kernel_%d_%d+redo_%d", p->nt_tight, feat, nt);
+    p->last_nt = p->nt_tight; p->last_lds = p->lds_tight; p->last_grid = grid_for_variant(p, a.B, p->nt_tight, p->lds_tight, false);
+  }
   // Distribution (ik_kernel.h): 7/8 of each wave's share is static — one contiguous row range per XCD — and the tail
   // of the batch goes through the ticket counter.  Measured on G1 (kernel ms by static sixteenths): 16 → 1.283,
   // 15 → 1.233, 14 → 1.183, 12 → 1.185, 8 → 1.193, 4 → 1.195, 0 → 1.264: the tail needs ≈4 dynamic rounds to even
   // out, and every wave opening with an atomic costs more than the balance returns.  Short problems (the 8-row
   // variants) and thin batches stay static.
   const int per_wave = a.B / grid;
-  const bool dynamic = nt > 8 && per_wave >= 4;
+  const bool dynamic = nt > 8 && per_wave >= 4 && !tight;              // (a redo launch walks its static share, ik_kernel.h)
   al.static_rounds = dynamic ? (per_wave * 7) / 8 : INT32_MAX;
   HIP_OK(clk_begin(p, al, stream));
   if (mkh::launch_variant(nt, nr, feat, w3, grid, lds, stream, p->d_dev, al, dtaps) != 0)

@@ -165,6 +165,9 @@ struct SolveArgs {
   // state is at least two solves old and written at its end; nullptr = cold
   int8_t* warm;                    // (B, nv)
   int32_t warm_age;
+  // != 0: a REDO launch — only the problems whose status_out has one of these bits are solved (again), the others are
+  // skipped where the wave draws its next problem (collision builds: the full-row launch behind a tight-rows one)
+  int32_t redo_mask;
   // cycle stamps of every problem, (B, 16) as the `cycles` tap — read only by kernels compiled with -DMKH_CLOCKS (experiment
   // builds, tools/phase_clocks.py); nullptr otherwise
   long long* clk;

@@ -4,6 +4,7 @@ examples/arm_ur5e.py:30-37 avoids collisions between the `wrist_3_link` capsule 
 box; a synthetic scene covers every pair type the device routine knows."""
 
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -13,6 +14,7 @@ import oracle_configs as oc
 from oracle import ik as oik
 
 pytestmark = pytest.mark.gpu
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SCENE = """<mujoco><compiler angle="radian"/><worldbody>
   <geom name="floor" type="plane" size="1 1 .1" pos="0 0 -0.35" quat="0.99 0.05 -0.08 0"/>
@@ -459,3 +461,89 @@ def test_tie_rule_is_pinned():
         assert np.isfinite(h_ref).all() and np.abs(G_ref[0, 3:]).max() > 1e-3      # the lever arm is visible in the row
         np.testing.assert_allclose(h[0], h_ref, rtol=0, atol=1e-12)
         np.testing.assert_allclose(G[0], G_ref, rtol=0, atol=1e-12)
+
+
+def test_tight_rows_then_redo_equals_full_rows():
+    """Capsule-only collision sets whose pairs outnumber 48 − nv rows (the Shadow hand: 40 — here 50 — pairs, 24 rows) run a TIGHT-rows
+    launch on the 48-row build first — the tightest contacts get the rows, dropped ones are checked at the solution — and the
+    full-row build then re-solves the instances that launch flagged (SolveArgs::redo_mask).  Status and v equal the full-row
+    solve's (MKH_FLAG_FULL_ROWS), in a regime where the tight launch alone leaves instances flagged (counted in a subprocess
+    with MKH_DEBUG_NO_REDO) and in the benchmark's own."""
+    import subprocess
+    import sys
+    from mink_amd import _native as nat, workloads
+    import native_configs as nc
+    code = r"""
+import sys, numpy as np
+sys.path[:0] = [%r, %r]
+import native_configs as nc
+import mink_amd as mink
+from mink_amd import _native as nat, workloads
+import oracle_configs as oc
+m = workloads.load_robot("shadow_left"); nm = nat.NativeModel(m)
+fingers = oc.SHADOW_FINGERS
+groups = [[f"{f}_1", f"{f}_2"] for f in fingers]
+pairs = [(groups[i], groups[j]) for i in range(5) for j in range(i + 1, 5)] + [(sum(groups, []), ["floor"])]
+col = mink.CollisionAvoidanceLimit(m, pairs, collision_detection_distance=0.5, minimum_distance_from_collisions=0.004)
+fts = [nc._ft(m, f, "site", 1.0, 0.0, 1.0) for f in fingers]
+B = 1024
+prob = nat.NativeProblem(nm, frame_tasks=fts, posture_tasks=[{"cost": 1e-2}], configuration_limits=[nc._cfg_limit(m)],
+                         collision_limits=[col._native_desc()[1]], max_batch=B)
+rng = np.random.default_rng(5)
+p0 = nat.NativeProblem(nm, frame_tasks=fts, max_batch=8192)
+qp, _ = workloads.make_batch(m, nm, p0, rng, 8192, base_q=m.qpos0, sigma=0.3)
+_, hp = col.compute_qp_inequalities(mink.Configuration(m, qp), 0.25)
+hmin = np.where(np.isfinite(hp), hp, np.inf).min(axis=1)
+ok = np.flatnonzero(hmin > 0)
+q = qp[ok[np.argsort(hmin[ok])][:B]]                  # the closest starts that are not inside d_min: their rows bind
+far = nm.integrate(q, rng.normal(scale=1.0, size=(B, m.nv)), 1.0)
+dummy = np.zeros((B, 5, 7)); dummy[:, :, 0] = 1.0
+p1 = nat.NativeProblem(nm, frame_tasks=fts, max_batch=B)
+tgf = p1.solve(far, dummy, None, None, 1.0, 1.0, taps=["frame_pose"], solve_qp=False)[2]["frame_pose"]
+np.savez(sys.argv[1], q=q, tg=tgf)
+v, st = prob.solve(q, tgf, m.qpos0[None, :], None, 2.0, 1e-5)
+print("KERNEL", prob.last_kernel(), "FLAGGED", int(((st & 16) != 0).sum()))
+""" % (REPO_ROOT, os.path.join(REPO_ROOT, "tests"))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "batch.npz")
+        env = dict(os.environ, MKH_DEBUG_NO_REDO="1")
+        out = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("KERNEL")][0].split()
+        assert line[1] == "ik_solve_kernel_48_72", line
+        flagged_by_tight = int(line[3])
+        d = np.load(path)
+        q, tgf = d["q"], d["tg"]
+    m = workloads.load_robot("shadow_left")
+    nm = nat.NativeModel(m)
+    fingers = oc.SHADOW_FINGERS
+    groups = [[f"{f}_1", f"{f}_2"] for f in fingers]
+    pairs = [(groups[i], groups[j]) for i in range(5) for j in range(i + 1, 5)] + [(sum(groups, []), ["floor"])]
+    col = mink.CollisionAvoidanceLimit(m, pairs, collision_detection_distance=0.5, minimum_distance_from_collisions=0.004)
+    assert len(col.geom_id_pairs) == 50
+    fts = [nc._ft(m, f, "site", 1.0, 0.0, 1.0) for f in fingers]
+    B = len(q)
+    prob = nat.NativeProblem(nm, frame_tasks=fts, posture_tasks=[{"cost": 1e-2}], configuration_limits=[nc._cfg_limit(m)],
+                             collision_limits=[col._native_desc()[1]], max_batch=B)
+    v, st = prob.solve(q, tgf, m.qpos0[None, :], None, 2.0, 1e-5)
+    assert prob.last_kernel() == "ik_solve_kernel_48_72+redo_64", prob.last_kernel()
+    vf, stf = prob.solve(q, tgf, m.qpos0[None, :], None, 2.0, 1e-5, full_rows=True)
+    assert prob.last_kernel() == "ik_solve_kernel_64_72", prob.last_kernel()
+    print("tight launch alone left %d of %d instances flagged; after the redo launch %d (full rows: %d)" % (
+        flagged_by_tight, B, int(((st & 16) != 0).sum()), int(((stf & 16) != 0).sum())))
+    assert flagged_by_tight >= 10
+    np.testing.assert_array_equal(st, stf)
+    ok = (st & 14) == 0
+    scale = np.maximum(1.0, np.abs(vf[ok]).max(axis=1, keepdims=True))
+    assert (np.abs(v[ok] - vf[ok]) / scale).max() < 1e-9
+    # the benchmark's regime (BASELINE configs[3]): the tightest 24 contacts always suffice there
+    prob2, dt2, damping2 = nc.build("shadow_c4", nm, 512)
+    key = m.key_qpos[m.name2id("key", "grasp hard")]
+    q2, tg2 = workloads.make_batch(m, nm, prob2, np.random.default_rng(5), 512, base_q=key)
+    q2[::2] = 0.5 * (q2[::2] + key)
+    v2, st2 = prob2.solve(q2, tg2, key[None, :], None, dt2, damping2)
+    assert prob2.last_kernel() == "ik_solve_kernel_48_72+redo_64"
+    v2f, st2f = prob2.solve(q2, tg2, key[None, :], None, dt2, damping2, full_rows=True)
+    np.testing.assert_array_equal(st2, st2f)
+    assert (st2 & ~1 == 0).all() and (np.abs(v2 - v2f) / np.maximum(1.0, np.abs(v2f).max(axis=1, keepdims=True))).max() < 1e-9
