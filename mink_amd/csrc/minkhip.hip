@@ -1097,6 +1097,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
     at.work_counter = p->d_work;
     const int pw = a.B / gt;
     at.static_rounds = (pw >= 4) ? (pw * 7) / 8 : INT32_MAX;
+    HIP_OK(clk_begin(p, at, stream));                 // (clock builds: the stamps of the launch that does the work)
     if (mkh::launch_variant(p->nt_tight, 0, feat, false, gt, p->lds_tight, stream, p->d_dev_tight, at, nullptr) != 0)
       return fail(MKH_E_INVALID, "no kernel variant ik_solve_kernel_%d_%d", p->nt_tight, feat);
     HIP_OK(hipGetLastError());
@@ -1119,7 +1120,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hi
   const int per_wave = a.B / grid;
   const bool dynamic = nt > 8 && per_wave >= 4 && !tight;              // (a redo launch walks its static share, ik_kernel.h)
   al.static_rounds = dynamic ? (per_wave * 7) / 8 : INT32_MAX;
-  HIP_OK(clk_begin(p, al, stream));
+  if (!tight) HIP_OK(clk_begin(p, al, stream));
   if (mkh::launch_variant(nt, nr, feat, w3, grid, lds, stream, p->d_dev, al, dtaps) != 0)
     return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
   HIP_OK(hipGetLastError());
