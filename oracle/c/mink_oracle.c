@@ -94,6 +94,8 @@ typedef struct {
       *subtree_com, *cdof;
   double *H, *c, *G, *h, *J, *e, *jacp, *jacr, *tmpv, *tmpq;
   double *qp;     /* QP workspace */
+  double *dq;     /* (nv) */
+  int *idx;       /* (nv) */
   double *pool;
 } Work;
 
@@ -102,7 +104,7 @@ static Work *work_new(const MkoModel *m, int mrows) {
   size_t n = 0;
   n += (size_t)nb * (3 + 4 + 9 + 3 + 3) + (size_t)nj * 6 + (size_t)ng * 12 + (size_t)ns * 12 + (size_t)nv * 6;
   n += (size_t)nv * nv + nv + (size_t)mrows * nv + mrows + (size_t)6 * nv * 2 + (size_t)nv * nv + nv + (size_t)6 * nv + 4 * (size_t)nv + 4 * (size_t)nq;
-  n += (size_t)4 * nv * nv + (size_t)8 * nv + (size_t)4 * mrows + 64;
+  n += (size_t)4 * nv * nv + (size_t)8 * nv + (size_t)4 * mrows + 64 + nv;
   Work *w = (Work *)malloc(sizeof(Work));
   w->pool = (double *)calloc(n, sizeof(double));
   double *p = w->pool;
@@ -114,10 +116,12 @@ static Work *work_new(const MkoModel *m, int mrows) {
   TAKE(jacp, 3 * nv); TAKE(jacr, 3 * nv); TAKE(J, (size_t)nv * nv + 6 * nv); TAKE(e, nv + 6);
   TAKE(tmpv, 4 * nv); TAKE(tmpq, 4 * nq);
   TAKE(qp, (size_t)4 * nv * nv + 8 * nv + 4 * mrows + 64);
+  TAKE(dq, nv);
 #undef TAKE
+  w->idx = (int *)calloc((size_t)nv + 1, sizeof(int));
   return w;
 }
-static void work_free(Work *w) { free(w->pool); free(w); }
+static void work_free(Work *w) { free(w->idx); free(w->pool); free(w); }
 
 static void local2global(const Work *d, double *xpos, double *xmat, const double *pos, const double *quat, int body) {
   double t[3], q[4];
@@ -447,7 +451,7 @@ static void frame_transform_jacobian(const MkoModel *m, Work *d, int type, int i
 /* Task.compute_qp_objective (mink/tasks/task.py:105-138): H += JwᵀJw + μI, c += −weᵀJw */
 static void add_objective(int nv, int k, const double *J, const double *e, const double *cost, double gain, double lm,
                           double *H, double *c) {
-  double we[64 + 6];
+  double we[k > 0 ? k : 1];
   double mu = 0.0;
   for (int r = 0; r < k; ++r) { we[r] = cost[r] * (-gain * e[r]); mu += we[r] * we[r]; }
   mu *= lm;
@@ -614,18 +618,182 @@ int32_t mko_solve_qp(int32_t n, int32_t m, const double *P, const double *q, con
   return rc;
 }
 
+
+/* ------------------------------------------------------------------ CollisionAvoidanceLimit rows
+ * mink/limits/collision_avoidance_limit.py:187-229 on top of mj_geomDistance (third-party, restated from the published
+ * pair routines — engine_collision_primitive.c: mjraw_SphereSphere, mjc_CapsuleCapsule, mjraw_SphereCapsule,
+ * mjc_PlaneSphere, mjc_PlaneCapsule — in the operation order of oracle/mjmath.py:375-462, 768-833; PARITY UNPINNED
+ * against the wheel).  Plane / sphere / capsule pairs only. */
+enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3 };
+typedef struct { double dist, pos[3], n[3]; } Con;
+
+static int sphere_sphere(Con *out, const double *p1, double r1, const double *p2, double r2, double margin) {
+  double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+  const double cdist = sqrt(dif[0] * dif[0] + dif[1] * dif[1] + dif[2] * dif[2]);
+  const double dist = cdist - r1 - r2;
+  if (dist > margin) return 0;
+  double n[3];
+  if (cdist < mjMINVAL) { n[0] = 1; n[1] = 0; n[2] = 0; }
+  else for (int k = 0; k < 3; ++k) n[k] = dif[k] / cdist;
+  out->dist = dist;
+  for (int k = 0; k < 3; ++k) { out->n[k] = n[k]; out->pos[k] = p1[k] + n[k] * (r1 + 0.5 * dist); }
+  return 1;
+}
+
+static double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+static int capsule_capsule(Con *out, const double *pos1, const double *mat1, const double *size1, const double *pos2,
+                           const double *mat2, const double *size2, double margin) {
+  const double axis1[3] = {mat1[2], mat1[5], mat1[8]}, axis2[3] = {mat2[2], mat2[5], mat2[8]};
+  const double dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
+  const double ma = axis1[0] * axis1[0] + axis1[1] * axis1[1] + axis1[2] * axis1[2];
+  const double mb = -(axis1[0] * axis2[0] + axis1[1] * axis2[1] + axis1[2] * axis2[2]);
+  const double mc = axis2[0] * axis2[0] + axis2[1] * axis2[1] + axis2[2] * axis2[2];
+  const double u = -(axis1[0] * dif[0] + axis1[1] * dif[1] + axis1[2] * dif[2]);
+  const double v = axis2[0] * dif[0] + axis2[1] * dif[1] + axis2[2] * dif[2];
+  const double det = ma * mc - mb * mb;
+  int n = 0;
+  if (fabs(det) >= mjMINVAL) {
+    double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+    if (x1 > size1[1]) { x1 = size1[1]; x2 = (v - mb * size1[1]) / mc; }
+    else if (x1 < -size1[1]) { x1 = -size1[1]; x2 = (v + mb * size1[1]) / mc; }
+    if (x2 > size2[1]) { x2 = size2[1]; x1 = (u - mb * size2[1]) / ma; }
+    else if (x2 < -size2[1]) { x2 = -size2[1]; x1 = (u + mb * size2[1]) / ma; }
+    x1 = clampd(x1, -size1[1], size1[1]);
+    x2 = clampd(x2, -size2[1], size2[1]);
+    double a[3], b[3];
+    for (int k = 0; k < 3; ++k) { a[k] = pos1[k] + axis1[k] * x1; b[k] = pos2[k] + axis2[k] * x2; }
+    n += sphere_sphere(out + n, a, size1[0], b, size2[0], margin);
+  } else {
+    /* parallel axes: both ends of each capsule against the other segment, the first two that project inside */
+    double cx1[4], cx2[4];
+    int nc = 0;
+    for (int s = 0; s < 2; ++s) {
+      const double x1 = (s ? -1.0 : 1.0) * size1[1], x2 = (v - mb * x1) / mc;
+      if (-size2[1] <= x2 && x2 <= size2[1]) { cx1[nc] = x1; cx2[nc] = x2; ++nc; }
+    }
+    for (int s = 0; s < 2; ++s) {
+      const double x2 = (s ? -1.0 : 1.0) * size2[1], x1 = (u - mb * x2) / ma;
+      if (-size1[1] <= x1 && x1 <= size1[1]) { cx1[nc] = x1; cx2[nc] = x2; ++nc; }
+    }
+    for (int i = 0; i < nc && i < 2; ++i) {
+      double a[3], b[3];
+      for (int k = 0; k < 3; ++k) { a[k] = pos1[k] + axis1[k] * cx1[i]; b[k] = pos2[k] + axis2[k] * cx2[i]; }
+      n += sphere_sphere(out + n, a, size1[0], b, size2[0], margin);
+    }
+  }
+  return n;
+}
+
+static int sphere_capsule(Con *out, const double *pos1, const double *size1, const double *pos2, const double *mat2,
+                          const double *size2, double margin) {
+  const double axis[3] = {mat2[2], mat2[5], mat2[8]};
+  double x = axis[0] * (pos1[0] - pos2[0]) + axis[1] * (pos1[1] - pos2[1]) + axis[2] * (pos1[2] - pos2[2]);
+  x = clampd(x, -size2[1], size2[1]);
+  const double b[3] = {pos2[0] + axis[0] * x, pos2[1] + axis[1] * x, pos2[2] + axis[2] * x};
+  return sphere_sphere(out, pos1, size1[0], b, size2[0], margin);
+}
+
+static int plane_sphere(Con *out, const double *pos1, const double *mat1, const double *pos2, double r2, double margin) {
+  const double n[3] = {mat1[2], mat1[5], mat1[8]};
+  const double cdist = n[0] * (pos2[0] - pos1[0]) + n[1] * (pos2[1] - pos1[1]) + n[2] * (pos2[2] - pos1[2]);
+  const double dist = cdist - r2;
+  if (dist > margin) return 0;
+  out->dist = dist;
+  for (int k = 0; k < 3; ++k) { out->n[k] = n[k]; out->pos[k] = pos2[k] - n[k] * (r2 + 0.5 * dist); }
+  return 1;
+}
+
+static int plane_capsule(Con *out, const double *pos1, const double *mat1, const double *pos2, const double *mat2,
+                         const double *size2, double margin) {
+  const double axis[3] = {mat2[2], mat2[5], mat2[8]};
+  int n = 0;
+  for (int s = 0; s < 2; ++s) {
+    const double sg = s ? -1.0 : 1.0;
+    const double e[3] = {pos2[0] + axis[0] * sg * size2[1], pos2[1] + axis[1] * sg * size2[1], pos2[2] + axis[2] * sg * size2[1]};
+    n += plane_sphere(out + n, pos1, mat1, e, size2[0], margin);
+  }
+  return n;
+}
+
+/* mj_geomDistance (collision_avoidance_limit.py:219): smallest signed distance, fromto = the connecting segment;
+ * returns distmax (fromto zeroed) when nothing is closer.  *err set for a pair type outside the restated set. */
+static double geom_distance(const MkoModel *m, const Work *d, int g1, int g2, double distmax, double *fromto, int *err) {
+  int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+  const int flip = t1 > t2;
+  if (flip) { int t = g1; g1 = g2; g2 = t; t = t1; t1 = t2; t2 = t; }
+  const double *p1 = d->geom_xpos + 3 * g1, *p2 = d->geom_xpos + 3 * g2;
+  const double *R1 = d->geom_xmat + 9 * g1, *R2 = d->geom_xmat + 9 * g2;
+  const double *s1 = m->geom_size + 3 * g1, *s2 = m->geom_size + 3 * g2;
+  Con cons[2];
+  int n;
+  if (t1 == GEOM_CAPSULE && t2 == GEOM_CAPSULE) n = capsule_capsule(cons, p1, R1, s1, p2, R2, s2, distmax);
+  else if (t1 == GEOM_SPHERE && t2 == GEOM_SPHERE) n = sphere_sphere(cons, p1, s1[0], p2, s2[0], distmax);
+  else if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) n = sphere_capsule(cons, p1, s1, p2, R2, s2, distmax);
+  else if (t1 == GEOM_PLANE && t2 == GEOM_SPHERE) n = plane_sphere(cons, p1, R1, p2, s2[0], distmax);
+  else if (t1 == GEOM_PLANE && t2 == GEOM_CAPSULE) n = plane_capsule(cons, p1, R1, p2, R2, s2, distmax);
+  else { *err = 1; n = 0; }
+  for (int k = 0; k < 6; ++k) fromto[k] = 0.0;
+  if (!n) return distmax;
+  const Con *c = (n == 2 && cons[1].dist < cons[0].dist) ? cons + 1 : cons;      /* first minimum */
+  const double sg = flip ? -1.0 : 1.0;
+  for (int k = 0; k < 3; ++k) {
+    fromto[k] = c->pos[k] - c->n[k] * (0.5 * sg * c->dist);
+    fromto[3 + k] = c->pos[k] + c->n[k] * (0.5 * sg * c->dist);
+  }
+  return c->dist;
+}
+
+/* one limit's rows after kinematics + comPos: G (n_pairs, nv) zero-initialised by the caller, h (n_pairs) */
+static int collision_rows(const MkoModel *m, Work *w, const MkoCollisionLimit *c, double dt, double *G, double *h) {
+  const int nv = m->nv;
+  int err = 0;
+  for (int k = 0; k < c->n_pairs; ++k) {
+    const int g1 = c->pairs[2 * k], g2 = c->pairs[2 * k + 1];
+    double fromto[6];
+    h[k] = INFINITY;
+    const double dist = geom_distance(m, w, g1, g2, c->detection_distance, fromto, &err);
+    if (dist == c->detection_distance) continue;                       /* Contact.inactive (:53-56) */
+    if (dist > c->minimum_distance) h[k] = c->gain * (dist - c->minimum_distance) / dt + c->bound_relaxation;
+    else h[k] = c->bound_relaxation;
+    double normal[3] = {fromto[3] - fromto[0], fromto[4] - fromto[1], fromto[5] - fromto[2]};
+    normalize3(normal);                                                /* Contact.normal (:44-50) */
+    jac(m, w, w->jacp, NULL, fromto + 3, m->geom_bodyid[g2]);          /* compute_contact_normal_jacobian (:59-72) */
+    jac(m, w, w->jacr, NULL, fromto, m->geom_bodyid[g1]);
+    for (int j = 0; j < nv; ++j) {
+      double s = 0;
+      for (int r = 0; r < 3; ++r) s += normal[r] * (w->jacp[r * nv + j] - w->jacr[r * nv + j]);
+      G[(size_t)k * nv + j] = -s;
+    }
+  }
+  return err ? -2 : 0;
+}
+
+int32_t mko_collision_rows(const MkoModel *m, const MkoCollisionLimit *c, const double *q, double dt, double *G_out,
+                           double *h_out) {
+  Work *w = work_new(m, 1);
+  kinematics(m, w, q);
+  comPos(m, w);
+  memset(G_out, 0, sizeof(double) * (size_t)c->n_pairs * m->nv);
+  const int rc = collision_rows(m, w, c, dt, G_out, h_out);
+  work_free(w);
+  return rc;
+}
+
 /* ------------------------------------------------------------------ solve_ik */
 static int count_rows(const MkoModel *m, const MkoProblem *p) {
   int rows = 2 * p->n_vel;
   if (p->has_cfg_limit)
     for (int j = 0; j < m->njnt; ++j)
       if (m->jnt_type[j] != JNT_FREE && m->jnt_limited[j]) rows += 2 * (m->jnt_type[j] == JNT_BALL ? 3 : 1);
+  for (int l = 0; l < p->n_coll; ++l) rows += p->coll[l].n_pairs;
+  rows += p->n_dense_limit_rows;
   return rows;
 }
 
 static int32_t solve_one(const MkoModel *m, const MkoProblem *p, Work *w, int mrows, const double *q,
                          const double *frame_targets, const double *posture_targets, const double *com_targets,
-                         double dt, double damping, double *v_out, double *H_out, double *c_out) {
+                         const MkoDenseRows *dense, double dt, double damping, double *v_out, double *H_out, double *c_out) {
   const int nv = m->nv, nq = m->nq;
   kinematics(m, w, q);
   comPos(m, w);
@@ -681,6 +849,12 @@ static int32_t solve_one(const MkoModel *m, const MkoProblem *p, Work *w, int mr
     jacSubtreeCom(m, w, w->J, w->J + 3 * nv, 1);
     add_objective(nv, 3, w->J, e, ct->cost, ct->gain, ct->lm_damping, w->H, w->c);
   }
+  if (dense)
+    for (int t = 0, r0 = 0; t < p->n_dense; r0 += p->dense[t].k, ++t) {
+      const MkoDenseTask *dt_ = p->dense + t;
+      add_objective(nv, dt_->k, dense->task_J + (size_t)r0 * nv, dense->task_e + r0, dt_->cost, dt_->gain, dt_->lm_damping,
+                    w->H, w->c);
+    }
   if (H_out) memcpy(H_out, w->H, sizeof(double) * nv * nv);
   if (c_out) memcpy(c_out, w->c, sizeof(double) * nv);
   /* _compute_qp_inequalities (solve_ik.py:25-40) */
@@ -691,7 +865,7 @@ static int32_t solve_one(const MkoModel *m, const MkoProblem *p, Work *w, int mr
     double *lower = w->tmpq, *upper = w->tmpq + nq, *dqmax = w->tmpv, *dqmin = w->tmpv + nv;
     for (int i = 0; i < nq; ++i) { lower[i] = -mjMAXVAL; upper[i] = mjMAXVAL; }
     int nidx = 0;
-    int idx[64];
+    int *idx = w->idx;
     for (int j = 0; j < m->njnt; ++j) {
       const int jt = m->jnt_type[j];
       if (jt == JNT_FREE || !m->jnt_limited[j]) continue;
@@ -718,7 +892,27 @@ static int32_t solve_one(const MkoModel *m, const MkoProblem *p, Work *w, int mr
     for (int k = 0; k < p->n_vel; ++k) { w->G[(size_t)(rows + k) * nv + p->vel_idx[k]] = -1.0; w->h[rows + k] = dt * p->vel_limit[k]; }
     rows += p->n_vel;
   }
-  double dq[64];
+  /* CollisionAvoidanceLimit rows; an inactive pair's row (h = +inf, G = 0: collision_avoidance_limit.py:191-197) can never
+   * bind and is left out of the QP — same optimum */
+  for (int l = 0; l < p->n_coll; ++l) {
+    const MkoCollisionLimit *cl = p->coll + l;
+    double *Gc = w->G + (size_t)rows * nv, *hc = w->h + rows;
+    if (collision_rows(m, w, cl, dt, Gc, hc)) { for (int i = 0; i < nv; ++i) v_out[i] = NAN; return -2; }
+    int keep = 0;
+    for (int k = 0; k < cl->n_pairs; ++k) {
+      if (!isfinite(hc[k])) continue;
+      if (keep != k) { memcpy(Gc + (size_t)keep * nv, Gc + (size_t)k * nv, sizeof(double) * nv); hc[keep] = hc[k]; }
+      ++keep;
+    }
+    rows += keep;
+  }
+  if (dense)
+    for (int k = 0; k < p->n_dense_limit_rows; ++k) {
+      if (!isfinite(dense->limit_h[k])) continue;                       /* an inactive row of a caller's limit */
+      memcpy(w->G + (size_t)rows * nv, dense->limit_G + (size_t)k * nv, sizeof(double) * nv);
+      w->h[rows++] = dense->limit_h[k];
+    }
+  double *dq = w->dq;
   const int32_t rc = solve_qp_ws(nv, rows, w->H, w->c, w->G, w->h, dq, w->qp);
   if (rc) { for (int i = 0; i < nv; ++i) v_out[i] = NAN; return rc; }
   for (int i = 0; i < nv; ++i) v_out[i] = dq[i] / dt;     /* solve_ik.py:104 */
@@ -728,10 +922,9 @@ static int32_t solve_one(const MkoModel *m, const MkoProblem *p, Work *w, int mr
 int32_t mko_solve_ik(const MkoModel *m, const MkoProblem *p, const double *q, const double *frame_targets,
                      const double *posture_targets, const double *com_targets, double dt, double damping,
                      double *v_out, double *H_out, double *c_out) {
-  if (m->nv > 64) return -1;
   const int mrows = count_rows(m, p);
   Work *w = work_new(m, mrows > 0 ? mrows : 1);
-  const int32_t rc = solve_one(m, p, w, mrows > 0 ? mrows : 1, q, frame_targets, posture_targets, com_targets, dt,
+  const int32_t rc = solve_one(m, p, w, mrows > 0 ? mrows : 1, q, frame_targets, posture_targets, com_targets, NULL, dt,
                                damping, v_out, H_out, c_out);
   work_free(w);
   return rc;
@@ -739,9 +932,20 @@ int32_t mko_solve_ik(const MkoModel *m, const MkoProblem *p, const double *q, co
 
 int32_t mko_solve_ik_batch(const MkoModel *m, const MkoProblem *p, int32_t B, const double *q,
                            const double *frame_targets, const double *posture_targets, int32_t posture_batched,
-                           const double *com_targets, double dt, double damping, int32_t nthreads, double *v_out,
-                           int32_t *status_out) {
-  if (m->nv > 64) return -1;
+                           const double *com_targets, int32_t com_batched, double dt, double damping, int32_t nthreads,
+                           double *v_out, int32_t *status_out) {
+  return mko_solve_ik_batch_dense(m, p, B, q, frame_targets, posture_targets, posture_batched, com_targets, com_batched,
+                                  NULL, dt, damping, nthreads, v_out, status_out);
+}
+
+int32_t mko_solve_ik_batch_dense(const MkoModel *m, const MkoProblem *p, int32_t B, const double *q,
+                                 const double *frame_targets, const double *posture_targets, int32_t posture_batched,
+                                 const double *com_targets, int32_t com_batched, const MkoDenseRows *rows, double dt,
+                                 double damping, int32_t nthreads, double *v_out, int32_t *status_out) {
+  int K = 0;
+  for (int t = 0; t < p->n_dense; ++t) K += p->dense[t].k;
+  const int M = p->n_dense_limit_rows;
+  if ((K || M) && !rows) return -3;
   const int mrows = count_rows(m, p) > 0 ? count_rows(m, p) : 1;
 #ifdef _OPENMP
   if (nthreads < 1) nthreads = 1;
@@ -754,8 +958,16 @@ int32_t mko_solve_ik_batch(const MkoModel *m, const MkoProblem *p, int32_t B, co
 #endif
     for (int b = 0; b < B; ++b) {
       const double *pt = posture_targets ? posture_targets + (posture_batched ? (size_t)b * p->n_posture * m->nq : 0) : NULL;
+      const double *ct = com_targets ? com_targets + (com_batched ? (size_t)b * p->n_com * 3 : 0) : NULL;
+      MkoDenseRows rb;
+      if (rows) {
+        rb.task_e = K ? rows->task_e + (size_t)b * K : NULL;
+        rb.task_J = K ? rows->task_J + (size_t)b * K * m->nv : NULL;
+        rb.limit_G = M ? rows->limit_G + (size_t)b * M * m->nv : NULL;
+        rb.limit_h = M ? rows->limit_h + (size_t)b * M : NULL;
+      }
       const int32_t rc = solve_one(m, p, w, mrows, q + (size_t)b * m->nq, frame_targets + (size_t)b * p->n_frame * 7, pt,
-                                   com_targets, dt, damping, v_out + (size_t)b * m->nv, NULL, NULL);
+                                   ct, rows ? &rb : NULL, dt, damping, v_out + (size_t)b * m->nv, NULL, NULL);
       if (status_out) status_out[b] = rc;
     }
     work_free(w);

@@ -31,7 +31,8 @@ _MODEL_FIELDS = (
     + [(n, PI32) for n in ("jnt_type", "jnt_qposadr", "jnt_dofadr", "jnt_bodyid", "jnt_limited")]
     + [(n, PF64) for n in ("jnt_pos", "jnt_axis", "jnt_range")]
     + [("dof_parentid", PI32), ("qpos0", PF64), ("site_bodyid", PI32), ("site_pos", PF64), ("site_quat", PF64),
-       ("geom_bodyid", PI32), ("geom_pos", PF64), ("geom_quat", PF64), ("mocap_pos", PF64), ("mocap_quat", PF64)]
+       ("geom_bodyid", PI32), ("geom_pos", PF64), ("geom_quat", PF64), ("mocap_pos", PF64), ("mocap_quat", PF64),
+       ("geom_type", PI32), ("geom_size", PF64)]
 )
 
 
@@ -52,11 +53,26 @@ class MkoComTask(C.Structure):
     _fields_ = [("cost", C.c_double * 3), ("gain", C.c_double), ("lm_damping", C.c_double)]
 
 
+class MkoCollisionLimit(C.Structure):
+    _fields_ = [("n_pairs", C.c_int32), ("pairs", PI32), ("gain", C.c_double), ("minimum_distance", C.c_double),
+                ("detection_distance", C.c_double), ("bound_relaxation", C.c_double)]
+
+
+class MkoDenseTask(C.Structure):
+    _fields_ = [("k", C.c_int32), ("cost", PF64), ("gain", C.c_double), ("lm_damping", C.c_double)]
+
+
+class MkoDenseRows(C.Structure):
+    _fields_ = [("task_e", PF64), ("task_J", PF64), ("limit_G", PF64), ("limit_h", PF64)]
+
+
 class MkoProblem(C.Structure):
     _fields_ = [("n_frame", C.c_int32), ("frame", C.POINTER(MkoFrameTask)), ("n_posture", C.c_int32),
                 ("posture", C.POINTER(MkoPostureTask)), ("n_com", C.c_int32), ("com", C.POINTER(MkoComTask)),
                 ("has_cfg_limit", C.c_int32), ("cfg_gain", C.c_double), ("cfg_min_distance", C.c_double),
-                ("n_vel", C.c_int32), ("vel_idx", PI32), ("vel_limit", PF64)]
+                ("n_vel", C.c_int32), ("vel_idx", PI32), ("vel_limit", PF64),
+                ("n_coll", C.c_int32), ("coll", C.POINTER(MkoCollisionLimit)),
+                ("n_dense", C.c_int32), ("dense", C.POINTER(MkoDenseTask)), ("n_dense_limit_rows", C.c_int32)]
 
 
 def build() -> str:
@@ -72,8 +88,10 @@ def lib():
             build()
         L = C.CDLL(LIB)
         L.mko_solve_ik_batch.restype = C.c_int32
+        L.mko_solve_ik_batch_dense.restype = C.c_int32
         L.mko_solve_ik.restype = C.c_int32
         L.mko_solve_qp.restype = C.c_int32
+        L.mko_collision_rows.restype = C.c_int32
         _lib = L
     return _lib
 
@@ -84,7 +102,10 @@ _FRAME_TYPES = {"body": 0, "geom": 1, "site": 2}
 class CProblem:
     """One solve_ik call site (model + tasks + limits) compiled into the C structs."""
 
-    def __init__(self, model, tasks: Sequence, limits: Optional[Sequence]):
+    def __init__(self, model, tasks: Sequence, limits: Optional[Sequence], dense_tasks: Sequence = (),
+                 dense_limit_rows: int = 0):
+        """dense_tasks: caller-defined tasks as dicts {cost (k,), gain, lm_damping} whose e / J arrive per instance in
+        solve_batch(dense=...); dense_limit_rows: number of rows of the caller-defined limits (their G, h likewise)."""
         self.model = model
         self._keep = []          # numpy buffers the C structs point into
         mm = MkoModel()
@@ -134,8 +155,16 @@ class CProblem:
             limits = [ik.ConfigurationLimitSpec()]                 # solve_ik.py:28-29
         cfg = [l for l in limits if isinstance(l, ik.ConfigurationLimitSpec)]
         vel = [l for l in limits if isinstance(l, ik.VelocityLimitSpec)]
-        if len(cfg) > 1 or len(vel) > 1 or len(cfg) + len(vel) != len(limits):
-            raise TypeError("the C restatement covers one ConfigurationLimit and one VelocityLimit")
+        col = [l for l in limits if isinstance(l, ik.CollisionAvoidanceLimitSpec)]
+        if len(cfg) > 1 or len(vel) > 1 or len(cfg) + len(vel) + len(col) != len(limits):
+            raise TypeError("the C restatement covers one ConfigurationLimit, one VelocityLimit and CollisionAvoidanceLimits")
+        # (collision rows are stacked after the box rows whatever their place in `limits`: the optimum of the strictly
+        # convex QP does not depend on the row order)
+        gt = np.asarray(model.geom_type)
+        for l in col:
+            for g1, g2 in l.geom_id_pairs:
+                if not {int(gt[g1]), int(gt[g2])} <= {0, 2, 3} or (int(gt[g1]) == 0 and int(gt[g2]) == 0):
+                    raise TypeError("the C restatement covers plane / sphere / capsule pairs")
         if cfg and vel and limits.index(cfg[0]) > limits.index(vel[0]):
             raise TypeError("row order: ConfigurationLimit first")
         pr.has_cfg_limit = 1 if cfg else 0
@@ -146,7 +175,39 @@ class CProblem:
             vl = np.ascontiguousarray(np.asarray(vel[0].limit, dtype=np.float64))
             self._keep += [vi, vl]
             pr.n_vel, pr.vel_idx, pr.vel_limit = len(vi), vi.ctypes.data_as(PI32), vl.ctypes.data_as(PF64)
+        cl = (MkoCollisionLimit * max(1, len(col)))()
+        for i, l in enumerate(col):
+            pa_ = np.ascontiguousarray(np.asarray(l.geom_id_pairs, dtype=np.int32).reshape(-1, 2))
+            self._keep.append(pa_)
+            cl[i].n_pairs, cl[i].pairs = len(pa_), pa_.ctypes.data_as(PI32)
+            cl[i].gain, cl[i].minimum_distance = float(l.gain), float(l.minimum_distance_from_collisions)
+            cl[i].detection_distance, cl[i].bound_relaxation = float(l.collision_detection_distance), float(l.bound_relaxation)
+        self._keep.append(cl)
+        pr.n_coll, pr.coll = len(col), cl
+        self.collisions = col
+        da = (MkoDenseTask * max(1, len(dense_tasks)))()
+        for i, t in enumerate(dense_tasks):
+            c = np.ascontiguousarray(np.asarray(t["cost"], dtype=np.float64).ravel())
+            self._keep.append(c)
+            da[i].k, da[i].cost = len(c), c.ctypes.data_as(PF64)
+            da[i].gain, da[i].lm_damping = float(t.get("gain", 1.0)), float(t.get("lm_damping", 0.0))
+        self._keep.append(da)
+        pr.n_dense, pr.dense, pr.n_dense_limit_rows = len(dense_tasks), da, int(dense_limit_rows)
+        self.dense_K = sum(int(da[i].k) for i in range(len(dense_tasks)))
         self.cproblem = pr
+
+    def collision_rows(self, q, dt: float, which: int = 0):
+        """(G, h) of the `which`-th CollisionAvoidanceLimit at q — every pair a row, h = +inf for an inactive pair."""
+        m = self.model
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        n = self.cproblem.coll[which].n_pairs
+        G = np.empty((n, m.nv))
+        h = np.empty(n)
+        rc = lib().mko_collision_rows(C.byref(self.cmodel), C.byref(self.cproblem.coll[which]), q.ctypes.data_as(PF64),
+                                      C.c_double(dt), G.ctypes.data_as(PF64), h.ctypes.data_as(PF64))
+        if rc:
+            raise RuntimeError(f"mko_collision_rows: {rc}")
+        return G, h
 
     def _targets(self):
         ft = np.array([t.target for t in self.frames], dtype=np.float64).reshape(len(self.frames), 7)
@@ -173,8 +234,9 @@ class CProblem:
         return (v, (H, c)) if return_problem else v
 
     def solve_batch(self, q, frame_targets, posture_target, dt: float, damping: float, com_target=None,
-                    nthreads: int = 1):
-        """q (B, nq), frame_targets (B, n_frame, 7), posture_target (n_posture, nq) or (B, n_posture, nq)."""
+                    nthreads: int = 1, dense: Optional[dict] = None):
+        """q (B, nq), frame_targets (B, n_frame, 7), posture_target (n_posture, nq) or (B, n_posture, nq), com_target
+        (n_com, 3) or (B, n_com, 3); dense: {task_e (B, K), task_J (B, K, nv), limit_G (B, M, nv), limit_h (B, M)}."""
         m = self.model
         q = np.ascontiguousarray(q, dtype=np.float64)
         B = q.shape[0]
@@ -183,12 +245,26 @@ class CProblem:
         pt = np.ascontiguousarray(posture_target, dtype=np.float64) if len(self.postures) else np.zeros(1)
         batched = 1 if (len(self.postures) and pt.ndim == 3) else 0
         ct = np.ascontiguousarray(com_target, dtype=np.float64) if len(self.coms) else np.zeros(3)
+        com_batched = 1 if (len(self.coms) and ct.ndim == 3) else 0
+        if com_batched and ct.shape[0] != B:
+            raise ValueError("com_target (B, n_com, 3) does not match the batch")
         v = np.empty((B, m.nv))
         st = np.empty(B, dtype=np.int32)
-        rc = lib().mko_solve_ik_batch(C.byref(self.cmodel), C.byref(self.cproblem), C.c_int32(B), q.ctypes.data_as(PF64),
-                                      ft.ctypes.data_as(PF64), pt.ctypes.data_as(PF64), C.c_int32(batched),
-                                      ct.ctypes.data_as(PF64), C.c_double(dt), C.c_double(damping), C.c_int32(nthreads),
-                                      v.ctypes.data_as(PF64), st.ctypes.data_as(PI32))
+        rows, keep = None, []
+        K, M = self.dense_K, int(self.cproblem.n_dense_limit_rows)
+        if K or M:
+            rows = MkoDenseRows()
+            for name, shape in (("task_e", (B, K)), ("task_J", (B, K, m.nv)), ("limit_G", (B, M, m.nv)), ("limit_h", (B, M))):
+                a = np.ascontiguousarray(dense[name], dtype=np.float64) if shape[1] else np.zeros(1)
+                if shape[1] and a.shape != shape:
+                    raise ValueError(f"dense[{name!r}]: expected {shape}, got {a.shape}")
+                keep.append(a)
+                setattr(rows, name, a.ctypes.data_as(PF64))
+        rc = lib().mko_solve_ik_batch_dense(C.byref(self.cmodel), C.byref(self.cproblem), C.c_int32(B), q.ctypes.data_as(PF64),
+                                            ft.ctypes.data_as(PF64), pt.ctypes.data_as(PF64), C.c_int32(batched),
+                                            ct.ctypes.data_as(PF64), C.c_int32(com_batched),
+                                            C.byref(rows) if rows is not None else None, C.c_double(dt), C.c_double(damping),
+                                            C.c_int32(nthreads), v.ctypes.data_as(PF64), st.ctypes.data_as(PI32))
         if rc:
             raise RuntimeError(f"mko_solve_ik_batch: {rc}")
         return v, st

@@ -78,3 +78,36 @@ def rand_q(m, rng):
     return q
 
 
+
+
+def chain_mjcf(ndof, seed=0, sites_every=25):
+    """A serial chain of `ndof` one-dof bodies (hinge, every seventh a slide; all limited) — one body per dof, so
+    ndof = 100 is 101 bodies with the world: past both one-wavefront limits.  Sites every `sites_every` links and at the
+    tip."""
+    rng = np.random.default_rng(seed)
+
+    def fmt(v):
+        return " ".join(f"{x:.6f}" for x in v)
+
+    sites = []
+    lines = ['<mujoco>', '  <compiler angle="radian" autolimits="true"/>', '  <worldbody>']
+    depth = 0
+    for i in range(ndof):
+        pad = "  " * (depth + 2)
+        pos = np.array([0.0, 0.0, 0.04]) + rng.normal(scale=0.01, size=3)
+        quat = olie.so3_exp(rng.normal(scale=0.3, size=3))
+        lines.append(f'{pad}<body name="b{i}" pos="{fmt(pos)}" quat="{fmt(quat)}">')
+        lines.append(f'{pad}  <inertial pos="0 0 0.02" mass="{rng.uniform(0.1, 0.5):.4f}" diaginertia="1 1 1"/>')
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        if i % 7 == 6:
+            lines.append(f'{pad}  <joint name="j{i}" type="slide" axis="{fmt(ax)}" range="-0.02 0.02"/>')
+        else:
+            lines.append(f'{pad}  <joint name="j{i}" type="hinge" axis="{fmt(ax)}" range="-0.6 0.6"/>')
+        if (i + 1) % sites_every == 0 or i == ndof - 1:
+            sites.append(f"s{i}")
+            lines.append(f'{pad}  <site name="s{i}" pos="0.01 0 0.03"/>')
+        depth += 1
+    for i in reversed(range(ndof)):
+        lines.append("  " * (i + 2) + "</body>")
+    lines += ['  </worldbody>', '</mujoco>']
+    return "\n".join(lines), sites

@@ -248,6 +248,69 @@ def test_production_kernel_against_2048_real_mink_instances(nat):
         assert (stR[r * B:(r + 1) * B] == st).all()
 
 
+def test_production_collision_path_against_2048_real_mink_instances(nat):
+    """tests/golden/ik_shadow_c4_big.npz (make_golden_big2.py: the REAL mink on 2 048 instances of config 4, half of them
+    pulled towards `grasp hard`: 17 contacts in range on average, up to 33) against the PLAIN call — the tight-rows launch
+    `48_72` with 24 rows for the 40 pairs plus the full-row redo launch for the instances it flags, whose row selection cannot be
+    tapped — and against the full-row build by flag.  The contact bounds h of all 40 pairs ride along (taps, parity build)."""
+    d = _golden("shadow_c4_big")
+    m = oc.model("shadow_left")
+    nm = nat.NativeModel(m)
+    B = len(d["q"])
+    prob, dt, damping = nc.build("shadow_c4", nm, B)
+    assert dt == float(d["dt"]) and damping == float(d["damping"])
+    main = np.ones(B, bool); main[7::8] = False
+    vs = np.maximum(1.0, np.abs(d["v"]).max(axis=1, keepdims=True))
+    fin = np.isfinite(d["coll_h"])
+    assert fin.sum(axis=1).max() > 24            # more contacts in range than tight rows somewhere: the redo launch has work
+
+    def check(v, st, what):
+        assert (st & ~1 == 0).all(), (what, np.unique(st, return_counts=True))
+        err = np.abs(v - d["v"]) / vs
+        print(f"shadow_c4_big {what} ({prob.last_kernel()}): max rel v err main {err[main].max():.2e} small-angle {err[~main].max():.2e}")
+        assert err[main].max() < 1e-8 and err[~main].max() < 1e-5
+
+    args = (d["q"], d["frame_targets"], d["posture_target"][None, :], None, dt, damping)
+    v, st = prob.solve(*args)
+    assert prob.last_kernel() == "ik_solve_kernel_48_72+redo_64", prob.last_kernel()
+    check(v, st, "tight rows + redo")
+    v2, st2 = prob.solve(*args, full_rows=True)
+    assert prob.last_kernel() == "ik_solve_kernel_64_72", prob.last_kernel()
+    check(v2, st2, "full rows")
+    _, _, t = prob.solve(*args, taps=["coll_h"])
+    assert (np.isfinite(t["coll_h"]) == fin).all()
+    np.testing.assert_allclose(t["coll_h"][fin], d["coll_h"][fin], rtol=0, atol=1e-9 * max(1.0, np.abs(d["coll_h"][fin]).max()))
+    # tiled ×8 = the BASELINE batch: persistent wavefronts run several rounds, the redo launch scans 16 384 statuses
+    R = 8
+    probR, _, _ = nc.build("shadow_c4", nm, R * B)
+    vR, stR = probR.solve(np.tile(d["q"], (R, 1)), np.tile(d["frame_targets"], (R, 1, 1)), d["posture_target"][None, :], None, dt, damping)
+    assert probR.last_kernel() == "ik_solve_kernel_48_72+redo_64"
+    for r in range(R):
+        np.testing.assert_array_equal(vR[r * B:(r + 1) * B], v)
+        assert (stR[r * B:(r + 1) * B] == st).all()
+
+
+def test_small_arm_kernels_against_4096_real_mink_instances(nat):
+    """tests/golden/ik_ur5e_c2_big.npz (make_golden_big2.py: the REAL mink on 4 096 instances of config 2, the batch the
+    metric is quoted on) on the row kernel (the default at this size) and, by flag, the lane and wavefront kernels."""
+    d = _golden("ur5e_c2_big")
+    m = oc.model("ur5e")
+    nm = nat.NativeModel(m)
+    B = len(d["q"])
+    prob, dt, damping = nc.build("ur5e_c2", nm, B)
+    assert dt == float(d["dt"]) and damping == float(d["damping"])
+    main = np.ones(B, bool); main[7::8] = False
+    vs = np.maximum(1.0, np.abs(d["v"]).max(axis=1, keepdims=True))
+    args = (d["q"], d["frame_targets"], d["posture_target"][None, :], None, dt, damping)
+    for flags, kernel in (({}, "ik_quad_kernel"), ({"lane_kernel": True}, "ik_lane_kernel"), ({"wave_kernel": True}, "ik_solve_kernel")):
+        v, st = prob.solve(*args, **flags)
+        assert prob.last_kernel().startswith(kernel), prob.last_kernel()
+        assert (st & ~1 == 0).all(), (kernel, np.unique(st, return_counts=True))
+        err = np.abs(v - d["v"]) / vs
+        print(f"ur5e_c2_big ({prob.last_kernel()}): max rel v err main {err[main].max():.2e} small-angle {err[~main].max():.2e}")
+        assert err[main].max() < 1e-8 and err[~main].max() < 1e-5
+
+
 @pytest.mark.parametrize("name", ["aloha_coll", "shadow_tips"])
 def test_mesh_dependent_collision_setups_against_real_mink(nat, name):
     """tests/golden/make_golden_mesh.py: the REAL mink on the two set-ups whose collision geoms come from mesh assets —

@@ -155,19 +155,28 @@ def test_other_configs_full_batch(name, B):
         v_ref = oik.solve_ik(m, q[i], tasks, dt_o, damp_o, limits)
         worst = max(worst, np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max()))
     print(name, "oracle subsample max rel err", worst, "pivots mean", t["qp_iters"].mean())
-    assert worst < 1e-7
-    if not prob.n_pairs:
-        # the whole batch against the plain-C oracle (no collision rows in its scope)
-        import os
-        from oracle import cport
-        mm, tasks, limits, dt_o, damp_o = cfgfn(tg[0], base)
-        v_ref, st_ref = cport.CProblem(mm, tasks, limits).solve_batch(q, tg, base[None, :], dt_o, damp_o,
-                                                                     nthreads=min(16, os.cpu_count() or 1))
-        assert (st_ref == 0).all()
-        v2, st2 = prob.solve(q, tg, base[None, :], None, dt, damping)       # production kernel variant
-        err = np.abs(v2 - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
-        print(name, "all %d problems vs C oracle: max rel err %.2e (kernel %s)" % (B, err.max(), prob.last_kernel()))
-        assert err.max() < 1e-7
+    assert worst < 1e-8                    # the stated tolerance
+    # the whole batch on the PRODUCTION kernel against the plain-C oracle (round 4: contact rows of plane / sphere /
+    # capsule pairs are in its scope — collision_avoidance_limit.py:187-229)
+    import os
+    from oracle import cport
+    mm, tasks, limits, dt_o, damp_o = cfgfn(tg[0], base)
+    v_ref, st_ref = cport.CProblem(mm, tasks, limits).solve_batch(q, tg, base[None, :], dt_o, damp_o,
+                                                                 nthreads=min(16, os.cpu_count() or 1))
+    assert (st_ref == 0).all()
+    v2, st2 = prob.solve(q, tg, base[None, :], None, dt, damping)       # production kernel variant
+    assert ((st2 & ~1) == 0).all(), np.unique(st2)
+    if prob.n_pairs:
+        assert prob.last_kernel() == "ik_solve_kernel_48_72+redo_64", prob.last_kernel()
+    err = np.abs(v2 - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
+    print(name, "all %d problems vs C oracle: max rel err %.2e (kernel %s)" % (B, err.max(), prob.last_kernel()))
+    assert err.max() < 1e-8
+    if prob.n_pairs:
+        v3, st3 = prob.solve(q, tg, base[None, :], None, dt, damping, full_rows=True)
+        assert prob.last_kernel() == "ik_solve_kernel_64_72", prob.last_kernel()
+        err3 = np.abs(v3 - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
+        print(name, "full-row build vs C oracle: max rel err %.2e" % err3.max())
+        assert ((st3 & ~1) == 0).all() and err3.max() < 1e-8
 
 
 def test_g1_full_batch_against_c_oracle(g1_setup):
@@ -306,3 +315,121 @@ def test_cold_start_refinement_agrees_with_the_plain_low_rank_start(monkeypatch)
         err_o = (np.abs(v[idx] - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))).max()
         print("dt x %g: refinement vs none %.2e, vs C oracle %.2e" % (scale, err, err_o))
         assert err < 1e-9 and err_o < 1e-9
+
+
+_BENCH_KERNELS = {"ur5e_c2": "ik_quad_kernel", "g1_c3": "ik_solve_kernel_44_32_r44_w3", "g1_full": "ik_solve_kernel_44_36_r44",
+                  "shadow_c4": "ik_solve_kernel_48_72+redo_64", "g1_plugin": "ik_solve_kernel_48_256"}
+
+
+def _oracle_specs_of_bench(name, model, prob_desc):
+    """The oracle-side statement of a bench workload (mink_amd/workloads.py::bench_config), written out independently."""
+    from oracle import ik
+    site = lambda s: model.name2id("site", s)
+    cost6 = lambda p, o: np.array([p] * 3 + [o] * 3, dtype=np.float64)
+    hinge = [int(model.jnt_dofadr[j]) for j in range(model.njnt) if model.jnt_type[j] != 0]
+    vel = ik.VelocityLimitSpec(np.array(hinge), np.full(len(hinge), np.pi))
+    z7 = np.zeros(7)
+    if name == "ur5e_c2":
+        return ([ik.FrameTaskSpec(site("attachment_site"), "site", cost6(1.0, 1.0), z7, lm_damping=1.0),
+                 ik.PostureTaskSpec(np.full(model.nv, 1e-2), None)], [ik.ConfigurationLimitSpec(), vel], {})
+    feet_palms = [ik.FrameTaskSpec(site(s), "site", cost6(200.0, o), z7, lm_damping=1.0)
+                  for s, o in (("left_foot", 10.0), ("right_foot", 10.0), ("left_palm", 0.0), ("right_palm", 0.0))]
+    post = ik.PostureTaskSpec(np.full(model.nv, 1.0), None)
+    if name == "g1_c3":
+        return feet_palms + [post], [ik.ConfigurationLimitSpec(), vel], {}
+    if name == "g1_full":
+        pel = ik.FrameTaskSpec(model.name2id("body", "pelvis"), "body", cost6(0.0, 10.0), z7)
+        return [pel] + feet_palms + [post, ik.ComTaskSpec(np.full(3, 200.0), None)], [ik.ConfigurationLimitSpec(), vel], {}
+    if name == "g1_plugin":
+        return (feet_palms + [post], [ik.ConfigurationLimitSpec(), vel],
+                {"dense_tasks": [{"cost": np.full(3, 50.0), "gain": 1.0, "lm_damping": 0.0}], "dense_limit_rows": 2})
+    if name == "shadow_c4":
+        tips = [ik.FrameTaskSpec(site(f), "site", cost6(1.0, 0.0), z7, lm_damping=1.0)
+                for f in ("thumb", "first", "middle", "ring", "little")]
+        pairs = [tuple(p) for p in np.load(oc.GOLDEN + "/shadow_c4_geom_pairs.npy")]
+        return (tips + [ik.PostureTaskSpec(np.full(model.nv, 1e-2), None)],
+                [ik.ConfigurationLimitSpec(), ik.CollisionAvoidanceLimitSpec(pairs, collision_detection_distance=0.03)], {})
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin"])
+def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name):
+    """Exactly what `bench.py --config <name>` times — the same constructors, the same generated batch (per-instance CoM
+    targets for the G1 full example, half of the Shadow instances pulled towards `grasp hard`, the caller's rows of the plugin
+    workload), the plain call, hence the production kernel — with EVERY instance held against the plain-C restatement of the
+    reference pipeline at the stated 1e-8·max(1, ‖v_ref‖∞)."""
+    import os
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+    from oracle import cport
+    B = workloads.BENCH_CONFIGS[name]["batch"]
+    model = workloads.load_bench_robot(name)
+    nm = nat.NativeModel(model)
+    prob, dt, damping = workloads.bench_config(name, model, nm, B)
+    rng = np.random.default_rng(2024)
+    q, tg, pt, com = workloads.bench_batch(name, model, nm, prob, rng, B)
+    dense = workloads.bench_dense(name, model, nm, q, rng)
+    v, st = prob.solve(q, tg, pt, com, dt, damping, dense=dense)
+    assert prob.last_kernel() == _BENCH_KERNELS[name], prob.last_kernel()
+    assert ((st & ~1) == 0).all(), np.unique(st, return_counts=True)
+    tasks, limits, extra = _oracle_specs_of_bench(name, model, prob)
+    if name == "shadow_c4":          # the bench's pair list (built by the product's CollisionAvoidanceLimit) = real mink's, recorded
+        from mink_amd.limits import CollisionAvoidanceLimit
+        groups = [[f"{f}_1", f"{f}_2"] for f in workloads.SHADOW_FINGERS]
+        col = CollisionAvoidanceLimit(model, [(groups[i], groups[j]) for i in range(5) for j in range(i + 1, 5)])
+        np.testing.assert_array_equal(np.array(col.geom_id_pairs), np.load(oc.GOLDEN + "/shadow_c4_geom_pairs.npy"))
+    cp = cport.CProblem(oc.model(workloads.BENCH_CONFIGS[name]["robot"]), tasks, limits, **extra)
+    v_ref, st_ref = cp.solve_batch(q, tg, pt, dt, damping, com_target=com, dense=dense, nthreads=min(16, os.cpu_count() or 1))
+    assert (st_ref == 0).all(), np.unique(st_ref, return_counts=True)
+    err = np.abs(v - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
+    print("%s: all %d instances vs C oracle: max rel err %.2e, p99 %.2e (kernel %s)"
+          % (name, B, err.max(), np.percentile(err, 99), prob.last_kernel()))
+    assert err.max() < 1e-8
+    if name == "shadow_c4":          # the regime must exercise the rows: contacts in range on most instances
+        G, h = cp.collision_rows(q[0], dt)
+        assert np.isfinite(h).sum() >= 5
+
+
+def _numpy_oracle_chunk(args):
+    name, idx, q, tg, pt, dt, damping = args
+    from mink_amd import workloads
+    from oracle import ik
+    model = workloads.load_bench_robot(name)
+    site = model.name2id("site", "attachment_site")
+    hinge = [int(model.jnt_dofadr[j]) for j in range(model.njnt) if model.jnt_type[j] != 0]
+    g = lambda n: model.name2id("geom", n)
+    pairs = [(g("wrist_3_link"), g("floor")), (g("wrist_3_link"), g("wall"))]
+    out = []
+    for i in idx:
+        tasks = [ik.FrameTaskSpec(site, "site", np.ones(6), tg[i, 0], lm_damping=1.0)]
+        limits = [ik.ConfigurationLimitSpec(), ik.CollisionAvoidanceLimitSpec(pairs, collision_detection_distance=0.3),
+                  ik.VelocityLimitSpec(np.array(hinge), np.full(len(hinge), np.pi))]
+        out.append(ik.solve_ik(model, q[i], tasks, dt, damping, limits))
+    return np.array(out)
+
+
+def test_ur5e_convex_at_its_bench_batch_against_the_numpy_oracle():
+    """The sixth bench workload: a cylinder–box pair goes through the general convex routine, which the C restatement does
+    not carry — all 4 096 instances against the numpy restatement (oracle/gjk.py) on every host core.  Tolerance 2e-5: rows of
+    G from GJK witness points are good to ~1e-5 (the distance itself to 1e-13)."""
+    import multiprocessing as mp
+    import os
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+    name = "ur5e_convex"
+    B = workloads.BENCH_CONFIGS[name]["batch"]
+    model = workloads.load_bench_robot(name)
+    nm = nat.NativeModel(model)
+    prob, dt, damping = workloads.bench_config(name, model, nm, B)
+    q, tg, pt, _ = workloads.bench_batch(name, model, nm, prob, np.random.default_rng(2024), B)
+    v, st = prob.solve(q, tg, pt, None, dt, damping)
+    assert prob.last_kernel() == "ik_solve_kernel_32_136", prob.last_kernel()
+    assert ((st & ~1) == 0).all(), np.unique(st, return_counts=True)
+    ncpu = min(16, os.cpu_count() or 1)
+    chunks = np.array_split(np.arange(B), ncpu * 4)
+    with mp.get_context("fork").Pool(ncpu) as pool:
+        parts = pool.map(_numpy_oracle_chunk, [(name, c, q, tg, pt, dt, damping) for c in chunks])
+    v_ref = np.concatenate(parts)
+    err = np.abs(v - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
+    print("ur5e_convex: all %d instances vs numpy oracle: max rel err %.2e, p99 %.2e" % (B, err.max(), np.percentile(err, 99)))
+    assert err.max() < 2e-5

@@ -86,3 +86,117 @@ def test_c_oracle_vs_2048_real_mink_instances(golden_dir):
     err = np.abs(v - d["v"]) / vs
     main = np.ones(len(v), bool); main[7::8] = False
     assert err[main].max() < 1e-8 and err[~main].max() < 1e-5, (err[main].max(), err[~main].max())
+
+
+def test_c_collision_rows_vs_real_mink_fixture(golden_dir):
+    """CollisionAvoidanceLimit in the C restatement (plane / sphere / capsule pairs): every row of the Shadow config 4
+    fixture recorded from the real mink — h of all 40 pairs on every instance (which pairs are inactive included), G on the
+    instances that carry it — and v through the C Goldfarb–Idnani with the contact rows stacked behind the box rows."""
+    d = _load(golden_dir, "shadow_c4")
+    m, tasks, limits, dt, damping = oc.shadow_c4(d["frame_targets"][0], d["posture_target"])
+    prob = cport.CProblem(m, tasks, limits)
+    npair = len(limits[1].geom_id_pairs)
+    for i in range(len(d["q"])):
+        G, h = prob.collision_rows(d["q"][i], dt)
+        h_ref = d["h"][i][-npair:]
+        fin = np.isfinite(h_ref)
+        np.testing.assert_array_equal(np.isfinite(h), fin)
+        np.testing.assert_allclose(h[fin], h_ref[fin], rtol=0, atol=1e-12 * max(1.0, np.abs(h_ref[fin]).max()))
+        if i < len(d["G"]):
+            np.testing.assert_allclose(G, d["G"][i][-npair:], rtol=0, atol=1e-13)
+    v, st = prob.solve_batch(d["q"], d["frame_targets"], d["posture_target"][None, :], dt, damping, nthreads=2)
+    assert (st == 0).all()
+    np.testing.assert_allclose(v, d["v"], rtol=0, atol=1e-9 * max(1.0, np.abs(d["v"]).max()))
+    # the same rows from the numpy restatement, on a configuration with the fingers pulled together
+    cfg = ik.Configuration(m, 0.5 * (d["q"][3] + m.key_qpos[m.name2id("key", "grasp hard")]))
+    G_np, h_np = ik.limit_inequalities(cfg, limits[1], dt)
+    G_c, h_c = prob.collision_rows(cfg.q, dt)
+    np.testing.assert_array_equal(np.isfinite(h_c), np.isfinite(h_np))
+    np.testing.assert_allclose(G_c, G_np, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(h_c[np.isfinite(h_c)], h_np[np.isfinite(h_np)], rtol=0, atol=1e-12)
+    with pytest.raises(TypeError):          # a box: outside the restated pair set, refused at construction
+        mu, _, _, _, _ = oc.ur5e_c2([np.zeros(7)], np.zeros(6))
+        box = [g for g in range(mu.ngeom) if int(mu.geom_type[g]) == 6]
+        cport.CProblem(mu, [], [ik.CollisionAvoidanceLimitSpec([(box[0], 0)])])
+
+
+def test_c_batched_com_targets(golden_dir):
+    d = _load(golden_dir, "g1_full")
+    n = len(d["q"])
+    m, tasks, limits, dt, damping = oc.g1_full(d["frame_targets"][0], d["posture_target"], d["com_target"][0])
+    prob = cport.CProblem(m, tasks, limits)
+    v, st = prob.solve_batch(d["q"], d["frame_targets"], d["posture_target"][None, :], dt, damping,
+                             com_target=d["com_target"].reshape(n, 1, 3))
+    assert (st == 0).all()
+    # (the C side groups objectives by kind: H differs from mink's order at 1e-16, v at 1e-10 of its size)
+    np.testing.assert_allclose(v, d["v"], rtol=0, atol=1e-9 * max(1.0, np.abs(d["v"]).max()))
+
+
+def test_c_oracle_takes_more_than_64_dofs():
+    """A 100-dof hinge / slide chain (the size the two-wavefront device path is checked at): C against numpy."""
+    import random_models as rm
+    from mink_amd import mjcf
+    xml, sites = rm.chain_mjcf(100)
+    m = mjcf.loads_mjcf(xml)
+    assert m.nv == 100
+    rng = np.random.default_rng(2)
+    q = rm.rand_q(m, rng)
+    tgt = ik.Configuration(m, rm.rand_q(m, rng))
+    tasks = [ik.FrameTaskSpec(m.name2id("site", s), "site", np.array([1.0, 1.0, 1.0, 0.3, 0.3, 0.3]),
+                              tgt.get_transform_frame_to_world(m.name2id("site", s), "site"), lm_damping=0.5) for s in sites]
+    tasks.append(ik.PostureTaskSpec(np.full(m.nv, 0.05), np.array(m.qpos0)))
+    limits = [ik.ConfigurationLimitSpec(), ik.VelocityLimitSpec(np.arange(m.nv), np.full(m.nv, 1.0))]
+    v_np = ik.solve_ik(m, q, tasks, 0.02, 1e-4, limits)
+    v_c = cport.CProblem(m, tasks, limits).solve(q, 0.02, 1e-4)
+    np.testing.assert_allclose(v_c, v_np, rtol=0, atol=1e-10 * max(1.0, np.abs(v_np).max()))
+    assert (np.abs(np.abs(v_np) - 1.0) < 1e-9).sum() > 3          # velocity bounds bind
+
+
+def test_c_dense_rows_vs_numpy(golden_dir):
+    """Caller-defined task / limit rows in the C restatement (mink/tasks/task.py:105-138, limits/limit.py:34-57) against the
+    numpy restatement's DenseTaskSpec / DenseLimitSpec on G1 config 3 + 5 task rows + 3 limit rows (one inactive)."""
+    d = _load(golden_dir, "g1_c3")
+    m, tasks, limits, dt, damping = oc.g1_c3(d["frame_targets"][0], d["posture_target"])
+    n, nv = len(d["q"]), m.nv
+    rng = np.random.default_rng(11)
+    e = rng.normal(scale=0.05, size=(n, 5)); J = rng.normal(size=(n, 5, nv))
+    G = rng.normal(size=(n, 3, nv)); h = np.abs(rng.normal(scale=1e-3, size=(n, 3))) + 1e-4
+    h[:, 1] = np.inf
+    dts = [{"cost": np.array([3.0, 2.0, 1.0]), "gain": 0.8, "lm_damping": 0.5}, {"cost": np.array([4.0, 0.0])}]
+    prob = cport.CProblem(m, tasks, limits, dense_tasks=dts, dense_limit_rows=3)
+    v, st = prob.solve_batch(d["q"], d["frame_targets"], d["posture_target"][None, :], dt, damping,
+                             dense={"task_e": e, "task_J": J, "limit_G": G, "limit_h": h})
+    assert (st == 0).all()
+    bound = 0
+    for i in range(n):
+        mm, t_i, l_i, _, _ = oc.g1_c3(d["frame_targets"][i], d["posture_target"])
+        t_i = t_i + [ik.DenseTaskSpec(e[i, :3], J[i, :3], dts[0]["cost"], 0.8, 0.5), ik.DenseTaskSpec(e[i, 3:], J[i, 3:], dts[1]["cost"])]
+        v_np = ik.solve_ik(mm, d["q"][i], t_i, dt, damping, l_i + [ik.DenseLimitSpec(G[i], h[i])])
+        np.testing.assert_allclose(v[i], v_np, rtol=0, atol=1e-10 * max(1.0, np.abs(v_np).max()))
+        bound += int((np.abs(G[i, [0, 2]] @ (v_np * dt) - h[i, [0, 2]]) < 1e-9).sum())
+    assert bound > 0                        # the caller's rows bind somewhere
+
+
+def test_c_oracle_vs_the_big_shadow_and_ur5e_real_mink_fixtures(golden_dir):
+    """tests/golden/make_golden_big2.py: 2 048 Shadow instances with contact rows (up to 33 contacts in range) and 4 096 UR5e
+    instances from the real mink pin the checker that the GPU tests hold whole bench batches against."""
+    d = _load(golden_dir, "shadow_c4_big")
+    m, tasks, limits, dt, damping = oc.shadow_c4(d["frame_targets"][0], d["posture_target"])
+    prob = cport.CProblem(m, tasks, limits)
+    v, st = prob.solve_batch(d["q"], d["frame_targets"], d["posture_target"][None, :], dt, damping, nthreads=4)
+    assert (st == 0).all()
+    main = np.ones(len(v), bool); main[7::8] = False
+    err = np.abs(v - d["v"]) / np.maximum(1.0, np.abs(d["v"]).max(axis=1, keepdims=True))
+    assert err[main].max() < 1e-8 and err[~main].max() < 1e-5, (err[main].max(), err[~main].max())
+    for i in range(0, len(v), 64):
+        _, h = prob.collision_rows(d["q"][i], dt)
+        fin = np.isfinite(d["coll_h"][i])
+        np.testing.assert_array_equal(np.isfinite(h), fin)
+        np.testing.assert_allclose(h[fin], d["coll_h"][i][fin], rtol=0, atol=1e-11 * max(1.0, np.abs(h[fin]).max()))
+    d = _load(golden_dir, "ur5e_c2_big")
+    m, tasks, limits, dt, damping = oc.ur5e_c2(d["frame_targets"][0], d["posture_target"])
+    v, st = cport.CProblem(m, tasks, limits).solve_batch(d["q"], d["frame_targets"], d["posture_target"][None, :], dt, damping, nthreads=4)
+    assert (st == 0).all()
+    main = np.ones(len(v), bool); main[7::8] = False
+    err = np.abs(v - d["v"]) / np.maximum(1.0, np.abs(d["v"]).max(axis=1, keepdims=True))
+    assert err[main].max() < 1e-8 and err[~main].max() < 1e-5, (err[main].max(), err[~main].max())
