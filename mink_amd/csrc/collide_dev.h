@@ -353,8 +353,11 @@ __device__ __forceinline__ Contact to_world(Contact k, const M3& R, V3 o) {
 template <bool SIMPLE = false, bool CONVEX = false>
 __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t2, V3 s2, V3 p2, Q4 q2,
                                               double distmax, double& dist, V3& from, V3& to,
-                                              const double* hv1 = nullptr, int hn1 = 0, const double* hv2 = nullptr, int hn2 = 0) {
+                                              const double* hv1 = nullptr, int hn1 = 0, const double* hv2 = nullptr, int hn2 = 0,
+                                              bool* need_epa = nullptr) {
   // hv / hn: hull vertices (geom frame) of a mesh geom
+  // need_epa (general convex pairs): set when the pair's cores OVERLAP — dist / from / to are then placeholders and the
+  // caller finishes the pair at wave level with geom_overlap_distance (the expanding polytope is a wave-cooperative routine)
   const bool flip = t1 > t2;
   if (flip) {
     int ti = t1; t1 = t2; t2 = ti;
@@ -412,7 +415,9 @@ __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t
     c.dist = dot(z1, pt - p1); c.hit = c.dist <= distmax; c.n = z1; c.pos = pt - (0.5 * c.dist) * z1;
   } else if (CONVEX && t1 >= GEOM_SPHERE && t1 <= GEOM_MESH && t2 >= GEOM_SPHERE && t2 <= GEOM_MESH) {
     const ConvexGeom g1{t1, s1, p1, R1, hv1, hn1}, g2{t2, s2, p2, R2, hv2, hn2};
-    c.hit = cvx_distance(g1, g2, distmax, c.dist, c.pos, c.n);
+    bool ne = false;
+    c.hit = cvx_distance(g1, g2, distmax, c.dist, c.pos, c.n, ne);
+    if (need_epa) *need_epa = ne;
   } else {
     dist = distmax; from = {0, 0, 0}; to = {0, 0, 0};
     return false;
@@ -423,6 +428,27 @@ __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t
   from = c.pos - (0.5 * sgn * c.dist) * c.n;
   to = c.pos + (0.5 * sgn * c.dist) * c.n;
   return true;
+}
+
+// Second half of geom_distance for a general convex pair whose cores overlap: every lane of the wavefront calls this with
+// the SAME (wave-uniform) pair; ws = the expanding polytope's LDS workspace (kEpaWsDoubles).
+__device__ __forceinline__ void geom_overlap_distance(int t1, V3 s1, V3 p1, Q4 q1, int t2, V3 s2, V3 p2, Q4 q2, double& dist, V3& from,
+                                                      V3& to, const double* hv1, int hn1, const double* hv2, int hn2, double* ws) {
+  const bool flip = t1 > t2;
+  if (flip) {
+    int ti = t1; t1 = t2; t2 = ti;
+    V3 tv = s1; s1 = s2; s2 = tv; tv = p1; p1 = p2; p2 = tv;
+    Q4 tq = q1; q1 = q2; q2 = tq;
+    const double* th = hv1; hv1 = hv2; hv2 = th; ti = hn1; hn1 = hn2; hn2 = ti;
+  }
+  const ConvexGeom g1{t1, s1, p1, qmat(q1), hv1, hn1}, g2{t2, s2, p2, qmat(q2), hv2, hn2};
+  const CvxEpa e = cvx_epa(g1, g2, ws);
+  Contact c;
+  cvx_overlap_contact(g1, g2, e, c.dist, c.pos, c.n);
+  const double sgn = flip ? -1.0 : 1.0;
+  dist = c.dist;
+  from = c.pos - (0.5 * sgn * c.dist) * c.n;
+  to = c.pos + (0.5 * sgn * c.dist) * c.n;
 }
 
 }  // namespace mkh

@@ -8,9 +8,11 @@
 // witness points / normal to ~1e-7 (the support-gap test |v|² − v·w ≤ 1e-14·|v|² bounds the angle of v by its square
 // root).  MuJoCo's own answer for these pairs (libccd MPR on shapes inflated by half the margin, tolerance 1e-6) is an
 // approximation of the same quantity.  Spheres and capsules enter as their core (point / segment) plus a radius.
-// Overlapping shapes: an upper bound of the penetration depth, min over unit d of h₁(d) + h₂(−d) by projected descent from
-// the best of the centre-to-centre direction and the shapes' axes (mink only uses the sign of such a distance —
-// h = bound_relaxation — and the direction).  oracle/gjk.py is the CPU statement of the same algorithm.
+// Overlapping shapes: the smallest separating translation (depth, direction, deepest points) by the expanding polytope
+// algorithm, the wavefront cooperating on one pair at a time (cvx_epa below; round 4 — rounds 2 and 3 ran a projected
+// descent of h₁(d) + h₂(−d), which stalls on the kinks of polytope support functions: device and oracle stopped at different
+// points of the same kink, found by the whole-batch parity test of the `ur5e_convex` workload).  mink uses the sign of such
+// a distance (h = bound_relaxation) and the direction.  oracle/gjk.py is the CPU statement of the same algorithm.
 //
 // Register discipline (round 3).  The first version kept the simplex in arrays indexed by the sub-algorithm's results
 // (`W[idx[i]]`, `P[faces[f][li[t]]]`): hipcc sends every runtime-indexed private array to SCRATCH, so a GJK run was a
@@ -20,18 +22,12 @@
 // tetrahedron are four static instantiations.  Nothing is indexed at run time; the routine compiles without scratch.
 #pragma once
 #include "lie_dev.h"
+#include "wave_ops.h"
 
 namespace mkh {
 
 constexpr int kGeomSphere = 2, kGeomCapsule = 3, kGeomEllipsoid = 4, kGeomCylinder = 5, kGeomBox = 6, kGeomMesh = 7;
 constexpr int kGjkMaxIters = 128;
-// Overlapping shapes (cvx_penetration): mink uses the SIGN of such a distance (h = bound_relaxation) and the direction of the
-// row; a projected-gradient descent converges linearly, so every digit of the direction costs iterations — and a launch
-// waits for its slowest wavefront: with the first version's 128 × 20 support evaluations at 1e-12 a UR5e batch with one
-// cylinder–box pair spent 0.19 of its 0.25 ms on the 3 % of instances that start inside the wall.  1e-7 on the gradient
-// (the direction to ~1e-7 rad), 40 steps of at most 10 halvings.
-constexpr int kPenMaxIters = 40, kPenMaxHalvings = 10;
-constexpr double kPenTol = 1e-7;
 
 // vert / nvert: convex-hull vertices of a mesh geom in the geom's frame (global memory, 3 doubles each); nullptr else
 struct ConvexGeom { int type; V3 size; V3 pos; M3 R; const double* vert; int nvert; };
@@ -243,54 +239,185 @@ __device__ __forceinline__ bool cvx_gjk(const ConvexGeom& g1, const ConvexGeom& 
   return true;
 }
 
-// depth (> 0) and direction (from 1 to 2) of a separating translation of two overlapping shapes
-__device__ __forceinline__ double cvx_penetration(const ConvexGeom& g1, double r1, const ConvexGeom& g2, double r2, V3& dir) {
-  auto hs = [&](V3 d, V3& s) -> double {
-    s = cvx_support(g1, d) - cvx_support(g2, -1.0 * d);
-    return dot(d, s) + r1 + r2;
-  };
-  V3 d0 = g2.pos - g1.pos;
-  const double n0 = sqrt(dot(d0, d0));
-  d0 = n0 > 1e-12 ? (1.0 / n0) * d0 : V3{1.0, 0.0, 0.0};
-  V3 s, d = d0;
-  double h = hs(d0, s);
-#pragma nounroll
-  for (int k = 0; k < 12; ++k) {                  // ± axes of both shapes (column c of R1 / R2, by selects)
-    const bool first = k < 6;
-    const int c = (k % 6) >> 1;
-    const double m0 = first ? g1.R.m[0] : g2.R.m[0], m1 = first ? g1.R.m[1] : g2.R.m[1], m2 = first ? g1.R.m[2] : g2.R.m[2];
-    const double m3 = first ? g1.R.m[3] : g2.R.m[3], m4 = first ? g1.R.m[4] : g2.R.m[4], m5 = first ? g1.R.m[5] : g2.R.m[5];
-    const double m6 = first ? g1.R.m[6] : g2.R.m[6], m7 = first ? g1.R.m[7] : g2.R.m[7], m8 = first ? g1.R.m[8] : g2.R.m[8];
-    V3 cd{c == 0 ? m0 : (c == 1 ? m1 : m2), c == 0 ? m3 : (c == 1 ? m4 : m5), c == 0 ? m6 : (c == 1 ? m7 : m8)};
-    if (k & 1) cd = -1.0 * cd;
-    V3 sc;
-    const double hc = hs(cd, sc);
-    if (hc < h) { h = hc; s = sc; d = cd; }
-  }
-  double step = 1.0;
-#pragma nounroll
-  for (int it = 0; it < kPenMaxIters; ++it) {
-    const V3 g = s - dot(s, d) * d;               // gradient of d·s(d) on the sphere
-    const double gn = sqrt(dot(g, g));
-    if (gn < kPenTol * fmax(1.0, fabs(h))) break;
-    bool ok = false;
-#pragma nounroll
-    for (int ls = 0; ls < kPenMaxHalvings; ++ls) {
-      V3 dn = d - (step / fmax(sqrt(dot(s, s)), 1e-300)) * g;
-      dn = (1.0 / sqrt(dot(dn, dn))) * dn;
-      V3 sn;
-      const double hn = hs(dn, sn);
-      if (hn < h) { d = dn; h = hn; s = sn; ok = true; step = fmin(step * 1.5, 4.0); break; }
-      step *= 0.5;
+// ---------------------------------------------------------------------------------------------------------------------
+// Overlapping cores: the SMALLEST separating translation — the point of the boundary of the Minkowski difference
+// D = {x₁ − x₂} nearest to the origin — by the expanding polytope algorithm (van den Bergen 2001), ONE pair per call with
+// the whole wavefront cooperating: the faces of the inner polytope are spread over the lanes (slot s on lane s mod 64), so
+// "the face whose plane is nearest to the origin", "the faces that see the new support point" and the horizon of those are
+// wave reductions / ballots instead of loops; vertices, faces and one bit per directed edge live in `ws` (LDS,
+// kEpaWsDoubles).  Plane offsets are SIGNED: the start polytope (two support points along ±x, the farthest point from
+// their line, both sides of that triangle) need not contain the origin yet; faces with a negative offset are expanded
+// first.  A face is final when the support point along its normal lies within kEpaTol of its plane.  oracle/gjk.py
+// `penetration` states the same rules (slot order of new faces, ties by slot) sequentially.  What MuJoCo's collider
+// returns for such a pair approximates this quantity (libccd MPR to 1e-6 in mujoco 3.1.6; its native GJK + EPA later).
+// Arguments arrive wave-uniform; every lane executes every statement (no divergent call).
+constexpr int kEpaMaxV = 48, kEpaMaxF = 92;
+constexpr double kEpaTol = 1e-12;
+constexpr int kEpaOffV = 0, kEpaOffF = 6 * kEpaMaxV, kEpaOffI = kEpaOffF + 4 * kEpaMaxF, kEpaOffE = kEpaOffI + (kEpaMaxF + 1) / 2,
+              kEpaOffL = kEpaOffE + kEpaMaxV, kEpaWsDoubles = kEpaOffL + (kEpaMaxF + 7) / 8 + 1;
+struct CvxEpa { double depth; V3 n, a, b; };
+
+__device__ __forceinline__ double wave_min_f64(double x) {
+  x = fmin(x, dpp_f64<0xB1>(x));
+  x = fmin(x, dpp_f64<0x4E>(x));
+  x = fmin(x, dpp_f64<0x141>(x));
+  x = fmin(x, dpp_f64<0x140>(x));
+  return fmin(fmin(readlane_f64(x, 0), readlane_f64(x, 16)), fmin(readlane_f64(x, 32), readlane_f64(x, 48)));
+}
+
+__device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom& g2, double* ws) {
+  const int lane = lane_id();
+  double* const V = ws + kEpaOffV;                                   // vertex k: W at V[6k], A (its point on shape 1) at V[6k + 3]
+  double* const F = ws + kEpaOffF;                                   // face s: unit normal F[4s..4s+2], plane offset F[4s+3]
+  int* const Fi = reinterpret_cast<int*>(ws + kEpaOffI);             // face s: i | j << 8 | k << 16, −1 = free slot
+  unsigned long long* const E = reinterpret_cast<unsigned long long*>(ws + kEpaOffE);   // bit j of E[i]: edge i→j of a visible face
+  unsigned char* const freel = reinterpret_cast<unsigned char*>(ws + kEpaOffL);         // freed slots in ascending order
+  const double kInf = __builtin_huge_val();
+  int nvert = 0;
+  auto add = [&](V3 d) -> V3 {                                       // support point of D along d (uniform): vertex nvert
+    const V3 a = cvx_support(g1, d);
+    const V3 w = a - cvx_support(g2, -1.0 * d);
+    if (lane == 0) {
+      double* o = V + 6 * nvert;
+      o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = a.x; o[4] = a.y; o[5] = a.z;
     }
-    if (!ok) break;
+    ++nvert;
+    return w;
+  };
+  auto vtx = [&](int k) -> V3 { return V3{V[6 * k], V[6 * k + 1], V[6 * k + 2]}; };
+  // face (i, j, k) in its given winding → slot s (a triangle without area can never be the nearest face, but stays: the
+  // surface must remain closed)
+  auto put_face = [&](int s, int i, int j, int k, V3 wi, V3 wj, V3 wk) {
+    const V3 n = cross(wj - wi, wk - wi);
+    const double l = sqrt(dot(n, n));
+    double* o = F + 4 * s;
+    if (l < 1e-150) { o[0] = 0.0; o[1] = 0.0; o[2] = 0.0; o[3] = kInf; }
+    else {
+      const V3 u{n.x / l, n.y / l, n.z / l};
+      o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = dot(u, wi);
+    }
+    Fi[s] = i | (j << 8) | (k << 16);
+  };
+  const V3 w0 = add(V3{1.0, 0.0, 0.0}), w1 = add(V3{-1.0, 0.0, 0.0});
+  const V3 u = w1 - w0;
+  const double uu = dot(u, u);
+  const double ax = fabs(u.x), ay = fabs(u.y), az = fabs(u.z);
+  V3 e{0.0, 0.0, 0.0};
+  if (ax <= ay && ax <= az) e.x = 1.0; else if (ay <= az) e.y = 1.0; else e.z = 1.0;     // (numpy argmin: the first minimum)
+  V3 v = uu > 0.0 ? e - (dot(e, u) / uu) * u : e;
+  v = (1.0 / sqrt(dot(v, v))) * v;
+  V3 w2 = add(v);
+  if (fabs(dot(w2 - w0, v)) <= 1e-12 * fmax(1.0, sqrt(uu))) { --nvert; w2 = add(-1.0 * v); }
+  V3 n0 = cross(w1 - w0, w2 - w0);
+  n0 = (1.0 / fmax(sqrt(dot(n0, n0)), 1e-300)) * n0;
+  const V3 w3 = add(n0), w4 = add(-1.0 * n0);
+  const V3 sum5 = (((w0 + w1) + w2) + w3) + w4;
+  const V3 cen{sum5.x / 5.0, sum5.y / 5.0, sum5.z / 5.0};
+  wave_sync();
+  if (lane < 6) {
+    const int i = lane % 3, j = (lane + 1) % 3, k = lane < 3 ? 3 : 4;
+    const V3 wi = i == 0 ? w0 : (i == 1 ? w1 : w2), wj = j == 0 ? w0 : (j == 1 ? w1 : w2), wk = lane < 3 ? w3 : w4;
+    put_face(lane, i, j, k, wi, wj, wk);
+    if (F[4 * lane] * (wi.x - cen.x) + F[4 * lane + 1] * (wi.y - cen.y) + F[4 * lane + 2] * (wi.z - cen.z) < 0.0)
+      put_face(lane, i, k, j, wi, wk, wj);
   }
-  dir = d;
-  return h;
+  wave_sync();
+  int nslots = 6, best = 0;
+#pragma nounroll
+  for (;;) {
+    // the face whose plane is nearest to the origin (signed), lowest slot on ties
+    double my_off = kInf;
+    unsigned my_slot = 0xffffffffu;
+    for (int s = lane; s < nslots; s += 64)
+      if (Fi[s] >= 0) { const double off = F[4 * s + 3]; if (off < my_off || my_slot == 0xffffffffu) { my_off = off; my_slot = (unsigned)s; } }
+    const double mo = wave_min_f64(my_off);
+    best = (int)wave_min_u32((my_slot != 0xffffffffu && my_off == mo) ? my_slot : 0xffffffffu);
+    const V3 nb{F[4 * best], F[4 * best + 1], F[4 * best + 2]};
+    const double off = F[4 * best + 3];
+    if (nvert >= kEpaMaxV) break;
+    const int ip = nvert;
+    const V3 p = add(nb);
+    const double gap = dot(nb, p) - off;
+    if (gap <= kEpaTol * fmax(1.0, fabs(off))) { --nvert; break; }          // the face is (within the gap) a face of D itself
+    if (lane < kEpaMaxV) E[lane] = 0ull;
+    wave_sync();
+    // faces that see p, and one bit per directed edge of those
+    bool vis0 = false, vis1 = false;
+    int id0 = -1, id1 = -1;
+    {
+      const int s = lane;
+      if (s < nslots && (id0 = Fi[s]) >= 0) {
+        const double o = F[4 * s + 3];
+        vis0 = (F[4 * s] * p.x + F[4 * s + 1] * p.y + F[4 * s + 2] * p.z) - o > 1e-13 * fmax(1.0, fabs(o)) || s == best;
+      }
+      const int t = lane + 64;
+      if (t < nslots && (id1 = Fi[t]) >= 0) {
+        const double o = F[4 * t + 3];
+        vis1 = (F[4 * t] * p.x + F[4 * t + 1] * p.y + F[4 * t + 2] * p.z) - o > 1e-13 * fmax(1.0, fabs(o)) || t == best;
+      }
+    }
+    auto mark = [&](int id) {
+      const int i = id & 255, j = (id >> 8) & 255, k = (id >> 16) & 255;
+      atomicOr(&E[i], 1ull << j); atomicOr(&E[j], 1ull << k); atomicOr(&E[k], 1ull << i);
+    };
+    if (vis0) mark(id0);
+    if (vis1) mark(id1);
+    wave_sync();
+    // horizon: edges of visible faces whose twin belongs to a face that does not see p
+    auto horizon = [&](int id) -> int {
+      const int i = id & 255, j = (id >> 8) & 255, k = (id >> 16) & 255;
+      return (int)(((E[j] >> i) & 1ull) ^ 1ull) | ((int)(((E[k] >> j) & 1ull) ^ 1ull) << 1) | ((int)(((E[i] >> k) & 1ull) ^ 1ull) << 2);
+    };
+    const int hz0 = vis0 ? horizon(id0) : 0, hz1 = vis1 ? horizon(id1) : 0;
+    const int c0 = __popc(hz0), c1 = __popc(hz1);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const unsigned long long v0m = __ballot(vis0), v1m = __ballot(vis1);
+    const unsigned long long a0 = __ballot(c0 & 1), b0 = __ballot(c0 & 2), a1 = __ballot(c1 & 1), b1 = __ballot(c1 & 2);
+    const int tot0 = __popcll(a0) + 2 * __popcll(b0), tot1 = __popcll(a1) + 2 * __popcll(b1);
+    const int nvis = __popcll(v0m) + __popcll(v1m), nh = tot0 + tot1;
+    if (nslots - nvis + nh > kEpaMaxF) { --nvert; break; }                    // out of slots: the nearest face so far is the answer
+    int q0 = __popcll(a0 & lt) + 2 * __popcll(b0 & lt);                        // index of this lane's first horizon edge, (slot, edge) order
+    int q1 = tot0 + __popcll(a1 & lt) + 2 * __popcll(b1 & lt);
+    if (vis0) { freel[__popcll(v0m & lt)] = (unsigned char)lane; Fi[lane] = -1; }
+    if (vis1) { freel[__popcll(v0m) + __popcll(v1m & lt)] = (unsigned char)(lane + 64); Fi[lane + 64] = -1; }
+    wave_sync();
+    auto emit = [&](int id, int hz, int q) {
+      const int i = id & 255, j = (id >> 8) & 255, k = (id >> 16) & 255;
+#pragma unroll
+      for (int ed = 0; ed < 3; ++ed) {
+        if (!((hz >> ed) & 1)) continue;
+        const int a_ = ed == 0 ? i : (ed == 1 ? j : k), b_ = ed == 0 ? j : (ed == 1 ? k : i);
+        const int slot = q < nvis ? (int)freel[q] : nslots + (q - nvis);
+        put_face(slot, a_, b_, ip, vtx(a_), vtx(b_), p);
+        ++q;
+      }
+    };
+    if (hz0) emit(id0, hz0, q0);
+    if (hz1) emit(id1, hz1, q1);
+    if (nh > nvis) nslots += nh - nvis;
+    wave_sync();
+  }
+  wave_sync();
+  const V3 nb{F[4 * best], F[4 * best + 1], F[4 * best + 2]};
+  const int id = Fi[best];
+  const int i = id & 255, j = (id >> 8) & 255, k = (id >> 16) & 255;
+  const V3 wi = vtx(i), wj = vtx(j), wk = vtx(k);
+  const CvxW3 t = cvx_closest_triangle(wi, wj, wk);                          // the face's point nearest to the origin, barycentric
+  const V3 ai{V[6 * i + 3], V[6 * i + 4], V[6 * i + 5]}, aj{V[6 * j + 3], V[6 * j + 4], V[6 * j + 5]}, ak{V[6 * k + 3], V[6 * k + 4], V[6 * k + 5]};
+  CvxEpa r;
+  r.a = t.l0 * ai + (t.l1 * aj + t.l2 * ak);
+  r.b = r.a - (t.l0 * wi + (t.l1 * wj + t.l2 * wk));
+  r.n = nb;
+  // (geom 2 translated by t overlaps geom 1 iff t ∈ D: the shortest separating translation of geom 2 is depth·n)
+  r.depth = dot(nb, cvx_support(g1, nb)) - dot(nb, cvx_support(g2, -1.0 * nb));
+  wave_sync();
+  return r;
 }
 
 // One contact in mj_geomDistance's convention: n from geom 1 to geom 2, pos the midpoint of the witness points.
-__device__ __forceinline__ bool cvx_distance(const ConvexGeom& g1, const ConvexGeom& g2, double margin, double& dist, V3& pos, V3& nrm) {
+// need_epa: the cores overlap — the caller runs cvx_epa for this pair at wave level (cvx_overlap_contact finishes the contact).
+__device__ __forceinline__ bool cvx_distance(const ConvexGeom& g1, const ConvexGeom& g2, double margin, double& dist, V3& pos, V3& nrm,
+                                             bool& need_epa) {
   const double r1 = cvx_core_radius(g1), r2 = cvx_core_radius(g2);
   double dc = 0.0;
   V3 pa{0, 0, 0}, pb{0, 0, 0};
@@ -302,12 +429,17 @@ __device__ __forceinline__ bool cvx_distance(const ConvexGeom& g1, const ConvexG
     pos = 0.5 * ((pa + r1 * nrm) + (pb - r2 * nrm));
     return true;
   }
-  V3 n;
-  const double depth = cvx_penetration(g1, r1, g2, r2, n);
-  const V3 a = cvx_support(g1, n) + r1 * n;       // deepest point of 1 along n
-  const V3 b = cvx_support(g2, -1.0 * n) - r2 * n;
-  dist = -depth; nrm = n; pos = 0.5 * (a + b);
+  need_epa = true;
+  dist = 0.0; nrm = {1.0, 0.0, 0.0}; pos = {0.0, 0.0, 0.0};
   return true;
+}
+
+// the contact of an overlapping pair from the expanding polytope's answer: the deepest points a − b = depth·n
+__device__ __forceinline__ void cvx_overlap_contact(const ConvexGeom& g1, const ConvexGeom& g2, const CvxEpa& e, double& dist, V3& pos, V3& nrm) {
+  const double r1 = cvx_core_radius(g1), r2 = cvx_core_radius(g2);
+  dist = -(e.depth + r1 + r2);
+  nrm = e.n;
+  pos = 0.5 * ((e.a + r1 * e.n) + (e.b - r2 * e.n));
 }
 
 }  // namespace mkh

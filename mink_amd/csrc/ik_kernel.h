@@ -1306,20 +1306,20 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
   // the result is the reference's; one that does not hold sets MKH_ST_ROW_OVERFLOW.
   double* const sH = smem + L.hsel;                         // h of every pair (only laid out when n_pairs > max_rows)
   const bool can_select = n_pairs > max_rows;
-  // contact of pair pi at the current poses: active, h, unit normal, witness points, dof chains
-  auto contact_of = [&](int pi, double& hk, V3& nrm, V3& from, V3& to, uint64_t& m1, uint64_t& m2) -> bool {
-    const auto& cp = pairs[pi];
+  // the expanding polytope's workspace (general convex pairs whose cores overlap): behind the h of every pair
+  double* const sEpa = smem + L.hsel + (can_select ? lds_even(n_pairs) : 0);
+  // world poses of the two geoms of pair pi
+  auto pair_poses = [&](const auto& cp, V3& gp1, Q4& gq1, V3& gp2, Q4& gq2) {
     const double* x1 = sX + cp.body1;
     const double* x2 = sX + cp.body2;
-    Q4 bq1{x1[3 * XS], x1[4 * XS], x1[5 * XS], x1[6 * XS]}, bq2{x2[3 * XS], x2[4 * XS], x2[5 * XS], x2[6 * XS]};
-    V3 gp1 = V3{x1[0], x1[XS], x1[2 * XS]} + qrot(bq1, V3{cp.lpos1[0], cp.lpos1[1], cp.lpos1[2]});
-    V3 gp2 = V3{x2[0], x2[XS], x2[2 * XS]} + qrot(bq2, V3{cp.lpos2[0], cp.lpos2[1], cp.lpos2[2]});
-    Q4 gq1 = qmul(bq1, Q4{cp.lquat1[0], cp.lquat1[1], cp.lquat1[2], cp.lquat1[3]});
-    Q4 gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
-    double dist;
-    geom_distance<kSimpleColl, kConvexColl>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
-                  V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to,
-                  cp.vert1, cp.nvert1, cp.vert2, cp.nvert2);
+    const Q4 bq1{x1[3 * XS], x1[4 * XS], x1[5 * XS], x1[6 * XS]}, bq2{x2[3 * XS], x2[4 * XS], x2[5 * XS], x2[6 * XS]};
+    gp1 = V3{x1[0], x1[XS], x1[2 * XS]} + qrot(bq1, V3{cp.lpos1[0], cp.lpos1[1], cp.lpos1[2]});
+    gp2 = V3{x2[0], x2[XS], x2[2 * XS]} + qrot(bq2, V3{cp.lpos2[0], cp.lpos2[1], cp.lpos2[2]});
+    gq1 = qmul(bq1, Q4{cp.lquat1[0], cp.lquat1[1], cp.lquat1[2], cp.lquat1[3]});
+    gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
+  };
+  // a pair's distance and witness points → active, h, unit normal, dof chains
+  auto finish_contact = [&](const auto& cp, double dist, V3 from, V3 to, double& hk, V3& nrm, uint64_t& m1, uint64_t& m2) -> bool {
     const bool active = dist != cp.ddetect;                  // Contact.inactive (:52-56)
     hk = kInf;
     if (active) {
@@ -1331,6 +1331,30 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
       m2 = cp.mask2;
     }
     return active;
+  };
+  // contact of pair pi at the current poses.  need_epa: a general convex pair whose cores overlap — finished at wave level
+  // below (overlap_of), the values returned here are placeholders
+  auto contact_of = [&](int pi, double& hk, V3& nrm, V3& from, V3& to, uint64_t& m1, uint64_t& m2, bool& need_epa) -> bool {
+    const auto& cp = pairs[pi];
+    V3 gp1, gp2;
+    Q4 gq1, gq2;
+    pair_poses(cp, gp1, gq1, gp2, gq2);
+    double dist;
+    geom_distance<kSimpleColl, kConvexColl>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
+                  V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to,
+                  cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, &need_epa);
+    return finish_contact(cp, dist, from, to, hk, nrm, m1, m2);
+  };
+  // the same for ONE wave-uniform pair whose cores overlap, every lane cooperating (expanding polytope, convex_dev.h)
+  auto overlap_of = [&](int pi, double& hk, V3& nrm, V3& from, V3& to, uint64_t& m1, uint64_t& m2) -> bool {
+    const auto& cp = pairs[pi];
+    V3 gp1, gp2;
+    Q4 gq1, gq2;
+    pair_poses(cp, gp1, gq1, gp2, gq2);
+    double dist;
+    geom_overlap_distance(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
+                          V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, dist, from, to, cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, sEpa);
+    return finish_contact(cp, dist, from, to, hk, nrm, m1, m2);
   };
   // position of pair pi in the order (h, index) among all pairs (h = +inf: not detected)
   auto rank_of = [&](int pi, double hk) -> int {
@@ -1357,7 +1381,19 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
         const double hs = sH[pi];
         want = hs < kInf && rank_of(pi, hs) >= max_rows;
       }
-      if (want) active = contact_of(pi, hk, nrm, from, to, m1, m2);
+      bool need_epa = false;
+      if (want) active = contact_of(pi, hk, nrm, from, to, m1, m2, need_epa);
+      if constexpr (kConvexColl) {
+        // pairs whose cores overlap: one at a time, the wavefront cooperating on the expanding polytope
+        for (unsigned long long em = __ballot(want && need_epa); em; em &= em - 1) {
+          const int l = (int)__builtin_ctzll(em);
+          double hk_e = kInf;
+          V3 n_e{1, 0, 0}, f_e{0, 0, 0}, t_e{0, 0, 0};
+          uint64_t m1_e = 0, m2_e = 0;
+          const bool act_e = overlap_of(base + l, hk_e, n_e, f_e, t_e, m1_e, m2_e);
+          if (lane == l) { active = act_e; hk = hk_e; nrm = n_e; from = f_e; to = t_e; m1 = m1_e; m2 = m2_e; }
+        }
+      }
       if (mode != 0) {
         // G·Δq ≤ h at the solution?  (G·Δq = −nᵀ(ṗ₂(to) − ṗ₁(from)) for joint displacements Δq, the dofs of each geom's chain)
         if (active) {

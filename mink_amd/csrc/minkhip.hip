@@ -687,7 +687,9 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     const int want = P.n_pairs + P.n_dense_limit_rows;          // half-space rows that can be active at once
     P.max_rows = want < (kWave - m->nv) ? want : (kWave - m->nv);
     if (const char* cap = getenv("MKH_DEBUG_MAX_ROWS")) { const int c = atoi(cap); if (c > 0 && c < P.max_rows) P.max_rows = c; }   // (experiments)
-    P.n_hsel = P.n_pairs > P.max_rows ? P.n_pairs : 0;
+    // LDS behind the per-problem ranges: h of every pair when pairs outnumber rows (row selection), then the expanding polytope's
+    // workspace when some pair goes through the general convex routine (collision_phase: the same two terms)
+    P.n_hsel = (P.n_pairs > P.max_rows ? lds_even(P.n_pairs) : 0) + (p->convex_pairs ? kEpaWsDoubles : 0);
   }
   const int ntab = m->nv + P.max_rows;
   {

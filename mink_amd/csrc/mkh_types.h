@@ -125,7 +125,7 @@ struct DeviceProblem {
   const double* dense_wgain;       // [n_dense_rows] cost·(−gain) of each row: weighted error = wgain·e
   // (appended last: the offsets of the fields above are what the register allocation of the W3 builds was tuned on —
   //  one int32 in the middle cost the headline kernel 25 spilled VGPRs)
-  int32_t n_hsel;        // n_pairs when there are more pairs than rows (LDS for the h of every pair: row selection), else 0
+  int32_t n_hsel;        // doubles of LDS behind the per-problem ranges: n_pairs (even) when there are more pairs than rows (h of every pair: row selection) + the expanding polytope's workspace when a pair needs the general convex routine
 };
 
 struct SolveArgs {

@@ -18,7 +18,6 @@ import numpy as np
 
 GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = 0, 2, 3, 4, 5, 6, 7
 MAX_ITERS = 128
-PEN_MAX_ITERS, PEN_MAX_HALVINGS, PEN_TOL = 40, 10, 1e-7      # overlapping shapes: only the sign and the direction are used
 
 
 def core_radius(gtype, size):
@@ -173,45 +172,101 @@ def gjk_cores(t1, s1, p1, R1, t2, s2, p2, R2):
     return float(np.sqrt(v @ v)), pa, pb, False
 
 
-def penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2):
-    """Depth and direction (from 1 to 2) of the smallest translation that separates two overlapping shapes, by projected
-    descent of h(d) = h₁(d) + h₂(−d) over unit d from the centre-to-centre direction."""
-    def h_and_s(d):
-        s = support(t1, s1, p1, R1, d) - support(t2, s2, p2, R2, -d)
-        return float(d @ s) + r1 + r2, s
+EPA_MAXV, EPA_MAXF, EPA_TOL = 48, 92, 1e-12        # vertices, faces (= 2·V − 4), relative gap at which a face counts as final
 
-    # start: the best of the centre-to-centre direction and the ± axes of both shapes (the face normals of boxes and
-    # cylinder caps: for polytopes the minimum sits on a face normal of the Minkowski difference)
-    d0 = p2 - p1
-    n = np.sqrt(d0 @ d0)
-    cands = [d0 / n if n > 1e-12 else np.array([1.0, 0.0, 0.0])]
-    for R in (R1, R2):
-        for k in range(3):
-            cands += [R[:, k].copy(), -R[:, k]]
-    h, s, d = np.inf, None, None
-    for c in cands:
-        hc, sc = h_and_s(c)
-        if hc < h:
-            h, s, d = hc, sc, c
-    step = 1.0
-    for _ in range(PEN_MAX_ITERS):
-        g = s - (s @ d) * d                            # gradient of d·s(d) on the sphere
-        gn = np.sqrt(g @ g)
-        if gn < PEN_TOL * max(1.0, abs(h)):
+
+def _epa_face(W, i, j, k):
+    """(i, j, k, unit normal, plane offset) of the triangle in its given winding; a triangle without area can never be the
+    closest face (offset +inf) but stays in the list: the surface must remain closed."""
+    n = np.cross(W[j] - W[i], W[k] - W[i])
+    l = np.sqrt(n @ n)
+    if l < 1e-150:
+        return [i, j, k, np.zeros(3), np.inf]
+    n = n / l
+    return [i, j, k, n, float(n @ W[i])]
+
+
+def penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2):
+    """Overlapping cores: depth, direction (from 1 to 2) and witness points (a on core 1, b on core 2) of the SMALLEST
+    translation that separates them — the point of the boundary of the Minkowski difference D = {x₁ − x₂} closest to the
+    origin — by the expanding polytope algorithm (van den Bergen 2001): an inner polytope of D grows by the support point in
+    the direction of the face whose plane is nearest to the origin until that face is a face of D (gap ≤ EPA_TOL).  Plane
+    offsets are SIGNED: the start polytope (two support points along ±x, the farthest point from their line, both sides of
+    that triangle) need not contain the origin yet; every face with a negative offset is expanded first.  What MuJoCo's own
+    collider returns for such a pair is an approximation of this quantity (libccd MPR, tolerance 1e-6, in the pinned
+    mujoco ≥ 3.1.6; GJK + EPA since its native convex collider).  The device runs the same rules (slot order, ties) one face
+    per lane: mink_amd/csrc/convex_dev.h cvx_epa."""
+    W, A = [], []
+
+    def add(d):
+        a = support(t1, s1, p1, R1, d)
+        W.append(a - support(t2, s2, p2, R2, -d))
+        A.append(a)
+        return len(W) - 1
+
+    ex = np.array([1.0, 0.0, 0.0])
+    add(ex); add(-ex)
+    u = W[1] - W[0]
+    uu = u @ u
+    k = int(np.argmin(np.abs(u)))
+    e = np.zeros(3); e[k] = 1.0
+    v = e - ((e @ u) / uu) * u if uu > 0.0 else e
+    v = v / np.sqrt(v @ v)
+    add(v)
+    if abs((W[2] - W[0]) @ v) <= 1e-12 * max(1.0, np.sqrt(uu)):      # nothing on that side of the line: the other side
+        W.pop(); A.pop(); add(-v)
+    n = np.cross(W[1] - W[0], W[2] - W[0])
+    n = n / max(np.sqrt(n @ n), 1e-300)
+    add(n); add(-n)
+    c = (W[0] + W[1] + W[2] + W[3] + W[4]) / 5.0                     # an interior point: orientation of the first faces
+    faces = []
+    for (i, j, k) in ((0, 1, 3), (1, 2, 3), (2, 0, 3), (0, 1, 4), (1, 2, 4), (2, 0, 4)):
+        f = _epa_face(W, i, j, k)
+        if f[3] @ (W[i] - c) < 0.0:
+            f = _epa_face(W, i, k, j)
+        faces.append(f)                                              # slots 0..5; a removed face leaves its slot free (None)
+    while True:
+        alive = [s for s, f in enumerate(faces) if f is not None]
+        best = min(alive, key=lambda s: (faces[s][4], s))            # nearest plane, lowest slot on ties
+        i, j, k, nb, off = faces[best]
+        if len(W) >= EPA_MAXV:
             break
-        ok = False
-        for _ in range(PEN_MAX_HALVINGS):
-            dn = d - (step / max(np.sqrt(s @ s), 1e-300)) * g
-            dn = dn / np.sqrt(dn @ dn)
-            hn, sn = h_and_s(dn)
-            if hn < h:
-                d, h, s, ok = dn, hn, sn, True
-                step = min(step * 1.5, 4.0)
-                break
-            step *= 0.5
-        if not ok:
+        ip = add(nb)
+        gap = nb @ W[ip] - off
+        if gap <= EPA_TOL * max(1.0, abs(off)):                      # the face is (within the gap) a face of D itself
+            W.pop(); A.pop()
             break
-    return h, d
+        p = W[ip]
+        vis = [s for s in alive if faces[s][3] @ p - faces[s][4] > 1e-13 * max(1.0, abs(faces[s][4])) or s == best]
+        visset = set(vis)
+        owner = {}
+        for s in alive:
+            f = faces[s]
+            for e in ((f[0], f[1]), (f[1], f[2]), (f[2], f[0])):
+                owner[e] = s in visset
+        horizon = [e for s in vis for e in ((faces[s][0], faces[s][1]), (faces[s][1], faces[s][2]), (faces[s][2], faces[s][0]))
+                   if not owner.get((e[1], e[0]), False)]            # in (slot, edge) order
+        if len(faces) - len(vis) + len(horizon) > EPA_MAXF:          # out of slots: the nearest face so far is the answer
+            W.pop(); A.pop()
+            break
+        free = list(vis) + list(range(len(faces), len(faces) + max(0, len(horizon) - len(vis))))
+        for s in vis:
+            faces[s] = None
+        for q, (a_, b_) in enumerate(horizon):                       # new face q takes the q-th free slot
+            while len(faces) <= free[q]:
+                faces.append(None)
+            faces[free[q]] = _epa_face(W, a_, b_, ip)
+    alive = [s for s, f in enumerate(faces) if f is not None]
+    best = min(alive, key=lambda s: (faces[s][4], s))
+    i, j, k, nb, off = faces[best]
+    idx, lam = _closest_triangle([W[i], W[j], W[k]])                 # the face's point nearest to the origin, barycentric
+    g = (i, j, k)
+    a = sum(l * A[g[t]] for t, l in zip(idx, lam))
+    w = sum(l * W[g[t]] for t, l in zip(idx, lam))
+    # (geom 2 translated by t overlaps geom 1 iff t ∈ D: the shortest separating translation of geom 2 is depth·n, n the
+    #  outward normal of the nearest face — mj_geomDistance's direction "from 1 to 2")
+    depth = float(nb @ support(t1, s1, p1, R1, nb) - nb @ support(t2, s2, p2, R2, -nb))
+    return depth + r1 + r2, nb, a, a - w
 
 
 def convex_distance(t1, s1, p1, R1, t2, s2, p2, R2, margin):
@@ -226,7 +281,6 @@ def convex_distance(t1, s1, p1, R1, t2, s2, p2, R2, margin):
         n = (pb - pa) / dist_c
         a, b = pa + r1 * n, pb - r2 * n
         return dist, 0.5 * (a + b), n
-    depth, n = penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2)
-    a = support(t1, s1, p1, R1, n) + r1 * n           # deepest point of 1 along n
-    b = support(t2, s2, p2, R2, -n) - r2 * n          # deepest point of 2 against n
+    depth, n, a, b = penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2)
+    a, b = a + r1 * n, b - r2 * n                     # the deepest points: a − b = depth·n
     return -depth, 0.5 * (a + b), n

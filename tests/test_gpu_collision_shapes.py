@@ -276,6 +276,7 @@ def test_general_convex_pairs_against_the_oracle():
                                            minimum_distance_from_collisions=0.01)
     active = np.zeros(9, dtype=int)
     apart = np.zeros(9, dtype=int)
+    worst_near, n_near = np.zeros(9), np.zeros(9, dtype=int)
     for i in range(B):
         o = oik.Configuration(m, q[i])
         G_ref, h_ref = oik.limit_inequalities(o, spec, dt)
@@ -287,8 +288,19 @@ def test_general_convex_pairs_against_the_oracle():
         np.testing.assert_allclose(h[i][sep], h_ref[sep], rtol=0, atol=1e-9 * max(1.0, np.abs(h_ref[sep]).max(initial=0.0)))
         np.testing.assert_allclose(G[i][sep], G_ref[sep], atol=1e-5)
         np.testing.assert_array_equal(h[i][fin & ~sep], h_ref[fin & ~sep])      # closer than d_min (or overlapping): h = relaxation
+        # ... and their rows: the direction of an OVERLAPPING pair is the smallest separating translation (expanding polytope,
+        # round 4).  Pairs of a cylinder / box / capsule converge to a face of the Minkowski difference; an ellipsoid against a
+        # curved shape stops at the vertex budget with the direction good to ~1e-2 (oracle/gjk.py EPA_MAXV), path-dependent
+        near = fin & ~sep
+        worst_near = np.maximum(worst_near, np.where(near, np.abs(G[i] - G_ref).max(axis=1), 0.0))
+        n_near += near
     print("active / separated instances per pair:", list(zip([tuple(p) for p in col.geom_id_pairs], active, apart)))
     assert (apart > 0).all(), apart
+    types = [(int(m.geom_type[a]), int(m.geom_type[b])) for a, b in col.geom_id_pairs]
+    print("rows of pairs inside d_min / overlapping: count, max |dG| per pair:", list(zip(types, n_near, worst_near)))
+    assert n_near.sum() > 0
+    for (ta, tb), w in zip(types, worst_near):
+        assert w < (2e-5 if 4 not in (ta, tb) else 5e-2), (ta, tb, w)      # (4 = ellipsoid)
     # the solve on instances that start outside d_min for every pair (the lean collision variant with the convex routine)
     q = _rand_q(m, rng, 4096)
     G, h = col.compute_qp_inequalities(mink.Configuration(m, q), dt)
