@@ -380,6 +380,14 @@ int32_t mkh_integrate(MkhModel *model, int32_t B, const double *q, const double 
 int32_t mkh_lie_eval(int32_t device, int32_t op, int32_t n, const double *a, const double *b, double *out,
                      int32_t flags, void *hip_stream);
 
+/* mujoco.mj_geomDistance(model, data, geom1, geom2, distmax, fromto) — the third-party routine behind every row of
+ * CollisionAvoidanceLimit (mink/limits/collision_avoidance_limit.py:214-229) — element-wise on the device routines of the
+ * collision phase (primitive geoms; parity tests only, host pointers).  pairs (n, 22): per pair two records of
+ * (mjtGeom type, size[3], world position[3], world quaternion wxyz[4]); dist_out (n): the signed distance, distmax when
+ * nothing is closer, NaN for a pair of types without a routine; fromto_out (n, 6): the connecting segment, geom1 → geom2. */
+int32_t mkh_geom_distance_eval(int32_t device, int32_t n, const double *pairs, double distmax, double *dist_out,
+                               double *fromto_out, void *hip_stream);
+
 /* Launch geometry of the most recent solve / eval on this problem (the kernel variant depends on the call; see
  * mkh_problem_last_kernel); before any launch, that of the lean direct variant for a batch of B.  For benchmarks
  * and occupancy reports. */

@@ -163,6 +163,8 @@ def lib() -> C.CDLL:
                                 C.c_int32, C.c_void_p]
     L.mkh_lie_eval.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.mkh_lie_eval.restype = C.c_int32
+    L.mkh_geom_distance_eval.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mkh_geom_distance_eval.restype = C.c_int32
     L.mkh_problem_launch_info.argtypes = [C.c_void_p, C.c_int32] + [C.POINTER(C.c_int32)] * 4
     for f in ("mkh_model_create", "mkh_problem_create", "mkh_problem_num_task_rows",
               "mkh_problem_num_collision_pairs", "mkh_solve", "mkh_eval", "mkh_integrate",
@@ -177,6 +179,7 @@ EXPORTED_SYMBOLS = (
     "mkh_problem_create", "mkh_problem_destroy", "mkh_problem_num_task_rows",
     "mkh_problem_num_collision_pairs", "mkh_solve", "mkh_eval", "mkh_integrate", "mkh_problem_launch_info",
     "mkh_solve_steps", "mkh_problem_last_kernel", "mkh_lie_eval", "mkh_solve_dense", "mkh_solve_until",
+    "mkh_geom_distance_eval",
 )
 
 LIE_OPS = {"se3_log": (0, 7, 0, (6,)), "se3_jlog": (1, 7, 0, (6, 6)), "se3_ljacinv": (2, 6, 0, (6, 6)),
@@ -196,6 +199,20 @@ def lie_eval(op: str, a, b=None, device: int = 0) -> np.ndarray:
     out = np.empty((n,) + oshape)
     _check(lib().mkh_lie_eval(int(device), code, n, a.ctypes.data, b.ctypes.data if nb else None, out.ctypes.data, 0, None))
     return out
+
+
+def geom_distance_eval(type1, size1, pos1, quat1, type2, size2, pos2, quat2, distmax: float, device: int = 0):
+    """mj_geomDistance of n primitive geom pairs on the device routines of the collision phase (mkh_geom_distance_eval):
+    types (n,), sizes (n, 3), world positions (n, 3), world quaternions wxyz (n, 4) → dist (n,), fromto (n, 6)."""
+    t1 = _f64(type1).reshape(-1, 1)
+    n = len(t1)
+    rec = np.concatenate([t1, _f64(size1).reshape(n, 3), _f64(pos1).reshape(n, 3), _f64(quat1).reshape(n, 4),
+                          _f64(type2).reshape(n, 1), _f64(size2).reshape(n, 3), _f64(pos2).reshape(n, 3),
+                          _f64(quat2).reshape(n, 4)], axis=1)
+    rec = np.ascontiguousarray(rec)
+    dist, fromto = np.empty(n), np.empty((n, 6))
+    _check(lib().mkh_geom_distance_eval(int(device), n, rec.ctypes.data, float(distmax), dist.ctypes.data, fromto.ctypes.data, None))
+    return dist, fromto
 
 
 def _check(rc: int) -> None:

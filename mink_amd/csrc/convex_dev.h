@@ -252,7 +252,7 @@ __device__ __forceinline__ bool cvx_gjk(const ConvexGeom& g1, const ConvexGeom& 
 // returns for such a pair approximates this quantity (libccd MPR to 1e-6 in mujoco 3.1.6; its native GJK + EPA later).
 // Arguments arrive wave-uniform; every lane executes every statement (no divergent call).
 constexpr int kEpaMaxV = 48, kEpaMaxF = 92;
-constexpr double kEpaTol = 1e-12;
+constexpr double kEpaTol = 1e-11;
 constexpr int kEpaOffV = 0, kEpaOffF = 6 * kEpaMaxV, kEpaOffI = kEpaOffF + 4 * kEpaMaxF, kEpaOffE = kEpaOffI + (kEpaMaxF + 1) / 2,
               kEpaOffL = kEpaOffE + kEpaMaxV, kEpaWsDoubles = kEpaOffL + (kEpaMaxF + 7) / 8 + 1;
 struct CvxEpa { double depth; V3 n, a, b; };
@@ -323,6 +323,10 @@ __device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom
   }
   wave_sync();
   int nslots = 6, best = 0;
+  bool intact = true;
+  int ans_id = -1;                                                   // the answer so far: vertices, normal, offset of the nearest face
+  V3 ans_n{1.0, 0.0, 0.0};
+  double ans_off = 0.0;
 #pragma nounroll
   for (;;) {
     // the face whose plane is nearest to the origin (signed), lowest slot on ties
@@ -334,6 +338,10 @@ __device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom
     best = (int)wave_min_u32((my_slot != 0xffffffffu && my_off == mo) ? my_slot : 0xffffffffu);
     const V3 nb{F[4 * best], F[4 * best + 1], F[4 * best + 2]};
     const double off = F[4 * best + 3];
+    // the nearest plane can only move outwards as the polytope grows; when it jumps back in, a sliver face (three nearly
+    // collinear support points near convergence: a normal without digits) has been created — the previous face stands
+    if (ans_id >= 0 && ans_off >= 0.0 && off < ans_off - 1e-9 * fmax(1.0, ans_off)) { intact = false; break; }
+    ans_id = Fi[best]; ans_n = nb; ans_off = off;
     if (nvert >= kEpaMaxV) break;
     const int ip = nvert;
     const V3 p = add(nb);
@@ -398,8 +406,29 @@ __device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom
     wave_sync();
   }
   wave_sync();
-  const V3 nb{F[4 * best], F[4 * best + 1], F[4 * best + 2]};
-  const int id = Fi[best];
+  if (intact) {
+    // a face of D is usually covered by several coplanar triangles: of those in the answer's plane (offsets within 1e-9)
+    // the one NEAREST to the origin as a triangle — the one that holds the foot of the perpendicular — gives the witness
+    // points (a clamped foot on a neighbouring triangle would put them off the shapes)
+    const double thr = ans_off + 1e-9 * fmax(1.0, fabs(ans_off));
+    double my_d2 = kInf;
+    unsigned my_slot = 0xffffffffu;
+    for (int sl = lane; sl < nslots; sl += 64) {
+      const int fid = Fi[sl];
+      if (fid < 0 || !(F[4 * sl + 3] <= thr)) continue;
+      const V3 a_ = vtx(fid & 255), b_ = vtx((fid >> 8) & 255), c_ = vtx((fid >> 16) & 255);
+      const CvxW3 t = cvx_closest_triangle(a_, b_, c_);
+      const V3 w = t.l0 * a_ + (t.l1 * b_ + t.l2 * c_);
+      const double d2 = dot(w, w);
+      if (d2 < my_d2 || my_slot == 0xffffffffu) { my_d2 = d2; my_slot = (unsigned)sl; }
+    }
+    const double md = wave_min_f64(my_d2);
+    const int win = (int)wave_min_u32((my_slot != 0xffffffffu && my_d2 == md) ? my_slot : 0xffffffffu);
+    ans_id = Fi[win];
+    ans_n = V3{F[4 * win], F[4 * win + 1], F[4 * win + 2]};
+  }
+  const V3 nb = ans_n;
+  const int id = ans_id;
   const int i = id & 255, j = (id >> 8) & 255, k = (id >> 16) & 255;
   const V3 wi = vtx(i), wj = vtx(j), wk = vtx(k);
   const CvxW3 t = cvx_closest_triangle(wi, wj, wk);                          // the face's point nearest to the origin, barycentric

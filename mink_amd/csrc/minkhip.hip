@@ -1591,3 +1591,69 @@ extern "C" int32_t mkh_lie_eval(int32_t device, int32_t op, int32_t n, const dou
   if (e != hipSuccess) return fail(MKH_E_HIP, "lie_eval: %s", hipGetErrorString(e));
   return MKH_OK;
 }
+
+// ------------------------------------------------------------------ mkh_geom_distance_eval
+namespace {
+// One geom pair per lane through the device's geom_distance (collide_dev.h / convex_dev.h) — the routine behind the
+// collision rows — with the wave-level second half for general convex pairs whose cores overlap.  A pair is 22 doubles: two
+// records of (type, size[3], pos[3], quat[4] wxyz).
+__global__ __launch_bounds__(64) void geom_distance_eval_kernel(int n, const double* __restrict__ g, double distmax,
+                                                                double* __restrict__ dist_out, double* __restrict__ fromto_out) {
+  __shared__ __attribute__((aligned(16))) double ws[kEpaWsDoubles];
+  const int lane = lane_id();
+  const int base = blockIdx.x * 64;
+  auto load = [&](int i, int& t1, V3& s1, V3& p1, Q4& q1, int& t2, V3& s2, V3& p2, Q4& q2) {
+    const double* r = g + 22 * (size_t)i;
+    t1 = (int)r[0]; s1 = {r[1], r[2], r[3]}; p1 = {r[4], r[5], r[6]}; q1 = {r[7], r[8], r[9], r[10]};
+    t2 = (int)r[11]; s2 = {r[12], r[13], r[14]}; p2 = {r[15], r[16], r[17]}; q2 = {r[18], r[19], r[20], r[21]};
+  };
+  const int i = base + lane;
+  const bool want = i < n;
+  double dist = distmax;
+  V3 from{0, 0, 0}, to{0, 0, 0};
+  bool need_epa = false, known = true;
+  if (want) {
+    int t1, t2; V3 s1, p1, s2, p2; Q4 q1, q2;
+    load(i, t1, s1, p1, q1, t2, s2, p2, q2);
+    known = geom_distance<false, true>(t1, s1, p1, q1, t2, s2, p2, q2, distmax, dist, from, to, nullptr, 0, nullptr, 0, &need_epa);
+  }
+  for (unsigned long long em = __ballot(want && need_epa); em; em &= em - 1) {
+    const int l = (int)__builtin_ctzll(em);
+    int t1, t2; V3 s1, p1, s2, p2; Q4 q1, q2;
+    load(base + l, t1, s1, p1, q1, t2, s2, p2, q2);
+    double d_e; V3 f_e, t_e;
+    geom_overlap_distance(t1, s1, p1, q1, t2, s2, p2, q2, d_e, f_e, t_e, nullptr, 0, nullptr, 0, ws);
+    if (lane == l) { dist = d_e; from = f_e; to = t_e; }
+  }
+  if (want) {
+    dist_out[i] = known ? dist : __builtin_nan("");
+    double* o = fromto_out + 6 * (size_t)i;
+    o[0] = from.x; o[1] = from.y; o[2] = from.z; o[3] = to.x; o[4] = to.y; o[5] = to.z;
+  }
+}
+}  // namespace
+
+extern "C" int32_t mkh_geom_distance_eval(int32_t device, int32_t n, const double* pairs, double distmax, double* dist_out,
+                                          double* fromto_out, void* hip_stream) {
+  if (n < 1 || !pairs || !dist_out || !fromto_out) return fail(MKH_E_INVALID, "mkh_geom_distance_eval: null argument or n < 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MKH_E_NOGPU, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(MKH_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+  HIP_OK(hipSetDevice(device));
+  hipStream_t stream = (hipStream_t)hip_stream;
+  double *dg = nullptr, *dd = nullptr, *df = nullptr;
+  hipError_t e = hipMalloc((void**)&dg, (size_t)n * 22 * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&dd, (size_t)n * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&df, (size_t)n * 48);
+  if (e == hipSuccess) e = hipMemcpyAsync(dg, pairs, (size_t)n * 22 * 8, hipMemcpyHostToDevice, stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(geom_distance_eval_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, n, dg, distmax, dd, df);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(dist_out, dd, (size_t)n * 8, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(fromto_out, df, (size_t)n * 48, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(dg); (void)hipFree(dd); (void)hipFree(df);
+  if (e != hipSuccess) return fail(MKH_E_HIP, "geom_distance_eval: %s", hipGetErrorString(e));
+  return MKH_OK;
+}

@@ -172,7 +172,7 @@ def gjk_cores(t1, s1, p1, R1, t2, s2, p2, R2):
     return float(np.sqrt(v @ v)), pa, pb, False
 
 
-EPA_MAXV, EPA_MAXF, EPA_TOL = 48, 92, 1e-12        # vertices, faces (= 2·V − 4), relative gap at which a face counts as final
+EPA_MAXV, EPA_MAXF, EPA_TOL = 48, 92, 1e-11        # vertices, faces (= 2·V − 4), relative gap at which a face counts as final
 
 
 def _epa_face(W, i, j, k):
@@ -225,10 +225,17 @@ def penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2):
         if f[3] @ (W[i] - c) < 0.0:
             f = _epa_face(W, i, k, j)
         faces.append(f)                                              # slots 0..5; a removed face leaves its slot free (None)
+    answer, intact = None, True
     while True:
         alive = [s for s, f in enumerate(faces) if f is not None]
         best = min(alive, key=lambda s: (faces[s][4], s))            # nearest plane, lowest slot on ties
         i, j, k, nb, off = faces[best]
+        # the nearest plane can only move outwards as the polytope grows; when it jumps back in, a sliver face (three nearly
+        # collinear support points near convergence: a normal without digits) has been created — the previous face stands
+        if answer is not None and answer[4] >= 0.0 and off < answer[4] - 1e-9 * max(1.0, answer[4]):
+            intact = False
+            break
+        answer = (i, j, k, nb, off)
         if len(W) >= EPA_MAXV:
             break
         ip = add(nb)
@@ -256,9 +263,20 @@ def penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2):
             while len(faces) <= free[q]:
                 faces.append(None)
             faces[free[q]] = _epa_face(W, a_, b_, ip)
-    alive = [s for s, f in enumerate(faces) if f is not None]
-    best = min(alive, key=lambda s: (faces[s][4], s))
-    i, j, k, nb, off = faces[best]
+    if intact:
+        # a face of D is usually covered by several coplanar triangles: of those in the answer's plane (offsets within 1e-9)
+        # the one NEAREST to the origin as a triangle — the one that holds the foot of the perpendicular — gives the witness
+        # points (a clamped foot on a neighbouring triangle would put them off the shapes)
+        thr = answer[4] + 1e-9 * max(1.0, abs(answer[4]))
+        cand = []
+        for s, f in enumerate(faces):
+            if f is None or not f[4] <= thr:
+                continue
+            idx, lam = _closest_triangle([W[f[0]], W[f[1]], W[f[2]]])
+            w = sum(l * W[(f[0], f[1], f[2])[t]] for t, l in zip(idx, lam))
+            cand.append((float(w @ w), s))
+        answer = faces[min(cand)[1]]
+    i, j, k, nb, off = answer
     idx, lam = _closest_triangle([W[i], W[j], W[k]])                 # the face's point nearest to the origin, barycentric
     g = (i, j, k)
     a = sum(l * A[g[t]] for t, l in zip(idx, lam))
