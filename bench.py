@@ -70,6 +70,53 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
+def _sha256(path: str):
+    import hashlib
+    try:
+        h = hashlib.sha256()
+        with open(path, "rb") as fh:
+            for blk in iter(lambda: fh.read(1 << 20), b""):
+                h.update(blk)
+        return h.hexdigest()
+    except OSError:
+        return None
+
+
+def _resource_table():
+    try:
+        with open(os.path.join(REPO, "mink_amd", "kernel_resources.json")) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return {}
+
+
+def kernel_keys(kernel: str) -> list:
+    """Names of every launch behind a `last_kernel()` string, as keyed in mink_amd/kernel_resources.json: the tight-rows call
+    `ik_solve_kernel_48_72+redo_64` is two launches (the 48-row build and the full-row redo of the same feature set)."""
+    if kernel.startswith("ik_quad_kernel"):
+        return [f"ik_quad_kernel<{16 if '_16' in kernel else 8},{1 if kernel.endswith('_loop') else 0}>"]
+    if kernel.startswith("ik_lane_kernel_"):
+        return [f"ik_lane_kernel<{kernel.split('_')[3]},{1 if kernel.endswith('_loop') else 0}>"]
+    main, _, redo = kernel.partition("+redo_")
+    keys = [main]
+    if redo:
+        feat = main.split("_")[4]
+        keys.append(f"ik_solve_kernel_{redo}_{feat}")
+    return keys
+
+
+_LIB_SHA = {}
+
+
+def loaded_library_sha256():
+    """sha256 of the libminkhip.so THIS process loaded."""
+    from mink_amd import _native as nat
+    path = getattr(nat.lib(), "_name", None)
+    if path not in _LIB_SHA:
+        _LIB_SHA[path] = _sha256(path) if path else None
+    return _LIB_SHA[path]
+
+
 def _newest_pmc(config: str, B: int):
     """Newest committed PMC summary of this workload (tools/profile.sh → profiles/<tag>_<config>_b<B>_pmc.json;
     round-1 files of the headline config are named <tag>_g1_b65536_pmc.json)."""
@@ -84,29 +131,49 @@ def _newest_pmc(config: str, B: int):
     return None, None
 
 
-def measured_traffic(config: str, B: int):
-    """HBM bytes per launch of the IK kernel from the PMC passes (FETCH_SIZE + WRITE_SIZE, separate
-    rocprofv3 --pmc runs, calibrated on a known-size copy: tools/profile.sh, tools/rocprof_summary.py).
-    Counters cannot be read from inside a timed run, so this comes from the newest committed summary of the
-    same workload; None when no calibrated summary exists."""
+def profile_check(js, src, kernel: str) -> dict:
+    """Is the committed counter summary a profile of what just ran?  Counters cannot be read inside a timed run, so `traffic`
+    and the issue-slot shares come from profiles/ — but only from a summary stamped (tools/rocprof_summary.py "provenance") with
+    the code objects of exactly the kernels this run launched; anything else is reported as stale and NOT replayed."""
+    keys = kernel_keys(kernel)
+    table = _resource_table()
+    now = {k: (table.get(k) or {}).get("code_sha256") for k in keys}
+    prov = (js or {}).get("provenance") or {}
+    then = prov.get("kernel_code_sha256") or {}
+    kernels_match = bool(js) and sorted(prov.get("kernels") or []) == sorted(keys)
+    code_match = kernels_match and all(now[k] is not None and now[k] == then.get(k) for k in keys)
+    lib_now = loaded_library_sha256()
+    return {"source": src, "kernels_ran": keys, "kernels_profiled": prov.get("kernels"),
+            "kernel_code_sha256": now, "profile_kernel_code_sha256": then or None,
+            "library_sha256": lib_now, "profile_library_sha256": prov.get("library_sha256"),
+            "library_match": lib_now is not None and lib_now == prov.get("library_sha256"),
+            "profile_git_head": prov.get("git_head"),
+            "kernel_code_match": code_match, "stale_profile": not code_match}
+
+
+def measured_traffic(config: str, B: int, kernel: str):
+    """HBM bytes per solve call from the PMC passes (FETCH_SIZE + WRITE_SIZE of EVERY launch of the call — a tight-rows solve
+    is two —, separate rocprofv3 --pmc runs, calibrated on a known-size copy: tools/profile.sh, tools/rocprof_summary.py), from
+    the newest committed summary of the same workload IF it is a profile of the code that just ran (profile_check).
+    Returns (bytes or None, check)."""
     js, src = _newest_pmc(config, B)
+    chk = profile_check(js, src, kernel)
     hbm = (js or {}).get("hbm", {})
-    return (hbm["traffic_bytes_per_launch"], src) if "traffic_bytes_per_launch" in hbm else None
+    ok = not chk["stale_profile"] and "traffic_bytes_per_launch" in hbm
+    return (hbm["traffic_bytes_per_launch"] if ok else None), chk
 
 
-def measured_valu_issue(config: str, B: int, waves_per_simd: int):
+def measured_valu_issue(config: str, B: int, waves_per_simd: float, kernel: str):
     """What the kernel runs out of, from the same committed PMC summary as `traffic` (tools/profile.sh →
     tools/rocprof_summary.py "derived"): VALU issue = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of a wave's cycles in which
     it issues a VALU instruction) × the waves that share a SIMD; LDS pipe = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES (the CU's one
-    LDS index unit, bank-conflict replays included).  None without a summary."""
+    LDS index unit, bank-conflict replays included).  None without a summary of the code that ran (profile_check)."""
     js, src = _newest_pmc(config, B)
+    if profile_check(js, src, kernel)["stale_profile"]:
+        return None
     try:
-        k = js["ik_solve_kernel"]
         d = js.get("derived") or {}
-        per_wave = d.get("valu_active_per_wave_cycle")
-        if per_wave is None:                                 # summaries of rounds 1 and 2
-            skip = 0 if "solve_kernel" in js else 1          # (round-1 summaries list the FK-only setup launch first)
-            per_wave = sum(k["SQ_ACTIVE_INST_VALU"]["per_dispatch"][skip:]) / sum(k["SQ_WAVE_CYCLES"]["per_dispatch"][skip:])
+        per_wave = d["valu_active_per_wave_cycle"]
         out = {"valu_active_share_of_wave_cycles": per_wave, "waves_per_simd": waves_per_simd,
                "simd_issue_slots_used": waves_per_simd * per_wave, "source": src}
         for key in ("lds_pipe_busy_per_cu_cycle", "lds_bank_conflict_per_lds_inst_active", "lds_bank_conflict_per_cu_cycle",
@@ -139,20 +206,9 @@ def binding_resource(valu):
 
 
 def kernel_resources(kernel: str):
-    """Registers / spills / scratch of a kernel as the compiler reported them when the library was built
+    """Registers / spills / scratch of the kernel that does the work as the compiler reported them when the library was built
     (mink_amd/kernel_resources.json, written by mink_amd/csrc/build.py)."""
-    try:
-        with open(os.path.join(REPO, "mink_amd", "kernel_resources.json")) as fh:
-            table = json.load(fh)
-    except (OSError, ValueError):
-        return None
-    key = kernel.split("+")[0]                       # ("…_48_72+redo_64": the tight-rows build does the work)
-    if kernel.startswith("ik_quad_kernel"):
-        key = f"ik_quad_kernel<{16 if '_16' in kernel else 8},{1 if kernel.endswith('_loop') else 0}>"
-    if kernel.startswith("ik_lane_kernel_"):
-        nv = kernel.split("_")[3]
-        key = f"ik_lane_kernel<{nv},{1 if kernel.endswith('_loop') else 0}>"
-    e = table.get(key)
+    e = _resource_table().get(kernel_keys(kernel)[0])
     if e is None:
         return None
     return {"vgprs": e.get("vgprs"), "vgpr_spills": e.get("vgpr_spills_with_callees"), "sgpr_spills": e.get("sgpr_spills_with_callees"),
@@ -200,14 +256,15 @@ def measure_side_config(name, dev, steps=20, warmup=3, batch=None, seed=2000):
     kernel = prob.last_kernel()
     bps = cfg["bytes_per_solve"]
     ach = bps * B / (kern_ms * 1e-3) / 1e9
-    traffic = measured_traffic(name, B)
+    traffic, chk = measured_traffic(name, B, kernel)
     res = kernel_resources(kernel) or {}
     out = {"name": name, "batch": B, "kernel": kernel, "value": B * steps / wall, "unit": "solves/s", "steps": steps,
            "kernel_ms": kern_ms, "kernel_ms_median": statistics.median(ms),
            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": bps * B,
-                        "traffic": traffic[0] if traffic else None, "traffic_source": traffic[1] if traffic else None},
-           "traffic_over_algorithmic": (traffic[0] / (bps * B)) if traffic else None,
+                        "traffic": traffic, "traffic_source": chk["source"], "stale_profile": chk["stale_profile"],
+                        "kernel_code_match": chk["kernel_code_match"], "library_match": chk["library_match"]},
+           "traffic_over_algorithmic": (traffic / (bps * B)) if traffic else None,
            "vgpr_spills": res.get("vgpr_spills"), "sgpr_spills": res.get("sgpr_spills"),
            "scratch_bytes_per_lane": res.get("scratch_bytes_per_lane"), "waves_per_simd": res.get("occupancy_waves_per_simd"),
            "failed_instances": int(((status & ~1) != 0).sum()),
@@ -266,18 +323,18 @@ def _oracle_specs(config, targets, posture_target, com_target):
 def cpu_baseline(config, q, targets, posture_target, com_target, budget_s=20.0):
     """Restated reference timed on the host cores over a bounded sample of the same workload: the plain-C
     port of the reference pipeline (oracle/c: dense H, c, G, h + Goldfarb–Idnani, like mink + MuJoCo +
-    quadprog) on all host threads.  Configs the C port does not cover (collision limits) and boxes where it
-    cannot be built use the numpy port on one thread."""
+    quadprog; contact rows of plane / sphere / capsule pairs since round 4: the Shadow config) on all host threads.  Boxes
+    where it cannot be built use the numpy port on one thread."""
     com0 = None if com_target is None else com_target[0, 0]
     try:
         m, tasks, limits, dt, damping = _oracle_specs(config, targets[0], posture_target[0], com0)
         from oracle import cport
         prob = cport.CProblem(m, tasks, limits)
         threads = usable_cpus()
-        ct = None if com0 is None else com0[None, :]
+        ct = lambda n: None if com_target is None else com_target[:n]          # per-instance CoM targets (B, 1, 3)
         n0 = min(len(q), 512 * threads)
         t0 = time.perf_counter()
-        prob.solve_batch(q[:n0], targets[:n0], posture_target, dt, damping, com_target=ct, nthreads=threads)
+        prob.solve_batch(q[:n0], targets[:n0], posture_target, dt, damping, com_target=ct(n0), nthreads=threads)
         rate = n0 / (time.perf_counter() - t0)
         total = max(n0, rate * budget_s / threads)        # ≈ budget_s core-seconds of CPU work in all
         n = int(min(len(q), total))
@@ -285,7 +342,7 @@ def cpu_baseline(config, q, targets, posture_target, com_target, budget_s=20.0):
         t0 = time.perf_counter()
         bad = 0
         for _ in range(reps):
-            _, st = prob.solve_batch(q[:n], targets[:n], posture_target, dt, damping, com_target=ct, nthreads=threads)
+            _, st = prob.solve_batch(q[:n], targets[:n], posture_target, dt, damping, com_target=ct(n), nthreads=threads)
             bad += int((st != 0).sum())
         el = time.perf_counter() - t0
         return {"value": n * reps / el, "unit": "solves/s", "cores": threads, "kind": "port",
@@ -400,6 +457,20 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    # what the process group really is: its own world size and, per rank, the device it computes on (all-gathered), so that a
+    # line for N GPUs shows N ranks on N distinct devices
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "local_rank": local_rank, "device_index": dev.index, "name": props.name,
+          "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
+                                               getattr(props, "pci_device_id", 0)),
+          "uuid": str(getattr(props, "uuid", "")), "host": socket.gethostname()}
+    devices = [me]
+    pg_world = 1
+    if dist is not None:
+        pg_world = dist.get_world_size()
+        devices = [None] * pg_world
+        dist.all_gather_object(devices, me)
+
     cfg = workloads.BENCH_CONFIGS[args.config]
     B = args.batch or cfg["batch"]
     model = workloads.load_bench_robot(args.config)
@@ -504,18 +575,15 @@ def main():
         ach = bps * B / (kern_ms * 1e-3) / 1e9
         info = prob.launch_info(B)
         kernel = prob.last_kernel()
-        nt = info["tableau_rows"]
-        waves_per_simd = 4 if nt <= 8 else (3 if (nt <= 24 or kernel.endswith("_w3")) else 2)   # (_w3: 168-register map)
-        if kernel.startswith("ik_lane_kernel"):
-            waves_per_simd = 2                            # lane_kernel.h: amdgpu_waves_per_eu(2, 2)
-        # (a launch with fewer wavefronts than the register map allows — the row kernel at 4 096 instances is one wavefront
-        #  per SIMD — cannot use more issue slots than it has wavefronts)
-        waves_per_simd = min(waves_per_simd, max(1.0, info["grid"] / float(N_SIMDS)))
-        traffic = measured_traffic(args.config, B)
-        valu = measured_valu_issue(args.config, B, waves_per_simd)
+        # resident wavefronts per SIMD: the compiler's occupancy of the kernel that ran (kernel_resources.json), bounded by the
+        # wavefronts the launch has (the row kernel at 4 096 instances is ONE wavefront per SIMD)
+        occ = (kernel_resources(kernel) or {}).get("occupancy_waves_per_simd") or 1
+        waves_per_simd = min(float(occ), max(1.0, info["grid"] / float(N_SIMDS)))
+        traffic, chk = measured_traffic(args.config, B, kernel)
+        valu = measured_valu_issue(args.config, B, waves_per_simd, kernel)
         roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "traffic": traffic[0] if traffic else None,
-                "traffic_source": traffic[1] if traffic else None,
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": chk["source"], "stale_profile": chk["stale_profile"], "profile_check": chk,
                 "kernel": kernel, "kernel_ms": kern_ms, "kernel_ms_median": kern_ms_median,
                 "algorithmic_bytes_per_solve": bps, "algorithmic_bytes_per_launch": bps * B,
                 # what the kernel really runs out of (PMC: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x resident waves
@@ -552,6 +620,9 @@ def main():
             "config": {"workload": cfg["workload"], "name": args.config,
                        "batch_per_gpu": B, "global_batch": world * B,
                        "parallelism": f"batch-sharded x{world}, no data-path collective",
+                       "world_size": pg_world, "backend": (dist.get_backend() if dist is not None else None),
+                       "devices": devices,
+                       "distinct_devices": len({(d["host"], d["pci_bus_id"], d["uuid"]) for d in devices}),
                        "launch": info, "failed_instances": n_bad},
             "roofline": roof,
         }

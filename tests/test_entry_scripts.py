@@ -69,10 +69,43 @@ def test_bench_helpers():
     assert workloads.BENCH_CONFIGS["shadow_c4"]["bytes_per_solve"] == 668
     assert b.issued_flop_per_solve("ik_solve_kernel_62_32_r44") > b.issued_flop_per_solve("ik_solve_kernel_8_0") > 0
     assert 1 <= b.usable_cpus() <= (os.cpu_count() or 1)
-    t = b.measured_traffic("g1_c3", 65536)
-    assert t is None or t[0] > 0
-    assert b.measured_traffic("g1_c3", 12345) is None
     assert b._free_port() > 0
+    assert b.kernel_keys("ik_solve_kernel_48_72+redo_64") == ["ik_solve_kernel_48_72", "ik_solve_kernel_64_72"]
+    assert b.kernel_keys("ik_quad_kernel") == ["ik_quad_kernel<8,0>"] and b.kernel_keys("ik_lane_kernel_6") == ["ik_lane_kernel<6,0>"]
+
+
+def test_counters_are_only_replayed_from_a_profile_of_the_code_that_ran(monkeypatch, tmp_path):
+    """`roofline.traffic` / `valu_issue_view` come from profiles/ (counters cannot be read inside a timed run): a summary is
+    used only when its provenance stamp (tools/rocprof_summary.py) names the kernels of this run with the sha256 of the
+    code objects in the library now loaded (mink_amd/kernel_resources.json); anything else → None + stale_profile."""
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(REPO, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    table = b._resource_table()
+    k = "ik_solve_kernel_44_32_r44_w3"
+    assert table[k]["code_sha256"]
+    monkeypatch.setattr(b, "REPO", str(tmp_path))
+    monkeypatch.setattr(b, "_resource_table", lambda: table)
+    (tmp_path / "profiles").mkdir()
+    summ = {"hbm": {"traffic_bytes_per_launch": 64.7e6}, "derived": {"valu_active_per_wave_cycle": 0.25},
+            "provenance": {"kernels": [k], "kernel_code_sha256": {k: table[k]["code_sha256"]}, "library_sha256": "x", "git_head": "y"}}
+    path = tmp_path / "profiles" / "r99_g1_c3_b65536_pmc.json"
+    path.write_text(json.dumps(summ))
+    t, chk = b.measured_traffic("g1_c3", 65536, k)
+    assert t == 64.7e6 and chk["kernel_code_match"] and not chk["stale_profile"]
+    assert b.measured_valu_issue("g1_c3", 65536, 3.0, k)["simd_issue_slots_used"] == 0.75
+    # another kernel ran than the one profiled / the kernel was rebuilt since / a summary without a stamp (rounds 1-3)
+    t, chk = b.measured_traffic("g1_c3", 65536, "ik_solve_kernel_44_32_r44")
+    assert t is None and chk["stale_profile"]
+    summ["provenance"]["kernel_code_sha256"][k] = "0" * 64
+    path.write_text(json.dumps(summ))
+    t, chk = b.measured_traffic("g1_c3", 65536, k)
+    assert t is None and chk["stale_profile"] and b.measured_valu_issue("g1_c3", 65536, 3.0, k) is None
+    del summ["provenance"]
+    path.write_text(json.dumps(summ))
+    assert b.measured_traffic("g1_c3", 65536, k)[0] is None
+    assert b.measured_traffic("g1_c3", 12345, k)[0] is None          # no summary of that batch at all
 
 
 def test_bench_refuses_wrong_world(monkeypatch):

@@ -31,6 +31,13 @@ def test_self_launched_two_rank_line():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["global_batch"] == 2 * 4096
     assert d["value"] > 0 and d["gather"]["value"] > 0 and d["gather"]["bytes_per_step_to_rank0"] == 4096 * 43 * 8
     assert "roofline" in d and d["scaling"] == "weak" and "cpu_baseline" not in d
+    # what the process group saw: its own world size and every rank's device (here: both ranks on device 0 — the line says so)
+    c = d["config"]
+    assert c["world_size"] == 2 and c["backend"] == "gloo" and [x["rank"] for x in c["devices"]] == [0, 1]
+    assert all(x["name"] and x["pci_bus_id"] for x in c["devices"]) and c["distinct_devices"] == 1
+    # the counters of the line are either a profile of the code that ran, or absent and flagged
+    rf = d["roofline"]
+    assert rf["stale_profile"] == (rf["traffic"] is None) and rf["profile_check"]["kernels_ran"]
 
 
 def test_two_gpu_line_is_refused_on_one_gpu():

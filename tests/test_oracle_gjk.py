@@ -203,3 +203,30 @@ def test_plane_mesh_is_the_lowest_hull_vertex():
         n = Rp[:, 2]
         heights = (p2 + hull @ R2.T - pp) @ n
         assert len(cons) == 1 and abs(cons[0][0] - heights.min()) < 1e-14
+
+
+def test_penetration_depth_is_the_global_minimum_over_directions():
+    """Overlapping shapes (expanding polytope, round 4): the reported depth is min over unit d of h₁(d) + h₂(−d) — no direction
+    of a dense grid on the sphere separates the shapes with a shorter translation, and the reported direction attains it."""
+    rng = np.random.default_rng(21)
+    N = 6000
+    k = np.arange(N) + 0.5
+    phi, th = np.arccos(1 - 2 * k / N), np.pi * (1 + 5 ** 0.5) * k
+    D = np.stack([np.cos(th) * np.sin(phi), np.sin(th) * np.sin(phi), np.cos(phi)], axis=1)
+    for t1, t2 in [(gjk.GEOM_CYLINDER, gjk.GEOM_BOX), (gjk.GEOM_CYLINDER, gjk.GEOM_CYLINDER), (gjk.GEOM_ELLIPSOID, gjk.GEOM_BOX),
+                   (gjk.GEOM_CAPSULE, gjk.GEOM_ELLIPSOID)]:
+        for _ in range(3):
+            s1, s2 = SIZES[t1](rng), SIZES[t2](rng)
+            p1 = rng.uniform(-0.1, 0.1, 3)
+            p2 = p1 + rng.uniform(-0.04, 0.04, 3)
+            R1, R2 = _rand_rot(rng), _rand_rot(rng)
+            dist, pos, n = gjk.convex_distance(t1, s1, p1, R1, t2, s2, p2, R2, 10.0)
+            assert dist < 0.0
+            r = gjk.core_radius(t1, s1) + gjk.core_radius(t2, s2)
+            h = lambda d: d @ (gjk.support(t1, s1, p1, R1, d) - gjk.support(t2, s2, p2, R2, -d)) + r
+            grid = min(h(d) for d in D)
+            assert -dist <= grid + 1e-9, ((t1, t2), -dist, grid)
+            assert abs(h(n) + dist) < 1e-9
+            # the witness points are that translation apart, along n
+            a, b = pos + 0.5 * dist * n, pos - 0.5 * dist * n
+            assert abs(np.linalg.norm(a - b) + dist) < 1e-12

@@ -10,10 +10,57 @@ HBM bytes per IK launch from FETCH_SIZE / WRITE_SIZE calibrated on that copy.
 """
 import csv
 import glob
+import hashlib
 import json
 import os
+import re
 import sys
 from collections import defaultdict
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short_kernel_name(profiler_name: str) -> str:
+    """rocprofv3's demangled kernel name → the key of mink_amd/kernel_resources.json (`ik_solve_kernel_44_32_r44_w3`,
+    `ik_quad_kernel<8,0>`, `ik_lane_kernel<6,1>`)."""
+    m = re.search(r"(ik_[a-z0-9_]+)(<[^>]*>)?", profiler_name)
+    if not m:
+        return profiler_name
+    name, targs = m.group(1), m.group(2)
+    if targs:
+        vals = [{"true": "1", "false": "0"}.get(t.strip(), t.strip()) for t in targs[1:-1].split(",")]
+        name += "<" + ",".join(vals) + ">"
+    return name
+
+
+def provenance(kernels: list) -> dict:
+    """What was profiled: sha256 of the libminkhip.so next to the package (the one the workload loads), the git HEAD it was
+    linked at (mink_amd/build_info.json, written by build.py — the GPU box has no .git) and, per kernel of the timed solve,
+    the sha256 of the kernel's code object (kernel_resources.json).  bench.py compares these with what IT loaded and ran."""
+    out = {"kernels": [short_kernel_name(k) for k in kernels]}
+    lib = os.path.join(REPO, "mink_amd", "libminkhip.so")
+    try:
+        h = hashlib.sha256()
+        with open(lib, "rb") as fh:
+            for blk in iter(lambda: fh.read(1 << 20), b""):
+                h.update(blk)
+        out["library_sha256"] = h.hexdigest()
+    except OSError:
+        out["library_sha256"] = None
+    try:
+        with open(os.path.join(REPO, "mink_amd", "build_info.json")) as fh:
+            info = json.load(fh)
+        out["git_head"], out["git_dirty_sources"] = info.get("git_head"), info.get("git_dirty_sources")
+        out["library_sha256_at_build"] = info.get("library_sha256")
+    except (OSError, ValueError):
+        out["git_head"] = None
+    try:
+        with open(os.path.join(REPO, "mink_amd", "kernel_resources.json")) as fh:
+            table = json.load(fh)
+        out["kernel_code_sha256"] = {k: (table.get(k) or {}).get("code_sha256") for k in out["kernels"]}
+    except (OSError, ValueError):
+        out["kernel_code_sha256"] = {}
+    return out
 
 COPY_BYTES = 64 * 1024 * 1024 * 8          # tools/pmc_workload.py: 512 MiB read and 512 MiB written
 
@@ -39,6 +86,7 @@ def pmc(out_path, dirs):
     launches of a tap variant before them (FK-only target generation, CoM targets: workloads.bench_batch) are listed
     under "setup_dispatches" and do not enter any per-launch figure."""
     ik, setup, copy, resources = defaultdict(list), defaultdict(list), defaultdict(list), {}
+    companions = defaultdict(lambda: defaultdict(list))      # other launches of one solve call (the redo launch of tight rows)
     solve_kernel = None
     for d in dirs:
         counters, res = read_counters(d)
@@ -46,8 +94,13 @@ def pmc(out_path, dirs):
         if iks:
             # (a tight-rows solve is two launches — the 48-row build and the full-row redo behind it, equally often: the one
             #  that does the work has the larger counters)
-            main = max(iks, key=lambda k: (max(len(per) for per in iks[k].values()), sum(sum(per.values()) for per in iks[k].values())))
+            count = lambda k: max(len(per) for per in iks[k].values())
+            main = max(iks, key=lambda k: (count(k), sum(sum(per.values()) for per in iks[k].values())))
             solve_kernel = main
+            for k in iks:
+                if k != main and count(k) == count(main):
+                    for c, per in iks[k].items():
+                        companions[k][c] += [per[i] for i in sorted(per)]
         for k, cs in counters.items():
             if k in iks:
                 resources[k] = res[k]
@@ -63,8 +116,12 @@ def pmc(out_path, dirs):
                     tgt[c] = [max(vals + tgt.get(c, []))]
                 else:
                     tgt[c] = tgt.get(c, []) + vals
+    solve_kernels = [solve_kernel] + sorted(companions) if solve_kernel else []
     summary = {"solve_kernel": solve_kernel,
+               "solve_kernels": solve_kernels,            # every launch of ONE solve call (main first)
+               "provenance": provenance(solve_kernels),
                "ik_solve_kernel": {c: {"per_dispatch": v} for c, v in sorted(ik.items())},
+               "companion_launches": {k: {c: {"per_dispatch": v} for c, v in sorted(cs.items())} for k, cs in companions.items()},
                "setup_dispatches": {c: {"per_dispatch": v} for c, v in sorted(setup.items())},
                "calibration_copy_512MiB": {c: v[0] for c, v in sorted(copy.items())},
                "kernel_resources": resources}
@@ -77,7 +134,16 @@ def pmc(out_path, dirs):
             raw = sum(ik[c]) / len(ik[c]) * 1024.0
             hbm[c] = {"raw_bytes_per_launch": raw, "calibration_factor": cal, "bytes_per_launch": raw * cal}
     if len(hbm) == 2:
-        hbm["traffic_bytes_per_launch"] = hbm["FETCH_SIZE"]["bytes_per_launch"] + hbm["WRITE_SIZE"]["bytes_per_launch"]
+        main_bytes = hbm["FETCH_SIZE"]["bytes_per_launch"] + hbm["WRITE_SIZE"]["bytes_per_launch"]
+        hbm["main_kernel_bytes_per_launch"] = main_bytes
+        # the other launches of the same solve call (same calibration): one solve = all of them
+        extra = 0.0
+        for k, cs in companions.items():
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                if c in cs and cs[c]:
+                    extra += sum(cs[c]) / len(cs[c]) * 1024.0 * hbm[c]["calibration_factor"]
+        hbm["companion_bytes_per_launch"] = extra
+        hbm["traffic_bytes_per_launch"] = main_bytes + extra
     summary["hbm"] = hbm
     # Shares that say what the kernel waits for / runs out of (sums over the solve dispatches; a ratio is only formed from
     # counters of ONE pass, or against SQ_WAVE_CYCLES of the same workload, which every SQ pass of tools/profile.sh carries).
