@@ -24,7 +24,9 @@
  *     passes.  One in-flight call per MkhProblem: asynchronous calls on one handle must be
  *     ordered (same stream, or events) — a handle carries the staging buffers and the ticket
  *     counter that hands the tail of a batch to idle wavefronts, so two of its launches running
- *     at the same time would corrupt each other.  Distinct problems are independent.  A device-pointer
+ *     at the same time would corrupt each other.  Distinct problems are independent.  An MkhModel is shared by the
+ *     problems created on it and by every caller of mkh_integrate: that entry point is re-entrant (its small host-pointer
+ *     path stages through one buffer of the model under a mutex; every other path holds no state of the model).  A device-pointer
  *     call is one plain kernel launch with no host-side state: it can be captured into a hipGraph and
  *     replayed (tests/test_gpu_scale.py::test_launches_replay_inside_a_hip_graph).
  *   - per-instance `status` (int32): bit flags MKH_ST_*.

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -67,6 +68,8 @@ struct PinnedScratch {
 struct MkhModel {
   int device = 0;
   PinnedScratch small;             // mkh_integrate, host pointers
+  std::mutex small_mutex;          // one model serves many callers (every Configuration of a FlatModel shares it): the small
+                                   // host-pointer path of mkh_integrate is serialised, so the entry point stays re-entrant
   int nq = 0, nv = 0, nbody = 0, njnt = 0, ngeom = 0, nsite = 0, nrounds = 0;
   // host copies needed when problems are created
   std::vector<int32_t> body_parentid, body_rootid, body_jntnum, body_jntadr, body_dofnum, body_dofadr;
@@ -102,6 +105,7 @@ struct MkhProblem {
   // tightest contacts get them, dropped ones are checked at the solution — launched first; the full-row variant then re-solves
   // what it flagged (SolveArgs::redo_mask)
   DeviceProblem* d_dev_tight = nullptr;
+  int32_t* d_status_tight = nullptr;   // status of a tight-rows call whose caller passed no status_out (the redo launch reads it)
   int nt_tight = 0, lds_tight = 0;
   // 3-waves-per-SIMD register map + compact LDS layout (ik_kernel.h MKH_W3; variants without collision rows):
   // LDS bytes per wavefront, 0 when no such variant is compiled for this tableau size or it would not reach 12 waves per CU
@@ -885,7 +889,8 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       p->nt_tight = 48;
       p->lds_tight = lds_t(T.prefetch != 0);
       if (hipMalloc((void**)&p->d_dev_tight, sizeof(DeviceProblem)) != hipSuccess ||
-          hipMemcpy(p->d_dev_tight, &T, sizeof(DeviceProblem), hipMemcpyHostToDevice) != hipSuccess)
+          hipMemcpy(p->d_dev_tight, &T, sizeof(DeviceProblem), hipMemcpyHostToDevice) != hipSuccess ||
+          hipMalloc((void**)&p->d_status_tight, (size_t)p->max_batch * sizeof(int32_t)) != hipSuccess)
         return bail(fail(MKH_E_HIP, "descriptor upload failed"));
     }
   }
@@ -904,7 +909,7 @@ void mkh_problem_destroy(MkhProblem* p) {
   (void)hipSetDevice(p->device);
   (void)hipFree(p->d_frame); (void)hipFree(p->d_posture_cost); (void)hipFree(p->d_cfg_lower); (void)hipFree(p->d_cfg_upper);
   (void)hipFree(p->d_vel); (void)hipFree(p->d_pairs); (void)hipFree(p->d_dev); (void)hipFree(p->d_taps); (void)hipFree(p->d_work);
-  (void)hipFree(p->d_lane); (void)hipFree(p->d_warm); (void)hipFree(p->d_dev_tight);
+  (void)hipFree(p->d_lane); (void)hipFree(p->d_warm); (void)hipFree(p->d_dev_tight); (void)hipFree(p->d_status_tight);
   (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain); (void)hipFree(p->s_iters);
   (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh); (void)hipFree(p->s_dbox); (void)hipFree(p->d_clk);
   (void)hipFree(p->s_q); (void)hipFree(p->s_ft); (void)hipFree(p->s_pt); (void)hipFree(p->s_ct); (void)hipFree(p->s_v); (void)hipFree(p->s_status);
@@ -972,7 +977,11 @@ static hipError_t clk_end(MkhProblem* p, int B, hipStream_t stream) {
   return hipSuccess;
 }
 
-static int32_t launch(MkhProblem* p, const SolveArgs& a, const TapArgs* taps, hipStream_t stream, int32_t flags) {
+static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps, hipStream_t stream, int32_t flags) {
+  // (the kernel choice must not depend on whether the caller wants the status: a call without status_out on a handle with a
+  //  tight-rows build keeps it in a buffer of the handle — round-3 advisor finding)
+  SolveArgs a = a_in;
+  if (!a.status_out && p->d_status_tight && a.do_qp) a.status_out = p->d_status_tight;
   (void)hipGetLastError();          // a stale error of an unrelated earlier runtime call must not be blamed on this launch
   const TapArgs* dtaps = nullptr;
   if (taps) {
@@ -1457,6 +1466,7 @@ int32_t mkh_integrate(MkhModel* m, int32_t B, const double* q, const double* v, 
   }
   const size_t bq = (size_t)B * m->nq * 8, bv = (size_t)B * m->nv * 8;
   if (2 * bq + bv <= kSmallCallBytes) {               // small call: through the pinned scratch (see PinnedScratch)
+    std::lock_guard<std::mutex> lock(m->small_mutex);   // (threads of one process share the model: round-3 advisor finding)
     HIP_OK(m->small.ensure());
     char* const h = m->small.host;
     char* const d = m->small.dev;

@@ -168,7 +168,7 @@ struct SolveArgs {
   // != 0: a REDO launch — only the problems whose status_out has one of these bits are solved (again), the others are
   // skipped where the wave draws its next problem (collision builds: the full-row launch behind a tight-rows one)
   int32_t redo_mask;
-  // cycle stamps of every problem, (B, 16) as the `cycles` tap — read only by kernels compiled with -DMKH_CLOCKS (experiment
+  // cycle stamps of every problem, (B, 24) — 16 as the `cycles` tap + 8 finer ones — read only by kernels compiled with -DMKH_CLOCKS (experiment
   // builds, tools/phase_clocks.py); nullptr otherwise
   long long* clk;
 };

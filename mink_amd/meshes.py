@@ -13,7 +13,8 @@ the reference rely on, because the wheel is absent here:
 
 [upstream-recall: src/user/user_mesh.cc `mjCMesh::Process`, `mjCMesh::FitGeom`, mujoco 3.1.x; parity unpinned against the
 wheel — the restatement is pinned by its own properties in tests/test_meshes_cpu.py: exact mass properties of boxes,
-cylinders and capsules tessellated on the spot, invariance under rigid motions of the input.]
+cylinders and capsules tessellated on the spot, invariance under rigid motions of the input, the legacy / exact rules on a
+non-convex solid with known values.]
 """
 
 from __future__ import annotations
@@ -84,36 +85,54 @@ def load_mesh_file(path: str) -> Tuple[np.ndarray, np.ndarray]:
 
 
 # ------------------------------------------------------------------ mass properties
-def mass_properties(verts: np.ndarray, faces: np.ndarray):
-    """Volume, centre of mass and second-moment matrix ∫ (x − com)(x − com)ᵀ dV of the volume enclosed by the triangles
-    (unit density): signed tetrahedra from the area-weighted centroid of the surface, as the compiler does — exact for a
-    closed, consistently oriented surface whatever the apex, and well behaved for the slightly open ones of real assets."""
+def mass_properties(verts: np.ndarray, faces: np.ndarray, exact: bool = False):
+    """Volume, centre of mass and second-moment matrix ∫ (x − com)(x − com)ᵀ dV of the solid bounded by the triangles (unit
+    density), from one tetrahedron (pyramid) per face.
+
+    exact = False — the compiler's default, `<compiler exactmeshinertia="false">` ("legacy"): every pyramid counts with
+    the ABSOLUTE value of its volume; volume and centre of mass from pyramids whose apex is the area-weighted centroid of the
+    surface, the second moments from pyramids whose apex is that centre of mass.  Equal to the exact values for a convex
+    mesh (every pyramid is positive), different for a non-convex one — which most collision meshes of the menagerie are.
+    exact = True — `exactmeshinertia="true"`: signed volumes; exact for any closed, consistently oriented surface.
+    [upstream-recall: user_mesh.cc mjCMesh::Process, mujoco 3.1.x — unpinned against the wheel; round-3 advisor finding]"""
     a, b, c = verts[faces[:, 0]], verts[faces[:, 1]], verts[faces[:, 2]]
     nrm = np.cross(b - a, c - a)
     area = 0.5 * np.linalg.norm(nrm, axis=1)
     if area.sum() <= 0.0:
         raise MeshError("mesh has no area")
     apex = ((a + b + c) / 3.0 * area[:, None]).sum(axis=0) / area.sum()
+
+    def second_moments(a, b, c, det):
+        s = a + b + c
+        return (np.einsum("i,ij,ik->jk", det, a, a) + np.einsum("i,ij,ik->jk", det, b, b) + np.einsum("i,ij,ik->jk", det, c, c) +
+                np.einsum("i,ij,ik->jk", det, s, s)) / 120.0              # ∫ x xᵀ dV over the pyramids, about their common apex
+
     a, b, c = a - apex, b - apex, c - apex
     det = np.einsum("ij,ij->i", a, np.cross(b, c))                        # 6 × signed volume of (apex, a, b, c)
+    if exact:
+        vol = det.sum() / 6.0
+        if vol < 0.0:                                                     # triangles wound inwards: same solid
+            det, vol = -det, -vol
+        if vol <= 1e-18:
+            raise MeshError("mesh encloses no volume")
+        com = (det[:, None] * (a + b + c)).sum(axis=0) / 24.0 / vol       # (relative to the apex)
+        C = second_moments(a, b, c, det) - vol * np.outer(com, com)
+        return vol, com + apex, C
+    det = np.abs(det)
     vol = det.sum() / 6.0
-    if vol < 0.0:                                                         # triangles wound inwards: same solid
-        det, vol = -det, -vol
     if vol <= 1e-18:
         raise MeshError("mesh encloses no volume")
-    com = (det[:, None] * (a + b + c)).sum(axis=0) / 24.0 / vol           # (relative to the apex)
-    s = a + b + c
-    C = (np.einsum("i,ij,ik->jk", det, a, a) + np.einsum("i,ij,ik->jk", det, b, b) + np.einsum("i,ij,ik->jk", det, c, c) +
-         np.einsum("i,ij,ik->jk", det, s, s)) / 120.0                     # ∫ x xᵀ dV about the apex
-    C -= vol * np.outer(com, com)
-    return vol, com + apex, C
+    com = (det[:, None] * (a + b + c)).sum(axis=0) / 24.0 / vol
+    a, b, c = a - com, b - com, c - com                                   # second pass: pyramids from the centre of mass
+    det2 = np.abs(np.einsum("ij,ij->i", a, np.cross(b, c)))
+    return vol, com + apex, second_moments(a, b, c, det2)
 
 
-def inertial_frame(verts: np.ndarray, faces: np.ndarray):
+def inertial_frame(verts: np.ndarray, faces: np.ndarray, exact: bool = False):
     """(pos, R, boxsz, volume): centre of mass, principal axes (columns of R, right-handed, principal inertias in
     decreasing order — so the LONGEST extent of the solid is along z, the axis of a fitted capsule / cylinder) and the
     half-sizes of the box of the same volume-inertia."""
-    vol, com, C = mass_properties(verts, faces)
+    vol, com, C = mass_properties(verts, faces, exact)
     inertia = np.trace(C) * np.eye(3) - C
     w, V = np.linalg.eigh(inertia)
     order = np.argsort(-w)                                                # decreasing principal inertias
@@ -165,11 +184,11 @@ def mat2quat(R: np.ndarray) -> np.ndarray:
 class MeshAsset:
     """One `<mesh>` asset compiled: inertial frame (pos, quat), inertia box, hull vertices in the inertial frame."""
 
-    def __init__(self, path: str, scale=(1.0, 1.0, 1.0)):
+    def __init__(self, path: str, scale=(1.0, 1.0, 1.0), exact: bool = False):
         v, f = load_mesh_file(path)
         v = v * np.asarray(scale, dtype=np.float64)
         self.path = path
-        self.pos, R, self.boxsz, self.volume = inertial_frame(v, f)
+        self.pos, R, self.boxsz, self.volume = inertial_frame(v, f, exact)
         self.R = R
         self.quat = mat2quat(R)
         # vertices in the inertial frame, at the precision the compiled model stores them in (mjModel.mesh_vert is float32)
@@ -186,7 +205,7 @@ class MeshAsset:
         return self._hull
 
 
-def load_assets(mesh_elems, meshdir: str, resolve_attrs) -> Dict[str, MeshAsset]:
+def load_assets(mesh_elems, meshdir: str, resolve_attrs, exact: bool = False) -> Dict[str, MeshAsset]:
     """name → MeshAsset for the `<mesh>` elements of an MJCF `<asset>` section (name defaults to the file's stem)."""
     out: Dict[str, MeshAsset] = {}
     for el in mesh_elems:
@@ -195,17 +214,17 @@ def load_assets(mesh_elems, meshdir: str, resolve_attrs) -> Dict[str, MeshAsset]
             continue                                                      # (vertex data inlined in the XML: not read here)
         name = a.get("name") or os.path.splitext(os.path.basename(a["file"]))[0]
         scale = [float(x) for x in a.get("scale", "1 1 1").split()]
-        out[name] = _LazyAsset(os.path.join(meshdir, a["file"]), scale)
+        out[name] = _LazyAsset(os.path.join(meshdir, a["file"]), scale, exact)
     return out
 
 
 class _LazyAsset:
     """A mesh asset that is only read when a geom that matters (collision candidate / fitted primitive) refers to it."""
 
-    def __init__(self, path, scale):
-        self.path, self.scale, self._asset = path, scale, None
+    def __init__(self, path, scale, exact=False):
+        self.path, self.scale, self.exact, self._asset = path, scale, exact, None
 
     def get(self) -> MeshAsset:
         if self._asset is None:
-            self._asset = MeshAsset(self.path, self.scale)
+            self._asset = MeshAsset(self.path, self.scale, self.exact)
         return self._asset

@@ -108,8 +108,12 @@ class _Compiler:
         self.autolimits = True  # MuJoCo >= 3.0 default
         self.eulerseq = "xyz"
         self.meshdir = ""
+        self.exactmeshinertia = False  # the 3.1.x default: "legacy" pyramid sums (mink_amd/meshes.py mass_properties)
 
     def update(self, el: ET.Element):
+        em = el.get("exactmeshinertia")
+        if em is not None:
+            self.exactmeshinertia = em == "true"
         md = el.get("meshdir")
         if md is not None:
             self.meshdir = md
@@ -248,7 +252,7 @@ def load_mjcf(path: str) -> FlatModel:
     from . import meshes as _meshes
     mesh_elems = [m for asset in root.findall("asset") for m in asset.findall("mesh")]
     assets = _meshes.load_assets(mesh_elems, os.path.join(os.path.dirname(os.path.abspath(path)), comp.meshdir),
-                                 lambda el: defaults.resolve("mesh", el, None))
+                                 lambda el: defaults.resolve("mesh", el, None), exact=comp.exactmeshinertia)
     mesh_ids: Dict[str, int] = {}          # asset name → index in the FlatModel's mesh arrays (meshes of type="mesh" geoms)
     mesh_hulls: List[np.ndarray] = []
 
@@ -294,18 +298,30 @@ def load_mjcf(path: str) -> FlatModel:
                 # (mink_amd/meshes.py).  valid = 2: usable as a collision geom — the axes of the inertial frame are
                 # only defined up to half turns (eigenvectors), which no primitive and no hull distance can see, but a
                 # FrameTask on this geom could: frames on it stay refused (Configuration._frame_id).
-                asset = lazy.get()
-                pos = pos + _quat_rotate(quat, asset.pos)
-                quat = _normalize(_quat_mul(quat, asset.quat))
-                if gtype == GEOM_MESH:
-                    name_m = a["mesh"]
-                    if name_m not in mesh_ids:
-                        mesh_ids[name_m] = len(mesh_hulls)
-                        mesh_hulls.append(asset.hull_vert)
-                    dataid = mesh_ids[name_m]
-                else:
-                    size = _meshes.fit_primitive(gtype, asset.boxsz) * float(a.get("fitscale", 1.0))
-                valid = 2
+                # An asset this reader cannot compile (a format it does not read, an open surface, a flat hull) leaves the
+                # geom at valid = 0 — refused where it is USED, with CollisionAvoidanceLimit's own message — instead of
+                # failing the whole model load (round-3 advisor finding).
+                try:
+                    asset = lazy.get()
+                    hull = None
+                    if gtype == GEOM_MESH:
+                        hull = asset.hull_vert
+                    else:
+                        fitted = _meshes.fit_primitive(gtype, asset.boxsz) * float(a.get("fitscale", 1.0))
+                except (_meshes.MeshError, ValueError, RuntimeError, OSError):        # (scipy's QhullError is a RuntimeError)
+                    asset = None
+                if asset is not None:
+                    pos = pos + _quat_rotate(quat, asset.pos)
+                    quat = _normalize(_quat_mul(quat, asset.quat))
+                    if gtype == GEOM_MESH:
+                        name_m = a["mesh"]
+                        if name_m not in mesh_ids:
+                            mesh_ids[name_m] = len(mesh_hulls)
+                            mesh_hulls.append(hull)
+                        dataid = mesh_ids[name_m]
+                    else:
+                        size = fitted
+                    valid = 2
         if gtype not in (GEOM_MESH, GEOM_PLANE) and valid:
             need = {GEOM_SPHERE: 1, GEOM_CAPSULE: 2, GEOM_CYLINDER: 2,
                     GEOM_BOX: 3, GEOM_ELLIPSOID: 3}[gtype]

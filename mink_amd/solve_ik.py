@@ -60,11 +60,13 @@ def _fold_box_rows(G: np.ndarray, h: np.ndarray):
     g > 0, a lower bound for g < 0.  The reference stacks such rows into its dense G like any other
     (mink/solve_ik.py:25-40) and quadprog treats them as general constraints; on the device they join lo ≤ Δq ≤ hi and
     cost no tableau row — an acceleration-style limit [I; −I] (2·nv rows) would otherwise never fit next to
-    64 − nv half-space rows.  Returns (lo, hi, G_rest, h_rest): (B, nv), (B, nv), (B, m', nv), (B, m')."""
+    64 − nv half-space rows.  Returns (lo, hi, G_rest, h_rest, any_single): (B, nv), (B, nv), (B, m', nv), (B, m'), and whether
+    the limit HAS single-entry rows at all — the structural fact the handle's layout is keyed on (their current values may
+    all be inactive, h = +inf: the same handle must serve the next call where they are not)."""
     B, m, nv = G.shape
     lo, hi = np.full((B, nv), -np.inf), np.full((B, nv), np.inf)
     if m == 0:
-        return lo, hi, G, h
+        return lo, hi, G, h, False
     pattern = (G != 0.0).any(axis=0)                                # (m, nv): columns a row ever touches
     single = pattern.sum(axis=1) == 1
     for r in np.flatnonzero(single):
@@ -78,7 +80,7 @@ def _fold_box_rows(G: np.ndarray, h: np.ndarray):
         bad = zero & (hr < 0.0)                                     # 0·Δq ≤ h < 0: infeasible, as the reference would find
         hi[bad, k], lo[bad, k] = -np.inf, np.inf
     keep = ~single
-    return lo, hi, G[:, keep], h[:, keep]
+    return lo, hi, G[:, keep], h[:, keep], bool(single.any())
 
 
 def _dense_inputs(configuration: Configuration, layout, dt: float):
@@ -143,10 +145,10 @@ def _compile(configuration: Configuration, tasks: Sequence, limits: Optional[Seq
         # the shape), keep the rows for this call
         raw = [_limit_rows(configuration, lim, dense_dt) for lim in layout["dense_limits"]]
         folded = [_fold_box_rows(np.asarray(G), np.asarray(h)) for G, h in raw]
-        layout["dense_limit_data"] = [(G, h) for _, _, G, h in folded]
+        layout["dense_limit_data"] = [(G, h) for _, _, G, h, _ in folded]
         layout["dense_limit_rows"] = sum(h.shape[-1] for _, h in layout["dense_limit_data"])
         lo = np.maximum.reduce([f[0] for f in folded]); hi = np.minimum.reduce([f[1] for f in folded])
-        if np.isfinite(lo).any() or np.isfinite(hi).any() or (lo > hi).any():
+        if any(f[4] for f in folded):          # (structural: a box limit whose rows are all inactive now keeps its handle)
             layout["dense_box"] = (lo, hi)
         cap = 64 - configuration.nv
         if layout["dense_limit_rows"] > cap:

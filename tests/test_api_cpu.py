@@ -273,8 +273,8 @@ def test_fold_box_rows_of_caller_defined_limits():
     G[0, 3, 4] = 1.0; G[1, 3, 4] = -1.0; h[:, 3] = 0.5         # sign differs per instance; instance 2 has g = 0
     G[:, 4, 0] = 1.0; G[:, 4, 2] = 1.0; h[:, 4] = 1.0          # two entries: general
     h[:, 5] = [1.0, 1.0, -1.0]                                 # all-zero row: general (the solver reports 0 ≤ −1 infeasible)
-    lo, hi, Gr, hr = _fold_box_rows(G, h)
-    assert Gr.shape == (B, 3, nv) and hr.shape == (B, 3)
+    lo, hi, Gr, hr, single = _fold_box_rows(G, h)
+    assert Gr.shape == (B, 3, nv) and hr.shape == (B, 3) and single
     np.testing.assert_array_equal(hi[:, 1], [0.5, 1.0, np.inf])
     np.testing.assert_array_equal(lo[:, 1], [-0.25] * 3)
     np.testing.assert_array_equal(hi[:, 4], [0.5, np.inf, np.inf])
@@ -282,8 +282,14 @@ def test_fold_box_rows_of_caller_defined_limits():
     assert np.isinf(lo[:, [0, 2, 3]]).all() and np.isinf(hi[:, [0, 2, 3]]).all()
     # g = 0 with h < 0 in one instance of a single-entry row: infeasible box for that instance only
     G2 = np.zeros((2, 1, nv)); G2[0, 0, 3] = 1.0; h2 = np.array([[1.0], [-1.0]])
-    lo2, hi2, _, _ = _fold_box_rows(G2, h2)
+    lo2, hi2, _, _, _ = _fold_box_rows(G2, h2)
     assert hi2[0, 3] == 1.0 and lo2[1, 3] > hi2[1, 3]
+    # the layout key is structural: single-entry rows that are all inactive now (h = +inf) still announce the box — the handle
+    # (and its warm-start state) must not be rebuilt when they switch on at the next call (round-3 advisor finding)
+    h3 = np.full((2, 1), np.inf)
+    lo3, hi3, G3r, _, single3 = _fold_box_rows(G2, h3)
+    assert single3 and G3r.shape[1] == 0 and np.isinf(hi3).all() and np.isinf(lo3).all()
+    assert _fold_box_rows(np.ones((2, 1, nv)), np.ones((2, 1)))[4] is False
 
 
 def test_partial_override_detection():

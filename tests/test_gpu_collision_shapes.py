@@ -559,3 +559,27 @@ print("KERNEL", prob.last_kernel(), "FLAGGED", int(((st & 16) != 0).sum()))
     v2f, st2f = prob2.solve(q2, tg2, key[None, :], None, dt2, damping2, full_rows=True)
     np.testing.assert_array_equal(st2, st2f)
     assert (st2 & ~1 == 0).all() and (np.abs(v2 - v2f) / np.maximum(1.0, np.abs(v2f).max(axis=1, keepdims=True))).max() < 1e-9
+
+
+def test_kernel_choice_does_not_depend_on_the_status_pointer():
+    """A C caller may pass status_out = NULL.  On a handle with a tight-rows build that call used to fall back to the 64-row
+    build (the redo launch reads the status): the same inputs ran different kernels depending on an OUTPUT pointer (round-3
+    advisor finding).  Now the status of such a call lives in a buffer of the handle: same kernels, same v."""
+    import ctypes as C
+    from mink_amd import _native as nat, workloads
+    import native_configs as nc
+    model = workloads.load_robot("shadow_left")
+    nm = nat.NativeModel(model)
+    B = 2048
+    prob, dt, damping = nc.build("shadow_c4", nm, B)
+    base = model.key_qpos[model.name2id("key", "grasp hard")]
+    q, tg = workloads.make_batch(model, nm, prob, np.random.default_rng(9), B, base_q=base)
+    q[::2] = 0.5 * (q[::2] + base)
+    v_ref, st_ref = prob.solve(q, tg, base[None, :], None, dt, damping)
+    assert prob.last_kernel() == "ik_solve_kernel_48_72+redo_64"
+    v = np.full_like(v_ref, np.nan)
+    pt = np.ascontiguousarray(base[None, :])
+    nat._check(nat.lib().mkh_solve(prob.handle, B, q.ctypes.data, tg.ctypes.data, pt.ctypes.data, None, float(dt), float(damping),
+                                   v.ctypes.data, None, 0, None))
+    assert prob.last_kernel() == "ik_solve_kernel_48_72+redo_64", prob.last_kernel()
+    np.testing.assert_array_equal(v, v_ref)

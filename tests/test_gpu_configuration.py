@@ -84,3 +84,29 @@ def test_check_limits(ur5e):
     q[0] = 1e4                                                            # x of the free joint
     c2.update(q)
     c2.check_limits(safety_break=True)
+
+
+def test_integrate_from_two_threads_sharing_one_model(ur5e):
+    """Every Configuration of a FlatModel shares ONE native model, ctypes releases the GIL inside the call, and the small
+    host-pointer path of mkh_integrate stages through a buffer of that model: two threads with their own Configurations must
+    not see each other's q / v (round-3 advisor finding; the path is serialised by a mutex in the library)."""
+    import threading
+    q_ref = ur5e.key_qpos[ur5e.name2id("key", "home")]
+    errs = []
+
+    def work(sign, n=400):
+        cfg = mink.Configuration(ur5e, q_ref)
+        v = sign * np.arange(1, ur5e.nv + 1, dtype=np.float64)
+        for k in range(n):
+            dt = 1e-3 * (1 + k % 7)
+            out = cfg.integrate(v, dt)
+            if not np.allclose(out, q_ref + dt * v, atol=1e-14):
+                errs.append((sign, k))
+                return
+
+    ts = [threading.Thread(target=work, args=(s,)) for s in (1.0, -1.0, 0.5)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs[:3]

@@ -118,3 +118,79 @@ def test_from_mjmodel_takes_the_hull_from_mesh_graph():
     assert out["mesh_vertnum"].tolist() == [4, 4] and out["mesh_vertadr"].tolist() == [0, 4]
     np.testing.assert_array_equal(out["mesh_vert"][:4], m.mesh_vert[5:9])
     np.testing.assert_array_equal(out["mesh_vert"][4:], m.mesh_vert[[0, 2, 3, 4]])
+
+
+def _l_prism(a=0.3, b=0.1, h=0.05):
+    """A non-convex solid: the L-shaped polygon (0,0) (a,0) (a,b) (b,b) (b,a) (0,a) extruded over z ∈ [−h, h]."""
+    poly = np.array([[0, 0], [a, 0], [a, b], [b, b], [b, a], [0, a]], dtype=float)
+    n = len(poly)
+    v = np.concatenate([np.c_[poly, np.full(n, -h)], np.c_[poly, np.full(n, h)]])
+    f = []
+    for i in range(n):                                   # side walls (outward for a counter-clockwise polygon)
+        j = (i + 1) % n
+        f += [(i, j, n + j), (i, n + j, n + i)]
+    tris = [(0, 1, 2), (0, 2, 3), (0, 3, 5), (3, 4, 5)]  # the polygon, triangulated (all inside the L)
+    for t in tris:
+        f.append((t[0], t[2], t[1]))                     # bottom: normal −z
+        f.append((n + t[0], n + t[1], n + t[2]))         # top: normal +z
+    return v, np.array(f), a, b, h
+
+
+def test_legacy_and_exact_mesh_inertia_rules():
+    """`<compiler exactmeshinertia>`: the default ("legacy") sums every face pyramid with the ABSOLUTE value of its volume —
+    exact for a convex mesh only —, "true" sums signed volumes — exact for any closed surface (mink_amd/meshes.py
+    mass_properties; round-3 advisor finding: the fitted capsules of non-convex collision meshes depend on it)."""
+    rng = np.random.default_rng(3)
+    # convex: both rules give the exact values
+    v, f = _box(0.03, 0.05, 0.11)
+    for exact in (False, True):
+        vol, com, C = meshes.mass_properties(v + 0.2, f, exact)
+        np.testing.assert_allclose(vol, 8 * 0.03 * 0.05 * 0.11, rtol=1e-12)
+        np.testing.assert_allclose(com, 0.2, atol=1e-13)
+        np.testing.assert_allclose(np.diag(C), vol * np.array([0.03, 0.05, 0.11]) ** 2 / 3, rtol=1e-10)
+    # non-convex: the signed rule is exact ...
+    v, f, a, b, h = _l_prism()
+    vol, com, C = meshes.mass_properties(v, f, exact=True)
+    area = a * b + b * (a - b)                                           # two rectangles: [0,a]×[0,b] and [0,b]×[b,a]
+    np.testing.assert_allclose(vol, area * 2 * h, rtol=1e-12)
+    cx = (a * b * a / 2 + b * (a - b) * b / 2) / area
+    np.testing.assert_allclose(com, [cx, cx, 0.0], atol=1e-13)
+    # ... the legacy rule is not: pyramids that face away from the surface centroid count positive too — a larger volume
+    vol_l, com_l, C_l = meshes.mass_properties(v, f, exact=False)
+    assert vol_l > vol * 1.01
+    # recomputed from its definition: Σ |pyramid| from the area-weighted surface centroid
+    A, B, Cc = v[f[:, 0]], v[f[:, 1]], v[f[:, 2]]
+    ar = 0.5 * np.linalg.norm(np.cross(B - A, Cc - A), axis=1)
+    apex = ((A + B + Cc) / 3 * ar[:, None]).sum(0) / ar.sum()
+    pyr = np.abs(np.einsum("ij,ij->i", A - apex, np.cross(B - apex, Cc - apex))) / 6
+    np.testing.assert_allclose(vol_l, pyr.sum(), rtol=1e-12)
+    np.testing.assert_allclose(com_l, (pyr[:, None] * (0.75 * (A + B + Cc) / 3 + 0.25 * apex)).sum(0) / pyr.sum(), atol=1e-13)
+    # both rules are invariant under rigid motions of the input
+    R, t = _random_rotation(rng), rng.normal(size=3)
+    for exact in (False, True):
+        v0, c0, C0 = meshes.mass_properties(v, f, exact)
+        v1, c1, C1 = meshes.mass_properties(v @ R.T + t, f, exact)
+        np.testing.assert_allclose(v1, v0, rtol=1e-11)
+        np.testing.assert_allclose(c1, R @ c0 + t, atol=1e-12)
+        np.testing.assert_allclose(C1, R @ C0 @ R.T, atol=1e-14)
+    # the MJCF reader honours the compiler flag
+    from mink_amd import mjcf
+    assert mjcf._Compiler().exactmeshinertia is False
+
+
+def test_an_asset_the_reader_cannot_compile_does_not_fail_the_model_load(tmp_path):
+    """A collision geom on a mesh that cannot be compiled (here: a flat sheet — no volume) is marked geom_valid = 0 and refused
+    where it is used; the model itself loads (round-3 advisor finding)."""
+    from mink_amd import mjcf
+    tri = np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]], [[1, 0, 0], [1, 1, 0], [0, 1, 0]]], dtype="<f4")
+    with open(tmp_path / "sheet.stl", "wb") as fh:
+        fh.write(b"\0" * 80 + struct.pack("<I", len(tri)))
+        for t in tri:
+            fh.write(struct.pack("<3f", 0, 0, 1) + t.tobytes() + b"\0\0")
+    xml = f"""<mujoco><compiler meshdir="{tmp_path}"/><asset><mesh name="sheet" file="sheet.stl"/></asset>
+    <worldbody><body name="b"><joint type="hinge" axis="0 0 1"/><geom name="g" type="mesh" mesh="sheet"/>
+    <geom name="c" type="capsule" mesh="sheet"/><geom name="s" type="sphere" size="0.1"/></body></worldbody></mujoco>"""
+    p = tmp_path / "m.xml"
+    p.write_text(xml)
+    m = mjcf.load_mjcf(str(p))
+    assert m.nv == 1 and list(np.asarray(m.geom_valid)) == [0, 0, 1]
