@@ -577,9 +577,15 @@ def test_kernel_choice_does_not_depend_on_the_status_pointer():
     q[::2] = 0.5 * (q[::2] + base)
     v_ref, st_ref = prob.solve(q, tg, base[None, :], None, dt, damping)
     assert prob.last_kernel() == "ik_solve_kernel_48_72+redo_64"
-    v = np.full_like(v_ref, np.nan)
-    pt = np.ascontiguousarray(base[None, :])
-    nat._check(nat.lib().mkh_solve(prob.handle, B, q.ctypes.data, tg.ctypes.data, pt.ctypes.data, None, float(dt), float(damping),
-                                   v.ctypes.data, None, 0, None))
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    q_d, tg_d, pt_d = to(q), to(tg), to(base[None, :])
+    v_d = torch.full((B, model.nv), float("nan"), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    nat._check(nat.lib().mkh_solve(prob.handle, B, q_d.data_ptr(), tg_d.data_ptr(), pt_d.data_ptr(), None, float(dt), float(damping),
+                                   v_d.data_ptr(), None, nat.FLAG_DEVICE_PTRS, stream))      # status_out = NULL, device pointers
+    torch.cuda.synchronize()
     assert prob.last_kernel() == "ik_solve_kernel_48_72+redo_64", prob.last_kernel()
-    np.testing.assert_array_equal(v, v_ref)
+    np.testing.assert_array_equal(v_d.cpu().numpy(), v_ref)
