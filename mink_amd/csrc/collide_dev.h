@@ -354,8 +354,9 @@ template <bool SIMPLE = false, bool CONVEX = false>
 __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t2, V3 s2, V3 p2, Q4 q2,
                                               double distmax, double& dist, V3& from, V3& to,
                                               const double* hv1 = nullptr, int hn1 = 0, const double* hv2 = nullptr, int hn2 = 0,
-                                              bool* need_epa = nullptr) {
+                                              bool* need_epa = nullptr, double* gjk_slot = nullptr) {
   // hv / hn: hull vertices (geom frame) of a mesh geom
+  // gjk_slot (general convex pairs): this lane's simplex storage in LDS (convex_dev.h cvx_gjk: kGjkSlots lanes at a time)
   // need_epa (general convex pairs): set when the pair's cores OVERLAP — dist / from / to are then placeholders and the
   // caller finishes the pair at wave level with geom_overlap_distance (the expanding polytope is a wave-cooperative routine)
   const bool flip = t1 > t2;
@@ -414,9 +415,13 @@ __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t
     const V3 pt = cvx_support(g2, -1.0 * z1);
     c.dist = dot(z1, pt - p1); c.hit = c.dist <= distmax; c.n = z1; c.pos = pt - (0.5 * c.dist) * z1;
   } else if (CONVEX && t1 >= GEOM_SPHERE && t1 <= GEOM_MESH && t2 >= GEOM_SPHERE && t2 <= GEOM_MESH) {
-    const ConvexGeom g1{t1, s1, p1, R1, hv1, hn1}, g2{t2, s2, p2, R2, hv2, hn2};
+    // in the frame of geom 1: pose of geom 2 there, contact rotated back
+    const Q4 q1c = qconj(q1);
+    const ConvexRel g{t1, s1, hv1, hn1, t2, s2, hv2, hn2, qmul(q1c, q2), qrot(q1c, p2 - p1)};
     bool ne = false;
-    c.hit = cvx_distance(g1, g2, distmax, c.dist, c.pos, c.n, ne);
+    c.hit = cvx_distance(g, distmax, c.dist, c.pos, c.n, ne, gjk_slot);
+    c.pos = p1 + qrot(q1, c.pos);
+    c.n = qrot(q1, c.n);
     if (need_epa) *need_epa = ne;
   } else {
     dist = distmax; from = {0, 0, 0}; to = {0, 0, 0};
@@ -428,6 +433,16 @@ __device__ __forceinline__ bool geom_distance(int t1, V3 s1, V3 p1, Q4 q1, int t
   from = c.pos - (0.5 * sgn * c.dist) * c.n;
   to = c.pos + (0.5 * sgn * c.dist) * c.n;
   return true;
+}
+
+// Does geom_distance send this pair of types through GJK (no analytic routine; plane–ellipsoid / plane–mesh are analytic)?
+__device__ __forceinline__ bool geom_pair_runs_gjk(int a, int b) {
+  if (a > b) { const int x = a; a = b; b = x; }
+  const bool analytic = (a == GEOM_CAPSULE && b == GEOM_CAPSULE) || (a == GEOM_SPHERE && b == GEOM_SPHERE) ||
+                        (a == GEOM_SPHERE && b == GEOM_CAPSULE) || a == GEOM_PLANE ||
+                        (b == GEOM_BOX && (a == GEOM_SPHERE || a == GEOM_CAPSULE || a == GEOM_BOX)) ||
+                        (b == GEOM_CYLINDER && (a == GEOM_SPHERE || a == GEOM_CAPSULE));
+  return !analytic && a >= GEOM_SPHERE && b <= GEOM_MESH;
 }
 
 // Second half of geom_distance for a general convex pair whose cores overlap: every lane of the wavefront calls this with

@@ -28,6 +28,10 @@ namespace mkh {
 
 constexpr int kGeomSphere = 2, kGeomCapsule = 3, kGeomEllipsoid = 4, kGeomCylinder = 5, kGeomBox = 6, kGeomMesh = 7;
 constexpr int kGjkMaxIters = 128;
+// On a curved rim GJK converges linearly (the squared distance gains a digit every three or four iterations, the last ones
+// below anything a row of G can see): once an iteration moves |v|² by less than this fraction the simplex stands.  The
+// distance is then good to ~1e-12 relative, the witness points to ~1e-6 of the shapes' size; oracle/gjk.py: GJK_PROGRESS.
+constexpr double kGjkProgress = 1e-12;
 
 // vert / nvert: convex-hull vertices of a mesh geom in the geom's frame (global memory, 3 doubles each); nullptr else
 struct ConvexGeom { int type; V3 size; V3 pos; M3 R; const double* vert; int nvert; };
@@ -36,30 +40,29 @@ __device__ __forceinline__ double cvx_core_radius(const ConvexGeom& g) {
   return (g.type == kGeomSphere || g.type == kGeomCapsule) ? g.size.x : 0.0;
 }
 
-// support point of the CORE in the world: argmax_x d·x
-__device__ __forceinline__ V3 cvx_support(const ConvexGeom& g, V3 d) {
-  const V3 dl = mulT(g.R, d);
+// support point of the CORE in the geom's own frame: argmax_x dl·x
+__device__ __forceinline__ V3 cvx_support_local(const int type, const V3 size, const double* vert, const int nvert, const V3 dl) {
   V3 s{0.0, 0.0, 0.0};
-  if (g.type == kGeomCapsule) {
-    s.z = dl.z >= 0.0 ? g.size.y : -g.size.y;
-  } else if (g.type == kGeomBox) {
-    s = {dl.x >= 0.0 ? g.size.x : -g.size.x, dl.y >= 0.0 ? g.size.y : -g.size.y, dl.z >= 0.0 ? g.size.z : -g.size.z};
-  } else if (g.type == kGeomCylinder) {
+  if (type == kGeomCapsule) {
+    s.z = dl.z >= 0.0 ? size.y : -size.y;
+  } else if (type == kGeomBox) {
+    s = {dl.x >= 0.0 ? size.x : -size.x, dl.y >= 0.0 ? size.y : -size.y, dl.z >= 0.0 ? size.z : -size.z};
+  } else if (type == kGeomCylinder) {
     const double n = sqrt(dl.x * dl.x + dl.y * dl.y);
-    s.z = dl.z >= 0.0 ? g.size.y : -g.size.y;
-    if (n >= 1e-300) { const double k = g.size.x * fast_rcp(n); s.x = k * dl.x; s.y = k * dl.y; }
-  } else if (g.type == kGeomEllipsoid) {
-    const V3 e{g.size.x * dl.x, g.size.y * dl.y, g.size.z * dl.z};
+    s.z = dl.z >= 0.0 ? size.y : -size.y;
+    if (n >= 1e-300) { const double k = size.x * fast_rcp(n); s.x = k * dl.x; s.y = k * dl.y; }
+  } else if (type == kGeomEllipsoid) {
+    const V3 e{size.x * dl.x, size.y * dl.y, size.z * dl.z};
     const double n = sqrt(dot(e, e));
-    if (n < 1e-300) s = {g.size.x, 0.0, 0.0};
-    else { const double k = fast_rcp(n); s = {g.size.x * e.x * k, g.size.y * e.y * k, g.size.z * e.z * k}; }
-  } else if (g.type == kGeomMesh) {
+    if (n < 1e-300) s = {size.x, 0.0, 0.0};
+    else { const double k = fast_rcp(n); s = {size.x * e.x * k, size.y * e.y * k, size.z * e.z * k}; }
+  } else if (type == kGeomMesh) {
     // hull vertices: the first maximiser of d·x (numpy argmax order, oracle/gjk.py).  Four vertices per trip: the loads of
     // a trip are independent, the running maximum is the only chain.
     double best = -__builtin_huge_val();
-    const double* v = g.vert;
+    const double* v = vert;
     int i = 0;
-    for (; i + 4 <= g.nvert; i += 4) {
+    for (; i + 4 <= nvert; i += 4) {
       const double* p = v + 3 * i;
       const double x0 = p[0], y0 = p[1], z0 = p[2], x1 = p[3], y1 = p[4], z1 = p[5];
       const double x2 = p[6], y2 = p[7], z2 = p[8], x3 = p[9], y3 = p[10], z3 = p[11];
@@ -70,15 +73,29 @@ __device__ __forceinline__ V3 cvx_support(const ConvexGeom& g, V3 d) {
       if (d2 > best) { best = d2; s = {x2, y2, z2}; }
       if (d3 > best) { best = d3; s = {x3, y3, z3}; }
     }
-    for (; i < g.nvert; ++i) {
+    for (; i < nvert; ++i) {
       const double* p = v + 3 * i;
       const double x0 = p[0], y0 = p[1], z0 = p[2];
       const double d0 = dl.x * x0 + dl.y * y0 + dl.z * z0;
       if (d0 > best) { best = d0; s = {x0, y0, z0}; }
     }
   }
-  return g.pos + mul(g.R, s);
+  return s;
 }
+
+// support point of the CORE in the world: argmax_x d·x
+__device__ __forceinline__ V3 cvx_support(const ConvexGeom& g, V3 d) {
+  return g.pos + mul(g.R, cvx_support_local(g.type, g.size, g.vert, g.nvert, mulT(g.R, d)));
+}
+
+// The pair in the frame of shape 1 (the separated case, cvx_gjk): shape 1 needs no rotation at all and shape 2 one
+// quaternion — 13 doubles of geometry instead of 30 live across the loop, a third fewer rotations per iteration.
+struct ConvexRel { int t1; V3 s1; const double* vert1; int nvert1; int t2; V3 s2; const double* vert2; int nvert2; Q4 q21; V3 p21; };
+__device__ __forceinline__ V3 cvx_support1(const ConvexRel& g, V3 d) { return cvx_support_local(g.t1, g.s1, g.vert1, g.nvert1, d); }
+__device__ __forceinline__ V3 cvx_support2(const ConvexRel& g, V3 d) {
+  return g.p21 + qrot(g.q21, cvx_support_local(g.t2, g.s2, g.vert2, g.nvert2, qrot(qconj(g.q21), d)));
+}
+
 
 // Closest point of a simplex to the origin as barycentric weights on the simplex's own vertices + the vertices kept
 // (bit i of keep).  keep = 0 from the tetrahedron: the origin is inside.
@@ -89,7 +106,7 @@ struct CvxW4 { double l0, l1, l2, l3; int keep; };
 __device__ __forceinline__ CvxW2 cvx_closest_segment(V3 a, V3 b) {
   const V3 ab = b - a;
   const double den = dot(ab, ab);
-  const double t = den <= 0.0 ? 0.0 : -dot(a, ab) / den;
+  const double t = den <= 0.0 ? 0.0 : -dot(a, ab) * fast_rcp(den);
   if (t <= 0.0) return {1.0, 0.0, 1};
   if (t >= 1.0) return {0.0, 1.0, 2};
   return {1.0 - t, t, 3};
@@ -103,22 +120,22 @@ __device__ __forceinline__ CvxW3 cvx_closest_triangle(V3 a, V3 b, V3 c) {
   if (d3 >= 0.0 && d4 <= d3) return {0.0, 1.0, 0.0, 2};
   const double vc = d1 * d4 - d3 * d2;
   if (vc <= 0.0 && d1 >= 0.0 && d3 <= 0.0) {
-    const double v = d1 / (d1 - d3);
+    const double v = d1 * fast_rcp(d1 - d3);
     return {1.0 - v, v, 0.0, 3};
   }
   const double d5 = -dot(ab, c), d6 = -dot(ac, c);
   if (d6 >= 0.0 && d5 <= d6) return {0.0, 0.0, 1.0, 4};
   const double vb = d5 * d2 - d1 * d6;
   if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) {
-    const double w = d2 / (d2 - d6);
+    const double w = d2 * fast_rcp(d2 - d6);
     return {1.0 - w, 0.0, w, 5};
   }
   const double va = d3 * d6 - d5 * d4;
   if (va <= 0.0 && (d4 - d3) >= 0.0 && (d5 - d6) >= 0.0) {
-    const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+    const double w = (d4 - d3) * fast_rcp((d4 - d3) + (d5 - d6));
     return {0.0, 1.0 - w, w, 6};
   }
-  const double den = 1.0 / (va + vb + vc);
+  const double den = fast_rcp(va + vb + vc);
   const double v = vb * den, w = vc * den;
   return {1.0 - v - w, v, w, 7};
 }
@@ -146,7 +163,9 @@ __device__ __forceinline__ void cvx_tet_face(V3 a, V3 b, V3 c, V3 dv, double& be
 __device__ __forceinline__ CvxW4 cvx_closest_tetrahedron(V3 p0, V3 p1, V3 p2, V3 p3) {
   CvxW4 best{0.0, 0.0, 0.0, 0.0, 0};
   double best_d2 = __builtin_huge_val();
-  cvx_tet_face<0, 1, 2>(p0, p1, p2, p3, best_d2, best);       // (face, opposite vertex) as in oracle/gjk.py _FACES
+  // (face, opposite vertex) as in oracle/gjk.py _FACES.  p3 is the vertex GJK has just added, (p0, p1, p2) the simplex it
+  // stood on: that face cannot hold a point closer than the one it held already (the caller stops on "no progress"), and the
+  // origin and p3 lie on the same side of it — only the three faces at p3 are looked at.
   cvx_tet_face<0, 2, 3>(p0, p2, p3, p1, best_d2, best);
   cvx_tet_face<0, 3, 1>(p0, p3, p1, p2, best_d2, best);
   cvx_tet_face<1, 3, 2>(p1, p3, p2, p0, best_d2, best);
@@ -157,26 +176,47 @@ __device__ __forceinline__ CvxW4 cvx_closest_tetrahedron(V3 p0, V3 p1, V3 p2, V3
 // `cutoff`: the caller discards the pair when the cores are farther apart than this — the loop stops as soon as its
 // certified lower bound says so (dist = that bound, no witness points): two or three iterations instead of ~9 for the
 // pairs of a batch that are nowhere near each other.
-__device__ __forceinline__ bool cvx_gjk(const ConvexGeom& g1, const ConvexGeom& g2, const double cutoff, double& dist, V3& pa, V3& pb) {
-  V3 d = g1.pos - g2.pos;
+//
+// The simplex lives in LDS (round 4): vertex k of this lane at S[(6k + c)·kGjkSlots], c = 0..2 its point of the difference,
+// 3..5 its point on shape 1 — lane slots side by side, so the lanes of a wavefront never share a bank.  Rounds 2 and 3 kept
+// it in named registers with select networks for every append / compaction (runtime-indexed private arrays go to scratch):
+// 196 VGPRs, which as a callee saved 82 registers per problem (209 MB of scratch traffic per launch of the `ur5e_convex`
+// workload) and inlined spilled inside the loop.  LDS takes runtime indices: the loop keeps the logical order of the vertices as
+// four 2-bit slot numbers, loads the ≤ 3 standing vertices per iteration and the points on shape 1 only at the end.
+constexpr int kGjkSlots = 32;                       // lanes of a wavefront that run GJK at the same time (the caller batches)
+constexpr int kGjkWsDoubles = 24 * kGjkSlots;
+// (in the frame of shape 1: pa / pb come out in that frame)
+__device__ __forceinline__ bool cvx_gjk(const ConvexRel& g, const double cutoff, double& dist, V3& pa, V3& pb, double* S) {
+  auto ldW = [&](int k) -> V3 { const double* p = S + 6 * k * kGjkSlots; return V3{p[0], p[kGjkSlots], p[2 * kGjkSlots]}; };
+  auto ldA = [&](int k) -> V3 { const double* p = S + (6 * k + 3) * kGjkSlots; return V3{p[0], p[kGjkSlots], p[2 * kGjkSlots]}; };
+  auto st = [&](int k, V3 w, V3 a) {
+    double* p = S + 6 * k * kGjkSlots;
+    p[0] = w.x; p[kGjkSlots] = w.y; p[2 * kGjkSlots] = w.z; p[3 * kGjkSlots] = a.x; p[4 * kGjkSlots] = a.y; p[5 * kGjkSlots] = a.z;
+  };
+  V3 d = -1.0 * g.p21;
   if (dot(d, d) < 1e-30) d = {1.0, 0.0, 0.0};
   const V3 zero{0.0, 0.0, 0.0};
-  V3 W0, W1 = zero, W2 = zero, W3 = zero, A0, A1 = zero, A2 = zero, A3 = zero;     // simplex of the difference / points on shape 1
-  double lam0 = 1.0, lam1 = 0.0, lam2 = 0.0;       // weights of the last accepted simplex (n ≤ 3 vertices)
+  int ord = 0;                                     // physical slot of logical vertex i: bits [2i, 2i + 2)
   int n = 1;
-  A0 = cvx_support(g1, -1.0 * d);
-  W0 = A0 - cvx_support(g2, d);
-  V3 v = W0;
+  double lam0 = 1.0, lam1 = 0.0, lam2 = 0.0;       // weights of the last accepted simplex (n ≤ 3 vertices)
+  {
+    const V3 a0 = cvx_support1(g, -1.0 * d);
+    const V3 w0 = a0 - cvx_support2(g, d);
+    st(0, w0, a0);
+    pa = w0;                                       // (v below)
+  }
+  V3 v = pa;
   double lb = 0.0;
 #pragma nounroll
   for (int it = 0; it < kGjkMaxIters; ++it) {
+    const V3 W0 = ldW(ord & 3), W1 = n > 1 ? ldW((ord >> 2) & 3) : zero, W2 = n > 2 ? ldW((ord >> 4) & 3) : zero;
     const double vv = dot(v, v);
     double scale = fmax(1e-300, dot(W0, W0));
     if (n > 1) scale = fmax(scale, dot(W1, W1));
     if (n > 2) scale = fmax(scale, dot(W2, W2));
     if (vv <= 1e-28 * scale) return false;
-    const V3 a = cvx_support(g1, -1.0 * v);
-    const V3 w = a - cvx_support(g2, v);
+    const V3 a = cvx_support1(g, -1.0 * v);
+    const V3 w = a - cvx_support2(g, v);
     const double vw = dot(v, w);
     if (vv - vw <= 1e-14 * vv) break;             // no support point is closer to the origin along v: converged
     lb = fmax(lb, vw / sqrt(vv));                 // every point of the difference is at least this far: a certified bound
@@ -186,54 +226,56 @@ __device__ __forceinline__ bool cvx_gjk(const ConvexGeom& g1, const ConvexGeom& 
     same = same || (n > 1 && dot(w - W1, w - W1) <= tol);
     same = same || (n > 2 && dot(w - W2, w - W2) <= tol);
     if (same) break;                              // the same vertex again (polytopes): converged
-    // append at slot n, closest point of the new simplex: weights on the slots + keep mask
+    // the free physical slot takes the new vertex (logical index n)
+    int used = 1 << (ord & 3);
+    if (n > 1) used |= 1 << ((ord >> 2) & 3);
+    if (n > 2) used |= 1 << ((ord >> 4) & 3);
+    const int fr = __builtin_ctz(~used);
+    st(fr, w, a);
+    // closest point of the new simplex: weights on the logical vertices + keep mask
     double l0, l1, l2 = 0.0, l3 = 0.0;
     int keep;
     if (n == 1) {
-      W1 = w; A1 = a;
-      const CvxW2 r = cvx_closest_segment(W0, W1);
+      const CvxW2 r = cvx_closest_segment(W0, w);
       l0 = r.l0; l1 = r.l1; keep = r.keep;
     } else if (n == 2) {
-      W2 = w; A2 = a;
-      const CvxW3 r = cvx_closest_triangle(W0, W1, W2);
+      const CvxW3 r = cvx_closest_triangle(W0, W1, w);
       l0 = r.l0; l1 = r.l1; l2 = r.l2; keep = r.keep;
     } else {
-      W3 = w; A3 = a;
-      const CvxW4 r = cvx_closest_tetrahedron(W0, W1, W2, W3);
+      const CvxW4 r = cvx_closest_tetrahedron(W0, W1, W2, w);
       l0 = r.l0; l1 = r.l1; l2 = r.l2; l3 = r.l3; keep = r.keep;
       if (keep == 0) {
         if (lb > 0.0) break;                      // "origin inside" against a certified separation: a flat tetrahedron
         return false;
       }
     }
-    const V3 vn = (l0 * W0 + l1 * W1) + (l2 * W2 + l3 * W3);
+    const V3 Wn1 = n == 1 ? w : W1, Wn2 = n == 2 ? w : W2, Wn3 = n == 3 ? w : zero;      // logical vertices 1..3 of the new simplex
+    const V3 vn = (l0 * W0 + l1 * Wn1) + (l2 * Wn2 + l3 * Wn3);
     // no progress, or a point closer than the certified bound — both are a thin simplex misclassified (or a barycentric
-    // denominator lost) to rounding: the previous simplex (slots [0, n), weights lam) is the answer
+    // denominator lost) to rounding: the previous simplex (logical [0, n), weights lam) is the answer
     const double vnn = dot(vn, vn);
     if (vnn >= vv || vnn < lb * lb * (1.0 - 1e-10)) break;
-    // compact the kept vertices to the front (slot order): a select network, no indexed storage
-    V3 nW0 = zero, nW1 = zero, nW2 = zero, nA0 = zero, nA1 = zero, nA2 = zero;
+    const bool done = vv - vnn <= kGjkProgress * vv;          // the distance has stopped moving: this simplex is the answer
+    // keep the kept vertices in their order: new slot numbers and weights
+    const int full = ord | (fr << (2 * n));        // logical → physical of the simplex with the new vertex
+    int nord = 0, c = 0;
     double nl0 = 0.0, nl1 = 0.0, nl2 = 0.0;
-    int c = 0;
-#define MKH_CVX_PUT(Ws, As, ls, s)                                         \
-    if ((keep >> s) & 1) {                                                 \
-      if (c == 0) { nW0 = Ws; nA0 = As; nl0 = ls; }                        \
-      else if (c == 1) { nW1 = Ws; nA1 = As; nl1 = ls; }                   \
-      else { nW2 = Ws; nA2 = As; nl2 = ls; }                               \
-      ++c;                                                                 \
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if ((keep >> i) & 1) {
+        const double li = i == 0 ? l0 : (i == 1 ? l1 : (i == 2 ? l2 : l3));
+        nord |= ((full >> (2 * i)) & 3) << (2 * c);
+        if (c == 0) nl0 = li; else if (c == 1) nl1 = li; else nl2 = li;
+        ++c;
+      }
     }
-    MKH_CVX_PUT(W0, A0, l0, 0)
-    MKH_CVX_PUT(W1, A1, l1, 1)
-    MKH_CVX_PUT(W2, A2, l2, 2)
-    MKH_CVX_PUT(W3, A3, l3, 3)
-#undef MKH_CVX_PUT
-    W0 = nW0; W1 = nW1; W2 = nW2; A0 = nA0; A1 = nA1; A2 = nA2;
-    lam0 = nl0; lam1 = nl1; lam2 = nl2;
+    ord = nord; lam0 = nl0; lam1 = nl1; lam2 = nl2;
     n = c; v = vn;
+    if (done) break;
   }
-  pa = lam0 * A0;
-  if (n > 1) pa = pa + lam1 * A1;
-  if (n > 2) pa = pa + lam2 * A2;
+  pa = lam0 * ldA(ord & 3);
+  if (n > 1) pa = pa + lam1 * ldA((ord >> 2) & 3);
+  if (n > 2) pa = pa + lam2 * ldA((ord >> 4) & 3);
   pb = pa - v;
   dist = sqrt(dot(v, v));
   return true;
@@ -443,14 +485,15 @@ __device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom
   return r;
 }
 
-// One contact in mj_geomDistance's convention: n from geom 1 to geom 2, pos the midpoint of the witness points.
+// One contact in mj_geomDistance's convention: n from geom 1 to geom 2, pos the midpoint of the witness points — in the frame
+// of geom 1 (the caller rotates pos / nrm back).
 // need_epa: the cores overlap — the caller runs cvx_epa for this pair at wave level (cvx_overlap_contact finishes the contact).
-__device__ __forceinline__ bool cvx_distance(const ConvexGeom& g1, const ConvexGeom& g2, double margin, double& dist, V3& pos, V3& nrm,
-                                             bool& need_epa) {
-  const double r1 = cvx_core_radius(g1), r2 = cvx_core_radius(g2);
+__device__ __forceinline__ bool cvx_distance(const ConvexRel& g, double margin, double& dist, V3& pos, V3& nrm, bool& need_epa,
+                                             double* gjk_slot) {
+  const double r1 = (g.t1 == kGeomSphere || g.t1 == kGeomCapsule) ? g.s1.x : 0.0, r2 = (g.t2 == kGeomSphere || g.t2 == kGeomCapsule) ? g.s2.x : 0.0;
   double dc = 0.0;
   V3 pa{0, 0, 0}, pb{0, 0, 0};
-  const bool apart = cvx_gjk(g1, g2, margin + r1 + r2, dc, pa, pb);
+  const bool apart = cvx_gjk(g, margin + r1 + r2, dc, pa, pb, gjk_slot);
   if (apart && dc > 1e-9) {                       // (cores apart: also when only the spherical shells overlap)
     dist = dc - r1 - r2;
     if (dist > margin) return false;

@@ -57,7 +57,13 @@
 // one (FEAT 30).  Measured and kept inlined: the plane / sphere / capsule builds (FEAT 72 / 88: the Shadow hand, whose phases
 // fit — as calls 0.402 → 0.472 ms, prologues and callee-saved registers); FEAT 31, every feature + taps, is the parity build
 // and its cycle stamps sit inside the phases.
-#if defined(MKH_W3) || (defined(MKH_FEAT) && (MKH_FEAT & 8) && !(MKH_FEAT & 1) && !(MKH_FEAT & 64))
+// Round 4, the builds of the general convex routine (FEAT 136): GJK keeps its simplex in LDS and works in the frame of shape 1
+// (143 VGPRs instead of 196), the overlapping case left the per-lane path (the expanding polytope is a wave-level routine, a
+// real and rarely taken call of its own: overlap_pair).  Measured on `ur5e_convex` (4 096 instances, one cylinder–box pair):
+// the phase INLINED on the 32-row map 0.178 ms / 27 MB of HBM traffic; as a call on the 32-row map 0.186 ms / 88 MB (its
+// prologue still saves ≈50 callee-saved VGPRs per problem); as a call on the 16-row three-waves map 0.156 ms — kept
+// (minkhip.hip launch(): calls_nt_min).  -DMKH_INLINE_136 builds the inlined variant for A/B runs.
+#if defined(MKH_W3) || (defined(MKH_FEAT) && (MKH_FEAT & 8) && !(MKH_FEAT & 1) && !(MKH_FEAT & 64) && (!(MKH_FEAT & 128) || !defined(MKH_INLINE_136)))
 #define MKH_CALLS 1
 #endif
 
@@ -1266,6 +1272,28 @@ __device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, int, in
 #else
 #define MKH_COLL_ATTR __forceinline__
 #endif
+// One general convex pair whose cores overlap, the wavefront cooperating (geom_overlap_distance → cvx_epa).  A REAL call in
+// every build: the path is rare (a pair in penetration) and its registers must not count against the phase around it; the
+// pair's descriptor and the body poses arrive as generic pointers.
+struct OverlapOut { double dist; V3 from, to; };
+__device__ __attribute__((noinline)) OverlapOut overlap_pair(const CollisionPairDev* cpp, const double* sX, int XS, double* ws) {
+  cpp = reinterpret_cast<const CollisionPairDev*>(uni((unsigned long long)reinterpret_cast<size_t>(cpp)));
+  sX = reinterpret_cast<const double*>(uni((unsigned long long)reinterpret_cast<size_t>(sX)));
+  ws = reinterpret_cast<double*>(uni((unsigned long long)reinterpret_cast<size_t>(ws)));
+  XS = uni(XS);
+  const CollisionPairDev& cp = *cpp;
+  const double* x1 = sX + cp.body1;
+  const double* x2 = sX + cp.body2;
+  const Q4 bq1{x1[3 * XS], x1[4 * XS], x1[5 * XS], x1[6 * XS]}, bq2{x2[3 * XS], x2[4 * XS], x2[5 * XS], x2[6 * XS]};
+  const V3 gp1 = V3{x1[0], x1[XS], x1[2 * XS]} + qrot(bq1, V3{cp.lpos1[0], cp.lpos1[1], cp.lpos1[2]});
+  const V3 gp2 = V3{x2[0], x2[XS], x2[2 * XS]} + qrot(bq2, V3{cp.lpos2[0], cp.lpos2[1], cp.lpos2[2]});
+  const Q4 gq1 = qmul(bq1, Q4{cp.lquat1[0], cp.lquat1[1], cp.lquat1[2], cp.lquat1[3]});
+  const Q4 gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
+  OverlapOut o;
+  geom_overlap_distance(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
+                        V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, o.dist, o.from, o.to, cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, ws);
+  return o;
+}
 __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapArgs* tp, int pb, double dt, int mode,
                                               const LdsLayout& Lk) {
   constexpr int NT = MKH_NT, FEAT = MKH_FEAT;
@@ -1334,7 +1362,7 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
   };
   // contact of pair pi at the current poses.  need_epa: a general convex pair whose cores overlap — finished at wave level
   // below (overlap_of), the values returned here are placeholders
-  auto contact_of = [&](int pi, double& hk, V3& nrm, V3& from, V3& to, uint64_t& m1, uint64_t& m2, bool& need_epa) -> bool {
+  auto contact_of = [&](int pi, double& hk, V3& nrm, V3& from, V3& to, uint64_t& m1, uint64_t& m2, bool& need_epa, double* gjk_slot) -> bool {
     const auto& cp = pairs[pi];
     V3 gp1, gp2;
     Q4 gq1, gq2;
@@ -1342,19 +1370,14 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
     double dist;
     geom_distance<kSimpleColl, kConvexColl>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
                   V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to,
-                  cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, &need_epa);
+                  cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, &need_epa, gjk_slot);
     return finish_contact(cp, dist, from, to, hk, nrm, m1, m2);
   };
-  // the same for ONE wave-uniform pair whose cores overlap, every lane cooperating (expanding polytope, convex_dev.h)
+  // the same for ONE wave-uniform pair whose cores overlap, every lane cooperating (expanding polytope: overlap_pair above)
   auto overlap_of = [&](int pi, double& hk, V3& nrm, V3& from, V3& to, uint64_t& m1, uint64_t& m2) -> bool {
-    const auto& cp = pairs[pi];
-    V3 gp1, gp2;
-    Q4 gq1, gq2;
-    pair_poses(cp, gp1, gq1, gp2, gq2);
-    double dist;
-    geom_overlap_distance(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
-                          V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, dist, from, to, cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, sEpa);
-    return finish_contact(cp, dist, from, to, hk, nrm, m1, m2);
+    const OverlapOut o = overlap_pair((const CollisionPairDev*)(pairs + pi), sX, XS, sEpa);
+    from = o.from; to = o.to;
+    return finish_contact(pairs[pi], o.dist, from, to, hk, nrm, m1, m2);
   };
   // position of pair pi in the order (h, index) among all pairs (h = +inf: not detected)
   auto rank_of = [&](int pi, double hk) -> int {
@@ -1382,7 +1405,19 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
         want = hs < kInf && rank_of(pi, hs) >= max_rows;
       }
       bool need_epa = false;
-      if (want) active = contact_of(pi, hk, nrm, from, to, m1, m2, need_epa);
+      if constexpr (kConvexColl) {
+        // GJK keeps its simplex in LDS (the front of the expanding polytope's workspace): kGjkSlots lanes at a time
+        const bool gjk = want && geom_pair_runs_gjk(pairs[pi].type1, pairs[pi].type2);
+        const unsigned long long gm = __ballot(gjk);
+        const int rank = __popcll(gm & ((1ull << lane) - 1ull));
+        for (int b0 = 0; b0 == 0 || b0 < __popcll(gm); b0 += kGjkSlots) {
+          const bool mine = want && (gjk ? (rank >= b0 && rank < b0 + kGjkSlots) : b0 == 0);
+          if (mine) active = contact_of(pi, hk, nrm, from, to, m1, m2, need_epa, sEpa + (rank - b0));
+        }
+        wave_sync();
+      } else {
+        if (want) active = contact_of(pi, hk, nrm, from, to, m1, m2, need_epa, nullptr);
+      }
       if constexpr (kConvexColl) {
         // pairs whose cores overlap: one at a time, the wavefront cooperating on the expanding polytope
         for (unsigned long long em = __ballot(want && need_epa); em; em &= em - 1) {
@@ -1850,8 +1885,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       }
     }
     };
-#ifdef MKH_COLL_CALL
-    constexpr bool kCollFirst = true;      // a real callee: while the tableau is dead
+#if defined(MKH_COLL_CALL) || (MKH_FEAT & 128)
+    constexpr bool kCollFirst = true;      // a real callee (or, general convex pairs: overlap_pair inside the phase): while the tableau is dead
 #else
     constexpr bool kCollFirst = false;     // inlined (plane / sphere / capsule builds): after the H accumulation, as in round 2
 #endif

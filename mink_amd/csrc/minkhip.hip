@@ -693,7 +693,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     if (const char* cap = getenv("MKH_DEBUG_MAX_ROWS")) { const int c = atoi(cap); if (c > 0 && c < P.max_rows) P.max_rows = c; }   // (experiments)
     // LDS behind the per-problem ranges: h of every pair when pairs outnumber rows (row selection), then the expanding polytope's
     // workspace when some pair goes through the general convex routine (collision_phase: the same two terms)
-    P.n_hsel = (P.n_pairs > P.max_rows ? lds_even(P.n_pairs) : 0) + (p->convex_pairs ? kEpaWsDoubles : 0);
+    P.n_hsel = (P.n_pairs > P.max_rows ? lds_even(P.n_pairs) : 0) + (p->convex_pairs ? (kEpaWsDoubles > kGjkWsDoubles ? kEpaWsDoubles : kGjkWsDoubles) : 0);
   }
   const int ntab = m->nv + P.max_rows;
   {
@@ -1055,11 +1055,11 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   // map of a 32-row tableau for the compiler's sake: a small arm keeps a small tableau (UR5e + 2 collision rows: phase 0 on
   // 32 rows was a third of the solve) — at least `calls_nt_min` rows, so that the callees still find a usable register file
   // Measured (UR5e + 2 collision rows, 4 096 instances): analytic pairs 0.060 ms on 32 rows, 0.049 on 16 and on 8; with a
-  // cylinder–box pair on the general convex routine 0.174 ms on 32 rows, 0.213 on 16, 0.372 on 8 — GJK wants the 256-register
-  // file of the 2-waves map, so those builds keep 32.
+  // cylinder–box pair on the general convex routine (round 4: simplex in LDS, 143 VGPRs) 0.186 ms on 32 rows, 0.156 on 16
+  // and on 24 — round 3's register-resident GJK (196 VGPRs) wanted the 2-waves file and kept 32 rows.
   static const int dbg_min = getenv("MKH_DEBUG_CALLS_NT") ? atoi(getenv("MKH_DEBUG_CALLS_NT")) : 0;
   const int calls_nt_min = dbg_min ? dbg_min : 16;
-  const bool calls = feat == F_COLL || feat == (F_ALL & ~F_TAPS) || (dbg_min && feat == (F_COLL | F_CONVEX_COLL));
+  const bool calls = feat == F_COLL || feat == (F_ALL & ~F_TAPS) || feat == (F_COLL | F_CONVEX_COLL);
   if (calls && p->nt < 32) {
     static const int kV[] = {8, 16, 24, 32};
     for (int v : kV) if (v >= p->nt && v >= calls_nt_min) { nt = v; break; }
@@ -1609,7 +1609,7 @@ namespace {
 // records of (type, size[3], pos[3], quat[4] wxyz).
 __global__ __launch_bounds__(64) void geom_distance_eval_kernel(int n, const double* __restrict__ g, double distmax,
                                                                 double* __restrict__ dist_out, double* __restrict__ fromto_out) {
-  __shared__ __attribute__((aligned(16))) double ws[kEpaWsDoubles];
+  __shared__ __attribute__((aligned(16))) double ws[kEpaWsDoubles > 2 * kGjkWsDoubles ? kEpaWsDoubles : 2 * kGjkWsDoubles];
   const int lane = lane_id();
   const int base = blockIdx.x * 64;
   auto load = [&](int i, int& t1, V3& s1, V3& p1, Q4& q1, int& t2, V3& s2, V3& p2, Q4& q2) {
@@ -1625,7 +1625,9 @@ __global__ __launch_bounds__(64) void geom_distance_eval_kernel(int n, const dou
   if (want) {
     int t1, t2; V3 s1, p1, s2, p2; Q4 q1, q2;
     load(i, t1, s1, p1, q1, t2, s2, p2, q2);
-    known = geom_distance<false, true>(t1, s1, p1, q1, t2, s2, p2, q2, distmax, dist, from, to, nullptr, 0, nullptr, 0, &need_epa);
+    // (two GJK banks: every lane of this kernel may hold a convex pair)
+    known = geom_distance<false, true>(t1, s1, p1, q1, t2, s2, p2, q2, distmax, dist, from, to, nullptr, 0, nullptr, 0, &need_epa,
+                                       ws + (lane >> 5) * kGjkWsDoubles + (lane & 31));
   }
   for (unsigned long long em = __ballot(want && need_epa); em; em &= em - 1) {
     const int l = (int)__builtin_ctzll(em);

@@ -18,6 +18,7 @@ import numpy as np
 
 GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = 0, 2, 3, 4, 5, 6, 7
 MAX_ITERS = 128
+GJK_PROGRESS = 1e-12     # an iteration that moves |v|² by less than this fraction ends the loop (convex_dev.h kGjkProgress)
 
 
 def core_radius(gtype, size):
@@ -99,7 +100,9 @@ def _closest_triangle(P):
     return [0, 1, 2], [1.0 - v - w, v, w]
 
 
-_FACES = ((0, 1, 2, 3), (0, 2, 3, 1), (0, 3, 1, 2), (1, 3, 2, 0))   # (face, opposite vertex)
+# (face, opposite vertex).  Vertex 3 is the one GJK has just added: the face (0, 1, 2) it stood on cannot hold a closer point
+# than it held already (the loop stops on "no progress"), and the origin and vertex 3 lie on the same side of it.
+_FACES = ((0, 2, 3, 1), (0, 3, 1, 2), (1, 3, 2, 0))
 
 
 def _closest_tetrahedron(P):
@@ -165,8 +168,11 @@ def gjk_cores(t1, s1, p1, R1, t2, s2, p2, R2):
         if v_new @ v_new >= vv or v_new @ v_new < lb * lb * (1.0 - 1e-10):
             W, A, lam = W[:-1], A[:-1], lam_prev      # the previous simplex is the answer
             break
+        done = vv - v_new @ v_new <= GJK_PROGRESS * vv
         W, A, v = Wn, An, v_new
         lam_prev = lam
+        if done:
+            break
     pa = sum(l * x for l, x in zip(lam, A))
     pb = pa - v
     return float(np.sqrt(v @ v)), pa, pb, False

@@ -108,7 +108,7 @@ def test_overlapping_general_convex_pairs_against_the_oracle(pair):
     for i in np.flatnonzero(deep):
         R1, R2 = _quat2mat(q1[i]).reshape(3, 3), _quat2mat(q2[i]).reshape(3, 3)
         la, lb = R1.T @ (fromto[i, :3] - p1[i]), R2.T @ (fromto[i, 3:] - p2[i])
-        tol_w = 1e-5 if flat else 2e-3          # (a polytope that stopped on its budget leaves its witness a chord off a curved patch)
+        tol_w = 1e-5 if flat else 5e-3          # (a polytope that stopped on its budget leaves its witness a chord off a curved patch)
         assert _outside(t1[i], s1[i], la) < tol_w and _outside(t2[i], s2[i], lb) < tol_w, (i, la, lb)
         assert abs(np.linalg.norm(fromto[i, 3:] - fromto[i, :3]) + dist[i]) < 1e-9
 

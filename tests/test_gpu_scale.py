@@ -423,7 +423,7 @@ def test_ur5e_convex_at_its_bench_batch_against_the_numpy_oracle():
     prob, dt, damping = workloads.bench_config(name, model, nm, B)
     q, tg, pt, _ = workloads.bench_batch(name, model, nm, prob, np.random.default_rng(2024), B)
     v, st = prob.solve(q, tg, pt, None, dt, damping)
-    assert prob.last_kernel() == "ik_solve_kernel_32_136", prob.last_kernel()
+    assert prob.last_kernel() == "ik_solve_kernel_16_136", prob.last_kernel()
     assert ((st & ~1) == 0).all(), np.unique(st, return_counts=True)
     ncpu = min(16, os.cpu_count() or 1)
     chunks = np.array_split(np.arange(B), ncpu * 4)

@@ -64,7 +64,9 @@ def run(name, B=None):
         st[z, k] = st[z, k - 1]
     d = np.diff(st, axis=1)
     for k, n in enumerate(NAMES):
-        print("    %-22s mean %8.0f  (%4.1f%%)" % (n, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean()))
+        print("    %-22s mean %8.0f  (%4.1f%%)   p50 %7.0f  p90 %7.0f  p99 %7.0f  max %7d" % (
+            n, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean(), np.median(d[:, k]), np.percentile(d[:, k], 90),
+            np.percentile(d[:, k], 99), d[:, k].max()))
     sub = ["phase-0 publish", "phase-0 rcp+pivot", "GI select", "flip/GI publish", "flip/GI ratio test", "flip/GI pivot"]
     if "_r" in prob.last_kernel():
         sub = ["low-rank: J rows", "low-rank: S, w", "low-rank: elimination", "low-rank: rank-1 dof block (+publish)", "ratio test", "pivot"]
