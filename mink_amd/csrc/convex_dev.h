@@ -293,6 +293,10 @@ __device__ __forceinline__ bool cvx_gjk(const ConvexRel& g, const double cutoff,
 // `penetration` states the same rules (slot order of new faces, ties by slot) sequentially.  What MuJoCo's collider
 // returns for such a pair approximates this quantity (libccd MPR to 1e-6 in mujoco 3.1.6; its native GJK + EPA later).
 // Arguments arrive wave-uniform; every lane executes every statement (no divergent call).
+// (the workgroup-per-problem kernel, wide_kernel.h, runs it in one of four wavefronts: a wave-local fence instead of the barrier)
+#ifndef MKH_EPA_SYNC
+#define MKH_EPA_SYNC() wave_sync()
+#endif
 constexpr int kEpaMaxV = 48, kEpaMaxF = 92;
 constexpr double kEpaTol = 1e-11;
 constexpr int kEpaOffV = 0, kEpaOffF = 6 * kEpaMaxV, kEpaOffI = kEpaOffF + 4 * kEpaMaxF, kEpaOffE = kEpaOffI + (kEpaMaxF + 1) / 2,
@@ -355,7 +359,7 @@ __device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom
   const V3 w3 = add(n0), w4 = add(-1.0 * n0);
   const V3 sum5 = (((w0 + w1) + w2) + w3) + w4;
   const V3 cen{sum5.x / 5.0, sum5.y / 5.0, sum5.z / 5.0};
-  wave_sync();
+  MKH_EPA_SYNC();
   if (lane < 6) {
     const int i = lane % 3, j = (lane + 1) % 3, k = lane < 3 ? 3 : 4;
     const V3 wi = i == 0 ? w0 : (i == 1 ? w1 : w2), wj = j == 0 ? w0 : (j == 1 ? w1 : w2), wk = lane < 3 ? w3 : w4;
@@ -363,7 +367,7 @@ __device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom
     if (F[4 * lane] * (wi.x - cen.x) + F[4 * lane + 1] * (wi.y - cen.y) + F[4 * lane + 2] * (wi.z - cen.z) < 0.0)
       put_face(lane, i, k, j, wi, wk, wj);
   }
-  wave_sync();
+  MKH_EPA_SYNC();
   int nslots = 6, best = 0;
   bool intact = true;
   int ans_id = -1;                                                   // the answer so far: vertices, normal, offset of the nearest face
@@ -390,7 +394,7 @@ __device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom
     const double gap = dot(nb, p) - off;
     if (gap <= kEpaTol * fmax(1.0, fabs(off))) { --nvert; break; }          // the face is (within the gap) a face of D itself
     if (lane < kEpaMaxV) E[lane] = 0ull;
-    wave_sync();
+    MKH_EPA_SYNC();
     // faces that see p, and one bit per directed edge of those
     bool vis0 = false, vis1 = false;
     int id0 = -1, id1 = -1;
@@ -412,7 +416,7 @@ __device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom
     };
     if (vis0) mark(id0);
     if (vis1) mark(id1);
-    wave_sync();
+    MKH_EPA_SYNC();
     // horizon: edges of visible faces whose twin belongs to a face that does not see p
     auto horizon = [&](int id) -> int {
       const int i = id & 255, j = (id >> 8) & 255, k = (id >> 16) & 255;
@@ -430,7 +434,7 @@ __device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom
     int q1 = tot0 + __popcll(a1 & lt) + 2 * __popcll(b1 & lt);
     if (vis0) { freel[__popcll(v0m & lt)] = (unsigned char)lane; Fi[lane] = -1; }
     if (vis1) { freel[__popcll(v0m) + __popcll(v1m & lt)] = (unsigned char)(lane + 64); Fi[lane + 64] = -1; }
-    wave_sync();
+    MKH_EPA_SYNC();
     auto emit = [&](int id, int hz, int q) {
       const int i = id & 255, j = (id >> 8) & 255, k = (id >> 16) & 255;
 #pragma unroll
@@ -445,9 +449,9 @@ __device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom
     if (hz0) emit(id0, hz0, q0);
     if (hz1) emit(id1, hz1, q1);
     if (nh > nvis) nslots += nh - nvis;
-    wave_sync();
+    MKH_EPA_SYNC();
   }
-  wave_sync();
+  MKH_EPA_SYNC();
   if (intact) {
     // a face of D is usually covered by several coplanar triangles: of those in the answer's plane (offsets within 1e-9)
     // the one NEAREST to the origin as a triangle — the one that holds the foot of the perpendicular — gives the witness
@@ -481,7 +485,7 @@ __device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom
   r.n = nb;
   // (geom 2 translated by t overlaps geom 1 iff t ∈ D: the shortest separating translation of geom 2 is depth·n)
   r.depth = dot(nb, cvx_support(g1, nb)) - dot(nb, cvx_support(g2, -1.0 * nb));
-  wave_sync();
+  MKH_EPA_SYNC();
   return r;
 }
 

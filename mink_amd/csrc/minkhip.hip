@@ -15,10 +15,12 @@
 #include <limits>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "ik_kernel.h"
 #include "lane_kernel.h"
+#include "wide_types.h"
 
 using namespace mkh;
 
@@ -77,6 +79,8 @@ struct MkhModel {
   std::vector<int32_t> dof_bodyid, dof_jntid, dof_parentid, site_bodyid, geom_bodyid, geom_type;
   std::vector<double> body_pos, body_quat, site_pos, site_quat, geom_size, geom_pos, geom_quat, jnt_range;
   std::vector<double> jnt_pos, jnt_axis, jnt_qpos0;   // (per joint; qpos0 at the joint's first qpos address)
+  std::vector<double> body_ipos, body_mass, body_subtreemass;
+  bool big = false;                // more than 64 bodies or dofs: no lane tables — every problem runs on the workgroup-per-problem kernel
   std::vector<int32_t> geom_dataid, mesh_vertadr, mesh_vertnum;   // mesh geoms: hull vertices (geom frame) in d_mesh_vert
   double* d_mesh_vert = nullptr;
   // device tables
@@ -105,7 +109,14 @@ struct MkhProblem {
   // tightest contacts get them, dropped ones are checked at the solution — launched first; the full-row variant then re-solves
   // what it flagged (SolveArgs::redo_mask)
   DeviceProblem* d_dev_tight = nullptr;
-  int32_t* d_status_tight = nullptr;   // status of a tight-rows call whose caller passed no status_out (the redo launch reads it)
+  int32_t* d_status_tight = nullptr;   // status of a call with a redo launch whose caller passed no status_out (the redo launch reads it)
+  // the workgroup-per-problem kernel (wide_kernel.h): every call of a model beyond one wavefront (wide_only), or the redo
+  // launch of the instances a wavefront kernel flagged MKH_ST_ROW_OVERFLOW
+  WideProblem wide{};
+  WideProblem* d_wide = nullptr;
+  bool wide_only = false;
+  int wide_grid = 0, wide_lds = 0;
+  std::vector<void*> wide_allocs;
   int nt_tight = 0, lds_tight = 0;
   // 3-waves-per-SIMD register map + compact LDS layout (ik_kernel.h MKH_W3; variants without collision rows):
   // LDS bytes per wavefront, 0 when no such variant is compiled for this tableau size or it would not reach 12 waves per CU
@@ -157,6 +168,7 @@ int launch_variant(int nt, int nr, int feat, bool w3, int grid, int lds_bytes, h
                    const SolveArgs& a, const TapArgs* taps);
 int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);
 int launch_quad(int nt, bool loop, int grid, hipStream_t stream, const LaneProblem* P, const LaneDims& dims, const SolveArgs& a);   // returns its LDS bytes per wavefront
+int launch_wide(int grid, int lds_bytes, hipStream_t stream, const WideProblem* P, const SolveArgs& a);
 constexpr int kLaneMinBatchLoop = 28672;  // fused loops of a small arm: row kernel below, lane kernel from here (M targets/s at 16 384: 39.7 vs 24.1, at 32 768: 42.4 vs 48.2)
 constexpr int kLaneMinBatch = 73728;  // plain solves of a small arm: row kernel below, lane kernel from here (launch())
 }
@@ -305,6 +317,169 @@ static void assign_taps(const MkhTaps* taps, const DeviceProblem& P, size_t Bz, 
   t.t_cycles = (long long*)alloc(taps->cycles, Bz * 16 * 8, true);
 }
 
+
+// The descriptor of the workgroup-per-problem kernel (wide_kernel.h): plain arrays over bodies / joints / dofs (no 64-wide
+// lane tables), the kinematic tree by levels, the dof chain of every body as a bit set, LDS offsets, and the per-workgroup
+// slice of device memory (weighted Jacobian rows, contact records, the tableau when it does not fit in LDS).
+static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhProblemDesc* d, const std::vector<FrameTaskDev>& ft,
+                                  const std::vector<CollisionPairDev>& pairs, const std::vector<double>& dcost,
+                                  const std::vector<double>& dwgain) {
+  const double inf = std::numeric_limits<double>::infinity();
+  WideProblem& W = p->wide;
+  memset(&W, 0, sizeof W);
+  const int nv = m->nv, nb = m->nbody, nj = m->njnt;
+  W.nq = m->nq; W.nv = nv; W.nbody = nb; W.njnt = nj; W.robot_root = 1;
+  W.n_frame = d->n_frame_tasks; W.n_posture = d->n_posture_tasks; W.n_com = d->n_com_tasks;
+  W.n_cfg = d->n_configuration_limits; W.n_vel = d->n_velocity_limits; W.n_pairs = (int)pairs.size();
+  W.n_dense_tasks = d->n_dense_tasks; W.n_dense_rows = (int)dcost.size(); W.n_dense_limit_rows = d->n_dense_limit_rows;
+  W.dense_box = d->dense_limit_box ? 1 : 0;
+  auto up = [&](const auto& v, auto** out) -> hipError_t {
+    const hipError_t e = upload(v, out);
+    if (e == hipSuccess) p->wide_allocs.push_back((void*)*out);
+    return e;
+  };
+  // ---- the tree by levels, subtree ranges, dof chains
+  std::vector<int32_t> depth(nb, 0), level_start, level_body, last(nb), inrobot(nb), jadr(nb);
+  int maxd = 0;
+  for (int b = 1; b < nb; ++b) { depth[b] = depth[m->body_parentid[b]] + 1; if (depth[b] > maxd) maxd = depth[b]; }
+  for (int lv = 0; lv <= maxd; ++lv) {
+    level_start.push_back((int32_t)level_body.size());
+    for (int b = 0; b < nb; ++b) if (depth[b] == lv) level_body.push_back(b);
+  }
+  level_start.push_back((int32_t)level_body.size());
+  W.nlevels = maxd + 1;
+  for (int b = nb - 1; b >= 0; --b) {
+    last[b] = b;
+    for (int c = b + 1; c < nb; ++c) if (m->body_parentid[c] == b && last[c] > last[b]) last[b] = last[c];
+  }
+  for (int b = 0; b < nb; ++b) { inrobot[b] = (b >= 1 && m->body_rootid[b] == 1) ? 1 : 0; jadr[b] = m->body_jntadr[b] < 0 ? 0 : m->body_jntadr[b]; }
+  W.chain_words = (nv + 63) / 64;
+  std::vector<uint64_t> chain((size_t)nb * W.chain_words, 0ull);
+  for (int b = 1; b < nb; ++b) {
+    int x = b;
+    while (x > 0 && m->body_dofnum[x] == 0) x = m->body_parentid[x];
+    if (x == 0) continue;
+    for (int i = m->body_dofadr[x] + m->body_dofnum[x] - 1; i >= 0; i = m->dof_parentid[i])
+      chain[(size_t)b * W.chain_words + (i >> 6)] |= 1ull << (i & 63);
+  }
+  // ---- dofs
+  std::vector<int32_t> dkind(nv), dk(nv, 0), dqadr(nv, -1);
+  std::vector<double> dlo(nv, -inf), dhi(nv, inf);
+  for (int dd = 0; dd < nv; ++dd) {
+    const int j = m->dof_jntid[dd], jt = m->jnt_type[j], k = dd - m->jnt_dofadr[j];
+    if (jt == JNT_HINGE) { dkind[dd] = DOF_HINGE; dqadr[dd] = m->jnt_qposadr[j]; }
+    else if (jt == JNT_SLIDE) { dkind[dd] = DOF_SLIDE; dqadr[dd] = m->jnt_qposadr[j]; }
+    else if (jt == JNT_BALL) { dkind[dd] = DOF_BALL; dk[dd] = k; dqadr[dd] = m->jnt_qposadr[j]; }
+    else if (k < 3) { dkind[dd] = DOF_FREE_LIN; dk[dd] = k; }
+    else { dkind[dd] = DOF_FREE_ANG; dk[dd] = k - 3; }
+    if (((jt == JNT_HINGE || jt == JNT_SLIDE) || (jt == JNT_BALL && k == 0)) && m->jnt_limited[j]) {
+      dlo[dd] = m->jnt_range[2 * j]; dhi[dd] = m->jnt_range[2 * j + 1];
+    }
+  }
+  // ---- tasks and limits, one value per dof
+  std::vector<double> pcost((size_t)(W.n_posture ? W.n_posture : 1) * nv, 0.0);
+  for (int t = 0; t < W.n_posture; ++t) {
+    for (int i = 0; i < nv; ++i) pcost[(size_t)t * nv + i] = d->posture_tasks[t].cost[i];
+    W.posture_gain[t] = d->posture_tasks[t].gain; W.posture_lm[t] = d->posture_tasks[t].lm_damping;
+  }
+  int jrows = 0;
+  for (const auto& f : ft) jrows += __builtin_popcount(f.rowmask);      // (FrameTaskDev::jrow0 counts the same way)
+  for (int t = 0; t < W.n_com; ++t) {
+    W.com_rowmask[t] = 0;
+    for (int k = 0; k < 3; ++k) { W.com_cost[t][k] = d->com_tasks[t].cost[k]; if (d->com_tasks[t].cost[k] != 0.0) W.com_rowmask[t] |= 1 << k; }
+    W.com_gain[t] = d->com_tasks[t].gain; W.com_lm[t] = d->com_tasks[t].lm_damping;
+    W.com_jrow0[t] = jrows; jrows += __builtin_popcount(W.com_rowmask[t]);
+  }
+  W.n_jrows = jrows;
+  for (int t = 0, r0 = 0; t < W.n_dense_tasks; ++t) {
+    W.dense_row0[t] = r0; W.dense_k[t] = d->dense_tasks[t].k; W.dense_lm[t] = d->dense_tasks[t].lm_damping; r0 += d->dense_tasks[t].k;
+  }
+  std::vector<double> clo((size_t)(W.n_cfg ? W.n_cfg : 1) * nv, -inf), chi((size_t)(W.n_cfg ? W.n_cfg : 1) * nv, inf);
+  for (int t = 0; t < W.n_cfg; ++t) {
+    const MkhConfigurationLimitDesc& c = d->configuration_limits[t];
+    W.cfg_gain[t] = c.gain;
+    for (int k = 0; k < c.n_indices; ++k) {
+      const int dof = c.indices[k], qa = m->jnt_qposadr[m->dof_jntid[dof]];     // (validated by the caller)
+      clo[(size_t)t * nv + dof] = c.lower[qa]; chi[(size_t)t * nv + dof] = c.upper[qa];
+    }
+  }
+  std::vector<double> vlim((size_t)(W.n_vel ? W.n_vel : 1) * nv, inf);
+  for (int t = 0; t < W.n_vel; ++t) {
+    const MkhVelocityLimitDesc& v = d->velocity_limits[t];
+    for (int k = 0; k < v.n_indices; ++k) vlim[(size_t)t * nv + v.indices[k]] = std::fmin(vlim[(size_t)t * nv + v.indices[k]], v.limit[k]);
+  }
+  hipError_t e = hipSuccess;
+#define MKH_UP(vec, field) if (e == hipSuccess) { std::remove_const_t<std::remove_pointer_t<decltype(W.field)>>* dp = nullptr; e = up(vec, &dp); W.field = dp; }
+  MKH_UP(level_start, level_start) MKH_UP(level_body, level_body) MKH_UP(m->body_parentid, body_parent) MKH_UP(jadr, body_jntadr)
+  MKH_UP(m->body_jntnum, body_jntnum) MKH_UP(last, body_last) MKH_UP(inrobot, body_inrobot)
+  MKH_UP(m->body_pos, body_pos) MKH_UP(m->body_quat, body_quat) MKH_UP(m->body_ipos, body_ipos) MKH_UP(m->body_mass, body_mass)
+  MKH_UP(m->body_subtreemass, body_stmass) MKH_UP(m->jnt_type, jnt_type) MKH_UP(m->jnt_qposadr, jnt_qadr) MKH_UP(m->jnt_axis, jnt_axis)
+  MKH_UP(m->jnt_pos, jnt_pos) MKH_UP(m->jnt_qpos0, jnt_qpos0) MKH_UP(m->dof_jntid, dof_jnt) MKH_UP(dkind, dof_kind) MKH_UP(dk, dof_k)
+  MKH_UP(m->dof_bodyid, dof_body) MKH_UP(dqadr, dof_qadr) MKH_UP(dlo, dof_lo) MKH_UP(dhi, dof_hi) MKH_UP(chain, chain)
+  MKH_UP(ft, frame) MKH_UP(pcost, posture_cost) MKH_UP(dcost, dense_cost) MKH_UP(dwgain, dense_wgain) MKH_UP(clo, cfg_lower)
+  MKH_UP(chi, cfg_upper) MKH_UP(vlim, vel_limit) MKH_UP(pairs, pairs)
+#undef MKH_UP
+  if (e != hipSuccess) return fail(MKH_E_HIP, "wide problem upload: %s", hipGetErrorString(e));
+  // ---- LDS layout and the per-workgroup slice of device memory
+  const int rows_max = W.n_pairs + W.n_dense_limit_rows;
+  W.max_rows = rows_max < kWideMaxRows ? rows_max : kWideMaxRows;
+  const int Ncap = nv + W.max_rows, R_all = W.n_jrows + W.n_dense_rows;
+  auto ev = [](int x) { return (x + 1) & ~1; };
+  int o = 0;
+  W.o_q = o; o += ev(W.nq);
+  W.o_X = o; o += ev(7 * nb);
+  W.o_jnt = o; o += ev(6 * (nj > 0 ? nj : 1));
+  W.o_dof = o; o += 10 * nv;
+  W.o_task = o; o += 64 * (W.n_frame > 0 ? W.n_frame : 1);
+  W.o_com = o; o += W.n_com > 0 ? 4 * nb : 0;
+  W.o_we = o; o += ev(R_all > 0 ? R_all : 1);
+  W.o_c = o; o += ev(nv);
+  W.o_hd = o; o += ev(nv);
+  W.o_z = o; o += ev(Ncap); W.o_w = o; o += ev(Ncap); W.o_lo = o; o += ev(nv); W.o_hi = o; o += ev(nv);
+  W.o_rown = o; o += ev(Ncap); W.o_ref = o; o += ev(Ncap); W.o_col = o; o += ev(Ncap);
+  W.o_red = o; o += kWideThreads + kWideThreads / 2;
+  W.o_state = o; o += ev((Ncap + 1) / 2);
+  W.o_cws = o; o += p->convex_pairs ? 4 * (kEpaWsDoubles > kGjkWsDoubles ? kEpaWsDoubles : kGjkWsDoubles) : 0;
+  const int lds_cap = (160 * 1024 - 2048) / 8;                              // doubles of LDS one workgroup may take
+  W.tableau_in_lds = (long long)o + (long long)Ncap * Ncap <= lds_cap ? 1 : 0;
+  W.o_T = o; o += W.tableau_in_lds ? Ncap * Ncap : 0;
+  W.lds_doubles = o;
+  if (o > lds_cap) return fail(MKH_E_LIMIT, "model too large for the workgroup-per-problem kernel (%d KB of LDS per problem)", o / 128);
+  long long w = 0;
+  W.ws_jw = w; w += (long long)(R_all > 0 ? R_all : 1) * nv;
+  W.ws_rec = w; w += (long long)(W.n_pairs > 0 ? W.n_pairs : 1) * 10;
+  W.ws_rowpair = w; w += ev((W.max_rows + 2) / 2);
+  W.ws_T = w; w += W.tableau_in_lds ? 0 : (long long)Ncap * Ncap;
+  W.ws_stride = (w + 15) & ~15ll;
+  const int per_cu = (160 * 1024) / (o * 8) < 2 ? ((160 * 1024) / (o * 8) < 1 ? 1 : (160 * 1024) / (o * 8)) : 2;
+  int grid = m->num_cus * per_cu;
+  if (grid > p->max_batch) grid = p->max_batch;
+  while (grid > 1 && (long long)grid * W.ws_stride * 8 > (1ll << 30)) grid /= 2;      // (≤ 1 GB of slices)
+  double* ws = nullptr;
+  if (hipMalloc((void**)&ws, (size_t)grid * W.ws_stride * 8) != hipSuccess) return fail(MKH_E_HIP, "wide workspace (%lld MB)", (long long)grid * W.ws_stride * 8 >> 20);
+  p->wide_allocs.push_back(ws);
+  W.ws = ws;
+  p->wide_grid = grid; p->wide_lds = o * 8;
+  if (hipMalloc((void**)&p->d_wide, sizeof(WideProblem)) != hipSuccess ||
+      hipMemcpy(p->d_wide, &W, sizeof(WideProblem), hipMemcpyHostToDevice) != hipSuccess)
+    return fail(MKH_E_HIP, "wide descriptor upload failed");
+  if (!p->d_status_tight && hipMalloc((void**)&p->d_status_tight, (size_t)p->max_batch * sizeof(int32_t)) != hipSuccess)
+    return fail(MKH_E_HIP, "status buffer");
+  return MKH_OK;
+}
+
+// one launch of the workgroup-per-problem kernel: every instance (redo_mask = 0) or the ones a wavefront kernel flagged
+static int32_t launch_wide_kernel(MkhProblem* p, const SolveArgs& a, hipStream_t stream, int32_t redo_mask) {
+  SolveArgs aw = a;
+  aw.redo_mask = redo_mask;
+  int grid = p->wide_grid < a.B ? p->wide_grid : a.B;
+  if (grid < 1) grid = 1;
+  const int rc = mkh::launch_wide(grid, p->wide_lds, stream, p->d_wide, aw);
+  if (rc != 0) return fail(MKH_E_HIP, "wide kernel: %s", hipGetErrorString((hipError_t)rc));
+  HIP_OK(hipGetLastError());
+  return MKH_OK;
+}
+
 extern "C" {
 
 int32_t mkh_version(void) { return MKH_VERSION; }
@@ -334,13 +509,18 @@ int32_t mkh_model_create(const MkhFlatModel* h, int32_t device, MkhModel** out) 
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MKH_E_NOGPU, "no HIP device visible");
   if (device < 0 || device >= ndev) return fail(MKH_E_INVALID, "device %d out of range (%d visible)", device, ndev);
-  if (h->nbody > kWave) return fail(MKH_E_LIMIT, "nbody=%d exceeds the one-wavefront limit of %d bodies", h->nbody, kWave);
-  if (h->nv > kWave) return fail(MKH_E_LIMIT, "nv=%d exceeds the one-wavefront limit of %d dofs", h->nv, kWave);
+  // (more than 64 bodies or dofs: beyond the wavefront kernels — the workgroup-per-problem kernel takes every call, wide_kernel.h)
+  const bool big = h->nbody > kWave || h->nv > kWave;
+  if (h->nbody > 4096 || h->nv > 1024) return fail(MKH_E_LIMIT, "nbody=%d / nv=%d: at most 4096 bodies and 1024 dofs", h->nbody, h->nv);
   if (h->nv < 1 || h->nbody < 2) return fail(MKH_E_INVALID, "model has no degrees of freedom");
   HIP_OK(hipSetDevice(device));
   MkhModel* m = new MkhModel();
   m->device = device;
+  m->big = big;
   m->nq = h->nq; m->nv = h->nv; m->nbody = h->nbody; m->njnt = h->njnt; m->ngeom = h->ngeom; m->nsite = h->nsite;
+  m->body_ipos.assign(h->body_ipos, h->body_ipos + 3 * h->nbody);
+  m->body_mass.assign(h->body_mass, h->body_mass + h->nbody);
+  m->body_subtreemass.assign(h->body_subtreemass, h->body_subtreemass + h->nbody);
   auto cpi = [](const int32_t* p, int n) { return std::vector<int32_t>(p, p + n); };
   auto cpd = [](const double* p, int n) { return std::vector<double>(p, p + n); };
   m->body_parentid = cpi(h->body_parentid, h->nbody); m->body_rootid = cpi(h->body_rootid, h->nbody);
@@ -385,10 +565,11 @@ int32_t mkh_model_create(const MkhFlatModel* h, int32_t device, MkhModel** out) 
   }
   int nrounds = 0;
   while ((1 << nrounds) < maxdepth) ++nrounds;
-  if (nrounds > kMaxRounds) { delete m; return fail(MKH_E_LIMIT, "kinematic tree too deep"); }
+  if (!big && nrounds > kMaxRounds) { delete m; return fail(MKH_E_LIMIT, "kinematic tree too deep"); }
   m->nrounds = nrounds;
   std::vector<double> body_f(BF_COUNT * 64, 0.0);
   std::vector<int32_t> body_i(BI_COUNT * 64, 0);
+  if (!big) {                                      // (the lane tables of the wavefront kernels: ≤ 64 bodies / dofs)
   std::vector<int> subtree_last(h->nbody);
   for (int b = h->nbody - 1; b >= 0; --b) {
     subtree_last[b] = b;
@@ -429,6 +610,7 @@ int32_t mkh_model_create(const MkhFlatModel* h, int32_t device, MkhModel** out) 
       int aa = body_i[(BI_ANC0 + r) * 64 + a];
       if (body_i[(BI_ANC0 + r + 1) * 64 + b] != aa) { delete m; return fail(MKH_E_INVALID, "internal: ancestor table"); }
     }
+  }
   // ---- joint arrays
   std::vector<double> jnt_f(h->njnt * JF_COUNT, 0.0);
   std::vector<int32_t> jnt_i(h->njnt * JI_COUNT, 0);
@@ -447,7 +629,7 @@ int32_t mkh_model_create(const MkhFlatModel* h, int32_t device, MkhModel** out) 
   std::vector<int32_t> dof_i(DI_COUNT * 64, 0);
   std::vector<double> dof_f(DF_COUNT * 64, 0.0);
   for (int d = 0; d < 64; ++d) { dof_f[DF_RANGE_LO * 64 + d] = -inf; dof_f[DF_RANGE_HI * 64 + d] = inf; dof_i[DI_QADR * 64 + d] = -1; }
-  for (int d = 0; d < h->nv; ++d) {
+  for (int d = 0; d < (big ? 0 : h->nv); ++d) {
     const int j = h->dof_jntid[d];
     const int jt = h->jnt_type[j];
     const int k = d - h->jnt_dofadr[j];
@@ -556,14 +738,14 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       if (resolve(s.root_type, s.root_id, f.root_body, lp, lq) != MKH_OK) return bail(MKH_E_INVALID);
       for (int k = 0; k < 3; ++k) f.root_lpos[k] = lp[k];
       for (int k = 0; k < 4; ++k) f.root_lquat[k] = lq[k];
-      f.root_mask = dof_chain_mask(m, f.root_body);
+      f.root_mask = m->big ? 0ull : dof_chain_mask(m, f.root_body);
     }
     for (int k = 0; k < 6; ++k) {
       if (!(s.cost[k] >= 0.0)) return bail(fail(MKH_E_INVALID, "frame task %d: cost must be >= 0", t));
       f.cost[k] = s.cost[k];
     }
     f.gain = s.gain; f.lm_damping = s.lm_damping;
-    f.dof_mask = dof_chain_mask(m, f.body);
+    f.dof_mask = m->big ? 0ull : dof_chain_mask(m, f.body);
     f.row0 = row; row += 6;
     f.any_ori = (s.cost[3] != 0.0 || s.cost[4] != 0.0 || s.cost[5] != 0.0) ? 1 : 0;
     f.rowmask = 0;
@@ -573,7 +755,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   }
   std::vector<double> pcost((size_t)(d->n_posture_tasks ? d->n_posture_tasks : 1) * 64, 0.0);
   for (int t = 0; t < d->n_posture_tasks; ++t) {
-    for (int i = 0; i < m->nv; ++i) pcost[t * 64 + i] = d->posture_tasks[t].cost[i];
+    for (int i = 0; i < (m->big ? 0 : m->nv); ++i) pcost[t * 64 + i] = d->posture_tasks[t].cost[i];
     P.posture_gain[t] = d->posture_tasks[t].gain; P.posture_lm[t] = d->posture_tasks[t].lm_damping;
     P.posture_row0[t] = row; row += m->nv;
   }
@@ -621,6 +803,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       const int jt = m->jnt_type[m->dof_jntid[dof]];
       if (jt == JNT_FREE) return bail(fail(MKH_E_INVALID, "configuration limit on free-joint dof %d (the reference skips free joints)", dof));
       const int qa = m->jnt_qposadr[m->dof_jntid[dof]];
+      if (m->big) continue;                                  // (beyond 64 dofs: build_wide_problem keeps its own arrays)
       clo[t * 64 + dof] = c.lower[qa];
       chi[t * 64 + dof] = c.upper[qa];
     }
@@ -631,7 +814,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     for (int k = 0; k < v.n_indices; ++k) {
       const int dof = v.indices[k];
       if (dof < 0 || dof >= m->nv) return bail(fail(MKH_E_INVALID, "velocity limit: dof %d out of range", dof));
-      vlim[t * 64 + dof] = std::fmin(vlim[t * 64 + dof], v.limit[k]);
+      if (!m->big) vlim[t * 64 + dof] = std::fmin(vlim[t * 64 + dof], v.limit[k]);
     }
   }
   // ---- collision pairs
@@ -676,7 +859,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       for (int i = 0; i < 3; ++i) { cp.size1[i] = m->geom_size[3 * g1 + i]; cp.size2[i] = m->geom_size[3 * g2 + i];
                                     cp.lpos1[i] = m->geom_pos[3 * g1 + i]; cp.lpos2[i] = m->geom_pos[3 * g2 + i]; }
       for (int i = 0; i < 4; ++i) { cp.lquat1[i] = m->geom_quat[4 * g1 + i]; cp.lquat2[i] = m->geom_quat[4 * g2 + i]; }
-      cp.mask1 = dof_chain_mask(m, cp.body1); cp.mask2 = dof_chain_mask(m, cp.body2);
+      if (!m->big) { cp.mask1 = dof_chain_mask(m, cp.body1); cp.mask2 = dof_chain_mask(m, cp.body2); }
       cp.gain = c.gain; cp.dmin = c.minimum_distance_from_collisions; cp.ddetect = c.collision_detection_distance;
       cp.relax = c.bound_relaxation;
       pairs.push_back(cp);
@@ -687,6 +870,15 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   for (const auto& cp : pairs)
     for (int ty : {cp.type1, cp.type2})
       if (ty != GEOM_PLANE && ty != GEOM_SPHERE && ty != GEOM_CAPSULE) p->simple_pairs = false;
+  if (m->big) {
+    // beyond one wavefront: the workgroup-per-problem kernel takes every call of this problem (wide_kernel.h)
+    const int32_t rc = build_wide_problem(p, m, d, ft, pairs, dcost, dwgain);
+    if (rc != MKH_OK) return bail(rc);
+    p->wide_only = true;
+    snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_wide_kernel");
+    *out = p;
+    return MKH_OK;
+  }
   {
     const int want = P.n_pairs + P.n_dense_limit_rows;          // half-space rows that can be active at once
     P.max_rows = want < (kWave - m->nv) ? want : (kWave - m->nv);
@@ -900,6 +1092,14 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       hipMalloc((void**)&p->d_work, 128) != hipSuccess || hipMemset(p->d_work, 0, 128) != hipSuccess ||
       hipDeviceSynchronize() != hipSuccess)   // (hipMemset may return before the fill has run; launches may come on any stream)
     return bail(fail(MKH_E_HIP, "descriptor upload failed"));
+  // More rows can be active at once than the 64 − nv the wavefront kernels hold (the reference stacks them all:
+  // mink/solve_ik.py:25-40): the instances a launch flags MKH_ST_ROW_OVERFLOW are solved again by the workgroup-per-problem
+  // kernel with every row (launch(): the redo launch behind plain solves)
+  static const bool no_wide = getenv("MKH_DEBUG_NO_WIDE") != nullptr;          // (tests: what the wavefront kernel alone leaves flagged)
+  if (!no_wide && P.n_pairs + P.n_dense_limit_rows > kWave - m->nv) {
+    const int32_t rc = build_wide_problem(p, m, d, ft, pairs, dcost, dwgain);
+    if (rc != MKH_OK) return bail(rc);
+  }
   *out = p;
   return MKH_OK;
 }
@@ -912,6 +1112,8 @@ void mkh_problem_destroy(MkhProblem* p) {
   (void)hipFree(p->d_lane); (void)hipFree(p->d_warm); (void)hipFree(p->d_dev_tight); (void)hipFree(p->d_status_tight);
   (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain); (void)hipFree(p->s_iters);
   (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh); (void)hipFree(p->s_dbox); (void)hipFree(p->d_clk);
+  for (void* w : p->wide_allocs) (void)hipFree(w);
+  (void)hipFree(p->d_wide);
   (void)hipFree(p->s_q); (void)hipFree(p->s_ft); (void)hipFree(p->s_pt); (void)hipFree(p->s_ct); (void)hipFree(p->s_v); (void)hipFree(p->s_status);
   p->small.release();
   if (p->st_in) (void)hipStreamDestroy(p->st_in);
@@ -982,6 +1184,16 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   //  tight-rows build keeps it in a buffer of the handle — round-3 advisor finding)
   SolveArgs a = a_in;
   if (!a.status_out && p->d_status_tight && a.do_qp) a.status_out = p->d_status_tight;
+  if (p->wide_only) {
+    if (taps || a.n_steps > 1 || a.pos_threshold >= 0.0)
+      return fail(MKH_E_INVALID, "models beyond one wavefront (more than 64 bodies or dofs) run on the workgroup-per-problem kernel: "
+                                 "no parity taps, no fused loops (call mkh_solve and mkh_integrate in turn)");
+    snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_wide_kernel");
+    p->last_grid = p->wide_grid < a.B ? p->wide_grid : a.B; p->last_lds = p->wide_lds; p->last_nt = p->wide.nv + p->wide.max_rows;
+    return launch_wide_kernel(p, a, stream, 0);
+  }
+  // (plain solves of a problem whose rows can outnumber the tableau's: the flagged instances once more, with every row)
+  const bool wide_redo = p->d_wide && a.do_qp && a.status_out && !taps && a.n_steps <= 1 && !(a.pos_threshold >= 0.0);
   (void)hipGetLastError();          // a stale error of an unrelated earlier runtime call must not be blamed on this launch
   const TapArgs* dtaps = nullptr;
   if (taps) {
@@ -1136,6 +1348,11 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
     return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
   HIP_OK(hipGetLastError());
   HIP_OK(clk_end(p, a.B, stream));
+  if (wide_redo) {
+    const size_t len = strlen(p->last_kernel);
+    snprintf(p->last_kernel + len, sizeof(p->last_kernel) - len, "+wide");
+    return launch_wide_kernel(p, a, stream, MKH_ST_ROW_OVERFLOW);
+  }
   return MKH_OK;
 }
 

@@ -1,0 +1,620 @@
+// ik_wide_kernel — one WORKGROUP (256 threads) per problem: the path for what one wavefront cannot hold.
+//
+// The wavefront kernels (ik_kernel.h) keep a problem's tableau column in the registers of 64 lanes: nv + active half-space
+// rows ≤ 64, nbody ≤ 64.  The reference has no such limit — `solve_ik` stacks every row its limits return
+// (mink/solve_ik.py:25-40: np.vstack(G_list)) on any nv (:43-65), and CollisionAvoidanceLimit returns one row per pair
+// (mink/limits/collision_avoidance_limit.py:187-210).  This kernel takes
+//   * models with more than 64 bodies or dofs (every call), and
+//   * the instances of a collision / plugin-row problem in which more rows are ACTIVE than the wavefront kernel has tableau
+//     rows and a row it dropped is violated at its solution (MKH_ST_ROW_OVERFLOW): a redo launch behind the normal one
+//     (SolveArgs::redo_mask) that solves exactly those, every detected contact a row.
+// It does not have to be fast, it has to return mink's answer; the structure is still the device's: body poses level by
+// level of the kinematic tree, (task, dof) pairs / (i, j) entries of H / tableau entries spread over the 256 threads, the
+// dual active-set iteration of the wavefront kernels (Goldfarb–Idnani on a symmetric sweep tableau, tools/proto_tableau_qp.py)
+// with the tableau in LDS when (nv + rows)² doubles fit next to the per-problem state, else in a slice of device memory.
+//
+// Covered: FrameTask / RelativeFrameTask (body, geom, site frames), PostureTask (any number: DampingTask is one), ComTask,
+// caller-defined task rows, ConfigurationLimit, VelocityLimit, CollisionAvoidanceLimit (every pair type of collide_dev.h /
+// convex_dev.h), caller-defined limit rows and box rows.  Not covered: parity taps, the fused caller loops (the host loops).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mkh_types.h"
+#include "wave_ops.h"
+// (a workgroup of four wavefronts: the wave-cooperative expanding polytope must not use the workgroup barrier)
+#define MKH_EPA_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#include "collide_dev.h"
+#include "wide_types.h"
+
+namespace mkh {
+
+__device__ __forceinline__ bool wide_on_chain(const WideProblem& P, int body, int k) {
+  return (P.chain[(size_t)body * P.chain_words + (k >> 6)] >> (k & 63)) & 1ull;
+}
+
+// Column k of frame task t (6 rows, unweighted) — frame_column_fn of ik_kernel.h with the chain tests handed in.
+__device__ __forceinline__ void wide_frame_column(const double* o, const double* kd, bool on_frame, bool rel, bool on_root, double (&Jt)[6]) {
+  const V3 d_ang{kd[0], kd[1], kd[2]}, d_lin{kd[3], kd[4], kd[5]}, d_anchor{kd[6], kd[7], kd[8]};
+  V3 a{0, 0, 0}, w{0, 0, 0};
+  if (on_frame) {
+    const V3 pf{o[27], o[28], o[29]};
+    const V3 jp = d_lin + cross(d_ang, pf - d_anchor);
+    M3 Rf;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Rf.m[i] = o[18 + i];
+    a = mulT(Rf, jp); w = mulT(Rf, d_ang);              // body-frame Jacobian (configuration.py:148-153)
+  }
+  double sign = -1.0;                                    // FrameTask: J = −jlog(T_tb)·ᴮJ  (frame_task.py:144-146)
+  if (rel) {
+    sign = 1.0;                                          // RelativeFrameTask: J = +jlog(T_tf)·(ᶠJ − Ad·ʳJ)  (relative_frame_task.py:131-142)
+    if (on_root) {
+      const V3 pr{o[45], o[46], o[47]};
+      const V3 jp = d_lin + cross(d_ang, pr - d_anchor);
+      M3 Rr, Rrf;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { Rr.m[i] = o[36 + i]; Rrf.m[i] = o[48 + i]; }
+      const V3 ar = mulT(Rr, jp), wr = mulT(Rr, d_ang);
+      const V3 Rw = mul(Rrf, wr);                        // Ad(T_fr⁻¹) = [[R, [t]×R],[0, R]]
+      a = a - (mul(Rrf, ar) + cross(V3{o[57], o[58], o[59]}, Rw));
+      w = w - Rw;
+    }
+  }
+  // jlog = [[J, −J·Q·J],[0, J]]:  y = J·w;  rows 0-2 = ±J·(a − Q·y), rows 3-5 = ±y
+  const double wv[3] = {w.x, w.y, w.z}, av[3] = {a.x, a.y, a.z};
+  double y[3], z3[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) y[r] = o[3 * r] * wv[0] + o[3 * r + 1] * wv[1] + o[3 * r + 2] * wv[2];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) z3[r] = av[r] - (o[9 + 3 * r] * y[0] + o[9 + 3 * r + 1] * y[1] + o[9 + 3 * r + 2] * y[2]);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    Jt[r] = sign * (o[3 * r] * z3[0] + o[3 * r + 1] * z3[1] + o[3 * r + 2] * z3[2]);
+    Jt[3 + r] = sign * y[r];
+  }
+}
+
+// index states of the active-set iteration (tools/proto_tableau_qp.py)
+enum { WS_FREE = 0, WS_AT_LO = 1, WS_AT_HI = 2, WS_ROW_OFF = 3, WS_ROW_ON = 4, WS_ZERO = 5 };
+
+__global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem* __restrict__ Pg, SolveArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const WideProblem& P = *Pg;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, NT_ = kWideThreads;
+  const int nq = P.nq, nv = P.nv, nbody = P.nbody, XS = nbody;
+  const double kInf = __builtin_huge_val();
+  double* const sq = smem + P.o_q;
+  double* const sX = smem + P.o_X;                       // body poses, component-major: X[c][body]
+  double* const sJnt = smem + P.o_jnt;                   // per joint: axis, anchor (world)
+  double* const sDof = smem + P.o_dof;                   // per dof: ang, lin, anchor, q
+  double* const sTask = smem + P.o_task;                 // per frame task: the 64-double block of ik_kernel.h's task lanes
+  double* const sCom = smem + P.o_com;                   // per body: subtree CoM, subtree mass
+  double* const sWe = smem + P.o_we;                     // weighted error of every Jacobian row (compact rows + dense rows)
+  double* const sC = smem + P.o_c;                       // c
+  double* const sHd = smem + P.o_hd;                     // diagonal part of H owned by the posture tasks
+  double* const sZ = smem + P.o_z;
+  double* const sW = smem + P.o_w;
+  double* const sLo = smem + P.o_lo;
+  double* const sHi = smem + P.o_hi;
+  double* const sRown = smem + P.o_rown;
+  double* const sRef = smem + P.o_ref;
+  double* const sCol = smem + P.o_col;
+  double* const sRed = smem + P.o_red;                   // 2 × 256: reductions
+  int* const sRedI = reinterpret_cast<int*>(sRed + NT_);
+  int* const sState = reinterpret_cast<int*>(smem + P.o_state);
+  double* const sCws = smem + P.o_cws + wave * (kEpaWsDoubles > kGjkWsDoubles ? kEpaWsDoubles : kGjkWsDoubles);   // this wave's GJK / EPA workspace
+  double* const wsb = P.ws + (size_t)blockIdx.x * P.ws_stride;
+  double* const Jw = wsb + P.ws_jw;                      // weighted Jacobian rows [R][nv]
+  double* const rec = wsb + P.ws_rec;                    // per pair: h, n, from, to (10 doubles)
+  int* const rowpair = reinterpret_cast<int*>(wsb + P.ws_rowpair);
+  double* const T = P.tableau_in_lds ? smem + P.o_T : wsb + P.ws_T;
+  const int R_task = P.n_jrows, R_all = P.n_jrows + P.n_dense_rows;
+
+  auto block_sum = [&](double x) -> double {
+    x = wave_sum(x);
+    __syncthreads();
+    if (lane == 0) sRed[wave] = x;
+    __syncthreads();
+    return (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
+  };
+  // arg-max / arg-min over the candidates of all threads: largest (smallest) value, lowest index on ties; idx −1 when none
+  auto block_arg = [&](double val, int idx, bool want_max, double& best, int& besti) {
+    __syncthreads();
+    sRed[tid] = val; sRedI[tid] = idx;
+    __syncthreads();
+    for (int s = NT_ / 2; s > 0; s >>= 1) {
+      if (tid < s) {
+        const double a = sRed[tid], b = sRed[tid + s];
+        const int ia = sRedI[tid], ib = sRedI[tid + s];
+        const bool take_b = ib >= 0 && (ia < 0 || (want_max ? b > a : b < a) || (b == a && ib < ia));
+        if (take_b) { sRed[tid] = b; sRedI[tid] = ib; }
+      }
+      __syncthreads();
+    }
+    best = sRed[0]; besti = sRedI[0];
+    __syncthreads();
+  };
+
+  for (int pb = (int)blockIdx.x; pb < A.B; pb += (int)gridDim.x) {
+    if (A.redo_mask && !(A.status_out[pb] & A.redo_mask)) continue;          // (wave-uniform: the whole workgroup skips)
+    __syncthreads();
+    int status = 0;
+    // ------------------------------------------------------------ inputs
+    for (int i = tid; i < nq; i += NT_) sq[i] = A.q[(size_t)pb * nq + i];
+    __syncthreads();
+    // ------------------------------------------------------------ FK, level by level (mj_kinematics)
+    for (int lv = 0; lv < P.nlevels; ++lv) {
+      for (int idx = P.level_start[lv] + tid; idx < P.level_start[lv + 1]; idx += NT_) {
+        const int b = P.level_body[idx];
+        V3 xp{0, 0, 0};
+        Q4 xq{1, 0, 0, 0};
+        if (b > 0) {
+          const int pa = P.body_parent[b];
+          const Q4 pq{sX[3 * XS + pa], sX[4 * XS + pa], sX[5 * XS + pa], sX[6 * XS + pa]};
+          xp = V3{sX[pa], sX[XS + pa], sX[2 * XS + pa]} + qrot(pq, V3{P.body_pos[3 * b], P.body_pos[3 * b + 1], P.body_pos[3 * b + 2]});
+          xq = qmul(pq, Q4{P.body_quat[4 * b], P.body_quat[4 * b + 1], P.body_quat[4 * b + 2], P.body_quat[4 * b + 3]});
+          const int jadr = P.body_jntadr[b], jnum = P.body_jntnum[b];
+          for (int jn = 0; jn < jnum; ++jn) {
+            const int j = jadr + jn, jt = P.jnt_type[j], qa = P.jnt_qadr[j];
+            const V3 axl{P.jnt_axis[3 * j], P.jnt_axis[3 * j + 1], P.jnt_axis[3 * j + 2]};
+            const V3 jp{P.jnt_pos[3 * j], P.jnt_pos[3 * j + 1], P.jnt_pos[3 * j + 2]};
+            if (jt == JNT_FREE) {
+              xp = {sq[qa], sq[qa + 1], sq[qa + 2]};
+              xq = qnormalize(Q4{sq[qa + 3], sq[qa + 4], sq[qa + 5], sq[qa + 6]});
+            }
+            // joint axis / anchor in the world, in the frame the joint acts in (before it is applied)
+            const V3 ax = qrot(xq, axl), an = xp + qrot(xq, jp);
+            double* o = sJnt + j * 6;
+            o[0] = ax.x; o[1] = ax.y; o[2] = ax.z; o[3] = an.x; o[4] = an.y; o[5] = an.z;
+            if (jt == JNT_SLIDE) {
+              xp = xp + (sq[qa] - P.jnt_qpos0[j]) * ax;
+            } else if (jt == JNT_HINGE || jt == JNT_BALL) {
+              const Q4 qloc = (jt == JNT_HINGE) ? axis_angle(axl, sq[qa] - P.jnt_qpos0[j])
+                                                : qnormalize(Q4{sq[qa], sq[qa + 1], sq[qa + 2], sq[qa + 3]});
+              xq = qmul(xq, qloc);
+              xp = an - qrot(xq, jp);
+            }
+          }
+          xq = qnormalize(xq);
+        }
+        sX[b] = xp.x; sX[XS + b] = xp.y; sX[2 * XS + b] = xp.z;
+        sX[3 * XS + b] = xq.w; sX[4 * XS + b] = xq.x; sX[5 * XS + b] = xq.y; sX[6 * XS + b] = xq.z;
+      }
+      __syncthreads();
+    }
+    // ------------------------------------------------------------ dof axes (cdof): jacp(p) = lin + ang × (p − anchor), jacr = ang
+    bool viol = false;
+    for (int d = tid; d < nv; d += NT_) {
+      const int kind = P.dof_kind[d], dk = P.dof_k[d], j = P.dof_jnt[d], body = P.dof_body[d], qa = P.dof_qadr[d];
+      V3 ang{0, 0, 0}, lin{0, 0, 0}, anchor{0, 0, 0};
+      double qd = 0.0;
+      const double* o = sJnt + j * 6;
+      if (kind == DOF_HINGE) { ang = {o[0], o[1], o[2]}; anchor = {o[3], o[4], o[5]}; qd = sq[qa]; }
+      else if (kind == DOF_SLIDE) { lin = {o[0], o[1], o[2]}; qd = sq[qa]; }
+      else if (kind == DOF_FREE_LIN) { lin = {dk == 0 ? 1.0 : 0.0, dk == 1 ? 1.0 : 0.0, dk == 2 ? 1.0 : 0.0}; }
+      else {                                               // ball / free rotational dof: body-frame axis k about the joint anchor
+        const M3 Rm = qmat(Q4{sX[3 * XS + body], sX[4 * XS + body], sX[5 * XS + body], sX[6 * XS + body]});
+        ang = (dk == 0) ? V3{Rm.m[0], Rm.m[3], Rm.m[6]} : ((dk == 1) ? V3{Rm.m[1], Rm.m[4], Rm.m[7]} : V3{Rm.m[2], Rm.m[5], Rm.m[8]});
+        anchor = (kind == DOF_FREE_ANG) ? V3{sX[body], sX[XS + body], sX[2 * XS + body]} : V3{o[3], o[4], o[5]};
+      }
+      // Configuration.check_limits (mink/configuration.py:77-110), tol = 1e-6 (a limited ball joint: the quaternion's w, first dof)
+      if (kind == DOF_HINGE || kind == DOF_SLIDE) viol = viol || qd < P.dof_lo[d] - 1e-6 || qd > P.dof_hi[d] + 1e-6;
+      if (kind == DOF_BALL && dk == 0) viol = viol || sq[qa] < P.dof_lo[d] - 1e-6 || sq[qa] > P.dof_hi[d] + 1e-6;
+      double* s = sDof + d * 10;
+      s[0] = ang.x; s[1] = ang.y; s[2] = ang.z; s[3] = lin.x; s[4] = lin.y; s[5] = lin.z;
+      s[6] = anchor.x; s[7] = anchor.y; s[8] = anchor.z; s[9] = qd;
+    }
+    if (__syncthreads_or(viol ? 1 : 0)) status |= 1;
+    // ------------------------------------------------------------ subtree CoM (mj_comPos) for ComTask
+    if (P.n_com > 0) {
+      for (int b = tid; b < nbody; b += NT_) {             // (a subtree is a contiguous id range in MuJoCo's depth-first order)
+        double sx = 0, sy = 0, sz = 0;
+        for (int c = b; c <= P.body_last[b]; ++c) {
+          if (!P.body_inrobot[c]) continue;
+          const Q4 cq{sX[3 * XS + c], sX[4 * XS + c], sX[5 * XS + c], sX[6 * XS + c]};
+          const V3 xi = V3{sX[c], sX[XS + c], sX[2 * XS + c]} + qrot(cq, V3{P.body_ipos[3 * c], P.body_ipos[3 * c + 1], P.body_ipos[3 * c + 2]});
+          sx += P.body_mass[c] * xi.x; sy += P.body_mass[c] * xi.y; sz += P.body_mass[c] * xi.z;
+        }
+        const double stm = P.body_stmass[b];
+        V3 cs;
+        if (stm >= 1e-15) { const double im = fast_rcp(stm); cs = {sx * im, sy * im, sz * im}; }
+        else {
+          const Q4 bq{sX[3 * XS + b], sX[4 * XS + b], sX[5 * XS + b], sX[6 * XS + b]};
+          cs = V3{sX[b], sX[XS + b], sX[2 * XS + b]} + qrot(bq, V3{P.body_ipos[3 * b], P.body_ipos[3 * b + 1], P.body_ipos[3 * b + 2]});
+        }
+        sCom[4 * b] = cs.x; sCom[4 * b + 1] = cs.y; sCom[4 * b + 2] = cs.z; sCom[4 * b + 3] = stm;
+      }
+      __syncthreads();
+    }
+    // ------------------------------------------------------------ frame tasks: pose, error, jlog (the task lanes of ik_kernel.h)
+    double mu_part = 0.0;                                  // Levenberg–Marquardt terms owned by this thread
+    for (int t = tid; t < P.n_frame; t += NT_) {
+      const FrameTaskDev& ft = P.frame[t];
+      SE3 F;
+      const Q4 bq{sX[3 * XS + ft.body], sX[4 * XS + ft.body], sX[5 * XS + ft.body], sX[6 * XS + ft.body]};
+      F.p = V3{sX[ft.body], sX[XS + ft.body], sX[2 * XS + ft.body]} + qrot(bq, V3{ft.lpos[0], ft.lpos[1], ft.lpos[2]});
+      F.q = qmul(bq, Q4{ft.lquat[0], ft.lquat[1], ft.lquat[2], ft.lquat[3]});
+      const double* tg = A.frame_targets + ((size_t)pb * P.n_frame + t) * 7;
+      const SE3 Tt{Q4{tg[0], tg[1], tg[2], tg[3]}, V3{tg[4], tg[5], tg[6]}};
+      double* o = sTask + t * 64;
+      V3 ev, ew;
+      double Jm[9], Qm[9];
+      bool ident;
+      if (!ft.relative) {
+        se3_log(se3_mul(se3_inv(F), Tt), ev, ew);          // e = target.minus(frame)  (frame_task.py:119-122)
+        se3_ljacinv(ev, ew, Jm, Qm, ident);                // jlog(T_tb) = ljacinv(e)   (frame_task.py:144-146)
+      } else {
+        const int rb = ft.root_body;
+        const Q4 rq0{sX[3 * XS + rb], sX[4 * XS + rb], sX[5 * XS + rb], sX[6 * XS + rb]};
+        SE3 Rt;
+        Rt.p = V3{sX[rb], sX[XS + rb], sX[2 * XS + rb]} + qrot(rq0, V3{ft.root_lpos[0], ft.root_lpos[1], ft.root_lpos[2]});
+        Rt.q = qmul(rq0, Q4{ft.root_lquat[0], ft.root_lquat[1], ft.root_lquat[2], ft.root_lquat[3]});
+        const SE3 Tfr = se3_mul(se3_inv(Rt), F);
+        se3_log(se3_mul(se3_inv(Tt), Tfr), ev, ew);        // e = T_fr.rminus(target)  (relative_frame_task.py:106-129)
+        se3_ljacinv(-1.0 * ev, -1.0 * ew, Jm, Qm, ident);
+        const SE3 Trf = se3_inv(Tfr);
+        const M3 Rr = qmat(Rt.q), Rrf = qmat(Trf.q);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { o[36 + i] = Rr.m[i]; o[48 + i] = Rrf.m[i]; }
+        o[45] = Rt.p.x; o[46] = Rt.p.y; o[47] = Rt.p.z;
+        o[57] = Trf.p.x; o[58] = Trf.p.y; o[59] = Trf.p.z;
+      }
+      const M3 Rf = qmat(F.q);
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { o[i] = Jm[i]; o[9 + i] = Qm[i]; o[18 + i] = Rf.m[i]; }
+      o[27] = F.p.x; o[28] = F.p.y; o[29] = F.p.z;
+      const double e6[6] = {ev.x, ev.y, ev.z, ew.x, ew.y, ew.z};
+      double ss = 0.0;
+      int c = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        const double we = ft.cost[r] * (-ft.gain * e6[r]);  // weighted_error (task.py:129-130)
+        ss += we * we;
+        if ((ft.rowmask >> r) & 1) { sWe[ft.jrow0 + c] = we; ++c; }
+      }
+      mu_part += ft.lm_damping * ss;                        // task.py:131
+    }
+    // ComTask error & LM term (com_task.py:71-82)
+    if (tid == 0)
+      for (int t = 0; t < P.n_com; ++t) {
+        const double* tg = A.com_target + (A.com_batched ? (size_t)pb * P.n_com * 3 : 0) + t * 3;
+        const double* cr = sCom + P.robot_root * 4;
+        double ss = 0.0;
+        int c = 0;
+        for (int r = 0; r < 3; ++r) {
+          const double we = P.com_cost[t][r] * (-P.com_gain[t] * (cr[r] - tg[r]));
+          ss += we * we;
+          if ((P.com_rowmask[t] >> r) & 1) { sWe[P.com_jrow0[t] + c] = we; ++c; }
+        }
+        mu_part += P.com_lm[t] * ss;
+      }
+    // caller-defined tasks: weighted errors and LM terms (task.py:129-131)
+    if (tid == 0)
+      for (int t = 0; t < P.n_dense_tasks; ++t) {
+        const double* de = A.dense_e + (size_t)pb * P.n_dense_rows + P.dense_row0[t];
+        double ss = 0.0;
+        for (int r = 0; r < P.dense_k[t]; ++r) {
+          const double we = P.dense_wgain[P.dense_row0[t] + r] * de[r];
+          sWe[R_task + P.dense_row0[t] + r] = we;
+          ss += we * we;
+        }
+        mu_part += P.dense_lm[t] * ss;
+      }
+    // ------------------------------------------------------------ posture tasks (diagonal; posture_task.py:87-142)
+    for (int d = tid; d < nv; d += NT_) { sC[d] = 0.0; sHd[d] = 0.0; }
+    __syncthreads();
+    for (int t = 0; t < P.n_posture; ++t) {
+      const double* tq = A.posture_target + (A.posture_batched ? ((size_t)pb * P.n_posture + t) * nq : (size_t)t * nq);
+      double ssw = 0.0;
+      for (int d = tid; d < nv; d += NT_) {
+        const int kind = P.dof_kind[d], dk = P.dof_k[d], qa = P.dof_qadr[d];
+        double e = 0.0, jd = 0.0;
+        if (kind == DOF_HINGE || kind == DOF_SLIDE) { e = tq[qa] - sDof[d * 10 + 9]; jd = -1.0; }     // mj_differentiatePos, dt = 1
+        else if (kind == DOF_BALL) {
+          const Q4 q1{sq[qa], sq[qa + 1], sq[qa + 2], sq[qa + 3]}, q2{tq[qa], tq[qa + 1], tq[qa + 2], tq[qa + 3]};
+          const V3 dv = quat2vel(qmul(qconj(q1), q2));
+          e = (dk == 0) ? dv.x : ((dk == 1) ? dv.y : dv.z);
+          jd = -1.0;
+        }                                                  // free-joint dofs: error and column zeroed (posture_task.py:115-116,139-141)
+        const double cost = P.posture_cost[(size_t)t * nv + d];
+        const double we = cost * (-P.posture_gain[t] * e), wj = cost * jd;
+        sHd[d] += wj * wj;
+        sC[d] -= we * wj;
+        ssw += we * we;
+      }
+      if (P.posture_lm[t] != 0.0) { const double s = block_sum(ssw); if (tid == 0) mu_part += P.posture_lm[t] * s; }
+    }
+    const double mu_total = A.damping + block_sum(mu_part);  // solve_ik.py:16 + Σ μ_t
+    // ------------------------------------------------------------ weighted Jacobian rows Jw[r][k] (weighted_jacobian, task.py:129)
+    for (int e = tid; e < P.n_frame * nv; e += NT_) {
+      const int t = e / nv, k = e - t * nv;
+      const FrameTaskDev& ft = P.frame[t];
+      const bool on_f = wide_on_chain(P, ft.body, k), rel = ft.relative != 0, on_r = rel && wide_on_chain(P, ft.root_body, k);
+      double Jt[6] = {0, 0, 0, 0, 0, 0};
+      if (on_f || on_r) wide_frame_column(sTask + t * 64, sDof + k * 10, on_f, rel, on_r, Jt);
+      int c = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+        if ((ft.rowmask >> r) & 1) { Jw[(size_t)(ft.jrow0 + c) * nv + k] = ft.cost[r] * Jt[r]; ++c; }
+    }
+    for (int e = tid; e < P.n_com * nv; e += NT_) {        // CoM Jacobian column (mj_jacSubtreeCom closed form)
+      const int t = e / nv, k = e - t * nv;
+      const int body = P.dof_body[k];
+      double Jt[3] = {0, 0, 0};
+      if (P.body_inrobot[body]) {
+        const double* cd = sCom + body * 4;
+        const double* kd = sDof + k * 10;
+        const double fac = cd[3] * fast_rcp(sCom[P.robot_root * 4 + 3]);
+        const V3 jc = fac * (V3{kd[3], kd[4], kd[5]} + cross(V3{kd[0], kd[1], kd[2]}, V3{cd[0], cd[1], cd[2]} - V3{kd[6], kd[7], kd[8]}));
+        Jt[0] = jc.x; Jt[1] = jc.y; Jt[2] = jc.z;
+      }
+      int c = 0;
+      for (int r = 0; r < 3; ++r)
+        if ((P.com_rowmask[t] >> r) & 1) { Jw[(size_t)(P.com_jrow0[t] + c) * nv + k] = P.com_cost[t][r] * Jt[r]; ++c; }
+    }
+    for (int e = tid; e < P.n_dense_rows * nv; e += NT_) {  // caller-defined rows: W·J straight from memory
+      const int r = e / nv, k = e - r * nv;
+      Jw[(size_t)(R_task + r) * nv + k] = P.dense_cost[r] * A.dense_J[((size_t)pb * P.n_dense_rows + r) * nv + k];
+    }
+    __syncthreads();
+    // c = −weighted_errorᵀ·weighted_jacobian (task.py:133-134)
+    for (int k = tid; k < nv; k += NT_) {
+      double c = sC[k];
+      for (int r = 0; r < R_all; ++r) c -= sWe[r] * Jw[(size_t)r * nv + k];
+      sC[k] = c;
+    }
+    // ------------------------------------------------------------ box limits (configuration_limit.py:94-124, velocity_limit.py:96-101)
+    bool box_bad = false;
+    for (int d = tid; d < nv; d += NT_) {
+      double lo = -kInf, hi = kInf;
+      const int kind = P.dof_kind[d], dk = P.dof_k[d], qa = P.dof_qadr[d];
+      const double qd = sDof[d * 10 + 9];
+      for (int t = 0; t < P.n_cfg; ++t) {
+        const double lw = P.cfg_lower[(size_t)t * nv + d], up = P.cfg_upper[(size_t)t * nv + d];
+        if (kind == DOF_BALL) {                            // (a limited ball joint: the reference differentiates quaternions, see ik_kernel.h)
+          const Q4 qc{sq[qa], sq[qa + 1], sq[qa + 2], sq[qa + 3]};
+          if (up < kInf) {
+            const V3 dv = quat2vel(qmul(qconj(qc), Q4{up, up, up, up}));
+            hi = fmin(hi, P.cfg_gain[t] * ((dk == 0) ? dv.x : ((dk == 1) ? dv.y : dv.z)));
+          }
+          if (lw > -kInf) {
+            const V3 dv = quat2vel(qmul(qconj(Q4{lw, lw, lw, lw}), qc));
+            lo = fmax(lo, -(P.cfg_gain[t] * ((dk == 0) ? dv.x : ((dk == 1) ? dv.y : dv.z))));
+          }
+          continue;
+        }
+        if (up < kInf) hi = fmin(hi, P.cfg_gain[t] * (up - qd));
+        if (lw > -kInf) lo = fmax(lo, -(P.cfg_gain[t] * (qd - lw)));
+      }
+      for (int t = 0; t < P.n_vel; ++t) {
+        const double vm = P.vel_limit[(size_t)t * nv + d];
+        if (vm < kInf) { hi = fmin(hi, A.dt * vm); lo = fmax(lo, -(A.dt * vm)); }
+      }
+      if (A.dense_lo) lo = fmax(lo, A.dense_lo[(size_t)pb * nv + d]);
+      if (A.dense_hi) hi = fmin(hi, A.dense_hi[(size_t)pb * nv + d]);
+      sLo[d] = lo; sHi[d] = hi;
+      box_bad = box_bad || lo > hi + 1e-12;
+    }
+    if (__syncthreads_or(box_bad ? 1 : 0)) status |= 2;              // inconsistent box ⇒ quadprog "constraints are inconsistent"
+    // ------------------------------------------------------------ contacts (collision_avoidance_limit.py:187-229): every one a row
+    // each wavefront takes kGjkSlots pairs per trip (GJK keeps its simplex in the wave's LDS workspace)
+    for (int base = 0; base < P.n_pairs; base += 4 * kGjkSlots) {
+      const int pi = base + wave * kGjkSlots + lane;
+      const bool want = lane < kGjkSlots && pi < P.n_pairs;
+      double dist = 0.0;
+      V3 from{0, 0, 0}, to{0, 0, 0};
+      bool need_epa = false;
+      auto poses = [&](const CollisionPairDev& cp, V3& gp1, Q4& gq1, V3& gp2, Q4& gq2) {
+        const int b1 = cp.body1, b2 = cp.body2;
+        const Q4 bq1{sX[3 * XS + b1], sX[4 * XS + b1], sX[5 * XS + b1], sX[6 * XS + b1]}, bq2{sX[3 * XS + b2], sX[4 * XS + b2], sX[5 * XS + b2], sX[6 * XS + b2]};
+        gp1 = V3{sX[b1], sX[XS + b1], sX[2 * XS + b1]} + qrot(bq1, V3{cp.lpos1[0], cp.lpos1[1], cp.lpos1[2]});
+        gp2 = V3{sX[b2], sX[XS + b2], sX[2 * XS + b2]} + qrot(bq2, V3{cp.lpos2[0], cp.lpos2[1], cp.lpos2[2]});
+        gq1 = qmul(bq1, Q4{cp.lquat1[0], cp.lquat1[1], cp.lquat1[2], cp.lquat1[3]});
+        gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
+      };
+      if (want) {
+        const CollisionPairDev& cp = P.pairs[pi];
+        V3 gp1, gp2; Q4 gq1, gq2;
+        poses(cp, gp1, gq1, gp2, gq2);
+        geom_distance<false, true>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
+                                   V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to,
+                                   cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, &need_epa, sCws + lane);
+      }
+      // pairs whose cores overlap: one at a time, this wavefront cooperating on the expanding polytope
+      for (unsigned long long em = __ballot(want && need_epa); em; em &= em - 1) {
+        const int l = (int)__builtin_ctzll(em);
+        const CollisionPairDev& cp = P.pairs[base + wave * kGjkSlots + l];
+        V3 gp1, gp2; Q4 gq1, gq2;
+        poses(cp, gp1, gq1, gp2, gq2);
+        double d_e; V3 f_e, t_e;
+        geom_overlap_distance(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
+                              V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, d_e, f_e, t_e, cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, sCws);
+        if (lane == l) { dist = d_e; from = f_e; to = t_e; }
+      }
+      if (want) {
+        const CollisionPairDev& cp = P.pairs[pi];
+        double* o = rec + (size_t)pi * 10;
+        double hk = kInf;
+        if (dist != cp.ddetect) {                            // Contact.inactive (:52-56)
+          hk = (dist > cp.dmin) ? (cp.gain * (dist - cp.dmin) / A.dt) + cp.relax : cp.relax;      // :200-205
+          V3 nrm = to - from;                                // Contact.normal (:46-50)
+          const double nn = sqrt(dot(nrm, nrm));
+          nrm = (nn < 1e-15) ? V3{1.0, 0.0, 0.0} : fast_rcp(nn) * nrm;
+          o[1] = nrm.x; o[2] = nrm.y; o[3] = nrm.z; o[4] = from.x; o[5] = from.y; o[6] = from.z; o[7] = to.x; o[8] = to.y; o[9] = to.z;
+        }
+        o[0] = hk;
+      }
+    }
+    __syncthreads();
+    // row order: the detected contacts in pair order, then the caller's rows with a finite bound
+    if (tid == 0) {
+      int m = 0, over = 0;
+      for (int pi = 0; pi < P.n_pairs; ++pi)
+        if (rec[(size_t)pi * 10] < kInf) { if (m < P.max_rows) rowpair[m++] = pi; else over = 1; }
+      for (int r = 0; r < P.n_dense_limit_rows; ++r)
+        if (A.dense_h[(size_t)pb * P.n_dense_limit_rows + r] < kInf) { if (m < P.max_rows) rowpair[m++] = -1 - r; else over = 1; }
+      sRedI[0] = m; sRedI[1] = over;
+    }
+    __syncthreads();
+    const int m = sRedI[0];
+    if (sRedI[1]) status |= 16;                              // (more rows than the workspace holds: kWideMaxRows)
+    const int N = nv + m;
+    __syncthreads();
+    // ------------------------------------------------------------ tableau K = [[H, Aᵀ],[A, 0]], z, w, states
+    for (int e = tid; e < nv * nv; e += NT_) {               // H = λI + Σ JwᵀJw (+ the posture tasks' diagonal)
+      const int i = e / nv, j = e - i * nv;
+      if (j < i) continue;
+      double s = 0.0;
+      for (int r = 0; r < R_all; ++r) s += Jw[(size_t)r * nv + i] * Jw[(size_t)r * nv + j];
+      if (i == j) s += mu_total + sHd[i];
+      T[(size_t)i * N + j] = s; T[(size_t)j * N + i] = s;
+    }
+    for (int e = tid; e < m * nv; e += NT_) {                // A: G[s][k] = −nᵀ(jacp₂(to) − jacp₁(from))   (compute_contact_normal_jacobian :59-72)
+      const int s = e / nv, k = e - s * nv;
+      const int rp = rowpair[s];
+      double a;
+      if (rp >= 0) {
+        const CollisionPairDev& cp = P.pairs[rp];
+        const double* o = rec + (size_t)rp * 10;
+        const double* kd = sDof + k * 10;
+        const V3 d_ang{kd[0], kd[1], kd[2]}, d_lin{kd[3], kd[4], kd[5]}, d_anchor{kd[6], kd[7], kd[8]};
+        V3 dj{0, 0, 0};
+        if (wide_on_chain(P, cp.body2, k)) dj = dj + d_lin + cross(d_ang, V3{o[7], o[8], o[9]} - d_anchor);
+        if (wide_on_chain(P, cp.body1, k)) dj = dj - (d_lin + cross(d_ang, V3{o[4], o[5], o[6]} - d_anchor));
+        a = -dot(V3{o[1], o[2], o[3]}, dj);
+      } else {
+        a = A.dense_G[((size_t)pb * P.n_dense_limit_rows + (-1 - rp)) * nv + k];
+      }
+      T[(size_t)(nv + s) * N + k] = a; T[(size_t)k * N + nv + s] = a;
+    }
+    for (int e = tid; e < m * m; e += NT_) T[(size_t)(nv + e / m) * N + nv + e % m] = 0.0;
+    for (int i = tid; i < N; i += NT_) {
+      sZ[i] = 0.0;
+      if (i < nv) { sW[i] = sC[i]; sState[i] = WS_ZERO; sRown[i] = 1.0; }
+      else {
+        const int rp = rowpair[i - nv];
+        sW[i] = -(rp >= 0 ? rec[(size_t)rp * 10] : A.dense_h[(size_t)pb * P.n_dense_limit_rows + (-1 - rp)]);     // w = A·0 − h
+        sState[i] = WS_ROW_OFF;
+      }
+    }
+    __syncthreads();
+    for (int s = tid; s < m; s += NT_) {
+      double nn = 0.0;
+      for (int k = 0; k < nv; ++k) { const double a = T[(size_t)(nv + s) * N + k]; nn += a * a; }
+      sRown[nv + s] = nn > 0.0 ? sqrt(nn) : 1.0;
+    }
+    __syncthreads();
+    // ------------------------------------------------------------ the QP: dual active set on the sweep tableau
+    // step(p, α): z −= α·τ on the basic indices, w += α·τ on the others (τ = column p); p itself: w_p += α when basic, z_p += α when not
+    auto take_column = [&](int p) {
+      for (int i = tid; i < N; i += NT_) sCol[i] = T[(size_t)i * N + p];
+      __syncthreads();
+    };
+    auto step = [&](int p, double alpha, bool p_basic) {     // (sCol holds column p)
+      for (int i = tid; i < N; i += NT_) {
+        const int st = sState[i];
+        if (st == WS_FREE || st == WS_ROW_ON) sZ[i] -= alpha * sCol[i]; else sW[i] += alpha * sCol[i];
+      }
+      __syncthreads();
+      if (tid == 0) { if (p_basic) sW[p] += alpha; else sZ[p] += alpha; }
+      __syncthreads();
+    };
+    auto sweep = [&](int k, bool reverse) {                  // (sCol holds column k)
+      const double d = sCol[k], inv = 1.0 / d, sg = reverse ? -1.0 : 1.0;
+      for (int e = tid; e < N * N; e += NT_) {
+        const int i = e / N, j = e - i * N;
+        double v;
+        if (i == k && j == k) v = -inv;
+        else if (i == k) v = sg * sCol[j] * inv;
+        else if (j == k) v = sg * sCol[i] * inv;
+        else v = T[e] - sCol[i] * sCol[j] * inv;
+        T[e] = v;
+      }
+      __syncthreads();
+    };
+    int iters = 0;
+    const int max_iters = 20 * (N + 4);
+    if (!(status & 14) && A.do_qp) {
+      // phase 0: bring every dof into the basis (x0 = −H⁻¹c), no ratio tests
+      for (int k = 0; k < nv; ++k) {
+        take_column(k);
+        const double d = sCol[k];
+        if (!(d > 0.0)) { status |= 4; break; }
+        const double wk = sW[k];
+        __syncthreads();
+        step(k, -wk / d, false);
+        if (tid == 0) { sW[k] = 0.0; sState[k] = WS_FREE; }
+        sweep(k, false);
+      }
+      for (int i = tid; i < N; i += NT_) { const double r = fabs(T[(size_t)i * N + i]); sRef[i] = r == 0.0 ? 1.0 : r; }
+      __syncthreads();
+      while (!(status & 14)) {
+        // most violated primal condition among basic dofs / inactive rows
+        double bv = 0.0; int bi = -1;
+        for (int i = tid; i < N; i += NT_) {
+          double v = -kInf;
+          if (sState[i] == WS_FREE) v = fmax(sZ[i] - sHi[i], sLo[i] - sZ[i]);
+          else if (sState[i] == WS_ROW_OFF) v = sW[i] / sRown[i];
+          if (v > 1e-12 && (bi < 0 || v > bv)) { bv = v; bi = i; }
+        }
+        double pv; int p;
+        block_arg(bv, bi, true, pv, p);
+        if (p < 0) break;                                    // optimal
+        const bool p_basic = sState[p] == WS_FREE;
+        const bool upper = p_basic && (sZ[p] - sHi[p] > sLo[p] - sZ[p]);
+        const double beta = p_basic ? (upper ? sHi[p] : sLo[p]) : 0.0;
+        const double sgn = p_basic ? (upper ? -1.0 : 1.0) : 1.0;
+        for (;;) {
+          if (++iters > max_iters) { status |= 8; break; }
+          take_column(p);
+          const double tpp = sCol[p];
+          double full = kInf;
+          if (p_basic) { if (fabs(tpp) > 1e-12 * sRef[p]) full = (sZ[p] - beta) / tpp; }
+          else if (-tpp > 1e-12 * sRef[p]) full = -sW[p] / tpp;
+          const double t2 = fabs(full);
+          // ratio test on dual feasibility, α = sgn·t, t ≥ 0
+          double t1v = kInf; int t1i = -1;
+          for (int i = tid; i < N; i += NT_) {
+            if (i == p) continue;
+            const double r = sgn * sCol[i];
+            const int st = sState[i];
+            double t = kInf;
+            if (st == WS_ROW_ON) { if (r > 0.0) t = sZ[i] / r; }
+            else if (st == WS_AT_HI) { if (r > 0.0) t = -sW[i] / r; }
+            else if (st == WS_AT_LO) { if (r < 0.0) t = sW[i] / -r; }
+            if (t < kInf && (t1i < 0 || t < t1v)) { t1v = t; t1i = i; }
+          }
+          double t1; int l;
+          block_arg(t1v, t1i, false, t1, l);
+          if (l < 0) t1 = kInf;
+          if (!(fmin(t1, t2) < kInf)) { status |= 2; break; }            // no step possible: infeasible
+          if (t2 <= t1) {
+            step(p, sgn * t2, p_basic);
+            if (tid == 0) {
+              if (p_basic) { sZ[p] = beta; sState[p] = upper ? WS_AT_HI : WS_AT_LO; }
+              else { sW[p] = 0.0; sState[p] = WS_ROW_ON; }
+            }
+            sweep(p, p_basic);
+            break;
+          }
+          step(p, sgn * t1, p_basic);
+          const bool l_row = sState[l] == WS_ROW_ON;
+          __syncthreads();
+          if (tid == 0) {
+            if (l_row) { sZ[l] = 0.0; sState[l] = WS_ROW_OFF; }
+            else { sW[l] = 0.0; sState[l] = WS_FREE; }
+          }
+          take_column(l);
+          sweep(l, l_row);
+        }
+      }
+    }
+    // ------------------------------------------------------------ v = Δq / dt (solve_ik.py:104)
+    if (A.v_out) {
+      const bool ok = !(status & 14);
+      for (int d = tid; d < nv; d += NT_) A.v_out[(size_t)pb * nv + d] = ok ? sZ[d] / A.dt : __builtin_nan("");
+    }
+    if (A.status_out && tid == 0) A.status_out[pb] = status;
+  }
+}
+
+}  // namespace mkh

@@ -1,0 +1,49 @@
+// Descriptor of the workgroup-per-problem kernel (wide_kernel.h), shared with the host side (minkhip.hip build_wide_problem).
+#pragma once
+#include <stdint.h>
+
+#include "mkh_types.h"
+
+namespace mkh {
+
+constexpr int kWideThreads = 256;
+constexpr int kWideMaxRows = 448;          // half-space rows of one instance (contacts in range + caller's rows); more: MKH_ST_ROW_OVERFLOW
+
+struct WideProblem {
+  int32_t nq, nv, nbody, njnt, nlevels, chain_words;
+  int32_t n_frame, n_posture, n_com, n_cfg, n_vel, n_pairs, n_jrows;
+  int32_t n_dense_tasks, n_dense_rows, n_dense_limit_rows, dense_box, robot_root;
+  int32_t max_rows;                        // row capacity of the tableau workspace (≤ kWideMaxRows)
+  int32_t tableau_in_lds;
+  // LDS offsets (doubles)
+  int32_t o_q, o_X, o_jnt, o_dof, o_task, o_com, o_we, o_c, o_hd, o_z, o_w, o_lo, o_hi, o_rown, o_ref, o_col, o_red, o_state, o_cws, o_T,
+      lds_doubles;
+  // model (plain arrays)
+  const int32_t *level_start, *level_body, *body_parent, *body_jntadr, *body_jntnum, *body_last, *body_inrobot;
+  const double *body_pos, *body_quat, *body_ipos, *body_mass, *body_stmass;
+  const int32_t *jnt_type, *jnt_qadr;
+  const double *jnt_axis, *jnt_pos, *jnt_qpos0;
+  const int32_t *dof_jnt, *dof_kind, *dof_k, *dof_body, *dof_qadr;
+  const double *dof_lo, *dof_hi;           // joint range seen by check_limits (±inf: none)
+  const uint64_t* chain;                   // [nbody][chain_words]: dofs that move body b (mj_jac's ancestor walk)
+  // tasks
+  const FrameTaskDev* frame;
+  const double* posture_cost;              // [n_posture][nv]
+  double posture_gain[kMaxPostureTasks], posture_lm[kMaxPostureTasks];
+  double com_cost[kMaxComTasks][3], com_gain[kMaxComTasks], com_lm[kMaxComTasks];
+  int32_t com_rowmask[kMaxComTasks], com_jrow0[kMaxComTasks];
+  int32_t dense_row0[kMaxDenseTasks], dense_k[kMaxDenseTasks];
+  double dense_lm[kMaxDenseTasks];
+  const double *dense_cost, *dense_wgain;
+  // limits
+  const double *cfg_lower, *cfg_upper;     // [n_cfg][nv]
+  double cfg_gain[kMaxBoxTerms];
+  const double* vel_limit;                 // [n_vel][nv]
+  const CollisionPairDev* pairs;
+  // per-workgroup slice of device memory: weighted Jacobian rows, pair records, row → pair map, (the tableau)
+  double* ws;
+  long long ws_stride;                     // doubles per workgroup
+  long long ws_jw, ws_rec, ws_rowpair, ws_T;
+};
+
+}  // namespace mkh
