@@ -168,7 +168,7 @@ int launch_variant(int nt, int nr, int feat, bool w3, int grid, int lds_bytes, h
                    const SolveArgs& a, const TapArgs* taps);
 int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);
 int launch_quad(int nt, bool loop, int grid, hipStream_t stream, const LaneProblem* P, const LaneDims& dims, const SolveArgs& a);   // returns its LDS bytes per wavefront
-int launch_wide(int grid, int lds_bytes, hipStream_t stream, const WideProblem* P, const SolveArgs& a);
+int launch_wide(int grid, int lds_bytes, hipStream_t stream, const WideProblem* P, const SolveArgs& a, const TapArgs* taps);
 constexpr int kLaneMinBatchLoop = 28672;  // fused loops of a small arm: row kernel below, lane kernel from here (M targets/s at 16 384: 39.7 vs 24.1, at 32 768: 42.4 vs 48.2)
 constexpr int kLaneMinBatch = 73728;  // plain solves of a small arm: row kernel below, lane kernel from here (launch())
 }
@@ -469,12 +469,12 @@ static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhPro
 }
 
 // one launch of the workgroup-per-problem kernel: every instance (redo_mask = 0) or the ones a wavefront kernel flagged
-static int32_t launch_wide_kernel(MkhProblem* p, const SolveArgs& a, hipStream_t stream, int32_t redo_mask) {
+static int32_t launch_wide_kernel(MkhProblem* p, const SolveArgs& a, hipStream_t stream, int32_t redo_mask, const TapArgs* dtaps = nullptr) {
   SolveArgs aw = a;
   aw.redo_mask = redo_mask;
   int grid = p->wide_grid < a.B ? p->wide_grid : a.B;
   if (grid < 1) grid = 1;
-  const int rc = mkh::launch_wide(grid, p->wide_lds, stream, p->d_wide, aw);
+  const int rc = mkh::launch_wide(grid, p->wide_lds, stream, p->d_wide, aw, dtaps);
   if (rc != 0) return fail(MKH_E_HIP, "wide kernel: %s", hipGetErrorString((hipError_t)rc));
   HIP_OK(hipGetLastError());
   return MKH_OK;
@@ -875,6 +875,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     const int32_t rc = build_wide_problem(p, m, d, ft, pairs, dcost, dwgain);
     if (rc != MKH_OK) return bail(rc);
     p->wide_only = true;
+    if (hipMalloc((void**)&p->d_taps, sizeof(TapArgs)) != hipSuccess) return bail(fail(MKH_E_HIP, "descriptor upload failed"));
     snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_wide_kernel");
     *out = p;
     return MKH_OK;
@@ -1185,12 +1186,18 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   SolveArgs a = a_in;
   if (!a.status_out && p->d_status_tight && a.do_qp) a.status_out = p->d_status_tight;
   if (p->wide_only) {
-    if (taps || a.n_steps > 1 || a.pos_threshold >= 0.0)
+    if ((taps && (taps->t_task_e || taps->t_task_J || taps->t_qp_iters || taps->t_cycles)) || a.n_steps > 1 || a.pos_threshold >= 0.0)
       return fail(MKH_E_INVALID, "models beyond one wavefront (more than 64 bodies or dofs) run on the workgroup-per-problem kernel: "
-                                 "no parity taps, no fused loops (call mkh_solve and mkh_integrate in turn)");
+                                 "no per-task (e, J) / iteration taps, no fused loops (call mkh_solve and mkh_integrate in turn)");
+    const TapArgs* dt_ = nullptr;
+    if (taps) {
+      HIP_OK(hipMemcpyAsync(p->d_taps, taps, sizeof(TapArgs), hipMemcpyHostToDevice, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+      dt_ = p->d_taps;
+    }
     snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_wide_kernel");
     p->last_grid = p->wide_grid < a.B ? p->wide_grid : a.B; p->last_lds = p->wide_lds; p->last_nt = p->wide.nv + p->wide.max_rows;
-    return launch_wide_kernel(p, a, stream, 0);
+    return launch_wide_kernel(p, a, stream, 0, dt_);
   }
   // (plain solves of a problem whose rows can outnumber the tableau's: the flagged instances once more, with every row)
   const bool wide_redo = p->d_wide && a.do_qp && a.status_out && !taps && a.n_steps <= 1 && !(a.pos_threshold >= 0.0);

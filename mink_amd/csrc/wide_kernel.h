@@ -76,7 +76,7 @@ __device__ __forceinline__ void wide_frame_column(const double* o, const double*
 // index states of the active-set iteration (tools/proto_tableau_qp.py)
 enum { WS_FREE = 0, WS_AT_LO = 1, WS_AT_HI = 2, WS_ROW_OFF = 3, WS_ROW_ON = 4, WS_ZERO = 5 };
 
-__global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem* __restrict__ Pg, SolveArgs A) {
+__global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem* __restrict__ Pg, SolveArgs A, const TapArgs* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const WideProblem& P = *Pg;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, NT_ = kWideThreads;
@@ -108,6 +108,9 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
   int* const rowpair = reinterpret_cast<int*>(wsb + P.ws_rowpair);
   double* const T = P.tableau_in_lds ? smem + P.o_T : wsb + P.ws_T;
   const int R_task = P.n_jrows, R_all = P.n_jrows + P.n_dense_rows;
+  // parity taps (mkh_eval): body poses, frame poses, subtree CoM, H, c, the box, the contact rows — what the reference's
+  // Configuration / build_ik expose; the per-task (e, J) taps are the wavefront kernels'
+#define MKH_WTAP(f) (tp ? tp->f : nullptr)
 
   auto block_sum = [&](double x) -> double {
     x = wave_sum(x);
@@ -181,6 +184,10 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       }
       __syncthreads();
     }
+    if (MKH_WTAP(t_xpos))
+      for (int e = tid; e < nbody * 3; e += NT_) MKH_WTAP(t_xpos)[(size_t)pb * nbody * 3 + e] = sX[(e % 3) * XS + e / 3];
+    if (MKH_WTAP(t_xquat))
+      for (int e = tid; e < nbody * 4; e += NT_) MKH_WTAP(t_xquat)[(size_t)pb * nbody * 4 + e] = sX[(3 + e % 4) * XS + e / 4];
     // ------------------------------------------------------------ dof axes (cdof): jacp(p) = lin + ang × (p − anchor), jacr = ang
     bool viol = false;
     for (int d = tid; d < nv; d += NT_) {
@@ -272,7 +279,21 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
         if ((ft.rowmask >> r) & 1) { sWe[ft.jrow0 + c] = we; ++c; }
       }
       mu_part += ft.lm_damping * ss;                        // task.py:131
+      if (MKH_WTAP(t_frame_pose)) {                          // pose of the frame in the world (RelativeFrameTask: in its root frame)
+        SE3 Fo = F;
+        if (ft.relative) {
+          const int rb = ft.root_body;
+          const Q4 rq0{sX[3 * XS + rb], sX[4 * XS + rb], sX[5 * XS + rb], sX[6 * XS + rb]};
+          SE3 Rt;
+          Rt.p = V3{sX[rb], sX[XS + rb], sX[2 * XS + rb]} + qrot(rq0, V3{ft.root_lpos[0], ft.root_lpos[1], ft.root_lpos[2]});
+          Rt.q = qmul(rq0, Q4{ft.root_lquat[0], ft.root_lquat[1], ft.root_lquat[2], ft.root_lquat[3]});
+          Fo = se3_mul(se3_inv(Rt), F);
+        }
+        double* t7 = MKH_WTAP(t_frame_pose) + ((size_t)pb * P.n_frame + t) * 7;
+        t7[0] = Fo.q.w; t7[1] = Fo.q.x; t7[2] = Fo.q.y; t7[3] = Fo.q.z; t7[4] = Fo.p.x; t7[5] = Fo.p.y; t7[6] = Fo.p.z;
+      }
     }
+    if (MKH_WTAP(t_subtree_com) && P.n_com > 0 && tid < 3) MKH_WTAP(t_subtree_com)[(size_t)pb * 3 + tid] = sCom[P.robot_root * 4 + tid];
     // ComTask error & LM term (com_task.py:71-82)
     if (tid == 0)
       for (int t = 0; t < P.n_com; ++t) {
@@ -392,6 +413,8 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       if (A.dense_lo) lo = fmax(lo, A.dense_lo[(size_t)pb * nv + d]);
       if (A.dense_hi) hi = fmin(hi, A.dense_hi[(size_t)pb * nv + d]);
       sLo[d] = lo; sHi[d] = hi;
+      if (MKH_WTAP(t_box_lo)) MKH_WTAP(t_box_lo)[(size_t)pb * nv + d] = lo;
+      if (MKH_WTAP(t_box_hi)) MKH_WTAP(t_box_hi)[(size_t)pb * nv + d] = hi;
       box_bad = box_bad || lo > hi + 1e-12;
     }
     if (__syncthreads_or(box_bad ? 1 : 0)) status |= 2;              // inconsistent box ⇒ quadprog "constraints are inconsistent"
@@ -503,6 +526,17 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       sRown[nv + s] = nn > 0.0 ? sqrt(nn) : 1.0;
     }
     __syncthreads();
+    if (tp) {
+      if (tp->t_H) for (int e = tid; e < nv * nv; e += NT_) tp->t_H[(size_t)pb * nv * nv + e] = T[(size_t)(e / nv) * N + e % nv];
+      if (tp->t_c) for (int k = tid; k < nv; k += NT_) tp->t_c[(size_t)pb * nv + k] = sC[k];
+      if (tp->t_coll_h) for (int pi = tid; pi < P.n_pairs; pi += NT_) tp->t_coll_h[(size_t)pb * P.n_pairs + pi] = rec[(size_t)pi * 10];
+      if (tp->t_coll_G)                                       // the row of EVERY detected contact (build_ik returns them all)
+        for (int e = tid; e < m * nv; e += NT_) {
+          const int rp = rowpair[e / nv];
+          if (rp >= 0) tp->t_coll_G[((size_t)pb * P.n_pairs + rp) * nv + e % nv] = T[(size_t)(nv + e / nv) * N + e % nv];
+        }
+      __syncthreads();
+    }
     // ------------------------------------------------------------ the QP: dual active set on the sweep tableau
     // step(p, α): z −= α·τ on the basic indices, w += α·τ on the others (τ = column p); p itself: w_p += α when basic, z_p += α when not
     auto take_column = [&](int p) {

@@ -150,13 +150,16 @@ def _compile(configuration: Configuration, tasks: Sequence, limits: Optional[Seq
         lo = np.maximum.reduce([f[0] for f in folded]); hi = np.minimum.reduce([f[1] for f in folded])
         if any(f[4] for f in folded):          # (structural: a box limit whose rows are all inactive now keeps its handle)
             layout["dense_box"] = (lo, hi)
-        cap = 64 - configuration.nv
+        # (more general rows than the 64 − nv a wavefront holds: the instances in which that many are active are solved again by
+        #  the workgroup-per-problem kernel with every row, as the reference's np.vstack would — mink/solve_ik.py:25-40; its
+        #  workspace holds 448 rows per instance)
+        cap = 448
         if layout["dense_limit_rows"] > cap:
             names = ", ".join(type(lim).__name__ for lim in layout["dense_limits"])
             raise exceptions.LimitDefinitionError(
                 f"caller-defined limits ({names}) contribute {layout['dense_limit_rows']} general rows G·Δq ≤ h (rows with a "
-                f"single nonzero entry are folded into the per-dof box and do not count); one wavefront holds at most "
-                f"64 − nv = {cap} half-space rows per instance for this model, shared with collision contacts")
+                f"single nonzero entry are folded into the per-dof box and do not count); at most {cap} half-space rows per "
+                f"instance, shared with collision contacts")
     key = (_key(groups), batch, layout["dense_limit_rows"], layout.get("dense_box") is not None)
     cache = configuration._problems
     prob = cache.pop(key, None)

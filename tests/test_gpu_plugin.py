@@ -305,10 +305,33 @@ def test_user_box_rows_on_g1_do_not_use_tableau_rows():
         v_ref = oik2.solve_ik(mo, q[i], otasks, dt_o, damp_o, olims)
         np.testing.assert_allclose(v_m[i], v_ref, rtol=0, atol=1e-8 * max(1.0, np.abs(v_ref).max()))
 
+    # More general rows than the 64 − nv = 21 a wavefront holds: round 3 refused them (LimitDefinitionError); the reference
+    # stacks any number (mink/solve_ik.py:25-40).  Now the wavefront kernel keeps the tightest 21 and the instances in which a
+    # dropped row is violated are solved again by the workgroup-per-problem kernel with all 30 — the oracle's answer.
+    class Many(mink.Limit):
+        def compute_qp_inequalities(self, configuration, dt):
+            rng2 = np.random.default_rng(0)
+            G30 = np.zeros((30, m.nv)); G30[:, 6:] = rng2.normal(size=(30, m.nv - 6))
+            return mink.Constraint(G=G30, h=np.full(30, 2e-3))
+
+    v_w, st_w = mink.solve_ik(cfg, tasks, 5e-3, "mi355x", 1e-1, limits=[mink.ConfigurationLimit(m), Many()], return_status=True)
+    assert (st_w & ~1 == 0).all(), np.unique(st_w)
+    assert list(cfg._problems.values())[-1].last_kernel().endswith("+wide")
+    cm = Many().compute_qp_inequalities(cfg, 5e-3)
+    assert ((cm.G @ (v_w * 5e-3).T).T <= cm.h + 1e-10).all()
+    nbind = 0
+    for i in range(0, B, 12):
+        fts = np.stack([t.transform_target_to_world.wxyz_xyz[i] for t in tasks[:4]])
+        mo, otasks, olims, dt_o, damp_o = oc2.g1_c3(fts, stand)
+        v_ref = oik2.solve_ik(mo, q[i], otasks, dt_o, damp_o, [olims[0], oik2.DenseLimitSpec(cm.G, cm.h)])
+        np.testing.assert_allclose(v_w[i], v_ref, rtol=0, atol=1e-8 * max(1.0, np.abs(v_ref).max()))
+        nbind = max(nbind, int((np.abs(cm.G @ (v_ref * dt_o) - cm.h) < 1e-9).sum()))
+    print("30 general rows on G1: up to %d binding at the solution" % nbind)
+
     class TooMany(mink.Limit):
         def compute_qp_inequalities(self, configuration, dt):
             rng2 = np.random.default_rng(0)
-            return mink.Constraint(G=rng2.normal(size=(30, m.nv)), h=np.ones(30))
+            return mink.Constraint(G=rng2.normal(size=(460, m.nv)), h=np.ones(460))
 
     with pytest.raises(mink.LimitDefinitionError, match="general rows"):
         mink.solve_ik(cfg, tasks, 5e-3, "mi355x", 1e-1, limits=[TooMany()])
