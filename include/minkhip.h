@@ -47,7 +47,8 @@ extern "C" {
 #define MKH_E_INVALID (-1)   /* bad argument / unsupported model feature   */
 #define MKH_E_HIP (-2)       /* HIP runtime error (message has the detail)  */
 #define MKH_E_NOGPU (-3)     /* no gfx950 device visible                    */
-#define MKH_E_LIMIT (-4)     /* model exceeds a compiled-in size limit      */
+#define MKH_E_LIMIT (-4)     /* exceeds a compiled-in size limit (4096 bodies, 1024 dofs, 16 frame tasks, ...; models
+                                beyond 64 bodies or 64 dofs run, on the workgroup-per-problem kernel) */
 
 /* per-instance status bits written to status_out */
 #define MKH_ST_OK 0
@@ -55,8 +56,12 @@ extern "C" {
 #define MKH_ST_INFEASIBLE 2      /* constraints inconsistent (quadprog "no solution" → mink/solve_ik.py:103 assert) */
 #define MKH_ST_NOT_PD 4          /* H not positive definite (quadprog "matrix G is not positive definite") */
 #define MKH_ST_ITER_LIMIT 8      /* active-set iteration cap hit */
-#define MKH_ST_ROW_OVERFLOW 16   /* more simultaneously detected contacts than tableau rows (64 - nv) AND a contact that found no
-                                    row is violated at the solution (the tightest contacts get the rows; the rest are checked) */
+#define MKH_ST_ROW_OVERFLOW 16   /* more half-space rows active at once than the solve could hold AND a row that found no place is
+                                    violated at the solution.  Plain solves (mkh_solve / mkh_solve_dense) never return it below 448
+                                    rows per instance: a wavefront kernel holds 64 - nv rows (the tightest contacts get them, the rest
+                                    are checked at the solution), and the instances it flags are solved again with EVERY row by the
+                                    workgroup-per-problem kernel.  The fused loops (mkh_solve_steps / mkh_solve_until) and calls
+                                    with taps still report it. */
 
 /* flags */
 #define MKH_FLAG_DEVICE_PTRS 1   /* data pointers are device pointers; async on stream */

@@ -115,6 +115,14 @@ BENCH_CONFIGS: Dict[str, dict] = {
                                 "CYLINDER (menagerie's eef_collision class): FrameTask + ConfigurationLimit + "
                                 "CollisionAvoidanceLimit(cylinder-plane floor, cylinder-box wall: general convex routine) + "
                                 "VelocityLimit, dt=5e-2, damping=1e-3"},
+    # G1 config 3 with a CollisionAvoidanceLimit over 46 pairs of the model's own primitive collision geoms (foot spheres, knee
+    # and shoulder cylinders, finger boxes, the floor; every pair analytic).  nv + pairs = 89 > 64: the wavefront kernel holds
+    # the 21 tightest contacts, the instances in which a dropped one is violated are solved again with every row by the
+    # workgroup-per-problem kernel (wide_kernel.h) — the path that lifts the one-wavefront limit, driver-measured
+    "g1_coll": {"robot": "g1", "key": "stand", "batch": 16384, "bytes_per_solve": 44 * 8 + 4 * 7 * 8 + 43 * 8 + 4,
+                "workload": "Unitree G1 config 3 + CollisionAvoidanceLimit(46 analytic pairs of the model's primitive collision geoms: "
+                            "foot spheres x floor / opposite foot / opposite knee cylinder / opposite finger box, cylinders and boxes x "
+                            "floor; detect 0.25 m, d_min 5 mm), dt=5e-3, damping=1e-1"},
     # the same set-up with the packaged model's CAPSULE wrist geom (analytic pairs only): the reference point of ur5e_convex
     "ur5e_coll": {"robot": "ur5e", "key": "home", "batch": 4096, "bytes_per_solve": 6 * 8 + 7 * 8 + 6 * 8 + 4,
                   "workload": "UR5e, the collision set-up of examples/arm_ur5e.py:20-47 (capsule-plane floor, capsule-box wall), "
@@ -132,6 +140,26 @@ def load_bench_robot(name: str) -> FlatModel:
     return model
 
 
+def g1_collision_pairs(model: FlatModel):
+    """46 geom-id pairs among G1's primitive collision geoms (bodies of the robot only), every one with an analytic distance
+    routine: the eight foot spheres against the floor (8), left against right foot spheres (16), knee / shoulder cylinders and
+    finger boxes against the floor (6), foot spheres against the opposite knee cylinder (8) and the opposite finger box (8)."""
+    gt, gv, gb = np.asarray(model.geom_type), np.asarray(model.geom_valid), np.asarray(model.geom_bodyid)
+    robot = [g for g in range(model.ngeom) if gv[g] == 1 and model.body_names[int(gb[g])].endswith("_link")]
+    floor = [g for g in range(model.ngeom) if gt[g] == 0][0]
+    side = lambda g: model.body_names[int(gb[g])].split("_")[0]
+    sph = {s: [g for g in robot if gt[g] == 2 and side(g) == s] for s in ("left", "right")}
+    knee = {s: [g for g in robot if gt[g] == 5 and side(g) == s and "knee" in model.body_names[int(gb[g])]] for s in ("left", "right")}
+    cyl = [g for g in robot if gt[g] == 5]
+    box = {s: [g for g in robot if gt[g] == 6 and side(g) == s] for s in ("left", "right")}
+    pairs = [(g, floor) for g in sph["left"] + sph["right"]]
+    pairs += [(a, b) for a in sph["left"] for b in sph["right"]]
+    pairs += [(g, floor) for g in cyl + box["left"] + box["right"]]
+    for s, o in (("left", "right"), ("right", "left")):
+        pairs += [(a, b) for a in sph[s] for b in knee[o]] + [(a, b) for a in sph[s] for b in box[o]]
+    return pairs
+
+
 def bench_config(name: str, model: FlatModel, nmodel: "nat.NativeModel", max_batch: int):
     """NativeProblem, dt, damping of a BASELINE config (same descriptors as tests/native_configs.py, built from
     the product's own constructors so that bench.py does not touch tests/ or oracle/)."""
@@ -140,6 +168,15 @@ def bench_config(name: str, model: FlatModel, nmodel: "nat.NativeModel", max_bat
     cfg = [configuration_limit_desc(model)]
     if name == "g1_c3":
         return g1_config(model, nmodel, max_batch)
+    if name == "g1_coll":
+        fts = [_frame_desc(model, s, "site", 200.0, 10.0, 1.0) for s in ("left_foot", "right_foot")] + \
+              [_frame_desc(model, s, "site", 200.0, 0.0, 1.0) for s in ("left_palm", "right_palm")]
+        col = {"geom_id_pairs": np.array(g1_collision_pairs(model)), "gain": 0.85, "minimum_distance_from_collisions": 0.005,
+               "collision_detection_distance": 0.25, "bound_relaxation": 0.0}
+        prob = nat.NativeProblem(nmodel, frame_tasks=fts, posture_tasks=[{"cost": 1.0}], configuration_limits=cfg,
+                                 velocity_limits=[velocity_limit_desc(model, _hinge_velocities(model))],
+                                 collision_limits=[col], max_batch=max_batch)
+        return prob, 5e-3, 1e-1
     if name == "ur5e_c2":
         prob = nat.NativeProblem(nmodel, frame_tasks=[_frame_desc(model, "attachment_site", "site", 1.0, 1.0, 1.0)],
                                  posture_tasks=[{"cost": 1e-2}], configuration_limits=cfg,

@@ -213,9 +213,10 @@ def _chain_xml(n_links, seed=0):
 
 
 def test_maximum_sizes_of_one_wavefront():
-    """The one-wavefront limits (SURVEY §8a sizes): 64 bodies / 64 dofs.  A 63-link serial chain
-    (64 bodies with the world, nv = 63, tree depth 63 ⇒ 6 pointer-jumping rounds, 64-row tableau) solves to oracle
-    accuracy; one link more is refused with a clear error instead of a wrong answer."""
+    """The one-wavefront limits (SURVEY §8a sizes): 64 bodies / 64 dofs.  A 63-link serial chain (64 bodies with the world,
+    nv = 63, tree depth 63 ⇒ 6 pointer-jumping rounds, 64-row tableau) solves to oracle accuracy on the wavefront kernel; one
+    link more — round 3: refused — runs on the workgroup-per-problem kernel (round 4, tests/test_gpu_wide.py has the 100-dof
+    chain): the same answer from either side of the limit."""
     import mink_amd as mink
     from oracle import cport
     from oracle import ik as oik
@@ -242,6 +243,23 @@ def test_maximum_sizes_of_one_wavefront():
     err = np.abs(v - v_c).max(axis=1) / np.maximum(1.0, np.abs(v_c).max(axis=1))
     print("63-dof chain vs C oracle: max rel err %.2e" % err.max())
     assert err.max() < 1e-7
-    with pytest.raises(Exception, match="one-wavefront limit"):
-        big = mink.loads_mjcf(_chain_xml(64))
-        mink.Configuration(big, np.zeros((1, big.nq))).native          # the device model is created on first use
+    assert list(cfg._problems.values())[-1].last_kernel().startswith("ik_solve_kernel_64")
+    big = mink.loads_mjcf(_chain_xml(64))
+    assert big.nbody == 65 and big.nv == 64
+    qb = rng.uniform(-0.6, 0.6, size=(B, big.nq))
+    cfgb = mink.Configuration(big, qb)
+    ftb = mink.FrameTask("tip", "site", position_cost=1.0, orientation_cost=0.5, lm_damping=1.0)
+    ftb.set_target(mink.Configuration(big, qb + rng.normal(scale=0.05, size=qb.shape)).get_transform_frame_to_world("tip", "site"))
+    postb = mink.PostureTask(big, cost=1e-1)
+    postb.set_target(np.zeros(big.nq))
+    limsb = [mink.ConfigurationLimit(big), mink.VelocityLimit(big, {f"j{i}": 2.0 for i in range(64)})]
+    vb = mink.solve_ik(cfgb, [ftb, postb], dt, "mi355x", damping, limits=limsb)
+    assert list(cfgb._problems.values())[-1].last_kernel() == "ik_wide_kernel"
+    tsb = [oik.FrameTaskSpec(big.name2id("site", "tip"), "site", ftb.cost, ftb.transform_target_to_world.wxyz_xyz[0], 1.0, 1.0),
+           oik.PostureTaskSpec(postb.cost, postb.target_q, 1.0)]
+    lsb = [oik.ConfigurationLimitSpec(), oik.VelocityLimitSpec(limsb[1].indices, limsb[1].limit)]
+    vb_c, stb_c = cport.CProblem(big, tsb, lsb).solve_batch(qb, ftb.transform_target_to_world.wxyz_xyz[:, None, :],
+                                                            postb.target_q[None, :], dt, damping)
+    errb = np.abs(vb - vb_c).max(axis=1) / np.maximum(1.0, np.abs(vb_c).max(axis=1))
+    print("64-dof chain (65 bodies) on the wide kernel vs C oracle: max rel err %.2e" % errb.max())
+    assert (stb_c == 0).all() and errb.max() < 1e-8
