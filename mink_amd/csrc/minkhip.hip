@@ -1096,7 +1096,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   // More rows can be active at once than the 64 − nv the wavefront kernels hold (the reference stacks them all:
   // mink/solve_ik.py:25-40): the instances a launch flags MKH_ST_ROW_OVERFLOW are solved again by the workgroup-per-problem
   // kernel with every row (launch(): the redo launch behind plain solves)
-  static const bool no_wide = getenv("MKH_DEBUG_NO_WIDE") != nullptr;          // (tests: what the wavefront kernel alone leaves flagged)
+  const bool no_wide = getenv("MKH_DEBUG_NO_WIDE") != nullptr;                 // (tests: what the wavefront kernel alone leaves flagged; read per handle)
   if (!no_wide && P.n_pairs + P.n_dense_limit_rows > kWave - m->nv) {
     const int32_t rc = build_wide_problem(p, m, d, ft, pairs, dcost, dwgain);
     if (rc != MKH_OK) return bail(rc);
