@@ -170,6 +170,15 @@ def pmc(out_path, dirs):
         "wave_cycles_per_dispatch": tot("SQ_WAVE_CYCLES"), "valu_insts_per_dispatch": tot("SQ_INSTS_VALU"),
         "salu_insts_per_dispatch": tot("SQ_INSTS_SALU"), "lds_insts_per_dispatch": tot("SQ_INSTS_LDS"),
     }
+    # VALU instructions by class, per dispatch (the instruction-class counters of gfx950; "other" = moves, selects, lane
+    # reads / writes, compares, DPP moves — everything the class counters do not name)
+    cls = {k: tot("SQ_INSTS_VALU_" + k) for k in ("FMA_F64", "MUL_F64", "ADD_F64", "TRANS_F64", "INT32", "INT64", "CVT")}
+    if tot("SQ_INSTS_VALU") and all(v is not None for v in cls.values()):
+        cls["other"] = tot("SQ_INSTS_VALU") - sum(cls.values())
+        summary["derived"]["valu_insts_by_class_per_dispatch"] = cls
+    for k in ("SQ_INSTS_BRANCH", "SQ_INSTS_SMEM", "SQ_INSTS_LDS_LOAD", "SQ_INSTS_LDS_STORE", "SQ_INSTS_LDS_ATOMIC", "SQ_INSTS_MFMA"):
+        if tot(k) is not None:
+            summary["derived"][k.lower()[3:] + "_per_dispatch"] = tot(k)
     with open(out_path, "w") as fh:
         json.dump(summary, fh, indent=1)
     print(json.dumps(hbm, indent=1))
