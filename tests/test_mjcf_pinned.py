@@ -24,6 +24,17 @@ def _unit(*q):
     return q / np.linalg.norm(q)
 
 
+def _rotmat(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def _zaxis(q):
+    return _rotmat(q)[:, 2]
+
+
 def _check_chain(m, bodies, joints, atol=1e-15):
     for name, parent, pos, quat, mass, ipos in bodies:
         b = m.name2id("body", name)
@@ -248,24 +259,72 @@ def test_shadow_left(source):
         assert m.geom_type[g] == 3 and m.body_names[m.geom_bodyid[g]] == body and m.geom_valid[g] == 1
         np.testing.assert_array_equal(m.geom_size[g], size)
         np.testing.assert_array_equal(m.geom_pos[g], pos)
-    # mesh-fitted capsule (left_hand.xml:149 `type="capsule" mesh="f_distal_pst"`): fitted to the asset's inertia box when the
-    # model was compiled (mink_amd/meshes.py; flag 2 = usable as a collision geom, its frame's axes only up to half turns).
-    # f_distal_pst.obj is a ≈26 mm fingertip, ≈14 mm across: radius and half-length of the fit must be of that size, the
-    # capsule must sit in the distal body with its axis along the finger (body z)
-    g = m.name2id("geom", "first_3")
-    assert m.geom_valid[g] == 2 and m.geom_type[g] == 3 and m.body_names[m.geom_bodyid[g]] == "lh_ffdistal"
-    assert 0.005 < m.geom_size[g][0] < 0.009 and 0.005 < m.geom_size[g][1] < 0.012
-    assert abs(m.geom_pos[g][0]) < 1e-3 and abs(m.geom_pos[g][1]) < 2e-3 and 0.010 < m.geom_pos[g][2] < 0.025
-    qw, qx, qy, qz = m.geom_quat[g]
-    zaxis = np.array([2 * (qx * qz + qw * qy), 2 * (qy * qz - qw * qx), 1 - 2 * (qx * qx + qy * qy)])
-    assert abs(abs(zaxis[2]) - 1.0) < 0.02, zaxis                         # capsule axis ∥ finger axis
-    # the one true mesh collision geom of the hand (left_hand.xml:101 `type="mesh" mesh="forearm_collision"`): its hull
+    # mesh-fitted capsules (left_hand.xml:149 / :263 `type="capsule" mesh="f_distal_pst"` / `"th_distal_pst"`, mesh scale 0.001 :8):
+    # radius, half-length, centre and axis TYPED from the output of tests/golden/derive_mesh_pins.py — a second derivation that
+    # shares no code with the reader (own OBJ parser, per-triangle loops, Jacobi eigen-solver); flag 2 = fitted, frame axes only
+    # up to half turns.  (This pin is what found, in round 4, that this fixture still carried the exact-inertia fit after the
+    # reader had moved to the compiler's legacy default.)
+    for geom, body, radius, halflen, pos, axis in (
+            ("first_3", "lh_ffdistal", 0.00668597552241, 0.00779683667472,
+             (-2.39844179808e-05, 0.000420732553707, 0.0176464755128), (-0.000011283, 0.002690022, 0.999996382)),
+            ("thumb_3", "lh_thdistal", 0.00817286083005, 0.00785656372807,
+             (-8.25444041129e-07, 0.000802518760052, 0.0195533730824), (0.000106926, -0.003173490, -0.999994959))):
+        g = m.name2id("geom", geom)
+        assert m.geom_valid[g] == 2 and m.geom_type[g] == 3 and m.body_names[m.geom_bodyid[g]] == body
+        np.testing.assert_allclose(m.geom_size[g][:2], (radius, halflen), rtol=1e-9)
+        np.testing.assert_allclose(m.geom_pos[g], pos, rtol=0, atol=1e-12)
+        zaxis = _zaxis(m.geom_quat[g])
+        assert abs(abs(zaxis @ np.array(axis)) - 1.0) < 1e-9, (geom, zaxis)   # capsule axis, up to its direction
+    # the one true mesh collision geom of the hand (left_hand.xml:101 `type="mesh" mesh="forearm_collision"`): its hull.
+    # forearm_collision.obj has 228 distinct vertices, 98 of them on the hull (qhull on the file's own coordinates, same script);
+    # the six extreme vertices below are READ OFF THE FILE (× 0.001) — the model stores the hull in the mesh's inertial frame, so
+    # geom_pos + R(geom_quat)·hull must reproduce them in the body frame (float32 storage: 1e-8)
     fm = [k for k in range(m.ngeom) if m.geom_type[k] == 7 and m.geom_dataid[k] >= 0]
     assert len(fm) == 1 and m.body_names[m.geom_bodyid[fm[0]]] == "lh_forearm"
     hull = m.mesh_hull(fm[0])
-    assert 20 < len(hull) < 400 and 0.05 < np.ptp(hull, axis=0).max() < 0.3
+    assert len(hull) == 98
+    in_body = m.geom_pos[fm[0]] + hull @ _rotmat(m.geom_quat[fm[0]]).T
+    for d, lo, hi in ((0, (-0.074762627, -2.3e-08, 0.156506897), (0.074762581, -2.3e-08, 0.156506897)),
+                      (1, (-0.006898247, -0.07444371, 0.156506897), (0.006898201, 0.074443657, 0.156506897)),
+                      (2, None, (0.067499977, -2.3e-08, 0.182800003))):
+        if lo is not None:
+            assert np.abs(in_body - np.array(lo)).sum(axis=1).min() < 3e-8, (d, lo)
+            assert abs(in_body[:, d].min() - lo[d]) < 1e-8
+        assert np.abs(in_body - np.array(hi)).sum(axis=1).min() < 3e-8, (d, hi)
+        assert abs(in_body[:, d].max() - hi[d]) < 1e-8
+    assert abs(in_body[:, 2].min() - (-4e-09)) < 1e-8                       # the base of the forearm: the plane z = 0 of the file
     g = m.name2id("geom", "floor")                          # scene_left.xml: pos="0 0 -0.1" size="0 0 0.05"
     np.testing.assert_array_equal(m.geom_pos[g], (0, 0, -0.1))
     np.testing.assert_array_equal(m.geom_size[g], (0, 0, 0.05))
     assert m.body_mocapid[m.name2id("body", "thumb_target")] == 0
     np.testing.assert_array_equal(m.mocap_pos[0], (0.5, 0, 0.5))
+
+
+# ------------------------------------------------------------------------------------------------ ALOHA
+# aloha.xml: meshes scaled 0.001 (:9-14); class "collision" = `<geom group="3" type="capsule" .../>` (:86-87), so every
+# `<geom class="collision" mesh=...>` is a capsule FITTED to its mesh; the geom's own pos / quat (typed from the XML, quat
+# normalised by hand) compose with the mesh's inertial frame.  Radius / half-length / centre / axis: typed from
+# tests/golden/derive_mesh_pins.py (see the Shadow test).  Body placement typed from aloha.xml:100-125.
+ALOHA_CAPSULES = [  # body, parent, body pos, radius, half-length, centre in the body frame, axis in the body frame
+    ("left/shoulder_link", "left/base_link", (0, 0, 0.079), 0.0346084511082, 0.0294520521564,
+     (0.000632571956375, 7.75043501511e-11, 0.020391457864), (0, 1, 0)),                      # :111 pos="0 0 -0.003" quat="1 0 0 1"
+    ("left/upper_arm_link", "left/shoulder_link", (0, 0, 0.04805), 0.0340304611975, 0.152895847956,
+     (0.018794847185, 1.06888765445e-09, 0.203813886889), (0.137037749, -0.000000001, 0.990565826)),   # :117 quat="1 0 0 1"
+    ("left/upper_forearm_link", "left/upper_arm_link", (0.05955, 0, 0.3), 0.0255845380061, 0.0864867043566,
+     (0.0915029827223, 4.669695453e-08, 5.33518918792e-08), (1, 0, 0)),                       # :123 no pos / quat
+]
+
+
+def test_aloha_fitted_capsules():
+    import os
+    m = oc.FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", "aloha__scene.json"))
+    for body, parent, bpos, radius, halflen, pos, axis in ALOHA_CAPSULES:
+        b = m.name2id("body", body)
+        assert m.body_names[m.body_parentid[b]] == parent
+        np.testing.assert_allclose(m.body_pos[b], bpos, rtol=0, atol=1e-15)
+        gs = [k for k in range(m.ngeom) if m.geom_bodyid[k] == b and m.geom_type[k] == 3]
+        assert len(gs) == 1 and m.geom_valid[gs[0]] == 2, body            # one collision capsule per link, fitted
+        g = gs[0]
+        np.testing.assert_allclose(m.geom_size[g][:2], (radius, halflen), rtol=1e-9)
+        np.testing.assert_allclose(m.geom_pos[g], pos, rtol=0, atol=1e-12)
+        assert abs(abs(_zaxis(m.geom_quat[g]) @ np.array(axis)) - 1.0) < 1e-8, body
