@@ -19,7 +19,7 @@ _ROBOTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "robots")
 
 
 def load_robot(name: str) -> FlatModel:
-    """Packaged FlatModel of a benchmark robot: 'ur5e', 'g1', 'shadow_left'."""
+    """Packaged FlatModel of a benchmark robot: 'ur5e', 'g1', 'shadow_left', 'h1'."""
     return FlatModel.load(os.path.join(_ROBOTS, f"{name}.json"))
 
 
@@ -123,6 +123,11 @@ BENCH_CONFIGS: Dict[str, dict] = {
                 "workload": "Unitree G1 config 3 + CollisionAvoidanceLimit(46 analytic pairs of the model's primitive collision geoms: "
                             "foot spheres x floor / opposite foot / opposite knee cylinder / opposite finger box, cylinders and boxes x "
                             "floor; detect 0.25 m, d_min 5 mm), dt=5e-3, damping=1e-1"},
+    # a mid-size robot (17–32 dofs: H1, Go1, Spot, Allegro — one wavefront per problem with most lanes idle): Unitree H1 under
+    # the G1 task set, examples/humanoid_h1.py:22-52 without the pelvis / CoM tasks
+    "h1_c3": {"robot": "h1", "key": "stand", "batch": 65536, "bytes_per_solve": 26 * 8 + 4 * 7 * 8 + 25 * 8 + 4,
+              "workload": "Unitree H1 (nq=26,nv=25): 4 FrameTasks(feet pos 200/ori 10, wrists pos 200/ori 0, lm 1)+PostureTask(1)+"
+                          "ConfigurationLimit+VelocityLimit(pi), dt=5e-3, damping=1e-1 (examples/humanoid_h1.py:22-52)"},
     # the same set-up with the packaged model's CAPSULE wrist geom (analytic pairs only): the reference point of ur5e_convex
     "ur5e_coll": {"robot": "ur5e", "key": "home", "batch": 4096, "bytes_per_solve": 6 * 8 + 7 * 8 + 6 * 8 + 4,
                   "workload": "UR5e, the collision set-up of examples/arm_ur5e.py:20-47 (capsule-plane floor, capsule-box wall), "
@@ -168,6 +173,12 @@ def bench_config(name: str, model: FlatModel, nmodel: "nat.NativeModel", max_bat
     cfg = [configuration_limit_desc(model)]
     if name == "g1_c3":
         return g1_config(model, nmodel, max_batch)
+    if name == "h1_c3":
+        fts = [_frame_desc(model, s, "site", 200.0, 10.0, 1.0) for s in ("left_foot", "right_foot")] + \
+              [_frame_desc(model, s, "site", 200.0, 0.0, 1.0) for s in ("left_wrist", "right_wrist")]
+        prob = nat.NativeProblem(nmodel, frame_tasks=fts, posture_tasks=[{"cost": 1.0}], configuration_limits=cfg,
+                                 velocity_limits=[velocity_limit_desc(model, _hinge_velocities(model))], max_batch=max_batch)
+        return prob, 5e-3, 1e-1
     if name == "g1_coll":
         fts = [_frame_desc(model, s, "site", 200.0, 10.0, 1.0) for s in ("left_foot", "right_foot")] + \
               [_frame_desc(model, s, "site", 200.0, 0.0, 1.0) for s in ("left_palm", "right_palm")]

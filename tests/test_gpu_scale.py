@@ -332,9 +332,13 @@ def _oracle_specs_of_bench(name, model, prob_desc):
     if name == "ur5e_c2":
         return ([ik.FrameTaskSpec(site("attachment_site"), "site", cost6(1.0, 1.0), z7, lm_damping=1.0),
                  ik.PostureTaskSpec(np.full(model.nv, 1e-2), None)], [ik.ConfigurationLimitSpec(), vel], {})
-    feet_palms = [ik.FrameTaskSpec(site(s), "site", cost6(200.0, o), z7, lm_damping=1.0)
+    feet_palms = [] if name == "h1_c3" else [ik.FrameTaskSpec(site(s), "site", cost6(200.0, o), z7, lm_damping=1.0)
                   for s, o in (("left_foot", 10.0), ("right_foot", 10.0), ("left_palm", 0.0), ("right_palm", 0.0))]
     post = ik.PostureTaskSpec(np.full(model.nv, 1.0), None)
+    if name == "h1_c3":
+        return ([ik.FrameTaskSpec(site(s), "site", cost6(200.0, o), z7, lm_damping=1.0)
+                 for s, o in (("left_foot", 10.0), ("right_foot", 10.0), ("left_wrist", 0.0), ("right_wrist", 0.0))] + [post],
+                [ik.ConfigurationLimitSpec(), vel], {})
     if name == "g1_c3":
         return feet_palms + [post], [ik.ConfigurationLimitSpec(), vel], {}
     if name == "g1_full":
@@ -352,7 +356,7 @@ def _oracle_specs_of_bench(name, model, prob_desc):
     raise KeyError(name)
 
 
-@pytest.mark.parametrize("name", ["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin"])
+@pytest.mark.parametrize("name", ["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin", "h1_c3"])
 def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name):
     """Exactly what `bench.py --config <name>` times — the same constructors, the same generated batch (per-instance CoM
     targets for the G1 full example, half of the Shadow instances pulled towards `grasp hard`, the caller's rows of the plugin
@@ -370,7 +374,7 @@ def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name):
     q, tg, pt, com = workloads.bench_batch(name, model, nm, prob, rng, B)
     dense = workloads.bench_dense(name, model, nm, q, rng)
     v, st = prob.solve(q, tg, pt, com, dt, damping, dense=dense)
-    assert prob.last_kernel() == _BENCH_KERNELS[name], prob.last_kernel()
+    assert name not in _BENCH_KERNELS or prob.last_kernel() == _BENCH_KERNELS[name], prob.last_kernel()
     assert ((st & ~1) == 0).all(), np.unique(st, return_counts=True)
     tasks, limits, extra = _oracle_specs_of_bench(name, model, prob)
     if name == "shadow_c4":          # the bench's pair list (built by the product's CollisionAvoidanceLimit) = real mink's, recorded
@@ -378,7 +382,7 @@ def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name):
         groups = [[f"{f}_1", f"{f}_2"] for f in workloads.SHADOW_FINGERS]
         col = CollisionAvoidanceLimit(model, [(groups[i], groups[j]) for i in range(5) for j in range(i + 1, 5)])
         np.testing.assert_array_equal(np.array(col.geom_id_pairs), np.load(oc.GOLDEN + "/shadow_c4_geom_pairs.npy"))
-    cp = cport.CProblem(oc.model(workloads.BENCH_CONFIGS[name]["robot"]), tasks, limits, **extra)
+    cp = cport.CProblem(model if name == "h1_c3" else oc.model(workloads.BENCH_CONFIGS[name]["robot"]), tasks, limits, **extra)
     v_ref, st_ref = cp.solve_batch(q, tg, pt, dt, damping, com_target=com, dense=dense, nthreads=min(16, os.cpu_count() or 1))
     assert (st_ref == 0).all(), np.unique(st_ref, return_counts=True)
     err = np.abs(v - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
