@@ -953,14 +953,22 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     if (fits) P.n_dpairs = n;
   }
   if (P.n_jrows > 0 && P.n_pairs == 0 && !p->has_relative && P.n_dense_rows == 0 &&
-      P.n_dense_limit_rows == 0 && P.n_jrows <= kMuBig &&
-      // fewer task rows than dofs by a margin: half (measured on arms and hands), three quarters for humanoid-size tableaus
-      (2 * P.n_jrows <= m->nv || (m->nv >= 32 && 4 * P.n_jrows <= 3 * m->nv))) {
+      P.n_dense_limit_rows == 0 && P.n_jrows <= kMuBig) {
     // (NT = NR: the task residuals are eliminated outside the tableau, one column of [S | Jh] per lane — wood_start; the
     //  S columns sit on lanes [NR, NR + n_μ) or, when those do not exist, on lanes [0, n_μ) in a second register set)
     static const int kWoodVariants[] = {16, 24, 32, 44, 48};
+    int cand = 0;
     for (int v : kWoodVariants)
-      if (m->nv <= v && (v + P.n_jrows <= kWave || P.n_jrows <= v)) { p->wood_nt = v; p->wood_nr = v; break; }
+      if (m->nv <= v && (v + P.n_jrows <= kWave || P.n_jrows <= v)) { cand = v; break; }
+    const bool big = P.n_jrows > kMu || cand + P.n_jrows > kWave;
+    // When it pays.  Fewer task rows than dofs by a margin — half, three quarters for humanoid-size tableaus — measured in
+    // rounds 1-2 on arms, hands and the G1; round 4 (tools/bench_wood_criterion.py, H1 / Go1 / Spot / Allegro / Shadow with
+    // 12-18 rows on 18-25 dofs): whenever the small elimination applies (≤ kMu rows, S columns on lanes of their own) the
+    // low-rank start wins by 1.15-1.38 x up to rows = dofs; the large one (> kMu rows) loses beyond three quarters
+    // (Shadow 21 / 24: 0.57 x, H1 24 / 25: 0.93 x) and keeps the old margin.
+    const bool pays = 2 * P.n_jrows <= m->nv || (m->nv >= 32 && 4 * P.n_jrows <= 3 * m->nv) ||
+                      (!big && m->nv >= 16 && P.n_jrows <= m->nv) || getenv("MKH_DEBUG_WOOD_ALWAYS");
+    if (cand && pays) { p->wood_nt = cand; p->wood_nr = cand; }
     if (p->wood_nt) {
       p->wood_big = P.n_jrows > kMu || p->wood_nr + P.n_jrows > kWave;
       const int sp = lds_even(P.n_jrows);
