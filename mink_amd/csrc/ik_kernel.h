@@ -364,10 +364,14 @@ struct PreOut { int status, d_kind, d_k, d_body, d_qadr, conv; double mu_lane; V
 #define MKH_PRE_TC_PARAMS , long long* clk_row
 #define MKH_PRE_TC_ARGS , (A.clk ? A.clk + (size_t)pb * 24 + 20 : nullptr)
 #define MKH_PRE_TICK() do { if (clk_row) { *clk_row = __builtin_readcyclecounter(); ++clk_row; } asm volatile("" : "+v"(lane)); } while (0)
+// phase-stop (tools/phase_census.sh): slot 15 of the problem's clock row holds the boundary after which the solve is abandoned,
+// so that the PMC counters of launches with stop = k and k + 1 differ by phase k + 1's instructions.  0 = run to the end.
+#define MKH_PRE_STOP(id) do { if (clk_row_stop == (id)) return PreOut{}; } while (0)
 #else
 #define MKH_PRE_TC_PARAMS
 #define MKH_PRE_TC_ARGS
 #define MKH_PRE_TICK() do { asm volatile("" : "+v"(lane)); } while (0)
+#define MKH_PRE_STOP(id) do {} while (0)
 #endif
 #else
 #define MKH_PRE_ATTR __forceinline__
@@ -378,6 +382,7 @@ struct PreOut { int status, d_kind, d_k, d_body, d_qadr, conv; double mu_lane; V
 #else
 #define MKH_PRE_TICK() do { if (MKH_TAP(t_cycles)) tc[tci] = __builtin_readcyclecounter(); ++tci; asm volatile("" : "+v"(lane)); } while (0)
 #endif
+#define MKH_PRE_STOP(id) do {} while (0)
 #endif
 // The descriptor fields pre_phases reads, loaded through the constant address space (scalar loads) with the table pointers
 // typed as global memory: inside a real function the compiler has to treat pointers that arrive as arguments or come out
@@ -437,6 +442,9 @@ __device__ MKH_PRE_ATTR PreOut pre_phases(const DeviceProblem* Pq, const TapArgs
   constexpr bool kTaps = (FEAT & F_TAPS) != 0, kRel = (FEAT & F_REL) != 0, kCom = (FEAT & F_COM) != 0;
   constexpr bool kSteps = (FEAT & F_STEPS) != 0, kWood = (FEAT & F_WOOD) != 0;
   extern __shared__ __attribute__((aligned(16))) double smem[];
+#if defined(MKH_CALLS) && defined(MKH_CLOCKS)
+  const int clk_row_stop = clk_row ? (int)clk_row[-5] : 0;      // (clk_row = slot 20 of the problem's row)
+#endif
 #ifdef MKH_CALLS
   // arguments of a real call arrive in VGPRs: make the wave-uniform ones scalar again
   pb = uni(pb); oz = uni(oz); off_q = uni(off_q); off_tgt = uni(off_tgt);
@@ -537,6 +545,7 @@ __device__ MKH_PRE_ATTR PreOut pre_phases(const DeviceProblem* Pq, const TapArgs
     wave_sync();
     MKH_MARK("fk_done");
     MKH_PRE_TICK();   // 1: FK done
+    MKH_PRE_STOP(1);
     // --------------------- joint anchors / axes in the world (xanchor, xaxis)
     if (is_body && b_jnum > 0) {
       if (b_jnum == 1) {
@@ -682,6 +691,7 @@ __device__ MKH_PRE_ATTR PreOut pre_phases(const DeviceProblem* Pq, const TapArgs
 
     MKH_MARK("axes_done");
     MKH_PRE_TICK();   // 2: joint axes / dof lanes / com done
+    MKH_PRE_STOP(2);
     // ------------------------------------------- task lanes: pose, error, jlog
     double mu_lane = 0.0;  // Levenberg–Marquardt term of the task owned by this lane
     bool conv_lane = true; // this lane's frame task is within the thresholds (rows with a nonzero cost only)
@@ -1146,6 +1156,9 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
   }
   wave_sync();
   if (prof) prof[0] = __builtin_readcyclecounter();                    // Jacobian rows staged
+#if defined(MKH_WOOD_CALL) && defined(MKH_CLOCKS)
+  if (prof && (int)prof[-2] == 6) return WoodOut{0.0, 0.0, 0.0, 0.0, 0, 0};   // phase-stop 6 (prof = slot 17 of the problem's row)
+#endif
   // ---- S = I + Jh·Jhᵀ and Jw·z by (column, row-chunk) lanes: 64/n_μ chunks of rows per column, each lane a handful of
   // dot products on its own LDS addresses.  A row of Jh is nonzero only on the kinematic chain of its task (12–16 of the
   // 43 dofs on G1): the dot products walk the set bits of the column's chain mask instead of all NR dofs.
@@ -1226,6 +1239,9 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
   if (is_s) sW[my_c] -= we_mu;                                         // w = Jw·z − r
   wave_sync();
   if (prof) prof[1] = __builtin_readcyclecounter();                    // S and w ready
+#if defined(MKH_WOOD_CALL) && defined(MKH_CLOCKS)
+  if (prof && (int)prof[-2] == 7) return WoodOut{0.0, 0.0, 0.0, 0.0, 0, 0};   // phase-stop 7
+#endif
   // ---- elimination (K = the smallest compiled row capacity that holds n_μ)
   double ssq = 0.0, quad = 0.0, zw = 0.0;
   // (the 24-row and two-register-set instantiations only exist in the F_COM variants, which the host also picks for
@@ -1693,6 +1709,12 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
 #define MKH_CLK MKH_TAP(t_cycles)
 #endif
 #define MKH_TICK() do { if (MKH_CLK) tc[tci] = __builtin_readcyclecounter(); ++tci; asm volatile("" : "+v"(lane)); } while (0)
+#ifdef MKH_CLOCKS
+    const int phase_stop = A.clk ? (int)A.clk[(size_t)pb * 24 + 15] : 0;   // (see MKH_PRE_STOP)
+#define MKH_STOP(id) if (phase_stop && phase_stop <= (id)) break
+#else
+#define MKH_STOP(id) do {} while (0)
+#endif
 #define MKH_LAP0() do { if (MKH_CLK) tl = __builtin_readcyclecounter(); } while (0)
 #define MKH_LAP(i) do { if (MKH_CLK) { const long long n_ = __builtin_readcyclecounter(); ta[i] += n_ - tl; tl = n_; } } while (0)
     MKH_MARK("problem_begin");
@@ -1780,6 +1802,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
 
     MKH_MARK("tasklanes_done");
     MKH_TICK();   // 3: task lanes done
+    MKH_STOP(3);
     // ------------------------------------------- posture tasks (diagonal)
     double c_lane = 0.0;   // c[lane]
     double hdiag = 0.0;    // H[lane][lane]
@@ -1842,6 +1865,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     hdiag += mu_total;
 #if defined(MKH_WOOD_CALL) && defined(MKH_CLOCKS)
     if (A.clk && lane == 0) A.clk[(size_t)pb * 24 + 22] = __builtin_readcyclecounter();            // [22] posture / damping / dense tasks done
+    MKH_STOP(4);
 #endif
     const double hdiag_base = hdiag;   // damping + Σμ + posture diagonal: the explicit diagonal of H
 
@@ -1942,6 +1966,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     if constexpr (kWood) box_limits();
 #if defined(MKH_WOOD_CALL) && defined(MKH_CLOCKS)
     if (A.clk && lane == 0) A.clk[(size_t)pb * 24 + 23] = __builtin_readcyclecounter();            // [23] box limits done
+    MKH_STOP(5);
 #endif
     // ---- low-rank start: Jacobian rows, S = I + Jh·Jhᵀ, LDLᵀ elimination (wood_start above), then the dof block of the
     // tableau by n_μ rank-1 updates that do not depend on each other:  R[i][j] = Σ_r Z[r][i]·Z[r][j]/d_r
@@ -1961,6 +1986,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta, lo, hi,
                       A.clk ? A.clk + (size_t)pb * 24 + 17 : nullptr);
       if (A.clk && lane == 0) A.clk[(size_t)pb * 24 + 19] = __builtin_readcyclecounter();          // [19] back in the kernel
+      MKH_STOP(8);
 #elif defined(MKH_WOOD_CALL)
       wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta, lo, hi);
 #else
@@ -2302,6 +2328,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     }
     MKH_MARK("phase0_done");
     MKH_TICK();   // 6: tableau built, phase 0 done
+    MKH_STOP(9);
     const int nact = kWood ? nv : kWave;                     // lanes that still own a live index
     int n_loop = 0, n_piv = 0;   // profiling (qp_iters tap): loop iterations / rank-1 pivots after x0
     // ---- phase 1a (box limits only): block principal pivoting.  lo ≤ x ≤ hi with H ≻ 0 is a bound-constrained

@@ -1177,7 +1177,16 @@ static hipError_t clk_begin(MkhProblem* p, SolveArgs& a, hipStream_t stream) {
   if (!p->d_clk)
     if (hipError_t e = hipMalloc((void**)&p->d_clk, (size_t)p->max_batch * 24 * sizeof(long long))) return e;
   a.clk = p->d_clk;
-  return hipMemsetAsync(p->d_clk, 0, (size_t)a.B * 24 * sizeof(long long), stream);
+  if (hipError_t e = hipMemsetAsync(p->d_clk, 0, (size_t)a.B * 24 * sizeof(long long), stream)) return e;
+  // MKH_DEBUG_PHASE_STOP=k (tools/phase_census.sh): slot 15 of every row = the phase boundary after which the kernel abandons the solve
+  static const int stop = getenv("MKH_DEBUG_PHASE_STOP") ? atoi(getenv("MKH_DEBUG_PHASE_STOP")) : 0;
+  if (stop) {
+    std::vector<long long> h((size_t)a.B, (long long)stop);
+    if (hipError_t e = hipMemcpy2DAsync(p->d_clk + 15, 24 * sizeof(long long), h.data(), sizeof(long long), sizeof(long long), (size_t)a.B,
+                                        hipMemcpyHostToDevice, stream)) return e;
+    return hipStreamSynchronize(stream);
+  }
+  return hipSuccess;
 }
 static hipError_t clk_end(MkhProblem* p, int B, hipStream_t stream) {
   if (!clk_path()) return hipSuccess;
