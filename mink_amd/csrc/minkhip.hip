@@ -1150,7 +1150,7 @@ static int lds_for_nt(const MkhProblem* p, int nt) {
 
 static int grid_for_variant(const MkhProblem* p, int B, int nt, int lds, bool w3 = false) {
   int wpc = waves_per_cu(nt, lds, w3);
-  // diagnostic: cap the resident waves per CU (occupancy experiments); never raises it
+  // diagnostic: cap the resident waves per CU (occupancy experiments, docs/HISTORY.md §7b); never raises it
   static const int dbg = getenv("MKH_DEBUG_WAVES_PER_CU") ? atoi(getenv("MKH_DEBUG_WAVES_PER_CU")) : 0;
   if (dbg > 0 && dbg < wpc) wpc = dbg;
   int g = p->model->num_cus * wpc;

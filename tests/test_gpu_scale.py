@@ -415,7 +415,7 @@ def _numpy_oracle_chunk(args):
 def test_ur5e_convex_at_its_bench_batch_against_the_numpy_oracle():
     """The sixth bench workload: a cylinder–box pair goes through the general convex routine, which the C restatement does
     not carry — all 4 096 instances against the numpy restatement (oracle/gjk.py) on every host core.  Tolerance 2e-5: rows of
-    G from GJK witness points are good to ~1e-5 (DESIGN §3.6; the distance itself to 1e-13)."""
+    G from GJK witness points are good to ~1e-5 (DESIGN §3.7; the distance itself to 1e-13)."""
     import multiprocessing as mp
     import os
     from mink_amd import _native as nat
