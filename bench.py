@@ -94,7 +94,8 @@ def kernel_keys(kernel: str) -> list:
     """Names of every launch behind a `last_kernel()` string, as keyed in mink_amd/kernel_resources.json: the tight-rows call
     `ik_solve_kernel_48_72+redo_64` is two launches (the 48-row build and the full-row redo of the same feature set)."""
     if kernel.startswith("ik_quad_kernel"):
-        return [f"ik_quad_kernel<{16 if '_16' in kernel else 8},{1 if kernel.endswith('_loop') else 0}>"]
+        nt = 32 if "_32" in kernel else (16 if "_16" in kernel else 8)          # (_32: two DPP rows per problem)
+        return [f"ik_quad_kernel<{nt},{1 if kernel.endswith('_loop') else 0},{32 if nt == 32 else 16}>"]
     if kernel.startswith("ik_lane_kernel_"):
         return [f"ik_lane_kernel<{kernel.split('_')[3]},{1 if kernel.endswith('_loop') else 0}>"]
     wide = kernel.endswith("+wide")              # (the redo launch of the workgroup-per-problem kernel behind a wavefront kernel)

@@ -24,16 +24,18 @@
 
 namespace mkh {
 
-constexpr int kLaneMaxLinks = 16;
+constexpr int kLaneMaxLinks = 16;       // descriptor of the lane kernel and of the row kernel's one-row builds
 constexpr int kLaneMaxDofs = 8;         // the lane kernel's own limit (its register arrays)
-constexpr int kLaneDescDofs = 16;       // capacity of the shared descriptor (the row kernel takes up to 16 dofs)
+constexpr int kLaneDescDofs = 16;       // (the row kernel takes up to 16 dofs on one DPP row)
+constexpr int kLaneMaxLinks2 = 32, kLaneDescDofs2 = 32;   // descriptor of the row kernel's two-row build (17 … 32 dofs or links)
 constexpr int kLaneMaxFrames = 8;       // frame tasks of a problem (round 3: 4 → 8, a hand's fingertips + its palm)
 
 struct LaneLink {
   int32_t parent;        // link index of the parent body, −1 = world
-  int32_t jtype;         // −1 none, JNT_SLIDE, JNT_HINGE
+  int32_t jtype;         // −1 none, JNT_SLIDE, JNT_HINGE; JNT_BALL: the rotation of a free joint (two-row build of the row kernel only —
+                         // a free joint is three slide links along the world axes with `pos` = 0 and this link on top of them)
   int32_t dof;           // dof / register index of the joint coordinate
-  int32_t pad;
+  int32_t qadr;          // JNT_BALL: address of the quaternion in q
   double pos[3], quat[4];
   double axis[3], jpos[3], qpos0;
 };
@@ -45,21 +47,43 @@ struct LaneFrame {
   double lpos[3], lquat[4], cost[6], gain, lm_damping;
 };
 
-struct LaneProblem {
+// ML links, MD dofs of capacity: two instantiations, so that the two-row build's larger tables leave the layout (and with it
+// the register allocation) of the lane kernel and of the one-row builds exactly as it was
+template <int ML, int MD>
+struct LaneProblemT {
   int32_t nq, nv, nlink, n_frame, n_posture, n_cfg, n_vel, pad;
-  LaneLink link[kLaneMaxLinks];
-  int32_t dof_link[kLaneDescDofs];   // link whose joint moves dof d (−1: not on any task chain)
-  int32_t dof_qadr[kLaneDescDofs];
-  double range_lo[kLaneDescDofs], range_hi[kLaneDescDofs];    // joint range for check_limits (±inf)
+  LaneLink link[ML];
+  int32_t dof_link[MD];   // link whose joint moves dof d (−1: not on any task chain)
+  int32_t dof_qadr[MD];
+  double range_lo[MD], range_hi[MD];    // joint range for check_limits (±inf)
   LaneFrame frame[kLaneMaxFrames];
-  double posture_cost[kMaxPostureTasks][kLaneDescDofs], posture_gain[kMaxPostureTasks], posture_lm[kMaxPostureTasks];
-  double cfg_gain[kMaxBoxTerms], cfg_lower[kMaxBoxTerms][kLaneDescDofs], cfg_upper[kMaxBoxTerms][kLaneDescDofs];
-  double vel_limit[kMaxBoxTerms][kLaneDescDofs];
+  double posture_cost[kMaxPostureTasks][MD], posture_gain[kMaxPostureTasks], posture_lm[kMaxPostureTasks];
+  double cfg_gain[kMaxBoxTerms], cfg_lower[kMaxBoxTerms][MD], cfg_upper[kMaxBoxTerms][MD];
+  double vel_limit[kMaxBoxTerms][MD];
   // per dof, for the row kernel (quad_kernel.h: one load level less than dof_link → link): the joint's axis and anchor in its
   // body frame, and whether it is a slide joint
-  double dof_axis[kLaneDescDofs][3], dof_jpos[kLaneDescDofs][3];
-  int32_t dof_slide[kLaneDescDofs];
+  double dof_axis[MD][3], dof_jpos[MD][3];
+  int32_t dof_slide[MD];
 };
+using LaneProblem = LaneProblemT<kLaneMaxLinks, kLaneDescDofs>;
+using LaneProblem2 = LaneProblemT<kLaneMaxLinks2, kLaneDescDofs2>;
+
+// the same problem in the smaller descriptor (host side; the builder fills the large one)
+template <int ML, int MD, int ML2, int MD2>
+inline void lane_problem_narrow(const LaneProblemT<ML2, MD2>& b, LaneProblemT<ML, MD>& a) {
+  a.nq = b.nq; a.nv = b.nv; a.nlink = b.nlink; a.n_frame = b.n_frame; a.n_posture = b.n_posture; a.n_cfg = b.n_cfg; a.n_vel = b.n_vel; a.pad = 0;
+  for (int i = 0; i < ML; ++i) a.link[i] = b.link[i];
+  for (int i = 0; i < kLaneMaxFrames; ++i) a.frame[i] = b.frame[i];
+  for (int d = 0; d < MD; ++d) {
+    a.dof_link[d] = b.dof_link[d]; a.dof_qadr[d] = b.dof_qadr[d]; a.range_lo[d] = b.range_lo[d]; a.range_hi[d] = b.range_hi[d];
+    a.dof_slide[d] = b.dof_slide[d];
+    for (int c = 0; c < 3; ++c) { a.dof_axis[d][c] = b.dof_axis[d][c]; a.dof_jpos[d][c] = b.dof_jpos[d][c]; }
+    for (int t = 0; t < kMaxPostureTasks; ++t) a.posture_cost[t][d] = b.posture_cost[t][d];
+    for (int t = 0; t < kMaxBoxTerms; ++t) { a.cfg_lower[t][d] = b.cfg_lower[t][d]; a.cfg_upper[t][d] = b.cfg_upper[t][d]; a.vel_limit[t][d] = b.vel_limit[t][d]; }
+  }
+  for (int t = 0; t < kMaxPostureTasks; ++t) { a.posture_gain[t] = b.posture_gain[t]; a.posture_lm[t] = b.posture_lm[t]; }
+  for (int t = 0; t < kMaxBoxTerms; ++t) a.cfg_gain[t] = b.cfg_gain[t];
+}
 
 // The sizes of a LaneProblem, by value in the row kernel's arguments (SGPRs at wave start instead of a dependent load).
 // `qadr_identity`: dof d reads q[d] (always the case for nq = nv with hinge / slide joints only; checked on the host).

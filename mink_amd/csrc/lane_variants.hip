@@ -22,12 +22,19 @@ int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stre
   return -1;
 }
 
-int launch_quad(int nt, bool loop, int grid, hipStream_t stream, const LaneProblem* P, const LaneDims& dims, const SolveArgs& a) {
-#define MKH_QUAD_LAUNCH(NT, LOOP) hipLaunchKernelGGL((ik_quad_kernel<NT, LOOP>), dim3(grid), dim3(kWave), quad_lds_bytes(), stream, P, dims, a)
-  if (nt == 8) { if (loop) MKH_QUAD_LAUNCH(8, true); else MKH_QUAD_LAUNCH(8, false); }
-  else { if (loop) MKH_QUAD_LAUNCH(16, true); else MKH_QUAD_LAUNCH(16, false); }
+int launch_quad(int nt, bool loop, int grid, hipStream_t stream, const void* Pv, const LaneDims& dims, const SolveArgs& a) {
+  const LaneProblem* P = (const LaneProblem*)Pv;          // (nt == 32: a LaneProblem2)
+#define MKH_QUAD_LAUNCH(NT, LOOP, LP) hipLaunchKernelGGL((ik_quad_kernel<NT, LOOP, LP>), dim3(grid), dim3(kWave), quad_lds_bytes(LP), stream, P, dims, a)
+  if (nt == 32) {
+    if (loop) return -1;
+    const LaneProblem2* P = (const LaneProblem2*)Pv;
+    MKH_QUAD_LAUNCH(32, false, 32);
+    return quad_lds_bytes(32);
+  }   // two DPP rows per problem: single solves
+  if (nt == 8) { if (loop) MKH_QUAD_LAUNCH(8, true, 16); else MKH_QUAD_LAUNCH(8, false, 16); }
+  else { if (loop) MKH_QUAD_LAUNCH(16, true, 16); else MKH_QUAD_LAUNCH(16, false, 16); }
 #undef MKH_QUAD_LAUNCH
-  return quad_lds_bytes();
+  return quad_lds_bytes(16);
 }
 
 }  // namespace mkh

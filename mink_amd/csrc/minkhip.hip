@@ -167,7 +167,7 @@ namespace mkh {
 int launch_variant(int nt, int nr, int feat, bool w3, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
                    const SolveArgs& a, const TapArgs* taps);
 int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);
-int launch_quad(int nt, bool loop, int grid, hipStream_t stream, const LaneProblem* P, const LaneDims& dims, const SolveArgs& a);   // returns its LDS bytes per wavefront
+int launch_quad(int nt, bool loop, int grid, hipStream_t stream, const void* P, const LaneDims& dims, const SolveArgs& a);   // returns its LDS bytes per wavefront
 int launch_wide(int grid, int lds_bytes, hipStream_t stream, const WideProblem* P, const SolveArgs& a, const TapArgs* taps);
 constexpr int kLaneMinBatchLoop = 28672;  // fused loops of a small arm: row kernel below, lane kernel from here (M targets/s at 16 384: 39.7 vs 24.1, at 32 768: 42.4 vs 48.2)
 constexpr int kLaneMinBatch = 73728;  // plain solves of a small arm: row kernel below, lane kernel from here (launch())
@@ -180,14 +180,19 @@ constexpr int kLaneMinBatch = 73728;  // plain solves of a small arm: row kernel
 static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const DeviceProblem& P,
                               const std::vector<FrameTaskDev>& ft, const std::vector<double>& pcost,
                               const std::vector<double>& clo, const std::vector<double>& chi,
-                              const std::vector<double>& vlim, bool has_relative, LaneProblem& L) {
+                              const std::vector<double>& vlim, bool has_relative, LaneProblem2& L) {
   const double inf = std::numeric_limits<double>::infinity();
-  if (m->nv > kLaneDescDofs || m->nq != m->nv) return 0;
+  if (m->nv > kLaneDescDofs2) return 0;
   if (P.n_frame < 1 || P.n_frame > kLaneMaxFrames || has_relative || P.n_com || P.n_pairs || P.n_dense_rows ||
       P.n_dense_limit_rows || P.dense_box)       // (dense_box: per-instance box rows of a plugin limit, wavefront kernels only)
     return 0;
-  for (int j = 0; j < m->njnt; ++j)
+  // hinge / slide joints; the two-row build of the row kernel (17 … 32 dofs or links) also takes free joints — a floating base
+  bool has_free = false;
+  for (int j = 0; j < m->njnt; ++j) {
+    if (m->jnt_type[j] == JNT_FREE && m->body_jntnum[m->jnt_bodyid[j]] == 1) { has_free = true; continue; }
     if (m->jnt_type[j] != JNT_HINGE && m->jnt_type[j] != JNT_SLIDE) return 0;
+  }
+  if (m->nq != m->nv + (has_free ? 1 : 0)) return 0;      // (one free joint at most: its quaternion is the extra coordinate)
   memset(&L, 0, sizeof L);
   L.nq = m->nq; L.nv = m->nv; L.n_frame = P.n_frame; L.n_posture = P.n_posture; L.n_cfg = P.n_cfg; L.n_vel = P.n_vel;
   // links = the bodies on the chains world → frame bodies, in body-id order (parents first)
@@ -195,6 +200,7 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
   for (int t = 0; t < P.n_frame; ++t)
     for (int b = ft[t].body; b > 0; b = m->body_parentid[b]) need[b] = 1;
   int nl = 0;
+  int free_link[4] = {-1, -1, -1, -1};
   std::vector<int> link_of_jnt(m->njnt, -1);
   // Pose of a jointless body relative to its nearest ancestor that is a link (or the world): folded into the local
   // transforms of its children and of the frames attached to it, so that it costs neither a link nor LDS.
@@ -227,8 +233,27 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
     }
     // A body with k > 1 joints becomes a chain of k links with identity offsets: mj_kinematics applies a body's
     // joints one after the other in the moving body frame, which is exactly a serial chain of coincident frames.
+    if (m->jnt_type[m->body_jntadr[b]] == JNT_FREE) {
+      // mj_kinematics: a free body's pose IS its qpos (body_pos / body_quat are not used): three slide links along the world
+      // axes from the origin, then the rotation
+      const int jj = m->body_jntadr[b];
+      if (nl + 4 > kLaneMaxLinks2) return 0;
+      for (int i = 0; i < 4; ++i) {
+        LaneLink& k = L.link[nl];
+        k.parent = i == 0 ? -1 : nl - 1;
+        k.quat[0] = 1.0;
+        k.jtype = i < 3 ? JNT_SLIDE : JNT_BALL;
+        k.dof = m->jnt_dofadr[jj] + (i < 3 ? i : 3);
+        k.qadr = m->jnt_qposadr[jj] + 3;
+        if (i < 3) k.axis[i] = 1.0;
+        free_link[i] = nl++;
+      }
+      link_of_jnt[jj] = nl - 1;
+      link_of[b] = nl - 1;
+      continue;
+    }
     for (int i = 0; i < m->body_jntnum[b]; ++i) {
-      if (nl >= kLaneMaxLinks) return 0;
+      if (nl >= kLaneMaxLinks2) return 0;
       LaneLink& k = L.link[nl];
       k.parent = i == 0 ? link_of[pb] : nl - 1;
       k.quat[0] = 1.0;
@@ -244,9 +269,18 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
     }
   }
   L.nlink = nl;
-  for (int dd = 0; dd < kLaneDescDofs; ++dd) { L.dof_link[dd] = -1; L.dof_qadr[dd] = 0; L.range_lo[dd] = -inf; L.range_hi[dd] = inf; }
+  for (int dd = 0; dd < kLaneDescDofs2; ++dd) { L.dof_link[dd] = -1; L.dof_qadr[dd] = 0; L.range_lo[dd] = -inf; L.range_hi[dd] = inf; }
   for (int dd = 0; dd < m->nv; ++dd) {
     const int j = m->dof_jntid[dd];
+    if (m->jnt_type[j] == JNT_FREE) {
+      // dofs 0-2: translations along the world axes (the slide links); 3-5: rotations about the body's own axes through its origin
+      const int k = dd - m->jnt_dofadr[j];
+      L.dof_link[dd] = link_of_jnt[j] < 0 ? -1 : (k < 3 ? free_link[k] : free_link[3]);
+      L.dof_qadr[dd] = m->jnt_qposadr[j] + (k < 3 ? k : k + 1);      // (rotations: any finite entry — their posture cost is zero, mink/tasks/posture_task.py:95-99)
+      L.dof_axis[dd][k % 3] = 1.0;
+      L.dof_slide[dd] = k < 3;
+      continue;
+    }
     L.dof_link[dd] = link_of_jnt[j];
     L.dof_qadr[dd] = m->jnt_qposadr[j];
     for (int c = 0; c < 3; ++c) { L.dof_axis[dd][c] = m->jnt_axis[3 * j + c]; L.dof_jpos[dd][c] = m->jnt_pos[3 * j + c]; }
@@ -265,11 +299,12 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
     f.gain = ft[t].gain; f.lm_damping = ft[t].lm_damping;
   }
   for (int t = 0; t < P.n_posture; ++t) {
-    for (int dd = 0; dd < m->nv; ++dd) L.posture_cost[t][dd] = pcost[t * 64 + dd];
+    for (int dd = 0; dd < m->nv; ++dd)      // (free-joint dofs: error and Jacobian column are zero, posture_task.py:115-116,139-141)
+      L.posture_cost[t][dd] = m->jnt_type[m->dof_jntid[dd]] == JNT_FREE ? 0.0 : pcost[t * 64 + dd];
     L.posture_gain[t] = P.posture_gain[t]; L.posture_lm[t] = P.posture_lm[t];
   }
   for (int t = 0; t < kMaxBoxTerms; ++t)
-    for (int dd = 0; dd < kLaneDescDofs; ++dd) { L.cfg_lower[t][dd] = -inf; L.cfg_upper[t][dd] = inf; L.vel_limit[t][dd] = inf; }
+    for (int dd = 0; dd < kLaneDescDofs2; ++dd) { L.cfg_lower[t][dd] = -inf; L.cfg_upper[t][dd] = inf; L.vel_limit[t][dd] = inf; }
   for (int t = 0; t < P.n_cfg; ++t) {
     L.cfg_gain[t] = P.cfg_gain[t];
     for (int dd = 0; dd < m->nv; ++dd) { L.cfg_lower[t][dd] = clo[t * 64 + dd]; L.cfg_upper[t][dd] = chi[t * 64 + dd]; }
@@ -277,6 +312,7 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
   for (int t = 0; t < P.n_vel; ++t)
     for (int dd = 0; dd < m->nv; ++dd) L.vel_limit[t][dd] = vlim[t * 64 + dd];
   (void)d;
+  if (has_free || m->nv > 16 || nl > 16) return 32;                                     // (32: the row kernel on two DPP rows per problem)
   return m->nv <= 4 ? 4 : (m->nv <= 6 ? 6 : (m->nv == 7 ? 7 : (m->nv == 8 ? 8 : 16)));   // (16: the row kernel only)
 }
 
@@ -1054,17 +1090,22 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     }
   }
   {
-    LaneProblem lp;
+    LaneProblem2 lp;
     const int small_cls = build_lane_problem(m, d, P, ft, pcost, clo, chi, vlim, p->has_relative, lp);
     p->lane_nv = small_cls <= 8 ? small_cls : 0;
-    p->quad_nt = small_cls ? (small_cls <= 8 ? 8 : 16) : 0;
+    p->quad_nt = small_cls ? (small_cls <= 8 ? 8 : (small_cls == 32 ? 32 : 16)) : 0;
+    if (getenv("MKH_DEBUG_NO_PAIR_ROWS") && p->quad_nt == 32) p->quad_nt = 0;   // (A/B switch: 17 … 32-dof robots back on the wavefront kernel)
     if (small_cls) {
       p->lane_lds = lane_lds_bytes(lp.nlink);
       bool ident = true;
       for (int dd = 0; dd < lp.nv; ++dd) ident = ident && lp.dof_qadr[dd] == dd;
       p->lane_dims = LaneDims{lp.nq, lp.nv, lp.nlink, lp.n_frame, lp.n_posture, lp.n_cfg, lp.n_vel, ident ? 1 : 0};
-      if (hipMalloc((void**)&p->d_lane, sizeof(LaneProblem)) != hipSuccess ||
-          hipMemcpy(p->d_lane, &lp, sizeof(LaneProblem), hipMemcpyHostToDevice) != hipSuccess)
+      // (the lane kernel and the one-row builds of the row kernel read the small descriptor, the two-row build the large one)
+      LaneProblem lp1;
+      if (small_cls != 32) lane_problem_narrow(lp, lp1);
+      const void* src = small_cls == 32 ? (const void*)&lp : (const void*)&lp1;
+      const size_t bytes = small_cls == 32 ? sizeof(LaneProblem2) : sizeof(LaneProblem);
+      if (hipMalloc((void**)&p->d_lane, bytes) != hipSuccess || hipMemcpy(p->d_lane, src, bytes, hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(MKH_E_HIP, "lane descriptor upload failed"));
     }
   }
@@ -1244,12 +1285,15 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   // (9 … 16 dofs — hands, mobile arms: the row kernel with sixteen column registers, whatever the batch; there is no lane
   //  kernel of that size to hand over to)
   // (MKH_FLAG_WARM_START: the row kernel keeps its partition in the handle's warm-start buffer like the wavefront kernels)
-  if (p->quad_nt && small_ok && !((flags & MKH_FLAG_LANE_KERNEL) && p->lane_nv) &&
+  // (17 … 32 dofs or links, floating bases — H1, Go1, Spot, Allegro: the row kernel on TWO DPP rows per problem, two problems per
+  //  wavefront; single solves only — the fused loops of such robots integrate a quaternion and stay on the wavefront kernel)
+  if (p->quad_nt && small_ok && !(p->quad_nt == 32 && loop) && !((flags & MKH_FLAG_LANE_KERNEL) && p->lane_nv) &&
       (!p->lane_nv || a.B < (loop ? mkh::kLaneMinBatchLoop : mkh::kLaneMinBatch) || (flags & MKH_FLAG_QUAD_KERNEL))) {
-    const int grid = (a.B + 3) / 4;
+    const int per_wave = p->quad_nt == 32 ? 2 : 4;
+    const int grid = (a.B + per_wave - 1) / per_wave;
     p->last_grid = grid; p->last_nt = p->quad_nt;
     snprintf(p->last_kernel, sizeof(p->last_kernel), p->quad_nt == 8 ? (loop ? "ik_quad_kernel_loop" : "ik_quad_kernel")
-                                                                      : (loop ? "ik_quad_kernel_16_loop" : "ik_quad_kernel_16"));
+                                                     : (p->quad_nt == 32 ? "ik_quad_kernel_32" : (loop ? "ik_quad_kernel_16_loop" : "ik_quad_kernel_16")));
     SolveArgs aq = a;
     HIP_OK(clk_begin(p, aq, stream));
     p->last_lds = mkh::launch_quad(p->quad_nt, loop, grid, stream, p->d_lane, p->lane_dims, aq);

@@ -32,14 +32,14 @@
 
 namespace mkh {
 
-constexpr int kQuadRow = 16;                                  // lanes per problem
-constexpr int kQuadPerWave = kWave / kQuadRow;
-constexpr int kQuadPoseDoubles = 7 * kQuadRow;                // link poses [component][link]
-constexpr int kQuadAncDoubles = kQuadRow / 2;                 // ancestor index per link (int32)
+// LP = lanes per problem: 16 (one DPP row, nv ≤ 16) or 32 (TWO rows, 17 … 32 dofs or links, floating bases: Unitree H1 / Go1, Spot,
+// Allegro — round 4).  On two rows the DPP broadcast still works row by row, so a value u that every lane of the problem needs
+// from lane i is taken from `ua` = (own u on row 0, the other row's u on row 1) for i < 16 and from `ub` (the other way round) for
+// i ≥ 16: one ds_swizzle exchange of the rows (lane ⊕ 16) per broadcast vector, then 16 + 16 `row_newbcast` FMAs.
 constexpr int kQuadTaskDoubles = 28;                          // per frame task: A1 (9), A2 (9), frame position (3), W·e (6), μ
-constexpr int kQuadRowDoubles = kQuadPoseDoubles + kQuadAncDoubles + kLaneMaxFrames * kQuadTaskDoubles;
-static_assert(kLaneMaxLinks <= kQuadRow && kLaneDescDofs <= kQuadRow, "a problem must fit one DPP row");
-__host__ __device__ inline int quad_lds_bytes() { return kQuadPerWave * kQuadRowDoubles * (int)sizeof(double); }
+__host__ __device__ constexpr int quad_row_doubles(int lp) { return 7 * lp + lp / 2 + kLaneMaxFrames * kQuadTaskDoubles; }   // poses [component][link], ancestors, task blocks
+static_assert(kLaneMaxLinks <= 16 && kLaneDescDofs <= 16 && kLaneMaxLinks2 <= 32 && kLaneDescDofs2 <= 32, "a problem must fit one / two DPP rows");
+__host__ __device__ inline int quad_lds_bytes(int lp = 16) { return (kWave / lp) * quad_row_doubles(lp) * (int)sizeof(double); }
 
 // ---------------------------------------------------------------- DPP row primitives (all 64 lanes must be active)
 // s_nop 4: a DPP operand must not be read within 5 wait states of an EXEC write (and 2 of a VALU write of that register)
@@ -118,15 +118,100 @@ __device__ __forceinline__ double quad_max(double x) {
   return x;
 }
 
+
+// ---------------------------------------------------------------- two DPP rows per problem
+// the other row's value (lane ⊕ 16): ds_swizzle, bit mode, xor mask 0x10
+__device__ __forceinline__ double quad_swap16(const double x) {
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(x), 0x401F), hi = __builtin_amdgcn_ds_swizzle(__double2hiint(x), 0x401F);
+  return __hiloint2double(hi, lo);
+}
+struct QuadAB { double a, b; };                      // u as seen through row_newbcast:i for i < 16 (a) and for i ≥ 16 (b)
+__device__ __forceinline__ QuadAB quad_ab(const double u, const bool upper_row) {
+  const double sw = quad_swap16(u);
+  return QuadAB{upper_row ? sw : u, upper_row ? u : sw};
+}
+#define MKH_QFMAC2(D, U, I) "v_fmac_f64_dpp " D ", " U ", %[g] row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void quad_rank1_ab(double (&T)[32], const QuadAB u, const double g) {
+  asm volatile("s_nop 4\n\t" MKH_QFMAC2("%[t0]", "%[u]", 0) MKH_QFMAC2("%[t1]", "%[u]", 1) MKH_QFMAC2("%[t2]", "%[u]", 2) MKH_QFMAC2("%[t3]", "%[u]", 3)
+               MKH_QFMAC2("%[t4]", "%[u]", 4) MKH_QFMAC2("%[t5]", "%[u]", 5) MKH_QFMAC2("%[t6]", "%[u]", 6) MKH_QFMAC2("%[t7]", "%[u]", 7)
+               MKH_QFMAC2("%[t8]", "%[u]", 8) MKH_QFMAC2("%[t9]", "%[u]", 9) MKH_QFMAC2("%[t10]", "%[u]", 10) MKH_QFMAC2("%[t11]", "%[u]", 11)
+               MKH_QFMAC2("%[t12]", "%[u]", 12) MKH_QFMAC2("%[t13]", "%[u]", 13) MKH_QFMAC2("%[t14]", "%[u]", 14) MKH_QFMAC2("%[t15]", "%[u]", 15)
+               : [t0] "+v"(T[0]), [t1] "+v"(T[1]), [t2] "+v"(T[2]), [t3] "+v"(T[3]), [t4] "+v"(T[4]), [t5] "+v"(T[5]),
+                 [t6] "+v"(T[6]), [t7] "+v"(T[7]), [t8] "+v"(T[8]), [t9] "+v"(T[9]), [t10] "+v"(T[10]), [t11] "+v"(T[11]),
+                 [t12] "+v"(T[12]), [t13] "+v"(T[13]), [t14] "+v"(T[14]), [t15] "+v"(T[15])
+               : [u] "v"(u.a), [g] "v"(g));
+  asm volatile("s_nop 4\n\t" MKH_QFMAC2("%[t0]", "%[u]", 0) MKH_QFMAC2("%[t1]", "%[u]", 1) MKH_QFMAC2("%[t2]", "%[u]", 2) MKH_QFMAC2("%[t3]", "%[u]", 3)
+               MKH_QFMAC2("%[t4]", "%[u]", 4) MKH_QFMAC2("%[t5]", "%[u]", 5) MKH_QFMAC2("%[t6]", "%[u]", 6) MKH_QFMAC2("%[t7]", "%[u]", 7)
+               MKH_QFMAC2("%[t8]", "%[u]", 8) MKH_QFMAC2("%[t9]", "%[u]", 9) MKH_QFMAC2("%[t10]", "%[u]", 10) MKH_QFMAC2("%[t11]", "%[u]", 11)
+               MKH_QFMAC2("%[t12]", "%[u]", 12) MKH_QFMAC2("%[t13]", "%[u]", 13) MKH_QFMAC2("%[t14]", "%[u]", 14) MKH_QFMAC2("%[t15]", "%[u]", 15)
+               : [t0] "+v"(T[16]), [t1] "+v"(T[17]), [t2] "+v"(T[18]), [t3] "+v"(T[19]), [t4] "+v"(T[20]), [t5] "+v"(T[21]),
+                 [t6] "+v"(T[22]), [t7] "+v"(T[23]), [t8] "+v"(T[24]), [t9] "+v"(T[25]), [t10] "+v"(T[26]), [t11] "+v"(T[27]),
+                 [t12] "+v"(T[28]), [t13] "+v"(T[29]), [t14] "+v"(T[30]), [t15] "+v"(T[31])
+               : [u] "v"(u.b), [g] "v"(g));
+}
+#undef MKH_QFMAC2
+#define MKH_QDOT2(A, I) "v_fmac_f64_dpp " A ", %[u], %[t" #I "] row_newbcast:" #I " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ double quad_dot_ab(const double (&T)[32], const QuadAB u, const double acc) {
+  double a = acc, b = 0.0;
+  asm volatile("s_nop 4\n\t" MKH_QDOT2("%[a]", 0) MKH_QDOT2("%[b]", 1) MKH_QDOT2("%[a]", 2) MKH_QDOT2("%[b]", 3)
+               MKH_QDOT2("%[a]", 4) MKH_QDOT2("%[b]", 5) MKH_QDOT2("%[a]", 6) MKH_QDOT2("%[b]", 7)
+               MKH_QDOT2("%[a]", 8) MKH_QDOT2("%[b]", 9) MKH_QDOT2("%[a]", 10) MKH_QDOT2("%[b]", 11)
+               MKH_QDOT2("%[a]", 12) MKH_QDOT2("%[b]", 13) MKH_QDOT2("%[a]", 14) MKH_QDOT2("%[b]", 15)
+               : [a] "+v"(a), [b] "+v"(b)
+               : [u] "v"(u.a), [t0] "v"(T[0]), [t1] "v"(T[1]), [t2] "v"(T[2]), [t3] "v"(T[3]), [t4] "v"(T[4]), [t5] "v"(T[5]),
+                 [t6] "v"(T[6]), [t7] "v"(T[7]), [t8] "v"(T[8]), [t9] "v"(T[9]), [t10] "v"(T[10]), [t11] "v"(T[11]),
+                 [t12] "v"(T[12]), [t13] "v"(T[13]), [t14] "v"(T[14]), [t15] "v"(T[15]));
+  asm volatile("s_nop 4\n\t" MKH_QDOT2("%[a]", 0) MKH_QDOT2("%[b]", 1) MKH_QDOT2("%[a]", 2) MKH_QDOT2("%[b]", 3)
+               MKH_QDOT2("%[a]", 4) MKH_QDOT2("%[b]", 5) MKH_QDOT2("%[a]", 6) MKH_QDOT2("%[b]", 7)
+               MKH_QDOT2("%[a]", 8) MKH_QDOT2("%[b]", 9) MKH_QDOT2("%[a]", 10) MKH_QDOT2("%[b]", 11)
+               MKH_QDOT2("%[a]", 12) MKH_QDOT2("%[b]", 13) MKH_QDOT2("%[a]", 14) MKH_QDOT2("%[b]", 15)
+               : [a] "+v"(a), [b] "+v"(b)
+               : [u] "v"(u.b), [t0] "v"(T[16]), [t1] "v"(T[17]), [t2] "v"(T[18]), [t3] "v"(T[19]), [t4] "v"(T[20]), [t5] "v"(T[21]),
+                 [t6] "v"(T[22]), [t7] "v"(T[23]), [t8] "v"(T[24]), [t9] "v"(T[25]), [t10] "v"(T[26]), [t11] "v"(T[27]),
+                 [t12] "v"(T[28]), [t13] "v"(T[29]), [t14] "v"(T[30]), [t15] "v"(T[31]));
+  return a + b;
+}
+#undef MKH_QDOT2
+// the operations of the kernel body by lanes per problem
+template <int LP, int NT> __device__ __forceinline__ void qrank1(double (&T)[NT], const double u, const double g, const bool upper_row) {
+  if constexpr (LP == 32) quad_rank1_ab(T, quad_ab(u, upper_row), g); else quad_rank1(T, u, g);
+}
+template <int LP, int NT> __device__ __forceinline__ double qdot(const double (&T)[NT], const double u, const double acc, const bool upper_row) {
+  if constexpr (LP == 32) return quad_dot_ab(T, quad_ab(u, upper_row), acc); else return quad_dot(T, u, acc);
+}
+template <int LP> __device__ __forceinline__ double qsum(double x) {
+  x = quad_sum(x);
+  if constexpr (LP == 32) x += quad_swap16(x);
+  return x;
+}
+template <int LP> __device__ __forceinline__ double qmin(double x) {
+  x = quad_min(x);
+  if constexpr (LP == 32) x = fmin(x, quad_swap16(x));
+  return x;
+}
+template <int LP> __device__ __forceinline__ double qmax(double x) {
+  x = quad_max(x);
+  if constexpr (LP == 32) x = fmax(x, quad_swap16(x));
+  return x;
+}
+
 // Principal pivot on index K of the rows whose `act` is set: s = +1 sweeps K INTO the free set (pivot element: a Schur
 // complement diagonal of H, > 0), s = −1 sweeps it OUT (−(H_FF⁻¹)_KK < 0).  Lane j holds column j: T[i] = a_ij, cc = ĉ_j.
 //   a_ij ← a_ij − a_iK·a_Kj / d (i, j ≠ K),   a_Kj ← s·a_Kj / d,   a_KK ← −1/d;   the matrix stays symmetric, so row K is
 // register K of every lane, and the new column K (lane K) is that row again: lane K clears its column and takes part in
 // the same rank-1 update with the multiplier −s/d.  Returns "the pivot element had the wrong sign" (H is not ≻ 0).
-template <int K, int NT>
-__device__ __forceinline__ bool quad_pivot(double (&T)[NT], double& cc, const int l, const bool act, const double s) {
+template <int K, int NT, int LP = 16>
+__device__ __forceinline__ bool quad_pivot(double (&T)[NT], double& cc, const int l, const bool act, const double s, const bool upper_row = false) {
   const double rowk = T[K];
-  const double d = quad_bcast<K>(rowk), ck = quad_bcast<K>(cc);
+  double d, ck;
+  QuadAB rk{0.0, 0.0};
+  if constexpr (LP == 32) {
+    rk = quad_ab(rowk, upper_row);
+    const QuadAB c2 = quad_ab(cc, upper_row);
+    d = quad_bcast<K % 16>(K < 16 ? rk.a : rk.b); ck = quad_bcast<K % 16>(K < 16 ? c2.a : c2.b);
+  } else {
+    d = quad_bcast<K>(rowk); ck = quad_bcast<K>(cc);
+  }
   const bool ok = s * d > 0.0, go = act && ok, isk = l == K;
   const double inv = go ? fast_rcp(go ? d : 1.0) : 0.0;
   const double g = rowk * inv;
@@ -136,7 +221,7 @@ __device__ __forceinline__ bool quad_pivot(double (&T)[NT], double& cc, const in
     for (int i = 0; i < NT; ++i) T[i] = 0.0;
     cc = 0.0;
   }
-  quad_rank1(T, rowk, -gg);
+  if constexpr (LP == 32) quad_rank1_ab(T, rk, -gg); else quad_rank1(T, rowk, -gg);
   cc = fma(-ck, gg, cc);
   T[K] = go ? (isk ? -inv : s * g) : T[K];
   return act && !ok;
@@ -146,11 +231,20 @@ __device__ __forceinline__ bool quad_pivot(double (&T)[NT], double& cc, const in
 // (solve, q ← q + Δq) on its own problem until its frame tasks are within the thresholds or the budget is spent; rows
 // that are finished idle through the remaining iterations of their wavefront (masked commits).
 // NT: column registers per lane = the largest nv the instantiation takes (8: arms; 16: hands, mobile arms).
-template <int NT, bool LOOP>
-__global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restrict__ Pg, const LaneDims D, const SolveArgs A) {
+template <int NT, bool LOOP, int LP = 16>
+__global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblemT<LP, LP>* __restrict__ Pg, const LaneDims D, const SolveArgs A) {
+  static_assert((LP == 16 && NT <= 16) || (LP == 32 && NT == 32 && !LOOP), "one DPP row: ≤ 16 column registers; two rows: 32, single solves");
+  constexpr int kQuadRow = LP, kQuadPerWave = kWave / LP, kQuadPoseDoubles = 7 * LP, kQuadAncDoubles = LP / 2, kQuadRowDoubles = quad_row_doubles(LP);
+  constexpr unsigned long long kRowBits = LP == 32 ? 0xffffffffull : 0xffffull;
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const LaneProblem& P = *Pg;
-  const int lane = (int)threadIdx.x, row = lane >> 4, l = lane & 15, rbase = lane & 48;
+  const LaneProblemT<LP, LP>& P = *Pg;
+  const int lane = (int)threadIdx.x, row = lane / LP, l = lane & (LP - 1), rbase = lane & (64 - LP);
+  const bool upper_row = (lane & 16) != 0;           // (two rows per problem: which of the two this lane sits on)
+  // a set of lanes as bits of THIS problem / of any problem of the wavefront
+  auto own_bits = [&](const unsigned long long m) -> unsigned { return (unsigned)((m >> rbase) & kRowBits); };
+  auto any_bits = [&](const unsigned long long m) -> unsigned {
+    return LP == 32 ? (unsigned)((m | (m >> 32)) & kRowBits) : (unsigned)((m | (m >> 16) | (m >> 32) | (m >> 48)) & kRowBits);
+  };
   const int pb_raw = (int)blockIdx.x * kQuadPerWave + row;
   const bool live = pb_raw < A.B;
   const int pb = live ? pb_raw : A.B - 1;            // idle rows of the last wave redo the last problem, store nothing
@@ -160,7 +254,7 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
   double* const sX = S;                               // sX[c·16 + link]
   int* const sAnc = (int*)(S + kQuadPoseDoubles);
   double* const sT = S + kQuadPoseDoubles + kQuadAncDoubles;
-  auto row_mask = [&](const bool p) -> unsigned { return (unsigned)(__ballot(p) >> rbase) & 0xffffu; };
+  auto row_mask = [&](const bool p) -> unsigned { return own_bits(__ballot(p)); };
   int status = 0;
 #ifdef MKH_CLOCKS   // experiment builds (tools/phase_clocks.py): cycle stamps at the phase boundaries, row 24·pb of SolveArgs::clk
   long long tc[8];
@@ -217,7 +311,7 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
       const double we = cost * (-P.posture_gain[t] * (ptq[t] - qd));
       diag = fma(cost, cost, diag);
       cc = fma(we, cost, cc);                        // c −= (W·e)·(−cost)
-      mu_total += P.posture_lm[t] * quad_sum(we * we);
+      mu_total += P.posture_lm[t] * qsum<LP>(we * we);
     }
   }
   // box limits
@@ -245,7 +339,11 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
     const double qv = bperm_f64(qd, rbase + (jt >= 0 ? L.dof : 0)) - L.qpos0;
     V3 xp{L.pos[0], L.pos[1], L.pos[2]};
     Q4 xq{L.quat[0], L.quat[1], L.quat[2], L.quat[3]};
-    if (jt >= 0) {
+    if (LP == 32 && jt == JNT_BALL) {
+      // the rotation of a free joint: the body's orientation is the (normalised) quaternion of q (mj_kinematics)
+      const double* qq = A.q + (size_t)pb * nq + L.qadr;
+      xq = Q4{qq[0], qq[1], qq[2], qq[3]};
+    } else if (jt >= 0) {
       const V3 ax{L.axis[0], L.axis[1], L.axis[2]};
       if (jt == JNT_SLIDE) {
         xp = xp + qv * qrot(xq, ax);
@@ -375,7 +473,7 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
       for (int r = 0; r < 6; ++r) {
         if ((ft.rowmask >> r) & 1) {                 // (uniform: rows with zero cost contribute nothing)
           cc = fma(-t[21 + r], Jw[r], cc);
-          quad_rank1(T, Jw[r], Jw[r]);
+          qrank1<LP>(T, Jw[r], Jw[r], upper_row);
         }
       }
       mu_total += t[27];
@@ -396,7 +494,7 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
 
   MKH_QTICK();
   // ------------------------------------------------------------------- QP
-  const double tolw = 1e-16 * quad_max(dv ? hdiag : 0.0);         // (the wavefront kernel's multiplier threshold)
+  const double tolw = 1e-16 * qmax<LP>(dv ? hdiag : 0.0);         // (the wavefront kernel's multiplier threshold)
   bool done = (status & 2) != 0 || (LOOP && fin);
   // Starting partition from the diagonal estimate x_l ≈ −c_l / H_ll: dofs it puts outside the box start AT that bound
   // (any partition is a valid start of block principal pivoting; the benchmark's velocity limits saturate most dofs of
@@ -420,11 +518,10 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
   }
   {
     const unsigned long long fr = __ballot(st == 0 && !done);
-    const unsigned mine = (unsigned)(fr >> rbase) & 0xffffu;
-    const unsigned any = (unsigned)(fr | (fr >> 16) | (fr >> 32) | (fr >> 48)) & 0xffffu;
+    const unsigned mine = own_bits(fr), any = any_bits(fr);
     quad_for<NT>([&](auto kc) {
       constexpr int K = decltype(kc)::value;
-      if ((any >> K) & 1u) { if (quad_pivot<K, NT>(T, cc, l, ((mine >> K) & 1u) != 0, 1.0)) { status |= 4; done = true; } }
+      if ((any >> K) & 1u) { if (quad_pivot<K, NT, LP>(T, cc, l, ((mine >> K) & 1u) != 0, 1.0, upper_row)) { status |= 4; done = true; } }
     });
   }
   MKH_QTICK();
@@ -440,7 +537,7 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
   for (int it = 0; it < 10 * NT + 10; ++it) {
     if (!__ballot(!done)) break;                     // every row of the wave has its optimum
     const double xb = st == 1 ? lo : (st == 2 ? hi : 0.0);
-    const double val = quad_dot(T, xb, cc);          // −x_l of a free index, the multiplier w_l of a bound one
+    const double val = qdot<LP>(T, xb, cc, upper_row);          // −x_l of a free index, the multiplier w_l of a bound one
     const double xn = st ? xb : -val;
     int f = 0;                                       // 0 keep, 1 → lower, 2 → upper, 3 → free
     if (!st) {
@@ -457,9 +554,9 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
     unsigned blockm = 0, relm = 0;
     if (__ballot(mode == 1 && !done)) {
       const double aj = (f == 2) ? (hi - xc) / dstep : ((f == 1) ? (lo - xc) / dstep : 1.0);   // (|dstep| > 1e-12 where f is 1 or 2)
-      amin = quad_min((mode == 1 && !st) ? aj : 1.0);
+      amin = qmin<LP>((mode == 1 && !st) ? aj : 1.0);
       const double viol = (dv && st == 1) ? -val : ((dv && st == 2) ? val : 0.0);
-      const double vmax = quad_max(viol);
+      const double vmax = qmax<LP>(viol);
       blockm = row_mask(mode == 1 && !st && f != 0 && aj == amin);
       relm = row_mask(st != 0 && viol == vmax && vmax > tolw);
     }
@@ -498,12 +595,11 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblem* __restri
       }
     }
     const unsigned long long flips = __ballot(flip);
-    const unsigned mine = (unsigned)(flips >> rbase) & 0xffffu, freem = row_mask(st == 0);
-    const unsigned any = (unsigned)(flips | (flips >> 16) | (flips >> 32) | (flips >> 48)) & 0xffffu;
+    const unsigned mine = own_bits(flips), freem = row_mask(st == 0), any = any_bits(flips);
     quad_for<NT>([&](auto kc) {
       constexpr int K = decltype(kc)::value;
       if ((any >> K) & 1u) {
-        if (quad_pivot<K, NT>(T, cc, l, ((mine >> K) & 1u) != 0, ((freem >> K) & 1u) ? -1.0 : 1.0)) { status |= 4; done = true; }
+        if (quad_pivot<K, NT, LP>(T, cc, l, ((mine >> K) & 1u) != 0, ((freem >> K) & 1u) ? -1.0 : 1.0, upper_row)) { status |= 4; done = true; }
       }
     });
     if (flip) st = (f == 3) ? 0 : f;

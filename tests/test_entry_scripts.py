@@ -71,7 +71,7 @@ def test_bench_helpers():
     assert 1 <= b.usable_cpus() <= (os.cpu_count() or 1)
     assert b._free_port() > 0
     assert b.kernel_keys("ik_solve_kernel_48_72+redo_64") == ["ik_solve_kernel_48_72", "ik_solve_kernel_64_72"]
-    assert b.kernel_keys("ik_quad_kernel") == ["ik_quad_kernel<8,0>"] and b.kernel_keys("ik_lane_kernel_6") == ["ik_lane_kernel<6,0>"]
+    assert b.kernel_keys("ik_quad_kernel") == ["ik_quad_kernel<8,0,16>"] and b.kernel_keys("ik_quad_kernel_32") == ["ik_quad_kernel<32,0,32>"] and b.kernel_keys("ik_lane_kernel_6") == ["ik_lane_kernel<6,0>"]
     assert b.kernel_keys("ik_solve_kernel_64_8+wide") == ["ik_solve_kernel_64_8", "ik_wide_kernel"]
 
 

@@ -113,18 +113,24 @@ def test_ur5e_batch_vs_other_kernels_and_c_oracle(nat, vmax, dt):
                                           ("stanford_tidybot__scene_base", QUAD),
                                           ("stanford_tidybot__scene_mobile_kinova", QUAD + "_16"),
                                           ("leap_hand__scene_right", QUAD + "_16"), ("leap_hand__scene_left", QUAD + "_16"),
-                                          ("stanford_tidybot__scene", "ik_solve_kernel")])
+                                          ("stanford_tidybot__scene", QUAD + "_32"), ("wonik_allegro__scene_left", QUAD + "_32"),
+                                          ("unitree_go1__scene", QUAD + "_32"), ("boston_dynamics_spot__scene", QUAD + "_32"),
+                                          ("unitree_h1__scene", QUAD + "_32"), ("shadow_hand__scene_right", QUAD + "_32"),
+                                          ("unitree_g1__scene", "ik_solve_kernel")])
 def test_other_small_robots(nat, scene, kernel):
     """7-dof arms, a 3-dof base with slide joints and a body frame; 9 … 16 dofs on sixteen column registers: the 10-dof mobile
-    arm (three joints on its base body) and the 16-dof LEAP hands (a tree of four fingers); 18 dofs stay on the wavefront kernel."""
+    arm (three joints on its base body) and the 16-dof LEAP hands (a tree of four fingers); 17 … 32 dofs on TWO DPP rows per
+    problem (round 4): the 18-dof Tidybot, the Allegro and Shadow hands, and the floating bases — Go1, Spot, H1 (a free joint =
+    three slide links + a quaternion link); the 43-dof G1 stays on the wavefront kernel."""
     m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", scene + ".json"))
     nm = nat.NativeModel(m)
     B = 514
     sites = [i for i, n in enumerate(m.site_names) if n and m.site_bodyid[i] > 0]
     frame = ("site", sites[-1]) if sites else ("body", int(np.argmax(m.body_depth)))
     ft = {"frame_type": frame[0], "frame_id": frame[1], "cost": [1.0, 1.0, 1.0, 0.3, 0.3, 0.3], "gain": 0.9, "lm_damping": 0.5}
-    vidx = [int(m.jnt_dofadr[j]) for j in range(m.njnt)]
-    vlim = np.where([m.jnt_type[j] == 2 for j in range(m.njnt)], 0.2, 1.0)
+    hs = [j for j in range(m.njnt) if m.jnt_type[j] in (2, 3)]
+    vidx = [int(m.jnt_dofadr[j]) for j in hs]
+    vlim = np.where([m.jnt_type[j] == 2 for j in hs], 0.2, 1.0)
     prob = nat.NativeProblem(nm, frame_tasks=[ft], posture_tasks=[{"cost": 3e-2, "gain": 0.5, "lm_damping": 0.1}],
                              configuration_limits=[nc._cfg_limit(m)], velocity_limits=[{"indices": vidx, "limit": vlim}],
                              max_batch=B)
@@ -370,6 +376,45 @@ def test_real_mink_fixtures_of_the_sixteen_register_build(nat, name, scene):
     np.testing.assert_allclose(pr.P[main], d["H"][main], rtol=0, atol=1e-10 * np.abs(d["H"]).max())
     np.testing.assert_allclose(pr.q[main], d["c"][main], rtol=0, atol=1e-10 * max(1.0, np.abs(d["c"]).max()))
     np.testing.assert_allclose(pr.P[~main], d["H"][~main], rtol=0, atol=1e-6 * np.abs(d["H"]).max())      # (small-angle stream)
+
+
+@pytest.mark.parametrize("name,scene", [("h1_c", "unitree_h1__scene"), ("go1_c", "unitree_go1__scene")])
+def test_real_mink_fixtures_of_the_two_row_build(nat, name, scene):
+    """The REAL mink (tests/golden/make_golden_mid.py) on the Unitree H1 — the tasks of examples/humanoid_h1.py without the CoM
+    task: a body-frame pelvis task, feet, wrists, posture — and on the Go1 with the tasks of examples/quadruped_go1.py: the public
+    API on its default dispatch, which for these floating-base robots is the row kernel on two DPP rows per problem
+    (`ik_quad_kernel_32`), against the recorded v; every eighth instance is the small-angle stream (1e-5).  The
+    same call pinned to the wavefront kernel gives the same answer."""
+    import mink_amd as mink
+    d = np.load(os.path.join(oc.GOLDEN, f"ik_{name}.npz"))
+    m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", scene + ".json"))
+    B = len(d["q"])
+    cfg = mink.Configuration(m, d["q"])
+    if name == "h1_c":
+        tasks = [mink.FrameTask("pelvis", "body", position_cost=0.0, orientation_cost=10.0)]
+        tasks += [mink.FrameTask(s, "site", position_cost=200.0, orientation_cost=10.0, lm_damping=1.0) for s in ("right_foot", "left_foot")]
+        tasks += [mink.FrameTask(s, "site", position_cost=200.0, orientation_cost=0.0, lm_damping=1.0) for s in ("right_wrist", "left_wrist")]
+        post = mink.PostureTask(m, cost=1.0)
+        lims = [mink.ConfigurationLimit(m), mink.VelocityLimit(m, {m.jnt_names[j]: np.pi for j in range(m.njnt) if m.jnt_type[j] == 3})]
+    else:
+        tasks = [mink.FrameTask("trunk", "body", position_cost=1.0, orientation_cost=1.0)]
+        tasks += [mink.FrameTask(s, "site", position_cost=1.0, orientation_cost=0.0) for s in ("FL", "FR", "RR", "RL")]
+        post = mink.PostureTask(m, cost=1e-5)
+        lims = [mink.ConfigurationLimit(m)]
+    for k, t in enumerate(tasks):
+        t.set_target(mink.SE3(d["frame_targets"][:, k]))
+    post.set_target(d["posture_target"])
+    tasks.append(post)
+    v = mink.solve_ik(cfg, tasks, float(d["dt"]), "quadprog", float(d["damping"]), limits=lims)
+    prob = list(cfg._problems.values())[-1]
+    assert prob.last_kernel() == QUAD + "_32", prob.last_kernel()
+    main = np.ones(B, bool); main[7::8] = False
+    err = _rel(v, d["v"])
+    print("%s: row kernel (two rows per problem) vs real mink: max rel err main %.1e small-angle %.1e" % (name, err[main].max(), err[~main].max()))
+    assert err[main].max() < 1e-8 and err[~main].max() < 1e-5
+    pr = mink.build_ik(cfg, tasks, float(d["dt"]), float(d["damping"]), lims)        # (H, c: the wavefront kernel's taps)
+    np.testing.assert_allclose(pr.P[main], d["H"][main], rtol=0, atol=1e-10 * np.abs(d["H"]).max())
+    np.testing.assert_allclose(pr.q[main], d["c"][main], rtol=0, atol=1e-10 * max(1.0, np.abs(d["c"]).max()))
 
 
 @pytest.mark.parametrize("scene", ["universal_robots_ur5e__scene", "leap_hand__scene_right"])
