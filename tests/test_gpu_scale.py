@@ -318,7 +318,7 @@ def test_cold_start_refinement_agrees_with_the_plain_low_rank_start(monkeypatch)
 
 
 _BENCH_KERNELS = {"ur5e_c2": "ik_quad_kernel", "g1_c3": "ik_solve_kernel_44_32_r44_w3", "g1_full": "ik_solve_kernel_44_36_r44",
-                  "shadow_c4": "ik_solve_kernel_48_72+redo_64", "g1_plugin": "ik_solve_kernel_48_256"}
+                  "shadow_c4": "ik_solve_kernel_48_72+redo_64", "g1_plugin": "ik_solve_kernel_48_256", "h1_c3": "ik_quad_kernel_32"}
 
 
 def _oracle_specs_of_bench(name, model, prob_desc):

@@ -38,6 +38,9 @@ for grp in "${PMC_GROUPS[@]}"; do
 done
 python "$R/tools/rocprof_summary.py" pmc "$R/gpurun_out/${TAG}_${NAME}_pmc.json" "${DIRS[@]}"
 if [ -z "${MKH_PROFILE_PMC_ONLY:-}" ]; then
+# the plain bench line of the same binary on the same box replays the counters just collected (bench.py reads profiles/ and
+# checks the summary's code-object hashes against what it runs)
+cp "$R/gpurun_out/${TAG}_${NAME}_pmc.json" "$R/gpurun_out/${TAG}_${NAME}_kernel_stats.csv" "$R/profiles/" 2>/dev/null
 python "$R/bench.py" --config $CFG --batch $B --steps 20 --warmup 3 > "$R/gpurun_out/${TAG}_${NAME}_bench.json" 2> "$O/bench.err"
 cat "$R/gpurun_out/${TAG}_${NAME}_bench.json"
 head -5 "$R/gpurun_out/${TAG}_${NAME}_kernel_stats.csv"
