@@ -90,7 +90,7 @@ def pmc(out_path, dirs):
     solve_kernel = None
     for d in dirs:
         counters, res = read_counters(d)
-        iks = {k: cs for k, cs in counters.items() if "ik_solve_kernel" in k or "ik_lane_kernel" in k or "ik_quad_kernel" in k}
+        iks = {k: cs for k, cs in counters.items() if "ik_solve_kernel" in k or "ik_lane_kernel" in k or "ik_quad_kernel" in k or "ik_wide_kernel" in k}
         if iks:
             # (a tight-rows solve is two launches — the 48-row build and the full-row redo behind it, equally often: the one
             #  that does the work has the larger counters)
