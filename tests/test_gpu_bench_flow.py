@@ -47,3 +47,31 @@ def test_two_gpu_line_is_refused_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        env=_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "only 1 GPU(s) visible" in r.stderr and "{" not in r.stdout
+
+
+def test_rccl_process_group_of_one_runs_the_gather_and_the_timing_reduce():
+    """The collectives of the N-rank bench — `gather_rows` (dist.gather of v into row blocks of a preallocated result) and the
+    MAX all-reduce of the elapsed time — on the `nccl` backend (= RCCL), in the only world this box can form: one rank.  It
+    proves the RCCL build initialises on the box and that the calls the scaling run makes execute on device tensors; it says
+    nothing about xGMI."""
+    code = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from mink_amd.distributed import gather_rows, shard_bounds
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29633", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", world_size=1, rank=0)
+assert dist.get_backend() == "nccl"
+v = torch.arange(4096 * 43, dtype=torch.float64, device="cuda").reshape(4096, 43)
+out = torch.empty_like(v)
+got = gather_rows(v, 4096, dst=0, out=out)
+t = torch.tensor([1.25], dtype=torch.float64, device="cuda")
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+dist.barrier()
+torch.cuda.synchronize()
+assert got.data_ptr() == out.data_ptr() and torch.equal(out, v) and t.item() == 1.25 and shard_bounds(4096, 1, 0) == (0, 4096)
+dist.destroy_process_group()
+print("RCCL_OK")
+""" % REPO
+    r = subprocess.run([sys.executable, "-c", code], env=_env(HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
