@@ -417,7 +417,35 @@ def test_real_mink_fixtures_of_the_two_row_build(nat, name, scene):
     np.testing.assert_allclose(pr.q[main], d["c"][main], rtol=0, atol=1e-10 * max(1.0, np.abs(d["c"]).max()))
 
 
-@pytest.mark.parametrize("scene", ["universal_robots_ur5e__scene", "leap_hand__scene_right"])
+@pytest.mark.parametrize("B", [1, 3, 129])
+def test_two_row_build_on_ragged_batches(nat, B):
+    """Two problems per wavefront: an odd batch leaves the upper half of the last wavefront idle (it redoes the last problem and
+    stores nothing); one instance is half a wavefront.  Go1 (floating base) against the wavefront kernel and the C oracle."""
+    m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", "unitree_go1__scene.json"))
+    nm = nat.NativeModel(m)
+    fts = [{"frame_type": "site", "frame_id": m.name2id("site", s), "cost": [1.0, 1.0, 1.0, 0.0, 0.0, 0.0], "gain": 1.0, "lm_damping": 0.5}
+           for s in ("FL", "FR", "RL", "RR")]
+    fts.append({"frame_type": "body", "frame_id": m.name2id("body", "trunk"), "cost": [1.0] * 6, "gain": 1.0, "lm_damping": 0.0})
+    hs = [j for j in range(m.njnt) if m.jnt_type[j] == 3]
+    vidx = [int(m.jnt_dofadr[j]) for j in hs]
+    prob = nat.NativeProblem(nm, frame_tasks=fts, posture_tasks=[{"cost": 1e-3}], configuration_limits=[nc._cfg_limit(m)],
+                             velocity_limits=[{"indices": vidx, "limit": np.full(len(vidx), 2.0)}], max_batch=B)
+    home = m.key_qpos[m.name2id("key", "home")]
+    q, tg = workloads.make_batch(m, nm, prob, np.random.default_rng(B), B, base_q=home)
+    v, st = prob.solve(q, tg, home[None, :], None, 1e-2, 1e-4)
+    assert prob.last_kernel() == QUAD + "_32" and (st & ~1 == 0).all()
+    vw, stw = prob.solve(q, tg, home[None, :], None, 1e-2, 1e-4, wave_kernel=True)
+    assert prob.last_kernel().startswith("ik_solve_kernel") and (stw == st).all()
+    assert _rel(v, vw).max() < 1e-8
+    c6 = lambda f: np.array(f["cost"], dtype=np.float64)
+    tasks = [oik.FrameTaskSpec(f["frame_id"], f["frame_type"], c6(f), tg[0, k], 1.0, f["lm_damping"]) for k, f in enumerate(fts)]
+    tasks.append(oik.PostureTaskSpec(np.full(m.nv, 1e-3), home))
+    limits = [oik.ConfigurationLimitSpec(), oik.VelocityLimitSpec(np.array(vidx), np.full(len(vidx), 2.0))]
+    v_c, st_c = cport.CProblem(m, tasks, limits).solve_batch(q, tg, home[None, :], 1e-2, 1e-4)
+    assert (st_c == 0).all() and _rel(v, v_c).max() < 1e-8
+
+
+@pytest.mark.parametrize("scene", ["universal_robots_ur5e__scene", "leap_hand__scene_right", "unitree_h1__scene"])
 def test_warm_start_across_calls(nat, scene):
     """MKH_FLAG_WARM_START on the row kernel: a closed loop of single solves on the same batch — every step's v equals the
     cold solve's (the optimum is unique), whatever partition the previous call left in the handle; a permuted batch (a wrong
@@ -428,7 +456,7 @@ def test_warm_start_across_calls(nat, scene):
     sites = [i for i, n in enumerate(m.site_names) if n and m.site_bodyid[i] > 0]
     tips = sites[-4:] if m.nv > 8 else sites[-1:]
     fts = [{"frame_type": "site", "frame_id": i, "cost": [1.0, 1.0, 1.0, 0.2, 0.2, 0.2], "gain": 1.0, "lm_damping": 1.0} for i in tips]
-    vidx = [int(m.jnt_dofadr[j]) for j in range(m.njnt)]
+    vidx = [int(m.jnt_dofadr[j]) for j in range(m.njnt) if m.jnt_type[j] in (2, 3)]
     kw = dict(frame_tasks=fts, posture_tasks=[{"cost": 1e-2}], configuration_limits=[nc._cfg_limit(m)],
               velocity_limits=[{"indices": vidx, "limit": np.full(len(vidx), 1.0)}], max_batch=B)
     prob, cold = nat.NativeProblem(nm, **kw), nat.NativeProblem(nm, **kw)

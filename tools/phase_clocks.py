@@ -48,7 +48,7 @@ def run(name, B=None):
     c = c[ok]
     tot = c[:, 7] - c[:, 0]
     print(f"{name} B={B} kernel {prob.last_kernel()} launch {prob.launch_info(B)}")
-    if prob.last_kernel() == "ik_quad_kernel":  # row-per-problem kernel: its own six intervals
+    if prob.last_kernel().startswith("ik_quad_kernel"):  # row-per-problem kernel: its own six intervals
         d = np.diff(c[:, :7], axis=1)
         print("  per-row cycles: mean %.0f  p50 %.0f  p99 %.0f" % (tot.mean(), np.median(tot), np.percentile(tot, 99)))
         for k, n in enumerate(["load q", "FK (links)", "task lanes", "objective + limits", "QP: all dofs in", "QP: flips"]):
