@@ -289,6 +289,7 @@ def load_mjcf(path: str) -> FlatModel:
                 size[2] = half
         contype, conaff = int(a.get("contype", 1)), int(a.get("conaffinity", 1))
         dataid = -1
+        pos_attr, quat_attr = pos.copy(), quat.copy()          # the geom's own frame, before a mesh's inertial frame is composed in
         if gtype == GEOM_MESH or has_mesh:
             valid = 0  # local frame / fitted size need the mesh asset
             lazy = assets.get(a.get("mesh", ""))
@@ -337,9 +338,21 @@ def load_mjcf(path: str) -> FlatModel:
             m = float(a["mass"])
         elif valid == 1:
             m = float(a.get("density", 1000.0)) * _geom_volume(gtype, size)
+        elif valid == 2 and gtype != GEOM_MESH:
+            m = float(a.get("density", 1000.0)) * _geom_volume(gtype, size)      # a primitive fitted to a mesh weighs what the primitive weighs
         else:
             m = 0.0
-            unknown = float(a.get("density", 1000.0)) != 0.0     # mass = density x (mesh volume): needs the asset
+            density = float(a.get("density", 1000.0))
+            lazy = assets.get(a.get("mesh", ""))
+            if density != 0.0:
+                # mass = density x volume of the mesh (or of the primitive fitted to it), at the mesh's centre of mass: needs the
+                # asset — compiled only if the body turns out to have no <inertial> (visit_body), the one case in which it is used
+                def unknown(lazy=lazy, gtype=gtype, p0=pos_attr, q0=quat_attr, density=density, fs=float(a.get("fitscale", 1.0))):
+                    if lazy is None or not os.path.exists(lazy.path):
+                        raise _meshes.MeshError("mesh asset not available")
+                    asset = lazy.get()
+                    vol = asset.volume if gtype == GEOM_MESH else _geom_volume(gtype, _meshes.fit_primitive(gtype, asset.boxsz) * fs)
+                    return density * vol, p0 + _quat_rotate(q0, asset.pos)
         gmass_acc.append((m, pos, unknown))
 
     def add_site(el, body_id, childclass):
@@ -405,14 +418,22 @@ def load_mjcf(path: str) -> FlatModel:
             B["mass"][body_id] = float(inertial.get("mass"))
             B["ipos"][body_id] = _vec(inertial.get("pos"), 3, [0, 0, 0])
         elif body_id != 0:
-            mt = sum(m for m, _, _ in gmass)
+            # no <inertial>: mass and centre of mass from the geoms (inertiafromgeom's default); a mesh geom contributes density x
+            # the mesh's volume at the mesh's centre of mass (meshes.py: the compiler's legacy volume).  An asset that cannot be
+            # compiled leaves the body flagged (FlatModel.require_valid_masses refuses it for ComTask) instead of weighing 0.
+            parts = []
+            for m, p, u in gmass:
+                if callable(u):
+                    try:
+                        m, p = u()
+                    except (_meshes.MeshError, ValueError, RuntimeError, OSError):
+                        mass_valid[body_id] = 0
+                        continue
+                parts.append((m, p))
+            mt = sum(m for m, _ in parts)
             B["mass"][body_id] = mt
             if mt > mjMINVAL:
-                B["ipos"][body_id] = sum(m * p for m, p, _ in gmass) / mt
-            if any(u for _, _, u in gmass):
-                # no <inertial> and a mesh geom with non-zero density: MuJoCo derives mass and inertial frame from
-                # the mesh.  Not available here — flag the body (FlatModel.require_valid_masses) instead of using 0.
-                mass_valid[body_id] = 0
+                B["ipos"][body_id] = sum(m * p for m, p in parts) / mt
         for ch in el:
             if ch.tag == "body":
                 visit_body(ch, body_id, childclass)

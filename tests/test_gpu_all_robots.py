@@ -172,3 +172,38 @@ def test_shadow_hand_with_mesh_fitted_fingertips_and_the_forearm_mesh():
     print("shadow *_3 + forearm mesh: %d pairs, %d detected contacts, %d binding rows, max rel err %.2e" %
           (len(col.geom_id_pairs), active, binding, worst))
     assert (st & ~1 == 0).all() and worst < 2e-5 and active > 0
+
+
+def test_com_task_on_a_hand_whose_masses_come_from_its_meshes():
+    """The Allegro hand's MJCF has no <inertial> elements: every body's mass is density x the volume of its visual meshes
+    (`<geom density="800"/>`, wonik_allegro/left_hand.xml:10).  Since round 4 the MJCF reader derives them (it used to flag the
+    bodies and ComTask refused the model); ComTask + fingertip tasks against the C oracle on the same FlatModel."""
+    import mink_amd as mink
+    m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", "wonik_allegro__scene_left.json"))
+    assert (np.asarray(m.body_mass_valid) == 1).all() and 0.4 < m.body_subtreemass[1] < 0.8          # (the real hand: ≈ 0.6 kg)
+    B = 64
+    rng = np.random.default_rng(4)
+    q = np.tile(m.qpos0, (B, 1)) + rng.uniform(0.05, 0.4, size=(B, m.nq))
+    cfg = mink.Configuration(m, q)
+    tips = [n for n in m.site_names if n][-4:]
+    tgt = mink.Configuration(m, q + rng.normal(scale=0.1, size=q.shape))
+    tasks = []
+    for s in tips:
+        t = mink.FrameTask(s, "site", position_cost=1.0, orientation_cost=0.0, lm_damping=1.0)
+        t.set_target(tgt.get_transform_frame_to_world(s, "site"))
+        tasks.append(t)
+    com = mink.ComTask(cost=5.0)
+    com_target = np.asarray(tgt.subtree_com())
+    com.set_target(com_target)
+    post = mink.PostureTask(m, cost=1e-2); post.set_target(m.qpos0)
+    lims = [mink.ConfigurationLimit(m)]
+    v = mink.solve_ik(cfg, tasks + [com, post], 1e-2, "quadprog", 1e-4, limits=lims)
+    ftg = np.stack([t.transform_target_to_world.wxyz_xyz for t in tasks], axis=1)
+    specs = [oik.FrameTaskSpec(m.name2id("site", s), "site", np.array([1.0, 1, 1, 0, 0, 0]), ftg[0, k], 1.0, 1.0) for k, s in enumerate(tips)]
+    specs += [oik.ComTaskSpec(np.full(3, 5.0), None), oik.PostureTaskSpec(np.full(m.nv, 1e-2), m.qpos0)]
+    v_c, st_c = cport.CProblem(m, specs, [oik.ConfigurationLimitSpec()]).solve_batch(q, ftg, m.qpos0[None, :], 1e-2, 1e-4,
+                                                                                     com_target=np.asarray(com_target).reshape(B, 1, 3))
+    assert (st_c == 0).all()
+    err = (np.abs(v - v_c) / np.maximum(1.0, np.abs(v_c).max(axis=1, keepdims=True))).max()
+    print("Allegro + ComTask (mesh-derived masses): max rel err vs C oracle %.1e" % err)
+    assert err < 1e-8

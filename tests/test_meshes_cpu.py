@@ -194,3 +194,45 @@ def test_an_asset_the_reader_cannot_compile_does_not_fail_the_model_load(tmp_pat
     p.write_text(xml)
     m = mjcf.load_mjcf(str(p))
     assert m.nv == 1 and list(np.asarray(m.geom_valid)) == [0, 0, 1]
+
+
+def test_body_mass_from_mesh_geoms_when_there_is_no_inertial(tmp_path):
+    """A body without <inertial> gets mass and centre of mass from its geoms (`inertiafromgeom` default); a mesh geom weighs
+    density x the mesh's volume at the mesh's centre of mass, a primitive fitted to a mesh what the fitted primitive weighs — what a
+    ComTask on the Allegro hands (21 such bodies, `<geom density="800"/>` on visual meshes) needs from the MJCF reader (round-3
+    review, missing item 5; a compiled MjModel carries these numbers).  A mesh file that is not there leaves the body flagged."""
+    from mink_amd import mjcf
+    v, f = _box(0.02, 0.03, 0.05)
+    v = v + np.array([0.1, -0.2, 0.3])                               # centre of mass away from the file's origin
+    with open(tmp_path / "brick.obj", "w") as fh:
+        for p in v:
+            fh.write("v %.9f %.9f %.9f\n" % tuple(p))
+        for t in f:
+            fh.write("f %d %d %d\n" % tuple(t + 1))
+    xml = f"""<mujoco><compiler meshdir="{tmp_path}"/>
+    <asset><mesh name="brick" file="brick.obj"/><mesh name="gone" file="gone.obj"/></asset>
+    <worldbody>
+      <body name="a" pos="1 0 0"><joint type="hinge" axis="0 0 1"/>
+        <geom type="mesh" mesh="brick" density="800" pos="0 0 0.5" contype="0" conaffinity="0"/>
+        <geom type="sphere" size="0.1" mass="0.25" pos="0 1 0"/>
+        <geom type="capsule" mesh="brick" pos="0.2 0 0"/>
+        <geom type="box" size="0.1 0.1 0.1" mass="0" pos="5 5 5"/>
+      </body>
+      <body name="b"><joint type="hinge" axis="0 0 1"/><geom type="mesh" mesh="gone" contype="0" conaffinity="0"/></body>
+      <body name="c"><inertial pos="0 0 0.1" mass="2"/><joint type="hinge" axis="0 0 1"/><geom type="mesh" mesh="gone"/></body>
+    </worldbody></mujoco>"""
+    p = tmp_path / "m.xml"
+    p.write_text(xml)
+    m = mjcf.load_mjcf(str(p))
+    a, b, c = (m.name2id("body", n) for n in "abc")
+    vol = 8 * 0.02 * 0.03 * 0.05
+    # the fitted capsule: inertia box of the brick = the brick; radius = mean of the two short half-sizes, half-length = long − r/2
+    r, h = 0.025, 0.05 - 0.0125
+    m_caps = 1000.0 * (np.pi * r * r * 2 * h + 4.0 / 3.0 * np.pi * r ** 3)
+    parts = [(800.0 * vol, np.array([0.1, -0.2, 0.3 + 0.5])), (0.25, np.array([0.0, 1.0, 0.0])),
+             (m_caps, np.array([0.2 + 0.1, -0.2, 0.3]))]
+    mt = sum(w for w, _ in parts)
+    assert list(np.asarray(m.body_mass_valid)[[a, b, c]]) == [1, 0, 1]
+    np.testing.assert_allclose(m.body_mass[a], mt, rtol=1e-12)
+    np.testing.assert_allclose(m.body_ipos[a], sum(w * x for w, x in parts) / mt, rtol=0, atol=1e-12)
+    assert m.body_mass[c] == 2.0 and m.body_mass[b] == 0.0
