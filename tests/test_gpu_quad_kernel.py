@@ -417,6 +417,66 @@ def test_real_mink_fixtures_of_the_two_row_build(nat, name, scene):
     np.testing.assert_allclose(pr.q[main], d["c"][main], rtol=0, atol=1e-10 * max(1.0, np.abs(d["c"]).max()))
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MKH_FUZZ_SEEDS", "10"))))
+def test_random_trees_on_the_two_row_build(nat, seed):
+    """Random trees with 17 … 32 dofs or a FLOATING root (hinge / slide joints elsewhere; branching, fixed bodies, several joints on
+    one body, frames on sites and bodies, zero-cost rows, per-dof posture costs, random gains / LM damping / limits) through the
+    public API: default dispatch = the row kernel on two DPP rows per problem; the same compiled problem on the wavefront kernel
+    and on the C oracle."""
+    import mink_amd as mink
+    from random_models import random_mjcf, rand_q
+    rng = np.random.default_rng(9100 + seed)
+    free = seed % 2 == 0
+    for _ in range(200):
+        nbody = int(rng.integers(4, 20))
+        xml, sites = random_mjcf(rng, nbody, free_root=free, no_ball=True)
+        m = mink.loads_mjcf(xml)
+        if (free and 7 <= m.nv <= 32) or (not free and 17 <= m.nv <= 32):
+            break
+    else:
+        pytest.skip("no draw in range")
+    B = 53
+    q = np.stack([rand_q(m, rng) for _ in range(B)])
+    cfg = mink.Configuration(m, q)
+    tgt_cfg = mink.Configuration(m, cfg.integrate(rng.normal(scale=0.2, size=(B, m.nv)), 1.0))
+    frames = [(s, "site") for s in sites] + [(f"b{i}", "body") for i in range(nbody)]
+    picks = [frames[i] for i in rng.choice(len(frames), size=min(int(rng.integers(1, 7)), len(frames)), replace=False)]
+    tasks, specs = [], []
+    for name, typ in picks:
+        pc = rng.uniform(0.5, 20.0) * (rng.uniform(size=3) < 0.8)
+        oc_ = rng.uniform(0.1, 5.0) * (rng.uniform() < 0.6)
+        if not pc.any() and oc_ == 0.0:
+            pc = np.ones(3)
+        gain, lm = float(rng.uniform(0.3, 1.0)), float(rng.uniform(0.0, 1.0))
+        ft = mink.FrameTask(name, typ, position_cost=pc, orientation_cost=oc_, gain=gain, lm_damping=lm)
+        ft.set_target(tgt_cfg.get_transform_frame_to_world(name, typ))
+        tasks.append(ft)
+        specs.append((m.name2id(typ, name), typ, ft.cost.copy(), gain, lm))
+    post = mink.PostureTask(m, cost=rng.uniform(0.0, 1.0, size=m.nv) * (rng.uniform(size=m.nv) < 0.8), gain=float(rng.uniform(0.2, 1.0)),
+                            lm_damping=float(rng.uniform(0.0, 0.5)))
+    post.set_target(rand_q(m, rng))
+    vel = {m.jnt_names[j]: float(rng.uniform(0.2, 3.0)) for j in range(m.njnt) if m.jnt_type[j] in (2, 3) and rng.uniform() < 0.7}
+    lims = [mink.ConfigurationLimit(m, gain=float(rng.uniform(0.5, 1.0)))] + ([mink.VelocityLimit(m, vel)] if vel else [])
+    dt, damping = float(rng.choice([2e-3, 1e-2, 5e-2])), float(rng.choice([1e-6, 1e-3, 1e-1]))
+    v = mink.solve_ik(cfg, tasks + [post], dt, "mi355x", damping, limits=lims)
+    prob = list(cfg._problems.values())[-1]
+    if prob.last_kernel().startswith("ik_solve_kernel"):
+        pytest.skip("more than 32 links on the frames' chains: wavefront kernel")
+    assert prob.last_kernel() == QUAD + "_32", prob.last_kernel()
+    ftg = np.stack([ft.transform_target_to_world.wxyz_xyz for ft in tasks], axis=1)
+    ptq = post.target_q[None, :]
+    vw, stw = prob.solve(q, ftg, ptq, None, dt, damping, wave_kernel=True)
+    assert prob.last_kernel().startswith("ik_solve_kernel") and (stw & ~1 == 0).all()
+    ts = [oik.FrameTaskSpec(fid, typ, cost, ft.transform_target_to_world.wxyz_xyz[0], gain, lm) for (fid, typ, cost, gain, lm), ft in zip(specs, tasks)]
+    ts.append(oik.PostureTaskSpec(post.cost, post.target_q, post.gain, post.lm_damping))
+    ls = [oik.ConfigurationLimitSpec(lims[0].gain)] + ([oik.VelocityLimitSpec(lims[1].indices, lims[1].limit)] if vel else [])
+    v_c, st_c = cport.CProblem(m, ts, ls).solve_batch(q, ftg, ptq, dt, damping)
+    assert (st_c == 0).all()
+    print("seed %d: nv %d (%s root), %d bodies, %d frame tasks: two-row vs wavefront %.1e, vs C oracle %.1e" % (
+        seed, m.nv, "free" if free else "fixed", nbody, len(tasks), _rel(v, vw).max(), _rel(v, v_c).max()))
+    assert _rel(v, vw).max() < 1e-8 and _rel(v, v_c).max() < 1e-7
+
+
 @pytest.mark.parametrize("B", [1, 3, 129])
 def test_two_row_build_on_ragged_batches(nat, B):
     """Two problems per wavefront: an odd batch leaves the upper half of the last wavefront idle (it redoes the last problem and
