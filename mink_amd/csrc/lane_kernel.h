@@ -64,6 +64,14 @@ struct LaneProblemT {
   // body frame, and whether it is a slide joint
   double dof_axis[MD][3], dof_jpos[MD][3];
   int32_t dof_slide[MD];
+  // ComTask (two-row build of the row kernel only; appended so that the offsets above stay what they were): every body of the robot
+  // is a link then; a link carries its own mass (jointless children folded in) at link_ipos, its subtree is the contiguous range
+  // [link, link_last] (links are in body order), link_stmass that range's mass; bodies fixed to the world enter as a constant
+  int32_t n_com, com_rowmask;
+  double com_cost[3], com_gain, com_lm, com_minv;       // com_minv = 1 / mass of the subtree of body 1
+  double com_static[3];                                  // Σ m·p over the bodies of that subtree that are fixed to the world
+  double link_mass[ML], link_ipos[ML][3], link_stmass[ML];
+  int32_t link_last[ML];
 };
 using LaneProblem = LaneProblemT<kLaneMaxLinks, kLaneDescDofs>;
 using LaneProblem2 = LaneProblemT<kLaneMaxLinks2, kLaneDescDofs2>;
@@ -83,6 +91,7 @@ inline void lane_problem_narrow(const LaneProblemT<ML2, MD2>& b, LaneProblemT<ML
   }
   for (int t = 0; t < kMaxPostureTasks; ++t) { a.posture_gain[t] = b.posture_gain[t]; a.posture_lm[t] = b.posture_lm[t]; }
   for (int t = 0; t < kMaxBoxTerms; ++t) a.cfg_gain[t] = b.cfg_gain[t];
+  a.n_com = 0; a.com_rowmask = 0;                        // (no ComTask on the small descriptor)
 }
 
 // The sizes of a LaneProblem, by value in the row kernel's arguments (SGPRs at wave start instead of a dependent load).

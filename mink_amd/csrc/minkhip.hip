@@ -183,9 +183,11 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
                               const std::vector<double>& vlim, bool has_relative, LaneProblem2& L) {
   const double inf = std::numeric_limits<double>::infinity();
   if (m->nv > kLaneDescDofs2) return 0;
-  if (P.n_frame < 1 || P.n_frame > kLaneMaxFrames || has_relative || P.n_com || P.n_pairs || P.n_dense_rows ||
+  if (P.n_frame < 1 || P.n_frame > kLaneMaxFrames || has_relative || P.n_com > 1 || P.n_pairs || P.n_dense_rows ||
       P.n_dense_limit_rows || P.dense_box)       // (dense_box: per-instance box rows of a plugin limit, wavefront kernels only)
     return 0;
+  const bool com = P.n_com == 1;                 // ComTask: the two-row build of the row kernel, every body of the robot a link
+  if (com && (m->big || m->body_mass.empty())) return 0;
   // hinge / slide joints; the two-row build of the row kernel (17 … 32 dofs or links) also takes free joints — a floating base
   bool has_free = false;
   for (int j = 0; j < m->njnt; ++j) {
@@ -199,6 +201,12 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
   std::vector<int> need(m->nbody, 0), link_of(m->nbody, -1);
   for (int t = 0; t < P.n_frame; ++t)
     for (int b = ft[t].body; b > 0; b = m->body_parentid[b]) need[b] = 1;
+  std::vector<char> in_robot(m->nbody, 0);           // subtree of body 1 (mj_jacSubtreeCom(m, d, jac, 1): com_task.py:71-97)
+  if (com)
+    for (int b = 1; b < m->nbody; ++b) {
+      in_robot[b] = b == 1 || in_robot[m->body_parentid[b]];
+      if (in_robot[b]) need[b] = 1;
+    }
   int nl = 0;
   int free_link[4] = {-1, -1, -1, -1};
   std::vector<int> link_of_jnt(m->njnt, -1);
@@ -287,6 +295,43 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
     L.dof_slide[dd] = m->jnt_type[j] == JNT_SLIDE;
     if (m->jnt_limited[j]) { L.range_lo[dd] = m->jnt_range[2 * j]; L.range_hi[dd] = m->jnt_range[2 * j + 1]; }
   }
+  if (com) {
+    L.n_com = 1;
+    L.com_rowmask = P.com_rowmask[0];
+    for (int k = 0; k < 3; ++k) L.com_cost[k] = P.com_cost[0][k];
+    L.com_gain = P.com_gain[0]; L.com_lm = P.com_lm[0];
+    double mtot = 0.0;
+    std::vector<double> wsum(3 * (nl > 0 ? nl : 1), 0.0);        // Σ m·(centre of mass in the link frame) per link
+    for (int b = 1; b < m->nbody; ++b) {
+      if (!in_robot[b]) continue;
+      const double mb = m->body_mass[b];
+      mtot += mb;
+      // the body's centre of mass in the frame of its link (its own frame, or through the folded jointless chain) — or in the world
+      Xf at = ident;
+      if (m->body_jntnum[b] == 0) at = fold[b];
+      const Xf cw = compose(at, &m->body_ipos[3 * b], ident.q);
+      const int a = link_of[b];
+      if (a < 0) { for (int k = 0; k < 3; ++k) L.com_static[k] += mb * cw.p[k]; continue; }
+      L.link_mass[a] += mb;
+      for (int k = 0; k < 3; ++k) wsum[3 * a + k] += mb * cw.p[k];
+    }
+    if (!(mtot > 0.0)) return 0;
+    L.com_minv = 1.0 / mtot;
+    for (int a = 0; a < nl; ++a) {
+      for (int k = 0; k < 3; ++k) L.link_ipos[a][k] = L.link_mass[a] > 0.0 ? wsum[3 * a + k] / L.link_mass[a] : 0.0;
+      // links are in body order (depth first): the subtree of a link is the range up to the next link that is not below it
+      int last = a;
+      for (int c = a + 1; c < nl; ++c) {
+        int up = L.link[c].parent;
+        while (up > a) up = L.link[up].parent;
+        if (up != a) break;
+        last = c;
+      }
+      L.link_last[a] = last;
+      for (int c = a; c <= last; ++c) L.link_stmass[a] += L.link_mass[c];
+    }
+    for (int dd = 0; dd < m->nv; ++dd) if (L.dof_link[dd] < 0) return 0;     // (every dof of the robot moves mass: all need their link)
+  }
   for (int t = 0; t < P.n_frame; ++t) {
     LaneFrame& f = L.frame[t];
     f.link = link_of[ft[t].body];
@@ -312,7 +357,7 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
   for (int t = 0; t < P.n_vel; ++t)
     for (int dd = 0; dd < m->nv; ++dd) L.vel_limit[t][dd] = vlim[t * 64 + dd];
   (void)d;
-  if (has_free || m->nv > 16 || nl > 16) return 32;                                     // (32: the row kernel on two DPP rows per problem)
+  if (has_free || com || m->nv > 16 || nl > 16) return 32;                                     // (32: the row kernel on two DPP rows per problem)
   return m->nv <= 4 ? 4 : (m->nv <= 6 ? 6 : (m->nv == 7 ? 7 : (m->nv == 8 ? 8 : 16)));   // (16: the row kernel only)
 }
 

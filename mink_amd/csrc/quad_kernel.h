@@ -37,7 +37,8 @@ namespace mkh {
 // from lane i is taken from `ua` = (own u on row 0, the other row's u on row 1) for i < 16 and from `ub` (the other way round) for
 // i ≥ 16: one ds_swizzle exchange of the rows (lane ⊕ 16) per broadcast vector, then 16 + 16 `row_newbcast` FMAs.
 constexpr int kQuadTaskDoubles = 28;                          // per frame task: A1 (9), A2 (9), frame position (3), W·e (6), μ
-__host__ __device__ constexpr int quad_row_doubles(int lp) { return 7 * lp + lp / 2 + kLaneMaxFrames * kQuadTaskDoubles; }   // poses [component][link], ancestors, task blocks
+// poses [component][link], ancestors, task blocks; two-row build: + m·com of every link and the subtree centres of mass (ComTask)
+__host__ __device__ constexpr int quad_row_doubles(int lp) { return 7 * lp + lp / 2 + kLaneMaxFrames * kQuadTaskDoubles + (lp == 32 ? 6 * lp : 0); }
 static_assert(kLaneMaxLinks <= 16 && kLaneDescDofs <= 16 && kLaneMaxLinks2 <= 32 && kLaneDescDofs2 <= 32, "a problem must fit one / two DPP rows");
 __host__ __device__ inline int quad_lds_bytes(int lp = 16) { return (kWave / lp) * quad_row_doubles(lp) * (int)sizeof(double); }
 
@@ -477,6 +478,56 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblemT<LP, LP>*
         }
       }
       mu_total += t[27];
+    }
+  }
+  if constexpr (LP == 32) {
+    if (P.n_com) {
+      // ------------------------------------------- ComTask (com_task.py:71-97): e = com − target, J = mj_jacSubtreeCom(body 1)
+      // lane = link: m·(world centre of mass) of the link's own mass; then the sums over its subtree — links are in body order,
+      // a subtree is a contiguous range of them
+      double* const sW = sT + kLaneMaxFrames * kQuadTaskDoubles;       // [3][LP]
+      double* const sC = sW + 3 * LP;                                   // [3][LP] subtree centres of mass
+      V3 mw{0.0, 0.0, 0.0};
+      if (l < nlink) {
+        const V3 lp{sX[l], sX[kQuadRow + l], sX[2 * kQuadRow + l]};
+        const Q4 lq{sX[3 * kQuadRow + l], sX[4 * kQuadRow + l], sX[5 * kQuadRow + l], sX[6 * kQuadRow + l]};
+        mw = P.link_mass[l] * (lp + qrot(lq, V3{P.link_ipos[l][0], P.link_ipos[l][1], P.link_ipos[l][2]}));
+      }
+      sW[l] = mw.x; sW[LP + l] = mw.y; sW[2 * LP + l] = mw.z;
+      const V3 all{qsum<LP>(mw.x) + P.com_static[0], qsum<LP>(mw.y) + P.com_static[1], qsum<LP>(mw.z) + P.com_static[2]};
+      wave_sync();
+      if (l < nlink) {
+        V3 acc{0.0, 0.0, 0.0};
+        const int last = P.link_last[l];
+        for (int j = l; j <= last; ++j) acc = acc + V3{sW[j], sW[LP + j], sW[2 * LP + j]};
+        const double ms = P.link_stmass[l];
+        const double inv = ms > 0.0 ? 1.0 / ms : 0.0;
+        sC[l] = acc.x * inv; sC[LP + l] = acc.y * inv; sC[2 * LP + l] = acc.z * inv;
+      }
+      wave_sync();
+      const double* ctp = A.com_target + (A.com_batched ? (size_t)pb * 3 : 0);
+      const V3 e = P.com_minv * all - V3{ctp[0], ctp[1], ctp[2]};
+      // lane = dof: ∂com/∂q_k = (m_subtree / M)·(axis × (c_subtree − anchor)) for a rotation, (m_subtree / M)·axis for a translation
+      const int a = dla;
+      const Q4 lq{sX[3 * kQuadRow + a], sX[4 * kQuadRow + a], sX[5 * kQuadRow + a], sX[6 * kQuadRow + a]};
+      const V3 axw = qrot(lq, d_axis);
+      const V3 an = V3{sX[a], sX[kQuadRow + a], sX[2 * kQuadRow + a]} + qrot(lq, d_jpos);
+      const V3 cs{sC[a], sC[LP + a], sC[2 * LP + a]};
+      const V3 lin = slide ? axw : cross(axw, cs - an);
+      const double w = has ? P.link_stmass[a] * P.com_minv : 0.0;
+      const double Jc[3] = {w * lin.x, w * lin.y, w * lin.z}, e3[3] = {e.x, e.y, e.z};
+      double ss = 0.0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if ((P.com_rowmask >> r) & 1) {                  // (uniform)
+          const double we = P.com_cost[r] * (-P.com_gain * e3[r]);
+          const double Jw = P.com_cost[r] * Jc[r];
+          cc = fma(-we, Jw, cc);
+          qrank1<LP>(T, Jw, Jw, upper_row);
+          ss += we * we;
+        }
+      }
+      mu_total += P.com_lm * ss;
     }
   }
   diag += dv ? mu_total : 1.0;                       // padded dofs: identity, x = 0

@@ -128,6 +128,10 @@ BENCH_CONFIGS: Dict[str, dict] = {
     "h1_c3": {"robot": "h1", "key": "stand", "batch": 65536, "bytes_per_solve": 26 * 8 + 4 * 7 * 8 + 25 * 8 + 4,
               "workload": "Unitree H1 (nq=26,nv=25): 4 FrameTasks(feet pos 200/ori 10, wrists pos 200/ori 0, lm 1)+PostureTask(1)+"
                           "ConfigurationLimit+VelocityLimit(pi), dt=5e-3, damping=1e-1 (examples/humanoid_h1.py:22-52)"},
+    # ... and the reference's H1 example as written (examples/humanoid_h1.py:22-52): + pelvis orientation + ComTask, per-instance CoM target
+    "h1_full": {"robot": "h1", "key": "stand", "batch": 65536, "bytes_per_solve": 26 * 8 + 5 * 7 * 8 + 3 * 8 + 25 * 8 + 4,
+                "workload": "Unitree H1 full example: pelvis-orientation + 4 FrameTasks + PostureTask + ComTask(per-instance target) + "
+                            "box limits (examples/humanoid_h1.py:22-52), dt=5e-3, damping=1e-1"},
     # the same set-up with the packaged model's CAPSULE wrist geom (analytic pairs only): the reference point of ur5e_convex
     "ur5e_coll": {"robot": "ur5e", "key": "home", "batch": 4096, "bytes_per_solve": 6 * 8 + 7 * 8 + 6 * 8 + 4,
                   "workload": "UR5e, the collision set-up of examples/arm_ur5e.py:20-47 (capsule-plane floor, capsule-box wall), "
@@ -173,11 +177,15 @@ def bench_config(name: str, model: FlatModel, nmodel: "nat.NativeModel", max_bat
     cfg = [configuration_limit_desc(model)]
     if name == "g1_c3":
         return g1_config(model, nmodel, max_batch)
-    if name == "h1_c3":
+    if name in ("h1_c3", "h1_full"):
         fts = [_frame_desc(model, s, "site", 200.0, 10.0, 1.0) for s in ("left_foot", "right_foot")] + \
               [_frame_desc(model, s, "site", 200.0, 0.0, 1.0) for s in ("left_wrist", "right_wrist")]
+        extra = {}
+        if name == "h1_full":
+            fts = [_frame_desc(model, "pelvis", "body", 0.0, 10.0)] + fts
+            extra = {"com_tasks": [{"cost": 200.0}]}
         prob = nat.NativeProblem(nmodel, frame_tasks=fts, posture_tasks=[{"cost": 1.0}], configuration_limits=cfg,
-                                 velocity_limits=[velocity_limit_desc(model, _hinge_velocities(model))], max_batch=max_batch)
+                                 velocity_limits=[velocity_limit_desc(model, _hinge_velocities(model))], max_batch=max_batch, **extra)
         return prob, 5e-3, 1e-1
     if name == "g1_coll":
         fts = [_frame_desc(model, s, "site", 200.0, 10.0, 1.0) for s in ("left_foot", "right_foot")] + \

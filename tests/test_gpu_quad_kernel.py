@@ -378,7 +378,7 @@ def test_real_mink_fixtures_of_the_sixteen_register_build(nat, name, scene):
     np.testing.assert_allclose(pr.P[~main], d["H"][~main], rtol=0, atol=1e-6 * np.abs(d["H"]).max())      # (small-angle stream)
 
 
-@pytest.mark.parametrize("name,scene", [("h1_c", "unitree_h1__scene"), ("go1_c", "unitree_go1__scene")])
+@pytest.mark.parametrize("name,scene", [("h1_c", "unitree_h1__scene"), ("go1_c", "unitree_go1__scene"), ("h1_full", "unitree_h1__scene")])
 def test_real_mink_fixtures_of_the_two_row_build(nat, name, scene):
     """The REAL mink (tests/golden/make_golden_mid.py) on the Unitree H1 — the tasks of examples/humanoid_h1.py without the CoM
     task: a body-frame pelvis task, feet, wrists, posture — and on the Go1 with the tasks of examples/quadruped_go1.py: the public
@@ -390,7 +390,7 @@ def test_real_mink_fixtures_of_the_two_row_build(nat, name, scene):
     m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", scene + ".json"))
     B = len(d["q"])
     cfg = mink.Configuration(m, d["q"])
-    if name == "h1_c":
+    if name in ("h1_c", "h1_full"):
         tasks = [mink.FrameTask("pelvis", "body", position_cost=0.0, orientation_cost=10.0)]
         tasks += [mink.FrameTask(s, "site", position_cost=200.0, orientation_cost=10.0, lm_damping=1.0) for s in ("right_foot", "left_foot")]
         tasks += [mink.FrameTask(s, "site", position_cost=200.0, orientation_cost=0.0, lm_damping=1.0) for s in ("right_wrist", "left_wrist")]
@@ -405,6 +405,10 @@ def test_real_mink_fixtures_of_the_two_row_build(nat, name, scene):
         t.set_target(mink.SE3(d["frame_targets"][:, k]))
     post.set_target(d["posture_target"])
     tasks.append(post)
+    if name == "h1_full":                              # examples/humanoid_h1.py as written: + ComTask(200), per-instance CoM target
+        com = mink.ComTask(cost=200.0)
+        com.set_target(d["com_targets"][:, 0])
+        tasks.append(com)
     v = mink.solve_ik(cfg, tasks, float(d["dt"]), "quadprog", float(d["damping"]), limits=lims)
     prob = list(cfg._problems.values())[-1]
     assert prob.last_kernel() == QUAD + "_32", prob.last_kernel()
@@ -458,22 +462,31 @@ def test_random_trees_on_the_two_row_build(nat, seed):
     vel = {m.jnt_names[j]: float(rng.uniform(0.2, 3.0)) for j in range(m.njnt) if m.jnt_type[j] in (2, 3) and rng.uniform() < 0.7}
     lims = [mink.ConfigurationLimit(m, gain=float(rng.uniform(0.5, 1.0)))] + ([mink.VelocityLimit(m, vel)] if vel else [])
     dt, damping = float(rng.choice([2e-3, 1e-2, 5e-2])), float(rng.choice([1e-6, 1e-3, 1e-1]))
-    v = mink.solve_ik(cfg, tasks + [post], dt, "mi355x", damping, limits=lims)
+    com, com_t = None, None
+    if seed % 3 == 0:                                   # ... and a ComTask with per-instance targets (zero-cost rows allowed)
+        cost = rng.uniform(1.0, 50.0, size=3) * (rng.uniform(size=3) < 0.8)
+        com = mink.ComTask(cost=cost if cost.any() else np.ones(3), gain=float(rng.uniform(0.3, 1.0)), lm_damping=float(rng.uniform(0.0, 0.5)))
+        com_t = np.asarray(tgt_cfg.subtree_com())
+        com.set_target(com_t)
+    v = mink.solve_ik(cfg, tasks + [post] + ([com] if com is not None else []), dt, "mi355x", damping, limits=lims)
     prob = list(cfg._problems.values())[-1]
     if prob.last_kernel().startswith("ik_solve_kernel"):
         pytest.skip("more than 32 links on the frames' chains: wavefront kernel")
     assert prob.last_kernel() == QUAD + "_32", prob.last_kernel()
     ftg = np.stack([ft.transform_target_to_world.wxyz_xyz for ft in tasks], axis=1)
     ptq = post.target_q[None, :]
-    vw, stw = prob.solve(q, ftg, ptq, None, dt, damping, wave_kernel=True)
+    ctg = None if com is None else com_t.reshape(B, 1, 3)
+    vw, stw = prob.solve(q, ftg, ptq, ctg, dt, damping, wave_kernel=True)
     assert prob.last_kernel().startswith("ik_solve_kernel") and (stw & ~1 == 0).all()
     ts = [oik.FrameTaskSpec(fid, typ, cost, ft.transform_target_to_world.wxyz_xyz[0], gain, lm) for (fid, typ, cost, gain, lm), ft in zip(specs, tasks)]
     ts.append(oik.PostureTaskSpec(post.cost, post.target_q, post.gain, post.lm_damping))
+    if com is not None:
+        ts.append(oik.ComTaskSpec(np.asarray(com.cost, dtype=np.float64), None, com.gain, com.lm_damping))
     ls = [oik.ConfigurationLimitSpec(lims[0].gain)] + ([oik.VelocityLimitSpec(lims[1].indices, lims[1].limit)] if vel else [])
-    v_c, st_c = cport.CProblem(m, ts, ls).solve_batch(q, ftg, ptq, dt, damping)
+    v_c, st_c = cport.CProblem(m, ts, ls).solve_batch(q, ftg, ptq, dt, damping, com_target=ctg)
     assert (st_c == 0).all()
-    print("seed %d: nv %d (%s root), %d bodies, %d frame tasks: two-row vs wavefront %.1e, vs C oracle %.1e" % (
-        seed, m.nv, "free" if free else "fixed", nbody, len(tasks), _rel(v, vw).max(), _rel(v, v_c).max()))
+    print("seed %d: nv %d (%s root), %d bodies, %d frame tasks%s: two-row vs wavefront %.1e, vs C oracle %.1e" % (
+        seed, m.nv, "free" if free else "fixed", nbody, len(tasks), " + ComTask" if com is not None else "", _rel(v, vw).max(), _rel(v, v_c).max()))
     assert _rel(v, vw).max() < 1e-8 and _rel(v, v_c).max() < 1e-7
 
 

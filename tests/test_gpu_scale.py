@@ -318,7 +318,8 @@ def test_cold_start_refinement_agrees_with_the_plain_low_rank_start(monkeypatch)
 
 
 _BENCH_KERNELS = {"ur5e_c2": "ik_quad_kernel", "g1_c3": "ik_solve_kernel_44_32_r44_w3", "g1_full": "ik_solve_kernel_44_36_r44",
-                  "shadow_c4": "ik_solve_kernel_48_72+redo_64", "g1_plugin": "ik_solve_kernel_48_256", "h1_c3": "ik_quad_kernel_32"}
+                  "shadow_c4": "ik_solve_kernel_48_72+redo_64", "g1_plugin": "ik_solve_kernel_48_256", "h1_c3": "ik_quad_kernel_32",
+                  "h1_full": "ik_quad_kernel_32"}
 
 
 def _oracle_specs_of_bench(name, model, prob_desc):
@@ -332,13 +333,16 @@ def _oracle_specs_of_bench(name, model, prob_desc):
     if name == "ur5e_c2":
         return ([ik.FrameTaskSpec(site("attachment_site"), "site", cost6(1.0, 1.0), z7, lm_damping=1.0),
                  ik.PostureTaskSpec(np.full(model.nv, 1e-2), None)], [ik.ConfigurationLimitSpec(), vel], {})
-    feet_palms = [] if name == "h1_c3" else [ik.FrameTaskSpec(site(s), "site", cost6(200.0, o), z7, lm_damping=1.0)
+    feet_palms = [] if name in ("h1_c3", "h1_full") else [ik.FrameTaskSpec(site(s), "site", cost6(200.0, o), z7, lm_damping=1.0)
                   for s, o in (("left_foot", 10.0), ("right_foot", 10.0), ("left_palm", 0.0), ("right_palm", 0.0))]
     post = ik.PostureTaskSpec(np.full(model.nv, 1.0), None)
-    if name == "h1_c3":
-        return ([ik.FrameTaskSpec(site(s), "site", cost6(200.0, o), z7, lm_damping=1.0)
-                 for s, o in (("left_foot", 10.0), ("right_foot", 10.0), ("left_wrist", 0.0), ("right_wrist", 0.0))] + [post],
-                [ik.ConfigurationLimitSpec(), vel], {})
+    if name in ("h1_c3", "h1_full"):
+        fts = [ik.FrameTaskSpec(site(s), "site", cost6(200.0, o), z7, lm_damping=1.0)
+               for s, o in (("left_foot", 10.0), ("right_foot", 10.0), ("left_wrist", 0.0), ("right_wrist", 0.0))]
+        if name == "h1_full":
+            pel = ik.FrameTaskSpec(model.name2id("body", "pelvis"), "body", cost6(0.0, 10.0), z7)
+            return [pel] + fts + [post, ik.ComTaskSpec(np.full(3, 200.0), None)], [ik.ConfigurationLimitSpec(), vel], {}
+        return fts + [post], [ik.ConfigurationLimitSpec(), vel], {}
     if name == "g1_c3":
         return feet_palms + [post], [ik.ConfigurationLimitSpec(), vel], {}
     if name == "g1_full":
@@ -356,7 +360,7 @@ def _oracle_specs_of_bench(name, model, prob_desc):
     raise KeyError(name)
 
 
-@pytest.mark.parametrize("name", ["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin", "h1_c3"])
+@pytest.mark.parametrize("name", ["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin", "h1_c3", "h1_full"])
 def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name):
     """Exactly what `bench.py --config <name>` times — the same constructors, the same generated batch (per-instance CoM
     targets for the G1 full example, half of the Shadow instances pulled towards `grasp hard`, the caller's rows of the plugin
@@ -382,7 +386,7 @@ def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name):
         groups = [[f"{f}_1", f"{f}_2"] for f in workloads.SHADOW_FINGERS]
         col = CollisionAvoidanceLimit(model, [(groups[i], groups[j]) for i in range(5) for j in range(i + 1, 5)])
         np.testing.assert_array_equal(np.array(col.geom_id_pairs), np.load(oc.GOLDEN + "/shadow_c4_geom_pairs.npy"))
-    cp = cport.CProblem(model if name == "h1_c3" else oc.model(workloads.BENCH_CONFIGS[name]["robot"]), tasks, limits, **extra)
+    cp = cport.CProblem(model if name in ("h1_c3", "h1_full") else oc.model(workloads.BENCH_CONFIGS[name]["robot"]), tasks, limits, **extra)
     v_ref, st_ref = cp.solve_batch(q, tg, pt, dt, damping, com_target=com, dense=dense, nthreads=min(16, os.cpu_count() or 1))
     assert (st_ref == 0).all(), np.unique(st_ref, return_counts=True)
     err = np.abs(v - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))

@@ -144,11 +144,11 @@ def _small_robot_specs(name, m, d, i):
         tasks = [ik.FrameTaskSpec(s, "site", np.array([1.0, 1, 1, 0, 0, 0]), d["frame_targets"][i, k], 1.0, 1.0) for k, s in enumerate(sid)]
         tasks.append(ik.PostureTaskSpec(np.full(m.nv, 1e-2), d["posture_target"]))
         vlim = np.full(m.nv, np.pi)
-    elif name in ("h1_c", "go1_c"):
+    elif name in ("h1_c", "go1_c", "h1_full"):
         # tests/golden/make_golden_mid.py: the tasks of examples/humanoid_h1.py (without the CoM task) / quadruped_go1.py
         c6 = lambda p, o: np.array([p] * 3 + [o] * 3, dtype=np.float64)
         hinge = np.array([int(m.jnt_dofadr[j]) for j in range(m.njnt) if m.jnt_type[j] == 3])
-        if name == "h1_c":
+        if name in ("h1_c", "h1_full"):
             spec = [("pelvis", "body", c6(0, 10), 0.0)] + [(s, "site", c6(200, 10), 1.0) for s in ("right_foot", "left_foot")] + \
                    [(s, "site", c6(200, 0), 1.0) for s in ("right_wrist", "left_wrist")]
             pcost, limits = 1.0, [ik.ConfigurationLimitSpec(), ik.VelocityLimitSpec(hinge, np.full(len(hinge), np.pi))]
@@ -157,6 +157,8 @@ def _small_robot_specs(name, m, d, i):
             pcost, limits = 1e-5, [ik.ConfigurationLimitSpec()]
         tasks = [ik.FrameTaskSpec(m.name2id(ft, n), ft, c, d["frame_targets"][i, k], 1.0, lm) for k, (n, ft, c, lm) in enumerate(spec)]
         tasks.append(ik.PostureTaskSpec(np.full(m.nv, pcost), d["posture_target"]))
+        if name == "h1_full":                          # examples/humanoid_h1.py:33: ComTask(cost=200), per-instance target
+            tasks.append(ik.ComTaskSpec(np.full(3, 200.0), d["com_targets"][i, 0]))
         return tasks, limits
     else:
         tasks = [ik.FrameTaskSpec(m.name2id("site", "pinch_site"), "site", np.ones(6), d["frame_targets"][i, 0], 1.0, 1.0)]
@@ -170,7 +172,7 @@ def _small_robot_specs(name, m, d, i):
 
 
 @pytest.mark.parametrize("name,scene", [("leap_c", "leap_hand__scene_right"), ("kinova_c", "stanford_tidybot__scene_mobile_kinova"),
-                                        ("h1_c", "unitree_h1__scene"), ("go1_c", "unitree_go1__scene")])
+                                        ("h1_c", "unitree_h1__scene"), ("go1_c", "unitree_go1__scene"), ("h1_full", "unitree_h1__scene")])
 def test_oracle_vs_real_mink_on_the_hands_and_mobile_arms(golden_dir, name, scene):
     """The real mink on a 16-dof hand (four fingertip tasks) and a 10-dof mobile arm (DampingTask on the base), the robots of
     the row kernel's sixteen-register build: H, c, h, G, e, J and v of the oracle against it."""
