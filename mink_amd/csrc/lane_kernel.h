@@ -72,6 +72,8 @@ struct LaneProblemT {
   double com_static[3];                                  // Σ m·p over the bodies of that subtree that are fixed to the world
   double link_mass[ML], link_ipos[ML][3], link_stmass[ML];
   int32_t link_last[ML];
+  // RelativeFrameTask (two-row build only; appended for the same reason): frame task t measures its frame in the frame `root`
+  struct Rel { int32_t relative, root_link; uint32_t rchain; int32_t pad; double rlpos[3], rlquat[4]; } rel[kLaneMaxFrames];
 };
 using LaneProblem = LaneProblemT<kLaneMaxLinks, kLaneDescDofs>;
 using LaneProblem2 = LaneProblemT<kLaneMaxLinks2, kLaneDescDofs2>;
@@ -91,7 +93,8 @@ inline void lane_problem_narrow(const LaneProblemT<ML2, MD2>& b, LaneProblemT<ML
   }
   for (int t = 0; t < kMaxPostureTasks; ++t) { a.posture_gain[t] = b.posture_gain[t]; a.posture_lm[t] = b.posture_lm[t]; }
   for (int t = 0; t < kMaxBoxTerms; ++t) a.cfg_gain[t] = b.cfg_gain[t];
-  a.n_com = 0; a.com_rowmask = 0;                        // (no ComTask on the small descriptor)
+  a.n_com = 0; a.com_rowmask = 0;                        // (no ComTask, no RelativeFrameTask on the small descriptor)
+  for (int t = 0; t < kLaneMaxFrames; ++t) a.rel[t].relative = 0;
 }
 
 // The sizes of a LaneProblem, by value in the row kernel's arguments (SGPRs at wave start instead of a dependent load).

@@ -183,7 +183,7 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
                               const std::vector<double>& vlim, bool has_relative, LaneProblem2& L) {
   const double inf = std::numeric_limits<double>::infinity();
   if (m->nv > kLaneDescDofs2) return 0;
-  if (P.n_frame < 1 || P.n_frame > kLaneMaxFrames || has_relative || P.n_com > 1 || P.n_pairs || P.n_dense_rows ||
+  if (P.n_frame < 1 || P.n_frame > kLaneMaxFrames || P.n_com > 1 || P.n_pairs || P.n_dense_rows ||
       P.n_dense_limit_rows || P.dense_box)       // (dense_box: per-instance box rows of a plugin limit, wavefront kernels only)
     return 0;
   const bool com = P.n_com == 1;                 // ComTask: the two-row build of the row kernel, every body of the robot a link
@@ -199,8 +199,11 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
   L.nq = m->nq; L.nv = m->nv; L.n_frame = P.n_frame; L.n_posture = P.n_posture; L.n_cfg = P.n_cfg; L.n_vel = P.n_vel;
   // links = the bodies on the chains world → frame bodies, in body-id order (parents first)
   std::vector<int> need(m->nbody, 0), link_of(m->nbody, -1);
-  for (int t = 0; t < P.n_frame; ++t)
+  for (int t = 0; t < P.n_frame; ++t) {
     for (int b = ft[t].body; b > 0; b = m->body_parentid[b]) need[b] = 1;
+    if (ft[t].relative)                              // RelativeFrameTask: the root frame's chain as well (two-row build)
+      for (int b = ft[t].root_body; b > 0; b = m->body_parentid[b]) need[b] = 1;
+  }
   std::vector<char> in_robot(m->nbody, 0);           // subtree of body 1 (mj_jacSubtreeCom(m, d, jac, 1): com_task.py:71-97)
   if (com)
     for (int b = 1; b < m->nbody; ++b) {
@@ -342,6 +345,16 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
     for (int i = 0; i < 4; ++i) f.lquat[i] = fl.q[i];
     for (int i = 0; i < 6; ++i) f.cost[i] = ft[t].cost[i];
     f.gain = ft[t].gain; f.lm_damping = ft[t].lm_damping;
+    if (ft[t].relative) {
+      auto& r = L.rel[t];
+      r.relative = 1;
+      r.root_link = link_of[ft[t].root_body];
+      r.rchain = (uint32_t)ft[t].root_mask;
+      const Xf rl = folded[ft[t].root_body] ? compose(fold[ft[t].root_body], ft[t].root_lpos, ft[t].root_lquat)
+                                             : compose(ident, ft[t].root_lpos, ft[t].root_lquat);
+      for (int i = 0; i < 3; ++i) r.rlpos[i] = rl.p[i];
+      for (int i = 0; i < 4; ++i) r.rlquat[i] = rl.q[i];
+    }
   }
   for (int t = 0; t < P.n_posture; ++t) {
     for (int dd = 0; dd < m->nv; ++dd)      // (free-joint dofs: error and Jacobian column are zero, posture_task.py:115-116,139-141)
@@ -357,7 +370,7 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
   for (int t = 0; t < P.n_vel; ++t)
     for (int dd = 0; dd < m->nv; ++dd) L.vel_limit[t][dd] = vlim[t * 64 + dd];
   (void)d;
-  if (has_free || com || m->nv > 16 || nl > 16) return 32;                                     // (32: the row kernel on two DPP rows per problem)
+  if (has_free || com || has_relative || m->nv > 16 || nl > 16) return 32;                                     // (32: the row kernel on two DPP rows per problem)
   return m->nv <= 4 ? 4 : (m->nv <= 6 ? 6 : (m->nv == 7 ? 7 : (m->nv == 8 ? 8 : 16)));   // (16: the row kernel only)
 }
 

@@ -402,8 +402,28 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblemT<LP, LP>*
     V3 ev, ew;
     double Jm[9], Qm[9];
     bool ident;
-    se3_log(se3_mul(se3_inv(F), Tt), ev, ew);        // e = target.minus(frame)
-    se3_ljacinv(ev, ew, Jm, Qm, ident);              // jlog(T_tb) = ljacinv(e)
+    bool rel = false;
+    if constexpr (LP == 32) rel = P.rel[l].relative != 0;
+    if (rel) {
+      // RelativeFrameTask (relative_frame_task.py:106-142): e = log(T_target⁻¹·T_fr), T_fr = the frame in the root frame;
+      // J = jlog(T_tf)·(ᶠJ − Ad(T_fr⁻¹)·ʳJ) — a dof on the chains of both frames drops out, one on the root's chain only enters
+      // with the opposite sign, and the column is the FrameTask's formula at the frame's position (see the dof lanes): only
+      // the sign of the first block and of jlog's argument differ
+      const auto& rr = P.rel[l];
+      V3 bp{0, 0, 0};
+      Q4 bq{1, 0, 0, 0};
+      if (rr.root_link >= 0) {
+        const int a = rr.root_link;
+        bp = V3{sX[a], sX[kQuadRow + a], sX[2 * kQuadRow + a]};
+        bq = Q4{sX[3 * kQuadRow + a], sX[4 * kQuadRow + a], sX[5 * kQuadRow + a], sX[6 * kQuadRow + a]};
+      }
+      const SE3 R{qmul(bq, Q4{rr.rlquat[0], rr.rlquat[1], rr.rlquat[2], rr.rlquat[3]}), bp + qrot(bq, V3{rr.rlpos[0], rr.rlpos[1], rr.rlpos[2]})};
+      se3_log(se3_mul(se3_inv(Tt), se3_mul(se3_inv(R), F)), ev, ew);
+      se3_ljacinv(-1.0 * ev, -1.0 * ew, Jm, Qm, ident);            // jlog(T_tf) = ljacinv(−log T_tf)
+    } else {
+      se3_log(se3_mul(se3_inv(F), Tt), ev, ew);      // e = target.minus(frame)
+      se3_ljacinv(ev, ew, Jm, Qm, ident);            // jlog(T_tb) = ljacinv(e)
+    }
     const double e6[6] = {ev.x, ev.y, ev.z, ew.x, ew.y, ew.z};
     if (LOOP && until) {
       const double pt = A.pos_threshold, ot = A.ori_threshold;
@@ -428,7 +448,8 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblemT<LP, LP>*
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          A1[3 * i + j] = -(Jm[3 * i] * Rf.m[3 * j] + Jm[3 * i + 1] * Rf.m[3 * j + 1] + Jm[3 * i + 2] * Rf.m[3 * j + 2]);
+          const double jr = Jm[3 * i] * Rf.m[3 * j] + Jm[3 * i + 1] * Rf.m[3 * j + 1] + Jm[3 * i + 2] * Rf.m[3 * j + 2];
+          A1[3 * i + j] = rel ? jr : -jr;
           t[3 * i + j] = A1[3 * i + j];
         }
     }
@@ -458,7 +479,15 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblemT<LP, LP>*
     for (int f = 0; f < nf; ++f) {
       const LaneFrame& ft = P.frame[f];
       const double* const t = sT + f * kQuadTaskDoubles;
-      const bool on = has && ((ft.chain >> l) & 1u);
+      bool on = has && ((ft.chain >> l) & 1u);
+      double sgn = 1.0;
+      if constexpr (LP == 32) {
+        if (P.rel[f].relative) {                     // (uniform) signed membership: frame chain − root chain
+          const bool onr = has && ((P.rel[f].rchain >> l) & 1u);
+          sgn = (on && !onr) ? 1.0 : -1.0;
+          on = on != onr;
+        }
+      }
       const V3 Fp{t[18], t[19], t[20]};
       const V3 lin = slide ? axw : cross(axw, Fp - an);
       double Jw[6];
@@ -467,8 +496,8 @@ __global__ __launch_bounds__(64) void ik_quad_kernel(const LaneProblemT<LP, LP>*
         const double a1l = t[3 * r] * lin.x + t[3 * r + 1] * lin.y + t[3 * r + 2] * lin.z;
         const double a1a = t[3 * r] * axw.x + t[3 * r + 1] * axw.y + t[3 * r + 2] * axw.z;
         const double a2a = t[9 + 3 * r] * axw.x + t[9 + 3 * r + 1] * axw.y + t[9 + 3 * r + 2] * axw.z;
-        Jw[r] = on ? ft.cost[r] * (slide ? a1l : a1l + a2a) : 0.0;           // weighted_jacobian (task.py:129)
-        Jw[3 + r] = on && !slide ? ft.cost[3 + r] * a1a : 0.0;
+        Jw[r] = on ? (sgn * ft.cost[r]) * (slide ? a1l : a1l + a2a) : 0.0;   // weighted_jacobian (task.py:129)
+        Jw[3 + r] = on && !slide ? (sgn * ft.cost[3 + r]) * a1a : 0.0;
       }
 #pragma unroll
       for (int r = 0; r < 6; ++r) {

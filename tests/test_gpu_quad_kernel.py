@@ -445,17 +445,27 @@ def test_random_trees_on_the_two_row_build(nat, seed):
     tgt_cfg = mink.Configuration(m, cfg.integrate(rng.normal(scale=0.2, size=(B, m.nv)), 1.0))
     frames = [(s, "site") for s in sites] + [(f"b{i}", "body") for i in range(nbody)]
     picks = [frames[i] for i in rng.choice(len(frames), size=min(int(rng.integers(1, 7)), len(frames)), replace=False)]
-    tasks, specs = [], []
+    tasks, specs, n_rel = [], [], 0
     for name, typ in picks:
         pc = rng.uniform(0.5, 20.0) * (rng.uniform(size=3) < 0.8)
         oc_ = rng.uniform(0.1, 5.0) * (rng.uniform() < 0.6)
         if not pc.any() and oc_ == 0.0:
             pc = np.ones(3)
         gain, lm = float(rng.uniform(0.3, 1.0)), float(rng.uniform(0.0, 1.0))
-        ft = mink.FrameTask(name, typ, position_cost=pc, orientation_cost=oc_, gain=gain, lm_damping=lm)
-        ft.set_target(tgt_cfg.get_transform_frame_to_world(name, typ))
+        if seed % 4 in (1, 2) and len(tasks) >= 1 and rng.uniform() < 0.7:
+            # RelativeFrameTask: this frame measured in the frame of an earlier pick (chains that share dofs, root-only dofs)
+            rname, rtyp = picks[int(rng.integers(0, len(tasks)))]
+            if (rname, rtyp) == (name, typ):
+                rname, rtyp = "b0", "body"
+            ft = mink.RelativeFrameTask(name, typ, rname, rtyp, position_cost=pc, orientation_cost=oc_, gain=gain, lm_damping=lm)
+            ft.set_target(tgt_cfg.get_transform(name, typ, rname, rtyp))
+            specs.append(("rel", m.name2id(typ, name), typ, m.name2id(rtyp, rname), rtyp, ft.cost.copy(), gain, lm))
+            n_rel += 1
+        else:
+            ft = mink.FrameTask(name, typ, position_cost=pc, orientation_cost=oc_, gain=gain, lm_damping=lm)
+            ft.set_target(tgt_cfg.get_transform_frame_to_world(name, typ))
+            specs.append((m.name2id(typ, name), typ, ft.cost.copy(), gain, lm))
         tasks.append(ft)
-        specs.append((m.name2id(typ, name), typ, ft.cost.copy(), gain, lm))
     post = mink.PostureTask(m, cost=rng.uniform(0.0, 1.0, size=m.nv) * (rng.uniform(size=m.nv) < 0.8), gain=float(rng.uniform(0.2, 1.0)),
                             lm_damping=float(rng.uniform(0.0, 0.5)))
     post.set_target(rand_q(m, rng))
@@ -473,20 +483,36 @@ def test_random_trees_on_the_two_row_build(nat, seed):
     if prob.last_kernel().startswith("ik_solve_kernel"):
         pytest.skip("more than 32 links on the frames' chains: wavefront kernel")
     assert prob.last_kernel() == QUAD + "_32", prob.last_kernel()
-    ftg = np.stack([ft.transform_target_to_world.wxyz_xyz for ft in tasks], axis=1)
+    ftg = np.stack([(ft.transform_target_to_root if isinstance(ft, mink.RelativeFrameTask) else ft.transform_target_to_world).wxyz_xyz
+                    for ft in tasks], axis=1)
     ptq = post.target_q[None, :]
     ctg = None if com is None else com_t.reshape(B, 1, 3)
     vw, stw = prob.solve(q, ftg, ptq, ctg, dt, damping, wave_kernel=True)
     assert prob.last_kernel().startswith("ik_solve_kernel") and (stw & ~1 == 0).all()
-    ts = [oik.FrameTaskSpec(fid, typ, cost, ft.transform_target_to_world.wxyz_xyz[0], gain, lm) for (fid, typ, cost, gain, lm), ft in zip(specs, tasks)]
-    ts.append(oik.PostureTaskSpec(post.cost, post.target_q, post.gain, post.lm_damping))
-    if com is not None:
-        ts.append(oik.ComTaskSpec(np.asarray(com.cost, dtype=np.float64), None, com.gain, com.lm_damping))
     ls = [oik.ConfigurationLimitSpec(lims[0].gain)] + ([oik.VelocityLimitSpec(lims[1].indices, lims[1].limit)] if vel else [])
-    v_c, st_c = cport.CProblem(m, ts, ls).solve_batch(q, ftg, ptq, dt, damping, com_target=ctg)
-    assert (st_c == 0).all()
+
+    def oracle_tasks(i):
+        ts = []
+        for sp, k in zip(specs, range(len(specs))):
+            if sp[0] == "rel":
+                ts.append(oik.RelativeFrameTaskSpec(sp[1], sp[2], sp[3], sp[4], sp[5], ftg[i, k], sp[6], sp[7]))
+            else:
+                ts.append(oik.FrameTaskSpec(sp[0], sp[1], sp[2], ftg[i, k], sp[3], sp[4]))
+        ts.append(oik.PostureTaskSpec(post.cost, post.target_q, post.gain, post.lm_damping))
+        if com is not None:
+            ts.append(oik.ComTaskSpec(np.asarray(com.cost, dtype=np.float64), com_t[i], com.gain, com.lm_damping))
+        return ts
+
+    if n_rel:                                           # (the C restatement has no RelativeFrameTask: numpy oracle on a sample)
+        for i in (0, B // 2, B - 1):
+            v_ref = oik.solve_ik(m, q[i], oracle_tasks(i), dt, damping, ls)
+            assert np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max()) < 1e-8, (i, n_rel)
+        v_c = vw
+    else:
+        v_c, st_c = cport.CProblem(m, oracle_tasks(0), ls).solve_batch(q, ftg, ptq, dt, damping, com_target=ctg)
+        assert (st_c == 0).all()
     print("seed %d: nv %d (%s root), %d bodies, %d frame tasks%s: two-row vs wavefront %.1e, vs C oracle %.1e" % (
-        seed, m.nv, "free" if free else "fixed", nbody, len(tasks), " + ComTask" if com is not None else "", _rel(v, vw).max(), _rel(v, v_c).max()))
+        seed, m.nv, "free" if free else "fixed", nbody, len(tasks), (" + ComTask" if com is not None else "") + (" (%d relative)" % n_rel if n_rel else ""), _rel(v, vw).max(), _rel(v, v_c).max()))
     assert _rel(v, vw).max() < 1e-8 and _rel(v, v_c).max() < 1e-7
 
 
@@ -516,6 +542,37 @@ def test_two_row_build_on_ragged_batches(nat, B):
     limits = [oik.ConfigurationLimitSpec(), oik.VelocityLimitSpec(np.array(vidx), np.full(len(vidx), 2.0))]
     v_c, st_c = cport.CProblem(m, tasks, limits).solve_batch(q, tg, home[None, :], 1e-2, 1e-4)
     assert (st_c == 0).all() and _rel(v, v_c).max() < 1e-8
+
+
+def test_real_mink_fixture_of_the_arm_with_a_hand(nat):
+    """The task set of examples/arm_hand_iiwa_allegro.py:62-94 — a FrameTask on the arm's attachment site, a posture task, one
+    RelativeFrameTask per fingertip measured in the PALM — recorded with the real mink on a 7 + 16-dof arm + hand
+    (tests/golden/make_golden_mid.py): the public API on its default dispatch, which since round 4 is the two-row build of the row
+    kernel for such a robot (a dof on the chains of both frames drops out of a relative task's Jacobian, one on the root's chain
+    only enters with the opposite sign), against the recorded v; the wavefront kernel gives the same."""
+    import mink_amd as mink
+    d = np.load(os.path.join(oc.GOLDEN, "ik_arm_hand.npz"))
+    m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "arm_hand.json"))
+    B = len(d["q"])
+    cfg = mink.Configuration(m, d["q"])
+    ee = mink.FrameTask("attachment_site", "site", position_cost=1.0, orientation_cost=1.0, lm_damping=1.0)
+    ee.set_target(mink.SE3(d["frame_targets"][:, 0]))
+    post = mink.PostureTask(m, cost=5e-2); post.set_target(d["posture_target"])
+    fingers = []
+    for k, t in enumerate(("ff_tip", "mf_tip", "rf_tip", "th_tip")):
+        f = mink.RelativeFrameTask(t, "site", "palm", "body", position_cost=1.0, orientation_cost=0.0, lm_damping=1.0)
+        f.set_target(mink.SE3(d["frame_targets"][:, 1 + k]))
+        fingers.append(f)
+    tasks, lims = [ee, post] + fingers, [mink.ConfigurationLimit(m)]
+    v = mink.solve_ik(cfg, tasks, float(d["dt"]), "quadprog", float(d["damping"]), limits=lims)
+    prob = list(cfg._problems.values())[-1]
+    assert prob.last_kernel() == QUAD + "_32", prob.last_kernel()
+    main = np.ones(B, bool); main[7::8] = False
+    err = _rel(v, d["v"])
+    print("arm + hand (4 RelativeFrameTasks): two-row build vs real mink: max rel err main %.1e small-angle %.1e" % (err[main].max(), err[~main].max()))
+    assert err[main].max() < 1e-8 and err[~main].max() < 1e-5
+    pr = mink.build_ik(cfg, tasks, float(d["dt"]), float(d["damping"]), lims)        # (H, c: the wavefront kernel's taps)
+    np.testing.assert_allclose(pr.P[main], d["H"][main], rtol=0, atol=1e-10 * np.abs(d["H"]).max())
 
 
 @pytest.mark.parametrize("scene", ["universal_robots_ur5e__scene", "leap_hand__scene_right", "unitree_h1__scene"])

@@ -193,3 +193,34 @@ def test_oracle_vs_real_mink_on_the_hands_and_mobile_arms(golden_dir, name, scen
         np.testing.assert_allclose(e, d["task_e"][i], rtol=0, atol=1e-13)
         v = ik.solve_ik(m, cfg, tasks, dt, damping, limits)
         np.testing.assert_allclose(v, d["v"][i], rtol=0, atol=1e-9 * max(1.0, np.abs(d["v"][i]).max()))
+
+
+def _arm_hand_specs(m, d, i):
+    """tests/golden/make_golden_mid.py::arm_hand — the task set of examples/arm_hand_iiwa_allegro.py:62-94."""
+    one = np.array([1.0, 1, 1, 0, 0, 0])
+    tasks = [ik.FrameTaskSpec(m.name2id("site", "attachment_site"), "site", np.ones(6), d["frame_targets"][i, 0], 1.0, 1.0),
+             ik.PostureTaskSpec(np.full(m.nv, 5e-2), d["posture_target"])]
+    palm = m.name2id("body", "palm")
+    for k, t in enumerate(("ff_tip", "mf_tip", "rf_tip", "th_tip")):
+        tasks.append(ik.RelativeFrameTaskSpec(m.name2id("site", t), "site", palm, "body", one, d["frame_targets"][i, 1 + k], 1.0, 1.0))
+    return tasks, [ik.ConfigurationLimitSpec()]
+
+
+def test_oracle_vs_real_mink_on_the_arm_with_a_hand(golden_dir):
+    """The real mink on a 7-dof arm carrying a 16-dof hand with the reference's arm + hand task set (one RelativeFrameTask per
+    fingertip, measured in the palm): H, c, h, e and v of the oracle against it."""
+    from mink_amd.flatmodel import FlatModel
+    d = _load(golden_dir, "arm_hand")
+    m = FlatModel.load(os.path.join(golden_dir, "models", "arm_hand.json"))
+    dt, damping = float(d["dt"]), float(d["damping"])
+    for i in range(len(d["q"])):
+        tasks, limits = _arm_hand_specs(m, d, i)
+        cfg = ik.Configuration(m, d["q"][i])
+        P, c, G, h = ik.build_ik(cfg, tasks, dt, damping, limits)
+        np.testing.assert_allclose(P, d["H"][i], rtol=0, atol=1e-12 * max(1.0, np.abs(d["H"][i]).max()))
+        np.testing.assert_allclose(c, d["c"][i], rtol=0, atol=1e-12 * max(1.0, np.abs(d["c"][i]).max()))
+        np.testing.assert_allclose(h, d["h"][i], rtol=0, atol=1e-13)
+        e = np.concatenate([ik.task_error_jacobian(cfg, t)[0] for t in tasks])
+        np.testing.assert_allclose(e, d["task_e"][i], rtol=0, atol=1e-13)
+        v = ik.solve_ik(m, cfg, tasks, dt, damping, limits)
+        np.testing.assert_allclose(v, d["v"][i], rtol=0, atol=1e-9 * max(1.0, np.abs(d["v"][i]).max()))
