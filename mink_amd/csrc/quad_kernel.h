@@ -1,5 +1,8 @@
 // One 16-LANE ROW per problem: differential IK for small robots (nv ≤ 16, hinge / slide joints): arms at small and mid-size
-// batches, hands and mobile arms (9 … 16 dofs) at every batch size.
+// batches, hands and mobile arms (9 … 16 dofs) at every batch size.  Round 4: the same source on TWO rows per problem (LP = 32,
+// two problems per wavefront) for 17 … 32 dofs or links — Unitree H1 / Go1, Spot, Allegro, arms carrying hands — with a floating
+// base (a free joint = three slide links + a quaternion link), ComTask (com_task.py:71-97) and RelativeFrameTask
+// (relative_frame_task.py:106-142); see "two DPP rows per problem" below and DESIGN.md §3.4.
 //
 // The wavefront kernel (ik_kernel.h) gives a 6-dof arm 64 lanes of which 6-10 work; the lane kernel (lane_kernel.h)
 // gives it one lane, i.e. one ≈48 µs dependent instruction stream — right for ≥ 8 192 problems, where every SIMD
