@@ -1205,15 +1205,19 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
       for (int i0 = 0; i0 < rpc; i0 += 8) {
         const int row0 = wr0 + i0;
         if (row0 > n_mu) break;
-        const double* b[8];
+        // (the eight rows through ONE address and compile-time offsets j·NR: rows past the right-hand side are read — whatever
+        //  lies behind the rows in this wave's LDS, or 0 past its end — and never stored; eight clamped row pointers cost
+        //  eight address additions per chain bit, 261 of a G1 solve's 504 VALU instructions in this phase were such arithmetic)
+        const double* const b0 = sJ + row0 * NR;
         double acc[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const int r = row0 + j; b[j] = sJ + (r < n_mu ? r : n_mu) * NR; acc[j] = 0.0; }
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0;
         for (uint64_t mk = chain & ~a_mask; mk; mk &= mk - 1) {        // S: the free dofs of the chain
           const int k = __ffsll((unsigned long long)mk) - 1;
           const double av = a[k];
+          const double* const bk = b0 + k;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] = fma(av, b[j][k], acc[j]);
+          for (int j = 0; j < 8; ++j) acc[j] = fma(av, bk[j * NR], acc[j]);
         }
         if (chain & a_mask) {                                          // Jw·z̃ also takes the predicted dofs (z̃ = β)
           const int jr = n_mu - row0;                                  // the right-hand-side row of this pass, if any
@@ -1726,7 +1730,11 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     const int ol = lane + oz;
     const DeviceProblem* Pq = Pg;
     asm volatile("" : "+s"(Pq));          // opaque: descriptor fields are (re)loaded where they are used
-    const DeviceProblem& P = *Pq;
+    // ... through the CONSTANT address space: scalar loads.  As a plain reference the fields — wave-uniform, but read inside
+    // lane-conditional code — came by per-lane flat_load, each a full s_waitcnt in front of the table load that depends on it:
+    // the posture / box-limit phase alone was ten dependent L2 round trips (10.6 k of a G1 solve's 104 k wave cycles for ≈150
+    // instructions; round 4, found with the phase × class census)
+    const MKH_CONSTANT DeviceProblem& P = *(const MKH_CONSTANT DeviceProblem*)Pq;
     MKH_ARGS_AT_USE();                     // ... and so are the call arguments (low-rank variants)
     wave_sync();  // previous problem's LDS readers are done
     // ------------------------------------------------------------ load inputs
