@@ -594,6 +594,9 @@ __device__ MKH_PRE_ATTR PreOut pre_phases(const DeviceProblem* Pq, const TapArgs
     {
     V3 d_ang{0, 0, 0}, d_lin{0, 0, 0}, d_anchor{0, 0, 0};
     double q_dof = 0.0;  // joint coordinate for hinge/slide dofs
+    // (the joint range of check_limits below, requested with the dof's other table entries: as `lo || hi` inside the two
+    //  conditionals it was four loads one after the other, each behind its own full wait — 3 k of this phase's 7 k cycles)
+    const double r_lo = P.dof_f[DF_RANGE_LO * 64 + ol], r_hi = P.dof_f[DF_RANGE_HI * 64 + ol];
     if (is_dof) {
       const auto* di = P.dof_i + ol;
       const int d_jnt = di[DI_JNT * 64];
@@ -627,15 +630,12 @@ __device__ MKH_PRE_ATTR PreOut pre_phases(const DeviceProblem* Pq, const TapArgs
     }
     // Configuration.check_limits (mink/configuration.py:77-110), tol = 1e-6
     {
-      bool viol = false;
-      if (is_dof && (d_kind == DOF_HINGE || d_kind == DOF_SLIDE))
-        viol = q_dof < P.dof_f[DF_RANGE_LO * 64 + ol] - 1e-6 || q_dof > P.dof_f[DF_RANGE_HI * 64 + ol] + 1e-6;
       // a limited ball joint: the reference's loop compares q[jnt_qposadr] — the quaternion's w — with the range
       // (configuration.py:92-99); the range sits on the joint's first dof lane only
-      if (is_dof && d_kind == DOF_BALL && d_k == 0) {
-        const double qw = sq[d_qadr];
-        viol = qw < P.dof_f[DF_RANGE_LO * 64 + ol] - 1e-6 || qw > P.dof_f[DF_RANGE_HI * 64 + ol] + 1e-6;
-      }
+      const bool ball0 = is_dof && d_kind == DOF_BALL && d_k == 0;
+      const bool ranged = (is_dof && (d_kind == DOF_HINGE || d_kind == DOF_SLIDE)) || ball0;
+      const double qc = ball0 ? sq[ball0 ? d_qadr : 0] : q_dof;
+      const bool viol = ranged & ((qc < r_lo - 1e-6) | (qc > r_hi + 1e-6));
       if (__ballot(viol)) status |= 1;
     }
     // stash the dof's motion axis in LDS; phases below reload it instead of keeping 20 VGPRs live
@@ -1069,9 +1069,15 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
   const unsigned long long a_mask = __ballot(clamped);                 // predicted active set (wave-uniform)
   // weighted error of residual row my_c (read before the Jacobian rows may overwrite the task blocks):
   // a frame-task row, or (−1 − 3·t − r) row r of ComTask t: cost·(−gain·(com − target))   (com_task.py:71-82)
+  // (per-lane entries of the descriptor's tables, requested together here — each used to be fetched where it is needed, one L2
+  //  round trip after the other: the residual's source, the first pass of (task, dof) pairs, the lane's column of S)
+  const int pre_src = P.mu_src[is_s ? my_c : 0];
+  const int pre_t = P.jpair_task[lane], pre_k = P.jpair_dof[lane];
+  const int pre_wc = P.wood_col[ol], pre_wr0 = P.wood_row0[ol];
+  const uint64_t pre_chain = P.wood_mask[ol];
   double we_mu = 0.0;
   if (is_s) {
-    const int src = P.mu_src[my_c];
+    const int src = pre_src;
     if (src >= 0) we_mu = sTask[src];
     else if (kCom) {
       const int t = (-1 - src) / 3, r = (-1 - src) % 3;
@@ -1089,7 +1095,7 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
     double Jo[6] = {0, 0, 0, 0, 0, 0};
     int rowmask = 0, o0 = 0;
     if (pi < n_jp) {
-      const int t = P.jpair_task[pi], k = P.jpair_dof[pi];
+      const int t = base == 0 ? pre_t : P.jpair_task[pi], k = base == 0 ? pre_k : P.jpair_dof[pi];
       const auto& ft = frames[t];
       const double* o = sTask + t * 64;
       const double* dd = sDof + k * 10;
@@ -1195,10 +1201,10 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
       sW[lane] = wacc;
     }
   } else {
-    const int wc = P.wood_col[ol], wr0 = P.wood_row0[ol];
+    const int wc = pre_wc, wr0 = pre_wr0;
     if (wc >= 0) {
       const double* a = sJ + wc * NR;
-      const uint64_t chain = P.wood_mask[ol];
+      const uint64_t chain = pre_chain;
       const int rpc = P.wood_rpc;
       // eight rows per pass (one pass for G1's 7 rows per lane): the lane's own column entry is read once per pass, and
       // the walk over the chain bits — a dependent ffs → address → LDS read → FMA chain per bit — runs once
