@@ -490,7 +490,9 @@ __device__ MKH_PRE_ATTR PreOut pre_phases(const DeviceProblem* Pq, const TapArgs
         const int j = b_jadr + jn;
         const int jt = P.jnt_i[j * JI_COUNT + JI_TYPE];
         const int qa = P.jnt_i[j * JI_COUNT + JI_QADR];
-        const auto* jf = P.jnt_f + j * JF_COUNT;
+        // (the joint's constants with its type, not behind it: inside the branches they were a third dependent L2 round trip)
+        const auto* jfp = P.jnt_f + j * JF_COUNT;
+        const double jf[JF_COUNT] = {jfp[0], jfp[1], jfp[2], jfp[3], jfp[4], jfp[5], jfp[6]};
         if (jt == JNT_FREE) {
           xp = {sq[qa], sq[qa + 1], sq[qa + 2]};
           xq = qnormalize(Q4{sq[qa + 3], sq[qa + 4], sq[qa + 5], sq[qa + 6]});
