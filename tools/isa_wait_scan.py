@@ -3,7 +3,7 @@
 behind single reads: a dependent LDS or L2 round trip each.  This is how round 4 found the 4.5 % of the headline that sat in the
 S = I + Jh·Jhᵀ accumulation (eight clamped row pointers: eight reads, each behind its own full wait, per chain bit).
 
-    python tools/isa_wait_scan.py 44_32_r44_w3 [48_72 ...]
+    python tools/isa_wait_scan.py 44_32_r44_w3 [48_72 ...]          (MKH_SCAN_MIN=<n>: report loops with at least n such waits, default 3)
 """
 import os
 import re
@@ -43,7 +43,7 @@ def scan(asm):
                         singles += 1 if 0 < pend_v <= 2 else 0
                         pend_v = 0
             valu = sum(b.startswith("v_") for b in body)
-            if singles >= 3 and len(body) < 500:
+            if singles >= int(os.environ.get("MKH_SCAN_MIN", "3")) and len(body) < 500:
                 out.append((func, m.group(1), len(body), valu, singles))
     return out
 
