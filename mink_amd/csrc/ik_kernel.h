@@ -1073,13 +1073,19 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
   // a frame-task row, or (−1 − 3·t − r) row r of ComTask t: cost·(−gain·(com − target))   (com_task.py:71-82)
   // (per-lane entries of the descriptor's tables, requested together here — each used to be fetched where it is needed, one L2
   //  round trip after the other: the residual's source, the first pass of (task, dof) pairs, the lane's column of S)
-  const int pre_src = P.mu_src[is_s ? my_c : 0];
-  const int pre_t = P.jpair_task[lane], pre_k = P.jpair_dof[lane];
-  const int pre_wc = P.wood_col[ol], pre_wr0 = P.wood_row0[ol];
-  const uint64_t pre_chain = P.wood_mask[ol];
+  // (humanoid-size builds only: in the 16- / 24- / 32-row builds the six values cost this function spilled registers)
+  constexpr bool kPre = NR >= 44;
+  int pre_src = 0, pre_t = 0, pre_k = 0, pre_wc = 0, pre_wr0 = 0;
+  uint64_t pre_chain = 0;
+  if constexpr (kPre) {
+    pre_src = P.mu_src[is_s ? my_c : 0];
+    pre_t = P.jpair_task[lane]; pre_k = P.jpair_dof[lane];
+    pre_wc = P.wood_col[ol]; pre_wr0 = P.wood_row0[ol];
+    pre_chain = P.wood_mask[ol];
+  }
   double we_mu = 0.0;
   if (is_s) {
-    const int src = pre_src;
+    const int src = kPre ? pre_src : P.mu_src[my_c];
     if (src >= 0) we_mu = sTask[src];
     else if (kCom) {
       const int t = (-1 - src) / 3, r = (-1 - src) % 3;
@@ -1097,7 +1103,7 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
     double Jo[6] = {0, 0, 0, 0, 0, 0};
     int rowmask = 0, o0 = 0;
     if (pi < n_jp) {
-      const int t = base == 0 ? pre_t : P.jpair_task[pi], k = base == 0 ? pre_k : P.jpair_dof[pi];
+      const int t = (kPre && base == 0) ? pre_t : P.jpair_task[pi], k = (kPre && base == 0) ? pre_k : P.jpair_dof[pi];
       const auto& ft = frames[t];
       const double* o = sTask + t * 64;
       const double* dd = sDof + k * 10;
@@ -1203,10 +1209,10 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
       sW[lane] = wacc;
     }
   } else {
-    const int wc = pre_wc, wr0 = pre_wr0;
+    const int wc = kPre ? pre_wc : P.wood_col[ol], wr0 = kPre ? pre_wr0 : P.wood_row0[ol];
     if (wc >= 0) {
       const double* a = sJ + wc * NR;
-      const uint64_t chain = pre_chain;
+      const uint64_t chain = kPre ? pre_chain : P.wood_mask[ol];
       const int rpc = P.wood_rpc;
       // eight rows per pass (one pass for G1's 7 rows per lane): the lane's own column entry is read once per pass, and
       // the walk over the chain bits — a dependent ffs → address → LDS read → FMA chain per bit — runs once
