@@ -40,7 +40,9 @@
 extern "C" {
 #endif
 
-#define MKH_VERSION 105
+/* 106 (round 4): + mkh_geom_distance_eval; models up to 4 096 bodies / 1 024 dofs and instances with up to 448 active half-space rows
+ * (the workgroup-per-problem kernel) where 105 returned MKH_E_LIMIT / MKH_ST_ROW_OVERFLOW.  No struct changed. */
+#define MKH_VERSION 106
 
 /* return codes */
 #define MKH_OK 0
