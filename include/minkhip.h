@@ -40,17 +40,23 @@
 extern "C" {
 #endif
 
-/* 106 (round 4): + mkh_geom_distance_eval; models up to 4 096 bodies / 1 024 dofs and instances with up to 448 active half-space rows
- * (the workgroup-per-problem kernel) where 105 returned MKH_E_LIMIT / MKH_ST_ROW_OVERFLOW.  No struct changed. */
-#define MKH_VERSION 106
+/* 106 (round 4): + mkh_geom_distance_eval; models beyond 64 bodies / dofs and instances with up to 448 active half-space rows
+ * (the workgroup-per-problem kernel) where 105 returned MKH_E_LIMIT / MKH_ST_ROW_OVERFLOW.  No struct changed.
+ * 107 (round 5): no signature or struct changed; calls that 106 refused now run — on models beyond 64 bodies / dofs the per-task
+ * (e, J) and iteration taps (mkh_eval) and the fused loops mkh_solve_steps / mkh_solve_until; the fused loops and calls with taps
+ * no longer report MKH_ST_ROW_OVERFLOW below 448 rows per instance (the flagged instances run again with every row). */
+#define MKH_VERSION 107
 
 /* return codes */
 #define MKH_OK 0
 #define MKH_E_INVALID (-1)   /* bad argument / unsupported model feature   */
 #define MKH_E_HIP (-2)       /* HIP runtime error (message has the detail)  */
 #define MKH_E_NOGPU (-3)     /* no gfx950 device visible                    */
-#define MKH_E_LIMIT (-4)     /* exceeds a compiled-in size limit (4096 bodies, 1024 dofs, 16 frame tasks, ...; models
-                                beyond 64 bodies or 64 dofs run, on the workgroup-per-problem kernel) */
+#define MKH_E_LIMIT (-4)     /* exceeds a size limit (16 frame tasks, ...).  Models beyond 64 bodies or 64 dofs run on the
+                                workgroup-per-problem kernel, which keeps a problem's kinematic state in the 160 KB of LDS of one
+                                CU: ≈ 8·(nq + 7·nbody + 6·njnt + 14·nv + 5.5·(nv + rows) + 64·frame tasks) bytes ≤ 158 KB — a
+                                serial chain fits up to ≈ 550 dofs; mkh_problem_create reports the figure.  (mkh_model_create
+                                itself refuses only beyond 4096 bodies / 1024 dofs.) */
 
 /* per-instance status bits written to status_out */
 #define MKH_ST_OK 0
@@ -59,11 +65,14 @@ extern "C" {
 #define MKH_ST_NOT_PD 4          /* H not positive definite (quadprog "matrix G is not positive definite") */
 #define MKH_ST_ITER_LIMIT 8      /* active-set iteration cap hit */
 #define MKH_ST_ROW_OVERFLOW 16   /* more half-space rows active at once than the solve could hold AND a row that found no place is
-                                    violated at the solution.  Plain solves (mkh_solve / mkh_solve_dense) never return it below 448
-                                    rows per instance: a wavefront kernel holds 64 - nv rows (the tightest contacts get them, the rest
-                                    are checked at the solution), and the instances it flags are solved again with EVERY row by the
-                                    workgroup-per-problem kernel.  The fused loops (mkh_solve_steps / mkh_solve_until) and calls
-                                    with taps still report it. */
+                                    violated at the solution.  No entry point returns it below 448 rows per instance: a wavefront
+                                    kernel holds 64 - nv rows (the tightest contacts get them, the rest are checked at the
+                                    solution), and the instances it flags are solved again with EVERY row by the
+                                    workgroup-per-problem kernel — plain solves, calls with taps and (round 5) the fused loops
+                                    mkh_solve_steps / mkh_solve_until, whose flagged instances run their whole loop again.  Beyond
+                                    448 contacts in range the same rule applies one level up: the 448 tightest are rows, the bit
+                                    is set only if a dropped one is violated at the solution; caller-defined limit rows that find
+                                    no place set it unconditionally. */
 
 /* flags */
 #define MKH_FLAG_DEVICE_PTRS 1   /* data pointers are device pointers; async on stream */

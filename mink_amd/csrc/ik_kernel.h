@@ -1931,7 +1931,11 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       }
     }
     };
-#if defined(MKH_COLL_CALL) || (MKH_FEAT & 128)
+#if defined(MKH_COLL_CALL) || (MKH_FEAT & 128) || ((MKH_FEAT & 30) == 30)
+    // (round 5: the parity build FEAT 31 — every feature + taps, phases inlined — carries the general convex routine too, and with
+    //  it overlap_pair, a REAL call that owns the whole register file: behind the H accumulation it overwrote the pinned tableau
+    //  of the rare instance with a PENETRATING general convex pair — a silently wrong H, hence v, found by comparing a call with
+    //  taps against the plain call on 1 024 G1 instances with 45 contacts each)
     constexpr bool kCollFirst = true;      // a real callee (or, general convex pairs: overlap_pair inside the phase): while the tableau is dead
 #else
     constexpr bool kCollFirst = false;     // inlined (plane / sphere / capsule builds): after the H accumulation, as in round 2

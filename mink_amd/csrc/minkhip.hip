@@ -144,8 +144,9 @@ struct MkhProblem {
   double *d_dense_cost = nullptr, *d_dense_wgain = nullptr;
   DeviceProblem* d_dev = nullptr;   // device copy of `dev` (the kernel reads the descriptor from memory)
   TapArgs* d_taps = nullptr;
-  int last_grid = 0, last_lds = 0, last_nt = 0;   // geometry of the most recent launch (mkh_problem_launch_info)
+  int last_grid = 0, last_lds = 0, last_nt = 0, last_block = kWave;   // geometry of the most recent launch (mkh_problem_launch_info)
   long long* d_clk = nullptr;      // MKH_DEBUG_CLOCKS (experiment builds): cycle stamps of the last launch
+  double* d_qkeep = nullptr;       // fused loops with a redo launch behind them: the call's q as it came (q_out may alias it)
   int8_t* d_warm = nullptr;        // MKH_FLAG_WARM_START: active set of every instance after the previous solve (max_batch × nv)
   int warm_age = 0, warm_B = 0;    // solves since the state was reset / the batch size it belongs to
   uint32_t* d_work = nullptr;      // ticket counter of the dynamic problem distribution (zeroed by the kernel's last draw)
@@ -485,6 +486,15 @@ static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhPro
     W.com_jrow0[t] = jrows; jrows += __builtin_popcount(W.com_rowmask[t]);
   }
   W.n_jrows = jrows;
+  // rows of the (e, J) tap layout — the same order mkh_problem_create counts for the wavefront kernels (DeviceProblem::n_rows_tap)
+  {
+    int row = 6 * W.n_frame;
+    for (int t = 0; t < W.n_posture; ++t) { W.posture_row0[t] = row; row += nv; }
+    for (int t = 0; t < W.n_com; ++t) { W.com_row0[t] = row; row += 3; }
+    W.dense_tap_row0 = row;
+    for (int t = 0; t < W.n_dense_tasks; ++t) row += d->dense_tasks[t].k;
+    W.n_rows_tap = row;
+  }
   for (int t = 0, r0 = 0; t < W.n_dense_tasks; ++t) {
     W.dense_row0[t] = r0; W.dense_k[t] = d->dense_tasks[t].k; W.dense_lm[t] = d->dense_tasks[t].lm_damping; r0 += d->dense_tasks[t].k;
   }
@@ -507,7 +517,7 @@ static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhPro
   MKH_UP(level_start, level_start) MKH_UP(level_body, level_body) MKH_UP(m->body_parentid, body_parent) MKH_UP(jadr, body_jntadr)
   MKH_UP(m->body_jntnum, body_jntnum) MKH_UP(last, body_last) MKH_UP(inrobot, body_inrobot)
   MKH_UP(m->body_pos, body_pos) MKH_UP(m->body_quat, body_quat) MKH_UP(m->body_ipos, body_ipos) MKH_UP(m->body_mass, body_mass)
-  MKH_UP(m->body_subtreemass, body_stmass) MKH_UP(m->jnt_type, jnt_type) MKH_UP(m->jnt_qposadr, jnt_qadr) MKH_UP(m->jnt_axis, jnt_axis)
+  MKH_UP(m->body_subtreemass, body_stmass) MKH_UP(m->jnt_type, jnt_type) MKH_UP(m->jnt_qposadr, jnt_qadr) MKH_UP(m->jnt_dofadr, jnt_dadr) MKH_UP(m->jnt_axis, jnt_axis)
   MKH_UP(m->jnt_pos, jnt_pos) MKH_UP(m->jnt_qpos0, jnt_qpos0) MKH_UP(m->dof_jntid, dof_jnt) MKH_UP(dkind, dof_kind) MKH_UP(dk, dof_k)
   MKH_UP(m->dof_bodyid, dof_body) MKH_UP(dqadr, dof_qadr) MKH_UP(dlo, dof_lo) MKH_UP(dhi, dof_hi) MKH_UP(chain, chain)
   MKH_UP(ft, frame) MKH_UP(pcost, posture_cost) MKH_UP(dcost, dense_cost) MKH_UP(dwgain, dense_wgain) MKH_UP(clo, cfg_lower)
@@ -538,11 +548,14 @@ static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhPro
   W.tableau_in_lds = (long long)o + (long long)Ncap * Ncap <= lds_cap ? 1 : 0;
   W.o_T = o; o += W.tableau_in_lds ? Ncap * Ncap : 0;
   W.lds_doubles = o;
-  if (o > lds_cap) return fail(MKH_E_LIMIT, "model too large for the workgroup-per-problem kernel (%d KB of LDS per problem)", o / 128);
+  if (o > lds_cap)
+    return fail(MKH_E_LIMIT, "model too large for the workgroup-per-problem kernel: %d KB of LDS per problem, 158 KB available (per problem "
+                "≈ 8·(nq + 7·nbody + 6·njnt + 14·nv + 5.5·(nv + rows) + 64·frame tasks) bytes: a serial chain fits up to ≈ 550 dofs)", o / 128);
   long long w = 0;
   W.ws_jw = w; w += (long long)(R_all > 0 ? R_all : 1) * nv;
   W.ws_rec = w; w += (long long)(W.n_pairs > 0 ? W.n_pairs : 1) * 10;
   W.ws_rowpair = w; w += ev((W.max_rows + 2) / 2);
+  W.ws_rank = w; w += ev((W.n_pairs + 2) / 2);
   W.ws_T = w; w += W.tableau_in_lds ? 0 : (long long)Ncap * Ncap;
   W.ws_stride = (w + 15) & ~15ll;
   const int per_cu = (160 * 1024) / (o * 8) < 2 ? ((160 * 1024) / (o * 8) < 1 ? 1 : (160 * 1024) / (o * 8)) : 2;
@@ -971,6 +984,8 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     p->wide_only = true;
     if (hipMalloc((void**)&p->d_taps, sizeof(TapArgs)) != hipSuccess) return bail(fail(MKH_E_HIP, "descriptor upload failed"));
     snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_wide_kernel");
+    p->dev.n_rows_tap = p->wide.n_rows_tap;        // (what mkh_problem_num_task_rows reports; the wavefront descriptor is not built)
+    p->last_grid = p->wide_grid; p->last_lds = p->wide_lds; p->last_nt = p->wide.nv + p->wide.max_rows; p->last_block = kWideThreads;
     *out = p;
     return MKH_OK;
   }
@@ -1217,7 +1232,7 @@ void mkh_problem_destroy(MkhProblem* p) {
   (void)hipSetDevice(p->device);
   (void)hipFree(p->d_frame); (void)hipFree(p->d_posture_cost); (void)hipFree(p->d_cfg_lower); (void)hipFree(p->d_cfg_upper);
   (void)hipFree(p->d_vel); (void)hipFree(p->d_pairs); (void)hipFree(p->d_dev); (void)hipFree(p->d_taps); (void)hipFree(p->d_work);
-  (void)hipFree(p->d_lane); (void)hipFree(p->d_warm); (void)hipFree(p->d_dev_tight); (void)hipFree(p->d_status_tight);
+  (void)hipFree(p->d_lane); (void)hipFree(p->d_warm); (void)hipFree(p->d_qkeep); (void)hipFree(p->d_dev_tight); (void)hipFree(p->d_status_tight);
   (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain); (void)hipFree(p->s_iters);
   (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh); (void)hipFree(p->s_dbox); (void)hipFree(p->d_clk);
   for (void* w : p->wide_allocs) (void)hipFree(w);
@@ -1261,8 +1276,8 @@ int32_t mkh_problem_launch_info(const MkhProblem* p, int32_t B, int32_t* grid, i
   if (!p) return fail(MKH_E_INVALID, "null problem");
   // what the most recent launch of this problem used (the variant depends on the call: taps, fused steps, the
   // low-rank QP start); before any launch, the lean direct variant
-  if (grid) *grid = p->last_nt ? p->last_grid : grid_for(p, B);
-  if (block) *block = kWave;
+  if (grid) *grid = p->wide_only ? (p->wide_grid < B ? p->wide_grid : B) : (p->last_nt ? p->last_grid : grid_for(p, B));
+  if (block) *block = p->last_block;        // (64: one wavefront per workgroup; 256 on the workgroup-per-problem kernel)
   if (lds_bytes) *lds_bytes = p->last_nt ? p->last_lds : p->lds_bytes;
   if (tableau_rows) *tableau_rows = p->last_nt ? p->last_nt : p->nt;
   return MKH_OK;
@@ -1302,9 +1317,9 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   SolveArgs a = a_in;
   if (!a.status_out && p->d_status_tight && a.do_qp) a.status_out = p->d_status_tight;
   if (p->wide_only) {
-    if ((taps && (taps->t_task_e || taps->t_task_J || taps->t_qp_iters || taps->t_cycles)) || a.n_steps > 1 || a.pos_threshold >= 0.0)
-      return fail(MKH_E_INVALID, "models beyond one wavefront (more than 64 bodies or dofs) run on the workgroup-per-problem kernel: "
-                                 "no per-task (e, J) / iteration taps, no fused loops (call mkh_solve and mkh_integrate in turn)");
+    if (taps && taps->t_cycles)
+      return fail(MKH_E_INVALID, "models beyond one wavefront (more than 64 bodies or dofs) run on the workgroup-per-problem kernel, "
+                                 "which has no cycle-counter tap");
     const TapArgs* dt_ = nullptr;
     if (taps) {
       HIP_OK(hipMemcpyAsync(p->d_taps, taps, sizeof(TapArgs), hipMemcpyHostToDevice, stream));
@@ -1313,10 +1328,21 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
     }
     snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_wide_kernel");
     p->last_grid = p->wide_grid < a.B ? p->wide_grid : a.B; p->last_lds = p->wide_lds; p->last_nt = p->wide.nv + p->wide.max_rows;
+    p->last_block = kWideThreads;
     return launch_wide_kernel(p, a, stream, 0, dt_);
   }
-  // (plain solves of a problem whose rows can outnumber the tableau's: the flagged instances once more, with every row)
-  const bool wide_redo = p->d_wide && a.do_qp && a.status_out && !taps && a.n_steps <= 1 && !(a.pos_threshold >= 0.0);
+  // A problem whose rows can outnumber the tableau's: the flagged instances once more, with every row — plain solves, calls
+  // with taps (the workgroup-per-problem kernel writes every tap but the cycle counters) and, round 5, the fused loops: an
+  // instance that overflows at some step runs its whole loop again from its ORIGINAL q, of which the handle keeps a copy for
+  // the duration of the call (q_out may alias q) — a device-to-device copy of B·nq doubles in front of the launch
+  const bool wide_redo = p->d_wide && a.do_qp && a.status_out && !(taps && taps->t_cycles);
+  const double* q_redo = a.q;
+  if (wide_redo && a.q_out) {
+    HIP_OK(ensure(&p->d_qkeep, (size_t)p->max_batch * p->dev.nq));
+    HIP_OK(hipMemcpyAsync(p->d_qkeep, a.q, (size_t)a.B * p->dev.nq * sizeof(double), hipMemcpyDefault, stream));
+    q_redo = p->d_qkeep;
+  }
+  p->last_block = kWave;
   (void)hipGetLastError();          // a stale error of an unrelated earlier runtime call must not be blamed on this launch
   const TapArgs* dtaps = nullptr;
   if (taps) {
@@ -1477,7 +1503,9 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   if (wide_redo) {
     const size_t len = strlen(p->last_kernel);
     snprintf(p->last_kernel + len, sizeof(p->last_kernel) - len, "+wide");
-    return launch_wide_kernel(p, a, stream, MKH_ST_ROW_OVERFLOW);
+    SolveArgs ar = a;
+    ar.q = q_redo;
+    return launch_wide_kernel(p, ar, stream, MKH_ST_ROW_OVERFLOW, dtaps);
   }
   return MKH_OK;
 }

@@ -8,14 +8,19 @@
 //   * the instances of a collision / plugin-row problem in which more rows are ACTIVE than the wavefront kernel has tableau
 //     rows and a row it dropped is violated at its solution (MKH_ST_ROW_OVERFLOW): a redo launch behind the normal one
 //     (SolveArgs::redo_mask) that solves exactly those, every detected contact a row.
-// It does not have to be fast, it has to return mink's answer; the structure is still the device's: body poses level by
+// It has to return mink's answer first; the structure is still the device's: body poses level by
 // level of the kinematic tree, (task, dof) pairs / (i, j) entries of H / tableau entries spread over the 256 threads, the
 // dual active-set iteration of the wavefront kernels (Goldfarb–Idnani on a symmetric sweep tableau, tools/proto_tableau_qp.py)
 // with the tableau in LDS when (nv + rows)² doubles fit next to the per-problem state, else in a slice of device memory.
 //
 // Covered: FrameTask / RelativeFrameTask (body, geom, site frames), PostureTask (any number: DampingTask is one), ComTask,
 // caller-defined task rows, ConfigurationLimit, VelocityLimit, CollisionAvoidanceLimit (every pair type of collide_dev.h /
-// convex_dev.h), caller-defined limit rows and box rows.  Not covered: parity taps, the fused caller loops (the host loops).
+// convex_dev.h), caller-defined limit rows and box rows; every parity tap of MkhTaps except the cycle counters (round 5: per-task
+// (e, J) and the iteration counts too, so that Configuration.get_frame_jacobian / Task.compute_error / compute_jacobian work on
+// big models — mink/configuration.py:112-155, mink/tasks/task.py:81-103); the fused caller loops mkh_solve_steps /
+// mkh_solve_until (round 5: the step loop runs inside this kernel, q in LDS, per-instance break on the callers' thresholds —
+// examples/arm_ur5e_actuators.py:88-97), also as the redo of a fused loop of a wavefront kernel that met more contacts than it
+// has rows (the host keeps a copy of q for that launch: q_out may alias q).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
   double* const Jw = wsb + P.ws_jw;                      // weighted Jacobian rows [R][nv]
   double* const rec = wsb + P.ws_rec;                    // per pair: h, n, from, to (10 doubles)
   int* const rowpair = reinterpret_cast<int*>(wsb + P.ws_rowpair);
+  int* const rowrank = reinterpret_cast<int*>(wsb + P.ws_rank);
   double* const T = P.tableau_in_lds ? smem + P.o_T : wsb + P.ws_T;
   const int R_task = P.n_jrows, R_all = P.n_jrows + P.n_dense_rows;
   // parity taps (mkh_eval): body poses, frame poses, subtree CoM, H, c, the box, the contact rows — what the reference's
@@ -140,10 +146,19 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
   for (int pb = (int)blockIdx.x; pb < A.B; pb += (int)gridDim.x) {
     if (A.redo_mask && !(A.status_out[pb] & A.redo_mask)) continue;          // (wave-uniform: the whole workgroup skips)
     __syncthreads();
-    int status = 0;
     // ------------------------------------------------------------ inputs
     for (int i = tid; i < nq; i += NT_) sq[i] = A.q[(size_t)pb * nq + i];
     __syncthreads();
+    // Fused outer loop (mkh_solve_steps / mkh_solve_until; the semantics of ik_kernel.h's loop): q stays in LDS between steps,
+    // status is the OR over the steps, an instance stops at the first step whose QP fails; with thresholds the test sits
+    // behind the frame-task errors of the NEXT step (the error at the integrated q), one check-only pass after the last
+    // allowed iteration.
+    const int n_steps = A.n_steps > 1 ? A.n_steps : 1;
+    const bool until = A.pos_threshold >= 0.0;
+    const bool integrate = A.n_steps > 1 || A.q_out != nullptr;
+    int status_all = 0, it_done = 0, conv_flag = 0;
+    for (int step = 0; step < n_steps + (until ? 1 : 0); ++step) {
+    int status = 0;
     // ------------------------------------------------------------ FK, level by level (mj_kinematics)
     for (int lv = 0; lv < P.nlevels; ++lv) {
       for (int idx = P.level_start[lv] + tid; idx < P.level_start[lv + 1]; idx += NT_) {
@@ -234,6 +249,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
     }
     // ------------------------------------------------------------ frame tasks: pose, error, jlog (the task lanes of ik_kernel.h)
     double mu_part = 0.0;                                  // Levenberg–Marquardt terms owned by this thread
+    bool conv_mine = true;                                 // this thread's frame tasks are within the thresholds (rows with a nonzero cost only)
     for (int t = tid; t < P.n_frame; t += NT_) {
       const FrameTaskDev& ft = P.frame[t];
       SE3 F;
@@ -277,8 +293,12 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
         const double we = ft.cost[r] * (-ft.gain * e6[r]);  // weighted_error (task.py:129-130)
         ss += we * we;
         if ((ft.rowmask >> r) & 1) { sWe[ft.jrow0 + c] = we; ++c; }
+        if (MKH_WTAP(t_task_e)) MKH_WTAP(t_task_e)[(size_t)pb * P.n_rows_tap + ft.row0 + r] = e6[r];
       }
       mu_part += ft.lm_damping * ss;                        // task.py:131
+      if (until)
+        conv_mine = conv_mine && (!(ft.rowmask & 7) || dot(ev, ev) <= A.pos_threshold * A.pos_threshold) &&
+                    (!(ft.rowmask & 56) || dot(ew, ew) <= A.ori_threshold * A.ori_threshold);
       if (MKH_WTAP(t_frame_pose)) {                          // pose of the frame in the world (RelativeFrameTask: in its root frame)
         SE3 Fo = F;
         if (ft.relative) {
@@ -293,6 +313,11 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
         t7[0] = Fo.q.w; t7[1] = Fo.q.x; t7[2] = Fo.q.y; t7[3] = Fo.q.z; t7[4] = Fo.p.x; t7[5] = Fo.p.y; t7[6] = Fo.p.z;
       }
     }
+    if (until && step > 0) {                                 // (workgroup-uniform: every thread sees the same vote)
+      it_done = step;
+      if (!__syncthreads_or(conv_mine ? 0 : 1)) { conv_flag = 1; status_all |= status; break; }   // every frame task achieved
+      if (step == n_steps) { status_all |= status; break; }                                        // iteration budget spent
+    }
     if (MKH_WTAP(t_subtree_com) && P.n_com > 0 && tid < 3) MKH_WTAP(t_subtree_com)[(size_t)pb * 3 + tid] = sCom[P.robot_root * 4 + tid];
     // ComTask error & LM term (com_task.py:71-82)
     if (tid == 0)
@@ -304,6 +329,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
         for (int r = 0; r < 3; ++r) {
           const double we = P.com_cost[t][r] * (-P.com_gain[t] * (cr[r] - tg[r]));
           ss += we * we;
+          if (MKH_WTAP(t_task_e)) MKH_WTAP(t_task_e)[(size_t)pb * P.n_rows_tap + P.com_row0[t] + r] = cr[r] - tg[r];
           if ((P.com_rowmask[t] >> r) & 1) { sWe[P.com_jrow0[t] + c] = we; ++c; }
         }
         mu_part += P.com_lm[t] * ss;
@@ -317,6 +343,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
           const double we = P.dense_wgain[P.dense_row0[t] + r] * de[r];
           sWe[R_task + P.dense_row0[t] + r] = we;
           ss += we * we;
+          if (MKH_WTAP(t_task_e)) MKH_WTAP(t_task_e)[(size_t)pb * P.n_rows_tap + P.dense_tap_row0 + P.dense_row0[t] + r] = de[r];
         }
         mu_part += P.dense_lm[t] * ss;
       }
@@ -338,6 +365,8 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
         }                                                  // free-joint dofs: error and column zeroed (posture_task.py:115-116,139-141)
         const double cost = P.posture_cost[(size_t)t * nv + d];
         const double we = cost * (-P.posture_gain[t] * e), wj = cost * jd;
+        if (MKH_WTAP(t_task_e)) MKH_WTAP(t_task_e)[(size_t)pb * P.n_rows_tap + P.posture_row0[t] + d] = e;
+        if (MKH_WTAP(t_task_J)) MKH_WTAP(t_task_J)[((size_t)pb * P.n_rows_tap + P.posture_row0[t] + d) * nv + d] = jd;   // (the buffer arrives zeroed)
         sHd[d] += wj * wj;
         sC[d] -= we * wj;
         ssw += we * we;
@@ -352,6 +381,10 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       const bool on_f = wide_on_chain(P, ft.body, k), rel = ft.relative != 0, on_r = rel && wide_on_chain(P, ft.root_body, k);
       double Jt[6] = {0, 0, 0, 0, 0, 0};
       if (on_f || on_r) wide_frame_column(sTask + t * 64, sDof + k * 10, on_f, rel, on_r, Jt);
+      if (MKH_WTAP(t_task_J)) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r) MKH_WTAP(t_task_J)[((size_t)pb * P.n_rows_tap + ft.row0 + r) * nv + k] = Jt[r];
+      }
       int c = 0;
 #pragma unroll
       for (int r = 0; r < 6; ++r)
@@ -368,13 +401,17 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
         const V3 jc = fac * (V3{kd[3], kd[4], kd[5]} + cross(V3{kd[0], kd[1], kd[2]}, V3{cd[0], cd[1], cd[2]} - V3{kd[6], kd[7], kd[8]}));
         Jt[0] = jc.x; Jt[1] = jc.y; Jt[2] = jc.z;
       }
+      if (MKH_WTAP(t_task_J))
+        for (int r = 0; r < 3; ++r) MKH_WTAP(t_task_J)[((size_t)pb * P.n_rows_tap + P.com_row0[t] + r) * nv + k] = Jt[r];
       int c = 0;
       for (int r = 0; r < 3; ++r)
         if ((P.com_rowmask[t] >> r) & 1) { Jw[(size_t)(P.com_jrow0[t] + c) * nv + k] = P.com_cost[t][r] * Jt[r]; ++c; }
     }
     for (int e = tid; e < P.n_dense_rows * nv; e += NT_) {  // caller-defined rows: W·J straight from memory
       const int r = e / nv, k = e - r * nv;
-      Jw[(size_t)(R_task + r) * nv + k] = P.dense_cost[r] * A.dense_J[((size_t)pb * P.n_dense_rows + r) * nv + k];
+      const double jr = A.dense_J[((size_t)pb * P.n_dense_rows + r) * nv + k];
+      Jw[(size_t)(R_task + r) * nv + k] = P.dense_cost[r] * jr;
+      if (MKH_WTAP(t_task_J)) MKH_WTAP(t_task_J)[((size_t)pb * P.n_rows_tap + P.dense_tap_row0 + r) * nv + k] = jr;
     }
     __syncthreads();
     // c = −weighted_errorᵀ·weighted_jacobian (task.py:133-134)
@@ -468,18 +505,35 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       }
     }
     __syncthreads();
-    // row order: the detected contacts in pair order, then the caller's rows with a finite bound
+    // Rows: the detected contacts in pair order, then the caller's rows with a finite bound.  More contacts in range than the
+    // workspace has rows (kWideMaxRows): the rule of the wavefront kernels (collision_phase) — the max_rows TIGHTEST (smallest
+    // h, ties by pair index) become rows, the rest are checked at the solution below; a dropped one that holds there was
+    // inactive, so the result is still the reference's (mink/solve_ik.py:25-40 stacks every row).
+    int n_det = 0;
+    for (int pi = tid; pi < P.n_pairs; pi += NT_) n_det += rec[(size_t)pi * 10] < kInf ? 1 : 0;
+    n_det = (int)(block_sum((double)n_det) + 0.5);
+    const bool select = n_det > P.max_rows;
+    if (select) {
+      for (int pi = tid; pi < P.n_pairs; pi += NT_) {
+        const double hk = rec[(size_t)pi * 10];
+        int rank = 0;
+        if (hk < kInf)
+          for (int j = 0; j < P.n_pairs; ++j) { const double hj = rec[(size_t)j * 10]; rank += (hj < hk || (hj == hk && j < pi)) ? 1 : 0; }
+        rowrank[pi] = rank;
+      }
+      __syncthreads();
+    }
     if (tid == 0) {
       int m = 0, over = 0;
       for (int pi = 0; pi < P.n_pairs; ++pi)
-        if (rec[(size_t)pi * 10] < kInf) { if (m < P.max_rows) rowpair[m++] = pi; else over = 1; }
-      for (int r = 0; r < P.n_dense_limit_rows; ++r)
+        if (rec[(size_t)pi * 10] < kInf && (!select || rowrank[pi] < P.max_rows)) rowpair[m++] = pi;
+      for (int r = 0; r < P.n_dense_limit_rows; ++r)       // (the caller's rows are not ranked: one that finds no place is reported)
         if (A.dense_h[(size_t)pb * P.n_dense_limit_rows + r] < kInf) { if (m < P.max_rows) rowpair[m++] = -1 - r; else over = 1; }
       sRedI[0] = m; sRedI[1] = over;
     }
     __syncthreads();
     const int m = sRedI[0];
-    if (sRedI[1]) status |= 16;                              // (more rows than the workspace holds: kWideMaxRows)
+    if (sRedI[1]) status |= 16;
     const int N = nv + m;
     __syncthreads();
     // ------------------------------------------------------------ tableau K = [[H, Aᵀ],[A, 0]], z, w, states
@@ -543,7 +597,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       for (int i = tid; i < N; i += NT_) sCol[i] = T[(size_t)i * N + p];
       __syncthreads();
     };
-    auto step = [&](int p, double alpha, bool p_basic) {     // (sCol holds column p)
+    auto take_step = [&](int p, double alpha, bool p_basic) {     // (sCol holds column p)
       for (int i = tid; i < N; i += NT_) {
         const int st = sState[i];
         if (st == WS_FREE || st == WS_ROW_ON) sZ[i] -= alpha * sCol[i]; else sW[i] += alpha * sCol[i];
@@ -565,7 +619,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       }
       __syncthreads();
     };
-    int iters = 0;
+    int iters = 0, n_outer = 0, n_piv = 0;                  // (qp_iters tap: ratio-test rounds, violated conditions handled, sweeps after phase 0)
     const int max_iters = 20 * (N + 4);
     if (!(status & 14) && A.do_qp) {
       // phase 0: bring every dof into the basis (x0 = −H⁻¹c), no ratio tests
@@ -575,7 +629,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
         if (!(d > 0.0)) { status |= 4; break; }
         const double wk = sW[k];
         __syncthreads();
-        step(k, -wk / d, false);
+        take_step(k, -wk / d, false);
         if (tid == 0) { sW[k] = 0.0; sState[k] = WS_FREE; }
         sweep(k, false);
       }
@@ -593,6 +647,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
         double pv; int p;
         block_arg(bv, bi, true, pv, p);
         if (p < 0) break;                                    // optimal
+        ++n_outer;
         const bool p_basic = sState[p] == WS_FREE;
         const bool upper = p_basic && (sZ[p] - sHi[p] > sLo[p] - sZ[p]);
         const double beta = p_basic ? (upper ? sHi[p] : sLo[p]) : 0.0;
@@ -622,15 +677,16 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
           if (l < 0) t1 = kInf;
           if (!(fmin(t1, t2) < kInf)) { status |= 2; break; }            // no step possible: infeasible
           if (t2 <= t1) {
-            step(p, sgn * t2, p_basic);
+            take_step(p, sgn * t2, p_basic);
             if (tid == 0) {
               if (p_basic) { sZ[p] = beta; sState[p] = upper ? WS_AT_HI : WS_AT_LO; }
               else { sW[p] = 0.0; sState[p] = WS_ROW_ON; }
             }
             sweep(p, p_basic);
+            ++n_piv;
             break;
           }
-          step(p, sgn * t1, p_basic);
+          take_step(p, sgn * t1, p_basic);
           const bool l_row = sState[l] == WS_ROW_ON;
           __syncthreads();
           if (tid == 0) {
@@ -639,15 +695,71 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
           }
           take_column(l);
           sweep(l, l_row);
+          ++n_piv;
         }
       }
     }
-    // ------------------------------------------------------------ v = Δq / dt (solve_ik.py:104)
-    if (A.v_out) {
-      const bool ok = !(status & 14);
-      for (int d = tid; d < nv; d += NT_) A.v_out[(size_t)pb * nv + d] = ok ? sZ[d] / A.dt : __builtin_nan("");
+    if (MKH_WTAP(t_qp_iters) && tid == 0) MKH_WTAP(t_qp_iters)[pb] = (iters & 1023) | ((n_outer & 1023) << 10) | ((n_piv & 1023) << 20);
+    // the contacts that found no row: G·Δq ≤ h at the solution?  (the wavefront kernels' collision_phase, mode 1)
+    if (select && A.do_qp && !(status & 14)) {
+      __syncthreads();
+      bool viol = false;
+      for (int pi = tid; pi < P.n_pairs; pi += NT_) {
+        const double* o = rec + (size_t)pi * 10;
+        if (!(o[0] < kInf) || rowrank[pi] < P.max_rows) continue;
+        const CollisionPairDev& cp = P.pairs[pi];
+        V3 vel{0, 0, 0};
+        for (int k = 0; k < nv; ++k) {
+          const bool c2 = wide_on_chain(P, cp.body2, k), c1 = wide_on_chain(P, cp.body1, k);
+          if (!c1 && !c2) continue;
+          const double* kd = sDof + k * 10;
+          const V3 d_ang{kd[0], kd[1], kd[2]}, d_lin{kd[3], kd[4], kd[5]}, d_anchor{kd[6], kd[7], kd[8]};
+          const double dq = sZ[k];
+          if (c2) vel = vel + dq * (d_lin + cross(d_ang, V3{o[7], o[8], o[9]} - d_anchor));
+          if (c1) vel = vel - dq * (d_lin + cross(d_ang, V3{o[4], o[5], o[6]} - d_anchor));
+        }
+        viol = viol || (-dot(V3{o[1], o[2], o[3]}, vel) > o[0] + 1e-9 * (1.0 + fabs(o[0])));
+      }
+      if (__syncthreads_or(viol ? 1 : 0)) status |= 16;
     }
-    if (A.status_out && tid == 0) A.status_out[pb] = status;
+    status_all |= status;
+    // ------------------------------------------------------------ v = Δq / dt (solve_ik.py:104)
+    const bool last = until || (step + 1 == n_steps) || (status & 14);     // (until: v of every step — the loop may end at the next check)
+    if (last) {
+      if (A.v_out) {
+        const bool ok = !(status & 14);
+        for (int d = tid; d < nv; d += NT_) A.v_out[(size_t)pb * nv + d] = ok ? sZ[d] / A.dt : __builtin_nan("");
+      }
+      if (status & 14) break;
+    }
+    if (integrate) {
+      // q ← q ⊕ Δq (mj_integratePos; Configuration.integrate_inplace, mink/configuration.py:228-236)
+      __syncthreads();
+      for (int j = tid; j < P.njnt; j += NT_) {
+        const int jt = P.jnt_type[j];
+        int qa = P.jnt_qadr[j], va = P.jnt_dadr[j];
+        if (jt == JNT_HINGE || jt == JNT_SLIDE) { sq[qa] += sZ[va]; continue; }
+        if (jt == JNT_FREE) {
+          for (int i = 0; i < 3; ++i) sq[qa + i] += sZ[va + i];
+          qa += 3; va += 3;
+        }
+        const V3 w{sZ[va], sZ[va + 1], sZ[va + 2]};
+        const double n = sqrt(dot(w, w));
+        const V3 ax = (n < 1e-15) ? V3{1.0, 0.0, 0.0} : (1.0 / n) * w;
+        const Q4 qr = (n == 0.0) ? Q4{1, 0, 0, 0} : axis_angle(ax, n);
+        const Q4 r = qmul(qnormalize(Q4{sq[qa], sq[qa + 1], sq[qa + 2], sq[qa + 3]}), qr);
+        sq[qa] = r.w; sq[qa + 1] = r.x; sq[qa + 2] = r.y; sq[qa + 3] = r.z;
+      }
+      __syncthreads();
+    }
+    }  // step loop
+    __syncthreads();
+    if (A.q_out) for (int i = tid; i < nq; i += NT_) A.q_out[(size_t)pb * nq + i] = sq[i];
+    if (until && tid == 0) {
+      if (A.iters_out) A.iters_out[pb] = it_done;
+      if (A.converged_out) A.converged_out[pb] = conv_flag;
+    }
+    if (A.status_out && tid == 0) A.status_out[pb] = status_all;
   }
 }
 

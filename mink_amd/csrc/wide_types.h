@@ -15,13 +15,17 @@ struct WideProblem {
   int32_t n_dense_tasks, n_dense_rows, n_dense_limit_rows, dense_box, robot_root;
   int32_t max_rows;                        // row capacity of the tableau workspace (≤ kWideMaxRows)
   int32_t tableau_in_lds;
+  // rows of the (e, J) tap layout (MkhTaps::task_e / task_J): frame tasks 6 each (FrameTaskDev::row0), then per posture task
+  // nv, per CoM task 3, then the caller-defined tasks
+  int32_t n_rows_tap, dense_tap_row0;
+  int32_t posture_row0[kMaxPostureTasks], com_row0[kMaxComTasks];
   // LDS offsets (doubles)
   int32_t o_q, o_X, o_jnt, o_dof, o_task, o_com, o_we, o_c, o_hd, o_z, o_w, o_lo, o_hi, o_rown, o_ref, o_col, o_red, o_state, o_cws, o_T,
       lds_doubles;
   // model (plain arrays)
   const int32_t *level_start, *level_body, *body_parent, *body_jntadr, *body_jntnum, *body_last, *body_inrobot;
   const double *body_pos, *body_quat, *body_ipos, *body_mass, *body_stmass;
-  const int32_t *jnt_type, *jnt_qadr;
+  const int32_t *jnt_type, *jnt_qadr, *jnt_dadr;
   const double *jnt_axis, *jnt_pos, *jnt_qpos0;
   const int32_t *dof_jnt, *dof_kind, *dof_k, *dof_body, *dof_qadr;
   const double *dof_lo, *dof_hi;           // joint range seen by check_limits (±inf: none)
@@ -43,7 +47,7 @@ struct WideProblem {
   // per-workgroup slice of device memory: weighted Jacobian rows, pair records, row → pair map, (the tableau)
   double* ws;
   long long ws_stride;                     // doubles per workgroup
-  long long ws_jw, ws_rec, ws_rowpair, ws_T;
+  long long ws_jw, ws_rec, ws_rowpair, ws_rank, ws_T;   // (ws_rank: per pair, its rank by h when more contacts are in range than rows — int32)
 };
 
 }  // namespace mkh

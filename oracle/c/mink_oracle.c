@@ -623,8 +623,10 @@ int32_t mko_solve_qp(int32_t n, int32_t m, const double *P, const double *q, con
  * mink/limits/collision_avoidance_limit.py:187-229 on top of mj_geomDistance (third-party, restated from the published
  * pair routines — engine_collision_primitive.c: mjraw_SphereSphere, mjc_CapsuleCapsule, mjraw_SphereCapsule,
  * mjc_PlaneSphere, mjc_PlaneCapsule — in the operation order of oracle/mjmath.py:375-462, 768-833; PARITY UNPINNED
- * against the wheel).  Plane / sphere / capsule pairs only. */
-enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3 };
+ * against the wheel).  Plane / sphere / capsule pairs, and (round 5) box against plane / sphere / capsule and cylinder against
+ * plane / sphere / capsule — mjc_PlaneBox, mjc_PlaneCylinder, mjc_SphereBox, mjc_SphereCylinder, mjc_CapsuleBox, in the
+ * operation order of oracle/mjmath.py:469-633, 738-765 (which carries the tie rules). */
+enum { GEOM_PLANE = 0, GEOM_SPHERE = 2, GEOM_CAPSULE = 3, GEOM_CYLINDER = 5, GEOM_BOX = 6 };
 typedef struct { double dist, pos[3], n[3]; } Con;
 
 static int sphere_sphere(Con *out, const double *p1, double r1, const double *p2, double r2, double margin) {
@@ -716,6 +718,207 @@ static int plane_capsule(Con *out, const double *pos1, const double *mat1, const
   return n;
 }
 
+/* R (row-major 3×3) and its transpose applied to a vector */
+static void matT_vec(double *r, const double *R, const double *v) {
+  for (int k = 0; k < 3; ++k) r[k] = R[k] * v[0] + R[3 + k] * v[1] + R[6 + k] * v[2];
+}
+static void mat_vec(double *r, const double *R, const double *v) {
+  for (int k = 0; k < 3; ++k) r[k] = R[3 * k] * v[0] + R[3 * k + 1] * v[1] + R[3 * k + 2] * v[2];
+}
+/* contacts found in the frame of geom 2 → world (oracle/mjmath.py::_to_world) */
+static void con_to_world(Con *c, int n, const double *R, const double *o) {
+  for (int i = 0; i < n; ++i) {
+    double p[3], nn[3];
+    mat_vec(p, R, c[i].pos); mat_vec(nn, R, c[i].n);
+    for (int k = 0; k < 3; ++k) { c[i].pos[k] = o[k] + p[k]; c[i].n[k] = nn[k]; }
+  }
+}
+
+/* mjc_PlaneBox: the lowest corner; ties towards the −size corner (oracle/mjmath.py:469-479) */
+static int plane_box(Con *out, const double *pos1, const double *mat1, const double *pos2, const double *mat2, const double *size2,
+                     double margin) {
+  const double n[3] = {mat1[2], mat1[5], mat1[8]};
+  double nb[3], vec[3], rv[3];
+  matT_vec(nb, mat2, n);
+  for (int k = 0; k < 3; ++k) vec[k] = nb[k] < 0.0 ? size2[k] : -size2[k];
+  const double dist = (n[0] * (pos2[0] - pos1[0]) + n[1] * (pos2[1] - pos1[1]) + n[2] * (pos2[2] - pos1[2])) +
+                      (nb[0] * vec[0] + nb[1] * vec[1] + nb[2] * vec[2]);
+  if (dist > margin) return 0;
+  mat_vec(rv, mat2, vec);
+  out->dist = dist;
+  for (int k = 0; k < 3; ++k) { out->n[k] = n[k]; out->pos[k] = pos2[k] + rv[k] - n[k] * (0.5 * dist); }
+  return 1;
+}
+
+/* mjc_PlaneCylinder: the lowest rim point; a cap parallel to the plane ties to its centre (oracle/mjmath.py:482-495) */
+static int plane_cylinder(Con *out, const double *pos1, const double *mat1, const double *pos2, const double *mat2,
+                          const double *size2, double margin) {
+  const double n[3] = {mat1[2], mat1[5], mat1[8]}, axis[3] = {mat2[2], mat2[5], mat2[8]};
+  const double c = n[0] * axis[0] + n[1] * axis[1] + n[2] * axis[2];
+  double radial[3], pt[3];
+  for (int k = 0; k < 3; ++k) radial[k] = n[k] - c * axis[k];
+  const double rl = sqrt(radial[0] * radial[0] + radial[1] * radial[1] + radial[2] * radial[2]);
+  for (int k = 0; k < 3; ++k) pt[k] = pos2[k] - axis[k] * (c < 0.0 ? -size2[1] : size2[1]);
+  if (rl > mjMINVAL) for (int k = 0; k < 3; ++k) pt[k] = pt[k] - radial[k] * (size2[0] / rl);
+  const double dist = n[0] * (pt[0] - pos1[0]) + n[1] * (pt[1] - pos1[1]) + n[2] * (pt[2] - pos1[2]);
+  if (dist > margin) return 0;
+  out->dist = dist;
+  for (int k = 0; k < 3; ++k) { out->n[k] = n[k]; out->pos[k] = pt[k] - n[k] * (0.5 * dist); }
+  return 1;
+}
+
+/* ball of radius r centred at p (box frame) against the box ±s (mjc_SphereBox; oracle/mjmath.py:527-548) */
+static int ball_box_local(Con *out, const double *p, double r, const double *s, double margin) {
+  double d[3];
+  for (int k = 0; k < 3; ++k) d[k] = clampd(p[k], -s[k], s[k]) - p[k];
+  const double dl = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (dl - r > margin) return 0;
+  if (dl > mjMINVAL) {
+    const double dist = dl - r;
+    out->dist = dist;
+    for (int k = 0; k < 3; ++k) { out->n[k] = d[k] / dl; out->pos[k] = p[k] + out->n[k] * (r + 0.5 * dist); }
+    return 1;
+  }
+  const double face[3] = {s[0] - fabs(p[0]), s[1] - fabs(p[1]), s[2] - fabs(p[2])};
+  int k = 0;
+  for (int i = 1; i < 3; ++i) if (face[i] < face[k]) k = i;
+  double n[3] = {0, 0, 0};
+  n[k] = p[k] <= 0.0 ? 1.0 : -1.0;
+  const double closest = face[k];
+  out->dist = -closest - r;
+  for (int i = 0; i < 3; ++i) { out->n[i] = n[i]; out->pos[i] = p[i] + n[i] * (0.5 * (r - closest)); }
+  return 1;
+}
+
+/* ball against a cylinder in its own frame (mjc_SphereCylinder; oracle/mjmath.py:591-611) */
+static int ball_cylinder_local(Con *out, const double *p, double r, double rad, double half, double margin) {
+  const double rho = hypot(p[0], p[1]);
+  const double sc = rho > rad ? rad / rho : 1.0;
+  const double cl[3] = {p[0] * sc, p[1] * sc, clampd(p[2], -half, half)};
+  const double d[3] = {cl[0] - p[0], cl[1] - p[1], cl[2] - p[2]};
+  const double dl = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  if (dl - r > margin) return 0;
+  if (dl > mjMINVAL) {
+    const double dist = dl - r;
+    out->dist = dist;
+    for (int k = 0; k < 3; ++k) { out->n[k] = d[k] / dl; out->pos[k] = p[k] + out->n[k] * (r + 0.5 * dist); }
+    return 1;
+  }
+  const double fr = rad - rho, fz = half - fabs(p[2]);
+  double closest, n[3];
+  if (fz < fr) { closest = fz; n[0] = 0; n[1] = 0; n[2] = p[2] <= 0.0 ? 1.0 : -1.0; }
+  else {
+    closest = fr;
+    if (rho > mjMINVAL) { n[0] = -p[0] / rho; n[1] = -p[1] / rho; n[2] = 0; } else { n[0] = -1; n[1] = 0; n[2] = 0; }
+  }
+  out->dist = -closest - r;
+  for (int k = 0; k < 3; ++k) { out->n[k] = n[k]; out->pos[k] = p[k] + n[k] * (0.5 * (r - closest)); }
+  return 1;
+}
+
+static int sphere_box(Con *out, const double *pos1, const double *size1, const double *pos2, const double *mat2,
+                      const double *size2, double margin) {
+  const double dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
+  double p[3];
+  matT_vec(p, mat2, dif);
+  const int n = ball_box_local(out, p, size1[0], size2, margin);
+  con_to_world(out, n, mat2, pos2);
+  return n;
+}
+
+static int sphere_cylinder(Con *out, const double *pos1, const double *size1, const double *pos2, const double *mat2,
+                           const double *size2, double margin) {
+  const double dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]};
+  double p[3];
+  matT_vec(p, mat2, dif);
+  const int n = ball_cylinder_local(out, p, size1[0], size2[0], size2[1], margin);
+  con_to_world(out, n, mat2, pos2);
+  return n;
+}
+
+/* argmin over |t| ≤ l of dist(c + t·a, box ±s): root of the piecewise-linear derivative over its sorted breakpoints
+ * (oracle/mjmath.py:551-588, including its flat-stretch and rounding rules) */
+static double seg_box_g(const double *c, const double *a, const double *s, double t, int on, double tol) {
+  double v = 0.0;
+  for (int i = 0; i < 3; ++i) {
+    const double p = c[i] + t * a[i];
+    double e = p - clampd(p, -s[i], s[i]);
+    if (i == on) e = 0.0;
+    v += a[i] * e;
+  }
+  return fabs(v) <= tol ? 0.0 : v;
+}
+static double seg_box_param(const double *c, const double *a, double l, const double *s) {
+  double cm = fmax(fabs(c[0]), fmax(fabs(c[1]), fabs(c[2]))), sm = fmax(s[0], fmax(s[1], s[2]));
+  const double tol = 1e-13 * (l + cm + sm);
+  double ts[8], gs[8];
+  int n = 0;
+  ts[n] = -l; gs[n] = seg_box_g(c, a, s, -l, -1, tol); ++n;
+  ts[n] = l; gs[n] = seg_box_g(c, a, s, l, -1, tol); ++n;
+  for (int i = 0; i < 3; ++i)
+    if (fabs(a[i]) >= mjMINVAL)
+      for (int sg = 0; sg < 2; ++sg) {
+        const double e = sg ? s[i] : -s[i], tb = (e - c[i]) / a[i];
+        if (-l < tb && tb < l) { ts[n] = tb; gs[n] = seg_box_g(c, a, s, tb, i, tol); ++n; }
+      }
+  for (int i = 1; i < n; ++i) {                     /* stable insertion sort by t (Python's list.sort is stable) */
+    const double t = ts[i], g = gs[i];
+    int j = i - 1;
+    while (j >= 0 && ts[j] > t) { ts[j + 1] = ts[j]; gs[j + 1] = gs[j]; --j; }
+    ts[j + 1] = t; gs[j + 1] = g;
+  }
+  if (gs[0] > 0.0) return -l;
+  if (gs[n - 1] < 0.0) return l;
+  int lo = 0, hi = n - 1;
+  for (int i = 0; i < n; ++i) if (gs[i] <= 0.0) lo = i;              /* last point with g ≤ 0 */
+  for (int i = n - 1; i >= 0; --i) if (gs[i] >= 0.0) hi = i;         /* first point with g ≥ 0 */
+  const double tL = ts[lo], gL = gs[lo], tR = ts[hi], gR = gs[hi];
+  if (gR - gL > 0.0) return tL + (tR - tL) * (-gL / (gR - gL));
+  return 0.5 * (tL + tR);
+}
+
+static int capsule_box(Con *out, const double *pos1, const double *mat1, const double *size1, const double *pos2,
+                       const double *mat2, const double *size2, double margin) {
+  const double dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]}, ax[3] = {mat1[2], mat1[5], mat1[8]};
+  double c[3], a[3], p[3];
+  matT_vec(c, mat2, dif); matT_vec(a, mat2, ax);
+  const double t = seg_box_param(c, a, size1[1], size2);
+  for (int k = 0; k < 3; ++k) p[k] = c[k] + t * a[k];
+  const int n = ball_box_local(out, p, size1[0], size2, margin);
+  con_to_world(out, n, mat2, pos2);
+  return n;
+}
+
+/* capsule against cylinder: 64 bisection steps on the derivative of the squared distance along the capsule axis, then
+ * ball-against-cylinder (oracle/mjmath.py:738-765) */
+static double cap_cyl_g(const double *c, const double *a, double t, double rad, double half) {
+  const double p[3] = {c[0] + t * a[0], c[1] + t * a[1], c[2] + t * a[2]};
+  const double rho = hypot(p[0], p[1]), sc = rho > rad ? rad / rho : 1.0;
+  const double cl[3] = {p[0] * sc, p[1] * sc, clampd(p[2], -half, half)};
+  return a[0] * (p[0] - cl[0]) + a[1] * (p[1] - cl[1]) + a[2] * (p[2] - cl[2]);
+}
+static int capsule_cylinder(Con *out, const double *pos1, const double *mat1, const double *size1, const double *pos2,
+                            const double *mat2, const double *size2, double margin) {
+  const double dif[3] = {pos1[0] - pos2[0], pos1[1] - pos2[1], pos1[2] - pos2[2]}, ax[3] = {mat1[2], mat1[5], mat1[8]};
+  double c[3], a[3], p[3];
+  matT_vec(c, mat2, dif); matT_vec(a, mat2, ax);
+  const double l = size1[1], rad = size2[0], half = size2[1];
+  double lo = -l, hi = l, t;
+  if (cap_cyl_g(c, a, lo, rad, half) >= 0.0) t = lo;
+  else if (cap_cyl_g(c, a, hi, rad, half) <= 0.0) t = hi;
+  else {
+    for (int it = 0; it < 64; ++it) {
+      const double mid = 0.5 * (lo + hi);
+      if (cap_cyl_g(c, a, mid, rad, half) < 0.0) lo = mid; else hi = mid;
+    }
+    t = hi;
+  }
+  for (int k = 0; k < 3; ++k) p[k] = c[k] + t * a[k];
+  const int n = ball_cylinder_local(out, p, size1[0], rad, half, margin);
+  con_to_world(out, n, mat2, pos2);
+  return n;
+}
+
 /* mj_geomDistance (collision_avoidance_limit.py:219): smallest signed distance, fromto = the connecting segment;
  * returns distmax (fromto zeroed) when nothing is closer.  *err set for a pair type outside the restated set. */
 static double geom_distance(const MkoModel *m, const Work *d, int g1, int g2, double distmax, double *fromto, int *err) {
@@ -732,6 +935,12 @@ static double geom_distance(const MkoModel *m, const Work *d, int g1, int g2, do
   else if (t1 == GEOM_SPHERE && t2 == GEOM_CAPSULE) n = sphere_capsule(cons, p1, s1, p2, R2, s2, distmax);
   else if (t1 == GEOM_PLANE && t2 == GEOM_SPHERE) n = plane_sphere(cons, p1, R1, p2, s2[0], distmax);
   else if (t1 == GEOM_PLANE && t2 == GEOM_CAPSULE) n = plane_capsule(cons, p1, R1, p2, R2, s2, distmax);
+  else if (t1 == GEOM_PLANE && t2 == GEOM_BOX) n = plane_box(cons, p1, R1, p2, R2, s2, distmax);
+  else if (t1 == GEOM_PLANE && t2 == GEOM_CYLINDER) n = plane_cylinder(cons, p1, R1, p2, R2, s2, distmax);
+  else if (t1 == GEOM_SPHERE && t2 == GEOM_BOX) n = sphere_box(cons, p1, s1, p2, R2, s2, distmax);
+  else if (t1 == GEOM_SPHERE && t2 == GEOM_CYLINDER) n = sphere_cylinder(cons, p1, s1, p2, R2, s2, distmax);
+  else if (t1 == GEOM_CAPSULE && t2 == GEOM_BOX) n = capsule_box(cons, p1, R1, s1, p2, R2, s2, distmax);
+  else if (t1 == GEOM_CAPSULE && t2 == GEOM_CYLINDER) n = capsule_cylinder(cons, p1, R1, s1, p2, R2, s2, distmax);
   else { *err = 1; n = 0; }
   for (int k = 0; k < 6; ++k) fromto[k] = 0.0;
   if (!n) return distmax;

@@ -37,7 +37,7 @@ typedef struct {
   const int32_t *geom_bodyid;
   const double *geom_pos, *geom_quat;
   const double *mocap_pos, *mocap_quat;
-  const int32_t *geom_type;     /* mjtGeom: 0 plane, 2 sphere, 3 capsule (the pair types restated here) */
+  const int32_t *geom_type;     /* mjtGeom: 0 plane, 2 sphere, 3 capsule, 5 cylinder, 6 box (the pair types restated here) */
   const double *geom_size;      /* (ngeom, 3) */
 } MkoModel;
 

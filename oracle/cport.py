@@ -97,6 +97,8 @@ def lib():
 
 
 _FRAME_TYPES = {"body": 0, "geom": 1, "site": 2}
+# (mjtGeom pairs, smaller type first, with a routine in oracle/c/mink_oracle.c::geom_distance)
+_C_PAIR_TYPES = {(3, 3), (2, 2), (2, 3), (0, 2), (0, 3), (0, 6), (0, 5), (2, 6), (2, 5), (3, 6), (3, 5)}
 
 
 class CProblem:
@@ -163,8 +165,10 @@ class CProblem:
         gt = np.asarray(model.geom_type)
         for l in col:
             for g1, g2 in l.geom_id_pairs:
-                if not {int(gt[g1]), int(gt[g2])} <= {0, 2, 3} or (int(gt[g1]) == 0 and int(gt[g2]) == 0):
-                    raise TypeError("the C restatement covers plane / sphere / capsule pairs")
+                a, b = sorted((int(gt[g1]), int(gt[g2])))
+                if (a, b) not in _C_PAIR_TYPES:
+                    raise TypeError("the C restatement covers plane / sphere / capsule pairs and box / cylinder against "
+                                    f"plane / sphere / capsule, not geom types ({a}, {b})")
         if cfg and vel and limits.index(cfg[0]) > limits.index(vel[0]):
             raise TypeError("row order: ConfigurationLimit first")
         pr.has_cfg_limit = 1 if cfg else 0

@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 def test_version_and_struct_layout(lib):
     from mink_amd import _native as nat
-    assert lib.mkh_version() == 106
+    assert lib.mkh_version() == 107
     # ctypes mirrors must match the C layout the library was compiled with
     assert ctypes.sizeof(nat.MkhFrameTaskDesc) == 8 + 6 * 8 + 16 + 8
     assert ctypes.sizeof(nat.MkhComTaskDesc) == 3 * 8 + 16

@@ -319,7 +319,7 @@ def test_cold_start_refinement_agrees_with_the_plain_low_rank_start(monkeypatch)
 
 _BENCH_KERNELS = {"ur5e_c2": "ik_quad_kernel", "g1_c3": "ik_solve_kernel_44_32_r44_w3", "g1_full": "ik_solve_kernel_44_36_r44",
                   "shadow_c4": "ik_solve_kernel_48_72+redo_64", "g1_plugin": "ik_solve_kernel_48_256", "h1_c3": "ik_quad_kernel_32",
-                  "h1_full": "ik_quad_kernel_32"}
+                  "h1_full": "ik_quad_kernel_32", "g1_coll": "ik_solve_kernel_64_8+wide", "ur5e_coll": "ik_solve_kernel_16_8"}
 
 
 def _oracle_specs_of_bench(name, model, prob_desc):
@@ -345,6 +345,16 @@ def _oracle_specs_of_bench(name, model, prob_desc):
         return fts + [post], [ik.ConfigurationLimitSpec(), vel], {}
     if name == "g1_c3":
         return feet_palms + [post], [ik.ConfigurationLimitSpec(), vel], {}
+    if name == "g1_coll":       # (the pair list is written out by name in test_g1_coll_pair_list_is_what_the_workload_says)
+        from mink_amd import workloads
+        col = ik.CollisionAvoidanceLimitSpec([tuple(p) for p in workloads.g1_collision_pairs(model)], gain=0.85,
+                                             minimum_distance_from_collisions=0.005, collision_detection_distance=0.25)
+        return feet_palms + [post], [ik.ConfigurationLimitSpec(), vel, col], {}
+    if name == "ur5e_coll":
+        g = lambda n: model.name2id("geom", n)
+        col = ik.CollisionAvoidanceLimitSpec([(g("wrist_3_link"), g("floor")), (g("wrist_3_link"), g("wall"))], collision_detection_distance=0.3)
+        return ([ik.FrameTaskSpec(site("attachment_site"), "site", cost6(1.0, 1.0), z7, lm_damping=1.0)],
+                [ik.ConfigurationLimitSpec(), vel, col], {})
     if name == "g1_full":
         pel = ik.FrameTaskSpec(model.name2id("body", "pelvis"), "body", cost6(0.0, 10.0), z7)
         return [pel] + feet_palms + [post, ik.ComTaskSpec(np.full(3, 200.0), None)], [ik.ConfigurationLimitSpec(), vel], {}
@@ -360,8 +370,22 @@ def _oracle_specs_of_bench(name, model, prob_desc):
     raise KeyError(name)
 
 
-@pytest.mark.parametrize("name", ["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin", "h1_c3", "h1_full"])
-def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name):
+def test_g1_coll_pair_list_is_what_the_workload_says():
+    """`g1_coll`'s 46 pairs by geom TYPE and body side, independent of the list comprehension that builds them."""
+    from mink_amd import workloads
+    model = workloads.load_bench_robot("g1_coll")
+    pairs = workloads.g1_collision_pairs(model)
+    gt, gb = np.asarray(model.geom_type), np.asarray(model.geom_bodyid)
+    kinds = sorted(tuple(sorted((int(gt[a]), int(gt[b])))) for a, b in pairs)
+    from collections import Counter
+    assert Counter(kinds) == Counter({(0, 2): 8, (2, 2): 16, (0, 5): 4, (0, 6): 2, (2, 5): 8, (2, 6): 8}), Counter(kinds)
+    assert len(set(map(tuple, pairs))) == 46
+    for a, b in pairs:                       # no pair inside one body, planes only as the second geom
+        assert gb[a] != gb[b] and gt[a] != 0
+
+
+@pytest.mark.parametrize("name", ["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin", "h1_c3", "h1_full", "g1_coll", "ur5e_coll"])
+def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name, monkeypatch):
     """Exactly what `bench.py --config <name>` times — the same constructors, the same generated batch (per-instance CoM
     targets for the G1 full example, half of the Shadow instances pulled towards `grasp hard`, the caller's rows of the plugin
     workload), the plain call, hence the production kernel — with EVERY instance held against the plain-C restatement of the
@@ -396,6 +420,24 @@ def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name):
     if name == "shadow_c4":          # the regime must exercise the rows: contacts in range on most instances
         G, h = cp.collision_rows(q[0], dt)
         assert np.isfinite(h).sum() >= 5
+    if name == "g1_coll":
+        # the pair of launches the bench times: the wavefront kernel holds 21 rows, the workgroup-per-problem kernel re-solves
+        # what it flags.  How many that is: the same batch on a handle without the redo launch (MKH_DEBUG_NO_WIDE, read per handle)
+        monkeypatch.setenv("MKH_DEBUG_NO_WIDE", "1")
+        alone, _, _ = workloads.bench_config(name, model, nm, B)
+        monkeypatch.delenv("MKH_DEBUG_NO_WIDE")
+        v1, st1 = alone.solve(q, tg, pt, com, dt, damping)
+        assert alone.last_kernel() == "ik_solve_kernel_64_8", alone.last_kernel()
+        flagged = np.flatnonzero(st1 & 16)
+        rows = np.array([np.isfinite(cp.collision_rows(q[i], dt, which=0)[1]).sum() for i in range(0, B, 64)])
+        print("g1_coll: %d of %d instances re-solved with every row by the wide kernel (err on those: %.2e); contacts in range "
+              "per instance: mean %.1f, max %d" % (len(flagged), B, err[flagged].max() if len(flagged) else 0.0, rows.mean(), rows.max()))
+        # (measured: on this batch NO instance is flagged — up to 22 contacts are in range, but never is a dropped one violated at
+        #  the 21-row solution; the second launch of the pair is an empty sweep.  The redo path itself is held at scale by
+        #  tests/test_gpu_wide.py, in a regime with 40+ contacts in range)
+        assert rows.max() > 21
+        ok = np.setdiff1d(np.arange(B), flagged)
+        np.testing.assert_array_equal(v1[ok], v[ok])          # the redo launch touches nothing else
 
 
 def _numpy_oracle_chunk(args):
@@ -441,3 +483,41 @@ def test_ur5e_convex_at_its_bench_batch_against_the_numpy_oracle():
     err = np.abs(v - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
     print("ur5e_convex: all %d instances vs numpy oracle: max rel err %.2e, p99 %.2e" % (B, err.max(), np.percentile(err, 99)))
     assert err.max() < 2e-5
+
+
+def _numpy_h_chunk(args):
+    name, idx, q, dt = args
+    from mink_amd import workloads
+    from oracle import ik
+    model = workloads.load_bench_robot(name)
+    g = lambda n: model.name2id("geom", n)
+    spec = ik.CollisionAvoidanceLimitSpec([(g("wrist_3_link"), g("floor")), (g("wrist_3_link"), g("wall"))], collision_detection_distance=0.3)
+    return np.array([ik.limit_inequalities(ik.Configuration(model, q[i]), spec, dt)[1] for i in idx])
+
+
+def test_ur5e_convex_contact_distances_at_scale():
+    """`ur5e_convex` holds v to 2e-5 because a row of G inherits the accuracy of GJK's witness points; the DISTANCE behind h is
+    good to 1e-13.  h of both pairs (cylinder-plane analytic, cylinder-box through GJK / the expanding polytope) on all 4 096
+    instances of the bench batch against the numpy restatement at 1e-9·max(1, |h|) — which pairs are in range included."""
+    import multiprocessing as mp
+    import os
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+    name = "ur5e_convex"
+    B = workloads.BENCH_CONFIGS[name]["batch"]
+    model = workloads.load_bench_robot(name)
+    nm = nat.NativeModel(model)
+    prob, dt, damping = workloads.bench_config(name, model, nm, B)
+    q, tg, pt, _ = workloads.bench_batch(name, model, nm, prob, np.random.default_rng(2024), B)
+    _, _, taps = prob.solve(q, tg, pt, None, dt, damping, taps=["coll_h"], solve_qp=False)
+    h = taps["coll_h"]
+    ncpu = min(16, os.cpu_count() or 1)
+    chunks = np.array_split(np.arange(B), ncpu * 2)
+    with mp.get_context("fork").Pool(ncpu) as pool:
+        h_ref = np.concatenate(pool.map(_numpy_h_chunk, [(name, c, q, dt) for c in chunks]))
+    np.testing.assert_array_equal(np.isfinite(h), np.isfinite(h_ref))
+    fin = np.isfinite(h_ref)
+    err = np.abs(h[fin] - h_ref[fin]) / np.maximum(1.0, np.abs(h_ref[fin]))
+    pen = int((h_ref[fin] == 0.0).sum())
+    print("ur5e_convex: h of %d contacts in range on %d instances (%d at or inside d_min): max rel err %.2e" % (fin.sum(), B, pen, err.max()))
+    assert fin[:, 1].sum() > B // 8 and err.max() < 1e-9

@@ -114,10 +114,89 @@ def test_c_collision_rows_vs_real_mink_fixture(golden_dir):
     np.testing.assert_array_equal(np.isfinite(h_c), np.isfinite(h_np))
     np.testing.assert_allclose(G_c, G_np, rtol=0, atol=1e-13)
     np.testing.assert_allclose(h_c[np.isfinite(h_c)], h_np[np.isfinite(h_np)], rtol=0, atol=1e-12)
-    with pytest.raises(TypeError):          # a box: outside the restated pair set, refused at construction
+    with pytest.raises(TypeError):          # box against box: outside the restated pair set, refused at construction
         mu, _, _, _, _ = oc.ur5e_c2([np.zeros(7)], np.zeros(6))
         box = [g for g in range(mu.ngeom) if int(mu.geom_type[g]) == 6]
-        cport.CProblem(mu, [], [ik.CollisionAvoidanceLimitSpec([(box[0], 0)])])
+        cport.CProblem(mu, [], [ik.CollisionAvoidanceLimitSpec([(box[0], box[0])])])
+
+
+def _geom_soup(rng, n_each=3):
+    """A model whose bodies are free-floating geoms of every type the C restatement knows: one plane on the world, then
+    spheres, capsules, cylinders and boxes on free bodies (random sizes)."""
+    from mink_amd import mjcf
+    parts, names = ['<geom name="floor" type="plane" size="0 0 0.01"/>'], ["floor"]
+    k = 0
+    for ty, mk in (("sphere", lambda: "%.3f" % rng.uniform(0.02, 0.1)),
+                   ("capsule", lambda: "%.3f %.3f" % (rng.uniform(0.02, 0.06), rng.uniform(0.05, 0.2))),
+                   ("cylinder", lambda: "%.3f %.3f" % (rng.uniform(0.03, 0.1), rng.uniform(0.03, 0.2))),
+                   ("box", lambda: "%.3f %.3f %.3f" % tuple(rng.uniform(0.03, 0.15, size=3)))):
+        for _ in range(n_each):
+            nm = "%s%d" % (ty, k); k += 1
+            parts.append('<body name="b_%s"><freejoint/><inertial pos="0 0 0" mass="1" diaginertia="1 1 1"/>'
+                         '<geom name="%s" type="%s" size="%s"/></body>' % (nm, nm, ty, mk()))
+            names.append(nm)
+    return mjcf.loads_mjcf("<mujoco><worldbody>" + "".join(parts) + "</worldbody></mujoco>"), names
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_c_box_and_cylinder_pairs_equal_the_numpy_restatement(seed):
+    """Round 5: box against plane / sphere / capsule and cylinder against plane / sphere / capsule in the C restatement
+    (what `g1_coll` and `ur5e_coll` need on every instance of their bench batch) — rows G, h of every such pair of a soup of
+    free-floating geoms at random poses, separated AND penetrating, against oracle/mjmath.py's routines (which
+    tests/test_oracle_collision_shapes.py holds against brute force)."""
+    rng = np.random.default_rng(100 + seed)
+    m, names = _geom_soup(rng)
+    gt = np.asarray(m.geom_type)
+    ok = cport._C_PAIR_TYPES
+    pairs = [(a, b) for a in range(m.ngeom) for b in range(a + 1, m.ngeom)
+             if tuple(sorted((int(gt[a]), int(gt[b])))) in ok]
+    assert {tuple(sorted((int(gt[a]), int(gt[b])))) for a, b in pairs} == ok
+    spec = ik.CollisionAvoidanceLimitSpec(pairs, collision_detection_distance=0.6, minimum_distance_from_collisions=0.01)
+    prob = cport.CProblem(m, [], [spec])
+    worst_G = worst_h = 0.0
+    n_pen = n_act = 0
+    for _ in range(6):
+        q = np.array(m.qpos0, dtype=np.float64)
+        for j in range(m.njnt):
+            a = int(m.jnt_qposadr[j])
+            q[a:a + 3] = rng.normal(scale=0.25, size=3) + [0, 0, 0.15]
+            w = rng.normal(size=4); q[a + 3:a + 7] = w / np.linalg.norm(w)
+        cfg = ik.Configuration(m, q)
+        G_np, h_np = ik.limit_inequalities(cfg, spec, 0.01)
+        G_c, h_c = prob.collision_rows(q, 0.01)
+        np.testing.assert_array_equal(np.isfinite(h_c), np.isfinite(h_np))
+        fin = np.isfinite(h_np)
+        n_act += int(fin.sum()); n_pen += int((h_np[fin] == 0.0).sum())
+        worst_h = max(worst_h, np.abs(h_c[fin] - h_np[fin]).max())
+        worst_G = max(worst_G, np.abs(G_c - G_np).max())
+    assert n_act > 50 and n_pen > 5, (n_act, n_pen)
+    assert worst_h < 1e-11 and worst_G < 1e-12, (worst_h, worst_G)
+
+
+def test_c_oracle_solves_g1_with_its_primitive_collision_pairs():
+    """`g1_coll` (46 analytic pairs incl. cylinders and boxes, all rows stacked as the reference does: solve_ik.py:25-40):
+    the C restatement against the numpy one on a few instances of the bench distribution."""
+    from mink_amd import workloads
+    m = workloads.load_bench_robot("g1_coll")
+    pairs = workloads.g1_collision_pairs(m)
+    stand = m.key_qpos[m.name2id("key", "stand")]
+    rng = np.random.default_rng(5)
+    q = workloads.sample_q(m, rng, 6, stand)
+    tg = np.zeros((6, 4, 7)); tg[:, :, 0] = 1.0
+    for i in range(6):
+        cfg = ik.Configuration(m, workloads.sample_q(m, rng, 1, stand)[0])
+        for k, s in enumerate(("left_foot", "right_foot", "left_palm", "right_palm")):
+            tg[i, k] = cfg.get_transform_frame_to_world(m.name2id("site", s), "site")
+    col = ik.CollisionAvoidanceLimitSpec([tuple(p) for p in pairs], gain=0.85, minimum_distance_from_collisions=0.005,
+                                         collision_detection_distance=0.25)
+    _, tasks, limits, dt, damping = oc.g1_c3(tg[0], stand)
+    prob = cport.CProblem(m, tasks, limits + [col])
+    v, st = prob.solve_batch(q, tg, stand[None, :], dt, damping)
+    assert (st == 0).all()
+    for i in range(6):
+        _, t_i, _, _, _ = oc.g1_c3(tg[i], stand)
+        v_ref = ik.solve_ik(m, q[i], t_i, dt, damping, limits + [col])
+        np.testing.assert_allclose(v[i], v_ref, rtol=0, atol=1e-9 * max(1.0, np.abs(v_ref).max()))
 
 
 def test_c_batched_com_targets(golden_dir):
