@@ -1329,7 +1329,10 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
     snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_wide_kernel");
     p->last_grid = p->wide_grid < a.B ? p->wide_grid : a.B; p->last_lds = p->wide_lds; p->last_nt = p->wide.nv + p->wide.max_rows;
     p->last_block = kWideThreads;
-    return launch_wide_kernel(p, a, stream, 0, dt_);
+    HIP_OK(clk_begin(p, a, stream));                         // (MKH_DEBUG_CLOCKS=<file>: phase stamps of every problem, tools/wide_phase_clocks.py)
+    const int32_t rcw = launch_wide_kernel(p, a, stream, 0, dt_);
+    if (rcw == MKH_OK) HIP_OK(clk_end(p, a.B, stream));
+    return rcw;
   }
   // A problem whose rows can outnumber the tableau's: the flagged instances once more, with every row — plain solves, calls
   // with taps (the workgroup-per-problem kernel writes every tap but the cycle counters) and, round 5, the fused loops: an

@@ -81,7 +81,258 @@ __device__ __forceinline__ void wide_frame_column(const double* o, const double*
 // index states of the active-set iteration (tools/proto_tableau_qp.py)
 enum { WS_FREE = 0, WS_AT_LO = 1, WS_AT_HI = 2, WS_ROW_OFF = 3, WS_ROW_ON = 4, WS_ZERO = 5 };
 
-__global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem* __restrict__ Pg, SolveArgs A, const TapArgs* __restrict__ tp) {
+typedef __attribute__((address_space(3))) double lds_f64;
+
+// T[i][j] += α·u[i]·u[j] (kTwo: + β·v[i]·v[j]) on the leading n × n block of the row-major tableau (row stride N): THE inner loop of
+// this kernel — a sweep is one such update with the row / column fix-up folded in, H is accumulated by them.  Each wavefront takes
+// every fourth row, lanes take columns (consecutive addresses: no bank conflicts), eight rows per trip so that sixteen LDS reads
+// are in flight; u[i]·u[j] is formed before α enters, so the update is bitwise symmetric and a tableau column can be read as
+// a row.  kfix ≥ 0 (a sweep on index kfix, α = −1/d): row and column kfix get ±u/d (`sgi`) and the diagonal entry −1/d in the
+// same pass — every entry has one owner (wave = row mod 4, lane = column mod 64), so no barrier separates update and fix-up.
+// (Round 4 walked the flat index with an integer division per element and one dependent LDS round trip after the other:
+//  12.6 k cycles per 75 x 75 sweep.)
+template <bool kTwo, class TP>
+__device__ __forceinline__ void wide_rank1(TP* Tp, int n, int N, const lds_f64* u, double alpha, const lds_f64* v2, double beta,
+                                           int kfix, double sgi, int wave, int lane) {
+  constexpr int NW = kWideThreads / 64, RB = 8;
+  for (int jb = 0; jb < n; jb += 64) {
+    const int j = jb + lane;
+    if (j >= n) continue;
+    const bool colk = j == kfix;
+    const double uj = u[j], vj = kTwo ? v2[j] : 0.0;
+    TP* const c = Tp + j;
+    int i = wave;
+    for (; i + (RB - 1) * NW < n; i += RB * NW) {
+      double t[RB], ui[RB], vi[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        t[r] = c[(size_t)(i + r * NW) * N];
+        ui[r] = u[i + r * NW];
+        vi[r] = kTwo ? v2[i + r * NW] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        double x = fma(ui[r] * uj, alpha, t[r]);
+        if (kTwo) x = fma(vi[r] * vj, beta, x);
+        if (!kTwo) x = colk ? sgi * ui[r] : x;
+        c[(size_t)(i + r * NW) * N] = x;
+      }
+    }
+    // the rest of this wave's rows, all requested at once (≤ RB − 1 of them)
+    {
+      double t[RB - 1], ui[RB - 1], vi[RB - 1];
+#pragma unroll
+      for (int r = 0; r < RB - 1; ++r) {
+        const bool in = i + r * NW < n;
+        t[r] = in ? c[(size_t)(i + r * NW) * N] : 0.0;
+        ui[r] = in ? u[i + r * NW] : 0.0;
+        vi[r] = (kTwo && in) ? v2[i + r * NW] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < RB - 1; ++r) {
+        double x = fma(ui[r] * uj, alpha, t[r]);
+        if (kTwo) x = fma(vi[r] * vj, beta, x);
+        if (!kTwo) x = colk ? sgi * ui[r] : x;
+        if (i + r * NW < n) c[(size_t)(i + r * NW) * N] = x;
+      }
+    }
+    // row kfix, by the wave that owns it (its lanes wrote these entries above: program order, no barrier)
+    if (!kTwo && kfix >= 0 && wave == (kfix & (NW - 1))) c[(size_t)kfix * N] = colk ? alpha : sgi * uj;
+  }
+}
+
+// What the tableau phases need of the kernel's state: a REAL call (noinline) — the kernel around them carries the inlined distance
+// routines and sits at its register ceiling (256 VGPRs, 470 spilled SGPRs); as callees the two hot loops get a register allocation of
+// their own (round 5: the same inner loop compiled inline took 11 k cycles per sweep, spilling scalars inside it).
+struct WideQpCtx {
+  double* T;                    // tableau (LDS or the workgroup's slice of device memory)
+  int in_lds, N, nv;
+  int o_z, o_w, o_lo, o_hi, o_rown, o_ref, o_col, o_red, o_state;      // LDS offsets (doubles)
+};
+
+// H = λI + Σ JwᵀJw (+ the posture tasks' diagonal, added by the caller): two weighted Jacobian rows per pass, staged in LDS (sCol,
+// sRef — both free until the QP), T += u·uᵀ + v·vᵀ  (round 4: every entry walked all rows of Jw in device memory — 185 k cycles
+// on the G1 with two hands, an eighth of the solve).  The next pair of rows is requested before the current update runs.
+__device__ __attribute__((noinline)) void wide_accumulate_h(WideQpCtx X, const double* Jw, int R_all) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, N = X.N, nv = X.nv;
+  lds_f64* const sCol = (lds_f64*)(smem + X.o_col);
+  lds_f64* const sRef = (lds_f64*)(smem + X.o_ref);
+  double* const T = X.T;
+  for (int e = tid; e < N * N; e += kWideThreads) T[e] = 0.0;
+  // (rows of nv ≤ 4·256 doubles: up to four entries of each of the two rows per thread)
+  double a0[4], a1[4];
+  auto fetch = [&](int r) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = tid + c * kWideThreads;
+      a0[c] = (k < nv && r < R_all) ? Jw[(size_t)r * nv + k] : 0.0;
+      a1[c] = (k < nv && r + 1 < R_all) ? Jw[(size_t)(r + 1) * nv + k] : 0.0;
+    }
+  };
+  fetch(0);
+  for (int r = 0; r < R_all; r += 2) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int k = tid + c * kWideThreads;
+      if (k < nv) { sCol[k] = a0[c]; sRef[k] = a1[c]; }
+    }
+    __syncthreads();
+    fetch(r + 2);
+    if (X.in_lds) wide_rank1<true>((lds_f64*)T, nv, N, sCol, 1.0, sRef, 1.0, -1, 0.0, wave, lane);
+    else wide_rank1<true>(T, nv, N, sCol, 1.0, sRef, 1.0, -1, 0.0, wave, lane);
+  }
+  __syncthreads();
+}
+
+
+struct WideQpOut { int status, iters, n_outer, n_piv; };
+
+// The QP of one problem: dual active set (Goldfarb–Idnani) on the symmetric sweep tableau K = [[H, Aᵀ],[A, 0]] (tools/proto_tableau_qp.py),
+// N = nv + rows.  One pivot = stage column p (barrier), the step on z / w by the owners of the indices, the sweep (rank-1 update
+// with the row / column fix-up folded in), barrier: two barriers (round 4: seven, and a second pass over row and column).
+__device__ __attribute__((noinline)) WideQpOut wide_qp(WideQpCtx X, long long* clk) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, N = X.N, nv = X.nv;
+  constexpr int NT_ = kWideThreads;
+  const double kInf = __builtin_huge_val();
+  lds_f64* const sZ = (lds_f64*)(smem + X.o_z);
+  lds_f64* const sW = (lds_f64*)(smem + X.o_w);
+  const lds_f64* const sLo = (const lds_f64*)(smem + X.o_lo);
+  const lds_f64* const sHi = (const lds_f64*)(smem + X.o_hi);
+  const lds_f64* const sRown = (const lds_f64*)(smem + X.o_rown);
+  lds_f64* const sRef = (lds_f64*)(smem + X.o_ref);
+  lds_f64* const sCol = (lds_f64*)(smem + X.o_col);
+  lds_f64* const sRed = (lds_f64*)(smem + X.o_red);
+  typedef __attribute__((address_space(3))) int lds_i32;
+  lds_i32* const sRedI = (lds_i32*)(smem + X.o_red + NT_);
+  lds_i32* const sState = (lds_i32*)(smem + X.o_state);
+  double* const T = X.T;
+  int status = 0;
+  // arg-max / arg-min over the candidates of all threads: largest (smallest) value, lowest index on ties; idx −1 when none.
+  // One DPP reduction per wavefront, then four entries through LDS (round 4: a 256-wide tree with nine barriers).
+  auto block_arg = [&](double val, int idx, bool want_max, double& best, int& besti) {
+    const double key = idx < 0 ? -kInf : (want_max ? val : -val);       // (arg-min = arg-max of the negated values)
+    const double mk = wave_max(key);
+    const unsigned cand = (idx >= 0 && key == mk) ? (unsigned)idx : 0xffffffffu;
+    const unsigned mi = wave_min_u32(cand);
+    __syncthreads();
+    if (lane == 0) { sRed[wave] = mk; sRedI[wave] = (int)mi; }
+    __syncthreads();
+    double b = -kInf; int bi = -1;
+#pragma unroll
+    for (int w = 0; w < NT_ / 64; ++w) {
+      const double kw = sRed[w]; const int iw = sRedI[w];
+      if (iw >= 0 && (bi < 0 || kw > b || (kw == b && iw < bi))) { b = kw; bi = iw; }
+    }
+    best = want_max ? b : -b; besti = bi;
+    __syncthreads();
+  };
+  auto take_column = [&](int p) {                          // (the tableau is bitwise symmetric: column p = row p, consecutive addresses)
+    for (int i = tid; i < N; i += NT_) sCol[i] = T[(size_t)p * N + i];
+    __syncthreads();
+  };
+  // step(p, α): z −= α·τ on the basic indices, w += α·τ on the others (τ = column p); p itself: w_p += α when basic, z_p += α when not
+  auto take_step = [&](int p, double alpha, bool p_basic) {     // (sCol holds column p; every index is updated by its owner thread)
+    for (int i = tid; i < N; i += NT_) {
+      const int st = sState[i];
+      if (st == WS_FREE || st == WS_ROW_ON) sZ[i] -= alpha * sCol[i]; else sW[i] += alpha * sCol[i];
+      if (i == p) { if (p_basic) sW[p] += alpha; else sZ[p] += alpha; }
+    }
+  };
+  auto sweep = [&](int k, bool reverse) {                  // (sCol holds column k)
+    const double d = sCol[k], inv = 1.0 / d, sgi = reverse ? -inv : inv;
+    if (X.in_lds) wide_rank1<false>((lds_f64*)T, N, N, sCol, -inv, sCol, 0.0, k, sgi, wave, lane);
+    else wide_rank1<false>(T, N, N, sCol, -inv, sCol, 0.0, k, sgi, wave, lane);
+    __syncthreads();
+  };
+  int iters = 0, n_outer = 0, n_piv = 0;
+  const int max_iters = 20 * (N + 4);
+  // phase 0: bring every dof into the basis (x0 = −H⁻¹c), no ratio tests
+  for (int k = 0; k < nv; ++k) {
+    const double wk = sW[k];
+    take_column(k);
+    const double d = sCol[k];
+    if (!(d > 0.0)) { status |= 4; break; }
+    take_step(k, -wk / d, false);
+    if (tid == (k & (NT_ - 1))) { sW[k] = 0.0; sState[k] = WS_FREE; }      // (k's owner, behind its own step)
+    sweep(k, false);
+  }
+  __syncthreads();
+  for (int i = tid; i < N; i += NT_) { const double r = fabs(T[(size_t)i * N + i]); sRef[i] = r == 0.0 ? 1.0 : r; }
+  __syncthreads();
+  if (clk && tid == 0) clk[10] = (long long)__builtin_readcyclecounter();
+  while (!(status & 14)) {
+    // most violated primal condition among basic dofs / inactive rows
+    double bv = 0.0; int bi = -1;
+    for (int i = tid; i < N; i += NT_) {
+      double v = -kInf;
+      if (sState[i] == WS_FREE) v = fmax(sZ[i] - sHi[i], sLo[i] - sZ[i]);
+      else if (sState[i] == WS_ROW_OFF) v = sW[i] / sRown[i];
+      if (v > 1e-12 && (bi < 0 || v > bv)) { bv = v; bi = i; }
+    }
+    double pv; int p;
+    block_arg(bv, bi, true, pv, p);
+    if (p < 0) break;                                    // optimal
+    ++n_outer;
+    const bool p_basic = sState[p] == WS_FREE;
+    const bool upper = p_basic && (sZ[p] - sHi[p] > sLo[p] - sZ[p]);
+    const double beta = p_basic ? (upper ? sHi[p] : sLo[p]) : 0.0;
+    const double sgn = p_basic ? (upper ? -1.0 : 1.0) : 1.0;
+    for (;;) {
+      if (++iters > max_iters) { status |= 8; break; }
+      take_column(p);
+      const double tpp = sCol[p];
+      double full = kInf;
+      if (p_basic) { if (fabs(tpp) > 1e-12 * sRef[p]) full = (sZ[p] - beta) / tpp; }
+      else if (-tpp > 1e-12 * sRef[p]) full = -sW[p] / tpp;
+      const double t2 = fabs(full);
+      // ratio test on dual feasibility, α = sgn·t, t ≥ 0
+      double t1v = kInf; int t1i = -1;
+      for (int i = tid; i < N; i += NT_) {
+        if (i == p) continue;
+        const double r = sgn * sCol[i];
+        const int st = sState[i];
+        double t = kInf;
+        if (st == WS_ROW_ON) { if (r > 0.0) t = sZ[i] / r; }
+        else if (st == WS_AT_HI) { if (r > 0.0) t = -sW[i] / r; }
+        else if (st == WS_AT_LO) { if (r < 0.0) t = sW[i] / -r; }
+        if (t < kInf && (t1i < 0 || t < t1v)) { t1v = t; t1i = i; }
+      }
+      double t1; int l;
+      block_arg(t1v, t1i, false, t1, l);
+      if (l < 0) t1 = kInf;
+      if (!(fmin(t1, t2) < kInf)) { status |= 2; break; }            // no step possible: infeasible
+      if (t2 <= t1) {
+        take_step(p, sgn * t2, p_basic);
+        if (tid == (p & (NT_ - 1))) {
+          if (p_basic) { sZ[p] = beta; sState[p] = upper ? WS_AT_HI : WS_AT_LO; }
+          else { sW[p] = 0.0; sState[p] = WS_ROW_ON; }
+        }
+        sweep(p, p_basic);
+        ++n_piv;
+        break;
+      }
+      const bool l_row = sState[l] == WS_ROW_ON;
+      __syncthreads();                                   // (every thread has read l's state)
+      take_step(p, sgn * t1, p_basic);
+      if (tid == (l & (NT_ - 1))) {
+        if (l_row) { sZ[l] = 0.0; sState[l] = WS_ROW_OFF; }
+        else { sW[l] = 0.0; sState[l] = WS_FREE; }
+      }
+      __syncthreads();                                   // (column p is consumed: sCol is staged again)
+      take_column(l);
+      sweep(l, l_row);
+      ++n_piv;
+    }
+  }
+  return WideQpOut{status, iters, n_outer, n_piv};
+}
+
+// (two workgroups per CU: every phase of this kernel is latency-bound — one wavefront per SIMD waits out each LDS round trip and
+//  barrier alone — so the second resident workgroup is worth more than the registers it costs)
+__global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProblem* __restrict__ Pg, SolveArgs A, const TapArgs* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const WideProblem& P = *Pg;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, NT_ = kWideThreads;
@@ -117,6 +368,10 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
   // parity taps (mkh_eval): body poses, frame poses, subtree CoM, H, c, the box, the contact rows — what the reference's
   // Configuration / build_ik expose; the per-task (e, J) taps are the wavefront kernels'
 #define MKH_WTAP(f) (tp ? tp->f : nullptr)
+  // phase stamps (SolveArgs::clk, MKH_DEBUG_CLOCKS=<file>: tools/wide_phase_clocks.py): slot k of row pb = shader clock at phase
+  // boundary k of the problem's LAST step — 0 start, 1 FK, 2 dof axes / CoM, 3 task lanes, 4 posture / LM, 5 Jacobian rows, 6 c / box,
+  // 7 contacts, 8 rows selected, 9 tableau built, 10 phase 0 done, 11 active set done, 12 end
+#define MKH_WSTAMP(k) do { if (A.clk && tid == 0) A.clk[(size_t)pb * 24 + (k)] = (long long)__builtin_readcyclecounter(); } while (0)
 
   auto block_sum = [&](double x) -> double {
     x = wave_sum(x);
@@ -125,24 +380,6 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
     __syncthreads();
     return (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
   };
-  // arg-max / arg-min over the candidates of all threads: largest (smallest) value, lowest index on ties; idx −1 when none
-  auto block_arg = [&](double val, int idx, bool want_max, double& best, int& besti) {
-    __syncthreads();
-    sRed[tid] = val; sRedI[tid] = idx;
-    __syncthreads();
-    for (int s = NT_ / 2; s > 0; s >>= 1) {
-      if (tid < s) {
-        const double a = sRed[tid], b = sRed[tid + s];
-        const int ia = sRedI[tid], ib = sRedI[tid + s];
-        const bool take_b = ib >= 0 && (ia < 0 || (want_max ? b > a : b < a) || (b == a && ib < ia));
-        if (take_b) { sRed[tid] = b; sRedI[tid] = ib; }
-      }
-      __syncthreads();
-    }
-    best = sRed[0]; besti = sRedI[0];
-    __syncthreads();
-  };
-
   for (int pb = (int)blockIdx.x; pb < A.B; pb += (int)gridDim.x) {
     if (A.redo_mask && !(A.status_out[pb] & A.redo_mask)) continue;          // (wave-uniform: the whole workgroup skips)
     __syncthreads();
@@ -159,6 +396,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
     int status_all = 0, it_done = 0, conv_flag = 0;
     for (int step = 0; step < n_steps + (until ? 1 : 0); ++step) {
     int status = 0;
+    MKH_WSTAMP(0);
     // ------------------------------------------------------------ FK, level by level (mj_kinematics)
     for (int lv = 0; lv < P.nlevels; ++lv) {
       for (int idx = P.level_start[lv] + tid; idx < P.level_start[lv + 1]; idx += NT_) {
@@ -203,6 +441,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       for (int e = tid; e < nbody * 3; e += NT_) MKH_WTAP(t_xpos)[(size_t)pb * nbody * 3 + e] = sX[(e % 3) * XS + e / 3];
     if (MKH_WTAP(t_xquat))
       for (int e = tid; e < nbody * 4; e += NT_) MKH_WTAP(t_xquat)[(size_t)pb * nbody * 4 + e] = sX[(3 + e % 4) * XS + e / 4];
+    MKH_WSTAMP(1);
     // ------------------------------------------------------------ dof axes (cdof): jacp(p) = lin + ang × (p − anchor), jacr = ang
     bool viol = false;
     for (int d = tid; d < nv; d += NT_) {
@@ -247,6 +486,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       }
       __syncthreads();
     }
+    MKH_WSTAMP(2);
     // ------------------------------------------------------------ frame tasks: pose, error, jlog (the task lanes of ik_kernel.h)
     double mu_part = 0.0;                                  // Levenberg–Marquardt terms owned by this thread
     bool conv_mine = true;                                 // this thread's frame tasks are within the thresholds (rows with a nonzero cost only)
@@ -347,6 +587,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
         }
         mu_part += P.dense_lm[t] * ss;
       }
+    MKH_WSTAMP(3);
     // ------------------------------------------------------------ posture tasks (diagonal; posture_task.py:87-142)
     for (int d = tid; d < nv; d += NT_) { sC[d] = 0.0; sHd[d] = 0.0; }
     __syncthreads();
@@ -374,6 +615,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       if (P.posture_lm[t] != 0.0) { const double s = block_sum(ssw); if (tid == 0) mu_part += P.posture_lm[t] * s; }
     }
     const double mu_total = A.damping + block_sum(mu_part);  // solve_ik.py:16 + Σ μ_t
+    MKH_WSTAMP(4);
     // ------------------------------------------------------------ weighted Jacobian rows Jw[r][k] (weighted_jacobian, task.py:129)
     for (int e = tid; e < P.n_frame * nv; e += NT_) {
       const int t = e / nv, k = e - t * nv;
@@ -414,6 +656,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       if (MKH_WTAP(t_task_J)) MKH_WTAP(t_task_J)[((size_t)pb * P.n_rows_tap + P.dense_tap_row0 + r) * nv + k] = jr;
     }
     __syncthreads();
+    MKH_WSTAMP(5);
     // c = −weighted_errorᵀ·weighted_jacobian (task.py:133-134)
     for (int k = tid; k < nv; k += NT_) {
       double c = sC[k];
@@ -455,6 +698,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       box_bad = box_bad || lo > hi + 1e-12;
     }
     if (__syncthreads_or(box_bad ? 1 : 0)) status |= 2;              // inconsistent box ⇒ quadprog "constraints are inconsistent"
+    MKH_WSTAMP(6);
     // ------------------------------------------------------------ contacts (collision_avoidance_limit.py:187-229): every one a row
     // each wavefront takes kGjkSlots pairs per trip (GJK keeps its simplex in the wave's LDS workspace)
     for (int base = 0; base < P.n_pairs; base += 4 * kGjkSlots) {
@@ -505,6 +749,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       }
     }
     __syncthreads();
+    MKH_WSTAMP(7);
     // Rows: the detected contacts in pair order, then the caller's rows with a finite bound.  More contacts in range than the
     // workspace has rows (kWideMaxRows): the rule of the wavefront kernels (collision_phase) — the max_rows TIGHTEST (smallest
     // h, ties by pair index) become rows, the rest are checked at the solution below; a dropped one that holds there was
@@ -536,15 +781,14 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
     if (sRedI[1]) status |= 16;
     const int N = nv + m;
     __syncthreads();
+    MKH_WSTAMP(8);
     // ------------------------------------------------------------ tableau K = [[H, Aᵀ],[A, 0]], z, w, states
-    for (int e = tid; e < nv * nv; e += NT_) {               // H = λI + Σ JwᵀJw (+ the posture tasks' diagonal)
-      const int i = e / nv, j = e - i * nv;
-      if (j < i) continue;
-      double s = 0.0;
-      for (int r = 0; r < R_all; ++r) s += Jw[(size_t)r * nv + i] * Jw[(size_t)r * nv + j];
-      if (i == j) s += mu_total + sHd[i];
-      T[(size_t)i * N + j] = s; T[(size_t)j * N + i] = s;
-    }
+    WideQpCtx X;
+    X.T = T; X.in_lds = P.tableau_in_lds; X.N = N; X.nv = nv;
+    X.o_z = P.o_z; X.o_w = P.o_w; X.o_lo = P.o_lo; X.o_hi = P.o_hi; X.o_rown = P.o_rown; X.o_ref = P.o_ref; X.o_col = P.o_col;
+    X.o_red = P.o_red; X.o_state = P.o_state;
+    wide_accumulate_h(X, Jw, R_all);
+    for (int d = tid; d < nv; d += NT_) T[(size_t)d * N + d] += mu_total + sHd[d];
     for (int e = tid; e < m * nv; e += NT_) {                // A: G[s][k] = −nᵀ(jacp₂(to) − jacp₁(from))   (compute_contact_normal_jacobian :59-72)
       const int s = e / nv, k = e - s * nv;
       const int rp = rowpair[s];
@@ -563,7 +807,6 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       }
       T[(size_t)(nv + s) * N + k] = a; T[(size_t)k * N + nv + s] = a;
     }
-    for (int e = tid; e < m * m; e += NT_) T[(size_t)(nv + e / m) * N + nv + e % m] = 0.0;
     for (int i = tid; i < N; i += NT_) {
       sZ[i] = 0.0;
       if (i < nv) { sW[i] = sC[i]; sState[i] = WS_ZERO; sRown[i] = 1.0; }
@@ -591,114 +834,15 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
         }
       __syncthreads();
     }
-    // ------------------------------------------------------------ the QP: dual active set on the sweep tableau
-    // step(p, α): z −= α·τ on the basic indices, w += α·τ on the others (τ = column p); p itself: w_p += α when basic, z_p += α when not
-    auto take_column = [&](int p) {
-      for (int i = tid; i < N; i += NT_) sCol[i] = T[(size_t)i * N + p];
-      __syncthreads();
-    };
-    auto take_step = [&](int p, double alpha, bool p_basic) {     // (sCol holds column p)
-      for (int i = tid; i < N; i += NT_) {
-        const int st = sState[i];
-        if (st == WS_FREE || st == WS_ROW_ON) sZ[i] -= alpha * sCol[i]; else sW[i] += alpha * sCol[i];
-      }
-      __syncthreads();
-      if (tid == 0) { if (p_basic) sW[p] += alpha; else sZ[p] += alpha; }
-      __syncthreads();
-    };
-    auto sweep = [&](int k, bool reverse) {                  // (sCol holds column k)
-      const double d = sCol[k], inv = 1.0 / d, sg = reverse ? -1.0 : 1.0;
-      for (int e = tid; e < N * N; e += NT_) {
-        const int i = e / N, j = e - i * N;
-        double v;
-        if (i == k && j == k) v = -inv;
-        else if (i == k) v = sg * sCol[j] * inv;
-        else if (j == k) v = sg * sCol[i] * inv;
-        else v = T[e] - sCol[i] * sCol[j] * inv;
-        T[e] = v;
-      }
-      __syncthreads();
-    };
+    MKH_WSTAMP(9);
+    // ------------------------------------------------------------ the QP: dual active set on the sweep tableau (wide_qp)
     int iters = 0, n_outer = 0, n_piv = 0;                  // (qp_iters tap: ratio-test rounds, violated conditions handled, sweeps after phase 0)
-    const int max_iters = 20 * (N + 4);
     if (!(status & 14) && A.do_qp) {
-      // phase 0: bring every dof into the basis (x0 = −H⁻¹c), no ratio tests
-      for (int k = 0; k < nv; ++k) {
-        take_column(k);
-        const double d = sCol[k];
-        if (!(d > 0.0)) { status |= 4; break; }
-        const double wk = sW[k];
-        __syncthreads();
-        take_step(k, -wk / d, false);
-        if (tid == 0) { sW[k] = 0.0; sState[k] = WS_FREE; }
-        sweep(k, false);
-      }
-      for (int i = tid; i < N; i += NT_) { const double r = fabs(T[(size_t)i * N + i]); sRef[i] = r == 0.0 ? 1.0 : r; }
-      __syncthreads();
-      while (!(status & 14)) {
-        // most violated primal condition among basic dofs / inactive rows
-        double bv = 0.0; int bi = -1;
-        for (int i = tid; i < N; i += NT_) {
-          double v = -kInf;
-          if (sState[i] == WS_FREE) v = fmax(sZ[i] - sHi[i], sLo[i] - sZ[i]);
-          else if (sState[i] == WS_ROW_OFF) v = sW[i] / sRown[i];
-          if (v > 1e-12 && (bi < 0 || v > bv)) { bv = v; bi = i; }
-        }
-        double pv; int p;
-        block_arg(bv, bi, true, pv, p);
-        if (p < 0) break;                                    // optimal
-        ++n_outer;
-        const bool p_basic = sState[p] == WS_FREE;
-        const bool upper = p_basic && (sZ[p] - sHi[p] > sLo[p] - sZ[p]);
-        const double beta = p_basic ? (upper ? sHi[p] : sLo[p]) : 0.0;
-        const double sgn = p_basic ? (upper ? -1.0 : 1.0) : 1.0;
-        for (;;) {
-          if (++iters > max_iters) { status |= 8; break; }
-          take_column(p);
-          const double tpp = sCol[p];
-          double full = kInf;
-          if (p_basic) { if (fabs(tpp) > 1e-12 * sRef[p]) full = (sZ[p] - beta) / tpp; }
-          else if (-tpp > 1e-12 * sRef[p]) full = -sW[p] / tpp;
-          const double t2 = fabs(full);
-          // ratio test on dual feasibility, α = sgn·t, t ≥ 0
-          double t1v = kInf; int t1i = -1;
-          for (int i = tid; i < N; i += NT_) {
-            if (i == p) continue;
-            const double r = sgn * sCol[i];
-            const int st = sState[i];
-            double t = kInf;
-            if (st == WS_ROW_ON) { if (r > 0.0) t = sZ[i] / r; }
-            else if (st == WS_AT_HI) { if (r > 0.0) t = -sW[i] / r; }
-            else if (st == WS_AT_LO) { if (r < 0.0) t = sW[i] / -r; }
-            if (t < kInf && (t1i < 0 || t < t1v)) { t1v = t; t1i = i; }
-          }
-          double t1; int l;
-          block_arg(t1v, t1i, false, t1, l);
-          if (l < 0) t1 = kInf;
-          if (!(fmin(t1, t2) < kInf)) { status |= 2; break; }            // no step possible: infeasible
-          if (t2 <= t1) {
-            take_step(p, sgn * t2, p_basic);
-            if (tid == 0) {
-              if (p_basic) { sZ[p] = beta; sState[p] = upper ? WS_AT_HI : WS_AT_LO; }
-              else { sW[p] = 0.0; sState[p] = WS_ROW_ON; }
-            }
-            sweep(p, p_basic);
-            ++n_piv;
-            break;
-          }
-          take_step(p, sgn * t1, p_basic);
-          const bool l_row = sState[l] == WS_ROW_ON;
-          __syncthreads();
-          if (tid == 0) {
-            if (l_row) { sZ[l] = 0.0; sState[l] = WS_ROW_OFF; }
-            else { sW[l] = 0.0; sState[l] = WS_FREE; }
-          }
-          take_column(l);
-          sweep(l, l_row);
-          ++n_piv;
-        }
-      }
+      const WideQpOut qo = wide_qp(X, A.clk ? A.clk + (size_t)pb * 24 : nullptr);
+      status |= qo.status; iters = qo.iters; n_outer = qo.n_outer; n_piv = qo.n_piv;
     }
+    MKH_WSTAMP(11);
+    if (A.clk && tid == 0) { A.clk[(size_t)pb * 24 + 13] = iters; A.clk[(size_t)pb * 24 + 14] = n_piv; A.clk[(size_t)pb * 24 + 16] = N; }
     if (MKH_WTAP(t_qp_iters) && tid == 0) MKH_WTAP(t_qp_iters)[pb] = (iters & 1023) | ((n_outer & 1023) << 10) | ((n_piv & 1023) << 20);
     // the contacts that found no row: G·Δq ≤ h at the solution?  (the wavefront kernels' collision_phase, mode 1)
     if (select && A.do_qp && !(status & 14)) {
@@ -760,6 +904,7 @@ __global__ __launch_bounds__(kWideThreads) void ik_wide_kernel(const WideProblem
       if (A.converged_out) A.converged_out[pb] = conv_flag;
     }
     if (A.status_out && tid == 0) A.status_out[pb] = status_all;
+    MKH_WSTAMP(12);
   }
 }
 

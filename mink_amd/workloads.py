@@ -83,6 +83,7 @@ def _hinge_velocities(model: FlatModel, vmax: float = np.pi) -> dict:
 
 
 SHADOW_FINGERS = ("thumb", "first", "middle", "ring", "little")
+G1_HANDS_TIPS = ("ff_tip", "mf_tip", "rf_tip", "th_tip")
 
 # BASELINE.json configs: robot, keyframe, default batch, algorithmic bytes per solve
 # (q + frame targets + v + status, shared posture target; G1 full adds nothing per instance when the
@@ -132,6 +133,14 @@ BENCH_CONFIGS: Dict[str, dict] = {
     "h1_full": {"robot": "h1", "key": "stand", "batch": 65536, "bytes_per_solve": 26 * 8 + 5 * 7 * 8 + 3 * 8 + 25 * 8 + 4,
                 "workload": "Unitree H1 full example: pelvis-orientation + 4 FrameTasks + PostureTask + ComTask(per-instance target) + "
                             "box limits (examples/humanoid_h1.py:22-52), dt=5e-3, damping=1e-1"},
+    # A model beyond one wavefront (round 5): the G1 with a 16-dof Allegro hand attached to each wrist (mink_amd/compose.py) —
+    # 75 dofs, 86 bodies — under the G1 task set plus the arm + hand examples' fingertip tasks (one RelativeFrameTask per
+    # fingertip, measured in its palm: examples/arm_hand_iiwa_allegro.py:77-94).  Every call runs on the workgroup-per-problem
+    # kernel (wide_kernel.h)
+    "g1_hands": {"robot": "g1_hands", "key": "stand", "batch": 8192, "bytes_per_solve": 76 * 8 + 12 * 7 * 8 + 75 * 8 + 4,
+                 "workload": "Unitree G1 + two Allegro hands (nq=76,nv=75, 86 bodies): 4 FrameTasks(feet+palms) + 8 RelativeFrameTasks "
+                             "(fingertips in their palm, pos 1) + PostureTask + ConfigurationLimit + VelocityLimit, dt=5e-3, damping=1e-1 "
+                             "(examples/humanoid_g1.py:28-52 + examples/arm_hand_iiwa_allegro.py:62-94)"},
     # the same set-up with the packaged model's CAPSULE wrist geom (analytic pairs only): the reference point of ur5e_convex
     "ur5e_coll": {"robot": "ur5e", "key": "home", "batch": 4096, "bytes_per_solve": 6 * 8 + 7 * 8 + 6 * 8 + 4,
                   "workload": "UR5e, the collision set-up of examples/arm_ur5e.py:20-47 (capsule-plane floor, capsule-box wall), "
@@ -139,8 +148,20 @@ BENCH_CONFIGS: Dict[str, dict] = {
 }
 
 
+def g1_with_hands() -> FlatModel:
+    """The G1 carrying a 16-dof Allegro hand on each wrist — `attach_site.attach(hand)` of the reference's arm + hand examples
+    (examples/arm_hand_iiwa_allegro.py:32-42), twice: 43 + 32 = 75 dofs, 86 bodies (the model of the `g1_hands` workload: past
+    one wavefront in both counts).  The left-hand model serves both sides (the packaged right hand carries no fingertip sites)."""
+    from .compose import attach
+    hand = load_robot("allegro_left")
+    m = attach(load_robot("g1"), hand, site="left_palm", prefix="lh/", pos=(0.0, 0.0, 0.02))
+    return attach(m, hand, site="right_palm", prefix="rh/", pos=(0.0, 0.0, 0.02))
+
+
 def load_bench_robot(name: str) -> FlatModel:
     """FlatModel of a bench config (BENCH_CONFIGS key); `ur5e_convex` turns the wrist_3_link capsule into a cylinder."""
+    if BENCH_CONFIGS[name]["robot"] == "g1_hands":
+        return g1_with_hands()
     model = load_robot(BENCH_CONFIGS[name]["robot"])
     if name == "ur5e_convex":
         from .flatmodel import GEOM_CYLINDER
@@ -186,6 +207,17 @@ def bench_config(name: str, model: FlatModel, nmodel: "nat.NativeModel", max_bat
             extra = {"com_tasks": [{"cost": 200.0}]}
         prob = nat.NativeProblem(nmodel, frame_tasks=fts, posture_tasks=[{"cost": 1.0}], configuration_limits=cfg,
                                  velocity_limits=[velocity_limit_desc(model, _hinge_velocities(model))], max_batch=max_batch, **extra)
+        return prob, 5e-3, 1e-1
+    if name == "g1_hands":
+        fts = [_frame_desc(model, s, "site", 200.0, 10.0, 1.0) for s in ("left_foot", "right_foot")] + \
+              [_frame_desc(model, s, "site", 200.0, 0.0, 1.0) for s in ("left_palm", "right_palm")]
+        for side in ("lh", "rh"):
+            for tip in G1_HANDS_TIPS:
+                d = _frame_desc(model, f"{side}/{tip}", "site", 1.0, 0.0, 1.0)
+                d.update(root_type="body", root_id=model.name2id("body", f"{side}/palm"))
+                fts.append(d)
+        prob = nat.NativeProblem(nmodel, frame_tasks=fts, posture_tasks=[{"cost": 1.0}], configuration_limits=cfg,
+                                 velocity_limits=[velocity_limit_desc(model, _hinge_velocities(model))], max_batch=max_batch)
         return prob, 5e-3, 1e-1
     if name == "g1_coll":
         fts = [_frame_desc(model, s, "site", 200.0, 10.0, 1.0) for s in ("left_foot", "right_foot")] + \

@@ -104,7 +104,7 @@ static Work *work_new(const MkoModel *m, int mrows) {
   size_t n = 0;
   n += (size_t)nb * (3 + 4 + 9 + 3 + 3) + (size_t)nj * 6 + (size_t)ng * 12 + (size_t)ns * 12 + (size_t)nv * 6;
   n += (size_t)nv * nv + nv + (size_t)mrows * nv + mrows + (size_t)6 * nv * 2 + (size_t)nv * nv + nv + (size_t)6 * nv + 4 * (size_t)nv + 4 * (size_t)nq;
-  n += (size_t)4 * nv * nv + (size_t)8 * nv + (size_t)4 * mrows + 64 + nv;
+  n += (size_t)4 * nv * nv + (size_t)8 * nv + (size_t)4 * mrows + 64 + nv + (size_t)12 * nv;
   Work *w = (Work *)malloc(sizeof(Work));
   w->pool = (double *)calloc(n, sizeof(double));
   double *p = w->pool;
@@ -113,7 +113,7 @@ static Work *work_new(const MkoModel *m, int mrows) {
   TAKE(xanchor, nj * 3); TAKE(xaxis, nj * 3); TAKE(geom_xpos, ng * 3); TAKE(geom_xmat, ng * 9);
   TAKE(site_xpos, ns * 3); TAKE(site_xmat, ns * 9); TAKE(cdof, nv * 6);
   TAKE(H, nv * nv); TAKE(c, nv); TAKE(G, (size_t)mrows * nv); TAKE(h, mrows);
-  TAKE(jacp, 3 * nv); TAKE(jacr, 3 * nv); TAKE(J, (size_t)nv * nv + 6 * nv); TAKE(e, nv + 6);
+  TAKE(jacp, 3 * nv); TAKE(jacr, 3 * nv); TAKE(J, (size_t)nv * nv + 18 * nv); TAKE(e, nv + 6);
   TAKE(tmpv, 4 * nv); TAKE(tmpq, 4 * nq);
   TAKE(qp, (size_t)4 * nv * nv + 8 * nv + 4 * mrows + 64);
   TAKE(dq, nv);
@@ -1016,6 +1016,38 @@ static int32_t solve_one(const MkoModel *m, const MkoProblem *p, Work *w, int mr
     const double *target = frame_targets + 7 * t;
     double Tf[7], Tfi[7], Tti[7], Tbt[7], Ttb[7], e[6], JL[36];
     frame_transform_jacobian(m, w, ft->frame_type, ft->frame_id, Tf, J6);
+    if (ft->root_type >= 0) {
+      /* RelativeFrameTask (relative_frame_task.py:106-142): T_fr = T_root⁻¹·T_frame, e = T_fr.rminus(target) = log(target⁻¹·T_fr),
+       * J = jlog(T_tf)·(ᶠJ − Ad(T_fr⁻¹)·ʳJ) with Ad(T) = [[R, [t]×R],[0, R]] (se3.py:187-194) */
+      double *Jr = w->J + 12 * nv;
+      double Tr[7], Tri[7], Tfr[7], Trf[7], Ttf[7], R[9], S[9], SR[9];
+      frame_transform_jacobian(m, w, ft->root_type, ft->root_id, Tr, Jr);
+      se3_inverse(Tri, Tr);
+      se3_multiply(Tfr, Tri, Tf);
+      se3_inverse(Tti, target);
+      se3_multiply(Ttf, Tti, Tfr);
+      se3_log(e, Ttf);
+      se3_jlog(JL, Ttf);
+      se3_inverse(Trf, Tfr);
+      quat2Mat(R, Trf);
+      skew(S, Trf + 4);
+      mat3mul(SR, S, R);
+      for (int k = 0; k < nv; ++k) {
+        double d6[6];
+        for (int i = 0; i < 3; ++i) {
+          double a = 0, b = 0;
+          for (int j = 0; j < 3; ++j) { a += R[3 * i + j] * Jr[j * nv + k] + SR[3 * i + j] * Jr[(3 + j) * nv + k]; b += R[3 * i + j] * Jr[(3 + j) * nv + k]; }
+          d6[i] = J6[i * nv + k] - a; d6[3 + i] = J6[(3 + i) * nv + k] - b;
+        }
+        for (int r = 0; r < 6; ++r) {
+          double sacc = 0;
+          for (int i = 0; i < 6; ++i) sacc += JL[6 * r + i] * d6[i];
+          Jt[r * nv + k] = sacc;
+        }
+      }
+      add_objective(nv, 6, Jt, e, ft->cost, ft->gain, ft->lm_damping, w->H, w->c);
+      continue;
+    }
     se3_inverse(Tfi, Tf);
     se3_multiply(Tbt, Tfi, target);
     se3_log(e, Tbt);                                   /* target.minus(frame) (frame_task.py:119-122) */

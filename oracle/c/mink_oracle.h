@@ -43,7 +43,9 @@ typedef struct {
 
 enum { MKO_FRAME_BODY = 0, MKO_FRAME_GEOM = 1, MKO_FRAME_SITE = 2 };
 
-typedef struct { int32_t frame_type, frame_id; double cost[6], gain, lm_damping; } MkoFrameTask;
+/* root_type < 0: FrameTask (mink/tasks/frame_task.py); else RelativeFrameTask(frame, root) — mink/tasks/relative_frame_task.py:28-142,
+ * the task's target slot holds transform_target_to_root */
+typedef struct { int32_t frame_type, frame_id; double cost[6], gain, lm_damping; int32_t root_type, root_id; } MkoFrameTask;
 typedef struct { const double *cost; double gain, lm_damping; } MkoPostureTask;       /* cost: (nv,) */
 typedef struct { double cost[3], gain, lm_damping; } MkoComTask;
 

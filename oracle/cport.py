@@ -42,7 +42,7 @@ class MkoModel(C.Structure):
 
 class MkoFrameTask(C.Structure):
     _fields_ = [("frame_type", C.c_int32), ("frame_id", C.c_int32), ("cost", C.c_double * 6), ("gain", C.c_double),
-                ("lm_damping", C.c_double)]
+                ("lm_damping", C.c_double), ("root_type", C.c_int32), ("root_id", C.c_int32)]
 
 
 class MkoPostureTask(C.Structure):
@@ -121,11 +121,12 @@ class CProblem:
             self._keep.append(a)
             setattr(mm, name, a.ctypes.data_as(typ))
         self.cmodel = mm
-        frames = [t for t in tasks if isinstance(t, ik.FrameTaskSpec)]
+        # (FrameTasks and RelativeFrameTasks share the frame-target slots, in the caller's order)
+        frames = [t for t in tasks if isinstance(t, (ik.FrameTaskSpec, ik.RelativeFrameTaskSpec))]
         postures = [t for t in tasks if isinstance(t, ik.PostureTaskSpec)]
         coms = [t for t in tasks if isinstance(t, ik.ComTaskSpec)]
         if len(frames) + len(postures) + len(coms) != len(tasks):
-            raise TypeError("the C restatement covers FrameTask, PostureTask and ComTask")
+            raise TypeError("the C restatement covers FrameTask, RelativeFrameTask, PostureTask and ComTask")
         # the C side adds objectives grouped by kind; float addition is not associative, so keep the
         # caller's order within each kind (H differs from the numpy oracle only at the 1e-16 level)
         self.frames, self.postures, self.coms = frames, postures, coms
@@ -136,6 +137,9 @@ class CProblem:
             fa[i].cost[:] = [float(x) for x in t.cost]
             fa[i].gain = float(t.gain)
             fa[i].lm_damping = float(t.lm_damping)
+            rel = isinstance(t, ik.RelativeFrameTaskSpec)
+            fa[i].root_type = _FRAME_TYPES[t.root_type] if rel else -1
+            fa[i].root_id = int(t.root_id) if rel else 0
         pa = (MkoPostureTask * max(1, len(postures)))()
         for i, t in enumerate(postures):
             c = np.ascontiguousarray(np.asarray(t.cost, dtype=np.float64))

@@ -319,7 +319,8 @@ def test_cold_start_refinement_agrees_with_the_plain_low_rank_start(monkeypatch)
 
 _BENCH_KERNELS = {"ur5e_c2": "ik_quad_kernel", "g1_c3": "ik_solve_kernel_44_32_r44_w3", "g1_full": "ik_solve_kernel_44_36_r44",
                   "shadow_c4": "ik_solve_kernel_48_72+redo_64", "g1_plugin": "ik_solve_kernel_48_256", "h1_c3": "ik_quad_kernel_32",
-                  "h1_full": "ik_quad_kernel_32", "g1_coll": "ik_solve_kernel_64_8+wide", "ur5e_coll": "ik_solve_kernel_16_8"}
+                  "h1_full": "ik_quad_kernel_32", "g1_coll": "ik_solve_kernel_64_8+wide", "ur5e_coll": "ik_solve_kernel_16_8",
+                  "g1_hands": "ik_wide_kernel"}
 
 
 def _oracle_specs_of_bench(name, model, prob_desc):
@@ -345,6 +346,10 @@ def _oracle_specs_of_bench(name, model, prob_desc):
         return fts + [post], [ik.ConfigurationLimitSpec(), vel], {}
     if name == "g1_c3":
         return feet_palms + [post], [ik.ConfigurationLimitSpec(), vel], {}
+    if name == "g1_hands":
+        tips = [ik.RelativeFrameTaskSpec(site(f"{side}/{tip}"), "site", model.name2id("body", f"{side}/palm"), "body", cost6(1.0, 0.0), z7, lm_damping=1.0)
+                for side in ("lh", "rh") for tip in ("ff_tip", "mf_tip", "rf_tip", "th_tip")]
+        return feet_palms + tips + [post], [ik.ConfigurationLimitSpec(), vel], {}
     if name == "g1_coll":       # (the pair list is written out by name in test_g1_coll_pair_list_is_what_the_workload_says)
         from mink_amd import workloads
         col = ik.CollisionAvoidanceLimitSpec([tuple(p) for p in workloads.g1_collision_pairs(model)], gain=0.85,
@@ -384,7 +389,7 @@ def test_g1_coll_pair_list_is_what_the_workload_says():
         assert gb[a] != gb[b] and gt[a] != 0
 
 
-@pytest.mark.parametrize("name", ["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin", "h1_c3", "h1_full", "g1_coll", "ur5e_coll"])
+@pytest.mark.parametrize("name", ["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin", "h1_c3", "h1_full", "g1_coll", "ur5e_coll", "g1_hands"])
 def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name, monkeypatch):
     """Exactly what `bench.py --config <name>` times — the same constructors, the same generated batch (per-instance CoM
     targets for the G1 full example, half of the Shadow instances pulled towards `grasp hard`, the caller's rows of the plugin
@@ -410,7 +415,7 @@ def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name, monk
         groups = [[f"{f}_1", f"{f}_2"] for f in workloads.SHADOW_FINGERS]
         col = CollisionAvoidanceLimit(model, [(groups[i], groups[j]) for i in range(5) for j in range(i + 1, 5)])
         np.testing.assert_array_equal(np.array(col.geom_id_pairs), np.load(oc.GOLDEN + "/shadow_c4_geom_pairs.npy"))
-    cp = cport.CProblem(model if name in ("h1_c3", "h1_full") else oc.model(workloads.BENCH_CONFIGS[name]["robot"]), tasks, limits, **extra)
+    cp = cport.CProblem(model if name in ("h1_c3", "h1_full", "g1_hands") else oc.model(workloads.BENCH_CONFIGS[name]["robot"]), tasks, limits, **extra)
     v_ref, st_ref = cp.solve_batch(q, tg, pt, dt, damping, com_target=com, dense=dense, nthreads=min(16, os.cpu_count() or 1))
     assert (st_ref == 0).all(), np.unique(st_ref, return_counts=True)
     err = np.abs(v - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))

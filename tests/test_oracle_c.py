@@ -279,3 +279,29 @@ def test_c_oracle_vs_the_big_shadow_and_ur5e_real_mink_fixtures(golden_dir):
     main = np.ones(len(v), bool); main[7::8] = False
     err = np.abs(v - d["v"]) / np.maximum(1.0, np.abs(d["v"]).max(axis=1, keepdims=True))
     assert err[main].max() < 1e-8 and err[~main].max() < 1e-5, (err[main].max(), err[~main].max())
+
+
+def test_c_relative_frame_task_vs_the_real_mink_fixture(golden_dir):
+    """Round 5: RelativeFrameTask (mink/tasks/relative_frame_task.py:106-142) in the C restatement — the real-mink fixture of the
+    reference's arm + hand task set (tests/golden/make_golden_mid.py::arm_hand): H, c of every instance through mko_solve_ik,
+    v of the batch."""
+    import os
+    from mink_amd.flatmodel import FlatModel
+    from test_oracle_ik import _arm_hand_specs
+    d = _load(golden_dir, "arm_hand")
+    m = FlatModel.load(os.path.join(golden_dir, "models", "arm_hand.json"))
+    dt, damping = float(d["dt"]), float(d["damping"])
+    for i in range(0, len(d["q"]), 5):
+        tasks, limits = _arm_hand_specs(m, d, i)
+        v, (H, c) = cport.CProblem(m, tasks, limits).solve(d["q"][i], dt, damping, return_problem=True)
+        np.testing.assert_allclose(H, d["H"][i], rtol=0, atol=1e-11 * max(1.0, np.abs(d["H"][i]).max()))
+        np.testing.assert_allclose(c, d["c"][i], rtol=0, atol=1e-11 * max(1.0, np.abs(d["c"][i]).max()))
+        np.testing.assert_allclose(v, d["v"][i], rtol=0, atol=1e-9 * max(1.0, np.abs(d["v"][i]).max()))
+    tasks, limits = _arm_hand_specs(m, d, 0)
+    # (batch layout: frame-target slots in the caller's task order — FrameTask first, then the four RelativeFrameTasks)
+    v, st = cport.CProblem(m, tasks, limits).solve_batch(d["q"], d["frame_targets"], d["posture_target"][None, :], dt, damping)
+    assert (st == 0).all()
+    vs = np.maximum(1.0, np.abs(d["v"]).max(axis=1, keepdims=True))
+    err = np.abs(v - d["v"]) / vs
+    main = np.ones(len(v), bool); main[7::8] = False           # (every eighth instance: the small-angle sub-stream, 1e-5)
+    assert err[main].max() < 1e-8 and err[~main].max() < 1e-5, (err[main].max(), err[~main].max())

@@ -18,6 +18,10 @@ ROBOTS = {
     "ur5e": EX + "universal_robots_ur5e/scene.xml",
     "g1": EX + "unitree_g1/scene.xml",
     "shadow_left": EX + "shadow_hand/scene_left.xml",
+    "h1": EX + "unitree_h1/scene.xml",
+    # the hand alone (no scene): what the reference's arm + hand examples attach to an arm (examples/arm_hand_iiwa_allegro.py:10-42);
+    # mink_amd.compose.attach puts two of them on the G1's wrists for the `g1_hands` workload (75 dofs, 86 bodies)
+    "allegro_left": EX + "wonik_allegro/left_hand.xml",
 }
 out = os.path.join(REPO, "mink_amd", "robots")
 os.makedirs(out, exist_ok=True)
