@@ -545,6 +545,18 @@ static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhPro
   W.o_state = o; o += ev((Ncap + 1) / 2);
   W.o_cws = o; o += p->convex_pairs ? 4 * (kEpaWsDoubles > kGjkWsDoubles ? kEpaWsDoubles : kGjkWsDoubles) : 0;
   const int lds_cap = (160 * 1024 - 2048) / 8;                              // doubles of LDS one workgroup may take
+  // staging vectors of the block pivots (wide_kernel.h wide_rank4): over the poses / joint axes when they fit, else appended — unless
+  // that would push the tableau out of LDS or cost the second resident workgroup
+  W.blk_stride = ev(Ncap);
+  W.o_blk = -1;
+  if (8 * W.blk_stride <= W.o_dof - W.o_X) W.o_blk = W.o_X;
+  else {
+    const long long with = (long long)o + 8 * W.blk_stride, t = (long long)Ncap * Ncap;
+    const bool keeps_t = (with + t <= lds_cap) == ((long long)o + t <= lds_cap);
+    const long long tot0 = (long long)o + ((long long)o + t <= lds_cap ? t : 0), tot1 = with + (with + t <= lds_cap ? t : 0);
+    const bool keeps_two = (tot1 * 8 <= 80 * 1024) == (tot0 * 8 <= 80 * 1024);
+    if (with <= lds_cap && keeps_t && keeps_two) { W.o_blk = o; o += 8 * W.blk_stride; }
+  }
   W.tableau_in_lds = (long long)o + (long long)Ncap * Ncap <= lds_cap ? 1 : 0;
   W.o_T = o; o += W.tableau_in_lds ? Ncap * Ncap : 0;
   W.lds_doubles = o;

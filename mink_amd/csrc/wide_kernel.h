@@ -101,35 +101,18 @@ __device__ __forceinline__ void wide_rank1(TP* Tp, int n, int N, const lds_f64* 
     const bool colk = j == kfix;
     const double uj = u[j], vj = kTwo ? v2[j] : 0.0;
     TP* const c = Tp + j;
-    int i = wave;
-    for (; i + (RB - 1) * NW < n; i += RB * NW) {
+    for (int i = wave; i < n; i += RB * NW) {
+      // (rows past the end: the loads go to the last row — a valid address, no divergent guard —, only the stores are predicated)
       double t[RB], ui[RB], vi[RB];
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
-        t[r] = c[(size_t)(i + r * NW) * N];
-        ui[r] = u[i + r * NW];
-        vi[r] = kTwo ? v2[i + r * NW] : 0.0;
+        const int ii = i + r * NW < n ? i + r * NW : n - 1;
+        t[r] = c[(size_t)ii * N];
+        ui[r] = u[ii];
+        vi[r] = kTwo ? v2[ii] : 0.0;
       }
 #pragma unroll
       for (int r = 0; r < RB; ++r) {
-        double x = fma(ui[r] * uj, alpha, t[r]);
-        if (kTwo) x = fma(vi[r] * vj, beta, x);
-        if (!kTwo) x = colk ? sgi * ui[r] : x;
-        c[(size_t)(i + r * NW) * N] = x;
-      }
-    }
-    // the rest of this wave's rows, all requested at once (≤ RB − 1 of them)
-    {
-      double t[RB - 1], ui[RB - 1], vi[RB - 1];
-#pragma unroll
-      for (int r = 0; r < RB - 1; ++r) {
-        const bool in = i + r * NW < n;
-        t[r] = in ? c[(size_t)(i + r * NW) * N] : 0.0;
-        ui[r] = in ? u[i + r * NW] : 0.0;
-        vi[r] = (kTwo && in) ? v2[i + r * NW] : 0.0;
-      }
-#pragma unroll
-      for (int r = 0; r < RB - 1; ++r) {
         double x = fma(ui[r] * uj, alpha, t[r]);
         if (kTwo) x = fma(vi[r] * vj, beta, x);
         if (!kTwo) x = colk ? sgi * ui[r] : x;
@@ -141,6 +124,51 @@ __device__ __forceinline__ void wide_rank1(TP* Tp, int n, int N, const lds_f64* 
   }
 }
 
+// T[i][j] −= Σ_c V[i][c]·U[c][j], c < 4, on the leading n × n block: four pivots (or four Jacobian rows) per pass over the tableau —
+// a quarter of the tableau traffic and of the barriers of four rank-1 passes.  U: [4][stride] (lane-contiguous), Vt: [i][4] (two
+// 16-byte broadcast reads per row).  k0 ≥ 0 (a BLOCK SWEEP on the indices k0 … k0+3, k0 a multiple of 4, Vt = U·E with E the
+// inverse of the 4 × 4 pivot block): columns k0 … k0+3 are left alone by the update, and rows / columns k0+c are then written by
+// wave c — the owner of row k0+c — as E·Uᵀ (the new rows of a swept tableau) and −E on the block itself.
+// (Measured and dropped: the row factors through the lanes and v_readlane instead of broadcast LDS reads — 5.76 → 6.5 ms on the
+//  G1 with two hands: with two workgroups per CU the passes are bound by VALU issue, not by the LDS return path.)
+template <class TP>
+__device__ __forceinline__ void wide_rank4(TP* Tp, int n, int N, const lds_f64* U, int stride, const lds_f64* Vt, int k0, const double (&E)[4][4],
+                                           int wave, int lane) {
+  constexpr int NW = kWideThreads / 64, RB = 6;
+  for (int jb = 0; jb < n; jb += 64) {
+    const int j = jb + lane;
+    const bool jin = k0 >= 0 && (unsigned)(j - k0) < 4u;
+    if (j < n && !jin) {
+      const double u0 = U[j], u1 = U[stride + j], u2 = U[2 * stride + j], u3 = U[3 * stride + j];
+      TP* const c = Tp + j;
+      for (int i = wave; i < n; i += RB * NW) {
+        double t[RB], v[RB][4];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const int ii = i + r * NW < n ? i + r * NW : n - 1;
+          t[r] = c[(size_t)ii * N];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[r][q] = Vt[4 * ii + q];
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+          const double x = fma(-v[r][3], u3, fma(-v[r][2], u2, fma(-v[r][1], u1, fma(-v[r][0], u0, t[r]))));
+          if (i + r * NW < n) c[(size_t)(i + r * NW) * N] = x;
+        }
+      }
+    }
+    if (k0 >= 0 && j < n) {
+      // rows / columns of the block, by the wave that owns row k0 + wave (its lanes' writes above precede these in program order;
+      // nobody else writes the columns: the update skipped them)
+      const int kr = k0 + wave;
+      double val = Vt[4 * j + wave];
+      if (jin) val = -E[wave][(j - k0) & 3];
+      Tp[(size_t)kr * N + j] = val;
+      if (!jin) Tp[(size_t)j * N + kr] = val;
+    }
+  }
+}
+
 // What the tableau phases need of the kernel's state: a REAL call (noinline) — the kernel around them carries the inlined distance
 // routines and sits at its register ceiling (256 VGPRs, 470 spilled SGPRs); as callees the two hot loops get a register allocation of
 // their own (round 5: the same inner loop compiled inline took 11 k cycles per sweep, spilling scalars inside it).
@@ -148,6 +176,7 @@ struct WideQpCtx {
   double* T;                    // tableau (LDS or the workgroup's slice of device memory)
   int in_lds, N, nv;
   int o_z, o_w, o_lo, o_hi, o_rown, o_ref, o_col, o_red, o_state;      // LDS offsets (doubles)
+  int o_blk, blk_stride;        // staging of the block pivots / rank-4 accumulation (−1: none)
 };
 
 // H = λI + Σ JwᵀJw (+ the posture tasks' diagonal, added by the caller): two weighted Jacobian rows per pass, staged in LDS (sCol,
@@ -160,6 +189,25 @@ __device__ __attribute__((noinline)) void wide_accumulate_h(WideQpCtx X, const d
   lds_f64* const sRef = (lds_f64*)(smem + X.o_ref);
   double* const T = X.T;
   for (int e = tid; e < N * N; e += kWideThreads) T[e] = 0.0;
+  if (X.o_blk >= 0) {
+    // four rows per pass: U[c][k] = Jw[r + c][k], Vt[k][c] = −U[c][k]
+    lds_f64* const U = (lds_f64*)(smem + X.o_blk);
+    lds_f64* const Vt = U + 4 * X.blk_stride;
+    const double none[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int r = 0; r < R_all; r += 4) {
+      __syncthreads();
+      for (int c = 0; c < 4; ++c)
+        for (int k = tid; k < nv; k += kWideThreads) {
+          const double x = (r + c < R_all) ? Jw[(size_t)(r + c) * nv + k] : 0.0;
+          U[c * X.blk_stride + k] = x; Vt[4 * k + c] = -x;
+        }
+      __syncthreads();
+      if (X.in_lds) wide_rank4((lds_f64*)T, nv, N, U, X.blk_stride, Vt, -1, none, wave, lane);
+      else wide_rank4(T, nv, N, U, X.blk_stride, Vt, -1, none, wave, lane);
+    }
+    __syncthreads();
+    return;
+  }
   // (rows of nv ≤ 4·256 doubles: up to four entries of each of the two rows per thread)
   double a0[4], a1[4];
   auto fetch = [&](int r) {
@@ -186,6 +234,62 @@ __device__ __attribute__((noinline)) void wide_accumulate_h(WideQpCtx X, const d
   __syncthreads();
 }
 
+
+// Contacts of one problem (collision_avoidance_limit.py:187-229): every pair's distance and witness points → rec[pair] = {h, n, from, to}
+// (h = +inf: not in range).  Each wavefront takes kGjkSlots pairs per trip (GJK keeps its simplex in the wave's LDS workspace).
+__device__ __attribute__((noinline)) void wide_contacts(const WideProblem* Pg, double dt, double* rec, const double* sX, int XS, double* sCwsAll) {
+  const WideProblem& P = *Pg;
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double kInf = __builtin_huge_val();
+  double* const sCws = sCwsAll + wave * (kEpaWsDoubles > kGjkWsDoubles ? kEpaWsDoubles : kGjkWsDoubles);   // this wave's GJK / EPA workspace
+  for (int base = 0; base < P.n_pairs; base += 4 * kGjkSlots) {
+      const int pi = base + wave * kGjkSlots + lane;
+      const bool want = lane < kGjkSlots && pi < P.n_pairs;
+      double dist = 0.0;
+      V3 from{0, 0, 0}, to{0, 0, 0};
+      bool need_epa = false;
+      auto poses = [&](const CollisionPairDev& cp, V3& gp1, Q4& gq1, V3& gp2, Q4& gq2) {
+        const int b1 = cp.body1, b2 = cp.body2;
+        const Q4 bq1{sX[3 * XS + b1], sX[4 * XS + b1], sX[5 * XS + b1], sX[6 * XS + b1]}, bq2{sX[3 * XS + b2], sX[4 * XS + b2], sX[5 * XS + b2], sX[6 * XS + b2]};
+        gp1 = V3{sX[b1], sX[XS + b1], sX[2 * XS + b1]} + qrot(bq1, V3{cp.lpos1[0], cp.lpos1[1], cp.lpos1[2]});
+        gp2 = V3{sX[b2], sX[XS + b2], sX[2 * XS + b2]} + qrot(bq2, V3{cp.lpos2[0], cp.lpos2[1], cp.lpos2[2]});
+        gq1 = qmul(bq1, Q4{cp.lquat1[0], cp.lquat1[1], cp.lquat1[2], cp.lquat1[3]});
+        gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
+      };
+      if (want) {
+        const CollisionPairDev& cp = P.pairs[pi];
+        V3 gp1, gp2; Q4 gq1, gq2;
+        poses(cp, gp1, gq1, gp2, gq2);
+        geom_distance<false, true>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
+                                   V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to,
+                                   cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, &need_epa, sCws + lane);
+      }
+      // pairs whose cores overlap: one at a time, this wavefront cooperating on the expanding polytope
+      for (unsigned long long em = __ballot(want && need_epa); em; em &= em - 1) {
+        const int l = (int)__builtin_ctzll(em);
+        const CollisionPairDev& cp = P.pairs[base + wave * kGjkSlots + l];
+        V3 gp1, gp2; Q4 gq1, gq2;
+        poses(cp, gp1, gq1, gp2, gq2);
+        double d_e; V3 f_e, t_e;
+        geom_overlap_distance(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
+                              V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, d_e, f_e, t_e, cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, sCws);
+        if (lane == l) { dist = d_e; from = f_e; to = t_e; }
+      }
+      if (want) {
+        const CollisionPairDev& cp = P.pairs[pi];
+        double* o = rec + (size_t)pi * 10;
+        double hk = kInf;
+        if (dist != cp.ddetect) {                            // Contact.inactive (:52-56)
+          hk = (dist > cp.dmin) ? (cp.gain * (dist - cp.dmin) / dt) + cp.relax : cp.relax;      // :200-205
+          V3 nrm = to - from;                                // Contact.normal (:46-50)
+          const double nn = sqrt(dot(nrm, nrm));
+          nrm = (nn < 1e-15) ? V3{1.0, 0.0, 0.0} : fast_rcp(nn) * nrm;
+          o[1] = nrm.x; o[2] = nrm.y; o[3] = nrm.z; o[4] = from.x; o[5] = from.y; o[6] = from.z; o[7] = to.x; o[8] = to.y; o[9] = to.z;
+        }
+        o[0] = hk;
+      }
+  }
+}
 
 struct WideQpOut { int status, iters, n_outer, n_piv; };
 
@@ -249,8 +353,74 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp(WideQpCtx X, long long* c
   };
   int iters = 0, n_outer = 0, n_piv = 0;
   const int max_iters = 20 * (N + 4);
-  // phase 0: bring every dof into the basis (x0 = −H⁻¹c), no ratio tests
-  for (int k = 0; k < nv; ++k) {
+  // phase 0: bring every dof into the basis (x0 = −H⁻¹c), no ratio tests.  Four dofs per pass where the staging vectors exist:
+  // with K the block, U = T[:, K], D = T[K, K], E = D⁻¹ the four sweeps in a row are  T ← T − U·E·Uᵀ off the block,
+  // T[K, :] ← E·Uᵀ, T[K, K] ← −E, and the four steps are z_K ← −E·w_K with every other index moved along U·z_K
+  // (the state after the block is the one the four single pivots reach — K basic, w_K = 0 — so only rounding differs).
+  int k_first = 0;
+  if (X.o_blk >= 0) {
+    lds_f64* const U = (lds_f64*)(smem + X.o_blk);
+    lds_f64* const Vt = U + 4 * X.blk_stride;
+    const int bs = X.blk_stride;
+    for (; k_first + 4 <= nv; k_first += 4) {
+      const int k0 = k_first;
+      double wK[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) wK[c] = sW[k0 + c];
+      for (int c = 0; c < 4; ++c)
+        for (int i = tid; i < N; i += NT_) U[c * bs + i] = T[(size_t)(k0 + c) * N + i];
+      __syncthreads();
+      // E = D⁻¹: the four sweeps on the 4 × 4 block itself (every thread, redundantly — the values are uniform), which leave −D⁻¹;
+      // D is a principal block of the Schur complement of an SPD H, so every pivot is positive unless H is not
+      double M[4][4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) M[a][b] = U[a * bs + k0 + b];
+      bool pd = true;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double d = M[q][q];
+        pd = pd && d > 0.0;
+        const double inv = 1.0 / d;
+        double rq[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) rq[b] = M[q][b];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            if (a != q && b != q) M[a][b] = fma(-(rq[a] * rq[b]), inv, M[a][b]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (b != q) { M[q][b] = rq[b] * inv; M[b][q] = rq[b] * inv; }
+        M[q][q] = -inv;
+      }
+      if (!pd) { status |= 4; break; }
+      double E[4][4], a4[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) E[a][b] = -M[a][b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) a4[a] = -(E[a][0] * wK[0] + E[a][1] * wK[1] + E[a][2] * wK[2] + E[a][3] * wK[3]);
+      // the step and V = U·E, by the owner of every index
+      for (int i = tid; i < N; i += NT_) {
+        const double ui[4] = {U[i], U[bs + i], U[2 * bs + i], U[3 * bs + i]};
+        const double sstep = a4[0] * ui[0] + a4[1] * ui[1] + a4[2] * ui[2] + a4[3] * ui[3];
+        const int st = sState[i];
+        if (st == WS_FREE || st == WS_ROW_ON) sZ[i] -= sstep; else sW[i] += sstep;
+        if ((unsigned)(i - k0) < 4u) { sZ[i] += a4[(i - k0) & 3]; sW[i] = 0.0; sState[i] = WS_FREE; }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Vt[4 * i + c] = E[c][0] * ui[0] + E[c][1] * ui[1] + E[c][2] * ui[2] + E[c][3] * ui[3];
+      }
+      __syncthreads();
+      if (X.in_lds) wide_rank4((lds_f64*)T, N, N, U, bs, Vt, k0, E, wave, lane);
+      else wide_rank4(T, N, N, U, bs, Vt, k0, E, wave, lane);
+      __syncthreads();
+    }
+  }
+  for (int k = k_first; k < nv && !(status & 14); ++k) {
     const double wk = sW[k];
     take_column(k);
     const double d = sCol[k];
@@ -357,7 +527,6 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
   double* const sRed = smem + P.o_red;                   // 2 × 256: reductions
   int* const sRedI = reinterpret_cast<int*>(sRed + NT_);
   int* const sState = reinterpret_cast<int*>(smem + P.o_state);
-  double* const sCws = smem + P.o_cws + wave * (kEpaWsDoubles > kGjkWsDoubles ? kEpaWsDoubles : kGjkWsDoubles);   // this wave's GJK / EPA workspace
   double* const wsb = P.ws + (size_t)blockIdx.x * P.ws_stride;
   double* const Jw = wsb + P.ws_jw;                      // weighted Jacobian rows [R][nv]
   double* const rec = wsb + P.ws_rec;                    // per pair: h, n, from, to (10 doubles)
@@ -700,54 +869,9 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
     if (__syncthreads_or(box_bad ? 1 : 0)) status |= 2;              // inconsistent box ⇒ quadprog "constraints are inconsistent"
     MKH_WSTAMP(6);
     // ------------------------------------------------------------ contacts (collision_avoidance_limit.py:187-229): every one a row
-    // each wavefront takes kGjkSlots pairs per trip (GJK keeps its simplex in the wave's LDS workspace)
-    for (int base = 0; base < P.n_pairs; base += 4 * kGjkSlots) {
-      const int pi = base + wave * kGjkSlots + lane;
-      const bool want = lane < kGjkSlots && pi < P.n_pairs;
-      double dist = 0.0;
-      V3 from{0, 0, 0}, to{0, 0, 0};
-      bool need_epa = false;
-      auto poses = [&](const CollisionPairDev& cp, V3& gp1, Q4& gq1, V3& gp2, Q4& gq2) {
-        const int b1 = cp.body1, b2 = cp.body2;
-        const Q4 bq1{sX[3 * XS + b1], sX[4 * XS + b1], sX[5 * XS + b1], sX[6 * XS + b1]}, bq2{sX[3 * XS + b2], sX[4 * XS + b2], sX[5 * XS + b2], sX[6 * XS + b2]};
-        gp1 = V3{sX[b1], sX[XS + b1], sX[2 * XS + b1]} + qrot(bq1, V3{cp.lpos1[0], cp.lpos1[1], cp.lpos1[2]});
-        gp2 = V3{sX[b2], sX[XS + b2], sX[2 * XS + b2]} + qrot(bq2, V3{cp.lpos2[0], cp.lpos2[1], cp.lpos2[2]});
-        gq1 = qmul(bq1, Q4{cp.lquat1[0], cp.lquat1[1], cp.lquat1[2], cp.lquat1[3]});
-        gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
-      };
-      if (want) {
-        const CollisionPairDev& cp = P.pairs[pi];
-        V3 gp1, gp2; Q4 gq1, gq2;
-        poses(cp, gp1, gq1, gp2, gq2);
-        geom_distance<false, true>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
-                                   V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to,
-                                   cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, &need_epa, sCws + lane);
-      }
-      // pairs whose cores overlap: one at a time, this wavefront cooperating on the expanding polytope
-      for (unsigned long long em = __ballot(want && need_epa); em; em &= em - 1) {
-        const int l = (int)__builtin_ctzll(em);
-        const CollisionPairDev& cp = P.pairs[base + wave * kGjkSlots + l];
-        V3 gp1, gp2; Q4 gq1, gq2;
-        poses(cp, gp1, gq1, gp2, gq2);
-        double d_e; V3 f_e, t_e;
-        geom_overlap_distance(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
-                              V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, d_e, f_e, t_e, cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, sCws);
-        if (lane == l) { dist = d_e; from = f_e; to = t_e; }
-      }
-      if (want) {
-        const CollisionPairDev& cp = P.pairs[pi];
-        double* o = rec + (size_t)pi * 10;
-        double hk = kInf;
-        if (dist != cp.ddetect) {                            // Contact.inactive (:52-56)
-          hk = (dist > cp.dmin) ? (cp.gain * (dist - cp.dmin) / A.dt) + cp.relax : cp.relax;      // :200-205
-          V3 nrm = to - from;                                // Contact.normal (:46-50)
-          const double nn = sqrt(dot(nrm, nrm));
-          nrm = (nn < 1e-15) ? V3{1.0, 0.0, 0.0} : fast_rcp(nn) * nrm;
-          o[1] = nrm.x; o[2] = nrm.y; o[3] = nrm.z; o[4] = from.x; o[5] = from.y; o[6] = from.z; o[7] = to.x; o[8] = to.y; o[9] = to.z;
-        }
-        o[0] = hk;
-      }
-    }
+    // (a REAL call: the distance routines — GJK, the expanding polytope — want ≈150 registers of their own; inlined, they cost the
+    //  two-workgroups-per-CU build of this kernel 98 spilled VGPRs)
+    if (P.n_pairs > 0) wide_contacts(Pg, A.dt, rec, smem + P.o_X, XS, smem + P.o_cws);
     __syncthreads();
     MKH_WSTAMP(7);
     // Rows: the detected contacts in pair order, then the caller's rows with a finite bound.  More contacts in range than the
@@ -786,7 +910,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
     WideQpCtx X;
     X.T = T; X.in_lds = P.tableau_in_lds; X.N = N; X.nv = nv;
     X.o_z = P.o_z; X.o_w = P.o_w; X.o_lo = P.o_lo; X.o_hi = P.o_hi; X.o_rown = P.o_rown; X.o_ref = P.o_ref; X.o_col = P.o_col;
-    X.o_red = P.o_red; X.o_state = P.o_state;
+    X.o_red = P.o_red; X.o_state = P.o_state; X.o_blk = P.o_blk; X.blk_stride = P.blk_stride;
     wide_accumulate_h(X, Jw, R_all);
     for (int d = tid; d < nv; d += NT_) T[(size_t)d * N + d] += mu_total + sHd[d];
     for (int e = tid; e < m * nv; e += NT_) {                // A: G[s][k] = −nᵀ(jacp₂(to) − jacp₁(from))   (compute_contact_normal_jacobian :59-72)

@@ -22,6 +22,10 @@ struct WideProblem {
   // LDS offsets (doubles)
   int32_t o_q, o_X, o_jnt, o_dof, o_task, o_com, o_we, o_c, o_hd, o_z, o_w, o_lo, o_hi, o_rown, o_ref, o_col, o_red, o_state, o_cws, o_T,
       lds_doubles;
+  // eight staging vectors of `blk_stride` doubles for the block pivots of phase 0 and the rank-4 accumulation of H (wide_rank4): on
+  // top of the body poses / joint axes when they fit there (dead once the contacts are evaluated), else a region of their own;
+  // −1: no room — single pivots, rank-2 accumulation
+  int32_t o_blk, blk_stride;
   // model (plain arrays)
   const int32_t *level_start, *level_body, *body_parent, *body_jntadr, *body_jntnum, *body_last, *body_inrobot;
   const double *body_pos, *body_quat, *body_ipos, *body_mass, *body_stmass;
