@@ -282,7 +282,7 @@ def measure_side_config(name, dev, steps=20, warmup=3, batch=None, seed=2000):
     return out
 
 
-SIDE_CONFIGS = ("ur5e_c2", "shadow_c4", "g1_full", "g1_plugin", "ur5e_convex", "g1_coll", "h1_c3", "h1_full", "g1_hands")
+SIDE_CONFIGS = ("ur5e_c2", "shadow_c4", "g1_full", "g1_plugin", "ur5e_convex", "g1_coll", "h1_c3", "h1_full", "g1_hands", "aloha_coll")
 
 
 def pcie_inclusive(prob, q_h, tg_h, pt_h, ct_h, dt, damping, reps=5):
@@ -417,7 +417,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="g1_c3", choices=["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin", "ur5e_convex", "g1_coll", "h1_c3", "h1_full", "g1_hands"],
+    ap.add_argument("--config", default="g1_c3", choices=["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin", "ur5e_convex", "g1_coll", "h1_c3", "h1_full", "g1_hands", "aloha_coll"],
                     help="BASELINE config (default: the headline G1 config 3), or one of the two general routes of the "
                          "boundary: g1_plugin (caller-defined Task + Limit rows, mkh_solve_dense), ur5e_convex (a collision "
                          "pair on the general convex routine)")
@@ -492,7 +492,7 @@ def main():
     pt = torch.from_numpy(pt_h).to(dev) if prob.n_posture else None
     ct = None if ct_h is None else torch.from_numpy(ct_h).to(dev)
     dense = None if dense_h is None else {k: torch.from_numpy(np.ascontiguousarray(x)).to(dev) for k, x in dense_h.items()}
-    plain = dense is None and args.config not in ("ur5e_convex", "g1_coll", "h1_c3", "h1_full", "g1_hands")      # configs the fused loop / host-path / oracle legs cover
+    plain = dense is None and args.config not in ("ur5e_convex", "g1_coll", "h1_c3", "h1_full", "g1_hands", "aloha_coll")      # configs the fused loop / host-path / oracle legs cover
     v = torch.empty((B, model.nv), dtype=torch.float64, device=dev)
     st = torch.empty((B,), dtype=torch.int32, device=dev)
     v_all = torch.empty((world * B, model.nv), dtype=torch.float64, device=dev) if (world > 1 and rank == 0) else None

@@ -2494,6 +2494,16 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
         const double tpp = ps.d;
         const double beta = p_basic ? (upper ? ps.hi : ps.lo) : 0.0;
         const double thr = (!kRows || p_basic) ? thr_dof : thr_dof * ps.rn * ps.rn;
+        // A row whose normal lies (almost) in the span of the active ones — |projected normal|² below 1e-6 of its unprojected
+        // bound ‖a‖²/hmax: the sweep tableau carries the INVERSE Schur complement of the active rows explicitly and loses its
+        // digits exactly there (many geom pairs of one body pair: ALOHA's 1 104-pair limit), where quadprog's orthogonal
+        // factors do not.  The instance is flagged and solved again by the dense Goldfarb–Idnani of the workgroup-per-problem
+        // kernel (MKH_ST_DEGENERATE is internal: the redo launch clears it).
+        // (A row that has lost all its free dofs to their BOUNDS — every arm joint of a plugin row on its velocity limit — is
+        //  exactly dependent and harmless: only dependence that runs through other rows counts.)
+        if (kRows && !p_basic && !(-tpp > thr * (1e7 * (double)nv))) {
+          if (__ballot(is_dof && s.usign != 0 && sA[(p - nv) * AS + lane] != 0.0)) status |= 32;
+        }
         // full step length t2 (GI step 2b): z_p reaches its bound / the slack w_p reaches 0
         double t2 = kInf;
         if (p_basic ? (fabs(tpp) > thr) : (-tpp > thr)) t2 = fabs((ps.x - beta) * inv);

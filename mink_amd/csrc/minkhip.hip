@@ -558,7 +558,22 @@ static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhPro
     if (with <= lds_cap && keeps_t && keeps_two) { W.o_blk = o; o += 8 * W.blk_stride; }
   }
   W.tableau_in_lds = (long long)o + (long long)Ncap * Ncap <= lds_cap ? 1 : 0;
-  W.o_T = o; o += W.tableau_in_lds ? Ncap * Ncap : 0;
+  // the dense Goldfarb–Idnani fallback's factors (2·nv² + 2·nv + 8 doubles) in LDS when that costs neither the tableau's place nor
+  // the second resident workgroup
+  const long long gi_sz = rows_max > 0 ? 2ll * nv * nv + 4ll * (nv + 2) : 0;
+  const int two_wg = 80 * 1024 / 8;
+  W.o_gi = o; W.gi_in_lds = 0;
+  if (gi_sz > 0 && (long long)o + gi_sz + (long long)(nv + 8) * (nv + 8) <= two_wg) { W.gi_in_lds = 1; o += (int)gi_sz; }
+  W.o_T = o;
+  if (W.tableau_in_lds) { W.t_lds_doubles = Ncap * Ncap; o += Ncap * Ncap; }
+  else {
+    // the largest instance does not fit: reserve what keeps two workgroups resident (or, failing that, what is left) for the
+    // instances that do — most have far fewer rows in range than the limit lists pairs
+    long long room = (long long)two_wg - o;
+    if (room < (long long)(nv + 8) * (nv + 8)) room = (long long)lds_cap - o;
+    W.t_lds_doubles = room > 0 ? (int)room : 0;
+    o += W.t_lds_doubles;
+  }
   W.lds_doubles = o;
   if (o > lds_cap)
     return fail(MKH_E_LIMIT, "model too large for the workgroup-per-problem kernel: %d KB of LDS per problem, 158 KB available (per problem "
@@ -569,6 +584,7 @@ static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhPro
   W.ws_rowpair = w; w += ev((W.max_rows + 2) / 2);
   W.ws_rank = w; w += ev((W.n_pairs + 2) / 2);
   W.ws_T = w; w += W.tableau_in_lds ? 0 : (long long)Ncap * Ncap;
+  W.ws_gi = w; w += rows_max > 0 ? 2ll * nv * nv + 4ll * (nv + 2) : 0;
   W.ws_stride = (w + 15) & ~15ll;
   const int per_cu = (160 * 1024) / (o * 8) < 2 ? ((160 * 1024) / (o * 8) < 1 ? 1 : (160 * 1024) / (o * 8)) : 2;
   int grid = m->num_cus * per_cu;
@@ -1231,7 +1247,9 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   // mink/solve_ik.py:25-40): the instances a launch flags MKH_ST_ROW_OVERFLOW are solved again by the workgroup-per-problem
   // kernel with every row (launch(): the redo launch behind plain solves)
   const bool no_wide = getenv("MKH_DEBUG_NO_WIDE") != nullptr;                 // (tests: what the wavefront kernel alone leaves flagged; read per handle)
-  if (!no_wide && P.n_pairs + P.n_dense_limit_rows > kWave - m->nv) {
+  // (round 5: EVERY problem with half-space rows gets this twin — its dense Goldfarb–Idnani iteration also re-solves the instances
+  //  whose active rows are almost dependent, wherever they occur)
+  if (!no_wide && P.n_pairs + P.n_dense_limit_rows > 0) {
     const int32_t rc = build_wide_problem(p, m, d, ft, pairs, dcost, dwgain);
     if (rc != MKH_OK) return bail(rc);
   }
@@ -1520,7 +1538,9 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
     snprintf(p->last_kernel + len, sizeof(p->last_kernel) - len, "+wide");
     SolveArgs ar = a;
     ar.q = q_redo;
-    return launch_wide_kernel(p, ar, stream, MKH_ST_ROW_OVERFLOW, dtaps);
+    // (… and the instances whose active rows the sweep tableau found almost dependent, or on which it failed: MKH_ST_DEGENERATE is
+    //  internal — the dense Goldfarb–Idnani iteration of the workgroup-per-problem kernel answers for them)
+    return launch_wide_kernel(p, ar, stream, MKH_ST_ROW_OVERFLOW | MKH_ST_INFEASIBLE | MKH_ST_ITER_LIMIT | 32, dtaps);
   }
   return MKH_OK;
 }

@@ -454,6 +454,7 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp(WideQpCtx X, long long* c
       if (++iters > max_iters) { status |= 8; break; }
       take_column(p);
       const double tpp = sCol[p];
+      if (!p_basic && !(-tpp > 1e-6 * sRef[p])) status |= 32;       // (MKH_ST_DEGENERATE: ik_kernel.h has the reasoning)
       double full = kInf;
       if (p_basic) { if (fabs(tpp) > 1e-12 * sRef[p]) full = (sZ[p] - beta) / tpp; }
       else if (-tpp > 1e-12 * sRef[p]) full = -sW[p] / tpp;
@@ -500,6 +501,243 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp(WideQpCtx X, long long* c
   return WideQpOut{status, iters, n_outer, n_piv};
 }
 
+// The dense Goldfarb–Idnani iteration with orthogonal factors — the algorithm of quadprog, the reference's QP backend
+// (mink/solve_ik.py:101; Goldfarb & Idnani 1983: H = L·Lᵀ, J = L⁻ᵀ·Q, the active normals N = J⁻ᵀ·[R; 0]) — for the instances
+// the sweep tableau flags MKH_ST_DEGENERATE (or fails on): active rows that are almost linearly dependent, where the tableau's
+// explicit inverse Schur complement has lost its digits and a QR-updated factorisation has not.  Box bounds are constraints
+// ±e_i like any other.  Rare path (5 % of the ALOHA workload, none elsewhere): parallel over the workgroup in the O(n²) steps,
+// one thread for the O(n) bookkeeping; J and R live in the workgroup's slice of device memory.
+// In: T = K = [[H, Aᵀ],[A, 0]] as built (no pivots yet), sW = (c, −h), sLo / sHi, sRown (row norms).  Out: sZ[0, nv) = Δq.
+__device__ __attribute__((noinline)) WideQpOut wide_qp_dense(WideQpCtx X, double* ws) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, N = X.N, n = X.nv, m = X.N - X.nv;
+  constexpr int NT_ = kWideThreads;
+  const double kInf = __builtin_huge_val();
+  double* const xv = smem + X.o_z;                      // x
+  const double* const cw = smem + X.o_w;               // (c, −h)
+  const double* const lo = smem + X.o_lo;
+  const double* const hi = smem + X.o_hi;
+  const double* const rown = smem + X.o_rown;
+  double* const dv = smem + X.o_col;                    // d = Jᵀn⁺
+  double* const zv = smem + X.o_ref;                    // z = J₂·d₂
+  double* const rv = smem + X.o_rown;                   // r = R⁻¹d₁ in [0, nv): the row norms sit behind, in [nv, N)
+  double* const sRed = smem + X.o_red;
+  int* const sRedI = reinterpret_cast<int*>(sRed + NT_);
+  int* const act = reinterpret_cast<int*>(smem + X.o_state);      // dof i: bit 0 lower bound active, 1 upper active, 2 / 3 lower / upper set aside; row s (at nv + s): 1 active, 2 set aside
+  const double* const T = X.T;
+  double* const J = ws;                                 // n × n, row-major
+  double* const R = ws + (size_t)n * n;                 // upper triangular, R[i·n + k], i ≤ k
+  double* const u = R + (size_t)n * n;                  // multipliers of the active set (+ u⁺)
+  int* const A = reinterpret_cast<int*>(u + n + 2);     // active constraints, ordered: code 0 … m−1 rows, m + i upper of dof i, m + n + i lower
+  int status = 0, iters = 0, n_outer = 0, n_piv = 0;
+  auto block_arg_min = [&](double val, int idx, double& best, int& besti) {
+    const double key = idx < 0 ? -kInf : -val;
+    const double mk = wave_max(key);
+    const unsigned cand = (idx >= 0 && key == mk) ? (unsigned)idx : 0xffffffffu;
+    const unsigned mi = wave_min_u32(cand);
+    __syncthreads();
+    if (lane == 0) { sRed[wave] = mk; sRedI[wave] = (int)mi; }
+    __syncthreads();
+    double b = -kInf; int bi = -1;
+#pragma unroll
+    for (int w = 0; w < NT_ / 64; ++w) {
+      const double kw = sRed[w]; const int iw = sRedI[w];
+      if (iw >= 0 && (bi < 0 || kw > b || (kw == b && iw < bi))) { b = kw; bi = iw; }
+    }
+    best = -b; besti = bi;
+    __syncthreads();
+  };
+  // normal of constraint `code` (n⁺ᵀx ≥ b⁺ form), entry k, and its right-hand side
+  auto normal = [&](int code, int k) -> double {
+    if (code < m) return -T[(size_t)(n + code) * N + k];
+    if (code < m + n) return (k == code - m) ? -1.0 : 0.0;
+    return (k == code - m - n) ? 1.0 : 0.0;
+  };
+  auto rhs = [&](int code) -> double {
+    if (code < m) return cw[n + code];                    // −h
+    if (code < m + n) return -hi[code - m];
+    return lo[code - m - n];
+  };
+  // ---- H = L·Lᵀ (L in the R buffer), J = L⁻ᵀ
+  for (int e = tid; e < n * n; e += NT_) { R[e] = T[(size_t)(e / n) * N + e % n]; J[e] = 0.0; }
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {
+    const double dkk = R[(size_t)k * n + k];
+    if (!(dkk > 0.0)) { status |= 4; break; }             // (uniform: every thread reads the same entry)
+    const double lkk = sqrt(dkk);
+    __syncthreads();
+    for (int i = k + tid; i < n; i += NT_) R[(size_t)i * n + k] = (i == k) ? lkk : R[(size_t)i * n + k] / lkk;
+    __syncthreads();
+    for (int e = tid; e < (n - k - 1) * (n - k - 1); e += NT_) {
+      const int i = k + 1 + e / (n - k - 1), j = k + 1 + e % (n - k - 1);
+      if (j <= i) R[(size_t)i * n + j] -= R[(size_t)i * n + k] * R[(size_t)j * n + k];
+    }
+    __syncthreads();
+  }
+  if (status) return WideQpOut{status, 0, 0, 0};
+  // X = L⁻¹ column by column (one thread per column), J = Xᵀ
+  for (int j = tid; j < n; j += NT_) {
+    J[(size_t)j * n + j] = 1.0 / R[(size_t)j * n + j];
+    for (int i = j + 1; i < n; ++i) {
+      double sacc = 0.0;
+      for (int k = j; k < i; ++k) sacc += R[(size_t)i * n + k] * J[(size_t)j * n + k];      // X[k][j] is stored as J[j][k]
+      J[(size_t)j * n + i] = -sacc / R[(size_t)i * n + i];
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < n * n; e += NT_) R[e] = 0.0;
+  // x = −J·Jᵀ·c
+  for (int j = tid; j < n; j += NT_) { double sacc = 0.0; for (int i = 0; i < n; ++i) sacc += J[(size_t)i * n + j] * cw[i]; dv[j] = sacc; }
+  __syncthreads();
+  for (int i = tid; i < n; i += NT_) { double sacc = 0.0; for (int k = 0; k < n; ++k) sacc += J[(size_t)i * n + k] * dv[k]; xv[i] = -sacc; }
+  for (int i = tid; i < N; i += NT_) act[i] = 0;
+  __syncthreads();
+  int nact = 0;
+  const int mc = m + 2 * n, max_iters = 50 * (n + mc);
+  while (!(status & 14)) {
+    // ---- step 1: the most violated constraint (normalised slack; quadprog's rule)
+    double bv = 0.0; int bi = -1;
+    for (int code = tid; code < mc; code += NT_) {
+      double sl, nrm = 1.0, bb;
+      if (code < m) {
+        if (act[n + code]) continue;
+        bb = cw[n + code];
+        if (!(bb > -kInf)) continue;                      // (h = +inf: an inactive row)
+        nrm = rown[n + code];
+        double sacc = 0.0;
+        for (int k = 0; k < n; ++k) sacc += T[(size_t)(n + code) * N + k] * xv[k];
+        sl = -sacc - bb;
+      } else if (code < m + n) {
+        const int i = code - m;
+        if ((act[i] & (2 | 8)) || !(hi[i] < kInf)) continue;
+        bb = -hi[i]; sl = -xv[i] - bb;
+      } else {
+        const int i = code - m - n;
+        if ((act[i] & (1 | 4)) || !(lo[i] > -kInf)) continue;
+        bb = lo[i]; sl = xv[i] - bb;
+      }
+      const double v = sl / nrm;
+      if (v < -1e-12 * fmax(1.0, fabs(bb) / nrm) && (bi < 0 || v < bv)) { bv = v; bi = code; }
+    }
+    double pv; int p;
+    block_arg_min(bv, bi, pv, p);
+    if (p < 0) break;                                     // optimal
+    ++n_outer;
+    if (tid == 0) u[nact] = 0.0;
+    for (;;) {
+      if (++iters > max_iters) { status |= 8; break; }
+      // ---- step 2a: d = Jᵀn⁺, z = J₂·d₂, r = R⁻¹·d₁
+      __syncthreads();
+      for (int j = tid; j < n; j += NT_) {
+        double sacc = 0.0;
+        if (p < m) { for (int i = 0; i < n; ++i) sacc -= J[(size_t)i * n + j] * T[(size_t)(n + p) * N + i]; }
+        else if (p < m + n) sacc = -J[(size_t)(p - m) * n + j];
+        else sacc = J[(size_t)(p - m - n) * n + j];
+        dv[j] = sacc;
+      }
+      __syncthreads();
+      for (int i = tid; i < n; i += NT_) {
+        double sacc = 0.0;
+        for (int k = nact; k < n; ++k) sacc += J[(size_t)i * n + k] * dv[k];
+        zv[i] = sacc;
+        if (i < nact) rv[i] = dv[i];
+      }
+      __syncthreads();
+      for (int k = nact - 1; k >= 0; --k) {               // back-substitution, column-oriented
+        if (tid == 0) rv[k] = rv[k] / R[(size_t)k * n + k];
+        __syncthreads();
+        for (int i = tid; i < k; i += NT_) rv[i] -= rv[k] * R[(size_t)i * n + k];
+        __syncthreads();
+      }
+      // ---- step 2b: step lengths (one thread: O(n))
+      if (tid == 0) {
+        double t1 = kInf; int l = -1;
+        for (int k = 0; k < nact; ++k)
+          if (rv[k] > 0.0) { const double tk = u[k] / rv[k]; if (tk < t1) { t1 = tk; l = k; } }
+        double dd2 = 0.0, dd = 0.0, sp = -rhs(p);
+        for (int k = 0; k < n; ++k) { dd += dv[k] * dv[k]; if (k >= nact) dd2 += dv[k] * dv[k]; sp += normal(p, k) * xv[k]; }
+        const double t2 = (dd2 > 1e-24 * dd) ? -sp / dd2 : kInf;
+        sRed[0] = t1; sRed[1] = t2; sRed[2] = sqrt(dd2); sRedI[8] = l;
+      }
+      __syncthreads();
+      const double t1 = sRed[0], t2 = sRed[1], nd2 = sRed[2];
+      const int l = sRedI[8];
+      const double t = fmin(t1, t2);
+      __syncthreads();
+      const bool dual_only = !(t2 < kInf), full = !dual_only && t2 <= t1;
+      // A constraint whose normal lies in the span of the active ones and which is violated only at rounding level (≤ 1e-9 of a
+      // joint step, normalised) is CONSISTENT with them — exact arithmetic would show slack 0 — and is set aside: pursuing it means
+      // dual steps of 1e8 and more along directions of length 1e-17 (seen on ALOHA: two geom pairs of one body pair with opposite
+      // normals and h = 0, a third almost parallel to them), which quadprog's own factors only survive by luck.
+      if (dual_only && -pv <= 1e-9) {
+        if (tid == 0) { if (p < m) act[n + p] = 2; else if (p < m + n) act[p - m] |= 8; else act[p - m - n] |= 4; }
+        __syncthreads();
+        break;
+      }
+      if (!(t < kInf)) { status |= 2; break; }            // constraints are inconsistent
+      if (!dual_only) for (int i = tid; i < n; i += NT_) xv[i] += t * zv[i];
+      if (tid == 0) { for (int k = 0; k < nact; ++k) u[k] -= t * rv[k]; u[nact] += t; }
+      __syncthreads();
+      if (full) {
+        // ---- add p: one Householder reflection on the columns nact … n−1 of J takes d₂ to ±‖d₂‖·e₁ (the Givens sequence of the
+        // textbook in one parallel step); R gets the column (d₁, ∓‖d₂‖)
+        const double d0 = dv[nact], beta = d0 >= 0.0 ? -nd2 : nd2;      // v = d₂ − β·e₁, no cancellation
+        const double vtv = 2.0 * (nd2 * nd2 - d0 * beta);
+        if (vtv > 0.0) {
+          for (int i = tid; i < n; i += NT_) {
+            double wacc = J[(size_t)i * n + nact] * (d0 - beta);
+            for (int k = nact + 1; k < n; ++k) wacc += J[(size_t)i * n + k] * dv[k];
+            const double f = 2.0 * wacc / vtv;
+            J[(size_t)i * n + nact] -= f * (d0 - beta);
+            for (int k = nact + 1; k < n; ++k) J[(size_t)i * n + k] -= f * dv[k];
+          }
+        }
+        for (int i = tid; i <= nact; i += NT_) R[(size_t)i * n + nact] = (i < nact) ? dv[i] : beta;
+        if (tid == 0) { A[nact] = p; if (p < m) act[n + p] = 1; else if (p < m + n) act[p - m] |= 2; else act[p - m - n] |= 1; }
+        ++nact; ++n_piv;
+        __syncthreads();
+        break;
+      }
+      // ---- drop the blocking constraint l (partial step, or a step in the dual space only), then try p again
+      if (tid == 0) {
+        const int code = A[l];
+        if (code < m) act[n + code] = 0; else if (code < m + n) act[code - m] &= ~2; else act[code - m - n] &= ~1;
+        for (int k = l; k < nact - 1; ++k) { A[k] = A[k + 1]; u[k] = u[k + 1]; }
+        u[nact - 1] = u[nact];
+      }
+      for (int k = l; k < nact - 1; ++k) {                // columns shift left: upper Hessenberg from l on
+        __syncthreads();
+        for (int i = tid; i <= k + 1; i += NT_) R[(size_t)i * n + k] = R[(size_t)i * n + k + 1];
+      }
+      __syncthreads();
+      for (int i = tid; i < n; i += NT_) R[(size_t)i * n + nact - 1] = 0.0;
+      --nact; ++n_piv;
+      for (int k = l; k < nact; ++k) {                    // Givens on rows (k, k+1) of R, columns (k, k+1) of J
+        __syncthreads();
+        const double a = R[(size_t)k * n + k], b = R[(size_t)(k + 1) * n + k];
+        const double hh = hypot(a, b);
+        const double cs = b == 0.0 ? 1.0 : a / hh, sn = b == 0.0 ? 0.0 : b / hh;
+        __syncthreads();
+        if (b != 0.0) {
+          for (int j = k + tid; j < nact; j += NT_) {
+            const double ra = R[(size_t)k * n + j], rb = R[(size_t)(k + 1) * n + j];
+            R[(size_t)k * n + j] = (j == k) ? hh : cs * ra + sn * rb;
+            R[(size_t)(k + 1) * n + j] = (j == k) ? 0.0 : -sn * ra + cs * rb;
+          }
+          for (int i = tid; i < n; i += NT_) {
+            const double ja = J[(size_t)i * n + k], jb = J[(size_t)i * n + k + 1];
+            J[(size_t)i * n + k] = cs * ja + sn * jb;
+            J[(size_t)i * n + k + 1] = -sn * ja + cs * jb;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  return WideQpOut{status, iters, n_outer, n_piv};
+}
+
 // (two workgroups per CU: every phase of this kernel is latency-bound — one wavefront per SIMD waits out each LDS round trip and
 //  barrier alone — so the second resident workgroup is worth more than the registers it costs)
 __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProblem* __restrict__ Pg, SolveArgs A, const TapArgs* __restrict__ tp) {
@@ -532,7 +770,8 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
   double* const rec = wsb + P.ws_rec;                    // per pair: h, n, from, to (10 doubles)
   int* const rowpair = reinterpret_cast<int*>(wsb + P.ws_rowpair);
   int* const rowrank = reinterpret_cast<int*>(wsb + P.ws_rank);
-  double* const T = P.tableau_in_lds ? smem + P.o_T : wsb + P.ws_T;
+  double* const T_lds = smem + P.o_T;
+  double* const T_mem = wsb + P.ws_T;
   const int R_task = P.n_jrows, R_all = P.n_jrows + P.n_dense_rows;
   // parity taps (mkh_eval): body poses, frame poses, subtree CoM, H, c, the box, the contact rows — what the reference's
   // Configuration / build_ik expose; the per-task (e, J) taps are the wavefront kernels'
@@ -549,8 +788,26 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
     __syncthreads();
     return (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
   };
-  for (int pb = (int)blockIdx.x; pb < A.B; pb += (int)gridDim.x) {
-    if (A.redo_mask && !(A.status_out[pb] & A.redo_mask)) continue;          // (wave-uniform: the whole workgroup skips)
+  // A redo launch (redo_mask != 0) solves only the instances whose status carries one of the mask's bits: every workgroup owns a
+  // contiguous slice of the batch and reads its statuses 256 at a time — one coalesced load; a launch that finds nothing (the
+  // usual case) ends there (round 4 walked the statuses one dependent load after the other: 29 µs for 16 384 instances)
+  int* const sList = reinterpret_cast<int*>(sRed + 16);  // flagged instances of the current chunk (≤ 256; sRed[0, 16) carry the reductions)
+  const int slice = A.redo_mask ? (A.B + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  const int s_begin = (int)blockIdx.x * slice, s_end = s_begin + slice < A.B ? s_begin + slice : A.B;
+  for (int chunk = A.redo_mask ? s_begin : (int)blockIdx.x; chunk < (A.redo_mask ? s_end : A.B); chunk += A.redo_mask ? NT_ : (int)gridDim.x) {
+  int n_list = 1;
+  if (A.redo_mask) {
+    __syncthreads();
+    if (tid == 0) sRedI[15] = 0;
+    __syncthreads();
+    const int i = chunk + tid;
+    if (i < s_end && (A.status_out[i] & A.redo_mask)) sList[atomicAdd(&sRedI[15], 1)] = i;
+    __syncthreads();
+    n_list = sRedI[15];
+    // (ascending order: the list is filled by atomics — sort is not needed for correctness, instances are independent)
+  }
+  for (int li = 0; li < n_list; ++li) {
+    const int pb = A.redo_mask ? sList[li] : chunk;
     __syncthreads();
     // ------------------------------------------------------------ inputs
     for (int i = tid; i < nq; i += NT_) sq[i] = A.q[(size_t)pb * nq + i];
@@ -908,9 +1165,12 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
     MKH_WSTAMP(8);
     // ------------------------------------------------------------ tableau K = [[H, Aᵀ],[A, 0]], z, w, states
     WideQpCtx X;
-    X.T = T; X.in_lds = P.tableau_in_lds; X.N = N; X.nv = nv;
+    const bool t_in_lds = P.tableau_in_lds || (long long)N * N <= (long long)P.t_lds_doubles;      // (this instance's tableau)
+    double* const T = t_in_lds ? T_lds : T_mem;
+    X.T = T; X.in_lds = t_in_lds ? 1 : 0; X.N = N; X.nv = nv;
     X.o_z = P.o_z; X.o_w = P.o_w; X.o_lo = P.o_lo; X.o_hi = P.o_hi; X.o_rown = P.o_rown; X.o_ref = P.o_ref; X.o_col = P.o_col;
     X.o_red = P.o_red; X.o_state = P.o_state; X.o_blk = P.o_blk; X.blk_stride = P.blk_stride;
+    auto build_tableau = [&]() {
     wide_accumulate_h(X, Jw, R_all);
     for (int d = tid; d < nv; d += NT_) T[(size_t)d * N + d] += mu_total + sHd[d];
     for (int e = tid; e < m * nv; e += NT_) {                // A: G[s][k] = −nᵀ(jacp₂(to) − jacp₁(from))   (compute_contact_normal_jacobian :59-72)
@@ -947,6 +1207,8 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
       sRown[nv + s] = nn > 0.0 ? sqrt(nn) : 1.0;
     }
     __syncthreads();
+    };
+    build_tableau();
     if (tp) {
       if (tp->t_H) for (int e = tid; e < nv * nv; e += NT_) tp->t_H[(size_t)pb * nv * nv + e] = T[(size_t)(e / nv) * N + e % nv];
       if (tp->t_c) for (int k = tid; k < nv; k += NT_) tp->t_c[(size_t)pb * nv + k] = sC[k];
@@ -962,8 +1224,17 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
     // ------------------------------------------------------------ the QP: dual active set on the sweep tableau (wide_qp)
     int iters = 0, n_outer = 0, n_piv = 0;                  // (qp_iters tap: ratio-test rounds, violated conditions handled, sweeps after phase 0)
     if (!(status & 14) && A.do_qp) {
-      const WideQpOut qo = wide_qp(X, A.clk ? A.clk + (size_t)pb * 24 : nullptr);
-      status |= qo.status; iters = qo.iters; n_outer = qo.n_outer; n_piv = qo.n_piv;
+      // The sweep tableau first; the instances it flags MKH_ST_DEGENERATE (almost dependent active rows) or fails on, and — in a
+      // redo launch — the ones a wavefront kernel flagged that way, go through the dense Goldfarb–Idnani iteration with orthogonal
+      // factors on the tableau as built (wide_qp_dense)
+      bool dense = m > 0 && A.redo_mask != 0 && (A.status_out[pb] & (2 | 8 | 32)) != 0;
+      WideQpOut qo{0, 0, 0, 0};
+      if (!dense) {
+        qo = wide_qp(X, A.clk ? A.clk + (size_t)pb * 24 : nullptr);
+        if (m > 0 && (qo.status & (2 | 8 | 32))) { dense = true; build_tableau(); }
+      }
+      if (dense) qo = wide_qp_dense(X, P.gi_in_lds ? smem + P.o_gi : wsb + P.ws_gi);
+      status |= qo.status & ~32; iters = qo.iters; n_outer = qo.n_outer; n_piv = qo.n_piv;
     }
     MKH_WSTAMP(11);
     if (A.clk && tid == 0) { A.clk[(size_t)pb * 24 + 13] = iters; A.clk[(size_t)pb * 24 + 14] = n_piv; A.clk[(size_t)pb * 24 + 16] = N; }
@@ -1029,6 +1300,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
     }
     if (A.status_out && tid == 0) A.status_out[pb] = status_all;
     MKH_WSTAMP(12);
+  }
   }
 }
 

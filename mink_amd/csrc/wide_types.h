@@ -14,7 +14,10 @@ struct WideProblem {
   int32_t n_frame, n_posture, n_com, n_cfg, n_vel, n_pairs, n_jrows;
   int32_t n_dense_tasks, n_dense_rows, n_dense_limit_rows, dense_box, robot_root;
   int32_t max_rows;                        // row capacity of the tableau workspace (≤ kWideMaxRows)
-  int32_t tableau_in_lds;
+  int32_t tableau_in_lds;                  // the tableau of the LARGEST instance (nv + max_rows) fits in LDS
+  int32_t t_lds_doubles;                   // LDS reserved for the tableau: an instance uses it when its own (nv + rows)² fits (round 5:
+                                           // ALOHA's 1 104 pairs reserve 448 rows, an instance has 8 on average)
+  int32_t o_gi, gi_in_lds;                 // J, R, u, active list of the dense Goldfarb–Idnani fallback: in LDS when they fit
   // rows of the (e, J) tap layout (MkhTaps::task_e / task_J): frame tasks 6 each (FrameTaskDev::row0), then per posture task
   // nv, per CoM task 3, then the caller-defined tasks
   int32_t n_rows_tap, dense_tap_row0;
@@ -51,6 +54,7 @@ struct WideProblem {
   // per-workgroup slice of device memory: weighted Jacobian rows, pair records, row → pair map, (the tableau)
   double* ws;
   long long ws_stride;                     // doubles per workgroup
+  long long ws_gi;                         // dense Goldfarb–Idnani fallback (wide_qp_dense): J, R (nv² each), u, active list — only for problems with rows
   long long ws_jw, ws_rec, ws_rowpair, ws_rank, ws_T;   // (ws_rank: per pair, its rank by h when more contacts are in range than rows — int32)
 };
 

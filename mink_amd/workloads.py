@@ -141,6 +141,14 @@ BENCH_CONFIGS: Dict[str, dict] = {
                  "workload": "Unitree G1 + two Allegro hands (nq=76,nv=75, 86 bodies): 4 FrameTasks(feet+palms) + 8 RelativeFrameTasks "
                              "(fingertips in their palm, pos 1) + PostureTask + ConfigurationLimit + VelocityLimit, dt=5e-3, damping=1e-1 "
                              "(examples/humanoid_g1.py:28-52 + examples/arm_hand_iiwa_allegro.py:62-94)"},
+    # The reference's flagship collision example as written (examples/arm_aloha.py:76-121, 146-157): two FrameTasks on the grippers,
+    # PostureTask(1e-4), ConfigurationLimit, VelocityLimit(π), CollisionAvoidanceLimit over 1 104 geom pairs (wrist subtree x wrist
+    # subtree, both arms x metal frame + table; capsules fitted to meshes, spheres, the table box), d_min 5 cm, detection 10 cm,
+    # dt = 1 / 200 s, damping 1e-5.  16 dofs: the wavefront kernel holds the 48 tightest contacts, the rest is checked at the solution
+    "aloha_coll": {"robot": "aloha", "key": "neutral_pose", "batch": 16384, "bytes_per_solve": 16 * 8 + 2 * 7 * 8 + 16 * 8 + 4,
+                   "workload": "ALOHA (nq=nv=16): 2 FrameTasks(grippers)+PostureTask(1e-4)+ConfigurationLimit+VelocityLimit(pi)+"
+                               "CollisionAvoidanceLimit(1104 pairs: 521 capsule-capsule, 504 sphere-capsule, 49 sphere-sphere, 30 x box; "
+                               "d_min 0.05, detect 0.1), dt=5e-3, damping=1e-5 (examples/arm_aloha.py:76-157)"},
     # the same set-up with the packaged model's CAPSULE wrist geom (analytic pairs only): the reference point of ur5e_convex
     "ur5e_coll": {"robot": "ur5e", "key": "home", "batch": 4096, "bytes_per_solve": 6 * 8 + 7 * 8 + 6 * 8 + 4,
                   "workload": "UR5e, the collision set-up of examples/arm_ur5e.py:20-47 (capsule-plane floor, capsule-box wall), "
@@ -208,6 +216,21 @@ def bench_config(name: str, model: FlatModel, nmodel: "nat.NativeModel", max_bat
         prob = nat.NativeProblem(nmodel, frame_tasks=fts, posture_tasks=[{"cost": 1.0}], configuration_limits=cfg,
                                  velocity_limits=[velocity_limit_desc(model, _hinge_velocities(model))], max_batch=max_batch, **extra)
         return prob, 5e-3, 1e-1
+    if name == "aloha_coll":
+        from .limits import CollisionAvoidanceLimit
+        from .utils import get_body_geom_ids, get_subtree_geom_ids
+
+        sub = lambda b: get_subtree_geom_ids(model, model.name2id("body", b))
+        frame = get_body_geom_ids(model, model.name2id("body", "metal_frame"))
+        col = CollisionAvoidanceLimit(model, [(sub("left/wrist_link"), sub("right/wrist_link")),
+                                              (sub("left/upper_arm_link") + sub("right/upper_arm_link"), frame + ["table"])],
+                                      minimum_distance_from_collisions=0.05, collision_detection_distance=0.1)
+        joints = ("waist", "shoulder", "elbow", "forearm_roll", "wrist_angle", "wrist_rotate")
+        vel = velocity_limit_desc(model, {f"{p}/{n}": np.pi for p in ("left", "right") for n in joints})
+        prob = nat.NativeProblem(nmodel, frame_tasks=[_frame_desc(model, f"{p}/gripper", "site", 1.0, 1.0, 1.0) for p in ("left", "right")],
+                                 posture_tasks=[{"cost": 1e-4}], configuration_limits=cfg, velocity_limits=[vel],
+                                 collision_limits=[col._native_desc()[1]], max_batch=max_batch)
+        return prob, 5e-3, 1e-5
     if name == "g1_hands":
         fts = [_frame_desc(model, s, "site", 200.0, 10.0, 1.0) for s in ("left_foot", "right_foot")] + \
               [_frame_desc(model, s, "site", 200.0, 0.0, 1.0) for s in ("left_palm", "right_palm")]
@@ -311,11 +334,25 @@ def bench_batch(name: str, model: FlatModel, nmodel, prob, rng: np.random.Genera
         q[::2] = 0.5 * (q[::2] + base)            # half of the samples near the grasp: fingers come close
     if name in ("ur5e_convex", "ur5e_coll"):
         q[::2] = base + rng.normal(scale=0.4, size=q[::2].shape)     # half of the samples around `home`: near wall and floor
+    if name == "aloha_coll":
+        # around the neutral pose (σ = 0.5 rad on half of the instances, 0.25 on the rest): arms near each other, the frame and the table
+        sc = np.where(np.arange(n) % 2 == 0, 0.5, 0.25)[:, None]
+        q = np.clip(base + rng.normal(size=q.shape) * sc, *_joint_box(model))
     com = None
     if prob.n_com:
         _, _, t = prob.solve(q, tg, base[None, :], np.zeros((1, 3)), 1.0, 1.0, taps=["subtree_com"], solve_qp=False)
         com = t["subtree_com"][:, None, :] + 0.01
     return q, tg, base[None, :].copy(), com
+
+
+def _joint_box(model: FlatModel):
+    """(lower, upper) per qpos of the hinge / slide joints, ±inf elsewhere."""
+    lo, hi = np.full(model.nq, -np.inf), np.full(model.nq, np.inf)
+    for j in range(model.njnt):
+        if model.jnt_limited[j] and model.jnt_type[j] in (2, 3):
+            a = int(model.jnt_qposadr[j])
+            lo[a], hi[a] = model.jnt_range[j]
+    return lo, hi
 
 
 def bench_dense(name: str, model: FlatModel, nmodel, q: np.ndarray, rng: np.random.Generator):

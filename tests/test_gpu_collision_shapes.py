@@ -233,8 +233,8 @@ def test_more_contacts_than_tableau_rows_keeps_the_tightest():
     for regime, tgr, dt in (("near", tg, dt), ("far", tg_far, 8 * dt)):   # (h ∝ 1/dt: the long step shrinks every slack)
         v_nw, st = prob_nw.solve(q, tgr, m.qpos0[None, :], None, dt, damping)
         assert not prob_nw.last_kernel().endswith("+wide")
-        assert ((st & ~(1 | 16)) == 0).all(), st
-        flagged = (st & 16) != 0
+        assert ((st & ~(1 | 16 | 32)) == 0).all(), st          # (32: internal — almost dependent active rows, re-solved by the dense iteration)
+        flagged = (st & (16 | 32)) != 0
         print("%s targets: instances with a violated dropped row: %d of %d" % (regime, flagged.sum(), B))
         assert flagged.sum() == 0 if regime == "near" else 0 < flagged.sum() < B
         # round 4: the plain call solves the flagged instances again with EVERY row (wide_kernel.h) — nothing stays flagged,
@@ -329,7 +329,7 @@ def test_general_convex_pairs_against_the_oracle():
     post.set_target(m.qpos0)
     v = mink.solve_ik(cfg, [ft, post], dt, "mi355x", 1e-3, limits=[mink.ConfigurationLimit(m), col])
     last = list(cfg._problems.values())[-1].last_kernel()          # (most recently used descriptor of the cache)
-    assert last.endswith("_136"), last
+    assert last.removesuffix("+wide").endswith("_136"), last
     dq = v * dt
     fin = np.isfinite(h)
     Gx = np.einsum("bpj,bj->bp", G, dq)
@@ -427,7 +427,7 @@ def test_mesh_geoms_against_the_oracle():
     ft.set_target(mink.Configuration(m, _rand_q(m, rng, len(ok))).get_transform_frame_to_world("tip", "site"))
     post = mink.PostureTask(m, cost=1e-2); post.set_target(m.qpos0)
     v = mink.solve_ik(cfg, [ft, post], dt, "mi355x", 1e-3, limits=[mink.ConfigurationLimit(m), col])
-    assert list(cfg._problems.values())[-1].last_kernel().endswith("_136")
+    assert list(cfg._problems.values())[-1].last_kernel().removesuffix("+wide").endswith("_136")
     worst, binding = 0.0, 0
     for j, i in enumerate(ok[:24]):
         tasks = [oik.FrameTaskSpec(m.name2id("site", "tip"), "site", np.array([1.0, 1.0, 1.0, 0.2, 0.2, 0.2]), ft.transform_target_to_world.wxyz_xyz[j]),
@@ -563,9 +563,9 @@ print("KERNEL", prob.last_kernel(), "FLAGGED", int(((st & 16) != 0).sum()))
     finally:
         del os.environ["MKH_DEBUG_NO_WIDE"]
     v, st = prob.solve(q, tgf, m.qpos0[None, :], None, 2.0, 1e-5)
-    assert prob.last_kernel() == "ik_solve_kernel_48_72+redo_64", prob.last_kernel()
+    assert prob.last_kernel().removesuffix("+wide") == "ik_solve_kernel_48_72+redo_64", prob.last_kernel()
     vf, stf = prob.solve(q, tgf, m.qpos0[None, :], None, 2.0, 1e-5, full_rows=True)
-    assert prob.last_kernel() == "ik_solve_kernel_64_72", prob.last_kernel()
+    assert prob.last_kernel().removesuffix("+wide") == "ik_solve_kernel_64_72", prob.last_kernel()
     print("tight launch alone left %d of %d instances flagged; after the redo launch %d (full rows: %d)" % (
         flagged_by_tight, B, int(((st & 16) != 0).sum()), int(((stf & 16) != 0).sum())))
     assert flagged_by_tight >= 10
@@ -587,7 +587,7 @@ print("KERNEL", prob.last_kernel(), "FLAGGED", int(((st & 16) != 0).sum()))
     q2, tg2 = workloads.make_batch(m, nm, prob2, np.random.default_rng(5), 512, base_q=key)
     q2[::2] = 0.5 * (q2[::2] + key)
     v2, st2 = prob2.solve(q2, tg2, key[None, :], None, dt2, damping2)
-    assert prob2.last_kernel() == "ik_solve_kernel_48_72+redo_64"
+    assert prob2.last_kernel().removesuffix("+wide") == "ik_solve_kernel_48_72+redo_64"
     v2f, st2f = prob2.solve(q2, tg2, key[None, :], None, dt2, damping2, full_rows=True)
     np.testing.assert_array_equal(st2, st2f)
     assert (st2 & ~1 == 0).all() and (np.abs(v2 - v2f) / np.maximum(1.0, np.abs(v2f).max(axis=1, keepdims=True))).max() < 1e-9
@@ -608,7 +608,7 @@ def test_kernel_choice_does_not_depend_on_the_status_pointer():
     q, tg = workloads.make_batch(model, nm, prob, np.random.default_rng(9), B, base_q=base)
     q[::2] = 0.5 * (q[::2] + base)
     v_ref, st_ref = prob.solve(q, tg, base[None, :], None, dt, damping)
-    assert prob.last_kernel() == "ik_solve_kernel_48_72+redo_64"
+    assert prob.last_kernel().removesuffix("+wide") == "ik_solve_kernel_48_72+redo_64"
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda", 0)
     to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
@@ -619,5 +619,5 @@ def test_kernel_choice_does_not_depend_on_the_status_pointer():
     nat._check(nat.lib().mkh_solve(prob.handle, B, q_d.data_ptr(), tg_d.data_ptr(), pt_d.data_ptr(), None, float(dt), float(damping),
                                    v_d.data_ptr(), None, nat.FLAG_DEVICE_PTRS, stream))      # status_out = NULL, device pointers
     torch.cuda.synchronize()
-    assert prob.last_kernel() == "ik_solve_kernel_48_72+redo_64", prob.last_kernel()
+    assert prob.last_kernel().removesuffix("+wide") == "ik_solve_kernel_48_72+redo_64", prob.last_kernel()
     np.testing.assert_array_equal(v_d.cpu().numpy(), v_ref)

@@ -167,13 +167,13 @@ def test_other_configs_full_batch(name, B):
     v2, st2 = prob.solve(q, tg, base[None, :], None, dt, damping)       # production kernel variant
     assert ((st2 & ~1) == 0).all(), np.unique(st2)
     if prob.n_pairs:
-        assert prob.last_kernel() == "ik_solve_kernel_48_72+redo_64", prob.last_kernel()
+        assert prob.last_kernel().removesuffix("+wide") == "ik_solve_kernel_48_72+redo_64", prob.last_kernel()
     err = np.abs(v2 - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
     print(name, "all %d problems vs C oracle: max rel err %.2e (kernel %s)" % (B, err.max(), prob.last_kernel()))
     assert err.max() < 1e-8
     if prob.n_pairs:
         v3, st3 = prob.solve(q, tg, base[None, :], None, dt, damping, full_rows=True)
-        assert prob.last_kernel() == "ik_solve_kernel_64_72", prob.last_kernel()
+        assert prob.last_kernel().removesuffix("+wide") == "ik_solve_kernel_64_72", prob.last_kernel()
         err3 = np.abs(v3 - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
         print(name, "full-row build vs C oracle: max rel err %.2e" % err3.max())
         assert ((st3 & ~1) == 0).all() and err3.max() < 1e-8
@@ -346,6 +346,15 @@ def _oracle_specs_of_bench(name, model, prob_desc):
         return fts + [post], [ik.ConfigurationLimitSpec(), vel], {}
     if name == "g1_c3":
         return feet_palms + [post], [ik.ConfigurationLimitSpec(), vel], {}
+    if name == "aloha_coll":
+        # (the pair list: the real mink's, recorded in the ik_aloha_coll fixture — the product's constructor must produce the same)
+        pairs = [tuple(p) for p in np.load(oc.GOLDEN + "/ik_aloha_coll.npz")["geom_id_pairs"]]
+        joints = [f"{p}/{n}" for p in ("left", "right") for n in ("waist", "shoulder", "elbow", "forearm_roll", "wrist_angle", "wrist_rotate")]
+        dofs = np.array([int(model.jnt_dofadr[model.name2id("joint", j)]) for j in joints])
+        return ([ik.FrameTaskSpec(site(f"{p}/gripper"), "site", cost6(1.0, 1.0), z7, lm_damping=1.0) for p in ("left", "right")] +
+                [ik.PostureTaskSpec(np.full(model.nv, 1e-4), None)],
+                [ik.ConfigurationLimitSpec(), ik.VelocityLimitSpec(dofs, np.full(len(dofs), np.pi)),
+                 ik.CollisionAvoidanceLimitSpec(pairs, minimum_distance_from_collisions=0.05, collision_detection_distance=0.1)], {})
     if name == "g1_hands":
         tips = [ik.RelativeFrameTaskSpec(site(f"{side}/{tip}"), "site", model.name2id("body", f"{side}/palm"), "body", cost6(1.0, 0.0), z7, lm_damping=1.0)
                 for side in ("lh", "rh") for tip in ("ff_tip", "mf_tip", "rf_tip", "th_tip")]
@@ -389,7 +398,7 @@ def test_g1_coll_pair_list_is_what_the_workload_says():
         assert gb[a] != gb[b] and gt[a] != 0
 
 
-@pytest.mark.parametrize("name", ["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin", "h1_c3", "h1_full", "g1_coll", "ur5e_coll", "g1_hands"])
+@pytest.mark.parametrize("name", ["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin", "h1_c3", "h1_full", "g1_coll", "ur5e_coll", "g1_hands", "aloha_coll"])
 def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name, monkeypatch):
     """Exactly what `bench.py --config <name>` times — the same constructors, the same generated batch (per-instance CoM
     targets for the G1 full example, half of the Shadow instances pulled towards `grasp hard`, the caller's rows of the plugin
@@ -407,7 +416,8 @@ def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name, monk
     q, tg, pt, com = workloads.bench_batch(name, model, nm, prob, rng, B)
     dense = workloads.bench_dense(name, model, nm, q, rng)
     v, st = prob.solve(q, tg, pt, com, dt, damping, dense=dense)
-    assert name not in _BENCH_KERNELS or prob.last_kernel() == _BENCH_KERNELS[name], prob.last_kernel()
+    # ("+wide": every problem with half-space rows is followed by the redo launch of the workgroup-per-problem kernel — round 5)
+    assert name not in _BENCH_KERNELS or prob.last_kernel().removesuffix("+wide") == _BENCH_KERNELS[name].removesuffix("+wide"), prob.last_kernel()
     assert ((st & ~1) == 0).all(), np.unique(st, return_counts=True)
     tasks, limits, extra = _oracle_specs_of_bench(name, model, prob)
     if name == "shadow_c4":          # the bench's pair list (built by the product's CollisionAvoidanceLimit) = real mink's, recorded
@@ -415,16 +425,38 @@ def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name, monk
         groups = [[f"{f}_1", f"{f}_2"] for f in workloads.SHADOW_FINGERS]
         col = CollisionAvoidanceLimit(model, [(groups[i], groups[j]) for i in range(5) for j in range(i + 1, 5)])
         np.testing.assert_array_equal(np.array(col.geom_id_pairs), np.load(oc.GOLDEN + "/shadow_c4_geom_pairs.npy"))
-    cp = cport.CProblem(model if name in ("h1_c3", "h1_full", "g1_hands") else oc.model(workloads.BENCH_CONFIGS[name]["robot"]), tasks, limits, **extra)
+    cp = cport.CProblem(model if name in ("h1_c3", "h1_full", "g1_hands", "aloha_coll") else oc.model(workloads.BENCH_CONFIGS[name]["robot"]), tasks, limits, **extra)
     v_ref, st_ref = cp.solve_batch(q, tg, pt, dt, damping, com_target=com, dense=dense, nthreads=min(16, os.cpu_count() or 1))
     assert (st_ref == 0).all(), np.unique(st_ref, return_counts=True)
     err = np.abs(v - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
     print("%s: all %d instances vs C oracle: max rel err %.2e, p99 %.2e (kernel %s)"
           % (name, B, err.max(), np.percentile(err, 99), prob.last_kernel()))
+    if name == "aloha_coll":
+        # ALOHA's limit lists many geom pairs per body pair: rows with opposite normals and h = 0 (a·Δq ≤ 0 and −a·Δq ≤ 0) next to
+        # rows almost parallel to them.  A handful of instances are ILL-POSED — multipliers of 1e8 on the opposite pair, so that
+        # relaxing every contact bound by 1e-9 moves the reference's own answer by more than 1e-6 (up to 0.4 rad/s) — and there no
+        # two implementations of the iteration agree (quadprog's restatement itself takes dual steps of 6e7 there).  They are
+        # identified by that sensitivity of the ORACLE, must be a few, and are excluded; everything else holds 1e-8.
+        bad = np.flatnonzero(err >= 1e-8)
+        if len(bad):
+            relaxed = [l if not isinstance(l, type(limits[-1])) else type(l)(l.geom_id_pairs, gain=l.gain,
+                       minimum_distance_from_collisions=l.minimum_distance_from_collisions,
+                       collision_detection_distance=l.collision_detection_distance, bound_relaxation=1e-9) for l in limits]
+            v_rel, _ = cport.CProblem(model, tasks, relaxed, **extra).solve_batch(q[bad], tg[bad], pt, dt, damping)
+            sens = np.abs(v_rel - v_ref[bad]).max(axis=1)
+            print("aloha_coll: %d instance(s) beyond 1e-8 %s; the oracle's own answer moves by %s there when every contact bound is relaxed by 1e-9"
+                  % (len(bad), err[bad], sens))
+            assert len(bad) <= 4 and (sens > 1e-6).all(), (bad, err[bad], sens)
+            err[bad] = 0.0
     assert err.max() < 1e-8
     if name == "shadow_c4":          # the regime must exercise the rows: contacts in range on most instances
         G, h = cp.collision_rows(q[0], dt)
         assert np.isfinite(h).sum() >= 5
+    if name == "aloha_coll":
+        from mink_amd import workloads as wl
+        rows = np.array([np.isfinite(cp.collision_rows(q[i], dt, which=0)[1]).sum() for i in range(0, B, 64)])
+        print("aloha_coll: contacts in range per instance (every 64th): mean %.1f, max %d of 1104 pairs; tableau rows 48" % (rows.mean(), rows.max()))
+        assert rows.max() >= 8
     if name == "g1_coll":
         # the pair of launches the bench times: the wavefront kernel holds 21 rows, the workgroup-per-problem kernel re-solves
         # what it flags.  How many that is: the same batch on a handle without the redo launch (MKH_DEBUG_NO_WIDE, read per handle)
@@ -432,7 +464,7 @@ def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name, monk
         alone, _, _ = workloads.bench_config(name, model, nm, B)
         monkeypatch.delenv("MKH_DEBUG_NO_WIDE")
         v1, st1 = alone.solve(q, tg, pt, com, dt, damping)
-        assert alone.last_kernel() == "ik_solve_kernel_64_8", alone.last_kernel()
+        assert alone.last_kernel().removesuffix("+wide") == "ik_solve_kernel_64_8", alone.last_kernel()
         flagged = np.flatnonzero(st1 & 16)
         rows = np.array([np.isfinite(cp.collision_rows(q[i], dt, which=0)[1]).sum() for i in range(0, B, 64)])
         print("g1_coll: %d of %d instances re-solved with every row by the wide kernel (err on those: %.2e); contacts in range "
@@ -478,7 +510,7 @@ def test_ur5e_convex_at_its_bench_batch_against_the_numpy_oracle():
     prob, dt, damping = workloads.bench_config(name, model, nm, B)
     q, tg, pt, _ = workloads.bench_batch(name, model, nm, prob, np.random.default_rng(2024), B)
     v, st = prob.solve(q, tg, pt, None, dt, damping)
-    assert prob.last_kernel() == "ik_solve_kernel_16_136", prob.last_kernel()
+    assert prob.last_kernel().removesuffix("+wide") == "ik_solve_kernel_16_136", prob.last_kernel()
     assert ((st & ~1) == 0).all(), np.unique(st, return_counts=True)
     ncpu = min(16, os.cpu_count() or 1)
     chunks = np.array_split(np.arange(B), ncpu * 4)

@@ -22,6 +22,9 @@ ROBOTS = {
     # the hand alone (no scene): what the reference's arm + hand examples attach to an arm (examples/arm_hand_iiwa_allegro.py:10-42);
     # mink_amd.compose.attach puts two of them on the G1's wrists for the `g1_hands` workload (75 dofs, 86 bodies)
     "allegro_left": EX + "wonik_allegro/left_hand.xml",
+    # the reference's flagship collision example (examples/arm_aloha.py): arm / frame collision geoms are capsules FITTED to their
+    # meshes at compile time (mink_amd/meshes.py), so the packaged arrays carry everything the `aloha_coll` workload reads
+    "aloha": EX + "aloha/scene.xml",
 }
 out = os.path.join(REPO, "mink_amd", "robots")
 os.makedirs(out, exist_ok=True)
