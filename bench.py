@@ -262,6 +262,21 @@ def measure_side_config(name, dev, steps=20, warmup=3, batch=None, seed=2000):
     kern_ms = sum(ms) / len(ms)
     status = st.cpu().numpy()
     kernel = prob.last_kernel()
+    redo = None
+    if kernel.endswith("+wide"):
+        # how many instances the second launch of the pair re-solved (more contacts in range than tableau rows and one violated, or
+        # almost dependent active rows): the same batch on a handle WITHOUT the redo launch (MKH_DEBUG_NO_WIDE is read per handle)
+        os.environ["MKH_DEBUG_NO_WIDE"] = "1"
+        try:
+            alone, _, _ = workloads.bench_config(name, model, nm, B)
+        finally:
+            del os.environ["MKH_DEBUG_NO_WIDE"]
+        st1 = torch.empty((B,), dtype=torch.int32, device=dev)
+        alone.solve(q, tg, pt, ct, dt, damping, out=torch.empty_like(v), status_out=st1, dense=dense)
+        s1 = st1.cpu().numpy()
+        redo = {"row_overflow": int(((s1 & 16) != 0).sum()), "almost_dependent_rows": int(((s1 & 32) != 0).sum()),
+                "failed_on_the_tableau": int(((s1 & (2 | 8)) != 0).sum()), "of": B}
+        alone.close()
     bps = cfg["bytes_per_solve"]
     ach = bps * B / (kern_ms * 1e-3) / 1e9
     traffic, chk = measured_traffic(name, B, kernel)
@@ -276,13 +291,38 @@ def measure_side_config(name, dev, steps=20, warmup=3, batch=None, seed=2000):
            "vgpr_spills": res.get("vgpr_spills"), "sgpr_spills": res.get("sgpr_spills"),
            "scratch_bytes_per_lane": res.get("scratch_bytes_per_lane"), "waves_per_simd": res.get("occupancy_waves_per_simd"),
            "failed_instances": int(((status & ~1) != 0).sum()),
-           "active_half_spaces_note": None, "workload": cfg["workload"]}
-    out.pop("active_half_spaces_note")
+           "redo_instances": redo, "workload": cfg["workload"]}
+    if redo is None:
+        out.pop("redo_instances")
     prob.close()
     return out
 
 
 SIDE_CONFIGS = ("ur5e_c2", "shadow_c4", "g1_full", "g1_plugin", "ur5e_convex", "g1_coll", "h1_c3", "h1_full", "g1_hands", "aloha_coll")
+
+
+def batch_sweep(prob, q, tg, pt, ct, dt, damping, v, st, batches=(1, 256, 1024, 4096, 16384, 65536), reps=20):
+    """The headline problem at smaller batches (RL-sized callers run 1 k - 4 k environments): slices of the resident batch on the
+    same handle, `reps` launches each between HIP events; kernel ms = the median launch.  One solve alone is the latency of the
+    kernel's dependent instruction stream, a full machine needs 3 072 resident wavefronts."""
+    import torch
+    out = []
+    for b in batches:
+        if b > q.shape[0]:
+            continue
+        qs, ts, vs, ss = q[:b], tg[:b], v[:b], st[:b]
+        cs = None if ct is None else (ct[:b] if ct.shape[0] == q.shape[0] else ct)
+        for _ in range(3):
+            prob.solve(qs, ts, pt, cs, dt, damping, out=vs, status_out=ss)
+        ev = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); prob.solve(qs, ts, pt, cs, dt, damping, out=vs, status_out=ss); e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+        ms = statistics.median(a.elapsed_time(b_) for a, b_ in ev)
+        out.append({"batch": b, "kernel": prob.last_kernel(), "kernel_ms": ms, "solves_per_s": b / (ms * 1e-3)})
+    return out
 
 
 def pcie_inclusive(prob, q_h, tg_h, pt_h, ct_h, dt, damping, reps=5):
@@ -571,6 +611,13 @@ def main():
     gc.enable()
     kern_ms = sum(kern_list) / len(kern_list)             # average launch duration of the solve kernel (roofline)
     kern_ms_median = statistics.median(kern_list)
+    # N > 1: what every rank saw on its own device (all-gathered), so that a scaling curve explains itself — a slow rank, a shared
+    # device or a throttled one shows up as ITS kernel time, not as a lower total
+    per_rank = [{"rank": rank, "kernel_ms": kern_ms, "kernel_ms_median": kern_ms_median, "value_alone": B / (kern_ms_median * 1e-3)}]
+    if dist is not None:
+        per_rank = [None] * pg_world
+        dist.all_gather_object(per_rank, {"rank": rank, "kernel_ms": kern_ms, "kernel_ms_median": kern_ms_median,
+                                          "value_alone": B / (kern_ms_median * 1e-3)})
     if os.environ.get("MKH_BENCH_DEBUG"):
         print("kernel ms per step:", [round(x, 3) for x in kern_list], file=sys.stderr)
 
@@ -634,7 +681,23 @@ def main():
                        "launch": info, "failed_instances": n_bad},
             "roofline": roof,
         }
+        if world > 1:
+            ideal = sum(r["value_alone"] for r in per_rank)
+            out["per_rank"] = per_rank
+            out["scaling_view"] = {"sum_of_rank_rates_alone": ideal, "value_over_that": value / ideal,
+                                   "note": "value_alone = batch / this rank's median kernel time: the rate the rank would sustain by itself; "
+                                           "the batch shards with no data-path collective, so value / sum is what barriers, launch skew and "
+                                           "the slowest rank cost (the driver computes the 1 -> N efficiency from its own N = 1 run)"}
         if gather is not None:
+            # the optional gather of v to rank 0 against the links it uses: N - 1 peers, each over its own xGMI link into rank 0
+            # (MI355X: 7 links x ~153 GB/s per GPU, point to point — /opt/skills/guides/MI355X_MICROARCH.md)
+            gm = gather.get("gather_ms_rank0_median")
+            if gm:
+                gb = gather["bytes_per_step_to_rank0"] / (gm * 1e-3) / 1e9
+                gather["achieved_GBps_into_rank0"] = gb
+                gather["xgmi_links_used"] = world - 1
+                gather["xgmi_peak_GBps_into_rank0"] = 153.0 * (world - 1)
+                gather["frac_of_link_peak"] = gb / (153.0 * (world - 1))
             out["gather"] = gather
         res = kernel_resources(kernel)
         if res is not None:
@@ -657,6 +720,8 @@ def main():
             out["converged_targets"] = conv
             if not args.no_pcie_leg:
                 out["pcie_inclusive_value"] = pcie_inclusive(prob, q_h, tg_h, pt_h, ct_h, dt, damping)
+                if args.config == "g1_c3" and args.batch is None:
+                    out["batch_sweep"] = batch_sweep(prob, q, tg, pt, ct, dt, damping, v, st)
         if world == 1 and args.config == "g1_c3" and args.batch is None and not args.no_other_configs:
             # every other named workload behind the boundary, measured by the same command (20 launches each, < 0.2 s of
             # GPU time per config): the three other single-GPU BASELINE configs and the two general routes
