@@ -1398,6 +1398,16 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
   // below (overlap_of), the values returned here are placeholders
   auto contact_of = [&](int pi, double& hk, V3& nrm, V3& from, V3& to, uint64_t& m1, uint64_t& m2, bool& need_epa, double* gjk_slot) -> bool {
     const auto& cp = pairs[pi];
+    if constexpr (!kSimpleColl && !kConvexColl) {
+      // a pair without an analytic routine in the ANALYTIC build: its contact was evaluated by convex_contacts_kernel in front of
+      // this launch (the general convex routine — GJK, the expanding polytope — owns a kernel of its own there: no callee-saved
+      // register blocks in scratch, which were 284 x the algorithmic bytes of `ur5e_convex`)
+      if (cp.cv_slot >= 0) {
+        const double* r = P.cv_contacts + ((size_t)pb * P.n_cv + cp.cv_slot) * 7;
+        from = V3{r[1], r[2], r[3]}; to = V3{r[4], r[5], r[6]};
+        return finish_contact(cp, r[0], from, to, hk, nrm, m1, m2);
+      }
+    }
     V3 gp1, gp2;
     Q4 gq1, gq2;
     pair_poses(cp, gp1, gq1, gp2, gq2);

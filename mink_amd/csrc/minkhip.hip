@@ -22,6 +22,9 @@
 #include "lane_kernel.h"
 #include "wide_types.h"
 
+namespace mkh {
+struct CvPre { int32_t n_cv; const int32_t* pair; const int32_t* chain_adr; const int32_t* chain; };     // (convex_pre.hip)
+}
 using namespace mkh;
 
 static thread_local std::string g_err;
@@ -146,6 +149,10 @@ struct MkhProblem {
   TapArgs* d_taps = nullptr;
   int last_grid = 0, last_lds = 0, last_nt = 0, last_block = kWave;   // geometry of the most recent launch (mkh_problem_launch_info)
   long long* d_clk = nullptr;      // MKH_DEBUG_CLOCKS (experiment builds): cycle stamps of the last launch
+  // general convex pairs of plain solves: evaluated by convex_contacts_kernel in front of the analytic collision build
+  mkh::CvPre cv{};
+  double* d_cv = nullptr;          // [max_batch][n_cv][7]
+  int32_t *d_cv_pair = nullptr, *d_cv_adr = nullptr, *d_cv_chain = nullptr;
   double* d_qkeep = nullptr;       // fused loops with a redo launch behind them: the call's q as it came (q_out may alias it)
   int8_t* d_warm = nullptr;        // MKH_FLAG_WARM_START: active set of every instance after the previous solve (max_batch × nv)
   int warm_age = 0, warm_B = 0;    // solves since the state was reset / the batch size it belongs to
@@ -170,6 +177,7 @@ int launch_variant(int nt, int nr, int feat, bool w3, int grid, int lds_bytes, h
 int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);
 int launch_quad(int nt, bool loop, int grid, hipStream_t stream, const void* P, const LaneDims& dims, const SolveArgs& a);   // returns its LDS bytes per wavefront
 int launch_wide(int grid, int lds_bytes, hipStream_t stream, const WideProblem* P, const SolveArgs& a, const TapArgs* taps);
+int launch_convex_pre(hipStream_t stream, const WideProblem* P, const CvPre& C, int B, const double* q, double* out);
 constexpr int kLaneMinBatchLoop = 28672;  // fused loops of a small arm: row kernel below, lane kernel from here (M targets/s at 16 384: 39.7 vs 24.1, at 32 768: 42.4 vs 48.2)
 constexpr int kLaneMinBatch = 73728;  // plain solves of a small arm: row kernel below, lane kernel from here (launch())
 }
@@ -954,6 +962,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   }
   // ---- collision pairs
   std::vector<CollisionPairDev> pairs;
+  int n_cv = 0;
   for (int t = 0; t < d->n_collision_limits; ++t) {
     const MkhCollisionLimitDesc& c = d->collision_limits[t];
     for (int k = 0; k < c.n_pairs; ++k) {
@@ -979,7 +988,8 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
         return cb && (a == GEOM_PLANE ? (b == GEOM_ELLIPSOID || b == GEOM_MESH) : (a >= GEOM_SPHERE && a <= GEOM_MESH));
       };
       auto supported = [&](int a, int b) { return analytic(a, b) || convex(a, b); };
-      if (!analytic(t1, t2) && convex(t1, t2)) p->convex_pairs = true;
+      cp.cv_slot = -1;
+      if (!analytic(t1, t2) && convex(t1, t2)) { p->convex_pairs = true; cp.cv_slot = n_cv++; }
       if (!supported(t1, t2)) return bail(fail(MKH_E_INVALID, "collision pair (%d,%d): geom types (%d,%d) are not supported (height fields)", g1, g2, t1, t2));
       for (int side = 0; side < 2; ++side) {
         const int g = side ? g2 : g1;
@@ -1253,6 +1263,28 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     const int32_t rc = build_wide_problem(p, m, d, ft, pairs, dcost, dwgain);
     if (rc != MKH_OK) return bail(rc);
   }
+  // The two-kernel split of general convex pairs (convex_pre.hip): per convex pair the chains root → body of its two geoms, and
+  // the buffer of pre-evaluated contacts the analytic build reads.  It uses the plain model arrays of the twin above.
+  static const bool no_split = getenv("MKH_DEBUG_NO_CONVEX_SPLIT") != nullptr;      // (A/B: the in-kernel routine, round 4's path)
+  if (p->d_wide && n_cv > 0 && !no_split) {
+    std::vector<int32_t> cv_pair, adr{0}, chain;
+    for (size_t k = 0; k < pairs.size(); ++k) {
+      if (pairs[k].cv_slot < 0) continue;
+      cv_pair.push_back((int32_t)k);
+      for (int body : {pairs[k].body1, pairs[k].body2}) {
+        std::vector<int32_t> up;
+        for (int b = body; b > 0; b = m->body_parentid[b]) up.push_back(b);
+        chain.insert(chain.end(), up.rbegin(), up.rend());
+        adr.push_back((int32_t)chain.size());
+      }
+    }
+    if (upload(cv_pair, &p->d_cv_pair) != hipSuccess || upload(adr, &p->d_cv_adr) != hipSuccess || upload(chain, &p->d_cv_chain) != hipSuccess ||
+        hipMalloc((void**)&p->d_cv, (size_t)p->max_batch * n_cv * 7 * sizeof(double)) != hipSuccess)
+      return bail(fail(MKH_E_HIP, "convex pre-pass buffers"));
+    p->cv = mkh::CvPre{n_cv, p->d_cv_pair, p->d_cv_adr, p->d_cv_chain};
+    p->dev.n_cv = n_cv; p->dev.cv_contacts = p->d_cv;
+    if (hipMemcpy(p->d_dev, &p->dev, sizeof(DeviceProblem), hipMemcpyHostToDevice) != hipSuccess) return bail(fail(MKH_E_HIP, "descriptor upload failed"));
+  }
   *out = p;
   return MKH_OK;
 }
@@ -1262,7 +1294,8 @@ void mkh_problem_destroy(MkhProblem* p) {
   (void)hipSetDevice(p->device);
   (void)hipFree(p->d_frame); (void)hipFree(p->d_posture_cost); (void)hipFree(p->d_cfg_lower); (void)hipFree(p->d_cfg_upper);
   (void)hipFree(p->d_vel); (void)hipFree(p->d_pairs); (void)hipFree(p->d_dev); (void)hipFree(p->d_taps); (void)hipFree(p->d_work);
-  (void)hipFree(p->d_lane); (void)hipFree(p->d_warm); (void)hipFree(p->d_qkeep); (void)hipFree(p->d_dev_tight); (void)hipFree(p->d_status_tight);
+  (void)hipFree(p->d_lane); (void)hipFree(p->d_warm); (void)hipFree(p->d_qkeep);
+  (void)hipFree(p->d_cv); (void)hipFree(p->d_cv_pair); (void)hipFree(p->d_cv_adr); (void)hipFree(p->d_cv_chain); (void)hipFree(p->d_dev_tight); (void)hipFree(p->d_status_tight);
   (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain); (void)hipFree(p->s_iters);
   (void)hipFree(p->s_de); (void)hipFree(p->s_dJ); (void)hipFree(p->s_dG); (void)hipFree(p->s_dh); (void)hipFree(p->s_dbox); (void)hipFree(p->d_clk);
   for (void* w : p->wide_allocs) (void)hipFree(w);
@@ -1436,11 +1469,17 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   if (a.n_steps > 1 || a.q_out || a.pos_threshold >= 0.0) need |= F_STEPS;
   const bool dense = p->dev.n_dense_rows > 0 || p->dev.n_dense_limit_rows > 0 || p->dev.dense_box;
   if (dense) need |= 64;                                              // plugin rows: only the all-feature variants have them
+  // (general convex pairs of a plain solve: their contacts come from convex_contacts_kernel, launched below in front of the
+  //  ANALYTIC build — round 5; without the pre-pass buffers, the build with the routine inside)
+  // Measured (ur5e_convex, one cylinder–box pair; in-kernel routine / split): 4 096 instances 0.165 / 0.207 ms, 16 384 0.463 / 0.505,
+  // 65 536 1.270 / 0.970: GJK is one long dependent chain per lane — in front of a small batch its latency adds to the solve's, on
+  // a large one 64 busy lanes per wavefront beat one busy lane per problem.  The split from 32 768 (instance, pair) items on.
+  const bool cv_split = need == F_COLL && p->convex_pairs && p->d_cv != nullptr && (long long)a.B * p->cv.n_cv >= 32768;
   int feat;
   if (need == 0) feat = 0;
   else if (need == 64) feat = F_DENSE;                                // plugin rows next to frame / posture tasks and box limits: lean build
   else if (need == F_STEPS) feat = F_STEPS;
-  else if (need == F_COLL) feat = p->simple_pairs ? (F_COLL | F_SIMPLE_COLL) : (p->convex_pairs ? (F_COLL | F_CONVEX_COLL) : F_COLL);
+  else if (need == F_COLL) feat = p->simple_pairs ? (F_COLL | F_SIMPLE_COLL) : ((p->convex_pairs && !cv_split) ? (F_COLL | F_CONVEX_COLL) : F_COLL);
   // (fused loops over capsule-only collision sets — the Shadow hand's closed loop — have a build of their own: the
   //  all-feature one spills 534 VGPRs at this tableau size)
   else if (need == (F_COLL | F_STEPS) && p->simple_pairs) feat = F_COLL | F_SIMPLE_COLL | F_STEPS;
@@ -1529,10 +1568,19 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   const bool dynamic = nt > 8 && per_wave >= 4 && !tight;              // (a redo launch walks its static share, ik_kernel.h)
   al.static_rounds = dynamic ? (per_wave * 7) / 8 : INT32_MAX;
   if (!tight) HIP_OK(clk_begin(p, al, stream));
+  if (cv_split) {
+    const int rc = mkh::launch_convex_pre(stream, p->d_wide, p->cv, a.B, a.q, p->d_cv);
+    if (rc != 0) return fail(MKH_E_HIP, "convex pre-pass: %s", hipGetErrorString((hipError_t)rc));
+  }
   if (mkh::launch_variant(nt, nr, feat, w3, grid, lds, stream, p->d_dev, al, dtaps) != 0)
     return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
   HIP_OK(hipGetLastError());
   HIP_OK(clk_end(p, a.B, stream));
+  if (cv_split) {                                          // ("convex_pre+": the pre-pass launch in front)
+    char tmp[64];
+    snprintf(tmp, sizeof tmp, "convex_pre+%s", p->last_kernel);
+    snprintf(p->last_kernel, sizeof(p->last_kernel), "%s", tmp);
+  }
   if (wide_redo) {
     const size_t len = strlen(p->last_kernel);
     snprintf(p->last_kernel + len, sizeof(p->last_kernel) - len, "+wide");

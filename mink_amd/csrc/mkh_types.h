@@ -64,6 +64,9 @@ struct CollisionPairDev {
   const double* vert1;
   const double* vert2;
   int32_t nvert1, nvert2;
+  // ≥ 0: a pair WITHOUT an analytic routine whose contact of a plain solve is evaluated by the kernel in front of the solve
+  // (convex_pre.hip) — slot of its (dist, from, to) record in DeviceProblem::cv_contacts; −1: analytic pair
+  int32_t cv_slot, cv_pad;
 };
 
 struct DeviceProblem {
@@ -126,6 +129,10 @@ struct DeviceProblem {
   // (appended last: the offsets of the fields above are what the register allocation of the W3 builds was tuned on —
   //  one int32 in the middle cost the headline kernel 25 spilled VGPRs)
   int32_t n_hsel;        // doubles of LDS behind the per-problem ranges: n_pairs (even) when there are more pairs than rows (h of every pair: row selection) + the expanding polytope's workspace when a pair needs the general convex routine
+  // general convex pairs of plain solves: (dist, from[3], to[3]) per (instance, convex pair), written by convex_contacts_kernel
+  // in front of the solve and read by the analytic collision build (round 5: the two-kernel split)
+  int32_t n_cv, n_cv_pad;
+  const double* cv_contacts;       // [max_batch][n_cv][7], owned by the problem handle
 };
 
 struct SolveArgs {

@@ -510,7 +510,7 @@ def test_ur5e_convex_at_its_bench_batch_against_the_numpy_oracle():
     prob, dt, damping = workloads.bench_config(name, model, nm, B)
     q, tg, pt, _ = workloads.bench_batch(name, model, nm, prob, np.random.default_rng(2024), B)
     v, st = prob.solve(q, tg, pt, None, dt, damping)
-    assert prob.last_kernel().removesuffix("+wide") == "ik_solve_kernel_16_136", prob.last_kernel()
+    assert prob.last_kernel() == "ik_solve_kernel_16_136+wide", prob.last_kernel()
     assert ((st & ~1) == 0).all(), np.unique(st, return_counts=True)
     ncpu = min(16, os.cpu_count() or 1)
     chunks = np.array_split(np.arange(B), ncpu * 4)
@@ -558,3 +558,37 @@ def test_ur5e_convex_contact_distances_at_scale():
     pen = int((h_ref[fin] == 0.0).sum())
     print("ur5e_convex: h of %d contacts in range on %d instances (%d at or inside d_min): max rel err %.2e" % (fin.sum(), B, pen, err.max()))
     assert fin[:, 1].sum() > B // 8 and err.max() < 1e-9
+
+
+def test_convex_pairs_in_a_kernel_of_their_own_from_32768_items():
+    """Round 5: from 32 768 (instance, pair) items on, plain solves evaluate general convex pairs in `convex_contacts_kernel` in
+    front of the ANALYTIC collision build (mink_amd/csrc/convex_pre.hip: no callee-saved register blocks in scratch; 1.27 → 0.97 ms
+    at 65 536 instances).  Same answers as the routine inside the solve kernel (MKH_FLAG... none: the small batch takes that path)
+    to the tolerance of rows through GJK, and the numpy oracle on a sample."""
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+    name = "ur5e_convex"
+    B = 32768
+    model = workloads.load_bench_robot(name)
+    nm = nat.NativeModel(model)
+    prob, dt, damping = workloads.bench_config(name, model, nm, B)
+    q, tg, pt, _ = workloads.bench_batch(name, model, nm, prob, np.random.default_rng(7), B)
+    v, st = prob.solve(q, tg, pt, None, dt, damping)
+    assert prob.last_kernel() == "convex_pre+ik_solve_kernel_16_8+wide", prob.last_kernel()
+    assert ((st & ~1) == 0).all(), np.unique(st, return_counts=True)
+    parts = [prob.solve(q[i:i + 4096], tg[i:i + 4096], pt, None, dt, damping) for i in range(0, B, 4096)]
+    assert prob.last_kernel() == "ik_solve_kernel_16_136+wide", prob.last_kernel()
+    v_in = np.concatenate([p_[0] for p_ in parts])
+    err = np.abs(v - v_in).max(axis=1) / np.maximum(1.0, np.abs(v_in).max(axis=1))
+    bad = np.flatnonzero(err >= 2e-5)
+    print("ur5e_convex, %d instances: split vs in-kernel routine max rel %.2e; beyond 2e-5: %d" % (B, err.max(), len(bad)))
+    # the two paths see the geoms through different FK rounding; where the cylinder sits AT or INSIDE d_min of the wall (h = 0) the
+    # normal comes from the expanding polytope's witness points and moves at the 1e-4 level with them (a handful of instances);
+    # everywhere else the rows agree to the tolerance of GJK
+    assert len(bad) <= B // 2000
+    if len(bad):
+        _, _, t = prob.solve(q[bad], tg[bad], pt, None, dt, damping, taps=["coll_h"], solve_qp=False)
+        assert (t["coll_h"].min(axis=1) == 0.0).all(), t["coll_h"]
+    v_ref = _numpy_oracle_chunk((name, np.arange(0, B, 1024), q, tg, pt, dt, damping))
+    e2 = np.abs(v[::1024] - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
+    assert e2.max() < 2e-5, e2.max()

@@ -306,7 +306,9 @@ np.save(%r, st)
     v1, st1, taps = prob.solve(q, tg, stand[None, :], None, dt, damping, taps=["coll_h", "coll_G", "H", "task_e"])
     assert prob.last_kernel().endswith("+wide") and ((st1 & ~1) == 0).all()
     v0, _ = prob.solve(q, tg, stand[None, :], None, dt, damping)
-    np.testing.assert_allclose(v1, v0, rtol=0, atol=1e-8 * max(1.0, np.abs(v0).max()))
+    # (plain solves take the contacts of general convex pairs from the kernel in front — other FK rounding, GJK witness points to
+    #  ~1e-6 —, the call with taps from the routine inside the solve kernel: the tolerance of rows through GJK)
+    np.testing.assert_allclose(v1, v0, rtol=0, atol=5e-6 * max(1.0, np.abs(v0).max()))
     i = idx[0]
     m = oc.model("g1")
     mm, tasks, limits, _, damp_o = oc.g1_c3(tg[i], stand)
