@@ -101,6 +101,8 @@ def kernel_keys(kernel: str) -> list:
     wide = kernel.endswith("+wide")              # (the redo launch of the workgroup-per-problem kernel behind a wavefront kernel)
     if wide:
         kernel = kernel[:-len("+wide")]
+    if kernel.startswith("convex_pre+"):         # (general convex pairs evaluated by a kernel in front of the analytic build)
+        return ["convex_contacts_kernel"] + kernel_keys(kernel[len("convex_pre+"):] + ("+wide" if wide else ""))
     if kernel == "ik_wide_kernel":
         return ["ik_wide_kernel"]
     main, _, redo = kernel.partition("+redo_")
