@@ -603,6 +603,7 @@ static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhPro
   p->wide_allocs.push_back(ws);
   W.ws = ws;
   p->wide_grid = grid; p->wide_lds = o * 8;
+
   if (hipMalloc((void**)&p->d_wide, sizeof(WideProblem)) != hipSuccess ||
       hipMemcpy(p->d_wide, &W, sizeof(WideProblem), hipMemcpyHostToDevice) != hipSuccess)
     return fail(MKH_E_HIP, "wide descriptor upload failed");
@@ -1586,9 +1587,12 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
     snprintf(p->last_kernel + len, sizeof(p->last_kernel) - len, "+wide");
     SolveArgs ar = a;
     ar.q = q_redo;
+    HIP_OK(clk_begin(p, ar, stream));                      // (MKH_DEBUG_CLOCKS: the stamps of the redo launch overwrite the main kernel's)
     // (… and the instances whose active rows the sweep tableau found almost dependent, or on which it failed: MKH_ST_DEGENERATE is
     //  internal — the dense Goldfarb–Idnani iteration of the workgroup-per-problem kernel answers for them)
-    return launch_wide_kernel(p, ar, stream, MKH_ST_ROW_OVERFLOW | MKH_ST_INFEASIBLE | MKH_ST_ITER_LIMIT | 32, dtaps);
+    const int32_t rcr = launch_wide_kernel(p, ar, stream, MKH_ST_ROW_OVERFLOW | MKH_ST_INFEASIBLE | MKH_ST_ITER_LIMIT | 32, dtaps);
+    if (rcr == MKH_OK) HIP_OK(clk_end(p, a.B, stream));
+    return rcr;
   }
   return MKH_OK;
 }

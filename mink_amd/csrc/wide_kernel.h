@@ -643,11 +643,26 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp_dense(WideQpCtx X, double
         if (i < nact) rv[i] = dv[i];
       }
       __syncthreads();
+      if (nact <= 64) {
+        // back-substitution inside ONE wavefront: lane i carries r_i in a register, the pivot travels by v_readlane — no barrier per
+        // column (two 4-wave barriers per column were most of an iteration's synchronisation: 2·nact of ≈ 2·nact + 10)
+        if (wave == 0) {
+          double ri = lane < nact ? rv[lane] : 0.0;
+          for (int k = nact - 1; k >= 0; --k) {
+            const double rk = readlane_f64(ri, k) / R[(size_t)k * n + k];
+            if (lane < k) ri -= rk * R[(size_t)lane * n + k];
+            if (lane == k) ri = rk;
+          }
+          if (lane < nact) rv[lane] = ri;
+        }
+        __syncthreads();
+      } else {
       for (int k = nact - 1; k >= 0; --k) {               // back-substitution, column-oriented
         if (tid == 0) rv[k] = rv[k] / R[(size_t)k * n + k];
         __syncthreads();
         for (int i = tid; i < k; i += NT_) rv[i] -= rv[k] * R[(size_t)i * n + k];
         __syncthreads();
+      }
       }
       // ---- step 2b: step lengths (one thread: O(n))
       if (tid == 0) {
@@ -790,7 +805,10 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
   };
   // A redo launch (redo_mask != 0) solves only the instances whose status carries one of the mask's bits: every workgroup owns a
   // contiguous slice of the batch and reads its statuses 256 at a time — one coalesced load; a launch that finds nothing (the
-  // usual case) ends there (round 4 walked the statuses one dependent load after the other: 29 µs for 16 384 instances)
+  // usual case) ends there (round 4 walked the statuses one dependent load after the other: 29 µs for 16 384 instances).
+  // (Measured and dropped: chunks of 16 statuses handed out through a ticket counter, so that clustered flagged instances spread
+  //  over the machine — ALOHA's 519 re-solved instances 5.85 → 5.56 ms, but every launch that finds NOTHING, the usual case, pays
+  //  two or three serial atomic round trips per workgroup: +8 µs on a 45 µs UR5e solve.)
   int* const sList = reinterpret_cast<int*>(sRed + 16);  // flagged instances of the current chunk (≤ 256; sRed[0, 16) carry the reductions)
   const int slice = A.redo_mask ? (A.B + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   const int s_begin = (int)blockIdx.x * slice, s_end = s_begin + slice < A.B ? s_begin + slice : A.B;
@@ -1149,10 +1167,25 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
       }
       __syncthreads();
     }
+    // (in pair order, 256 pairs per trip: ballot + prefix — one thread walking 1 104 records in device memory cost the ALOHA redo
+    //  350 k cycles per instance, a third of it)
+    if (tid == 0) sRedI[2] = 0;
+    __syncthreads();
+    for (int base = 0; base < P.n_pairs; base += NT_) {
+      const int pi = base + tid;
+      const bool on = pi < P.n_pairs && rec[(size_t)pi * 10] < kInf && (!select || rowrank[pi] < P.max_rows);
+      const unsigned long long bm = __ballot(on);
+      if (lane == 0) sRedI[4 + wave] = __popcll(bm);
+      __syncthreads();
+      int off = sRedI[2];
+      for (int w = 0; w < wave; ++w) off += sRedI[4 + w];
+      if (on) rowpair[off + __popcll(bm & ((1ull << lane) - 1ull))] = pi;
+      __syncthreads();
+      if (tid == 0) sRedI[2] += sRedI[4] + sRedI[5] + sRedI[6] + sRedI[7];
+      __syncthreads();
+    }
     if (tid == 0) {
-      int m = 0, over = 0;
-      for (int pi = 0; pi < P.n_pairs; ++pi)
-        if (rec[(size_t)pi * 10] < kInf && (!select || rowrank[pi] < P.max_rows)) rowpair[m++] = pi;
+      int m = sRedI[2], over = 0;
       for (int r = 0; r < P.n_dense_limit_rows; ++r)       // (the caller's rows are not ranked: one that finds no place is reported)
         if (A.dense_h[(size_t)pb * P.n_dense_limit_rows + r] < kInf) { if (m < P.max_rows) rowpair[m++] = -1 - r; else over = 1; }
       sRedI[0] = m; sRedI[1] = over;
