@@ -459,7 +459,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="g1_c3", choices=["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin", "ur5e_convex", "g1_coll", "h1_c3", "h1_full", "g1_hands", "aloha_coll"],
+    ap.add_argument("--config", default="g1_c3", choices=["ur5e_c2", "g1_c3", "g1_full", "shadow_c4", "g1_plugin", "ur5e_convex", "g1_coll", "h1_c3", "h1_full", "g1_hands", "aloha_coll", "ur5e_coll"],
                     help="BASELINE config (default: the headline G1 config 3), or one of the two general routes of the "
                          "boundary: g1_plugin (caller-defined Task + Limit rows, mkh_solve_dense), ur5e_convex (a collision "
                          "pair on the general convex routine)")

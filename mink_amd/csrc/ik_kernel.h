@@ -1342,9 +1342,11 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
   tp = reinterpret_cast<const TapArgs*>(uni((unsigned long long)reinterpret_cast<size_t>(tp)));
   const MKH_CONSTANT DeviceProblem& P = *(const MKH_CONSTANT DeviceProblem*)Pq;
   const MKH_GLOBAL CollisionPairDev* const pairs = (const MKH_GLOBAL CollisionPairDev*)P.pairs;
+  const MKH_GLOBAL PairCull* const cull = (const MKH_GLOBAL PairCull*)P.cull;
 #else
   const DeviceProblem& P = *Pq;
   const CollisionPairDev* const pairs = P.pairs;
+  const PairCull* const cull = P.cull;
 #endif
   const int lane = lane_id();
   const int nv = P.nv, n_pairs = P.n_pairs, max_rows = P.max_rows;
@@ -1366,10 +1368,40 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
   // (collision_avoidance_limit.py:187-210); here the max_rows TIGHTEST (smallest h, ties by pair index) become rows and
   // the solution is checked against the rest after the QP — a dropped row that holds at the solution was inactive, so
   // the result is the reference's; one that does not hold sets MKH_ST_ROW_OVERFLOW.
-  double* const sH = smem + L.hsel;                         // h of every pair (only laid out when n_pairs > max_rows)
+  double* const sH = smem + L.hsel;                         // h of every candidate pair (only laid out when n_pairs > max_rows)
   const bool can_select = n_pairs > max_rows;
-  // the expanding polytope's workspace (general convex pairs whose cores overlap): behind the h of every pair
-  double* const sEpa = smem + L.hsel + (can_select ? lds_even(n_pairs) : 0);
+  // More than one wavefront of pairs (the reference's ALOHA example: 1 104): a cull pass over bounding spheres first — a pair whose
+  // centres are farther apart than rbound₁ + rbound₂ + detection distance is beyond that distance, and that is all mj_geomDistance
+  // says about it — and the distance routines run over the COMPACTED list of the pairs that are left, 64 at a time (17 trips of the
+  // routines with a few busy lanes each were 48 % of an ALOHA solve).  The list is ascending in the pair index, so rows, ranks
+  // and ties are what they were.  (The capsule-only builds keep the plain loop: their pair sets fit one trip.)
+  constexpr bool kCull = !kSimpleColl;
+  const bool use_cull = kCull && cull != nullptr;
+  unsigned short* const sList = reinterpret_cast<unsigned short*>(smem + L.hsel + (can_select ? lds_even(n_pairs) : 0));
+  // the expanding polytope's workspace (general convex pairs whose cores overlap): behind the h of every pair and the list
+  double* const sEpa = smem + L.hsel + (can_select ? lds_even(n_pairs) : 0) + (use_cull ? lds_even((n_pairs + 3) / 4) : 0);
+  int n_cand = n_pairs;
+  if (use_cull) {
+    n_cand = 0;
+    for (int base = 0; base < n_pairs; base += 64) {
+      const int pi = base + lane;
+      bool keep = false;
+      if (pi < n_pairs) {
+        const auto& c = cull[pi];
+        const double* x1 = sX + c.body1;
+        const double* x2 = sX + c.body2;
+        const Q4 bq1{x1[3 * XS], x1[4 * XS], x1[5 * XS], x1[6 * XS]}, bq2{x2[3 * XS], x2[4 * XS], x2[5 * XS], x2[6 * XS]};
+        const V3 d = (V3{x2[0], x2[XS], x2[2 * XS]} + qrot(bq2, V3{c.lpos2[0], c.lpos2[1], c.lpos2[2]})) -
+                     (V3{x1[0], x1[XS], x1[2 * XS]} + qrot(bq1, V3{c.lpos1[0], c.lpos1[1], c.lpos1[2]}));
+        keep = !(dot(d, d) > c.reach2);
+        if (!keep && mode == 0 && MKH_TAP(t_coll_h)) MKH_TAP(t_coll_h)[(size_t)pb * n_pairs + pi] = kInf;
+      }
+      const unsigned long long km = __ballot(keep);
+      if (keep) sList[n_cand + __popcll(km & ((1ull << lane) - 1ull))] = (unsigned short)pi;
+      n_cand += __popcll(km);
+    }
+    wave_sync();
+  }
   // world poses of the two geoms of pair pi
   auto pair_poses = [&](const auto& cp, V3& gp1, Q4& gq1, V3& gp2, Q4& gq2) {
     const double* x1 = sX + cp.body1;
@@ -1424,11 +1456,11 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
     return finish_contact(pairs[pi], o.dist, from, to, hk, nrm, m1, m2);
   };
   // position of pair pi in the order (h, index) among all pairs (h = +inf: not detected)
-  auto rank_of = [&](int pi, double hk) -> int {
+  auto rank_of = [&](int k, double hk) -> int {            // (k: position in the candidate list, which is ascending in the pair index)
     int rank = 0;
-    for (int j = 0; j < n_pairs; ++j) {
+    for (int j = 0; j < n_cand; ++j) {
       const double hj = sH[j];
-      rank += (hj < hk || (hj == hk && j < pi)) ? 1 : 0;
+      rank += (hj < hk || (hj == hk && j < k)) ? 1 : 0;
     }
     return rank;
   };
@@ -1437,16 +1469,18 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
   bool rows_dropped = false, viol = false;
   for (int pass = 0; pass < 2; ++pass) {
     nrows = 0;
-    for (int base = 0; base < n_pairs; base += 64) {
-      const int pi = base + lane;
+    for (int base = 0; base < n_cand; base += 64) {
+      const int kc = base + lane;                            // candidate, and the pair it stands for
+      const bool in_list = kc < n_cand;
+      const int pi = !in_list ? n_pairs : (use_cull ? (int)sList[kc] : kc);
       bool active = false;
       double hk = kInf;
       V3 nrm{1, 0, 0}, from{0, 0, 0}, to{0, 0, 0};
       uint64_t m1 = 0, m2 = 0;
-      bool want = pi < n_pairs;
+      bool want = in_list;
       if (mode != 0 && want) {                               // mode 1: only the contacts that found no tableau row
-        const double hs = sH[pi];
-        want = hs < kInf && rank_of(pi, hs) >= max_rows;
+        const double hs = sH[kc];
+        want = hs < kInf && rank_of(kc, hs) >= max_rows;
       }
       bool need_epa = false;
       if constexpr (kConvexColl) {
@@ -1469,7 +1503,7 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
           double hk_e = kInf;
           V3 n_e{1, 0, 0}, f_e{0, 0, 0}, t_e{0, 0, 0};
           uint64_t m1_e = 0, m2_e = 0;
-          const bool act_e = overlap_of(base + l, hk_e, n_e, f_e, t_e, m1_e, m2_e);
+          const bool act_e = overlap_of(use_cull ? (int)sList[base + l] : base + l, hk_e, n_e, f_e, t_e, m1_e, m2_e);
           if (lane == l) { active = act_e; hk = hk_e; nrm = n_e; from = f_e; to = t_e; m1 = m1_e; m2 = m2_e; }
         }
       }
@@ -1489,9 +1523,9 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
         }
         continue;
       }
-      if (pi < n_pairs) {
+      if (in_list) {
         if (pass == 0) {
-          if (can_select) sH[pi] = hk;
+          if (can_select) sH[kc] = hk;
           if (MKH_TAP(t_coll_h)) MKH_TAP(t_coll_h)[(size_t)pb * n_pairs + pi] = hk;
           if (MKH_TAP(t_coll_G) && active) {
             // the tap holds the row of EVERY detected contact (Limit.compute_qp_inequalities / build_ik return them all),
@@ -1508,7 +1542,7 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
             }
           }
         } else if (active) {
-          active = rank_of(pi, hk) < max_rows;
+          active = rank_of(kc, hk) < max_rows;
         }
       }
       const unsigned long long am = __ballot(active);

@@ -86,6 +86,7 @@ struct MkhModel {
   bool big = false;                // more than 64 bodies or dofs: no lane tables — every problem runs on the workgroup-per-problem kernel
   std::vector<int32_t> geom_dataid, mesh_vertadr, mesh_vertnum;   // mesh geoms: hull vertices (geom frame) in d_mesh_vert
   double* d_mesh_vert = nullptr;
+  std::vector<double> h_mesh_vert;   // (host copy: bounding radii of mesh geoms, mkh_problem_create)
   // device tables
   double* d_body_f = nullptr;
   int32_t* d_body_i = nullptr;
@@ -144,6 +145,8 @@ struct MkhProblem {
   double* d_posture_cost = nullptr;
   double *d_cfg_lower = nullptr, *d_cfg_upper = nullptr, *d_vel = nullptr;
   CollisionPairDev* d_pairs = nullptr;
+  PairCull* d_cull = nullptr;          // bounding-sphere records of the pairs (problems with more than 64 of them)
+  bool use_cull = false;
   double *d_dense_cost = nullptr, *d_dense_wgain = nullptr;
   DeviceProblem* d_dev = nullptr;   // device copy of `dev` (the kernel reads the descriptor from memory)
   TapArgs* d_taps = nullptr;
@@ -425,7 +428,7 @@ static void assign_taps(const MkhTaps* taps, const DeviceProblem& P, size_t Bz, 
 // lane tables), the kinematic tree by levels, the dof chain of every body as a bit set, LDS offsets, and the per-workgroup
 // slice of device memory (weighted Jacobian rows, contact records, the tableau when it does not fit in LDS).
 static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhProblemDesc* d, const std::vector<FrameTaskDev>& ft,
-                                  const std::vector<CollisionPairDev>& pairs, const std::vector<double>& dcost,
+                                  const std::vector<CollisionPairDev>& pairs, const std::vector<PairCull>& culls, const std::vector<double>& dcost,
                                   const std::vector<double>& dwgain) {
   const double inf = std::numeric_limits<double>::infinity();
   WideProblem& W = p->wide;
@@ -530,13 +533,17 @@ static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhPro
   MKH_UP(m->dof_bodyid, dof_body) MKH_UP(dqadr, dof_qadr) MKH_UP(dlo, dof_lo) MKH_UP(dhi, dof_hi) MKH_UP(chain, chain)
   MKH_UP(ft, frame) MKH_UP(pcost, posture_cost) MKH_UP(dcost, dense_cost) MKH_UP(dwgain, dense_wgain) MKH_UP(clo, cfg_lower)
   MKH_UP(chi, cfg_upper) MKH_UP(vlim, vel_limit) MKH_UP(pairs, pairs)
-#undef MKH_UP
-  if (e != hipSuccess) return fail(MKH_E_HIP, "wide problem upload: %s", hipGetErrorString(e));
   // ---- LDS layout and the per-workgroup slice of device memory
   const int rows_max = W.n_pairs + W.n_dense_limit_rows;
   W.max_rows = rows_max < kWideMaxRows ? rows_max : kWideMaxRows;
   const int Ncap = nv + W.max_rows, R_all = W.n_jrows + W.n_dense_rows;
   auto ev = [](int x) { return (x + 1) & ~1; };
+  // more than a wavefront of pairs: bounding-sphere cull in front of the distance routines (wide_contacts; the candidate list —
+  // 16-bit pair indices — lives in the three QP vectors behind o_rown, which are dead until the tableau is built)
+  W.cull = nullptr;
+  if (W.n_pairs > kWave && W.n_pairs < 65536 && W.n_pairs <= 12 * ev(Ncap) && culls.size() == pairs.size() && !getenv("MKH_DEBUG_NO_CULL")) { MKH_UP(culls, cull) }
+#undef MKH_UP
+  if (e != hipSuccess) return fail(MKH_E_HIP, "wide problem upload: %s", hipGetErrorString(e));
   int o = 0;
   W.o_q = o; o += ev(W.nq);
   W.o_X = o; o += ev(7 * nb);
@@ -604,6 +611,16 @@ static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhPro
   W.ws = ws;
   p->wide_grid = grid; p->wide_lds = o * 8;
 
+  {
+    uint32_t cap = 256;
+    while (cap < (uint32_t)p->max_batch) cap *= 2;
+    int32_t* rq = nullptr;
+    if (hipMalloc((void**)&rq, ((size_t)cap + 4) * sizeof(int32_t)) != hipSuccess) return fail(MKH_E_HIP, "redo queue");
+    p->wide_allocs.push_back(rq);
+    if (hipMemset(rq, 0xff, (size_t)cap * sizeof(int32_t)) != hipSuccess || hipMemset(rq + cap, 0, 4 * sizeof(int32_t)) != hipSuccess)
+      return fail(MKH_E_HIP, "redo queue");
+    W.redo_queue = rq; W.redo_ctr = reinterpret_cast<uint32_t*>(rq + cap); W.redo_cap = cap; W.redo_pad = 0;
+  }
   if (hipMalloc((void**)&p->d_wide, sizeof(WideProblem)) != hipSuccess ||
       hipMemcpy(p->d_wide, &W, sizeof(WideProblem), hipMemcpyHostToDevice) != hipSuccess)
     return fail(MKH_E_HIP, "wide descriptor upload failed");
@@ -803,7 +820,8 @@ int32_t mkh_model_create(const MkhFlatModel* h, int32_t device, MkhModel** out) 
   if (e == hipSuccess) e = upload(dof_f, &m->d_dof_f);
   hipDeviceProp_t prop;
   if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
-  if (e == hipSuccess && h->nmesh > 0) e = upload(std::vector<double>(h->mesh_vert, h->mesh_vert + (size_t)h->nmeshvert * 3), &m->d_mesh_vert);
+  if (h->nmesh > 0) m->h_mesh_vert.assign(h->mesh_vert, h->mesh_vert + (size_t)h->nmeshvert * 3);
+  if (e == hipSuccess && h->nmesh > 0) e = upload(m->h_mesh_vert, &m->d_mesh_vert);
   if (e != hipSuccess) { mkh_model_destroy(m); return fail(MKH_E_HIP, "model upload: %s", hipGetErrorString(e)); }
   m->num_cus = prop.multiProcessorCount;
   *out = m;
@@ -963,6 +981,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   }
   // ---- collision pairs
   std::vector<CollisionPairDev> pairs;
+  std::vector<PairCull> culls;
   int n_cv = 0;
   for (int t = 0; t < d->n_collision_limits; ++t) {
     const MkhCollisionLimitDesc& c = d->collision_limits[t];
@@ -1009,6 +1028,35 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       cp.gain = c.gain; cp.dmin = c.minimum_distance_from_collisions; cp.ddetect = c.collision_detection_distance;
       cp.relax = c.bound_relaxation;
       pairs.push_back(cp);
+      // bounding spheres for the cull pass of problems with more than one wavefront of pairs (mkh_types.h PairCull)
+      auto rbound = [&](int g) -> double {
+        const double* sz = &m->geom_size[3 * g];
+        switch (m->geom_type[g]) {
+          case GEOM_SPHERE: return sz[0];
+          case GEOM_CAPSULE: return sz[0] + sz[1];
+          case GEOM_ELLIPSOID: return std::fmax(sz[0], std::fmax(sz[1], sz[2]));
+          case GEOM_CYLINDER: return std::hypot(sz[0], sz[1]);
+          case GEOM_BOX: return std::sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]);
+          case GEOM_MESH: {
+            const int k = m->geom_dataid[g];
+            double r2 = 0.0;
+            if (k < 0 || m->h_mesh_vert.empty()) return inf;
+            for (int v = 0; v < m->mesh_vertnum[k]; ++v) {
+              const double* x = &m->h_mesh_vert[3 * ((size_t)m->mesh_vertadr[k] + v)];
+              r2 = std::fmax(r2, x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+            }
+            return std::sqrt(r2);
+          }
+          default: return inf;                                 // planes (and anything unbounded): never culled
+        }
+      };
+      PairCull pc;
+      memset(&pc, 0, sizeof pc);
+      pc.body1 = cp.body1; pc.body2 = cp.body2;
+      for (int i = 0; i < 3; ++i) { pc.lpos1[i] = cp.lpos1[i]; pc.lpos2[i] = cp.lpos2[i]; }
+      const double reach = (rbound(g1) + rbound(g2) + std::fmax(cp.ddetect, 0.0)) * (1.0 + 1e-9) + 1e-12;
+      pc.reach2 = reach * reach;
+      culls.push_back(pc);
     }
   }
   P.n_pairs = (int)pairs.size();
@@ -1018,7 +1066,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       if (ty != GEOM_PLANE && ty != GEOM_SPHERE && ty != GEOM_CAPSULE) p->simple_pairs = false;
   if (m->big) {
     // beyond one wavefront: the workgroup-per-problem kernel takes every call of this problem (wide_kernel.h)
-    const int32_t rc = build_wide_problem(p, m, d, ft, pairs, dcost, dwgain);
+    const int32_t rc = build_wide_problem(p, m, d, ft, pairs, culls, dcost, dwgain);
     if (rc != MKH_OK) return bail(rc);
     p->wide_only = true;
     if (hipMalloc((void**)&p->d_taps, sizeof(TapArgs)) != hipSuccess) return bail(fail(MKH_E_HIP, "descriptor upload failed"));
@@ -1035,6 +1083,9 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     // LDS behind the per-problem ranges: h of every pair when pairs outnumber rows (row selection), then the expanding polytope's
     // workspace when some pair goes through the general convex routine (collision_phase: the same two terms)
     P.n_hsel = (P.n_pairs > P.max_rows ? lds_even(P.n_pairs) : 0) + (p->convex_pairs ? (kEpaWsDoubles > kGjkWsDoubles ? kEpaWsDoubles : kGjkWsDoubles) : 0);
+    // the cull pass's candidate list (16-bit pair indices) when the pairs do not fit one trip of the wavefront
+    p->use_cull = P.n_pairs > kWave && P.n_pairs < 65536 && !p->simple_pairs && !getenv("MKH_DEBUG_NO_CULL");
+    if (p->use_cull) P.n_hsel += lds_even((P.n_pairs + 3) / 4);
   }
   const int ntab = m->nv + P.max_rows;
   {
@@ -1050,11 +1101,12 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   if (e == hipSuccess) e = upload(chi, &p->d_cfg_upper);
   if (e == hipSuccess) e = upload(vlim, &p->d_vel);
   if (e == hipSuccess) e = upload(pairs, &p->d_pairs);
+  if (e == hipSuccess && p->use_cull) e = upload(culls, &p->d_cull);
   if (e == hipSuccess) e = upload(dcost, &p->d_dense_cost);
   if (e == hipSuccess) e = upload(dwgain, &p->d_dense_wgain);
   if (e != hipSuccess) return bail(fail(MKH_E_HIP, "problem upload: %s", hipGetErrorString(e)));
   P.frame = p->d_frame; P.posture_cost = p->d_posture_cost; P.cfg_lower = p->d_cfg_lower; P.cfg_upper = p->d_cfg_upper;
-  P.vel_limit = p->d_vel; P.pairs = p->d_pairs;
+  P.vel_limit = p->d_vel; P.pairs = p->d_pairs; P.cull = p->use_cull ? p->d_cull : nullptr;
   P.dense_cost = p->d_dense_cost; P.dense_wgain = p->d_dense_wgain;
 
   P.nt = p->nt;
@@ -1261,7 +1313,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   // (round 5: EVERY problem with half-space rows gets this twin — its dense Goldfarb–Idnani iteration also re-solves the instances
   //  whose active rows are almost dependent, wherever they occur)
   if (!no_wide && P.n_pairs + P.n_dense_limit_rows > 0) {
-    const int32_t rc = build_wide_problem(p, m, d, ft, pairs, dcost, dwgain);
+    const int32_t rc = build_wide_problem(p, m, d, ft, pairs, culls, dcost, dwgain);
     if (rc != MKH_OK) return bail(rc);
   }
   // The two-kernel split of general convex pairs (convex_pre.hip): per convex pair the chains root → body of its two geoms, and
@@ -1294,7 +1346,7 @@ void mkh_problem_destroy(MkhProblem* p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
   (void)hipFree(p->d_frame); (void)hipFree(p->d_posture_cost); (void)hipFree(p->d_cfg_lower); (void)hipFree(p->d_cfg_upper);
-  (void)hipFree(p->d_vel); (void)hipFree(p->d_pairs); (void)hipFree(p->d_dev); (void)hipFree(p->d_taps); (void)hipFree(p->d_work);
+  (void)hipFree(p->d_vel); (void)hipFree(p->d_pairs); (void)hipFree(p->d_cull); (void)hipFree(p->d_dev); (void)hipFree(p->d_taps); (void)hipFree(p->d_work);
   (void)hipFree(p->d_lane); (void)hipFree(p->d_warm); (void)hipFree(p->d_qkeep);
   (void)hipFree(p->d_cv); (void)hipFree(p->d_cv_pair); (void)hipFree(p->d_cv_adr); (void)hipFree(p->d_cv_chain); (void)hipFree(p->d_dev_tight); (void)hipFree(p->d_status_tight);
   (void)hipFree(p->d_dense_cost); (void)hipFree(p->d_dense_wgain); (void)hipFree(p->s_iters);

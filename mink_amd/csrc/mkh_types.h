@@ -69,6 +69,16 @@ struct CollisionPairDev {
   int32_t cv_slot, cv_pad;
 };
 
+// Bounding-sphere record of a collision pair (problems with more than one wavefront of pairs: collision_phase's cull pass): the two
+// geom centres in their body frames and reach² = ((rbound1 + rbound2 + detection distance)·(1 + 1e-9))² — a pair whose centres are
+// farther apart than that is beyond the detection distance, which is all mj_geomDistance says about it (returns distmax:
+// collision_avoidance_limit.py:214-229, Contact.inactive :52-56).  +inf with a plane: never culled.
+struct PairCull {
+  int32_t body1, body2;
+  double lpos1[3], lpos2[3];
+  double reach2;
+};
+
 struct DeviceProblem {
   // sizes
   int32_t nq, nv, nbody, njnt, nrounds;
@@ -133,6 +143,7 @@ struct DeviceProblem {
   // in front of the solve and read by the analytic collision build (round 5: the two-kernel split)
   int32_t n_cv, n_cv_pad;
   const double* cv_contacts;       // [max_batch][n_cv][7], owned by the problem handle
+  const PairCull* cull;  // one record per pair when n_pairs > 64, else nullptr (ik_kernel.h collision_phase)
 };
 
 struct SolveArgs {

@@ -242,9 +242,34 @@ __device__ __attribute__((noinline)) void wide_contacts(const WideProblem* Pg, d
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const double kInf = __builtin_huge_val();
   double* const sCws = sCwsAll + wave * (kEpaWsDoubles > kGjkWsDoubles ? kEpaWsDoubles : kGjkWsDoubles);   // this wave's GJK / EPA workspace
-  for (int base = 0; base < P.n_pairs; base += 4 * kGjkSlots) {
-      const int pi = base + wave * kGjkSlots + lane;
-      const bool want = lane < kGjkSlots && pi < P.n_pairs;
+  // More than a wavefront of pairs: bounding spheres first (mkh_types.h PairCull, the rule of ik_kernel.h's collision_phase) —
+  // the distance routines run over the pairs that are left (ALOHA: a few dozen of 1 104).  The list's order is of no
+  // consequence here: every pair has its own record.
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  unsigned short* const sList = reinterpret_cast<unsigned short*>(smem + P.o_rown);
+  int* const sCount = reinterpret_cast<int*>(smem + P.o_red);
+  const bool use_cull = P.cull != nullptr;
+  int n_cand = P.n_pairs;
+  if (use_cull) {
+    __syncthreads();
+    if (tid == 0) *sCount = 0;
+    __syncthreads();
+    for (int pi = tid; pi < P.n_pairs; pi += kWideThreads) {
+      const PairCull& c = P.cull[pi];
+      const int b1 = c.body1, b2 = c.body2;
+      const Q4 bq1{sX[3 * XS + b1], sX[4 * XS + b1], sX[5 * XS + b1], sX[6 * XS + b1]}, bq2{sX[3 * XS + b2], sX[4 * XS + b2], sX[5 * XS + b2], sX[6 * XS + b2]};
+      const V3 d = (V3{sX[b2], sX[XS + b2], sX[2 * XS + b2]} + qrot(bq2, V3{c.lpos2[0], c.lpos2[1], c.lpos2[2]})) -
+                   (V3{sX[b1], sX[XS + b1], sX[2 * XS + b1]} + qrot(bq1, V3{c.lpos1[0], c.lpos1[1], c.lpos1[2]}));
+      if (!(dot(d, d) > c.reach2)) sList[atomicAdd(sCount, 1)] = (unsigned short)pi;
+      else rec[(size_t)pi * 10] = kInf;
+    }
+    __syncthreads();
+    n_cand = *sCount;
+  }
+  for (int base = 0; base < n_cand; base += 4 * kGjkSlots) {
+      const int kc = base + wave * kGjkSlots + lane;
+      const bool want = lane < kGjkSlots && kc < n_cand;
+      const int pi = !want ? 0 : (use_cull ? (int)sList[kc] : kc);
       double dist = 0.0;
       V3 from{0, 0, 0}, to{0, 0, 0};
       bool need_epa = false;
@@ -267,7 +292,7 @@ __device__ __attribute__((noinline)) void wide_contacts(const WideProblem* Pg, d
       // pairs whose cores overlap: one at a time, this wavefront cooperating on the expanding polytope
       for (unsigned long long em = __ballot(want && need_epa); em; em &= em - 1) {
         const int l = (int)__builtin_ctzll(em);
-        const CollisionPairDev& cp = P.pairs[base + wave * kGjkSlots + l];
+        const CollisionPairDev& cp = P.pairs[use_cull ? (int)sList[base + wave * kGjkSlots + l] : base + wave * kGjkSlots + l];
         V3 gp1, gp2; Q4 gq1, gq2;
         poses(cp, gp1, gq1, gp2, gq2);
         double d_e; V3 f_e, t_e;
@@ -757,6 +782,16 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp_dense(WideQpCtx X, double
 //  barrier alone — so the second resident workgroup is worth more than the registers it costs)
 __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProblem* __restrict__ Pg, SolveArgs A, const TapArgs* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  // A redo launch whose slice of the batch carries no flagged status — the usual case — ends HERE, before the layout is read and
+  // before the first spilled register is stored: the stores of the body's prologue made an idle launch write 66 KB of scratch per
+  // workgroup (34 MB per launch in the WRITE_SIZE counter, r05 profiles of shadow_c4 / g1_coll / ur5e_coll).
+  if (A.redo_mask) {
+    const int slice0 = (A.B + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int b0 = (int)blockIdx.x * slice0, e0 = b0 + slice0 < A.B ? b0 + slice0 : A.B;
+    int any = 0;
+    for (int i = b0 + (int)threadIdx.x; i < e0; i += kWideThreads) any |= A.status_out[i] & A.redo_mask;
+    if (!__syncthreads_or(any)) return;
+  }
   const WideProblem& P = *Pg;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, NT_ = kWideThreads;
   const int nq = P.nq, nv = P.nv, nbody = P.nbody, XS = nbody;
@@ -803,29 +838,62 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
     __syncthreads();
     return (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
   };
-  // A redo launch (redo_mask != 0) solves only the instances whose status carries one of the mask's bits: every workgroup owns a
-  // contiguous slice of the batch and reads its statuses 256 at a time — one coalesced load; a launch that finds nothing (the
-  // usual case) ends there (round 4 walked the statuses one dependent load after the other: 29 µs for 16 384 instances).
-  // (Measured and dropped: chunks of 16 statuses handed out through a ticket counter, so that clustered flagged instances spread
-  //  over the machine — ALOHA's 519 re-solved instances 5.85 → 5.56 ms, but every launch that finds NOTHING, the usual case, pays
-  //  two or three serial atomic round trips per workgroup: +8 µs on a 45 µs UR5e solve.)
+  // A redo launch (redo_mask != 0) solves only the instances whose status carries one of the mask's bits.  Every workgroup owns a
+  // contiguous slice of the batch, reads its statuses 256 at a time — one coalesced load (round 4 walked them one dependent load
+  // after the other: 29 µs for 16 384 instances) — and PUSHES what it finds into one queue of the launch; then the workgroups that
+  // found anything take instances from that queue until it is empty.  (A workgroup solving its own slice only: ALOHA's 519
+  // flagged instances of 16 384 are one per slice on average and six in the worst slice — the launch took six dense solves, not
+  // two.  Workgroups with an empty slice never get here (the early exit above), so a launch that finds nothing, the usual
+  // case, pays for none of this; a ticket counter over ALL workgroups instead cost such launches +8 µs.)
+  // The queue is a ring that is never reset: head ≤ tail always (an entry is taken by compare-and-swap on head, never past
+  // tail), a workgroup leaves when head = tail, and one that pushes later drains what it pushed itself if nobody else does.
   int* const sList = reinterpret_cast<int*>(sRed + 16);  // flagged instances of the current chunk (≤ 256; sRed[0, 16) carry the reductions)
-  const int slice = A.redo_mask ? (A.B + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-  const int s_begin = (int)blockIdx.x * slice, s_end = s_begin + slice < A.B ? s_begin + slice : A.B;
-  for (int chunk = A.redo_mask ? s_begin : (int)blockIdx.x; chunk < (A.redo_mask ? s_end : A.B); chunk += A.redo_mask ? NT_ : (int)gridDim.x) {
-  int n_list = 1;
   if (A.redo_mask) {
-    __syncthreads();
-    if (tid == 0) sRedI[15] = 0;
-    __syncthreads();
-    const int i = chunk + tid;
-    if (i < s_end && (A.status_out[i] & A.redo_mask)) sList[atomicAdd(&sRedI[15], 1)] = i;
-    __syncthreads();
-    n_list = sRedI[15];
-    // (ascending order: the list is filled by atomics — sort is not needed for correctness, instances are independent)
+    const int slice = (A.B + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int s_begin = (int)blockIdx.x * slice, s_end = s_begin + slice < A.B ? s_begin + slice : A.B;
+    for (int chunk = s_begin; chunk < s_end; chunk += NT_) {
+      __syncthreads();
+      if (tid == 0) sRedI[15] = 0;
+      __syncthreads();
+      const int i = chunk + tid;
+      if (i < s_end && (A.status_out[i] & A.redo_mask)) sList[atomicAdd(&sRedI[15], 1)] = i;
+      __syncthreads();
+      const int n = sRedI[15];
+      if (n > 0) {
+        if (tid == 0) sRedI[14] = (int)__hip_atomic_fetch_add(&P.redo_ctr[1], (uint32_t)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const uint32_t base = (uint32_t)sRedI[14];
+        if (tid < n) __hip_atomic_store(&P.redo_queue[(base + (uint32_t)tid) & (P.redo_cap - 1u)], sList[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
-  for (int li = 0; li < n_list; ++li) {
-    const int pb = A.redo_mask ? sList[li] : chunk;
+  for (int chunk = (int)blockIdx.x;; chunk += (int)gridDim.x) {
+  {
+    int pb;
+    if (A.redo_mask) {
+      __syncthreads();
+      if (tid == 0) {
+        int item = -1;
+        for (;;) {
+          const uint32_t h = __hip_atomic_load(&P.redo_ctr[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const uint32_t t = __hip_atomic_load(&P.redo_ctr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((int32_t)(t - h) <= 0) break;
+          uint32_t expect = h;
+          if (!__hip_atomic_compare_exchange_strong(&P.redo_ctr[0], &expect, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+          int32_t* const slot = &P.redo_queue[h & (P.redo_cap - 1u)];
+          while ((item = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(2);   // (reserved, on its way)
+          __hip_atomic_store(slot, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        sRedI[14] = item;
+      }
+      __syncthreads();
+      pb = sRedI[14];
+      if (pb < 0) break;
+    } else {
+      if (chunk >= A.B) break;
+      pb = chunk;
+    }
     __syncthreads();
     // ------------------------------------------------------------ inputs
     for (int i = tid; i < nq; i += NT_) sq[i] = A.q[(size_t)pb * nq + i];

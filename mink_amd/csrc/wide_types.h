@@ -51,6 +51,13 @@ struct WideProblem {
   double cfg_gain[kMaxBoxTerms];
   const double* vel_limit;                 // [n_vel][nv]
   const CollisionPairDev* pairs;
+  const PairCull* cull;                    // bounding-sphere records (more than 64 pairs: wide_contacts' cull pass), else nullptr
+  // redo launches: the flagged instances of all workgroups go through ONE queue (ring of redo_cap entries, −1 = empty;
+  // redo_ctr[0] = head, [1] = tail, never reset — the ring is at least as long as the largest batch)
+  int32_t* redo_queue;
+  uint32_t* redo_ctr;
+  uint32_t redo_cap;                       // power of two ≥ max_batch
+  uint32_t redo_pad;
   // per-workgroup slice of device memory: weighted Jacobian rows, pair records, row → pair map, (the tableau)
   double* ws;
   long long ws_stride;                     // doubles per workgroup

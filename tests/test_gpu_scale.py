@@ -592,3 +592,35 @@ def test_convex_pairs_in_a_kernel_of_their_own_from_32768_items():
     v_ref = _numpy_oracle_chunk((name, np.arange(0, B, 1024), q, tg, pt, dt, damping))
     e2 = np.abs(v[::1024] - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
     assert e2.max() < 2e-5, e2.max()
+
+
+def test_the_bounding_sphere_cull_of_many_pairs_changes_nothing(monkeypatch):
+    """Round 5: a problem with more than one wavefront of collision pairs (the reference's ALOHA example: 1 104) drops the pairs
+    whose bounding spheres are farther apart than the detection distance before the distance routines run (ik_kernel.h
+    collision_phase, wide_kernel.h wide_contacts: 5.9 → 2.7 ms).  A culled pair is one mj_geomDistance answers `distmax` for
+    (collision_avoidance_limit.py:214-229), so NOTHING may change: bitwise the same v, statuses, h of every pair (the tap layout
+    of all 1 104) with the cull and without it (MKH_DEBUG_NO_CULL, read when the handle is created)."""
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+    name, B = "aloha_coll", 4096
+    model = workloads.load_bench_robot(name)
+    nm = nat.NativeModel(model)
+    out = {}
+    for cull in (True, False):
+        if cull:
+            monkeypatch.delenv("MKH_DEBUG_NO_CULL", raising=False)
+        else:
+            monkeypatch.setenv("MKH_DEBUG_NO_CULL", "1")
+        prob, dt, damping = workloads.bench_config(name, model, nm, B)
+        q, tg, pt, _ = workloads.bench_batch(name, model, nm, prob, np.random.default_rng(11), B)
+        v, st = prob.solve(q, tg, pt, None, dt, damping)
+        assert prob.last_kernel() == "ik_solve_kernel_64_8+wide", prob.last_kernel()
+        _, _, t = prob.solve(q[:512], tg[:512], pt, None, dt, damping, taps=["coll_h"], solve_qp=False)
+        out[cull] = (v, st, t["coll_h"])
+    h = out[True][2]
+    in_range = np.isfinite(h).sum(axis=1)
+    print("aloha_coll: %d pairs, in range per instance: mean %.1f, max %d" % (h.shape[1], in_range.mean(), in_range.max()))
+    assert h.shape[1] == 1104 and in_range.max() < h.shape[1] // 4
+    np.testing.assert_array_equal(out[True][0], out[False][0])
+    np.testing.assert_array_equal(out[True][1], out[False][1])
+    np.testing.assert_array_equal(out[True][2], out[False][2])

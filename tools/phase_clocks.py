@@ -17,6 +17,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 path = os.path.join(tempfile.gettempdir(), "mkh_clocks.bin")
 os.environ["MKH_DEBUG_CLOCKS"] = path
+os.environ.setdefault("MKH_DEBUG_NO_WIDE", "1")     # (the workgroup-per-problem redo launch would overwrite the stamps of the wavefront kernel)
 
 import torch  # noqa: E402
 

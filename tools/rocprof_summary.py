@@ -94,8 +94,10 @@ def pmc(out_path, dirs):
         if iks:
             # (a tight-rows solve is two launches — the 48-row build and the full-row redo behind it, equally often: the one
             #  that does the work has the larger counters)
+            #  The workgroup-per-problem redo launch behind a wavefront kernel is never the main one: its 256-thread workgroups
+            #  win on some counters (SQ_WAVES) and lose on others, and the choice must be the same in every pass.
             count = lambda k: max(len(per) for per in iks[k].values())
-            main = max(iks, key=lambda k: (count(k), sum(sum(per.values()) for per in iks[k].values())))
+            main = max(iks, key=lambda k: (count(k), "ik_wide_kernel" not in k, sum(sum(per.values()) for per in iks[k].values())))
             solve_kernel = main
             for k in iks:
                 if k != main and count(k) == count(main):
