@@ -1281,11 +1281,18 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     const DeviceProblem& P0 = p->dev;
     const int cap = 48 - m->nv;
     static const bool no_tight = getenv("MKH_DEBUG_NO_TIGHT_ROWS") != nullptr;      // (A/B of this path)
-    if (!no_tight && p->simple_pairs && P0.n_dense_limit_rows == 0 && P0.n_dense_rows == 0 && !P0.dense_box && p->nt == 64 &&
-        cap >= 16 && P0.n_pairs > cap) {
+    // Round 5: the same for pair sets with boxes, cylinders, ... (the analytic collision build) — a humanoid-size robot reserves
+    // 64 − nv rows, which costs the 64-row build a resident wavefront or two in LDS: G1 with 46 pairs (21 rows, 24.6 KB: 6
+    // wavefronts per CU) 0.757 → ≈ 0.60 ms with 5 rows on the 48-row build.  Few contacts are in range at a time when
+    // collision avoidance works; when many are, the cost is the two launches (MKH_FLAG_FULL_ROWS pins the full-row build).
+    //  Humanoid-size robots only (32 dofs and up): ALOHA (16 dofs, 48 rows reserved, 1 104 pairs) measures 2.26 → 2.53 ms this
+    //  way — its full build is not short of wavefronts, and the instances that overflow 32 rows walk the pair list twice.
+    const bool generic = !p->simple_pairs && !p->convex_pairs && P0.n_pairs > 0 && m->nv >= 32 && cap >= 4 && !getenv("MKH_DEBUG_NO_TIGHT_GENERIC");
+    if (!no_tight && (p->simple_pairs ? cap >= 16 : generic) && P0.n_dense_limit_rows == 0 && P0.n_dense_rows == 0 && !P0.dense_box && p->nt == 64 &&
+        P0.n_pairs > cap) {
       DeviceProblem T = P0;
       T.max_rows = cap;
-      T.n_hsel = T.n_pairs;
+      T.n_hsel = lds_even(T.n_pairs) + (p->use_cull ? lds_even((T.n_pairs + 3) / 4) : 0);
       T.nt = 48;
       auto lds_t = [&](bool pre) {
         return lds_layout(T.nq, T.nv, T.nbody, T.njnt, T.n_frame, T.n_posture, T.n_com, T.max_rows, 6, j_stride_direct(T.nv, 48), 0, pre,
@@ -1577,7 +1584,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
     w3 = true; lds = p->wood_lds_bytes_w3;
   }
   // tight rows first (see mkh_problem_create): plain solves on the capsule-only collision build whose caller takes the status
-  const bool tight = p->d_dev_tight && feat == (F_COLL | F_SIMPLE_COLL) && !nr && !w3 && a.do_qp && a.status_out && !taps &&
+  const bool tight = p->d_dev_tight && (feat == (F_COLL | F_SIMPLE_COLL) || feat == F_COLL) && !nr && !w3 && a.do_qp && a.status_out && !taps &&
                      !(flags & MKH_FLAG_FULL_ROWS);
   static const bool no_redo = getenv("MKH_DEBUG_NO_REDO") != nullptr;       // (tests: what the tight launch alone leaves flagged)
   if (tight && no_redo) {

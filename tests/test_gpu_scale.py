@@ -319,7 +319,7 @@ def test_cold_start_refinement_agrees_with_the_plain_low_rank_start(monkeypatch)
 
 _BENCH_KERNELS = {"ur5e_c2": "ik_quad_kernel", "g1_c3": "ik_solve_kernel_44_32_r44_w3", "g1_full": "ik_solve_kernel_44_36_r44",
                   "shadow_c4": "ik_solve_kernel_48_72+redo_64", "g1_plugin": "ik_solve_kernel_48_256", "h1_c3": "ik_quad_kernel_32",
-                  "h1_full": "ik_quad_kernel_32", "g1_coll": "ik_solve_kernel_64_8+wide", "ur5e_coll": "ik_solve_kernel_16_8",
+                  "h1_full": "ik_quad_kernel_32", "g1_coll": "ik_solve_kernel_48_8+redo_64+wide", "ur5e_coll": "ik_solve_kernel_16_8",
                   "g1_hands": "ik_wide_kernel"}
 
 
@@ -458,14 +458,22 @@ def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name, monk
         print("aloha_coll: contacts in range per instance (every 64th): mean %.1f, max %d of 1104 pairs; tableau rows 48" % (rows.mean(), rows.max()))
         assert rows.max() >= 8
     if name == "g1_coll":
-        # the pair of launches the bench times: the wavefront kernel holds 21 rows, the workgroup-per-problem kernel re-solves
-        # what it flags.  How many that is: the same batch on a handle without the redo launch (MKH_DEBUG_NO_WIDE, read per handle)
+        # the launches the bench times (round 5: tight rows first, as for the Shadow hand): the 48-row build with 5 rows, the
+        # 64-row build with 21 on what that one flags, the workgroup-per-problem kernel on what is flagged then.  How many that is:
+        # the same batch on a handle without the last launch (MKH_DEBUG_NO_WIDE, read per handle)
         monkeypatch.setenv("MKH_DEBUG_NO_WIDE", "1")
         alone, _, _ = workloads.bench_config(name, model, nm, B)
         monkeypatch.delenv("MKH_DEBUG_NO_WIDE")
         v1, st1 = alone.solve(q, tg, pt, com, dt, damping)
-        assert alone.last_kernel().removesuffix("+wide") == "ik_solve_kernel_64_8", alone.last_kernel()
+        assert alone.last_kernel() == "ik_solve_kernel_48_8+redo_64", alone.last_kernel()
         flagged = np.flatnonzero(st1 & 16)
+        # ... and the full-row build alone (MKH_FLAG_FULL_ROWS), another kernel with the same answers
+        v_full, st_full = alone.solve(q, tg, pt, com, dt, damping, full_rows=True)
+        assert alone.last_kernel() == "ik_solve_kernel_64_8", alone.last_kernel()
+        okf = (st_full & 16) == 0
+        e_full = np.abs(v_full - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
+        print("g1_coll: full-row build alone: max rel err %.2e on the %d instances it does not flag" % (e_full[okf].max(), okf.sum()))
+        assert e_full[okf].max() < 1e-8
         rows = np.array([np.isfinite(cp.collision_rows(q[i], dt, which=0)[1]).sum() for i in range(0, B, 64)])
         print("g1_coll: %d of %d instances re-solved with every row by the wide kernel (err on those: %.2e); contacts in range "
               "per instance: mean %.1f, max %d" % (len(flagged), B, err[flagged].max() if len(flagged) else 0.0, rows.mean(), rows.max()))
