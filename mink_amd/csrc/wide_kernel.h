@@ -785,11 +785,15 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
   // A redo launch whose slice of the batch carries no flagged status — the usual case — ends HERE, before the layout is read and
   // before the first spilled register is stored: the stores of the body's prologue made an idle launch write 66 KB of scratch per
   // workgroup (34 MB per launch in the WRITE_SIZE counter, r05 profiles of shadow_c4 / g1_coll / ur5e_coll).
+  // (A workgroup's share of the statuses: chunks of 16 — one 64-byte line — dealt round-robin, so that a cluster of flagged
+  //  instances spreads over the workgroups.)
   if (A.redo_mask) {
-    const int slice0 = (A.B + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int b0 = (int)blockIdx.x * slice0, e0 = b0 + slice0 < A.B ? b0 + slice0 : A.B;
+    const int nck = (A.B + 15) >> 4;
     int any = 0;
-    for (int i = b0 + (int)threadIdx.x; i < e0; i += kWideThreads) any |= A.status_out[i] & A.redo_mask;
+    for (int c = (int)blockIdx.x + ((int)threadIdx.x >> 4) * (int)gridDim.x; c < nck; c += (kWideThreads / 16) * (int)gridDim.x) {
+      const int i = c * 16 + ((int)threadIdx.x & 15);
+      if (i < A.B) any |= A.status_out[i] & A.redo_mask;
+    }
     if (!__syncthreads_or(any)) return;
   }
   const WideProblem& P = *Pg;
@@ -838,25 +842,24 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
     __syncthreads();
     return (sRed[0] + sRed[1]) + (sRed[2] + sRed[3]);
   };
-  // A redo launch (redo_mask != 0) solves only the instances whose status carries one of the mask's bits.  Every workgroup owns a
-  // contiguous slice of the batch, reads its statuses 256 at a time — one coalesced load (round 4 walked them one dependent load
-  // after the other: 29 µs for 16 384 instances) — and PUSHES what it finds into one queue of the launch; then the workgroups that
-  // found anything take instances from that queue until it is empty.  (A workgroup solving its own slice only: ALOHA's 519
-  // flagged instances of 16 384 are one per slice on average and six in the worst slice — the launch took six dense solves, not
-  // two.  Workgroups with an empty slice never get here (the early exit above), so a launch that finds nothing, the usual
+  // A redo launch (redo_mask != 0) solves only the instances whose status carries one of the mask's bits.  Every workgroup reads
+  // its share of the statuses 256 at a time (round 4 walked them one dependent load after the other: 29 µs for 16 384 instances)
+  // and PUSHES what it finds into one queue of the launch; then the workgroups that found anything take instances from that
+  // queue until it is empty.  (A workgroup solving a contiguous slice of its own: ALOHA's 519 flagged instances of 16 384 come
+  // in clusters — the launch took six dense solves one after the other where two would do.  Workgroups with an empty slice never get here (the early exit above), so a launch that finds nothing, the usual
   // case, pays for none of this; a ticket counter over ALL workgroups instead cost such launches +8 µs.)
   // The queue is a ring that is never reset: head ≤ tail always (an entry is taken by compare-and-swap on head, never past
   // tail), a workgroup leaves when head = tail, and one that pushes later drains what it pushed itself if nobody else does.
   int* const sList = reinterpret_cast<int*>(sRed + 16);  // flagged instances of the current chunk (≤ 256; sRed[0, 16) carry the reductions)
   if (A.redo_mask) {
-    const int slice = (A.B + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int s_begin = (int)blockIdx.x * slice, s_end = s_begin + slice < A.B ? s_begin + slice : A.B;
-    for (int chunk = s_begin; chunk < s_end; chunk += NT_) {
+    const int nck = (A.B + 15) >> 4;
+    for (int c0 = (int)blockIdx.x; c0 < nck; c0 += (NT_ / 16) * (int)gridDim.x) {
       __syncthreads();
       if (tid == 0) sRedI[15] = 0;
       __syncthreads();
-      const int i = chunk + tid;
-      if (i < s_end && (A.status_out[i] & A.redo_mask)) sList[atomicAdd(&sRedI[15], 1)] = i;
+      const int c = c0 + (tid >> 4) * (int)gridDim.x;
+      const int i = c * 16 + (tid & 15);
+      if (c < nck && i < A.B && (A.status_out[i] & A.redo_mask)) sList[atomicAdd(&sRedI[15], 1)] = i;
       __syncthreads();
       const int n = sRedI[15];
       if (n > 0) {

@@ -41,6 +41,9 @@ def run(name, B=None):
     tot = (c[:, 12] - c[:, 0]).astype(np.float64)
     print("%s, B = %d: %d workgroups; per problem %.0f k core-clock cycles; N = %.0f, ratio-test rounds %.1f, pivots after phase 0 %.1f"
           % (name, B, prob.launch_info(B)["grid"], tot.mean() / 1e3, c[:, 16].mean(), c[:, 13].mean(), c[:, 14].mean()))
+    print("  per problem: p50 %.0f k, p90 %.0f k, p99 %.0f k, max %.0f k cycles; ratio-test rounds: p50 %.0f, p99 %.0f, max %.0f"
+          % (np.percentile(tot, 50) / 1e3, np.percentile(tot, 90) / 1e3, np.percentile(tot, 99) / 1e3, tot.max() / 1e3,
+             np.percentile(c[:, 13], 50), np.percentile(c[:, 13], 99), c[:, 13].max()))
     for k, n in enumerate(NAMES):
         print("  %-16s %9.0f cycles  %5.1f %%" % (n, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean()))
 
