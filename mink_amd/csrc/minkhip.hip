@@ -575,7 +575,7 @@ static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhPro
   W.tableau_in_lds = (long long)o + (long long)Ncap * Ncap <= lds_cap ? 1 : 0;
   // the dense Goldfarb–Idnani fallback's factors (2·nv² + 2·nv + 8 doubles) in LDS when that costs neither the tableau's place nor
   // the second resident workgroup
-  const long long gi_sz = rows_max > 0 ? 2ll * nv * nv + 4ll * (nv + 2) : 0;
+  const long long gi_sz = rows_max > 0 ? 2ll * nv * (nv | 1) + 4ll * (nv + 2) : 0;
   const int two_wg = 80 * 1024 / 8;
   W.o_gi = o; W.gi_in_lds = 0;
   if (gi_sz > 0 && (long long)o + gi_sz + (long long)(nv + 8) * (nv + 8) <= two_wg) { W.gi_in_lds = 1; o += (int)gi_sz; }
@@ -599,7 +599,7 @@ static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhPro
   W.ws_rowpair = w; w += ev((W.max_rows + 2) / 2);
   W.ws_rank = w; w += ev((W.n_pairs + 2) / 2);
   W.ws_T = w; w += W.tableau_in_lds ? 0 : (long long)Ncap * Ncap;
-  W.ws_gi = w; w += rows_max > 0 ? 2ll * nv * nv + 4ll * (nv + 2) : 0;
+  W.ws_gi = w; w += rows_max > 0 ? 2ll * nv * (nv | 1) + 4ll * (nv + 2) : 0;
   W.ws_stride = (w + 15) & ~15ll;
   const int per_cu = (160 * 1024) / (o * 8) < 2 ? ((160 * 1024) / (o * 8) < 1 ? 1 : (160 * 1024) / (o * 8)) : 2;
   int grid = m->num_cus * per_cu;

@@ -533,7 +533,7 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp(WideQpCtx X, long long* c
 // ±e_i like any other.  Rare path (5 % of the ALOHA workload, none elsewhere): parallel over the workgroup in the O(n²) steps,
 // one thread for the O(n) bookkeeping; J and R live in the workgroup's slice of device memory.
 // In: T = K = [[H, Aᵀ],[A, 0]] as built (no pivots yet), sW = (c, −h), sLo / sHi, sRown (row norms).  Out: sZ[0, nv) = Δq.
-__device__ __attribute__((noinline)) WideQpOut wide_qp_dense(WideQpCtx X, double* ws) {
+__device__ __attribute__((noinline)) WideQpOut wide_qp_dense(WideQpCtx X, double* ws, long long* clk) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, N = X.N, n = X.nv, m = X.N - X.nv;
   constexpr int NT_ = kWideThreads;
@@ -550,11 +550,16 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp_dense(WideQpCtx X, double
   int* const sRedI = reinterpret_cast<int*>(sRed + NT_);
   int* const act = reinterpret_cast<int*>(smem + X.o_state);      // dof i: bit 0 lower bound active, 1 upper active, 2 / 3 lower / upper set aside; row s (at nv + s): 1 active, 2 set aside
   const double* const T = X.T;
-  double* const J = ws;                                 // n × n, row-major
-  double* const R = ws + (size_t)n * n;                 // upper triangular, R[i·n + k], i ≤ k
-  double* const u = R + (size_t)n * n;                  // multipliers of the active set (+ u⁺)
+  const int ld = n | 1;                                 // row stride of J and R: odd, so that a column walks all LDS banks
+  double* const J = ws;                                 // n × n, row-major (stride ld)
+  double* const R = ws + (size_t)n * ld;                // upper triangular, R[i·ld + k], i ≤ k
+  double* const u = R + (size_t)n * ld;                 // multipliers of the active set (+ u⁺)
   int* const A = reinterpret_cast<int*>(u + n + 2);     // active constraints, ordered: code 0 … m−1 rows, m + i upper of dof i, m + n + i lower
   int status = 0, iters = 0, n_outer = 0, n_piv = 0;
+  // (clock stamps of the sections, MKH_DEBUG_CLOCKS: slots 17 … 22 of the problem's row — factors, violated-constraint search,
+  //  directions, step lengths, add, drop)
+  long long t_sec[6] = {0, 0, 0, 0, 0, 0}, t_last = clk ? (long long)__builtin_readcyclecounter() : 0;
+#define MKH_DSEC(k) do { if (clk) { const long long now_ = (long long)__builtin_readcyclecounter(); t_sec[k] += now_ - t_last; t_last = now_; } } while (0)
   auto block_arg_min = [&](double val, int idx, double& best, int& besti) {
     const double key = idx < 0 ? -kInf : -val;
     const double mk = wave_max(key);
@@ -584,39 +589,41 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp_dense(WideQpCtx X, double
     return lo[code - m - n];
   };
   // ---- H = L·Lᵀ (L in the R buffer), J = L⁻ᵀ
-  for (int e = tid; e < n * n; e += NT_) { R[e] = T[(size_t)(e / n) * N + e % n]; J[e] = 0.0; }
+  for (int e = tid; e < n * n; e += NT_) { const int i_ = e / n, j_ = e % n; R[(size_t)i_ * ld + j_] = T[(size_t)i_ * N + j_]; J[(size_t)i_ * ld + j_] = 0.0; }
   __syncthreads();
   for (int k = 0; k < n; ++k) {
-    const double dkk = R[(size_t)k * n + k];
+    const double dkk = R[(size_t)k * ld + k];
     if (!(dkk > 0.0)) { status |= 4; break; }             // (uniform: every thread reads the same entry)
     const double lkk = sqrt(dkk);
     __syncthreads();
-    for (int i = k + tid; i < n; i += NT_) R[(size_t)i * n + k] = (i == k) ? lkk : R[(size_t)i * n + k] / lkk;
+    for (int i = k + tid; i < n; i += NT_) R[(size_t)i * ld + k] = (i == k) ? lkk : R[(size_t)i * ld + k] / lkk;
     __syncthreads();
     for (int e = tid; e < (n - k - 1) * (n - k - 1); e += NT_) {
       const int i = k + 1 + e / (n - k - 1), j = k + 1 + e % (n - k - 1);
-      if (j <= i) R[(size_t)i * n + j] -= R[(size_t)i * n + k] * R[(size_t)j * n + k];
+      if (j <= i) R[(size_t)i * ld + j] -= R[(size_t)i * ld + k] * R[(size_t)j * ld + k];
     }
     __syncthreads();
   }
   if (status) return WideQpOut{status, 0, 0, 0};
   // X = L⁻¹ column by column (one thread per column), J = Xᵀ
   for (int j = tid; j < n; j += NT_) {
-    J[(size_t)j * n + j] = 1.0 / R[(size_t)j * n + j];
+    J[(size_t)j * ld + j] = 1.0 / R[(size_t)j * ld + j];
     for (int i = j + 1; i < n; ++i) {
       double sacc = 0.0;
-      for (int k = j; k < i; ++k) sacc += R[(size_t)i * n + k] * J[(size_t)j * n + k];      // X[k][j] is stored as J[j][k]
-      J[(size_t)j * n + i] = -sacc / R[(size_t)i * n + i];
+      for (int k = j; k < i; ++k) sacc += R[(size_t)i * ld + k] * J[(size_t)j * ld + k];      // X[k][j] is stored as J[j][k]
+      J[(size_t)j * ld + i] = -sacc / R[(size_t)i * ld + i];
     }
   }
   __syncthreads();
-  for (int e = tid; e < n * n; e += NT_) R[e] = 0.0;
+  for (int e = tid; e < n * ld; e += NT_) R[e] = 0.0;
   // x = −J·Jᵀ·c
-  for (int j = tid; j < n; j += NT_) { double sacc = 0.0; for (int i = 0; i < n; ++i) sacc += J[(size_t)i * n + j] * cw[i]; dv[j] = sacc; }
+  for (int j = tid; j < n; j += NT_) { double sacc = 0.0; for (int i = 0; i < n; ++i) sacc += J[(size_t)i * ld + j] * cw[i]; dv[j] = sacc; }
   __syncthreads();
-  for (int i = tid; i < n; i += NT_) { double sacc = 0.0; for (int k = 0; k < n; ++k) sacc += J[(size_t)i * n + k] * dv[k]; xv[i] = -sacc; }
+  for (int i = tid; i < n; i += NT_) { double sacc = 0.0; for (int k = 0; k < n; ++k) sacc += J[(size_t)i * ld + k] * dv[k]; xv[i] = -sacc; }
   for (int i = tid; i < N; i += NT_) act[i] = 0;
   __syncthreads();
+  MKH_DSEC(0);
+  if (clk && tid == 0) clk[10] = (long long)__builtin_readcyclecounter();
   int nact = 0;
   const int mc = m + 2 * n, max_iters = 50 * (n + mc);
   while (!(status & 14)) {
@@ -646,6 +653,7 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp_dense(WideQpCtx X, double
     }
     double pv; int p;
     block_arg_min(bv, bi, pv, p);
+    MKH_DSEC(1);
     if (p < 0) break;                                     // optimal
     ++n_outer;
     if (tid == 0) u[nact] = 0.0;
@@ -655,15 +663,15 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp_dense(WideQpCtx X, double
       __syncthreads();
       for (int j = tid; j < n; j += NT_) {
         double sacc = 0.0;
-        if (p < m) { for (int i = 0; i < n; ++i) sacc -= J[(size_t)i * n + j] * T[(size_t)(n + p) * N + i]; }
-        else if (p < m + n) sacc = -J[(size_t)(p - m) * n + j];
-        else sacc = J[(size_t)(p - m - n) * n + j];
+        if (p < m) { for (int i = 0; i < n; ++i) sacc -= J[(size_t)i * ld + j] * T[(size_t)(n + p) * N + i]; }
+        else if (p < m + n) sacc = -J[(size_t)(p - m) * ld + j];
+        else sacc = J[(size_t)(p - m - n) * ld + j];
         dv[j] = sacc;
       }
       __syncthreads();
       for (int i = tid; i < n; i += NT_) {
         double sacc = 0.0;
-        for (int k = nact; k < n; ++k) sacc += J[(size_t)i * n + k] * dv[k];
+        for (int k = nact; k < n; ++k) sacc += J[(size_t)i * ld + k] * dv[k];
         zv[i] = sacc;
         if (i < nact) rv[i] = dv[i];
       }
@@ -672,10 +680,16 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp_dense(WideQpCtx X, double
         // back-substitution inside ONE wavefront: lane i carries r_i in a register, the pivot travels by v_readlane — no barrier per
         // column (two 4-wave barriers per column were most of an iteration's synchronisation: 2·nact of ≈ 2·nact + 10)
         if (wave == 0) {
+          // (the diagonal's reciprocals by their lanes at once, and the column of step k − 1 on its way while step k computes:
+          //  a division and an LDS round trip per step were half of this loop)
           double ri = lane < nact ? rv[lane] : 0.0;
+          const double invd = lane < nact ? 1.0 / R[(size_t)lane * ld + lane] : 0.0;
+          double rnext = lane < nact ? R[(size_t)lane * ld + nact - 1] : 0.0;
           for (int k = nact - 1; k >= 0; --k) {
-            const double rk = readlane_f64(ri, k) / R[(size_t)k * n + k];
-            if (lane < k) ri -= rk * R[(size_t)lane * n + k];
+            const double rcol = rnext;
+            if (k > 0) rnext = lane < nact ? R[(size_t)lane * ld + k - 1] : 0.0;
+            const double rk = readlane_f64(ri, k) * readlane_f64(invd, k);
+            if (lane < k) ri -= rk * rcol;
             if (lane == k) ri = rk;
           }
           if (lane < nact) rv[lane] = ri;
@@ -683,21 +697,28 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp_dense(WideQpCtx X, double
         __syncthreads();
       } else {
       for (int k = nact - 1; k >= 0; --k) {               // back-substitution, column-oriented
-        if (tid == 0) rv[k] = rv[k] / R[(size_t)k * n + k];
+        if (tid == 0) rv[k] = rv[k] / R[(size_t)k * ld + k];
         __syncthreads();
-        for (int i = tid; i < k; i += NT_) rv[i] -= rv[k] * R[(size_t)i * n + k];
+        for (int i = tid; i < k; i += NT_) rv[i] -= rv[k] * R[(size_t)i * ld + k];
         __syncthreads();
       }
       }
-      // ---- step 2b: step lengths (one thread: O(n))
-      if (tid == 0) {
-        double t1 = kInf; int l = -1;
-        for (int k = 0; k < nact; ++k)
-          if (rv[k] > 0.0) { const double tk = u[k] / rv[k]; if (tk < t1) { t1 = tk; l = k; } }
-        double dd2 = 0.0, dd = 0.0, sp = -rhs(p);
-        for (int k = 0; k < n; ++k) { dd += dv[k] * dv[k]; if (k >= nact) dd2 += dv[k] * dv[k]; sp += normal(p, k) * xv[k]; }
+      MKH_DSEC(2);
+      // ---- step 2b: step lengths — wave 0, one constraint / one dof per lane (one thread walking them: 8.7 k cycles per iteration,
+      //      a third of this function on ALOHA)
+      if (wave == 0) {
+        double t1l = kInf; int ll = -1;
+        for (int k = lane; k < nact; k += 64) {
+          const double rk = rv[k];
+          if (rk > 0.0) { const double tk = u[k] / rk; if (tk < t1l) { t1l = tk; ll = k; } }
+        }
+        const double t1w = -wave_max(-t1l);
+        const unsigned lw = wave_min_u32((ll >= 0 && t1l == t1w) ? (unsigned)ll : 0xffffffffu);       // (lowest index on ties)
+        double dd2 = 0.0, dd = 0.0, sp = 0.0;
+        for (int k = lane; k < n; k += 64) { const double dk = dv[k]; dd += dk * dk; if (k >= nact) dd2 += dk * dk; sp += normal(p, k) * xv[k]; }
+        dd = wave_sum(dd); dd2 = wave_sum(dd2); sp = wave_sum(sp) - rhs(p);
         const double t2 = (dd2 > 1e-24 * dd) ? -sp / dd2 : kInf;
-        sRed[0] = t1; sRed[1] = t2; sRed[2] = sqrt(dd2); sRedI[8] = l;
+        if (lane == 0) { sRed[0] = t1w; sRed[1] = t2; sRed[2] = sqrt(dd2); sRedI[8] = (int)lw; }
       }
       __syncthreads();
       const double t1 = sRed[0], t2 = sRed[1], nd2 = sRed[2];
@@ -716,8 +737,9 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp_dense(WideQpCtx X, double
       }
       if (!(t < kInf)) { status |= 2; break; }            // constraints are inconsistent
       if (!dual_only) for (int i = tid; i < n; i += NT_) xv[i] += t * zv[i];
-      if (tid == 0) { for (int k = 0; k < nact; ++k) u[k] -= t * rv[k]; u[nact] += t; }
+      if (wave == 0) { for (int k = lane; k < nact; k += 64) u[k] -= t * rv[k]; if (lane == 0) u[nact] += t; }
       __syncthreads();
+      MKH_DSEC(3);
       if (full) {
         // ---- add p: one Householder reflection on the columns nact … n−1 of J takes d₂ to ±‖d₂‖·e₁ (the Givens sequence of the
         // textbook in one parallel step); R gets the column (d₁, ∓‖d₂‖)
@@ -725,56 +747,77 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp_dense(WideQpCtx X, double
         const double vtv = 2.0 * (nd2 * nd2 - d0 * beta);
         if (vtv > 0.0) {
           for (int i = tid; i < n; i += NT_) {
-            double wacc = J[(size_t)i * n + nact] * (d0 - beta);
-            for (int k = nact + 1; k < n; ++k) wacc += J[(size_t)i * n + k] * dv[k];
+            double wacc = J[(size_t)i * ld + nact] * (d0 - beta);
+            for (int k = nact + 1; k < n; ++k) wacc += J[(size_t)i * ld + k] * dv[k];
             const double f = 2.0 * wacc / vtv;
-            J[(size_t)i * n + nact] -= f * (d0 - beta);
-            for (int k = nact + 1; k < n; ++k) J[(size_t)i * n + k] -= f * dv[k];
+            J[(size_t)i * ld + nact] -= f * (d0 - beta);
+            for (int k = nact + 1; k < n; ++k) J[(size_t)i * ld + k] -= f * dv[k];
           }
         }
-        for (int i = tid; i <= nact; i += NT_) R[(size_t)i * n + nact] = (i < nact) ? dv[i] : beta;
+        for (int i = tid; i <= nact; i += NT_) R[(size_t)i * ld + nact] = (i < nact) ? dv[i] : beta;
         if (tid == 0) { A[nact] = p; if (p < m) act[n + p] = 1; else if (p < m + n) act[p - m] |= 2; else act[p - m - n] |= 1; }
         ++nact; ++n_piv;
         __syncthreads();
+        MKH_DSEC(4);
         break;
       }
       // ---- drop the blocking constraint l (partial step, or a step in the dual space only), then try p again
-      if (tid == 0) {
-        const int code = A[l];
-        if (code < m) act[n + code] = 0; else if (code < m + n) act[code - m] &= ~2; else act[code - m - n] &= ~1;
-        for (int k = l; k < nact - 1; ++k) { A[k] = A[k + 1]; u[k] = u[k + 1]; }
-        u[nact - 1] = u[nact];
+      if (wave == 0) {                                    // (the lists close up: a lane per entry, loads before stores)
+        if (lane == 0) {
+          const int code = A[l];
+          if (code < m) act[n + code] = 0; else if (code < m + n) act[code - m] &= ~2; else act[code - m - n] &= ~1;
+        }
+        for (int k0 = l; k0 < nact; k0 += 64) {
+          const int k = k0 + lane;
+          const bool on = k < nact;
+          const double uu = on ? u[k + 1] : 0.0;
+          const int aa = (on && k < nact - 1) ? A[k + 1] : 0;
+          if (on) u[k] = uu;
+          if (on && k < nact - 1) A[k] = aa;
+        }
       }
-      for (int k = l; k < nact - 1; ++k) {                // columns shift left: upper Hessenberg from l on
+      // columns shift left: upper Hessenberg from l on — every entry at once when the block fits the workgroup
+      if ((nact - 1 - l) * nact <= NT_) {
+        const int kk = l + tid / nact, ii = tid % nact;
+        const bool on = tid < (nact - 1 - l) * nact && ii <= kk + 1;
+        const double val = on ? R[(size_t)ii * ld + kk + 1] : 0.0;
         __syncthreads();
-        for (int i = tid; i <= k + 1; i += NT_) R[(size_t)i * n + k] = R[(size_t)i * n + k + 1];
+        if (on) R[(size_t)ii * ld + kk] = val;
+      } else {
+        for (int k = l; k < nact - 1; ++k) {
+          __syncthreads();
+          for (int i = tid; i <= k + 1; i += NT_) R[(size_t)i * ld + k] = R[(size_t)i * ld + k + 1];
+        }
       }
       __syncthreads();
-      for (int i = tid; i < n; i += NT_) R[(size_t)i * n + nact - 1] = 0.0;
+      for (int i = tid; i < n; i += NT_) R[(size_t)i * ld + nact - 1] = 0.0;
       --nact; ++n_piv;
       for (int k = l; k < nact; ++k) {                    // Givens on rows (k, k+1) of R, columns (k, k+1) of J
         __syncthreads();
-        const double a = R[(size_t)k * n + k], b = R[(size_t)(k + 1) * n + k];
+        const double a = R[(size_t)k * ld + k], b = R[(size_t)(k + 1) * ld + k];
         const double hh = hypot(a, b);
         const double cs = b == 0.0 ? 1.0 : a / hh, sn = b == 0.0 ? 0.0 : b / hh;
         __syncthreads();
         if (b != 0.0) {
           for (int j = k + tid; j < nact; j += NT_) {
-            const double ra = R[(size_t)k * n + j], rb = R[(size_t)(k + 1) * n + j];
-            R[(size_t)k * n + j] = (j == k) ? hh : cs * ra + sn * rb;
-            R[(size_t)(k + 1) * n + j] = (j == k) ? 0.0 : -sn * ra + cs * rb;
+            const double ra = R[(size_t)k * ld + j], rb = R[(size_t)(k + 1) * ld + j];
+            R[(size_t)k * ld + j] = (j == k) ? hh : cs * ra + sn * rb;
+            R[(size_t)(k + 1) * ld + j] = (j == k) ? 0.0 : -sn * ra + cs * rb;
           }
           for (int i = tid; i < n; i += NT_) {
-            const double ja = J[(size_t)i * n + k], jb = J[(size_t)i * n + k + 1];
-            J[(size_t)i * n + k] = cs * ja + sn * jb;
-            J[(size_t)i * n + k + 1] = -sn * ja + cs * jb;
+            const double ja = J[(size_t)i * ld + k], jb = J[(size_t)i * ld + k + 1];
+            J[(size_t)i * ld + k] = cs * ja + sn * jb;
+            J[(size_t)i * ld + k + 1] = -sn * ja + cs * jb;
           }
         }
       }
       __syncthreads();
+      MKH_DSEC(5);
     }
   }
   __syncthreads();
+  if (clk && tid == 0) for (int k = 0; k < 6; ++k) clk[17 + k] = t_sec[k];
+#undef MKH_DSEC
   return WideQpOut{status, iters, n_outer, n_piv};
 }
 
@@ -1337,7 +1380,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
         qo = wide_qp(X, A.clk ? A.clk + (size_t)pb * 24 : nullptr);
         if (m > 0 && (qo.status & (2 | 8 | 32))) { dense = true; build_tableau(); }
       }
-      if (dense) qo = wide_qp_dense(X, P.gi_in_lds ? smem + P.o_gi : wsb + P.ws_gi);
+      if (dense) qo = wide_qp_dense(X, P.gi_in_lds ? smem + P.o_gi : wsb + P.ws_gi, A.clk ? A.clk + (size_t)pb * 24 : nullptr);
       status |= qo.status & ~32; iters = qo.iters; n_outer = qo.n_outer; n_piv = qo.n_piv;
     }
     MKH_WSTAMP(11);

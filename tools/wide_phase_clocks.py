@@ -44,6 +44,10 @@ def run(name, B=None):
     print("  per problem: p50 %.0f k, p90 %.0f k, p99 %.0f k, max %.0f k cycles; ratio-test rounds: p50 %.0f, p99 %.0f, max %.0f"
           % (np.percentile(tot, 50) / 1e3, np.percentile(tot, 90) / 1e3, np.percentile(tot, 99) / 1e3, tot.max() / 1e3,
              np.percentile(c[:, 13], 50), np.percentile(c[:, 13], 99), c[:, 13].max()))
+    if (c[:, 17:23] > 0).any():
+        dn = ["factors + x0", "violated-constraint search", "directions d, z, r", "step lengths + updates", "add (Householder)", "drop (Givens)"]
+        ds = c[:, 17:23].astype(np.float64)
+        print("  dense Goldfarb–Idnani iteration (%d instances): " % (ds.sum(axis=1) > 0).sum() + "; ".join("%s %.0f k" % (a, b / 1e3) for a, b in zip(dn, ds.mean(axis=0))))
     for k, n in enumerate(NAMES):
         print("  %-16s %9.0f cycles  %5.1f %%" % (n, d[:, k].mean(), 100 * d[:, k].mean() / tot.mean()))
 
