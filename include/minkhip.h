@@ -298,7 +298,10 @@ void mkh_model_destroy(MkhModel *model);
  * posture_task.py:29-52, com_task.py:25-35 and of the three limits) into a device descriptor. */
 /* max_batch: the largest B any later call on this handle may pass — with host OR device pointers: it sizes everything the
  * handle owns per instance (staging buffers, the active sets kept for MKH_FLAG_WARM_START).  A call with B > max_batch
- * returns MKH_E_INVALID before anything is launched. */
+ * returns MKH_E_INVALID before anything is launched.
+ * A handle owns device state its launches share (ticket counters, the workspace slices and the redo queue of the
+ * workgroup-per-problem kernel, warm-start sets): calls on ONE handle must not overlap in time — one stream at a time, or
+ * streams ordered by events.  Handles of the same model are independent of each other. */
 int32_t mkh_problem_create(MkhModel *model, const MkhProblemDesc *desc, int32_t max_batch, MkhProblem **out);
 void mkh_problem_destroy(MkhProblem *problem);
 int32_t mkh_problem_num_task_rows(const MkhProblem *problem);
