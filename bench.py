@@ -469,6 +469,9 @@ def main():
     ap.add_argument("--gather", action="store_true",
                     help="(kept for compatibility) N>1 always reports the RCCL-gather variant in the 'gather' object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-loop-legs", action="store_true",
+                    help="skip the fused-loop figures (loop20_targets_per_s, converged_targets): tools/profile.sh's trace pass, whose "
+                         "per-kernel averages should be those of the timed launches")
     ap.add_argument("--no-pcie-leg", action="store_true",
                     help="skip the host-pointer (PCIe-inclusive) leg: it launches the SAME kernel on quarter batches (chunked "
                          "host path), which would pull down that kernel's average in a rocprofv3 --stats run of this command")
@@ -704,7 +707,7 @@ def main():
         res = kernel_resources(kernel)
         if res is not None:
             out["kernel_resources"] = res
-        if world == 1 and plain:
+        if world == 1 and plain and not args.no_loop_legs:
             out["loop20_targets_per_s"] = loop_targets(prob, q, tg, pt, ct, dt, damping, B, max_iters=20)
             # ... and a figure that deserves the name: targets that lie inside the joint ranges (the SURVEY §8(d) distribution of
             # the headline batch leaves most G1 targets just outside them, workloads.make_batch), the iteration budget raised

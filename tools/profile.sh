@@ -3,6 +3,7 @@
 #   gpurun --timeout 900 -- 'bash tools/profile.sh r02a g1_c3'        (config defaults to g1_c3)
 #   MKH_PROFILE_BATCH=1048576 bash tools/profile.sh r02b ur5e_c2      (a batch other than the config's own)
 #   MKH_PROFILE_PMC_ONLY=1 bash tools/profile.sh r02a ur5e_c2         (the four counter passes only)
+#   MKH_PROFILE_TRACE_ONLY=1 bash tools/profile.sh r05 shadow_c4      (the kernel-trace pass only)
 # then copy gpurun_out/<tag>_* into profiles/.  Kernel trace/stats and each --pmc group are separate
 # passes (counters are never combined with sys/runtime/hip traces).  Every rocprofv3 pass runs under a hard timeout:
 # a profiler that fails to finalise (seen once after a GPU fault report inside the tool) must not eat the GPU budget.
@@ -18,10 +19,11 @@ cd /tmp && export TMPDIR=/tmp
 
 if [ -z "${MKH_PROFILE_PMC_ONLY:-}" ]; then
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace" -o k -- \
-  python "$R/bench.py" --config $CFG --batch $B --steps 20 --warmup 3 --no-cpu-baseline --no-pcie-leg > "$O/bench_under_trace.json" 2> "$O/trace.log"
+  python "$R/bench.py" --config $CFG --batch $B --steps 20 --warmup 3 --no-cpu-baseline --no-pcie-leg --no-loop-legs > "$O/bench_under_trace.json" 2> "$O/trace.log"
 python "$R/tools/rocprof_summary.py" stats "$R/gpurun_out/${TAG}_${NAME}_kernel_stats.csv" "$O/trace" > /dev/null
 fi
 
+if [ -n "${MKH_PROFILE_TRACE_ONLY:-}" ]; then cp "$R/gpurun_out/${TAG}_${NAME}_kernel_stats.csv" "$R/profiles/" 2>/dev/null; exit 0; fi
 i=0
 PMC_GROUPS=("FETCH_SIZE" "WRITE_SIZE" \
         "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
