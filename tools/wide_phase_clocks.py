@@ -39,8 +39,8 @@ def run(name, B=None):
         B = len(c)
     d = np.diff(c[:, :13], axis=1).astype(np.float64)
     tot = (c[:, 12] - c[:, 0]).astype(np.float64)
-    print("%s, B = %d: %d workgroups; per problem %.0f k core-clock cycles; N = %.0f, ratio-test rounds %.1f, pivots after phase 0 %.1f"
-          % (name, B, prob.launch_info(B)["grid"], tot.mean() / 1e3, c[:, 16].mean(), c[:, 13].mean(), c[:, 14].mean()))
+    print("%s, B = %d: per problem %.0f k core-clock cycles; N = %.0f, ratio-test rounds %.1f, pivots after phase 0 %.1f"
+          % (name, B, tot.mean() / 1e3, c[:, 16].mean(), c[:, 13].mean(), c[:, 14].mean()))
     print("  per problem: p50 %.0f k, p90 %.0f k, p99 %.0f k, max %.0f k cycles; ratio-test rounds: p50 %.0f, p99 %.0f, max %.0f"
           % (np.percentile(tot, 50) / 1e3, np.percentile(tot, 90) / 1e3, np.percentile(tot, 99) / 1e3, tot.max() / 1e3,
              np.percentile(c[:, 13], 50), np.percentile(c[:, 13], 99), c[:, 13].max()))
