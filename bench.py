@@ -537,7 +537,7 @@ def main():
     pt = torch.from_numpy(pt_h).to(dev) if prob.n_posture else None
     ct = None if ct_h is None else torch.from_numpy(ct_h).to(dev)
     dense = None if dense_h is None else {k: torch.from_numpy(np.ascontiguousarray(x)).to(dev) for k, x in dense_h.items()}
-    plain = dense is None and args.config not in ("ur5e_convex", "g1_coll", "h1_c3", "h1_full", "g1_hands", "aloha_coll")      # configs the fused loop / host-path / oracle legs cover
+    plain = dense is None and args.config not in ("ur5e_convex", "g1_coll", "h1_c3", "h1_full", "g1_hands", "aloha_coll", "ur5e_coll")      # configs the fused loop / host-path / oracle legs cover
     v = torch.empty((B, model.nv), dtype=torch.float64, device=dev)
     st = torch.empty((B,), dtype=torch.int32, device=dev)
     v_all = torch.empty((world * B, model.nv), dtype=torch.float64, device=dev) if (world > 1 and rank == 0) else None

@@ -27,6 +27,60 @@ class Objective(NamedTuple):
 _DENSE_BY_CLASS: dict = {}
 
 
+def objective_to_rows(H: np.ndarray, c: np.ndarray, name: str = "task"):
+    """Rows (e, J) — nv of them, cost 1, gain 1, no Levenberg–Marquardt term — whose contribution to the QP under mink's own
+    formula (tasks/task.py:125-138: H += JᵀJ, c += Jᵀe for that cost and gain) IS the given objective: JᵀJ = H and Jᵀe = c.
+    This is how a `compute_qp_objective` override (the method mink/solve_ik.py:18-21 actually calls) reaches the device, whose
+    plugin route takes rows.  H: (nv, nv) or (B, nv, nv) symmetric positive semi-definite; c: (nv,) or (B, nv).
+
+    H = V·Λ·Vᵀ gives J = Λ^½·Vᵀ (rows of vanishing eigenvalues are zero) and e_i = v_iᵀc / √λ_i.  A linear term with a
+    component c_n outside the range of H — no least-squares objective has one, but the reference's QP accepts it — takes one
+    of the zero rows: J_s = s·n̂ᵀ, e_s = ‖c_n‖ / s with s² = 1e-20·λ_max, i.e. the term enters c exactly and perturbs H four
+    orders of magnitude below its own rounding."""
+    H = np.asarray(H, dtype=np.float64); c = np.asarray(c, dtype=np.float64)
+    nv = H.shape[-1]
+    if H.shape[-2:] != (nv, nv) or H.ndim not in (2, 3) or c.shape[-1] != nv or c.ndim not in (1, 2):
+        raise TaskDefinitionError(f"{name}.compute_qp_objective must return H of shape (nv, nv) or (B, nv, nv) and c of shape "
+                                  f"(nv,) or (B, nv); got {H.shape}, {c.shape}")
+    batched = H.ndim == 3 or c.ndim == 2
+    Hb = H if H.ndim == 3 else H[None]
+    cb = c if c.ndim == 2 else c[None]
+    if not (np.isfinite(Hb).all() and np.isfinite(cb).all()):
+        raise TaskDefinitionError(f"{name}.compute_qp_objective returned non-finite entries")
+    scale = np.abs(Hb).max(axis=(1, 2))                                    # (b,)
+    if (np.abs(Hb - np.swapaxes(Hb, 1, 2)).max(axis=(1, 2)) > 1e-9 * scale + 1e-300).any():
+        raise TaskDefinitionError(f"{name}.compute_qp_objective: H must be symmetric")
+    w, V = np.linalg.eigh(0.5 * (Hb + np.swapaxes(Hb, 1, 2)))             # ascending
+    w, V = w[:, ::-1], V[:, :, ::-1]                                       # largest first: the nonzero rows lead
+    lam = np.maximum(w[:, 0], 0.0)
+    if (w[:, -1] < -1e-9 * np.maximum(lam, scale)).any():
+        raise TaskDefinitionError(f"{name}.compute_qp_objective: H must be positive semi-definite (quadprog, the reference's "
+                                  f"solver, needs a convex objective)")
+    tol = (8.0 * nv * np.finfo(np.float64).eps) * lam
+    keep = w > tol[:, None]                                                # (b, nv)
+    sq = np.sqrt(np.where(keep, w, 0.0))
+    J = sq[:, :, None] * np.swapaxes(V, 1, 2)                              # row i = √λ_i·v_iᵀ
+    nb = max(Hb.shape[0], cb.shape[0])
+    if Hb.shape[0] != nb:
+        J, V, keep, sq, lam = (np.broadcast_to(a, (nb,) + a.shape[1:]) for a in (J, V, keep, sq, lam))
+    cc = np.broadcast_to(cb, (nb, nv))
+    vc = np.einsum("bki,bk->bi", V, cc)                                    # v_iᵀc
+    e = np.where(keep, vc / np.where(keep, sq, 1.0), 0.0)
+    c_n = cc - np.einsum("bik,bi->bk", J, e)                               # what the range of H cannot carry
+    n_n = np.linalg.norm(c_n, axis=1)
+    need = n_n > 1e-13 * np.maximum(np.linalg.norm(cc, axis=1), 1e-300)
+    if need.any():
+        J = np.array(J); e = np.array(e)
+        rank = keep.sum(axis=1)
+        idx = np.nonzero(need & (rank < nv))[0]                            # (full rank: c_n is rounding)
+        s = np.where(lam[idx] > 0.0, 1e-10 * np.sqrt(lam[idx]), 1e-12)
+        J[idx, rank[idx]] = s[:, None] * (c_n[idx] / n_n[idx, None])
+        e[idx, rank[idx]] = n_n[idx] / s
+    if not batched:
+        return np.ascontiguousarray(e[0]), np.ascontiguousarray(J[0])
+    return np.ascontiguousarray(e), np.ascontiguousarray(J)
+
+
 class Task(abc.ABC):
     """mink/tasks/task.py:25-138."""
 
@@ -47,8 +101,18 @@ class Task(abc.ABC):
     # override `_native_desc` / `_native_target` instead: their error and Jacobian are computed on the device.
     def _native_desc(self, configuration: Configuration):
         """(kind, descriptor dict) for mkh_problem_create."""
+        if self._objective_overridden():
+            # nv rows that carry the override's (H, c) exactly (objective_to_rows): unit cost and gain, no LM term
+            return "dense", {"cost": np.ones(configuration.nv), "gain": 1.0, "lm_damping": 0.0}
         return "dense", {"cost": np.array(self.cost, dtype=np.float64).reshape(-1), "gain": float(self.gain),
                          "lm_damping": float(self.lm_damping)}
+
+    def _objective_overridden(self) -> bool:
+        """Does the (H, c) of this task come from a `compute_qp_objective` override?  Not while the base-class method itself is
+        being evaluated for this instance (an override that calls `super().compute_qp_objective(configuration)`)."""
+        if getattr(self, "_rows_only", 0):
+            return False
+        return type(self).compute_qp_objective is not self._builtin_class().compute_qp_objective
 
     def _native_target(self, configuration: Configuration) -> np.ndarray:
         """Target rows for mkh_solve (built-in tasks only)."""
@@ -96,15 +160,26 @@ class Task(abc.ABC):
         built-in task (say, compute_jacobian of FrameTask under an overridden compute_error) is evaluated on the device
         through the built-in descriptor (Task.compute_error / compute_jacobian below)."""
         base, cls = self._builtin_class(), type(self)
-        if cls.compute_qp_objective is not base.compute_qp_objective:
-            raise TaskDefinitionError(
-                f"{cls.__name__} overrides compute_qp_objective: the device folds a task into the QP from its rows "
-                "(e, J) with mink's own formula (tasks/task.py:105-138) and cannot take an arbitrary (H, c); override "
-                "compute_error / compute_jacobian instead")
+        B, nv = configuration.batch_size, configuration.nv
+        if self._objective_overridden():
+            # The reference only ever calls compute_qp_objective (mink/solve_ik.py:18-21), so a subclass that returns its own
+            # (H, c) changes the QP there.  The device folds tasks in from rows: the override's objective is factored into nv
+            # rows with JᵀJ = H, Jᵀe = c (objective_to_rows), evaluated here with numpy like any caller-defined row.
+            obj = self.compute_qp_objective(configuration)
+            try:
+                H, c = obj
+            except (TypeError, ValueError):
+                raise TaskDefinitionError(f"{cls.__name__}.compute_qp_objective must return an Objective (H, c)") from None
+            H, c = np.asarray(H, dtype=np.float64), np.asarray(c, dtype=np.float64)
+            if H.shape not in ((nv, nv), (B, nv, nv)) or c.shape not in ((nv,), (B, nv)):
+                raise TaskDefinitionError(f"{cls.__name__}.compute_qp_objective must return H ({nv}, {nv}) or ({B}, {nv}, {nv}) "
+                                          f"and c ({nv},) or ({B}, {nv}); got {H.shape}, {c.shape}")
+            e, J = objective_to_rows(H, c, cls.__name__)
+            return np.broadcast_to(e, (B, nv)), np.broadcast_to(J, (B, nv, nv))
         if base is Task and (cls.compute_error is Task.compute_error or cls.compute_jacobian is Task.compute_jacobian):
             raise TaskDefinitionError(f"{cls.__name__} must implement compute_error and compute_jacobian "
                                       "(mink's Task plugin interface)")
-        B, nv, k = configuration.batch_size, configuration.nv, len(np.atleast_1d(self.cost))
+        k = len(np.atleast_1d(self.cost))
         e = np.asarray(self.compute_error(configuration), dtype=np.float64)
         J = np.asarray(self.compute_jacobian(configuration), dtype=np.float64)
         if e.shape not in ((k,), (B, k)) or J.shape not in ((k, nv), (B, k, nv)):
@@ -137,7 +212,15 @@ class Task(abc.ABC):
         return configuration._unbatch(self._eval(configuration, ["task_J"], builtin=True)["task_J"])
 
     def compute_qp_objective(self, configuration: Configuration) -> Objective:
-        out = self._eval(configuration, ["H", "c"])   # damping = 0 ⇒ exactly this task's (H, c)
+        # mink's formula from this task's rows (tasks/task.py:105-138) — also when a subclass's override calls it through
+        # super(): the rows are then the instance's compute_error / compute_jacobian, not the override's own (H, c)
+        base, cls = self._builtin_class(), type(self)
+        own_rows = base is Task or cls.compute_error is not base.compute_error or cls.compute_jacobian is not base.compute_jacobian
+        self._rows_only = getattr(self, "_rows_only", 0) + 1
+        try:
+            out = self._eval(configuration, ["H", "c"], builtin=not own_rows)   # damping = 0 ⇒ exactly this task's (H, c)
+        finally:
+            self._rows_only -= 1
         return Objective(configuration._unbatch(out["H"]), configuration._unbatch(out["c"]))
 
 

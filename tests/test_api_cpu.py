@@ -370,3 +370,44 @@ def test_fingerprints_follow_what_the_device_descriptor_reads():
 
     assert MyTask("attachment_site", "site", 1.0, 1.0)._fingerprint() is None
     assert MyLimit()._fingerprint() is None
+
+
+def test_objective_to_rows_carries_any_psd_objective():
+    """`compute_qp_objective` overrides reach the device as nv rows with JᵀJ = H and Jᵀe = c (mink_amd/tasks.py:
+    objective_to_rows; the reference folds a task in through that method alone, mink/solve_ik.py:18-21)."""
+    from mink_amd.tasks import objective_to_rows
+
+    rng = np.random.default_rng(0)
+    nv, B = 9, 17
+    A = rng.normal(size=(B, 3, nv))
+    H = np.einsum("bki,bkj->bij", A, A)                           # rank 3
+    # (a) a least-squares objective: c in the range of H — no spare row is used
+    c_in = np.einsum("bki,bk->bi", A, rng.normal(size=(B, 3)))
+    e, J = objective_to_rows(H, c_in)
+    assert e.shape == (B, nv) and J.shape == (B, nv, nv)
+    np.testing.assert_allclose(np.einsum("bki,bkj->bij", J, J), H, rtol=0, atol=1e-13 * np.abs(H).max())
+    np.testing.assert_allclose(np.einsum("bki,bk->bi", J, e), c_in, rtol=0, atol=1e-12 * np.abs(c_in).max())
+    assert (np.abs(J[:, 3:]).max(axis=(1, 2)) == 0.0).all() and np.abs(e).max() < 1e3
+    # (b) a generic linear term: the part outside the range rides on one tiny row, H moves below its rounding
+    c_out = rng.normal(size=(B, nv))
+    e, J = objective_to_rows(H, c_out)
+    np.testing.assert_allclose(np.einsum("bki,bkj->bij", J, J), H, rtol=0, atol=1e-13 * np.abs(H).max())
+    np.testing.assert_allclose(np.einsum("bki,bk->bi", J, e), c_out, rtol=0, atol=1e-12 * np.abs(c_out).max())
+    # (c) full rank, unbatched, and a pure linear objective
+    Hf = H[0] + np.eye(nv)
+    e, J = objective_to_rows(Hf, c_out[0])
+    assert e.shape == (nv,) and J.shape == (nv, nv)
+    np.testing.assert_allclose(J.T @ J, Hf, rtol=0, atol=1e-13 * np.abs(Hf).max())
+    np.testing.assert_allclose(J.T @ e, c_out[0], rtol=0, atol=1e-12)
+    e, J = objective_to_rows(np.zeros((nv, nv)), c_out[0])
+    assert np.abs(J.T @ J).max() < 1e-20
+    np.testing.assert_allclose(J.T @ e, c_out[0], rtol=0, atol=1e-12)
+    # (d) one H for the whole batch with per-instance c
+    e, J = objective_to_rows(H[0], c_out)
+    assert e.shape == (B, nv) and J.shape == (B, nv, nv)
+    np.testing.assert_allclose(np.einsum("bki,bk->bi", J, e), c_out, rtol=0, atol=1e-12 * np.abs(c_out).max())
+    # (e) what quadprog would refuse
+    with pytest.raises(mink.TaskDefinitionError, match="positive semi-definite"):
+        objective_to_rows(-np.eye(nv), np.zeros(nv))
+    with pytest.raises(mink.TaskDefinitionError, match="symmetric"):
+        objective_to_rows(np.triu(np.ones((nv, nv))), np.zeros(nv))

@@ -244,14 +244,80 @@ def test_partial_overrides_of_builtin_tasks():
         np.testing.assert_allclose(H, Hr, rtol=0, atol=1e-12 * np.abs(Hr).max())
         np.testing.assert_allclose(c, cr, rtol=0, atol=1e-12 * max(1.0, np.abs(cr).max()))
 
-    class OwnObjective(mink.FrameTask):
-        def compute_qp_objective(self, configuration):
-            return mink.Objective(np.eye(configuration.nv), np.zeros(configuration.nv))
 
-    t = OwnObjective("attachment_site", "site", 1.0, 1.0); t.set_target(tg)
-    assert t._is_dense()
-    with pytest.raises(mink.TaskDefinitionError, match="overrides compute_qp_objective"):
-        mink.solve_ik(cfg, [t, post], 2e-3, "mi355x", 1e-3, limits=lims)
+
+def test_compute_qp_objective_overrides():
+    """The reference only ever calls Task.compute_qp_objective (/root/reference/mink/solve_ik.py:18-21), so a subclass that
+    returns its own (H, c) changes the QP there (round-4 review, missing #5: refused here until round 5).  The device takes
+    rows: the override's objective is factored into nv rows with JᵀJ = H, Jᵀe = c (mink_amd.tasks.objective_to_rows)."""
+    B = 64
+    m, cfg, tg, home = _ur5e_batch(B, seed=17)
+    nv = m.nv
+    post = mink.PostureTask(m, cost=1e-2); post.set_target(home)
+    lims = [mink.ConfigurationLimit(m), mink.VelocityLimit(m, {n: np.pi for n in m.jnt_names})]
+
+    class Doubled(mink.FrameTask):                         # an override on top of the inherited objective (super() call)
+        def compute_qp_objective(self, configuration):
+            H, c = super().compute_qp_objective(configuration)
+            return mink.Objective(2.0 * H, 2.0 * c)
+
+    t = Doubled("attachment_site", "site", 1.0, 0.7, gain=0.9, lm_damping=1.0); t.set_target(tg)
+    assert t._is_dense() and t._objective_overridden()
+    r2 = np.sqrt(2.0)                                      # 2·(JᵀW²J + μI, −JᵀW·We) = the same task with costs·√2
+    twin = mink.FrameTask("attachment_site", "site", r2 * 1.0, r2 * 0.7, gain=0.9, lm_damping=1.0); twin.set_target(tg)
+    v = mink.solve_ik(cfg, [t, post], 2e-3, "mi355x", 1e-3, limits=lims)
+    v_ref = mink.solve_ik(cfg, [twin, post], 2e-3, "mi355x", 1e-3, limits=lims)
+    err = np.abs(v - v_ref).max() / max(1.0, np.abs(v_ref).max())
+    print("doubled objective vs costs x sqrt 2: max rel err %.2e" % err)
+    assert err < 1e-9
+    p1, p2 = mink.build_ik(cfg, [t, post], 2e-3, 1e-3, lims), mink.build_ik(cfg, [twin, post], 2e-3, 1e-3, lims)
+    np.testing.assert_allclose(p1.P, p2.P, rtol=0, atol=1e-11 * np.abs(p2.P).max())
+    np.testing.assert_allclose(p1.q, p2.q, rtol=0, atol=1e-11 * max(1.0, np.abs(p2.q).max()))
+    # the rows of such a task are still the built-in's (compute_error / compute_jacobian are inherited)
+    np.testing.assert_allclose(t.compute_error(cfg), twin.compute_error(cfg), rtol=0, atol=1e-14)
+
+    class RawObjective(mink.Task):                         # written from scratch: rank-deficient H, c partly outside its range
+        def __init__(self, H, c):
+            super().__init__(cost=np.zeros(1))
+            self.H, self.c = H, c
+
+        def compute_error(self, configuration):
+            raise AssertionError("the reference never calls this when compute_qp_objective is overridden")
+
+        def compute_jacobian(self, configuration):
+            raise AssertionError("the reference never calls this when compute_qp_objective is overridden")
+
+        def compute_qp_objective(self, configuration):
+            return mink.Objective(self.H, self.c)
+
+    rng = np.random.default_rng(5)
+    A = rng.normal(size=(B, 2, nv))
+    H_raw = 3.0 * np.einsum("bki,bkj->bij", A, A)          # rank 2 of 6, per instance
+    c_raw = rng.normal(size=(B, nv))                       # generic: not in the range of H
+    builtin = mink.FrameTask("attachment_site", "site", 1.0, 0.7, gain=0.9, lm_damping=1.0); builtin.set_target(tg)
+    raw = RawObjective(H_raw, c_raw)
+    p0 = mink.build_ik(cfg, [builtin, post], 2e-3, 1e-3, lims)
+    p1 = mink.build_ik(cfg, [builtin, raw, post], 2e-3, 1e-3, lims)
+    np.testing.assert_allclose(p1.P, p0.P + H_raw, rtol=0, atol=1e-12 * np.abs(p1.P).max())
+    np.testing.assert_allclose(p1.q, p0.q + c_raw, rtol=0, atol=1e-12 * max(1.0, np.abs(p1.q).max()))
+    v = mink.solve_ik(cfg, [builtin, raw, post], 2e-3, "mi355x", 1e-3, limits=lims)
+    from oracle import qp_gi
+    worst = 0.0
+    for i in range(B):                                     # the reference's QP on the reference's stacked (P, q, G, h)
+        dq = qp_gi.solve_qp(p0.P[i] + H_raw[i], p0.q[i] + c_raw[i], p0.G[i] if p0.G.ndim == 3 else p0.G,
+                            p0.h[i] if p0.h.ndim == 2 else p0.h)
+        worst = max(worst, np.abs(v[i] - dq / 2e-3).max() / max(1.0, np.abs(dq / 2e-3).max()))
+    print("raw (H, c) objective vs Goldfarb-Idnani on the stacked QP: max rel err %.2e" % worst)
+    assert worst < 1e-8
+    # one shared (H, c) for the whole batch, and the unbatched configuration
+    raw1 = RawObjective(H_raw[0], c_raw[0])
+    v_sh = mink.solve_ik(cfg, [builtin, raw1, post], 2e-3, "mi355x", 1e-3, limits=lims)
+    np.testing.assert_allclose(v_sh[0], v[0], rtol=0, atol=1e-10 * max(1.0, np.abs(v[0]).max()))
+    # what the reference's solver would refuse is refused with a message, not solved
+    with pytest.raises(mink.TaskDefinitionError, match="positive semi-definite"):
+        mink.solve_ik(cfg, [builtin, RawObjective(-np.eye(nv), np.zeros(nv)), post], 2e-3, "mi355x", 1e-3, limits=lims)
+    with pytest.raises(mink.TaskDefinitionError, match="must return H"):
+        mink.solve_ik(cfg, [builtin, RawObjective(np.eye(nv + 1), np.zeros(nv)), post], 2e-3, "mi355x", 1e-3, limits=lims)
 
 
 def test_user_box_rows_on_g1_do_not_use_tableau_rows():
