@@ -12,11 +12,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <atomic>
 #include <limits>
 #include <mutex>
 #include <string>
-#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -56,7 +54,6 @@ static hipError_t upload(const std::vector<T>& h, T** d) {
   return e;
 }
 
-constexpr int kHostChunks = 8;   // large host-pointer calls: chunks whose copies overlap their neighbours' kernels (solve_impl)
 // Small host-pointer calls (a control loop's single configuration: the reference's everyday use) go through ONE pinned,
 // device-visible host buffer: the kernel reads its inputs and writes its outputs across the bus itself — a launch and a
 // synchronize instead of five staged copies of ≈8 µs host time each, whatever their size.
@@ -167,8 +164,7 @@ struct MkhProblem {
   double *s_q = nullptr, *s_ft = nullptr, *s_pt = nullptr, *s_ct = nullptr, *s_v = nullptr;
   // host-pointer calls on large batches: copies of chunk c + 1 / c − 1 run beside the kernel of chunk c
   hipStream_t st_in = nullptr, st_out = nullptr;
-  hipEvent_t ev_start = nullptr, ev_in[kHostChunks] = {}, ev_k[kHostChunks] = {};
-  int chunk_quantum = 0;           // problems the previous chunked call's kernel ran at a time (its grid): chunks are cut in whole rounds
+  hipEvent_t ev_start = nullptr, ev_in[4] = {nullptr, nullptr, nullptr, nullptr}, ev_k[4] = {nullptr, nullptr, nullptr, nullptr};
   int32_t* s_status = nullptr;
   int32_t* s_iters = nullptr;      // [2][max_batch]: iterations, converged (mkh_solve_until, host-pointer calls)
   size_t s_pt_cap = 0, s_ct_cap = 0;
@@ -1369,7 +1365,7 @@ void mkh_problem_destroy(MkhProblem* p) {
   if (p->st_in) (void)hipStreamDestroy(p->st_in);
   if (p->st_out) (void)hipStreamDestroy(p->st_out);
   if (p->ev_start) (void)hipEventDestroy(p->ev_start);
-  for (int i = 0; i < kHostChunks; ++i) { if (p->ev_in[i]) (void)hipEventDestroy(p->ev_in[i]); if (p->ev_k[i]) (void)hipEventDestroy(p->ev_k[i]); }
+  for (int i = 0; i < 4; ++i) { if (p->ev_in[i]) (void)hipEventDestroy(p->ev_in[i]); if (p->ev_k[i]) (void)hipEventDestroy(p->ev_k[i]); }
   delete p;
 }
 
@@ -1804,26 +1800,17 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
   // Only where the copies are worth overlapping (≥ 32 MB staged: tools/bench_host_path.py — G1 at 65 536 instances
   // 2.02 → 1.72 ms per call, the G1 full example 2.79 → 2.19 ms; a 65 536-instance UR5e call moves 10 MB around a 0.08 ms
   // kernel and LOSES 0.15 ms to the events and the three extra launches).
-  // Round 5: the two copy directions overlap as well.  A copy from or to PAGEABLE host memory (numpy arrays: every caller of
-  // this path) keeps the calling thread until it is done, so one thread issuing "all inputs, then all outputs" had the PCIe
-  // link busy in one direction at a time (0.69 ms in + 0.41 ms out around a 0.78 ms kernel: 1.38 ms per G1 call).  The
-  // outputs are now drained by a second host thread, chunk by chunk as the kernels finish, while this one is still feeding
-  // inputs; eight chunks instead of four shorten what cannot overlap (first copy in, last kernel, last copy out).
-  // MKH_DEBUG_NO_D2H_THREAD=1: the one-thread sequence (A/B); MKH_DEBUG_CHUNKS=n: another chunk count (2 … 8).
   static const bool no_chunks = getenv("MKH_DEBUG_NO_CHUNKS") != nullptr;      // (A/B of this path)
-  static const bool no_d2h_thread = getenv("MKH_DEBUG_NO_D2H_THREAD") != nullptr;
-  static const int max_chunks = [] { const char* e = getenv("MKH_DEBUG_CHUNKS"); const int n = e ? atoi(e) : kHostChunks;
-                                     return n < 2 ? 2 : (n > kHostChunks ? kHostChunks : n); }();
   const size_t staged_bytes = (size_t)B * sizeof(double) *
       (nq + (size_t)P.n_frame * 7 + nv + (pbat ? (size_t)P.n_posture * nq : 0) + (cbat ? (size_t)P.n_com * 3 : 0) + (q_out ? nq : 0));
-  int n_chunks = (!no_chunks && !taps && !Kd && !Md && !Bd && v_out && B >= 2 * 8192 && staged_bytes >= ((size_t)32 << 20))
-                     ? (B / 8192 < max_chunks ? B / 8192 : max_chunks) : 1;
+  const int n_chunks = (!no_chunks && !taps && !Kd && !Md && !Bd && v_out && B >= 2 * 8192 && staged_bytes >= ((size_t)32 << 20))
+                           ? (B / 8192 < 4 ? B / 8192 : 4) : 1;
   if (n_chunks > 1) {
     if (!p->st_in) {
       HIP_OK(hipStreamCreateWithFlags(&p->st_in, hipStreamNonBlocking));
       HIP_OK(hipStreamCreateWithFlags(&p->st_out, hipStreamNonBlocking));
       HIP_OK(hipEventCreateWithFlags(&p->ev_start, hipEventDisableTiming));
-      for (int i = 0; i < kHostChunks; ++i) {
+      for (int i = 0; i < 4; ++i) {
         HIP_OK(hipEventCreateWithFlags(&p->ev_in[i], hipEventDisableTiming));
         HIP_OK(hipEventCreateWithFlags(&p->ev_k[i], hipEventDisableTiming));
       }
@@ -1834,49 +1821,10 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
     if (n_ct && !cbat) HIP_OK(hipMemcpyAsync(p->s_ct, com_target, n_ct * sizeof(double), hipMemcpyHostToDevice, stream));
     HIP_OK(hipEventRecord(p->ev_start, stream));
     HIP_OK(hipStreamWaitEvent(p->st_in, p->ev_start, 0));
-    size_t chunk = ((size_t)B / n_chunks) / 64 * 64;                // ≥ 8 192; the last chunk takes the remainder
-    // Whole rounds per chunk.  A wavefront kernel runs `grid` problems at a time (every resident wavefront one): a chunk of
-    // 8 192 G1 instances on 3 072 wavefronts is 2.67 rounds and costs 3 — eight such chunks 1.0 ms of kernel time for a batch
-    // that takes 0.78 ms in one launch, and the kernels are what the overlapped pipeline waits for.  The grid of the handle's
-    // previous chunked call (the same kernel, as a rule) is the quantum: 7 × 9 216 + 1 024 instead of 8 × 8 192.
-    if (p->chunk_quantum >= 64 && p->chunk_quantum % 64 == 0 && (size_t)p->chunk_quantum < chunk) {
-      const size_t G = (size_t)p->chunk_quantum;
-      size_t r = (chunk + G / 2) / G;
-      while (((size_t)B + r * G - 1) / (r * G) > (size_t)max_chunks) ++r;
-      chunk = r * G;
-      n_chunks = (int)(((size_t)B + chunk - 1) / chunk);
-    }
+    const size_t chunk = ((size_t)B / n_chunks) / 64 * 64;          // ≥ 8 192; the last chunk takes the remainder
     const size_t ft_w = (size_t)P.n_frame * 7, pt_w = (size_t)P.n_posture * nq, ct_w = (size_t)P.n_com * 3;
     int32_t rc = MKH_OK;
     hipError_t e = hipSuccess;
-    // the outputs of chunk c: behind its kernel on st_out (either thread)
-    auto drain = [&](int c) -> hipError_t {
-      const size_t off = c * chunk, Bc = (c + 1 < n_chunks) ? chunk : (size_t)B - off;
-      hipError_t eo = hipStreamWaitEvent(p->st_out, p->ev_k[c], 0);
-      if (eo == hipSuccess) eo = hipMemcpyAsync(v_out + off * nv, p->s_v + off * nv, Bc * nv * sizeof(double), hipMemcpyDeviceToHost, p->st_out);
-      if (eo == hipSuccess && q_out) eo = hipMemcpyAsync(q_out + off * nq, p->s_q + off * nq, Bc * nq * sizeof(double), hipMemcpyDeviceToHost, p->st_out);
-      if (eo == hipSuccess && status_out) eo = hipMemcpyAsync(status_out + off, p->s_status + off, Bc * sizeof(int32_t), hipMemcpyDeviceToHost, p->st_out);
-      if (eo == hipSuccess && until && iters_out) eo = hipMemcpyAsync(iters_out + off, p->s_iters + off, Bc * sizeof(int32_t), hipMemcpyDeviceToHost, p->st_out);
-      if (eo == hipSuccess && until && converged_out) eo = hipMemcpyAsync(converged_out + off, p->s_iters + mb + off, Bc * sizeof(int32_t), hipMemcpyDeviceToHost, p->st_out);
-      return eo;
-    };
-    // The draining thread: takes chunk c once this thread has recorded its kernel's event (an event that has not been recorded
-    // yet would not be waited for), stops at the first chunk that never will be.
-    std::atomic<int> recorded{0};
-    std::atomic<bool> issued_all{false};
-    hipError_t e_out = hipSuccess;
-    std::thread drainer;
-    if (!no_d2h_thread) {
-      const int device = p->model->device;
-      drainer = std::thread([&, device] {
-        e_out = hipSetDevice(device);
-        for (int c = 0; c < n_chunks && e_out == hipSuccess; ++c) {
-          while (recorded.load(std::memory_order_acquire) <= c && !issued_all.load(std::memory_order_acquire)) std::this_thread::yield();
-          if (recorded.load(std::memory_order_acquire) <= c) break;
-          e_out = drain(c);
-        }
-      });
-    }
     // (an error inside the loop must not return: copies that read the caller's q / targets may be in flight on st_in)
     auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
     for (int c = 0; c < n_chunks && rc == MKH_OK && e == hipSuccess; ++c) {
@@ -1896,15 +1844,16 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
       if (until) { ac.iters_out = p->s_iters + off; ac.converged_out = p->s_iters + mb + off; }
       if (a.warm) ac.warm = a.warm + off * nv;
       rc = launch(p, ac, nullptr, stream, flags);
-      if (rc == MKH_OK && ok(hipEventRecord(p->ev_k[c], stream))) recorded.store(c + 1, std::memory_order_release);
-      if (c == 0 && rc == MKH_OK) p->chunk_quantum = (p->last_block == kWave && (size_t)p->last_grid < Bc) ? p->last_grid : 0;
+      if (rc == MKH_OK) ok(hipEventRecord(p->ev_k[c], stream));
     }
-    issued_all.store(true, std::memory_order_release);
-    if (drainer.joinable()) {
-      drainer.join();
-      if (e == hipSuccess) e = e_out;
-    } else {
-      for (int c = 0; c < n_chunks && rc == MKH_OK && e == hipSuccess; ++c) e = drain(c);
+    for (int c = 0; c < n_chunks && rc == MKH_OK && e == hipSuccess; ++c) {
+      const size_t off = c * chunk, Bc = (c + 1 < n_chunks) ? chunk : (size_t)B - off;
+      e = hipStreamWaitEvent(p->st_out, p->ev_k[c], 0);
+      if (e == hipSuccess) e = hipMemcpyAsync(v_out + off * nv, p->s_v + off * nv, Bc * nv * sizeof(double), hipMemcpyDeviceToHost, p->st_out);
+      if (e == hipSuccess && q_out) e = hipMemcpyAsync(q_out + off * nq, p->s_q + off * nq, Bc * nq * sizeof(double), hipMemcpyDeviceToHost, p->st_out);
+      if (e == hipSuccess && status_out) e = hipMemcpyAsync(status_out + off, p->s_status + off, Bc * sizeof(int32_t), hipMemcpyDeviceToHost, p->st_out);
+      if (e == hipSuccess && until && iters_out) e = hipMemcpyAsync(iters_out + off, p->s_iters + off, Bc * sizeof(int32_t), hipMemcpyDeviceToHost, p->st_out);
+      if (e == hipSuccess && until && converged_out) e = hipMemcpyAsync(converged_out + off, p->s_iters + mb + off, Bc * sizeof(int32_t), hipMemcpyDeviceToHost, p->st_out);
     }
     // (a failed call still drains what it started: the staging buffers belong to the handle)
     const hipError_t e1 = hipStreamSynchronize(p->st_in), e2 = hipStreamSynchronize(stream), e3 = hipStreamSynchronize(p->st_out);

@@ -1,7 +1,6 @@
 #!/usr/bin/env python
 """Host-pointer (PCIe-inclusive) call rate of a BASELINE config, chunked (default) against single-shot
-(MKH_DEBUG_NO_CHUNKS=1 in the environment), the outputs drained by a second host thread (default) against one thread
-(MKH_DEBUG_NO_D2H_THREAD=1), other chunk counts (MKH_DEBUG_CHUNKS=n).  GPU only.     python tools/bench_host_path.py [config] [reps]"""
+(MKH_DEBUG_NO_CHUNKS=1 in the environment).  GPU only.     python tools/bench_host_path.py [config] [reps]"""
 import os
 import sys
 import time
@@ -29,20 +28,9 @@ def main():
         v, st = prob.solve(q, tg, pt, ct, dt, damping)
         ts.append(time.perf_counter() - t0)
     ts = np.array(ts[2:])
-    mode = "single-shot" if os.environ.get("MKH_DEBUG_NO_CHUNKS") else "chunked x%s%s" % (
-        os.environ.get("MKH_DEBUG_CHUNKS", "8"), ", one host thread" if os.environ.get("MKH_DEBUG_NO_D2H_THREAD") else ", outputs drained by a second thread")
     print("%-10s B=%d %s  %s: median %.3f ms (%.1f M solves/s), min %.3f, max %.3f" % (
-        config, B, prob.last_kernel(), mode, 1e3 * np.median(ts), B / np.median(ts) / 1e6, 1e3 * ts.min(), 1e3 * ts.max()))
-    if os.environ.get("MKH_HOST_PATH_PREALLOC"):
-        # the caller's own output arrays (no fresh pages to fault in inside the copy): what a control loop that reuses its buffers sees
-        v = np.empty((B, model.nv)); st = np.empty((B,), dtype=np.int32)
-        ts = []
-        for _ in range(reps + 2):
-            t0 = time.perf_counter()
-            prob.solve(q, tg, pt, ct, dt, damping, out=v, status_out=st)
-            ts.append(time.perf_counter() - t0)
-        ts = np.array(ts[2:])
-        print("%-10s   ... into preallocated outputs: median %.3f ms (%.1f M solves/s)" % (config, 1e3 * np.median(ts), B / np.median(ts) / 1e6))
+        config, B, prob.last_kernel(), "single-shot" if os.environ.get("MKH_DEBUG_NO_CHUNKS") else "chunked    ",
+        1e3 * np.median(ts), B / np.median(ts) / 1e6, 1e3 * ts.min(), 1e3 * ts.max()))
 
 
 if __name__ == "__main__":
