@@ -91,7 +91,7 @@ __host__ __device__ inline int lds_even(int x) { return (x + 1) & ~1; }
 __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int njnt, int n_frame,
                                                 int n_posture, int n_com, int max_rows, int j_rows, int j_stride,
                                                 int s_doubles = 0, bool prefetch = false, bool compact = false,
-                                                bool wood = false, int n_hsel = 0) {
+                                                bool wood = false, int n_hsel = 0, bool piv_small = false) {
   LdsLayout L;
   int o = 0;
   const int x_sz = 7 * lds_even(nbody), jnt_sz = lds_even(njnt * 6);
@@ -123,7 +123,11 @@ __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int n
   L.col = o;  o += max_rows * 16;
   L.A = o;    o += max_rows * a_stride_for(nv);       // half-space rows A[s][0..stride)
   const bool piv_apart = !compact || wood;
-  L.piv = piv_apart ? o : u0 + j_sz;  o += piv_apart ? 2 * kPivBuf : 0;    // two pivot column broadcast buffers (64 entries + 8 scalar slots of the pivot lane): look-ahead publishing
+  // two pivot column broadcast buffers (64 entries + 8 scalar slots of the pivot lane): look-ahead publishing.  (piv_small, the
+  // F_COM builds with one more resident wave: a low-rank start never publishes ahead — one buffer for the QP, and the
+  // elimination's published row + 1/d_r + ω_r = kWoodRow + 2·kMuBig doubles: 32 doubles less, the difference between 9 and 10
+  // wavefronts per CU for the G1 full example — LDS is handed out in 1 280-byte granules on gfx950)
+  L.piv = piv_apart ? o : u0 + j_sz;  o += piv_apart ? (piv_small ? kWoodRow + 2 * kMuBig : 2 * kPivBuf) : 0;
   L.S = o;    o += lds_even(s_doubles);   // low-rank start: columns of −Jh·Jhᵀ + right-hand sides
   // second buffers of the per-problem inputs: the next problem's q / targets are fetched straight into LDS
   // (global_load_lds) while the current problem is being solved
@@ -434,7 +438,13 @@ __device__ __forceinline__ LdsLayout kernel_lds_layout(const PT& P0) {
                     (kWood && !wood_s_aliases_dof(P0.nv, P0.n_jrows, lds_even(P0.n_jrows), P0.n_com > 0 ? P0.nbody : 0))
                         ? P0.n_jrows * (lds_even(P0.n_jrows) + 1) : 0,
                     kernel_prefetch(P0), kCompact || (kWood && P0.wood_compact != 0), kWood,
-                    (FEAT & F_COLL) ? P0.n_hsel : 0);       // (a compile-time 0 without collision rows: one value less to keep)
+                    (FEAT & F_COLL) ? P0.n_hsel : 0,        // (a compile-time 0 without collision rows: one value less to keep)
+#if defined(MKH_W3) && (MKH_FEAT & 4) && (MKH_FEAT & 32)
+                    true
+#else
+                    false
+#endif
+                    );
 }
 __device__ MKH_PRE_ATTR PreOut pre_phases(const DeviceProblem* Pq, const TapArgs* tp, int pb, int oz, int off_q, int off_tgt,
                                           bool until, double pos_thr, double ori_thr MKH_PRE_TC_PARAMS) {
@@ -1013,6 +1023,66 @@ __device__ __forceinline__ void wood_eliminate(int n_mu, int NR, int lane, doubl
   ssq = lane < NR ? sJ[n_mu * NR + lane] : 0.0;
 }
 
+// One more resident wave per SIMD for the F_COM builds (MKH_W3 with ComTask rows: the reference's humanoid example as written):
+// wood_start as ONE callee needs ≈150 VGPRs there — the dense Jh·Jhᵀ product keeps 24 accumulators, the elimination a 24-row
+// column, and hipcc lets both ranges overlap with the pair lanes' values — and everything beyond the 104 caller-saved registers
+// below v168 is a callee-saved block (v40-47, v56-63, …) that the prologue stores to scratch and the epilogue reloads: 45
+// registers, 360 B per lane and call, the reason this build measured 2.27 ms against 1.48 ms on two waves in round 4.  The two
+// heavy phases are callees of their own here, each inside the caller-saved set; they talk through LDS offsets (a pointer
+// argument would arrive as a flat address).
+#if defined(MKH_W3) && (MKH_FEAT & 4)
+#define MKH_WOOD_SPLIT 1
+struct WoodElimOut { double ssq, quad, zw; int status; };
+template <int K, bool DUAL>
+__device__ __attribute__((noinline)) WoodElimOut wood_eliminate_call(int n_mu, int off_J, int off_S, int SP, int off_Row) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  n_mu = uni(n_mu); off_J = uni(off_J); off_S = uni(off_S); SP = uni(SP); off_Row = uni(off_Row);
+  const int lane = lane_id();
+  double* const sS = smem + off_S;
+  double* const sRow = smem + off_Row;
+  WoodElimOut o{0.0, 0.0, 0.0, 0};
+  int clamp = 0;
+  double beta = 0.0;
+  const WoodRefine rf{false, 0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};          // (no cold-start refinement in the F_COM builds)
+  wood_eliminate<K, DUAL>(n_mu, MKH_NT, lane, smem + off_J, sS, SP, sS + n_mu * SP, sRow, sRow + kWoodRow, o.ssq, o.quad, o.zw, o.status,
+                          rf, clamp, beta);
+  return o;
+}
+// the dense product S = I + Jh·Jhᵀ and Jw·z̃ of the F_COM builds (see wood_start)
+__device__ __attribute__((noinline)) void wood_s_dense_call(int n_mu, int nv, int off_J, int off_S, int SP, unsigned a_lo, unsigned a_hi) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int NR = MKH_NT;
+  n_mu = uni(n_mu); nv = uni(nv); off_J = uni(off_J); off_S = uni(off_S); SP = uni(SP);
+  const unsigned long long a_mask = ((unsigned long long)(unsigned)uni((int)a_hi) << 32) | (unsigned)uni((int)a_lo);
+  const int lane = lane_id();
+  const double* const sJ = smem + off_J;
+  double* const sS = smem + off_S;
+  double* const sW = sS + n_mu * SP;
+  double acc[kMuBig];
+#pragma unroll
+  for (int r = 0; r < kMuBig; ++r) acc[r] = 0.0;
+  double wacc = 0.0;
+  const int rows0 = (int)(lane & 15), rows1 = 16 + (int)(lane & 15);
+  const bool has0 = rows0 < n_mu, has1 = rows1 < n_mu, mine = lane < n_mu;
+  const double* c0 = sJ + (has0 ? rows0 : 0) * NR;
+  const double* c1 = sJ + (has1 ? rows1 : 0) * NR;
+  const double* cm = sJ + (mine ? lane : 0) * NR;
+  const double* zs = sJ + n_mu * NR;
+  for (int k = 0; k < nv; ++k) {
+    const double p0 = has0 ? c0[k] : 0.0, p1 = has1 ? c1[k] : 0.0;
+    const double g = mine ? cm[k] : 0.0;
+    WoodAll<kMuBig>::step(acc, p0, p1, ((a_mask >> k) & 1) ? 0.0 : g);   // acc[r] += Jh[r][k]·Jh[c][k], free dofs only
+    wacc = fma(g, zs[k], wacc);
+  }
+  if (mine) {
+#pragma unroll
+    for (int r = 0; r < kMuBig; ++r)
+      if (r < n_mu) sS[lane * SP + r] = acc[r] + (r == lane ? 1.0 : 0.0);
+    sW[lane] = wacc;
+  }
+}
+#endif
+
 // A real call in the 3-waves variants (see pre_phases) and in the F_COM builds, whose 24-row / two-pass instantiations do not
 // fit next to the kernel's own live values (86 spilled VGPRs when inlined).
 #if defined(MKH_CALLS) || (MKH_FEAT & 4)
@@ -1186,6 +1256,10 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
     // Dense product (F_COM builds: ComTask rows reach every dof, and with 24 rows the chain walk below — a dependent
     // ffs → address → LDS read per bit, 43 bits × 2 passes for a CoM column — took 39 k cycles): lane c accumulates column c
     // of Jh·Jhᵀ and (Jw·z)[c] over the dofs; column k of Jh arrives as two 16-lane planes, broadcast by the DPP network.
+#ifdef MKH_WOOD_SPLIT
+    wood_s_dense_call(n_mu, nv, (int)(sJ - smem), (int)(sS - smem), SP, (unsigned)a_mask, (unsigned)(a_mask >> 32));
+    asm volatile("" : "+v"(lane));
+#else
     double acc[kMuBig];
 #pragma unroll
     for (int r = 0; r < kMuBig; ++r) acc[r] = 0.0;
@@ -1208,6 +1282,7 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
         if (r < n_mu) sS[lane * SP + r] = acc[r] + (r == lane ? 1.0 : 0.0);
       sW[lane] = wacc;
     }
+#endif
   } else {
     const int wc = kPre ? pre_wc : P.wood_col[ol], wr0 = kPre ? pre_wr0 : P.wood_row0[ol];
     if (wc >= 0) {
@@ -1270,9 +1345,20 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
   constexpr bool kRefine = !kCom && NR >= 44 && !(MKH_FEAT & F_STEPS);
   const WoodRefine rf{kRefine && a_mask == 0 && !dual && P.wood_refine != 0, nv, lo, hi, -c_lane * (dsq * dsq), dsq, hdiag_base * dsq, -c_lane * dsq};
   if constexpr (kCom) {
+#ifdef MKH_WOOD_SPLIT
+    {
+      const int oJ = (int)(sJ - smem), oS = (int)(sS - smem), oR = (int)(sRow - smem);
+      const WoodElimOut eo = dual ? wood_eliminate_call<kMuBig, true>(n_mu, oJ, oS, SP, oR)
+                                  : (n_mu <= kMu ? wood_eliminate_call<kMu, false>(n_mu, oJ, oS, SP, oR)
+                                                 : wood_eliminate_call<kMuBig, false>(n_mu, oJ, oS, SP, oR));
+      asm volatile("" : "+v"(lane));
+      ssq = eo.ssq; quad = eo.quad; zw = eo.zw; status |= eo.status;
+    }
+#else
     if (dual) wood_eliminate<kMuBig, true>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status, rf, clamp, beta);
     else if (n_mu <= kMu) wood_eliminate<kMu, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status, rf, clamp, beta);
     else wood_eliminate<kMuBig, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status, rf, clamp, beta);
+#endif
   } else {
     wood_eliminate<kMu, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status, rf, clamp, beta);
   }
@@ -2384,7 +2470,10 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       const int kn = (k + 1 < k_end) ? k + 1 : k;                      // (last pivot: a harmless re-publication of column k)
       {
         const double rn = MKH_TAB<NT>::get_dyn(ts, kn);                        // R[kn][lane] before update k
-        const double cn = bufc[kn];                                    // R[kn][k] (broadcast)
+        // R[kn][k]: lane kn's entry of the published column, by v_readlane (round 5; as a broadcast read of bufc[kn] it was a
+        // full LDS round trip in front of the FMA that depends on it, in every pivot: Shadow config 4 0.342 -> 0.333 ms,
+        // g1_coll 0.596 -> 0.580, the plugin workload 1.689 -> 1.680)
+        const double cn = readlane_f64(own, kn);
         own_next = (lane == kn) ? 0.0 : fma(cn, -g, rn);               // the same FMA the update applies to row kn
         pd = readlane_f64(s.D, kn); psg = readlane_f64(s.sg, kn); px = readlane_f64(s.x, kn);
       }

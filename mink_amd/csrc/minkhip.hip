@@ -389,7 +389,13 @@ static int build_lane_problem(const MkhModel* m, const MkhProblemDesc* d, const 
 // Resident wavefronts per CU of a kernel variant: bounded by LDS (160 KiB/CU) and by the register map the
 // variant was built for (4 waves/SIMD for NT ≤ 8, 3 for NT ≤ 24, else 2 — ik_kernel.h MKH_WAVES).
 static int waves_per_cu(int nt, int lds_bytes, bool w3 = false) {
-  const int by_lds = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
+  int by_lds = (160 * 1024) / (lds_bytes > 0 ? lds_bytes : 1);
+  // gfx950 hands LDS out in granules of 320 dwords: 128 of them per CU.  A persistent kernel must not be launched with more
+  // workgroups than are resident at once — the ones that wait for a slot start when the first ones EXIT, i.e. after the whole
+  // batch, and then walk their static share alone (round 5: `44_36_r44_w3` asked for 16 064 B, 10 per CU by division, 9 by
+  // granules: 2.12 ms instead of 1.44 with a third of the CUs idle; SQ_WAVE_CYCLES / SQ_BUSY_CYCLES gave it away).  Applied
+  // where a layout lands between the two figures: the F_COM builds on the one-more-wave map.
+  if (w3 && nt == 44 && lds_bytes > (160 * 1024) / 12) by_lds = 128 / ((lds_bytes + 1279) / 1280);
   // (w3: the high-occupancy build of the variant — one more resident wave per SIMD than its plain register map)
   const int by_regs = 4 * (nt <= 8 ? 4 : (nt <= 24 ? (w3 ? 4 : 3) : (w3 ? 3 : 2)));
   const int w = by_lds < by_regs ? by_lds : by_regs;
@@ -1172,10 +1178,10 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     if (p->wood_nt) {
       p->wood_big = P.n_jrows > kMu || p->wood_nr + P.n_jrows > kWave;
       const int sp = lds_even(P.n_jrows);
-      auto lds_wood = [&](bool pre, bool compact) {
+      auto lds_wood = [&](bool pre, bool compact, bool piv_small = false) {
         return lds_layout(P.nq, P.nv, P.nbody, P.njnt, P.n_frame, P.n_posture, P.n_com, P.max_rows, P.n_jrows + 1, p->wood_nr,
                           wood_s_aliases_dof(P.nv, P.n_jrows, sp, P.n_com > 0 ? P.nbody : 0) ? 0 : P.n_jrows * (sp + 1),
-                          pre, compact, true);
+                          pre, compact, true, 0, piv_small);
       };
       // 2-waves map: the plain layout, or — when that would cost a resident wave and the pair lanes need one pass only (the
       // compact layout lets the Jacobian rows overwrite the task blocks) — the compact one
@@ -1236,6 +1242,18 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
         if (waves_per_cu(p->wood_nt, lds_wood(false, true).total * (int)sizeof(double), true) == full) {
           P.prefetch_w3w = waves_per_cu(p->wood_nt, lds_wood(true, true).total * (int)sizeof(double), true) == full ? 1 : 0;
           p->wood_lds_bytes_w3 = lds_wood(P.prefetch_w3w != 0, true).total * (int)sizeof(double);
+        }
+      }
+      // ... and the F_COM builds of a humanoid-size robot (ComTask rows and / or up to 24 task rows: `44_36_r44_w3`, round 5).
+      // Their 25 rows of Jh take 8.8 KB of the compact layout — 15.4 KB for the G1 full example, 10 wavefronts per CU instead
+      // of 8 — so the bar is "more resident wavefronts than the two-waves map", not all twelve.
+      static const bool no_com_w3 = getenv("MKH_DEBUG_NO_COM_W3") != nullptr;       // (A/B switch)
+      if (!no_com_w3 && p->wood_nt == 44 && P.n_jpairs <= kWave && (P.n_com > 0 || p->wood_big)) {
+        const int two = waves_per_cu(p->wood_nt, 1, false);     // 8
+        const int w = waves_per_cu(p->wood_nt, lds_wood(false, true, true).total * (int)sizeof(double), true);
+        if (w > two) {
+          P.prefetch_w3w = waves_per_cu(p->wood_nt, lds_wood(true, true, true).total * (int)sizeof(double), true) == w ? 1 : 0;
+          p->wood_lds_bytes_w3 = lds_wood(P.prefetch_w3w != 0, true, true).total * (int)sizeof(double);
         }
       }
       double mn = __builtin_huge_val();
@@ -1580,7 +1598,8 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   if (!nr && p->lds_bytes_w3 && !(flags & MKH_FLAG_TWO_WAVES))
     for (const auto& v : kW3Variants) w3 = w3 || (v[0] == nt && v[1] == feat);
   if (w3) lds = p->lds_bytes_w3;
-  if (nr && p->wood_lds_bytes_w3 && !(flags & MKH_FLAG_TWO_WAVES) && (feat == F_WOOD || feat == (F_WOOD | F_STEPS))) {
+  if (nr && p->wood_lds_bytes_w3 && !(flags & MKH_FLAG_TWO_WAVES) &&
+      (feat == F_WOOD || feat == (F_WOOD | F_STEPS) || (feat == (F_WOOD | F_COM) && nt == 44))) {
     w3 = true; lds = p->wood_lds_bytes_w3;
   }
   // tight rows first (see mkh_problem_create): plain solves on the capsule-only collision build whose caller takes the status
@@ -1627,6 +1646,13 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   const int per_wave = a.B / grid;
   const bool dynamic = nt > 8 && per_wave >= 4 && !tight;              // (a redo launch walks its static share, ik_kernel.h)
   al.static_rounds = dynamic ? (per_wave * 7) / 8 : INT32_MAX;
+  // Resident wavefronts that do not divide by the four SIMDs of a CU (10: three on two SIMDs, two on the others): a wavefront
+  // that shares its SIMD with two others is slower than one that shares it with one, and equal static shares make the batch wait
+  // for the slow ones.  Half of the batch through the ticket counter there, so that the fast wavefronts take more of it.
+  // (MKH_DEBUG_STATIC_78=1: the 7/8 rule everywhere — A/B)
+  static const bool static78 = getenv("MKH_DEBUG_STATIC_78") != nullptr;
+  if (dynamic && !static78 && grid == p->model->num_cus * (grid / p->model->num_cus) && ((grid / p->model->num_cus) & 3) != 0)
+    al.static_rounds = per_wave / 2;
   if (!tight) HIP_OK(clk_begin(p, al, stream));
   if (cv_split) {
     const int rc = mkh::launch_convex_pre(stream, p->d_wide, p->cv, a.B, a.q, p->d_cv);

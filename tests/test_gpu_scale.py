@@ -249,7 +249,10 @@ def test_low_rank_start_with_com_rows_and_many_task_rows():
     _, _, t = prob.solve(q, tg, stand[None, :], np.zeros((1, 3)), dt, damping, taps=["subtree_com"], solve_qp=False)
     com = t["subtree_com"][:, None, :] + 0.01
     v, st = prob.solve(q, tg, stand[None, :], com, dt, damping)
+    assert prob.last_kernel() == "ik_solve_kernel_44_36_r44_w3", prob.last_kernel()      # (round 5: ten wavefronts per CU)
+    v2w, st2w = prob.solve(q, tg, stand[None, :], com, dt, damping, two_waves=True)
     assert prob.last_kernel() == "ik_solve_kernel_44_36_r44", prob.last_kernel()
+    assert (st2w == st).all() and np.abs(v2w - v).max() <= 1e-9 * max(1.0, np.abs(v).max())
     vd, std = prob.solve(q, tg, stand[None, :], com, dt, damping, direct_qp=True)
     assert prob.last_kernel() == "ik_solve_kernel_44_6", prob.last_kernel()
     assert (st == 0).all() and (std == 0).all()
@@ -258,7 +261,7 @@ def test_low_rank_start_with_com_rows_and_many_task_rows():
     assert err < 1e-9
     n = 512                                            # (the C oracle takes one CoM target for the whole batch)
     vs, sts = prob.solve(q[:n], tg[:n], stand[None, :], com[0], dt, damping)
-    assert prob.last_kernel() == "ik_solve_kernel_44_36_r44" and (sts == 0).all()
+    assert prob.last_kernel() == "ik_solve_kernel_44_36_r44_w3" and (sts == 0).all()
     m, tasks, limits, dt_o, damp_o = oc.g1_full(tg[0], stand, com[0, 0])
     v_c, st_c = cport.CProblem(m, tasks, limits).solve_batch(q[:n], tg[:n], stand[None, :], dt_o, damp_o, com_target=com[0, 0])
     assert (st_c == 0).all()
@@ -271,7 +274,7 @@ def test_low_rank_start_with_com_rows_and_many_task_rows():
                             velocity_limits=[nc._vel_limit(model)], max_batch=B)
     q2, tg2 = workloads.make_batch(model, nm, p20, np.random.default_rng(4), B, base_q=stand)
     v2, st2 = p20.solve(q2, tg2, stand[None, :], None, 5e-3, 1e-1)
-    assert p20.last_kernel() == "ik_solve_kernel_44_36_r44", p20.last_kernel()
+    assert p20.last_kernel() == "ik_solve_kernel_44_36_r44_w3", p20.last_kernel()
     v2d, st2d = p20.solve(q2, tg2, stand[None, :], None, 5e-3, 1e-1, direct_qp=True)
     assert "_r" not in p20.last_kernel()
     assert (st2 == 0).all() and (st2d == 0).all()
@@ -317,7 +320,7 @@ def test_cold_start_refinement_agrees_with_the_plain_low_rank_start(monkeypatch)
         assert err < 1e-9 and err_o < 1e-9
 
 
-_BENCH_KERNELS = {"ur5e_c2": "ik_quad_kernel", "g1_c3": "ik_solve_kernel_44_32_r44_w3", "g1_full": "ik_solve_kernel_44_36_r44",
+_BENCH_KERNELS = {"ur5e_c2": "ik_quad_kernel", "g1_c3": "ik_solve_kernel_44_32_r44_w3", "g1_full": "ik_solve_kernel_44_36_r44_w3",
                   "shadow_c4": "ik_solve_kernel_48_72+redo_64", "g1_plugin": "ik_solve_kernel_48_256", "h1_c3": "ik_quad_kernel_32",
                   "h1_full": "ik_quad_kernel_32", "g1_coll": "ik_solve_kernel_48_8+redo_64+wide", "ur5e_coll": "ik_solve_kernel_16_8",
                   "g1_hands": "ik_wide_kernel"}
@@ -449,6 +452,13 @@ def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name, monk
             assert len(bad) <= 4 and (sens > 1e-6).all(), (bad, err[bad], sens)
             err[bad] = 0.0
     assert err.max() < 1e-8
+    if name == "g1_full":
+        # round 5: one more resident wave per SIMD (10 wavefronts per CU, the heavy phases of the low-rank start as callees of
+        # their own).  The two-waves build of the same algorithm (MKH_FLAG_TWO_WAVES) is another kernel with the same answers.
+        v2w, st2w = prob.solve(q, tg, pt, com, dt, damping, two_waves=True)
+        assert prob.last_kernel() == "ik_solve_kernel_44_36_r44", prob.last_kernel()
+        assert (st2w == st).all()
+        assert np.abs(v2w - v).max() <= 1e-9 * max(1.0, np.abs(v).max())
     if name == "shadow_c4":          # the regime must exercise the rows: contacts in range on most instances
         G, h = cp.collision_rows(q[0], dt)
         assert np.isfinite(h).sum() >= 5
