@@ -1403,6 +1403,29 @@ static int lds_for_nt(const MkhProblem* p, int nt) {
                     P.prefetch != 0, false, false, P.n_hsel).total * (int)sizeof(double);
 }
 
+// Static rounds of a wavefront kernel's problem distribution (ik_kernel.h): each wavefront first walks `static` problems of its
+// XCD's contiguous row range, the rest of the batch goes through the ticket counter.  Static rows share cache lines inside one
+// L2 and cost no atomic; the ticket tail evens out what the static part left uneven — QP work varies by ±9 % per problem,
+// CUs differ by a few per cent — and that grows with the number of rounds.  Round 1 measured the 1.18-ms kernel of its day
+// flat between 4/16 and 14/16 static and took 7/8; on today's kernels (round 5, sweep by sixteenths at 65 536 / 32 768 / 16 384
+// G1 instances, the plugin workload and the G1 full example): 21 rounds per wavefront want 6 of them dynamic (0.779 -> 0.752 ms
+// on the headline), 10 want 2, 5 want 1, 32 of the two-waves plugin build 6 or more (1.681 -> 1.632 ms).
+// `uneven`: resident wavefronts per CU that do not divide by its four SIMDs (ten: 3 + 3 + 2 + 2) — a wavefront that shares its
+// SIMD with two others is slower than one that shares it with one, so nearly half of the batch goes through the counter there
+// (G1 full example 1.37 -> 1.24 ms).  MKH_DEBUG_STATIC_78=1: the old 7/8 rule; MKH_DEBUG_STATIC_16THS=n: n sixteenths (sweeps).
+static int static_rounds_for(int per_wave, bool uneven, bool loops = false) {
+  static const bool static78 = getenv("MKH_DEBUG_STATIC_78") != nullptr;
+  static const int dbg_16ths = getenv("MKH_DEBUG_STATIC_16THS") ? atoi(getenv("MKH_DEBUG_STATIC_16THS")) : -1;
+  if (dbg_16ths >= 0 && dbg_16ths <= 16) return (per_wave * dbg_16ths) / 16;
+  if (static78) return (per_wave * 7) / 8;
+  if (uneven) return (per_wave * 9) / 16;
+  // (fused loops: a problem is 3 … 40 solves long and the threshold-terminated ones differ by that much — half of the batch
+  //  dynamic: converged targets of the headline's loop leg 5.45 -> 5.65 M/s; the fixed-count loops do not care)
+  if (loops) return per_wave / 2;
+  const int dyn = (3 * per_wave - 2) / 10;
+  return per_wave - (dyn < 1 ? 1 : dyn);
+}
+
 static int grid_for_variant(const MkhProblem* p, int B, int nt, int lds, bool w3 = false) {
   int wpc = waves_per_cu(nt, lds, w3);
   // diagnostic: cap the resident waves per CU (occupancy experiments, docs/HISTORY.md §7b); never raises it
@@ -1599,7 +1622,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
     for (const auto& v : kW3Variants) w3 = w3 || (v[0] == nt && v[1] == feat);
   if (w3) lds = p->lds_bytes_w3;
   if (nr && p->wood_lds_bytes_w3 && !(flags & MKH_FLAG_TWO_WAVES) &&
-      (feat == F_WOOD || feat == (F_WOOD | F_STEPS) || (feat == (F_WOOD | F_COM) && nt == 44))) {
+      (feat == F_WOOD || feat == (F_WOOD | F_STEPS) || ((feat == (F_WOOD | F_COM) || feat == (F_WOOD | F_COM | F_STEPS)) && nt == 44))) {
     w3 = true; lds = p->wood_lds_bytes_w3;
   }
   // tight rows first (see mkh_problem_create): plain solves on the capsule-only collision build whose caller takes the status
@@ -1622,7 +1645,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
     SolveArgs at = a;
     at.work_counter = p->d_work;
     const int pw = a.B / gt;
-    at.static_rounds = (pw >= 4) ? (pw * 7) / 8 : INT32_MAX;
+    at.static_rounds = (pw >= 4) ? static_rounds_for(pw, gt % p->model->num_cus == 0 && ((gt / p->model->num_cus) & 3) != 0) : INT32_MAX;
     HIP_OK(clk_begin(p, at, stream));                 // (clock builds: the stamps of the launch that does the work)
     if (mkh::launch_variant(p->nt_tight, 0, feat, false, gt, p->lds_tight, stream, p->d_dev_tight, at, nullptr) != 0)
       return fail(MKH_E_INVALID, "no kernel variant ik_solve_kernel_%d_%d", p->nt_tight, feat);
@@ -1638,21 +1661,13 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
     snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_solve_kernel_%d_%d+redo_%d", p->nt_tight, feat, nt);
     p->last_nt = p->nt_tight; p->last_lds = p->lds_tight; p->last_grid = grid_for_variant(p, a.B, p->nt_tight, p->lds_tight, false);
   }
-  // Distribution (ik_kernel.h): 7/8 of each wave's share is static — one contiguous row range per XCD — and the tail
-  // of the batch goes through the ticket counter.  Measured on G1 (kernel ms by static sixteenths): 16 → 1.283,
-  // 15 → 1.233, 14 → 1.183, 12 → 1.185, 8 → 1.193, 4 → 1.195, 0 → 1.264: the tail needs ≈4 dynamic rounds to even
-  // out, and every wave opening with an atomic costs more than the balance returns.  Short problems (the 8-row
-  // variants) and thin batches stay static.
+  // Distribution (ik_kernel.h): most of each wave's share is static — one contiguous row range per XCD — and the tail
+  // of the batch goes through the ticket counter (how much: static_rounds_for above).  Round 1, on G1 (kernel ms by static
+  // sixteenths): 16 → 1.283, 15 → 1.233, 14 → 1.183, 12 → 1.185, 8 → 1.193, 4 → 1.195, 0 → 1.264: every wave opening with an
+  // atomic costs more than the balance returns.  Short problems (the 8-row variants) and thin batches stay static.
   const int per_wave = a.B / grid;
   const bool dynamic = nt > 8 && per_wave >= 4 && !tight;              // (a redo launch walks its static share, ik_kernel.h)
-  al.static_rounds = dynamic ? (per_wave * 7) / 8 : INT32_MAX;
-  // Resident wavefronts that do not divide by the four SIMDs of a CU (10: three on two SIMDs, two on the others): a wavefront
-  // that shares its SIMD with two others is slower than one that shares it with one, and equal static shares make the batch wait
-  // for the slow ones.  Half of the batch through the ticket counter there, so that the fast wavefronts take more of it.
-  // (MKH_DEBUG_STATIC_78=1: the 7/8 rule everywhere — A/B)
-  static const bool static78 = getenv("MKH_DEBUG_STATIC_78") != nullptr;
-  if (dynamic && !static78 && grid == p->model->num_cus * (grid / p->model->num_cus) && ((grid / p->model->num_cus) & 3) != 0)
-    al.static_rounds = per_wave / 2;
+  al.static_rounds = dynamic ? static_rounds_for(per_wave, grid % p->model->num_cus == 0 && ((grid / p->model->num_cus) & 3) != 0, a.n_steps > 1) : INT32_MAX;
   if (!tight) HIP_OK(clk_begin(p, al, stream));
   if (cv_split) {
     const int rc = mkh::launch_convex_pre(stream, p->d_wide, p->cv, a.B, a.q, p->d_cv);

@@ -162,3 +162,36 @@ def test_warm_start_across_calls_gives_the_cold_answers():
     vh, sth = prob.solve(qw[:100], tg[:100], stand[None, :], None, dt, damping, warm_start=True)
     vc, _ = cold.solve(qw[:100], tg[:100], stand[None, :], None, dt, damping)
     assert np.abs(vh - vc).max() / max(1.0, np.abs(vc).max()) < 1e-9
+
+
+def test_fused_loops_of_the_g1_full_example_on_ten_wavefronts_per_cu():
+    """Round 5: the F_COM builds of the low-rank start (ComTask rows, up to 24 task rows) on the one-more-wave register map —
+    `44_52_r44_w3` runs the fused loops of the reference's humanoid example.  Same loop on the two-waves build, and as single
+    solves + integrate."""
+    model = workloads.load_robot("g1")
+    nm = nat.NativeModel(model)
+    stand = model.key_qpos[0]
+    B = 1024
+    prob, dt, damping = nc.build("g1_full", nm, B)
+    q0, tg = workloads.make_batch(model, nm, prob, np.random.default_rng(9), B, base_q=stand)
+    _, _, t = prob.solve(q0, tg, stand[None, :], np.zeros((1, 3)), dt, damping, taps=["subtree_com"], solve_qp=False)
+    com = t["subtree_com"][:, None, :] + 0.01
+    qf, vf, stf = prob.solve(q0, tg, stand[None, :], com, dt, damping, n_steps=4)
+    assert prob.last_kernel() == "ik_solve_kernel_44_52_r44_w3", prob.last_kernel()
+    q2, v2, st2 = prob.solve(q0, tg, stand[None, :], com, dt, damping, n_steps=4, two_waves=True)
+    assert prob.last_kernel() == "ik_solve_kernel_44_52_r44", prob.last_kernel()
+    assert ((stf & ~1) == 0).all() and (st2 == stf).all()
+    np.testing.assert_allclose(qf, q2, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(vf, v2, rtol=0, atol=1e-8 * max(1.0, np.abs(v2).max()))
+    qs = q0.copy()
+    for _ in range(4):
+        vs, _ = prob.solve(qs, tg, stand[None, :], com, dt, damping)
+        qs = nm.integrate(qs, vs, dt)
+    np.testing.assert_allclose(qf, qs, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(vf, vs, rtol=0, atol=1e-8 * max(1.0, np.abs(vs).max()))
+    # the threshold-terminated loop: iteration counts and flags of the two builds agree
+    out3 = prob.solve(q0, tg, stand[None, :], com, dt, damping, n_steps=6, until=(5e-2, 2e-1))
+    assert prob.last_kernel() == "ik_solve_kernel_44_52_r44_w3", prob.last_kernel()
+    out2 = prob.solve(q0, tg, stand[None, :], com, dt, damping, n_steps=6, until=(5e-2, 2e-1), two_waves=True)
+    np.testing.assert_array_equal(out3[3], out2[3]); np.testing.assert_array_equal(out3[4], out2[4])
+    np.testing.assert_allclose(out3[0], out2[0], rtol=0, atol=1e-10)
