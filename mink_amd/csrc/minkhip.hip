@@ -639,6 +639,7 @@ static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhPro
 static int32_t launch_wide_kernel(MkhProblem* p, const SolveArgs& a, hipStream_t stream, int32_t redo_mask, const TapArgs* dtaps = nullptr) {
   SolveArgs aw = a;
   aw.redo_mask = redo_mask;
+  aw.work_counter = p->d_work;        // (redo_mask = 0: the kernel as THE path of a model draws its problems from it)
   int grid = p->wide_grid < a.B ? p->wide_grid : a.B;
   if (grid < 1) grid = 1;
   const int rc = mkh::launch_wide(grid, p->wide_lds, stream, p->d_wide, aw, dtaps);
@@ -1075,7 +1076,9 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     const int32_t rc = build_wide_problem(p, m, d, ft, pairs, culls, dcost, dwgain);
     if (rc != MKH_OK) return bail(rc);
     p->wide_only = true;
-    if (hipMalloc((void**)&p->d_taps, sizeof(TapArgs)) != hipSuccess) return bail(fail(MKH_E_HIP, "descriptor upload failed"));
+    if (hipMalloc((void**)&p->d_taps, sizeof(TapArgs)) != hipSuccess || hipMalloc((void**)&p->d_work, 128) != hipSuccess ||
+        hipMemset(p->d_work, 0, 128) != hipSuccess)
+      return bail(fail(MKH_E_HIP, "descriptor upload failed"));
     snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_wide_kernel");
     p->dev.n_rows_tap = p->wide.n_rows_tap;        // (what mkh_problem_num_task_rows reports; the wavefront descriptor is not built)
     p->last_grid = p->wide_grid; p->last_lds = p->wide_lds; p->last_nt = p->wide.nv + p->wide.max_rows; p->last_block = kWideThreads;

@@ -913,7 +913,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
       }
     }
   }
-  for (int chunk = (int)blockIdx.x;; chunk += (int)gridDim.x) {
+  for (;;) {
   {
     int pb;
     if (A.redo_mask) {
@@ -937,8 +937,18 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
       pb = sRedI[14];
       if (pb < 0) break;
     } else {
-      if (chunk >= A.B) break;
-      pb = chunk;
+      // As THE path of a model (redo_mask = 0): every problem from the ticket counter — QP work varies by ±9 % per problem, a workgroup does 16 of an 8 192-instance batch, and with static
+      // strides the launch waited for the unluckiest of 512 sums.  Self-resetting like the wavefront kernels' counter: every
+      // workgroup ends on exactly one rejected draw, the last of them zeroes it.
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned tk = atomicAdd(A.work_counter, 1u);
+        if (tk == (unsigned)A.B + gridDim.x - 1u) atomicExch(A.work_counter, 0u);
+        sRedI[14] = (int)tk;
+      }
+      __syncthreads();
+      pb = sRedI[14];
+      if (pb >= A.B) break;
     }
     __syncthreads();
     // ------------------------------------------------------------ inputs
