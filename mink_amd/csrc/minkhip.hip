@@ -1254,7 +1254,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       if (!no_com_w3 && p->wood_nt == 44 && P.n_jpairs <= kWave && (P.n_com > 0 || p->wood_big)) {
         const int two = waves_per_cu(p->wood_nt, 1, false);     // 8
         const int w = waves_per_cu(p->wood_nt, lds_wood(false, true, true).total * (int)sizeof(double), true);
-        if (w > two) {
+        if (w >= two + 2) {                                   // (nine per CU — 3 + 2 + 2 + 2 — measured SLOWER than eight: 1.51 vs 1.44 ms)
           P.prefetch_w3w = waves_per_cu(p->wood_nt, lds_wood(true, true, true).total * (int)sizeof(double), true) == w ? 1 : 0;
           p->wood_lds_bytes_w3 = lds_wood(P.prefetch_w3w != 0, true, true).total * (int)sizeof(double);
         }
