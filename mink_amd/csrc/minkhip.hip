@@ -1416,10 +1416,16 @@ static int lds_for_nt(const MkhProblem* p, int nt) {
 // `uneven`: resident wavefronts per CU that do not divide by its four SIMDs (ten: 3 + 3 + 2 + 2) — a wavefront that shares its
 // SIMD with two others is slower than one that shares it with one, so nearly half of the batch goes through the counter there
 // (G1 full example 1.37 -> 1.24 ms).  MKH_DEBUG_STATIC_78=1: the old 7/8 rule; MKH_DEBUG_STATIC_16THS=n: n sixteenths (sweeps).
+// Below this many rounds per wavefront the batch is dealt statically as a whole (round 5, kernel ms on G1 config 3, ticket tail /
+// one strided share per wavefront: 12 288 instances = 4 rounds 0.186 / 0.177, 16 384 = 5.3 rounds 0.243 / 0.224, 20 480 = 6.7 rounds
+// 0.282 / 0.270, 24 576 = 8 rounds 0.321 / 0.335, 32 768 0.409 / 0.422, 65 536 0.754 / 0.827): over a few rounds the work of
+// the wavefronts has not drifted apart yet, and a ticket tail only adds its own ragged last round.  Round 1's threshold was 4.
+constexpr int kMinRoundsForTickets = 8;
 static int static_rounds_for(int per_wave, bool uneven, bool loops = false) {
   static const bool static78 = getenv("MKH_DEBUG_STATIC_78") != nullptr;
   static const int dbg_16ths = getenv("MKH_DEBUG_STATIC_16THS") ? atoi(getenv("MKH_DEBUG_STATIC_16THS")) : -1;
   if (dbg_16ths >= 0 && dbg_16ths <= 16) return (per_wave * dbg_16ths) / 16;
+  if (dbg_16ths == 99) return INT32_MAX;                     // (no ticket counter at all: one strided share per wavefront)
   if (static78) return (per_wave * 7) / 8;
   if (uneven) return (per_wave * 9) / 16;
   // (fused loops: a problem is 3 … 40 solves long and the threshold-terminated ones differ by that much — half of the batch
@@ -1648,7 +1654,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
     SolveArgs at = a;
     at.work_counter = p->d_work;
     const int pw = a.B / gt;
-    at.static_rounds = (pw >= 4) ? static_rounds_for(pw, gt % p->model->num_cus == 0 && ((gt / p->model->num_cus) & 3) != 0) : INT32_MAX;
+    at.static_rounds = (pw >= kMinRoundsForTickets) ? static_rounds_for(pw, gt % p->model->num_cus == 0 && ((gt / p->model->num_cus) & 3) != 0) : INT32_MAX;
     HIP_OK(clk_begin(p, at, stream));                 // (clock builds: the stamps of the launch that does the work)
     if (mkh::launch_variant(p->nt_tight, 0, feat, false, gt, p->lds_tight, stream, p->d_dev_tight, at, nullptr) != 0)
       return fail(MKH_E_INVALID, "no kernel variant ik_solve_kernel_%d_%d", p->nt_tight, feat);
@@ -1669,7 +1675,8 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   // sixteenths): 16 → 1.283, 15 → 1.233, 14 → 1.183, 12 → 1.185, 8 → 1.193, 4 → 1.195, 0 → 1.264: every wave opening with an
   // atomic costs more than the balance returns.  Short problems (the 8-row variants) and thin batches stay static.
   const int per_wave = a.B / grid;
-  const bool dynamic = nt > 8 && per_wave >= 4 && !tight;              // (a redo launch walks its static share, ik_kernel.h)
+  // (fused loops: problems of very different length — the ticket tail from four rounds on, as before)
+  const bool dynamic = nt > 8 && per_wave >= (a.n_steps > 1 ? 4 : kMinRoundsForTickets) && !tight;   // (a redo launch walks its static share, ik_kernel.h)
   al.static_rounds = dynamic ? static_rounds_for(per_wave, grid % p->model->num_cus == 0 && ((grid / p->model->num_cus) & 3) != 0, a.n_steps > 1) : INT32_MAX;
   if (!tight) HIP_OK(clk_begin(p, al, stream));
   if (cv_split) {
