@@ -1660,7 +1660,18 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
       return fail(MKH_E_INVALID, "no kernel variant ik_solve_kernel_%d_%d", p->nt_tight, feat);
     HIP_OK(hipGetLastError());
   }
-  const int grid = grid_for_variant(p, a.B, nt, lds, w3);
+  int grid = grid_for_variant(p, a.B, nt, lds, w3);
+  // One problem per workgroup instead of persistent wavefronts, for the humanoid-size builds of the one-more-wave map between
+  // 3.5 and 22 rounds (round 5): the hardware's workgroup dispatcher is a ticket counter that costs nothing, and a workgroup of
+  // these builds starts cheaply (the phases that need registers are callees).  Kernel ms on G1 config 3, persistent /
+  // one per workgroup: 12 288 instances 0.176 / 0.163, 16 384 0.224 / 0.209, 24 576 0.323 / 0.301, 32 768 0.411 / 0.390,
+  // 49 152 0.588 / 0.572, 65 536 0.751 / 0.743; outside the range it loses (8 192: 0.111 / 0.117, 131 072: 1.414 / 1.424), and so
+  // it does on every two-waves build (plugin workload 1.627 / 1.689, Shadow at 65 536 instances 1.186 / 1.226) and on the G1 full
+  // example's 25.6 rounds (1.244 / 1.265; at 16 384 instances 0.392 / 0.349).  The XCD still owns one contiguous row range
+  // (workgroup g: XCD g % 8, row g / 8 of its range).  MKH_DEBUG_PERSISTENT=1: persistent wavefronts everywhere (A/B).
+  static const bool persistent_only = getenv("MKH_DEBUG_PERSISTENT") != nullptr;
+  if (!persistent_only && !tight && w3 && nt == 44 && a.n_steps <= 1 && a.B > grid && 2 * (long long)a.B >= 7LL * grid && a.B <= 22 * grid)
+    grid = a.B;
   p->last_grid = grid; p->last_lds = lds; p->last_nt = nt;
   snprintf(p->last_kernel, sizeof(p->last_kernel), nr ? (w3 ? "ik_solve_kernel_%d_%d_r%d_w3" : "ik_solve_kernel_%d_%d_r%d") : (w3 ? "ik_solve_kernel_%d_%d_w3" : "ik_solve_kernel_%d_%d"), nt, feat, nr);
   SolveArgs al = a;

@@ -234,18 +234,29 @@ def test_production_kernel_against_2048_real_mink_instances(nat):
     v3, st3 = prob.solve(d["q"], d["frame_targets"], d["posture_target"][None, :], None, dt, damping, two_waves=True)
     check(v3, st3, "2-waves map")
     np.testing.assert_array_equal(v3, v)          # the two register maps run the same arithmetic
-    # 2 048 problems are one per resident wavefront: tile the fixture so that every persistent wavefront runs several
-    # rounds and the last eighth of the batch goes through the ticket counter — same inputs, so the same real-mink answers
-    R = 8
-    probR, _, _ = nc.build("g1_c3", nm, R * B)
-    vR, stR = probR.solve(np.tile(d["q"], (R, 1)), np.tile(d["frame_targets"], (R, 1, 1)), d["posture_target"][None, :],
-                          None, dt, damping)
-    assert probR.last_kernel() == "ik_solve_kernel_44_32_r44_w3"
-    info = probR.launch_info(R * B)
-    assert R * B >= 4 * info["grid"], info                 # ⇒ dynamic tail (minkhip.hip::launch)
-    for r in range(R):
-        np.testing.assert_array_equal(vR[r * B:(r + 1) * B], v)
-        assert (stR[r * B:(r + 1) * B] == st).all()
+    # 2 048 problems are one per resident wavefront: tile the fixture — same inputs, so the same real-mink answers — through
+    # the other two launch shapes of minkhip.hip::launch (round 5): × 8 = 16 384 instances, 5.3 rounds of the resident
+    # wavefronts: one problem per WORKGROUP (the dispatcher deals them); × 40 = 81 920 instances, 26.7 rounds: persistent
+    # wavefronts, a static share each and the tail of the batch through the ticket counter
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda", 0)
+    to = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    for R, persistent in ((8, False), (40, True)):
+        probR, _, _ = nc.build("g1_c3", nm, R * B)
+        # (device pointers: a host-pointer call of this size would be cut into chunks, each a launch of its own size)
+        vR, stR = probR.solve(to(np.tile(d["q"], (R, 1))), to(np.tile(d["frame_targets"], (R, 1, 1))), to(d["posture_target"][None, :]),
+                              None, dt, damping)
+        torch.cuda.synchronize()
+        vR, stR = vR.cpu().numpy(), stR.cpu().numpy()
+        assert probR.last_kernel() == "ik_solve_kernel_44_32_r44_w3"
+        info = probR.launch_info(R * B)
+        if persistent:
+            assert R * B >= 8 * info["grid"], info             # ⇒ dynamic tail (minkhip.hip::launch, kMinRoundsForTickets)
+        else:
+            assert info["grid"] == R * B, info
+        for r in range(R):
+            np.testing.assert_array_equal(vR[r * B:(r + 1) * B], v)
+            assert (stR[r * B:(r + 1) * B] == st).all()
 
 
 def test_production_collision_path_against_2048_real_mink_instances(nat):
