@@ -1667,7 +1667,8 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   // one per workgroup: 12 288 instances 0.176 / 0.163, 16 384 0.224 / 0.209, 24 576 0.323 / 0.301, 32 768 0.411 / 0.390,
   // 49 152 0.588 / 0.572, 65 536 0.751 / 0.743; outside the range it loses (8 192: 0.111 / 0.117, 131 072: 1.414 / 1.424), and so
   // it does on every two-waves build (plugin workload 1.627 / 1.689, Shadow at 65 536 instances 1.186 / 1.226) and on the G1 full
-  // example's 25.6 rounds (1.244 / 1.265; at 16 384 instances 0.392 / 0.349).  The XCD still owns one contiguous row range
+  // example's 25.6 rounds (1.244 / 1.265; at 16 384 instances 0.392 / 0.349).  Two, three, four problems per workgroup lie
+  // between the two shapes (65 536: 0.739 / 0.772 / 0.766).  The XCD still owns one contiguous row range
   // (workgroup g: XCD g % 8, row g / 8 of its range).  MKH_DEBUG_PERSISTENT=1: persistent wavefronts everywhere (A/B).
   static const bool persistent_only = getenv("MKH_DEBUG_PERSISTENT") != nullptr;
   if (!persistent_only && !tight && w3 && nt == 44 && a.n_steps <= 1 && a.B > grid && 2 * (long long)a.B >= 7LL * grid && a.B <= 22 * grid)
