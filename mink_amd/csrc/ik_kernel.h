@@ -4,6 +4,8 @@
 // exactly one wavefront; it loops over the problems of its XCD's contiguous slice of the batch
 // (workgroups are dealt round-robin to the 8 XCDs, each with its own L2: keeping neighbouring rows of
 // q / targets / v in ONE L2 lets partial cache lines at row boundaries merge before they reach HBM).
+// (The host picks the launch shape — minkhip.hip::launch: persistent wavefronts with a static share each and a ticket tail,
+//  or one workgroup per problem, for which the loop below runs once and the XCD ranges are the same.)
 // Lanes change role by phase:
 //   body lane   (l < nbody)   forward kinematics by pointer jumping over the tree
 //                             (replaces mj_kinematics, mink/configuration.py:63)
