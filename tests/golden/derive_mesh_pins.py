@@ -186,3 +186,13 @@ if __name__ == "__main__":
         print("  hull of the file's vertices (qhull): %d vertices" % len(ConvexHull(np.array(sorted(set(verts)))).vertices))
     except ImportError:
         pass
+    # Body mass and centre of mass from mesh geoms (round 5): wonik_allegro/left_hand.xml — class "allegro_left" sets
+    # `<geom density="800"/>` (:10), the visual classes are `type="mesh"` (:13), no body has an <inertial>, every collision geom has
+    # `mass="0"` (:38); so a finger link weighs 800 x the legacy volume of its visual mesh (no mesh scale in this file) at the
+    # mesh's centre of mass.  :136-138 rf_proximal = link_1.0, :148-149 rf_tip = link_3.0_tip at pos "0 0 0.0267" (:30).
+    for name, file, off in (("allegro rf_proximal (link_1.0)", "link_1.0.stl", (0, 0, 0)),
+                            ("allegro rf_tip (link_3.0_tip)", "link_3.0_tip.stl", (0, 0, 0.0267)),
+                            ("allegro rf_medial (link_2.0)", "link_2.0.stl", (0, 0, 0))):
+        verts, faces = read_stl(EX + "/wonik_allegro/assets/" + file)
+        V, com, _ = legacy_mass_properties(verts, faces)
+        print("%s:\n  mass %.12g  (volume %.12g)\n  ipos (%.12g, %.12g, %.12g)" % (name, 800.0 * V, V, com[0] + off[0], com[1] + off[1], com[2] + off[2]))

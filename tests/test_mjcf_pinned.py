@@ -328,3 +328,30 @@ def test_aloha_fitted_capsules():
         np.testing.assert_allclose(m.geom_size[g][:2], (radius, halflen), rtol=1e-9)
         np.testing.assert_allclose(m.geom_pos[g], pos, rtol=0, atol=1e-12)
         assert abs(abs(_zaxis(m.geom_quat[g]) @ np.array(axis)) - 1.0) < 1e-8, body
+
+
+def test_allegro_body_masses_from_mesh_geoms_second_derivation():
+    """Bodies WITHOUT <inertial> whose mass comes from mesh geoms (round-4 review: pinned only by the reader's own unit test).
+    wonik_allegro/left_hand.xml: class "allegro_left" sets `<geom density="800"/>` (:10), the visual classes are `type="mesh"`
+    (:13) with no mesh scale, every collision geom carries `mass="0"` (:38), no body has an <inertial> — so a finger link weighs
+    800 x the legacy volume of its visual mesh, at that mesh's centre of mass (+ the geom's own pos: the fingertip's
+    `pos="0 0 0.0267"`, :30).  The numbers below are TYPED from the output of tests/golden/derive_mesh_pins.py — its own STL
+    reader, plain loops over the triangles, nothing shared with mink_amd/mjcf.py / meshes.py — and compared with the committed
+    model fixture (what the reader compiled from the same files)."""
+    from mink_amd.flatmodel import FlatModel
+    import os
+    m = FlatModel.load(os.path.join(oc.GOLDEN, "models", "all", "wonik_allegro__scene_left.json"))
+    pins = {  # body: (mass, ipos)
+        "rf_proximal": (0.0272760563087, (2.75233141553e-08, -9.05955355725e-05, 0.0269997695608)),   # link_1.0.stl
+        "rf_medial": (0.018458520143, (-0.000192881578363, -7.79041643551e-05, 0.0225860114871)),    # link_2.0.stl
+        "rf_tip": (0.00684452138085, (7.27630463767e-12, -1.15602789957e-07, 0.0254027647694)),       # link_3.0_tip.stl at z + 0.0267
+    }
+    for name, (mass, ipos) in pins.items():
+        b = m.name2id("body", name)
+        assert m.body_mass_valid[b] == 1
+        np.testing.assert_allclose(m.body_mass[b], mass, rtol=1e-11)
+        np.testing.assert_allclose(m.body_ipos[b], ipos, rtol=0, atol=1e-13)
+    # the three fingers of the same build share the meshes: same masses (left_hand.xml:131-198)
+    for other in ("mf", "ff"):
+        for link in ("proximal", "medial", "tip"):
+            np.testing.assert_allclose(m.body_mass[m.name2id("body", f"{other}_{link}")], pins[f"rf_{link}"][0], rtol=1e-11)
