@@ -62,10 +62,11 @@ def test_compiler_stays_below_the_vgpr_cap(lib):
     import subprocess
     import sys
     out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_vgpr_cap.py"),
-                          "44_0", "44_32_r44", "44_32_r44_w3", "44_48_r44_w3", "44_0_w3", "64_30", "8_0", "48_31"],
+                          "44_0", "44_32_r44", "44_32_r44_w3", "44_48_r44_w3", "44_0_w3", "64_30", "8_0", "48_31",
+                          "44_36_r44_w3", "44_52_r44_w3"],          # (round 5: the F_COM builds on the one-more-wave map)
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count(" ok ") == 8, out.stdout
+    assert out.stdout.count(" ok ") == 10, out.stdout
 
 
 def test_production_kernels_do_not_spill_vector_registers():
