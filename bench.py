@@ -267,12 +267,9 @@ def measure_side_config(name, dev, steps=20, warmup=3, batch=None, seed=2000):
     redo = None
     if kernel.endswith("+wide"):
         # how many instances the second launch of the pair re-solved (more contacts in range than tableau rows and one violated, or
-        # almost dependent active rows): the same batch on a handle WITHOUT the redo launch (MKH_DEBUG_NO_WIDE is read per handle)
-        os.environ["MKH_DEBUG_NO_WIDE"] = "1"
-        try:
+        # almost dependent active rows): the same batch on a handle WITHOUT the redo launch (mkh_problem_create_diag, MKH_DIAG_NO_WIDE_REDO)
+        with nat.diag_options(nat.DIAG_NO_WIDE_REDO):
             alone, _, _ = workloads.bench_config(name, model, nm, B)
-        finally:
-            del os.environ["MKH_DEBUG_NO_WIDE"]
         st1 = torch.empty((B,), dtype=torch.int32, device=dev)
         alone.solve(q, tg, pt, ct, dt, damping, out=torch.empty_like(v), status_out=st1, dense=dense)
         s1 = st1.cpu().numpy()

@@ -44,8 +44,11 @@ extern "C" {
  * (the workgroup-per-problem kernel) where 105 returned MKH_E_LIMIT / MKH_ST_ROW_OVERFLOW.  No struct changed.
  * 107 (round 5): no signature or struct changed; calls that 106 refused now run — on models beyond 64 bodies / dofs the per-task
  * (e, J) and iteration taps (mkh_eval) and the fused loops mkh_solve_steps / mkh_solve_until; the fused loops and calls with taps
- * no longer report MKH_ST_ROW_OVERFLOW below 448 rows per instance (the flagged instances run again with every row). */
-#define MKH_VERSION 107
+ * no longer report MKH_ST_ROW_OVERFLOW below 448 rows per instance (the flagged instances run again with every row).
+ * 108 (round 6): + mkh_problem_create_diag and the MKH_DIAG_* bits (per-handle parity / measurement switches that used to be
+ * MKH_DEBUG_* environment variables: the product library no longer reads its environment); MKH_ST_DEGENERATE documented.  No
+ * struct and no existing signature changed. */
+#define MKH_VERSION 108
 
 /* return codes */
 #define MKH_OK 0
@@ -73,6 +76,12 @@ extern "C" {
                                     448 contacts in range the same rule applies one level up: the 448 tightest are rows, the bit
                                     is set only if a dropped one is violated at the solution; caller-defined limit rows that find
                                     no place set it unconditionally. */
+#define MKH_ST_DEGENERATE 32     /* the active half-space rows of this instance were almost linearly dependent (many geom pairs of one
+                                    body pair) and the answer comes from the tableau iteration, which loses digits there (errors up
+                                    to ~1e-6 relative).  Transient: the workgroup-per-problem kernel behind every problem with rows
+                                    re-solves such instances with orthogonal factors (quadprog's own algorithm) and clears the bit.
+                                    A caller sees it only where that launch does not run: handles created with
+                                    MKH_DIAG_NO_WIDE_REDO and calls that tap the cycle counters. */
 
 /* flags */
 #define MKH_FLAG_DEVICE_PTRS 1   /* data pointers are device pointers; async on stream */
@@ -303,6 +312,16 @@ void mkh_model_destroy(MkhModel *model);
  * workgroup-per-problem kernel, warm-start sets): calls on ONE handle must not overlap in time — one stream at a time, or
  * streams ordered by events.  Handles of the same model are independent of each other. */
 int32_t mkh_problem_create(MkhModel *model, const MkhProblemDesc *desc, int32_t max_batch, MkhProblem **out);
+/* The same with per-handle diagnostic switches (MKH_DIAG_* bits, 0 = mkh_problem_create).  They select among paths that return
+ * the same optimum and exist for parity tests ("what does the first launch alone leave flagged?") and measurements (bench.py's
+ * redo_instances); no counterpart in the reference (mink/solve_ik.py:68-105 has one path).  Unknown bits: MKH_E_INVALID. */
+#define MKH_DIAG_NO_WIDE_REDO 1    /* problems with half-space rows: do not build / launch the workgroup-per-problem kernel behind the
+                                      wavefront kernel — instances it would re-solve keep MKH_ST_ROW_OVERFLOW / _DEGENERATE / failures */
+#define MKH_DIAG_NO_TIGHT_REDO 2   /* collision problems on the tight-rows build: do not launch the full-row build behind it */
+#define MKH_DIAG_NO_COLD_REFINE 4  /* low-rank QP start: no second elimination for the bounds the unconstrained minimiser violates */
+#define MKH_DIAG_NO_PAIR_CULL 8    /* more than 64 collision pairs: no bounding-sphere cull in front of the distance routines */
+int32_t mkh_problem_create_diag(MkhModel *model, const MkhProblemDesc *desc, int32_t max_batch, int32_t diag,
+                                MkhProblem **out);
 void mkh_problem_destroy(MkhProblem *problem);
 int32_t mkh_problem_num_task_rows(const MkhProblem *problem);
 int32_t mkh_problem_num_collision_pairs(const MkhProblem *problem);

@@ -29,6 +29,27 @@ FLAG_TWO_WAVES = 64
 FLAG_WARM_START = 128
 FLAG_QUAD_KERNEL = 256
 FLAG_FULL_ROWS = 512
+# per-handle diagnostic switches of mkh_problem_create_diag (include/minkhip.h MKH_DIAG_*): parity tests and measurements only
+DIAG_NO_WIDE_REDO, DIAG_NO_TIGHT_REDO, DIAG_NO_COLD_REFINE, DIAG_NO_PAIR_CULL = 1, 2, 4, 8
+_diag_default = threading.local()
+
+
+class diag_options:
+    """`with diag_options(DIAG_NO_WIDE_REDO): prob = NativeProblem(...)` — every handle created by THIS thread inside the block
+    gets these MKH_DIAG_* bits (tests and bench.py build their problems through helper functions; the switch travels in the
+    call, not in the process environment).  A `diag=` argument of NativeProblem wins."""
+
+    def __init__(self, bits: int):
+        self.bits = int(bits)
+
+    def __enter__(self):
+        self.prev = getattr(_diag_default, "bits", 0)
+        _diag_default.bits = self.bits
+        return self
+
+    def __exit__(self, *exc):
+        _diag_default.bits = self.prev
+        return False
 ST_OUTSIDE_LIMITS, ST_INFEASIBLE, ST_NOT_PD, ST_ITER_LIMIT, ST_ROW_OVERFLOW = 1, 2, 4, 8, 16
 FRAME_TYPE_ID = {"body": 0, "geom": 1, "site": 2}
 
@@ -143,6 +164,8 @@ def lib() -> C.CDLL:
     L.mkh_model_destroy.argtypes = [C.c_void_p]
     L.mkh_model_destroy.restype = None
     L.mkh_problem_create.argtypes = [C.c_void_p, C.POINTER(MkhProblemDesc), C.c_int32, C.POINTER(C.c_void_p)]
+    L.mkh_problem_create_diag.argtypes = [C.c_void_p, C.POINTER(MkhProblemDesc), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.mkh_problem_create_diag.restype = C.c_int32
     L.mkh_problem_destroy.argtypes = [C.c_void_p]
     L.mkh_problem_destroy.restype = None
     L.mkh_problem_num_task_rows.argtypes = [C.c_void_p]
@@ -179,7 +202,7 @@ EXPORTED_SYMBOLS = (
     "mkh_problem_create", "mkh_problem_destroy", "mkh_problem_num_task_rows",
     "mkh_problem_num_collision_pairs", "mkh_solve", "mkh_eval", "mkh_integrate", "mkh_problem_launch_info",
     "mkh_solve_steps", "mkh_problem_last_kernel", "mkh_lie_eval", "mkh_solve_dense", "mkh_solve_until",
-    "mkh_geom_distance_eval",
+    "mkh_geom_distance_eval", "mkh_problem_create_diag",
 )
 
 LIE_OPS = {"se3_log": (0, 7, 0, (6,)), "se3_jlog": (1, 7, 0, (6, 6)), "se3_ljacinv": (2, 6, 0, (6, 6)),
@@ -301,7 +324,7 @@ class NativeProblem:
                  com_tasks: Sequence[dict] = (), configuration_limits: Sequence[dict] = (),
                  velocity_limits: Sequence[dict] = (), collision_limits: Sequence[dict] = (),
                  max_batch: int = 1, dense_tasks: Sequence[dict] = (), dense_limit_rows: int = 0,
-                 dense_limit_box: bool = False):
+                 dense_limit_box: bool = False, diag: Optional[int] = None):
         self.nmodel = nmodel
         m = nmodel.model
         keep = []
@@ -366,7 +389,14 @@ class NativeProblem:
         self.n_dense_rows = int(sum(len(np.atleast_1d(t["cost"])) for t in dense_tasks))
         self.n_dense_limit_rows = int(dense_limit_rows)
         h = C.c_void_p()
-        _check(lib().mkh_problem_create(nmodel.handle, C.byref(d), int(max_batch), C.byref(h)))
+        # (diag: DIAG_* bits — which launches stand behind this handle; 0 = the product's own choice, mkh_problem_create)
+        if diag is None:
+            diag = getattr(_diag_default, "bits", 0)
+        self.diag = int(diag)
+        if diag:
+            _check(lib().mkh_problem_create_diag(nmodel.handle, C.byref(d), int(max_batch), int(diag), C.byref(h)))
+        else:
+            _check(lib().mkh_problem_create(nmodel.handle, C.byref(d), int(max_batch), C.byref(h)))
         self.handle = h
         # one in-flight call per handle (it owns the staging buffers and the ticket counter): host-pointer calls are
         # synchronous, so a lock makes them safe from several threads; device-pointer calls are asynchronous and must

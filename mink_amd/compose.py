@@ -40,8 +40,10 @@ class _Body:
         self.joints, self.geoms, self.sites, self.children = [], [], [], []
 
 
-def _tree(m: FlatModel, prefix: str = "") -> _Body:
-    """The model as a tree of bodies carrying their own joints / geoms / sites (qpos0 slices stay with their joint)."""
+def _tree(m: FlatModel, prefix: str = "", tag: str = "parent") -> _Body:
+    """The model as a tree of bodies carrying their own joints / geoms / sites (qpos0 slices stay with their joint).
+    `tag`: which argument of attach() the model is — joints and meshes are identified by (tag, index), so attach(m, m, ...)
+    keeps the two copies apart (round-5 advisor finding: keys on id(model) collided there)."""
     nodes = []
     name = lambda n: (prefix + n) if (prefix and n) else n
     for b in range(m.nbody):
@@ -57,12 +59,12 @@ def _tree(m: FlatModel, prefix: str = "") -> _Body:
         a, t = int(m.jnt_qposadr[j]), int(m.jnt_type[j])
         nodes[int(m.jnt_bodyid[j])].joints.append(dict(
             type=t, pos=m.jnt_pos[j].copy(), axis=m.jnt_axis[j].copy(), range=m.jnt_range[j].copy(),
-            limited=int(m.jnt_limited[j]), name=name(m.jnt_names[j]), qpos0=m.qpos0[a:a + qpos_width(t)].copy(), src=(id(m), j)))
+            limited=int(m.jnt_limited[j]), name=name(m.jnt_names[j]), qpos0=m.qpos0[a:a + qpos_width(t)].copy(), src=(tag, j)))
     for g in range(m.ngeom):
         nodes[int(m.geom_bodyid[g])].geoms.append(dict(
             type=int(m.geom_type[g]), size=m.geom_size[g].copy(), pos=m.geom_pos[g].copy(), quat=m.geom_quat[g].copy(),
             contype=int(m.geom_contype[g]), conaffinity=int(m.geom_conaffinity[g]), valid=int(m.geom_valid[g]),
-            name=name(m.geom_names[g]), hull=(m.mesh_hull(g) if int(m.geom_dataid[g]) >= 0 else None), mesh=(id(m), int(m.geom_dataid[g]))))
+            name=name(m.geom_names[g]), hull=(m.mesh_hull(g) if int(m.geom_dataid[g]) >= 0 else None), mesh=(tag, int(m.geom_dataid[g]))))
     for s in range(m.nsite):
         nodes[int(m.site_bodyid[s])].sites.append(dict(pos=m.site_pos[s].copy(), quat=m.site_quat[s].copy(), name=name(m.site_names[s])))
     return nodes[0]
@@ -95,6 +97,16 @@ def _flatten(world: _Body, keys: Sequence = ()) -> FlatModel:
             G.append(dict(g, body=b))
         for s in k.sites:
             S.append(dict(s, body=b))
+    # MuJoCo's compiler (and dm_control's attach) refuse a model in which two elements of one kind share a name ("repeated
+    # name"); FlatModel.finalize() would silently keep the last one, and a FrameTask("ff_tip", "site") or a collision geom list
+    # would bind to the wrong hand (round-5 advisor finding: the same hand attached to both palms without prefixes)
+    for kind, names in (("body", [k.name for k in order]), ("joint", [j["name"] for j in J]), ("geom", [g["name"] for g in G]),
+                        ("site", [s["name"] for s in S]), ("key", [k for k, _ in keys])):
+        seen = set()
+        for n in names:
+            if n and n in seen:
+                raise ValueError(f"attach: repeated {kind} name '{n}' in the composed model — give the child a distinct `prefix`")
+            seen.add(n)
     njnt = len(J)
     qadr, dadr, nq, nv = [], [], 0, 0
     for j in J:
@@ -189,12 +201,18 @@ def attach(parent: FlatModel, child: FlatModel, site: Optional[str] = None, body
     The bodies below ``child``'s world body become children of the body that carries ``site`` (or of ``body``), their poses
     composed with the site's pose and with (``pos``, ``quat``) — the example moves the palm before attaching; geoms and sites
     of the child's world body move to that body too.  Names of the child get ``prefix`` (dm_control writes ``<model>/<name>``).
-    Keyframes: the parent's are kept, the child's joints take ``child_key`` of the child when given, else their qpos0.
+    Keyframes: the parent's are kept, the child's joints take ``child_key`` of the child when given, else their qpos0; the
+    child's own keyframes are dropped.  Two elements of one kind with the same name raise ValueError, as MuJoCo's compiler and
+    dm_control do ("repeated name"): attach the same child twice with two prefixes.
+    Difference from dm_control: ``site.attach`` wraps the child in an extra jointless frame body named after the child model;
+    here the child's top-level bodies hang directly under the body that carries the site, so ``nbody`` is one less per
+    attachment and body ids after the attachment point are shifted by one against the reference's compiled model — kinematics,
+    dofs, qpos layout and every named lookup (bodies, joints, sites, geoms) are the same.
     Returns a new FlatModel in MuJoCo's depth-first body order; neither argument is modified."""
     if (site is None) == (body is None):
         raise ValueError("attach: give exactly one of `site` and `body`")
     root = _tree(parent)
-    sub = _tree(child, prefix)
+    sub = _tree(child, prefix, "child")
     if site is not None:
         host = _find(root, lambda k: any(s["name"] == site for s in k.sites))
         if host is None:
@@ -224,12 +242,12 @@ def attach(parent: FlatModel, child: FlatModel, site: Optional[str] = None, body
         kq = child.key_qpos[child.name2id("key", child_key)]
         for j in range(child.njnt):
             a = int(child.jnt_qposadr[j])
-            ck[(id(child), j)] = kq[a:a + qpos_width(int(child.jnt_type[j]))].copy()
+            ck[("child", j)] = kq[a:a + qpos_width(int(child.jnt_type[j]))].copy()
     keys = []
     for i, kname in enumerate(parent.key_names):
         vals = dict(ck)
         for j in range(parent.njnt):
             a = int(parent.jnt_qposadr[j])
-            vals[(id(parent), j)] = parent.key_qpos[i][a:a + qpos_width(int(parent.jnt_type[j]))].copy()
+            vals[("parent", j)] = parent.key_qpos[i][a:a + qpos_width(int(parent.jnt_type[j]))].copy()
         keys.append((kname, vals))
     return _flatten(root, keys)

@@ -27,6 +27,19 @@ struct CvPre { int32_t n_cv; const int32_t* pair; const int32_t* chain_adr; cons
 }
 using namespace mkh;
 
+// Experiment switches (A/B runs, sweeps, phase censuses): environment variables MKH_DEBUG_* that change kernel selection, launch
+// shapes or caps.  They exist only in builds made with -DMKH_DEBUG_SWITCHES (MKH_EXTRA_FLAGS=-DMKH_DEBUG_SWITCHES python -m
+// mink_amd.csrc.build, normally under an MKH_BUILD_TAG): the product library never reads the environment, so a stray variable
+// cannot change a production handle's results or speed (round-5 review).  The four switches the parity tests and bench.py need
+// are per-handle diagnostic options of the ABI instead: mkh_problem_create_diag, MKH_DIAG_*.
+#if defined(MKH_CLOCKS) && !defined(MKH_DEBUG_SWITCHES)
+#define MKH_DEBUG_SWITCHES 1     // (a clock build is an experiment build: MKH_DEBUG_CLOCKS / MKH_DEBUG_PHASE_STOP drive its stamps)
+#endif
+#ifdef MKH_DEBUG_SWITCHES
+static inline const char* dbg_env(const char* name) { return getenv(name); }
+#else
+static inline const char* dbg_env(const char*) { return nullptr; }
+#endif
 static thread_local std::string g_err;
 static int32_t fail(int32_t code, const char* fmt, ...) {
   char buf[512];
@@ -147,6 +160,7 @@ struct MkhProblem {
   CollisionPairDev* d_pairs = nullptr;
   PairCull* d_cull = nullptr;          // bounding-sphere records of the pairs (problems with more than 64 of them)
   bool use_cull = false;
+  int32_t diag = 0;                // MKH_DIAG_* of mkh_problem_create_diag (parity / measurement switches of this handle)
   double *d_dense_cost = nullptr, *d_dense_wgain = nullptr;
   DeviceProblem* d_dev = nullptr;   // device copy of `dev` (the kernel reads the descriptor from memory)
   TapArgs* d_taps = nullptr;
@@ -547,7 +561,7 @@ static int32_t build_wide_problem(MkhProblem* p, const MkhModel* m, const MkhPro
   // more than a wavefront of pairs: bounding-sphere cull in front of the distance routines (wide_contacts; the candidate list —
   // 16-bit pair indices — lives in the three QP vectors behind o_rown, which are dead until the tableau is built)
   W.cull = nullptr;
-  if (W.n_pairs > kWave && W.n_pairs < 65536 && W.n_pairs <= 12 * ev(Ncap) && culls.size() == pairs.size() && !getenv("MKH_DEBUG_NO_CULL")) { MKH_UP(culls, cull) }
+  if (W.n_pairs > kWave && W.n_pairs < 65536 && W.n_pairs <= 12 * ev(Ncap) && culls.size() == pairs.size() && !(p->diag & MKH_DIAG_NO_PAIR_CULL)) { MKH_UP(culls, cull) }
 #undef MKH_UP
   if (e != hipSuccess) return fail(MKH_E_HIP, "wide problem upload: %s", hipGetErrorString(e));
   int o = 0;
@@ -852,8 +866,14 @@ static void fill_base(const MkhModel* m, DeviceProblem& P) {
 }
 
 int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_batch, MkhProblem** out) {
+  return mkh_problem_create_diag(m, d, max_batch, 0, out);
+}
+
+int32_t mkh_problem_create_diag(MkhModel* m, const MkhProblemDesc* d, int32_t max_batch, int32_t diag, MkhProblem** out) {
   if (!m || !d || !out) return fail(MKH_E_INVALID, "null argument");
   *out = nullptr;
+  if (diag & ~(MKH_DIAG_NO_WIDE_REDO | MKH_DIAG_NO_TIGHT_REDO | MKH_DIAG_NO_COLD_REFINE | MKH_DIAG_NO_PAIR_CULL))
+    return fail(MKH_E_INVALID, "unknown MKH_DIAG_* bits 0x%x", diag);
   if (max_batch < 1) return fail(MKH_E_INVALID, "max_batch must be >= 1");
   if (d->n_frame_tasks > kMaxFrameTasks) return fail(MKH_E_LIMIT, "at most %d frame tasks", kMaxFrameTasks);
   if (d->n_posture_tasks > kMaxPostureTasks) return fail(MKH_E_LIMIT, "at most %d posture tasks", kMaxPostureTasks);
@@ -868,6 +888,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   p->model = m;
   p->device = m->device;
   p->max_batch = max_batch;
+  p->diag = diag;
   DeviceProblem& P = p->dev;
   fill_base(m, P);
   P.n_frame = d->n_frame_tasks; P.n_posture = d->n_posture_tasks; P.n_com = d->n_com_tasks;
@@ -1088,12 +1109,12 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   {
     const int want = P.n_pairs + P.n_dense_limit_rows;          // half-space rows that can be active at once
     P.max_rows = want < (kWave - m->nv) ? want : (kWave - m->nv);
-    if (const char* cap = getenv("MKH_DEBUG_MAX_ROWS")) { const int c = atoi(cap); if (c > 0 && c < P.max_rows) P.max_rows = c; }   // (experiments)
+    if (const char* cap = dbg_env("MKH_DEBUG_MAX_ROWS")) { const int c = atoi(cap); if (c > 0 && c < P.max_rows) P.max_rows = c; }   // (experiments)
     // LDS behind the per-problem ranges: h of every pair when pairs outnumber rows (row selection), then the expanding polytope's
     // workspace when some pair goes through the general convex routine (collision_phase: the same two terms)
     P.n_hsel = (P.n_pairs > P.max_rows ? lds_even(P.n_pairs) : 0) + (p->convex_pairs ? (kEpaWsDoubles > kGjkWsDoubles ? kEpaWsDoubles : kGjkWsDoubles) : 0);
     // the cull pass's candidate list (16-bit pair indices) when the pairs do not fit one trip of the wavefront
-    p->use_cull = P.n_pairs > kWave && P.n_pairs < 65536 && !p->simple_pairs && !getenv("MKH_DEBUG_NO_CULL");
+    p->use_cull = P.n_pairs > kWave && P.n_pairs < 65536 && !p->simple_pairs && !(p->diag & MKH_DIAG_NO_PAIR_CULL);
     if (p->use_cull) P.n_hsel += lds_even((P.n_pairs + 3) / 4);
   }
   const int ntab = m->nv + P.max_rows;
@@ -1176,7 +1197,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     // low-rank start wins by 1.15-1.38 x up to rows = dofs; the large one (> kMu rows) loses beyond three quarters
     // (Shadow 21 / 24: 0.57 x, H1 24 / 25: 0.93 x) and keeps the old margin.
     const bool pays = 2 * P.n_jrows <= m->nv || (m->nv >= 32 && 4 * P.n_jrows <= 3 * m->nv) ||
-                      (!big && m->nv >= 16 && P.n_jrows <= m->nv) || getenv("MKH_DEBUG_WOOD_ALWAYS");
+                      (!big && m->nv >= 16 && P.n_jrows <= m->nv) || dbg_env("MKH_DEBUG_WOOD_ALWAYS");
     if (cand && pays) { p->wood_nt = cand; p->wood_nr = cand; }
     if (p->wood_nt) {
       p->wood_big = P.n_jrows > kMu || p->wood_nr + P.n_jrows > kWave;
@@ -1189,7 +1210,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       // 2-waves map: the plain layout, or — when that would cost a resident wave and the pair lanes need one pass only (the
       // compact layout lets the Jacobian rows overwrite the task blocks) — the compact one
       P.wood_compact = 0; P.prefetch_wc = 0;
-      P.wood_refine = getenv("MKH_DEBUG_NO_REFINE") ? 0 : 1;
+      P.wood_refine = (p->diag & MKH_DIAG_NO_COLD_REFINE) ? 0 : 1;
       {
         auto bytes = [&](bool pre, bool compact) { return lds_wood(pre, compact).total * (int)sizeof(double); };
         if (waves_per_cu(p->wood_nt, bytes(false, false)) < waves_per_cu(p->wood_nt, 1) && P.n_jrows > 0) {
@@ -1250,7 +1271,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
       // ... and the F_COM builds of a humanoid-size robot (ComTask rows and / or up to 24 task rows: `44_36_r44_w3`, round 5).
       // Their 25 rows of Jh take 8.8 KB of the compact layout — 15.4 KB for the G1 full example, 10 wavefronts per CU instead
       // of 8 — so the bar is "more resident wavefronts than the two-waves map", not all twelve.
-      static const bool no_com_w3 = getenv("MKH_DEBUG_NO_COM_W3") != nullptr;       // (A/B switch)
+      static const bool no_com_w3 = dbg_env("MKH_DEBUG_NO_COM_W3") != nullptr;       // (A/B switch)
       if (!no_com_w3 && p->wood_nt == 44 && P.n_jpairs <= kWave && (P.n_com > 0 || p->wood_big)) {
         const int two = waves_per_cu(p->wood_nt, 1, false);     // 8
         const int w = waves_per_cu(p->wood_nt, lds_wood(false, true, true).total * (int)sizeof(double), true);
@@ -1279,7 +1300,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
     const int small_cls = build_lane_problem(m, d, P, ft, pcost, clo, chi, vlim, p->has_relative, lp);
     p->lane_nv = small_cls <= 8 ? small_cls : 0;
     p->quad_nt = small_cls ? (small_cls <= 8 ? 8 : (small_cls == 32 ? 32 : 16)) : 0;
-    if (getenv("MKH_DEBUG_NO_PAIR_ROWS") && p->quad_nt == 32) p->quad_nt = 0;   // (A/B switch: 17 … 32-dof robots back on the wavefront kernel)
+    if (dbg_env("MKH_DEBUG_NO_PAIR_ROWS") && p->quad_nt == 32) p->quad_nt = 0;   // (A/B switch: 17 … 32-dof robots back on the wavefront kernel)
     if (small_cls) {
       p->lane_lds = lane_lds_bytes(lp.nlink);
       bool ident = true;
@@ -1301,14 +1322,14 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   {
     const DeviceProblem& P0 = p->dev;
     const int cap = 48 - m->nv;
-    static const bool no_tight = getenv("MKH_DEBUG_NO_TIGHT_ROWS") != nullptr;      // (A/B of this path)
+    static const bool no_tight = dbg_env("MKH_DEBUG_NO_TIGHT_ROWS") != nullptr;      // (A/B of this path)
     // Round 5: the same for pair sets with boxes, cylinders, ... (the analytic collision build) — a humanoid-size robot reserves
     // 64 − nv rows, which costs the 64-row build a resident wavefront or two in LDS: G1 with 46 pairs (21 rows, 24.6 KB: 6
     // wavefronts per CU) 0.757 → ≈ 0.60 ms with 5 rows on the 48-row build.  Few contacts are in range at a time when
     // collision avoidance works; when many are, the cost is the two launches (MKH_FLAG_FULL_ROWS pins the full-row build).
     //  Humanoid-size robots only (32 dofs and up): ALOHA (16 dofs, 48 rows reserved, 1 104 pairs) measures 2.26 → 2.53 ms this
     //  way — its full build is not short of wavefronts, and the instances that overflow 32 rows walk the pair list twice.
-    const bool generic = !p->simple_pairs && !p->convex_pairs && P0.n_pairs > 0 && m->nv >= 32 && cap >= 4 && !getenv("MKH_DEBUG_NO_TIGHT_GENERIC");
+    const bool generic = !p->simple_pairs && !p->convex_pairs && P0.n_pairs > 0 && m->nv >= 32 && cap >= 4 && !dbg_env("MKH_DEBUG_NO_TIGHT_GENERIC");
     if (!no_tight && (p->simple_pairs ? cap >= 16 : generic) && P0.n_dense_limit_rows == 0 && P0.n_dense_rows == 0 && !P0.dense_box && p->nt == 64 &&
         P0.n_pairs > cap) {
       DeviceProblem T = P0;
@@ -1337,7 +1358,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   // More rows can be active at once than the 64 − nv the wavefront kernels hold (the reference stacks them all:
   // mink/solve_ik.py:25-40): the instances a launch flags MKH_ST_ROW_OVERFLOW are solved again by the workgroup-per-problem
   // kernel with every row (launch(): the redo launch behind plain solves)
-  const bool no_wide = getenv("MKH_DEBUG_NO_WIDE") != nullptr;                 // (tests: what the wavefront kernel alone leaves flagged; read per handle)
+  const bool no_wide = (p->diag & MKH_DIAG_NO_WIDE_REDO) != 0;                  // (tests: what the wavefront kernel alone leaves flagged)
   // (round 5: EVERY problem with half-space rows gets this twin — its dense Goldfarb–Idnani iteration also re-solves the instances
   //  whose active rows are almost dependent, wherever they occur)
   if (!no_wide && P.n_pairs + P.n_dense_limit_rows > 0) {
@@ -1346,7 +1367,7 @@ int32_t mkh_problem_create(MkhModel* m, const MkhProblemDesc* d, int32_t max_bat
   }
   // The two-kernel split of general convex pairs (convex_pre.hip): per convex pair the chains root → body of its two geoms, and
   // the buffer of pre-evaluated contacts the analytic build reads.  It uses the plain model arrays of the twin above.
-  static const bool no_split = getenv("MKH_DEBUG_NO_CONVEX_SPLIT") != nullptr;      // (A/B: the in-kernel routine, round 4's path)
+  static const bool no_split = dbg_env("MKH_DEBUG_NO_CONVEX_SPLIT") != nullptr;      // (A/B: the in-kernel routine, round 4's path)
   if (p->d_wide && n_cv > 0 && !no_split) {
     std::vector<int32_t> cv_pair, adr{0}, chain;
     for (size_t k = 0; k < pairs.size(); ++k) {
@@ -1422,8 +1443,8 @@ static int lds_for_nt(const MkhProblem* p, int nt) {
 // the wavefronts has not drifted apart yet, and a ticket tail only adds its own ragged last round.  Round 1's threshold was 4.
 constexpr int kMinRoundsForTickets = 8;
 static int static_rounds_for(int per_wave, bool uneven, bool loops = false) {
-  static const bool static78 = getenv("MKH_DEBUG_STATIC_78") != nullptr;
-  static const int dbg_16ths = getenv("MKH_DEBUG_STATIC_16THS") ? atoi(getenv("MKH_DEBUG_STATIC_16THS")) : -1;
+  static const bool static78 = dbg_env("MKH_DEBUG_STATIC_78") != nullptr;
+  static const int dbg_16ths = dbg_env("MKH_DEBUG_STATIC_16THS") ? atoi(dbg_env("MKH_DEBUG_STATIC_16THS")) : -1;
   if (dbg_16ths >= 0 && dbg_16ths <= 16) return (per_wave * dbg_16ths) / 16;
   if (dbg_16ths == 99) return INT32_MAX;                     // (no ticket counter at all: one strided share per wavefront)
   if (static78) return (per_wave * 7) / 8;
@@ -1438,7 +1459,7 @@ static int static_rounds_for(int per_wave, bool uneven, bool loops = false) {
 static int grid_for_variant(const MkhProblem* p, int B, int nt, int lds, bool w3 = false) {
   int wpc = waves_per_cu(nt, lds, w3);
   // diagnostic: cap the resident waves per CU (occupancy experiments, docs/HISTORY.md §7b); never raises it
-  static const int dbg = getenv("MKH_DEBUG_WAVES_PER_CU") ? atoi(getenv("MKH_DEBUG_WAVES_PER_CU")) : 0;
+  static const int dbg = dbg_env("MKH_DEBUG_WAVES_PER_CU") ? atoi(dbg_env("MKH_DEBUG_WAVES_PER_CU")) : 0;
   if (dbg > 0 && dbg < wpc) wpc = dbg;
   int g = p->model->num_cus * wpc;
   return B < g ? B : g;
@@ -1458,7 +1479,7 @@ int32_t mkh_problem_launch_info(const MkhProblem* p, int32_t B, int32_t* grid, i
 
 // Experiment builds with -DMKH_CLOCKS (tools/phase_clocks.py): MKH_DEBUG_CLOCKS=<file> makes every launch of this process
 // synchronous and writes its (B, 24) cycle stamps to <file> — phase profile of kernels that cannot be tapped
-static const char* clk_path() { static const char* const s = getenv("MKH_DEBUG_CLOCKS"); return s; }
+static const char* clk_path() { static const char* const s = dbg_env("MKH_DEBUG_CLOCKS"); return s; }
 static hipError_t clk_begin(MkhProblem* p, SolveArgs& a, hipStream_t stream) {
   if (!clk_path()) return hipSuccess;
   if (!p->d_clk)
@@ -1466,7 +1487,7 @@ static hipError_t clk_begin(MkhProblem* p, SolveArgs& a, hipStream_t stream) {
   a.clk = p->d_clk;
   if (hipError_t e = hipMemsetAsync(p->d_clk, 0, (size_t)a.B * 24 * sizeof(long long), stream)) return e;
   // MKH_DEBUG_PHASE_STOP=k (tools/phase_census.sh): slot 15 of every row = the phase boundary after which the kernel abandons the solve
-  static const int stop = getenv("MKH_DEBUG_PHASE_STOP") ? atoi(getenv("MKH_DEBUG_PHASE_STOP")) : 0;
+  static const int stop = dbg_env("MKH_DEBUG_PHASE_STOP") ? atoi(dbg_env("MKH_DEBUG_PHASE_STOP")) : 0;
   if (stop) {
     std::vector<long long> h((size_t)a.B, (long long)stop);
     if (hipError_t e = hipMemcpy2DAsync(p->d_clk + 15, 24 * sizeof(long long), h.data(), sizeof(long long), sizeof(long long), (size_t)a.B,
@@ -1513,7 +1534,9 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   // the duration of the call (q_out may alias q) — a device-to-device copy of B·nq doubles in front of the launch
   const bool wide_redo = p->d_wide && a.do_qp && a.status_out && !(taps && taps->t_cycles);
   const double* q_redo = a.q;
-  if (wide_redo && a.q_out) {
+  // (only when q_out really aliases q: otherwise the redo reads the caller's q, which the first launch did not touch — the copy
+  //  was a latency cost of every small-batch control loop with collision limits, round-5 advisor finding)
+  if (wide_redo && a.q_out && a.q_out == a.q) {
     HIP_OK(ensure(&p->d_qkeep, (size_t)p->max_batch * p->dev.nq));
     HIP_OK(hipMemcpyAsync(p->d_qkeep, a.q, (size_t)a.B * p->dev.nq * sizeof(double), hipMemcpyDefault, stream));
     q_redo = p->d_qkeep;
@@ -1603,7 +1626,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   // Measured (UR5e + 2 collision rows, 4 096 instances): analytic pairs 0.060 ms on 32 rows, 0.049 on 16 and on 8; with a
   // cylinder–box pair on the general convex routine (round 4: simplex in LDS, 143 VGPRs) 0.186 ms on 32 rows, 0.156 on 16
   // and on 24 — round 3's register-resident GJK (196 VGPRs) wanted the 2-waves file and kept 32 rows.
-  static const int dbg_min = getenv("MKH_DEBUG_CALLS_NT") ? atoi(getenv("MKH_DEBUG_CALLS_NT")) : 0;
+  static const int dbg_min = dbg_env("MKH_DEBUG_CALLS_NT") ? atoi(dbg_env("MKH_DEBUG_CALLS_NT")) : 0;
   const int calls_nt_min = dbg_min ? dbg_min : 16;
   const bool calls = feat == F_COLL || feat == (F_ALL & ~F_TAPS) || feat == (F_COLL | F_CONVEX_COLL);
   if (calls && p->nt < 32) {
@@ -1637,7 +1660,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   // tight rows first (see mkh_problem_create): plain solves on the capsule-only collision build whose caller takes the status
   const bool tight = p->d_dev_tight && (feat == (F_COLL | F_SIMPLE_COLL) || feat == F_COLL) && !nr && !w3 && a.do_qp && a.status_out && !taps &&
                      !(flags & MKH_FLAG_FULL_ROWS);
-  static const bool no_redo = getenv("MKH_DEBUG_NO_REDO") != nullptr;       // (tests: what the tight launch alone leaves flagged)
+  const bool no_redo = (p->diag & MKH_DIAG_NO_TIGHT_REDO) != 0;              // (tests: what the tight launch alone leaves flagged)
   if (tight && no_redo) {
     const int gt = grid_for_variant(p, a.B, p->nt_tight, p->lds_tight, false);
     SolveArgs at = a;
@@ -1670,7 +1693,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   // example's 25.6 rounds (1.244 / 1.265; at 16 384 instances 0.392 / 0.349).  Two, three, four problems per workgroup lie
   // between the two shapes (65 536: 0.739 / 0.772 / 0.766).  The XCD still owns one contiguous row range
   // (workgroup g: XCD g % 8, row g / 8 of its range).  MKH_DEBUG_PERSISTENT=1: persistent wavefronts everywhere (A/B).
-  static const bool persistent_only = getenv("MKH_DEBUG_PERSISTENT") != nullptr;
+  static const bool persistent_only = dbg_env("MKH_DEBUG_PERSISTENT") != nullptr;
   // (fused loops, measured: no difference — 13.55 / 13.58 ms for the headline's 20-step loop, converged targets 5.64 / 5.58 M/s — they stay persistent)
   if (!persistent_only && !tight && w3 && nt == 44 && a.n_steps <= 1 && a.B > grid && 2 * (long long)a.B >= 7LL * grid && a.B <= 22 * grid)
     grid = a.B;
@@ -1864,7 +1887,7 @@ static int32_t run(MkhProblem* p, int32_t B, const double* q, const double* fram
   // Only where the copies are worth overlapping (≥ 32 MB staged: tools/bench_host_path.py — G1 at 65 536 instances
   // 2.02 → 1.72 ms per call, the G1 full example 2.79 → 2.19 ms; a 65 536-instance UR5e call moves 10 MB around a 0.08 ms
   // kernel and LOSES 0.15 ms to the events and the three extra launches).
-  static const bool no_chunks = getenv("MKH_DEBUG_NO_CHUNKS") != nullptr;      // (A/B of this path)
+  static const bool no_chunks = dbg_env("MKH_DEBUG_NO_CHUNKS") != nullptr;      // (A/B of this path)
   const size_t staged_bytes = (size_t)B * sizeof(double) *
       (nq + (size_t)P.n_frame * 7 + nv + (pbat ? (size_t)P.n_posture * nq : 0) + (cbat ? (size_t)P.n_com * 3 : 0) + (q_out ? nq : 0));
   const int n_chunks = (!no_chunks && !taps && !Kd && !Md && !Bd && v_out && B >= 2 * 8192 && staged_bytes >= ((size_t)32 << 20))

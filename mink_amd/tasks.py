@@ -5,6 +5,7 @@ mink/tasks/{task,frame_task,posture_task,com_task,damping_task}.py; targets may 
 from __future__ import annotations
 
 import abc
+import threading
 from typing import NamedTuple, Optional
 
 import numpy as np
@@ -81,6 +82,22 @@ def objective_to_rows(H: np.ndarray, c: np.ndarray, name: str = "task"):
     return np.ascontiguousarray(e), np.ascontiguousarray(J)
 
 
+# Re-entrancy marks of Task._eval / compute_qp_objective ("evaluate THIS instance through its rows" / "through the built-in
+# descriptor"), per THREAD: as instance attributes two threads sharing a task object (distributed workers) could pair an nv-row
+# descriptor with k-row data (round-5 advisor finding).
+_marks = threading.local()
+
+
+def _mark(kind: str, obj, delta: int = 0) -> int:
+    d = _marks.__dict__.setdefault(kind, {})
+    n = d.get(id(obj), 0) + delta
+    if n:
+        d[id(obj)] = n
+    else:
+        d.pop(id(obj), None)
+    return n
+
+
 class Task(abc.ABC):
     """mink/tasks/task.py:25-138."""
 
@@ -110,7 +127,7 @@ class Task(abc.ABC):
     def _objective_overridden(self) -> bool:
         """Does the (H, c) of this task come from a `compute_qp_objective` override?  Not while the base-class method itself is
         being evaluated for this instance (an override that calls `super().compute_qp_objective(configuration)`)."""
-        if getattr(self, "_rows_only", 0):
+        if _mark("rows_only", self):
             return False
         return type(self).compute_qp_objective is not self._builtin_class().compute_qp_objective
 
@@ -127,7 +144,7 @@ class Task(abc.ABC):
 
     def _fp_common(self):
         return (id(self), np.asarray(self.cost, dtype=np.float64).tobytes(), float(self.gain), float(self.lm_damping),
-                getattr(self, "_force_builtin", 0))
+                _mark("force_builtin", self))
 
     _PLUGIN_METHODS = ("compute_error", "compute_jacobian", "compute_qp_objective")
 
@@ -144,7 +161,7 @@ class Task(abc.ABC):
         built-in task that overrides ANY of compute_error / compute_jacobian / compute_qp_objective: the reference calls
         those through the instance (mink/solve_ik.py:13-22 → tasks/task.py:105-138), so an override must change the
         answer here too — the built-in device descriptor would silently ignore it."""
-        if getattr(self, "_force_builtin", 0):
+        if _mark("force_builtin", self):
             return False
         cls = type(self)
         hit = _DENSE_BY_CLASS.get(cls)
@@ -193,7 +210,7 @@ class Task(abc.ABC):
         from .solve_ik import _compile, _dense_inputs, _gather_targets, _pin
         force = builtin and self._builtin_class() is not Task
         if force:
-            self._force_builtin = getattr(self, "_force_builtin", 0) + 1
+            _mark("force_builtin", self, +1)
         try:
             prob, layout = _compile(configuration, [self], limits=[], batch=configuration.batch_size)
             ft, pt, ct = _gather_targets(configuration, layout)
@@ -202,13 +219,23 @@ class Task(abc.ABC):
                                        dense=_dense_inputs(configuration, layout, 1.0))
         finally:
             if force:
-                self._force_builtin -= 1
+                _mark("force_builtin", self, -1)
         return out
 
+    def _no_rows_of_an_objective(self, what: str) -> None:
+        # a task written from scratch that only overrides compute_qp_objective has no (e, J) of its own: the rows the device
+        # sees are a factorisation of its (H, c) (objective_to_rows, possibly with a synthetic row of norm 1e10·‖c_n‖), not an
+        # error or a Jacobian in mink's sense (round-5 advisor finding: they used to be returned)
+        if self._builtin_class() is Task and self._objective_overridden():
+            raise TaskDefinitionError(f"{type(self).__name__} defines its objective through compute_qp_objective only: it has no "
+                                      f"{what} (implement compute_error and compute_jacobian to get one)")
+
     def compute_error(self, configuration: Configuration) -> np.ndarray:
+        self._no_rows_of_an_objective("compute_error")
         return configuration._unbatch(self._eval(configuration, ["task_e"], builtin=True)["task_e"])
 
     def compute_jacobian(self, configuration: Configuration) -> np.ndarray:
+        self._no_rows_of_an_objective("compute_jacobian")
         return configuration._unbatch(self._eval(configuration, ["task_J"], builtin=True)["task_J"])
 
     def compute_qp_objective(self, configuration: Configuration) -> Objective:
@@ -216,11 +243,11 @@ class Task(abc.ABC):
         # super(): the rows are then the instance's compute_error / compute_jacobian, not the override's own (H, c)
         base, cls = self._builtin_class(), type(self)
         own_rows = base is Task or cls.compute_error is not base.compute_error or cls.compute_jacobian is not base.compute_jacobian
-        self._rows_only = getattr(self, "_rows_only", 0) + 1
+        _mark("rows_only", self, +1)
         try:
             out = self._eval(configuration, ["H", "c"], builtin=not own_rows)   # damping = 0 ⇒ exactly this task's (H, c)
         finally:
-            self._rows_only -= 1
+            _mark("rows_only", self, -1)
         return Objective(configuration._unbatch(out["H"]), configuration._unbatch(out["c"]))
 
 

@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 def test_version_and_struct_layout(lib):
     from mink_amd import _native as nat
-    assert lib.mkh_version() == 107
+    assert lib.mkh_version() == 108
     # ctypes mirrors must match the C layout the library was compiled with
     assert ctypes.sizeof(nat.MkhFrameTaskDesc) == 8 + 6 * 8 + 16 + 8
     assert ctypes.sizeof(nat.MkhComTaskDesc) == 3 * 8 + 16
@@ -53,6 +53,25 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip")):
                 src = open(os.path.join(root, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+
+
+def test_product_library_reads_no_debug_environment(lib):
+    """Round-5 review: MKH_DEBUG_* environment variables changed kernel selection, row caps and the redo launches of production
+    handles.  They are compiled out of the product build (minkhip.hip dbg_env: -DMKH_DEBUG_SWITCHES experiment builds only): no
+    such name is left in the shipped binary, and neither bench.py nor a test sets one — the four switches tests and bench need
+    are per-handle options of the ABI (mkh_problem_create_diag)."""
+    from mink_amd import _native as nat
+    blob = open(nat._LIB_PATH, "rb").read()
+    assert b"MKH_DEBUG_" not in blob
+    for root in (os.path.join(REPO, "tests"), REPO):
+        for f in os.listdir(root):
+            if f.endswith(".py") and f != "test_abi.py":
+                assert "MKH_DEBUG_" not in open(os.path.join(root, f)).read(), f
+    assert nat.DIAG_NO_WIDE_REDO | nat.DIAG_NO_TIGHT_REDO | nat.DIAG_NO_COLD_REFINE | nat.DIAG_NO_PAIR_CULL == 15
+    hdr = open(os.path.join(REPO, "include", "minkhip.h")).read()
+    for name, bit in (("NO_WIDE_REDO", 1), ("NO_TIGHT_REDO", 2), ("NO_COLD_REFINE", 4), ("NO_PAIR_CULL", 8)):
+        assert re.search(r"#define MKH_DIAG_%s %d\b" % (name, bit), hdr), name
+        assert getattr(nat, "DIAG_" + name) == bit
 
 
 def test_compiler_stays_below_the_vgpr_cap(lib):

@@ -5,6 +5,7 @@ out as ONE nested MJCF, and against the numpy oracle's kinematics."""
 import json
 
 import numpy as np
+import pytest
 
 from mink_amd import compose, mjcf
 from oracle import ik as oik
@@ -113,3 +114,36 @@ def _is_below(m, c, b):
     while c > 0 and c != b:
         c = int(m.body_parentid[c])
     return c == b
+
+
+def test_attach_refuses_repeated_names():
+    """MuJoCo's compiler and dm_control raise "repeated name" when two bodies / joints / sites / geoms of a composed model share a
+    name; FlatModel.finalize() alone would keep the last entry and a FrameTask or a collision geom list would silently bind to the
+    wrong copy (round-5 advisor finding: the same hand on both palms of the G1 without prefixes)."""
+    from mink_amd import workloads
+    from mink_amd.compose import attach
+    hand = workloads.load_robot("allegro_left")
+    m = attach(workloads.load_robot("g1"), hand, site="left_palm", pos=(0.0, 0.0, 0.02))
+    with pytest.raises(ValueError, match="repeated .* name .*prefix"):
+        attach(m, hand, site="right_palm", pos=(0.0, 0.0, 0.02))
+    ok = attach(m, hand, site="right_palm", prefix="rh/", pos=(0.0, 0.0, 0.02))
+    assert len(set(n for n in ok.body_names if n)) == len([n for n in ok.body_names if n])
+
+
+def test_attach_a_model_to_itself_keeps_the_two_copies_apart():
+    """attach(m, m, ...): joints and meshes are keyed by which ARGUMENT they come from, not by id(model) — the parent's keyframe
+    values stay on the parent's joints, the child's joints take `child_key` (or their qpos0)."""
+    arm = mjcf.loads_mjcf(ARM)
+    home = arm.key_qpos[arm.name2id("key", "home")]
+    assert np.abs(home - arm.qpos0).min() > 0.01
+    two = compose.attach(arm, arm, site="tool", prefix="b/")
+    assert (two.nv, two.nq, two.nbody) == (2 * arm.nv, 2 * arm.nq, 2 * arm.nbody - 1)
+    k = two.key_qpos[two.name2id("key", "home")]
+    first = [int(two.jnt_qposadr[two.name2id("joint", n)]) for n in arm.jnt_names]
+    second = [int(two.jnt_qposadr[two.name2id("joint", "b/" + n)]) for n in arm.jnt_names]
+    np.testing.assert_array_equal(k[first], home)
+    np.testing.assert_array_equal(k[second], arm.qpos0)                # (no child_key: the child's joints keep their qpos0)
+    two_k = compose.attach(arm, arm, site="tool", prefix="b/", child_key="home")
+    k2 = two_k.key_qpos[two_k.name2id("key", "home")]
+    np.testing.assert_array_equal(k2[first], home)
+    np.testing.assert_array_equal(k2[second], home)

@@ -223,13 +223,9 @@ def test_more_contacts_than_tableau_rows_keeps_the_tightest():
     prob1 = nat.NativeProblem(nm, frame_tasks=fts, max_batch=B)
     tg_far = prob1.solve(far, dummy, None, None, 1.0, 1.0, taps=["frame_pose"], solve_qp=False)[2]["frame_pose"]
     prob1.close()
-    # the wavefront kernel by itself (MKH_DEBUG_NO_WIDE, read when a handle is created): what round 2 / 3 returned
-    os.environ["MKH_DEBUG_NO_WIDE"] = "1"
-    try:
-        prob_nw = nat.NativeProblem(nm, frame_tasks=fts, posture_tasks=[{"cost": 1e-2}], configuration_limits=[nc._cfg_limit(m)],
-                                    collision_limits=[col._native_desc()[1]], max_batch=B)
-    finally:
-        del os.environ["MKH_DEBUG_NO_WIDE"]
+    # the wavefront kernel by itself (a handle created with MKH_DIAG_NO_WIDE_REDO): what round 2 / 3 returned
+    prob_nw = nat.NativeProblem(nm, frame_tasks=fts, posture_tasks=[{"cost": 1e-2}], configuration_limits=[nc._cfg_limit(m)],
+                                collision_limits=[col._native_desc()[1]], max_batch=B, diag=nat.DIAG_NO_WIDE_REDO)
     for regime, tgr, dt in (("near", tg, dt), ("far", tg_far, 8 * dt)):   # (h ∝ 1/dt: the long step shrinks every slack)
         v_nw, st = prob_nw.solve(q, tgr, m.qpos0[None, :], None, dt, damping)
         assert not prob_nw.last_kernel().endswith("+wide")
@@ -498,7 +494,7 @@ def test_tight_rows_then_redo_equals_full_rows():
     launch on the 48-row build first — the tightest contacts get the rows, dropped ones are checked at the solution — and the
     full-row build then re-solves the instances that launch flagged (SolveArgs::redo_mask).  Status and v equal the full-row
     solve's (MKH_FLAG_FULL_ROWS), in a regime where the tight launch alone leaves instances flagged (counted in a subprocess
-    with MKH_DEBUG_NO_REDO) and in the benchmark's own."""
+    on a handle created with MKH_DIAG_NO_TIGHT_REDO) and in the benchmark's own."""
     import subprocess
     import sys
     from mink_amd import _native as nat, workloads
@@ -518,7 +514,7 @@ col = mink.CollisionAvoidanceLimit(m, pairs, collision_detection_distance=0.5, m
 fts = [nc._ft(m, f, "site", 1.0, 0.0, 1.0) for f in fingers]
 B = 1024
 prob = nat.NativeProblem(nm, frame_tasks=fts, posture_tasks=[{"cost": 1e-2}], configuration_limits=[nc._cfg_limit(m)],
-                         collision_limits=[col._native_desc()[1]], max_batch=B)
+                         collision_limits=[col._native_desc()[1]], max_batch=B, diag=nat.DIAG_NO_TIGHT_REDO)
 rng = np.random.default_rng(5)
 p0 = nat.NativeProblem(nm, frame_tasks=fts, max_batch=8192)
 qp, _ = workloads.make_batch(m, nm, p0, rng, 8192, base_q=m.qpos0, sigma=0.3)
@@ -537,8 +533,7 @@ print("KERNEL", prob.last_kernel(), "FLAGGED", int(((st & 16) != 0).sum()))
     import tempfile
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "batch.npz")
-        env = dict(os.environ, MKH_DEBUG_NO_REDO="1")
-        out = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=300)
+        out = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("KERNEL")][0].split()
         assert line[1] == "ik_solve_kernel_48_72", line
@@ -557,13 +552,9 @@ print("KERNEL", prob.last_kernel(), "FLAGGED", int(((st & 16) != 0).sum()))
     prob = nat.NativeProblem(nm, frame_tasks=fts, posture_tasks=[{"cost": 1e-2}], configuration_limits=[nc._cfg_limit(m)],
                              collision_limits=[col._native_desc()[1]], max_batch=B)
     # (50 pairs against 40 rows: behind either launch sequence the workgroup-per-problem kernel re-solves what is still flagged;
-    #  MKH_DEBUG_NO_WIDE keeps this test on the two wavefront paths it compares)
-    os.environ["MKH_DEBUG_NO_WIDE"] = "1"
-    try:
-        prob = nat.NativeProblem(nm, frame_tasks=fts, posture_tasks=[{"cost": 1e-2}], configuration_limits=[nc._cfg_limit(m)],
-                                 collision_limits=[col._native_desc()[1]], max_batch=B)
-    finally:
-        del os.environ["MKH_DEBUG_NO_WIDE"]
+    #  MKH_DIAG_NO_WIDE_REDO keeps this test on the two wavefront paths it compares)
+    prob = nat.NativeProblem(nm, frame_tasks=fts, posture_tasks=[{"cost": 1e-2}], configuration_limits=[nc._cfg_limit(m)],
+                             collision_limits=[col._native_desc()[1]], max_batch=B, diag=nat.DIAG_NO_WIDE_REDO)
     v, st = prob.solve(q, tgf, m.qpos0[None, :], None, 2.0, 1e-5)
     assert prob.last_kernel().removesuffix("+wide") == "ik_solve_kernel_48_72+redo_64", prob.last_kernel()
     vf, stf = prob.solve(q, tgf, m.qpos0[None, :], None, 2.0, 1e-5, full_rows=True)

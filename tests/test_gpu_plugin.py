@@ -319,6 +319,22 @@ def test_compute_qp_objective_overrides():
     with pytest.raises(mink.TaskDefinitionError, match="must return H"):
         mink.solve_ik(cfg, [builtin, RawObjective(np.eye(nv + 1), np.zeros(nv)), post], 2e-3, "mi355x", 1e-3, limits=lims)
 
+    # a from-scratch task that defines ONLY its objective has no error / Jacobian to report (the rows the device folds in are a
+    # factorisation of (H, c), not mink's (e, J)): asking for them raises instead of returning those rows (round-5 advisor finding)
+    class OnlyObjective(mink.Task):
+        def __init__(self):
+            super().__init__(cost=np.zeros(1))
+
+        def compute_qp_objective(self, configuration):
+            return mink.Objective(np.eye(nv), np.ones(nv))
+
+    only = OnlyObjective()
+    for method in (only.compute_error, only.compute_jacobian):
+        with pytest.raises(mink.TaskDefinitionError, match="compute_qp_objective only"):
+            method(cfg)
+    v_only = mink.solve_ik(cfg, [builtin, only, post], 2e-3, "mi355x", 1e-3, limits=lims)
+    assert np.isfinite(v_only).all()
+
 
 def test_user_box_rows_on_g1_do_not_use_tableau_rows():
     """A caller-defined limit [I; −I] on G1 is 74 rows against 64 − 43 = 21 half-space rows per wavefront (round-2 advisor

@@ -285,7 +285,7 @@ def test_low_rank_start_with_com_rows_and_many_task_rows():
 
 def test_cold_start_refinement_agrees_with_the_plain_low_rank_start(monkeypatch):
     """the lean 44-row build re-factorises for the bounds the unconstrained minimiser violates before the
-    tableau exists.  Same optimum with the pass switched off (MKH_DEBUG_NO_REFINE, read when the handle is created), on
+    tableau exists.  Same optimum with the pass switched off (a handle created with MKH_DIAG_NO_COLD_REFINE), on
     ordinary problems, on heavily saturated ones (dt × 8: most dofs end on a velocity bound) and on instances that start ON
     their joint limits (bounds of exactly 0: the violated set is decided by rounding); C oracle on a sample."""
     from mink_amd import _native as nat
@@ -295,9 +295,9 @@ def test_cold_start_refinement_agrees_with_the_plain_low_rank_start(monkeypatch)
     nm = nat.NativeModel(model)
     B = 4096
     prob, dt, damping = nc.build("g1_c3", nm, B)
-    monkeypatch.setenv("MKH_DEBUG_NO_REFINE", "1")
-    plain, _, _ = nc.build("g1_c3", nm, B)
-    monkeypatch.delenv("MKH_DEBUG_NO_REFINE")
+    with nat.diag_options(nat.DIAG_NO_COLD_REFINE):
+        plain, _, _ = nc.build("g1_c3", nm, B)
+    assert plain.diag == nat.DIAG_NO_COLD_REFINE and prob.diag == 0
     stand = model.key_qpos[0]
     q, tg = workloads.make_batch(model, nm, prob, np.random.default_rng(77), B, base_q=stand)
     # a quarter of the batch on its joint limits
@@ -470,10 +470,9 @@ def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name, monk
     if name == "g1_coll":
         # the launches the bench times (round 5: tight rows first, as for the Shadow hand): the 48-row build with 5 rows, the
         # 64-row build with 21 on what that one flags, the workgroup-per-problem kernel on what is flagged then.  How many that is:
-        # the same batch on a handle without the last launch (MKH_DEBUG_NO_WIDE, read per handle)
-        monkeypatch.setenv("MKH_DEBUG_NO_WIDE", "1")
-        alone, _, _ = workloads.bench_config(name, model, nm, B)
-        monkeypatch.delenv("MKH_DEBUG_NO_WIDE")
+        # the same batch on a handle without the last launch (MKH_DIAG_NO_WIDE_REDO)
+        with nat.diag_options(nat.DIAG_NO_WIDE_REDO):
+            alone, _, _ = workloads.bench_config(name, model, nm, B)
         v1, st1 = alone.solve(q, tg, pt, com, dt, damping)
         assert alone.last_kernel() == "ik_solve_kernel_48_8+redo_64", alone.last_kernel()
         flagged = np.flatnonzero(st1 & 16)
@@ -617,7 +616,7 @@ def test_the_bounding_sphere_cull_of_many_pairs_changes_nothing(monkeypatch):
     whose bounding spheres are farther apart than the detection distance before the distance routines run (ik_kernel.h
     collision_phase, wide_kernel.h wide_contacts: 5.9 → 2.7 ms).  A culled pair is one mj_geomDistance answers `distmax` for
     (collision_avoidance_limit.py:214-229), so NOTHING may change: bitwise the same v, statuses, h of every pair (the tap layout
-    of all 1 104) with the cull and without it (MKH_DEBUG_NO_CULL, read when the handle is created)."""
+    of all 1 104) with the cull and without it (a handle created with MKH_DIAG_NO_PAIR_CULL)."""
     from mink_amd import _native as nat
     from mink_amd import workloads
     name, B = "aloha_coll", 4096
@@ -625,11 +624,8 @@ def test_the_bounding_sphere_cull_of_many_pairs_changes_nothing(monkeypatch):
     nm = nat.NativeModel(model)
     out = {}
     for cull in (True, False):
-        if cull:
-            monkeypatch.delenv("MKH_DEBUG_NO_CULL", raising=False)
-        else:
-            monkeypatch.setenv("MKH_DEBUG_NO_CULL", "1")
-        prob, dt, damping = workloads.bench_config(name, model, nm, B)
+        with nat.diag_options(0 if cull else nat.DIAG_NO_PAIR_CULL):
+            prob, dt, damping = workloads.bench_config(name, model, nm, B)
         q, tg, pt, _ = workloads.bench_batch(name, model, nm, prob, np.random.default_rng(11), B)
         v, st = prob.solve(q, tg, pt, None, dt, damping)
         assert prob.last_kernel() == "ik_solve_kernel_64_8+wide", prob.last_kernel()
@@ -673,17 +669,13 @@ def test_humanoid_with_more_than_a_wavefront_of_analytic_pairs(monkeypatch):
     dt, damping = 5e-2, 1e-1
     out = {}
     for cull in (True, False):
-        if cull:
-            monkeypatch.delenv("MKH_DEBUG_NO_CULL", raising=False)
-        else:
-            monkeypatch.setenv("MKH_DEBUG_NO_CULL", "1")
         prob = nat.NativeProblem(nm, frame_tasks=fts, posture_tasks=[{"cost": 1.0}], configuration_limits=[nc._cfg_limit(model)],
-                                 velocity_limits=[nc._vel_limit(model)], collision_limits=[col], max_batch=B)
+                                 velocity_limits=[nc._vel_limit(model)], collision_limits=[col], max_batch=B,
+                                 diag=0 if cull else nat.DIAG_NO_PAIR_CULL)
         q, tg = workloads.make_batch(model, nm, prob, np.random.default_rng(23), B, base_q=stand, sigma=0.5)
         v, st = prob.solve(q, tg, stand[None, :], None, dt, damping)
         assert prob.last_kernel() == "ik_solve_kernel_48_8+redo_64+wide", prob.last_kernel()
         out[cull] = (v, st)
-    monkeypatch.delenv("MKH_DEBUG_NO_CULL", raising=False)
     v, st = out[True]
     np.testing.assert_array_equal(v, out[False][0])
     np.testing.assert_array_equal(st, out[False][1])

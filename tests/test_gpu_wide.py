@@ -226,12 +226,14 @@ def test_g1_with_more_contacts_than_tableau_rows_gets_every_row():
 import sys, numpy as np
 sys.path[:0] = [%r, %r]
 import test_gpu_wide as T
-model, prob, pairs, q, tg, stand = T._g1_with_contacts(%d)
+from mink_amd import _native as nat
+with nat.diag_options(nat.DIAG_NO_WIDE_REDO):
+    model, prob, pairs, q, tg, stand = T._g1_with_contacts(%d)
 v, st = prob.solve(q, tg, stand[None, :], None, 5e-2, 1e-1)
 print("FLAGGED", int(((st & 16) != 0).sum()), prob.last_kernel())
 np.save(%r, st)
 """ % (REPO, os.path.join(REPO, "tests"), B, "/tmp/mkh_wide_st.npy")
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MKH_DEBUG_NO_WIDE="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     flagged = np.flatnonzero(np.load("/tmp/mkh_wide_st.npy") & 16)
     print(r.stdout.strip().splitlines()[-1])
@@ -283,11 +285,13 @@ def test_fused_loop_and_taps_with_more_contacts_than_tableau_rows():
 import sys, numpy as np
 sys.path[:0] = [%r, %r]
 import test_gpu_wide as T
-model, prob, pairs, q, tg, stand = T._g1_with_contacts(%d)
+from mink_amd import _native as nat
+with nat.diag_options(nat.DIAG_NO_WIDE_REDO):
+    model, prob, pairs, q, tg, stand = T._g1_with_contacts(%d)
 qK, vK, st = prob.solve(q, tg, stand[None, :], None, 5e-2, 1e-1, n_steps=%d)
 np.save(%r, st)
 """ % (REPO, os.path.join(REPO, "tests"), B, K, "/tmp/mkh_wide_st_loop.npy")
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MKH_DEBUG_NO_WIDE="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     flagged = np.flatnonzero(np.load("/tmp/mkh_wide_st_loop.npy") & 16)
     assert len(flagged) >= 2, len(flagged)

@@ -17,12 +17,16 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 path = os.path.join(tempfile.gettempdir(), "mkh_clocks.bin")
 os.environ["MKH_DEBUG_CLOCKS"] = path
-os.environ.setdefault("MKH_DEBUG_NO_WIDE", "1")     # (the workgroup-per-problem redo launch would overwrite the stamps of the wavefront kernel)
 
 import torch  # noqa: E402
 
 from mink_amd import _native as nat  # noqa: E402
 from mink_amd import workloads  # noqa: E402
+
+# (the workgroup-per-problem redo launch would overwrite the stamps of the wavefront kernel: every handle of this process is
+#  created with MKH_DIAG_NO_WIDE_REDO unless MKH_PC_WIDE=1)
+if not os.environ.get("MKH_PC_WIDE"):
+    nat._diag_default.bits = nat.DIAG_NO_WIDE_REDO
 
 NAMES = ["load+FK", "axes/dof/com", "task lanes", "posture+coll+J cols", "limits", "build T + phase 0", "active set"]
 

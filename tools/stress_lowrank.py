@@ -21,9 +21,8 @@ def main():
     model = workloads.load_robot("g1")
     nm = nat.NativeModel(model)
     prob, dt, _ = nc.build("g1_c3", nm, B)
-    os.environ["MKH_DEBUG_NO_REFINE"] = "1"
-    plain, _, _ = nc.build("g1_c3", nm, B)
-    del os.environ["MKH_DEBUG_NO_REFINE"]
+    with nat.diag_options(nat.DIAG_NO_COLD_REFINE):
+        plain, _, _ = nc.build("g1_c3", nm, B)
     stand = model.key_qpos[0]
     worst = 0.0
     for i in range(n_batches):

@@ -2,7 +2,9 @@
 """Per-phase cycle breakdown of the workgroup-per-problem kernel (wide_kernel.h MKH_WSTAMP): MKH_DEBUG_CLOCKS makes every launch of
 this process synchronous and dumps the shader-clock stamps of every problem.
 
-    python tools/wide_phase_clocks.py [config[:batch]] ...        (default: g1_hands)
+    MKH_BUILD_TAG=dbg MKH_EXTRA_FLAGS=-DMKH_DEBUG_SWITCHES python -m mink_amd.csrc.build     # (build container; round 6: the product
+    MKH_LIB_TAG=dbg python tools/wide_phase_clocks.py [config[:batch]] ...                      #  library reads no environment variable)
+(default config: g1_hands)
 """
 import os
 import sys
