@@ -3,6 +3,9 @@
 Run in the build container only (needs /root/reference):
 
     python tests/golden/make_golden.py
+    python tests/golden/make_golden.py --real-wheels     # on a machine WITH the mujoco / qpsolvers / quadprog wheels: re-run the
+                                                         # committed inputs through the real stack and diff (real_wheels.py);
+                                                         # writes nothing into this directory
 
 It imports ``mink`` from /root/reference.  The reference's third-party wheels
 ``mujoco`` and ``qpsolvers`` are not installed here, so they are replaced by
@@ -26,6 +29,10 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
+if "--real-wheels" in sys.argv[1:]:
+    sys.path.insert(0, HERE)
+    import real_wheels
+    sys.exit(real_wheels.main([a for a in sys.argv[1:] if a != "--real-wheels"]))
 sys.path[:0] = [os.path.join(REPO, "oracle", "stubs"), "/root/reference", REPO]
 
 import mujoco  # noqa: E402  (the stub)
