@@ -42,6 +42,10 @@ W3_WOOD = ((44, 44, 32), (44, 44, 48), (32, 32, 32), (32, 32, 48),    # (NT, NR,
            (24, 24, 32), (24, 24, 48), (16, 16, 32), (16, 16, 48),    # ... and, for NT ≤ 24, the 4-waves map (TabW4; same suffix _w3: "one more wave")
            (44, 44, 36), (44, 44, 52))                                # F_COM (ComTask rows / up to 24 task rows) and its fused loops: round 5, ik_kernel.h MKH_WOOD_SPLIT
 WOOD_FEATS = (32, 48, 33, 36, 52)      # F_WOOD, | F_STEPS, | F_TAPS (cycle-counter profiling only), | F_COM, | F_COM | F_STEPS
+# low-rank start WITH half-space rows (round 6; ik_kernel.h wood_start "half-space rows"): (NT, NR, FEAT) on the 2-waves map,
+# NR = NT (the rows' columns of the elimination sit behind the dofs in the tableau-wide rows of Jh); must match kWoodRowVariants
+# in minkhip.hip.  40 = F_WOOD | F_COLL (analytic pairs, phases as calls)
+WOOD_ROWS = ((48, 48, 40),)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-null-conversion"]
 # experiments: extra compiler flags for every translation unit (e.g. MKH_EXTRA_FLAGS="-DMKH_FORCE_COLL_CALL"); part of the
 # per-object command tag, so changing it recompiles
@@ -236,6 +240,22 @@ void launch_{nt}_{ft}_r{nr}(int grid, int lds_bytes, hipStream_t stream, const D
 }}  // namespace mkh
 """)
             srcs.append(name)
+    for nt, nr, ft in WOOD_ROWS:
+        name = f"variant_{nt}_{ft}_r{nr}"
+        _write_if_changed(os.path.join(BUILD, name + ".hip"), f"""// generated by build.py
+#define MKH_NT {nt}
+#define MKH_NR {nr}
+#define MKH_FEAT {ft}
+#define MKH_KERNEL_NAME ik_solve_kernel_{nt}_{ft}_r{nr}
+#include "../ik_kernel.h"
+namespace mkh {{
+void launch_{nt}_{ft}_r{nr}(int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P, const SolveArgs& a,
+                      const TapArgs* taps) {{
+  hipLaunchKernelGGL(ik_solve_kernel_{nt}_{ft}_r{nr}, dim3(grid), dim3(kWave), lds_bytes, stream, P, a, taps);
+}}
+}}  // namespace mkh
+""")
+        srcs.append(name)
     for nt, ft in W3:
         name = f"variant_{nt}_{ft}_w3"
         _write_if_changed(os.path.join(BUILD, name + ".hip"), f"""// generated by build.py
@@ -274,6 +294,8 @@ void launch_{nt}_{ft}_r{nr}_w3(int grid, int lds_bytes, hipStream_t stream, cons
                       for nt in NTS for ft in FEATS)
     decls += "\n" + "\n".join(f"void launch_{nt}_{ft}_r{nr}(int, int, hipStream_t, const DeviceProblem*, const SolveArgs&, const TapArgs*);"
                              for nt, nr in WOOD for ft in WOOD_FEATS)
+    decls += "\n" + "\n".join(f"void launch_{nt}_{ft}_r{nr}(int, int, hipStream_t, const DeviceProblem*, const SolveArgs&, const TapArgs*);"
+                             for nt, nr, ft in WOOD_ROWS)
     decls += "\n" + "\n".join(f"void launch_{nt}_{ft}_w3(int, int, hipStream_t, const DeviceProblem*, const SolveArgs&, const TapArgs*);"
                              for nt, ft in W3)
     decls += "\n" + "\n".join(f"void launch_{nt}_{ft}_r{nr}_w3(int, int, hipStream_t, const DeviceProblem*, const SolveArgs&, const TapArgs*);"
@@ -286,6 +308,8 @@ void launch_{nt}_{ft}_r{nr}_w3(int grid, int lds_bytes, hipStream_t stream, cons
                       for nt in NTS for ft in FEATS)
     cases += "\n" + "\n".join(f"  if (nt == {nt} && nr == {nr} && feat == {ft}) {{ launch_{nt}_{ft}_r{nr}(grid, lds_bytes, stream, P, a, taps); return 0; }}"
                               for nt, nr in WOOD for ft in WOOD_FEATS)
+    cases += "\n" + "\n".join(f"  if (nt == {nt} && nr == {nr} && feat == {ft}) {{ launch_{nt}_{ft}_r{nr}(grid, lds_bytes, stream, P, a, taps); return 0; }}"
+                              for nt, nr, ft in WOOD_ROWS)
     _write_if_changed(os.path.join(BUILD, "dispatch.hip"), f"""// generated by build.py
 #include <hip/hip_runtime.h>
 #include "../mkh_types.h"

@@ -93,12 +93,36 @@ __host__ __device__ inline int lds_even(int x) { return (x + 1) & ~1; }
 __host__ __device__ inline LdsLayout lds_layout(int nq, int nv, int nbody, int njnt, int n_frame,
                                                 int n_posture, int n_com, int max_rows, int j_rows, int j_stride,
                                                 int s_doubles = 0, bool prefetch = false, bool compact = false,
-                                                bool wood = false, int n_hsel = 0, bool piv_small = false) {
+                                                bool wood = false, int n_hsel = 0, bool piv_small = false, bool wood_rows = false) {
   LdsLayout L;
   int o = 0;
   const int x_sz = 7 * lds_even(nbody), jnt_sz = lds_even(njnt * 6);
   const int j_sz = lds_even(j_rows * j_stride);
   L.q = o;    o += lds_even(nq);
+  if (wood_rows) {
+    // low-rank start WITH half-space rows (round 6; F_WOOD | F_COLL builds): the rows [r][NT] of Jh — the dof part AND, behind it,
+    // the half-space rows' columns of the elimination — overwrite the joint axes and the task blocks as in the compact layout (one
+    // pass of (task, dof) pair lanes: the host checks n_jpairs <= 64), but the body poses, the dof axes and h of every pair stay:
+    // collision_phase reads them again after the QP (dropped contacts at the solution).  One pivot buffer (no look-ahead publishing).
+    L.tgt = o;  o += lds_even(n_frame * 7 + n_com * 3);
+    L.X = o;    o += x_sz;
+    const int u0 = o;
+    L.jnt = o;  o += jnt_sz;
+    L.task = o; o += n_frame * 64;
+    if (o - u0 < j_sz) o = u0 + j_sz;
+    L.J = u0;
+    L.dof = o;  o += lds_even(nv * 10);
+    L.com = o;  o += (n_com > 0 ? nbody * 4 : 0);
+    L.col = o;  o += max_rows * 16;
+    L.A = o;    o += max_rows * a_stride_for(nv);
+    L.piv = o;  o += kWoodRow + 2 * kMuBig;
+    L.S = o;    o += lds_even(s_doubles);
+    L.q2 = prefetch ? o : L.q;     o += prefetch ? lds_even(nq) : 0;
+    L.tgt2 = prefetch ? o : L.tgt; o += prefetch ? lds_even(n_frame * 7 + n_com * 3) : 0;
+    L.hsel = o; o += lds_even(n_hsel);
+    L.total = o;
+    return L;
+  }
   // compact (3-waves-per-SIMD variants, no collision rows): ranges that are not alive at the same time share storage.
   //   direct start:   {body poses, joint axes}              | {staged Jacobian rows of one task, pivot buffers}
   //   low-rank start: {body poses, joint axes, task blocks} | {all Jacobian rows} — the pair lanes hold their entries in
@@ -415,10 +439,11 @@ struct PreView {
 template <class PT>
 __device__ __forceinline__ bool kernel_prefetch(const PT& P0) {
   constexpr bool kWood = (MKH_FEAT & F_WOOD) != 0;
+  constexpr bool kWoodRows = kWood && (MKH_FEAT & (F_COLL | F_DENSE)) != 0;    // low-rank start with half-space rows: its own layout
 #ifdef MKH_W3
   return (kWood ? P0.prefetch_w3w : P0.prefetch_w3) != 0;
 #else
-  return ((kWood && P0.wood_compact != 0) ? P0.prefetch_wc : P0.prefetch) != 0;
+  return ((kWoodRows || (kWood && P0.wood_compact != 0)) ? P0.prefetch_wc : P0.prefetch) != 0;
 #endif
 }
 template <class PT>
@@ -435,6 +460,10 @@ __device__ __forceinline__ LdsLayout kernel_lds_layout(const PT& P0) {
 #else
   constexpr bool kCompact = false;
 #endif
+  constexpr bool kWoodRows = kWood && (FEAT & (F_COLL | F_DENSE)) != 0;
+  if constexpr (kWoodRows)     // (S never shares the dof stash here: collision_phase reads the axes again after the QP)
+    return lds_layout(P0.nq, P0.nv, P0.nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows, P0.n_jrows + 1, NR,
+                      P0.n_jrows * (lds_even(P0.n_jrows) + 1), kernel_prefetch(P0), false, true, (FEAT & F_COLL) ? P0.n_hsel : 0, true, true);
   return lds_layout(P0.nq, P0.nv, P0.nbody, P0.njnt, P0.n_frame, P0.n_posture, P0.n_com, P0.max_rows,
                     kWood ? P0.n_jrows + 1 : 6, kWood ? NR : j_stride_direct(P0.nv, NT),
                     (kWood && !wood_s_aliases_dof(P0.nv, P0.n_jrows, lds_even(P0.n_jrows), P0.n_com > 0 ? P0.nbody : 0))
@@ -873,7 +902,7 @@ __device__ MKH_PRE_ATTR DirectPairs direct_pairs(const DeviceProblem* Pq) {
 // reciprocal / multiplier chain in front of a 62-row update, later six at a time with a per-lane 6 × 6 LDLᵀ: 30 % of a
 // G1 solve.)
 // Outputs per dof lane: D = −H⁻¹[j][j] = σ²(Σ_r z_r²/d_r − 1),  x0 = −H⁻¹c = z − σ·Σ_r z_r·ω_r/d_r  (ω = L⁻¹w, w = Jw·z − r).
-struct WoodOut { double hdiag, dsq, x, D; int status, clamp; };
+struct WoodOut { double hdiag, dsq, x, D, rown; int status, clamp; };
 
 // cold-start refinement of wood_eliminate (single-pass lane layout): bounds, the dof's closed-form point and scales
 struct WoodRefine { bool on; int nv; double lo, hi, zfree, dsq, sqdg, zsq; };
@@ -1100,15 +1129,18 @@ __device__ __attribute__((noinline)) void wood_s_dense_call(int n_mu, int nv, in
 // it through (I − Jh_FᵀS⁻¹Jh_F)·Jh_Fᵀ = Jh_FᵀS⁻¹ and I − Jh_F·H̃_FF⁻¹·Jh_Fᵀ = S⁻¹); a predicted dof gets the diagonal
 // Dg·(1 + Σ z_r²/d_r) and its gradient Dg·β + c + √Dg·Σ z_r·ω_r/d_r, the right-hand side takes z̃ = β on predicted dofs.
 // No un-sweep pivot at all for a correct prediction: the warm starts of the fused loop and of MKH_FLAG_WARM_START.
+// nrows (builds with half-space rows, round 6): the rows A[s][:] staged in LDS by the collision phase take part — see "half-space
+// rows" below; their lanes [nv, nv + nrows) get D = T_rr[s][s], x = the slack A·x0 − h and rown = ‖A[s]‖ back.
 __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int off_q, int off_tgt, double c_lane, double hdiag_base,
-                                             int clamp, double beta, double lo, double hi,
+                                             int clamp, double beta, double lo, double hi, int nrows,
                                              long long* prof = nullptr) {   // prof (inlined profiling build only): cycle stamps
   constexpr int NR = MKH_NT;
   constexpr bool kCom = (MKH_FEAT & F_COM) != 0;
+  constexpr bool kRowsW = (MKH_FEAT & (F_COLL | F_DENSE)) != 0;         // half-space rows next to the low-rank start
   static_assert(MKH_NR == MKH_NT, "low-rank start: the residual rows are not tableau rows any more");
   extern __shared__ __attribute__((aligned(16))) double smem[];
 #ifdef MKH_WOOD_CALL
-  oz = uni(oz); off_q = uni(off_q); off_tgt = uni(off_tgt);
+  oz = uni(oz); off_q = uni(off_q); off_tgt = uni(off_tgt); nrows = uni(nrows);
   Pq = reinterpret_cast<const DeviceProblem*>(uni((unsigned long long)reinterpret_cast<size_t>(Pq)));
   const MKH_CONSTANT DeviceProblem& P = *(const MKH_CONSTANT DeviceProblem*)Pq;
   const MKH_GLOBAL FrameTaskDev* const frames = (const MKH_GLOBAL FrameTaskDev*)P.frame;
@@ -1243,14 +1275,73 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
   wave_sync();
   if (prof) prof[0] = __builtin_readcyclecounter();                    // Jacobian rows staged
 #if defined(MKH_WOOD_CALL) && defined(MKH_CLOCKS)
-  if (prof && (int)prof[-2] == 6) return WoodOut{0.0, 0.0, 0.0, 0.0, 0, 0};   // phase-stop 6 (prof = slot 17 of the problem's row)
+  if (prof && (int)prof[-2] == 6) return WoodOut{0.0, 0.0, 0.0, 0.0, 1.0, 0, 0};   // phase-stop 6 (prof = slot 17 of the problem's row)
 #endif
+  // ---- half-space rows (round 6).  With all dofs swept the tableau holds T_rd = A·H⁻¹ and T_rr = −A·H⁻¹·Aᵀ in the rows' block; the
+  // direct start gets there by nv single pivots over nv + rows tableau rows (43 for a G1: 40–47 % of the collision / plugin
+  // workloads).  With Ah = A·σ (σ = 1/√Dg, column scaling) and Y = Ah·Zᵀ:
+  //     T_rd[s][j] = σ_j·(Ah[s][j] − Σ_r Y[s][r]·Z[r][j]/d_r),      T_rr[s][t] = −Ah[s]·Ah[t] + Σ_r Y[s][r]·Y[t][r]/d_r,
+  // i.e. with the rows of Z extended by Z̃[r][nv + s] = −Y[s][r] the SAME n_μ rank-1 updates R[i][j] += Z̃[r][i]·Z̃[r][j]/d_r that
+  // build the dof block build the whole tableau on top of R_rd = Ah, R_rr = −Ah·Ahᵀ (lazy scale 1 on a row index).  And
+  // Y[s][·] = L⁻¹·(Jh·Ah[s]ᵀ): a half-space row is one more COLUMN of the elimination — lane nv + s carries −Jh·Ah[s]ᵀ next to
+  // the dof lanes' columns of Jh and gets −Y back, its Σ z²/d (the diagonal) and Σ z·ω/d (the slack: A·x0 = A·z⁰ + Σ z̃·ω/d).
+  // Lane nv + s walks the dofs of its row (the kinematic chains of the contact's two bodies): Jh·Ah[s]ᵀ and the right-hand side
+  // A·z⁰ against the rows of Jh, Ah[s]·Ah[t] against the other rows; the Gram entries wait in the row's slot of the contact
+  // table (normal and witness points are dead once the rows exist), at most 8 rows.
+  double row_a0 = 0.0, row_gs = 0.0, row_h = 0.0, row_n = 1.0;
+  const bool is_row = kRowsW && lane >= nv && lane < nv + nrows;
+  if constexpr (kRowsW) {
+    if (nrows > 0) {
+      const int AS = a_stride_for(nv);
+      double* const sA = smem + L.A;
+      double* const sCol = smem + L.col;
+      if (is_row) {
+        const int sr = lane - nv;
+        double* const col = sCol + sr * 16;
+        row_h = col[9];
+        uint64_t m = (MKH_FEAT & F_COLL) ? ((uint64_t)__double_as_longlong(col[10]) | (uint64_t)__double_as_longlong(col[11])) : ~0ull;
+        if (nv < 64) m &= (1ull << nv) - 1ull;
+        double accC[kMu + 1], accG[8], nn = 0.0;
+#pragma unroll
+        for (int r = 0; r <= kMu; ++r) accC[r] = 0.0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) accG[t] = 0.0;
+        const double* const a_row = sA + sr * AS;
+        for (; m; m &= m - 1) {
+          const int k = __ffsll((unsigned long long)m) - 1;
+          const double a = a_row[k], dk = sDof[k * 10 + 9];
+          const double ah = a * dk, ahk = ah * dk;
+          nn = fma(a, a, nn);
+          row_gs = fma(ah, ah, row_gs);
+          // (rows past the right-hand side / past the last half-space row: whatever lies behind them in this wave's LDS, never used)
+          const double* const jk = sJ + k;
+#pragma unroll
+          for (int r = 0; r <= kMu; ++r) accC[r] = fma(ah, jk[r * NR], accC[r]);
+          const double* const ak = sA + k;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) accG[t] = fma(ahk, ak[t * AS], accG[t]);
+        }
+        row_n = sqrt(nn);
+#pragma unroll
+        for (int r = 0; r <= kMu; ++r) {
+          if (r < n_mu) sJ[r * NR + lane] = -accC[r];
+          row_a0 = (r == n_mu) ? accC[r] : row_a0;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) col[t] = accG[t];
+      }
+      wave_sync();
+      if (is_dof)                                                      // the tableau's entries are Ah: scale the staged rows in place
+        for (int sr = 0; sr < nrows; ++sr) sA[sr * AS + lane] *= dsq;
+      wave_sync();
+    }
+  }
   // ---- S = I + Jh·Jhᵀ and Jw·z by (column, row-chunk) lanes: 64/n_μ chunks of rows per column, each lane a handful of
   // dot products on its own LDS addresses.  A row of Jh is nonzero only on the kinematic chain of its task (12–16 of the
   // 43 dofs on G1): the dot products walk the set bits of the column's chain mask instead of all NR dofs.
   // [column c][SP]: S[·][c], then [c]: (Jw·z)[c] − weighted error.  Lives in the dof stash (+ the subtree CoMs behind it:
   // axes / anchors / CoMs of the Jacobian columns are dead by now) when it fits, so that the low-rank start costs no LDS.
-  double* const sS = wood_s_aliases_dof(nv, n_mu, SP, P.n_com > 0 ? P.nbody : 0) ? sDof : smem + L.S;
+  double* const sS = (!kRowsW && wood_s_aliases_dof(nv, n_mu, SP, P.n_com > 0 ? P.nbody : 0)) ? sDof : smem + L.S;
   double* const sW = sS + n_mu * SP;
   for (int i = lane; i < n_mu * SP; i += kWave) sS[i] = 0.0;
   wave_sync();
@@ -1335,7 +1426,7 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
   wave_sync();
   if (prof) prof[1] = __builtin_readcyclecounter();                    // S and w ready
 #if defined(MKH_WOOD_CALL) && defined(MKH_CLOCKS)
-  if (prof && (int)prof[-2] == 7) return WoodOut{0.0, 0.0, 0.0, 0.0, 0, 0};   // phase-stop 7
+  if (prof && (int)prof[-2] == 7) return WoodOut{0.0, 0.0, 0.0, 0.0, 1.0, 0, 0};   // phase-stop 7
 #endif
   // ---- elimination (K = the smallest compiled row capacity that holds n_μ)
   double ssq = 0.0, quad = 0.0, zw = 0.0;
@@ -1344,7 +1435,7 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
   // (cold start only: a warm start brings its own prediction)
   // (compiled into the lean 44- / 48-row builds only: its code costs the others — register pressure of this function, scalar
   //  spills — more than the pivots it saves: G1 +1.5 %, but H1 / hands / quadrupeds −10 % and the G1 full example −4.5 %)
-  constexpr bool kRefine = !kCom && NR >= 44 && !(MKH_FEAT & F_STEPS);
+  constexpr bool kRefine = !kCom && NR >= 44 && !(MKH_FEAT & F_STEPS) && !kRowsW;
   const WoodRefine rf{kRefine && a_mask == 0 && !dual && P.wood_refine != 0, nv, lo, hi, -c_lane * (dsq * dsq), dsq, hdiag_base * dsq, -c_lane * dsq};
   if constexpr (kCom) {
 #ifdef MKH_WOOD_SPLIT
@@ -1362,7 +1453,12 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
     else wood_eliminate<kMuBig, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status, rf, clamp, beta);
 #endif
   } else {
-    wood_eliminate<kMu, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status, rf, clamp, beta);
+    if constexpr (kRowsW) {      // (tableau lanes [0, NR) + n_μ S lanes exceed the wavefront from NR = 48, n_μ = 17 on: two passes)
+      if (dual) wood_eliminate<kMu, true>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status, rf, clamp, beta);
+      else wood_eliminate<kMu, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status, rf, clamp, beta);
+    } else {
+      wood_eliminate<kMu, false>(n_mu, NR, lane, sJ, sS, SP, sW, sRow, sDinv, ssq, quad, zw, status, rf, clamp, beta);
+    }
   }
   wave_sync();
   WoodOut wo;
@@ -1373,11 +1469,15 @@ __device__ MKH_WOOD_ATTR WoodOut wood_start(const DeviceProblem* Pq, int oz, int
   wo.clamp = on_bound ? clamp : 0;
   wo.D = on_bound ? hdiag_base * (1.0 + quad) : (dsq * dsq) * (quad - 1.0);
   wo.x = on_bound ? fma(hdiag_base, beta, c_lane) + hdiag_base * dsq * zw : -c_lane * (dsq * dsq) - dsq * zw;
+  wo.rown = 1.0;
+  if constexpr (kRowsW) {
+    if (is_row) { wo.D = quad - row_gs; wo.x = (row_a0 + zw) - row_h; wo.rown = row_n; }   // T_rr[s][s], the slack A·x0 − h, ‖A[s]‖
+  }
   return wo;
 }
 #else
-struct WoodOut { double hdiag, dsq, x, D; int status, clamp; };
-__device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, int, int, double, double, int, double, double, double, long long* = nullptr) { return WoodOut{0.0, 0.0, 0.0, 0.0, 0, 0}; }
+struct WoodOut { double hdiag, dsq, x, D, rown; int status, clamp; };
+__device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, int, int, double, double, int, double, double, double, int, long long* = nullptr) { return WoodOut{0.0, 0.0, 0.0, 0.0, 1.0, 0, 0}; }
 #endif
 // ---------------------------------------------------------------- collision half-space rows (CollisionAvoidanceLimit)
 // mode 0: the contacts of this problem's geom pairs (mj_geomDistance, collision_avoidance_limit.py:187-229) become half-space
@@ -1741,7 +1841,9 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
 #else
   constexpr int NR = NT;
 #endif
-  static_assert(!kWood || !(kRel || kColl), "low-rank start: frame / posture / CoM tasks + box limits only");
+  static_assert(!kWood || !kRel, "low-rank start: frame / posture / CoM tasks, box limits and (round 6) half-space rows");
+  constexpr bool kWoodRows = kWood && kRows;       // low-rank start with half-space rows (wood_start "half-space rows")
+  static_assert(!kWoodRows || NR == NT, "the rows' columns of the elimination live in the tableau-wide rows of Jh");
 #ifdef MKH_W3
   constexpr bool kCompact = true;            // LDS ranges aliased by phase (lds_layout): 12 waves per CU need ≤ 13.3 KB each
   static_assert(!kColl, "compact LDS layout: the collision phase reads the body poses after the Jacobian rows");
@@ -2063,7 +2165,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       }
     }
     };
-#if defined(MKH_COLL_CALL) || (MKH_FEAT & 128) || ((MKH_FEAT & 30) == 30)
+#if defined(MKH_COLL_CALL) || (MKH_FEAT & 128) || ((MKH_FEAT & 30) == 30) || (MKH_FEAT & 32)
     // (round 5: the parity build FEAT 31 — every feature + taps, phases inlined — carries the general convex routine too, and with
     //  it overlap_pair, a REAL call that owns the whole register file: behind the H accumulation it overwrote the pinned tableau
     //  of the rare instance with a PENETRATING general convex pair — a silently wrong H, hence v, found by comparing a call with
@@ -2128,7 +2230,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
 #endif
     // ---- low-rank start: Jacobian rows, S = I + Jh·Jhᵀ, LDLᵀ elimination (wood_start above), then the dof block of the
     // tableau by n_μ rank-1 updates that do not depend on each other:  R[i][j] = Σ_r Z[r][i]·Z[r][j]/d_r
-    WoodOut wo{0.0, 0.0, 0.0, 0.0, 0, 0};
+    WoodOut wo{0.0, 0.0, 0.0, 0.0, 1.0, 0, 0};
     // predicted active set (warm starts: the previous fused step from the third step on / the previous call): the low-rank
     // start builds the tableau with these dofs already on their bounds
     int pred = 0;
@@ -2141,16 +2243,16 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     if constexpr (kWood) {
 #if defined(MKH_WOOD_CALL) && defined(MKH_CLOCKS)
       if (A.clk && lane == 0) A.clk[(size_t)pb * 24 + 16] = __builtin_readcyclecounter();          // [16] entry, [17] J rows, [18] S / w
-      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta, lo, hi,
+      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta, lo, hi, nrows,
                       A.clk ? A.clk + (size_t)pb * 24 + 17 : nullptr);
       if (A.clk && lane == 0) A.clk[(size_t)pb * 24 + 19] = __builtin_readcyclecounter();          // [19] back in the kernel
       MKH_STOP(8);
 #elif defined(MKH_WOOD_CALL)
-      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta, lo, hi);
+      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta, lo, hi, nrows);
 #else
       long long wprof[2] = {0, 0};
       const long long wt0 = MKH_TAP(t_cycles) ? __builtin_readcyclecounter() : 0;
-      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta, lo, hi, MKH_TAP(t_cycles) ? wprof : nullptr);
+      wo = wood_start(Pq, oz, (int)(sq - smem), (int)(sTgt - smem), c_lane, hdiag_base, pred, pred_beta, lo, hi, nrows, MKH_TAP(t_cycles) ? wprof : nullptr);
       if (MKH_TAP(t_cycles)) {                 // phase_profile.py: Jacobian rows | S and w | elimination  (slots 0, 1, 2)
         const long long wt1 = __builtin_readcyclecounter();
         ta[0] += wprof[0] - wt0; ta[1] += wprof[1] - wprof[0]; ta[2] += wt1 - wprof[1];
@@ -2162,6 +2264,16 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       hdiag = wo.hdiag;
       if (MKH_CLK) ta[3] -= __builtin_readcyclecounter();
       MKH_TAB<NT>::zero(ts);
+      if constexpr (kWoodRows) {
+        // the rows' block before the rank-1 updates: column nv + s (lane nv + s) = (Ah[s][·] | −Ah·Ah[s]ᵀ), rows nv + s of the dof
+        // columns = Ah[s][lane] (wood_start scaled the staged rows in place and left the Gram entries in the contact table)
+        if (nrows > 0) {
+          const bool row_lane = lane >= nv && lane < nv + nrows;
+          if (row_lane) load_leading_rows<NT>(ts, lds_addr(sA + (lane - nv) * AS), AS);   // (entries ≥ nv of a staged row are zero)
+          for (int sr = 0; sr < nrows; ++sr)
+            MKH_TAB<NT>::set_dyn(ts, nv + sr, is_dof ? sA[sr * AS + lane] : (row_lane ? -sCol[(lane - nv) * 16 + sr] : 0.0));
+        }
+      }
       const int n_mu = P.n_jrows;
       const double* const sDinv = sPiv + kWoodRow;
       // (streamed: the statement of row r requests the planes of row r + 1 behind its own FMAs, Z[r + 1][lane] is read one
@@ -2379,7 +2491,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       });
     }
     if (!A.do_qp) break;
-    if (kRows && nrows > 0) {
+    if (kRows && !kWood && nrows > 0) {
       // rows nv+s of the dof columns: one indexed register write per active row (a static_for over all NT
       // rows with a runtime range test cost 860 VALU instructions and 278 spilled SGPRs) ...
       for (int sr = 0; sr < nrows; ++sr) MKH_TAB<NT>::set_dyn(ts, nv + sr, is_dof ? sA[sr * AS + lane] : 0.0);
@@ -2410,6 +2522,11 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       s.rsign = (pred == 1) ? kSign : 0;
       s.x = is_dof ? wo.x : 0.0;                             // x_F = −H_FF⁻¹(c_F + H_FA·β)  /  w_A
       if (is_dof) { s.lo = lo; s.hi = hi; }
+      if constexpr (kWoodRows) {
+        if (lane >= nv && lane < nv + nrows) {               // an inactive half-space row: slack A·x0 − h, diagonal −A·H⁻¹·Aᵀ
+          s.sel = 2; s.lo = 0.0; s.x = wo.x; s.D = wo.D; rown = wo.rown;
+        }
+      }
     } else if (is_dof) {
       s.x = c_lane; s.lo = lo; s.hi = hi;                     // nonbasic at z = 0: w = c   (sel = 1 once swept)
     } else if (kRows && lane < nv + nrows) {
@@ -2490,7 +2607,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     MKH_MARK("phase0_done");
     MKH_TICK();   // 6: tableau built, phase 0 done
     MKH_STOP(9);
-    const int nact = kWood ? nv : kWave;                     // lanes that still own a live index
+    const int nact = (kWood && !kRows) ? nv : kWave;         // lanes that still own a live index
     int n_loop = 0, n_piv = 0;   // profiling (qp_iters tap): loop iterations / rank-1 pivots after x0
     // ---- phase 1a (box limits only): block principal pivoting.  lo ≤ x ≤ hi with H ≻ 0 is a bound-constrained
     // LCP with a P-matrix; Júdice & Pires (1994): flip ALL infeasible indices at once — free dofs outside their
@@ -2509,7 +2626,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     bool need_gi = kRows;        // half-space rows: always finish with Goldfarb–Idnani
     // (in the builds of the plugin route: the collision builds' boxes are ConfigurationLimit rows that seldom bind, and the
     //  block-step code costs them registers — 64_72: 0 → 38 spilled VGPRs)
-    constexpr bool kBoxSteps = !kRows || kDense;
+    constexpr bool kBoxSteps = !kRows || kDense || kWood;    // (round 6: and the low-rank builds with rows — a humanoid's velocity limits bind)
     if (kBoxSteps && !(status & 14)) {
       // Multipliers are sums of terms ≲ hmax·|Δq| ≈ hmax·1e-2: rounding noise ≈ 1e-16·hmax.  A bound dof whose
       // wrong-signed multiplier is below the threshold stays put (Δq error ≤ tolw / λ_min(H) ≈ 1e-12).

@@ -145,6 +145,10 @@ struct MkhProblem {
   // problem does not qualify; lower bound of the diagonal part of H without the damping argument, and
   // the largest squared task cost (conditioning gate, evaluated per call because damping is a call argument)
   int wood_nt = 0, wood_nr = 0, wood_lds_bytes = 0, wood_lds_bytes_w3 = 0;
+  // low-rank start WITH half-space rows (round 6; `48_40_r48`): the lane tables are in the descriptor(s), LDS bytes of that layout
+  // for the tight-rows descriptor and for the main one (0: not available there)
+  bool woodr_tables = false;
+  int woodr_lds_tight = 0, woodr_lds = 0;
   bool wood_big = false;           // more than kMu task rows, or S columns in a second register set: the F_COM builds carry those
   double wood_min_diag = 0.0, wood_max_cost2 = 0.0;
   // lane-per-problem kernel for small arms (lane_kernel.h): template size (0 = the problem does not qualify)
@@ -1182,6 +1186,64 @@ int32_t mkh_problem_create_diag(MkhModel* m, const MkhProblemDesc* d, int32_t ma
     }
     if (fits) P.n_dpairs = n;
   }
+  // The low-rank start's lane tables (ik_kernel.h wood_start): which column / row chunk of Jh·Jhᵀ a lane computes and over which
+  // dofs, the (task, dof) pair lanes of the Jacobian rows, the source of each residual's weighted error.  They depend on the
+  // tasks only — shared by the builds without rows and, round 6, the ones with half-space rows.  false: more than 256 pairs.
+  auto wood_tables = [&]() -> bool {
+    // (column, row-chunk) lanes of the Jh·Jhᵀ product: rows 0..n_jrows (the last one is the rhs)
+    const int groups = kWave / P.n_jrows;
+    P.wood_rpc = (P.n_jrows + 1 + groups - 1) / groups;
+    for (int l = 0; l < kWave; ++l) {
+      const int ch = l / P.n_jrows;
+      P.wood_col[l] = ch < groups ? l % P.n_jrows : -1;
+      P.wood_row0[l] = ch < groups ? ch * P.wood_rpc : 0;
+      P.wood_mask[l] = 0;
+      if (ch < groups)
+        for (size_t t = 0; t < ft.size(); ++t)
+          if (l % P.n_jrows >= ft[t].jrow0 && l % P.n_jrows < ft[t].jrow0 + __builtin_popcount(ft[t].rowmask & 63))
+            P.wood_mask[l] = ft[t].dof_mask;
+    }
+    // Jacobian columns by (task, dof) pair lanes; source of each residual's weighted error
+    P.n_jpairs = 0;
+    for (size_t t = 0; t < ft.size(); ++t) {
+      for (int k = 0; k < m->nv; ++k)
+        if ((ft[t].dof_mask >> k) & 1) {
+          if (P.n_jpairs >= 256) return false;
+          P.jpair_task[P.n_jpairs] = (int16_t)t; P.jpair_dof[P.n_jpairs] = (int16_t)k; ++P.n_jpairs;
+        }
+      int c = 0;
+      for (int r = 0; r < 6; ++r)
+        if ((ft[t].rowmask >> r) & 1) { P.mu_src[ft[t].jrow0 + c] = (int16_t)(t * 64 + 30 + r); ++c; }
+    }
+    // ComTask rows: dense over the robot's dofs; their weighted error is computed on the device (mu_src < 0)
+    for (int t = 0; t < P.n_com; ++t) {
+      int c = 0;
+      for (int r = 0; r < 3; ++r)
+        if ((P.com_rowmask[t] >> r) & 1) { P.mu_src[P.com_jrow0[t] + c] = (int16_t)(-1 - 3 * t - r); ++c; }
+      for (int l = 0; l < kWave; ++l)
+        if (P.wood_col[l] >= P.com_jrow0[t] && P.wood_col[l] < P.com_jrow0[t] + c)
+          P.wood_mask[l] = m->nv >= 64 ? ~0ull : ((1ull << m->nv) - 1ull);
+    }
+    return true;
+  };
+  // what the low-rank start's stability criterion compares (launch(): damping + the smallest posture diagonal against the largest
+  // task cost²)
+  auto wood_scales = [&]() {
+    double mn = __builtin_huge_val();
+    for (int i = 0; i < m->nv; ++i) {
+      double dsum = 0.0;
+      for (int t = 0; t < d->n_posture_tasks; ++t) {
+        // free-joint dofs carry no posture term (posture_task.py:115-116,139-141)
+        const int jt = m->jnt_type[m->dof_jntid[i]];
+        if (jt != 0) dsum += pcost[t * 64 + i] * pcost[t * 64 + i];
+      }
+      mn = dsum < mn ? dsum : mn;
+    }
+    p->wood_min_diag = mn;
+    p->wood_max_cost2 = 0.0;
+    for (const auto& f : ft) for (int k = 0; k < 6; ++k) p->wood_max_cost2 = fmax(p->wood_max_cost2, f.cost[k] * f.cost[k]);
+    for (int t = 0; t < P.n_com; ++t) for (int k = 0; k < 3; ++k) p->wood_max_cost2 = fmax(p->wood_max_cost2, P.com_cost[t][k] * P.com_cost[t][k]);
+  };
   if (P.n_jrows > 0 && P.n_pairs == 0 && !p->has_relative && P.n_dense_rows == 0 &&
       P.n_dense_limit_rows == 0 && P.n_jrows <= kMuBig) {
     // (NT = NR: the task residuals are eliminated outside the tableau, one column of [S | Jh] per lane — wood_start; the
@@ -1223,40 +1285,7 @@ int32_t mkh_problem_create_diag(MkhModel* m, const MkhProblemDesc* d, int32_t ma
         }
       }
       const LdsLayout Lw = P.wood_compact ? lds_wood(P.prefetch_wc != 0, true) : lds_wood(P.prefetch != 0, false);
-      // (column, row-chunk) lanes of the Jh·Jhᵀ product: rows 0..n_jrows (the last one is the rhs)
-      const int groups = kWave / P.n_jrows;
-      P.wood_rpc = (P.n_jrows + 1 + groups - 1) / groups;
-      for (int l = 0; l < kWave; ++l) {
-        const int ch = l / P.n_jrows;
-        P.wood_col[l] = ch < groups ? l % P.n_jrows : -1;
-        P.wood_row0[l] = ch < groups ? ch * P.wood_rpc : 0;
-        P.wood_mask[l] = 0;
-        if (ch < groups)
-          for (size_t t = 0; t < ft.size(); ++t)
-            if (l % P.n_jrows >= ft[t].jrow0 && l % P.n_jrows < ft[t].jrow0 + __builtin_popcount(ft[t].rowmask & 63))
-              P.wood_mask[l] = ft[t].dof_mask;
-      }
-      // Jacobian columns by (task, dof) pair lanes; source of each residual's weighted error
-      P.n_jpairs = 0;
-      for (size_t t = 0; t < ft.size() && p->wood_nt; ++t) {
-        for (int k = 0; k < m->nv; ++k)
-          if ((ft[t].dof_mask >> k) & 1) {
-            if (P.n_jpairs >= 256) { p->wood_nt = 0; break; }
-            P.jpair_task[P.n_jpairs] = (int16_t)t; P.jpair_dof[P.n_jpairs] = (int16_t)k; ++P.n_jpairs;
-          }
-        int c = 0;
-        for (int r = 0; r < 6; ++r)
-          if ((ft[t].rowmask >> r) & 1) { P.mu_src[ft[t].jrow0 + c] = (int16_t)(t * 64 + 30 + r); ++c; }
-      }
-      // ComTask rows: dense over the robot's dofs; their weighted error is computed on the device (mu_src < 0)
-      for (int t = 0; t < P.n_com; ++t) {
-        int c = 0;
-        for (int r = 0; r < 3; ++r)
-          if ((P.com_rowmask[t] >> r) & 1) { P.mu_src[P.com_jrow0[t] + c] = (int16_t)(-1 - 3 * t - r); ++c; }
-        for (int l = 0; l < kWave; ++l)
-          if (P.wood_col[l] >= P.com_jrow0[t] && P.wood_col[l] < P.com_jrow0[t] + c)
-            P.wood_mask[l] = m->nv >= 64 ? ~0ull : ((1ull << m->nv) - 1ull);
-      }
+      if (!wood_tables()) p->wood_nt = 0;
       p->wood_lds_bytes = Lw.total * (int)sizeof(double);
       if (p->wood_lds_bytes * 8 > 160 * 1024) p->wood_nt = 0;      // would cost residency
       // 3 waves per SIMD (compact layout: the Jacobian rows overwrite the task blocks, so the pair lanes need one pass)
@@ -1280,20 +1309,25 @@ int32_t mkh_problem_create_diag(MkhModel* m, const MkhProblemDesc* d, int32_t ma
           p->wood_lds_bytes_w3 = lds_wood(P.prefetch_w3w != 0, true, true).total * (int)sizeof(double);
         }
       }
-      double mn = __builtin_huge_val();
-      for (int i = 0; i < m->nv; ++i) {
-        double dsum = 0.0;
-        for (int t = 0; t < d->n_posture_tasks; ++t) {
-          // free-joint dofs carry no posture term (posture_task.py:115-116,139-141)
-          const int jt = m->jnt_type[m->dof_jntid[i]];
-          if (jt != 0) dsum += pcost[t * 64 + i] * pcost[t * 64 + i];
-        }
-        mn = dsum < mn ? dsum : mn;
-      }
-      p->wood_min_diag = mn;
-      for (const auto& f : ft) for (int k = 0; k < 6; ++k) p->wood_max_cost2 = fmax(p->wood_max_cost2, f.cost[k] * f.cost[k]);
-      for (int t = 0; t < P.n_com; ++t) for (int k = 0; k < 3; ++k) p->wood_max_cost2 = fmax(p->wood_max_cost2, P.com_cost[t][k] * P.com_cost[t][k]);
+      wood_scales();
     }
+  }
+  // ---- low-rank start WITH half-space rows (round 6; ik_kernel.h wood_start "half-space rows"): a collision problem whose
+  // tasks qualify for the low-rank start keeps it — every contact row is one more column of the n_μ-step elimination instead of
+  // the reason for nv single pivots on the whole tableau (47 % of `g1_coll`).  Analytic pair sets (FEAT 8 → 40), frame + posture
+  // tasks, at most kMu task rows, one pass of (task, dof) pair lanes (the Jacobian rows overwrite the task blocks in LDS) and at most
+  // 8 half-space rows per instance (the rows' Gram entries wait in the contact table); a 48-row tableau (mkh_problem_create below).
+  if (P.n_jrows > 0 && P.n_jrows <= kMu && P.n_pairs > 0 && !p->has_relative && P.n_com == 0 && P.n_dense_rows == 0 &&
+      P.n_dense_limit_rows == 0 && !P.dense_box && !p->simple_pairs && !p->convex_pairs) {
+    if (wood_tables() && P.n_jpairs <= kWave) { p->woodr_tables = true; wood_scales(); }
+  }
+  auto woodr_bytes = [&](const DeviceProblem& D, bool pre) {
+    return lds_layout(D.nq, D.nv, D.nbody, D.njnt, D.n_frame, D.n_posture, D.n_com, D.max_rows, D.n_jrows + 1, 48,
+                      D.n_jrows * (lds_even(D.n_jrows) + 1), pre, false, true, D.n_hsel, true, true).total * (int)sizeof(double);
+  };
+  if (p->woodr_tables && p->nt == 48 && P.max_rows <= 8) {
+    P.prefetch_wc = waves_per_cu(48, woodr_bytes(P, true)) == waves_per_cu(48, woodr_bytes(P, false)) ? 1 : 0;
+    p->woodr_lds = woodr_bytes(P, P.prefetch_wc != 0);
   }
   {
     LaneProblem2 lp;
@@ -1343,6 +1377,10 @@ int32_t mkh_problem_create_diag(MkhModel* m, const MkhProblemDesc* d, int32_t ma
       T.prefetch = waves_per_cu(48, lds_t(true)) == waves_per_cu(48, lds_t(false)) ? 1 : 0;
       p->nt_tight = 48;
       p->lds_tight = lds_t(T.prefetch != 0);
+      if (p->woodr_tables && T.max_rows <= 8) {               // the tight launch with the low-rank start (round 6)
+        T.prefetch_wc = waves_per_cu(48, woodr_bytes(T, true)) == waves_per_cu(48, woodr_bytes(T, false)) ? 1 : 0;
+        p->woodr_lds_tight = woodr_bytes(T, T.prefetch_wc != 0);
+      }
       if (hipMalloc((void**)&p->d_dev_tight, sizeof(DeviceProblem)) != hipSuccess ||
           hipMemcpy(p->d_dev_tight, &T, sizeof(DeviceProblem), hipMemcpyHostToDevice) != hipSuccess ||
           hipMalloc((void**)&p->d_status_tight, (size_t)p->max_batch * sizeof(int32_t)) != hipSuccess)
@@ -1647,6 +1685,10 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
     nt = p->wood_nt; nr = p->wood_nr; lds = p->wood_lds_bytes;
     feat = F_WOOD | (need & (F_STEPS | F_TAPS | F_COM)) | (p->wood_big ? F_COM : 0);
   }
+  // ... and, round 6, with half-space rows (`48_40_r48`: analytic collision pairs; mkh_problem_create "low-rank start WITH half-space
+  // rows"): the launch that does the work of a plain collision solve — the tight-rows one where it exists, else the main one
+  const bool woodr_ok = a.do_qp && !taps && feat == F_COLL && !(flags & MKH_FLAG_DIRECT_QP) && dg_min > 0.0 && dg_min >= 1e-7 * p->wood_max_cost2;
+  if (woodr_ok && p->woodr_lds && !p->d_dev_tight && nt == 48) { nr = 48; lds = p->woodr_lds; feat = F_WOOD | F_COLL; }
   // three resident waves per SIMD where a variant exists (FrameTask / PostureTask / RelativeFrameTask / ComTask, box limits)
   static const int kW3Variants[][2] = {{44, 0}};   // (44_6 and 44_16 still spill 34–76 VGPRs at 74 registers: scratch traffic makes them slower than their 2-waves builds)
   bool w3 = false;
@@ -1660,27 +1702,32 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   // tight rows first (see mkh_problem_create): plain solves on the capsule-only collision build whose caller takes the status
   const bool tight = p->d_dev_tight && (feat == (F_COLL | F_SIMPLE_COLL) || feat == F_COLL) && !nr && !w3 && a.do_qp && a.status_out && !taps &&
                      !(flags & MKH_FLAG_FULL_ROWS);
+  // (the tight launch itself on the low-rank start: same descriptor, its own LDS layout)
+  const bool tight_wood = tight && woodr_ok && p->woodr_lds_tight != 0;
+  const int t_feat = tight_wood ? (feat | F_WOOD) : feat, t_nr = tight_wood ? 48 : 0, t_lds = tight_wood ? p->woodr_lds_tight : p->lds_tight;
   const bool no_redo = (p->diag & MKH_DIAG_NO_TIGHT_REDO) != 0;              // (tests: what the tight launch alone leaves flagged)
+  char t_name[48];
+  snprintf(t_name, sizeof t_name, t_nr ? "ik_solve_kernel_%d_%d_r%d" : "ik_solve_kernel_%d_%d", p->nt_tight, t_feat, t_nr);
   if (tight && no_redo) {
-    const int gt = grid_for_variant(p, a.B, p->nt_tight, p->lds_tight, false);
+    const int gt = grid_for_variant(p, a.B, p->nt_tight, t_lds, false);
     SolveArgs at = a;
     at.work_counter = p->d_work;
     at.static_rounds = INT32_MAX;
-    if (mkh::launch_variant(p->nt_tight, 0, feat, false, gt, p->lds_tight, stream, p->d_dev_tight, at, nullptr) != 0)
-      return fail(MKH_E_INVALID, "no kernel variant ik_solve_kernel_%d_%d", p->nt_tight, feat);
+    if (mkh::launch_variant(p->nt_tight, t_nr, t_feat, false, gt, t_lds, stream, p->d_dev_tight, at, nullptr) != 0)
+      return fail(MKH_E_INVALID, "no kernel variant %s", t_name);
     HIP_OK(hipGetLastError());
-    snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_solve_kernel_%d_%d", p->nt_tight, feat);
+    snprintf(p->last_kernel, sizeof(p->last_kernel), "%s", t_name);
     return MKH_OK;
   }
   if (tight) {
-    const int gt = grid_for_variant(p, a.B, p->nt_tight, p->lds_tight, false);
+    const int gt = grid_for_variant(p, a.B, p->nt_tight, t_lds, false);
     SolveArgs at = a;
     at.work_counter = p->d_work;
     const int pw = a.B / gt;
     at.static_rounds = (pw >= kMinRoundsForTickets) ? static_rounds_for(pw, gt % p->model->num_cus == 0 && ((gt / p->model->num_cus) & 3) != 0) : INT32_MAX;
     HIP_OK(clk_begin(p, at, stream));                 // (clock builds: the stamps of the launch that does the work)
-    if (mkh::launch_variant(p->nt_tight, 0, feat, false, gt, p->lds_tight, stream, p->d_dev_tight, at, nullptr) != 0)
-      return fail(MKH_E_INVALID, "no kernel variant ik_solve_kernel_%d_%d", p->nt_tight, feat);
+    if (mkh::launch_variant(p->nt_tight, t_nr, t_feat, false, gt, t_lds, stream, p->d_dev_tight, at, nullptr) != 0)
+      return fail(MKH_E_INVALID, "no kernel variant %s", t_name);
     HIP_OK(hipGetLastError());
   }
   int grid = grid_for_variant(p, a.B, nt, lds, w3);
@@ -1703,8 +1750,8 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   al.work_counter = p->d_work;
   if (tight) {
     al.redo_mask = MKH_ST_ROW_OVERFLOW;              // the full-row build: only what the tight launch flagged
-    snprintf(p->last_kernel, sizeof(p->last_kernel), "ik_solve_kernel_%d_%d+redo_%d", p->nt_tight, feat, nt);
-    p->last_nt = p->nt_tight; p->last_lds = p->lds_tight; p->last_grid = grid_for_variant(p, a.B, p->nt_tight, p->lds_tight, false);
+    snprintf(p->last_kernel, sizeof(p->last_kernel), "%s+redo_%d", t_name, nt);
+    p->last_nt = p->nt_tight; p->last_lds = t_lds; p->last_grid = grid_for_variant(p, a.B, p->nt_tight, t_lds, false);
   }
   // Distribution (ik_kernel.h): most of each wave's share is static — one contiguous row range per XCD — and the tail
   // of the batch goes through the ticket counter (how much: static_rounds_for above).  Round 1, on G1 (kernel ms by static
