@@ -108,7 +108,9 @@ def kernel_keys(kernel: str) -> list:
     main, _, redo = kernel.partition("+redo_")
     keys = [main]
     if redo:
-        feat = main.split("_")[4]
+        feat = int(main.split("_")[4])
+        if "_r" in main[len("ik_solve_kernel_"):]:        # (a tight launch on the low-rank start, `48_40_r48`: its redo is the direct build)
+            feat &= ~32
         keys.append(f"ik_solve_kernel_{redo}_{feat}")
     if wide:
         keys.append("ik_wide_kernel")

@@ -74,6 +74,7 @@ def test_bench_helpers():
     assert b.kernel_keys("ik_quad_kernel") == ["ik_quad_kernel<8,0,16>"] and b.kernel_keys("ik_quad_kernel_32") == ["ik_quad_kernel<32,0,32>"] and b.kernel_keys("ik_lane_kernel_6") == ["ik_lane_kernel<6,0>"]
     assert b.kernel_keys("ik_solve_kernel_64_8+wide") == ["ik_solve_kernel_64_8", "ik_wide_kernel"]
     assert b.kernel_keys("ik_solve_kernel_48_8+redo_64+wide") == ["ik_solve_kernel_48_8", "ik_solve_kernel_64_8", "ik_wide_kernel"]
+    assert b.kernel_keys("ik_solve_kernel_48_40_r48+redo_64+wide") == ["ik_solve_kernel_48_40_r48", "ik_solve_kernel_64_8", "ik_wide_kernel"]
     assert b.kernel_keys("convex_pre+ik_solve_kernel_16_8+wide") == ["convex_contacts_kernel", "ik_solve_kernel_16_8", "ik_wide_kernel"]
     assert b.kernel_keys("ik_solve_kernel_48_72+redo_64+wide") == ["ik_solve_kernel_48_72", "ik_solve_kernel_64_72", "ik_wide_kernel"]
 

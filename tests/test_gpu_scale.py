@@ -322,7 +322,7 @@ def test_cold_start_refinement_agrees_with_the_plain_low_rank_start(monkeypatch)
 
 _BENCH_KERNELS = {"ur5e_c2": "ik_quad_kernel", "g1_c3": "ik_solve_kernel_44_32_r44_w3", "g1_full": "ik_solve_kernel_44_36_r44_w3",
                   "shadow_c4": "ik_solve_kernel_48_72+redo_64", "g1_plugin": "ik_solve_kernel_48_256", "h1_c3": "ik_quad_kernel_32",
-                  "h1_full": "ik_quad_kernel_32", "g1_coll": "ik_solve_kernel_48_8+redo_64+wide", "ur5e_coll": "ik_solve_kernel_16_8",
+                  "h1_full": "ik_quad_kernel_32", "g1_coll": "ik_solve_kernel_48_40_r48+redo_64+wide", "ur5e_coll": "ik_solve_kernel_16_8",
                   "g1_hands": "ik_wide_kernel"}
 
 
@@ -474,7 +474,7 @@ def test_every_bench_workload_at_its_bench_batch_against_the_c_oracle(name, monk
         with nat.diag_options(nat.DIAG_NO_WIDE_REDO):
             alone, _, _ = workloads.bench_config(name, model, nm, B)
         v1, st1 = alone.solve(q, tg, pt, com, dt, damping)
-        assert alone.last_kernel() == "ik_solve_kernel_48_8+redo_64", alone.last_kernel()
+        assert alone.last_kernel() == "ik_solve_kernel_48_40_r48+redo_64", alone.last_kernel()
         flagged = np.flatnonzero(st1 & 16)
         # ... and the full-row build alone (MKH_FLAG_FULL_ROWS), another kernel with the same answers
         v_full, st_full = alone.solve(q, tg, pt, com, dt, damping, full_rows=True)
@@ -674,7 +674,7 @@ def test_humanoid_with_more_than_a_wavefront_of_analytic_pairs(monkeypatch):
                                  diag=0 if cull else nat.DIAG_NO_PAIR_CULL)
         q, tg = workloads.make_batch(model, nm, prob, np.random.default_rng(23), B, base_q=stand, sigma=0.5)
         v, st = prob.solve(q, tg, stand[None, :], None, dt, damping)
-        assert prob.last_kernel() == "ik_solve_kernel_48_8+redo_64+wide", prob.last_kernel()
+        assert prob.last_kernel() == "ik_solve_kernel_48_40_r48+redo_64+wide", prob.last_kernel()
         out[cull] = (v, st)
     v, st = out[True]
     np.testing.assert_array_equal(v, out[False][0])
