@@ -466,4 +466,36 @@ __device__ __forceinline__ void geom_overlap_distance(int t1, V3 s1, V3 p1, Q4 q
   to = c.pos + (0.5 * sgn * c.dist) * c.n;
 }
 
+// Third part, on the pair's OWN lane (`if (lane == l)` behind the wave-level call): the expanding polytope's witness points onto
+// the exact features (convex_dev.h cvx_polish) — a certified stationary point next to its answer, same depth to its tolerance; the
+// answer stands when there is no certificate.  dist / from / to as geom_overlap_distance left them.
+__device__ __forceinline__ void geom_overlap_polish(int t1, V3 s1, V3 p1, Q4 q1, int t2, V3 s2, V3 p2, Q4 q2, double& dist, V3& from, V3& to) {
+#ifndef MKH_NO_POLISH
+  const bool flip = t1 > t2;
+  if (flip) {
+    int ti = t1; t1 = t2; t2 = ti;
+    V3 tv = s1; s1 = s2; s2 = tv; tv = p1; p1 = p2; p2 = tv;
+    Q4 tq = q1; q1 = q2; q2 = tq;
+  }
+  if (t1 == GEOM_MESH || t2 == GEOM_MESH) return;
+  const double r1 = (t1 == GEOM_SPHERE || t1 == GEOM_CAPSULE) ? s1.x : 0.0, r2 = (t2 == GEOM_SPHERE || t2 == GEOM_CAPSULE) ? s2.x : 0.0;
+  const double sgn = flip ? -1.0 : 1.0;
+  const V3 dv = to - from;                                   // = sgn·dist·n, n from geom 1 to geom 2 in the sorted order
+  const double l2 = dot(dv, dv);
+  if (!(l2 > 0.0) || !(dist < 0.0)) return;
+  const V3 n0 = (-sgn * cvx_rsqrt(l2)) * dv;
+  const double depth = -dist - r1 - r2;                      // of the cores
+  const Q4 q1c = qconj(q1);
+  const CvxPolish pl = cvx_polish(t1, s1, t2, s2, qmul(q1c, q2), qrot(q1c, p2 - p1), qrot(q1c, n0));
+  if (pl.ok && fabs(pl.h - depth) <= 1e-6 * fmax(depth, 1e-3)) {
+    const V3 n = qrot(q1, pl.n), a = p1 + qrot(q1, pl.a), b = p1 + qrot(q1, pl.b);
+    const double d = -(pl.h + r1 + r2);
+    const V3 pos = 0.5 * ((a + r1 * n) + (b - r2 * n));
+    dist = d;
+    from = pos - (0.5 * sgn * d) * n;
+    to = pos + (0.5 * sgn * d) * n;
+  }
+#endif
+}
+
 }  // namespace mkh

@@ -489,6 +489,210 @@ __device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom
   return r;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Witness points on the EXACT features (round 6; oracle/gjk.py `polish` is the numpy statement and carries the derivation).
+// GJK and the expanding polytope approximate a curved rim by chords: the distance converges to ~1e-13, the direction and the
+// witness points only to ~1e-6, and a row of G inherits that (`ur5e_convex`: v to 4e-6).  Both answers minimise the support
+// function of the difference over unit directions, h_D(n) = h_1(n) + h_2(−n) (signed distance −min h_D, n from shape 1 to
+// shape 2), with a ∈ F_1(n), b ∈ F_2(−n), a − b = h_D·n.  h_D is smooth except on the planes n·k = 0 (k a box axis, the axis of
+// a cylinder / a capsule's segment) and at the poles ±u of a cylinder.  Candidates, in this order: a pole within kKinkTol of
+// the given direction n0; the first two near planes together (n = ±k_a × k_b); each alone and none — Newton in the remaining
+// tangent space with the reduced Hessian Tᵀ(∇²h_1 + ∇²h_2)T − h_D·I (cylinder: (r/ρ)·t·tᵀ, ellipsoid: (S² − (S²d)(S²d)ᵀ/h²)/h,
+// zero otherwise).  A candidate is accepted only with a certificate: witnesses built from the support sets (a unique support
+// point fixes the other's through a − b = h_D·n; edge against edge is a 2 × 2 solve) lie in their shapes to kPolishTol.
+// Mesh hulls (kinks not enumerated) and non-unique witnesses (face against edge / face) keep the caller's answer.
+// Everything in the frame of shape 1: shape 2 sits at p21 with rotation R21.
+constexpr double kKinkTol = 1e-3, kPolishTol = 1e-10;
+
+
+// 1/√x: hardware estimate + two Newton steps (the routine normalises a dozen vectors per contact; the IEEE sqrt + division pair is
+// ≈ 30 instructions of one dependent chain each, on a single busy lane)
+__device__ __forceinline__ double cvx_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+
+__device__ __forceinline__ bool cvx_core_contains(int type, V3 size, V3 l, double tol) {
+  if (type == kGeomBox) return fabs(l.x) <= size.x + tol && fabs(l.y) <= size.y + tol && fabs(l.z) <= size.z + tol;
+  if (type == kGeomCylinder) return l.x * l.x + l.y * l.y <= (size.x + tol) * (size.x + tol) && fabs(l.z) <= size.y + tol;
+  if (type == kGeomEllipsoid) {
+    const double x = l.x / size.x, y = l.y / size.y, z = l.z / size.z;
+    return x * x + y * y + z * z <= 1.0 + 2.0 * tol / fmin(size.x, fmin(size.y, size.z));
+  }
+  if (type == kGeomCapsule) return l.x * l.x + l.y * l.y <= tol * tol && fabs(l.z) <= size.y + tol;
+  if (type == kGeomSphere) return dot(l, l) <= tol * tol;
+  return false;
+}
+
+// τᵀ·∇²h(d)·τ' of the core's support function, everything in the shape's own frame (d unit); ok = false at a cylinder's pole
+__device__ __forceinline__ void cvx_hess_form(int type, V3 size, V3 d, V3 t1, V3 t2, double& m11, double& m12, double& m22, bool& ok) {
+  if (type == kGeomCylinder) {
+    const double rho2 = d.x * d.x + d.y * d.y;
+    if (rho2 < 1e-24) { ok = false; return; }
+    const double ir = cvx_rsqrt(rho2);
+    const V3 t{-d.y * ir, d.x * ir, 0.0};
+    const double a = dot(t, t1), b = dot(t, t2), c = size.x * ir;
+    m11 += c * a * a; m12 += c * a * b; m22 += c * b * b;
+  } else if (type == kGeomEllipsoid) {
+    const V3 s2{size.x * size.x, size.y * size.y, size.z * size.z};
+    const V3 e{s2.x * d.x, s2.y * d.y, s2.z * d.z};
+    const double h2 = e.x * d.x + e.y * d.y + e.z * d.z, ih = cvx_rsqrt(h2), ih2 = ih * ih;
+    auto form = [&](V3 u, V3 w) { return ((s2.x * u.x * w.x + s2.y * u.y * w.y + s2.z * u.z * w.z) - dot(e, u) * dot(e, w) * ih2) * ih; };
+    m11 += form(t1, t1); m12 += form(t1, t2); m22 += form(t2, t2);
+  }
+}
+
+struct CvxPolish { bool ok; double h; V3 a, b, n; };
+#ifndef MKH_POLISH_ATTR
+#define MKH_POLISH_ATTR __forceinline__
+#endif
+// Inlined, with ONE evaluation site of the two support mappings (the Newton loop's; its last pass is the certificate's).  Measured
+// on `ur5e_convex` (phase clocks, collision phase per problem): as a real call every problem paid 68 k cycles for the callee-saved
+// blocks of a non-leaf collision phase, pair in range or not; with the support mapping as a callee of its own every evaluation
+// spilled the routine's live values around the call (≈ 4 k cycles each).
+__device__ MKH_POLISH_ATTR CvxPolish cvx_polish(const int t1, const V3 s1, const int t2, const V3 s2, const Q4 q21, const V3 p21, V3 n0) {
+  CvxPolish out{false, 0.0, {0, 0, 0}, {0, 0, 0}, {1, 0, 0}};
+  if (t1 == kGeomMesh || t2 == kGeomMesh) return out;
+  const M3 R21 = qmat(q21);
+  const double scale = fmax(fmax(fabs(s1.x), fmax(fabs(s1.y), fabs(s1.z))), fmax(fabs(s2.x), fmax(fabs(s2.y), fabs(s2.z))));
+  const double tol = kPolishTol * fmax(scale, 1e-3);
+  n0 = cvx_rsqrt(dot(n0, n0)) * n0;
+  // kink planes, slots 0-2: the axes of shape 1, 3-5: those of shape 2 (a box has three, a cylinder / capsule its z axis)
+  // (select chains on named values: a runtime index into R21.m would send the matrix to scratch)
+  const V3 c0{R21.m[0], R21.m[3], R21.m[6]}, c1{R21.m[1], R21.m[4], R21.m[7]}, c2{R21.m[2], R21.m[5], R21.m[8]};
+  auto kink = [&](int i) -> V3 {
+    const V3 r = i == 3 ? c0 : (i == 4 ? c1 : c2);
+    return i < 3 ? V3{i == 0 ? 1.0 : 0.0, i == 1 ? 1.0 : 0.0, i == 2 ? 1.0 : 0.0} : r;
+  };
+  const bool ax1 = t1 == kGeomBox, z1 = ax1 || t1 == kGeomCylinder || t1 == kGeomCapsule;
+  const bool ax2 = t2 == kGeomBox, z2 = ax2 || t2 == kGeomCylinder || t2 == kGeomCapsule;
+  int ka = -1, kb = -1;
+  {
+    const double d0 = fabs(n0.x), d1 = fabs(n0.y), d2 = fabs(n0.z), d3 = fabs(dot(n0, c0)), d4 = fabs(dot(n0, c1)), d5 = fabs(dot(n0, c2));
+    auto take = [&](bool has, double d, int i) { if (has && d < kKinkTol) { if (ka < 0) ka = i; else if (kb < 0) kb = i; } };
+    take(ax1, d0, 0); take(ax1, d1, 1); take(z1, d2, 2); take(ax2, d3, 3); take(ax2, d4, 4); take(z2, d5, 5);
+  }
+  const bool pole1 = t1 == kGeomCylinder && n0.x * n0.x + n0.y * n0.y < kKinkTol * kKinkTol;
+  const V3 cr2 = cross(n0, c2);
+  const bool pole2 = t2 == kGeomCylinder && dot(cr2, cr2) < kKinkTol * kKinkTol;
+  // candidates: 0 pole of 1, 1 pole of 2, 2 both near planes, 3 plane a, 4 plane b, 5 none
+#pragma nounroll
+  for (int c = 0; c < 6; ++c) {
+    int act_a = -1, act_b = -1, pole_of = 0;
+    V3 n = n0;
+    bool done = true;                                         // the direction is determined (no Newton)
+    if (c == 0) { if (!pole1) continue; n = V3{0.0, 0.0, n0.z >= 0.0 ? 1.0 : -1.0}; pole_of = 1; }
+    else if (c == 1) { if (!pole2) continue; n = (dot(n0, c2) >= 0.0 ? 1.0 : -1.0) * c2; pole_of = 2; }
+    else if (c == 2) {
+      if (kb < 0) continue;
+      const V3 x = cross(kink(ka), kink(kb));
+      const double l2 = dot(x, x);
+      if (!(l2 > 1e-12)) continue;
+      n = ((dot(x, n0) >= 0.0 ? 1.0 : -1.0) * cvx_rsqrt(l2)) * x;
+      act_a = ka; act_b = kb;
+    } else {
+      if (c == 3) { if (ka < 0) continue; act_a = ka; }
+      if (c == 4) { if (kb < 0) continue; act_a = kb; }
+      done = false;
+    }
+    const bool one = !done && act_a >= 0;
+    const V3 k = one ? kink(act_a) : V3{0, 0, 0};
+    if (one) n = n - dot(n, k) * k;
+    if (!done) n = cvx_rsqrt(dot(n, n)) * n;
+    bool good = true;
+    V3 a_s{0, 0, 0}, b_l{0, 0, 0}, b_s{0, 0, 0};
+    double h = 0.0;
+#pragma nounroll
+    for (int it = 0;; ++it) {
+      // the ONE evaluation site of the support mappings (b_l: the point of shape 2 in its own frame)
+      a_s = cvx_support_local(t1, s1, nullptr, 0, n);
+      b_l = cvx_support_local(t2, s2, nullptr, 0, mulT(R21, -1.0 * n));
+      b_s = p21 + mul(R21, b_l);
+      const V3 g = a_s - b_s;
+      h = dot(n, g);
+      if (done) break;
+      if (it == 8) { good = false; break; }
+      // Newton on the smooth piece: tangent basis, reduced Hessian
+      V3 ta, tb;
+      if (one) { ta = cross(n, k); ta = cvx_rsqrt(dot(ta, ta)) * ta; tb = ta; }
+      else {
+        const double ax = fabs(n.x), ay = fabs(n.y), az = fabs(n.z);
+        const bool ex = ax <= ay && ax <= az, ey = !ex && ay <= az;
+        const V3 e{ex ? 1.0 : 0.0, ey ? 1.0 : 0.0, (!ex && !ey) ? 1.0 : 0.0};
+        ta = cross(n, e); ta = cvx_rsqrt(dot(ta, ta)) * ta; tb = cross(n, ta);
+      }
+      double m11 = 0.0, m12 = 0.0, m22 = 0.0;
+      bool okh = true;
+      cvx_hess_form(t1, s1, n, ta, tb, m11, m12, m22, okh);
+      cvx_hess_form(t2, s2, mulT(R21, -1.0 * n), mulT(R21, ta), mulT(R21, tb), m11, m12, m22, okh);
+      if (!okh) { good = false; break; }
+      m11 -= h; m22 -= h;
+      const double thr = 1e-12 * fmax(1.0, fabs(h));
+      V3 delta;
+      if (one) {
+        if (!(m11 > thr)) { good = false; break; }
+        delta = (-dot(ta, g) * fast_rcp(m11)) * ta;
+      } else {
+        // (strict local minimum: both eigenvalues of the 2 × 2 form above the threshold — det > thr·(tr − thr), tr > 2·thr)
+        const double tr = m11 + m22, det = m11 * m22 - m12 * m12;
+        if (!(tr > 2.0 * thr && det > thr * (tr - thr))) { good = false; break; }
+        const double g1 = -dot(ta, g), g2 = -dot(tb, g), id = fast_rcp(det);
+        delta = ((m22 * g1 - m12 * g2) * id) * ta + ((m11 * g2 - m12 * g1) * id) * tb;
+      }
+      n = n + delta;
+      if (one) n = n - dot(n, k) * k;
+      n = cvx_rsqrt(dot(n, n)) * n;
+      // (quadratic convergence: a step below 1e-9 leaves an error below 1e-18 — the next pass only evaluates the certificate's points)
+      if (dot(delta, delta) < 1e-18) done = true;
+    }
+    if (!good) continue;
+    // ---- certificate: witnesses from the support sets
+    const int n1 = (act_a >= 0 && act_a < 3 ? 1 : 0) + (act_b >= 0 && act_b < 3 ? 1 : 0);
+    const int n2 = (act_a >= 3 ? 1 : 0) + (act_b >= 3 ? 1 : 0);
+    // 0 point, 1 segment, 2 face
+    const int set1 = (pole_of == 1 || n1 == 2) ? 2 : n1, set2 = (pole_of == 2 || n2 == 2) ? 2 : n2;
+    V3 a, b;
+    if (set1 == 0 && set2 == 0) {
+      const V3 r = (a_s - b_s) - h * n;
+      if (dot(r, r) > tol * tol) continue;
+      a = a_s; b = a - h * n;
+    } else if (set1 == 0) {
+      a = a_s; b = a - h * n;
+      if (!cvx_core_contains(t2, s2, mulT(R21, b - p21), tol)) continue;
+    } else if (set2 == 0) {
+      b = b_s; a = b + h * n;
+      if (!cvx_core_contains(t1, s1, a, tol)) continue;
+    } else if (set1 == 1 && set2 == 1) {
+      // edge / generator / core segment against the same: the support point with the coordinate along the shape's own active axis
+      // at either end (a box edge: ∓ its half-size there; a cylinder's generator or a capsule's core: ∓ the half-length)
+      const int j1 = (act_a >= 0 && act_a < 3) ? act_a : act_b, j2 = ((act_a >= 3) ? act_a : act_b) - 3;
+      const double e1 = ax1 ? (j1 == 0 ? s1.x : (j1 == 1 ? s1.y : s1.z)) : s1.y, e2 = ax2 ? (j2 == 0 ? s2.x : (j2 == 1 ? s2.y : s2.z)) : s2.y;
+      V3 a0 = a_s, bl0 = b_l;
+      if (j1 == 0) a0.x = -e1; else if (j1 == 1) a0.y = -e1; else a0.z = -e1;
+      if (j2 == 0) bl0.x = -e2; else if (j2 == 1) bl0.y = -e2; else bl0.z = -e2;
+      const V3 b0 = p21 + mul(R21, bl0);
+      const V3 ea = (2.0 * e1) * kink(j1), eb = (2.0 * e2) * kink(j2 + 3);
+      const double maa = dot(ea, ea), mab = -dot(ea, eb), mbb = dot(eb, eb);
+      const double det = maa * mbb - mab * mab;
+      if (fabs(det) < 1e-12 * maa * mbb) continue;            // parallel: the witness is not unique
+      const V3 r = (b0 + h * n) - a0;
+      const double r1 = dot(ea, r), r2 = -dot(eb, r), id = fast_rcp(det);
+      const double al = (mbb * r1 - mab * r2) * id, be = (maa * r2 - mab * r1) * id;
+      a = a0 + al * ea; b = b0 + be * eb;
+      const V3 rr = (a - b) - h * n;
+      if (!(al >= -1e-9 && al <= 1.0 + 1e-9 && be >= -1e-9 && be <= 1.0 + 1e-9) || dot(rr, rr) > tol * tol) continue;
+      b = a - h * n;
+    } else {
+      continue;
+    }
+    out.ok = true; out.h = h; out.a = a; out.b = b; out.n = n;
+    return out;
+  }
+  return out;
+}
+
 // One contact in mj_geomDistance's convention: n from geom 1 to geom 2, pos the midpoint of the witness points — in the frame
 // of geom 1 (the caller rotates pos / nrm back).
 // need_epa: the cores overlap — the caller runs cvx_epa for this pair at wave level (cvx_overlap_contact finishes the contact).
@@ -502,6 +706,16 @@ __device__ __forceinline__ bool cvx_distance(const ConvexRel& g, double margin, 
     dist = dc - r1 - r2;
     if (dist > margin) return false;
     nrm = (1.0 / dc) * (pb - pa);
+    // witness points on the exact features (cvx_polish above): same distance, certified
+#ifdef MKH_NO_POLISH                                // (A/B builds: the raw GJK / expanding-polytope answers)
+    const CvxPolish pl{false, 0.0, {0, 0, 0}, {0, 0, 0}, {1, 0, 0}};
+#else
+    const CvxPolish pl = cvx_polish(g.t1, g.s1, g.t2, g.s2, g.q21, g.p21, nrm);
+#endif
+    if (pl.ok && -pl.h > 0.0 && fabs(-pl.h - dc) <= 1e-6 * fmax(dc, 1e-3)) {
+      dc = -pl.h; pa = pl.a; pb = pl.b; nrm = pl.n;
+      dist = dc - r1 - r2;
+    }
     pos = 0.5 * ((pa + r1 * nrm) + (pb - r2 * nrm));
     return true;
   }
@@ -511,6 +725,8 @@ __device__ __forceinline__ bool cvx_distance(const ConvexRel& g, double margin, 
 }
 
 // the contact of an overlapping pair from the expanding polytope's answer: the deepest points a − b = depth·n
+// (the witness-point polish of such a pair runs on the pair's own lane afterwards — collide_dev.h geom_overlap_polish: inlined here,
+//  where all 64 lanes execute, it cost the `ur5e_convex` launch 0.1 ms of tail: the callee around it saves every register it touches)
 __device__ __forceinline__ void cvx_overlap_contact(const ConvexGeom& g1, const ConvexGeom& g2, const CvxEpa& e, double& dist, V3& pos, V3& nrm) {
   const double r1 = cvx_core_radius(g1), r2 = cvx_core_radius(g2);
   dist = -(e.depth + r1 + r2);

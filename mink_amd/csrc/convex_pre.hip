@@ -100,7 +100,10 @@ __global__ __launch_bounds__(64) void convex_contacts_kernel(const WideProblem* 
     double d_e; V3 f_e, t_e;
     geom_overlap_distance(cp->type1, V3{cp->size1[0], cp->size1[1], cp->size1[2]}, gp1, gq1, cp->type2,
                           V3{cp->size2[0], cp->size2[1], cp->size2[2]}, gp2, gq2, d_e, f_e, t_e, cp->vert1, cp->nvert1, cp->vert2, cp->nvert2, ws);
-    if (lane == l) { dist = d_e; from = f_e; to = t_e; }
+    if (lane == l) {
+      dist = d_e; from = f_e; to = t_e;
+      geom_overlap_polish(cp->type1, V3{cp->size1[0], cp->size1[1], cp->size1[2]}, gp1, gq1, cp->type2, V3{cp->size2[0], cp->size2[1], cp->size2[2]}, gp2, gq2, dist, from, to);
+    }
   }
   if (want) {
     double* o = out + (size_t)item * 7;

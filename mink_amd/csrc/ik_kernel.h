@@ -1638,10 +1638,19 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
     return finish_contact(cp, dist, from, to, hk, nrm, m1, m2);
   };
   // the same for ONE wave-uniform pair whose cores overlap, every lane cooperating (expanding polytope: overlap_pair above)
-  auto overlap_of = [&](int pi, double& hk, V3& nrm, V3& from, V3& to, uint64_t& m1, uint64_t& m2) -> bool {
+  // (mine: this lane is the pair's — it alone polishes the witness points, collide_dev.h geom_overlap_polish)
+  auto overlap_of = [&](int pi, bool mine, double& hk, V3& nrm, V3& from, V3& to, uint64_t& m1, uint64_t& m2) -> bool {
     const OverlapOut o = overlap_pair((const CollisionPairDev*)(pairs + pi), sX, XS, sEpa);
     from = o.from; to = o.to;
-    return finish_contact(pairs[pi], o.dist, from, to, hk, nrm, m1, m2);
+    double dist = o.dist;
+    if (mine) {
+      const auto& cp = pairs[pi];
+      V3 gp1, gp2;
+      Q4 gq1, gq2;
+      pair_poses(cp, gp1, gq1, gp2, gq2);
+      geom_overlap_polish(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2, V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, dist, from, to);
+    }
+    return finish_contact(pairs[pi], dist, from, to, hk, nrm, m1, m2);
   };
   // position of pair pi in the order (h, index) among all pairs (h = +inf: not detected)
   auto rank_of = [&](int k, double hk) -> int {            // (k: position in the candidate list, which is ascending in the pair index)
@@ -1691,7 +1700,7 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
           double hk_e = kInf;
           V3 n_e{1, 0, 0}, f_e{0, 0, 0}, t_e{0, 0, 0};
           uint64_t m1_e = 0, m2_e = 0;
-          const bool act_e = overlap_of(use_cull ? (int)sList[base + l] : base + l, hk_e, n_e, f_e, t_e, m1_e, m2_e);
+          const bool act_e = overlap_of(use_cull ? (int)sList[base + l] : base + l, lane == l, hk_e, n_e, f_e, t_e, m1_e, m2_e);
           if (lane == l) { active = act_e; hk = hk_e; nrm = n_e; from = f_e; to = t_e; m1 = m1_e; m2 = m2_e; }
         }
       }

@@ -2286,7 +2286,7 @@ __global__ __launch_bounds__(64) void geom_distance_eval_kernel(int n, const dou
     load(base + l, t1, s1, p1, q1, t2, s2, p2, q2);
     double d_e; V3 f_e, t_e;
     geom_overlap_distance(t1, s1, p1, q1, t2, s2, p2, q2, d_e, f_e, t_e, nullptr, 0, nullptr, 0, ws);
-    if (lane == l) { dist = d_e; from = f_e; to = t_e; }
+    if (lane == l) { dist = d_e; from = f_e; to = t_e; geom_overlap_polish(t1, s1, p1, q1, t2, s2, p2, q2, dist, from, to); }
   }
   if (want) {
     dist_out[i] = known ? dist : __builtin_nan("");

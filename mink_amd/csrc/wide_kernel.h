@@ -298,7 +298,10 @@ __device__ __attribute__((noinline)) void wide_contacts(const WideProblem* Pg, d
         double d_e; V3 f_e, t_e;
         geom_overlap_distance(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
                               V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, d_e, f_e, t_e, cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, sCws);
-        if (lane == l) { dist = d_e; from = f_e; to = t_e; }
+        if (lane == l) {
+          dist = d_e; from = f_e; to = t_e;
+          geom_overlap_polish(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2, V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, dist, from, to);
+        }
       }
       if (want) {
         const CollisionPairDev& cp = P.pairs[pi];

@@ -18,6 +18,7 @@ import numpy as np
 
 GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = 0, 2, 3, 4, 5, 6, 7
 MAX_ITERS = 128
+POLISH = True            # witness points on the exact features after GJK / the expanding polytope (polish below); tests switch it off to look at the raw answers
 GJK_PROGRESS = 1e-12     # an iteration that moves |v|² by less than this fraction ends the loop (convex_dev.h kGjkProgress)
 
 
@@ -293,6 +294,199 @@ def penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2):
     return depth + r1 + r2, nb, a, a - w
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Witness points on the exact features (round 6).  GJK and the expanding polytope approximate a curved rim by chords: the
+# distance converges to ~1e-13, the direction and the witness points only to ~1e-6 (thin simplices), and a row of G inherits
+# that.  Both answers are minimisers of the support function of the difference D = A ⊖ B over unit directions,
+#     h_D(n) = h_A(n) + h_B(−n),   signed distance = −min h_D   (n from shape 1 to shape 2; a local minimum when the cores overlap),
+# with witnesses a ∈ F_A(n), b ∈ F_B(−n) (the support SETS) and a − b = h_D(n)·n.  Given the approximate direction n0:
+#   * h_D is smooth except on KINKS: the planes n·k = 0 (k a box axis, the axis of a cylinder or of a capsule's segment) and the
+#     poles n = ±u of a cylinder.  The kinks within KINK_TOL of n0 are candidates to hold the minimiser exactly;
+#   * on a set of active kinks the direction is either determined (a pole; two planes: n = ±k₁ × k₂) or found by Newton in the
+#     remaining tangent space T with the reduced Hessian Tᵀ(∇²h_A(n) + ∇²h_B(−n))T − h_D(n)·I (the second term is the curvature
+#     of the unit sphere under a 1-homogeneous function; ∇²h of a cylinder is (r/ρ)·t·tᵀ along the rim, of an ellipsoid
+#     (S² − (S²d)(S²d)ᵀ/h²)/h, zero for polytopes, segments and points);
+#   * a candidate is ACCEPTED only with an exact certificate: witnesses built from the support sets (a unique support point of
+#     one shape fixes the other's witness through a − b = h_D·n; a segment against a segment is a 2 × 2 solve) must lie in their
+#     shapes to POLISH_TOL.  For separated shapes that is the optimality condition of a convex problem, so a wrongly snapped kink
+#     cannot pass.  No certificate (mesh hulls: their kinks are not enumerated; a face against an edge or a face: the witness is
+#     not unique) → the GJK / expanding-polytope answer stands.
+# mink_amd/csrc/convex_dev.h cvx_polish is the device statement.
+KINK_TOL, POLISH_TOL = 1e-3, 1e-10
+
+
+def _kinks(gtype, R):
+    """Unit normals k of the planes n·k = 0 on which the support point of the shape jumps."""
+    if gtype == GEOM_BOX:
+        return [R[:, 0], R[:, 1], R[:, 2]]
+    if gtype in (GEOM_CYLINDER, GEOM_CAPSULE):
+        return [R[:, 2]]
+    return []
+
+
+def _support_hessian(gtype, size, R, d):
+    """∇²h(d) of the core's support function at the unit direction d (world frame)."""
+    if gtype == GEOM_CYLINDER:
+        u = R[:, 2]
+        m = d - (d @ u) * u
+        rho = np.sqrt(m @ m)
+        if rho < 1e-12:
+            return None                                # (a pole: not smooth)
+        t = np.cross(u, m / rho)
+        return (size[0] / rho) * np.outer(t, t)
+    if gtype == GEOM_ELLIPSOID:
+        dl = R.T @ d
+        s2 = np.asarray(size[:3]) ** 2
+        h = np.sqrt(np.sum(s2 * dl * dl))
+        e = s2 * dl
+        return R @ ((np.diag(s2) - np.outer(e, e) / (h * h)) / h) @ R.T
+    return np.zeros((3, 3))
+
+
+def _contains(gtype, size, p, R, x, tol):
+    """x in the CORE of the shape, to the absolute tolerance tol."""
+    l = R.T @ (x - p)
+    if gtype == GEOM_BOX:
+        return bool(np.all(np.abs(l) <= np.asarray(size[:3]) + tol))
+    if gtype == GEOM_CYLINDER:
+        return bool(np.hypot(l[0], l[1]) <= size[0] + tol and abs(l[2]) <= size[1] + tol)
+    if gtype == GEOM_ELLIPSOID:
+        return bool(np.sum((l / np.asarray(size[:3])) ** 2) <= 1.0 + 2.0 * tol / min(size[:3]))
+    if gtype == GEOM_CAPSULE:
+        return bool(np.hypot(l[0], l[1]) <= tol and abs(l[2]) <= size[1] + tol)
+    if gtype == GEOM_SPHERE:
+        return bool(np.sqrt(l @ l) <= tol)
+    return False
+
+
+def _support_set(gtype, size, p, R, d, active, pole):
+    """The support set of the core along d: ('point', x) | ('segment', x0, x1) | ('face',) — `active`: the shape's kink planes d
+    lies on, `pole`: d is ± the axis of a cylinder."""
+    if gtype == GEOM_CYLINDER and pole:
+        return ("face",)
+    if not active:
+        return ("point", support(gtype, size, p, R, d))
+    if len(active) > 1:
+        return ("face",)
+    k = active[0]
+    # the two ends: support points a hair to either side of the plane
+    x0, x1 = support(gtype, size, p, R, d - 1e-6 * k), support(gtype, size, p, R, d + 1e-6 * k)
+    if gtype == GEOM_CYLINDER:                         # (the generator of d's radial direction, exactly)
+        c = support(gtype, size, p, R, d)
+        mid = c - ((c - p) @ k) * k
+        x0, x1 = mid - size[1] * k, mid + size[1] * k
+    return ("segment", x0, x1)
+
+
+def polish(t1, s1, p1, R1, t2, s2, p2, R2, n0):
+    """(signed core distance, a, b, n) with the witnesses on the exact features, or None without a certificate (see above)."""
+    if GEOM_MESH in (t1, t2):
+        return None
+    scale = max(float(np.max(np.abs(np.asarray(s1, dtype=np.float64).reshape(-1)[:3]))), float(np.max(np.abs(np.asarray(s2, dtype=np.float64).reshape(-1)[:3]))))
+    tol = POLISH_TOL * max(scale, 1e-3)
+    n0 = n0 / np.sqrt(n0 @ n0)
+    kinks = [(1, k) for k in _kinks(t1, R1)] + [(2, k) for k in _kinks(t2, R2)]
+    near = [(w, k) for (w, k) in kinks if abs(n0 @ k) < KINK_TOL]
+    poles = []
+    if t1 == GEOM_CYLINDER and np.linalg.norm(np.cross(n0, R1[:, 2])) < KINK_TOL:
+        poles.append((1, R1[:, 2] * (1.0 if n0 @ R1[:, 2] >= 0.0 else -1.0)))
+    if t2 == GEOM_CYLINDER and np.linalg.norm(np.cross(n0, R2[:, 2])) < KINK_TOL:
+        poles.append((2, R2[:, 2] * (1.0 if n0 @ R2[:, 2] >= 0.0 else -1.0)))
+
+    def h_of(n):
+        a, b = support(t1, s1, p1, R1, n), support(t2, s2, p2, R2, -n)
+        return a, b, float(n @ (a - b))
+
+    def certify(n, act, pole_of):
+        a_s, b_s, h = h_of(n)
+        A = _support_set(t1, s1, p1, R1, n, [k for (w, k) in act if w == 1], pole_of == 1)
+        Bs = _support_set(t2, s2, p2, R2, -n, [k for (w, k) in act if w == 2], pole_of == 2)
+        if A[0] == "point" and Bs[0] == "point":
+            a, b = A[1], Bs[1]
+            if np.linalg.norm((a - b) - h * n) > tol:
+                return None
+            b = a - h * n
+        elif A[0] == "point":
+            a = A[1]
+            b = a - h * n
+            if not _contains(t2, s2, p2, R2, b, tol):
+                return None
+        elif Bs[0] == "point":
+            b = Bs[1]
+            a = b + h * n
+            if not _contains(t1, s1, p1, R1, a, tol):
+                return None
+        elif A[0] == "segment" and Bs[0] == "segment":
+            ea, eb = A[2] - A[1], Bs[2] - Bs[1]
+            M = np.array([[ea @ ea, -(ea @ eb)], [-(ea @ eb), eb @ eb]])
+            if abs(np.linalg.det(M)) < 1e-12 * (ea @ ea) * (eb @ eb):
+                return None                            # parallel: the witness is not unique
+            r = Bs[1] + h * n - A[1]
+            al, be = np.linalg.solve(M, np.array([ea @ r, -(eb @ r)]))
+            a, b = A[1] + al * ea, Bs[1] + be * eb
+            if not (-1e-9 <= al <= 1.0 + 1e-9 and -1e-9 <= be <= 1.0 + 1e-9) or np.linalg.norm((a - b) - h * n) > tol:
+                return None
+            b = a - h * n
+        else:
+            return None
+        return -h, a, b, n
+
+    def newton(n, act):
+        ks = [k for (_, k) in act]
+        for k in ks:
+            n = n - (n @ k) * k
+        n = n / np.sqrt(n @ n)
+        for _ in range(8):
+            a, b, h = h_of(n)
+            if ks:
+                T = np.cross(n, ks[0])[:, None]
+                T = T / np.linalg.norm(T)
+            else:
+                e = np.zeros(3); e[int(np.argmin(np.abs(n)))] = 1.0
+                t1_ = np.cross(n, e); t1_ /= np.linalg.norm(t1_)
+                T = np.stack([t1_, np.cross(n, t1_)], axis=1)
+            HA, HB = _support_hessian(t1, s1, R1, n), _support_hessian(t2, s2, R2, -n)
+            if HA is None or HB is None:
+                return None
+            M = T.T @ (HA + HB) @ T - h * np.eye(T.shape[1])
+            if np.any(np.linalg.eigvalsh(M) <= 1e-12 * max(1.0, abs(h))):
+                return None                            # not a (strict) local minimum of the smooth piece
+            delta = T @ np.linalg.solve(M, -(T.T @ (a - b)))
+            n = n + delta
+            for k in ks:
+                n = n - (n @ k) * k
+            n = n / np.sqrt(n @ n)
+            if np.linalg.norm(delta) < 1e-9:           # (quadratic convergence: the error left is below 1e-18)
+                break
+        else:
+            return None                                # no convergence in eight steps
+        return n
+
+    # candidates in the device's order: the poles, the first two near kink planes together (slot order: the axes of shape 1, then
+    # those of shape 2; a third near plane is a degenerate pose and is ignored), each of them alone, none
+    near = near[:2]
+    cands = []
+    for (w, u) in poles:
+        cands.append((u, [], w))
+    if len(near) == 2:
+        c = np.cross(near[0][1], near[1][1])
+        if np.linalg.norm(c) > 1e-6:
+            c = c / np.linalg.norm(c)
+            cands.append((c * (1.0 if c @ n0 >= 0.0 else -1.0), [near[0], near[1]], 0))
+    for nk in near:
+        cands.append((None, [nk], 0))
+    cands.append((None, [], 0))
+    for n, act, pole_of in cands:
+        if n is None:
+            n = newton(n0.copy(), act)
+            if n is None:
+                continue
+        r = certify(n, act, pole_of)
+        if r is not None:
+            return r
+    return None
+
+
 def convex_distance(t1, s1, p1, R1, t2, s2, p2, R2, margin):
     """One contact (dist, pos, n) in mj_geomDistance's convention — n from geom 1 to geom 2, pos the midpoint of the
     witness points — or None beyond `margin`."""
@@ -303,8 +497,16 @@ def convex_distance(t1, s1, p1, R1, t2, s2, p2, R2, margin):
         if dist > margin:
             return None
         n = (pb - pa) / dist_c
+        pol = polish(t1, s1, p1, R1, t2, s2, p2, R2, n) if POLISH else None
+        if pol is not None and pol[0] > 0.0 and abs(pol[0] - dist_c) <= 1e-6 * max(dist_c, 1e-3):
+            dist_c, pa, pb, n = pol
+            dist = dist_c - r1 - r2
         a, b = pa + r1 * n, pb - r2 * n
         return dist, 0.5 * (a + b), n
     depth, n, a, b = penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2)
+    pol = polish(t1, s1, p1, R1, t2, s2, p2, R2, n) if POLISH else None
+    # (overlapping cores: a certified stationary point next to the polytope's answer — same depth to its tolerance)
+    if pol is not None and abs(-pol[0] - (depth - r1 - r2)) <= 1e-6 * max(depth - r1 - r2, 1e-3):
+        depth, a, b, n = -pol[0] + r1 + r2, pol[1], pol[2], pol[3]
     a, b = a + r1 * n, b - r2 * n                     # the deepest points: a − b = depth·n
     return -depth, 0.5 * (a + b), n

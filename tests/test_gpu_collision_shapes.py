@@ -266,13 +266,17 @@ CONVEX_PAIRS = [
 ]
 
 
+SEP_TOL = 1e-10     # rows of G of the general convex pairs (round 6: witness points polished onto the exact features; measured 6e-15)
+
+
 def test_general_convex_pairs_against_the_oracle():
     """The pairs MuJoCo sends to its general convex collider (no native routine): cylinder–box, cylinder–cylinder and the
     ellipsoid against every primitive — device (GJK on support mappings, convex_dev.h) against the numpy statement
-    (oracle/gjk.py, pinned against bounded minimisation in tests/test_oracle_gjk.py).  h to 1e-9; the rows of G to 1e-5:
-    the distance of a GJK run converges quadratically faster than its witness points (a support gap ε leaves an angle
-    √ε in the normal — 1e-7 at best, a few 1e-6 where a run ends on a thin simplex), and the two implementations may stop
-    one iteration apart.  (MuJoCo's own routine for these pairs, libccd MPR, runs to a tolerance of 1e-6.)"""
+    (oracle/gjk.py, pinned against bounded minimisation and by the KKT checker in tests/test_oracle_gjk.py).  h to 1e-9; the rows
+    of G to 1e-10 since round 6 (measured 6e-15 separated, 1.5e-14 overlapping): a GJK run leaves its witness points at ~1e-6 (a
+    support gap ε leaves an angle √ε in the normal, thin simplices lose the rest) and the expanding polytope's on an ellipsoid at
+    ~1e-2; both sides now move them onto the exact features with a certificate (convex_dev.h cvx_polish / oracle/gjk.py polish).
+    (MuJoCo's own routine for these pairs, libccd MPR, runs to a tolerance of 1e-6.)"""
     m = mink.loads_mjcf(CONVEX_SCENE)
     rng = np.random.default_rng(4)
     B = 192
@@ -287,6 +291,7 @@ def test_general_convex_pairs_against_the_oracle():
     active = np.zeros(9, dtype=int)
     apart = np.zeros(9, dtype=int)
     worst_near, n_near = np.zeros(9), np.zeros(9, dtype=int)
+    worst_sep = 0.0
     for i in range(B):
         o = oik.Configuration(m, q[i])
         G_ref, h_ref = oik.limit_inequalities(o, spec, dt)
@@ -296,21 +301,23 @@ def test_general_convex_pairs_against_the_oracle():
         sep = fin & (h_ref > 0.0)                       # separated by more than d_min: the Euclidean distance, exactly
         apart += sep
         np.testing.assert_allclose(h[i][sep], h_ref[sep], rtol=0, atol=1e-9 * max(1.0, np.abs(h_ref[sep]).max(initial=0.0)))
-        np.testing.assert_allclose(G[i][sep], G_ref[sep], atol=1e-5)
+        worst_sep = max(worst_sep, np.abs(G[i][sep] - G_ref[sep]).max(initial=0.0))
         np.testing.assert_array_equal(h[i][fin & ~sep], h_ref[fin & ~sep])      # closer than d_min (or overlapping): h = relaxation
         # ... and their rows: the direction of an OVERLAPPING pair is the smallest separating translation (expanding polytope,
-        # round 4).  Pairs of a cylinder / box / capsule converge to a face of the Minkowski difference; an ellipsoid against a
-        # curved shape stops at the vertex budget with the direction good to ~1e-2 (oracle/gjk.py EPA_MAXV), path-dependent
+        # round 4, polished in round 6: an ellipsoid against a curved shape used to stop at the vertex budget with the direction
+        # good to ~1e-2, path-dependent)
         near = fin & ~sep
         worst_near = np.maximum(worst_near, np.where(near, np.abs(G[i] - G_ref).max(axis=1), 0.0))
         n_near += near
     print("active / separated instances per pair:", list(zip([tuple(p) for p in col.geom_id_pairs], active, apart)))
+    print("rows of separated pairs: max |dG| %.2e" % worst_sep)
+    assert worst_sep < SEP_TOL
     assert (apart > 0).all(), apart
     types = [(int(m.geom_type[a]), int(m.geom_type[b])) for a, b in col.geom_id_pairs]
     print("rows of pairs inside d_min / overlapping: count, max |dG| per pair:", list(zip(types, n_near, worst_near)))
     assert n_near.sum() > 0
     for (ta, tb), w in zip(types, worst_near):
-        assert w < (2e-5 if 4 not in (ta, tb) else 5e-2), (ta, tb, w)      # (4 = ellipsoid)
+        assert w < 1e-10, (ta, tb, w)
     # the solve on instances that start outside d_min for every pair (the lean collision variant with the convex routine)
     q = _rand_q(m, rng, 4096)
     G, h = col.compute_qp_inequalities(mink.Configuration(m, q), dt)
@@ -330,10 +337,9 @@ def test_general_convex_pairs_against_the_oracle():
     dq = v * dt
     fin = np.isfinite(h)
     Gx = np.einsum("bpj,bj->bp", G, dq)
-    # (G here comes from the parity build's taps, v from the lean build: two compilations of the same GJK, whose witness
-    #  points — hence rows — agree to ~1e-7, the distance to 1e-13)
-    assert (Gx[fin] <= h[fin] + 1e-6).all()
-    binding = (np.abs(Gx - h) < 1e-6) & fin
+    # (G here comes from the parity build's taps, v from the lean build: two compilations of the same routine)
+    assert (Gx[fin] <= h[fin] + 1e-9).all()
+    binding = (np.abs(Gx - h) < 1e-9) & fin
     print("binding convex half-spaces: %d in %d instances" % (binding.sum(), binding.any(axis=1).sum()))
     assert binding.any(axis=1).sum() >= 8
     worst = 0.0
@@ -343,7 +349,7 @@ def test_general_convex_pairs_against_the_oracle():
         v_ref = oik.solve_ik(m, q[i], ts, dt, 1e-3, [oik.ConfigurationLimitSpec(), spec])
         worst = max(worst, np.abs(v[i] - v_ref).max() / max(1.0, np.abs(v_ref).max()))
     print("solve with general convex half-spaces vs oracle: max rel err %.2e" % worst)
-    assert worst < 1e-5
+    assert worst < 1e-9
 
 
 def _with_mesh_geoms(m, rng):

@@ -514,8 +514,10 @@ def _numpy_oracle_chunk(args):
 
 def test_ur5e_convex_at_its_bench_batch_against_the_numpy_oracle():
     """The sixth bench workload: a cylinder–box pair goes through the general convex routine, which the C restatement does
-    not carry — all 4 096 instances against the numpy restatement (oracle/gjk.py) on every host core.  Tolerance 2e-5: rows of
-    G from GJK witness points are good to ~1e-5 (the distance itself to 1e-13)."""
+    not carry — all 4 096 instances against the numpy restatement (oracle/gjk.py) on every host core.  Tolerance 1e-9 (SURVEY
+    §8d asks 1e-8) since round 6: the witness points of GJK / the expanding polytope are polished onto the exact features on
+    both sides (convex_dev.h cvx_polish, oracle/gjk.py polish; pinned by the KKT checker of tests/test_oracle_gjk.py) — measured
+    1.5e-13 on every instance, the 104 at or inside d_min included; with the raw witness points it was 3.7e-6."""
     import multiprocessing as mp
     import os
     from mink_amd import _native as nat
@@ -536,7 +538,7 @@ def test_ur5e_convex_at_its_bench_batch_against_the_numpy_oracle():
     v_ref = np.concatenate(parts)
     err = np.abs(v - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
     print("ur5e_convex: all %d instances vs numpy oracle: max rel err %.2e, p99 %.2e" % (B, err.max(), np.percentile(err, 99)))
-    assert err.max() < 2e-5
+    assert err.max() < 1e-9
 
 
 def _numpy_h_chunk(args):
@@ -550,8 +552,7 @@ def _numpy_h_chunk(args):
 
 
 def test_ur5e_convex_contact_distances_at_scale():
-    """`ur5e_convex` holds v to 2e-5 because a row of G inherits the accuracy of GJK's witness points; the DISTANCE behind h is
-    good to 1e-13.  h of both pairs (cylinder-plane analytic, cylinder-box through GJK / the expanding polytope) on all 4 096
+    """h of both pairs (cylinder-plane analytic, cylinder-box through GJK / the expanding polytope) on all 4 096
     instances of the bench batch against the numpy restatement at 1e-9·max(1, |h|) — which pairs are in range included."""
     import multiprocessing as mp
     import os
@@ -597,18 +598,20 @@ def test_convex_pairs_in_a_kernel_of_their_own_from_32768_items():
     assert prob.last_kernel() == "ik_solve_kernel_16_136+wide", prob.last_kernel()
     v_in = np.concatenate([p_[0] for p_ in parts])
     err = np.abs(v - v_in).max(axis=1) / np.maximum(1.0, np.abs(v_in).max(axis=1))
-    bad = np.flatnonzero(err >= 2e-5)
-    print("ur5e_convex, %d instances: split vs in-kernel routine max rel %.2e; beyond 2e-5: %d" % (B, err.max(), len(bad)))
-    # the two paths see the geoms through different FK rounding; where the cylinder sits AT or INSIDE d_min of the wall (h = 0) the
-    # normal comes from the expanding polytope's witness points and moves at the 1e-4 level with them (a handful of instances);
-    # everywhere else the rows agree to the tolerance of GJK
-    assert len(bad) <= B // 2000
+    bad = np.flatnonzero(err >= 1e-9)
+    print("ur5e_convex, %d instances: split vs in-kernel routine max rel %.2e; beyond 1e-9: %d" % (B, err.max(), len(bad)))
+    # the two paths see the geoms through different FK rounding; with the witness points polished onto the exact features (round 6)
+    # that is all that separates them (before: 2e-5, and the expanding polytope's witness points moved at the 1e-4 level) — except
+    # where the cylinder OVERLAPS the wall and the depth is almost flat in the direction: instance 32 654 of this batch has the rim
+    # against a vertical edge of the box, reduced curvature 0.0016 (the depth changes by 7e-7 over 0.03 rad, two local minima
+    # 1.2 % apart), the polytope stops at its vertex budget in one basin or the other and the polish certifies the one it is given
+    assert len(bad) <= B // 8192
     if len(bad):
         _, _, t = prob.solve(q[bad], tg[bad], pt, None, dt, damping, taps=["coll_h"], solve_qp=False)
         assert (t["coll_h"].min(axis=1) == 0.0).all(), t["coll_h"]
     v_ref = _numpy_oracle_chunk((name, np.arange(0, B, 1024), q, tg, pt, dt, damping))
     e2 = np.abs(v[::1024] - v_ref).max(axis=1) / np.maximum(1.0, np.abs(v_ref).max(axis=1))
-    assert e2.max() < 2e-5, e2.max()
+    assert e2.max() < 1e-9, e2.max()
 
 
 def test_the_bounding_sphere_cull_of_many_pairs_changes_nothing(monkeypatch):

@@ -156,7 +156,10 @@ def test_mesh_as_box_corners_is_the_box():
             s2 = SIZES[t2](rng)
             a = gjk.convex_distance(gjk.GEOM_MESH, corners, p1, R1, t2, s2, p2, R2, 10.0)
             b = gjk.convex_distance(gjk.GEOM_BOX, sb, p1, R1, t2, s2, p2, R2, 10.0)
-            assert abs(a[0] - b[0]) < 1e-12 and np.abs(a[2] - b[2]).max() < 1e-6
+            # (round 6: the box's witness points are polished onto the exact features, a mesh hull's are GJK's — its kinks are
+            #  not enumerated — so against a CURVED partner the normals differ by GJK's own error there)
+            ntol = 2e-5 if t2 in (gjk.GEOM_CYLINDER, gjk.GEOM_ELLIPSOID) else 1e-6
+            assert abs(a[0] - b[0]) < 1e-11 and np.abs(a[2] - b[2]).max() < ntol
         cons = mj._box_box(p1, R1.reshape(-1), sb, p2, R2.reshape(-1), sb, 10.0)
         d = gjk.convex_distance(gjk.GEOM_MESH, corners, p1, R1, gjk.GEOM_MESH, corners, p2, R2, 10.0)[0]
         d_ref = min(c[0] for c in cons)
@@ -230,3 +233,109 @@ def test_penetration_depth_is_the_global_minimum_over_directions():
             # the witness points are that translation apart, along n
             a, b = pos + 0.5 * dist * n, pos - 0.5 * dist * n
             assert abs(np.linalg.norm(a - b) + dist) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Round 6: witness points on the exact features (oracle/gjk.py polish; device: convex_dev.h cvx_polish).  The checker below shares
+# nothing with the support-mapping code: it takes the shapes as INEQUALITIES g(x) >= 0 (`_inside`), differentiates them, and asks
+# for multipliers of the Karush–Kuhn–Tucker conditions of  min |x − y|²  s.t.  x in A, y in B  by non-negative least squares.
+# The problem is convex, so a point that satisfies them to ε is the minimiser to ε.
+
+def _grad_inside(gtype, size, x):
+    """Rows: gradients of the constraints of `_inside` at x (local frame)."""
+    if gtype == gjk.GEOM_BOX:
+        return np.vstack([-np.eye(3), np.eye(3)])
+    if gtype == gjk.GEOM_CYLINDER:
+        return np.array([[-2 * x[0], -2 * x[1], 0.0], [0.0, 0.0, -1.0], [0.0, 0.0, 1.0]])
+    if gtype == gjk.GEOM_ELLIPSOID:
+        return np.array([-2 * x / size[:3] ** 2])
+    raise KeyError(gtype)
+
+
+def _kkt_residual(t1, s1, p1, R1, t2, s2, p2, R2, a, b, n):
+    """max over the two shapes of |unit normal − cone combination of the active constraint gradients|; also checks feasibility.
+    n: unit vector from a to b (separated) / the separating direction (overlapping)."""
+    from scipy.optimize import nnls
+    out = 0.0
+    for (t, s, p, R, x, d) in ((t1, s1, p1, R1, a, n), (t2, s2, p2, R2, b, -n)):
+        l = R.T @ (x - p)
+        g = _inside(t, s)(l)
+        scale = float(np.max(np.abs(s[:3])))
+        assert g.min() > -1e-11 * scale ** (2 if t != gjk.GEOM_BOX else 1), (t, g)
+        G = _grad_inside(t, s, l)
+        act = np.abs(g) < 1e-7 * scale ** 2
+        assert act.any(), (t, g)
+        # outward normal cone at x: −Σ λ_i ∇g_i, λ >= 0  must contain d (local frame)
+        Aeq = (-G[act]).T
+        Aeq = Aeq / np.maximum(np.linalg.norm(Aeq, axis=0), 1e-300)
+        lam, res = nnls(Aeq, R.T @ d)
+        out = max(out, res)
+    return out
+
+
+KKT_PAIRS = [(gjk.GEOM_CYLINDER, gjk.GEOM_BOX), (gjk.GEOM_CYLINDER, gjk.GEOM_CYLINDER), (gjk.GEOM_ELLIPSOID, gjk.GEOM_BOX),
+             (gjk.GEOM_ELLIPSOID, gjk.GEOM_CYLINDER), (gjk.GEOM_ELLIPSOID, gjk.GEOM_ELLIPSOID)]
+
+
+@pytest.mark.parametrize("pair", KKT_PAIRS)
+def test_polished_witness_points_satisfy_the_kkt_conditions_to_1e_10(pair):
+    """Separated pairs: GJK's own witness points miss the optimality conditions by 1e-8 … 1e-5 on curved features, the polished
+    ones hold them to 1e-10 — on every sample (the certificate is never missing for primitives)."""
+    rng = np.random.default_rng(100 + 7 * pair[0] + pair[1])
+    t1, t2 = pair
+    n_done, raw_worst, pol_worst = 0, 0.0, 0.0
+    while n_done < 120:
+        s1, s2 = SIZES[t1](rng), SIZES[t2](rng)
+        R1, R2 = _rand_rot(rng), _rand_rot(rng)
+        p1, p2 = np.zeros(3), rng.normal(size=3) * 0.35
+        d, pa, pb, ov = gjk.gjk_cores(t1, s1, p1, R1, t2, s2, p2, R2)
+        if ov or d < 1e-3:
+            continue
+        n_done += 1
+        n0 = (pb - pa) / d
+        r = gjk.polish(t1, s1, p1, R1, t2, s2, p2, R2, n0)
+        assert r is not None
+        dist, a, b, n = r
+        assert abs(dist - d) < 1e-7 * max(d, 1e-3) and abs(np.linalg.norm(b - a) - dist) < 1e-13
+        assert np.linalg.norm((b - a) / dist - n) < 1e-12
+        pol_worst = max(pol_worst, _kkt_residual(t1, s1, p1, R1, t2, s2, p2, R2, a, b, n))
+        try:
+            raw_worst = max(raw_worst, _kkt_residual(t1, s1, p1, R1, t2, s2, p2, R2, pa, pb, n0))
+        except AssertionError:
+            raw_worst = max(raw_worst, 1e-6)      # (a raw witness point that is not even on the boundary to 1e-7)
+        # and no closer pair exists: the brute-force minimiser agrees on the distance
+        if n_done % 30 == 0:
+            bf = _brute(t1, s1, p1, R1, t2, s2, p2, R2, rng)
+            assert not np.isfinite(bf) or abs(bf - dist) < 1e-6      # (inf: SLSQP gave up on all four starts)
+    print(pair, "KKT residual raw GJK %.1e, polished %.1e" % (raw_worst, pol_worst))
+    assert pol_worst < 1e-10
+    assert raw_worst > pol_worst
+
+
+def test_polished_overlapping_pairs_are_stationary_and_locally_minimal():
+    """Overlapping cores (the expanding polytope's answer polished): a − b = depth·n with n in the normal cone of A at a and −n in
+    that of B at b (same multiplier test), and no direction within 1e-3 rad of n has a smaller support width."""
+    rng = np.random.default_rng(77)
+    done = 0
+    while done < 60:
+        t1, t2 = KKT_PAIRS[done % 2]
+        s1, s2 = SIZES[t1](rng), SIZES[t2](rng)
+        R1, R2 = _rand_rot(rng), _rand_rot(rng)
+        p1, p2 = np.zeros(3), rng.normal(size=3) * 0.08
+        d, pa, pb, ov = gjk.gjk_cores(t1, s1, p1, R1, t2, s2, p2, R2)
+        if not ov:
+            continue
+        depth, n0, a0, b0 = gjk.penetration(t1, s1, p1, R1, 0.0, t2, s2, p2, R2, 0.0)
+        r = gjk.polish(t1, s1, p1, R1, t2, s2, p2, R2, n0)
+        if r is None:
+            continue                                  # (face against face / edge: no unique witness — the polytope's answer stands)
+        done += 1
+        sd, a, b, n = r
+        assert abs(-sd - depth) < 1e-6 * max(depth, 1e-3)
+        assert np.linalg.norm((a - b) - (-sd) * n) < 1e-12
+        assert _kkt_residual(t1, s1, p1, R1, t2, s2, p2, R2, a, b, n) < 1e-10
+        h = lambda m: m @ gjk.support(t1, s1, p1, R1, m) - m @ gjk.support(t2, s2, p2, R2, -m)
+        for _ in range(40):
+            m = n + 1e-3 * rng.normal(size=3)
+            m /= np.linalg.norm(m)
+            assert h(m) >= -sd - 1e-12
