@@ -738,6 +738,15 @@ def main():
             ref = recorded_reference_baseline(args.config)
             if ref is not None:
                 out["cpu_reference_recorded"] = ref
+        if world > 1:
+            # which fields of an N > 1 line were NOT measured by this run (round-5 review): the roofline's counter traffic and VALU
+            # view come from the committed single-GPU profile of the same kernel; the CPU baseline, the closed-loop legs, the
+            # PCIe-inclusive rate, the batch sweep and the other workloads are legs of the N = 1 line only
+            out["n1_only_fields"] = {"absent_here": ["cpu_baseline", "cpu_baseline_python", "cpu_reference_recorded", "loop20_targets_per_s",
+                                                     "converged_targets", "pcie_inclusive_value", "batch_sweep", "other_configs"],
+                                     "from_the_single_gpu_profile": ["roofline.traffic", "roofline.valu_issue_view", "roofline.binding_resource"],
+                                     "measured_by_this_run": ["value", "ms_per_step", "roofline.kernel_ms (rank 0)", "roofline.achieved", "per_rank",
+                                                              "scaling_view", "gather"]}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

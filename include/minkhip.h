@@ -97,9 +97,9 @@ extern "C" {
                                      * THIS problem handle (same batch size, instance i = instance i) ended.  The state lives
                                      * in the handle; it is used from its third solve on and reset when the batch size
                                      * changes.  Same optimum as a cold solve (the QP is strictly convex), fewer pivots:
-                                     * along an IK loop the active set changes by a few dofs per step.  The wavefront kernels
-                                     * and the row kernel of small robots (the lane kernel starts cold; both keep their
-                                     * partition inside mkh_solve_steps / _until). */
+                                     * along an IK loop the active set changes by a few dofs per step.  Every kernel
+                                     * family honours it: the wavefront kernels, the row kernel and (round 6) the lane kernel of
+                                     * small robots; all keep their partition inside mkh_solve_steps / _until. */
 #define MKH_FLAG_FULL_ROWS 512      /* collision problems: never launch the tight-rows variant first (fewer half-space rows than
                                      * geom pairs, the tightest contacts get them, flagged instances re-solved on the full-row
                                      * variant behind it) — parity/diagnostic switch */

@@ -357,10 +357,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LOOP ? 1 : 2
   // bound (any partition is a valid start).  On saturated problems (the benchmark's velocity limits: 5.8 of 6 dofs on a
   // bound) block principal pivoting then needs 1.2 factorisations on average instead of 3.4 from the all-free start
   // (counted on the tapped H, c, box of the benchmark batch; quad_kernel.h uses the same start).
+  // (the same across CALLS on one handle — MKH_FLAG_WARM_START, SolveArgs::warm, round 6: the partition this instance's previous solve
+  //  ended with, from the handle's third call on, like the wavefront and row kernels; single solves only — a fused loop carries it)
+  const bool warm_in = !LOOP && A.warm != nullptr && A.warm_age >= 2;
 #pragma unroll
   for (int d = 0; d < NV; ++d) {
     x[d] = 0.0;
-    if (!(LOOP && step >= 2)) {
+    if (warm_in) {
+      int w = (d < nv) ? (int)A.warm[(size_t)pb * nv + d] : 0;
+      if ((w == 2 && !(hi[d] < kInf)) || (w == 1 && !(lo[d] > -kInf))) w = 0;    // (a bound that is not there any more)
+      st[d] = w;
+    } else if (!(LOOP && step >= 2)) {
       const double xd = -c[d] * fast_rcp(H[d][d]);
       st[d] = (d < nv) ? (xd > hi[d] ? 2 : (xd < lo[d] ? 1 : 0)) : 0;
     }
@@ -482,6 +489,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LOOP ? 1 : 2
       }
     }
     if (A.status_out) A.status_out[pb] = status_all;
+    if (!LOOP && A.warm != nullptr) {
+#pragma unroll
+      for (int d = 0; d < NV; ++d)
+        if (d < nv) A.warm[(size_t)pb * nv + d] = (int8_t)((status_all & 14) ? 0 : st[d]);
+    }
     if (LOOP && until) {
       if (A.iters_out) A.iters_out[pb] = it_done;
       if (A.converged_out) A.converged_out[pb] = conv_flag;

@@ -139,3 +139,38 @@ def test_failure_status(nat):
     vw, stw = prob.solve(q, tg, home[None, :], None, dt, damping, wave_kernel=True)
     assert prob.last_kernel() == "ik_solve_kernel_8_0"
     assert (st == stw).all() and st[3] & 2 and np.isnan(v[3]).all() and np.isfinite(np.delete(v, 3, axis=0)).all()
+
+
+def test_warm_start_across_calls_on_the_lane_kernel(nat):
+    """MKH_FLAG_WARM_START on the lane kernel (round 6; it used to start cold): a closed loop of single solves of a UR5e batch whose
+    velocity limits bind on most dofs — every step's v equals the cold solve's (the optimum is unique) whatever partition the previous
+    call left in the handle; a permuted batch (a wrong prediction for every instance) and a changed batch size (state reset) still
+    give the right answers."""
+    m = workloads.load_robot("ur5e")
+    nm = nat.NativeModel(m)
+    B = 1500
+    idx = [int(m.jnt_dofadr[j]) for j in range(m.njnt)]
+    kw = dict(frame_tasks=[nc._ft(m, "attachment_site", "site", 1.0, 1.0, 1.0)], posture_tasks=[{"cost": 1e-2}],
+              configuration_limits=[nc._cfg_limit(m)], velocity_limits=[{"indices": idx, "limit": np.full(6, 0.3)}], max_batch=B)
+    prob, cold = nat.NativeProblem(nm, **kw), nat.NativeProblem(nm, **kw)
+    home = m.key_qpos[0]
+    q, tg = workloads.make_batch(m, nm, prob, np.random.default_rng(8), B, base_q=home)
+    pt = home[None, :]
+    dt, damping = 5e-2, 1e-3
+    rel = lambda a, b: np.abs(a - b).max(axis=1) / np.maximum(1.0, np.abs(b).max(axis=1))
+    qw, worst = q.copy(), 0.0
+    for step in range(10):
+        vw, stw = prob.solve(qw, tg, pt, None, dt, damping, warm_start=True, lane_kernel=True)
+        assert prob.last_kernel() == "ik_lane_kernel_6", prob.last_kernel()
+        vc, stc = cold.solve(qw, tg, pt, None, dt, damping, lane_kernel=True)
+        assert (stw == stc).all() and (stw & ~1 == 0).all()
+        worst = max(worst, rel(vw, vc).max())
+        qw = nm.integrate(qw, vw, dt)
+    print("UR5e: closed loop of 10 warm-started lane-kernel solves vs cold solves: max rel |dv| = %.2e" % worst)
+    assert worst < 1e-9
+    perm = np.random.default_rng(0).permutation(B)
+    vp, _ = prob.solve(qw[perm], tg[perm], pt, None, dt, damping, warm_start=True, lane_kernel=True)
+    vc, _ = cold.solve(qw[perm], tg[perm], pt, None, dt, damping, lane_kernel=True)
+    assert rel(vp, vc).max() < 1e-9
+    vh, _ = prob.solve(qw[:100], tg[:100], pt, None, dt, damping, warm_start=True, lane_kernel=True)
+    assert rel(vh, cold.solve(qw[:100], tg[:100], pt, None, dt, damping, lane_kernel=True)[0]).max() < 1e-9
