@@ -1762,27 +1762,32 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
   wave_sync();
   // G[s][lane] = −nᵀ(jacp₂(to) − jacp₁(from))   (compute_contact_normal_jacobian :59-72)
   // (two rows per trip: the rows are independent chains of ≈40 dependent fp64 operations)
+  // (robots up to 32 dofs — the Shadow hand of BASELINE config 4: 24 — put a row on each HALF of the wavefront, four rows per trip:
+  //  lane l works on dof l % 32 of row s + l / 32; round 6, the ≈ 17 rows of a Shadow instance took nine trips with 24 busy lanes)
   {
-    const double* ax = sDof + (is_dof ? lane : 0) * 10;
+    const bool halves = AS <= 32;
+    const int dl = halves ? (lane & 31) : lane, half = halves ? (lane >> 5) : 0, stride = halves ? 2 : 1;
+    const bool dof_l = dl < nv;
+    const double* ax = sDof + (dof_l ? dl : 0) * 10;
     const V3 d_ang{ax[0], ax[1], ax[2]}, d_lin{ax[3], ax[4], ax[5]}, d_anchor{ax[6], ax[7], ax[8]};
     auto row_entry = [&](int s) -> double {
       const double* o = sCol + s * 16;
       const uint64_t m1 = (uint64_t)__double_as_longlong(o[10]), m2 = (uint64_t)__double_as_longlong(o[11]);
       V3 n{o[0], o[1], o[2]};
       V3 dj{0, 0, 0};
-      if ((m2 >> lane) & 1) dj = dj + d_lin + cross(d_ang, V3{o[6], o[7], o[8]} - d_anchor);
-      if ((m1 >> lane) & 1) dj = dj - (d_lin + cross(d_ang, V3{o[3], o[4], o[5]} - d_anchor));
-      const double a = is_dof ? -dot(n, dj) : 0.0;
+      if ((m2 >> dl) & 1) dj = dj + d_lin + cross(d_ang, V3{o[6], o[7], o[8]} - d_anchor);
+      if ((m1 >> dl) & 1) dj = dj - (d_lin + cross(d_ang, V3{o[3], o[4], o[5]} - d_anchor));
+      const double a = dof_l ? -dot(n, dj) : 0.0;
       return a;
     };
-    int s = 0;
-    for (; s + 1 < nrows; s += 2) {
-      const double a0 = row_entry(s), a1 = row_entry(s + 1);
-      if (lane < AS) { sA[s * AS + lane] = a0; sA[(s + 1) * AS + lane] = a1; }
-    }
-    if (s < nrows) {
-      const double a0 = row_entry(s);
-      if (lane < AS) sA[s * AS + lane] = a0;
+    for (int s = 0; s < nrows; s += 2 * stride) {
+      // (a row past the last one: evaluated on the last row's record, not stored)
+      const int r0 = s + half, r1 = s + stride + half;
+      const double a0 = row_entry(r0 < nrows ? r0 : nrows - 1), a1 = row_entry(r1 < nrows ? r1 : nrows - 1);
+      if (dl < AS) {
+        if (r0 < nrows) sA[r0 * AS + dl] = a0;
+        if (r1 < nrows) sA[r1 * AS + dl] = a1;
+      }
     }
   }
   (void)NT;

@@ -119,7 +119,7 @@ def test_production_kernels_do_not_spill_vector_registers():
     #  `44_52_r44_w3` — the fused loops of the G1 full example on ten wavefronts per CU — enters with the 2 spilled VGPRs of its
     #  sibling `44_48_r44_w3`: 2.62 -> 3.01 M targets/s against the spill-free two-waves build it replaces as the default.
     #  Round 6 raised the builds that CARRY the general convex routine — `32/44/48/64_136`, `32/44/48/64_30`, `ik_wide_kernel`
-    #  80 -> 110 — by 4 ... 30: the witness-point polish behind GJK / the expanding polytope (convex_dev.h cvx_polish), a PARITY fix:
+    #  80 -> 110 — by 4 ... 34 (4 of them: the contact rows' two-halves loop of the collision-phase callee, Shadow 0.332 -> 0.317 ms): the witness-point polish behind GJK / the expanding polytope (convex_dev.h cvx_polish), a PARITY fix:
     #  `ur5e_convex` v 3.7e-6 -> 1.5e-13, rows of G 1e-5 -> 2e-14 on all 4 096 instances.  The compiler's count for a kernel includes
     #  its callees here; the added spills sit in the collision-phase callee (`44_136`: 192 scratch stores there, 7 in the kernel
     #  body — as before; `ik_wide_kernel`: wide_contacts 104 -> 233, the QP callees unchanged), the bench line of every workload on
