@@ -487,7 +487,10 @@ __device__ __forceinline__ void geom_overlap_polish(int t1, V3 s1, V3 p1, Q4 q1,
   const double depth = -dist - r1 - r2;                      // of the cores
   const Q4 q1c = qconj(q1);
   const CvxPolish pl = cvx_polish(t1, s1, t2, s2, qmul(q1c, q2), qrot(q1c, p2 - p1), qrot(q1c, n0));
-  if (pl.ok && fabs(pl.h - depth) <= 1e-6 * fmax(depth, 1e-3)) {
+  // (the same basin: a direction within 0.14 rad of the polytope's and a depth no larger than the polytope's own — which stops on a
+  //  vertex budget for doubly curved pairs, a few 1e-4 above the minimum — and within 1 % of it)
+  const double dscale = fmax(depth, 1e-3);
+  if (pl.ok && dot(pl.n, qrot(q1c, n0)) >= 0.99 && pl.h <= depth + 1e-9 * dscale && pl.h >= depth - 1e-2 * dscale) {
     const V3 n = qrot(q1, pl.n), a = p1 + qrot(q1, pl.a), b = p1 + qrot(q1, pl.b);
     const double d = -(pl.h + r1 + r2);
     const V3 pos = 0.5 * ((a + r1 * n) + (b - r2 * n));

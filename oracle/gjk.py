@@ -505,8 +505,10 @@ def convex_distance(t1, s1, p1, R1, t2, s2, p2, R2, margin):
         return dist, 0.5 * (a + b), n
     depth, n, a, b = penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2)
     pol = polish(t1, s1, p1, R1, t2, s2, p2, R2, n) if POLISH else None
-    # (overlapping cores: a certified stationary point next to the polytope's answer — same depth to its tolerance)
-    if pol is not None and abs(-pol[0] - (depth - r1 - r2)) <= 1e-6 * max(depth - r1 - r2, 1e-3):
+    # (overlapping cores: a certified stationary point in the polytope's basin — a direction within 0.14 rad of its answer and a depth
+    #  no larger than its own, which stops on a vertex budget a few 1e-4 above the minimum for doubly curved pairs, and within 1 %)
+    dc_, ds_ = depth - r1 - r2, max(depth - r1 - r2, 1e-3)
+    if pol is not None and pol[3] @ n >= 0.99 and -pol[0] <= dc_ + 1e-9 * ds_ and -pol[0] >= dc_ - 1e-2 * ds_:
         depth, a, b, n = -pol[0] + r1 + r2, pol[1], pol[2], pol[3]
     a, b = a + r1 * n, b - r2 * n                     # the deepest points: a − b = depth·n
     return -depth, 0.5 * (a + b), n

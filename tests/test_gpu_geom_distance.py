@@ -72,7 +72,8 @@ def test_device_geom_distance_against_the_oracle(pair):
         sep = hit & (d_ref > 1e-6)
         assert sep.sum() > 10
         np.testing.assert_allclose(dist[sep], d_ref[sep], rtol=0, atol=1e-9)
-        tol = 1e-9 if pair in ANALYTIC_PAIRS else 5e-6          # (GJK: witness points converge like the root of the distance's error)
+        # (general convex pairs: 5e-6 before round 6 — GJK's witness points; polished onto the exact features they measure 7e-16)
+        tol = 1e-9
         np.testing.assert_allclose(fromto[sep], ft_ref[sep], rtol=0, atol=tol)
         np.testing.assert_array_equal(fromto[~hit], 0.0)
 
@@ -97,20 +98,25 @@ def test_overlapping_general_convex_pairs_against_the_oracle(pair):
     err_p = np.abs(fromto - ft_ref).max(axis=1)[deep]
     print(pair, "overlapping:", int(deep.sum()), "max |d depth| %.2e, max angle %.2e, max |d fromto| %.2e; p90 angle %.2e"
           % (err_d.max(), ang.max(), err_p.max(), np.percentile(ang, 90)))
-    if flat:
-        assert err_d.max() < 1e-8 and ang.max() < 2e-5 and err_p.max() < 2e-5
-    else:
-        # two curved shapes: where the nearest boundary point lies on a doubly curved patch (rim against rim, an ellipsoid) the
-        # polytope may stop on its vertex budget or on the sliver guard — one iteration apart on the two sides
-        assert err_d.max() < 1e-7 and ang.max() < 2e-3 and np.percentile(ang, 90) < 1e-5 and err_p.max() < 2e-4
+    # (before round 6: flat pairs 1e-8 / 2e-5 / 2e-5; two curved shapes — the polytope stops on its vertex budget or on the sliver
+    #  guard, one iteration apart on the two sides — 1e-7 / 2e-3 / 2e-4.  With the witness points polished onto the exact features
+    #  the 256 instances of every pair measure ≤ 3e-15 in depth and ≤ 1.5e-10 in the points)
+    assert err_d.max() < 1e-12 and ang.max() < 1e-7 and err_p.max() < 1e-9
     # the witness points lie ON the two shapes and are the smallest separating translation apart — device side, by itself
     t1, s1, p1, q1, t2, s2, p2, q2 = a
+    # (round 6: on the shapes to 1e-9 wherever the polish found a certificate — nearly every instance; where it did not — a face
+    #  against a face or an edge, a stationary point that is not a strict minimum — the polytope's own witness stands, a chord off
+    #  a curved patch: 1e-5 for the flat pair, 5e-3 otherwise, as before)
+    exact = 0
     for i in np.flatnonzero(deep):
         R1, R2 = _quat2mat(q1[i]).reshape(3, 3), _quat2mat(q2[i]).reshape(3, 3)
         la, lb = R1.T @ (fromto[i, :3] - p1[i]), R2.T @ (fromto[i, 3:] - p2[i])
-        tol_w = 1e-5 if flat else 5e-3          # (a polytope that stopped on its budget leaves its witness a chord off a curved patch)
-        assert _outside(t1[i], s1[i], la) < tol_w and _outside(t2[i], s2[i], lb) < tol_w, (i, la, lb)
+        out = max(_outside(t1[i], s1[i], la), _outside(t2[i], s2[i], lb))
+        assert out < (1e-5 if flat else 5e-3), (i, la, lb)
+        exact += out < 1e-9
         assert abs(np.linalg.norm(fromto[i, 3:] - fromto[i, :3]) + dist[i]) < 1e-9
+    print(pair, "witness points on their shapes to 1e-9: %d of %d" % (exact, deep.sum()))
+    assert exact >= 0.9 * deep.sum()
 
 
 def _outside(t, s, x):
