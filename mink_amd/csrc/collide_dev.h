@@ -447,8 +447,10 @@ __device__ __forceinline__ bool geom_pair_runs_gjk(int a, int b) {
 
 // Second half of geom_distance for a general convex pair whose cores overlap: every lane of the wavefront calls this with
 // the SAME (wave-uniform) pair; ws = the expanding polytope's LDS workspace (kEpaWsDoubles).
+// tol: the polytope's gap tolerance — kEpaTol, or kLooseEpa for the run in front of the polish (geom_overlap_loose below says when)
 __device__ __forceinline__ void geom_overlap_distance(int t1, V3 s1, V3 p1, Q4 q1, int t2, V3 s2, V3 p2, Q4 q2, double& dist, V3& from,
-                                                      V3& to, const double* hv1, int hn1, const double* hv2, int hn2, double* ws) {
+                                                      V3& to, const double* hv1, int hn1, const double* hv2, int hn2, double* ws,
+                                                      const double tol = kEpaTol) {
   const bool flip = t1 > t2;
   if (flip) {
     int ti = t1; t1 = t2; t2 = ti;
@@ -457,7 +459,7 @@ __device__ __forceinline__ void geom_overlap_distance(int t1, V3 s1, V3 p1, Q4 q
     const double* th = hv1; hv1 = hv2; hv2 = th; ti = hn1; hn1 = hn2; hn2 = ti;
   }
   const ConvexGeom g1{t1, s1, p1, qmat(q1), hv1, hn1}, g2{t2, s2, p2, qmat(q2), hv2, hn2};
-  const CvxEpa e = cvx_epa(g1, g2, ws);
+  const CvxEpa e = cvx_epa(g1, g2, ws, tol);
   Contact c;
   cvx_overlap_contact(g1, g2, e, c.dist, c.pos, c.n);
   const double sgn = flip ? -1.0 : 1.0;
@@ -469,7 +471,17 @@ __device__ __forceinline__ void geom_overlap_distance(int t1, V3 s1, V3 p1, Q4 q
 // Third part, on the pair's OWN lane (`if (lane == l)` behind the wave-level call): the expanding polytope's witness points onto
 // the exact features (convex_dev.h cvx_polish) — a certified stationary point next to its answer, same depth to its tolerance; the
 // answer stands when there is no certificate.  dist / from / to as geom_overlap_distance left them.
-__device__ __forceinline__ void geom_overlap_polish(int t1, V3 s1, V3 p1, Q4 q1, int t2, V3 s2, V3 p2, Q4 q2, double& dist, V3& from, V3& to) {
+// Returns whether the answer is certified.  The callers run the polytope LOOSE first (geom_overlap_loose: not for mesh hulls, which
+// the polish never certifies) and once more at kEpaTol when this returns false — `tight` says which run's answer comes in.
+__device__ __forceinline__ bool geom_overlap_loose(int t1, int t2) {
+#ifdef MKH_NO_POLISH
+  return false;
+#else
+  return t1 != GEOM_MESH && t2 != GEOM_MESH;
+#endif
+}
+__device__ __forceinline__ bool geom_overlap_polish(int t1, V3 s1, V3 p1, Q4 q1, int t2, V3 s2, V3 p2, Q4 q2, double& dist, V3& from, V3& to,
+                                                    const bool tight = true) {
 #ifndef MKH_NO_POLISH
   const bool flip = t1 > t2;
   if (flip) {
@@ -477,12 +489,12 @@ __device__ __forceinline__ void geom_overlap_polish(int t1, V3 s1, V3 p1, Q4 q1,
     V3 tv = s1; s1 = s2; s2 = tv; tv = p1; p1 = p2; p2 = tv;
     Q4 tq = q1; q1 = q2; q2 = tq;
   }
-  if (t1 == GEOM_MESH || t2 == GEOM_MESH) return;
+  if (t1 == GEOM_MESH || t2 == GEOM_MESH) return false;
   const double r1 = (t1 == GEOM_SPHERE || t1 == GEOM_CAPSULE) ? s1.x : 0.0, r2 = (t2 == GEOM_SPHERE || t2 == GEOM_CAPSULE) ? s2.x : 0.0;
   const double sgn = flip ? -1.0 : 1.0;
   const V3 dv = to - from;                                   // = sgn·dist·n, n from geom 1 to geom 2 in the sorted order
   const double l2 = dot(dv, dv);
-  if (!(l2 > 0.0) || !(dist < 0.0)) return;
+  if (!(l2 > 0.0) || !(dist < 0.0)) return false;
   const V3 n0 = (-sgn * cvx_rsqrt(l2)) * dv;
   const double depth = -dist - r1 - r2;                      // of the cores
   const Q4 q1c = qconj(q1);
@@ -490,15 +502,17 @@ __device__ __forceinline__ void geom_overlap_polish(int t1, V3 s1, V3 p1, Q4 q1,
   // (the same basin: a direction within 0.14 rad of the polytope's and a depth no larger than the polytope's own — which stops on a
   //  vertex budget for doubly curved pairs, a few 1e-4 above the minimum — and within 1 % of it)
   const double dscale = fmax(depth, 1e-3);
-  if (pl.ok && dot(pl.n, qrot(q1c, n0)) >= 0.99 && pl.h <= depth + 1e-9 * dscale && pl.h >= depth - 1e-2 * dscale) {
+  if (pl.ok && dot(pl.n, qrot(q1c, n0)) >= 0.99 && pl.h <= depth + (tight ? 1e-9 : 1e-5) * dscale && pl.h >= depth - 1e-2 * dscale) {
     const V3 n = qrot(q1, pl.n), a = p1 + qrot(q1, pl.a), b = p1 + qrot(q1, pl.b);
     const double d = -(pl.h + r1 + r2);
     const V3 pos = 0.5 * ((a + r1 * n) + (b - r2 * n));
     dist = d;
     from = pos - (0.5 * sgn * d) * n;
     to = pos + (0.5 * sgn * d) * n;
+    return true;
   }
 #endif
+  return false;
 }
 
 }  // namespace mkh

@@ -186,7 +186,10 @@ __device__ __forceinline__ CvxW4 cvx_closest_tetrahedron(V3 p0, V3 p1, V3 p2, V3
 constexpr int kGjkSlots = 32;                       // lanes of a wavefront that run GJK at the same time (the caller batches)
 constexpr int kGjkWsDoubles = 24 * kGjkSlots;
 // (in the frame of shape 1: pa / pb come out in that frame)
-__device__ __forceinline__ bool cvx_gjk(const ConvexRel& g, const double cutoff, double& dist, V3& pa, V3& pb, double* S) {
+// gap / progress: the support-gap and no-progress tolerances of the run (1e-14 / kGjkProgress; round 6: a LOOSE run — kLooseGap — in
+// front of the witness-point polish, cvx_distance)
+__device__ __forceinline__ bool cvx_gjk(const ConvexRel& g, const double cutoff, double& dist, V3& pa, V3& pb, double* S,
+                                        const double gap = 1e-14, const double progress = kGjkProgress) {
   auto ldW = [&](int k) -> V3 { const double* p = S + 6 * k * kGjkSlots; return V3{p[0], p[kGjkSlots], p[2 * kGjkSlots]}; };
   auto ldA = [&](int k) -> V3 { const double* p = S + (6 * k + 3) * kGjkSlots; return V3{p[0], p[kGjkSlots], p[2 * kGjkSlots]}; };
   auto st = [&](int k, V3 w, V3 a) {
@@ -218,7 +221,7 @@ __device__ __forceinline__ bool cvx_gjk(const ConvexRel& g, const double cutoff,
     const V3 a = cvx_support1(g, -1.0 * v);
     const V3 w = a - cvx_support2(g, v);
     const double vw = dot(v, w);
-    if (vv - vw <= 1e-14 * vv) break;             // no support point is closer to the origin along v: converged
+    if (vv - vw <= gap * vv) break;               // no support point is closer to the origin along v: converged
     lb = fmax(lb, vw / sqrt(vv));                 // every point of the difference is at least this far: a certified bound
     if (lb > cutoff) { dist = lb; return true; }
     const double tol = 1e-28 * scale;
@@ -255,7 +258,7 @@ __device__ __forceinline__ bool cvx_gjk(const ConvexRel& g, const double cutoff,
     // denominator lost) to rounding: the previous simplex (logical [0, n), weights lam) is the answer
     const double vnn = dot(vn, vn);
     if (vnn >= vv || vnn < lb * lb * (1.0 - 1e-10)) break;
-    const bool done = vv - vnn <= kGjkProgress * vv;          // the distance has stopped moving: this simplex is the answer
+    const bool done = vv - vnn <= progress * vv;              // the distance has stopped moving: this simplex is the answer
     // keep the kept vertices in their order: new slot numbers and weights
     const int full = ord | (fr << (2 * n));        // logical → physical of the simplex with the new vertex
     int nord = 0, c = 0;
@@ -311,7 +314,7 @@ __device__ __forceinline__ double wave_min_f64(double x) {
   return fmin(fmin(readlane_f64(x, 0), readlane_f64(x, 16)), fmin(readlane_f64(x, 32), readlane_f64(x, 48)));
 }
 
-__device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom& g2, double* ws) {
+__device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom& g2, double* ws, const double tol = kEpaTol) {
   const int lane = lane_id();
   double* const V = ws + kEpaOffV;                                   // vertex k: W at V[6k], A (its point on shape 1) at V[6k + 3]
   double* const F = ws + kEpaOffF;                                   // face s: unit normal F[4s..4s+2], plane offset F[4s+3]
@@ -392,7 +395,7 @@ __device__ __forceinline__ CvxEpa cvx_epa(const ConvexGeom& g1, const ConvexGeom
     const int ip = nvert;
     const V3 p = add(nb);
     const double gap = dot(nb, p) - off;
-    if (gap <= kEpaTol * fmax(1.0, fabs(off))) { --nvert; break; }          // the face is (within the gap) a face of D itself
+    if (gap <= tol * fmax(1.0, fabs(off))) { --nvert; break; }              // the face is (within the gap) a face of D itself
     if (lane < kEpaMaxV) E[lane] = 0ull;
     MKH_EPA_SYNC();
     // faces that see p, and one bit per directed edge of those
@@ -696,26 +699,40 @@ __device__ MKH_POLISH_ATTR CvxPolish cvx_polish(const int t1, const V3 s1, const
 // One contact in mj_geomDistance's convention: n from geom 1 to geom 2, pos the midpoint of the witness points — in the frame
 // of geom 1 (the caller rotates pos / nrm back).
 // need_epa: the cores overlap — the caller runs cvx_epa for this pair at wave level (cvx_overlap_contact finishes the contact).
+// Round 6: GJK first runs LOOSE (support gap kLooseGap instead of 1e-14: half the support evaluations on a curved rim, where it
+// converges linearly) — the polish finishes its answer exactly and its certificate says so; without one (mesh hulls, a witness that
+// is not unique) the tight run follows, and its answer stands if the polish has none for it either.  oracle/gjk.py convex_distance.
+constexpr double kLooseGap = 1e-6, kLooseEpa = 1e-6;
 __device__ __forceinline__ bool cvx_distance(const ConvexRel& g, double margin, double& dist, V3& pos, V3& nrm, bool& need_epa,
                                              double* gjk_slot) {
   const double r1 = (g.t1 == kGeomSphere || g.t1 == kGeomCapsule) ? g.s1.x : 0.0, r2 = (g.t2 == kGeomSphere || g.t2 == kGeomCapsule) ? g.s2.x : 0.0;
-  double dc = 0.0;
-  V3 pa{0, 0, 0}, pb{0, 0, 0};
-  const bool apart = cvx_gjk(g, margin + r1 + r2, dc, pa, pb, gjk_slot);
-  if (apart && dc > 1e-9) {                       // (cores apart: also when only the spherical shells overlap)
-    dist = dc - r1 - r2;
-    if (dist > margin) return false;
+#ifdef MKH_NO_POLISH
+  const bool loose = false;                         // (A/B builds: the raw GJK / expanding-polytope answers)
+#else
+  const bool loose = g.t1 != kGeomMesh && g.t2 != kGeomMesh;
+#endif
+#pragma nounroll
+  for (int pass = loose ? 0 : 1; pass < 2; ++pass) {
+    const bool tight = pass != 0;
+    double dc = 0.0;
+    V3 pa{0, 0, 0}, pb{0, 0, 0};
+    const bool apart = cvx_gjk(g, margin + r1 + r2, dc, pa, pb, gjk_slot, tight ? 1e-14 : kLooseGap, tight ? kGjkProgress : kLooseGap);
+    if (!(apart && dc > 1e-9)) break;               // (cores apart: also when only the spherical shells overlap)
+    if (dc - r1 - r2 > margin * (1.0 + 1e-3) + 1e-6) return false;     // (beyond the margin by more than a loose run can be off)
     nrm = (1.0 / dc) * (pb - pa);
-    // witness points on the exact features (cvx_polish above): same distance, certified
-#ifdef MKH_NO_POLISH                                // (A/B builds: the raw GJK / expanding-polytope answers)
+#ifdef MKH_NO_POLISH
     const CvxPolish pl{false, 0.0, {0, 0, 0}, {0, 0, 0}, {1, 0, 0}};
 #else
+    // witness points on the exact features (cvx_polish above): same distance, certified
     const CvxPolish pl = cvx_polish(g.t1, g.s1, g.t2, g.s2, g.q21, g.p21, nrm);
 #endif
-    if (pl.ok && -pl.h > 0.0 && fabs(-pl.h - dc) <= 1e-6 * fmax(dc, 1e-3)) {
+    if (pl.ok && -pl.h > 0.0 && fabs(-pl.h - dc) <= (tight ? 1e-6 : 1e-3) * fmax(dc, 1e-3)) {
       dc = -pl.h; pa = pl.a; pb = pl.b; nrm = pl.n;
-      dist = dc - r1 - r2;
+    } else if (!tight) {
+      continue;                                     // no certificate for the loose answer: the tight run
     }
+    dist = dc - r1 - r2;
+    if (dist > margin) return false;
     pos = 0.5 * ((pa + r1 * nrm) + (pb - r2 * nrm));
     return true;
   }

@@ -1498,7 +1498,8 @@ __device__ __forceinline__ WoodOut wood_start(const DeviceProblem*, int, int, in
 // every build: the path is rare (a pair in penetration) and its registers must not count against the phase around it; the
 // pair's descriptor and the body poses arrive as generic pointers.
 struct OverlapOut { double dist; V3 from, to; };
-__device__ __attribute__((noinline)) OverlapOut overlap_pair(const CollisionPairDev* cpp, const double* sX, int XS, double* ws) {
+__device__ __attribute__((noinline)) OverlapOut overlap_pair(const CollisionPairDev* cpp, const double* sX, int XS, double* ws, double tol) {
+  tol = uni(tol);
   cpp = reinterpret_cast<const CollisionPairDev*>(uni((unsigned long long)reinterpret_cast<size_t>(cpp)));
   sX = reinterpret_cast<const double*>(uni((unsigned long long)reinterpret_cast<size_t>(sX)));
   ws = reinterpret_cast<double*>(uni((unsigned long long)reinterpret_cast<size_t>(ws)));
@@ -1513,7 +1514,7 @@ __device__ __attribute__((noinline)) OverlapOut overlap_pair(const CollisionPair
   const Q4 gq2 = qmul(bq2, Q4{cp.lquat2[0], cp.lquat2[1], cp.lquat2[2], cp.lquat2[3]});
   OverlapOut o;
   geom_overlap_distance(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
-                        V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, o.dist, o.from, o.to, cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, ws);
+                        V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, o.dist, o.from, o.to, cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, ws, tol);
   return o;
 }
 __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapArgs* tp, int pb, double dt, int mode,
@@ -1640,15 +1641,23 @@ __device__ MKH_COLL_ATTR int collision_phase(const DeviceProblem* Pq, const TapA
   // the same for ONE wave-uniform pair whose cores overlap, every lane cooperating (expanding polytope: overlap_pair above)
   // (mine: this lane is the pair's — it alone polishes the witness points, collide_dev.h geom_overlap_polish)
   auto overlap_of = [&](int pi, bool mine, double& hk, V3& nrm, V3& from, V3& to, uint64_t& m1, uint64_t& m2) -> bool {
-    const OverlapOut o = overlap_pair((const CollisionPairDev*)(pairs + pi), sX, XS, sEpa);
-    from = o.from; to = o.to;
-    double dist = o.dist;
-    if (mine) {
-      const auto& cp = pairs[pi];
-      V3 gp1, gp2;
-      Q4 gq1, gq2;
-      pair_poses(cp, gp1, gq1, gp2, gq2);
-      geom_overlap_polish(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2, V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, dist, from, to);
+    // (loose polytope + polish; without a certificate the tight polytope, whose answer stands if the polish has none for it either)
+    double dist = 0.0;
+    bool certified = false;
+#pragma nounroll
+    for (int pass = geom_overlap_loose(pairs[pi].type1, pairs[pi].type2) ? 0 : 1; pass < 2 && !certified; ++pass) {
+      const OverlapOut o = overlap_pair((const CollisionPairDev*)(pairs + pi), sX, XS, sEpa, pass ? kEpaTol : kLooseEpa);
+      from = o.from; to = o.to;
+      dist = o.dist;
+      bool ok = false;
+      if (mine) {
+        const auto& cp = pairs[pi];
+        V3 gp1, gp2;
+        Q4 gq1, gq2;
+        pair_poses(cp, gp1, gq1, gp2, gq2);
+        ok = geom_overlap_polish(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2, V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, dist, from, to, pass != 0);
+      }
+      certified = __ballot(ok) != 0;
     }
     return finish_contact(pairs[pi], dist, from, to, hk, nrm, m1, m2);
   };

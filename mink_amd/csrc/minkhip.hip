@@ -2284,9 +2284,16 @@ __global__ __launch_bounds__(64) void geom_distance_eval_kernel(int n, const dou
     const int l = (int)__builtin_ctzll(em);
     int t1, t2; V3 s1, p1, s2, p2; Q4 q1, q2;
     load(base + l, t1, s1, p1, q1, t2, s2, p2, q2);
-    double d_e; V3 f_e, t_e;
-    geom_overlap_distance(t1, s1, p1, q1, t2, s2, p2, q2, d_e, f_e, t_e, nullptr, 0, nullptr, 0, ws);
-    if (lane == l) { dist = d_e; from = f_e; to = t_e; geom_overlap_polish(t1, s1, p1, q1, t2, s2, p2, q2, dist, from, to); }
+    // (loose polytope + polish on the pair's lane; without a certificate the tight polytope — collide_dev.h geom_overlap_polish)
+    bool certified = false;
+#pragma nounroll
+    for (int pass = geom_overlap_loose(t1, t2) ? 0 : 1; pass < 2 && !certified; ++pass) {
+      double d_e; V3 f_e, t_e;
+      geom_overlap_distance(t1, s1, p1, q1, t2, s2, p2, q2, d_e, f_e, t_e, nullptr, 0, nullptr, 0, ws, pass ? mkh::kEpaTol : mkh::kLooseEpa);
+      bool ok = false;
+      if (lane == l) { dist = d_e; from = f_e; to = t_e; ok = geom_overlap_polish(t1, s1, p1, q1, t2, s2, p2, q2, dist, from, to, pass != 0); }
+      certified = __ballot(ok) != 0;
+    }
   }
   if (want) {
     dist_out[i] = known ? dist : __builtin_nan("");

@@ -295,12 +295,20 @@ __device__ __attribute__((noinline)) void wide_contacts(const WideProblem* Pg, d
         const CollisionPairDev& cp = P.pairs[use_cull ? (int)sList[base + wave * kGjkSlots + l] : base + wave * kGjkSlots + l];
         V3 gp1, gp2; Q4 gq1, gq2;
         poses(cp, gp1, gq1, gp2, gq2);
-        double d_e; V3 f_e, t_e;
-        geom_overlap_distance(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
-                              V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, d_e, f_e, t_e, cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, sCws);
-        if (lane == l) {
-          dist = d_e; from = f_e; to = t_e;
-          geom_overlap_polish(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2, V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, dist, from, to);
+        // (loose polytope + polish on the pair's lane; without a certificate the tight polytope — collide_dev.h geom_overlap_polish)
+        const V3 sz1{cp.size1[0], cp.size1[1], cp.size1[2]}, sz2{cp.size2[0], cp.size2[1], cp.size2[2]};
+        bool certified = false;
+#pragma nounroll
+        for (int pass = geom_overlap_loose(cp.type1, cp.type2) ? 0 : 1; pass < 2 && !certified; ++pass) {
+          double d_e; V3 f_e, t_e;
+          geom_overlap_distance(cp.type1, sz1, gp1, gq1, cp.type2, sz2, gp2, gq2, d_e, f_e, t_e, cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, sCws,
+                                pass ? kEpaTol : kLooseEpa);
+          bool ok = false;
+          if (lane == l) {
+            dist = d_e; from = f_e; to = t_e;
+            ok = geom_overlap_polish(cp.type1, sz1, gp1, gq1, cp.type2, sz2, gp2, gq2, dist, from, to, pass != 0);
+          }
+          certified = __ballot(ok) != 0;
         }
       }
       if (want) {

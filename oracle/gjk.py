@@ -125,8 +125,10 @@ def _closest_tetrahedron(P):
     return best
 
 
-def gjk_cores(t1, s1, p1, R1, t2, s2, p2, R2):
-    """Closest points of the two cores: (distance, point on 1, point on 2, overlapping)."""
+def gjk_cores(t1, s1, p1, R1, t2, s2, p2, R2, gap=1e-14, progress=None):
+    """Closest points of the two cores: (distance, point on 1, point on 2, overlapping).  gap / progress: the support-gap and
+    no-progress tolerances of the run (round 6: a LOOSE run — 1e-6 — in front of the witness-point polish, convex_distance)."""
+    progress = GJK_PROGRESS if progress is None else progress
     d = p1 - p2
     if d @ d < 1e-30:
         d = np.array([1.0, 0.0, 0.0])
@@ -144,7 +146,7 @@ def gjk_cores(t1, s1, p1, R1, t2, s2, p2, R2):
         a = support(t1, s1, p1, R1, -v)
         b = support(t2, s2, p2, R2, v)
         w = a - b
-        if vv - v @ w <= 1e-14 * vv:                  # no support point is closer to the origin along v: converged
+        if vv - v @ w <= gap * vv:                    # no support point is closer to the origin along v: converged
             break
         lb = max(lb, (v @ w) / np.sqrt(vv))           # every point of the difference is at least this far: a certified bound
         if any(((w - x) @ (w - x)) <= 1e-28 * scale for x in W):
@@ -169,7 +171,7 @@ def gjk_cores(t1, s1, p1, R1, t2, s2, p2, R2):
         if v_new @ v_new >= vv or v_new @ v_new < lb * lb * (1.0 - 1e-10):
             W, A, lam = W[:-1], A[:-1], lam_prev      # the previous simplex is the answer
             break
-        done = vv - v_new @ v_new <= GJK_PROGRESS * vv
+        done = vv - v_new @ v_new <= progress * vv
         W, A, v = Wn, An, v_new
         lam_prev = lam
         if done:
@@ -193,7 +195,7 @@ def _epa_face(W, i, j, k):
     return [i, j, k, n, float(n @ W[i])]
 
 
-def penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2):
+def penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2, tol=None):
     """Overlapping cores: depth, direction (from 1 to 2) and witness points (a on core 1, b on core 2) of the SMALLEST
     translation that separates them — the point of the boundary of the Minkowski difference D = {x₁ − x₂} closest to the
     origin — by the expanding polytope algorithm (van den Bergen 2001): an inner polytope of D grows by the support point in
@@ -247,7 +249,7 @@ def penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2):
             break
         ip = add(nb)
         gap = nb @ W[ip] - off
-        if gap <= EPA_TOL * max(1.0, abs(off)):                      # the face is (within the gap) a face of D itself
+        if gap <= (EPA_TOL if tol is None else tol) * max(1.0, abs(off)):   # the face is (within the gap) a face of D itself
             W.pop(); A.pop()
             break
         p = W[ip]
@@ -487,28 +489,44 @@ def polish(t1, s1, p1, R1, t2, s2, p2, R2, n0):
     return None
 
 
+LOOSE_GAP, LOOSE_EPA = 1e-6, 1e-6   # tolerances of the runs in front of the polish (convex_dev.h kLooseGap / kLooseEpa)
+
+
 def convex_distance(t1, s1, p1, R1, t2, s2, p2, R2, margin):
     """One contact (dist, pos, n) in mj_geomDistance's convention — n from geom 1 to geom 2, pos the midpoint of the
-    witness points — or None beyond `margin`."""
+    witness points — or None beyond `margin`.
+    Round 6: GJK and the expanding polytope first run LOOSE (support gap 1e-6 instead of 1e-14 / 1e-11: half the support
+    evaluations) — the polish finishes their answer exactly, and its certificate says so; without one (mesh hulls, non-unique
+    witnesses: a few per cent of overlapping pairs) the tight run follows, and its answer stands if the polish has none for it either."""
     r1, r2 = core_radius(t1, s1), core_radius(t2, s2)
-    dist_c, pa, pb, overlap = gjk_cores(t1, s1, p1, R1, t2, s2, p2, R2)
-    if not overlap and dist_c > 1e-9:                 # cores apart (also when only the spherical shells overlap)
-        dist = dist_c - r1 - r2
-        if dist > margin:
+    loose = POLISH and GEOM_MESH not in (t1, t2)
+    for tight in ((False, True) if loose else (True,)):
+        dist_c, pa, pb, overlap = gjk_cores(t1, s1, p1, R1, t2, s2, p2, R2) if tight else \
+            gjk_cores(t1, s1, p1, R1, t2, s2, p2, R2, LOOSE_GAP, LOOSE_GAP)
+        if overlap or not dist_c > 1e-9:
+            break
+        # cores apart (also when only the spherical shells overlap)
+        if dist_c - r1 - r2 > margin * (1.0 + 1e-3) + 1e-6:           # (beyond the margin by more than a loose run can be off)
             return None
         n = (pb - pa) / dist_c
         pol = polish(t1, s1, p1, R1, t2, s2, p2, R2, n) if POLISH else None
-        if pol is not None and pol[0] > 0.0 and abs(pol[0] - dist_c) <= 1e-6 * max(dist_c, 1e-3):
+        if pol is not None and pol[0] > 0.0 and abs(pol[0] - dist_c) <= (1e-6 if tight else 1e-3) * max(dist_c, 1e-3):
             dist_c, pa, pb, n = pol
-            dist = dist_c - r1 - r2
+        elif not tight:
+            continue                                                  # no certificate for the loose answer: the tight run
+        dist = dist_c - r1 - r2
+        if dist > margin:
+            return None
         a, b = pa + r1 * n, pb - r2 * n
         return dist, 0.5 * (a + b), n
-    depth, n, a, b = penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2)
-    pol = polish(t1, s1, p1, R1, t2, s2, p2, R2, n) if POLISH else None
-    # (overlapping cores: a certified stationary point in the polytope's basin — a direction within 0.14 rad of its answer and a depth
-    #  no larger than its own, which stops on a vertex budget a few 1e-4 above the minimum for doubly curved pairs, and within 1 %)
-    dc_, ds_ = depth - r1 - r2, max(depth - r1 - r2, 1e-3)
-    if pol is not None and pol[3] @ n >= 0.99 and -pol[0] <= dc_ + 1e-9 * ds_ and -pol[0] >= dc_ - 1e-2 * ds_:
-        depth, a, b, n = -pol[0] + r1 + r2, pol[1], pol[2], pol[3]
+    for tight in ((False, True) if loose else (True,)):
+        depth, n, a, b = penetration(t1, s1, p1, R1, r1, t2, s2, p2, R2, r2, None if tight else LOOSE_EPA)
+        pol = polish(t1, s1, p1, R1, t2, s2, p2, R2, n) if POLISH else None
+        # (overlapping cores: a certified stationary point in the polytope's basin — a direction within 0.14 rad of its answer and a depth
+        #  no larger than its own, which stops on a vertex budget a few 1e-4 above the minimum for doubly curved pairs, and within 1 %)
+        dc_, ds_ = depth - r1 - r2, max(depth - r1 - r2, 1e-3)
+        if pol is not None and pol[3] @ n >= 0.99 and -pol[0] <= dc_ + (1e-9 if tight else 1e-5) * ds_ and -pol[0] >= dc_ - 1e-2 * ds_:
+            depth, a, b, n = -pol[0] + r1 + r2, pol[1], pol[2], pol[3]
+            break
     a, b = a + r1 * n, b - r2 * n                     # the deepest points: a − b = depth·n
     return -depth, 0.5 * (a + b), n
