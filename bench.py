@@ -102,7 +102,9 @@ def kernel_keys(kernel: str) -> list:
     if wide:
         kernel = kernel[:-len("+wide")]
     if kernel.startswith("convex_pre+"):         # (general convex pairs evaluated by a kernel in front of the analytic build)
-        return ["convex_contacts_kernel"] + kernel_keys(kernel[len("convex_pre+"):] + ("+wide" if wide else ""))
+        keys = ["convex_contacts_kernel"] + kernel_keys(kernel[len("convex_pre+"):] + ("+wide" if wide else ""))
+        # (a problem with general convex pairs: the redo launch is the workgroup-per-problem kernel's build WITH the convex routine)
+        return [("ik_wide_kernel_cvx" if k == "ik_wide_kernel" else k) for k in keys]
     if kernel == "ik_wide_kernel":
         return ["ik_wide_kernel"]
     main, _, redo = kernel.partition("+redo_")
@@ -113,7 +115,9 @@ def kernel_keys(kernel: str) -> list:
             feat &= ~32
         keys.append(f"ik_solve_kernel_{redo}_{feat}")
     if wide:
-        keys.append("ik_wide_kernel")
+        # (FEAT 136 / the all-feature builds 30 / 31 carry the general convex routine, and so does the redo launch behind them)
+        feat_main = int(main.split("_")[4]) if main.startswith("ik_solve_kernel_") else 0
+        keys.append("ik_wide_kernel_cvx" if (feat_main & 128) else "ik_wide_kernel")
     return keys
 
 

@@ -197,7 +197,7 @@ int launch_variant(int nt, int nr, int feat, bool w3, int grid, int lds_bytes, h
                    const SolveArgs& a, const TapArgs* taps);
 int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);
 int launch_quad(int nt, bool loop, int grid, hipStream_t stream, const void* P, const LaneDims& dims, const SolveArgs& a);   // returns its LDS bytes per wavefront
-int launch_wide(int grid, int lds_bytes, hipStream_t stream, const WideProblem* P, const SolveArgs& a, const TapArgs* taps);
+int launch_wide(int grid, int lds_bytes, hipStream_t stream, const WideProblem* P, const SolveArgs& a, const TapArgs* taps, bool convex);
 int launch_convex_pre(hipStream_t stream, const WideProblem* P, const CvPre& C, int B, const double* q, double* out);
 constexpr int kLaneMinBatchLoop = 28672;  // fused loops of a small arm: row kernel below, lane kernel from here (M targets/s at 16 384: 39.7 vs 24.1, at 32 768: 42.4 vs 48.2)
 constexpr int kLaneMinBatch = 73728;  // plain solves of a small arm: row kernel below, lane kernel from here (launch())
@@ -660,7 +660,7 @@ static int32_t launch_wide_kernel(MkhProblem* p, const SolveArgs& a, hipStream_t
   aw.work_counter = p->d_work;        // (redo_mask = 0: the kernel as THE path of a model draws its problems from it)
   int grid = p->wide_grid < a.B ? p->wide_grid : a.B;
   if (grid < 1) grid = 1;
-  const int rc = mkh::launch_wide(grid, p->wide_lds, stream, p->d_wide, aw, dtaps);
+  const int rc = mkh::launch_wide(grid, p->wide_lds, stream, p->d_wide, aw, dtaps, p->convex_pairs);
   if (rc != 0) return fail(MKH_E_HIP, "wide kernel: %s", hipGetErrorString((hipError_t)rc));
   HIP_OK(hipGetLastError());
   return MKH_OK;

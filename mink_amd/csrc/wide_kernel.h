@@ -237,6 +237,10 @@ __device__ __attribute__((noinline)) void wide_accumulate_h(WideQpCtx X, const d
 
 // Contacts of one problem (collision_avoidance_limit.py:187-229): every pair's distance and witness points → rec[pair] = {h, n, from, to}
 // (h = +inf: not in range).  Each wavefront takes kGjkSlots pairs per trip (GJK keeps its simplex in the wave's LDS workspace).
+// CVX: the pair list holds pairs without an analytic routine (the general convex routine — GJK, the expanding polytope, the witness-point
+// polish — is compiled in).  Two builds of the kernel (round 6): the routine's frame doubled the scratch of EVERY launch of the one kernel
+// there was — `g1_hands`, which has no collision pair at all, moved 4.3 GB per launch instead of 3.0 (816 → 1 728 B per lane).
+template <bool CVX>
 __device__ __attribute__((noinline)) void wide_contacts(const WideProblem* Pg, double dt, double* rec, const double* sX, int XS, double* sCwsAll) {
   const WideProblem& P = *Pg;
   const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -285,11 +289,12 @@ __device__ __attribute__((noinline)) void wide_contacts(const WideProblem* Pg, d
         const CollisionPairDev& cp = P.pairs[pi];
         V3 gp1, gp2; Q4 gq1, gq2;
         poses(cp, gp1, gq1, gp2, gq2);
-        geom_distance<false, true>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
+        geom_distance<false, CVX>(cp.type1, V3{cp.size1[0], cp.size1[1], cp.size1[2]}, gp1, gq1, cp.type2,
                                    V3{cp.size2[0], cp.size2[1], cp.size2[2]}, gp2, gq2, cp.ddetect, dist, from, to,
                                    cp.vert1, cp.nvert1, cp.vert2, cp.nvert2, &need_epa, sCws + lane);
       }
       // pairs whose cores overlap: one at a time, this wavefront cooperating on the expanding polytope
+      if constexpr (CVX)
       for (unsigned long long em = __ballot(want && need_epa); em; em &= em - 1) {
         const int l = (int)__builtin_ctzll(em);
         const CollisionPairDev& cp = P.pairs[use_cull ? (int)sList[base + wave * kGjkSlots + l] : base + wave * kGjkSlots + l];
@@ -834,7 +839,8 @@ __device__ __attribute__((noinline)) WideQpOut wide_qp_dense(WideQpCtx X, double
 
 // (two workgroups per CU: every phase of this kernel is latency-bound — one wavefront per SIMD waits out each LDS round trip and
 //  barrier alone — so the second resident workgroup is worth more than the registers it costs)
-__global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProblem* __restrict__ Pg, SolveArgs A, const TapArgs* __restrict__ tp) {
+template <bool CVX>
+__device__ __forceinline__ void wide_kernel_body(const WideProblem* __restrict__ Pg, SolveArgs& A, const TapArgs* __restrict__ tp) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // A redo launch whose slice of the batch carries no flagged status — the usual case — ends HERE, before the layout is read and
   // before the first spilled register is stored: the stores of the body's prologue made an idle launch write 66 KB of scratch per
@@ -1281,7 +1287,7 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
     // ------------------------------------------------------------ contacts (collision_avoidance_limit.py:187-229): every one a row
     // (a REAL call: the distance routines — GJK, the expanding polytope — want ≈150 registers of their own; inlined, they cost the
     //  two-workgroups-per-CU build of this kernel 98 spilled VGPRs)
-    if (P.n_pairs > 0) wide_contacts(Pg, A.dt, rec, smem + P.o_X, XS, smem + P.o_cws);
+    if (P.n_pairs > 0) wide_contacts<CVX>(Pg, A.dt, rec, smem + P.o_X, XS, smem + P.o_cws);
     __syncthreads();
     MKH_WSTAMP(7);
     // Rows: the detected contacts in pair order, then the caller's rows with a finite bound.  More contacts in range than the
@@ -1470,6 +1476,15 @@ __global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProb
     MKH_WSTAMP(12);
   }
   }
+}
+
+// the two builds: pair lists of analytic pairs only (every model workload without general convex pairs, every redo launch behind an
+// analytic collision build) / with pairs that need the general convex routine
+__global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel(const WideProblem* __restrict__ Pg, SolveArgs A, const TapArgs* __restrict__ tp) {
+  wide_kernel_body<false>(Pg, A, tp);
+}
+__global__ __launch_bounds__(kWideThreads, 2) void ik_wide_kernel_cvx(const WideProblem* __restrict__ Pg, SolveArgs A, const TapArgs* __restrict__ tp) {
+  wide_kernel_body<true>(Pg, A, tp);
 }
 
 }  // namespace mkh

@@ -118,11 +118,13 @@ def test_production_kernels_do_not_spill_vector_registers():
     #  `48_72`, `64_72`, `48_256` and every build without rows are unchanged.  Round 5, a NEW kernel, not a raised entry:
     #  `44_52_r44_w3` — the fused loops of the G1 full example on ten wavefronts per CU — enters with the 2 spilled VGPRs of its
     #  sibling `44_48_r44_w3`: 2.62 -> 3.01 M targets/s against the spill-free two-waves build it replaces as the default.
-    #  Round 6 raised the builds that CARRY the general convex routine — `32/44/48/64_136`, `32/44/48/64_30`, `ik_wide_kernel`
-    #  80 -> 111, `convex_contacts_kernel` 0 -> 10 — by 4 ... 31 (4 of them: the contact rows' two-halves loop of the collision-phase callee, Shadow 0.332 -> 0.317 ms): the witness-point polish behind GJK / the expanding polytope (convex_dev.h cvx_polish), a PARITY fix:
+    #  Round 6 raised the builds that CARRY the general convex routine — `32/44/48/64_136`, `32/44/48/64_30`,
+    #  `convex_contacts_kernel` 0 -> 10, and the workgroup-per-problem kernel, which is TWO builds now: `ik_wide_kernel` (analytic pair
+    #  lists: every model workload and redo launch without general convex pairs) 80 -> 50 with 608 B of scratch per lane instead of
+    #  816, `ik_wide_kernel_cvx` (with the routine) 108 / 1 728 B — by 4 ... 31 (4 of them: the contact rows' two-halves loop of the collision-phase callee, Shadow 0.332 -> 0.317 ms): the witness-point polish behind GJK / the expanding polytope (convex_dev.h cvx_polish), a PARITY fix:
     #  `ur5e_convex` v 3.7e-6 -> 1.5e-13, rows of G 1e-5 -> 2e-14 on all 4 096 instances.  The compiler's count for a kernel includes
     #  its callees here; the added spills sit in the collision-phase callee (`44_136`: 192 scratch stores there, 7 in the kernel
-    #  body — as before; `ik_wide_kernel`: wide_contacts 104 -> 233, the QP callees unchanged), the bench line of every workload on
+    #  body — as before; the wide kernel: wide_contacts 104 -> 233, the QP callees unchanged), the bench line of every workload on
     #  these kernels moved by < 1 %; `ur5e_convex` itself 0.158 -> 0.174 -> 0.158 ms once GJK and the polytope run loose in front
     #  of the polish (half their support evaluations), 32 768 instances on the split path 0.84 -> 0.72 ms.  A NEW kernel, not a raised entry:
     #  `48_40_r48`, the low-rank start with half-space rows, enters with 3 (one double re-read outside the rank-1 streams).

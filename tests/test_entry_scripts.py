@@ -75,7 +75,8 @@ def test_bench_helpers():
     assert b.kernel_keys("ik_solve_kernel_64_8+wide") == ["ik_solve_kernel_64_8", "ik_wide_kernel"]
     assert b.kernel_keys("ik_solve_kernel_48_8+redo_64+wide") == ["ik_solve_kernel_48_8", "ik_solve_kernel_64_8", "ik_wide_kernel"]
     assert b.kernel_keys("ik_solve_kernel_48_40_r48+redo_64+wide") == ["ik_solve_kernel_48_40_r48", "ik_solve_kernel_64_8", "ik_wide_kernel"]
-    assert b.kernel_keys("convex_pre+ik_solve_kernel_16_8+wide") == ["convex_contacts_kernel", "ik_solve_kernel_16_8", "ik_wide_kernel"]
+    assert b.kernel_keys("convex_pre+ik_solve_kernel_16_8+wide") == ["convex_contacts_kernel", "ik_solve_kernel_16_8", "ik_wide_kernel_cvx"]
+    assert b.kernel_keys("ik_solve_kernel_16_136+wide") == ["ik_solve_kernel_16_136", "ik_wide_kernel_cvx"]
     assert b.kernel_keys("ik_solve_kernel_48_72+redo_64+wide") == ["ik_solve_kernel_48_72", "ik_solve_kernel_64_72", "ik_wide_kernel"]
 
 
