@@ -41,6 +41,11 @@ W3 = ((44, 0),)                        # must match kW3Variants in minkhip.hip
 W3_WOOD = ((44, 44, 32), (44, 44, 48), (32, 32, 32), (32, 32, 48),    # (NT, NR, FEAT) of the low-rank start with the 3-waves map
            (24, 24, 32), (24, 24, 48), (16, 16, 32), (16, 16, 48),    # ... and, for NT ≤ 24, the 4-waves map (TabW4; same suffix _w3: "one more wave")
            (44, 44, 36), (44, 44, 52))                                # F_COM (ComTask rows / up to 24 task rows) and its fused loops: round 5, ik_kernel.h MKH_WOOD_SPLIT
+# one problem per workgroup (round 6; ik_kernel.h MKH_ONE_SHOT): a twin of the humanoid-size one-more-wave build WITHOUT the persistent
+# loop's machinery (ticket draws, double-buffered inputs, loop-carried scalars) — launched when the grid is the batch (minkhip.hip launch()).
+# Measured: `44_32_r44_w3o` 0.713 -> 0.703 ms on the headline; the F_COM twin `44_36_r44_w3o` (12 spilled VGPRs) 0.350 -> 0.352 ms at
+# 16 384 instances of the G1 full example — not built.
+W3_WOOD_ONE_SHOT = ((44, 44, 32),)
 WOOD_FEATS = (32, 48, 33, 36, 52)      # F_WOOD, | F_STEPS, | F_TAPS (cycle-counter profiling only), | F_COM, | F_COM | F_STEPS
 # low-rank start WITH half-space rows (round 6; ik_kernel.h wood_start "half-space rows"): (NT, NR, FEAT) on the 2-waves map,
 # NR = NT (the rows' columns of the elimination sit behind the dofs in the tableau-wide rows of Jh); must match kWoodRowVariants
@@ -290,8 +295,28 @@ void launch_{nt}_{ft}_r{nr}_w3(int grid, int lds_bytes, hipStream_t stream, cons
 }}  // namespace mkh
 """)
         srcs.append(name)
+    for nt, nr, ft in W3_WOOD_ONE_SHOT:
+        name = f"variant_{nt}_{ft}_r{nr}_w3o"
+        _write_if_changed(os.path.join(BUILD, name + ".hip"), f"""// generated by build.py
+#define MKH_NT {nt}
+#define MKH_NR {nr}
+#define MKH_FEAT {ft}
+#define MKH_W3 1
+#define MKH_ONE_SHOT 1
+#define MKH_KERNEL_NAME ik_solve_kernel_{nt}_{ft}_r{nr}_w3o
+#include "../ik_kernel.h"
+namespace mkh {{
+void launch_{nt}_{ft}_r{nr}_w3o(int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P, const SolveArgs& a,
+                      const TapArgs* taps) {{
+  hipLaunchKernelGGL(ik_solve_kernel_{nt}_{ft}_r{nr}_w3o, dim3(grid), dim3(kWave), lds_bytes, stream, P, a, taps);
+}}
+}}  // namespace mkh
+""")
+        srcs.append(name)
     decls = "\n".join(f"void launch_{nt}_{ft}(int, int, hipStream_t, const DeviceProblem*, const SolveArgs&, const TapArgs*);"
                       for nt in NTS for ft in FEATS)
+    decls += "\n" + "\n".join(f"void launch_{nt}_{ft}_r{nr}_w3o(int, int, hipStream_t, const DeviceProblem*, const SolveArgs&, const TapArgs*);"
+                             for nt, nr, ft in W3_WOOD_ONE_SHOT)
     decls += "\n" + "\n".join(f"void launch_{nt}_{ft}_r{nr}(int, int, hipStream_t, const DeviceProblem*, const SolveArgs&, const TapArgs*);"
                              for nt, nr in WOOD for ft in WOOD_FEATS)
     decls += "\n" + "\n".join(f"void launch_{nt}_{ft}_r{nr}(int, int, hipStream_t, const DeviceProblem*, const SolveArgs&, const TapArgs*);"
@@ -300,7 +325,10 @@ void launch_{nt}_{ft}_r{nr}_w3(int grid, int lds_bytes, hipStream_t stream, cons
                              for nt, ft in W3)
     decls += "\n" + "\n".join(f"void launch_{nt}_{ft}_r{nr}_w3(int, int, hipStream_t, const DeviceProblem*, const SolveArgs&, const TapArgs*);"
                              for nt, nr, ft in W3_WOOD)
-    cases0 = "\n".join(f"  if (w3 && nt == {nt} && nr == {nr} && feat == {ft}) {{ launch_{nt}_{ft}_r{nr}_w3(grid, lds_bytes, stream, P, a, taps); return 0; }}"
+    cases0 = "\n".join(f"  if (one_shot && w3 && nt == {nt} && nr == {nr} && feat == {ft}) {{ launch_{nt}_{ft}_r{nr}_w3o(grid, lds_bytes, stream, P, a, taps); return 0; }}"
+                       for nt, nr, ft in W3_WOOD_ONE_SHOT)
+    cases0 += "\n  if (one_shot) return -1;\n"
+    cases0 += "\n".join(f"  if (w3 && nt == {nt} && nr == {nr} && feat == {ft}) {{ launch_{nt}_{ft}_r{nr}_w3(grid, lds_bytes, stream, P, a, taps); return 0; }}"
                        for nt, nr, ft in W3_WOOD)
     cases = cases0 + "\n" + "\n".join(f"  if (w3 && nt == {nt} && nr == 0 && feat == {ft}) {{ launch_{nt}_{ft}_w3(grid, lds_bytes, stream, P, a, taps); return 0; }}"
                       for nt, ft in W3)
@@ -316,7 +344,7 @@ void launch_{nt}_{ft}_r{nr}_w3(int grid, int lds_bytes, hipStream_t stream, cons
 namespace mkh {{
 {decls}
 int launch_variant(int nt, int nr, int feat, bool w3, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
-                   const SolveArgs& a, const TapArgs* taps) {{
+                   const SolveArgs& a, const TapArgs* taps, bool one_shot) {{
 {cases}
   return -1;
 }}

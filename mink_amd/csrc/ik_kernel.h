@@ -1961,12 +1961,29 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       }
     }
   };
+#ifdef MKH_ONE_SHOT
+  // One problem per workgroup, compiled as such (round 6; build.py W3_WOOD_ONE_SHOT — the host launches these builds with grid = B):
+  // the loop below runs once, and without the draws, the double-buffered inputs and the scalars they carry around it the kernel
+  // body of `44_32_r44_w3o` spills 26 SGPRs instead of 78 (109 `v_readlane` / 26 `v_writelane` instead of 206 / 78, 138 fewer VALU
+  // and 304 fewer SALU instructions of its 1 867 / 1 185).  Same XCD ranges as the persistent shape: workgroup g is row g / 8 of XCD g % 8.
+  (void)draw;
+  int pb_next = xcd_map ? xcd * ((A.B + kNumXcd - 1) / kNumXcd) + w_local : (int)blockIdx.x;
+  if (pb_next >= A.B) pb_next = -1;
+#else
   int pb_next = draw();
+#endif
   bool have_inputs = false;                            // the rows of `pb` are already on their way into (sq, sTgt)
+#ifdef MKH_ONE_SHOT
+  for (int trip_ = 0; trip_ < 1; ++trip_) {           // (one trip, known to the compiler: no loop is left)
+    if (pb_next < 0) break;
+    const int pb = pb_next;
+    pb_next = -1;
+#else
   for (;;) {
     if (pb_next < 0) break;
     const int pb = pb_next;
     pb_next = draw();
+#endif
     int status_all = 0;
     typename MKH_TAB<NT>::Regs ts;   // the tableau column (operand map: compiler-visible register tuples; else empty)
     long long tc[8];
@@ -2871,7 +2888,11 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     if (last) {
       if (A.v_out && is_dof) {
         const double bad = __builtin_nan("");
-        A.v_out[(size_t)pb * nv + lane] = (status & 14) ? bad : zfin / A.dt;   // v = dq / dt (solve_ik.py:104)
+        int pb_o = pb;
+#ifdef MKH_ONE_SHOT
+        asm volatile("" : "+s"(pb_o));       // (the row's address is computed HERE: in straight-line code it was hoisted to the kernel's entry and spilled)
+#endif
+        A.v_out[(size_t)pb_o * nv + lane] = (status & 14) ? bad : zfin / A.dt;   // v = dq / dt (solve_ik.py:104)
       }
       if (status & 14) break;
     }
@@ -2909,8 +2930,12 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       if (A.iters_out) A.iters_out[pb] = it_done;
       if (A.converged_out) A.converged_out[pb] = conv_flag;
     }
-    if (!kRows && A.warm && lane < nv) A.warm[(size_t)pb * nv + lane] = (int8_t)((status_all & 14) ? 0 : prev_bound);
-    if (A.status_out && lane == 0) A.status_out[pb] = status_all;
+    int pb_w = pb;
+#ifdef MKH_ONE_SHOT
+    asm volatile("" : "+s"(pb_w));
+#endif
+    if (!kRows && A.warm && lane < nv) A.warm[(size_t)pb_w * nv + lane] = (int8_t)((status_all & 14) ? 0 : prev_bound);
+    if (A.status_out && lane == 0) A.status_out[pb_w] = status_all;
     sq = (sq == smem + L.q) ? smem + L.q2 : smem + L.q;           // the next problem's rows are (being) fetched there
     sTgt = (sTgt == smem + L.tgt) ? smem + L.tgt2 : smem + L.tgt;
   }

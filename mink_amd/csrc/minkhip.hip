@@ -194,7 +194,7 @@ struct MkhProblem {
 // generated dispatcher.
 namespace mkh {
 int launch_variant(int nt, int nr, int feat, bool w3, int grid, int lds_bytes, hipStream_t stream, const DeviceProblem* P,
-                   const SolveArgs& a, const TapArgs* taps);
+                   const SolveArgs& a, const TapArgs* taps, bool one_shot = false);
 int launch_lane(int nv_max, bool loop, int grid, int lds_bytes, hipStream_t stream, const LaneProblem* P, const SolveArgs& a);
 int launch_quad(int nt, bool loop, int grid, hipStream_t stream, const void* P, const LaneDims& dims, const SolveArgs& a);   // returns its LDS bytes per wavefront
 int launch_wide(int grid, int lds_bytes, hipStream_t stream, const WideProblem* P, const SolveArgs& a, const TapArgs* taps, bool convex);
@@ -1742,10 +1742,19 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
   // (workgroup g: XCD g % 8, row g / 8 of its range).  MKH_DEBUG_PERSISTENT=1: persistent wavefronts everywhere (A/B).
   static const bool persistent_only = dbg_env("MKH_DEBUG_PERSISTENT") != nullptr;
   // (fused loops, measured: no difference — 13.55 / 13.58 ms for the headline's 20-step loop, converged targets 5.64 / 5.58 M/s — they stay persistent)
-  if (!persistent_only && !tight && w3 && nt == 44 && a.n_steps <= 1 && a.B > grid && 2 * (long long)a.B >= 7LL * grid && a.B <= 22 * grid)
+  // Round 6: where the build has a twin compiled for this shape (`44_32_r44_w3o`, below) there is no upper end — kernel ms, persistent /
+  // one per workgroup on the twin: 12 288 instances 0.166 / 0.151, 65 536 0.737 / 0.701, 73 728 0.817 / 0.786, 131 072 1.400 / 1.379,
+  // 262 144 2.750 / 2.728 (below 3.5 rounds the persistent shape stays: 10 240 instances 0.145 on both).
+  static const int os_max = dbg_env("MKH_DEBUG_ONE_SHOT_MAX") ? atoi(dbg_env("MKH_DEBUG_ONE_SHOT_MAX")) : 22;    // (A/B switch: upper end of the range, in rounds)
+  const bool has_twin = w3 && nt == 44 && nr == 44 && feat == F_WOOD && !dtaps;
+  if (!persistent_only && !tight && w3 && nt == 44 && a.n_steps <= 1 && a.B > grid && 2 * (long long)a.B >= 7LL * grid &&
+      (has_twin || a.B <= (long long)os_max * grid))
     grid = a.B;
+  // ... and, round 6, on a build WITHOUT the persistent loop's machinery where one exists (`44_32_r44_w3o`: build.py W3_WOOD_ONE_SHOT,
+  // ik_kernel.h MKH_ONE_SHOT — 78 → 32 spilled SGPRs in the kernel body, headline 0.713 → 0.703 ms; the F_COM twin measured no gain)
+  const bool one_shot = grid == a.B && has_twin;
   p->last_grid = grid; p->last_lds = lds; p->last_nt = nt;
-  snprintf(p->last_kernel, sizeof(p->last_kernel), nr ? (w3 ? "ik_solve_kernel_%d_%d_r%d_w3" : "ik_solve_kernel_%d_%d_r%d") : (w3 ? "ik_solve_kernel_%d_%d_w3" : "ik_solve_kernel_%d_%d"), nt, feat, nr);
+  snprintf(p->last_kernel, sizeof(p->last_kernel), nr ? (w3 ? (one_shot ? "ik_solve_kernel_%d_%d_r%d_w3o" : "ik_solve_kernel_%d_%d_r%d_w3") : "ik_solve_kernel_%d_%d_r%d") : (w3 ? "ik_solve_kernel_%d_%d_w3" : "ik_solve_kernel_%d_%d"), nt, feat, nr);
   SolveArgs al = a;
   al.work_counter = p->d_work;
   if (tight) {
@@ -1766,7 +1775,7 @@ static int32_t launch(MkhProblem* p, const SolveArgs& a_in, const TapArgs* taps,
     const int rc = mkh::launch_convex_pre(stream, p->d_wide, p->cv, a.B, a.q, p->d_cv);
     if (rc != 0) return fail(MKH_E_HIP, "convex pre-pass: %s", hipGetErrorString((hipError_t)rc));
   }
-  if (mkh::launch_variant(nt, nr, feat, w3, grid, lds, stream, p->d_dev, al, dtaps) != 0)
+  if (mkh::launch_variant(nt, nr, feat, w3, grid, lds, stream, p->d_dev, al, dtaps, one_shot) != 0)
     return fail(MKH_E_INVALID, "no kernel variant %s", p->last_kernel);
   HIP_OK(hipGetLastError());
   HIP_OK(clk_end(p, a.B, stream));

@@ -82,10 +82,11 @@ def test_compiler_stays_below_the_vgpr_cap(lib):
     import sys
     out = subprocess.run([sys.executable, os.path.join(REPO, "tools", "check_vgpr_cap.py"),
                           "44_0", "44_32_r44", "44_32_r44_w3", "44_48_r44_w3", "44_0_w3", "64_30", "8_0", "48_31",
-                          "44_36_r44_w3", "44_52_r44_w3"],          # (round 5: the F_COM builds on the one-more-wave map)
+                          "44_36_r44_w3", "44_52_r44_w3",           # (round 5: the F_COM builds on the one-more-wave map)
+                          "44_32_r44_w3o"],                         # (round 6: the headline's one-problem-per-workgroup twin)
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count(" ok ") == 10, out.stdout
+    assert out.stdout.count(" ok ") == 11, out.stdout
 
 
 def test_production_kernels_do_not_spill_vector_registers():
@@ -128,6 +129,10 @@ def test_production_kernels_do_not_spill_vector_registers():
     #  these kernels moved by < 1 %; `ur5e_convex` itself 0.158 -> 0.174 -> 0.158 ms once GJK and the polytope run loose in front
     #  of the polish (half their support evaluations), 32 768 instances on the split path 0.84 -> 0.72 ms.  A NEW kernel, not a raised entry:
     #  `48_40_r48`, the low-rank start with half-space rows, enters with 3 (one double re-read outside the rank-1 streams).
+    #  A NEW kernel, not a raised entry: `44_32_r44_w3o` (4), the one-problem-per-workgroup twin of the headline's
+    #  one-more-wave build, compiled without the persistent loop's machinery (the F_COM twin measured no gain and is not built): 78 -> 32 spilled SGPRs in the
+    #  headline's kernel body (206 -> 121 `v_readlane`), and in straight-line code the allocator parks `status_all` and two LDS
+    #  addresses in scratch instead — 9 scratch accesses per problem; headline 0.7130 -> 0.7030 ms in a same-box A/B.
     #  `ik_lane_kernel<7,0>` 75 -> 88 and `<8,0>` 102 -> 106: MKH_FLAG_WARM_START on the lane kernel (the partition read at the QP's
     #  start, written at the end) — a closed loop of single solves at 131 072 instances: iiwa 0.098 -> 0.062 ms, UR5e 0.084 -> 0.046
     #  with the flag; without it the kernels measure what they did (0.101 / 0.084))
