@@ -389,7 +389,11 @@ enum : int { F_TAPS = 1, F_REL = 2, F_COM = 4, F_COLL = 8, F_STEPS = 16, F_ALL =
 // file — the tableau is dead while they run — and the kernel keeps only what is live across the call.
 struct PreOut { int status, d_kind, d_k, d_body, d_qadr, conv; double mu_lane; V3 com_root; };
 #ifdef MKH_CALLS
+#ifdef MKH_ONE_SHOT
+#define MKH_PRE_ATTR __attribute__((noinline, internal_linkage))   // (lets the compiler prove that the callee reads no work-item id: wave_ops.h lane_id)
+#else
 #define MKH_PRE_ATTR __attribute__((noinline))
+#endif
 #ifdef MKH_CLOCKS     // experiment builds: the callee stamps slots 20.. of the problem's (B, 24) clock row itself
 #define MKH_PRE_TC_PARAMS , long long* clk_row
 #define MKH_PRE_TC_ARGS , (A.clk ? A.clk + (size_t)pb * 24 + 20 : nullptr)
@@ -1118,7 +1122,11 @@ __device__ __attribute__((noinline)) void wood_s_dense_call(int n_mu, int nv, in
 // fit next to the kernel's own live values (86 spilled VGPRs when inlined).
 #if defined(MKH_CALLS) || (MKH_FEAT & 4)
 #define MKH_WOOD_CALL 1
+#ifdef MKH_ONE_SHOT
+#define MKH_WOOD_ATTR __attribute__((noinline, internal_linkage))
+#else
 #define MKH_WOOD_ATTR __attribute__((noinline))
+#endif
 #else
 #define MKH_WOOD_ATTR __forceinline__
 #endif
@@ -1873,7 +1881,13 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
 #else
   constexpr bool kCompact = false;
 #endif
+#ifdef MKH_ONE_SHOT
+  // (the descriptor through the CONSTANT address space from the start: as a plain reference its sizes arrive by vector loads and the
+  //  whole LDS layout is computed in VGPRs — per problem in this build, ≈ 100 VALU instructions and two addresses that end up spilled)
+  const MKH_CONSTANT DeviceProblem& P0 = *(const MKH_CONSTANT DeviceProblem*)Pg;
+#else
   const DeviceProblem& P0 = *Pg;
+#endif
   extern __shared__ __attribute__((aligned(16))) double smem[];
   int lane = lane_id();     // (re-laundered at every phase boundary, see MKH_TICK)
   const int nq = P0.nq, nv = P0.nv, nbody = P0.nbody;
@@ -2883,7 +2897,9 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       if (collision_phase(Pq, tp, pb, A.dt, 1, L)) status |= 16;
       asm volatile("" : "+v"(lane));
     }
-    status_all |= status;
+    // (builds without the fused loop: ONE step — an assignment, so that the 0 above is a constant of the early exits and not a value
+    //  carried through the QP: the one-problem-per-workgroup twin spilled it)
+    if constexpr (kSteps) status_all |= status; else status_all = status;
     const bool last = until || (step + 1 == n_steps) || (status & 14);   // (until: v of every step — the loop may end at the next check)
     if (last) {
       if (A.v_out && is_dof) {

@@ -9,7 +9,14 @@
 
 namespace mkh {
 
+#ifdef MKH_ONE_SHOT
+// (mbcnt, not threadIdx.x & 63: a callee that reads the work-item id makes its caller keep v0 alive for the v31 argument of every
+//  call — in the one-problem-per-workgroup twin of the headline's kernel that was one of three spilled VGPRs; round 6.  That build
+//  only: everywhere else the change moves spill counts by ± a dozen and measures nothing or worse.)
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+#else
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+#endif
 
 // Broadcast lane `src` (wave-uniform) of x to all lanes through SGPRs.
 __device__ __forceinline__ double readlane_f64(double x, int src) {

@@ -129,10 +129,11 @@ def test_production_kernels_do_not_spill_vector_registers():
     #  these kernels moved by < 1 %; `ur5e_convex` itself 0.158 -> 0.174 -> 0.158 ms once GJK and the polytope run loose in front
     #  of the polish (half their support evaluations), 32 768 instances on the split path 0.84 -> 0.72 ms.  A NEW kernel, not a raised entry:
     #  `48_40_r48`, the low-rank start with half-space rows, enters with 3 (one double re-read outside the rank-1 streams).
-    #  A NEW kernel, not a raised entry: `44_32_r44_w3o` (4), the one-problem-per-workgroup twin of the headline's
-    #  one-more-wave build, compiled without the persistent loop's machinery (the F_COM twin measured no gain and is not built): 78 -> 32 spilled SGPRs in the
-    #  headline's kernel body (206 -> 121 `v_readlane`), and in straight-line code the allocator parks `status_all` and two LDS
-    #  addresses in scratch instead — 9 scratch accesses per problem; headline 0.7130 -> 0.7030 ms in a same-box A/B.
+    #  A NEW kernel: `44_32_r44_w3o`, the one-problem-per-workgroup twin of the headline's one-more-wave build, compiled without the
+    #  persistent loop's machinery — spill-FREE like its sibling (its first version parked `status_all`, the work-item id and two LDS
+    #  addresses in scratch: 67.6 MB of HBM traffic per launch instead of 62.2; `status_all` assigned instead of or-ed in builds
+    #  without the fused loop, lane ids by mbcnt and the descriptor through the constant address space in that build fixed it, and
+    #  the first of the three lowered a dozen entries of other builds — `64_88` 42 -> 8 — and raised `44_0_w3` by one).
     #  `ik_lane_kernel<7,0>` 75 -> 88 and `<8,0>` 102 -> 106: MKH_FLAG_WARM_START on the lane kernel (the partition read at the QP's
     #  start, written at the end) — a closed loop of single solves at 131 072 instances: iiwa 0.098 -> 0.062 ms, UR5e 0.084 -> 0.046
     #  with the flag; without it the kernels measure what they did (0.101 / 0.084))
