@@ -1988,8 +1988,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
 #endif
   bool have_inputs = false;                            // the rows of `pb` are already on their way into (sq, sTgt)
 #ifdef MKH_ONE_SHOT
-  for (int trip_ = 0; trip_ < 1; ++trip_) {           // (one trip, known to the compiler: no loop is left)
-    if (pb_next < 0) break;
+  if (pb_next >= 0) {                                   // (no loop at all)
     const int pb = pb_next;
     pb_next = -1;
 #else
@@ -2084,7 +2083,12 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     // (variants with half-space rows run Goldfarb–Idnani only: no block step to seed)
     const bool warm_in = !kRows && A.warm != nullptr && A.warm_age >= 2;
     if (!kRows && warm_in && lane < nv) prev_bound = A.warm[(size_t)pb * nv + lane];
+#if defined(MKH_ONE_SHOT) && !(MKH_FEAT & 16)
+    do {                                                     // (no fused loop in this build: ONE step, and no loop for the compiler to carry values around)
+    const int step = 0;
+#else
     for (int step = 0; step < n_steps + (until ? 1 : 0); ++step) {
+#endif
     int status = 0;
     tci = 1;                                                 // phase stamps 1..7 belong to the current step
 
@@ -2938,7 +2942,11 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       }
       wave_sync();
     }
+#if defined(MKH_ONE_SHOT) && !(MKH_FEAT & 16)
+    } while (0);
+#else
     }  // step loop
+#endif
     if (kSteps && A.q_out) {
       for (int i = lane; i < nq; i += 64) A.q_out[(size_t)pb * nq + i] = sq[i];
     }
