@@ -1883,7 +1883,8 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
 #endif
 #ifdef MKH_ONE_SHOT
   // (the descriptor through the CONSTANT address space from the start: as a plain reference its sizes arrive by vector loads and the
-  //  whole LDS layout is computed in VGPRs — per problem in this build, ≈ 100 VALU instructions and two addresses that end up spilled)
+  //  whole LDS layout is computed in VGPRs — per problem in this build, ≈ 100 VALU instructions and two addresses that end up spilled.
+  //  The persistent builds compute the layout once per wavefront; there the scalar version only adds spilled SGPRs — measured.)
   const MKH_CONSTANT DeviceProblem& P0 = *(const MKH_CONSTANT DeviceProblem*)Pg;
 #else
   const DeviceProblem& P0 = *Pg;
@@ -2083,8 +2084,11 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     // (variants with half-space rows run Goldfarb–Idnani only: no block step to seed)
     const bool warm_in = !kRows && A.warm != nullptr && A.warm_age >= 2;
     if (!kRows && warm_in && lane < nv) prev_bound = A.warm[(size_t)pb * nv + lane];
-#if defined(MKH_ONE_SHOT) && !(MKH_FEAT & 16)
-    do {                                                     // (no fused loop in this build: ONE step, and no loop for the compiler to carry values around)
+#if !(MKH_FEAT & 16)
+    // (no fused loop in this build: ONE step, and no loop for the compiler to carry values around — as a single-trip `for` it still was
+    //  one to the compiler: a dozen to twenty spilled SGPRs less in every build; plugin workload 1.643 → 1.603 ms, G1 full example 1.231
+    //  → 1.224, the headline's twin 0.694 → 0.691; round 6)
+    do {
     const int step = 0;
 #else
     for (int step = 0; step < n_steps + (until ? 1 : 0); ++step) {
@@ -2942,7 +2946,7 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
       }
       wave_sync();
     }
-#if defined(MKH_ONE_SHOT) && !(MKH_FEAT & 16)
+#if !(MKH_FEAT & 16)
     } while (0);
 #else
     }  // step loop
