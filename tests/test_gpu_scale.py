@@ -706,3 +706,25 @@ def test_humanoid_with_more_than_a_wavefront_of_analytic_pairs(monkeypatch):
           % (len(pairs), B, err.max(), rows.mean(), rows.max()))
     assert rows.max() > 21 and rows.mean() > 5
     assert err.max() < 1e-8
+
+
+def test_one_problem_per_workgroup_twin_on_ragged_batches():
+    """Round 6: from 3.5 rounds of the resident wavefronts on, the headline's kernel runs as its twin compiled for one problem per
+    workgroup (`44_32_r44_w3o`: no loop, lane ids by mbcnt, the descriptor through the constant address space).  Batch sizes that are
+    not multiples of the 8 XCDs take the plain workgroup → problem map; every size bitwise equal to the two-waves build (same
+    arithmetic, other register map) and without a NaN."""
+    from mink_amd import _native as nat
+    from mink_amd import workloads
+    name = "g1_c3"
+    model = workloads.load_bench_robot(name)
+    nm = nat.NativeModel(model)
+    for B in (10752, 10753, 12289, 16391):
+        prob, dt, damping = workloads.bench_config(name, model, nm, B)
+        q, tg, pt, ct = workloads.bench_batch(name, model, nm, prob, np.random.default_rng(B), B)
+        v1, s1 = prob.solve(q, tg, pt, ct, dt, damping)
+        assert prob.last_kernel() == "ik_solve_kernel_44_32_r44_w3o" and prob.launch_info(B)["grid"] == B, (prob.last_kernel(), prob.launch_info(B))
+        v2, s2 = prob.solve(q, tg, pt, ct, dt, damping, two_waves=True)
+        assert prob.last_kernel() == "ik_solve_kernel_44_32_r44"
+        np.testing.assert_array_equal(v1, v2)
+        assert (s1 == s2).all() and not np.isnan(v1).any()
+        prob.close()
