@@ -1848,10 +1848,16 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
   struct KernArgs { const DeviceProblem* P; SolveArgs A; const TapArgs* tp; };
   const MKH_CONSTANT SolveArgs* A_p = (const MKH_CONSTANT SolveArgs*)((const MKH_CONSTANT char*)__builtin_amdgcn_kernarg_segment_ptr() +
                                                                       offsetof(KernArgs, A));
+#ifndef MKH_ONE_SHOT
   asm volatile("" : "+s"(A_p));
+#endif
   const MKH_CONSTANT SolveArgs& A = *A_p;
   (void)A_k;
+#ifndef MKH_ONE_SHOT
 #define MKH_ARGS_AT_USE() asm volatile("" : "+s"(A_p)); const MKH_CONSTANT SolveArgs& A = *A_p
+#else
+#define MKH_ARGS_AT_USE() do {} while (0)
+#endif
 #else
   const SolveArgs& A = A_k;
 #define MKH_ARGS_AT_USE() do {} while (0)
@@ -2031,7 +2037,10 @@ void MKH_KERNEL_NAME(const DeviceProblem* __restrict__ Pg, const SolveArgs A_k, 
     asm volatile("s_mov_b32 %0, 0" : "=s"(oz));
     const int ol = lane + oz;
     const DeviceProblem* Pq = Pg;
+#ifndef MKH_ONE_SHOT
     asm volatile("" : "+s"(Pq));          // opaque: descriptor fields are (re)loaded where they are used
+#endif                                    // (no loop to hoist them out of in the one-problem-per-workgroup build — and as kernel arguments, not opaque
+                                          //  copies, the two pointers are re-read from the kernarg segment instead of spilled: 157 → 109 `v_readlane`)
     // ... through the CONSTANT address space: scalar loads.  As a plain reference the fields — wave-uniform, but read inside
     // lane-conditional code — came by per-lane flat_load, each a full s_waitcnt in front of the table load that depends on it:
     // the posture / box-limit phase alone was ten dependent L2 round trips (10.6 k of a G1 solve's 104 k wave cycles for ≈150
